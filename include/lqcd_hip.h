@@ -1,0 +1,160 @@
+/*
+ * lqcd_hip.h -- C ABI of liblqcd_hip.so, the MI355X-native Dirac-solver hot path for LatticeQCD.jl.
+ *
+ * The reference has no FFI for this path: the seam is Julia multiple dispatch on types owned by
+ * LatticeDiracOperators.jl / Gaugefields.jl.  Every entry point below cites the
+ * reference call site / generic function whose method a `ccall` stub replaces (INTEGRATION.md shows
+ * the Julia binding).  Citations are relative to /root/reference.
+ *
+ * Conventions
+ *   - every function returns int: LQCD_OK (0) or an LQCD_ERR_* code; lqcd_last_error() gives the message
+ *     (the Julia side turns non-zero into `error(msg)`, mirroring the reference's error(...) strings);
+ *   - host buffers are caller-owned and only borrowed for the call; device memory is library-owned
+ *     behind opaque handles;
+ *   - all calls are synchronous at return unless named *_async;
+ *   - host layouts are the reference's (Julia column-major), interleaved (re,im) doubles, LOCAL sub-lattice
+ *     of the calling rank, no wing:
+ *       gauge     U[mu][a,b,ix,iy,iz,it]   -> a + 3*(b + 3*(site + V*mu))     (src/updates/givenconfigurations.jl:49)
+ *       Wilson    psi[ic,ix,iy,iz,it,is]   -> ic + 3*(site + V*is)             (src/measurements/unusedfiles/measure_Pion_correlator.jl:244,376)
+ *       staggered psi[ic,ix,iy,iz,it,1]    -> ic + 3*site
+ *     with site = ix + NX*(iy + NY*(iz + NZ*it)), all 0-based.
+ *   - arithmetic is fp64 throughout.
+ */
+#ifndef LQCD_HIP_H
+#define LQCD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lqcd_ctx_s* lqcd_ctx_t;
+typedef struct lqcd_gauge_s* lqcd_gauge_t;
+typedef struct lqcd_spinor_s* lqcd_spinor_t;
+typedef struct lqcd_op_s* lqcd_op_t;
+
+enum {
+    LQCD_OK = 0,
+    LQCD_ERR_ARG = 1,           /* bad argument / shape mismatch */
+    LQCD_ERR_HIP = 2,           /* HIP runtime error (no device, OOM, launch failure) */
+    LQCD_ERR_NOT_CONVERGED = 3, /* solver hit maxiter: the reference raises error(...) here */
+    LQCD_ERR_COMM = 4,          /* RCCL error */
+    LQCD_ERR_UNSUPPORTED = 5
+};
+
+enum { LQCD_WILSON = 0, LQCD_STAGGERED = 1 };        /* "Dirac_operator" => "Wilson" | "Staggered"  (src/system/universe.jl:103-116) */
+enum { LQCD_FULL = 0, LQCD_EVEN = 1, LQCD_ODD = 2 }; /* site subset held by a spinor */
+enum { LQCD_LAYOUT_REFERENCE = 0, /* memory image of the Julia arrays, see above */
+       LQCD_LAYOUT_DISK = 1 };    /* ILDG / BridgeText flat order t,z,y,x,mu,a,b */
+
+/* ---------------------------------------------------------------- host-only helpers (no GPU needed) */
+int lqcd_version(void);
+const char* lqcd_last_error(void);
+/* number of HIP devices visible (0 if none) */
+int lqcd_device_count(void);
+/* reference site linearisation ix + NX*(iy + NY*(iz + NZ*it)) */
+int64_t lqcd_index_lex(const int L[4], int x, int y, int z, int t);
+/* device (checkerboard) position of a site: parity = (x+y+z+t)&1, cb = (x>>1) + (NX/2)*(y + NY*(z + NZ*t)) */
+int lqcd_index_cb(const int L[4], int x, int y, int z, int t, int* parity, int64_t* cb);
+/* inverse of lqcd_index_cb */
+int lqcd_coords_cb(const int L[4], int parity, int64_t cb, int xyzt[4]);
+/* local extents, origin and neighbour ranks of `rank` in the PE grid (the reference's PEs concept, src/mpirun.jl:17-19;
+ * rank = px + PX*(py + PY*(pz + PZ*pt))) */
+int lqcd_decompose(const int global_L[4], const int pe_grid[4], int rank, int local_L[4], int origin[4],
+                   int rank_fwd[4], int rank_bwd[4]);
+
+/* ---------------------------------------------------------------- context */
+/* One context = one rank's sub-lattice on one GPU.  pe_grid = {1,1,1,1}, rank 0 for a single GPU. */
+int lqcd_ctx_create(lqcd_ctx_t* ctx, int device, const int global_L[4], const int pe_grid[4], int rank);
+int lqcd_ctx_destroy(lqcd_ctx_t ctx);
+int lqcd_ctx_sync(lqcd_ctx_t ctx);
+/* tuning knobs (kernel variants); unknown key -> LQCD_ERR_ARG */
+int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
+int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);
+
+/* RCCL bootstrap for one-process-per-GPU runs: rank 0 creates the id, the host broadcasts the 128 bytes
+ * (torch.distributed / MPI.jl), every rank calls lqcd_ctx_comm_init.  Replaces the MPI.Init / PEs plumbing of
+ * src/mpi/mpimodule.jl:4-13. */
+int lqcd_comm_unique_id(unsigned char id[128]);
+int lqcd_ctx_comm_init(lqcd_ctx_t ctx, const unsigned char id[128], int nranks);
+/* in-process emulation of a PE grid on ONE device (testing the halo path without RCCL): link `n` contexts that
+ * were created with ranks 0..n-1 of the same pe_grid; afterwards use the lqcd_mdom_* collectives below. */
+int lqcd_ctx_link_local(lqcd_ctx_t* ctxs, int n);
+
+/* ---------------------------------------------------------------- gauge field  (Gaugefields.jl: Initialize_Gaugefields, universe.jl:41-49) */
+int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g);
+int lqcd_gauge_destroy(lqcd_gauge_t g);
+int lqcd_gauge_upload(lqcd_gauge_t g, const double* host, int layout);   /* substitute_U! / load_* (universe.jl:58-77) */
+int lqcd_gauge_download(lqcd_gauge_t g, double* host, int layout);
+int lqcd_gauge_unit(lqcd_gauge_t g);                                      /* condition = "cold" (universe.jl:41-49) */
+int lqcd_gauge_hot_start(lqcd_gauge_t g, uint64_t seed);                  /* condition = "hot"; counter-based, keyed by GLOBAL site */
+int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq);                   /* calculate_Plaquette (lqcd.jl:187-193), normalised 1/(6 V NC) */
+
+/* ---------------------------------------------------------------- fermion fields (Initialize_pseudofermion_fields, universe.jl:107,112) */
+int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, int subset);
+int lqcd_spinor_destroy(lqcd_spinor_t s);
+int lqcd_spinor_upload(lqcd_spinor_t s, const double* host);    /* reference layout; FULL-lattice host array even for EVEN/ODD subsets */
+int lqcd_spinor_download(lqcd_spinor_t s, double* host);        /* EVEN/ODD subsets write only their sites */
+int lqcd_spinor_zero(lqcd_spinor_t s);                          /* clear_fermion! */
+int lqcd_spinor_copy(lqcd_spinor_t dst, lqcd_spinor_t src);     /* substitute_fermion! */
+int lqcd_spinor_gaussian(lqcd_spinor_t s, uint64_t seed);       /* gauss_distribution_fermion!: re,im ~ N(0,1), keyed by GLOBAL site */
+int lqcd_spinor_z4(lqcd_spinor_t s, uint64_t seed);             /* Z4_distribution_fermi! (unusedfiles/measure_chiral_condensate.jl:180) */
+int lqcd_spinor_point_source(lqcd_spinor_t s, const int global_xyzt[4], int ic, int is); /* setindex_global! (measure_Pion_correlator.jl:376) */
+/* even/odd halves of a FULL spinor <-> EVEN/ODD spinors */
+int lqcd_spinor_extract(lqcd_spinor_t half, lqcd_spinor_t full);
+int lqcd_spinor_insert(lqcd_spinor_t full, lqcd_spinor_t half);
+
+/* BLAS-1 (LinearAlgebra.dot / add_fermion! on fermion fields; standardHMC.jl:54).
+ * dot is the Hermitian inner product sum conj(a) b; results are global (all-reduced over ranks). */
+int lqcd_dot(lqcd_spinor_t a, lqcd_spinor_t b, double* re, double* im);
+int lqcd_norm2(lqcd_spinor_t a, double* n2);
+int lqcd_axpy(double ar, double ai, lqcd_spinor_t x, lqcd_spinor_t y);                         /* y += a x */
+int lqcd_axpby(double ar, double ai, lqcd_spinor_t x, double br, double bi, lqcd_spinor_t y); /* y = a x + b y  (add_fermion!) */
+int lqcd_scale(double ar, double ai, lqcd_spinor_t x);
+
+/* ---------------------------------------------------------------- Dirac operator (Dirac_operator(U,x,params), universe.jl:137) */
+/* kappa_or_mass: "kappa" (Wilson) or "mass" (staggered); r: Wilson parameter; bc: "boundarycondition" (+-1 per direction,
+ * default [1,1,1,-1], parameter_structs.jl:133) */
+int lqcd_op_create(lqcd_ctx_t ctx, lqcd_op_t* op, int kind, lqcd_gauge_t g, double kappa_or_mass, double r,
+                   const int bc[4]);
+int lqcd_op_destroy(lqcd_op_t op);
+int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g);   /* the D(U) rebind idiom (unusedfiles/measure_chiral_condensate.jl:173) */
+/* mul!(y, D, x) / mul!(y, D', x) on FULL spinors */
+int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger);
+/* mul!(y, DdagD_operator(D), x):  out = D^dagger D in  (tmp is library scratch) */
+int lqcd_op_apply_DdagD(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in);
+/* parity hop: out (EVEN|ODD subset) = H in, in of the opposite subset; Wilson H = sum_nu[(r-g)U x+ + (r+g)U^+ x-],
+ * staggered H = 1/2 sum_nu eta(U x+ - U^+ x-) */
+int lqcd_op_hop(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger);
+
+/* ---------------------------------------------------------------- solvers (solve_DinvX!) */
+/* Stopping rule real(r.r) < eps (absolute, squared; default eps_CG = 1e-19, MaxCGstep = 3000,
+ * parameter_structs.jl:174-175).  x holds the initial guess on entry.  iters/final_rr may be NULL. */
+int lqcd_solve_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, int* iters,
+                        double* final_rr);                       /* solve_DinvX!(y, DdagD, x) -> cg (AbstractMD.jl:129 via calc_UdSfdU!) */
+int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,
+                        int* iters, double* final_rr);           /* solve_DinvX!(y, D | D', x) (standardHMC.jl:71) */
+int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,
+                           int* iters, double* final_rr);        /* even-odd preconditioned variant (Wilson) */
+/* benchmarking window: exactly niter CG iterations, exit test disabled (SURVEY.md 8(d) timing protocol) */
+int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int niter);
+
+/* ---------------------------------------------------------------- timing (hipEvents on the library's compute stream) */
+/* runs `warm` untimed + `reps` timed applications of D (or D^dagger) and returns the mean ms per application */
+int lqcd_bench_dslash(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps,
+                      double* ms_per_apply);
+/* ms per CG iteration over a fixed window of niter iterations (after `warm` untimed iterations) */
+int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int warm, int niter, double* ms_per_iter);
+
+/* ---------------------------------------------------------------- in-process multi-domain collectives (testing only) */
+int lqcd_mdom_op_apply(int n, lqcd_op_t* ops, lqcd_spinor_t* outs, lqcd_spinor_t* ins, int dagger);
+int lqcd_mdom_dot(int n, lqcd_spinor_t* a, lqcd_spinor_t* b, double* re, double* im);
+int lqcd_mdom_plaquette(int n, lqcd_gauge_t* g, double* plaq);
+int lqcd_mdom_solve_cg_DdagD(int n, lqcd_op_t* ops, lqcd_spinor_t* x, lqcd_spinor_t* b, double eps, int maxiter,
+                             int* iters, double* final_rr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

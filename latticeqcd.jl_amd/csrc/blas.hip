@@ -1,0 +1,204 @@
+// blas.hip -- BLAS-1 on fermion fields and deterministic two-stage reductions (SURVEY.md 8(a) a6:
+// LinearAlgebra.dot / add_fermion! / clear_fermion! of LatticeDiracOperators.jl; call sites
+// /root/reference/src/updates/standardHMC.jl:54, src/md/standardMD.jl:50-51).
+// All kernels stream double2 (16 B/lane, 1 KiB per wave instruction) with a grid-stride loop; reductions write
+// per-block partials that a single-block kernel sums in a fixed order (bit-reproducible run to run).
+#include "lqcd_internal.h"
+
+namespace lqcd {
+
+constexpr int RB = 256;  // reduction / streaming block size
+
+__device__ inline void block_reduce2(double a, double b, double* partial, int stride) {
+    __shared__ double red[2][RB / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0, sb = 0;
+#pragma unroll
+        for (int w = 0; w < RB / 64; w++) { sa += red[0][w]; sb += red[1][w]; }
+        partial[blockIdx.x * stride] = sa;
+        if (stride > 1) partial[blockIdx.x * stride + 1] = sb;
+    }
+}
+
+__global__ __launch_bounds__(RB) void dot_kernel(const double2* __restrict__ a, const double2* __restrict__ b, size_t n,
+                                                 double* partial) {
+    double re = 0, im = 0;
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n; i += (size_t)gridDim.x * RB) {
+        const double2 x = a[i], y = b[i];
+        re = fma(x.x, y.x, re); re = fma(x.y, y.y, re);
+        im = fma(x.x, y.y, im); im = fma(-x.y, y.x, im);
+    }
+    block_reduce2(re, im, partial, 2);
+}
+
+__global__ __launch_bounds__(RB) void norm2_kernel(const double2* __restrict__ a, size_t n, double* partial) {
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n; i += (size_t)gridDim.x * RB) {
+        const double2 x = a[i];
+        s = fma(x.x, x.x, s); s = fma(x.y, x.y, s);
+    }
+    block_reduce2(s, 0.0, partial, 1);
+}
+
+// sums nblocks partials of `nvals` interleaved values into out[0..nvals)
+__global__ __launch_bounds__(RB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* out) {
+    __shared__ double red[RB / 64];
+    for (int v = 0; v < nvals; v++) {
+        double s = 0;
+        for (int i = threadIdx.x; i < nblocks; i += RB) s += partial[(size_t)i * nvals + v];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0;
+            for (int w = 0; w < RB / 64; w++) t += red[w];
+            out[v] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(RB) void axpy_kernel(double ar, double ai, const double2* __restrict__ x, double2* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n; i += (size_t)gridDim.x * RB) {
+        const double2 xv = x[i];
+        double2 yv = y[i];
+        yv.x = fma(ar, xv.x, yv.x); yv.x = fma(-ai, xv.y, yv.x);
+        yv.y = fma(ar, xv.y, yv.y); yv.y = fma(ai, xv.x, yv.y);
+        y[i] = yv;
+    }
+}
+
+__global__ __launch_bounds__(RB) void axpby_kernel(double ar, double ai, const double2* __restrict__ x, double br, double bi,
+                                                   double2* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n; i += (size_t)gridDim.x * RB) {
+        const double2 xv = x[i], yv = y[i];
+        double2 r;
+        r.x = ar * xv.x - ai * xv.y + br * yv.x - bi * yv.y;
+        r.y = ar * xv.y + ai * xv.x + br * yv.y + bi * yv.x;
+        y[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(RB) void scale_kernel(double ar, double ai, double2* __restrict__ x, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n; i += (size_t)gridDim.x * RB) {
+        const double2 xv = x[i];
+        x[i] = make_double2(ar * xv.x - ai * xv.y, ar * xv.y + ai * xv.x);
+    }
+}
+
+int stream_grid(lqcd_ctx_s* c, size_t n) {
+    size_t nb = (n + RB - 1) / RB;
+    const size_t cap = (size_t)c->num_cu * 8;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// sum over ranks of n host doubles (RCCL all-reduce through the device scalar block)
+int allreduce_host(lqcd_ctx_s* c, double* vals, int n) {
+    if (c->nranks == 1 || !c->has_comm) return LQCD_OK;
+    ARGCHK(n <= 8, "allreduce_host: too many values");
+    double* d = c->d_scal + SCAL_DOUBLES - 8;
+    HIPCHK(hipMemcpyAsync(d, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(ncclAllReduce(d, d, n, ncclDouble, ncclSum, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(vals, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+// device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce) {
+    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(RB), 0, c->stream, c->d_partial, nblocks, nvals, c->d_scal + slot);
+    HIPCHK(hipGetLastError());
+    if (allreduce && c->nranks > 1 && c->has_comm)
+        NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm, c->stream));
+    return LQCD_OK;
+}
+
+static int fetch_slot(lqcd_ctx_s* c, int slot, int nvals, double* out) {
+    HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + slot, nvals * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nvals; i++) out[i] = c->h_scal[i];
+    return LQCD_OK;
+}
+
+int blas_dot(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, double* re, double* im, bool allreduce) {
+    HIPCHK(hipSetDevice(c->device));
+    const int nb = stream_grid(c, n);
+    hipLaunchKernelGGL(dot_kernel, dim3(nb), dim3(RB), 0, c->stream, a, b, n, c->d_partial);
+    HIPCHK(hipGetLastError());
+    LQCHK(reduce_to_slot(c, nb, 2, 0, allreduce));
+    double v[2];
+    LQCHK(fetch_slot(c, 0, 2, v));
+    *re = v[0];
+    *im = v[1];
+    return LQCD_OK;
+}
+
+int blas_norm2(lqcd_ctx_s* c, const double2* a, size_t n, double* n2, bool allreduce) {
+    HIPCHK(hipSetDevice(c->device));
+    const int nb = stream_grid(c, n);
+    hipLaunchKernelGGL(norm2_kernel, dim3(nb), dim3(RB), 0, c->stream, a, n, c->d_partial);
+    HIPCHK(hipGetLastError());
+    LQCHK(reduce_to_slot(c, nb, 1, 0, allreduce));
+    return fetch_slot(c, 0, 1, n2);
+}
+
+int blas_axpy(lqcd_ctx_s* c, double ar, double ai, const double2* x, double2* y, size_t n) {
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(c, n)), dim3(RB), 0, c->stream, ar, ai, x, y, n);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+int blas_axpby(lqcd_ctx_s* c, double ar, double ai, const double2* x, double br, double bi, double2* y, size_t n) {
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(c, n)), dim3(RB), 0, c->stream, ar, ai, x, br, bi, y, n);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n) {
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(c, n)), dim3(RB), 0, c->stream, ar, ai, x, n);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+}  // namespace lqcd
+
+using namespace lqcd;
+
+static bool same_shape(lqcd_spinor_t a, lqcd_spinor_t b) {
+    return a && b && a->ctx == b->ctx && a->kind == b->kind && a->subset == b->subset;
+}
+
+extern "C" int lqcd_dot(lqcd_spinor_t a, lqcd_spinor_t b, double* re, double* im) {
+    ARGCHK(same_shape(a, b) && re && im, "lqcd_dot: shape mismatch or null");
+    return blas_dot(a->ctx, a->data, b->data, a->elems, re, im, true);
+}
+extern "C" int lqcd_norm2(lqcd_spinor_t a, double* n2) {
+    ARGCHK(a && n2, "lqcd_norm2: null");
+    return blas_norm2(a->ctx, a->data, a->elems, n2, true);
+}
+extern "C" int lqcd_axpy(double ar, double ai, lqcd_spinor_t x, lqcd_spinor_t y) {
+    ARGCHK(same_shape(x, y), "lqcd_axpy: shape mismatch");
+    LQCHK(blas_axpy(x->ctx, ar, ai, x->data, y->data, x->elems));
+    HIPCHK(hipStreamSynchronize(x->ctx->stream));
+    return LQCD_OK;
+}
+extern "C" int lqcd_axpby(double ar, double ai, lqcd_spinor_t x, double br, double bi, lqcd_spinor_t y) {
+    ARGCHK(same_shape(x, y), "lqcd_axpby: shape mismatch");
+    LQCHK(blas_axpby(x->ctx, ar, ai, x->data, br, bi, y->data, x->elems));
+    HIPCHK(hipStreamSynchronize(x->ctx->stream));
+    return LQCD_OK;
+}
+extern "C" int lqcd_scale(double ar, double ai, lqcd_spinor_t x) {
+    ARGCHK(x, "lqcd_scale: null");
+    LQCHK(blas_scale(x->ctx, ar, ai, x->data, x->elems));
+    HIPCHK(hipStreamSynchronize(x->ctx->stream));
+    return LQCD_OK;
+}

@@ -1,0 +1,292 @@
+// capi.hip -- context management, PE-grid decomposition, RCCL bootstrap, error reporting, host-only index helpers.
+// The PE grid is the reference's PEs concept (/root/reference/src/mpirun.jl:17-19, src/mpi/mpimodule.jl:9-13):
+// rank = px + PX*(py + PY*(pz + PZ*pt)); one process (one context) per GPU.
+#include "lqcd_internal.h"
+
+#include <cstring>
+#include <mutex>
+
+namespace lqcd {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
+    (void)hipGetLastError();
+    return LQCD_ERR_HIP;
+}
+int nccl_fail(ncclResult_t e, const char* what, const char* file, int line) {
+    g_err = std::string("RCCL error: ") + ncclGetErrorString(e) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
+    return LQCD_ERR_COMM;
+}
+
+lqcd_spinor_s* scratch_get(lqcd_ctx_s* c, int kind, int subset) {
+    const int want_sub = subset == LQCD_FULL ? LQCD_FULL : LQCD_EVEN;  // half fields are interchangeable
+    for (lqcd_spinor_s* s : c->scratch)
+        if (!s->in_use && s->kind == kind && (s->subset == LQCD_FULL) == (want_sub == LQCD_FULL)) {
+            s->in_use = true;
+            s->subset = subset;
+            return s;
+        }
+    lqcd_spinor_s* s = nullptr;
+    if (lqcd_spinor_create(c, &s, kind, subset) != LQCD_OK) return nullptr;
+    s->in_use = true;
+    c->scratch.push_back(s);
+    return s;
+}
+void scratch_put(lqcd_spinor_s* s) {
+    if (s) s->in_use = false;
+}
+
+int plaquette_local_sum(lqcd_gauge_s* g, const double2* const ghost[4], double* sum);
+int gauge_pack_face(lqcd_gauge_s* g, int mu, double2* dst);
+
+static int decompose(const int gL[4], const int pe[4], int rank, int L[4], int origin[4], int coord[4], int nf[4], int nb[4]) {
+    int nranks = 1;
+    for (int mu = 0; mu < 4; mu++) {
+        ARGCHK(pe[mu] >= 1 && gL[mu] >= 2, "decompose: bad PE grid or lattice extent");
+        ARGCHK(gL[mu] % pe[mu] == 0, "decompose: global extent not divisible by the PE grid");
+        L[mu] = gL[mu] / pe[mu];
+        ARGCHK(L[mu] % 2 == 0, "decompose: local extents must be even (checkerboard layout)");
+        nranks *= pe[mu];
+    }
+    ARGCHK(rank >= 0 && rank < nranks, "decompose: rank outside the PE grid");
+    int q = rank;
+    for (int mu = 0; mu < 4; mu++) { coord[mu] = q % pe[mu]; q /= pe[mu]; origin[mu] = coord[mu] * L[mu]; }
+    for (int mu = 0; mu < 4; mu++) {
+        int cf[4] = {coord[0], coord[1], coord[2], coord[3]}, cb[4] = {coord[0], coord[1], coord[2], coord[3]};
+        cf[mu] = (coord[mu] + 1) % pe[mu];
+        cb[mu] = (coord[mu] + pe[mu] - 1) % pe[mu];
+        nf[mu] = cf[0] + pe[0] * (cf[1] + pe[1] * (cf[2] + pe[2] * cf[3]));
+        nb[mu] = cb[0] + pe[0] * (cb[1] + pe[1] * (cb[2] + pe[2] * cb[3]));
+    }
+    return LQCD_OK;
+}
+
+}  // namespace lqcd
+
+using namespace lqcd;
+
+extern "C" int lqcd_version(void) { return 100; }
+extern "C" const char* lqcd_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lqcd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int64_t lqcd_index_lex(const int L[4], int x, int y, int z, int t) {
+    return x + (int64_t)L[0] * (y + (int64_t)L[1] * (z + (int64_t)L[2] * t));
+}
+
+static void geom_from_L(Geom& g, const int L[4]) {
+    memset(&g, 0, sizeof(g));
+    for (int mu = 0; mu < 4; mu++) { g.L[mu] = L[mu]; g.gL[mu] = L[mu]; g.bc_fwd[mu] = g.bc_bwd[mu] = 1.0; }
+    g.XH = L[0] / 2;
+    g.Vh = (L[0] / 2) * L[1] * L[2] * L[3];
+}
+
+extern "C" int lqcd_index_cb(const int L[4], int x, int y, int z, int t, int* parity, int64_t* cb) {
+    ARGCHK(L && parity && cb, "lqcd_index_cb: null");
+    ARGCHK(L[0] % 2 == 0, "lqcd_index_cb: NX must be even");
+    ARGCHK(x >= 0 && x < L[0] && y >= 0 && y < L[1] && z >= 0 && z < L[2] && t >= 0 && t < L[3], "lqcd_index_cb: site out of range");
+    Geom g;
+    geom_from_L(g, L);
+    const int c[4] = {x, y, z, t};
+    *parity = (x + y + z + t) & 1;
+    *cb = coords_to_cb(g, c);
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_coords_cb(const int L[4], int parity, int64_t cb, int xyzt[4]) {
+    ARGCHK(L && xyzt, "lqcd_coords_cb: null");
+    ARGCHK(L[0] % 2 == 0, "lqcd_coords_cb: NX must be even");
+    Geom g;
+    geom_from_L(g, L);
+    ARGCHK((parity == 0 || parity == 1) && cb >= 0 && cb < g.Vh, "lqcd_coords_cb: index out of range");
+    cb_to_coords(g, parity, (int)cb, xyzt);
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_decompose(const int gL[4], const int pe[4], int rank, int L[4], int origin[4], int rank_fwd[4], int rank_bwd[4]) {
+    ARGCHK(gL && pe && L && origin && rank_fwd && rank_bwd, "lqcd_decompose: null");
+    int coord[4];
+    return decompose(gL, pe, rank, L, origin, coord, rank_fwd, rank_bwd);
+}
+
+// ---------------------------------------------------------------------------------- context
+extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], const int pe[4], int rank) {
+    ARGCHK(out && gL && pe, "lqcd_ctx_create: null argument");
+    int L[4], origin[4], coord[4], nf[4], nb[4];
+    LQCHK(decompose(gL, pe, rank, L, origin, coord, nf, nb));
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("lqcd_ctx_create: no such HIP device " + std::to_string(device) + " (" + std::to_string(ndev) + " visible) -- "
+                  "this library has no CPU fallback");
+        return LQCD_ERR_HIP;
+    }
+    HIPCHK(hipSetDevice(device));
+    const long long V = (long long)L[0] * L[1] * L[2] * L[3];
+    ARGCHK(V / 2 < (1ll << 31) / 16, "lqcd_ctx_create: local volume too large for 32-bit site indices");
+    lqcd_ctx_s* c = new lqcd_ctx_s;
+    c->device = device;
+    c->rank = rank;
+    c->nranks = pe[0] * pe[1] * pe[2] * pe[3];
+    geom_from_L(c->geom, L);
+    for (int mu = 0; mu < 4; mu++) {
+        c->gL[mu] = gL[mu]; c->pe[mu] = pe[mu]; c->coord[mu] = coord[mu];
+        c->nbr_fwd[mu] = nf[mu]; c->nbr_bwd[mu] = nb[mu];
+        c->geom.gL[mu] = gL[mu]; c->geom.origin[mu] = origin[mu];
+        c->geom.part[mu] = pe[mu] > 1 ? 1 : 0;
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->ev_t0));
+    HIPCHK(hipEventCreate(&c->ev_t1));
+    const size_t npart = (size_t)2 * c->geom.Vh / 64 + 4096;
+    HIPCHK(hipMalloc((void**)&c->d_partial, npart * 2 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&c->d_scal, SCAL_DOUBLES * sizeof(double)));
+    HIPCHK(hipMemset(c->d_scal, 0, SCAL_DOUBLES * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&c->h_scal, SCAL_DOUBLES * sizeof(double), hipHostMallocDefault));
+    for (int mu = 0; mu < 4; mu++) {
+        if (!c->geom.part[mu]) continue;
+        c->halo_elems[mu] = (size_t)2 * 6 * face_half_sites(c->geom, mu);
+        const size_t bytes = c->halo_elems[mu] * sizeof(double2);
+        HIPCHK(hipMalloc((void**)&c->send_fwd[mu], bytes));
+        HIPCHK(hipMalloc((void**)&c->send_bwd[mu], bytes));
+        HIPCHK(hipMalloc((void**)&c->recv_fwd[mu], bytes));
+        HIPCHK(hipMalloc((void**)&c->recv_bwd[mu], bytes));
+    }
+    *out = c;
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
+    if (!c) return LQCD_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (lqcd_spinor_s* s : c->scratch) { hipFree(s->data); delete s; }
+    for (int mu = 0; mu < 4; mu++) {
+        hipFree(c->send_fwd[mu]); hipFree(c->send_bwd[mu]); hipFree(c->recv_fwd[mu]); hipFree(c->recv_bwd[mu]);
+    }
+    if (c->has_comm) ncclCommDestroy(c->comm);
+    hipFree(c->d_partial); hipFree(c->d_scal); hipHostFree(c->h_scal);
+    hipEventDestroy(c->ev_pack); hipEventDestroy(c->ev_comm); hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
+    hipStreamDestroy(c->stream); hipStreamDestroy(c->comm_stream);
+    delete c;
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_ctx_sync(lqcd_ctx_t c) {
+    ARGCHK(c, "lqcd_ctx_sync: null");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->comm_stream));
+    return LQCD_OK;
+}
+
+static int* param_ptr(lqcd_ctx_s* c, const char* key) {
+    if (!strcmp(key, "dslash_block")) return &c->tun.dslash_block;
+    if (!strcmp(key, "xcd_remap")) return &c->tun.xcd_remap;
+    if (!strcmp(key, "dslash_variant")) return &c->tun.dslash_variant;
+    if (!strcmp(key, "nt_gauge")) return &c->tun.nt_gauge;
+    if (!strcmp(key, "nt_store")) return &c->tun.nt_store;
+    if (!strcmp(key, "cg_fused")) return &c->tun.cg_fused;
+    if (!strcmp(key, "graph")) return &c->tun.graph;
+    return nullptr;
+}
+extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
+    ARGCHK(c && key, "lqcd_ctx_set_param: null");
+    int* p = param_ptr(c, key);
+    ARGCHK(p, std::string("lqcd_ctx_set_param: unknown key ") + key);
+    if (!strcmp(key, "dslash_block")) ARGCHK(value == 64 || value == 128 || value == 256, "dslash_block must be 64, 128 or 256");
+    *p = value;
+    return LQCD_OK;
+}
+extern "C" int lqcd_ctx_get_param(lqcd_ctx_t c, const char* key, int* value) {
+    ARGCHK(c && key && value, "lqcd_ctx_get_param: null");
+    int* p = param_ptr(c, key);
+    ARGCHK(p, std::string("lqcd_ctx_get_param: unknown key ") + key);
+    *value = *p;
+    return LQCD_OK;
+}
+
+// ---------------------------------------------------------------------------------- RCCL bootstrap
+extern "C" int lqcd_comm_unique_id(unsigned char id[128]) {
+    ARGCHK(id, "lqcd_comm_unique_id: null");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId u;
+    NCCLCHK(ncclGetUniqueId(&u));
+    memcpy(id, &u, 128);
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_ctx_comm_init(lqcd_ctx_t c, const unsigned char id[128], int nranks) {
+    ARGCHK(c && id, "lqcd_ctx_comm_init: null");
+    ARGCHK(nranks == c->nranks, "lqcd_ctx_comm_init: nranks does not match the PE grid");
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    NCCLCHK(ncclCommInitRank(&c->comm, nranks, u, c->rank));
+    c->has_comm = true;
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_ctx_link_local(lqcd_ctx_t* ctxs, int n) {
+    ARGCHK(ctxs && n >= 1, "lqcd_ctx_link_local: null");
+    for (int r = 0; r < n; r++) {
+        ARGCHK(ctxs[r] && ctxs[r]->rank == r && ctxs[r]->nranks == n, "lqcd_ctx_link_local: contexts must be ranks 0..n-1 of one PE grid");
+        ARGCHK(ctxs[r]->device == ctxs[0]->device, "lqcd_ctx_link_local: all contexts must live on one device");
+        for (int mu = 0; mu < 4; mu++) ARGCHK(ctxs[r]->pe[mu] == ctxs[0]->pe[mu] && ctxs[r]->gL[mu] == ctxs[0]->gL[mu], "lqcd_ctx_link_local: PE grid mismatch");
+    }
+    for (int r = 0; r < n; r++) ctxs[r]->local_peers.assign(ctxs, ctxs + n);
+    return LQCD_OK;
+}
+
+// ---------------------------------------------------------------------------------- plaquette (single rank or RCCL ranks)
+extern "C" int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq) {
+    ARGCHK(g && plaq, "lqcd_gauge_plaquette: null");
+    lqcd_ctx_s* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    ARGCHK(c->local_peers.empty(), "lqcd_gauge_plaquette: context is part of an in-process PE grid, use lqcd_mdom_plaquette");
+    double2* ghost[4] = {nullptr, nullptr, nullptr, nullptr};
+    double2* sendb[4] = {nullptr, nullptr, nullptr, nullptr};
+    int st = LQCD_OK;
+    bool part = false;
+    for (int mu = 0; mu < 4; mu++) part = part || c->geom.part[mu];
+    if (part) {
+        ARGCHK(c->has_comm, "lqcd_gauge_plaquette: communicator not initialised");
+        for (int mu = 0; mu < 4 && st == LQCD_OK; mu++) {
+            if (!c->geom.part[mu]) continue;
+            const size_t bytes = (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu) * sizeof(double2);
+            if (hipMalloc((void**)&ghost[mu], bytes) != hipSuccess || hipMalloc((void**)&sendb[mu], bytes) != hipSuccess) { st = LQCD_ERR_HIP; break; }
+            st = gauge_pack_face(g, mu, sendb[mu]);
+        }
+        if (st == LQCD_OK) {
+            ncclGroupStart();
+            for (int mu = 0; mu < 4; mu++) {
+                if (!c->geom.part[mu]) continue;
+                const size_t nd = (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu) * 2;
+                ncclSend(sendb[mu], nd, ncclDouble, c->nbr_bwd[mu], c->comm, c->stream);
+                ncclRecv(ghost[mu], nd, ncclDouble, c->nbr_fwd[mu], c->comm, c->stream);
+            }
+            ncclResult_t r = ncclGroupEnd();
+            if (r != ncclSuccess) st = nccl_fail(r, "plaquette halo", __FILE__, __LINE__);
+        }
+    }
+    double sum = 0;
+    if (st == LQCD_OK) st = plaquette_local_sum(g, ghost, &sum);
+    for (int mu = 0; mu < 4; mu++) { if (ghost[mu]) hipFree(ghost[mu]); if (sendb[mu]) hipFree(sendb[mu]); }
+    if (st != LQCD_OK) return st;
+    LQCHK(allreduce_host(c, &sum, 1));
+    const double V = (double)c->gL[0] * c->gL[1] * c->gL[2] * c->gL[3];
+    *plaq = sum / (6.0 * V * 3.0);
+    return LQCD_OK;
+}

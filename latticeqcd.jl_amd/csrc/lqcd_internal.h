@@ -1,0 +1,247 @@
+// lqcd_internal.h -- shared internals of liblqcd_hip.so (gfx950 only; no CUDA-compat paths).
+//
+// Device data layout (HBM), chosen for coalesced 16-B/lane loads (one complex fp64 per lane, 1 KiB per
+// wave64 instruction):
+//   * sites are checkerboarded: parity p = (x+y+z+t)&1, cb = (x>>1) + XH*(y + LY*(z + LZ*t)), XH = LX/2
+//   * spinor  [parity][comp][cb]   comp = spin*3 + colour (Wilson, 12)  or colour (staggered, 3); element = double2
+//   * gauge   [parity][mu][a*3+b][cb]                                    element = double2 (row a, column b)
+// i.e. structure-of-arrays with the site index fastest; an EVEN/ODD spinor is one [comp][cb] block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lqcd_hip.h"
+
+namespace lqcd {
+
+struct Geom {           // local sub-lattice geometry, passed by value to kernels
+    int L[4];           // local extents
+    int XH;             // L[0]/2
+    int Vh;             // sites per parity
+    int part[4];        // 1 if direction is partitioned over ranks (neighbour is off-rank)
+    double bc_fwd[4];   // sign applied when a forward hop wraps locally across the GLOBAL boundary (unpartitioned dirs)
+    double bc_bwd[4];
+    int origin[4];      // global coordinates of local site (0,0,0,0)
+    int gL[4];          // global extents
+};
+
+// checkerboard index -> local coordinates
+__host__ __device__ inline void cb_to_coords(const Geom& g, int parity, int cb, int c[4]) {
+    int xh = cb % g.XH;
+    int q = cb / g.XH;
+    c[1] = q % g.L[1];
+    q /= g.L[1];
+    c[2] = q % g.L[2];
+    c[3] = q / g.L[2];
+    c[0] = 2 * xh + ((c[1] + c[2] + c[3] + parity) & 1);
+}
+__host__ __device__ inline int coords_to_cb(const Geom& g, const int c[4]) {
+    return (c[0] >> 1) + g.XH * (c[1] + g.L[1] * (c[2] + g.L[2] * c[3]));
+}
+
+// ---------------------------------------------------------------- faces (halo geometry)
+// A face of direction mu holds the sites with x_mu fixed; per parity it has Fh(mu) = Vh / L[mu] sites.
+// Face index f enumerates the remaining three coordinates in increasing direction order, the first of them halved
+// (checkerboarded) -- the same rule as the bulk cb index.
+__host__ __device__ inline int face_half_sites(const Geom& g, int mu) { return g.Vh / g.L[mu]; }
+__host__ __device__ inline void face_to_coords(const Geom& g, int mu, int fixed, int parity, int f, int c[4]) {
+    int d0 = (mu == 0) ? 1 : 0;
+    int d1 = (mu <= 1) ? 2 : 1;
+    int d2 = (mu <= 2) ? 3 : 2;
+    int h0 = g.L[d0] / 2;
+    int a0 = f % h0;
+    int q = f / h0;
+    c[d1] = q % g.L[d1];
+    c[d2] = q / g.L[d1];
+    c[mu] = fixed;
+    c[d0] = 2 * a0 + ((c[d1] + c[d2] + fixed + parity) & 1);
+}
+__host__ __device__ inline int coords_to_face(const Geom& g, int mu, const int c[4]) {
+    int d0 = (mu == 0) ? 1 : 0;
+    int d1 = (mu <= 1) ? 2 : 1;
+    int d2 = (mu <= 2) ? 3 : 2;
+    return (c[d0] >> 1) + (g.L[d0] / 2) * (c[d1] + g.L[d1] * c[d2]);
+}
+
+// ---------------------------------------------------------------- complex fp64 helpers
+struct cd {
+    double re, im;
+};
+__host__ __device__ inline cd mk(double a, double b) { cd r = {a, b}; return r; }
+__device__ inline cd ld(const double2* p) { double2 v = *p; return mk(v.x, v.y); }
+__device__ inline void st(double2* p, cd v) { *p = make_double2(v.re, v.im); }
+__device__ inline cd operator+(cd a, cd b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ inline cd operator-(cd a, cd b) { return mk(a.re - b.re, a.im - b.im); }
+__device__ inline cd operator*(double s, cd a) { return mk(s * a.re, s * a.im); }
+__device__ inline cd cmul(cd a, cd b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+// acc += a*b
+__device__ inline void cfma(cd& acc, cd a, cd b) {
+    acc.re = fma(a.re, b.re, acc.re); acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im); acc.im = fma(a.im, b.re, acc.im);
+}
+// acc += conj(a)*b
+__device__ inline void cfma_conj(cd& acc, cd a, cd b) {
+    acc.re = fma(a.re, b.re, acc.re); acc.re = fma(a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im); acc.im = fma(-a.im, b.re, acc.im);
+}
+// multiply by i^K
+template <int K> __device__ inline cd mul_ipow(cd a) {
+    constexpr int k = ((K % 4) + 4) % 4;
+    if constexpr (k == 0) return a;
+    else if constexpr (k == 1) return mk(-a.im, a.re);
+    else if constexpr (k == 2) return mk(-a.re, -a.im);
+    else return mk(a.im, -a.re);
+}
+
+// ---------------------------------------------------------------- counter-based RNG (identical bits on every rank / decomposition)
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t rng_key(uint64_t seed, uint64_t site, uint64_t a, uint64_t b) {
+    return splitmix64(splitmix64(splitmix64(seed ^ 0xA5A5A5A5DEADBEEFull) + site) + (a << 8) + b);
+}
+__host__ __device__ inline double u01(uint64_t k) { return ((k >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+// ---------------------------------------------------------------- runtime objects
+struct Ctx;
+
+struct Tunables {
+    int dslash_block = 128;   // threads per workgroup of the stencil kernels
+    int xcd_remap = 1;        // 1: each XCD gets a contiguous t-slab of the lattice (L2 locality)
+    int dslash_variant = 0;   // kernel variant selector (see dslash_wilson.hip)
+    int nt_gauge = 0;         // non-temporal loads for gauge links
+    int nt_store = 0;         // non-temporal stores for the output spinor
+    int cg_fused = 1;         // fused BLAS-1 / reductions in CG
+    int graph = 0;            // capture solver iterations in a hipGraph
+};
+
+}  // namespace lqcd
+
+struct lqcd_ctx_s {
+    int device = 0;
+    int gL[4], pe[4], rank = 0, nranks = 1, coord[4];
+    int nbr_fwd[4], nbr_bwd[4];
+    lqcd::Geom geom;
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_comm = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    // reductions
+    double* d_partial = nullptr;  // [MAX_PARTIAL_BLOCKS * 4]
+    double* d_scal = nullptr;     // small device scalar block (solver state)
+    double* h_scal = nullptr;     // pinned mirror
+    // halo buffers (sized for Wilson full-lattice: 2 parities * 6 comps * Fh)
+    double2* send_fwd[4] = {}, *send_bwd[4] = {}, *recv_fwd[4] = {}, *recv_bwd[4] = {};
+    size_t halo_elems[4] = {};
+    ncclComm_t comm = nullptr;
+    bool has_comm = false;
+    std::vector<lqcd_ctx_s*> local_peers;  // in-process emulation of the PE grid
+    // scratch spinors owned by the context (Temporalfields analogue)
+    std::vector<lqcd_spinor_s*> scratch;
+    lqcd::Tunables tun;
+    int num_cu = 256;
+};
+
+struct lqcd_gauge_s {
+    lqcd_ctx_s* ctx;
+    double2* data;  // [2][4][9][Vh]
+    size_t elems;
+};
+
+struct lqcd_spinor_s {
+    lqcd_ctx_s* ctx;
+    int kind;    // LQCD_WILSON | LQCD_STAGGERED
+    int subset;  // LQCD_FULL | LQCD_EVEN | LQCD_ODD
+    int ncomp;   // 12 | 3
+    double2* data;
+    size_t elems;  // ncomp * Vh * (1|2)
+    bool in_use = false;  // scratch-pool flag
+};
+
+struct lqcd_op_s {
+    lqcd_ctx_s* ctx;
+    int kind;
+    lqcd_gauge_s* gauge;
+    double km;  // kappa or mass
+    double r;
+    int bc[4];
+};
+
+namespace lqcd {
+
+constexpr int MAX_PARTIAL_BLOCKS = 4096;
+constexpr int SCAL_DOUBLES = 64;
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+int nccl_fail(ncclResult_t e, const char* what, const char* file, int line);
+
+#define HIPCHK(x)                                                              \
+    do {                                                                       \
+        hipError_t _e = (x);                                                   \
+        if (_e != hipSuccess) return lqcd::hip_fail(_e, #x, __FILE__, __LINE__); \
+    } while (0)
+#define NCCLCHK(x)                                                              \
+    do {                                                                        \
+        ncclResult_t _e = (x);                                                  \
+        if (_e != ncclSuccess) return lqcd::nccl_fail(_e, #x, __FILE__, __LINE__); \
+    } while (0)
+#define LQCHK(x)                       \
+    do {                               \
+        int _s = (x);                  \
+        if (_s != LQCD_OK) return _s;  \
+    } while (0)
+#define ARGCHK(cond, msg)                     \
+    do {                                      \
+        if (!(cond)) {                        \
+            lqcd::set_error(msg);             \
+            return LQCD_ERR_ARG;              \
+        }                                     \
+    } while (0)
+
+// ---- kernel launchers implemented across the .hip files
+// stencil: out = a * xin + b * Hop(in), for the parities selected by `parity_mode` (0, 1, or 2 = both).
+struct StencilCall {
+    int kind;
+    const double2* gauge;         // [2][4][9][Vh]
+    double2* out[2];              // per parity block (nullptr if not written)
+    const double2* in[2];         // per parity block of the INPUT field (hop reads in[1-p])
+    const double2* xin[2];        // per parity block of the diagonal term (may be nullptr when a == 0)
+    double a, b;
+    double r;                     // Wilson parameter
+    int dagger;
+    int parity_mode;              // 0 even out, 1 odd out, 2 both
+    double* norm_partial;         // if non-null: per-block partial sums of |out|^2 are written here
+};
+int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
+int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
+int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);
+int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path)
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode);
+int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
+int stencil_num_blocks(lqcd_ctx_s* c, int parity_mode);
+
+// BLAS-1 / reductions (blas.hip)
+int blas_dot(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, double* re, double* im, bool allreduce);
+int blas_norm2(lqcd_ctx_s* c, const double2* a, size_t n, double* n2, bool allreduce);
+int blas_axpy(lqcd_ctx_s* c, double ar, double ai, const double2* x, double2* y, size_t n);
+int blas_axpby(lqcd_ctx_s* c, double ar, double ai, const double2* x, double br, double bi, double2* y, size_t n);
+int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n);
+int allreduce_host(lqcd_ctx_s* c, double* vals, int n);
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce);
+int stream_grid(lqcd_ctx_s* c, size_t n);
+
+// fields.hip
+double2* spinor_block(lqcd_spinor_s* s, int p);
+int plaquette_local_sum(lqcd_gauge_s* g, const double2* const ghost[4], double* sum);
+int gauge_pack_face(lqcd_gauge_s* g, int mu, double2* dst);
+
+// scratch spinors
+lqcd_spinor_s* scratch_get(lqcd_ctx_s* c, int kind, int subset);
+void scratch_put(lqcd_spinor_s* s);
+
+}  // namespace lqcd

@@ -1,0 +1,712 @@
+// ops.hip -- operator application (with halo exchange), Krylov solvers, timing entry points.
+//
+// Replaces, behind the C ABI, LatticeDiracOperators.jl's mul!(y,D,x), DdagD_operator, and solve_DinvX!
+// (cg / bicgstab / even-odd bicgstab) -- SURVEY.md 8(a) a2-a5; reference call sites
+// /root/reference/src/md/AbstractMD.jl:129, src/updates/standardHMC.jl:71, src/md/standardMD.jl:95-96.
+#include "lqcd_internal.h"
+
+#include <cmath>
+#include <complex>
+#include <functional>
+
+namespace lqcd {
+
+double2* spinor_block(lqcd_spinor_s* s, int p);
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce);
+int stream_grid(lqcd_ctx_s* c, size_t n);
+
+// ---------------------------------------------------------------------------------- halo exchange
+static size_t halo_count(lqcd_ctx_s* c, int mu, int kind, int parity_mode) {
+    const int nh = kind == LQCD_WILSON ? 6 : 3;
+    return (size_t)(parity_mode == 2 ? 2 : 1) * nh * face_half_sites(c->geom, mu);
+}
+
+// RCCL path: one grouped send/recv per partitioned direction and face, on the communication stream, so the
+// transfer over xGMI overlaps the interior stencil running on the compute stream.
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode) {
+    ARGCHK(c->has_comm, "halo exchange: communicator not initialised (call lqcd_ctx_comm_init)");
+    HIPCHK(hipEventRecord(c->ev_pack, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+    NCCLCHK(ncclGroupStart());
+    for (int mu = 0; mu < 4; mu++) {
+        if (!c->geom.part[mu]) continue;
+        const size_t n = halo_count(c, mu, kind, parity_mode) * 2;  // doubles
+        NCCLCHK(ncclSend(c->send_fwd[mu], n, ncclDouble, c->nbr_fwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclSend(c->send_bwd[mu], n, ncclDouble, c->nbr_bwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclRecv(c->recv_bwd[mu], n, ncclDouble, c->nbr_bwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclRecv(c->recv_fwd[mu], n, ncclDouble, c->nbr_fwd[mu], c->comm, c->comm_stream));
+    }
+    NCCLCHK(ncclGroupEnd());
+    HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
+    return LQCD_OK;
+}
+
+// in-process emulation: every rank has packed; copy sender buffers into the peers' receive buffers
+int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode) {
+    for (int r = 0; r < n; r++) HIPCHK(hipStreamSynchronize(ctxs[r]->stream));
+    for (int r = 0; r < n; r++) {
+        lqcd_ctx_s* c = ctxs[r];
+        for (int mu = 0; mu < 4; mu++) {
+            if (!c->geom.part[mu]) continue;
+            const size_t bytes = halo_count(c, mu, kind, parity_mode) * sizeof(double2);
+            // my send_fwd lands in the +mu neighbour's recv_bwd; my send_bwd in the -mu neighbour's recv_fwd
+            HIPCHK(hipMemcpy(ctxs[c->nbr_fwd[mu]]->recv_bwd[mu], c->send_fwd[mu], bytes, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(ctxs[c->nbr_bwd[mu]]->recv_fwd[mu], c->send_bwd[mu], bytes, hipMemcpyDeviceToDevice));
+        }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    return LQCD_OK;
+}
+
+static bool any_partitioned(lqcd_ctx_s* c) {
+    return c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3];
+}
+
+// full stencil on one rank: pack -> (exchange || interior) -> exterior
+int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
+    HIPCHK(hipSetDevice(c->device));
+    if (!any_partitioned(c)) return launch_stencil_interior(c, s);
+    if (s.kind == LQCD_WILSON && s.r != 1.0) {
+        set_error("Wilson r != 1 is not supported on a partitioned lattice (halos carry spin-projected half spinors)");
+        return LQCD_ERR_UNSUPPORTED;
+    }
+    ARGCHK(c->local_peers.empty(), "this context belongs to an in-process PE grid: use the lqcd_mdom_* collectives");
+    LQCHK(launch_stencil_pack(c, s));
+    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode));
+    StencilCall si = s;
+    si.norm_partial = nullptr;
+    LQCHK(launch_stencil_interior(c, si));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    return launch_stencil_exterior(c, s);
+}
+
+// ---------------------------------------------------------------------------------- operator -> stencil calls
+static void fill_blocks(const double2* dst[2], lqcd_spinor_s* s) {
+    dst[0] = s ? spinor_block(s, 0) : nullptr;
+    dst[1] = s ? spinor_block(s, 1) : nullptr;
+}
+
+// out = D in  /  D^+ in on FULL spinors
+StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger) {
+    StencilCall s;
+    s.kind = op->kind;
+    s.gauge = op->gauge->data;
+    s.out[0] = spinor_block(out, 0);
+    s.out[1] = spinor_block(out, 1);
+    fill_blocks(s.in, in);
+    fill_blocks(s.xin, in);
+    if (op->kind == LQCD_WILSON) { s.a = 1.0; s.b = -op->km; }
+    else { s.a = op->km; s.b = dagger ? -0.5 : 0.5; }
+    s.r = op->r;
+    s.dagger = dagger;
+    s.parity_mode = 2;
+    s.norm_partial = nullptr;
+    return s;
+}
+
+// out(parity subset) = a*xin + b*H in, in of the opposite subset
+StencilCall make_hop_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* xin, double a, double b, int dagger) {
+    StencilCall s;
+    s.kind = op->kind;
+    s.gauge = op->gauge->data;
+    s.out[0] = spinor_block(out, 0);
+    s.out[1] = spinor_block(out, 1);
+    fill_blocks(s.in, in);
+    fill_blocks(s.xin, xin);
+    s.a = a;
+    s.b = (op->kind == LQCD_STAGGERED) ? b * (dagger ? -0.5 : 0.5) : b;
+    s.r = op->r;
+    s.dagger = dagger;
+    s.parity_mode = out->subset == LQCD_EVEN ? 0 : 1;
+    s.norm_partial = nullptr;
+    return s;
+}
+
+void apply_bc(lqcd_ctx_s* c, const int bc[4]) {
+    for (int mu = 0; mu < 4; mu++) {
+        // unpartitioned direction: this rank owns both ends, a local wrap is a global wrap
+        c->geom.bc_fwd[mu] = (double)bc[mu];
+        c->geom.bc_bwd[mu] = (double)bc[mu];
+    }
+}
+
+static int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* who) {
+    if (!(op && a && b && a->ctx == op->ctx && b->ctx == op->ctx && a->kind == op->kind && b->kind == op->kind &&
+          a->subset == LQCD_FULL && b->subset == LQCD_FULL && a != b)) {
+        set_error(std::string(who) + ": need two distinct FULL spinors of the operator's kind on the operator's context");
+        return LQCD_ERR_ARG;
+    }
+    return LQCD_OK;
+}
+
+int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial) {
+    apply_bc(op->ctx, op->bc);
+    StencilCall s = make_full_call(op, out, in, dagger);
+    s.norm_partial = norm_partial;
+    return stencil_apply(op->ctx, s);
+}
+
+// ---------------------------------------------------------------------------------- CG with device-resident scalars
+enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15 };
+
+__global__ void cg_scalar_alpha(double* s) {
+    if (s[S_DONE] != 0.0) return;
+    s[S_ALPHA] = s[S_RR] / s[S_PQ];
+}
+__global__ void cg_scalar_beta(double* s) {
+    if (s[S_DONE] != 0.0) return;
+    const double rrn = s[S_RRNEW];
+    s[S_BETA] = rrn / s[S_RR];
+    s[S_RR] = rrn;
+    s[S_ITERS] += 1.0;
+    if (rrn < s[S_EPS]) s[S_DONE] = 1.0;
+}
+
+constexpr int UB = 256;
+// x += alpha p ; r -= alpha q ; partial |r|^2
+__global__ __launch_bounds__(UB) void cg_update_xr(const double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ r,
+                                                    const double2* __restrict__ p, const double2* __restrict__ q, size_t n,
+                                                    double* partial) {
+    __shared__ double red[UB / 64];
+    double acc = 0;
+    if (s[S_DONE] == 0.0) {
+        const double al = s[S_ALPHA];
+        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+            const double2 pv = p[i], qv = q[i];
+            double2 xv = x[i], rv = r[i];
+            xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+            rv.x = fma(-al, qv.x, rv.x); rv.y = fma(-al, qv.y, rv.y);
+            x[i] = xv; r[i] = rv;
+            acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < UB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+// p = r + beta p
+__global__ __launch_bounds__(UB) void cg_update_p(const double* __restrict__ s, double2* __restrict__ p, const double2* __restrict__ r, size_t n) {
+    if (s[S_DONE] != 0.0) return;
+    const double be = s[S_BETA];
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 rv = r[i];
+        double2 pv = p[i];
+        pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
+        p[i] = pv;
+    }
+}
+__global__ __launch_bounds__(UB) void norm2_partial_kernel(const double2* __restrict__ a, size_t n, double* partial) {
+    __shared__ double red[UB / 64];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 v = a[i];
+        acc = fma(v.x, v.x, acc); acc = fma(v.y, v.y, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < UB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+// re(p.q) partials (unfused reference form c1 = p.q)
+__global__ __launch_bounds__(UB) void redot_partial_kernel(const double2* __restrict__ a, const double2* __restrict__ b, size_t n, double* partial) {
+    __shared__ double red[UB / 64];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 x = a[i], y = b[i];
+        acc = fma(x.x, y.x, acc); acc = fma(x.y, y.y, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < UB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+struct CgWork {
+    lqcd_spinor_s *r, *p, *q, *tmp;
+};
+
+// enqueue one CG iteration on the compute stream (no host synchronisation)
+static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
+    lqcd_ctx_s* c = op->ctx;
+    const size_t n = x->elems;
+    const bool fuse = c->tun.cg_fused && !any_partitioned(c);
+    // tmp = D p  (|tmp|^2 block partials fused into the stencil when the lattice is not partitioned)
+    LQCHK(op_apply_async(op, w.tmp, w.p, 0, fuse ? c->d_partial : nullptr));
+    int nb;
+    if (fuse) {
+        nb = stencil_num_blocks(c, 2);
+        LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+        LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+    } else if (c->tun.cg_fused) {
+        nb = stream_grid(c, n);
+        hipLaunchKernelGGL(norm2_partial_kernel, dim3(nb), dim3(UB), 0, c->stream, w.tmp->data, n, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+        LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+    } else {
+        // reference form: c1 = p . q
+        LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+        nb = stream_grid(c, n);
+        hipLaunchKernelGGL(redot_partial_kernel, dim3(nb), dim3(UB), 0, c->stream, w.p->data, w.q->data, n, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+    }
+    hipLaunchKernelGGL(cg_scalar_alpha, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+    nb = stream_grid(c, n);
+    hipLaunchKernelGGL(cg_update_xr, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, x->data, w.r->data, w.p->data, w.q->data, n, c->d_partial);
+    HIPCHK(hipGetLastError());
+    LQCHK(reduce_to_slot(c, nb, 1, S_RRNEW, true));
+    hipLaunchKernelGGL(cg_scalar_beta, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+    hipLaunchKernelGGL(cg_update_p, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, w.p->data, w.r->data, n);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+static int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0) {
+    lqcd_ctx_s* c = op->ctx;
+    const size_t n = x->elems;
+    // r = b - D^+ D x ; p = r
+    LQCHK(op_apply_async(op, w.tmp, x, 0, nullptr));
+    LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+    HIPCHK(hipMemcpyAsync(w.r->data, b->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, w.q->data, w.r->data, n));
+    HIPCHK(hipMemcpyAsync(w.p->data, w.r->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_norm2(c, w.r->data, n, rr0, true));
+    double init[8] = {*rr0, 0, 0, 0, 0, 0, eps, 0};
+    HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+static int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr) {
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    CgWork w;
+    w.r = scratch_get(c, x->kind, LQCD_FULL);
+    w.p = scratch_get(c, x->kind, LQCD_FULL);
+    w.q = scratch_get(c, x->kind, LQCD_FULL);
+    w.tmp = scratch_get(c, x->kind, LQCD_FULL);
+    int st = LQCD_OK;
+    double rr = 0;
+    int it = 0;
+    bool converged = false;
+    if (!(w.r && w.p && w.q && w.tmp)) st = LQCD_ERR_HIP;
+    if (st == LQCD_OK) st = cg_setup(op, x, b, w, fixed ? -1.0 : eps, &rr);
+    if (st == LQCD_OK && !fixed && rr < eps) converged = true;
+    const int check_every = 8;
+    while (st == LQCD_OK && !converged && it < maxiter) {
+        int burst = std::min(check_every, maxiter - it);
+        if (fixed) burst = maxiter - it;
+        for (int k = 0; k < burst && st == LQCD_OK; k++) st = cg_enqueue_iteration(op, x, w);
+        if (st != LQCD_OK) break;
+        hipError_t e = hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { st = hip_fail(e, "cg scalar readback", __FILE__, __LINE__); break; }
+        rr = c->h_scal[S_RR - S_RR];
+        it = (int)c->h_scal[S_ITERS - S_RR];
+        if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
+        if (!std::isfinite(rr)) { set_error("CG: residual is not finite"); st = LQCD_ERR_NOT_CONVERGED; }
+    }
+    scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (st != LQCD_OK) return st;
+    if (!fixed && !converged) {
+        set_error("The CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}
+
+// ---------------------------------------------------------------------------------- BiCGStab (host-side scalars)
+typedef std::complex<double> cplx;
+typedef std::function<int(double2* out, const double2* in)> ApplyFn;
+
+static int dotc(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, cplx* out) {
+    double re, im;
+    LQCHK(blas_dot(c, a, b, n, &re, &im, true));
+    *out = cplx(re, im);
+    return LQCD_OK;
+}
+
+static int bicgstab_core(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* const w[6], double eps,
+                         int maxiter, int* iters, double* final_rr) {
+    double2 *r = w[0], *r0 = w[1], *p = w[2], *v = w[3], *s = w[4], *t = w[5];
+    const size_t bytes = n * sizeof(double2);
+    LQCHK(A(v, x));
+    HIPCHK(hipMemcpyAsync(r, b, bytes, hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, v, r, n));
+    HIPCHK(hipMemcpyAsync(r0, r, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(p, r, bytes, hipMemcpyDeviceToDevice, c->stream));
+    double rr;
+    LQCHK(blas_norm2(c, r, n, &rr, true));
+    cplx rho(rr, 0.0);
+    int it = 0, st = LQCD_ERR_NOT_CONVERGED;
+    if (rr < eps) st = LQCD_OK;
+    for (it = 1; st != LQCD_OK && it <= maxiter; it++) {
+        LQCHK(A(v, p));
+        cplx r0v;
+        LQCHK(dotc(c, r0, v, n, &r0v));
+        const cplx alpha = rho / r0v;
+        // s = r - alpha v
+        HIPCHK(hipMemcpyAsync(s, r, bytes, hipMemcpyDeviceToDevice, c->stream));
+        LQCHK(blas_axpy(c, -alpha.real(), -alpha.imag(), v, s, n));
+        double ss;
+        LQCHK(blas_norm2(c, s, n, &ss, true));
+        if (ss < eps) {
+            LQCHK(blas_axpy(c, alpha.real(), alpha.imag(), p, x, n));
+            rr = ss; st = LQCD_OK; break;
+        }
+        LQCHK(A(t, s));
+        cplx ts;
+        double tt;
+        LQCHK(dotc(c, t, s, n, &ts));
+        LQCHK(blas_norm2(c, t, n, &tt, true));
+        const cplx omega = ts / tt;
+        LQCHK(blas_axpy(c, alpha.real(), alpha.imag(), p, x, n));
+        LQCHK(blas_axpy(c, omega.real(), omega.imag(), s, x, n));
+        // r = s - omega t
+        HIPCHK(hipMemcpyAsync(r, s, bytes, hipMemcpyDeviceToDevice, c->stream));
+        LQCHK(blas_axpy(c, -omega.real(), -omega.imag(), t, r, n));
+        LQCHK(blas_norm2(c, r, n, &rr, true));
+        if (rr < eps) { st = LQCD_OK; break; }
+        if (!std::isfinite(rr)) { set_error("BiCGStab: residual is not finite (breakdown)"); break; }
+        cplx rho1;
+        LQCHK(dotc(c, r0, r, n, &rho1));
+        const cplx beta = (rho1 / rho) * (alpha / omega);
+        // p = r + beta (p - omega v)
+        LQCHK(blas_axpy(c, -omega.real(), -omega.imag(), v, p, n));
+        LQCHK(blas_axpby(c, 1.0, 0.0, r, beta.real(), beta.imag(), p, n));
+        rho = rho1;
+    }
+    if (it > maxiter) it = maxiter;
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (st != LQCD_OK) {
+        set_error("The BiCGStab is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}
+
+}  // namespace lqcd
+
+using namespace lqcd;
+
+// ---------------------------------------------------------------------------------- C API: operator
+extern "C" int lqcd_op_create(lqcd_ctx_t ctx, lqcd_op_t* op, int kind, lqcd_gauge_t g, double km, double r, const int bc[4]) {
+    ARGCHK(ctx && op && g && bc, "lqcd_op_create: null argument");
+    ARGCHK(kind == LQCD_WILSON || kind == LQCD_STAGGERED, "lqcd_op_create: Dirac_operator not supported");
+    ARGCHK(g->ctx == ctx, "lqcd_op_create: gauge field belongs to another context");
+    for (int mu = 0; mu < 4; mu++) ARGCHK(bc[mu] == 1 || bc[mu] == -1, "lqcd_op_create: boundarycondition entries must be +1 or -1");
+    lqcd_op_s* o = new lqcd_op_s;
+    o->ctx = ctx; o->kind = kind; o->gauge = g; o->km = km; o->r = r;
+    for (int mu = 0; mu < 4; mu++) o->bc[mu] = bc[mu];
+    *op = o;
+    return LQCD_OK;
+}
+extern "C" int lqcd_op_destroy(lqcd_op_t op) { delete op; return LQCD_OK; }
+extern "C" int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g) {
+    ARGCHK(op && g && g->ctx == op->ctx, "lqcd_op_set_gauge: bad gauge field");
+    op->gauge = g;
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger) {
+    LQCHK(check_full(op, out, in, "lqcd_op_apply"));
+    LQCHK(op_apply_async(op, out, in, dagger ? 1 : 0, nullptr));
+    HIPCHK(hipStreamSynchronize(op->ctx->stream));
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_op_apply_DdagD(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in) {
+    LQCHK(check_full(op, out, in, "lqcd_op_apply_DdagD"));
+    lqcd_spinor_s* tmp = scratch_get(op->ctx, op->kind, LQCD_FULL);
+    if (!tmp) return LQCD_ERR_HIP;
+    int st = op_apply_async(op, tmp, in, 0, nullptr);
+    if (st == LQCD_OK) st = op_apply_async(op, out, tmp, 1, nullptr);
+    hipError_t e = hipStreamSynchronize(op->ctx->stream);
+    scratch_put(tmp);
+    if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync DdagD", __FILE__, __LINE__);
+    return st;
+}
+
+extern "C" int lqcd_op_hop(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger) {
+    ARGCHK(op && out && in && out->ctx == op->ctx && in->ctx == op->ctx && out->kind == op->kind && in->kind == op->kind,
+           "lqcd_op_hop: bad arguments");
+    ARGCHK((out->subset == LQCD_EVEN && in->subset == LQCD_ODD) || (out->subset == LQCD_ODD && in->subset == LQCD_EVEN),
+           "lqcd_op_hop: out and in must be opposite parity subsets");
+    apply_bc(op->ctx, op->bc);
+    StencilCall s = make_hop_call(op, out, in, nullptr, 0.0, 1.0, dagger ? 1 : 0);
+    LQCHK(stencil_apply(op->ctx, s));
+    HIPCHK(hipStreamSynchronize(op->ctx->stream));
+    return LQCD_OK;
+}
+
+// ---------------------------------------------------------------------------------- C API: solvers
+extern "C" int lqcd_solve_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, int* iters, double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_cg_DdagD"));
+    ARGCHK(maxiter >= 0, "lqcd_solve_cg_DdagD: maxiter < 0");
+    return cg_run(op, x, b, eps, maxiter, false, iters, final_rr);
+}
+extern "C" int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int niter) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_cg_DdagD_fixed"));
+    return cg_run(op, x, b, 0.0, niter, true, nullptr, nullptr);
+}
+
+extern "C" int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
+                                   double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab"));
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    lqcd_spinor_s* w[6];
+    double2* wd[6];
+    for (int i = 0; i < 6; i++) {
+        w[i] = scratch_get(c, op->kind, LQCD_FULL);
+        if (!w[i]) return LQCD_ERR_HIP;
+        wd[i] = w[i]->data;
+    }
+    // the stencil works on spinor handles; wrap raw pointers of the scratch fields
+    lqcd_spinor_s vin = *x, vout = *x;
+    ApplyFn A = [&](double2* out, const double2* in) -> int {
+        vin.data = const_cast<double2*>(in);
+        vout.data = out;
+        return op_apply_async(op, &vout, &vin, dagger ? 1 : 0, nullptr);
+    };
+    int st = bicgstab_core(c, A, x->elems, x->data, b->data, wd, eps, maxiter, iters, final_rr);
+    for (int i = 0; i < 6; i++) scratch_put(w[i]);
+    return st;
+}
+
+// even-odd (Schur) preconditioned BiCGStab, Wilson:
+//   (1 - k^2 H_eo H_oe) x_e = b_e + k H_eo b_o ;  x_o = b_o + k H_oe x_e
+extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
+                                      double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab_eo"));
+    ARGCHK(op->kind == LQCD_WILSON, "lqcd_solve_bicgstab_eo: Wilson only");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    apply_bc(c, op->bc);
+    const double k = op->km;
+    const int dg = dagger ? 1 : 0;
+    const size_t nh = x->elems / 2;
+    lqcd_spinor_s* w[6];
+    double2* wd[6];
+    for (int i = 0; i < 6; i++) { w[i] = scratch_get(c, op->kind, LQCD_EVEN); if (!w[i]) return LQCD_ERR_HIP; wd[i] = w[i]->data; }
+    lqcd_spinor_s* rhs = scratch_get(c, op->kind, LQCD_EVEN);
+    lqcd_spinor_s* to = scratch_get(c, op->kind, LQCD_ODD);
+    if (!rhs || !to) return LQCD_ERR_HIP;
+    // views of the even/odd halves of b and x
+    lqcd_spinor_s be = *b, bo = *b, xe = *x, xo = *x;
+    be.subset = xe.subset = LQCD_EVEN; bo.subset = xo.subset = LQCD_ODD;
+    be.elems = bo.elems = xe.elems = xo.elems = nh;
+    bo.data = b->data + nh; xo.data = x->data + nh;
+    int st = LQCD_OK;
+    // rhs = b_e + k H_eo b_o
+    { StencilCall s = make_hop_call(op, rhs, &bo, &be, 1.0, k, dg); st = stencil_apply(c, s); }
+    lqcd_spinor_s vin = xe, vout = xe;
+    ApplyFn A = [&](double2* out, const double2* in) -> int {
+        vin.data = const_cast<double2*>(in);
+        vout.data = out;
+        StencilCall s1 = make_hop_call(op, to, &vin, nullptr, 0.0, 1.0, dg);         // t_o = H_oe in
+        LQCHK(stencil_apply(c, s1));
+        StencilCall s2 = make_hop_call(op, &vout, to, &vin, 1.0, -k * k, dg);        // out = in - k^2 H_eo t_o
+        return stencil_apply(c, s2);
+    };
+    if (st == LQCD_OK) st = bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
+    // x_o = b_o + k H_oe x_e   (also on non-convergence, so x is a consistent best effort)
+    { StencilCall s = make_hop_call(op, &xo, &xe, &bo, 1.0, k, dg); int s2 = stencil_apply(c, s); if (st == LQCD_OK) st = s2; }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 6; i++) scratch_put(w[i]);
+    scratch_put(rhs); scratch_put(to);
+    if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync bicgstab_eo", __FILE__, __LINE__);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------- C API: timing
+extern "C" int lqcd_bench_dslash(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps, double* ms) {
+    LQCHK(check_full(op, out, in, "lqcd_bench_dslash"));
+    ARGCHK(reps > 0 && ms, "lqcd_bench_dslash: bad reps");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < warm; i++) LQCHK(op_apply_async(op, out, in, dagger ? 1 : 0, nullptr));
+    HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+    for (int i = 0; i < reps; i++) LQCHK(op_apply_async(op, out, in, dagger ? 1 : 0, nullptr));
+    HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_t1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, c->ev_t0, c->ev_t1));
+    *ms = (double)t / reps;
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int warm, int niter, double* ms_per_iter) {
+    LQCHK(check_full(op, x, b, "lqcd_bench_cg"));
+    ARGCHK(niter > 0 && ms_per_iter, "lqcd_bench_cg: bad niter");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    CgWork w;
+    w.r = scratch_get(c, x->kind, LQCD_FULL); w.p = scratch_get(c, x->kind, LQCD_FULL);
+    w.q = scratch_get(c, x->kind, LQCD_FULL); w.tmp = scratch_get(c, x->kind, LQCD_FULL);
+    if (!(w.r && w.p && w.q && w.tmp)) return LQCD_ERR_HIP;
+    double rr;
+    int st = cg_setup(op, x, b, w, -1.0, &rr);
+    for (int i = 0; i < warm && st == LQCD_OK; i++) st = cg_enqueue_iteration(op, x, w);
+    if (st == LQCD_OK) {
+        hipEventRecord(c->ev_t0, c->stream);
+        for (int i = 0; i < niter && st == LQCD_OK; i++) st = cg_enqueue_iteration(op, x, w);
+        hipEventRecord(c->ev_t1, c->stream);
+        hipError_t e = hipEventSynchronize(c->ev_t1);
+        float t = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, c->ev_t0, c->ev_t1);
+        if (e != hipSuccess && st == LQCD_OK) st = hip_fail(e, "bench_cg timing", __FILE__, __LINE__);
+        *ms_per_iter = (double)t / niter;
+    }
+    scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------- in-process multi-domain collectives
+namespace lqcd {
+int plaquette_local_sum(lqcd_gauge_s* g, const double2* const ghost[4], double* sum);
+int gauge_pack_face(lqcd_gauge_s* g, int mu, double2* dst);
+}
+
+static int mdom_check(int n, lqcd_ctx_s* c0) {
+    ARGCHK(n >= 1 && c0 && (int)c0->local_peers.size() == n, "lqcd_mdom_*: contexts are not linked with lqcd_ctx_link_local (or wrong n)");
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_mdom_op_apply(int n, lqcd_op_t* ops, lqcd_spinor_t* outs, lqcd_spinor_t* ins, int dagger) {
+    ARGCHK(ops && outs && ins && n >= 1, "lqcd_mdom_op_apply: null");
+    LQCHK(mdom_check(n, ops[0]->ctx));
+    std::vector<lqcd_ctx_s*> ctxs(n);
+    std::vector<StencilCall> calls(n);
+    for (int r = 0; r < n; r++) {
+        LQCHK(check_full(ops[r], outs[r], ins[r], "lqcd_mdom_op_apply"));
+        ctxs[r] = ops[r]->ctx;
+        ARGCHK(ctxs[r]->rank == r, "lqcd_mdom_op_apply: ops must be ordered by rank");
+        apply_bc(ctxs[r], ops[r]->bc);
+        calls[r] = make_full_call(ops[r], outs[r], ins[r], dagger ? 1 : 0);
+        if (ops[r]->kind == LQCD_WILSON && ops[r]->r != 1.0) { set_error("r != 1 unsupported on a partitioned lattice"); return LQCD_ERR_UNSUPPORTED; }
+    }
+    for (int r = 0; r < n; r++) LQCHK(launch_stencil_pack(ctxs[r], calls[r]));
+    LQCHK(halo_exchange_local_all(ctxs.data(), n, ops[0]->kind, 2));
+    for (int r = 0; r < n; r++) LQCHK(launch_stencil_interior(ctxs[r], calls[r]));
+    for (int r = 0; r < n; r++) LQCHK(launch_stencil_exterior(ctxs[r], calls[r]));
+    for (int r = 0; r < n; r++) HIPCHK(hipStreamSynchronize(ctxs[r]->stream));
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_mdom_dot(int n, lqcd_spinor_t* a, lqcd_spinor_t* b, double* re, double* im) {
+    ARGCHK(a && b && re && im && n >= 1, "lqcd_mdom_dot: null");
+    double sr = 0, si = 0;
+    for (int r = 0; r < n; r++) {
+        double x, y;
+        LQCHK(blas_dot(a[r]->ctx, a[r]->data, b[r]->data, a[r]->elems, &x, &y, false));
+        sr += x; si += y;
+    }
+    *re = sr; *im = si;
+    return LQCD_OK;
+}
+
+extern "C" int lqcd_mdom_plaquette(int n, lqcd_gauge_t* g, double* plaq) {
+    ARGCHK(g && plaq && n >= 1, "lqcd_mdom_plaquette: null");
+    LQCHK(mdom_check(n, g[0]->ctx));
+    // exchange forward gauge faces: ghost[mu] of rank r = x_mu = 0 slice of rank nbr_fwd[mu]
+    std::vector<std::vector<double2*>> ghost(n, std::vector<double2*>(4, nullptr));
+    int st = LQCD_OK;
+    for (int r = 0; r < n && st == LQCD_OK; r++) {
+        lqcd_ctx_s* c = g[r]->ctx;
+        for (int mu = 0; mu < 4 && st == LQCD_OK; mu++) {
+            if (!c->geom.part[mu]) continue;
+            const size_t elems = (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu);
+            if (hipMalloc((void**)&ghost[r][mu], elems * sizeof(double2)) != hipSuccess) { st = LQCD_ERR_HIP; break; }
+            st = gauge_pack_face(g[c->nbr_fwd[mu]], mu, ghost[r][mu]);
+        }
+    }
+    if (st == LQCD_OK && hipDeviceSynchronize() != hipSuccess) st = LQCD_ERR_HIP;
+    double total = 0;
+    for (int r = 0; r < n && st == LQCD_OK; r++) {
+        double s;
+        const double2* gp[4] = {ghost[r][0], ghost[r][1], ghost[r][2], ghost[r][3]};
+        st = plaquette_local_sum(g[r], gp, &s);
+        total += s;
+    }
+    for (int r = 0; r < n; r++) for (int mu = 0; mu < 4; mu++) if (ghost[r][mu]) hipFree(ghost[r][mu]);
+    if (st != LQCD_OK) return st;
+    lqcd_ctx_s* c0 = g[0]->ctx;
+    const double V = (double)c0->gL[0] * c0->gL[1] * c0->gL[2] * c0->gL[3];
+    *plaq = total / (6.0 * V * 3.0);
+    return LQCD_OK;
+}
+
+// plain host-driven CG over the linked domains (tests the halo path inside a solver)
+extern "C" int lqcd_mdom_solve_cg_DdagD(int n, lqcd_op_t* ops, lqcd_spinor_t* x, lqcd_spinor_t* b, double eps, int maxiter, int* iters,
+                                        double* final_rr) {
+    ARGCHK(ops && x && b && n >= 1, "lqcd_mdom_solve_cg_DdagD: null");
+    LQCHK(mdom_check(n, ops[0]->ctx));
+    std::vector<lqcd_spinor_t> r(n), p(n), q(n), tmp(n);
+    for (int k = 0; k < n; k++) {
+        lqcd_ctx_s* c = ops[k]->ctx;
+        r[k] = scratch_get(c, ops[k]->kind, LQCD_FULL); p[k] = scratch_get(c, ops[k]->kind, LQCD_FULL);
+        q[k] = scratch_get(c, ops[k]->kind, LQCD_FULL); tmp[k] = scratch_get(c, ops[k]->kind, LQCD_FULL);
+        if (!(r[k] && p[k] && q[k] && tmp[k])) return LQCD_ERR_HIP;
+    }
+    auto release = [&]() { for (int k = 0; k < n; k++) { scratch_put(r[k]); scratch_put(p[k]); scratch_put(q[k]); scratch_put(tmp[k]); } };
+    auto sync_all = [&]() { for (int k = 0; k < n; k++) hipStreamSynchronize(ops[k]->ctx->stream); };
+    int st = lqcd_mdom_op_apply(n, ops, tmp.data(), x, 0);
+    if (st == LQCD_OK) st = lqcd_mdom_op_apply(n, ops, q.data(), tmp.data(), 1);
+    for (int k = 0; k < n && st == LQCD_OK; k++) {
+        st = lqcd_spinor_copy(r[k], b[k]);
+        if (st == LQCD_OK) st = lqcd_axpy(-1.0, 0.0, q[k], r[k]);
+        if (st == LQCD_OK) st = lqcd_spinor_copy(p[k], r[k]);
+    }
+    double rr = 0, im;
+    if (st == LQCD_OK) st = lqcd_mdom_dot(n, r.data(), r.data(), &rr, &im);
+    int it = 0;
+    bool conv = st == LQCD_OK && rr < eps;
+    while (st == LQCD_OK && !conv && it < maxiter) {
+        it++;
+        st = lqcd_mdom_op_apply(n, ops, tmp.data(), p.data(), 0);
+        if (st == LQCD_OK) st = lqcd_mdom_op_apply(n, ops, q.data(), tmp.data(), 1);
+        double pq = 0;
+        if (st == LQCD_OK) st = lqcd_mdom_dot(n, p.data(), q.data(), &pq, &im);
+        const double alpha = rr / pq;
+        for (int k = 0; k < n && st == LQCD_OK; k++) {
+            st = blas_axpy(ops[k]->ctx, alpha, 0, p[k]->data, x[k]->data, x[k]->elems);
+            if (st == LQCD_OK) st = blas_axpy(ops[k]->ctx, -alpha, 0, q[k]->data, r[k]->data, x[k]->elems);
+        }
+        sync_all();
+        double rrn = 0;
+        if (st == LQCD_OK) st = lqcd_mdom_dot(n, r.data(), r.data(), &rrn, &im);
+        if (rrn < eps) { rr = rrn; conv = true; break; }
+        const double beta = rrn / rr;
+        for (int k = 0; k < n && st == LQCD_OK; k++) st = blas_axpby(ops[k]->ctx, 1.0, 0, r[k]->data, beta, 0, p[k]->data, x[k]->elems);
+        sync_all();
+        rr = rrn;
+    }
+    release();
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (st != LQCD_OK) return st;
+    if (!conv) { set_error("The CG is not converged! (mdom)"); return LQCD_ERR_NOT_CONVERGED; }
+    return LQCD_OK;
+}

@@ -1,0 +1,627 @@
+// stencil.hip -- Wilson and staggered Dslash for gfx950 (CDNA4), fp64.
+//
+// Replaces LinearAlgebra.mul!(y, D::Dirac_operator, x) / mul!(y, D', x) of LatticeDiracOperators.jl
+// (operator built at /root/reference/src/system/universe.jl:106-116,137).
+//
+// Design (HBM-bandwidth-bound, 1.375 flop/B -> no MFMA):
+//   * one lane per output site, lanes walk the checkerboard index, so every load is a 16-B/lane
+//     global_load_dwordx4 over >=256-B contiguous runs (1 KiB per wave instruction in the bulk);
+//   * spin projection (r = 1): only 6 of the 12 neighbour components enter the 3x3 colour mat-vec;
+//     the t direction loads only the 6 components its projector keeps;
+//   * workgroup -> lattice map is XCD-aware: XCD k (= blockIdx % 8) owns a contiguous range of the
+//     checkerboard index (a t-slab) and processes the even and odd sites of a chunk back to back, so
+//     the second use of every link (U_mu(n) forward from n, backward from n+mu) and the 8-fold spinor
+//     reuse are served from that XCD's L2 / the Infinity Cache instead of HBM;
+//   * optional fused |out|^2 block partials (CG: p.(D^+ D p) = |D p|^2) save a full pass over the field.
+// Multi-GPU: hops that leave the rank are skipped by the interior kernel and added by the exterior
+// kernels from spin-projected halos packed by pack kernels (see halo layout in lqcd_internal.h).
+#include "lqcd_internal.h"
+#include <algorithm>
+
+namespace lqcd {
+
+struct KArgs {
+    Geom g;
+    const double2* gauge;
+    double2* out[2];
+    const double2* in[2];
+    const double2* xin[2];
+    double a, b, r;
+    int parity_mode;
+    int nblocks;
+    int remap;
+    double* norm_partial;
+};
+
+struct HArgs {  // halo kernels
+    Geom g;
+    const double2* gauge;
+    double2* out[2];
+    const double2* in[2];
+    double b;
+    int parity_mode;
+    int dagger;
+    double2* send_fwd[4];
+    double2* send_bwd[4];
+    const double2* recv_fwd[4];
+    const double2* recv_bwd[4];
+    double sign_fwd[4];  // bc sign if this rank sits on the global upper boundary, else 1
+    double sign_bwd[4];
+};
+
+__device__ inline int remap_block(int b, int nb, int remap) {
+    if (!remap || (nb & 7)) return b;
+    return (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+// gamma_mu (mu = 0,1,2) has one entry per row: row a -> column PERM[mu][a], value i^GK[mu][a]
+// (SURVEY.md Appendix A).  gamma_4 = diag(1,1,-1,-1).
+constexpr int PERM[3][4] = {{3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}};
+constexpr int GK[3][4] = {{3, 3, 1, 1}, {2, 0, 0, 2}, {3, 1, 1, 3}};
+
+template <bool ADJ>
+__device__ inline void su3_mv(cd (&chi)[3], const cd (&u)[9], const cd (&h)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        cd t = mk(0.0, 0.0);
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            if constexpr (ADJ) cfma_conj(t, u[b * 3 + a], h[b]);
+            else cfma(t, u[a * 3 + b], h[b]);
+        }
+        chi[a] = t;
+    }
+}
+
+__device__ inline void load_link(cd (&u)[9], const double2* __restrict__ U, int Vh) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * Vh);
+}
+
+// spin projection h = rows 0,1 of (1 - S*gamma_mu) psi   (mu = 3: the two non-zero rows, factor 2 included)
+template <int MU, int S>
+__device__ inline void project(cd (&h0)[3], cd (&h1)[3], const double2* __restrict__ psi, int Vh) {
+    if constexpr (MU < 3) {
+        constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
+        constexpr int k0 = GK[MU][0] + (S > 0 ? 2 : 0), k1 = GK[MU][1] + (S > 0 ? 2 : 0);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            h0[c] = ld(psi + (size_t)(0 * 3 + c) * Vh) + mul_ipow<k0>(ld(psi + (size_t)(p0 * 3 + c) * Vh));
+            h1[c] = ld(psi + (size_t)(1 * 3 + c) * Vh) + mul_ipow<k1>(ld(psi + (size_t)(p1 * 3 + c) * Vh));
+        }
+    } else {
+        constexpr int base = S > 0 ? 2 : 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            h0[c] = 2.0 * ld(psi + (size_t)(base * 3 + c) * Vh);
+            h1[c] = 2.0 * ld(psi + (size_t)((base + 1) * 3 + c) * Vh);
+        }
+    }
+}
+
+// acc += (1 - S*gamma_mu) reconstructed from the two rows chi0, chi1
+template <int MU, int S>
+__device__ inline void reconstruct(cd (&acc)[12], const cd (&chi0)[3], const cd (&chi1)[3]) {
+    if constexpr (MU < 3) {
+        constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
+        constexpr int k0 = -GK[MU][0] + (S > 0 ? 2 : 0) + 8, k1 = -GK[MU][1] + (S > 0 ? 2 : 0) + 8;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            acc[c] = acc[c] + chi0[c];
+            acc[3 + c] = acc[3 + c] + chi1[c];
+            acc[p0 * 3 + c] = acc[p0 * 3 + c] + mul_ipow<k0>(chi0[c]);
+            acc[p1 * 3 + c] = acc[p1 * 3 + c] + mul_ipow<k1>(chi1[c]);
+        }
+    } else {
+        constexpr int base = S > 0 ? 2 : 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            acc[base * 3 + c] = acc[base * 3 + c] + chi0[c];
+            acc[(base + 1) * 3 + c] = acc[(base + 1) * 3 + c] + chi1[c];
+        }
+    }
+}
+
+// one hop, r = 1:  acc += (1 - S gamma_mu) [U or U^+] psi(nb) * sign
+template <int MU, int S, bool ADJ>
+__device__ inline void wilson_hop(cd (&acc)[12], const double2* __restrict__ psi, const double2* __restrict__ U,
+                                  int Vh, double sign) {
+    cd h0[3], h1[3], chi0[3], chi1[3], u[9];
+    project<MU, S>(h0, h1, psi, Vh);
+    load_link(u, U, Vh);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
+    su3_mv<ADJ>(chi0, u, h0);
+    su3_mv<ADJ>(chi1, u, h1);
+    reconstruct<MU, S>(acc, chi0, chi1);
+}
+
+// one hop, general r:  acc += (r - S gamma_mu) [U or U^+] psi(nb) * sign
+template <int MU, int S, bool ADJ>
+__device__ inline void wilson_hop_rgen(cd (&acc)[12], const double2* __restrict__ psi, const double2* __restrict__ U,
+                                       int Vh, double sign, double r) {
+    cd u[9], t[4][3];
+    load_link(u, U, Vh);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        cd h[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) h[c] = sign * ld(psi + (size_t)(s * 3 + c) * Vh);
+        su3_mv<ADJ>(t[s], u, h);
+    }
+    if constexpr (MU < 3) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            // -S * g(s) * t[perm(s)]
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                cd v = r * t[s][c];
+                cd w;
+                if (s == 0) w = mul_ipow<GK[MU][0] + (S > 0 ? 2 : 0)>(t[PERM[MU][0]][c]);
+                else if (s == 1) w = mul_ipow<GK[MU][1] + (S > 0 ? 2 : 0)>(t[PERM[MU][1]][c]);
+                else if (s == 2) w = mul_ipow<GK[MU][2] + (S > 0 ? 2 : 0)>(t[PERM[MU][2]][c]);
+                else w = mul_ipow<GK[MU][3] + (S > 0 ? 2 : 0)>(t[PERM[MU][3]][c]);
+                acc[s * 3 + c] = acc[s * 3 + c] + v + w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            double d = (s < 2) ? 1.0 : -1.0;
+            double f = r - (double)S * d;
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[s * 3 + c] = acc[s * 3 + c] + f * t[s][c];
+        }
+    }
+}
+
+// neighbour bookkeeping for one site
+struct Nbr {
+    int fwd[4], bwd[4];
+    double sf[4], sb[4];   // sign (0 => hop is off-rank, skipped by the interior kernel)
+};
+
+__device__ inline void neighbours(const Geom& g, int p, int i, Nbr& n, int c[4]) {
+    cb_to_coords(g, p, i, c);
+    const int q = c[0] & 1;
+    const int s1 = g.XH, s2 = g.XH * g.L[1], s3 = s2 * g.L[2];
+    // x
+    {
+        bool wf = c[0] == g.L[0] - 1, wb = c[0] == 0;
+        n.fwd[0] = q ? (wf ? i - (g.XH - 1) : i + 1) : i;
+        n.bwd[0] = q ? i : (wb ? i + (g.XH - 1) : i - 1);
+        n.sf[0] = wf ? (g.part[0] ? 0.0 : g.bc_fwd[0]) : 1.0;
+        n.sb[0] = wb ? (g.part[0] ? 0.0 : g.bc_bwd[0]) : 1.0;
+    }
+    const int strides[4] = {0, s1, s2, s3};
+#pragma unroll
+    for (int mu = 1; mu < 4; mu++) {
+        bool wf = c[mu] == g.L[mu] - 1, wb = c[mu] == 0;
+        n.fwd[mu] = wf ? i - (g.L[mu] - 1) * strides[mu] : i + strides[mu];
+        n.bwd[mu] = wb ? i + (g.L[mu] - 1) * strides[mu] : i - strides[mu];
+        n.sf[mu] = wf ? (g.part[mu] ? 0.0 : g.bc_fwd[mu]) : 1.0;
+        n.sb[mu] = wb ? (g.part[mu] ? 0.0 : g.bc_bwd[mu]) : 1.0;
+    }
+}
+
+template <int TB>
+__device__ inline void block_norm_partial(double v, double* partial) {
+    __shared__ double red[TB / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < TB / 64; w++) s += red[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Wilson
+template <int TB, bool DAG, bool RGEN>
+__global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
+    const int lb = remap_block(blockIdx.x, k.nblocks, k.remap);
+    int chunk, p;
+    if (k.parity_mode == 2) { chunk = lb >> 1; p = lb & 1; } else { chunk = lb; p = k.parity_mode; }
+    const int Vh = k.g.Vh;
+    const int i = chunk * TB + threadIdx.x;
+    const bool valid = i < Vh;
+    double nrm = 0.0;
+    if (valid) {
+        Nbr n;
+        int c[4];
+        neighbours(k.g, p, i, n, c);
+        cd acc[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+        const double2* __restrict__ psi = k.in[1 - p];
+        const double2* __restrict__ Uf = k.gauge + (size_t)(p * 4) * 9 * Vh + i;         // own links
+        const double2* __restrict__ Ub = k.gauge + (size_t)((1 - p) * 4) * 9 * Vh;       // neighbour's links
+        constexpr int SF = DAG ? -1 : 1;  // forward hop: (r - gamma) for D, (r + gamma) for D^+
+#define HOP(MU)                                                                                                  \
+    if (n.sf[MU] != 0.0) {                                                                                       \
+        if constexpr (RGEN) wilson_hop_rgen<MU, SF, false>(acc, psi + n.fwd[MU], Uf + (size_t)MU * 9 * Vh, Vh, n.sf[MU], k.r); \
+        else wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], Uf + (size_t)MU * 9 * Vh, Vh, n.sf[MU]);            \
+    }                                                                                                            \
+    if (n.sb[MU] != 0.0) {                                                                                       \
+        if constexpr (RGEN) wilson_hop_rgen<MU, -SF, true>(acc, psi + n.bwd[MU], Ub + (size_t)MU * 9 * Vh + n.bwd[MU], Vh, n.sb[MU], k.r); \
+        else wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], Ub + (size_t)MU * 9 * Vh + n.bwd[MU], Vh, n.sb[MU]); \
+    }
+        HOP(0) HOP(1) HOP(2) HOP(3)
+#undef HOP
+        double2* __restrict__ o = k.out[p] + i;
+        if (k.a != 0.0) {
+            const double2* __restrict__ x = k.xin[p] + i;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                cd xv = ld(x + (size_t)j * Vh);
+                cd v = mk(fma(k.b, acc[j].re, k.a * xv.re), fma(k.b, acc[j].im, k.a * xv.im));
+                nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+                st(o + (size_t)j * Vh, v);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                cd v = k.b * acc[j];
+                nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+                st(o + (size_t)j * Vh, v);
+            }
+        }
+    }
+    if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
+}
+
+// ------------------------------------------------------------------------------------------ staggered
+__device__ inline void stag_hop(cd (&acc)[3], const double2* __restrict__ psi, const double2* __restrict__ U, int Vh,
+                                double coef, bool adj) {
+    cd h[3], u[9], chi[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) h[c] = coef * ld(psi + (size_t)c * Vh);
+    load_link(u, U, Vh);
+    if (adj) su3_mv<true>(chi, u, h); else su3_mv<false>(chi, u, h);
+#pragma unroll
+    for (int c = 0; c < 3; c++) acc[c] = acc[c] + chi[c];
+}
+
+// eta_mu(n) = (-1)^(x_0+...+x_{mu-1}), global coordinates (local == global parity since extents/origins are even)
+__device__ inline double stag_eta(const int c[4], int mu) {
+    int e = 0;
+    for (int j = 0; j < mu; j++) e += c[j];
+    return (e & 1) ? -1.0 : 1.0;
+}
+
+template <int TB>
+__global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
+    const int lb = remap_block(blockIdx.x, k.nblocks, k.remap);
+    int chunk, p;
+    if (k.parity_mode == 2) { chunk = lb >> 1; p = lb & 1; } else { chunk = lb; p = k.parity_mode; }
+    const int Vh = k.g.Vh;
+    const int i = chunk * TB + threadIdx.x;
+    const bool valid = i < Vh;
+    double nrm = 0.0;
+    if (valid) {
+        Nbr n;
+        int c[4];
+        neighbours(k.g, p, i, n, c);
+        cd acc[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+        const double2* __restrict__ psi = k.in[1 - p];
+        const double2* __restrict__ Uf = k.gauge + (size_t)(p * 4) * 9 * Vh + i;
+        const double2* __restrict__ Ub = k.gauge + (size_t)((1 - p) * 4) * 9 * Vh;
+#pragma unroll
+        for (int mu = 0; mu < 4; mu++) {
+            const double eta = stag_eta(c, mu);
+            if (n.sf[mu] != 0.0) stag_hop(acc, psi + n.fwd[mu], Uf + (size_t)mu * 9 * Vh, Vh, eta * n.sf[mu], false);
+            if (n.sb[mu] != 0.0) stag_hop(acc, psi + n.bwd[mu], Ub + (size_t)mu * 9 * Vh + n.bwd[mu], Vh, -eta * n.sb[mu], true);
+        }
+        double2* __restrict__ o = k.out[p] + i;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cd v = k.b * acc[j];
+            if (k.a != 0.0) {
+                cd xv = ld(k.xin[p] + i + (size_t)j * Vh);
+                v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
+            }
+            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+            st(o + (size_t)j * Vh, v);
+        }
+    }
+    if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
+}
+
+// ------------------------------------------------------------------------------------------ halo: pack
+// blockIdx.y = 2*mu + side.  side 0: lower face (x_mu = 0) -> send_bwd[mu] = P psi   (receiver's forward hop)
+//                            side 1: upper face (x_mu = L-1) -> send_fwd[mu] = U^+ P psi (receiver's backward hop)
+// Buffers are [slot][ncomp_half][Fh] with slot = output parity of the RECEIVING site (0 when a single parity is computed).
+template <int MU>
+__device__ inline void wilson_pack_dir(const HArgs& k, int side, int slot, int pout, int f) {
+    const Geom& g = k.g;
+    const int Fh = face_half_sites(g, MU), Vh = g.Vh;
+    const int ps = 1 - pout;  // parity of the site being packed
+    int c[4];
+    face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
+    const int i = coords_to_cb(g, c);
+    const double2* __restrict__ psi = k.in[ps] + i;
+    cd h0[3], h1[3];
+    double2* dst;
+    if (side == 0) {
+        // receiver forward hop uses (1 - SF gamma), SF = dagger ? -1 : +1
+        if (k.dagger) project<MU, -1>(h0, h1, psi, Vh); else project<MU, 1>(h0, h1, psi, Vh);
+        dst = k.send_bwd[MU];
+    } else {
+        // receiver backward hop uses (1 + SF gamma) and U^+ of the sender's link
+        if (k.dagger) project<MU, 1>(h0, h1, psi, Vh); else project<MU, -1>(h0, h1, psi, Vh);
+        cd u[9], x0[3], x1[3];
+        load_link(u, k.gauge + ((size_t)(ps * 4 + MU) * 9) * Vh + i, Vh);
+        su3_mv<true>(x0, u, h0);
+        su3_mv<true>(x1, u, h1);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { h0[cc] = x0[cc]; h1[cc] = x1[cc]; }
+        dst = k.send_fwd[MU];
+    }
+    dst += (size_t)slot * 6 * Fh + f;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+        st(dst + (size_t)cc * Fh, h0[cc]);
+        st(dst + (size_t)(3 + cc) * Fh, h1[cc]);
+    }
+}
+
+__global__ __launch_bounds__(128) void wilson_pack(HArgs k) {
+    const int mu = blockIdx.y >> 1, side = blockIdx.y & 1;
+    if (!k.g.part[mu]) return;
+    const int Fh = face_half_sites(k.g, mu);
+    const int nslots = k.parity_mode == 2 ? 2 : 1;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots * Fh) return;
+    const int slot = t / Fh, f = t % Fh;
+    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
+    switch (mu) {
+    case 0: wilson_pack_dir<0>(k, side, slot, pout, f); break;
+    case 1: wilson_pack_dir<1>(k, side, slot, pout, f); break;
+    case 2: wilson_pack_dir<2>(k, side, slot, pout, f); break;
+    default: wilson_pack_dir<3>(k, side, slot, pout, f); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ halo: exterior
+// out(n) += b * (hop contributions that crossed the rank boundary in direction MU)
+template <int MU>
+__device__ inline void wilson_ext_dir(const HArgs& k, int side, int slot, int pout, int f) {
+    const Geom& g = k.g;
+    const int Fh = face_half_sites(g, MU), Vh = g.Vh;
+    int c[4];
+    face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, pout, f, c);
+    const int i = coords_to_cb(g, c);
+    cd acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+    cd h0[3], h1[3];
+    if (side == 1) {
+        // forward hop at the upper face: ghost = P psi(n+mu) from the +mu neighbour; multiply by own U_mu(n)
+        const double2* __restrict__ src = k.recv_fwd[MU] + (size_t)slot * 6 * Fh + f;
+        const double sg = k.sign_fwd[MU];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            h0[cc] = sg * ld(src + (size_t)cc * Fh);
+            h1[cc] = sg * ld(src + (size_t)(3 + cc) * Fh);
+        }
+        cd u[9], x0[3], x1[3];
+        load_link(u, k.gauge + ((size_t)(pout * 4 + MU) * 9) * Vh + i, Vh);
+        su3_mv<false>(x0, u, h0);
+        su3_mv<false>(x1, u, h1);
+        if (k.dagger) reconstruct<MU, -1>(acc, x0, x1); else reconstruct<MU, 1>(acc, x0, x1);
+    } else {
+        // backward hop at the lower face: ghost = U^+ P psi(n-mu) from the -mu neighbour
+        const double2* __restrict__ src = k.recv_bwd[MU] + (size_t)slot * 6 * Fh + f;
+        const double sg = k.sign_bwd[MU];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            h0[cc] = sg * ld(src + (size_t)cc * Fh);
+            h1[cc] = sg * ld(src + (size_t)(3 + cc) * Fh);
+        }
+        if (k.dagger) reconstruct<MU, 1>(acc, h0, h1); else reconstruct<MU, -1>(acc, h0, h1);
+    }
+    double2* __restrict__ o = k.out[pout] + i;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        // only rows touched by the reconstruction are non-zero; the compiler drops the rest for mu = 3
+        cd v = ld(o + (size_t)j * Vh);
+        v.re = fma(k.b, acc[j].re, v.re);
+        v.im = fma(k.b, acc[j].im, v.im);
+        st(o + (size_t)j * Vh, v);
+    }
+}
+
+// one launch per direction (faces of different directions share edge sites -> serialised on the stream);
+// blockIdx.y = side, the two faces of one direction are disjoint when L[mu] >= 2.
+template <int MU>
+__global__ __launch_bounds__(128) void wilson_exterior(HArgs k) {
+    const int side = blockIdx.y;
+    const int Fh = face_half_sites(k.g, MU);
+    const int nslots = k.parity_mode == 2 ? 2 : 1;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots * Fh) return;
+    const int slot = t / Fh, f = t % Fh;
+    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
+    wilson_ext_dir<MU>(k, side, slot, pout, f);
+}
+
+// staggered halos: 3 components; eta and the +/- sign are applied by the receiver
+__global__ __launch_bounds__(128) void staggered_pack(HArgs k) {
+    const int mu = blockIdx.y >> 1, side = blockIdx.y & 1;
+    if (!k.g.part[mu]) return;
+    const Geom& g = k.g;
+    const int Fh = face_half_sites(g, mu), Vh = g.Vh;
+    const int nslots = k.parity_mode == 2 ? 2 : 1;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots * Fh) return;
+    const int slot = t / Fh, f = t % Fh;
+    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
+    const int ps = 1 - pout;
+    int c[4];
+    face_to_coords(g, mu, side ? g.L[mu] - 1 : 0, ps, f, c);
+    const int i = coords_to_cb(g, c);
+    cd h[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) h[cc] = ld(k.in[ps] + i + (size_t)cc * Vh);
+    double2* dst;
+    if (side == 0) {
+        dst = k.send_bwd[mu];
+    } else {
+        cd u[9], x[3];
+        load_link(u, k.gauge + ((size_t)(ps * 4 + mu) * 9) * Vh + i, Vh);
+        su3_mv<true>(x, u, h);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) h[cc] = x[cc];
+        dst = k.send_fwd[mu];
+    }
+    dst += (size_t)slot * 3 * Fh + f;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) st(dst + (size_t)cc * Fh, h[cc]);
+}
+
+__global__ __launch_bounds__(128) void staggered_exterior(HArgs k, int mu) {
+    const int side = blockIdx.y;
+    const Geom& g = k.g;
+    const int Fh = face_half_sites(g, mu), Vh = g.Vh;
+    const int nslots = k.parity_mode == 2 ? 2 : 1;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots * Fh) return;
+    const int slot = t / Fh, f = t % Fh;
+    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
+    int c[4];
+    face_to_coords(g, mu, side ? g.L[mu] - 1 : 0, pout, f, c);
+    const int i = coords_to_cb(g, c);
+    const double eta = stag_eta(c, mu);
+    cd h[3], x[3];
+    if (side == 1) {
+        const double2* src = k.recv_fwd[mu] + (size_t)slot * 3 * Fh + f;
+        const double cf = eta * k.sign_fwd[mu];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) h[cc] = cf * ld(src + (size_t)cc * Fh);
+        cd u[9];
+        load_link(u, k.gauge + ((size_t)(pout * 4 + mu) * 9) * Vh + i, Vh);
+        su3_mv<false>(x, u, h);
+    } else {
+        const double2* src = k.recv_bwd[mu] + (size_t)slot * 3 * Fh + f;
+        const double cf = -eta * k.sign_bwd[mu];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) x[cc] = cf * ld(src + (size_t)cc * Fh);
+    }
+    double2* o = k.out[pout] + i;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        cd v = ld(o + (size_t)j * Vh);
+        v.re = fma(k.b, x[j].re, v.re);
+        v.im = fma(k.b, x[j].im, v.im);
+        st(o + (size_t)j * Vh, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host launchers
+static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
+    KArgs k;
+    k.g = c->geom;
+    k.gauge = s.gauge;
+    for (int p = 0; p < 2; p++) { k.out[p] = s.out[p]; k.in[p] = s.in[p]; k.xin[p] = s.xin[p]; }
+    k.a = s.a; k.b = s.b; k.r = s.r;
+    k.parity_mode = s.parity_mode;
+    const int chunks = (c->geom.Vh + TB - 1) / TB;
+    k.nblocks = chunks * (s.parity_mode == 2 ? 2 : 1);
+    k.remap = c->tun.xcd_remap;
+    k.norm_partial = s.norm_partial;
+    return k;
+}
+
+int stencil_num_blocks(lqcd_ctx_s* c, int parity_mode) {
+    const int TB = c->tun.dslash_block;
+    return ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
+}
+
+template <int TB>
+static int launch_interior_tb(lqcd_ctx_s* c, const StencilCall& s) {
+    KArgs k = make_kargs(c, s, TB);
+    dim3 grid(k.nblocks), block(TB);
+    if (s.kind == LQCD_WILSON) {
+        const bool rgen = (s.r != 1.0);
+        if (!rgen) {
+            if (s.dagger) hipLaunchKernelGGL((wilson_interior<TB, true, false>), grid, block, 0, c->stream, k);
+            else hipLaunchKernelGGL((wilson_interior<TB, false, false>), grid, block, 0, c->stream, k);
+        } else {
+            if (s.dagger) hipLaunchKernelGGL((wilson_interior<TB, true, true>), grid, block, 0, c->stream, k);
+            else hipLaunchKernelGGL((wilson_interior<TB, false, true>), grid, block, 0, c->stream, k);
+        }
+    } else {
+        hipLaunchKernelGGL((staggered_interior<TB>), grid, block, 0, c->stream, k);
+    }
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
+    switch (c->tun.dslash_block) {
+    case 64: return launch_interior_tb<64>(c, s);
+    case 256: return launch_interior_tb<256>(c, s);
+    default: return launch_interior_tb<128>(c, s);
+    }
+}
+
+static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
+    HArgs h;
+    h.g = c->geom;
+    h.gauge = s.gauge;
+    for (int p = 0; p < 2; p++) { h.out[p] = s.out[p]; h.in[p] = s.in[p]; }
+    h.b = s.b;
+    h.parity_mode = s.parity_mode;
+    h.dagger = s.dagger;
+    for (int mu = 0; mu < 4; mu++) {
+        h.send_fwd[mu] = c->send_fwd[mu]; h.send_bwd[mu] = c->send_bwd[mu];
+        h.recv_fwd[mu] = c->recv_fwd[mu]; h.recv_bwd[mu] = c->recv_bwd[mu];
+        h.sign_fwd[mu] = (c->coord[mu] == c->pe[mu] - 1) ? c->geom.bc_fwd[mu] : 1.0;
+        h.sign_bwd[mu] = (c->coord[mu] == 0) ? c->geom.bc_bwd[mu] : 1.0;
+    }
+    return h;
+}
+
+static int max_face_threads(lqcd_ctx_s* c, int parity_mode) {
+    int m = 0;
+    for (int mu = 0; mu < 4; mu++)
+        if (c->geom.part[mu]) m = std::max(m, face_half_sites(c->geom, mu));
+    return m * (parity_mode == 2 ? 2 : 1);
+}
+
+int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s) {
+    const int nt = max_face_threads(c, s.parity_mode);
+    if (nt == 0) return LQCD_OK;
+    HArgs h = make_hargs(c, s);
+    dim3 grid((nt + 127) / 128, 8), block(128);
+    if (s.kind == LQCD_WILSON) hipLaunchKernelGGL(wilson_pack, grid, block, 0, c->stream, h);
+    else hipLaunchKernelGGL(staggered_pack, grid, block, 0, c->stream, h);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
+    HArgs h = make_hargs(c, s);
+    for (int mu = 0; mu < 4; mu++) {
+        if (!c->geom.part[mu]) continue;
+        const int nt = face_half_sites(c->geom, mu) * (s.parity_mode == 2 ? 2 : 1);
+        dim3 grid((nt + 127) / 128, 2), block(128);
+        if (s.kind == LQCD_WILSON) {
+            switch (mu) {
+            case 0: hipLaunchKernelGGL(wilson_exterior<0>, grid, block, 0, c->stream, h); break;
+            case 1: hipLaunchKernelGGL(wilson_exterior<1>, grid, block, 0, c->stream, h); break;
+            case 2: hipLaunchKernelGGL(wilson_exterior<2>, grid, block, 0, c->stream, h); break;
+            default: hipLaunchKernelGGL(wilson_exterior<3>, grid, block, 0, c->stream, h); break;
+            }
+        } else {
+            hipLaunchKernelGGL(staggered_exterior, grid, block, 0, c->stream, h, mu);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return LQCD_OK;
+}
+
+}  // namespace lqcd

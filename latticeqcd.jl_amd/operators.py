@@ -1,0 +1,347 @@
+"""Host-side mirror of the LatticeDiracOperators.jl / Gaugefields.jl interface the reference calls on its hot path.
+
+Julia is not available in the build environment, so this Python layer stands where the thin Julia methods of
+INTEGRATION.md stand: same names (a trailing `_` replaces Julia's `!`), same argument order and meaning, same error
+behaviour (non-convergence and unsupported operators raise), everything forwarded to the C ABI of liblqcd_hip.so.
+
+Reference call sites mirrored (paths relative to /root/reference):
+  Initialize_Gaugefields(NC, Nwing, L...; condition)            src/system/universe.jl:41-49
+  Initialize_pseudofermion_fields(U[1], "Wilson"|"staggered")   src/system/universe.jl:107,112
+  Dirac_operator(U, x, params) / D(U) / D'                      src/system/universe.jl:103-137, unusedfiles/measure_chiral_condensate.jl:173
+  DdagD_operator, mul!, solve_DinvX!                            SURVEY.md 8(a) a2-a5 (LatticeDiracOperators.jl)
+  dot, clear_fermion!, add_fermion!, substitute_fermion!        src/updates/standardHMC.jl:54, src/md/standardMD.jl:50-51
+  gauss_distribution_fermion!, Z4_distribution_fermi!           unusedfiles/measure_chiral_condensate.jl:180
+  calculate_Plaquette                                           src/system/lqcd.jl:187-193
+
+Host arrays are numpy complex128, C order, with the memory image of the Julia arrays:
+  gauge U[mu,t,z,y,x,b,a], Wilson psi[s,t,z,y,x,c], staggered psi[t,z,y,x,c]   (local sub-lattice of this rank).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+from .lib import EVEN, FULL, ODD, STAGGERED, WILSON, LQCDError, NotConverged, check  # noqa: F401
+
+_KIND = {"wilson": WILSON, "staggered": STAGGERED}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Lattice:
+    """One rank's context: global lattice L=(NX,NY,NZ,NT), PE grid (the reference's PEs), rank, device."""
+
+    def __init__(self, L, pe_grid=(1, 1, 1, 1), rank=0, device=0):
+        self.L = tuple(int(v) for v in L)
+        self.pe = tuple(int(v) for v in pe_grid)
+        self.rank = int(rank)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        check(_l.lib().lqcd_ctx_create(C.byref(self._h), self.device, _l.i4(self.L), _l.i4(self.pe), self.rank))
+        lo, org, nf, nb = _l.i4([0] * 4), _l.i4([0] * 4), _l.i4([0] * 4), _l.i4([0] * 4)
+        check(_l.lib().lqcd_decompose(_l.i4(self.L), _l.i4(self.pe), self.rank, lo, org, nf, nb))
+        self.local_L = tuple(lo)
+        self.origin = tuple(org)
+        self.nranks = int(np.prod(self.pe))
+
+    # -- shapes of the local host arrays
+    @property
+    def gauge_shape(self):
+        l = self.local_L
+        return (4, l[3], l[2], l[1], l[0], 3, 3)
+
+    def fermion_shape(self, kind):
+        l = self.local_L
+        return (4, l[3], l[2], l[1], l[0], 3) if kind == WILSON else (l[3], l[2], l[1], l[0], 3)
+
+    def local_slices(self):
+        """numpy slices (t,z,y,x) selecting this rank's sub-lattice out of a global array."""
+        o, l = self.origin, self.local_L
+        return (slice(o[3], o[3] + l[3]), slice(o[2], o[2] + l[2]), slice(o[1], o[1] + l[1]), slice(o[0], o[0] + l[0]))
+
+    def set_param(self, key, value):
+        check(_l.lib().lqcd_ctx_set_param(self._h, key.encode(), int(value)))
+
+    def get_param(self, key):
+        v = C.c_int(0)
+        check(_l.lib().lqcd_ctx_get_param(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def sync(self):
+        check(_l.lib().lqcd_ctx_sync(self._h))
+
+    def comm_init(self, unique_id):
+        buf = (C.c_ubyte * 128)(*bytes(unique_id))
+        check(_l.lib().lqcd_ctx_comm_init(self._h, buf, self.nranks))
+
+    def close(self):
+        if self._h:
+            _l.lib().lqcd_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def comm_unique_id():
+    buf = (C.c_ubyte * 128)()
+    check(_l.lib().lqcd_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def link_local(lattices):
+    arr = (C.c_void_p * len(lattices))(*[lat._h for lat in lattices])
+    check(_l.lib().lqcd_ctx_link_local(arr, len(lattices)))
+
+
+# ------------------------------------------------------------------------------------ gauge fields
+class Gaugefields:
+    """The four link fields U[1:4] of the reference as one device object."""
+
+    def __init__(self, lattice):
+        self.lattice = lattice
+        self.NC = 3
+        self._h = C.c_void_p()
+        check(_l.lib().lqcd_gauge_create(lattice._h, C.byref(self._h)))
+
+    def upload(self, U, layout=_l.LAYOUT_REFERENCE):
+        U = np.ascontiguousarray(U, dtype=np.complex128)
+        assert U.size == int(np.prod(self.lattice.gauge_shape)), (U.shape, self.lattice.gauge_shape)
+        check(_l.lib().lqcd_gauge_upload(self._h, _ptr(U), int(layout)))
+        return self
+
+    def download(self, layout=_l.LAYOUT_REFERENCE):
+        U = np.empty(self.lattice.gauge_shape, dtype=np.complex128)
+        check(_l.lib().lqcd_gauge_download(self._h, _ptr(U), int(layout)))
+        return U
+
+    def close(self):
+        if self._h:
+            _l.lib().lqcd_gauge_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def Initialize_Gaugefields(NC, Nwing, NX, NY, NZ, NT, condition="cold", lattice=None, randomseed=111, **kw):
+    """Gaugefields.jl Initialize_Gaugefields(NC,Nwing,NX,NY,NZ,NT; condition) (universe.jl:41-49). NC = 3 only;
+    Nwing is accepted and ignored (device fields carry no wing)."""
+    if NC != 3:
+        raise LQCDError(_l.ERR_UNSUPPORTED, "only NC = 3 is supported on the HIP path")
+    lat = lattice if lattice is not None else Lattice((NX, NY, NZ, NT), **kw)
+    U = Gaugefields(lat)
+    if condition == "cold":
+        check(_l.lib().lqcd_gauge_unit(U._h))
+    elif condition == "hot":
+        check(_l.lib().lqcd_gauge_hot_start(U._h, C.c_uint64(int(randomseed))))
+    else:
+        raise LQCDError(_l.ERR_ARG, f"condition = {condition} is not supported")
+    return U
+
+
+def calculate_Plaquette(U):
+    """Plaquette normalised by 1/(6 V NC) (lqcd.jl:187-193 with factor 1/(comb*NV*NC))."""
+    p = C.c_double(0)
+    check(_l.lib().lqcd_gauge_plaquette(U._h, C.byref(p)))
+    return p.value
+
+
+# ------------------------------------------------------------------------------------ fermion fields
+class Fermionfields:
+    def __init__(self, lattice, kind, subset=FULL):
+        self.lattice = lattice
+        self.kind = kind
+        self.subset = subset
+        self._h = C.c_void_p()
+        check(_l.lib().lqcd_spinor_create(lattice._h, C.byref(self._h), int(kind), int(subset)))
+
+    def upload(self, psi):
+        psi = np.ascontiguousarray(psi, dtype=np.complex128)
+        assert psi.shape == self.lattice.fermion_shape(self.kind), (psi.shape, self.lattice.fermion_shape(self.kind))
+        check(_l.lib().lqcd_spinor_upload(self._h, _ptr(psi)))
+        return self
+
+    def download(self, into=None):
+        out = np.zeros(self.lattice.fermion_shape(self.kind), dtype=np.complex128) if into is None else into
+        check(_l.lib().lqcd_spinor_download(self._h, _ptr(out)))
+        return out
+
+    def similar(self):
+        return Fermionfields(self.lattice, self.kind, self.subset)
+
+    def close(self):
+        if self._h:
+            _l.lib().lqcd_spinor_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def Initialize_pseudofermion_fields(U, Dirac_operator, nowing=True, subset=FULL):
+    """Initialize_pseudofermion_fields(U[1], "Wilson" | "staggered"; nowing) (universe.jl:107,112)."""
+    key = Dirac_operator.lower()
+    if key not in _KIND:
+        raise LQCDError(_l.ERR_UNSUPPORTED, f"{Dirac_operator} is not supported")
+    return Fermionfields(U.lattice, _KIND[key], subset)
+
+
+def clear_fermion_(x):
+    check(_l.lib().lqcd_spinor_zero(x._h))
+
+
+def substitute_fermion_(dst, src):
+    check(_l.lib().lqcd_spinor_copy(dst._h, src._h))
+
+
+def gauss_distribution_fermion_(x, randomseed=112):
+    check(_l.lib().lqcd_spinor_gaussian(x._h, C.c_uint64(int(randomseed))))
+
+
+def Z4_distribution_fermi_(x, randomseed=113):
+    check(_l.lib().lqcd_spinor_z4(x._h, C.c_uint64(int(randomseed))))
+
+
+def setindex_global_(x, ic, ix, iy, iz, it, ispin):
+    """Point source b[ic,ix,iy,iz,it,is] = 1 at a GLOBAL site, all indices 0-based (measure_Pion_correlator.jl:376)."""
+    check(_l.lib().lqcd_spinor_point_source(x._h, _l.i4((ix, iy, iz, it)), int(ic), int(ispin)))
+
+
+def dot(a, b):
+    """Hermitian inner product sum conj(a) b (standardHMC.jl:54)."""
+    re, im = C.c_double(0), C.c_double(0)
+    check(_l.lib().lqcd_dot(a._h, b._h, C.byref(re), C.byref(im)))
+    return complex(re.value, im.value)
+
+
+def add_fermion_(c, alpha, a, beta=None, b=None):
+    """add_fermion!(c, alpha, a[, beta, b]):  c += alpha*a (+ beta*b)."""
+    al = complex(alpha)
+    check(_l.lib().lqcd_axpy(C.c_double(al.real), C.c_double(al.imag), a._h, c._h))
+    if b is not None:
+        be = complex(beta)
+        check(_l.lib().lqcd_axpy(C.c_double(be.real), C.c_double(be.imag), b._h, c._h))
+
+
+# ------------------------------------------------------------------------------------ Dirac operators
+class Dirac_operator:
+    """Dirac_operator(U, x, params::Dict) (universe.jl:137).  Keys read: "Dirac_operator", "κ"/"kappa", "r", "mass",
+    "eps_CG", "MaxCGstep", "boundarycondition", "method_CG".  `D(U)` rebinds the links, `D.adjoint()` is D'."""
+
+    def __init__(self, U, x, params, _dagger=False, _share=None):
+        self.params = dict(params)
+        name = self.params.get("Dirac_operator", "Wilson")
+        key = name.lower()
+        if key not in _KIND:
+            raise LQCDError(_l.ERR_UNSUPPORTED, f"{name} is not supported")  # universe.jl:129-131
+        self.kind = _KIND[key]
+        self.U = U
+        self.lattice = U.lattice
+        self.dagger = _dagger
+        self.eps_CG = float(self.params.get("eps_CG", 1e-19))          # parameter_structs.jl:174
+        self.MaxCGstep = int(self.params.get("MaxCGstep", 3000))        # parameter_structs.jl:175
+        self.method_CG = self.params.get("method_CG", "bicgstab")
+        self.bc = tuple(self.params.get("boundarycondition", (1, 1, 1, -1)))  # parameter_structs.jl:133
+        if self.kind == WILSON:
+            self.km = float(self.params.get("κ", self.params.get("kappa", 0.141139)))  # parameter_structs.jl:126
+            self.r = float(self.params.get("r", 1.0))
+        else:
+            self.km = float(self.params.get("mass", 0.5))
+            self.r = 1.0
+        if _share is not None:
+            self._h, self._owner = _share, False
+        else:
+            self._h, self._owner = C.c_void_p(), True
+            check(_l.lib().lqcd_op_create(self.lattice._h, C.byref(self._h), self.kind, U._h, C.c_double(self.km),
+                                          C.c_double(self.r), _l.i4(self.bc)))
+
+    def __call__(self, U):
+        check(_l.lib().lqcd_op_set_gauge(self._h, U._h))
+        self.U = U
+        return self
+
+    def adjoint(self):
+        return Dirac_operator(self.U, None, self.params, _dagger=not self.dagger, _share=self._h)
+
+    H = property(adjoint)
+
+    def close(self):
+        if self._owner and self._h:
+            _l.lib().lqcd_op_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class DdagD_operator:
+    """DdagD_operator(D): A = D'D, solved with CG."""
+
+    def __init__(self, D):
+        self.D = D
+        self.eps_CG, self.MaxCGstep = D.eps_CG, D.MaxCGstep
+
+
+def mul_(y, A, x):
+    """LinearAlgebra.mul!(y, A, x) for A = D, D' or D'D."""
+    if isinstance(A, DdagD_operator):
+        check(_l.lib().lqcd_op_apply_DdagD(A.D._h, y._h, x._h))
+    else:
+        check(_l.lib().lqcd_op_apply(A._h, y._h, x._h, int(A.dagger)))
+    return y
+
+
+def hop_(y, D, x):
+    """Parity hop: y (EVEN|ODD) = H x (opposite parity)."""
+    check(_l.lib().lqcd_op_hop(D._h, y._h, x._h, int(D.dagger)))
+    return y
+
+
+def solve_DinvX_(y, A, x, return_info=False):
+    """solve_DinvX!(y, A, x): y = A^{-1} x.  A::DdagD_operator -> CG; A::Dirac_operator -> BiCGStab
+    ("bicgstab") or its even-odd preconditioned form ("bicgstab_evenodd").  Stopping rule real(r.r) < eps_CG;
+    raises NotConverged after MaxCGstep (the reference raises error(...))."""
+    it, rr = C.c_int(0), C.c_double(0)
+    L = _l.lib()
+    if isinstance(A, DdagD_operator):
+        st = L.lqcd_solve_cg_DdagD(A.D._h, y._h, x._h, C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr))
+    elif A.method_CG in ("bicgstab_evenodd", "preconditiond_bicgstab"):
+        st = L.lqcd_solve_bicgstab_eo(A._h, y._h, x._h, int(A.dagger), C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr))
+    elif A.method_CG in ("bicgstab", "bicg"):
+        st = L.lqcd_solve_bicgstab(A._h, y._h, x._h, int(A.dagger), C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr))
+    else:
+        raise LQCDError(_l.ERR_ARG, f"method_CG = {A.method_CG} is not supported")
+    check(st)
+    return (it.value, rr.value) if return_info else None
+
+
+# ------------------------------------------------------------------------------------ timing helpers (bench.py)
+def bench_dslash(D, out, inp, warm=20, reps=200):
+    ms = C.c_double(0)
+    check(_l.lib().lqcd_bench_dslash(D._h, out._h, inp._h, int(D.dagger), int(warm), int(reps), C.byref(ms)))
+    return ms.value
+
+
+def bench_cg(D, x, b, warm=5, niter=50):
+    ms = C.c_double(0)
+    check(_l.lib().lqcd_bench_cg(D._h, x._h, b._h, int(warm), int(niter), C.byref(ms)))
+    return ms.value
+
+
+# ------------------------------------------------------------------------------------ in-process PE-grid emulation (tests)
+def _harr(objs):
+    return (C.c_void_p * len(objs))(*[o._h for o in objs])
+
+
+def mdom_mul_(ys, Ds, xs):
+    check(_l.lib().lqcd_mdom_op_apply(len(Ds), _harr(Ds), _harr(ys), _harr(xs), int(Ds[0].dagger)))
+
+
+def mdom_dot(As, Bs):
+    re, im = C.c_double(0), C.c_double(0)
+    check(_l.lib().lqcd_mdom_dot(len(As), _harr(As), _harr(Bs), C.byref(re), C.byref(im)))
+    return complex(re.value, im.value)
+
+
+def mdom_plaquette(Us):
+    p = C.c_double(0)
+    check(_l.lib().lqcd_mdom_plaquette(len(Us), _harr(Us), C.byref(p)))
+    return p.value
+
+
+def mdom_solve_cg(Ds, xs, bs, eps=1e-19, maxiter=3000):
+    it, rr = C.c_int(0), C.c_double(0)
+    check(_l.lib().lqcd_mdom_solve_cg_DdagD(len(Ds), _harr(Ds), _harr(xs), _harr(bs), C.c_double(eps), int(maxiter),
+                                            C.byref(it), C.byref(rr)))
+    return it.value, rr.value

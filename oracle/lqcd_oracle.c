@@ -1,0 +1,501 @@
+/*
+ * lqcd_oracle.c -- CPU oracle (plain C99).  TEST INFRASTRUCTURE ONLY; see lqcd_oracle.h.
+ *
+ * PARITY UNPINNED at the Dslash/CG level (the reference's arithmetic is in un-vendored Julia
+ * packages); pinned against the reference's gauge fixtures for formats, index
+ * order and plaquette.  Deliberately written differently from the device kernels: explicit 4x4
+ * gamma matrices (no spin-projection trick), reference host layout, one serial site loop in the
+ * reference's (it,iz,iy,ix) order with colour innermost, D^dagger literally as
+ * gamma5 D gamma5.
+ */
+#include "lqcd_oracle.h"
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef double complex cplx;
+
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
+
+/* gamma matrices, SURVEY.md Appendix A (LTK basis, all Hermitian, gamma5 = g1 g2 g3 g4) */
+static void gamma_mat(int nu, cplx g[4][4]) {
+    memset(g, 0, 16 * sizeof(cplx));
+    switch (nu) {
+    case 0: g[0][3] = -I; g[1][2] = -I; g[2][1] = I;  g[3][0] = I;  break;
+    case 1: g[0][3] = -1; g[1][2] = 1;  g[2][1] = 1;  g[3][0] = -1; break;
+    case 2: g[0][2] = -I; g[1][3] = I;  g[2][0] = I;  g[3][1] = -I; break;
+    case 3: g[0][0] = 1;  g[1][1] = 1;  g[2][2] = -1; g[3][3] = -1; break;
+    default: /* gamma5 */
+        g[0][2] = -1; g[1][3] = -1; g[2][0] = -1; g[3][1] = -1; break;
+    }
+}
+
+static inline long site_of(const int L[4], int x, int y, int z, int t) {
+    return x + (long)L[0] * (y + (long)L[1] * (z + (long)L[2] * t));
+}
+static inline long vol(const int L[4]) { return (long)L[0] * L[1] * L[2] * L[3]; }
+
+/* neighbour site in direction nu (sign = +1/-1); *wrapped set when the global boundary is crossed */
+static inline long neigh(const int L[4], const int c[4], int nu, int sign, int* wrapped) {
+    int d[4] = {c[0], c[1], c[2], c[3]};
+    d[nu] += sign;
+    *wrapped = 0;
+    if (d[nu] >= L[nu]) { d[nu] -= L[nu]; *wrapped = 1; }
+    if (d[nu] < 0)      { d[nu] += L[nu]; *wrapped = 1; }
+    return site_of(L, d[0], d[1], d[2], d[3]);
+}
+
+#define UIDX(V, mu, s, a, b) ((a) + 3 * ((b) + 3 * ((s) + (V) * (long)(mu))))
+#define PIDX(V, s, c, sp) ((c) + 3 * ((s) + (V) * (long)(sp)))
+
+/* ------------------------------------------------------------------ plaquette / unitarity */
+static void load_link(cplx M[3][3], const cplx* U, long V, int mu, long s) {
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) M[a][b] = U[UIDX(V, mu, s, a, b)];
+}
+static void mm(cplx C[3][3], cplx A[3][3], cplx B[3][3]) {
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            cplx t = 0;
+            for (int k = 0; k < 3; k++) t += A[a][k] * B[k][b];
+            C[a][b] = t;
+        }
+}
+static void mmd(cplx C[3][3], cplx A[3][3], cplx B[3][3]) { /* C = A B^dagger */
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            cplx t = 0;
+            for (int k = 0; k < 3; k++) t += A[a][k] * conj(B[b][k]);
+            C[a][b] = t;
+        }
+}
+
+double orc_plaquette(const double* Ud, const int L[4]) {
+    const cplx* U = (const cplx*)Ud;
+    long V = vol(L);
+    double sum = 0;
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t}, w;
+                    long s = site_of(L, x, y, z, t);
+                    for (int mu = 0; mu < 4; mu++)
+                        for (int nu = mu + 1; nu < 4; nu++) {
+                            cplx A[3][3], B[3][3], C[3][3], D[3][3], T1[3][3], T2[3][3], T3[3][3];
+                            load_link(A, U, V, mu, s);
+                            load_link(B, U, V, nu, neigh(L, c, mu, 1, &w));
+                            load_link(C, U, V, mu, neigh(L, c, nu, 1, &w));
+                            load_link(D, U, V, nu, s);
+                            mm(T1, A, B);
+                            mmd(T2, T1, C);
+                            mmd(T3, T2, D);
+                            sum += creal(T3[0][0] + T3[1][1] + T3[2][2]);
+                        }
+                }
+    return sum / (6.0 * (double)V * 3.0);
+}
+
+double orc_unitarity_dev(const double* Ud, const int L[4]) {
+    const cplx* U = (const cplx*)Ud;
+    long V = vol(L);
+    double dev = 0;
+    for (int mu = 0; mu < 4; mu++)
+        for (long s = 0; s < V; s++) {
+            cplx A[3][3], T[3][3];
+            load_link(A, U, V, mu, s);
+            mmd(T, A, A);
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double d = cabs(T[a][b] - (a == b ? 1.0 : 0.0));
+                    if (d > dev) dev = d;
+                }
+        }
+    return dev;
+}
+
+/* ------------------------------------------------------------------ Wilson */
+/* hop(n) = sum_nu [ (r - sg*g_nu) U_nu(n) x(n+nu) + (r + sg*g_nu) U_nu^+(n-nu) x(n-nu) ],  sg = +1 */
+static void wilson_hop_site(cplx acc[4][3], const cplx* U, const cplx* in, const int L[4], long V,
+                            const int c[4], double r, const int bc[4], cplx G[4][4][4]) {
+    long s = site_of(L, c[0], c[1], c[2], c[3]);
+    for (int sp = 0; sp < 4; sp++)
+        for (int a = 0; a < 3; a++) acc[sp][a] = 0;
+    for (int nu = 0; nu < 4; nu++) {
+        int w;
+        cplx tmp[4][3];
+        /* forward */
+        long np = neigh(L, c, nu, 1, &w);
+        double sgn = w ? (double)bc[nu] : 1.0;
+        for (int sp = 0; sp < 4; sp++)
+            for (int a = 0; a < 3; a++) {
+                cplx t = 0;
+                for (int b = 0; b < 3; b++) t += U[UIDX(V, nu, s, a, b)] * in[PIDX(V, np, b, sp)];
+                tmp[sp][a] = sgn * t;
+            }
+        for (int sp = 0; sp < 4; sp++)
+            for (int a = 0; a < 3; a++) {
+                cplx t = r * tmp[sp][a];
+                for (int s2 = 0; s2 < 4; s2++) t -= G[nu][sp][s2] * tmp[s2][a];
+                acc[sp][a] += t;
+            }
+        /* backward */
+        long nm = neigh(L, c, nu, -1, &w);
+        sgn = w ? (double)bc[nu] : 1.0;
+        for (int sp = 0; sp < 4; sp++)
+            for (int a = 0; a < 3; a++) {
+                cplx t = 0;
+                for (int b = 0; b < 3; b++) t += conj(U[UIDX(V, nu, nm, b, a)]) * in[PIDX(V, nm, b, sp)];
+                tmp[sp][a] = sgn * t;
+            }
+        for (int sp = 0; sp < 4; sp++)
+            for (int a = 0; a < 3; a++) {
+                cplx t = r * tmp[sp][a];
+                for (int s2 = 0; s2 < 4; s2++) t += G[nu][sp][s2] * tmp[s2][a];
+                acc[sp][a] += t;
+            }
+    }
+}
+
+static void apply_gamma5(cplx* out, const cplx* in, long V) {
+    /* gamma5 = [[0,0,-1,0],[0,0,0,-1],[-1,0,0,0],[0,-1,0,0]] */
+    for (long s = 0; s < V; s++)
+        for (int a = 0; a < 3; a++) {
+            cplx p0 = in[PIDX(V, s, a, 0)], p1 = in[PIDX(V, s, a, 1)], p2 = in[PIDX(V, s, a, 2)],
+                 p3 = in[PIDX(V, s, a, 3)];
+            out[PIDX(V, s, a, 0)] = -p2;
+            out[PIDX(V, s, a, 1)] = -p3;
+            out[PIDX(V, s, a, 2)] = -p0;
+            out[PIDX(V, s, a, 3)] = -p1;
+        }
+}
+
+static void wilson_D_plain(cplx* out, const cplx* U, const cplx* in, const int L[4], double kappa, double r,
+                           const int bc[4]) {
+    long V = vol(L);
+    cplx G[4][4][4];
+    for (int nu = 0; nu < 4; nu++) gamma_mat(nu, G[nu]);
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(static)
+#endif
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t};
+                    long s = site_of(L, x, y, z, t);
+                    cplx acc[4][3];
+                    wilson_hop_site(acc, U, in, L, V, c, r, bc, G);
+                    for (int sp = 0; sp < 4; sp++)
+                        for (int a = 0; a < 3; a++)
+                            out[PIDX(V, s, a, sp)] = in[PIDX(V, s, a, sp)] - kappa * acc[sp][a];
+                }
+}
+
+void orc_wilson_D(double* outd, const double* Ud, const double* ind, const int L[4], double kappa, double r,
+                  const int bc[4], int dagger) {
+    long V = vol(L);
+    cplx* out = (cplx*)outd;
+    const cplx* U = (const cplx*)Ud;
+    const cplx* in = (const cplx*)ind;
+    if (!dagger) {
+        wilson_D_plain(out, U, in, L, kappa, r, bc);
+        return;
+    }
+    /* D^dagger = gamma5 D gamma5 (Appendix A) */
+    cplx* t1 = (cplx*)malloc(sizeof(cplx) * 12 * V);
+    cplx* t2 = (cplx*)malloc(sizeof(cplx) * 12 * V);
+    apply_gamma5(t1, in, V);
+    wilson_D_plain(t2, U, t1, L, kappa, r, bc);
+    apply_gamma5(out, t2, V);
+    free(t1);
+    free(t2);
+}
+
+void orc_wilson_hop_parity(double* outd, const double* Ud, const double* ind, const int L[4], double r,
+                           const int bc[4], int dagger, int out_parity) {
+    long V = vol(L);
+    cplx* out = (cplx*)outd;
+    const cplx* U = (const cplx*)Ud;
+    const cplx* in0 = (const cplx*)ind;
+    cplx G[4][4][4];
+    for (int nu = 0; nu < 4; nu++) gamma_mat(nu, G[nu]);
+    cplx* in = (cplx*)in0;
+    cplx* t1 = NULL;
+    if (dagger) { /* gamma5 H gamma5 */
+        t1 = (cplx*)malloc(sizeof(cplx) * 12 * V);
+        apply_gamma5(t1, in0, V);
+        in = t1;
+    }
+    cplx* res = dagger ? (cplx*)malloc(sizeof(cplx) * 12 * V) : out;
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t};
+                    long s = site_of(L, x, y, z, t);
+                    cplx acc[4][3];
+                    if (((x + y + z + t) & 1) == out_parity)
+                        wilson_hop_site(acc, U, in, L, V, c, r, bc, G);
+                    else
+                        memset(acc, 0, sizeof(acc));
+                    for (int sp = 0; sp < 4; sp++)
+                        for (int a = 0; a < 3; a++) res[PIDX(V, s, a, sp)] = acc[sp][a];
+                }
+    if (dagger) {
+        apply_gamma5(out, res, V);
+        free(res);
+        free(t1);
+    }
+}
+
+/* ------------------------------------------------------------------ staggered */
+void orc_staggered_D(double* outd, const double* Ud, const double* ind, const int L[4], double mass,
+                     const int bc[4], int dagger) {
+    long V = vol(L);
+    cplx* out = (cplx*)outd;
+    const cplx* U = (const cplx*)Ud;
+    const cplx* in = (const cplx*)ind;
+    double hs = dagger ? -0.5 : 0.5; /* D_hop^dagger = -D_hop */
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(static)
+#endif
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t}, w;
+                    long s = site_of(L, x, y, z, t);
+                    cplx acc[3] = {0, 0, 0};
+                    for (int nu = 0; nu < 4; nu++) {
+                        /* eta_1 = 1, eta_nu = (-1)^(x_1+...+x_{nu-1}), 0-based global coordinates */
+                        int e = 0;
+                        for (int k = 0; k < nu; k++) e += c[k];
+                        double eta = (e & 1) ? -1.0 : 1.0;
+                        long np = neigh(L, c, nu, 1, &w);
+                        double sp = w ? (double)bc[nu] : 1.0;
+                        long nm = neigh(L, c, nu, -1, &w);
+                        double sm = w ? (double)bc[nu] : 1.0;
+                        for (int a = 0; a < 3; a++) {
+                            cplx f = 0, b_ = 0;
+                            for (int b = 0; b < 3; b++) {
+                                f += U[UIDX(V, nu, s, a, b)] * in[b + 3 * np];
+                                b_ += conj(U[UIDX(V, nu, nm, b, a)]) * in[b + 3 * nm];
+                            }
+                            acc[a] += eta * (sp * f - sm * b_);
+                        }
+                    }
+                    for (int a = 0; a < 3; a++) out[a + 3 * s] = mass * in[a + 3 * s] + hs * acc[a];
+                }
+}
+
+/* ------------------------------------------------------------------ BLAS-1 */
+void orc_dot(const double* ad, const double* bd, long n, double* re, double* im) {
+    const cplx* a = (const cplx*)ad;
+    const cplx* b = (const cplx*)bd;
+    cplx s = 0;
+    for (long i = 0; i < n; i++) s += conj(a[i]) * b[i];
+    *re = creal(s);
+    *im = cimag(s);
+}
+void orc_axpy(double ar, double ai, const double* xd, double* yd, long n) {
+    const cplx* x = (const cplx*)xd;
+    cplx* y = (cplx*)yd;
+    cplx a = ar + I * ai;
+    for (long i = 0; i < n; i++) y[i] += a * x[i];
+}
+static double norm2(const cplx* a, long n) {
+    double s = 0;
+    for (long i = 0; i < n; i++) s += creal(a[i]) * creal(a[i]) + cimag(a[i]) * cimag(a[i]);
+    return s;
+}
+static cplx cdot(const cplx* a, const cplx* b, long n) {
+    cplx s = 0;
+    for (long i = 0; i < n; i++) s += conj(a[i]) * b[i];
+    return s;
+}
+
+/* ------------------------------------------------------------------ operator dispatch */
+typedef struct {
+    int kind;
+    const cplx* U;
+    const int* L;
+    double km, r;
+    const int* bc;
+    long n; /* complex numbers per vector */
+} op_t;
+
+static void op_D(const op_t* o, cplx* out, const cplx* in, int dagger) {
+    if (o->kind == ORC_WILSON)
+        orc_wilson_D((double*)out, (const double*)o->U, (const double*)in, o->L, o->km, o->r, o->bc, dagger);
+    else
+        orc_staggered_D((double*)out, (const double*)o->U, (const double*)in, o->L, o->km, o->bc, dagger);
+}
+static op_t mk_op(int kind, const double* U, const int L[4], double km, double r, const int bc[4]) {
+    op_t o = {kind, (const cplx*)U, L, km, r, bc, (kind == ORC_WILSON ? 12 : 3) * vol(L)};
+    return o;
+}
+
+/* CG on D^dagger D: the loop of SURVEY.md 3.3
+ *   mul!(q,A,p); c1=p.q; alpha=rho/c1; x+=alpha p; r-=alpha q; rho'=r.r; beta=rho'/rho; p=beta p+r */
+static int cg_core(const op_t* o, cplx* x, const cplx* b, double eps, int maxiter, int fixed, int* iters,
+                   double* final_rr) {
+    long n = o->n;
+    cplx* res = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* p = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* q = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* tmp = (cplx*)malloc(sizeof(cplx) * n);
+    int status = 1, it = 0;
+    op_D(o, tmp, x, 0);
+    op_D(o, q, tmp, 1);
+    for (long i = 0; i < n; i++) res[i] = b[i] - q[i];
+    memcpy(p, res, sizeof(cplx) * n);
+    double rnorm = norm2(res, n);
+    if (!fixed && rnorm < eps) { status = 0; goto done; }
+    for (it = 1; it <= maxiter; it++) {
+        op_D(o, tmp, p, 0);
+        op_D(o, q, tmp, 1);
+        cplx c1 = cdot(p, q, n);
+        cplx alpha = rnorm / c1;
+        for (long i = 0; i < n; i++) x[i] += alpha * p[i];
+        for (long i = 0; i < n; i++) res[i] -= alpha * q[i];
+        double c3 = norm2(res, n);
+        if (!fixed && c3 < eps) { rnorm = c3; status = 0; break; }
+        double beta = c3 / rnorm;
+        for (long i = 0; i < n; i++) p[i] = beta * p[i] + res[i];
+        rnorm = c3;
+    }
+    if (it > maxiter) it = maxiter;
+done:
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rnorm;
+    free(res); free(p); free(q); free(tmp);
+    return status;
+}
+
+int orc_cg_DdagD(int kind, double* x, const double* U, const double* b, const int L[4], double km, double r,
+                 const int bc[4], double eps, int maxiter, int* iters, double* final_rr) {
+    op_t o = mk_op(kind, U, L, km, r, bc);
+    return cg_core(&o, (cplx*)x, (const cplx*)b, eps, maxiter, 0, iters, final_rr);
+}
+void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4], double km,
+                        double r, const int bc[4], int niter) {
+    op_t o = mk_op(kind, U, L, km, r, bc);
+    cg_core(&o, (cplx*)x, (const cplx*)b, 0.0, niter, 1, NULL, NULL);
+}
+
+/* BiCGStab (van der Vorst) for A x = b with a generic apply callback */
+typedef void (*apply_fn)(void* ctx, cplx* out, const cplx* in);
+
+static int bicgstab_core(apply_fn A, void* ctx, long n, cplx* x, const cplx* b, double eps, int maxiter,
+                         int* iters, double* final_rr) {
+    cplx* r = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* r0 = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* p = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* v = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* s = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* t = (cplx*)malloc(sizeof(cplx) * n);
+    int status = 1, it = 0;
+    A(ctx, v, x);
+    for (long i = 0; i < n; i++) r[i] = b[i] - v[i];
+    memcpy(r0, r, sizeof(cplx) * n);
+    memcpy(p, r, sizeof(cplx) * n);
+    double rr = norm2(r, n);
+    cplx rho = cdot(r0, r, n);
+    if (rr < eps) { status = 0; goto done; }
+    for (it = 1; it <= maxiter; it++) {
+        A(ctx, v, p);
+        cplx alpha = rho / cdot(r0, v, n);
+        for (long i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
+        double ss = norm2(s, n);
+        if (ss < eps) {
+            for (long i = 0; i < n; i++) x[i] += alpha * p[i];
+            rr = ss; status = 0; break;
+        }
+        A(ctx, t, s);
+        cplx omega = cdot(t, s, n) / norm2(t, n);
+        for (long i = 0; i < n; i++) x[i] += alpha * p[i] + omega * s[i];
+        for (long i = 0; i < n; i++) r[i] = s[i] - omega * t[i];
+        rr = norm2(r, n);
+        if (rr < eps) { status = 0; break; }
+        cplx rho1 = cdot(r0, r, n);
+        cplx beta = (rho1 / rho) * (alpha / omega);
+        for (long i = 0; i < n; i++) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+        rho = rho1;
+    }
+    if (it > maxiter) it = maxiter;
+done:
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    free(r); free(r0); free(p); free(v); free(s); free(t);
+    return status;
+}
+
+typedef struct { const op_t* o; int dagger; } full_ctx;
+static void apply_full(void* c, cplx* out, const cplx* in) {
+    full_ctx* f = (full_ctx*)c;
+    op_D(f->o, out, in, f->dagger);
+}
+
+int orc_bicgstab(int kind, double* x, const double* U, const double* b, const int L[4], double km, double r,
+                 const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr) {
+    op_t o = mk_op(kind, U, L, km, r, bc);
+    full_ctx f = {&o, dagger};
+    return bicgstab_core(apply_full, &f, o.n, (cplx*)x, (const cplx*)b, eps, maxiter, iters, final_rr);
+}
+
+/* even-odd preconditioning, Wilson:  D = [[1, -k H_eo], [-k H_oe, 1]]
+ *   (1 - k^2 H_eo H_oe) x_e = b_e + k H_eo b_o ;   x_o = b_o + k H_oe x_e
+ * Vectors stay full-lattice sized here; the "even" system lives on even sites with odd sites zero. */
+typedef struct { const double* U; const int* L; double kappa, r; const int* bc; int dagger; long V; cplx *w1, *w2; } eo_ctx;
+static void apply_schur(void* c, cplx* out, const cplx* in) {
+    eo_ctx* e = (eo_ctx*)c;
+    long n = 12 * e->V;
+    orc_wilson_hop_parity((double*)e->w1, e->U, (const double*)in, e->L, e->r, e->bc, e->dagger, 1); /* H_oe in */
+    orc_wilson_hop_parity((double*)e->w2, e->U, (const double*)e->w1, e->L, e->r, e->bc, e->dagger, 0); /* H_eo */
+    double k2 = e->kappa * e->kappa;
+    for (long i = 0; i < n; i++) out[i] = in[i] - k2 * e->w2[i];
+}
+static void mask_parity(cplx* v, const int L[4], int keep_parity) {
+    long V = vol(L);
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++)
+                    if (((x + y + z + t) & 1) != keep_parity) {
+                        long s = site_of(L, x, y, z, t);
+                        for (int sp = 0; sp < 4; sp++)
+                            for (int a = 0; a < 3; a++) v[PIDX(V, s, a, sp)] = 0;
+                    }
+}
+
+int orc_wilson_bicgstab_eo(double* xd, const double* U, const double* bd, const int L[4], double kappa, double r,
+                           const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr) {
+    long V = vol(L), n = 12 * V;
+    cplx* x = (cplx*)xd;
+    const cplx* b = (const cplx*)bd;
+    cplx* be = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* bo = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* xe = (cplx*)calloc(n, sizeof(cplx));
+    cplx* w = (cplx*)malloc(sizeof(cplx) * n);
+    eo_ctx e = {U, L, kappa, r, bc, dagger, V, (cplx*)malloc(sizeof(cplx) * n), (cplx*)malloc(sizeof(cplx) * n)};
+    memcpy(be, b, sizeof(cplx) * n); mask_parity(be, L, 0);
+    memcpy(bo, b, sizeof(cplx) * n); mask_parity(bo, L, 1);
+    /* rhs_e = b_e + k H_eo b_o */
+    orc_wilson_hop_parity((double*)w, U, (const double*)bo, L, r, bc, dagger, 0);
+    for (long i = 0; i < n; i++) be[i] += kappa * w[i];
+    /* initial guess: even part of x */
+    memcpy(xe, x, sizeof(cplx) * n); mask_parity(xe, L, 0);
+    int st = bicgstab_core(apply_schur, &e, n, xe, be, eps, maxiter, iters, final_rr);
+    /* x_o = b_o + k H_oe x_e */
+    orc_wilson_hop_parity((double*)w, U, (const double*)xe, L, r, bc, dagger, 1);
+    for (long i = 0; i < n; i++) x[i] = xe[i] + bo[i] + kappa * w[i];
+    free(be); free(bo); free(xe); free(w); free(e.w1); free(e.w2);
+    return st;
+}

@@ -1,0 +1,77 @@
+/*
+ * lqcd_oracle.h -- CPU oracle for the Dirac-solver hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  Nothing under latticeqcd.jl_amd/ (the product) may import, link or call it.
+ *
+ * PARITY STATUS: the arithmetic of this path lives in the un-vendored Julia packages
+ * LatticeDiracOperators.jl (compat 0.6.1, /root/reference/Project.toml:11,27) and
+ * Gaugefields.jl (compat 0.4-0.7, Project.toml:8,24); neither their source nor a Julia
+ * runtime exists in the build container.  This file restates their published algorithm
+ *  and is pinned against the reference ONLY where the reference
+ * holds data: gauge-configuration formats, site/link index order and plaquettes of the
+ * fixtures under /root/reference/test/confs_* (tests/golden/).  At the Dslash / CG level:
+ * **parity unpinned** -- the reference's own tests pin nothing there (test/runtests.jl:15
+ * checks end-of-run plaquettes at 10 %).  The operator conventions are defended by
+ * convention-independent identities in tests/test_oracle_identities.py.
+ *
+ * Memory layouts are the reference's host layouts (Julia column-major):
+ *   gauge  U[mu][a,b,ix,iy,iz,it]  (src/updates/givenconfigurations.jl:49)
+ *          -> flat index  a + 3*(b + 3*(site + V*mu)),  site = ix + NX*(iy + NY*(iz + NZ*it))
+ *   Wilson psi[ic,ix,iy,iz,it,is]  (src/measurements/unusedfiles/measure_Pion_correlator.jl:244,376)
+ *          -> flat index  ic + 3*(site + V*is)
+ *   staggered psi[ic,ix,iy,iz,it,1] -> ic + 3*site
+ * All arrays are interleaved (re,im) doubles.
+ */
+#ifndef LQCD_ORACLE_H
+#define LQCD_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_WILSON = 0, ORC_STAGGERED = 1 };
+
+/* number of threads used by the site loops (1 = the reference's serial loop) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
+
+/* plaquette, normalisation 1/(6*V*NC): src/measurements/unusedfiles/measure_plaquette.jl:41 */
+double orc_plaquette(const double* U, const int L[4]);
+/* max_{links} ||U U^dagger - 1||_max */
+double orc_unitarity_dev(const double* U, const int L[4]);
+
+/* y = D x or D^dagger x.  Wilson: D = 1 - kappa sum_nu[(r-g_nu)U_nu(n)d(n+nu) + (r+g_nu)U^+_nu(n-nu)d(n-nu)]
+ * (parameters from src/system/universe.jl:111-116,132-135) */
+void orc_wilson_D(double* out, const double* U, const double* in, const int L[4], double kappa,
+                  double r, const int bc[4], int dagger);
+/* y = (m + 1/2 sum_nu eta_nu(n)[U_nu(n)x(n+nu) - U^+_nu(n-nu)x(n-nu)]) x   (universe.jl:106-110) */
+void orc_staggered_D(double* out, const double* U, const double* in, const int L[4], double mass,
+                     const int bc[4], int dagger);
+/* only the hopping part restricted to output sites of one parity (0 even, 1 odd); other sites zeroed.
+ * Wilson: out = sum_nu[(r-g)U x+ + (r+g)U^+ x-]  (no kappa);  dagger flips the gamma signs. */
+void orc_wilson_hop_parity(double* out, const double* U, const double* in, const int L[4], double r,
+                           const int bc[4], int dagger, int out_parity);
+
+/* BLAS-1 on n complex numbers */
+void orc_dot(const double* a, const double* b, long n, double* re, double* im); /* sum conj(a) b */
+void orc_axpy(double ar, double ai, const double* x, double* y, long n);       /* y += a x */
+
+/* Krylov solvers; stopping rule real(r.r) < eps (absolute, squared) -- SURVEY.md 3.3;
+ * defaults eps=1e-19, maxiter=3000 from src/system/parameter_structs.jl:174-175.
+ * x holds the initial guess on entry.  Return 0 = converged, 1 = not converged. */
+int orc_cg_DdagD(int kind, double* x, const double* U, const double* b, const int L[4], double kappa_or_mass,
+                 double r, const int bc[4], double eps, int maxiter, int* iters, double* final_rr);
+int orc_bicgstab(int kind, double* x, const double* U, const double* b, const int L[4], double kappa_or_mass,
+                 double r, const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr);
+/* even-odd (Schur) preconditioned BiCGStab for Wilson D x = b (full-lattice in/out) */
+int orc_wilson_bicgstab_eo(double* x, const double* U, const double* b, const int L[4], double kappa, double r,
+                           const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr);
+
+/* fixed-length CG window with the exit test disabled (timing only): runs exactly niter iterations */
+void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4],
+                        double kappa_or_mass, double r, const int bc[4], int niter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,181 @@
+"""ctypes/numpy front end of the CPU oracle.  TEST INFRASTRUCTURE ONLY (see lqcd_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED at the Dslash/CG level; pinned on the reference's gauge fixtures (formats, index
+order, plaquette) -- see lqcd_oracle.h for the full statement.
+
+Array conventions (numpy, C order, complex128) -- same memory image as the reference's Julia arrays:
+  gauge     U[mu, t, z, y, x, b, a]      == Julia U[mu][a,b,x,y,z,t]
+  Wilson    psi[s, t, z, y, x, c]        == Julia psi[c,x,y,z,t,s]
+  staggered psi[t, z, y, x, c]           == Julia psi[c,x,y,z,t,1]
+L is always given as (NX, NY, NZ, NT).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+WILSON, STAGGERED = 0, 1
+
+
+def build():
+    """Compile liblqcd_oracle.so with gcc (recipe: oracle/Makefile)."""
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liblqcd_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_plaquette.restype = C.c_double
+        _LIB.orc_unitarity_dev.restype = C.c_double
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i4(v):
+    return (C.c_int * 4)(*[int(x) for x in v])
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def gauge_shape(L):
+    return (4, L[3], L[2], L[1], L[0], 3, 3)
+
+
+def wilson_shape(L):
+    return (4, L[3], L[2], L[1], L[0], 3)
+
+
+def staggered_shape(L):
+    return (L[3], L[2], L[1], L[0], 3)
+
+
+def _chk(a, shape):
+    assert a.dtype == np.complex128 and a.flags.c_contiguous and a.shape == tuple(shape), (a.dtype, a.shape, shape)
+
+
+def plaquette(U, L):
+    _chk(U, gauge_shape(L))
+    return lib().orc_plaquette(_p(U), _i4(L))
+
+
+def unitarity_dev(U, L):
+    _chk(U, gauge_shape(L))
+    return lib().orc_unitarity_dev(_p(U), _i4(L))
+
+
+def wilson_D(U, psi, L, kappa, r=1.0, bc=(1, 1, 1, -1), dagger=False):
+    _chk(U, gauge_shape(L)); _chk(psi, wilson_shape(L))
+    out = np.empty_like(psi)
+    lib().orc_wilson_D(_p(out), _p(U), _p(psi), _i4(L), C.c_double(kappa), C.c_double(r), _i4(bc), int(dagger))
+    return out
+
+
+def wilson_hop_parity(U, psi, L, r=1.0, bc=(1, 1, 1, -1), dagger=False, out_parity=0):
+    _chk(U, gauge_shape(L)); _chk(psi, wilson_shape(L))
+    out = np.empty_like(psi)
+    lib().orc_wilson_hop_parity(_p(out), _p(U), _p(psi), _i4(L), C.c_double(r), _i4(bc), int(dagger), int(out_parity))
+    return out
+
+
+def staggered_D(U, psi, L, mass, bc=(1, 1, 1, -1), dagger=False):
+    _chk(U, gauge_shape(L)); _chk(psi, staggered_shape(L))
+    out = np.empty_like(psi)
+    lib().orc_staggered_D(_p(out), _p(U), _p(psi), _i4(L), C.c_double(mass), _i4(bc), int(dagger))
+    return out
+
+
+def apply_D(kind, U, psi, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False):
+    if kind == WILSON:
+        return wilson_D(U, psi, L, km, r, bc, dagger)
+    return staggered_D(U, psi, L, km, bc, dagger)
+
+
+def cg_DdagD(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), eps=1e-19, maxiter=3000, x0=None):
+    """Returns (x, iters, final_rr, status) with status 0 = converged."""
+    x = np.zeros_like(b) if x0 is None else x0.copy()
+    it, rr = C.c_int(0), C.c_double(0)
+    st = lib().orc_cg_DdagD(int(kind), _p(x), _p(U), _p(b), _i4(L), C.c_double(km), C.c_double(r), _i4(bc),
+                            C.c_double(eps), int(maxiter), C.byref(it), C.byref(rr))
+    return x, it.value, rr.value, st
+
+
+def cg_DdagD_fixed(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), niter=1):
+    x = np.zeros_like(b)
+    lib().orc_cg_DdagD_fixed(int(kind), _p(x), _p(U), _p(b), _i4(L), C.c_double(km), C.c_double(r), _i4(bc),
+                             int(niter))
+    return x
+
+
+def bicgstab(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000, x0=None):
+    x = np.zeros_like(b) if x0 is None else x0.copy()
+    it, rr = C.c_int(0), C.c_double(0)
+    st = lib().orc_bicgstab(int(kind), _p(x), _p(U), _p(b), _i4(L), C.c_double(km), C.c_double(r), _i4(bc),
+                            int(dagger), C.c_double(eps), int(maxiter), C.byref(it), C.byref(rr))
+    return x, it.value, rr.value, st
+
+
+def wilson_bicgstab_eo(U, b, L, kappa, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000):
+    x = np.zeros_like(b)
+    it, rr = C.c_int(0), C.c_double(0)
+    st = lib().orc_wilson_bicgstab_eo(_p(x), _p(U), _p(b), _i4(L), C.c_double(kappa), C.c_double(r), _i4(bc),
+                                      int(dagger), C.c_double(eps), int(maxiter), C.byref(it), C.byref(rr))
+    return x, it.value, rr.value, st
+
+
+def dot(a, b):
+    re, im = C.c_double(0), C.c_double(0)
+    lib().orc_dot(_p(a), _p(b), C.c_long(a.size), C.byref(re), C.byref(im))
+    return complex(re.value, im.value)
+
+
+# ---------------------------------------------------------------- pure-numpy helpers for tests
+GAMMA = np.zeros((5, 4, 4), dtype=np.complex128)
+GAMMA[0][0, 3] = -1j; GAMMA[0][1, 2] = -1j; GAMMA[0][2, 1] = 1j; GAMMA[0][3, 0] = 1j
+GAMMA[1][0, 3] = -1; GAMMA[1][1, 2] = 1; GAMMA[1][2, 1] = 1; GAMMA[1][3, 0] = -1
+GAMMA[2][0, 2] = -1j; GAMMA[2][1, 3] = 1j; GAMMA[2][2, 0] = 1j; GAMMA[2][3, 1] = -1j
+GAMMA[3] = np.diag([1, 1, -1, -1])
+GAMMA[4][0, 2] = -1; GAMMA[4][1, 3] = -1; GAMMA[4][2, 0] = -1; GAMMA[4][3, 1] = -1
+
+
+def random_su3(rng, n):
+    """n random SU(3) matrices, row-wise Gram-Schmidt (the reference's hot start)."""
+    m = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
+    r0 = m[:, 0] / np.linalg.norm(m[:, 0], axis=1, keepdims=True)
+    r1 = m[:, 1] - np.sum(np.conj(r0) * m[:, 1], axis=1, keepdims=True) * r0
+    r1 /= np.linalg.norm(r1, axis=1, keepdims=True)
+    r2 = np.conj(np.cross(r0, r1))
+    return np.stack([r0, r1, r2], axis=1)
+
+
+def hot_gauge(L, seed):
+    """Seeded hot-start gauge field in oracle layout U[mu,t,z,y,x,b,a]."""
+    rng = np.random.default_rng(seed)
+    V = L[0] * L[1] * L[2] * L[3]
+    m = random_su3(rng, 4 * V).reshape(4, L[3], L[2], L[1], L[0], 3, 3)  # [.., a, b]
+    return np.ascontiguousarray(np.swapaxes(m, -1, -2))  # -> [.., b, a]
+
+
+def unit_gauge(L):
+    U = np.zeros(gauge_shape(L), dtype=np.complex128)
+    for a in range(3):
+        U[..., a, a] = 1.0
+    return U
+
+
+def gaussian_spinor(shape, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex128)

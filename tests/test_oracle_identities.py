@@ -1,0 +1,194 @@
+"""The oracle is parity-unpinned at the Dslash/CG level (the reference's arithmetic lives in un-vendored Julia
+packages); these convention-independent identities are its known-answer tests.  The same identities
+are run against the HIP path in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+L4 = (4, 4, 4, 4)
+LA = (4, 6, 2, 8)  # anisotropic: catches any x/y/z/t mix-up
+KAPPA, MASS = 0.141139, 0.5
+BC = (1, 1, 1, -1)
+
+
+def test_gamma_algebra(orc):
+    g = orc.GAMMA
+    for mu in range(4):
+        assert np.allclose(g[mu], g[mu].conj().T)
+        for nu in range(4):
+            acomm = g[mu] @ g[nu] + g[nu] @ g[mu]
+            assert np.allclose(acomm, 2 * np.eye(4) * (mu == nu))
+    assert np.allclose(g[4], g[0] @ g[1] @ g[2] @ g[3])
+
+
+@pytest.mark.parametrize("L", [L4, LA])
+@pytest.mark.parametrize("r", [1.0, 0.7])
+def test_wilson_adjoint_and_gamma5_hermiticity(orc, L, r):
+    U = orc.hot_gauge(L, 1)
+    a = orc.gaussian_spinor(orc.wilson_shape(L), 2)
+    b = orc.gaussian_spinor(orc.wilson_shape(L), 3)
+    Db = orc.wilson_D(U, b, L, KAPPA, r, BC, dagger=False)
+    Dda = orc.wilson_D(U, a, L, KAPPA, r, BC, dagger=True)   # oracle: literally gamma5 D gamma5
+    lhs = np.vdot(a, Db)
+    rhs = np.conj(np.vdot(b, Dda))
+    assert abs(lhs - rhs) < 1e-10 * abs(lhs)
+
+
+def plane_wave(L, k, bc):
+    """phase[t,z,y,x] = exp(i p.n), p_mu = 2 pi (k_mu + (bc_mu == -1)/2) / L_mu"""
+    p = [2 * np.pi * (k[mu] + (0.5 if bc[mu] == -1 else 0.0)) / L[mu] for mu in range(4)]
+    x, y, z, t = np.meshgrid(*[np.arange(L[mu]) for mu in range(4)], indexing="ij")
+    ph = np.exp(1j * (p[0] * x + p[1] * y + p[2] * z + p[3] * t))  # [x,y,z,t]
+    return np.ascontiguousarray(ph.transpose(3, 2, 1, 0)), p
+
+
+@pytest.mark.parametrize("k", [(0, 0, 0, 0), (1, 0, 2, 1), (3, 2, 1, 3)])
+def test_wilson_free_field_plane_wave(orc, k):
+    L, r = LA, 1.0
+    U = orc.unit_gauge(L)
+    ph, p = plane_wave(L, k, BC)
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal((4, 3)) + 1j * rng.standard_normal((4, 3))
+    psi = np.ascontiguousarray(u[:, None, None, None, None, :] * ph[None, ..., None])
+    out = orc.wilson_D(U, psi, L, KAPPA, r, BC)
+    M = np.eye(4, dtype=complex)
+    for mu in range(4):
+        M = M - 2 * KAPPA * (r * np.cos(p[mu]) * np.eye(4) - 1j * np.sin(p[mu]) * orc.GAMMA[mu])
+    expect = np.einsum("st,tc->sc", M, u)[:, None, None, None, None, :] * ph[None, ..., None]
+    assert rel_err(out, expect) < 1e-13
+
+
+def gauge_transform(U, g, L):
+    """U^g_mu(n) = g(n) U_mu(n) g(n+mu)^+ ; arrays U[mu,t,z,y,x,b,a] (matrix element [a,b] = U[..., b, a])."""
+    Ug = np.empty_like(U)
+    axis = {0: 3, 1: 2, 2: 1, 3: 0}
+    for mu in range(4):
+        M = np.swapaxes(U[mu], -1, -2)                      # [t,z,y,x,a,b]
+        gs = np.roll(g, -1, axis=axis[mu])                  # g(n+mu), periodic links
+        Mg = np.einsum("...ab,...bc,...dc->...ad", g, M, gs.conj())
+        Ug[mu] = np.swapaxes(Mg, -1, -2)
+    return np.ascontiguousarray(Ug)
+
+
+def test_wilson_gauge_covariance(orc):
+    L = LA
+    U = orc.hot_gauge(L, 7)
+    rng = np.random.default_rng(8)
+    V = L[0] * L[1] * L[2] * L[3]
+    g = orc.random_su3(rng, V).reshape(L[3], L[2], L[1], L[0], 3, 3)    # g[t,z,y,x,a,b]
+    psi = orc.gaussian_spinor(orc.wilson_shape(L), 9)
+    psig = np.ascontiguousarray(np.einsum("...ab,s...b->s...a", g, psi))
+    lhs = orc.wilson_D(gauge_transform(U, g, L), psig, L, KAPPA, 1.0, BC)
+    rhs = np.einsum("...ab,s...b->s...a", g, orc.wilson_D(U, psi, L, KAPPA, 1.0, BC))
+    assert rel_err(lhs, rhs) < 1e-13
+    assert abs(orc.plaquette(gauge_transform(U, g, L), L) - orc.plaquette(U, L)) < 1e-13
+
+
+def test_wilson_hop_parity_decomposition(orc):
+    L = LA
+    U = orc.hot_gauge(L, 11)
+    psi = orc.gaussian_spinor(orc.wilson_shape(L), 12)
+    for dag in (False, True):
+        he = orc.wilson_hop_parity(U, psi, L, 1.0, BC, dag, 0)
+        ho = orc.wilson_hop_parity(U, psi, L, 1.0, BC, dag, 1)
+        full = orc.wilson_D(U, psi, L, KAPPA, 1.0, BC, dag)
+        assert rel_err(psi - KAPPA * (he + ho), full) < 1e-13
+    # even output sites only depend on odd input sites
+    x, y, z, t = np.meshgrid(*[np.arange(L[mu]) for mu in range(4)], indexing="ij")
+    par = ((x + y + z + t) & 1).transpose(3, 2, 1, 0)
+    psi_e = psi * (par == 0)[None, ..., None]
+    assert np.abs(orc.wilson_hop_parity(U, np.ascontiguousarray(psi_e), L, 1.0, BC, False, 0)).max() == 0.0
+
+
+def test_staggered_identities(orc):
+    L = LA
+    U = orc.hot_gauge(L, 21)
+    a = orc.gaussian_spinor(orc.staggered_shape(L), 22)
+    b = orc.gaussian_spinor(orc.staggered_shape(L), 23)
+    Hb = orc.staggered_D(U, b, L, 0.0, BC)
+    Ha = orc.staggered_D(U, a, L, 0.0, BC)
+    # D_hop^+ = -D_hop
+    assert abs(np.vdot(a, Hb) + np.conj(np.vdot(b, Ha))) < 1e-10 * abs(np.vdot(a, Hb))
+    # D^+ as implemented is the true adjoint
+    Db = orc.staggered_D(U, b, L, MASS, BC)
+    Dda = orc.staggered_D(U, a, L, MASS, BC, dagger=True)
+    assert abs(np.vdot(a, Db) - np.conj(np.vdot(b, Dda))) < 1e-10 * abs(np.vdot(a, Db))
+    # free field: D^+ D = m^2 + sum sin^2 p on plane waves
+    U1 = orc.unit_gauge(L)
+    ph, p = plane_wave(L, (1, 2, 0, 3), BC)
+    psi = np.ascontiguousarray(ph[..., None] * np.array([1.0, 2.0 - 1j, 0.5j]))
+    out = orc.staggered_D(U1, orc.staggered_D(U1, psi, L, MASS, BC), L, MASS, BC, dagger=True)
+    lam = MASS ** 2 + sum(np.sin(p[mu]) ** 2 for mu in range(4))
+    assert rel_err(out, lam * psi) < 1e-13
+
+
+def dense_matrix(apply, shape):
+    n = int(np.prod(shape))
+    M = np.empty((n, n), dtype=np.complex128)
+    e = np.zeros(n, dtype=np.complex128)
+    for j in range(n):
+        e[j] = 1.0
+        M[:, j] = apply(e.reshape(shape)).reshape(-1)
+        e[j] = 0.0
+    return M
+
+
+@pytest.fixture(scope="module")
+def wilson_dense(orc):
+    """Dense 384x384 Wilson matrix on a 2x2x2x4 hot lattice (brute-force anchor for the Krylov solvers)."""
+    L = (2, 2, 2, 4)
+    U = orc.hot_gauge(L, 31)
+    M = dense_matrix(lambda v: orc.wilson_D(U, np.ascontiguousarray(v), L, KAPPA, 1.0, BC), orc.wilson_shape(L))
+    return L, U, M
+
+
+def test_wilson_dense_dagger(orc, wilson_dense):
+    L, U, M = wilson_dense
+    Md = dense_matrix(lambda v: orc.wilson_D(U, np.ascontiguousarray(v), L, KAPPA, 1.0, BC, dagger=True), orc.wilson_shape(L))
+    assert np.abs(Md - M.conj().T).max() < 1e-14
+
+
+def test_cg_vs_dense_solve(orc, wilson_dense):
+    L, U, M = wilson_dense
+    b = orc.gaussian_spinor(orc.wilson_shape(L), 32)
+    x, it, rr, st = orc.cg_DdagD(orc.WILSON, U, b, L, KAPPA, 1.0, BC, eps=1e-22, maxiter=3000)
+    assert st == 0 and rr < 1e-22
+    xd = np.linalg.solve(M.conj().T @ M, b.reshape(-1)).reshape(b.shape)
+    assert rel_err(x, xd) < 1e-10
+
+
+@pytest.mark.parametrize("dagger", [False, True])
+def test_bicgstab_and_eo_vs_dense_solve(orc, wilson_dense, dagger):
+    L, U, M = wilson_dense
+    b = orc.gaussian_spinor(orc.wilson_shape(L), 33)
+    A = M.conj().T if dagger else M
+    xd = np.linalg.solve(A, b.reshape(-1)).reshape(b.shape)
+    x, it, rr, st = orc.bicgstab(orc.WILSON, U, b, L, KAPPA, 1.0, BC, dagger, eps=1e-22)
+    assert st == 0 and rel_err(x, xd) < 1e-9
+    xe, ite, rre, ste = orc.wilson_bicgstab_eo(U, b, L, KAPPA, 1.0, BC, dagger, eps=1e-22)
+    assert ste == 0 and rel_err(xe, xd) < 1e-9
+    assert ite <= it  # Schur preconditioning never needs more iterations here
+
+
+def test_cg_on_reference_fixture(orc, lq):
+    """CG on the reference's thermalised 4^4 Wilson configuration with the reference's parameters
+    (test/test_wilson.toml: kappa = 0.141139, eps = 1e-19, BC = [1,1,1,-1])."""
+    import os
+    from conftest import GOLDEN
+    U = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L4)
+    b = orc.gaussian_spinor(orc.wilson_shape(L4), 41)
+    x, it, rr, st = orc.cg_DdagD(orc.WILSON, U, b, L4, KAPPA, 1.0, BC, eps=1e-19, maxiter=3000)
+    assert st == 0 and rr < 1e-19 and 10 < it < 500
+    res = b - orc.wilson_D(U, orc.wilson_D(U, x, L4, KAPPA, 1.0, BC), L4, KAPPA, 1.0, BC, dagger=True)
+    assert np.vdot(res, res).real < 1e-18
+
+
+def test_staggered_cg(orc):
+    L = (4, 4, 4, 4)
+    U = orc.hot_gauge(L, 51)
+    b = orc.gaussian_spinor(orc.staggered_shape(L), 52)
+    x, it, rr, st = orc.cg_DdagD(orc.STAGGERED, U, b, L, MASS, 1.0, BC, eps=1e-10)
+    assert st == 0 and rr < 1e-10
+    res = b - orc.staggered_D(U, orc.staggered_D(U, x, L, MASS, BC), L, MASS, BC, dagger=True)
+    assert np.vdot(res, res).real < 2e-10
