@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json metric on MI355X: CG iterations/s and Dslash GFLOP/s, 32^3x64 SU(3) Wilson fp64.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one CG iteration on D^+D (one D, one D^+ application + the BLAS-1/reduction work) of the
+fixed global lattice; for N > 1 the 4-D lattice is domain-decomposed over a PE grid (strong scaling), halos travel
+over RCCL inside liblqcd_hip.so, and the control plane (rendezvous of the RCCL id, barriers, max-over-ranks) uses
+torch.distributed with the gloo backend so that PyTorch never touches the GPU the library drives.
+Inputs are synthetic and resident in HBM before the timed region: hot-start links (seed 111), Gaussian source (seed 112),
+kappa = 0.141139, r = 1, BC = [1,1,1,-1].
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (Wilson Dslash kernel, algorithmic 960 B/site over HIP-event
+time measured on the library's own stream) and, at N = 1, "cpu_baseline" (the oracle timed on the host, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+WILSON_FLOP_PER_SITE = 1320
+WILSON_BYTES_PER_SITE = 960    # read psi 192 + 4 links 576 + write 192
+KAPPA = 0.141139
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--lattice", type=str, default="32,32,32,64")
+    ap.add_argument("--dslash-reps", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pe-grid", type=str, default="")
+    ap.add_argument("--set", action="append", default=[], help="library tunable key=value")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    gL = tuple(int(v) for v in args.lattice.split(","))
+
+    # load the HIP library first: the ROCm runtime it was built with (/opt/rocm) is the one this process uses
+    import latticeqcd_jl_amd as lq
+    lq.lib.lib()
+
+    dist = None
+    if world > 1:
+        import torch  # noqa: F401  (control plane only)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    pe = tuple(int(v) for v in args.pe_grid.split(",")) if args.pe_grid else lq.pegrid.choose_pe_grid(gL, world)
+    lat = lq.Lattice(gL, pe, rank, device=local_rank)
+    for kv in args.set:
+        k, v = kv.split("=")
+        lat.set_param(k, int(v))
+    if world > 1:
+        box = [lq.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        lat.comm_init(box[0])
+
+    def device_sync():
+        lat.sync()   # hipStreamSynchronize on the library's compute and communication streams
+
+    U = lq.Gaugefields(lat)
+    lq.lib.check(lq.lib.lib().lqcd_gauge_hot_start(U._h, __import__("ctypes").c_uint64(111)))
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": (1, 1, 1, -1)})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    x, y = b.similar(), b.similar()
+    V = gL[0] * gL[1] * gL[2] * gL[3]
+    Vloc = V // world
+
+    # ---- Dslash kernel timing (HIP events on the stream the kernel is launched on)
+    barrier()
+    ms_dslash = lq.bench_dslash(D, y, b, warm=20, reps=args.dslash_reps)
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([ms_dslash], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_dslash = float(t.item())
+    dslash_gflops = WILSON_FLOP_PER_SITE * V / (ms_dslash * 1e-3) / 1e9
+    achieved = WILSON_BYTES_PER_SITE * Vloc / (ms_dslash * 1e-3) / 1e9     # GB/s per GPU, algorithmic bytes
+
+    # ---- CG window: W warm-up + exactly K timed iterations, exit test disabled
+    sess = lq.CGSession(D, x, b)
+    sess.iterate(args.warmup)
+    device_sync(); barrier()
+    t0 = time.perf_counter()
+    sess.iterate(args.steps)
+    device_sync(); barrier()
+    dt = time.perf_counter() - t0
+    sess.close()
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    iters_per_s = args.steps / dt
+
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("wilson_dslash_bytes_per_launch_%dx%dx%dx%d" % gL)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "CG iters/sec (D^+D) & Dslash GFLOP/s, %d^3x%d SU(3) Wilson fp64" % (gL[0], gL[3]),
+        "value": iters_per_s,
+        "unit": "iter/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (hot-start SU(3) links seed 111, Gaussian source seed 112, kappa=0.141139, BC=[1,1,1,-1])",
+        "config": {"workload": "configs[3]: %dx%dx%dx%d Wilson D^+D CG (fixed-length window), fp64" % gL,
+                   "pe_grid": list(pe), "local_lattice": list(lat.local_L), "dslash_block": lat.get_param("dslash_block"),
+                   "xcd_remap": lat.get_param("xcd_remap")},
+        "dslash_gflops": dslash_gflops,
+        "dslash_ms": ms_dslash,
+        "roofline": {"bound": "hbm", "kernel": "wilson_interior (mul!(y,D,x))", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(lq, U, b, gL):
+    """The oracle (a port of the reference algorithm, NOT the reference itself -- Julia is not installed) timed on this
+    box's host cores on a bounded sample: CG windows of 1 and 0 iterations on the SAME 32^3x64 configuration; their
+    difference is one full CG iteration (2 Dslash + BLAS-1), single thread like the reference's serial Julia loop."""
+    from oracle import oracle as orc
+    Uh, bh = U.download(), b.download()
+    bc = (1, 1, 1, -1)
+    res = {}
+    for label, threads in (("1core", 1), ("allcores", os.cpu_count() or 1)):
+        orc.set_threads(threads)
+        t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=0); t_setup = time.perf_counter() - t0
+        t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=1); t_one = time.perf_counter() - t0
+        per_iter = max(t_one - t_setup, 1e-9)
+        t0 = time.perf_counter(); orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc); t_d = time.perf_counter() - t0
+        res[label] = {"iter_per_s": 1.0 / per_iter, "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / t_d / 1e9,
+                      "cores": threads}
+        if threads == 1 and (os.cpu_count() or 1) == 1:
+            break
+    one = res["1core"]
+    out = {"value": one["iter_per_s"], "unit": "iter/s", "cores": 1, "kind": "port",
+           "sample": "oracle CG on the same %dx%dx%dx%d configuration: time(1 iteration) - time(0 iterations), 1 thread" % gL,
+           "dslash_gflops": one["dslash_gflops"]}
+    if "allcores" in res:
+        out["allcores"] = res["allcores"]
+    return out
+
+
+if __name__ == "__main__":
+    main()

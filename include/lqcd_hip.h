@@ -147,6 +147,12 @@ int lqcd_bench_dslash(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dag
 /* ms per CG iteration over a fixed window of niter iterations (after `warm` untimed iterations) */
 int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int warm, int niter, double* ms_per_iter);
 
+/* CG session for externally timed windows (bench.py brackets these with its own barriers/clock):
+ * begin = r = b - D^+D x, p = r; iterate = enqueue n iterations (exit test disabled) and wait; end = release scratch */
+int lqcd_cg_session_begin(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b);
+int lqcd_cg_session_iterate(lqcd_op_t op, int n);
+int lqcd_cg_session_end(lqcd_op_t op);
+
 /* ---------------------------------------------------------------- in-process multi-domain collectives (testing only) */
 int lqcd_mdom_op_apply(int n, lqcd_op_t* ops, lqcd_spinor_t* outs, lqcd_spinor_t* ins, int dagger);
 int lqcd_mdom_dot(int n, lqcd_spinor_t* a, lqcd_spinor_t* b, double* re, double* im);

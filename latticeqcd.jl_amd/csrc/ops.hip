@@ -583,6 +583,40 @@ extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int
     return st;
 }
 
+// CG session (externally timed windows)
+namespace lqcd {
+struct CgSession { lqcd_op_s* op = nullptr; lqcd_spinor_s* x = nullptr; CgWork w; };
+static CgSession g_session;
+}
+extern "C" int lqcd_cg_session_begin(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b) {
+    LQCHK(check_full(op, x, b, "lqcd_cg_session_begin"));
+    ARGCHK(g_session.op == nullptr, "lqcd_cg_session_begin: a session is already open");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    CgWork& w = g_session.w;
+    w.r = scratch_get(c, x->kind, LQCD_FULL); w.p = scratch_get(c, x->kind, LQCD_FULL);
+    w.q = scratch_get(c, x->kind, LQCD_FULL); w.tmp = scratch_get(c, x->kind, LQCD_FULL);
+    if (!(w.r && w.p && w.q && w.tmp)) return LQCD_ERR_HIP;
+    double rr;
+    LQCHK(cg_setup(op, x, b, w, -1.0, &rr));
+    g_session.op = op;
+    g_session.x = x;
+    return LQCD_OK;
+}
+extern "C" int lqcd_cg_session_iterate(lqcd_op_t op, int n) {
+    ARGCHK(op && g_session.op == op, "lqcd_cg_session_iterate: no open session for this operator");
+    for (int i = 0; i < n; i++) LQCHK(cg_enqueue_iteration(op, g_session.x, g_session.w));
+    HIPCHK(hipStreamSynchronize(op->ctx->stream));
+    return LQCD_OK;
+}
+extern "C" int lqcd_cg_session_end(lqcd_op_t op) {
+    ARGCHK(op && g_session.op == op, "lqcd_cg_session_end: no open session for this operator");
+    CgWork& w = g_session.w;
+    scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+    g_session = CgSession();
+    return LQCD_OK;
+}
+
 // ---------------------------------------------------------------------------------- in-process multi-domain collectives
 namespace lqcd {
 int plaquette_local_sum(lqcd_gauge_s* g, const double2* const ghost[4], double* sum);

@@ -319,6 +319,21 @@ def bench_cg(D, x, b, warm=5, niter=50):
     return ms.value
 
 
+class CGSession:
+    """Externally timed CG window: begin (r = b - D'D x, p = r), then iterate(n) enqueues n iterations with the exit test
+    disabled and waits for them."""
+
+    def __init__(self, D, x, b):
+        self.D = D
+        check(_l.lib().lqcd_cg_session_begin(D._h, x._h, b._h))
+
+    def iterate(self, n):
+        check(_l.lib().lqcd_cg_session_iterate(self.D._h, int(n)))
+
+    def close(self):
+        check(_l.lib().lqcd_cg_session_end(self.D._h))
+
+
 # ------------------------------------------------------------------------------------ in-process PE-grid emulation (tests)
 def _harr(objs):
     return (C.c_void_p * len(objs))(*[o._h for o in objs])

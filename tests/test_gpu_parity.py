@@ -1,0 +1,444 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs, against the committed
+reference fixtures, and -- at sizes the oracle cannot reach quickly -- through size-independent identities.
+Tolerances (fp64, stated per test): Dslash <= 1e-13 relative per component; solver solutions <= 1e-9 relative,
+final r.r below eps and true residual recomputed independently; plaquette 1e-13."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+KAPPA, MASS = 0.141139, 0.5
+BC = (1, 1, 1, -1)
+DSLASH_TOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def gpu(lq):
+    assert lq.lib.device_count() > 0, "no HIP device visible: the product has no CPU fallback"
+    return lq
+
+
+def setup(lq, orc, L, kind, seed=1, U=None, r=1.0, bc=BC, km=None):
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, seed) if U is None else U
+    Ud = lq.Gaugefields(lat).upload(Uh)
+    name = "Wilson" if kind == lq.WILSON else "Staggered"
+    params = {"Dirac_operator": name, "κ": KAPPA if km is None else km, "mass": MASS if km is None else km, "r": r,
+              "boundarycondition": bc, "eps_CG": 1e-19, "MaxCGstep": 3000}
+    x = lq.Initialize_pseudofermion_fields(Ud, name)
+    D = lq.Dirac_operator(Ud, x, params)
+    return lat, Uh, Ud, D
+
+
+def host_spinor(orc, lat, kind, seed):
+    return orc.gaussian_spinor(lat.fermion_shape(kind), seed)
+
+
+# ------------------------------------------------------------------ layout / transfers
+@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2)])
+def test_upload_download_round_trip_bit_exact(gpu, orc, L):
+    lq = gpu
+    lat = lq.Lattice(L)
+    U = orc.hot_gauge(L, 3)
+    Ud = lq.Gaugefields(lat).upload(U)
+    assert np.array_equal(Ud.download(), U)
+    # disk-order upload == reference-order upload of the transposed image
+    disk = np.ascontiguousarray(U.transpose(1, 2, 3, 4, 0, 6, 5))
+    Ud2 = lq.Gaugefields(lat).upload(disk, layout=lq.lib.LAYOUT_DISK)
+    assert np.array_equal(Ud2.download(), U)
+    for kind in (lq.WILSON, lq.STAGGERED):
+        psi = host_spinor(orc, lat, kind, 4)
+        f = lq.Fermionfields(lat, kind).upload(psi)
+        assert np.array_equal(f.download(), psi)
+        # parity subsets hold exactly the sites with (x+y+z+t)&1 == parity
+        x, y, z, t = np.meshgrid(*[np.arange(L[mu]) for mu in range(4)], indexing="ij")
+        par = ((x + y + z + t) & 1).transpose(3, 2, 1, 0)
+        for sub, p in ((lq.EVEN, 0), (lq.ODD, 1)):
+            h = lq.Fermionfields(lat, kind, sub).upload(psi)
+            got = h.download()
+            mask = (par == p)[..., None] if kind == lq.STAGGERED else (par == p)[None, ..., None]
+            assert np.array_equal(got, psi * mask)
+
+
+def test_reference_fixture_plaquette_on_gpu(gpu, orc):
+    """The reference's thermalised configurations decode and give the golden plaquette on the device."""
+    import json
+    lq = gpu
+    with open(os.path.join(GOLDEN, "golden.json")) as f:
+        gold = json.load(f)["plaquette"]
+    for fname, L, key in (("wilson_4x4x4x4.ildg", (4, 4, 4, 4), "confs_HMC_L04040404_beta5.7_Wilson_kappa0.141139"),
+                          ("staggered_4x4x4x4.ildg", (4, 4, 4, 4), "confs_HMC_L04040404_beta5.7_Staggered_mass0.5"),
+                          ("domainwall_4x4x2x2.ildg", (4, 4, 2, 2), "confs_HMC_L04040404_beta5.7_Domainwall")):
+        U = lq.gauge_io.load_ildg(os.path.join(GOLDEN, fname), L)
+        Ud = lq.Gaugefields(lq.Lattice(L)).upload(U)
+        assert abs(lq.calculate_Plaquette(Ud) - gold[key]) < 1e-13
+
+
+def test_cold_and_hot_start(gpu, orc):
+    lq = gpu
+    L = (8, 8, 8, 8)
+    Uc = lq.Initialize_Gaugefields(3, 0, *L, condition="cold")
+    assert abs(lq.calculate_Plaquette(Uc) - 1.0) < 1e-14
+    Uh = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    U = Uh.download()
+    assert orc.unitarity_dev(U, L) < 1e-14
+    assert abs(orc.plaquette(U, L) - lq.calculate_Plaquette(Uh)) < 1e-13
+    assert abs(lq.calculate_Plaquette(Uh)) < 0.05           # random links: plaquette ~ 0
+    # determinism and seed sensitivity
+    assert np.array_equal(lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111).download(), U)
+    assert not np.array_equal(lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=112).download(), U)
+
+
+# ------------------------------------------------------------------ Dslash vs oracle
+@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2), (2, 2, 2, 4), (16, 8, 4, 4)])
+@pytest.mark.parametrize("dagger", [False, True])
+@pytest.mark.parametrize("r", [1.0, 0.7])
+def test_wilson_dslash_matches_oracle(gpu, orc, L, dagger, r):
+    lq = gpu
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, seed=5, r=r)
+    psi = host_spinor(orc, lat, lq.WILSON, 6)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    y = x.similar()
+    lq.mul_(y, D.adjoint() if dagger else D, x)
+    ref = orc.wilson_D(Uh, psi, L, KAPPA, r, BC, dagger)
+    assert rel_err(y.download(), ref) < DSLASH_TOL
+
+
+@pytest.mark.parametrize("bc", [(1, 1, 1, 1), (-1, 1, -1, 1), (-1, -1, -1, -1)])
+def test_wilson_boundary_conditions(gpu, orc, bc):
+    lq = gpu
+    L = (4, 6, 2, 4)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, seed=7, bc=bc)
+    psi = host_spinor(orc, lat, lq.WILSON, 8)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    y = x.similar()
+    lq.mul_(y, D, x)
+    assert rel_err(y.download(), orc.wilson_D(Uh, psi, L, KAPPA, 1.0, bc)) < DSLASH_TOL
+
+
+@pytest.mark.parametrize("block", [64, 128, 256])
+@pytest.mark.parametrize("remap", [0, 1])
+def test_wilson_dslash_kernel_variants(gpu, orc, block, remap):
+    lq = gpu
+    L = (8, 8, 8, 16)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, seed=9)
+    lat.set_param("dslash_block", block)
+    lat.set_param("xcd_remap", remap)
+    psi = host_spinor(orc, lat, lq.WILSON, 10)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    y = x.similar()
+    lq.mul_(y, D, x)
+    assert rel_err(y.download(), orc.wilson_D(Uh, psi, L, KAPPA, 1.0, BC)) < DSLASH_TOL
+
+
+def test_wilson_dslash_on_reference_fixture(gpu, orc):
+    lq = gpu
+    L = (4, 4, 4, 4)
+    U = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, U=U)
+    psi = host_spinor(orc, lat, lq.WILSON, 11)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    y, z = x.similar(), x.similar()
+    lq.mul_(y, D, x)
+    assert rel_err(y.download(), orc.wilson_D(U, psi, L, KAPPA, 1.0, BC)) < DSLASH_TOL
+    lq.mul_(z, lq.DdagD_operator(D), x)
+    ref = orc.wilson_D(U, orc.wilson_D(U, psi, L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True)
+    assert rel_err(z.download(), ref) < DSLASH_TOL
+
+
+@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2), (8, 8, 8, 8)])
+@pytest.mark.parametrize("dagger", [False, True])
+def test_staggered_dslash_matches_oracle(gpu, orc, L, dagger):
+    lq = gpu
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.STAGGERED, seed=12)
+    psi = host_spinor(orc, lat, lq.STAGGERED, 13)
+    x = lq.Fermionfields(lat, lq.STAGGERED).upload(psi)
+    y = x.similar()
+    lq.mul_(y, D.adjoint() if dagger else D, x)
+    assert rel_err(y.download(), orc.staggered_D(Uh, psi, L, MASS, BC, dagger)) < DSLASH_TOL
+
+
+@pytest.mark.parametrize("dagger", [False, True])
+def test_wilson_parity_hop_matches_oracle(gpu, orc, dagger):
+    lq = gpu
+    L = (8, 4, 6, 4)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, seed=14)
+    Dd = D.adjoint() if dagger else D
+    psi = host_spinor(orc, lat, lq.WILSON, 15)
+    for out_sub, in_sub, p in ((lq.EVEN, lq.ODD, 0), (lq.ODD, lq.EVEN, 1)):
+        xin = lq.Fermionfields(lat, lq.WILSON, in_sub).upload(psi)
+        yout = lq.Fermionfields(lat, lq.WILSON, out_sub)
+        lq.hop_(yout, Dd, xin)
+        ref = orc.wilson_hop_parity(Uh, psi, L, 1.0, BC, dagger, p)
+        assert rel_err(yout.download(), ref) < DSLASH_TOL
+
+
+# ------------------------------------------------------------------ BLAS-1
+def test_blas1_matches_numpy(gpu, orc):
+    lq = gpu
+    L = (8, 8, 4, 4)
+    lat = lq.Lattice(L)
+    a_h, b_h = host_spinor(orc, lat, lq.WILSON, 16), host_spinor(orc, lat, lq.WILSON, 17)
+    a, b = lq.Fermionfields(lat, lq.WILSON).upload(a_h), lq.Fermionfields(lat, lq.WILSON).upload(b_h)
+    d = lq.dot(a, b)
+    assert abs(d - np.vdot(a_h, b_h)) < 1e-12 * abs(d)
+    assert abs(lq.dot(a, a).imag) == 0.0
+    lq.add_fermion_(b, 0.3 - 0.7j, a)
+    assert rel_err(b.download(), b_h + (0.3 - 0.7j) * a_h) < 1e-15
+    c = a.similar()
+    lq.substitute_fermion_(c, a)
+    assert np.array_equal(c.download(), a_h)
+    lq.clear_fermion_(c)
+    assert np.abs(c.download()).max() == 0.0
+    # Gaussian / Z4 noise: unit variance per real component, <xi^+ xi> = #components
+    lq.gauss_distribution_fermion_(c, 112)
+    g = c.download()
+    assert abs(g.real.var() - 1.0) < 0.02 and abs(g.imag.var() - 1.0) < 0.02 and abs(g.mean()) < 0.01
+    lq.Z4_distribution_fermi_(c, 113)
+    z4 = c.download()
+    assert np.allclose(np.abs(z4), 1.0) and set(np.unique(z4)) == {1, -1, 1j, -1j}
+    lq.setindex_global_(c, 2, 1, 3, 0, 2, 3)
+    ps = c.download()
+    assert ps[3, 2, 0, 3, 1, 2] == 1.0 and np.abs(ps).sum() == 1.0
+
+
+# ------------------------------------------------------------------ identities on the device path (no oracle involved)
+def test_device_gamma5_hermiticity_and_linearity(gpu):
+    lq = gpu
+    L = (16, 16, 16, 16)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA})
+    a, b = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(a, 1)
+    lq.gauss_distribution_fermion_(b, 2)
+    Db, Dda = a.similar(), a.similar()
+    lq.mul_(Db, D, b)
+    lq.mul_(Dda, D.adjoint(), a)
+    lhs, rhs = lq.dot(a, Db), np.conj(lq.dot(b, Dda))
+    assert abs(lhs - rhs) < 1e-12 * abs(lhs)
+    # linearity: D(a + c b) = D a + c D b
+    Da, s = a.similar(), a.similar()
+    lq.mul_(Da, D, a)
+    lq.substitute_fermion_(s, a)
+    lq.add_fermion_(s, 0.5 + 2j, b)
+    Ds = a.similar()
+    lq.mul_(Ds, D, s)
+    lq.add_fermion_(Ds, -1.0, Da, -(0.5 + 2j), Db)
+    assert lq.dot(Ds, Ds).real < 1e-24 * lq.dot(Da, Da).real
+
+
+# ------------------------------------------------------------------ solvers
+def test_cg_matches_oracle_on_reference_fixture(gpu, orc):
+    """BASELINE config 1 geometry: 4^4, kappa = 0.141139, eps = 1e-19 on the reference's own thermalised configuration."""
+    lq = gpu
+    L = (4, 4, 4, 4)
+    U = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, U=U)
+    b_h = host_spinor(orc, lat, lq.WILSON, 41)
+    b = lq.Fermionfields(lat, lq.WILSON).upload(b_h)
+    x = b.similar()
+    it, rr = lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+    xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, b_h, L, KAPPA, 1.0, BC, eps=1e-19)
+    assert st == 0 and rr < 1e-19 and abs(it - ito) <= 1
+    assert rel_err(x.download(), xo) < 1e-9
+    res = b_h - orc.wilson_D(U, orc.wilson_D(U, x.download(), L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True)
+    assert np.vdot(res, res).real < 1e-18
+    # unfused reference form (c1 = p.q) gives the same answer
+    lat.set_param("cg_fused", 0)
+    x2 = b.similar()
+    it2, rr2 = lq.solve_DinvX_(x2, lq.DdagD_operator(D), b, return_info=True)
+    assert abs(it2 - it) <= 1 and rel_err(x2.download(), xo) < 1e-9
+
+
+def test_staggered_cg_8x8x8x8(gpu, orc):
+    """BASELINE config 2: 8^4 staggered Dslash + CG to 1e-10, hot-start links."""
+    lq = gpu
+    L = (8, 8, 8, 8)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.STAGGERED, seed=111)
+    D.eps_CG = 1e-10
+    b_h = host_spinor(orc, lat, lq.STAGGERED, 112)
+    b = lq.Fermionfields(lat, lq.STAGGERED).upload(b_h)
+    x = b.similar()
+    it, rr = lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+    xo, ito, rro, st = orc.cg_DdagD(orc.STAGGERED, Uh, b_h, L, MASS, 1.0, BC, eps=1e-10)
+    assert st == 0 and rr < 1e-10 and abs(it - ito) <= 1
+    assert abs(rr - rro) < 1e-6 * rro + 1e-16
+    assert rel_err(x.download(), xo) < 1e-9
+
+
+@pytest.mark.parametrize("dagger", [False, True])
+def test_bicgstab_and_evenodd_match_oracle(gpu, orc, dagger):
+    lq = gpu
+    L = (4, 4, 4, 8)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, seed=21)
+    Dd = D.adjoint() if dagger else D
+    b_h = host_spinor(orc, lat, lq.WILSON, 22)
+    b = lq.Fermionfields(lat, lq.WILSON).upload(b_h)
+    xo, ito, rro, st = orc.bicgstab(orc.WILSON, Uh, b_h, L, KAPPA, 1.0, BC, dagger, eps=1e-19)
+    assert st == 0
+    x = b.similar()
+    Dd.method_CG = "bicgstab"
+    it, rr = lq.solve_DinvX_(x, Dd, b, return_info=True)
+    assert rr < 1e-19 and rel_err(x.download(), xo) < 1e-8
+    xe = b.similar()
+    Dd.method_CG = "bicgstab_evenodd"
+    ite, rre = lq.solve_DinvX_(xe, Dd, b, return_info=True)
+    assert rre < 1e-19 and rel_err(xe.download(), xo) < 1e-8
+    res = b_h - orc.wilson_D(Uh, xe.download(), L, KAPPA, 1.0, BC, dagger)
+    assert np.vdot(res, res).real < 1e-17
+
+
+def test_evenodd_bicgstab_16x16x16x32_identities(gpu):
+    """BASELINE config 3 (16^3x32 Wilson, even-odd BiCGStab) at full size: the oracle is too slow here, so check the
+    true residual on the device and agreement with the unpreconditioned solve."""
+    lq = gpu
+    L = (16, 16, 16, 32)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    # hot-start links at kappa = 0.141139 are far from critical: both solves converge quickly
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-16, "MaxCGstep": 3000})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    x1, x2 = b.similar(), b.similar()
+    D.method_CG = "bicgstab_evenodd"
+    it1, rr1 = lq.solve_DinvX_(x1, D, b, return_info=True)
+    D.method_CG = "bicgstab"
+    it2, rr2 = lq.solve_DinvX_(x2, D, b, return_info=True)
+    assert it1 <= it2
+    r = b.similar()
+    lq.mul_(r, D, x1)
+    lq.add_fermion_(r, -1.0, b)
+    assert lq.dot(r, r).real < 1e-14
+    lq.add_fermion_(x2, -1.0, x1)
+    assert lq.dot(x2, x2).real < 1e-14 * lq.dot(x1, x1).real
+
+
+def test_solver_non_convergence_raises(gpu, orc):
+    lq = gpu
+    L = (4, 4, 4, 4)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, seed=31)
+    D.MaxCGstep = 2
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 5)
+    x = b.similar()
+    with pytest.raises(lq.NotConverged):
+        lq.solve_DinvX_(x, lq.DdagD_operator(D), b)
+    with pytest.raises(lq.NotConverged):
+        lq.solve_DinvX_(x, D, b)
+
+
+def test_argument_errors(gpu):
+    lq = gpu
+    lat = lq.Lattice((4, 4, 4, 4))
+    U = lq.Initialize_Gaugefields(3, 0, 4, 4, 4, 4, lattice=lat)
+    with pytest.raises(lq.LQCDError):
+        lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover"})     # universe.jl:129-131: error("not supported")
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson"})
+    w, s = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.STAGGERED)
+    with pytest.raises(lq.LQCDError):
+        lq.mul_(w, D, s)
+    with pytest.raises(lq.LQCDError):
+        lq.mul_(w, D, w)            # in-place application is not defined for a stencil
+    with pytest.raises(lq.LQCDError):
+        lq.Lattice((5, 4, 4, 4))
+    with pytest.raises(lq.LQCDError):
+        lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "boundarycondition": (1, 1, 1, 0)})
+
+
+# ------------------------------------------------------------------ in-process PE grids (halo path on one GPU)
+@pytest.mark.parametrize("pe", [(1, 1, 1, 2), (1, 1, 2, 2), (1, 2, 2, 2), (2, 1, 1, 2), (1, 1, 1, 4)])
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+def test_partitioned_dslash_equals_single_domain(gpu, orc, pe, kind_name):
+    """Every PE grid of SURVEY.md 8(e) (scaled down): N-domain Dslash == 1-domain Dslash == oracle, <= 1e-13."""
+    lq = gpu
+    gL = (8, 8, 8, 16)
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    n = int(np.prod(pe))
+    U = orc.hot_gauge(gL, 111)
+    shape = orc.wilson_shape(gL) if kind == lq.WILSON else orc.staggered_shape(gL)
+    lead = 1 if kind == lq.WILSON else 0
+    psi = orc.gaussian_spinor(shape, 112)
+    km = KAPPA if kind == lq.WILSON else MASS
+    lats = [lq.Lattice(gL, pe, r) for r in range(n)]
+    lq.link_local(lats)
+    Us, Ds, xs, ys = [], [], [], []
+    for lat in lats:
+        Ul = lq.pegrid.local_view(U, lat.local_L, lat.origin, lead=1)
+        Ud = lq.Gaugefields(lat).upload(Ul)
+        Us.append(Ud)
+        Ds.append(lq.Dirac_operator(Ud, None, {"Dirac_operator": kind_name, "κ": KAPPA, "mass": MASS, "boundarycondition": BC}))
+        xs.append(lq.Fermionfields(lat, kind).upload(lq.pegrid.local_view(psi, lat.local_L, lat.origin, lead=lead)))
+        ys.append(lq.Fermionfields(lat, kind))
+    for dagger in (False, True):
+        Dd = [D.adjoint() if dagger else D for D in Ds]
+        lq.mdom_mul_(ys, Dd, xs)
+        ref = orc.apply_D(kind, U, psi, gL, km, 1.0, BC, dagger)
+        for lat, y in zip(lats, ys):
+            want = lq.pegrid.local_view(ref, lat.local_L, lat.origin, lead=lead)
+            assert rel_err(y.download(), want) < DSLASH_TOL
+    # global reductions and plaquette across domains
+    d = lq.mdom_dot(xs, xs)
+    assert abs(d - np.vdot(psi, psi)) < 1e-12 * abs(d)
+    assert abs(lq.mdom_plaquette(Us) - orc.plaquette(U, gL)) < 1e-13
+
+
+def test_partitioned_cg_equals_single_domain(gpu, orc):
+    lq = gpu
+    gL, pe = (4, 4, 8, 8), (1, 1, 2, 2)
+    U = orc.hot_gauge(gL, 111)
+    b_h = orc.gaussian_spinor(orc.wilson_shape(gL), 112)
+    lats = [lq.Lattice(gL, pe, r) for r in range(4)]
+    lq.link_local(lats)
+    Ds, xs, bs = [], [], []
+    for lat in lats:
+        Ud = lq.Gaugefields(lat).upload(lq.pegrid.local_view(U, lat.local_L, lat.origin, lead=1))
+        Ds.append(lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": KAPPA}))
+        bs.append(lq.Fermionfields(lat, lq.WILSON).upload(lq.pegrid.local_view(b_h, lat.local_L, lat.origin, lead=1)))
+        xs.append(lq.Fermionfields(lat, lq.WILSON))
+    it, rr = lq.mdom_solve_cg(Ds, xs, bs, eps=1e-19)
+    xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, b_h, gL, KAPPA, 1.0, BC, eps=1e-19)
+    assert st == 0 and abs(it - ito) <= 1 and rr < 1e-19
+    for lat, x in zip(lats, xs):
+        assert rel_err(x.download(), lq.pegrid.local_view(xo, lat.local_L, lat.origin, lead=1)) < 1e-9
+
+
+# ------------------------------------------------------------------ full BASELINE size through identities
+def test_full_size_32x32x32x64_identities(gpu):
+    """BASELINE metric configuration (32^3x64 Wilson fp64, hot start seed 111, source seed 112): gamma5-hermiticity of the
+    device operator, CG residual decrease, and a checksum that is independent of the kernel variant."""
+    lq = gpu
+    L = (32, 32, 32, 64)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    assert abs(lq.calculate_Plaquette(U)) < 0.01
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-10, "MaxCGstep": 500})
+    a, b = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(a, 1)
+    lq.gauss_distribution_fermion_(b, 112)
+    Db, Dda = a.similar(), a.similar()
+    lq.mul_(Db, D, b)
+    lq.mul_(Dda, D.adjoint(), a)
+    lhs, rhs = lq.dot(a, Db), np.conj(lq.dot(b, Dda))
+    assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+    n_ref = lq.dot(Db, Db).real
+    for block, remap in ((64, 0), (256, 1), (128, 0)):
+        lat.set_param("dslash_block", block)
+        lat.set_param("xcd_remap", remap)
+        lq.mul_(Dda, D, b)
+        lq.add_fermion_(Dda, -1.0, Db)
+        assert lq.dot(Dda, Dda).real == 0.0, (block, remap)          # variants are bitwise identical per site
+    lat.set_param("dslash_block", 128)
+    lat.set_param("xcd_remap", 1)
+    x = b.similar()
+    it, rr = lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+    assert rr < 1e-10 and it < 500
+    r = b.similar()
+    lq.mul_(r, lq.DdagD_operator(D), x)
+    lq.add_fermion_(r, -1.0, b)
+    assert lq.dot(r, r).real < 1e-9
+    assert n_ref > 0
