@@ -200,6 +200,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "nt_store")) return &c->tun.nt_store;
     if (!strcmp(key, "cg_fused")) return &c->tun.cg_fused;
     if (!strcmp(key, "graph")) return &c->tun.graph;
+    if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;
     return nullptr;
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {

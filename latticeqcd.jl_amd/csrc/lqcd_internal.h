@@ -119,6 +119,7 @@ struct Tunables {
     int nt_store = 0;         // non-temporal stores for the output spinor
     int cg_fused = 1;         // fused BLAS-1 / reductions in CG
     int graph = 0;            // capture solver iterations in a hipGraph
+    int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)
 };
 
 }  // namespace lqcd
@@ -223,7 +224,7 @@ int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path)
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
-int stencil_num_blocks(lqcd_ctx_s* c, int parity_mode);
+int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode);
 
 // BLAS-1 / reductions (blas.hip)
 int blas_dot(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, double* re, double* im, bool allreduce);

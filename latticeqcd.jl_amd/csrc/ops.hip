@@ -250,7 +250,7 @@ static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w
     LQCHK(op_apply_async(op, w.tmp, w.p, 0, fuse ? c->d_partial : nullptr));
     int nb;
     if (fuse) {
-        nb = stencil_num_blocks(c, 2);
+        nb = stencil_num_blocks(c, op->kind, op->r, 2);
         LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
         LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
     } else if (c->tun.cg_fused) {

@@ -30,6 +30,7 @@ struct KArgs {
     int parity_mode;
     int nblocks;
     int remap;
+    int cps;   // chunks per t-slice per parity if the slice divides evenly into chunks and by 8, else 0 (remap 2)
     double* norm_partial;
 };
 
@@ -49,9 +50,27 @@ struct HArgs {  // halo kernels
     double sign_bwd[4];
 };
 
-__device__ inline int remap_block(int b, int nb, int remap) {
-    if (!remap || (nb & 7)) return b;
-    return (b & 7) * (nb >> 3) + (b >> 3);
+// workgroup -> (chunk of consecutive checkerboard sites, parity).  Observed (not contractual) dispatch: block b runs on
+// XCD b % 8, blocks of one XCD start in increasing b.  The maps only change speed, never results.
+//   remap 0: plain -- consecutive blocks = even/odd halves of consecutive chunks, round-robin over the XCDs
+//   remap 1: XCD k owns a contiguous 1/8 of the chunk list (a t-slab), even/odd of a chunk back to back
+//   remap 2: XCD k owns 1/8 of every t-slice (a z-slab) and sweeps t: the t-neighbour re-use distance is one slab step
+//            (fits the 4 MiB L2) and the 8 XCDs advance through t together (z-halo lines are shared through the MALL)
+__device__ inline void map_block(const KArgs& k, int& chunk, int& p) {
+    const int b = blockIdx.x, nb = k.nblocks;
+    const bool both = k.parity_mode == 2;
+    if (k.remap == 2 && k.cps > 0) {
+        const int cpr = k.cps >> 3;                 // chunks per XCD per t-slice (per parity)
+        const int xcd = b & 7;
+        int j = b >> 3;
+        if (both) { p = j & 1; j >>= 1; } else p = k.parity_mode;
+        const int t = j / cpr, s = xcd * cpr + (j - t * cpr);
+        chunk = t * k.cps + s;
+        return;
+    }
+    int lb = b;
+    if (k.remap && !(nb & 7)) lb = (b & 7) * (nb >> 3) + (b >> 3);
+    if (both) { chunk = lb >> 1; p = lb & 1; } else { chunk = lb; p = k.parity_mode; }
 }
 
 // gamma_mu (mu = 0,1,2) has one entry per row: row a -> column PERM[mu][a], value i^GK[mu][a]
@@ -222,9 +241,8 @@ __device__ inline void block_norm_partial(double v, double* partial) {
 // ------------------------------------------------------------------------------------------ Wilson
 template <int TB, bool DAG, bool RGEN>
 __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
-    const int lb = remap_block(blockIdx.x, k.nblocks, k.remap);
     int chunk, p;
-    if (k.parity_mode == 2) { chunk = lb >> 1; p = lb & 1; } else { chunk = lb; p = k.parity_mode; }
+    map_block(k, chunk, p);
     const int Vh = k.g.Vh;
     const int i = chunk * TB + threadIdx.x;
     const bool valid = i < Vh;
@@ -233,9 +251,17 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
         Nbr n;
         int c[4];
         neighbours(k.g, p, i, n, c);
-        cd acc[12];
+        cd acc[12], xv[12];
 #pragma unroll
         for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+        // diagonal term: issue its loads first so they overlap the hops instead of forming a ninth dependent round trip
+        if (k.a != 0.0) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) xv[j] = ld(k.xin[p] + i + (size_t)j * Vh);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 12; j++) xv[j] = mk(0.0, 0.0);
+        }
         const double2* __restrict__ psi = k.in[1 - p];
         const double2* __restrict__ Uf = k.gauge + (size_t)(p * 4) * 9 * Vh + i;         // own links
         const double2* __restrict__ Ub = k.gauge + (size_t)((1 - p) * 4) * 9 * Vh;       // neighbour's links
@@ -252,25 +278,209 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
         HOP(0) HOP(1) HOP(2) HOP(3)
 #undef HOP
         double2* __restrict__ o = k.out[p] + i;
-        if (k.a != 0.0) {
-            const double2* __restrict__ x = k.xin[p] + i;
 #pragma unroll
-            for (int j = 0; j < 12; j++) {
-                cd xv = ld(x + (size_t)j * Vh);
-                cd v = mk(fma(k.b, acc[j].re, k.a * xv.re), fma(k.b, acc[j].im, k.a * xv.im));
-                nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
-                st(o + (size_t)j * Vh, v);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 12; j++) {
-                cd v = k.b * acc[j];
-                nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
-                st(o + (size_t)j * Vh, v);
-            }
+        for (int j = 0; j < 12; j++) {
+            cd v = mk(fma(k.b, acc[j].re, k.a * xv[j].re), fma(k.b, acc[j].im, k.a * xv[j].im));
+            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+            st(o + (size_t)j * Vh, v);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
+}
+
+// ------------------------------------------------------------------------------------------ Wilson, direction-split
+// Variant 1 ("dirsplit"): a workgroup of 4 waves owns 64 consecutive checkerboard sites; wave w computes the two hops
+// of direction mu = w (all 42 loads of the direction issued as two short bursts), the four partial spinors are combined
+// through LDS and wave w writes spin row w.  Compared with one-lane-does-all-8-hops this cuts the wave lifetime ~6x and
+// phase-aligns the waves that touch the same lines, so the re-use of psi (9x) and of the links (2x) falls inside the
+// residency time of the XCD's 4 MiB L2 (measured: profiles/).  r = 1 only.
+template <int MU, bool DAG>
+__device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i) {
+    Nbr n;
+    int c[4];
+    neighbours(k.g, p, i, n, c);
+    const int Vh = k.g.Vh;
+    const double2* __restrict__ psi = k.in[1 - p];
+    const double2* __restrict__ Uf = k.gauge + ((size_t)(p * 4 + MU) * 9) * Vh + i;
+    const double2* __restrict__ Ub = k.gauge + ((size_t)((1 - p) * 4 + MU) * 9) * Vh + n.bwd[MU];
+    constexpr int SF = DAG ? -1 : 1;
+    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], Uf, Vh, n.sf[MU]);
+    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], Ub, Vh, n.sb[MU]);
+}
+
+template <bool DAG>
+__global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
+    __shared__ double2 part[4][12][64];  // 48 KiB
+    __shared__ double red[4];
+    int chunk, p;
+    map_block(k, chunk, p);
+    const int Vh = k.g.Vh;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < Vh;
+    cd acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+    // the diagonal term's loads are issued first so they are not a third dependent memory round trip after the barrier
+    cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    if (valid && k.a != 0.0) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + i + (size_t)(3 * w + cc) * Vh);
+    }
+    if (valid) {
+        switch (w) {
+        case 0: dirsplit_hops<0, DAG>(acc, k, p, i); break;
+        case 1: dirsplit_hops<1, DAG>(acc, k, p, i); break;
+        case 2: dirsplit_hops<2, DAG>(acc, k, p, i); break;
+        default: dirsplit_hops<3, DAG>(acc, k, p, i); break;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) part[w][j][lane] = make_double2(acc[j].re, acc[j].im);
+    __syncthreads();
+    double nrm = 0.0;
+    if (valid) {
+        double2* __restrict__ o = k.out[p] + i;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const int j = 3 * w + cc;
+            const double2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
+            cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+            cd v = k.b * s;
+            v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
+            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+            st(o + (size_t)j * Vh, v);
+        }
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Wilson, hop-split
+// Variant 2 ("hopsplit"): 8 waves per 64 sites, one per hop (direction x sign).  Every wave issues its 21 loads
+// (12 spinor + 9 link; 15 for the t hops) as ONE burst -- a workgroup has a single memory round trip -- and leaves the
+// colour-multiplied half spinor (6 complex) in LDS; six waves then reconstruct two output components each.
+template <int MU, int S, int ROW>
+struct Recon {  // contribution of hop (MU, S) to spin row ROW: src half-spinor row (or -1) and the power of i to apply
+    static constexpr int src = (MU < 3) ? (ROW < 2 ? ROW : (PERM[MU < 3 ? MU : 0][0] == ROW ? 0 : 1))
+                                        : ((ROW == (S > 0 ? 2 : 0)) ? 0 : (ROW == (S > 0 ? 3 : 1)) ? 1 : -1);
+    static constexpr int kpow = (MU < 3 && ROW >= 2) ? ((-GK[MU < 3 ? MU : 0][src < 0 ? 0 : src] + (S > 0 ? 2 : 0) + 8) % 4) : 0;
+};
+
+template <int MU, int S, int ROW>
+__device__ inline void add_hop(cd& sum, const double2 (*half)[6][64], int h, int c, int lane) {
+    constexpr int src = Recon<MU, S, ROW>::src;
+    if constexpr (src >= 0) {
+        const double2 v = half[h][src * 3 + c][lane];
+        sum = sum + mul_ipow<Recon<MU, S, ROW>::kpow>(mk(v.x, v.y));
+    }
+}
+
+template <int J, bool DAG>
+__device__ inline cd combine_comp(const double2 (*half)[6][64], int lane) {
+    constexpr int ROW = J / 3, c = J % 3, SF = DAG ? -1 : 1;
+    cd s0 = mk(0, 0), s1 = mk(0, 0);
+    add_hop<0, SF, ROW>(s0, half, 0, c, lane); add_hop<0, -SF, ROW>(s1, half, 1, c, lane);
+    add_hop<1, SF, ROW>(s0, half, 2, c, lane); add_hop<1, -SF, ROW>(s1, half, 3, c, lane);
+    add_hop<2, SF, ROW>(s0, half, 4, c, lane); add_hop<2, -SF, ROW>(s1, half, 5, c, lane);
+    add_hop<3, SF, ROW>(s0, half, 6, c, lane); add_hop<3, -SF, ROW>(s1, half, 7, c, lane);
+    return s0 + s1;
+}
+
+template <int MU, bool BWD, bool DAG>
+__device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, int p, int i) {
+    Nbr n;
+    int c[4];
+    neighbours(k.g, p, i, n, c);
+    const int Vh = k.g.Vh;
+    constexpr int S = (DAG ? -1 : 1) * (BWD ? -1 : 1);
+    const double sign = BWD ? n.sb[MU] : n.sf[MU];
+    const int nb = BWD ? n.bwd[MU] : n.fwd[MU];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) { chi0[cc] = mk(0, 0); chi1[cc] = mk(0, 0); }
+    if (sign != 0.0) {
+        const double2* __restrict__ psi = k.in[1 - p] + nb;
+        const double2* __restrict__ U = BWD ? k.gauge + ((size_t)((1 - p) * 4 + MU) * 9) * Vh + nb
+                                            : k.gauge + ((size_t)(p * 4 + MU) * 9) * Vh + i;
+        cd h0[3], h1[3], u[9];
+        project<MU, S>(h0, h1, psi, Vh);
+        load_link(u, U, Vh);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { h0[cc] = sign * h0[cc]; h1[cc] = sign * h1[cc]; }
+        su3_mv<BWD>(chi0, u, h0);
+        su3_mv<BWD>(chi1, u, h1);
+    }
+}
+
+template <bool DAG>
+__global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
+    __shared__ double2 half[8][6][64];  // 48 KiB
+    __shared__ double red[8];
+    int chunk, p;
+    map_block(k, chunk, p);
+    const int Vh = k.g.Vh;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < Vh;
+    cd xv[2] = {mk(0, 0), mk(0, 0)};
+    if (valid && w < 6 && k.a != 0.0) {
+        xv[0] = ld(k.xin[p] + i + (size_t)(2 * w) * Vh);
+        xv[1] = ld(k.xin[p] + i + (size_t)(2 * w + 1) * Vh);
+    }
+    cd chi0[3], chi1[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) { chi0[cc] = mk(0, 0); chi1[cc] = mk(0, 0); }
+    if (valid) {
+        switch (w) {
+        case 0: hop_half<0, false, DAG>(chi0, chi1, k, p, i); break;
+        case 1: hop_half<0, true, DAG>(chi0, chi1, k, p, i); break;
+        case 2: hop_half<1, false, DAG>(chi0, chi1, k, p, i); break;
+        case 3: hop_half<1, true, DAG>(chi0, chi1, k, p, i); break;
+        case 4: hop_half<2, false, DAG>(chi0, chi1, k, p, i); break;
+        case 5: hop_half<2, true, DAG>(chi0, chi1, k, p, i); break;
+        case 6: hop_half<3, false, DAG>(chi0, chi1, k, p, i); break;
+        default: hop_half<3, true, DAG>(chi0, chi1, k, p, i); break;
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+        half[w][cc][lane] = make_double2(chi0[cc].re, chi0[cc].im);
+        half[w][3 + cc][lane] = make_double2(chi1[cc].re, chi1[cc].im);
+    }
+    __syncthreads();
+    double nrm = 0.0;
+    if (valid && w < 6) {
+        cd s0, s1;
+        switch (w) {
+        case 0: s0 = combine_comp<0, DAG>(half, lane); s1 = combine_comp<1, DAG>(half, lane); break;
+        case 1: s0 = combine_comp<2, DAG>(half, lane); s1 = combine_comp<3, DAG>(half, lane); break;
+        case 2: s0 = combine_comp<4, DAG>(half, lane); s1 = combine_comp<5, DAG>(half, lane); break;
+        case 3: s0 = combine_comp<6, DAG>(half, lane); s1 = combine_comp<7, DAG>(half, lane); break;
+        case 4: s0 = combine_comp<8, DAG>(half, lane); s1 = combine_comp<9, DAG>(half, lane); break;
+        default: s0 = combine_comp<10, DAG>(half, lane); s1 = combine_comp<11, DAG>(half, lane); break;
+        }
+        double2* __restrict__ o = k.out[p] + i + (size_t)(2 * w) * Vh;
+        cd v0 = mk(fma(k.a, xv[0].re, k.b * s0.re), fma(k.a, xv[0].im, k.b * s0.im));
+        cd v1 = mk(fma(k.a, xv[1].re, k.b * s1.re), fma(k.a, xv[1].im, k.b * s1.im));
+        nrm = v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
+        st(o, v0);
+        st(o + Vh, v1);
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            k.norm_partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------ staggered
@@ -294,9 +504,8 @@ __device__ inline double stag_eta(const int c[4], int mu) {
 
 template <int TB>
 __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
-    const int lb = remap_block(blockIdx.x, k.nblocks, k.remap);
     int chunk, p;
-    if (k.parity_mode == 2) { chunk = lb >> 1; p = lb & 1; } else { chunk = lb; p = k.parity_mode; }
+    map_block(k, chunk, p);
     const int Vh = k.g.Vh;
     const int i = chunk * TB + threadIdx.x;
     const bool valid = i < Vh;
@@ -531,12 +740,18 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     const int chunks = (c->geom.Vh + TB - 1) / TB;
     k.nblocks = chunks * (s.parity_mode == 2 ? 2 : 1);
     k.remap = c->tun.xcd_remap;
+    const int slice = c->geom.XH * c->geom.L[1] * c->geom.L[2];  // sites per parity per t-slice
+    k.cps = (slice % TB == 0 && (slice / TB) % 8 == 0) ? slice / TB : 0;
     k.norm_partial = s.norm_partial;
     return k;
 }
 
-int stencil_num_blocks(lqcd_ctx_s* c, int parity_mode) {
-    const int TB = c->tun.dslash_block;
+static bool use_dirsplit(lqcd_ctx_s* c, int kind, double r) {   // variants 1/2 work on 64-site chunks
+    return (c->tun.dslash_variant == 1 || c->tun.dslash_variant == 2) && kind == LQCD_WILSON && r == 1.0;
+}
+
+int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
+    const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
     return ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
 }
 
@@ -544,11 +759,12 @@ template <int TB>
 static int launch_interior_tb(lqcd_ctx_s* c, const StencilCall& s) {
     KArgs k = make_kargs(c, s, TB);
     dim3 grid(k.nblocks), block(TB);
+    const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;  // occupancy limiter (experiments)
     if (s.kind == LQCD_WILSON) {
         const bool rgen = (s.r != 1.0);
         if (!rgen) {
-            if (s.dagger) hipLaunchKernelGGL((wilson_interior<TB, true, false>), grid, block, 0, c->stream, k);
-            else hipLaunchKernelGGL((wilson_interior<TB, false, false>), grid, block, 0, c->stream, k);
+            if (s.dagger) hipLaunchKernelGGL((wilson_interior<TB, true, false>), grid, block, pad, c->stream, k);
+            else hipLaunchKernelGGL((wilson_interior<TB, false, false>), grid, block, pad, c->stream, k);
         } else {
             if (s.dagger) hipLaunchKernelGGL((wilson_interior<TB, true, true>), grid, block, 0, c->stream, k);
             else hipLaunchKernelGGL((wilson_interior<TB, false, true>), grid, block, 0, c->stream, k);
@@ -561,6 +777,21 @@ static int launch_interior_tb(lqcd_ctx_s* c, const StencilCall& s) {
 }
 
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
+    if (use_dirsplit(c, s.kind, s.r)) {
+        KArgs k = make_kargs(c, s, 64);
+        const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
+        if (c->tun.dslash_variant == 2) {
+            dim3 grid(k.nblocks), block(512);
+            if (s.dagger) hipLaunchKernelGGL((wilson_hopsplit<true>), grid, block, pad, c->stream, k);
+            else hipLaunchKernelGGL((wilson_hopsplit<false>), grid, block, pad, c->stream, k);
+        } else {
+            dim3 grid(k.nblocks), block(256);
+            if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true>), grid, block, pad, c->stream, k);
+            else hipLaunchKernelGGL((wilson_dirsplit<false>), grid, block, pad, c->stream, k);
+        }
+        HIPCHK(hipGetLastError());
+        return LQCD_OK;
+    }
     switch (c->tun.dslash_block) {
     case 64: return launch_interior_tb<64>(c, s);
     case 256: return launch_interior_tb<256>(c, s);
