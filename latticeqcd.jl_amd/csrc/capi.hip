@@ -3,6 +3,7 @@
 // rank = px + PX*(py + PY*(pz + PZ*pt)); one process (one context) per GPU.
 #include "lqcd_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -85,6 +86,13 @@ static void geom_from_L(Geom& g, const int L[4]) {
     for (int mu = 0; mu < 4; mu++) { g.L[mu] = L[mu]; g.gL[mu] = L[mu]; g.bc_fwd[mu] = g.bc_bwd[mu] = 1.0; }
     g.XH = L[0] / 2;
     g.Vh = (L[0] / 2) * L[1] * L[2] * L[3];
+    // component stride: Vh rounded up to 64 sites (1 KiB, keeps every wave load on 8 whole cache lines) plus
+    // LQCD_PAD_CHUNKS * 64 sites (default 1) so that consecutive component arrays are NOT a power-of-two apart
+    int pad_chunks = 1;
+    if (const char* e = getenv("LQCD_PAD_CHUNKS")) pad_chunks = atoi(e);
+    if (pad_chunks < 0) pad_chunks = 0;
+    g.Vs = ((g.Vh + 63) / 64) * 64 + 64 * pad_chunks;
+    if (pad_chunks == 0) g.Vs = g.Vh;
 }
 
 extern "C" int lqcd_index_cb(const int L[4], int x, int y, int z, int t, int* parity, int64_t* cb) {
@@ -201,6 +209,9 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "cg_fused")) return &c->tun.cg_fused;
     if (!strcmp(key, "graph")) return &c->tun.graph;
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;
+    if (!strcmp(key, "xcd_nsub")) return &c->tun.xcd_nsub;
+    if (!strcmp(key, "xcd_ysplit")) return &c->tun.xcd_ysplit;
+    if (!strcmp(key, "dbg")) return &c->tun.dbg;
     return nullptr;
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {

@@ -23,7 +23,7 @@ __global__ void gauge_reorder(Geom g, double2* dev, double2* host_img, int layou
     for (int mu = 0; mu < 4; mu++)
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) {
-                double2* d = dev + ((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vh + i;
+                double2* d = dev + ((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vs + i;
                 double2* h = host_img + host_gauge_index(layout, V, mu, site, a, b);
                 if (to_device) *d = *h; else *h = *d;
             }
@@ -43,7 +43,7 @@ __global__ void spinor_reorder(Geom g, double2* dev0, double2* dev1, double2* ho
     const size_t site = c[0] + (size_t)g.L[0] * (c[1] + (size_t)g.L[1] * (c[2] + (size_t)g.L[2] * c[3]));
     for (int s = 0; s < nspin; s++)
         for (int ic = 0; ic < 3; ic++) {
-            double2* d = dev + (size_t)(s * 3 + ic) * g.Vh + i;
+            double2* d = dev + (size_t)(s * 3 + ic) * g.Vs + i;
             double2* h = host_img + ic + 3 * (site + V * s);
             if (to_device) *d = *h; else *h = *d;
         }
@@ -103,7 +103,7 @@ __global__ void gauge_hot(Geom g, double2* dev, uint64_t seed) {
     }
     for (int a = 0; a < 3; a++)
         for (int b = 0; b < 3; b++)
-            dev[((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vh + i] = make_double2(m[a][b][0], m[a][b][1]);
+            dev[((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vs + i] = make_double2(m[a][b][0], m[a][b][1]);
 }
 
 __global__ void gauge_unit(Geom g, double2* dev) {
@@ -113,7 +113,7 @@ __global__ void gauge_unit(Geom g, double2* dev) {
     const int p = s / g.Vh, i = s % g.Vh;
     for (int a = 0; a < 3; a++)
         for (int b = 0; b < 3; b++)
-            dev[((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vh + i] = make_double2(a == b ? 1.0 : 0.0, 0.0);
+            dev[((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vs + i] = make_double2(a == b ? 1.0 : 0.0, 0.0);
 }
 
 // mode 0: gaussian re,im ~ N(0,1); mode 1: Z4 noise (+-1, +-i)
@@ -135,7 +135,7 @@ __global__ void spinor_fill(Geom g, double2* dev0, double2* dev1, int ncomp, uin
             const int z = (int)(splitmix64(key) >> 62);
             v = make_double2(z == 0 ? 1.0 : (z == 2 ? -1.0 : 0.0), z == 1 ? 1.0 : (z == 3 ? -1.0 : 0.0));
         }
-        dev[(size_t)k * g.Vh + i] = v;
+        dev[(size_t)k * g.Vs + i] = v;
     }
 }
 
@@ -143,8 +143,8 @@ __global__ void spinor_fill(Geom g, double2* dev0, double2* dev1, int ncomp, uin
 __device__ inline void load_link_at(cd (&u)[9], const double2* gauge, const Geom& g, int mu, const int c[4]) {
     const int p = (c[0] + c[1] + c[2] + c[3]) & 1;
     const int i = coords_to_cb(g, c);
-    const double2* U = gauge + ((size_t)(p * 4 + mu) * 9) * g.Vh + i;
-    for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * g.Vh);
+    const double2* U = gauge + ((size_t)(p * 4 + mu) * 9) * g.Vs + i;
+    for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * g.Vs);
 }
 __device__ inline void mm(cd (&C)[9], const cd (&A)[9], const cd (&B)[9], bool adjB) {
     for (int a = 0; a < 3; a++)
@@ -222,7 +222,7 @@ __global__ void gauge_face_pack(Geom g, const double2* gauge, double2* dst, int 
     const int i = coords_to_cb(g, c);
     for (int nu = 0; nu < 4; nu++)
         for (int j = 0; j < 9; j++)
-            dst[((size_t)(p * 4 + nu) * 9 + j) * Fh + f] = gauge[((size_t)(p * 4 + nu) * 9 + j) * g.Vh + i];
+            dst[((size_t)(p * 4 + nu) * 9 + j) * Fh + f] = gauge[((size_t)(p * 4 + nu) * 9 + j) * g.Vs + i];
 }
 
 }  // namespace lqcd
@@ -235,10 +235,12 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
     HIPCHK(hipSetDevice(ctx->device));
     lqcd_gauge_s* x = new lqcd_gauge_s;
     x->ctx = ctx;
-    x->elems = (size_t)2 * 4 * 9 * ctx->geom.Vh;
+    x->elems = (size_t)2 * 4 * 9 * ctx->geom.Vs;
     x->data = nullptr;
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
     if (e != hipSuccess) { delete x; return hip_fail(e, "hipMalloc(gauge)", __FILE__, __LINE__); }
+    e = hipMemsetAsync(x->data, 0, x->elems * sizeof(double2), ctx->stream);  // stride padding stays zero
+    if (e != hipSuccess) { hipFree(x->data); delete x; return hip_fail(e, "memset(gauge)", __FILE__, __LINE__); }
     *g = x;
     return LQCD_OK;
 }
@@ -257,7 +259,7 @@ static int gauge_xfer(lqcd_gauge_t g, double* host, int layout, int to_device) {
     lqcd_ctx_s* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     double2* img = nullptr;
-    const size_t bytes = g->elems * sizeof(double2);
+    const size_t bytes = (size_t)2 * 4 * 9 * c->geom.Vh * sizeof(double2);  // host image is unpadded
     HIPCHK(hipMalloc((void**)&img, bytes));
     int st = LQCD_OK;
     const int nt = 2 * c->geom.Vh;
@@ -349,7 +351,7 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
     x->kind = kind;
     x->subset = subset;
     x->ncomp = kind == LQCD_WILSON ? 12 : 3;
-    x->elems = (size_t)x->ncomp * ctx->geom.Vh * (subset == LQCD_FULL ? 2 : 1);
+    x->elems = (size_t)x->ncomp * ctx->geom.Vs * (subset == LQCD_FULL ? 2 : 1);
     x->data = nullptr;
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
     if (e != hipSuccess) { delete x; return hip_fail(e, "hipMalloc(spinor)", __FILE__, __LINE__); }
@@ -370,7 +372,7 @@ extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
 namespace lqcd {
 // device pointer of the parity block p of a spinor (nullptr if the spinor does not hold that parity)
 double2* spinor_block(lqcd_spinor_s* s, int p) {
-    const size_t blk = (size_t)s->ncomp * s->ctx->geom.Vh;
+    const size_t blk = (size_t)s->ncomp * s->ctx->geom.Vs;
     if (s->subset == LQCD_FULL) return s->data + p * blk;
     if (s->subset == LQCD_EVEN) return p == 0 ? s->data : nullptr;
     return p == 1 ? s->data : nullptr;
@@ -457,7 +459,7 @@ extern "C" int lqcd_spinor_point_source(lqcd_spinor_t s, const int gx[4], int ic
     double2* blk = spinor_block(s, p);
     if (!blk) return LQCD_OK;
     const double2 one = make_double2(1.0, 0.0);
-    HIPCHK(hipMemcpy(blk + (size_t)(is * 3 + ic) * c->geom.Vh + coords_to_cb(c->geom, lc), &one, sizeof(one), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(blk + (size_t)(is * 3 + ic) * c->geom.Vs + coords_to_cb(c->geom, lc), &one, sizeof(one), hipMemcpyHostToDevice));
     return LQCD_OK;
 }
 

@@ -21,6 +21,8 @@ struct Geom {           // local sub-lattice geometry, passed by value to kernel
     int L[4];           // local extents
     int XH;             // L[0]/2
     int Vh;             // sites per parity
+    int Vs;             // component stride in sites: Vh + padding.  With Vh a power of two every component array would be a
+                        // multiple of 256 KiB apart and the 21 loads of a hop alias to one L2 set / memory channel.
     int part[4];        // 1 if direction is partitioned over ranks (neighbour is off-rank)
     double bc_fwd[4];   // sign applied when a forward hop wraps locally across the GLOBAL boundary (unpartitioned dirs)
     double bc_bwd[4];
@@ -113,12 +115,15 @@ struct Ctx;
 
 struct Tunables {
     int dslash_block = 128;   // threads per workgroup of the stencil kernels
-    int xcd_remap = 1;        // 1: each XCD gets a contiguous t-slab of the lattice (L2 locality)
-    int dslash_variant = 0;   // kernel variant selector (see dslash_wilson.hip)
+    int xcd_remap = 2;        // workgroup -> lattice map (stencil.hip map_block): 2 = per-XCD (y,z) tile swept through t
+    int dslash_variant = 2;   // Wilson r=1 kernel: 0 site-per-lane, 1 dirsplit (4 waves/64 sites), 2 hopsplit (8 waves/64 sites)
     int nt_gauge = 0;         // non-temporal loads for gauge links
     int nt_store = 0;         // non-temporal stores for the output spinor
-    int cg_fused = 1;         // fused BLAS-1 / reductions in CG
+    int cg_fused = 2;         // 0: reference form (c1 = p.q), 1: |Dp|^2 from the stencil, 2: + r-update fused into D^+, x/p updates merged
     int graph = 0;            // capture solver iterations in a hipGraph
+    int dbg = 0;              // timing ablations (results are wrong when non-zero)
+    int xcd_ysplit = 4;       // remap 2: tile the sub-domains in (y,z) instead of plain z-slabs
+    int xcd_nsub = 16;       // remap 2: sub-domains per t-slice (multiple of 8)
     int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)
 };
 
@@ -216,8 +221,14 @@ struct StencilCall {
     double r;                     // Wilson parameter
     int dagger;
     int parity_mode;              // 0 even out, 1 odd out, 2 both
-    double* norm_partial;         // if non-null: per-block partial sums of |out|^2 are written here
+    double* norm_partial = nullptr;  // if non-null: per-block partial sums of |out|^2 (or |r|^2 in update mode) are written here
+    // update mode (CG): instead of storing v = a*xin + b*Hop(in), do  r <- r - alpha*v  with alpha read from the device
+    // scalar block (upd_scal[S_ALPHA]); the kernel is a no-op once upd_scal[S_DONE] is set.  q = D^+ D p is never written.
+    const double* upd_scal = nullptr;
+    double2* upd[2] = {nullptr, nullptr};
 };
+// slots of the device scalar block d_scal used by the solvers
+enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16 };
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);

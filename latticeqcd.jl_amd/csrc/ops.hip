@@ -147,10 +147,9 @@ int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dag
 }
 
 // ---------------------------------------------------------------------------------- CG with device-resident scalars
-enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15 };
 
 __global__ void cg_scalar_alpha(double* s) {
-    if (s[S_DONE] != 0.0) return;
+    if (s[S_DONE] != 0.0) { s[S_XDONE] = 1.0; return; }   // the iterate of the converging iteration has been written
     s[S_ALPHA] = s[S_RR] / s[S_PQ];
 }
 __global__ void cg_scalar_beta(double* s) {
@@ -188,6 +187,24 @@ __global__ __launch_bounds__(UB) void cg_update_xr(const double* __restrict__ s,
         double t = 0;
         for (int w = 0; w < UB / 64; w++) t += red[w];
         partial[blockIdx.x] = t;
+    }
+}
+// fused tail of an iteration:  x += alpha p ;  p = r + beta p   (x is still updated in the iteration that converges,
+// p only while the solve continues; nothing is touched in later, overshooting launches)
+__global__ __launch_bounds__(UB) void cg_update_xp(const double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ p,
+                                                    const double2* __restrict__ r, size_t n) {
+    if (s[S_XDONE] != 0.0) return;
+    const double al = s[S_ALPHA], be = s[S_BETA];
+    const bool cont = s[S_DONE] == 0.0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        double2 pv = p[i], xv = x[i];
+        xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+        x[i] = xv;
+        if (cont) {
+            const double2 rv = r[i];
+            pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
+            p[i] = pv;
+        }
     }
 }
 // p = r + beta p
@@ -245,6 +262,28 @@ struct CgWork {
 static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n = x->elems;
+    if (c->tun.cg_fused >= 2 && !any_partitioned(c)) {
+        // fully fused form: 10 spinor passes per iteration instead of 13, q = D^+ D p is never written
+        //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
+        //   beta, convergence ; x += alpha p, p = r + beta p
+        const int nbs = stencil_num_blocks(c, op->kind, op->r, 2);
+        LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial));
+        LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true));
+        hipLaunchKernelGGL(cg_scalar_alpha, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+        apply_bc(c, op->bc);
+        StencilCall s2 = make_full_call(op, w.q, w.tmp, 1);
+        s2.norm_partial = c->d_partial;
+        s2.upd_scal = c->d_scal;
+        s2.upd[0] = spinor_block(w.r, 0);
+        s2.upd[1] = spinor_block(w.r, 1);
+        LQCHK(stencil_apply(c, s2));
+        LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true));
+        hipLaunchKernelGGL(cg_scalar_beta, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+        const int nbu = stream_grid(c, n);
+        hipLaunchKernelGGL(cg_update_xp, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
+        HIPCHK(hipGetLastError());
+        return LQCD_OK;
+    }
     const bool fuse = c->tun.cg_fused && !any_partitioned(c);
     // tmp = D p  (|tmp|^2 block partials fused into the stencil when the lattice is not partitioned)
     LQCHK(op_apply_async(op, w.tmp, w.p, 0, fuse ? c->d_partial : nullptr));
@@ -288,7 +327,7 @@ static int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w
     LQCHK(blas_axpy(c, -1.0, 0.0, w.q->data, w.r->data, n));
     HIPCHK(hipMemcpyAsync(w.p->data, w.r->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     LQCHK(blas_norm2(c, w.r->data, n, rr0, true));
-    double init[8] = {*rr0, 0, 0, 0, 0, 0, eps, 0};
+    double init[9] = {*rr0, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;

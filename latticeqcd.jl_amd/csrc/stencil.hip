@@ -30,9 +30,31 @@ struct KArgs {
     int parity_mode;
     int nblocks;
     int remap;
-    int cps;   // chunks per t-slice per parity if the slice divides evenly into chunks and by 8, else 0 (remap 2)
+    int cps;   // chunks per t-slice per parity if the slice divides evenly into chunks and by nsub, else 0 (remap 2)
+    int nsub;  // sub-domains per t-slice (multiple of 8): XCD k sweeps sub-domains k, k+8, ... one after the other
+    int cpp;   // chunks per z-plane per parity
+    int ysplit;  // sub-domains are (y,z) tiles: ysplit tiles across y (1 = plain z-slabs)
+    int dbg;     // timing ablations only (wrong results): 1 skip x-hop spinor loads, 2 skip x-hop link loads, 3 skip mat-vec
     double* norm_partial;
+    const double* upd_scal;   // update mode (see StencilCall)
+    double2* upd[2];
 };
+
+// final store of one output component: plain (out = v) or CG update mode (r -= alpha v); accumulates the squared norm
+__device__ inline void emit(const KArgs& k, int p, size_t off, cd v, double& nrm) {
+    if (k.upd_scal) {
+        const double al = k.upd_scal[S_ALPHA];
+        double2* rp = k.upd[p] + off;
+        cd r = ld(rp);
+        r.re = fma(-al, v.re, r.re); r.im = fma(-al, v.im, r.im);
+        nrm = fma(r.re, r.re, nrm); nrm = fma(r.im, r.im, nrm);
+        st(rp, r);
+    } else {
+        nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+        st(k.out[p] + off, v);
+    }
+}
+__device__ inline bool upd_done(const KArgs& k) { return k.upd_scal && k.upd_scal[S_DONE] != 0.0; }
 
 struct HArgs {  // halo kernels
     Geom g;
@@ -60,11 +82,24 @@ __device__ inline void map_block(const KArgs& k, int& chunk, int& p) {
     const int b = blockIdx.x, nb = k.nblocks;
     const bool both = k.parity_mode == 2;
     if (k.remap == 2 && k.cps > 0) {
-        const int cpr = k.cps >> 3;                 // chunks per XCD per t-slice (per parity)
+        const int cpr = k.cps / k.nsub;             // chunks per sub-domain per t-slice (per parity)
         const int xcd = b & 7;
         int j = b >> 3;
         if (both) { p = j & 1; j >>= 1; } else p = k.parity_mode;
-        const int t = j / cpr, s = xcd * cpr + (j - t * cpr);
+        const int per_pass = cpr * k.g.L[3];
+        const int pass = j / per_pass;
+        j -= pass * per_pass;
+        const int t = j / cpr, m = j - t * cpr, sd = xcd + 8 * pass;
+        int s;
+        if (k.ysplit > 1) {
+            // 2-D tiling of the (y-chunk, z) grid of a t-slice: sub-domain sd = (sy, sz), tile ty x tz chunks
+            const int sy = sd % k.ysplit, sz = sd / k.ysplit;
+            const int ty = k.cpp / k.ysplit, tz = cpr / ty;
+            const int zz = m / ty, yy = m - zz * ty;
+            s = (sz * tz + zz) * k.cpp + sy * ty + yy;
+        } else {
+            s = sd * cpr + m;
+        }
         chunk = t * k.cps + s;
         return;
     }
@@ -241,11 +276,12 @@ __device__ inline void block_norm_partial(double v, double* partial) {
 // ------------------------------------------------------------------------------------------ Wilson
 template <int TB, bool DAG, bool RGEN>
 __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
+    if (upd_done(k)) return;
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vh;
+    const int Vh = k.g.Vs;  // component stride in sites (padded)
     const int i = chunk * TB + threadIdx.x;
-    const bool valid = i < Vh;
+    const bool valid = i < k.g.Vh;
     double nrm = 0.0;
     if (valid) {
         Nbr n;
@@ -277,12 +313,10 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
     }
         HOP(0) HOP(1) HOP(2) HOP(3)
 #undef HOP
-        double2* __restrict__ o = k.out[p] + i;
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             cd v = mk(fma(k.b, acc[j].re, k.a * xv[j].re), fma(k.b, acc[j].im, k.a * xv[j].im));
-            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
-            st(o + (size_t)j * Vh, v);
+            emit(k, p, (size_t)j * Vh + i, v, nrm);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
@@ -299,7 +333,7 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     Nbr n;
     int c[4];
     neighbours(k.g, p, i, n, c);
-    const int Vh = k.g.Vh;
+    const int Vh = k.g.Vs;  // component stride in sites (padded)
     const double2* __restrict__ psi = k.in[1 - p];
     const double2* __restrict__ Uf = k.gauge + ((size_t)(p * 4 + MU) * 9) * Vh + i;
     const double2* __restrict__ Ub = k.gauge + ((size_t)((1 - p) * 4 + MU) * 9) * Vh + n.bwd[MU];
@@ -312,13 +346,14 @@ template <bool DAG>
 __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     __shared__ double2 part[4][12][64];  // 48 KiB
     __shared__ double red[4];
+    if (upd_done(k)) return;
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vh;
+    const int Vh = k.g.Vs;  // component stride in sites (padded)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int i = chunk * 64 + lane;
-    const bool valid = i < Vh;
+    const bool valid = i < k.g.Vh;
     cd acc[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
@@ -341,7 +376,6 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     __syncthreads();
     double nrm = 0.0;
     if (valid) {
-        double2* __restrict__ o = k.out[p] + i;
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
             const int j = 3 * w + cc;
@@ -349,8 +383,7 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
             cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
             cd v = k.b * s;
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
-            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
-            st(o + (size_t)j * Vh, v);
+            emit(k, p, (size_t)j * Vh + i, v, nrm);
         }
     }
     if (k.norm_partial) {
@@ -393,12 +426,25 @@ __device__ inline cd combine_comp(const double2 (*half)[6][64], int lane) {
     return s0 + s1;
 }
 
-template <int MU, bool BWD, bool DAG>
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ inline void load_link_nt(cd (&u)[9], const double2* __restrict__ U, int Vh) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(U + (size_t)j * Vh));
+        u[j] = mk(v.x, v.y);
+    }
+}
+__device__ inline void st_nt(double2* p, cd v) {
+    v2d t = {v.re, v.im};
+    __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(p));
+}
+
+template <int MU, bool BWD, bool DAG, bool NTG>
 __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, int p, int i) {
     Nbr n;
     int c[4];
     neighbours(k.g, p, i, n, c);
-    const int Vh = k.g.Vh;
+    const int Vh = k.g.Vs;  // component stride in sites (padded)
     constexpr int S = (DAG ? -1 : 1) * (BWD ? -1 : 1);
     const double sign = BWD ? n.sb[MU] : n.sf[MU];
     const int nb = BWD ? n.bwd[MU] : n.fwd[MU];
@@ -409,44 +455,67 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
         const double2* __restrict__ U = BWD ? k.gauge + ((size_t)((1 - p) * 4 + MU) * 9) * Vh + nb
                                             : k.gauge + ((size_t)(p * 4 + MU) * 9) * Vh + i;
         cd h0[3], h1[3], u[9];
-        project<MU, S>(h0, h1, psi, Vh);
-        load_link(u, U, Vh);
+        if (MU == 0 && k.dbg == 1) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) { h0[cc] = mk(1.0 + nb, 2.0); h1[cc] = mk(3.0, 4.0 + nb); }
+        } else {
+            project<MU, S>(h0, h1, psi, Vh);
+        }
+        if (MU == 0 && k.dbg == 2) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) u[j] = mk(1.0 + j, nb);
+        } else {
+            // the backward hop is the LAST of the two uses of a link: optionally load it non-temporally
+            if constexpr (BWD && NTG) load_link_nt(u, U, Vh); else load_link(u, U, Vh);
+        }
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) { h0[cc] = sign * h0[cc]; h1[cc] = sign * h1[cc]; }
-        su3_mv<BWD>(chi0, u, h0);
-        su3_mv<BWD>(chi1, u, h1);
+        if (k.dbg == 3) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) { chi0[cc] = h0[cc] + u[cc] + u[3 + cc]; chi1[cc] = h1[cc] + u[6 + cc]; }
+        } else {
+            su3_mv<BWD>(chi0, u, h0);
+            su3_mv<BWD>(chi1, u, h1);
+        }
     }
 }
 
-template <bool DAG>
+// NT bit 0: non-temporal backward-link loads; bit 1: non-temporal output stores
+template <bool DAG, int NT>
 __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
+    constexpr bool NTG = (NT & 1) != 0, NTS = (NT & 2) != 0;
     __shared__ double2 half[8][6][64];  // 48 KiB
     __shared__ double red[8];
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vh;
+    const int Vh = k.g.Vs;  // component stride in sites (padded)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int i = chunk * 64 + lane;
-    const bool valid = i < Vh;
-    cd xv[2] = {mk(0, 0), mk(0, 0)};
+    const bool valid = i < k.g.Vh;
+    if (upd_done(k)) return;
+    cd xv[2] = {mk(0, 0), mk(0, 0)}, rv[2] = {mk(0, 0), mk(0, 0)};
     if (valid && w < 6 && k.a != 0.0) {
         xv[0] = ld(k.xin[p] + i + (size_t)(2 * w) * Vh);
         xv[1] = ld(k.xin[p] + i + (size_t)(2 * w + 1) * Vh);
+    }
+    if (valid && w < 6 && k.upd_scal) {
+        rv[0] = ld(k.upd[p] + i + (size_t)(2 * w) * Vh);
+        rv[1] = ld(k.upd[p] + i + (size_t)(2 * w + 1) * Vh);
     }
     cd chi0[3], chi1[3];
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) { chi0[cc] = mk(0, 0); chi1[cc] = mk(0, 0); }
     if (valid) {
         switch (w) {
-        case 0: hop_half<0, false, DAG>(chi0, chi1, k, p, i); break;
-        case 1: hop_half<0, true, DAG>(chi0, chi1, k, p, i); break;
-        case 2: hop_half<1, false, DAG>(chi0, chi1, k, p, i); break;
-        case 3: hop_half<1, true, DAG>(chi0, chi1, k, p, i); break;
-        case 4: hop_half<2, false, DAG>(chi0, chi1, k, p, i); break;
-        case 5: hop_half<2, true, DAG>(chi0, chi1, k, p, i); break;
-        case 6: hop_half<3, false, DAG>(chi0, chi1, k, p, i); break;
-        default: hop_half<3, true, DAG>(chi0, chi1, k, p, i); break;
+        case 0: hop_half<0, false, DAG, NTG>(chi0, chi1, k, p, i); break;
+        case 1: hop_half<0, true, DAG, NTG>(chi0, chi1, k, p, i); break;
+        case 2: hop_half<1, false, DAG, NTG>(chi0, chi1, k, p, i); break;
+        case 3: hop_half<1, true, DAG, NTG>(chi0, chi1, k, p, i); break;
+        case 4: hop_half<2, false, DAG, NTG>(chi0, chi1, k, p, i); break;
+        case 5: hop_half<2, true, DAG, NTG>(chi0, chi1, k, p, i); break;
+        case 6: hop_half<3, false, DAG, NTG>(chi0, chi1, k, p, i); break;
+        default: hop_half<3, true, DAG, NTG>(chi0, chi1, k, p, i); break;
         }
     }
 #pragma unroll
@@ -466,12 +535,21 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
         case 4: s0 = combine_comp<8, DAG>(half, lane); s1 = combine_comp<9, DAG>(half, lane); break;
         default: s0 = combine_comp<10, DAG>(half, lane); s1 = combine_comp<11, DAG>(half, lane); break;
         }
-        double2* __restrict__ o = k.out[p] + i + (size_t)(2 * w) * Vh;
         cd v0 = mk(fma(k.a, xv[0].re, k.b * s0.re), fma(k.a, xv[0].im, k.b * s0.im));
         cd v1 = mk(fma(k.a, xv[1].re, k.b * s1.re), fma(k.a, xv[1].im, k.b * s1.im));
-        nrm = v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
-        st(o, v0);
-        st(o + Vh, v1);
+        if (k.upd_scal) {
+            // CG update mode: r (prefetched at kernel start) <- r - alpha v ; q is never written
+            const double al = k.upd_scal[S_ALPHA];
+            cd r0 = mk(fma(-al, v0.re, rv[0].re), fma(-al, v0.im, rv[0].im));
+            cd r1 = mk(fma(-al, v1.re, rv[1].re), fma(-al, v1.im, rv[1].im));
+            nrm = r0.re * r0.re + r0.im * r0.im + r1.re * r1.re + r1.im * r1.im;
+            double2* __restrict__ o = k.upd[p] + i + (size_t)(2 * w) * Vh;
+            st(o, r0); st(o + Vh, r1);
+        } else {
+            double2* __restrict__ o = k.out[p] + i + (size_t)(2 * w) * Vh;
+            nrm = v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
+            if constexpr (NTS) { st_nt(o, v0); st_nt(o + Vh, v1); } else { st(o, v0); st(o + Vh, v1); }
+        }
     }
     if (k.norm_partial) {
 #pragma unroll
@@ -504,11 +582,12 @@ __device__ inline double stag_eta(const int c[4], int mu) {
 
 template <int TB>
 __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
+    if (upd_done(k)) return;
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vh;
+    const int Vh = k.g.Vs;  // component stride in sites (padded)
     const int i = chunk * TB + threadIdx.x;
-    const bool valid = i < Vh;
+    const bool valid = i < k.g.Vh;
     double nrm = 0.0;
     if (valid) {
         Nbr n;
@@ -532,8 +611,7 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
                 cd xv = ld(k.xin[p] + i + (size_t)j * Vh);
                 v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
             }
-            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
-            st(o + (size_t)j * Vh, v);
+            emit(k, p, (size_t)j * Vh + i, v, nrm);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
@@ -546,7 +624,7 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
 template <int MU>
 __device__ inline void wilson_pack_dir(const HArgs& k, int side, int slot, int pout, int f) {
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, MU), Vh = g.Vh;
+    const int Fh = face_half_sites(g, MU), Vh = g.Vs;
     const int ps = 1 - pout;  // parity of the site being packed
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
@@ -599,7 +677,7 @@ __global__ __launch_bounds__(128) void wilson_pack(HArgs k) {
 template <int MU>
 __device__ inline void wilson_ext_dir(const HArgs& k, int side, int slot, int pout, int f) {
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, MU), Vh = g.Vh;
+    const int Fh = face_half_sites(g, MU), Vh = g.Vs;
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, pout, f, c);
     const int i = coords_to_cb(g, c);
@@ -662,7 +740,7 @@ __global__ __launch_bounds__(128) void staggered_pack(HArgs k) {
     const int mu = blockIdx.y >> 1, side = blockIdx.y & 1;
     if (!k.g.part[mu]) return;
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, mu), Vh = g.Vh;
+    const int Fh = face_half_sites(g, mu), Vh = g.Vs;
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslots * Fh) return;
@@ -694,7 +772,7 @@ __global__ __launch_bounds__(128) void staggered_pack(HArgs k) {
 __global__ __launch_bounds__(128) void staggered_exterior(HArgs k, int mu) {
     const int side = blockIdx.y;
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, mu), Vh = g.Vh;
+    const int Fh = face_half_sites(g, mu), Vh = g.Vs;
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslots * Fh) return;
@@ -741,8 +819,17 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.nblocks = chunks * (s.parity_mode == 2 ? 2 : 1);
     k.remap = c->tun.xcd_remap;
     const int slice = c->geom.XH * c->geom.L[1] * c->geom.L[2];  // sites per parity per t-slice
-    k.cps = (slice % TB == 0 && (slice / TB) % 8 == 0) ? slice / TB : 0;
+    k.nsub = (c->tun.xcd_nsub >= 8 && c->tun.xcd_nsub % 8 == 0) ? c->tun.xcd_nsub : 8;
+    k.cps = (slice % TB == 0 && (slice / TB) % k.nsub == 0) ? slice / TB : 0;
+    const int plane = c->geom.XH * c->geom.L[1];
+    k.cpp = (plane % TB == 0) ? plane / TB : 0;
+    k.ysplit = 1;
+    k.dbg = c->tun.dbg;
+    const int ys = c->tun.xcd_ysplit;
+    if (ys > 1 && k.cps > 0 && k.cpp > 0 && k.cpp % ys == 0 && k.nsub % ys == 0 && c->geom.L[2] % (k.nsub / ys) == 0) k.ysplit = ys;
     k.norm_partial = s.norm_partial;
+    k.upd_scal = s.upd_scal;
+    k.upd[0] = s.upd[0]; k.upd[1] = s.upd[1];
     return k;
 }
 
@@ -782,8 +869,11 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
         if (c->tun.dslash_variant == 2) {
             dim3 grid(k.nblocks), block(512);
-            if (s.dagger) hipLaunchKernelGGL((wilson_hopsplit<true>), grid, block, pad, c->stream, k);
-            else hipLaunchKernelGGL((wilson_hopsplit<false>), grid, block, pad, c->stream, k);
+            const int nt = (c->tun.nt_gauge ? 1 : 0) | (c->tun.nt_store ? 2 : 0);
+#define LQ_HS(D, N) hipLaunchKernelGGL((wilson_hopsplit<D, N>), grid, block, pad, c->stream, k)
+            if (s.dagger) { switch (nt) { case 1: LQ_HS(true, 1); break; case 2: LQ_HS(true, 2); break; case 3: LQ_HS(true, 3); break; default: LQ_HS(true, 0); } }
+            else { switch (nt) { case 1: LQ_HS(false, 1); break; case 2: LQ_HS(false, 2); break; case 3: LQ_HS(false, 3); break; default: LQ_HS(false, 0); } }
+#undef LQ_HS
         } else {
             dim3 grid(k.nblocks), block(256);
             if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true>), grid, block, pad, c->stream, k);

@@ -277,11 +277,15 @@ def test_cg_matches_oracle_on_reference_fixture(gpu, orc):
     assert rel_err(x.download(), xo) < 1e-9
     res = b_h - orc.wilson_D(U, orc.wilson_D(U, x.download(), L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True)
     assert np.vdot(res, res).real < 1e-18
-    # unfused reference form (c1 = p.q) gives the same answer
-    lat.set_param("cg_fused", 0)
-    x2 = b.similar()
-    it2, rr2 = lq.solve_DinvX_(x2, lq.DdagD_operator(D), b, return_info=True)
-    assert abs(it2 - it) <= 1 and rel_err(x2.download(), xo) < 1e-9
+    # the less fused forms (1: |Dp|^2 from the stencil; 0: the reference's literal c1 = p.q) give the same answer,
+    # for every stencil variant
+    for variant in (0, 1, 2):
+        lat.set_param("dslash_variant", variant)
+        for fused in (2, 1, 0):
+            lat.set_param("cg_fused", fused)
+            x2 = b.similar()
+            it2, rr2 = lq.solve_DinvX_(x2, lq.DdagD_operator(D), b, return_info=True)
+            assert abs(it2 - ito) <= 1 and rr2 < 1e-19 and rel_err(x2.download(), xo) < 1e-9, (variant, fused)
 
 
 def test_staggered_cg_8x8x8x8(gpu, orc):
