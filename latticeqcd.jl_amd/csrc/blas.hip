@@ -44,24 +44,50 @@ __global__ __launch_bounds__(RB) void norm2_kernel(const double2* __restrict__ a
     block_reduce2(s, 0.0, partial, 1);
 }
 
-// sums nblocks partials of `nvals` interleaved values into out[0..nvals)
-__global__ __launch_bounds__(RB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* out) {
-    __shared__ double red[RB / 64];
+// sums nblocks partials of `nvals` interleaved values into scal[slot..slot+nvals) in a fixed order (1024 threads, each a
+// strided partial sum, then a wave/LDS tree), optionally followed by a CG scalar step on the same thread (single rank):
+//   op 1: alpha = rr / pq      op 2: beta = rr'/rr, rr = rr', iters++, done = rr' < eps     (flags: see ops.hip)
+constexpr int FB = 1024;
+__device__ inline void cg_scalar_step(double* s, int op) {
+    if (op == 1) {
+        if (s[S_DONE] != 0.0) { s[S_XDONE] = 1.0; return; }
+        s[S_ALPHA] = s[S_RR] / s[S_PQ];
+    } else if (op == 2) {
+        if (s[S_DONE] != 0.0) return;
+        const double rrn = s[S_RRNEW];
+        s[S_BETA] = rrn / s[S_RR];
+        s[S_RR] = rrn;
+        s[S_ITERS] += 1.0;
+        if (rrn < s[S_EPS]) s[S_DONE] = 1.0;
+    }
+}
+__global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op) {
+    __shared__ double red[FB / 64];
     for (int v = 0; v < nvals; v++) {
-        double s = 0;
-        for (int i = threadIdx.x; i < nblocks; i += RB) s += partial[(size_t)i * nvals + v];
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int i = threadIdx.x;
+        for (; i + 3 * FB < nblocks; i += 4 * FB) {
+            s0 += partial[(size_t)i * nvals + v];
+            s1 += partial[(size_t)(i + FB) * nvals + v];
+            s2 += partial[(size_t)(i + 2 * FB) * nvals + v];
+            s3 += partial[(size_t)(i + 3 * FB) * nvals + v];
+        }
+        for (; i < nblocks; i += FB) s0 += partial[(size_t)i * nvals + v];
+        double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0;
-            for (int w = 0; w < RB / 64; w++) t += red[w];
-            out[v] = t;
+            for (int w = 0; w < FB / 64; w++) t += red[w];
+            scal[slot + v] = t;
         }
         __syncthreads();
     }
+    if (op && threadIdx.x == 0) cg_scalar_step(scal, op);
 }
+__global__ void cg_scalar_kernel(double* s, int op) { cg_scalar_step(s, op); }
 
 __global__ __launch_bounds__(RB) void axpy_kernel(double ar, double ai, const double2* __restrict__ x, double2* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n; i += (size_t)gridDim.x * RB) {
@@ -112,11 +138,17 @@ int allreduce_host(lqcd_ctx_s* c, double* vals, int n) {
 }
 
 // device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks
-int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce) {
-    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(RB), 0, c->stream, c->d_partial, nblocks, nvals, c->d_scal + slot);
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op) {
+    const bool multi = allreduce && c->nranks > 1 && c->has_comm;
+    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, c->d_partial, nblocks, nvals, c->d_scal, slot, multi ? 0 : cg_op);
     HIPCHK(hipGetLastError());
-    if (allreduce && c->nranks > 1 && c->has_comm)
+    if (multi) {
         NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm, c->stream));
+        if (cg_op) {
+            hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
+            HIPCHK(hipGetLastError());
+        }
+    }
     return LQCD_OK;
 }
 
@@ -132,7 +164,7 @@ int blas_dot(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, double
     const int nb = stream_grid(c, n);
     hipLaunchKernelGGL(dot_kernel, dim3(nb), dim3(RB), 0, c->stream, a, b, n, c->d_partial);
     HIPCHK(hipGetLastError());
-    LQCHK(reduce_to_slot(c, nb, 2, 0, allreduce));
+    LQCHK(reduce_to_slot(c, nb, 2, 0, allreduce, 0));
     double v[2];
     LQCHK(fetch_slot(c, 0, 2, v));
     *re = v[0];
@@ -145,7 +177,7 @@ int blas_norm2(lqcd_ctx_s* c, const double2* a, size_t n, double* n2, bool allre
     const int nb = stream_grid(c, n);
     hipLaunchKernelGGL(norm2_kernel, dim3(nb), dim3(RB), 0, c->stream, a, n, c->d_partial);
     HIPCHK(hipGetLastError());
-    LQCHK(reduce_to_slot(c, nb, 1, 0, allreduce));
+    LQCHK(reduce_to_slot(c, nb, 1, 0, allreduce, 0));
     return fetch_slot(c, 0, 1, n2);
 }
 

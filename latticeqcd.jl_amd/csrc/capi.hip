@@ -212,6 +212,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "xcd_nsub")) return &c->tun.xcd_nsub;
     if (!strcmp(key, "xcd_ysplit")) return &c->tun.xcd_ysplit;
     if (!strcmp(key, "dbg")) return &c->tun.dbg;
+    if (!strcmp(key, "persist_per_cu")) return &c->tun.persist_per_cu;
     return nullptr;
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {

@@ -121,6 +121,7 @@ struct Tunables {
     int nt_store = 0;         // non-temporal stores for the output spinor
     int cg_fused = 2;         // 0: reference form (c1 = p.q), 1: |Dp|^2 from the stencil, 2: + r-update fused into D^+, x/p updates merged
     int graph = 0;            // capture solver iterations in a hipGraph
+    int persist_per_cu = 2;   // variant 3: resident workgroups per CU
     int dbg = 0;              // timing ablations (results are wrong when non-zero)
     int xcd_ysplit = 4;       // remap 2: tile the sub-domains in (y,z) instead of plain z-slabs
     int xcd_nsub = 16;       // remap 2: sub-domains per t-slice (multiple of 8)
@@ -244,7 +245,7 @@ int blas_axpy(lqcd_ctx_s* c, double ar, double ai, const double2* x, double2* y,
 int blas_axpby(lqcd_ctx_s* c, double ar, double ai, const double2* x, double br, double bi, double2* y, size_t n);
 int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n);
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n);
-int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce);
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0);
 int stream_grid(lqcd_ctx_s* c, size_t n);
 
 // fields.hip

@@ -12,7 +12,6 @@
 namespace lqcd {
 
 double2* spinor_block(lqcd_spinor_s* s, int p);
-int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce);
 int stream_grid(lqcd_ctx_s* c, size_t n);
 
 // ---------------------------------------------------------------------------------- halo exchange
@@ -268,8 +267,7 @@ static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w
         //   beta, convergence ; x += alpha p, p = r + beta p
         const int nbs = stencil_num_blocks(c, op->kind, op->r, 2);
         LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial));
-        LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true));
-        hipLaunchKernelGGL(cg_scalar_alpha, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+        LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);
         StencilCall s2 = make_full_call(op, w.q, w.tmp, 1);
         s2.norm_partial = c->d_partial;
@@ -277,8 +275,7 @@ static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w
         s2.upd[0] = spinor_block(w.r, 0);
         s2.upd[1] = spinor_block(w.r, 1);
         LQCHK(stencil_apply(c, s2));
-        LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true));
-        hipLaunchKernelGGL(cg_scalar_beta, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+        LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));   // + beta, convergence flag
         const int nbu = stream_grid(c, n);
         hipLaunchKernelGGL(cg_update_xp, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
         HIPCHK(hipGetLastError());

@@ -78,8 +78,8 @@ struct HArgs {  // halo kernels
 //   remap 1: XCD k owns a contiguous 1/8 of the chunk list (a t-slab), even/odd of a chunk back to back
 //   remap 2: XCD k owns 1/8 of every t-slice (a z-slab) and sweeps t: the t-neighbour re-use distance is one slab step
 //            (fits the 4 MiB L2) and the 8 XCDs advance through t together (z-halo lines are shared through the MALL)
-__device__ inline void map_block(const KArgs& k, int& chunk, int& p) {
-    const int b = blockIdx.x, nb = k.nblocks;
+__device__ inline void map_block_v(const KArgs& k, int b, int& chunk, int& p) {
+    const int nb = k.nblocks;
     const bool both = k.parity_mode == 2;
     if (k.remap == 2 && k.cps > 0) {
         const int cpr = k.cps / k.nsub;             // chunks per sub-domain per t-slice (per parity)
@@ -107,6 +107,8 @@ __device__ inline void map_block(const KArgs& k, int& chunk, int& p) {
     if (k.remap && !(nb & 7)) lb = (b & 7) * (nb >> 3) + (b >> 3);
     if (both) { chunk = lb >> 1; p = lb & 1; } else { chunk = lb; p = k.parity_mode; }
 }
+
+__device__ inline void map_block(const KArgs& k, int& chunk, int& p) { map_block_v(k, blockIdx.x, chunk, p); }
 
 // gamma_mu (mu = 0,1,2) has one entry per row: row a -> column PERM[mu][a], value i^GK[mu][a]
 // (SURVEY.md Appendix A).  gamma_4 = diag(1,1,-1,-1).
@@ -439,6 +441,56 @@ __device__ inline void st_nt(double2* p, cd v) {
     __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(p));
 }
 
+template <int MU, int S>
+__device__ inline void project_regs(cd (&h0)[3], cd (&h1)[3], const cd* sp) {
+    if constexpr (MU < 3) {
+        constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
+        constexpr int k0 = GK[MU][0] + (S > 0 ? 2 : 0), k1 = GK[MU][1] + (S > 0 ? 2 : 0);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            h0[c] = sp[c] + mul_ipow<k0>(sp[p0 * 3 + c]);
+            h1[c] = sp[3 + c] + mul_ipow<k1>(sp[p1 * 3 + c]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { h0[c] = 2.0 * sp[c]; h1[c] = 2.0 * sp[3 + c]; }
+    }
+}
+
+// Buffer-addressed loads: the SRD (base, size) lives in SGPRs, every lane supplies ONE 32-bit byte offset and the component
+// stride goes into the scalar offset -- no per-load 64-bit address VGPR pair / v_lshl_add_u64 (21 of them per hop otherwise).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+__device__ inline __amdgpu_buffer_rsrc_t mkbuf(const double2* p, size_t elems) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const size_t bytes = elems * sizeof(double2);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes, 0x00020000);
+}
+__device__ inline cd bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    double2 d;
+    __builtin_memcpy(&d, &v, sizeof(d));
+    return mk(d.x, d.y);
+}
+// raw spinor components a hop needs (12, or the 6 the t projector keeps) and the link, all issued back to back
+template <int MU, int S>
+__device__ inline void load_hop_regs(cd* sp, cd (&u)[9], const double2* psi_block, const double2* link_block, unsigned Vs,
+                                     unsigned psi_site, unsigned link_site) {
+    const __amdgpu_buffer_rsrc_t rp = mkbuf(psi_block, (size_t)12 * Vs), ru = mkbuf(link_block, (size_t)9 * Vs);
+    const unsigned vp = psi_site * 16u, vu = link_site * 16u, cs = Vs * 16u;
+    if constexpr (MU < 3) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) sp[j] = bld(rp, vp, (unsigned)j * cs);
+    } else {
+        constexpr int base = S > 0 ? 2 : 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) sp[j] = bld(rp, vp, (unsigned)(base * 3 + j) * cs);
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) u[j] = bld(ru, vu, (unsigned)j * cs);
+}
+
 template <int MU, bool BWD, bool DAG, bool NTG>
 __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, int p, int i) {
     Nbr n;
@@ -455,18 +507,27 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
         const double2* __restrict__ U = BWD ? k.gauge + ((size_t)((1 - p) * 4 + MU) * 9) * Vh + nb
                                             : k.gauge + ((size_t)(p * 4 + MU) * 9) * Vh + i;
         cd h0[3], h1[3], u[9];
-        if (MU == 0 && k.dbg == 1) {
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) { h0[cc] = mk(1.0 + nb, 2.0); h1[cc] = mk(3.0, 4.0 + nb); }
+        constexpr bool USE_BUF = false;   // measured: buffer-addressed loads are ~5 % slower than flat loads here (profiles/)
+        if (USE_BUF && k.dbg == 0 && !(BWD && NTG)) {
+            cd sp[MU < 3 ? 12 : 6];
+            const int pp = BWD ? 1 - p : p;
+            load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge + ((size_t)(pp * 4 + MU) * 9) * Vh, (unsigned)Vh, (unsigned)nb,
+                                 (unsigned)(BWD ? nb : i));
+            project_regs<MU, S>(h0, h1, sp);
         } else {
-            project<MU, S>(h0, h1, psi, Vh);
-        }
-        if (MU == 0 && k.dbg == 2) {
+            if (MU == 0 && k.dbg == 1) {
 #pragma unroll
-            for (int j = 0; j < 9; j++) u[j] = mk(1.0 + j, nb);
-        } else {
-            // the backward hop is the LAST of the two uses of a link: optionally load it non-temporally
-            if constexpr (BWD && NTG) load_link_nt(u, U, Vh); else load_link(u, U, Vh);
+                for (int cc = 0; cc < 3; cc++) { h0[cc] = mk(1.0 + nb, 2.0); h1[cc] = mk(3.0, 4.0 + nb); }
+            } else {
+                project<MU, S>(h0, h1, psi, Vh);
+            }
+            if (MU == 0 && k.dbg == 2) {
+#pragma unroll
+                for (int j = 0; j < 9; j++) u[j] = mk(1.0 + j, nb);
+            } else {
+                // the backward hop is the LAST of the two uses of a link: optionally load it non-temporally
+                if constexpr (BWD && NTG) load_link_nt(u, U, Vh); else load_link(u, U, Vh);
+            }
         }
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) { h0[cc] = sign * h0[cc]; h1[cc] = sign * h1[cc]; }
@@ -558,6 +619,130 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
         __syncthreads();
         if (threadIdx.x == 0)
             k.norm_partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Wilson, hop-split, persistent
+// Variant 3: the hop-split kernel as a persistent, software-pipelined loop.  The stencil is latency/MLP-bound (halving the
+// resident workgroups costs only 1.3x, removing L2-miss traffic changes nothing -- profiles/), so the idle part of a
+// workgroup's life matters: launch + index arithmetic before the first load, and barrier + LDS combine + store after the
+// last one.  Here 2 workgroups per CU stay resident and walk the XCD's chunk sequence; every hop wave issues the 21 loads
+// of its NEXT chunk before it enters the barrier/combine of the current one, so the memory system always has work.
+template <int MU, bool BWD, bool DAG>
+__device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][64], double* red, int nvirt) {
+    constexpr int W = 2 * MU + (BWD ? 1 : 0);
+    constexpr int S = (DAG ? -1 : 1) * (BWD ? -1 : 1);
+    constexpr int NS = (MU < 3) ? 12 : 6;   // spinor components this hop reads
+    const int Vh = k.g.Vs;
+    const int lane = threadIdx.x & 63;
+    double nrm = 0.0;
+    cd sp[NS], u[9];
+    double sign = 0.0;
+    int i = 0, p = 0;
+    bool valid = false;
+
+    auto issue = [&](int vb) {
+        int chunk;
+        map_block_v(k, vb, chunk, p);
+        i = chunk * 64 + lane;
+        valid = i < k.g.Vh;
+        sign = 0.0;
+        if (valid) {
+            Nbr n;
+            int c[4];
+            neighbours(k.g, p, i, n, c);
+            sign = BWD ? n.sb[MU] : n.sf[MU];
+            const int nb = BWD ? n.bwd[MU] : n.fwd[MU];
+            if (sign != 0.0) {
+                const int pp = BWD ? 1 - p : p;
+                load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge + ((size_t)(pp * 4 + MU) * 9) * Vh, (unsigned)Vh, (unsigned)nb,
+                                     (unsigned)(BWD ? nb : i));
+            }
+        }
+    };
+
+    int vb = blockIdx.x;
+    issue(vb);
+    for (;;) {
+        cd chi0[3], chi1[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { chi0[cc] = mk(0, 0); chi1[cc] = mk(0, 0); }
+        if (valid && sign != 0.0) {
+            cd h0[3], h1[3];
+            project_regs<MU, S>(h0, h1, sp);
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) { h0[cc] = sign * h0[cc]; h1[cc] = sign * h1[cc]; }
+            su3_mv<BWD>(chi0, u, h0);
+            su3_mv<BWD>(chi1, u, h1);
+        }
+        const int ci = i, cp = p;
+        const bool cvalid = valid;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            half[W][cc][lane] = make_double2(chi0[cc].re, chi0[cc].im);
+            half[W][3 + cc][lane] = make_double2(chi1[cc].re, chi1[cc].im);
+        }
+        // operands of THIS chunk's epilogue first (they return first), then the NEXT chunk's hop loads
+        cd xv[2] = {mk(0, 0), mk(0, 0)}, rv[2] = {mk(0, 0), mk(0, 0)};
+        if constexpr (W < 6) {
+            if (cvalid && k.a != 0.0) {
+                xv[0] = ld(k.xin[cp] + ci + (size_t)(2 * W) * Vh);
+                xv[1] = ld(k.xin[cp] + ci + (size_t)(2 * W + 1) * Vh);
+            }
+            if (cvalid && k.upd_scal) {
+                rv[0] = ld(k.upd[cp] + ci + (size_t)(2 * W) * Vh);
+                rv[1] = ld(k.upd[cp] + ci + (size_t)(2 * W + 1) * Vh);
+            }
+        }
+        const int vb2 = vb + gridDim.x;
+        const bool more = vb2 < nvirt;
+        if (more) issue(vb2);
+        __syncthreads();   // every hop of chunk vb is in LDS
+        if constexpr (W < 6) {
+            if (cvalid) {
+                const cd s0 = combine_comp<2 * W, DAG>(half, lane), s1 = combine_comp<2 * W + 1, DAG>(half, lane);
+                cd v0 = mk(fma(k.a, xv[0].re, k.b * s0.re), fma(k.a, xv[0].im, k.b * s0.im));
+                cd v1 = mk(fma(k.a, xv[1].re, k.b * s1.re), fma(k.a, xv[1].im, k.b * s1.im));
+                if (k.upd_scal) {
+                    const double al = k.upd_scal[S_ALPHA];
+                    v0 = mk(fma(-al, v0.re, rv[0].re), fma(-al, v0.im, rv[0].im));
+                    v1 = mk(fma(-al, v1.re, rv[1].re), fma(-al, v1.im, rv[1].im));
+                }
+                nrm += v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
+                double2* __restrict__ o = (k.upd_scal ? k.upd[cp] : k.out[cp]) + ci + (size_t)(2 * W) * Vh;
+                st(o, v0);
+                st(o + Vh, v1);
+            }
+        }
+        __syncthreads();   // LDS is free again
+        if (!more) break;
+        vb = vb2;
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[W] = nrm;
+        __syncthreads();
+        if (W == 0 && lane == 0)
+            k.norm_partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    }
+}
+
+template <bool DAG>
+__global__ __launch_bounds__(512, 4) void wilson_hopsplit_persist(KArgs k, int nvirt) {
+    __shared__ double2 half[8][6][64];  // 48 KiB
+    __shared__ double red[8];
+    if (upd_done(k)) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (w) {
+    case 0: hopsplit_persist_loop<0, false, DAG>(k, half, red, nvirt); break;
+    case 1: hopsplit_persist_loop<0, true, DAG>(k, half, red, nvirt); break;
+    case 2: hopsplit_persist_loop<1, false, DAG>(k, half, red, nvirt); break;
+    case 3: hopsplit_persist_loop<1, true, DAG>(k, half, red, nvirt); break;
+    case 4: hopsplit_persist_loop<2, false, DAG>(k, half, red, nvirt); break;
+    case 5: hopsplit_persist_loop<2, true, DAG>(k, half, red, nvirt); break;
+    case 6: hopsplit_persist_loop<3, false, DAG>(k, half, red, nvirt); break;
+    default: hopsplit_persist_loop<3, true, DAG>(k, half, red, nvirt); break;
     }
 }
 
@@ -833,13 +1018,22 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     return k;
 }
 
-static bool use_dirsplit(lqcd_ctx_s* c, int kind, double r) {   // variants 1/2 work on 64-site chunks
-    return (c->tun.dslash_variant == 1 || c->tun.dslash_variant == 2) && kind == LQCD_WILSON && r == 1.0;
+static bool use_dirsplit(lqcd_ctx_s* c, int kind, double r) {   // variants 1/2/3 work on 64-site chunks
+    return (c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 3) && kind == LQCD_WILSON && r == 1.0;
+}
+static int persist_grid(lqcd_ctx_s* c, int nvirt) {
+    int g = c->num_cu * (c->tun.persist_per_cu > 0 ? c->tun.persist_per_cu : 2);
+    g -= g % 8;
+    if (g < 8) g = 8;
+    return std::min(g, nvirt);
 }
 
+// number of |.|^2 block partials the interior kernel writes
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
     const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
-    return ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
+    const int nvirt = ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
+    if (use_dirsplit(c, kind, r) && c->tun.dslash_variant == 3) return persist_grid(c, nvirt);
+    return nvirt;
 }
 
 template <int TB>
@@ -867,7 +1061,11 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
     if (use_dirsplit(c, s.kind, s.r)) {
         KArgs k = make_kargs(c, s, 64);
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
-        if (c->tun.dslash_variant == 2) {
+        if (c->tun.dslash_variant == 3) {
+            dim3 grid(persist_grid(c, k.nblocks)), block(512);
+            if (s.dagger) hipLaunchKernelGGL((wilson_hopsplit_persist<true>), grid, block, pad, c->stream, k, k.nblocks);
+            else hipLaunchKernelGGL((wilson_hopsplit_persist<false>), grid, block, pad, c->stream, k, k.nblocks);
+        } else if (c->tun.dslash_variant == 2) {
             dim3 grid(k.nblocks), block(512);
             const int nt = (c->tun.nt_gauge ? 1 : 0) | (c->tun.nt_store ? 2 : 0);
 #define LQ_HS(D, N) hipLaunchKernelGGL((wilson_hopsplit<D, N>), grid, block, pad, c->stream, k)

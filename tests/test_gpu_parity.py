@@ -138,7 +138,7 @@ def test_wilson_dslash_kernel_variants(gpu, orc, block, remap):
 @pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2), (16, 8, 4, 4), (6, 2, 2, 2)])
 @pytest.mark.parametrize("dagger", [False, True])
 @pytest.mark.parametrize("remap", [0, 1, 2])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_wilson_dirsplit_variant_matches_oracle(gpu, orc, L, dagger, remap, variant):
     """dslash_variant = 1: four waves per 64 sites (one per direction); 2: eight waves (one per hop); LDS combine."""
     lq = gpu
@@ -279,7 +279,7 @@ def test_cg_matches_oracle_on_reference_fixture(gpu, orc):
     assert np.vdot(res, res).real < 1e-18
     # the less fused forms (1: |Dp|^2 from the stencil; 0: the reference's literal c1 = p.q) give the same answer,
     # for every stencil variant
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         lat.set_param("dslash_variant", variant)
         for fused in (2, 1, 0):
             lat.set_param("cg_fused", fused)
