@@ -28,6 +28,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 WILSON_FLOP_PER_SITE = 1320
 WILSON_BYTES_PER_SITE = 960    # read psi 192 + 4 links 576 + write 192
 KAPPA = 0.141139
+KERNEL_NAMES = {0: "wilson_interior", 1: "wilson_dirsplit", 2: "wilson_hopsplit", 3: "wilson_hopsplit_persist"}
 
 
 def main():
@@ -137,11 +138,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic (hot-start SU(3) links seed 111, Gaussian source seed 112, kappa=0.141139, BC=[1,1,1,-1])",
         "config": {"workload": "configs[3]: %dx%dx%dx%d Wilson D^+D CG (fixed-length window), fp64" % gL,
-                   "pe_grid": list(pe), "local_lattice": list(lat.local_L), "dslash_block": lat.get_param("dslash_block"),
-                   "xcd_remap": lat.get_param("xcd_remap")},
+                   "pe_grid": list(pe), "local_lattice": list(lat.local_L), "dslash_variant": lat.get_param("dslash_variant"),
+                   "xcd_remap": lat.get_param("xcd_remap"), "xcd_nsub": lat.get_param("xcd_nsub"),
+                   "xcd_ysplit": lat.get_param("xcd_ysplit"), "cg_fused": lat.get_param("cg_fused")},
         "dslash_gflops": dslash_gflops,
         "dslash_ms": ms_dslash,
-        "roofline": {"bound": "hbm", "kernel": "wilson_interior (mul!(y,D,x))", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(lat.get_param("dslash_variant"), "wilson") + " (mul!(y,D,x))", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc},
     }

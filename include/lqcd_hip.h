@@ -73,11 +73,11 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
 int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);
 
-/* RCCL bootstrap for one-process-per-GPU runs: rank 0 creates the id, the host broadcasts the 128 bytes
- * (torch.distributed / MPI.jl), every rank calls lqcd_ctx_comm_init.  Replaces the MPI.Init / PEs plumbing of
- * src/mpi/mpimodule.jl:4-13. */
-int lqcd_comm_unique_id(unsigned char id[128]);
-int lqcd_ctx_comm_init(lqcd_ctx_t ctx, const unsigned char id[128], int nranks);
+/* RCCL bootstrap for one-process-per-GPU runs: rank 0 creates the id blob (two ncclUniqueIds: one communicator for halos,
+ * one for reductions), the host broadcasts the 256 bytes (torch.distributed / MPI.jl), every rank calls
+ * lqcd_ctx_comm_init.  Replaces the MPI.Init / PEs plumbing of src/mpi/mpimodule.jl:4-13. */
+int lqcd_comm_unique_id(unsigned char id[256]);
+int lqcd_ctx_comm_init(lqcd_ctx_t ctx, const unsigned char id[256], int nranks);
 /* in-process emulation of a PE grid on ONE device (testing the halo path without RCCL): link `n` contexts that
  * were created with ranks 0..n-1 of the same pe_grid; afterwards use the lqcd_mdom_* collectives below. */
 int lqcd_ctx_link_local(lqcd_ctx_t* ctxs, int n);

@@ -131,7 +131,7 @@ int allreduce_host(lqcd_ctx_s* c, double* vals, int n) {
     ARGCHK(n <= 8, "allreduce_host: too many values");
     double* d = c->d_scal + SCAL_DOUBLES - 8;
     HIPCHK(hipMemcpyAsync(d, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(ncclAllReduce(d, d, n, ncclDouble, ncclSum, c->comm, c->stream));
+    NCCLCHK(ncclAllReduce(d, d, n, ncclDouble, ncclSum, c->comm_red, c->stream));
     HIPCHK(hipMemcpyAsync(vals, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
@@ -143,7 +143,7 @@ int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allredu
     hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, c->d_partial, nblocks, nvals, c->d_scal, slot, multi ? 0 : cg_op);
     HIPCHK(hipGetLastError());
     if (multi) {
-        NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm, c->stream));
+        NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm_red, c->stream));
         if (cg_op) {
             hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
             HIPCHK(hipGetLastError());

@@ -149,6 +149,13 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
         c->geom.gL[mu] = gL[mu]; c->geom.origin[mu] = origin[mu];
         c->geom.part[mu] = pe[mu] > 1 ? 1 : 0;
     }
+    // testing aid: LQCD_FORCE_PARTITION=<bitmask> treats direction mu as partitioned even when pe[mu] == 1 (the neighbour
+    // rank is then this rank itself), which drives the whole pack / RCCL send-recv / interior-exterior machinery on ONE GPU
+    if (const char* e = getenv("LQCD_FORCE_PARTITION")) {
+        const int mask = atoi(e);
+        for (int mu = 0; mu < 4; mu++)
+            if ((mask >> mu) & 1) c->geom.part[mu] = 1;
+    }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -184,7 +191,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     for (int mu = 0; mu < 4; mu++) {
         hipFree(c->send_fwd[mu]); hipFree(c->send_bwd[mu]); hipFree(c->recv_fwd[mu]); hipFree(c->recv_bwd[mu]);
     }
-    if (c->has_comm) ncclCommDestroy(c->comm);
+    if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     hipFree(c->d_partial); hipFree(c->d_scal); hipHostFree(c->h_scal);
     hipEventDestroy(c->ev_pack); hipEventDestroy(c->ev_comm); hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
     hipStreamDestroy(c->stream); hipStreamDestroy(c->comm_stream);
@@ -232,22 +239,29 @@ extern "C" int lqcd_ctx_get_param(lqcd_ctx_t c, const char* key, int* value) {
 }
 
 // ---------------------------------------------------------------------------------- RCCL bootstrap
-extern "C" int lqcd_comm_unique_id(unsigned char id[128]) {
+// Two communicators per context: halo send/recv run on the communication stream, scalar all-reduces on the compute
+// stream; giving each stream its own communicator keeps RCCL's one-communicator-one-stream-at-a-time rule trivially true.
+extern "C" int lqcd_comm_unique_id(unsigned char id[256]) {
     ARGCHK(id, "lqcd_comm_unique_id: null");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
-    ncclUniqueId u;
-    NCCLCHK(ncclGetUniqueId(&u));
-    memcpy(id, &u, 128);
+    for (int k = 0; k < 2; k++) {
+        ncclUniqueId u;
+        NCCLCHK(ncclGetUniqueId(&u));
+        memcpy(id + 128 * k, &u, 128);
+    }
     return LQCD_OK;
 }
 
-extern "C" int lqcd_ctx_comm_init(lqcd_ctx_t c, const unsigned char id[128], int nranks) {
+extern "C" int lqcd_ctx_comm_init(lqcd_ctx_t c, const unsigned char id[256], int nranks) {
     ARGCHK(c && id, "lqcd_ctx_comm_init: null");
     ARGCHK(nranks == c->nranks, "lqcd_ctx_comm_init: nranks does not match the PE grid");
+    ARGCHK(!c->has_comm, "lqcd_ctx_comm_init: communicator already initialised");
     HIPCHK(hipSetDevice(c->device));
     ncclUniqueId u;
     memcpy(&u, id, 128);
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, u, c->rank));
+    memcpy(&u, id + 128, 128);
+    NCCLCHK(ncclCommInitRank(&c->comm_red, nranks, u, c->rank));
     c->has_comm = true;
     return LQCD_OK;
 }
@@ -287,8 +301,8 @@ extern "C" int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq) {
             for (int mu = 0; mu < 4; mu++) {
                 if (!c->geom.part[mu]) continue;
                 const size_t nd = (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu) * 2;
-                ncclSend(sendb[mu], nd, ncclDouble, c->nbr_bwd[mu], c->comm, c->stream);
-                ncclRecv(ghost[mu], nd, ncclDouble, c->nbr_fwd[mu], c->comm, c->stream);
+                ncclSend(sendb[mu], nd, ncclDouble, c->nbr_bwd[mu], c->comm_red, c->stream);
+                ncclRecv(ghost[mu], nd, ncclDouble, c->nbr_fwd[mu], c->comm_red, c->stream);
             }
             ncclResult_t r = ncclGroupEnd();
             if (r != ncclSuccess) st = nccl_fail(r, "plaquette halo", __FILE__, __LINE__);

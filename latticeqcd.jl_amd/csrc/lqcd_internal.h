@@ -144,7 +144,8 @@ struct lqcd_ctx_s {
     // halo buffers (sized for Wilson full-lattice: 2 parities * 6 comps * Fh)
     double2* send_fwd[4] = {}, *send_bwd[4] = {}, *recv_fwd[4] = {}, *recv_bwd[4] = {};
     size_t halo_elems[4] = {};
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
+    ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;
     std::vector<lqcd_ctx_s*> local_peers;  // in-process emulation of the PE grid
     // scratch spinors owned by the context (Temporalfields analogue)

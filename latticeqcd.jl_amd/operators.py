@@ -73,7 +73,8 @@ class Lattice:
         check(_l.lib().lqcd_ctx_sync(self._h))
 
     def comm_init(self, unique_id):
-        buf = (C.c_ubyte * 128)(*bytes(unique_id))
+        assert len(unique_id) == 256
+        buf = (C.c_ubyte * 256)(*bytes(unique_id))
         check(_l.lib().lqcd_ctx_comm_init(self._h, buf, self.nranks))
 
     def close(self):
@@ -83,7 +84,7 @@ class Lattice:
 
 
 def comm_unique_id():
-    buf = (C.c_ubyte * 128)()
+    buf = (C.c_ubyte * 256)()
     check(_l.lib().lqcd_comm_unique_id(buf))
     return bytes(buf)
 

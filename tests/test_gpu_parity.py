@@ -440,6 +440,48 @@ def test_partitioned_cg_equals_single_domain(gpu, orc):
         assert rel_err(x.download(), lq.pegrid.local_view(xo, lat.local_L, lat.origin, lead=1)) < 1e-9
 
 
+# ------------------------------------------------------------------ the real RCCL path on one GPU (self-partition)
+def test_rccl_self_partition_dslash_and_cg(gpu, orc):
+    """World-size-1 RCCL communicators + LQCD_FORCE_PARTITION: every direction in the mask is treated as partitioned with
+    this rank as its own neighbour, so pack -> ncclSend/ncclRecv (to self, on the communication stream) -> interior ||
+    exchange -> exterior and the all-reduced CG path run exactly as they do at N > 1.  Results must equal the oracle."""
+    lq = gpu
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        from oracle import oracle as orc
+        L, K, BC = (8, 4, 6, 8), 0.141139, (1, 1, 1, -1)
+        lat = lq.Lattice(L)
+        lat.comm_init(lq.comm_unique_id())
+        U = orc.hot_gauge(L, 111)
+        Ud = lq.Gaugefields(lat).upload(U)
+        for name, kind, km in (("Wilson", lq.WILSON, K), ("Staggered", lq.STAGGERED, 0.5)):
+            D = lq.Dirac_operator(Ud, None, {"Dirac_operator": name, "κ": K, "mass": 0.5, "boundarycondition": BC, "eps_CG": 1e-19})
+            psi = orc.gaussian_spinor(lat.fermion_shape(kind), 112)
+            x = lq.Fermionfields(lat, kind).upload(psi)
+            y = x.similar()
+            for dag in (False, True):
+                lq.mul_(y, D.adjoint() if dag else D, x)
+                ref = orc.apply_D(kind, U, psi, L, km, 1.0, BC, dag)
+                err = np.abs(y.download() - ref).max() / np.abs(ref).max()
+                assert err < 1e-13, (name, dag, err)
+            sol = x.similar()
+            it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+            xo, ito, rro, st = orc.cg_DdagD(kind, U, psi, L, km, 1.0, BC, eps=1e-19)
+            assert st == 0 and abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (name, it, ito)
+        assert abs(lq.calculate_Plaquette(Ud) - orc.plaquette(U, L)) < 1e-13
+        assert abs(lq.dot(x, x) - np.vdot(psi, psi)) < 1e-9
+        print("RCCL_SELF_OK")
+    """)
+    for mask in ("8", "14", "15"):     # t only; y,z,t (the 8-GPU grid shape); all four
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "RCCL_SELF_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
+
+
 # ------------------------------------------------------------------ full BASELINE size through identities
 def test_full_size_32x32x32x64_identities(gpu):
     """BASELINE metric configuration (32^3x64 Wilson fp64, hot start seed 111, source seed 112): gamma5-hermiticity of the
