@@ -806,15 +806,23 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
 // blockIdx.y = 2*mu + side.  side 0: lower face (x_mu = 0) -> send_bwd[mu] = P psi   (receiver's forward hop)
 //                            side 1: upper face (x_mu = L-1) -> send_fwd[mu] = U^+ P psi (receiver's backward hop)
 // Buffers are [slot][ncomp_half][Fh] with slot = output parity of the RECEIVING site (0 when a single parity is computed).
+// Everything is templated on MU and per-lane parities select pointers with ?: -- a per-lane run-time index into the
+// by-value argument struct would force a private (scratch) copy of it.
 template <int MU>
-__device__ inline void wilson_pack_dir(const HArgs& k, int side, int slot, int pout, int f) {
+__device__ inline void wilson_pack_dir(const HArgs& k, int side) {
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, MU), Vh = g.Vs;
+    if (!g.part[MU]) return;
+    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
+    const int nslots = k.parity_mode == 2 ? 2 : 1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots * Fh) return;
+    const int slot = t / Fh, f = t - slot * Fh;
+    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
     const int ps = 1 - pout;  // parity of the site being packed
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
     const int i = coords_to_cb(g, c);
-    const double2* __restrict__ psi = k.in[ps] + i;
+    const double2* __restrict__ psi = (ps ? k.in[1] : k.in[0]) + i;
     cd h0[3], h1[3];
     double2* dst;
     if (side == 0) {
@@ -841,64 +849,92 @@ __device__ inline void wilson_pack_dir(const HArgs& k, int side, int slot, int p
 }
 
 __global__ __launch_bounds__(128) void wilson_pack(HArgs k) {
-    const int mu = blockIdx.y >> 1, side = blockIdx.y & 1;
-    if (!k.g.part[mu]) return;
-    const int Fh = face_half_sites(k.g, mu);
-    const int nslots = k.parity_mode == 2 ? 2 : 1;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nslots * Fh) return;
-    const int slot = t / Fh, f = t % Fh;
-    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
-    switch (mu) {
-    case 0: wilson_pack_dir<0>(k, side, slot, pout, f); break;
-    case 1: wilson_pack_dir<1>(k, side, slot, pout, f); break;
-    case 2: wilson_pack_dir<2>(k, side, slot, pout, f); break;
-    default: wilson_pack_dir<3>(k, side, slot, pout, f); break;
+    const int side = blockIdx.y & 1;
+    switch (blockIdx.y >> 1) {
+    case 0: wilson_pack_dir<0>(k, side); break;
+    case 1: wilson_pack_dir<1>(k, side); break;
+    case 2: wilson_pack_dir<2>(k, side); break;
+    default: wilson_pack_dir<3>(k, side); break;
     }
 }
 
-// ------------------------------------------------------------------------------------------ halo: exterior
-// out(n) += b * (hop contributions that crossed the rank boundary in direction MU)
-template <int MU>
-__device__ inline void wilson_ext_dir(const HArgs& k, int side, int slot, int pout, int f) {
+// ------------------------------------------------------------------------------------------ halo: exterior (fused)
+// out(n) += b * (all hop contributions that crossed a rank boundary).  ONE launch: blockIdx.y = 2*mu + side enumerates the
+// faces; a boundary site that lies on several faces (edges, corners) is OWNED by its lowest partitioned direction (and,
+// there, by its face), whose thread gathers the contributions of every face the site touches and does a single
+// read-modify-write -- no inter-direction ordering, no atomics, deterministic.
+template <int NU, bool DAG>
+__device__ __forceinline__ void wilson_ext_add(cd (&acc)[12], const HArgs& k, const int (&c)[4], int slot, int pout, int i) {
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, MU), Vh = g.Vs;
+    if (!g.part[NU]) return;
+    const int Fh = g.Vh / g.L[NU], Vh = g.Vs;
+    if (c[NU] == g.L[NU] - 1) {
+        // forward hop at the upper face: ghost = P psi(n+nu) from the +nu neighbour; multiply by own U_nu(n)
+        const int f = coords_to_face(g, NU, c);
+        const double2* __restrict__ src = k.recv_fwd[NU] + (size_t)slot * 6 * Fh + f;
+        const double sg = k.sign_fwd[NU];
+        cd h0[3], h1[3], u[9], x0[3], x1[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            h0[cc] = sg * ld(src + (size_t)cc * Fh);
+            h1[cc] = sg * ld(src + (size_t)(3 + cc) * Fh);
+        }
+        load_link(u, k.gauge + ((size_t)(pout * 4 + NU) * 9) * Vh + i, Vh);
+        su3_mv<false>(x0, u, h0);
+        su3_mv<false>(x1, u, h1);
+        reconstruct<NU, DAG ? -1 : 1>(acc, x0, x1);
+    }
+    if (c[NU] == 0) {
+        // backward hop at the lower face: ghost = U^+ P psi(n-nu) from the -nu neighbour
+        const int f = coords_to_face(g, NU, c);
+        const double2* __restrict__ src = k.recv_bwd[NU] + (size_t)slot * 6 * Fh + f;
+        const double sg = k.sign_bwd[NU];
+        cd h0[3], h1[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            h0[cc] = sg * ld(src + (size_t)cc * Fh);
+            h1[cc] = sg * ld(src + (size_t)(3 + cc) * Fh);
+        }
+        reconstruct<NU, DAG ? 1 : -1>(acc, h0, h1);
+    }
+}
+
+// true if the site is already owned by a face of a lower partitioned direction, or (same direction) by the lower face
+template <int MU>
+__device__ inline bool ext_not_owner(const Geom& g, const int (&c)[4], int side) {
+    bool lower = false;
+    if (MU > 0) lower = lower || (g.part[0] && (c[0] == 0 || c[0] == g.L[0] - 1));
+    if (MU > 1) lower = lower || (g.part[1] && (c[1] == 0 || c[1] == g.L[1] - 1));
+    if (MU > 2) lower = lower || (g.part[2] && (c[2] == 0 || c[2] == g.L[2] - 1));
+    // extent 2 in direction MU: a site cannot be on both faces, nothing to do; side is only used for clarity
+    (void)side;
+    return lower;
+}
+
+template <int MU, bool DAG>
+__device__ __forceinline__ void wilson_ext_face(const HArgs& k, int side) {
+    const Geom& g = k.g;
+    if (!g.part[MU]) return;
+    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
+    const int nslots = k.parity_mode == 2 ? 2 : 1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots * Fh) return;
+    const int slot = t / Fh, f = t - slot * Fh;
+    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, pout, f, c);
+    if (ext_not_owner<MU>(g, c, side)) return;
     const int i = coords_to_cb(g, c);
     cd acc[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
-    cd h0[3], h1[3];
-    if (side == 1) {
-        // forward hop at the upper face: ghost = P psi(n+mu) from the +mu neighbour; multiply by own U_mu(n)
-        const double2* __restrict__ src = k.recv_fwd[MU] + (size_t)slot * 6 * Fh + f;
-        const double sg = k.sign_fwd[MU];
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++) {
-            h0[cc] = sg * ld(src + (size_t)cc * Fh);
-            h1[cc] = sg * ld(src + (size_t)(3 + cc) * Fh);
-        }
-        cd u[9], x0[3], x1[3];
-        load_link(u, k.gauge + ((size_t)(pout * 4 + MU) * 9) * Vh + i, Vh);
-        su3_mv<false>(x0, u, h0);
-        su3_mv<false>(x1, u, h1);
-        if (k.dagger) reconstruct<MU, -1>(acc, x0, x1); else reconstruct<MU, 1>(acc, x0, x1);
-    } else {
-        // backward hop at the lower face: ghost = U^+ P psi(n-mu) from the -mu neighbour
-        const double2* __restrict__ src = k.recv_bwd[MU] + (size_t)slot * 6 * Fh + f;
-        const double sg = k.sign_bwd[MU];
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++) {
-            h0[cc] = sg * ld(src + (size_t)cc * Fh);
-            h1[cc] = sg * ld(src + (size_t)(3 + cc) * Fh);
-        }
-        if (k.dagger) reconstruct<MU, 1>(acc, h0, h1); else reconstruct<MU, -1>(acc, h0, h1);
-    }
-    double2* __restrict__ o = k.out[pout] + i;
+    if (MU <= 0) wilson_ext_add<0, DAG>(acc, k, c, slot, pout, i);
+    if (MU <= 1) wilson_ext_add<1, DAG>(acc, k, c, slot, pout, i);
+    if (MU <= 2) wilson_ext_add<2, DAG>(acc, k, c, slot, pout, i);
+    wilson_ext_add<3, DAG>(acc, k, c, slot, pout, i);
+    double2* __restrict__ o = (pout ? k.out[1] : k.out[0]) + i;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
-        // only rows touched by the reconstruction are non-zero; the compiler drops the rest for mu = 3
         cd v = ld(o + (size_t)j * Vh);
         v.re = fma(k.b, acc[j].re, v.re);
         v.im = fma(k.b, acc[j].im, v.im);
@@ -906,89 +942,128 @@ __device__ inline void wilson_ext_dir(const HArgs& k, int side, int slot, int po
     }
 }
 
-// one launch per direction (faces of different directions share edge sites -> serialised on the stream);
-// blockIdx.y = side, the two faces of one direction are disjoint when L[mu] >= 2.
-template <int MU>
+template <bool DAG>
 __global__ __launch_bounds__(128) void wilson_exterior(HArgs k) {
-    const int side = blockIdx.y;
-    const int Fh = face_half_sites(k.g, MU);
-    const int nslots = k.parity_mode == 2 ? 2 : 1;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nslots * Fh) return;
-    const int slot = t / Fh, f = t % Fh;
-    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
-    wilson_ext_dir<MU>(k, side, slot, pout, f);
+    const int side = blockIdx.y & 1;
+    switch (blockIdx.y >> 1) {
+    case 0: wilson_ext_face<0, DAG>(k, side); break;
+    case 1: wilson_ext_face<1, DAG>(k, side); break;
+    case 2: wilson_ext_face<2, DAG>(k, side); break;
+    default: wilson_ext_face<3, DAG>(k, side); break;
+    }
 }
 
-// staggered halos: 3 components; eta and the +/- sign are applied by the receiver
-__global__ __launch_bounds__(128) void staggered_pack(HArgs k) {
-    const int mu = blockIdx.y >> 1, side = blockIdx.y & 1;
-    if (!k.g.part[mu]) return;
+// ------------------------------------------------------------------------------------------ staggered halos
+// 3 components; eta and the +/- sign are applied by the receiver
+template <int MU>
+__device__ inline void staggered_pack_dir(const HArgs& k, int side) {
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, mu), Vh = g.Vs;
+    if (!g.part[MU]) return;
+    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
     const int nslots = k.parity_mode == 2 ? 2 : 1;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslots * Fh) return;
-    const int slot = t / Fh, f = t % Fh;
+    const int slot = t / Fh, f = t - slot * Fh;
     const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
     const int ps = 1 - pout;
     int c[4];
-    face_to_coords(g, mu, side ? g.L[mu] - 1 : 0, ps, f, c);
+    face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
     const int i = coords_to_cb(g, c);
     cd h[3];
 #pragma unroll
-    for (int cc = 0; cc < 3; cc++) h[cc] = ld(k.in[ps] + i + (size_t)cc * Vh);
+    for (int cc = 0; cc < 3; cc++) h[cc] = ld((ps ? k.in[1] : k.in[0]) + i + (size_t)cc * Vh);
     double2* dst;
     if (side == 0) {
-        dst = k.send_bwd[mu];
+        dst = k.send_bwd[MU];
     } else {
         cd u[9], x[3];
-        load_link(u, k.gauge + ((size_t)(ps * 4 + mu) * 9) * Vh + i, Vh);
+        load_link(u, k.gauge + ((size_t)(ps * 4 + MU) * 9) * Vh + i, Vh);
         su3_mv<true>(x, u, h);
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) h[cc] = x[cc];
-        dst = k.send_fwd[mu];
+        dst = k.send_fwd[MU];
     }
     dst += (size_t)slot * 3 * Fh + f;
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) st(dst + (size_t)cc * Fh, h[cc]);
 }
 
-__global__ __launch_bounds__(128) void staggered_exterior(HArgs k, int mu) {
-    const int side = blockIdx.y;
+__global__ __launch_bounds__(128) void staggered_pack(HArgs k) {
+    const int side = blockIdx.y & 1;
+    switch (blockIdx.y >> 1) {
+    case 0: staggered_pack_dir<0>(k, side); break;
+    case 1: staggered_pack_dir<1>(k, side); break;
+    case 2: staggered_pack_dir<2>(k, side); break;
+    default: staggered_pack_dir<3>(k, side); break;
+    }
+}
+
+template <int NU>
+__device__ __forceinline__ void staggered_ext_add(cd (&acc)[3], const HArgs& k, const int (&c)[4], int slot, int pout, int i) {
     const Geom& g = k.g;
-    const int Fh = face_half_sites(g, mu), Vh = g.Vs;
-    const int nslots = k.parity_mode == 2 ? 2 : 1;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nslots * Fh) return;
-    const int slot = t / Fh, f = t % Fh;
-    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
-    int c[4];
-    face_to_coords(g, mu, side ? g.L[mu] - 1 : 0, pout, f, c);
-    const int i = coords_to_cb(g, c);
-    const double eta = stag_eta(c, mu);
-    cd h[3], x[3];
-    if (side == 1) {
-        const double2* src = k.recv_fwd[mu] + (size_t)slot * 3 * Fh + f;
-        const double cf = eta * k.sign_fwd[mu];
+    if (!g.part[NU]) return;
+    const int Fh = g.Vh / g.L[NU], Vh = g.Vs;
+    int e = 0;
+#pragma unroll
+    for (int j = 0; j < NU; j++) e += c[j];
+    const double eta = (e & 1) ? -1.0 : 1.0;
+    if (c[NU] == g.L[NU] - 1) {
+        const int f = coords_to_face(g, NU, c);
+        const double2* src = k.recv_fwd[NU] + (size_t)slot * 3 * Fh + f;
+        const double cf = eta * k.sign_fwd[NU];
+        cd h[3], u[9], x[3];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) h[cc] = cf * ld(src + (size_t)cc * Fh);
-        cd u[9];
-        load_link(u, k.gauge + ((size_t)(pout * 4 + mu) * 9) * Vh + i, Vh);
+        load_link(u, k.gauge + ((size_t)(pout * 4 + NU) * 9) * Vh + i, Vh);
         su3_mv<false>(x, u, h);
-    } else {
-        const double2* src = k.recv_bwd[mu] + (size_t)slot * 3 * Fh + f;
-        const double cf = -eta * k.sign_bwd[mu];
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) x[cc] = cf * ld(src + (size_t)cc * Fh);
+        for (int cc = 0; cc < 3; cc++) acc[cc] = acc[cc] + x[cc];
     }
-    double2* o = k.out[pout] + i;
+    if (c[NU] == 0) {
+        const int f = coords_to_face(g, NU, c);
+        const double2* src = k.recv_bwd[NU] + (size_t)slot * 3 * Fh + f;
+        const double cf = -eta * k.sign_bwd[NU];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) acc[cc] = acc[cc] + cf * ld(src + (size_t)cc * Fh);
+    }
+}
+
+template <int MU>
+__device__ inline void staggered_ext_face(const HArgs& k, int side) {
+    const Geom& g = k.g;
+    if (!g.part[MU]) return;
+    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
+    const int nslots = k.parity_mode == 2 ? 2 : 1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots * Fh) return;
+    const int slot = t / Fh, f = t - slot * Fh;
+    const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
+    int c[4];
+    face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, pout, f, c);
+    if (ext_not_owner<MU>(g, c, side)) return;
+    const int i = coords_to_cb(g, c);
+    cd acc[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    if (MU <= 0) staggered_ext_add<0>(acc, k, c, slot, pout, i);
+    if (MU <= 1) staggered_ext_add<1>(acc, k, c, slot, pout, i);
+    if (MU <= 2) staggered_ext_add<2>(acc, k, c, slot, pout, i);
+    staggered_ext_add<3>(acc, k, c, slot, pout, i);
+    double2* o = (pout ? k.out[1] : k.out[0]) + i;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         cd v = ld(o + (size_t)j * Vh);
-        v.re = fma(k.b, x[j].re, v.re);
-        v.im = fma(k.b, x[j].im, v.im);
+        v.re = fma(k.b, acc[j].re, v.re);
+        v.im = fma(k.b, acc[j].im, v.im);
         st(o + (size_t)j * Vh, v);
+    }
+}
+
+__global__ __launch_bounds__(128) void staggered_exterior(HArgs k) {
+    const int side = blockIdx.y & 1;
+    switch (blockIdx.y >> 1) {
+    case 0: staggered_ext_face<0>(k, side); break;
+    case 1: staggered_ext_face<1>(k, side); break;
+    case 2: staggered_ext_face<2>(k, side); break;
+    default: staggered_ext_face<3>(k, side); break;
     }
 }
 
@@ -1123,23 +1198,16 @@ int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s) {
 }
 
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
+    const int nt = max_face_threads(c, s.parity_mode);
+    if (nt == 0) return LQCD_OK;
     HArgs h = make_hargs(c, s);
-    for (int mu = 0; mu < 4; mu++) {
-        if (!c->geom.part[mu]) continue;
-        const int nt = face_half_sites(c->geom, mu) * (s.parity_mode == 2 ? 2 : 1);
-        dim3 grid((nt + 127) / 128, 2), block(128);
-        if (s.kind == LQCD_WILSON) {
-            switch (mu) {
-            case 0: hipLaunchKernelGGL(wilson_exterior<0>, grid, block, 0, c->stream, h); break;
-            case 1: hipLaunchKernelGGL(wilson_exterior<1>, grid, block, 0, c->stream, h); break;
-            case 2: hipLaunchKernelGGL(wilson_exterior<2>, grid, block, 0, c->stream, h); break;
-            default: hipLaunchKernelGGL(wilson_exterior<3>, grid, block, 0, c->stream, h); break;
-            }
-        } else {
-            hipLaunchKernelGGL(staggered_exterior, grid, block, 0, c->stream, h, mu);
-        }
-        HIPCHK(hipGetLastError());
+    dim3 grid((nt + 127) / 128, 8), block(128);
+    if (s.kind == LQCD_WILSON) {
+        if (s.dagger) hipLaunchKernelGGL(wilson_exterior<true>, grid, block, 0, c->stream, h);
+        else hipLaunchKernelGGL(wilson_exterior<false>, grid, block, 0, c->stream, h);
     }
+    else hipLaunchKernelGGL(staggered_exterior, grid, block, 0, c->stream, h);
+    HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
 
