@@ -127,7 +127,7 @@ int stream_grid(lqcd_ctx_s* c, size_t n) {
 
 // sum over ranks of n host doubles (RCCL all-reduce through the device scalar block)
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n) {
-    if (c->nranks == 1 || !c->has_comm) return LQCD_OK;
+    if (!c->has_comm) return LQCD_OK;
     ARGCHK(n <= 8, "allreduce_host: too many values");
     double* d = c->d_scal + SCAL_DOUBLES - 8;
     HIPCHK(hipMemcpyAsync(d, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -139,7 +139,7 @@ int allreduce_host(lqcd_ctx_s* c, double* vals, int n) {
 
 // device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks
 int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op) {
-    const bool multi = allreduce && c->nranks > 1 && c->has_comm;
+    const bool multi = allreduce && c->has_comm;   // also at world size 1 (self-partition tests exercise the collective)
     hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, c->d_partial, nblocks, nvals, c->d_scal, slot, multi ? 0 : cg_op);
     HIPCHK(hipGetLastError());
     if (multi) {

@@ -165,7 +165,7 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev_t0));
     HIPCHK(hipEventCreate(&c->ev_t1));
-    const size_t npart = (size_t)2 * c->geom.Vh / 64 + 4096;
+    const size_t npart = (size_t)2 * c->geom.Vh / 64 + 4096 + 8 * ((size_t)2 * c->geom.Vh / 128 + 8);  // interior + exterior partials
     HIPCHK(hipMalloc((void**)&c->d_partial, npart * 2 * sizeof(double)));
     HIPCHK(hipMalloc((void**)&c->d_scal, SCAL_DOUBLES * sizeof(double)));
     HIPCHK(hipMemset(c->d_scal, 0, SCAL_DOUBLES * sizeof(double)));

@@ -238,6 +238,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. 
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode);
+int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode);
 
 // BLAS-1 / reductions (blas.hip)
 int blas_dot(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, double* re, double* im, bool allreduce);

@@ -72,9 +72,8 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     ARGCHK(c->local_peers.empty(), "this context belongs to an in-process PE grid: use the lqcd_mdom_* collectives");
     LQCHK(launch_stencil_pack(c, s));
     LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode));
-    StencilCall si = s;
-    si.norm_partial = nullptr;
-    LQCHK(launch_stencil_interior(c, si));
+    // norm partials: the interior writes |.|^2 of what it produced, the exterior appends the corrections of the sites it updates
+    LQCHK(launch_stencil_interior(c, s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return launch_stencil_exterior(c, s);
 }
@@ -261,11 +260,11 @@ struct CgWork {
 static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n = x->elems;
-    if (c->tun.cg_fused >= 2 && !any_partitioned(c)) {
+    if (c->tun.cg_fused >= 2) {
         // fully fused form: 10 spinor passes per iteration instead of 13, q = D^+ D p is never written
         //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
         //   beta, convergence ; x += alpha p, p = r + beta p
-        const int nbs = stencil_num_blocks(c, op->kind, op->r, 2);
+        const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
         LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial));
         LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);

@@ -70,6 +70,10 @@ struct HArgs {  // halo kernels
     const double2* recv_bwd[4];
     double sign_fwd[4];  // bc sign if this rank sits on the global upper boundary, else 1
     double sign_bwd[4];
+    double* norm_partial;     // if non-null: per-block CORRECTIONS sum(|v_after|^2 - |v_before|^2) go to norm_partial[partial_offset + block]
+    int partial_offset;
+    const double* upd_scal;   // CG update mode: target is upd (r) and the coefficient is -alpha*b
+    double2* upd[2];
 };
 
 // workgroup -> (chunk of consecutive checkerboard sites, parity).  Observed (not contractual) dispatch: block b runs on
@@ -912,18 +916,18 @@ __device__ inline bool ext_not_owner(const Geom& g, const int (&c)[4], int side)
 }
 
 template <int MU, bool DAG>
-__device__ __forceinline__ void wilson_ext_face(const HArgs& k, int side) {
+__device__ __forceinline__ double wilson_ext_face(const HArgs& k, int side) {
     const Geom& g = k.g;
-    if (!g.part[MU]) return;
+    if (!g.part[MU]) return 0.0;
     const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nslots * Fh) return;
+    if (t >= nslots * Fh) return 0.0;
     const int slot = t / Fh, f = t - slot * Fh;
     const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, pout, f, c);
-    if (ext_not_owner<MU>(g, c, side)) return;
+    if (ext_not_owner<MU>(g, c, side)) return 0.0;
     const int i = coords_to_cb(g, c);
     cd acc[12];
 #pragma unroll
@@ -932,25 +936,44 @@ __device__ __forceinline__ void wilson_ext_face(const HArgs& k, int side) {
     if (MU <= 1) wilson_ext_add<1, DAG>(acc, k, c, slot, pout, i);
     if (MU <= 2) wilson_ext_add<2, DAG>(acc, k, c, slot, pout, i);
     wilson_ext_add<3, DAG>(acc, k, c, slot, pout, i);
-    double2* __restrict__ o = (pout ? k.out[1] : k.out[0]) + i;
+    const double coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
+    double2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + i;
+    double corr = 0.0;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
         cd v = ld(o + (size_t)j * Vh);
-        v.re = fma(k.b, acc[j].re, v.re);
-        v.im = fma(k.b, acc[j].im, v.im);
+        const double before = v.re * v.re + v.im * v.im;
+        v.re = fma(coef, acc[j].re, v.re);
+        v.im = fma(coef, acc[j].im, v.im);
+        corr += (v.re * v.re + v.im * v.im) - before;
         st(o + (size_t)j * Vh, v);
     }
+    return corr;
+}
+
+// block-level sum of the per-thread norm corrections of an exterior kernel (128 threads)
+__device__ inline void ext_partial(const HArgs& k, double corr) {
+    if (!k.norm_partial) return;
+    __shared__ double red[2];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) corr += __shfl_down(corr, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = corr;
+    __syncthreads();
+    if (threadIdx.x == 0) k.norm_partial[k.partial_offset + blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1];
 }
 
 template <bool DAG>
 __global__ __launch_bounds__(128) void wilson_exterior(HArgs k) {
+    if (k.upd_scal && k.upd_scal[S_DONE] != 0.0) return;
     const int side = blockIdx.y & 1;
+    double corr;
     switch (blockIdx.y >> 1) {
-    case 0: wilson_ext_face<0, DAG>(k, side); break;
-    case 1: wilson_ext_face<1, DAG>(k, side); break;
-    case 2: wilson_ext_face<2, DAG>(k, side); break;
-    default: wilson_ext_face<3, DAG>(k, side); break;
+    case 0: corr = wilson_ext_face<0, DAG>(k, side); break;
+    case 1: corr = wilson_ext_face<1, DAG>(k, side); break;
+    case 2: corr = wilson_ext_face<2, DAG>(k, side); break;
+    default: corr = wilson_ext_face<3, DAG>(k, side); break;
     }
+    ext_partial(k, corr);
 }
 
 // ------------------------------------------------------------------------------------------ staggered halos
@@ -1029,42 +1052,50 @@ __device__ __forceinline__ void staggered_ext_add(cd (&acc)[3], const HArgs& k, 
 }
 
 template <int MU>
-__device__ inline void staggered_ext_face(const HArgs& k, int side) {
+__device__ inline double staggered_ext_face(const HArgs& k, int side) {
     const Geom& g = k.g;
-    if (!g.part[MU]) return;
+    if (!g.part[MU]) return 0.0;
     const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nslots * Fh) return;
+    if (t >= nslots * Fh) return 0.0;
     const int slot = t / Fh, f = t - slot * Fh;
     const int pout = k.parity_mode == 2 ? slot : k.parity_mode;
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, pout, f, c);
-    if (ext_not_owner<MU>(g, c, side)) return;
+    if (ext_not_owner<MU>(g, c, side)) return 0.0;
     const int i = coords_to_cb(g, c);
     cd acc[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     if (MU <= 0) staggered_ext_add<0>(acc, k, c, slot, pout, i);
     if (MU <= 1) staggered_ext_add<1>(acc, k, c, slot, pout, i);
     if (MU <= 2) staggered_ext_add<2>(acc, k, c, slot, pout, i);
     staggered_ext_add<3>(acc, k, c, slot, pout, i);
-    double2* o = (pout ? k.out[1] : k.out[0]) + i;
+    const double coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
+    double2* o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + i;
+    double corr = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         cd v = ld(o + (size_t)j * Vh);
-        v.re = fma(k.b, acc[j].re, v.re);
-        v.im = fma(k.b, acc[j].im, v.im);
+        const double before = v.re * v.re + v.im * v.im;
+        v.re = fma(coef, acc[j].re, v.re);
+        v.im = fma(coef, acc[j].im, v.im);
+        corr += (v.re * v.re + v.im * v.im) - before;
         st(o + (size_t)j * Vh, v);
     }
+    return corr;
 }
 
 __global__ __launch_bounds__(128) void staggered_exterior(HArgs k) {
+    if (k.upd_scal && k.upd_scal[S_DONE] != 0.0) return;
     const int side = blockIdx.y & 1;
+    double corr;
     switch (blockIdx.y >> 1) {
-    case 0: staggered_ext_face<0>(k, side); break;
-    case 1: staggered_ext_face<1>(k, side); break;
-    case 2: staggered_ext_face<2>(k, side); break;
-    default: staggered_ext_face<3>(k, side); break;
+    case 0: corr = staggered_ext_face<0>(k, side); break;
+    case 1: corr = staggered_ext_face<1>(k, side); break;
+    case 2: corr = staggered_ext_face<2>(k, side); break;
+    default: corr = staggered_ext_face<3>(k, side); break;
     }
+    ext_partial(k, corr);
 }
 
 // ------------------------------------------------------------------------------------------ host launchers
@@ -1162,6 +1193,13 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
     }
 }
 
+static int max_face_threads(lqcd_ctx_s* c, int parity_mode);
+// interior block partials + (partitioned lattice) the exterior kernel's correction partials
+int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
+    const int nt = max_face_threads(c, parity_mode);
+    return stencil_num_blocks(c, kind, r, parity_mode) + (nt > 0 ? ((nt + 127) / 128) * 8 : 0);
+}
+
 static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
     HArgs h;
     h.g = c->geom;
@@ -1176,6 +1214,10 @@ static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
         h.sign_fwd[mu] = (c->coord[mu] == c->pe[mu] - 1) ? c->geom.bc_fwd[mu] : 1.0;
         h.sign_bwd[mu] = (c->coord[mu] == 0) ? c->geom.bc_bwd[mu] : 1.0;
     }
+    h.norm_partial = s.norm_partial;
+    h.partial_offset = stencil_num_blocks(c, s.kind, s.r, s.parity_mode);   // corrections are appended to the interior's partials
+    h.upd_scal = s.upd_scal;
+    h.upd[0] = s.upd[0]; h.upd[1] = s.upd[1];
     return h;
 }
 
