@@ -1,17 +1,20 @@
 #!/bin/bash
 # Builds liblqcd_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+#   LQCD_EXTRA_FLAGS="-DLQCD_GAUGE_AOSOA=0" LQCD_OUT=liblqcd_hip_soa.so ./build.sh   builds an A/B variant
 set -e
 cd "$(dirname "$0")"
 ARCH=${LQCD_ARCH:-gfx950}
-FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
-mkdir -p build
+OUT=${LQCD_OUT:-liblqcd_hip.so}
+BDIR=build/${OUT%.so}
+FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Wno-unused-variable $LQCD_EXTRA_FLAGS"
+mkdir -p $BDIR
 pids=()
 for f in stencil fields blas ops capi; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ lqcd_internal.h -nt build/$f.o ] || [ ../../include/lqcd_hip.h -nt build/$f.o ]; then
-    ( hipcc $FLAGS -c $f.hip -o build/$f.o ) &
+  if [ ! -f $BDIR/$f.o ] || [ $f.hip -nt $BDIR/$f.o ] || [ lqcd_internal.h -nt $BDIR/$f.o ] || [ ../../include/lqcd_hip.h -nt $BDIR/$f.o ] || [ build.sh -nt $BDIR/$f.o ]; then
+    ( hipcc $FLAGS -c $f.hip -o $BDIR/$f.o ) &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=$ARCH -shared -fPIC -o liblqcd_hip.so build/stencil.o build/fields.o build/blas.o build/ops.o build/capi.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
-echo "built $(pwd)/liblqcd_hip.so"
+hipcc --offload-arch=$ARCH -shared -fPIC -o $OUT $BDIR/stencil.o $BDIR/fields.o $BDIR/blas.o $BDIR/ops.o $BDIR/capi.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo "built $(pwd)/$OUT"

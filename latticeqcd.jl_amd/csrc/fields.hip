@@ -23,7 +23,7 @@ __global__ void gauge_reorder(Geom g, double2* dev, double2* host_img, int layou
     for (int mu = 0; mu < 4; mu++)
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) {
-                double2* d = dev + ((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vs + i;
+                double2* d = dev + glink_off(g, p, mu, i) + (size_t)(a * 3 + b) * glink_stride(g);
                 double2* h = host_img + host_gauge_index(layout, V, mu, site, a, b);
                 if (to_device) *d = *h; else *h = *d;
             }
@@ -103,7 +103,7 @@ __global__ void gauge_hot(Geom g, double2* dev, uint64_t seed) {
     }
     for (int a = 0; a < 3; a++)
         for (int b = 0; b < 3; b++)
-            dev[((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vs + i] = make_double2(m[a][b][0], m[a][b][1]);
+            dev[glink_off(g, p, mu, i) + (size_t)(a * 3 + b) * glink_stride(g)] = make_double2(m[a][b][0], m[a][b][1]);
 }
 
 __global__ void gauge_unit(Geom g, double2* dev) {
@@ -113,7 +113,7 @@ __global__ void gauge_unit(Geom g, double2* dev) {
     const int p = s / g.Vh, i = s % g.Vh;
     for (int a = 0; a < 3; a++)
         for (int b = 0; b < 3; b++)
-            dev[((size_t)(p * 4 + mu) * 9 + a * 3 + b) * g.Vs + i] = make_double2(a == b ? 1.0 : 0.0, 0.0);
+            dev[glink_off(g, p, mu, i) + (size_t)(a * 3 + b) * glink_stride(g)] = make_double2(a == b ? 1.0 : 0.0, 0.0);
 }
 
 // mode 0: gaussian re,im ~ N(0,1); mode 1: Z4 noise (+-1, +-i)
@@ -143,8 +143,8 @@ __global__ void spinor_fill(Geom g, double2* dev0, double2* dev1, int ncomp, uin
 __device__ inline void load_link_at(cd (&u)[9], const double2* gauge, const Geom& g, int mu, const int c[4]) {
     const int p = (c[0] + c[1] + c[2] + c[3]) & 1;
     const int i = coords_to_cb(g, c);
-    const double2* U = gauge + ((size_t)(p * 4 + mu) * 9) * g.Vs + i;
-    for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * g.Vs);
+    const double2* U = gauge + glink_off(g, p, mu, i);
+    for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * glink_stride(g));
 }
 __device__ inline void mm(cd (&C)[9], const cd (&A)[9], const cd (&B)[9], bool adjB) {
     for (int a = 0; a < 3; a++)
@@ -222,7 +222,7 @@ __global__ void gauge_face_pack(Geom g, const double2* gauge, double2* dst, int 
     const int i = coords_to_cb(g, c);
     for (int nu = 0; nu < 4; nu++)
         for (int j = 0; j < 9; j++)
-            dst[((size_t)(p * 4 + nu) * 9 + j) * Fh + f] = gauge[((size_t)(p * 4 + nu) * 9 + j) * g.Vs + i];
+            dst[((size_t)(p * 4 + nu) * 9 + j) * Fh + f] = gauge[glink_off(g, p, nu, i) + (size_t)j * glink_stride(g)];
 }
 
 }  // namespace lqcd
@@ -235,7 +235,7 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
     HIPCHK(hipSetDevice(ctx->device));
     lqcd_gauge_s* x = new lqcd_gauge_s;
     x->ctx = ctx;
-    x->elems = (size_t)2 * 4 * 9 * ctx->geom.Vs;
+    x->elems = gauge_elems(ctx->geom);
     x->data = nullptr;
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
     if (e != hipSuccess) { delete x; return hip_fail(e, "hipMalloc(gauge)", __FILE__, __LINE__); }

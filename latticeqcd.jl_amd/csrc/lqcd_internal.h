@@ -23,6 +23,7 @@ struct Geom {           // local sub-lattice geometry, passed by value to kernel
     int Vh;             // sites per parity
     int Vs;             // component stride in sites: Vh + padding.  With Vh a power of two every component array would be a
                         // multiple of 256 KiB apart and the 21 loads of a hop alias to one L2 set / memory channel.
+    int nch;            // number of 64-site chunks per parity = ceil(Vh / 64)
     int part[4];        // 1 if direction is partitioned over ranks (neighbour is off-rank)
     double bc_fwd[4];   // sign applied when a forward hop wraps locally across the GLOBAL boundary (unpartitioned dirs)
     double bc_bwd[4];
@@ -42,6 +43,36 @@ __host__ __device__ inline void cb_to_coords(const Geom& g, int parity, int cb, 
 }
 __host__ __device__ inline int coords_to_cb(const Geom& g, const int c[4]) {
     return (c[0] >> 1) + g.XH * (c[1] + g.L[1] * (c[2] + g.L[2] * c[3]));
+}
+
+// ---------------------------------------------------------------- gauge-field addressing
+// LQCD_GAUGE_AOSOA = 1 (default): chunk-blocked layout  [parity][chunk = cb/64][mu][a*3+b][cb%64] -- the 36 link components a
+// workgroup needs for 64 sites are ONE contiguous 36 KiB block (long DRAM bursts instead of 36 pieces of 1 KiB that are
+// 16 MB apart); every wave load is still 64 lanes x 16 B = 1 KiB contiguous.
+// LQCD_GAUGE_AOSOA = 0: plain structure-of-arrays [parity][mu][a*3+b][cb] with component stride Vs.
+#ifndef LQCD_GAUGE_AOSOA
+#define LQCD_GAUGE_AOSOA 1
+#endif
+__host__ __device__ inline size_t glink_off(const Geom& g, int p, int mu, int i) {   // element (a*3+b) = 0 of U_mu at (p, i)
+#if LQCD_GAUGE_AOSOA
+    return ((((size_t)p * g.nch + (size_t)(i >> 6)) * 4 + mu) * 9) * 64 + (i & 63);
+#else
+    return ((size_t)(p * 4 + mu) * 9) * g.Vs + i;
+#endif
+}
+__host__ __device__ inline int glink_stride(const Geom& g) {   // distance between consecutive components of one link
+#if LQCD_GAUGE_AOSOA
+    return 64;
+#else
+    return g.Vs;
+#endif
+}
+__host__ __device__ inline size_t gauge_elems(const Geom& g) {
+#if LQCD_GAUGE_AOSOA
+    return (size_t)2 * g.nch * 36 * 64;
+#else
+    return (size_t)2 * 4 * 9 * g.Vs;
+#endif
 }
 
 // ---------------------------------------------------------------- faces (halo geometry)

@@ -185,10 +185,10 @@ __device__ inline void reconstruct(cd (&acc)[12], const cd (&chi0)[3], const cd 
 // one hop, r = 1:  acc += (1 - S gamma_mu) [U or U^+] psi(nb) * sign
 template <int MU, int S, bool ADJ>
 __device__ inline void wilson_hop(cd (&acc)[12], const double2* __restrict__ psi, const double2* __restrict__ U,
-                                  int Vh, double sign) {
+                                  int Vh, int Us, double sign) {
     cd h0[3], h1[3], chi0[3], chi1[3], u[9];
     project<MU, S>(h0, h1, psi, Vh);
-    load_link(u, U, Vh);
+    load_link(u, U, Us);
 #pragma unroll
     for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
     su3_mv<ADJ>(chi0, u, h0);
@@ -199,9 +199,9 @@ __device__ inline void wilson_hop(cd (&acc)[12], const double2* __restrict__ psi
 // one hop, general r:  acc += (r - S gamma_mu) [U or U^+] psi(nb) * sign
 template <int MU, int S, bool ADJ>
 __device__ inline void wilson_hop_rgen(cd (&acc)[12], const double2* __restrict__ psi, const double2* __restrict__ U,
-                                       int Vh, double sign, double r) {
+                                       int Vh, int Us, double sign, double r) {
     cd u[9], t[4][3];
-    load_link(u, U, Vh);
+    load_link(u, U, Us);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         cd h[3];
@@ -305,17 +305,16 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
             for (int j = 0; j < 12; j++) xv[j] = mk(0.0, 0.0);
         }
         const double2* __restrict__ psi = k.in[1 - p];
-        const double2* __restrict__ Uf = k.gauge + (size_t)(p * 4) * 9 * Vh + i;         // own links
-        const double2* __restrict__ Ub = k.gauge + (size_t)((1 - p) * 4) * 9 * Vh;       // neighbour's links
+        const int Us = glink_stride(k.g);
         constexpr int SF = DAG ? -1 : 1;  // forward hop: (r - gamma) for D, (r + gamma) for D^+
 #define HOP(MU)                                                                                                  \
     if (n.sf[MU] != 0.0) {                                                                                       \
-        if constexpr (RGEN) wilson_hop_rgen<MU, SF, false>(acc, psi + n.fwd[MU], Uf + (size_t)MU * 9 * Vh, Vh, n.sf[MU], k.r); \
-        else wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], Uf + (size_t)MU * 9 * Vh, Vh, n.sf[MU]);            \
+        if constexpr (RGEN) wilson_hop_rgen<MU, SF, false>(acc, psi + n.fwd[MU], k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU], k.r); \
+        else wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU]);            \
     }                                                                                                            \
     if (n.sb[MU] != 0.0) {                                                                                       \
-        if constexpr (RGEN) wilson_hop_rgen<MU, -SF, true>(acc, psi + n.bwd[MU], Ub + (size_t)MU * 9 * Vh + n.bwd[MU], Vh, n.sb[MU], k.r); \
-        else wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], Ub + (size_t)MU * 9 * Vh + n.bwd[MU], Vh, n.sb[MU]); \
+        if constexpr (RGEN) wilson_hop_rgen<MU, -SF, true>(acc, psi + n.bwd[MU], k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU], k.r); \
+        else wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU]); \
     }
         HOP(0) HOP(1) HOP(2) HOP(3)
 #undef HOP
@@ -341,11 +340,12 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     neighbours(k.g, p, i, n, c);
     const int Vh = k.g.Vs;  // component stride in sites (padded)
     const double2* __restrict__ psi = k.in[1 - p];
-    const double2* __restrict__ Uf = k.gauge + ((size_t)(p * 4 + MU) * 9) * Vh + i;
-    const double2* __restrict__ Ub = k.gauge + ((size_t)((1 - p) * 4 + MU) * 9) * Vh + n.bwd[MU];
+    const double2* __restrict__ Uf = k.gauge + glink_off(k.g, p, MU, i);
+    const double2* __restrict__ Ub = k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
+    const int Us = glink_stride(k.g);
     constexpr int SF = DAG ? -1 : 1;
-    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], Uf, Vh, n.sf[MU]);
-    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], Ub, Vh, n.sb[MU]);
+    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], Uf, Vh, Us, n.sf[MU]);
+    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], Ub, Vh, Us, n.sb[MU]);
 }
 
 template <bool DAG>
@@ -479,10 +479,10 @@ __device__ inline cd bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 }
 // raw spinor components a hop needs (12, or the 6 the t projector keeps) and the link, all issued back to back
 template <int MU, int S>
-__device__ inline void load_hop_regs(cd* sp, cd (&u)[9], const double2* psi_block, const double2* link_block, unsigned Vs,
-                                     unsigned psi_site, unsigned link_site) {
-    const __amdgpu_buffer_rsrc_t rp = mkbuf(psi_block, (size_t)12 * Vs), ru = mkbuf(link_block, (size_t)9 * Vs);
-    const unsigned vp = psi_site * 16u, vu = link_site * 16u, cs = Vs * 16u;
+__device__ inline void load_hop_regs(cd* sp, cd (&u)[9], const double2* psi_block, const double2* gauge, size_t gauge_n, unsigned Vs,
+                                     unsigned Us, unsigned psi_site, unsigned link_off) {
+    const __amdgpu_buffer_rsrc_t rp = mkbuf(psi_block, (size_t)12 * Vs), ru = mkbuf(gauge, gauge_n);
+    const unsigned vp = psi_site * 16u, vu = link_off * 16u, cs = Vs * 16u, us = Us * 16u;
     if constexpr (MU < 3) {
 #pragma unroll
         for (int j = 0; j < 12; j++) sp[j] = bld(rp, vp, (unsigned)j * cs);
@@ -492,7 +492,7 @@ __device__ inline void load_hop_regs(cd* sp, cd (&u)[9], const double2* psi_bloc
         for (int j = 0; j < 6; j++) sp[j] = bld(rp, vp, (unsigned)(base * 3 + j) * cs);
     }
 #pragma unroll
-    for (int j = 0; j < 9; j++) u[j] = bld(ru, vu, (unsigned)j * cs);
+    for (int j = 0; j < 9; j++) u[j] = bld(ru, vu, (unsigned)j * us);
 }
 
 template <int MU, bool BWD, bool DAG, bool NTG>
@@ -508,15 +508,15 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
     for (int cc = 0; cc < 3; cc++) { chi0[cc] = mk(0, 0); chi1[cc] = mk(0, 0); }
     if (sign != 0.0) {
         const double2* __restrict__ psi = k.in[1 - p] + nb;
-        const double2* __restrict__ U = BWD ? k.gauge + ((size_t)((1 - p) * 4 + MU) * 9) * Vh + nb
-                                            : k.gauge + ((size_t)(p * 4 + MU) * 9) * Vh + i;
+        const double2* __restrict__ U = k.gauge + (BWD ? glink_off(k.g, 1 - p, MU, nb) : glink_off(k.g, p, MU, i));
+        const int Us = glink_stride(k.g);
         cd h0[3], h1[3], u[9];
         constexpr bool USE_BUF = false;   // measured: buffer-addressed loads are ~5 % slower than flat loads here (profiles/)
         if (USE_BUF && k.dbg == 0 && !(BWD && NTG)) {
             cd sp[MU < 3 ? 12 : 6];
             const int pp = BWD ? 1 - p : p;
-            load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge + ((size_t)(pp * 4 + MU) * 9) * Vh, (unsigned)Vh, (unsigned)nb,
-                                 (unsigned)(BWD ? nb : i));
+            load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge, gauge_elems(k.g), (unsigned)Vh, (unsigned)Us, (unsigned)nb,
+                                 (unsigned)glink_off(k.g, pp, MU, BWD ? nb : i));
             project_regs<MU, S>(h0, h1, sp);
         } else {
             if (MU == 0 && k.dbg == 1) {
@@ -530,7 +530,7 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
                 for (int j = 0; j < 9; j++) u[j] = mk(1.0 + j, nb);
             } else {
                 // the backward hop is the LAST of the two uses of a link: optionally load it non-temporally
-                if constexpr (BWD && NTG) load_link_nt(u, U, Vh); else load_link(u, U, Vh);
+                if constexpr (BWD && NTG) load_link_nt(u, U, Us); else load_link(u, U, Us);
             }
         }
 #pragma unroll
@@ -659,8 +659,8 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
             const int nb = BWD ? n.bwd[MU] : n.fwd[MU];
             if (sign != 0.0) {
                 const int pp = BWD ? 1 - p : p;
-                load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge + ((size_t)(pp * 4 + MU) * 9) * Vh, (unsigned)Vh, (unsigned)nb,
-                                     (unsigned)(BWD ? nb : i));
+                load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge, gauge_elems(k.g), (unsigned)Vh, (unsigned)glink_stride(k.g), (unsigned)nb,
+                                     (unsigned)glink_off(k.g, pp, MU, BWD ? nb : i));
             }
         }
     };
@@ -751,12 +751,12 @@ __global__ __launch_bounds__(512, 4) void wilson_hopsplit_persist(KArgs k, int n
 }
 
 // ------------------------------------------------------------------------------------------ staggered
-__device__ inline void stag_hop(cd (&acc)[3], const double2* __restrict__ psi, const double2* __restrict__ U, int Vh,
+__device__ inline void stag_hop(cd (&acc)[3], const double2* __restrict__ psi, const double2* __restrict__ U, int Vh, int Us,
                                 double coef, bool adj) {
     cd h[3], u[9], chi[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) h[c] = coef * ld(psi + (size_t)c * Vh);
-    load_link(u, U, Vh);
+    load_link(u, U, Us);
     if (adj) su3_mv<true>(chi, u, h); else su3_mv<false>(chi, u, h);
 #pragma unroll
     for (int c = 0; c < 3; c++) acc[c] = acc[c] + chi[c];
@@ -784,13 +784,12 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
         neighbours(k.g, p, i, n, c);
         cd acc[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
         const double2* __restrict__ psi = k.in[1 - p];
-        const double2* __restrict__ Uf = k.gauge + (size_t)(p * 4) * 9 * Vh + i;
-        const double2* __restrict__ Ub = k.gauge + (size_t)((1 - p) * 4) * 9 * Vh;
+        const int Us = glink_stride(k.g);
 #pragma unroll
         for (int mu = 0; mu < 4; mu++) {
             const double eta = stag_eta(c, mu);
-            if (n.sf[mu] != 0.0) stag_hop(acc, psi + n.fwd[mu], Uf + (size_t)mu * 9 * Vh, Vh, eta * n.sf[mu], false);
-            if (n.sb[mu] != 0.0) stag_hop(acc, psi + n.bwd[mu], Ub + (size_t)mu * 9 * Vh + n.bwd[mu], Vh, -eta * n.sb[mu], true);
+            if (n.sf[mu] != 0.0) stag_hop(acc, psi + n.fwd[mu], k.gauge + glink_off(k.g, p, mu, i), Vh, Us, eta * n.sf[mu], false);
+            if (n.sb[mu] != 0.0) stag_hop(acc, psi + n.bwd[mu], k.gauge + glink_off(k.g, 1 - p, mu, n.bwd[mu]), Vh, Us, -eta * n.sb[mu], true);
         }
         double2* __restrict__ o = k.out[p] + i;
 #pragma unroll
@@ -837,7 +836,7 @@ __device__ inline void wilson_pack_dir(const HArgs& k, int side) {
         // receiver backward hop uses (1 + SF gamma) and U^+ of the sender's link
         if (k.dagger) project<MU, 1>(h0, h1, psi, Vh); else project<MU, -1>(h0, h1, psi, Vh);
         cd u[9], x0[3], x1[3];
-        load_link(u, k.gauge + ((size_t)(ps * 4 + MU) * 9) * Vh + i, Vh);
+        load_link(u, k.gauge + glink_off(g, ps, MU, i), glink_stride(g));
         su3_mv<true>(x0, u, h0);
         su3_mv<true>(x1, u, h1);
 #pragma unroll
@@ -883,7 +882,7 @@ __device__ __forceinline__ void wilson_ext_add(cd (&acc)[12], const HArgs& k, co
             h0[cc] = sg * ld(src + (size_t)cc * Fh);
             h1[cc] = sg * ld(src + (size_t)(3 + cc) * Fh);
         }
-        load_link(u, k.gauge + ((size_t)(pout * 4 + NU) * 9) * Vh + i, Vh);
+        load_link(u, k.gauge + glink_off(g, pout, NU, i), glink_stride(g));
         su3_mv<false>(x0, u, h0);
         su3_mv<false>(x1, u, h1);
         reconstruct<NU, DAG ? -1 : 1>(acc, x0, x1);
@@ -1000,7 +999,7 @@ __device__ inline void staggered_pack_dir(const HArgs& k, int side) {
         dst = k.send_bwd[MU];
     } else {
         cd u[9], x[3];
-        load_link(u, k.gauge + ((size_t)(ps * 4 + MU) * 9) * Vh + i, Vh);
+        load_link(u, k.gauge + glink_off(g, ps, MU, i), glink_stride(g));
         su3_mv<true>(x, u, h);
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) h[cc] = x[cc];
@@ -1037,7 +1036,7 @@ __device__ __forceinline__ void staggered_ext_add(cd (&acc)[3], const HArgs& k, 
         cd h[3], u[9], x[3];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) h[cc] = cf * ld(src + (size_t)cc * Fh);
-        load_link(u, k.gauge + ((size_t)(pout * 4 + NU) * 9) * Vh + i, Vh);
+        load_link(u, k.gauge + glink_off(g, pout, NU, i), glink_stride(g));
         su3_mv<false>(x, u, h);
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) acc[cc] = acc[cc] + x[cc];

@@ -6,7 +6,7 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "liblqcd_hip.so")
+SO_PATH = os.environ.get("LQCD_HIP_LIB", os.path.join(_HERE, "csrc", "liblqcd_hip.so"))   # override: A/B builds of the same library
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "lqcd_hip.h")
 
 OK, ERR_ARG, ERR_HIP, ERR_NOT_CONVERGED, ERR_COMM, ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5
