@@ -93,7 +93,6 @@ static void geom_from_L(Geom& g, const int L[4]) {
     if (const char* e = getenv("LQCD_PAD_CHUNKS")) pad_chunks = atoi(e);
     if (pad_chunks < 0) pad_chunks = 0;
     g.Vs = ((g.Vh + 63) / 64) * 64 + 64 * pad_chunks;
-    if (pad_chunks == 0) g.Vs = g.Vh;
 }
 
 extern "C" int lqcd_index_cb(const int L[4], int x, int y, int z, int t, int* parity, int64_t* cb) {

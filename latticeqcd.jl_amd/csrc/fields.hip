@@ -43,7 +43,7 @@ __global__ void spinor_reorder(Geom g, double2* dev0, double2* dev1, double2* ho
     const size_t site = c[0] + (size_t)g.L[0] * (c[1] + (size_t)g.L[1] * (c[2] + (size_t)g.L[2] * c[3]));
     for (int s = 0; s < nspin; s++)
         for (int ic = 0; ic < 3; ic++) {
-            double2* d = dev + (size_t)(s * 3 + ic) * g.Vs + i;
+            double2* d = dev + sp_off(nspin * 3, i) + (size_t)(s * 3 + ic) * sp_stride(g);
             double2* h = host_img + ic + 3 * (site + V * s);
             if (to_device) *d = *h; else *h = *d;
         }
@@ -135,7 +135,7 @@ __global__ void spinor_fill(Geom g, double2* dev0, double2* dev1, int ncomp, uin
             const int z = (int)(splitmix64(key) >> 62);
             v = make_double2(z == 0 ? 1.0 : (z == 2 ? -1.0 : 0.0), z == 1 ? 1.0 : (z == 3 ? -1.0 : 0.0));
         }
-        dev[(size_t)k * g.Vs + i] = v;
+        dev[sp_off(ncomp, i) + (size_t)k * sp_stride(g)] = v;
     }
 }
 
@@ -459,7 +459,7 @@ extern "C" int lqcd_spinor_point_source(lqcd_spinor_t s, const int gx[4], int ic
     double2* blk = spinor_block(s, p);
     if (!blk) return LQCD_OK;
     const double2 one = make_double2(1.0, 0.0);
-    HIPCHK(hipMemcpy(blk + (size_t)(is * 3 + ic) * c->geom.Vs + coords_to_cb(c->geom, lc), &one, sizeof(one), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(blk + sp_off(s->ncomp, coords_to_cb(c->geom, lc)) + (size_t)(is * 3 + ic) * sp_stride(c->geom), &one, sizeof(one), hipMemcpyHostToDevice));
     return LQCD_OK;
 }
 

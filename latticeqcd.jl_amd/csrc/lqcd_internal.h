@@ -75,6 +75,28 @@ __host__ __device__ inline size_t gauge_elems(const Geom& g) {
 #endif
 }
 
+// ---------------------------------------------------------------- fermion-field addressing
+// LQCD_SPINOR_AOSOA = 1 (default): [parity][chunk = cb/64][comp][cb%64] (12 KiB contiguous per chunk of a Wilson field);
+// 0: [parity][comp][cb] with component stride Vs.  A parity block holds ncomp*Vs elements in both layouts, BLAS-1 is flat.
+#ifndef LQCD_SPINOR_AOSOA
+#define LQCD_SPINOR_AOSOA 1
+#endif
+__host__ __device__ inline size_t sp_off(int ncomp, int i) {   // offset of component 0 of site i inside a parity block
+#if LQCD_SPINOR_AOSOA
+    return (size_t)(i >> 6) * (size_t)(ncomp * 64) + (i & 63);
+#else
+    (void)ncomp;
+    return (size_t)i;
+#endif
+}
+__host__ __device__ inline int sp_stride(const Geom& g) {      // distance between consecutive components of one site
+#if LQCD_SPINOR_AOSOA
+    return 64;
+#else
+    return g.Vs;
+#endif
+}
+
 // ---------------------------------------------------------------- faces (halo geometry)
 // A face of direction mu holds the sites with x_mu fixed; per parity it has Fh(mu) = Vh / L[mu] sites.
 // Face index f enumerates the remaining three coordinates in increasing direction order, the first of them halved

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
     if (upd_done(k)) return;
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vs;  // component stride in sites (padded)
+    const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const int i = chunk * TB + threadIdx.x;
     const bool valid = i < k.g.Vh;
     double nrm = 0.0;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
         // diagonal term: issue its loads first so they overlap the hops instead of forming a ninth dependent round trip
         if (k.a != 0.0) {
 #pragma unroll
-            for (int j = 0; j < 12; j++) xv[j] = ld(k.xin[p] + i + (size_t)j * Vh);
+            for (int j = 0; j < 12; j++) xv[j] = ld(k.xin[p] + sp_off(12, i) + (size_t)j * Vh);
         } else {
 #pragma unroll
             for (int j = 0; j < 12; j++) xv[j] = mk(0.0, 0.0);
@@ -309,19 +309,19 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
         constexpr int SF = DAG ? -1 : 1;  // forward hop: (r - gamma) for D, (r + gamma) for D^+
 #define HOP(MU)                                                                                                  \
     if (n.sf[MU] != 0.0) {                                                                                       \
-        if constexpr (RGEN) wilson_hop_rgen<MU, SF, false>(acc, psi + n.fwd[MU], k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU], k.r); \
-        else wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU]);            \
+        if constexpr (RGEN) wilson_hop_rgen<MU, SF, false>(acc, psi + sp_off(12, n.fwd[MU]), k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU], k.r); \
+        else wilson_hop<MU, SF, false>(acc, psi + sp_off(12, n.fwd[MU]), k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU]);            \
     }                                                                                                            \
     if (n.sb[MU] != 0.0) {                                                                                       \
-        if constexpr (RGEN) wilson_hop_rgen<MU, -SF, true>(acc, psi + n.bwd[MU], k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU], k.r); \
-        else wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU]); \
+        if constexpr (RGEN) wilson_hop_rgen<MU, -SF, true>(acc, psi + sp_off(12, n.bwd[MU]), k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU], k.r); \
+        else wilson_hop<MU, -SF, true>(acc, psi + sp_off(12, n.bwd[MU]), k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU]); \
     }
         HOP(0) HOP(1) HOP(2) HOP(3)
 #undef HOP
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             cd v = mk(fma(k.b, acc[j].re, k.a * xv[j].re), fma(k.b, acc[j].im, k.a * xv[j].im));
-            emit(k, p, (size_t)j * Vh + i, v, nrm);
+            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
@@ -338,14 +338,14 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     Nbr n;
     int c[4];
     neighbours(k.g, p, i, n, c);
-    const int Vh = k.g.Vs;  // component stride in sites (padded)
+    const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const double2* __restrict__ psi = k.in[1 - p];
     const double2* __restrict__ Uf = k.gauge + glink_off(k.g, p, MU, i);
     const double2* __restrict__ Ub = k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
     const int Us = glink_stride(k.g);
     constexpr int SF = DAG ? -1 : 1;
-    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false>(acc, psi + n.fwd[MU], Uf, Vh, Us, n.sf[MU]);
-    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true>(acc, psi + n.bwd[MU], Ub, Vh, Us, n.sb[MU]);
+    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU]);
+    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU]);
 }
 
 template <bool DAG>
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     if (upd_done(k)) return;
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vs;  // component stride in sites (padded)
+    const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int i = chunk * 64 + lane;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     if (valid && k.a != 0.0) {
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + i + (size_t)(3 * w + cc) * Vh);
+        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp_off(12, i) + (size_t)(3 * w + cc) * Vh);
     }
     if (valid) {
         switch (w) {
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
             cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
             cd v = k.b * s;
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
-            emit(k, p, (size_t)j * Vh + i, v, nrm);
+            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm);
         }
     }
     if (k.norm_partial) {
@@ -481,7 +481,7 @@ __device__ inline cd bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 template <int MU, int S>
 __device__ inline void load_hop_regs(cd* sp, cd (&u)[9], const double2* psi_block, const double2* gauge, size_t gauge_n, unsigned Vs,
                                      unsigned Us, unsigned psi_site, unsigned link_off) {
-    const __amdgpu_buffer_rsrc_t rp = mkbuf(psi_block, (size_t)12 * Vs), ru = mkbuf(gauge, gauge_n);
+    const __amdgpu_buffer_rsrc_t rp = mkbuf(psi_block, (size_t)0x0FFFFFFF), ru = mkbuf(gauge, gauge_n);
     const unsigned vp = psi_site * 16u, vu = link_off * 16u, cs = Vs * 16u, us = Us * 16u;
     if constexpr (MU < 3) {
 #pragma unroll
@@ -500,14 +500,14 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
     Nbr n;
     int c[4];
     neighbours(k.g, p, i, n, c);
-    const int Vh = k.g.Vs;  // component stride in sites (padded)
+    const int Vh = sp_stride(k.g);  // spinor component stride in elements
     constexpr int S = (DAG ? -1 : 1) * (BWD ? -1 : 1);
     const double sign = BWD ? n.sb[MU] : n.sf[MU];
     const int nb = BWD ? n.bwd[MU] : n.fwd[MU];
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) { chi0[cc] = mk(0, 0); chi1[cc] = mk(0, 0); }
     if (sign != 0.0) {
-        const double2* __restrict__ psi = k.in[1 - p] + nb;
+        const double2* __restrict__ psi = k.in[1 - p] + sp_off(12, nb);
         const double2* __restrict__ U = k.gauge + (BWD ? glink_off(k.g, 1 - p, MU, nb) : glink_off(k.g, p, MU, i));
         const int Us = glink_stride(k.g);
         cd h0[3], h1[3], u[9];
@@ -515,7 +515,7 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
         if (USE_BUF && k.dbg == 0 && !(BWD && NTG)) {
             cd sp[MU < 3 ? 12 : 6];
             const int pp = BWD ? 1 - p : p;
-            load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge, gauge_elems(k.g), (unsigned)Vh, (unsigned)Us, (unsigned)nb,
+            load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge, gauge_elems(k.g), (unsigned)Vh, (unsigned)Us, (unsigned)sp_off(12, nb),
                                  (unsigned)glink_off(k.g, pp, MU, BWD ? nb : i));
             project_regs<MU, S>(h0, h1, sp);
         } else {
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
     __shared__ double red[8];
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vs;  // component stride in sites (padded)
+    const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int i = chunk * 64 + lane;
@@ -561,12 +561,12 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
     if (upd_done(k)) return;
     cd xv[2] = {mk(0, 0), mk(0, 0)}, rv[2] = {mk(0, 0), mk(0, 0)};
     if (valid && w < 6 && k.a != 0.0) {
-        xv[0] = ld(k.xin[p] + i + (size_t)(2 * w) * Vh);
-        xv[1] = ld(k.xin[p] + i + (size_t)(2 * w + 1) * Vh);
+        xv[0] = ld(k.xin[p] + sp_off(12, i) + (size_t)(2 * w) * Vh);
+        xv[1] = ld(k.xin[p] + sp_off(12, i) + (size_t)(2 * w + 1) * Vh);
     }
     if (valid && w < 6 && k.upd_scal) {
-        rv[0] = ld(k.upd[p] + i + (size_t)(2 * w) * Vh);
-        rv[1] = ld(k.upd[p] + i + (size_t)(2 * w + 1) * Vh);
+        rv[0] = ld(k.upd[p] + sp_off(12, i) + (size_t)(2 * w) * Vh);
+        rv[1] = ld(k.upd[p] + sp_off(12, i) + (size_t)(2 * w + 1) * Vh);
     }
     cd chi0[3], chi1[3];
 #pragma unroll
@@ -608,10 +608,10 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
             cd r0 = mk(fma(-al, v0.re, rv[0].re), fma(-al, v0.im, rv[0].im));
             cd r1 = mk(fma(-al, v1.re, rv[1].re), fma(-al, v1.im, rv[1].im));
             nrm = r0.re * r0.re + r0.im * r0.im + r1.re * r1.re + r1.im * r1.im;
-            double2* __restrict__ o = k.upd[p] + i + (size_t)(2 * w) * Vh;
+            double2* __restrict__ o = k.upd[p] + sp_off(12, i) + (size_t)(2 * w) * Vh;
             st(o, r0); st(o + Vh, r1);
         } else {
-            double2* __restrict__ o = k.out[p] + i + (size_t)(2 * w) * Vh;
+            double2* __restrict__ o = k.out[p] + sp_off(12, i) + (size_t)(2 * w) * Vh;
             nrm = v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
             if constexpr (NTS) { st_nt(o, v0); st_nt(o + Vh, v1); } else { st(o, v0); st(o + Vh, v1); }
         }
@@ -637,7 +637,7 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
     constexpr int W = 2 * MU + (BWD ? 1 : 0);
     constexpr int S = (DAG ? -1 : 1) * (BWD ? -1 : 1);
     constexpr int NS = (MU < 3) ? 12 : 6;   // spinor components this hop reads
-    const int Vh = k.g.Vs;
+    const int Vh = sp_stride(k.g);
     const int lane = threadIdx.x & 63;
     double nrm = 0.0;
     cd sp[NS], u[9];
@@ -659,7 +659,7 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
             const int nb = BWD ? n.bwd[MU] : n.fwd[MU];
             if (sign != 0.0) {
                 const int pp = BWD ? 1 - p : p;
-                load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge, gauge_elems(k.g), (unsigned)Vh, (unsigned)glink_stride(k.g), (unsigned)nb,
+                load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge, gauge_elems(k.g), (unsigned)Vh, (unsigned)glink_stride(k.g), (unsigned)sp_off(12, nb),
                                      (unsigned)glink_off(k.g, pp, MU, BWD ? nb : i));
             }
         }
@@ -690,12 +690,12 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
         cd xv[2] = {mk(0, 0), mk(0, 0)}, rv[2] = {mk(0, 0), mk(0, 0)};
         if constexpr (W < 6) {
             if (cvalid && k.a != 0.0) {
-                xv[0] = ld(k.xin[cp] + ci + (size_t)(2 * W) * Vh);
-                xv[1] = ld(k.xin[cp] + ci + (size_t)(2 * W + 1) * Vh);
+                xv[0] = ld(k.xin[cp] + sp_off(12, ci) + (size_t)(2 * W) * Vh);
+                xv[1] = ld(k.xin[cp] + sp_off(12, ci) + (size_t)(2 * W + 1) * Vh);
             }
             if (cvalid && k.upd_scal) {
-                rv[0] = ld(k.upd[cp] + ci + (size_t)(2 * W) * Vh);
-                rv[1] = ld(k.upd[cp] + ci + (size_t)(2 * W + 1) * Vh);
+                rv[0] = ld(k.upd[cp] + sp_off(12, ci) + (size_t)(2 * W) * Vh);
+                rv[1] = ld(k.upd[cp] + sp_off(12, ci) + (size_t)(2 * W + 1) * Vh);
             }
         }
         const int vb2 = vb + gridDim.x;
@@ -713,7 +713,7 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
                     v1 = mk(fma(-al, v1.re, rv[1].re), fma(-al, v1.im, rv[1].im));
                 }
                 nrm += v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
-                double2* __restrict__ o = (k.upd_scal ? k.upd[cp] : k.out[cp]) + ci + (size_t)(2 * W) * Vh;
+                double2* __restrict__ o = (k.upd_scal ? k.upd[cp] : k.out[cp]) + sp_off(12, ci) + (size_t)(2 * W) * Vh;
                 st(o, v0);
                 st(o + Vh, v1);
             }
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
     if (upd_done(k)) return;
     int chunk, p;
     map_block(k, chunk, p);
-    const int Vh = k.g.Vs;  // component stride in sites (padded)
+    const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const int i = chunk * TB + threadIdx.x;
     const bool valid = i < k.g.Vh;
     double nrm = 0.0;
@@ -788,18 +788,17 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
 #pragma unroll
         for (int mu = 0; mu < 4; mu++) {
             const double eta = stag_eta(c, mu);
-            if (n.sf[mu] != 0.0) stag_hop(acc, psi + n.fwd[mu], k.gauge + glink_off(k.g, p, mu, i), Vh, Us, eta * n.sf[mu], false);
-            if (n.sb[mu] != 0.0) stag_hop(acc, psi + n.bwd[mu], k.gauge + glink_off(k.g, 1 - p, mu, n.bwd[mu]), Vh, Us, -eta * n.sb[mu], true);
+            if (n.sf[mu] != 0.0) stag_hop(acc, psi + sp_off(3, n.fwd[mu]), k.gauge + glink_off(k.g, p, mu, i), Vh, Us, eta * n.sf[mu], false);
+            if (n.sb[mu] != 0.0) stag_hop(acc, psi + sp_off(3, n.bwd[mu]), k.gauge + glink_off(k.g, 1 - p, mu, n.bwd[mu]), Vh, Us, -eta * n.sb[mu], true);
         }
-        double2* __restrict__ o = k.out[p] + i;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             cd v = k.b * acc[j];
             if (k.a != 0.0) {
-                cd xv = ld(k.xin[p] + i + (size_t)j * Vh);
+                cd xv = ld(k.xin[p] + sp_off(3, i) + (size_t)j * Vh);
                 v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
             }
-            emit(k, p, (size_t)j * Vh + i, v, nrm);
+            emit(k, p, (size_t)j * Vh + sp_off(3, i), v, nrm);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
@@ -815,7 +814,7 @@ template <int MU>
 __device__ inline void wilson_pack_dir(const HArgs& k, int side) {
     const Geom& g = k.g;
     if (!g.part[MU]) return;
-    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
+    const int Fh = g.Vh / g.L[MU], Vh = sp_stride(g);
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslots * Fh) return;
@@ -825,7 +824,7 @@ __device__ inline void wilson_pack_dir(const HArgs& k, int side) {
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
     const int i = coords_to_cb(g, c);
-    const double2* __restrict__ psi = (ps ? k.in[1] : k.in[0]) + i;
+    const double2* __restrict__ psi = (ps ? k.in[1] : k.in[0]) + sp_off(12, i);
     cd h0[3], h1[3];
     double2* dst;
     if (side == 0) {
@@ -870,7 +869,7 @@ template <int NU, bool DAG>
 __device__ __forceinline__ void wilson_ext_add(cd (&acc)[12], const HArgs& k, const int (&c)[4], int slot, int pout, int i) {
     const Geom& g = k.g;
     if (!g.part[NU]) return;
-    const int Fh = g.Vh / g.L[NU], Vh = g.Vs;
+    const int Fh = g.Vh / g.L[NU], Vh = sp_stride(g);
     if (c[NU] == g.L[NU] - 1) {
         // forward hop at the upper face: ghost = P psi(n+nu) from the +nu neighbour; multiply by own U_nu(n)
         const int f = coords_to_face(g, NU, c);
@@ -918,7 +917,7 @@ template <int MU, bool DAG>
 __device__ __forceinline__ double wilson_ext_face(const HArgs& k, int side) {
     const Geom& g = k.g;
     if (!g.part[MU]) return 0.0;
-    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
+    const int Fh = g.Vh / g.L[MU], Vh = sp_stride(g);
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslots * Fh) return 0.0;
@@ -936,7 +935,7 @@ __device__ __forceinline__ double wilson_ext_face(const HArgs& k, int side) {
     if (MU <= 2) wilson_ext_add<2, DAG>(acc, k, c, slot, pout, i);
     wilson_ext_add<3, DAG>(acc, k, c, slot, pout, i);
     const double coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
-    double2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + i;
+    double2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp_off(12, i);
     double corr = 0.0;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
@@ -981,7 +980,7 @@ template <int MU>
 __device__ inline void staggered_pack_dir(const HArgs& k, int side) {
     const Geom& g = k.g;
     if (!g.part[MU]) return;
-    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
+    const int Fh = g.Vh / g.L[MU], Vh = sp_stride(g);
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslots * Fh) return;
@@ -993,7 +992,7 @@ __device__ inline void staggered_pack_dir(const HArgs& k, int side) {
     const int i = coords_to_cb(g, c);
     cd h[3];
 #pragma unroll
-    for (int cc = 0; cc < 3; cc++) h[cc] = ld((ps ? k.in[1] : k.in[0]) + i + (size_t)cc * Vh);
+    for (int cc = 0; cc < 3; cc++) h[cc] = ld((ps ? k.in[1] : k.in[0]) + sp_off(3, i) + (size_t)cc * Vh);
     double2* dst;
     if (side == 0) {
         dst = k.send_bwd[MU];
@@ -1024,7 +1023,7 @@ template <int NU>
 __device__ __forceinline__ void staggered_ext_add(cd (&acc)[3], const HArgs& k, const int (&c)[4], int slot, int pout, int i) {
     const Geom& g = k.g;
     if (!g.part[NU]) return;
-    const int Fh = g.Vh / g.L[NU], Vh = g.Vs;
+    const int Fh = g.Vh / g.L[NU], Vh = sp_stride(g);
     int e = 0;
 #pragma unroll
     for (int j = 0; j < NU; j++) e += c[j];
@@ -1054,7 +1053,7 @@ template <int MU>
 __device__ inline double staggered_ext_face(const HArgs& k, int side) {
     const Geom& g = k.g;
     if (!g.part[MU]) return 0.0;
-    const int Fh = g.Vh / g.L[MU], Vh = g.Vs;
+    const int Fh = g.Vh / g.L[MU], Vh = sp_stride(g);
     const int nslots = k.parity_mode == 2 ? 2 : 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslots * Fh) return 0.0;
@@ -1070,7 +1069,7 @@ __device__ inline double staggered_ext_face(const HArgs& k, int side) {
     if (MU <= 2) staggered_ext_add<2>(acc, k, c, slot, pout, i);
     staggered_ext_add<3>(acc, k, c, slot, pout, i);
     const double coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
-    double2* o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + i;
+    double2* o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp_off(3, i);
     double corr = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
