@@ -87,6 +87,7 @@ static void geom_from_L(Geom& g, const int L[4]) {
     g.XH = L[0] / 2;
     g.Vh = (L[0] / 2) * L[1] * L[2] * L[3];
     g.nch = (g.Vh + 63) / 64;
+    g.dXH = make_fastdiv(g.XH); g.dL1 = make_fastdiv(L[1]); g.dL2 = make_fastdiv(L[2]);
     // component stride: Vh rounded up to 64 sites (1 KiB, keeps every wave load on 8 whole cache lines) plus
     // LQCD_PAD_CHUNKS * 64 sites (default 1) so that consecutive component arrays are NOT a power-of-two apart
     int pad_chunks = 1;

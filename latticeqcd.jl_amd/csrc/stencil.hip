@@ -34,6 +34,8 @@ struct KArgs {
     int nsub;  // sub-domains per t-slice (multiple of 8): XCD k sweeps sub-domains k, k+8, ... one after the other
     int cpp;   // chunks per z-plane per parity
     int ysplit;  // sub-domains are (y,z) tiles: ysplit tiles across y (1 = plain z-slabs)
+    int cpr, ty, tz;                              // derived tile sizes (chunks)
+    FastDiv d_perpass, d_cpr, d_ysplit, d_ty;     // magic numbers for the block -> chunk map
     int dbg;     // timing ablations only (wrong results): 1 skip x-hop spinor loads, 2 skip x-hop link loads, 3 skip mat-vec
     double* norm_partial;
     const double* upd_scal;   // update mode (see StencilCall)
@@ -86,20 +88,20 @@ __device__ inline void map_block_v(const KArgs& k, int b, int& chunk, int& p) {
     const int nb = k.nblocks;
     const bool both = k.parity_mode == 2;
     if (k.remap == 2 && k.cps > 0) {
-        const int cpr = k.cps / k.nsub;             // chunks per sub-domain per t-slice (per parity)
+        const int cpr = k.cpr;                      // chunks per sub-domain per t-slice (per parity)
         const int xcd = b & 7;
         int j = b >> 3;
         if (both) { p = j & 1; j >>= 1; } else p = k.parity_mode;
         const int per_pass = cpr * k.g.L[3];
-        const int pass = j / per_pass;
+        const int pass = fdiv(j, k.d_perpass);
         j -= pass * per_pass;
-        const int t = j / cpr, m = j - t * cpr, sd = xcd + 8 * pass;
+        const int t = fdiv(j, k.d_cpr), m = j - t * cpr, sd = xcd + 8 * pass;
         int s;
         if (k.ysplit > 1) {
             // 2-D tiling of the (y-chunk, z) grid of a t-slice: sub-domain sd = (sy, sz), tile ty x tz chunks
-            const int sy = sd % k.ysplit, sz = sd / k.ysplit;
-            const int ty = k.cpp / k.ysplit, tz = cpr / ty;
-            const int zz = m / ty, yy = m - zz * ty;
+            const int sz = fdiv(sd, k.d_ysplit), sy = sd - sz * k.ysplit;
+            const int ty = k.ty, tz = k.tz;
+            const int zz = fdiv(m, k.d_ty), yy = m - zz * ty;
             s = (sz * tz + zz) * k.cpp + sy * ty + yy;
         } else {
             s = sd * cpr + m;
@@ -1116,6 +1118,13 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.dbg = c->tun.dbg;
     const int ys = c->tun.xcd_ysplit;
     if (ys > 1 && k.cps > 0 && k.cpp > 0 && k.cpp % ys == 0 && k.nsub % ys == 0 && c->geom.L[2] % (k.nsub / ys) == 0) k.ysplit = ys;
+    k.cpr = k.cps > 0 ? k.cps / k.nsub : 1;
+    k.ty = k.ysplit > 1 ? k.cpp / k.ysplit : 1;
+    k.tz = k.cpr / k.ty;
+    k.d_perpass = make_fastdiv(std::max(1, k.cpr * c->geom.L[3]));
+    k.d_cpr = make_fastdiv(std::max(1, k.cpr));
+    k.d_ysplit = make_fastdiv(std::max(1, k.ysplit));
+    k.d_ty = make_fastdiv(std::max(1, k.ty));
     k.norm_partial = s.norm_partial;
     k.upd_scal = s.upd_scal;
     k.upd[0] = s.upd[0]; k.upd[1] = s.upd[1];
