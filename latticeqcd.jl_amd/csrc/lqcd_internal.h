@@ -79,7 +79,9 @@ __host__ __device__ inline int coords_to_cb(const Geom& g, const int c[4]) {
 #define LQCD_GAUGE_AOSOA 1
 #endif
 __host__ __device__ inline size_t glink_off(const Geom& g, int p, int mu, int i) {   // element (a*3+b) = 0 of U_mu at (p, i)
-#if LQCD_GAUGE_AOSOA
+#if LQCD_GAUGE_AOSOA == 2   // parities interleaved per chunk: [chunk][parity][mu][9][64]
+    return ((((size_t)(i >> 6) * 2 + p) * 4 + mu) * 9) * 64 + (i & 63);
+#elif LQCD_GAUGE_AOSOA
     return ((((size_t)p * g.nch + (size_t)(i >> 6)) * 4 + mu) * 9) * 64 + (i & 63);
 #else
     return ((size_t)(p * 4 + mu) * 9) * g.Vs + i;
