@@ -57,7 +57,8 @@ def main():
     lq.lib.lib()
 
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("LQCD_BENCH_FORCE_DIST"))   # testing aid: take the N > 1 control path at world size 1
+    if world > 1 or force_dist:
         import torch  # noqa: F401  (control plane only)
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,7 +72,7 @@ def main():
     for kv in args.set:
         k, v = kv.split("=")
         lat.set_param(k, int(v))
-    if world > 1:
+    if world > 1 or force_dist:
         box = [lq.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         lat.comm_init(box[0])
