@@ -575,6 +575,137 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
     return st;
 }
 
+// ---------------------------------------------------------------------------------- multi-shift CG (RHMC solver)
+namespace lqcd {
+// x += a p ; r -= a q ; partial |r|^2      (scalars from the host)
+__global__ __launch_bounds__(UB) void ms_update_xr(double a, double2* __restrict__ x, double2* __restrict__ r, const double2* __restrict__ p,
+                                                    const double2* __restrict__ q, size_t n, double* partial) {
+    __shared__ double red[UB / 64];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 pv = p[i], qv = q[i];
+        double2 xv = x[i], rv = r[i];
+        xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y);
+        rv.x = fma(-a, qv.x, rv.x); rv.y = fma(-a, qv.y, rv.y);
+        x[i] = xv; r[i] = rv;
+        acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < UB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+// shifted system j:  x_j += a_j p_j ;  p_j = b_j p_j + z_j r     (one pass over x_j, p_j, r)
+__global__ __launch_bounds__(UB) void ms_update_shift(double aj, double bj, double zj, double2* __restrict__ xj, double2* __restrict__ pj,
+                                                       const double2* __restrict__ r, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        double2 pv = pj[i], xv = xj[i];
+        const double2 rv = r[i];
+        xv.x = fma(aj, pv.x, xv.x); xv.y = fma(aj, pv.y, xv.y);
+        pv.x = fma(bj, pv.x, zj * rv.x); pv.y = fma(bj, pv.y, zj * rv.y);
+        xj[i] = xv; pj[i] = pv;
+    }
+}
+}  // namespace lqcd
+
+// (D^+D + sigma_j) x_j = b for all j < ns, plus the unshifted solution x0 (may be NULL): one Krylov space, the shifted
+// iterates follow from the zeta recurrences (Jegerlehner).  Zero initial guesses.  Stops when rr * max(1, max_j zeta_j^2) < eps.
+extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
+                                        double eps, int maxiter, int* iters, double* final_rr) {
+    ARGCHK(op && b && ns >= 0 && (ns == 0 || (xs && sigma)), "lqcd_solve_multishift_cg: null argument");
+    ARGCHK(b->ctx == op->ctx && b->kind == op->kind && b->subset == LQCD_FULL, "lqcd_solve_multishift_cg: b must be a FULL spinor of the operator");
+    for (int j = 0; j < ns; j++) {
+        ARGCHK(xs[j] && xs[j]->ctx == op->ctx && xs[j]->kind == op->kind && xs[j]->subset == LQCD_FULL && xs[j] != b,
+               "lqcd_solve_multishift_cg: xs[j] must be distinct FULL spinors of the operator");
+        ARGCHK(sigma[j] >= 0.0, "lqcd_solve_multishift_cg: shifts must be non-negative");
+    }
+    if (x0) LQCHK(check_full(op, x0, b, "lqcd_solve_multishift_cg"));
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = b->elems, bytes = n * sizeof(double2);
+    lqcd_spinor_s* xbase = x0 ? x0 : scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* r = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* p = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* q = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* tmp = scratch_get(c, op->kind, LQCD_FULL);
+    std::vector<lqcd_spinor_s*> ps(ns, nullptr);
+    bool ok = xbase && r && p && q && tmp;
+    for (int j = 0; j < ns && ok; j++) { ps[j] = scratch_get(c, op->kind, LQCD_FULL); ok = ps[j] != nullptr; }
+    auto release = [&]() {
+        if (!x0) scratch_put(xbase);
+        scratch_put(r); scratch_put(p); scratch_put(q); scratch_put(tmp);
+        for (auto* s : ps) scratch_put(s);
+    };
+    if (!ok) { release(); return LQCD_ERR_HIP; }
+    auto run = [&]() -> int {
+        HIPCHK(hipMemsetAsync(xbase->data, 0, bytes, c->stream));
+        HIPCHK(hipMemcpyAsync(r->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(p->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+        for (int j = 0; j < ns; j++) {
+            HIPCHK(hipMemsetAsync(xs[j]->data, 0, bytes, c->stream));
+            HIPCHK(hipMemcpyAsync(ps[j]->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+        }
+        std::vector<double> zm(ns, 1.0), z0(ns, 1.0), zp(ns, 1.0);
+        double alpha_m = 1.0, beta_m = 0.0, rr = 0.0;
+        LQCHK(blas_norm2(c, r->data, n, &rr, true));
+        double resid = rr;
+        int it = 0, st = LQCD_ERR_NOT_CONVERGED;
+        if (rr < eps) st = LQCD_OK;
+        const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
+        for (it = 1; st != LQCD_OK && it <= maxiter; it++) {
+            // q = D^+ D p ;  p.(D^+D p) = |D p|^2 from the stencil's block partials
+            LQCHK(op_apply_async(op, tmp, p, 0, c->d_partial));
+            LQCHK(reduce_to_slot(c, nbs, 1, S_RED0, true));
+            LQCHK(op_apply_async(op, q, tmp, 1, nullptr));
+            HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            const double pAp = c->h_scal[0];
+            const double alpha = rr / pAp;
+            const int nb = stream_grid(c, n);
+            hipLaunchKernelGGL(ms_update_xr, dim3(nb), dim3(UB), 0, c->stream, alpha, xbase->data, r->data, p->data, q->data, n, c->d_partial);
+            HIPCHK(hipGetLastError());
+            LQCHK(reduce_to_slot(c, nb, 1, S_RED0, true));
+            HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            const double rrn = c->h_scal[0];
+            const double beta = rrn / rr;
+            LQCHK(blas_axpby(c, 1.0, 0.0, r->data, beta, 0.0, p->data, n));   // p = r + beta p
+            double zmax = 0.0;
+            for (int j = 0; j < ns; j++) {
+                const double den = zm[j] * alpha_m * (1.0 + alpha * sigma[j]) + alpha * beta_m * (zm[j] - z0[j]);
+                zp[j] = z0[j] * zm[j] * alpha_m / den;
+                const double ratio = zp[j] / z0[j];
+                hipLaunchKernelGGL(ms_update_shift, dim3(nb), dim3(UB), 0, c->stream, ratio * alpha, ratio * ratio * beta, zp[j],
+                                   xs[j]->data, ps[j]->data, r->data, n);
+                zmax = std::max(zmax, std::fabs(zp[j]));
+            }
+            HIPCHK(hipGetLastError());
+            for (int j = 0; j < ns; j++) { zm[j] = z0[j]; z0[j] = zp[j]; }
+            alpha_m = alpha; beta_m = beta; rr = rrn;
+            resid = rr * (zmax > 1.0 ? zmax * zmax : 1.0);
+            if (!std::isfinite(resid)) { set_error("multi-shift CG: residual is not finite"); break; }
+            if (resid < eps) { st = LQCD_OK; break; }
+        }
+        if (it > maxiter) it = maxiter;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (iters) *iters = it;
+        if (final_rr) *final_rr = resid;
+        if (st != LQCD_OK) {
+            set_error("The shifted CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(resid));
+            return LQCD_ERR_NOT_CONVERGED;
+        }
+        return LQCD_OK;
+    };
+    const int st = run();
+    release();
+    return st;
+}
+
 // ---------------------------------------------------------------------------------- C API: timing
 extern "C" int lqcd_bench_dslash(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps, double* ms) {
     LQCHK(check_full(op, out, in, "lqcd_bench_dslash"));

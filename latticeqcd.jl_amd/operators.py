@@ -307,6 +307,19 @@ def solve_DinvX_(y, A, x, return_info=False):
     return (it.value, rr.value) if return_info else None
 
 
+def shiftedcg(vec_x, vec_beta, x, A, b, eps=None, maxsteps=None, return_info=False):
+    """shiftedcg(vec_x, vec_β, x, A, b): (A + β_j) vec_x[j] = b for every shift and A x = b, A = D'D (RHMC; README.md:132).
+    Zero initial guesses; raises NotConverged after maxsteps."""
+    if not isinstance(A, DdagD_operator):
+        raise LQCDError(_l.ERR_ARG, "shiftedcg needs a DdagD_operator")
+    sig = (C.c_double * len(vec_beta))(*[float(v) for v in vec_beta])
+    it, rr = C.c_int(0), C.c_double(0)
+    check(_l.lib().lqcd_solve_multishift_cg(A.D._h, x._h if x is not None else None, _harr(vec_x), b._h, sig, len(vec_beta),
+                                            C.c_double(A.eps_CG if eps is None else eps),
+                                            int(A.MaxCGstep if maxsteps is None else maxsteps), C.byref(it), C.byref(rr)))
+    return (it.value, rr.value) if return_info else None
+
+
 # ------------------------------------------------------------------------------------ timing helpers (bench.py)
 def bench_dslash(D, out, inp, warm=20, reps=200):
     ms = C.c_double(0)

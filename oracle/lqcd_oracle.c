@@ -499,3 +499,66 @@ int orc_wilson_bicgstab_eo(double* xd, const double* U, const double* bd, const 
     free(be); free(bo); free(xe); free(w); free(e.w1); free(e.w2);
     return st;
 }
+
+/* ------------------------------------------------------------------ multi-shift CG  (RHMC)
+ * Solves (D^+D + sigma_j) x_j = b for all shifts at the cost of one Krylov space (Jegerlehner's shifted CG, the algorithm
+ * of LatticeDiracOperators' `shiftedcg`, [EXT-RECALL]): CG on the unshifted system, shifted iterates by the zeta recurrences.
+ * x0 = unshifted solution.  Zero initial guesses.  Stop when rr * max_j zeta_j^2 < eps.  Return 0 = converged. */
+int orc_multishift_cg(int kind, double* x0d, double* xsd, const double* U, const double* bd, const int L[4], double km, double r,
+                      const int bc[4], const double* sigma, int ns, double eps, int maxiter, int* iters, double* final_rr) {
+    op_t o = mk_op(kind, U, L, km, r, bc);
+    long n = o.n;
+    const cplx* b = (const cplx*)bd;
+    cplx* x0 = (cplx*)x0d;
+    cplx* xs = (cplx*)xsd;
+    cplx* res = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* p = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* q = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* tmp = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* ps = (cplx*)malloc(sizeof(cplx) * n * (ns > 0 ? ns : 1));
+    double* zm = (double*)malloc(sizeof(double) * (ns + 1));
+    double* z0 = (double*)malloc(sizeof(double) * (ns + 1));
+    double* zp = (double*)malloc(sizeof(double) * (ns + 1));
+    memset(x0, 0, sizeof(cplx) * n);
+    memset(xs, 0, sizeof(cplx) * n * ns);
+    memcpy(res, b, sizeof(cplx) * n);
+    memcpy(p, b, sizeof(cplx) * n);
+    for (int j = 0; j < ns; j++) { memcpy(ps + j * n, b, sizeof(cplx) * n); zm[j] = 1.0; z0[j] = 1.0; }
+    double alpha_m = 1.0, beta_m = 0.0, rr = norm2(res, n), resid = rr;
+    int status = 1, it = 0;
+    if (rr < eps) { status = 0; goto done; }
+    for (it = 1; it <= maxiter; it++) {
+        op_D(&o, tmp, p, 0);
+        op_D(&o, q, tmp, 1);
+        double pAp = creal(cdot(p, q, n));
+        double alpha = rr / pAp;
+        for (long i = 0; i < n; i++) x0[i] += alpha * p[i];
+        for (long i = 0; i < n; i++) res[i] -= alpha * q[i];
+        double rrn = norm2(res, n);
+        double beta = rrn / rr;
+        for (long i = 0; i < n; i++) p[i] = beta * p[i] + res[i];
+        double zmax = 0.0;
+        for (int j = 0; j < ns; j++) {
+            double den = zm[j] * alpha_m * (1.0 + alpha * sigma[j]) + alpha * beta_m * (zm[j] - z0[j]);
+            zp[j] = z0[j] * zm[j] * alpha_m / den;
+            double aj = (zp[j] / z0[j]) * alpha;
+            double bj = (zp[j] / z0[j]) * (zp[j] / z0[j]) * beta;
+            cplx* xj = xs + j * n;
+            cplx* pj = ps + j * n;
+            for (long i = 0; i < n; i++) xj[i] += aj * pj[i];
+            for (long i = 0; i < n; i++) pj[i] = bj * pj[i] + zp[j] * res[i];
+            if (fabs(zp[j]) > zmax) zmax = fabs(zp[j]);
+        }
+        for (int j = 0; j < ns; j++) { zm[j] = z0[j]; z0[j] = zp[j]; }
+        alpha_m = alpha; beta_m = beta; rr = rrn;
+        if (ns == 0) zmax = 1.0;
+        resid = rr * (zmax > 1.0 ? zmax * zmax : 1.0);
+        if (resid < eps) { status = 0; break; }
+    }
+    if (it > maxiter) it = maxiter;
+done:
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = resid;
+    free(res); free(p); free(q); free(tmp); free(ps); free(zm); free(z0); free(zp);
+    return status;
+}

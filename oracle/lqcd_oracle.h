@@ -67,6 +67,11 @@ int orc_bicgstab(int kind, double* x, const double* U, const double* b, const in
 int orc_wilson_bicgstab_eo(double* x, const double* U, const double* b, const int L[4], double kappa, double r,
                            const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr);
 
+/* multi-shift CG: (D^+D + sigma_j) x_j = b, j < ns, plus the unshifted solution x0 (RHMC solver).
+ * xs holds ns vectors back to back.  Stops when rr * max(1, max_j zeta_j^2) < eps. */
+int orc_multishift_cg(int kind, double* x0, double* xs, const double* U, const double* b, const int L[4], double kappa_or_mass,
+                      double r, const int bc[4], const double* sigma, int ns, double eps, int maxiter, int* iters, double* final_rr);
+
 /* fixed-length CG window with the exit test disabled (timing only): runs exactly niter iterations */
 void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4],
                         double kappa_or_mass, double r, const int bc[4], int niter);

@@ -120,6 +120,17 @@ def cg_DdagD_fixed(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), niter=1):
     return x
 
 
+def multishift_cg(kind, U, b, L, km, sigmas, r=1.0, bc=(1, 1, 1, -1), eps=1e-19, maxiter=3000):
+    """Returns (x0, [x_j], iters, resid, status): (D^+D + sigma_j) x_j = b and the unshifted solution x0."""
+    sig = np.ascontiguousarray(sigmas, dtype=np.float64)
+    x0 = np.zeros_like(b)
+    xs = np.zeros((len(sig),) + b.shape, dtype=np.complex128)
+    it, rr = C.c_int(0), C.c_double(0)
+    st = lib().orc_multishift_cg(int(kind), _p(x0), _p(xs), _p(U), _p(b), _i4(L), C.c_double(km), C.c_double(r), _i4(bc),
+                                 _p(sig), len(sig), C.c_double(eps), int(maxiter), C.byref(it), C.byref(rr))
+    return x0, [xs[j] for j in range(len(sig))], it.value, rr.value, st
+
+
 def bicgstab(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000, x0=None):
     x = np.zeros_like(b) if x0 is None else x0.copy()
     it, rr = C.c_int(0), C.c_double(0)

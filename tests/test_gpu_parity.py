@@ -517,3 +517,36 @@ def test_full_size_32x32x32x64_identities(gpu):
     lq.add_fermion_(r, -1.0, b)
     assert lq.dot(r, r).real < 1e-9
     assert n_ref > 0
+
+
+# ------------------------------------------------------------------ multi-shift CG
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+def test_multishift_cg_matches_oracle(gpu, orc, kind_name):
+    lq = gpu
+    L = (4, 4, 4, 8)
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    km = KAPPA if kind == lq.WILSON else MASS
+    lat, Uh, Ud, D = setup(lq, orc, L, kind, seed=71)
+    b_h = host_spinor(orc, lat, kind, 72)
+    b = lq.Fermionfields(lat, kind).upload(b_h)
+    sig = [0.0, 0.004, 0.06, 0.9, 4.0]
+    xs = [b.similar() for _ in sig]
+    x0 = b.similar()
+    A = lq.DdagD_operator(D)
+    it, resid = lq.shiftedcg(xs, sig, x0, A, b, eps=1e-20, return_info=True)
+    o0, oxs, oit, oresid, st = orc.multishift_cg(orc.WILSON if kind == lq.WILSON else orc.STAGGERED, Uh, b_h, L, km, sig, eps=1e-20)
+    assert st == 0 and resid < 1e-20 and abs(it - oit) <= 1
+    assert rel_err(x0.download(), o0) < 1e-9
+    for x, ox, s in zip(xs, oxs, sig):
+        assert rel_err(x.download(), ox) < 1e-9
+        # true residual of the shifted system recomputed on the device
+        r = b.similar()
+        lq.mul_(r, A, x)
+        lq.add_fermion_(r, s, x, -1.0, b)
+        assert lq.dot(r, r).real < 1e-18
+    # without the unshifted solution, and non-convergence raises
+    lq.shiftedcg(xs[:2], sig[:2], None, A, b, eps=1e-20)
+    with pytest.raises(lq.NotConverged):
+        lq.shiftedcg(xs, sig, x0, A, b, eps=1e-30, maxsteps=3)
+    with pytest.raises(lq.LQCDError):
+        lq.shiftedcg(xs[:1], [-1.0], x0, A, b)

@@ -192,3 +192,26 @@ def test_staggered_cg(orc):
     assert st == 0 and rr < 1e-10
     res = b - orc.staggered_D(U, orc.staggered_D(U, x, L, MASS, BC), L, MASS, BC, dagger=True)
     assert np.vdot(res, res).real < 2e-10
+
+
+@pytest.mark.parametrize("kind_name", ["wilson", "staggered"])
+def test_multishift_cg_true_residuals(orc, kind_name):
+    """Multi-shift CG (RHMC solver): every shifted system is solved from one Krylov space."""
+    L = (4, 4, 4, 4)
+    U = orc.hot_gauge(L, 61)
+    kind, km, shape = (orc.WILSON, KAPPA, orc.wilson_shape(L)) if kind_name == "wilson" else (orc.STAGGERED, MASS, orc.staggered_shape(L))
+    b = orc.gaussian_spinor(shape, 62)
+    sig = [0.0, 0.003, 0.05, 0.7, 3.0]
+    x0, xs, it, resid, st = orc.multishift_cg(kind, U, b, L, km, sig, eps=1e-20)
+    assert st == 0 and resid < 1e-20
+
+    def A(v):
+        return orc.apply_D(kind, U, orc.apply_D(kind, U, np.ascontiguousarray(v), L, km), L, km, dagger=True)
+
+    assert np.vdot(A(x0) - b, A(x0) - b).real < 2e-20
+    for s, x in zip(sig, xs):
+        res = A(x) + s * x - b
+        assert np.vdot(res, res).real < 2e-20
+    assert rel_err(xs[0], x0) < 1e-12                      # sigma = 0 reproduces the base solve
+    xcg, itcg, rrcg, stcg = orc.cg_DdagD(kind, U, b, L, km, eps=1e-20)
+    assert rel_err(x0, xcg) < 1e-9 and abs(it - itcg) <= 1
