@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configurations that are parity-test cases rather than the bench line:
+  configs[1]  8^4 staggered Dslash + CG to 1e-10 (hot start)
+  configs[2]  16^3x32 Wilson, even-odd preconditioned BiCGStab vs plain BiCGStab vs CG on D^+D
+  8(f) rank 3 multi-shift CG (16^3x32 staggered, 10 shifts)
+Prints one JSON object per configuration (time-to-solution, iterations, Dslash roofline fraction).  Not the driver's bench.py."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import latticeqcd_jl_amd as lq  # noqa: E402
+
+KAPPA, MASS = 0.141139, 0.5
+
+
+def timed(fn, reps=3):
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return best, out
+
+
+def main():
+    res = []
+    # ---- configs[1]: 8^4 staggered
+    L = (8, 8, 8, 8)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": MASS, "eps_CG": 1e-10})
+    b = lq.Fermionfields(lat, lq.STAGGERED)
+    lq.gauss_distribution_fermion_(b, 112)
+    x, y = b.similar(), b.similar()
+    ms = lq.bench_dslash(D, y, b, warm=50, reps=500)
+    V = 8 ** 4
+
+    def solve():
+        lq.clear_fermion_(x)
+        return lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+    dt, (it, rr) = timed(solve)
+    res.append({"config": "8^4 staggered Dslash + CG to 1e-10, fp64, hot start", "dslash_us": 1e3 * ms,
+                "dslash_gflops": 570 * V / ms / 1e6, "roofline_frac_672B": 672 * V / ms / 1e6 / 8000, "cg_iters": it,
+                "cg_final_rr": rr, "cg_ms": 1e3 * dt, "note": "4096 sites: launch-latency bound, 64 workgroups"})
+    # ---- configs[2]: 16^3x32 Wilson, even-odd BiCGStab
+    L = (16, 16, 16, 32)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-16})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    x, y = b.similar(), b.similar()
+    ms = lq.bench_dslash(D, y, b, warm=50, reps=500)
+    V = 16 ** 3 * 32
+    out = {"config": "16^3x32 Wilson Dslash + BiCGStab (even-odd preconditioned), fp64, hot start", "dslash_us": 1e3 * ms,
+           "dslash_gflops": 1320 * V / ms / 1e6, "roofline_frac_960B": 960 * V / ms / 1e6 / 8000}
+    for method in ("bicgstab_evenodd", "bicgstab"):
+        D.method_CG = method
+
+        def solve():
+            lq.clear_fermion_(x)
+            return lq.solve_DinvX_(x, D, b, return_info=True)
+        dt, (it, rr) = timed(solve)
+        out[method] = {"iters": it, "final_rr": rr, "ms": 1e3 * dt}
+
+    def solve_cg():
+        lq.clear_fermion_(x)
+        return lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+    dt, (it, rr) = timed(solve_cg)
+    out["cg_DdagD"] = {"iters": it, "final_rr": rr, "ms": 1e3 * dt, "iters_per_s": it / dt}
+    res.append(out)
+    # ---- multi-shift CG, staggered 16^3x32, 10 shifts
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": 0.05, "eps_CG": 1e-16})
+    b = lq.Fermionfields(lat, lq.STAGGERED)
+    lq.gauss_distribution_fermion_(b, 112)
+    sig = [1e-4 * 3 ** k for k in range(10)]
+    xs = [b.similar() for _ in sig]
+    x0 = b.similar()
+    A = lq.DdagD_operator(D)
+    dt, (it, rr) = timed(lambda: lq.shiftedcg(xs, sig, x0, A, b, return_info=True))
+    dts, (its, rrs) = timed(lambda: (lq.clear_fermion_(x0), lq.solve_DinvX_(x0, A, b, return_info=True))[1])
+    res.append({"config": "16^3x32 staggered multi-shift CG, 10 shifts, mass 0.05 (RHMC solver)", "iters": it, "resid": rr,
+                "ms": 1e3 * dt, "single_cg_iters": its, "single_cg_ms": 1e3 * dts,
+                "cost_vs_10_separate_solves": dt / (10 * dts)})
+    for r in res:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+/*
+ * c_abi_smoke.c -- drives liblqcd_hip.so from plain C (no Python, no torch): the drop-in boundary is a C ABI.
+ * Built and run by tests/test_gpu_parity.py::test_c_abi_from_plain_c on the GPU box:
+ *   gcc -std=c99 -I include tests/c_abi_smoke.c -o /tmp/c_abi_smoke -L latticeqcd.jl_amd/csrc -llqcd_hip -lm
+ * Checks, without any oracle: cold-start plaquette = 1, free-field Wilson D on a constant spinor
+ * (D psi = (1 - 8 kappa) psi for periodic BC and U = 1), gamma5-hermiticity on a hot start, CG true residual.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "lqcd_hip.h"
+
+#define CHECK(call)                                                                 \
+    do {                                                                            \
+        int st_ = (call);                                                           \
+        if (st_ != LQCD_OK) {                                                       \
+            fprintf(stderr, "%s failed (%d): %s\n", #call, st_, lqcd_last_error()); \
+            return 1;                                                               \
+        }                                                                           \
+    } while (0)
+
+int main(void) {
+    const int L[4] = {8, 8, 8, 8}, pe[4] = {1, 1, 1, 1}, bc_per[4] = {1, 1, 1, 1}, bc_apbc[4] = {1, 1, 1, -1};
+    const double kappa = 0.141139;
+    const long V = 8L * 8 * 8 * 8, n = 12 * V;
+    if (lqcd_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
+
+    lqcd_ctx_t ctx;
+    lqcd_gauge_t U;
+    lqcd_spinor_t a, b, Da, Ddb, x, r;
+    lqcd_op_t D;
+    CHECK(lqcd_ctx_create(&ctx, 0, L, pe, 0));
+    CHECK(lqcd_gauge_create(ctx, &U));
+    CHECK(lqcd_gauge_unit(U));
+    double plaq;
+    CHECK(lqcd_gauge_plaquette(U, &plaq));
+    if (fabs(plaq - 1.0) > 1e-14) { fprintf(stderr, "cold plaquette %.17g\n", plaq); return 1; }
+
+    CHECK(lqcd_spinor_create(ctx, &a, LQCD_WILSON, LQCD_FULL));
+    CHECK(lqcd_spinor_create(ctx, &b, LQCD_WILSON, LQCD_FULL));
+    CHECK(lqcd_spinor_create(ctx, &Da, LQCD_WILSON, LQCD_FULL));
+    CHECK(lqcd_spinor_create(ctx, &Ddb, LQCD_WILSON, LQCD_FULL));
+    CHECK(lqcd_spinor_create(ctx, &x, LQCD_WILSON, LQCD_FULL));
+    CHECK(lqcd_spinor_create(ctx, &r, LQCD_WILSON, LQCD_FULL));
+
+    /* free field, constant spinor, periodic BC: D psi = (1 - 8 kappa) psi  (r = 1: sum_nu 2 r cos 0 = 8) */
+    double* host = (double*)malloc(sizeof(double) * 2 * n);
+    for (long i = 0; i < n; i++) { host[2 * i] = 1.0 + (double)(i % 12); host[2 * i + 1] = -0.5 * (double)(i % 12); }
+    /* reference layout is ic + 3*(site + V*is): make the value depend on (ic,is) only -> constant over sites */
+    for (int is = 0; is < 4; is++)
+        for (long s = 0; s < V; s++)
+            for (int ic = 0; ic < 3; ic++) {
+                long idx = ic + 3 * (s + V * is);
+                host[2 * idx] = 1.0 + ic + 3 * is;
+                host[2 * idx + 1] = 0.25 * (ic - is);
+            }
+    CHECK(lqcd_spinor_upload(a, host));
+    CHECK(lqcd_op_create(ctx, &D, LQCD_WILSON, U, kappa, 1.0, bc_per));
+    CHECK(lqcd_op_apply(D, Da, a, 0));
+    double* out = (double*)malloc(sizeof(double) * 2 * n);
+    CHECK(lqcd_spinor_download(Da, out));
+    double maxerr = 0;
+    for (long i = 0; i < 2 * n; i++) {
+        double e = fabs(out[i] - (1.0 - 8.0 * kappa) * host[i]);
+        if (e > maxerr) maxerr = e;
+    }
+    if (maxerr > 1e-13) { fprintf(stderr, "free-field check failed: %.3e\n", maxerr); return 1; }
+    CHECK(lqcd_op_destroy(D));
+
+    /* hot start: <a, D b> = conj <b, D^+ a>, then CG with an independent residual check */
+    CHECK(lqcd_gauge_hot_start(U, 111));
+    CHECK(lqcd_op_create(ctx, &D, LQCD_WILSON, U, kappa, 1.0, bc_apbc));
+    CHECK(lqcd_spinor_gaussian(a, 1));
+    CHECK(lqcd_spinor_gaussian(b, 2));
+    CHECK(lqcd_op_apply(D, Da, b, 0));      /* Da := D b   */
+    CHECK(lqcd_op_apply(D, Ddb, a, 1));     /* Ddb := D^+ a */
+    double l_re, l_im, r_re, r_im;
+    CHECK(lqcd_dot(a, Da, &l_re, &l_im));
+    CHECK(lqcd_dot(b, Ddb, &r_re, &r_im));
+    if (fabs(l_re - r_re) > 1e-10 * fabs(l_re) || fabs(l_im + r_im) > 1e-10 * (fabs(l_re) + fabs(l_im))) {
+        fprintf(stderr, "gamma5-hermiticity failed: (%.15g,%.15g) vs conj(%.15g,%.15g)\n", l_re, l_im, r_re, r_im);
+        return 1;
+    }
+    int iters = 0;
+    double rr = 0, res2 = 0;
+    CHECK(lqcd_spinor_zero(x));
+    CHECK(lqcd_solve_cg_DdagD(D, x, b, 1e-19, 3000, &iters, &rr));
+    CHECK(lqcd_op_apply_DdagD(D, r, x));
+    CHECK(lqcd_axpy(-1.0, 0.0, b, r));
+    CHECK(lqcd_norm2(r, &res2));
+    if (!(rr < 1e-19) || !(res2 < 1e-18)) { fprintf(stderr, "CG failed: rr %.3e true %.3e\n", rr, res2); return 1; }
+    /* error path: maxiter too small -> LQCD_ERR_NOT_CONVERGED with a message */
+    CHECK(lqcd_spinor_zero(x));
+    if (lqcd_solve_cg_DdagD(D, x, b, 1e-19, 2, &iters, &rr) != LQCD_ERR_NOT_CONVERGED) { fprintf(stderr, "expected non-convergence\n"); return 1; }
+
+    printf("C_ABI_OK plaquette=1 free-field maxerr=%.2e CG iters ok true-res=%.2e msg=\"%s\"\n", maxerr, res2, lqcd_last_error());
+    free(host); free(out);
+    lqcd_op_destroy(D);
+    lqcd_spinor_destroy(a); lqcd_spinor_destroy(b); lqcd_spinor_destroy(Da); lqcd_spinor_destroy(Ddb);
+    lqcd_spinor_destroy(x); lqcd_spinor_destroy(r);
+    lqcd_gauge_destroy(U);
+    lqcd_ctx_destroy(ctx);
+    return 0;
+}

@@ -550,3 +550,15 @@ def test_multishift_cg_matches_oracle(gpu, orc, kind_name):
         lq.shiftedcg(xs, sig, x0, A, b, eps=1e-30, maxsteps=3)
     with pytest.raises(lq.LQCDError):
         lq.shiftedcg(xs[:1], [-1.0], x0, A, b)
+
+
+def test_c_abi_from_plain_c(gpu, tmp_path):
+    """liblqcd_hip.so driven from a plain C program (tests/c_abi_smoke.c): cold plaquette, free-field D, gamma5-hermiticity,
+    CG with an independent residual, error path."""
+    import subprocess
+    from test_host_logic import _build_c_smoke
+    exe = str(tmp_path / "c_abi_smoke")
+    r = _build_c_smoke(exe)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "C_ABI_OK" in run.stdout, run.stdout + run.stderr

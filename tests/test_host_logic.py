@@ -103,3 +103,20 @@ def test_gloo_world2_domain_decomposed_dslash():
                         "127.0.0.1", "--master-port", "29611", script], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DD_OK rank 0" in r.stdout and "DD_OK rank 1" in r.stdout
+
+
+def _build_c_smoke(out):
+    csrc = os.path.join(ROOT, "latticeqcd.jl_amd", "csrc")
+    cmd = ["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-o", out,
+           "-L", csrc, "-llqcd_hip", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lm"]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+def test_c_abi_program_compiles_and_fails_loudly_without_gpu(lq, tmp_path):
+    """The boundary is usable from plain C; without a GPU the program reports it instead of computing on the host."""
+    exe = str(tmp_path / "c_abi_smoke")
+    r = _build_c_smoke(exe)
+    assert r.returncode == 0, r.stderr
+    if lq.lib.device_count() == 0:
+        run = subprocess.run([exe], capture_output=True, text=True)
+        assert run.returncode == 2 and "no HIP device" in run.stderr
