@@ -59,6 +59,34 @@ __device__ inline void cg_scalar_step(double* s, int op) {
         s[S_RR] = rrn;
         s[S_ITERS] += 1.0;
         if (rrn < s[S_EPS]) s[S_DONE] = 1.0;
+    } else if (op >= 3 && op <= 6) {
+        // BiCGStab (ops.hip bicgstab_core): 3 alpha = rho/<r0,v> ; 4 half-step test on |s|^2 ; 5 omega = <t,s>/|t|^2 ;
+        // 6 iters++, convergence / breakdown, beta = (rho'/rho)(alpha/omega), rho = rho'
+        if (s[B_DONE] != 0.0) return;
+        if (op == 3) {
+            const double ar = s[B_RHO], ai = s[B_RHO + 1], br = s[B_R0V], bi = s[B_R0V + 1], d = br * br + bi * bi;
+            s[B_ALPHA] = (ar * br + ai * bi) / d;
+            s[B_ALPHA + 1] = (ai * br - ar * bi) / d;
+        } else if (op == 4) {
+            s[B_HALF] = (s[B_SS] < s[B_EPS]) ? 1.0 : 0.0;
+        } else if (op == 5) {
+            if (s[B_HALF] != 0.0) { s[B_OMEGA] = 0.0; s[B_OMEGA + 1] = 0.0; }   // x += alpha p only, r = s
+            else { s[B_OMEGA] = s[B_TS] / s[B_TT]; s[B_OMEGA + 1] = s[B_TS + 1] / s[B_TT]; }
+        } else {
+            s[B_ITERS] += 1.0;
+            const double rr = (s[B_HALF] != 0.0) ? s[B_SS] : s[B_RR];
+            s[B_RES] = rr;
+            if (s[B_HALF] != 0.0 || rr < s[B_EPS]) { s[B_DONE] = 1.0; return; }
+            if (!(fabs(rr) <= 1.79e308)) { s[B_DONE] = 2.0; return; }     // NaN / inf: breakdown
+            // beta = (rho1 / rho) * (alpha / omega)
+            const double r1r = s[B_RHO1], r1i = s[B_RHO1 + 1], r0r = s[B_RHO], r0i = s[B_RHO + 1], d0 = r0r * r0r + r0i * r0i;
+            const double qr = (r1r * r0r + r1i * r0i) / d0, qi = (r1i * r0r - r1r * r0i) / d0;
+            const double ar = s[B_ALPHA], ai = s[B_ALPHA + 1], wr = s[B_OMEGA], wi = s[B_OMEGA + 1], dw = wr * wr + wi * wi;
+            const double er = (ar * wr + ai * wi) / dw, ei = (ai * wr - ar * wi) / dw;
+            s[B_BETA] = qr * er - qi * ei;
+            s[B_BETA + 1] = qr * ei + qi * er;
+            s[B_RHO] = r1r; s[B_RHO + 1] = r1i;
+        }
     }
 }
 __global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op) {

@@ -311,6 +311,9 @@ struct StencilCall {
 };
 // slots of the device scalar block d_scal used by the solvers
 enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16 };
+// BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
+enum { B_RHO = 24, B_R0V = 26, B_ALPHA = 28, B_SS = 30, B_TS = 31, B_TT = 33, B_OMEGA = 34, B_RR = 36, B_RHO1 = 37, B_BETA = 39,
+       B_DONE = 41, B_ITERS = 42, B_EPS = 43, B_HALF = 44, B_RES = 45, B_END = 46 };
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);

@@ -369,15 +369,109 @@ static int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps,
     return LQCD_OK;
 }
 
-// ---------------------------------------------------------------------------------- BiCGStab (host-side scalars)
-typedef std::complex<double> cplx;
+// ---------------------------------------------------------------------------------- BiCGStab (device-resident scalars)
+// One iteration = 2 operator applications + 5 streaming kernels + 4 single-block reductions, all enqueued without a host
+// round trip; complex alpha/omega/beta live in d_scal[B_*] (scalar steps: blas.hip cg_scalar_step ops 3..6).  The host
+// polls the done flag every few iterations.  Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and
+// iteration count as the oracle's orc_bicgstab.
 typedef std::function<int(double2* out, const double2* in)> ApplyFn;
 
-static int dotc(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, cplx* out) {
-    double re, im;
-    LQCHK(blas_dot(c, a, b, n, &re, &im, true));
-    *out = cplx(re, im);
-    return LQCD_OK;
+template <int NV>
+__device__ inline void block_reduce_nv(double (&a)[NV], double* partial) {
+    __shared__ double red[NV][UB / 64];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[v] += __shfl_down(a[v], off, 64);
+        if ((threadIdx.x & 63) == 0) red[v][threadIdx.x >> 6] = a[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < UB / 64; w++) t += red[threadIdx.x][w];
+        partial[blockIdx.x * NV + threadIdx.x] = t;
+    }
+}
+// <a,b> = sum conj(a) b
+__global__ __launch_bounds__(UB) void bicg_dot(const double* __restrict__ sc, const double2* __restrict__ a, const double2* __restrict__ b, size_t n,
+                                                double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    double acc[2] = {0, 0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 x = a[i], y = b[i];
+        acc[0] = fma(x.x, y.x, acc[0]); acc[0] = fma(x.y, y.y, acc[0]);
+        acc[1] = fma(x.x, y.y, acc[1]); acc[1] = fma(-x.y, y.x, acc[1]);
+    }
+    block_reduce_nv<2>(acc, partial);
+}
+// s = r - alpha v ; partial |s|^2
+__global__ __launch_bounds__(UB) void bicg_s(const double* __restrict__ sc, double2* __restrict__ s, const double2* __restrict__ r,
+                                              const double2* __restrict__ v, size_t n, double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    const double ar = sc[B_ALPHA], ai = sc[B_ALPHA + 1];
+    double acc[1] = {0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 vv = v[i];
+        double2 sv = r[i];
+        sv.x = fma(-ar, vv.x, sv.x); sv.x = fma(ai, vv.y, sv.x);
+        sv.y = fma(-ar, vv.y, sv.y); sv.y = fma(-ai, vv.x, sv.y);
+        s[i] = sv;
+        acc[0] = fma(sv.x, sv.x, acc[0]); acc[0] = fma(sv.y, sv.y, acc[0]);
+    }
+    block_reduce_nv<1>(acc, partial);
+}
+// partials of <t,s> (2 values) and |t|^2
+__global__ __launch_bounds__(UB) void bicg_ts(const double* __restrict__ sc, const double2* __restrict__ t, const double2* __restrict__ s, size_t n,
+                                               double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    double acc[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 x = t[i], y = s[i];
+        acc[0] = fma(x.x, y.x, acc[0]); acc[0] = fma(x.y, y.y, acc[0]);
+        acc[1] = fma(x.x, y.y, acc[1]); acc[1] = fma(-x.y, y.x, acc[1]);
+        acc[2] = fma(x.x, x.x, acc[2]); acc[2] = fma(x.y, x.y, acc[2]);
+    }
+    block_reduce_nv<3>(acc, partial);
+}
+// x += alpha p + omega s ; r = s - omega t ; partials |r|^2, <r0,r>
+__global__ __launch_bounds__(UB) void bicg_xr(const double* __restrict__ sc, double2* __restrict__ x, double2* __restrict__ r,
+                                               const double2* __restrict__ p, const double2* __restrict__ s, const double2* __restrict__ t,
+                                               const double2* __restrict__ r0, size_t n, double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    const double ar = sc[B_ALPHA], ai = sc[B_ALPHA + 1], wr = sc[B_OMEGA], wi = sc[B_OMEGA + 1];
+    double acc[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 pv = p[i], sv = s[i], tv = t[i], zv = r0[i];
+        double2 xv = x[i], rv = sv;
+        xv.x = fma(ar, pv.x, xv.x); xv.x = fma(-ai, pv.y, xv.x);
+        xv.y = fma(ar, pv.y, xv.y); xv.y = fma(ai, pv.x, xv.y);
+        xv.x = fma(wr, sv.x, xv.x); xv.x = fma(-wi, sv.y, xv.x);
+        xv.y = fma(wr, sv.y, xv.y); xv.y = fma(wi, sv.x, xv.y);
+        rv.x = fma(-wr, tv.x, rv.x); rv.x = fma(wi, tv.y, rv.x);
+        rv.y = fma(-wr, tv.y, rv.y); rv.y = fma(-wi, tv.x, rv.y);
+        x[i] = xv; r[i] = rv;
+        acc[0] = fma(rv.x, rv.x, acc[0]); acc[0] = fma(rv.y, rv.y, acc[0]);
+        acc[1] = fma(zv.x, rv.x, acc[1]); acc[1] = fma(zv.y, rv.y, acc[1]);
+        acc[2] = fma(zv.x, rv.y, acc[2]); acc[2] = fma(-zv.y, rv.x, acc[2]);
+    }
+    block_reduce_nv<3>(acc, partial);
+}
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(UB) void bicg_p(const double* __restrict__ sc, double2* __restrict__ p, const double2* __restrict__ r,
+                                              const double2* __restrict__ v, size_t n) {
+    if (sc[B_DONE] != 0.0) return;
+    const double br = sc[B_BETA], bi = sc[B_BETA + 1], wr = sc[B_OMEGA], wi = sc[B_OMEGA + 1];
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 vv = v[i], rv = r[i];
+        double2 pv = p[i];
+        pv.x = fma(-wr, vv.x, pv.x); pv.x = fma(wi, vv.y, pv.x);
+        pv.y = fma(-wr, vv.y, pv.y); pv.y = fma(-wi, vv.x, pv.y);
+        double2 o;
+        o.x = fma(br, pv.x, rv.x); o.x = fma(-bi, pv.y, o.x);
+        o.y = fma(br, pv.y, rv.y); o.y = fma(bi, pv.x, o.y);
+        p[i] = o;
+    }
 }
 
 static int bicgstab_core(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* const w[6], double eps,
@@ -391,49 +485,44 @@ static int bicgstab_core(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, 
     HIPCHK(hipMemcpyAsync(p, r, bytes, hipMemcpyDeviceToDevice, c->stream));
     double rr;
     LQCHK(blas_norm2(c, r, n, &rr, true));
-    cplx rho(rr, 0.0);
+    double init[B_END - B_RHO] = {0};
+    init[B_RHO - B_RHO] = rr;
+    init[B_EPS - B_RHO] = eps;
+    init[B_RES - B_RHO] = rr;
+    HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     int it = 0, st = LQCD_ERR_NOT_CONVERGED;
+    bool breakdown = false;
     if (rr < eps) st = LQCD_OK;
-    for (it = 1; st != LQCD_OK && it <= maxiter; it++) {
-        LQCHK(A(v, p));
-        cplx r0v;
-        LQCHK(dotc(c, r0, v, n, &r0v));
-        const cplx alpha = rho / r0v;
-        // s = r - alpha v
-        HIPCHK(hipMemcpyAsync(s, r, bytes, hipMemcpyDeviceToDevice, c->stream));
-        LQCHK(blas_axpy(c, -alpha.real(), -alpha.imag(), v, s, n));
-        double ss;
-        LQCHK(blas_norm2(c, s, n, &ss, true));
-        if (ss < eps) {
-            LQCHK(blas_axpy(c, alpha.real(), alpha.imag(), p, x, n));
-            rr = ss; st = LQCD_OK; break;
+    const int nb = stream_grid(c, n), check_every = 4;
+    const double* sc = c->d_scal;
+    while (st != LQCD_OK && !breakdown && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        for (int k = 0; k < burst; k++) {
+            LQCHK(A(v, p));
+            hipLaunchKernelGGL(bicg_dot, dim3(nb), dim3(UB), 0, c->stream, sc, r0, v, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 2, B_R0V, true, 3));
+            hipLaunchKernelGGL(bicg_s, dim3(nb), dim3(UB), 0, c->stream, sc, s, r, v, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 1, B_SS, true, 4));
+            LQCHK(A(t, s));
+            hipLaunchKernelGGL(bicg_ts, dim3(nb), dim3(UB), 0, c->stream, sc, t, s, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 3, B_TS, true, 5));
+            hipLaunchKernelGGL(bicg_xr, dim3(nb), dim3(UB), 0, c->stream, sc, x, r, p, s, t, r0, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 3, B_RR, true, 6));
+            hipLaunchKernelGGL(bicg_p, dim3(nb), dim3(UB), 0, c->stream, sc, p, r, v, n);
+            HIPCHK(hipGetLastError());
         }
-        LQCHK(A(t, s));
-        cplx ts;
-        double tt;
-        LQCHK(dotc(c, t, s, n, &ts));
-        LQCHK(blas_norm2(c, t, n, &tt, true));
-        const cplx omega = ts / tt;
-        LQCHK(blas_axpy(c, alpha.real(), alpha.imag(), p, x, n));
-        LQCHK(blas_axpy(c, omega.real(), omega.imag(), s, x, n));
-        // r = s - omega t
-        HIPCHK(hipMemcpyAsync(r, s, bytes, hipMemcpyDeviceToDevice, c->stream));
-        LQCHK(blas_axpy(c, -omega.real(), -omega.imag(), t, r, n));
-        LQCHK(blas_norm2(c, r, n, &rr, true));
-        if (rr < eps) { st = LQCD_OK; break; }
-        if (!std::isfinite(rr)) { set_error("BiCGStab: residual is not finite (breakdown)"); break; }
-        cplx rho1;
-        LQCHK(dotc(c, r0, r, n, &rho1));
-        const cplx beta = (rho1 / rho) * (alpha / omega);
-        // p = r + beta (p - omega v)
-        LQCHK(blas_axpy(c, -omega.real(), -omega.imag(), v, p, n));
-        LQCHK(blas_axpby(c, 1.0, 0.0, r, beta.real(), beta.imag(), p, n));
-        rho = rho1;
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + B_RHO, (B_END - B_RHO) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        it = (int)c->h_scal[B_ITERS - B_RHO];
+        rr = c->h_scal[B_RES - B_RHO];
+        const double done = c->h_scal[B_DONE - B_RHO];
+        if (done == 1.0) st = LQCD_OK;
+        else if (done != 0.0) breakdown = true;
     }
-    if (it > maxiter) it = maxiter;
     if (iters) *iters = it;
     if (final_rr) *final_rr = rr;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (breakdown) { set_error("BiCGStab: residual is not finite (breakdown)"); return LQCD_ERR_NOT_CONVERGED; }
     if (st != LQCD_OK) {
         set_error("The BiCGStab is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
         return LQCD_ERR_NOT_CONVERGED;
@@ -577,47 +666,54 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
 
 // ---------------------------------------------------------------------------------- multi-shift CG (RHMC solver)
 namespace lqcd {
-// x += a p ; r -= a q ; partial |r|^2      (scalars from the host)
-__global__ __launch_bounds__(UB) void ms_update_xr(double a, double2* __restrict__ x, double2* __restrict__ r, const double2* __restrict__ p,
-                                                    const double2* __restrict__ q, size_t n, double* partial) {
-    __shared__ double red[UB / 64];
-    double acc = 0;
-    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
-        const double2 pv = p[i], qv = q[i];
-        double2 xv = x[i], rv = r[i];
-        xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y);
-        rv.x = fma(-a, qv.x, rv.x); rv.y = fma(-a, qv.y, rv.y);
-        x[i] = xv; r[i] = rv;
-        acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+// per-shift coefficient block in device memory: [sigma | zeta_{n-1} | zeta_n | a | b | z] (ns doubles each), alpha_{n-1}, beta_{n-1}
+// zeta recurrence (Jegerlehner hep-lat/9612014) after the base system's alpha_n, beta_n are known:
+//   zeta_{n+1} = zeta_n zeta_{n-1} alpha_{n-1} / (zeta_{n-1} alpha_{n-1} (1 + alpha_n sigma) + alpha_n beta_{n-1} (zeta_{n-1} - zeta_n))
+//   x_j += (zeta_{n+1}/zeta_n) alpha_n p_j ;  p_j = (zeta_{n+1}/zeta_n)^2 beta_n p_j + zeta_{n+1} r
+__global__ void ms_zeta(const double* __restrict__ sc, double* __restrict__ ms, int ns) {
+    if (sc[S_XDONE] != 0.0) return;
+    const double alpha = sc[S_ALPHA], beta = sc[S_BETA], alpha_m = ms[6 * ns], beta_m = ms[6 * ns + 1];
+    for (int j = threadIdx.x; j < ns; j += blockDim.x) {
+        const double sigma = ms[j], zm = ms[ns + j], z0 = ms[2 * ns + j];
+        const double den = zm * alpha_m * (1.0 + alpha * sigma) + alpha * beta_m * (zm - z0);
+        const double zp = z0 * zm * alpha_m / den, ratio = zp / z0;
+        ms[3 * ns + j] = ratio * alpha;
+        ms[4 * ns + j] = ratio * ratio * beta;
+        ms[5 * ns + j] = zp;
+        ms[ns + j] = z0;
+        ms[2 * ns + j] = zp;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int w = 0; w < UB / 64; w++) t += red[w];
-        partial[blockIdx.x] = t;
-    }
+    if (threadIdx.x == 0) { ms[6 * ns] = alpha; ms[6 * ns + 1] = beta; }
 }
-// shifted system j:  x_j += a_j p_j ;  p_j = b_j p_j + z_j r     (one pass over x_j, p_j, r)
-__global__ __launch_bounds__(UB) void ms_update_shift(double aj, double bj, double zj, double2* __restrict__ xj, double2* __restrict__ pj,
-                                                       const double2* __restrict__ r, size_t n) {
+// blockIdx.y = j < ns: shifted system j (x_j += a_j p_j ; p_j = b_j p_j + z_j r);  blockIdx.y = ns: base system
+// (x += alpha p ; p = r + beta p).  x is still updated in the iteration that converges; nothing is touched afterwards.
+__global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ sc, const double* __restrict__ ms, double2* const* __restrict__ ptr,
+                                                     double2* __restrict__ x0, double2* __restrict__ p0, const double2* __restrict__ r, size_t n,
+                                                     int ns) {
+    if (sc[S_XDONE] != 0.0) return;
+    const int j = blockIdx.y;
+    double a, bb, z;
+    double2 *x, *p;
+    if (j < ns) { a = ms[3 * ns + j]; bb = ms[4 * ns + j]; z = ms[5 * ns + j]; x = ptr[j]; p = ptr[ns + j]; }
+    else { a = sc[S_ALPHA]; bb = sc[S_BETA]; z = 1.0; x = x0; p = p0; }
     for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
-        double2 pv = pj[i], xv = xj[i];
+        double2 pv = p[i], xv = x[i];
         const double2 rv = r[i];
-        xv.x = fma(aj, pv.x, xv.x); xv.y = fma(aj, pv.y, xv.y);
-        pv.x = fma(bj, pv.x, zj * rv.x); pv.y = fma(bj, pv.y, zj * rv.y);
-        xj[i] = xv; pj[i] = pv;
+        xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y);
+        pv.x = fma(bb, pv.x, z * rv.x); pv.y = fma(bb, pv.y, z * rv.y);
+        x[i] = xv; p[i] = pv;
     }
 }
 }  // namespace lqcd
 
 // (D^+D + sigma_j) x_j = b for all j < ns, plus the unshifted solution x0 (may be NULL): one Krylov space, the shifted
-// iterates follow from the zeta recurrences (Jegerlehner).  Zero initial guesses.  Stops when rr * max(1, max_j zeta_j^2) < eps.
+// iterates follow from the zeta recurrences, which run on the device next to the CG scalars (no host round trip inside an
+// iteration; the host polls the convergence flag every 8 iterations).  Zero initial guesses.  Stops when |r|^2 < eps
+// (for sigma_j >= 0 every |zeta_j| <= 1, so the shifted residuals zeta_j r are then below eps as well).
 extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
                                         double eps, int maxiter, int* iters, double* final_rr) {
-    ARGCHK(op && b && ns >= 0 && (ns == 0 || (xs && sigma)), "lqcd_solve_multishift_cg: null argument");
+    ARGCHK(op && b && ns >= 0 && ns <= 1024 && (ns == 0 || (xs && sigma)), "lqcd_solve_multishift_cg: null argument or more than 1024 shifts");
     ARGCHK(b->ctx == op->ctx && b->kind == op->kind && b->subset == LQCD_FULL, "lqcd_solve_multishift_cg: b must be a FULL spinor of the operator");
     for (int j = 0; j < ns; j++) {
         ARGCHK(xs[j] && xs[j]->ctx == op->ctx && xs[j]->kind == op->kind && xs[j]->subset == LQCD_FULL && xs[j] != b,
@@ -636,72 +732,79 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
     std::vector<lqcd_spinor_s*> ps(ns, nullptr);
     bool ok = xbase && r && p && q && tmp;
     for (int j = 0; j < ns && ok; j++) { ps[j] = scratch_get(c, op->kind, LQCD_FULL); ok = ps[j] != nullptr; }
+    const size_t ms_doubles = 6 * (size_t)ns + 2, ms_bytes = ms_doubles * sizeof(double) + 2 * (size_t)ns * sizeof(double2*);
+    char* d_blk = nullptr;
+    if (ok && hipMalloc((void**)&d_blk, ms_bytes) != hipSuccess) ok = false;
     auto release = [&]() {
         if (!x0) scratch_put(xbase);
         scratch_put(r); scratch_put(p); scratch_put(q); scratch_put(tmp);
         for (auto* s : ps) scratch_put(s);
+        if (d_blk) (void)hipFree(d_blk);
     };
-    if (!ok) { release(); return LQCD_ERR_HIP; }
+    if (!ok) { release(); set_error("lqcd_solve_multishift_cg: out of device memory"); return LQCD_ERR_HIP; }
+    double* d_ms = (double*)d_blk;
+    double2** d_ptr = (double2**)(d_blk + ms_doubles * sizeof(double));
     auto run = [&]() -> int {
         HIPCHK(hipMemsetAsync(xbase->data, 0, bytes, c->stream));
         HIPCHK(hipMemcpyAsync(r->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(p->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+        std::vector<double> hms(ms_doubles, 1.0);    // zeta_{-1} = zeta_0 = 1, alpha_{-1} = 1
+        std::vector<double2*> hptr(2 * (size_t)ns);
         for (int j = 0; j < ns; j++) {
             HIPCHK(hipMemsetAsync(xs[j]->data, 0, bytes, c->stream));
             HIPCHK(hipMemcpyAsync(ps[j]->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+            hms[j] = sigma[j];
+            hptr[j] = xs[j]->data;
+            hptr[ns + j] = ps[j]->data;
         }
-        std::vector<double> zm(ns, 1.0), z0(ns, 1.0), zp(ns, 1.0);
-        double alpha_m = 1.0, beta_m = 0.0, rr = 0.0;
+        hms[6 * (size_t)ns + 1] = 0.0;               // beta_{-1} = 0
+        HIPCHK(hipMemcpyAsync(d_ms, hms.data(), ms_doubles * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (ns) HIPCHK(hipMemcpyAsync(d_ptr, hptr.data(), 2 * (size_t)ns * sizeof(double2*), hipMemcpyHostToDevice, c->stream));
+        double rr = 0.0;
         LQCHK(blas_norm2(c, r->data, n, &rr, true));
-        double resid = rr;
-        int it = 0, st = LQCD_ERR_NOT_CONVERGED;
-        if (rr < eps) st = LQCD_OK;
-        const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
-        for (it = 1; st != LQCD_OK && it <= maxiter; it++) {
-            // q = D^+ D p ;  p.(D^+D p) = |D p|^2 from the stencil's block partials
-            LQCHK(op_apply_async(op, tmp, p, 0, c->d_partial));
-            LQCHK(reduce_to_slot(c, nbs, 1, S_RED0, true));
-            LQCHK(op_apply_async(op, q, tmp, 1, nullptr));
-            HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            const double pAp = c->h_scal[0];
-            const double alpha = rr / pAp;
-            const int nb = stream_grid(c, n);
-            hipLaunchKernelGGL(ms_update_xr, dim3(nb), dim3(UB), 0, c->stream, alpha, xbase->data, r->data, p->data, q->data, n, c->d_partial);
-            HIPCHK(hipGetLastError());
-            LQCHK(reduce_to_slot(c, nb, 1, S_RED0, true));
-            HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            const double rrn = c->h_scal[0];
-            const double beta = rrn / rr;
-            LQCHK(blas_axpby(c, 1.0, 0.0, r->data, beta, 0.0, p->data, n));   // p = r + beta p
-            double zmax = 0.0;
-            for (int j = 0; j < ns; j++) {
-                const double den = zm[j] * alpha_m * (1.0 + alpha * sigma[j]) + alpha * beta_m * (zm[j] - z0[j]);
-                zp[j] = z0[j] * zm[j] * alpha_m / den;
-                const double ratio = zp[j] / z0[j];
-                hipLaunchKernelGGL(ms_update_shift, dim3(nb), dim3(UB), 0, c->stream, ratio * alpha, ratio * ratio * beta, zp[j],
-                                   xs[j]->data, ps[j]->data, r->data, n);
-                zmax = std::max(zmax, std::fabs(zp[j]));
-            }
-            HIPCHK(hipGetLastError());
-            for (int j = 0; j < ns; j++) { zm[j] = z0[j]; z0[j] = zp[j]; }
-            alpha_m = alpha; beta_m = beta; rr = rrn;
-            resid = rr * (zmax > 1.0 ? zmax * zmax : 1.0);
-            if (!std::isfinite(resid)) { set_error("multi-shift CG: residual is not finite"); break; }
-            if (resid < eps) { st = LQCD_OK; break; }
-        }
-        if (it > maxiter) it = maxiter;
+        double init[9] = {rr, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
+        HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        int it = 0;
+        bool converged = rr < eps;
+        const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n), check_every = 8;
+        while (!converged && it < maxiter) {
+            const int burst = std::min(check_every, maxiter - it);
+            for (int k = 0; k < burst; k++) {
+                // tmp = D p, alpha = rr / |tmp|^2 ; r -= alpha D^+ tmp in the stencil epilogue, beta = rr'/rr
+                LQCHK(op_apply_async(op, tmp, p, 0, c->d_partial));
+                LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));
+                apply_bc(c, op->bc);
+                StencilCall s2 = make_full_call(op, q, tmp, 1);
+                s2.norm_partial = c->d_partial;
+                s2.upd_scal = c->d_scal;
+                s2.upd[0] = spinor_block(r, 0);
+                s2.upd[1] = spinor_block(r, 1);
+                LQCHK(stencil_apply(c, s2));
+                LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
+                if (ns) hipLaunchKernelGGL(ms_zeta, dim3(1), dim3(64), 0, c->stream, c->d_scal, d_ms, ns);
+                hipLaunchKernelGGL(ms_update_all, dim3(nbu, ns + 1), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase->data, p->data,
+                                   r->data, n, ns);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            rr = c->h_scal[S_RR - S_RR];
+            it = (int)c->h_scal[S_ITERS - S_RR];
+            if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
+            if (!std::isfinite(rr)) { set_error("multi-shift CG: residual is not finite"); break; }
+        }
         if (iters) *iters = it;
-        if (final_rr) *final_rr = resid;
-        if (st != LQCD_OK) {
-            set_error("The shifted CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(resid));
+        if (final_rr) *final_rr = rr;
+        if (!converged) {
+            if (std::isfinite(rr))
+                set_error("The shifted CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
             return LQCD_ERR_NOT_CONVERGED;
         }
         return LQCD_OK;
     };
     const int st = run();
+    (void)hipStreamSynchronize(c->stream);
     release();
     return st;
 }
