@@ -142,6 +142,19 @@ int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int d
  * Zero initial guesses; stops when rr * max(1, max_j zeta_j^2) < eps. */
 int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
                              double eps, int maxiter, int* iters, double* final_rr);
+/* ---------------------------------------------------------------- pseudofermion action and force */
+/* evaluate_FermiAction(fa, U, eta) (src/updates/standardHMC.jl:71): S_f = eta^+ (D^+D)^-1 eta by CG from a zero guess.
+ * X receives (D^+D)^-1 eta; Y (may be NULL) receives D X.  Both stay on the device for lqcd_fermion_force. */
+int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t X, lqcd_spinor_t Y, double eps, int maxiter, double* Sf,
+                      int* iters);
+/* the outer-product sweep of calc_UdSfdU!(UdSfdU, fa, U, eta) (src/md/AbstractMD.jl:129): out_mu(n) = "U dS_f/dU", a general
+ * 3x3 matrix per link in a gauge-shaped field, DEFINED by
+ *     d/d eps S_f[ U_mu(n) -> exp(i eps T) U_mu(n) ] = -2 Im tr( T out_mu(n) )      for every Hermitian T
+ * (checked against finite differences of S_f in the tests).  Download with lqcd_gauge_download.  Single-GPU contexts only. */
+int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y);
+/* calc_UdSfdU! in one call: solve, Y = D X and the sweep, all resident; Sf and iters may be NULL */
+int lqcd_calc_UdSfdU(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t eta, double eps, int maxiter, double* Sf, int* iters);
+
 /* benchmarking window: exactly niter CG iterations, exit test disabled (SURVEY.md 8(d) timing protocol) */
 int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int niter);
 

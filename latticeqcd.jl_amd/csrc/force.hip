@@ -1,0 +1,191 @@
+// force.hip -- pseudofermion force "U dS_f/dU" on the device (reference call site calc_UdSfdU!,
+// /root/reference/src/md/AbstractMD.jl:129, wrapped by P_update_fermion! :120-135).
+//
+// S_f = eta^+ (D^+D)^-1 eta, X = (D^+D)^-1 eta, Y = D X  =>  delta S_f = -2 Re(Y^+ (delta D) X).  The output G_mu(n) is the
+// general 3x3 matrix defined by   d/d eps S_f[U_mu(n) -> exp(i eps T) U_mu(n)] = -2 Im tr(T G_mu(n))   (Hermitian T):
+//   Wilson:    G = kappa s [ sum_spin (U X(n+mu))_s ((r - g_mu) Y(n))_s^+  -  sum_spin X(n)_s (U (r + g_mu) Y(n+mu))_s^+ ]
+//   staggered: G = -1/2 eta_mu(n) s [ (U X(n+mu)) Y(n)^+ + X(n) (U Y(n+mu))^+ ]
+// s = boundary sign of the hop n -> n+mu.  X and Y stay resident after the solve; nothing goes back to the host.
+//
+// Mapping: workgroup = 64 consecutive checkerboard sites of one parity x 4 waves, wave = direction mu (wave-uniform gamma
+// algebra, every load/store 64 lanes x 16 B contiguous in the chunk-blocked layouts).  HBM-bound: reads X, Y at n and n+mu
+// (neighbour re-use through L2), the four links, writes four link-shaped matrices: 2*192 + 576 + 576 = 1536 B/site compulsory
+// (Wilson).  Runs once per MD step, against hundreds of Dslash applications in the solve that precedes it.
+#include "lqcd_internal.h"
+
+namespace lqcd {
+
+struct FArgs {
+    Geom g;
+    const double2* gauge;
+    double2* out;
+    const double2* X[2];
+    const double2* Y[2];
+    double coef;   // kappa (Wilson) or -1/2 (staggered)
+    double r;
+};
+
+// (g_MU psi)[S][c] for a full 4-spinor held in registers
+template <int MU, int S>
+__device__ __forceinline__ cd gamma_elem(const cd (&psi)[4][3], int c) {
+    if constexpr (MU < 3) return mul_ipow<GK[MU][S]>(psi[PERM[MU][S]][c]);
+    else return (S < 2) ? psi[S][c] : mk(-psi[S][c].re, -psi[S][c].im);
+}
+
+// out[s][c] = r psi[s][c] + SG (g_MU psi)[s][c]
+template <int MU, int SG>
+__device__ __forceinline__ void r_plus_gamma(cd (&out)[4][3], const cd (&psi)[4][3], double r) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const cd g0 = gamma_elem<MU, 0>(psi, c), g1 = gamma_elem<MU, 1>(psi, c), g2 = gamma_elem<MU, 2>(psi, c), g3 = gamma_elem<MU, 3>(psi, c);
+        out[0][c] = mk(fma(r, psi[0][c].re, SG * g0.re), fma(r, psi[0][c].im, SG * g0.im));
+        out[1][c] = mk(fma(r, psi[1][c].re, SG * g1.re), fma(r, psi[1][c].im, SG * g1.im));
+        out[2][c] = mk(fma(r, psi[2][c].re, SG * g2.re), fma(r, psi[2][c].im, SG * g2.im));
+        out[3][c] = mk(fma(r, psi[3][c].re, SG * g3.re), fma(r, psi[3][c].im, SG * g3.im));
+    }
+}
+
+__device__ __forceinline__ void mv3(cd (&o)[3], const cd (&u)[9], const cd (&v)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        cd t = mk(0.0, 0.0);
+        cfma(t, u[a * 3 + 0], v[0]);
+        cfma(t, u[a * 3 + 1], v[1]);
+        cfma(t, u[a * 3 + 2], v[2]);
+        o[a] = t;
+    }
+}
+// C[a][b] += sg * v[a] conj(w[b])
+__device__ __forceinline__ void outer_acc(cd (&C)[9], const cd (&v)[3], const cd (&w)[3], double sg) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            cd& t = C[a * 3 + b];
+            t.re = fma(sg * v[a].re, w[b].re, t.re); t.re = fma(sg * v[a].im, w[b].im, t.re);
+            t.im = fma(sg * v[a].im, w[b].re, t.im); t.im = fma(-sg * v[a].re, w[b].im, t.im);
+        }
+}
+
+__device__ __forceinline__ void load_spinor4(cd (&psi)[4][3], const double2* __restrict__ base, int Vs) {
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) psi[s][c] = ld(base + (size_t)(s * 3 + c) * Vs);
+}
+
+// forward neighbour of local site c in direction mu: checkerboard index and boundary sign
+__device__ __forceinline__ int fwd_neighbour(const Geom& g, const int (&c)[4], int mu, double& sign) {
+    int d[4] = {c[0], c[1], c[2], c[3]};
+    sign = 1.0;
+    if (++d[mu] == g.L[mu]) { d[mu] = 0; sign = g.bc_fwd[mu]; }
+    return coords_to_cb(g, d);
+}
+
+template <int MU>
+__device__ __forceinline__ void wilson_force_site(const FArgs& k, int p, int i, const int (&c)[4]) {
+    const Geom& g = k.g;
+    const int Vs = sp_stride(g), Gs = glink_stride(g);
+    double sg;
+    const int j = fwd_neighbour(g, c, MU, sg);
+    const double2* __restrict__ Xn = k.X[p] + sp_off(12, i);
+    const double2* __restrict__ Yn = k.Y[p] + sp_off(12, i);
+    const double2* __restrict__ Xp = k.X[1 - p] + sp_off(12, j);
+    const double2* __restrict__ Yp = k.Y[1 - p] + sp_off(12, j);
+    const size_t go = glink_off(g, p, MU, i);
+    cd u[9], C[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) { u[e] = ld(k.gauge + go + (size_t)e * Gs); C[e] = mk(0.0, 0.0); }
+    {   // + sum_s (U X(n+mu))_s ((r - g) Y(n))_s^+
+        cd y[4][3], z[4][3];
+        load_spinor4(y, Yn, Vs);
+        r_plus_gamma<MU, -1>(z, y, k.r);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            cd x[3], w[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) x[cc] = ld(Xp + (size_t)(s * 3 + cc) * Vs);
+            mv3(w, u, x);
+            outer_acc(C, w, z[s], 1.0);
+        }
+    }
+    {   // - sum_s X(n)_s (U (r + g) Y(n+mu))_s^+
+        cd y[4][3], q[4][3];
+        load_spinor4(y, Yp, Vs);
+        r_plus_gamma<MU, 1>(q, y, k.r);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            cd x[3], w[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) x[cc] = ld(Xn + (size_t)(s * 3 + cc) * Vs);
+            mv3(w, u, q[s]);
+            outer_acc(C, x, w, -1.0);
+        }
+    }
+    const double f = k.coef * sg;
+#pragma unroll
+    for (int e = 0; e < 9; e++) st(k.out + go + (size_t)e * Gs, mk(f * C[e].re, f * C[e].im));
+}
+
+__global__ __launch_bounds__(256) void wilson_force_kernel(FArgs k) {
+    const Geom& g = k.g;
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    if (i >= g.Vh) return;
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    switch (mu) {
+    case 0: wilson_force_site<0>(k, p, i, c); break;
+    case 1: wilson_force_site<1>(k, p, i, c); break;
+    case 2: wilson_force_site<2>(k, p, i, c); break;
+    default: wilson_force_site<3>(k, p, i, c); break;
+    }
+}
+
+__global__ __launch_bounds__(256) void staggered_force_kernel(FArgs k) {
+    const Geom& g = k.g;
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    if (i >= g.Vh) return;
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    const int Vs = sp_stride(g), Gs = glink_stride(g);
+    double sg;
+    const int j = fwd_neighbour(g, c, mu, sg);
+    int e = 0;                                   // eta_mu(n) = (-1)^(x_0 + ... + x_{mu-1}), GLOBAL coordinates
+    for (int nu = 0; nu < mu; nu++) e += c[nu] + g.origin[nu];
+    const double f = k.coef * sg * ((e & 1) ? -1.0 : 1.0);
+    const size_t go = glink_off(g, p, mu, i);
+    cd u[9], C[9], xn[3], yn[3], xp[3], yp[3], ux[3], uy[3];
+#pragma unroll
+    for (int q = 0; q < 9; q++) { u[q] = ld(k.gauge + go + (size_t)q * Gs); C[q] = mk(0.0, 0.0); }
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+        xn[cc] = ld(k.X[p] + sp_off(3, i) + (size_t)cc * Vs);
+        yn[cc] = ld(k.Y[p] + sp_off(3, i) + (size_t)cc * Vs);
+        xp[cc] = ld(k.X[1 - p] + sp_off(3, j) + (size_t)cc * Vs);
+        yp[cc] = ld(k.Y[1 - p] + sp_off(3, j) + (size_t)cc * Vs);
+    }
+    mv3(ux, u, xp);
+    mv3(uy, u, yp);
+    outer_acc(C, ux, yn, 1.0);
+    outer_acc(C, xn, uy, 1.0);
+#pragma unroll
+    for (int q = 0; q < 9; q++) st(k.out + go + (size_t)q * Gs, mk(f * C[q].re, f * C[q].im));
+}
+
+int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
+                         double r) {
+    FArgs k;
+    k.g = c->geom;
+    k.gauge = U->data;
+    k.out = out->data;
+    for (int p = 0; p < 2; p++) { k.X[p] = spinor_block(X, p); k.Y[p] = spinor_block(Y, p); }
+    k.coef = kind == LQCD_WILSON ? km : -0.5;
+    k.r = r;
+    const int nb = 2 * c->geom.nch;
+    if (kind == LQCD_WILSON) hipLaunchKernelGGL(wilson_force_kernel, dim3(nb), dim3(256), 0, c->stream, k);
+    else hipLaunchKernelGGL(staggered_force_kernel, dim3(nb), dim3(256), 0, c->stream, k);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+}  // namespace lqcd

@@ -178,6 +178,11 @@ template <int K> __device__ inline cd mul_ipow(cd a) {
     else return mk(a.im, -a.re);
 }
 
+// gamma_mu (mu = 0,1,2) has one entry per row: row a -> column PERM[mu][a], value i^GK[mu][a]  (SURVEY.md Appendix A);
+// gamma_4 = diag(1,1,-1,-1)
+constexpr int PERM[3][4] = {{3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}};
+constexpr int GK[3][4] = {{3, 3, 1, 1}, {2, 0, 0, 2}, {3, 1, 1, 3}};
+
 // ---------------------------------------------------------------- counter-based RNG (identical bits on every rank / decomposition)
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -317,6 +322,8 @@ enum { B_RHO = 24, B_R0V = 26, B_ALPHA = 28, B_SS = 30, B_TS = 31, B_TT = 33, B_
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);
+int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
+                         double r);   // force.hip
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path)
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);

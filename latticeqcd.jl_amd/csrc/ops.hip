@@ -809,6 +809,60 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
     return st;
 }
 
+// ---------------------------------------------------------------------------------- pseudofermion action and force
+// (evaluate_FermiAction standardHMC.jl:71, calc_UdSfdU! AbstractMD.jl:129)
+static int force_check(lqcd_op_s* op, const char* who) {
+    if (any_partitioned(op->ctx)) {
+        set_error(std::string(who) + ": the fermion force is not available on a partitioned lattice yet (single-GPU contexts only)");
+        return LQCD_ERR_UNSUPPORTED;
+    }
+    return LQCD_OK;
+}
+
+// S_f = eta^+ (D^+D)^-1 eta by CG from a zero guess; X = (D^+D)^-1 eta is returned, Y = D X if Y != NULL
+extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t X, lqcd_spinor_t Y, double eps, int maxiter, double* Sf,
+                                 int* iters) {
+    LQCHK(check_full(op, X, eta, "lqcd_fermi_action"));
+    if (Y) LQCHK(check_full(op, Y, eta, "lqcd_fermi_action"));
+    ARGCHK(X != eta && Y != eta && X != Y, "lqcd_fermi_action: eta, X and Y must be distinct fields");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(X->data, 0, X->elems * sizeof(double2), c->stream));
+    LQCHK(cg_run(op, X, eta, eps, maxiter, false, iters, nullptr));
+    if (Y) LQCHK(op_apply_async(op, Y, X, 0, nullptr));
+    double re = 0, im = 0;
+    LQCHK(blas_dot(c, eta->data, X->data, eta->elems, &re, &im, true));
+    if (Sf) *Sf = re;
+    return LQCD_OK;
+}
+
+// G_mu(n) = "U dS_f/dU" from resident X = (D^+D)^-1 eta and Y = D X (force.hip); out is a link-shaped field
+extern "C" int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y) {
+    LQCHK(check_full(op, X, Y, "lqcd_fermion_force"));
+    ARGCHK(out && out->ctx == op->ctx && out != op->gauge, "lqcd_fermion_force: out must be a gauge-shaped field of the same context, not the operator's links");
+    LQCHK(force_check(op, "lqcd_fermion_force"));
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    apply_bc(c, op->bc);
+    LQCHK(launch_fermion_force(c, op->kind, op->gauge, out, X, Y, op->km, op->r));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+// calc_UdSfdU!: solve, Y = D X and the outer-product sweep back to back on the device
+extern "C" int lqcd_calc_UdSfdU(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t eta, double eps, int maxiter, double* Sf, int* iters) {
+    ARGCHK(op && eta, "lqcd_calc_UdSfdU: null argument");
+    LQCHK(force_check(op, "lqcd_calc_UdSfdU"));
+    lqcd_ctx_s* c = op->ctx;
+    lqcd_spinor_s* X = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* Y = scratch_get(c, op->kind, LQCD_FULL);
+    int st = (X && Y) ? LQCD_OK : LQCD_ERR_HIP;
+    if (st == LQCD_OK) st = lqcd_fermi_action(op, eta, X, Y, eps, maxiter, Sf, iters);
+    if (st == LQCD_OK) st = lqcd_fermion_force(op, out, X, Y);
+    scratch_put(X); scratch_put(Y);
+    return st;
+}
+
 // ---------------------------------------------------------------------------------- C API: timing
 extern "C" int lqcd_bench_dslash(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps, double* ms) {
     LQCHK(check_full(op, out, in, "lqcd_bench_dslash"));

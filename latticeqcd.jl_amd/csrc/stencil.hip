@@ -118,8 +118,7 @@ __device__ inline void map_block(const KArgs& k, int& chunk, int& p) { map_block
 
 // gamma_mu (mu = 0,1,2) has one entry per row: row a -> column PERM[mu][a], value i^GK[mu][a]
 // (SURVEY.md Appendix A).  gamma_4 = diag(1,1,-1,-1).
-constexpr int PERM[3][4] = {{3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}};
-constexpr int GK[3][4] = {{3, 3, 1, 1}, {2, 0, 0, 2}, {3, 1, 1, 3}};
+// (tables PERM / GK: lqcd_internal.h)
 
 template <bool ADJ>
 __device__ inline void su3_mv(cd (&chi)[3], const cd (&u)[9], const cd (&h)[3]) {

@@ -320,6 +320,55 @@ def shiftedcg(vec_x, vec_beta, x, A, b, eps=None, maxsteps=None, return_info=Fal
     return (it.value, rr.value) if return_info else None
 
 
+# ------------------------------------------------------------------------------------ pseudofermion action and force
+class FermiAction:
+    """FermiAction(D, Dict("Nf"=>2)) (universe.jl:138): the 2-flavour pseudofermion action S_f = eta' (D'D)^-1 eta.
+    Keeps X = (D'D)^-1 eta and Y = D X resident between evaluate_FermiAction and calc_UdSfdU_."""
+
+    def __init__(self, D, params=None):
+        nf = (params or {}).get("Nf", 2)
+        if nf != 2:
+            raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Nf = {nf} needs the RHMC path (shiftedcg); only Nf = 2 is wired here")
+        self.D = D
+        kind = D.kind
+        self._temporary_fermionfields = [Fermionfields(D.lattice, kind) for _ in range(2)]   # standardMD.jl:50-51
+
+
+def gauss_sampling_in_action_(xi, U, fa, randomseed=112):
+    """gauss_sampling_in_action!(xi, U, fa) (standardMD.jl:95): xi ~ N(0,1) complex, unit variance per complex component."""
+    gauss_distribution_fermion_(xi, randomseed)
+    return xi
+
+
+def sample_pseudofermions_(eta, U, fa, xi):
+    """sample_pseudofermions!(eta, U, fa, xi) (standardMD.jl:96): eta = D' xi."""
+    return mul_(eta, fa.D(U).adjoint(), xi)
+
+
+def evaluate_FermiAction(fa, U, eta, return_info=False):
+    """evaluate_FermiAction(fa, U, eta) (standardHMC.jl:71): S_f = eta' (D'D)^-1 eta (CG from a zero guess)."""
+    D = fa.D(U)
+    X, Y = fa._temporary_fermionfields
+    S, it = C.c_double(0), C.c_int(0)
+    check(_l.lib().lqcd_fermi_action(D._h, eta._h, X._h, Y._h, C.c_double(D.eps_CG), D.MaxCGstep, C.byref(S), C.byref(it)))
+    return (S.value, it.value) if return_info else S.value
+
+
+def calc_UdSfdU_(UdSfdU, fa, U, eta):
+    """calc_UdSfdU!(UdSfdU, fa, U, eta) (AbstractMD.jl:129): UdSfdU[mu](n) = "U dS_f/dU" with
+    dS_f/d eps under U_mu(n) -> exp(i eps T) U_mu(n) equal to -2 Im tr(T UdSfdU_mu(n)).  UdSfdU is a Gaugefields-shaped field."""
+    D = fa.D(U)
+    S, it = C.c_double(0), C.c_int(0)
+    check(_l.lib().lqcd_calc_UdSfdU(D._h, UdSfdU._h, eta._h, C.c_double(D.eps_CG), D.MaxCGstep, C.byref(S), C.byref(it)))
+    return S.value
+
+
+def fermion_force_(UdSfdU, D, X, Y):
+    """The outer-product sweep alone, from resident X = (D'D)^-1 eta and Y = D X."""
+    check(_l.lib().lqcd_fermion_force(D._h, UdSfdU._h, X._h, Y._h))
+    return UdSfdU
+
+
 # ------------------------------------------------------------------------------------ timing helpers (bench.py)
 def bench_dslash(D, out, inp, warm=20, reps=200):
     ms = C.c_double(0)

@@ -562,3 +562,104 @@ done:
     free(res); free(p); free(q); free(tmp); free(ps); free(zm); free(z0); free(zp);
     return status;
 }
+
+/* ------------------------------------------------------------------ pseudofermion action and its force
+ * S_f = eta^+ (D^+D)^-1 eta  (reference callers: evaluate_FermiAction, src/updates/standardHMC.jl:71;
+ * calc_UdSfdU!, src/md/AbstractMD.jl:129).  With X = (D^+D)^-1 eta and Y = D X,
+ *   delta S_f = -2 Re( Y^+ (delta D) X ).
+ * The force field G_mu(n) ("U dS_f/dU", a general 3x3 matrix per link) is DEFINED by
+ *   d/d eps S_f[ U_mu(n) -> exp(i eps T) U_mu(n) ] at eps = 0   =   -2 Im tr( T G_mu(n) )     for every Hermitian T,
+ * which tests/test_oracle_identities.py checks by central differences of S_f itself (convention independent).
+ *   Wilson:    G = kappa s [ sum_spin (U X(n+mu))_s ((r - g_mu) Y(n))_s^+  -  sum_spin X(n)_s (U (r + g_mu) Y(n+mu))_s^+ ]
+ *   staggered: G = -1/2 eta_mu(n) s [ (U X(n+mu)) Y(n)^+ + X(n) (U Y(n+mu))^+ ]
+ * s = boundary sign when n -> n+mu crosses the global boundary.  Output in the gauge layout (UIDX). */
+double orc_fermi_action(int kind, double* Xd, double* Yd, const double* U, const double* eta, const int L[4], double km, double r,
+                        const int bc[4], double eps, int maxiter, int* iters, int* status) {
+    op_t o = mk_op(kind, U, L, km, r, bc);
+    cplx* X = (cplx*)Xd;
+    memset(X, 0, sizeof(cplx) * o.n);
+    int st = cg_core(&o, X, (const cplx*)eta, eps, maxiter, 0, iters, NULL);
+    if (status) *status = st;
+    if (Yd) op_D(&o, (cplx*)Yd, X, 0);
+    return creal(cdot((const cplx*)eta, X, o.n));
+}
+
+void orc_wilson_force(double* Gd, const double* Ud, const double* Xd, const double* Yd, const int L[4], double kappa, double r,
+                      const int bc[4]) {
+    const cplx *U = (const cplx*)Ud, *X = (const cplx*)Xd, *Y = (const cplx*)Yd;
+    cplx* G = (cplx*)Gd;
+    long V = vol(L);
+    cplx Gm[4][4][4];
+    for (int nu = 0; nu < 4; nu++) gamma_mat(nu, Gm[nu]);
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t}, w;
+                    long s = site_of(L, x, y, z, t);
+                    for (int mu = 0; mu < 4; mu++) {
+                        long np = neigh(L, c, mu, 1, &w);
+                        double sg = w ? (double)bc[mu] : 1.0;
+                        cplx W[4][3], Z[4][3], Q[4][3], UQ[4][3];
+                        for (int sp = 0; sp < 4; sp++)
+                            for (int a = 0; a < 3; a++) {
+                                cplx tw = 0;
+                                for (int b = 0; b < 3; b++) tw += U[UIDX(V, mu, s, a, b)] * X[PIDX(V, np, b, sp)];
+                                W[sp][a] = tw;
+                                cplx tz = r * Y[PIDX(V, s, a, sp)], tq = r * Y[PIDX(V, np, a, sp)];
+                                for (int s2 = 0; s2 < 4; s2++) {
+                                    tz -= Gm[mu][sp][s2] * Y[PIDX(V, s, a, s2)];
+                                    tq += Gm[mu][sp][s2] * Y[PIDX(V, np, a, s2)];
+                                }
+                                Z[sp][a] = tz;
+                                Q[sp][a] = tq;
+                            }
+                        for (int sp = 0; sp < 4; sp++)
+                            for (int a = 0; a < 3; a++) {
+                                cplx tq = 0;
+                                for (int b = 0; b < 3; b++) tq += U[UIDX(V, mu, s, a, b)] * Q[sp][b];
+                                UQ[sp][a] = tq;
+                            }
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) {
+                                cplx m = 0;
+                                for (int sp = 0; sp < 4; sp++)
+                                    m += W[sp][a] * conj(Z[sp][b]) - X[PIDX(V, s, a, sp)] * conj(UQ[sp][b]);
+                                G[UIDX(V, mu, s, a, b)] = kappa * sg * m;
+                            }
+                    }
+                }
+}
+
+void orc_staggered_force(double* Gd, const double* Ud, const double* Xd, const double* Yd, const int L[4], const int bc[4]) {
+    const cplx *U = (const cplx*)Ud, *X = (const cplx*)Xd, *Y = (const cplx*)Yd;
+    cplx* G = (cplx*)Gd;
+    long V = vol(L);
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t}, w;
+                    long s = site_of(L, x, y, z, t);
+                    for (int mu = 0; mu < 4; mu++) {
+                        int e = 0;
+                        for (int k = 0; k < mu; k++) e += c[k];
+                        double eta = (e & 1) ? -1.0 : 1.0;
+                        long np = neigh(L, c, mu, 1, &w);
+                        double sg = w ? (double)bc[mu] : 1.0;
+                        cplx UX[3], UY[3];
+                        for (int a = 0; a < 3; a++) {
+                            cplx tx = 0, ty = 0;
+                            for (int b = 0; b < 3; b++) {
+                                tx += U[UIDX(V, mu, s, a, b)] * X[b + 3 * np];
+                                ty += U[UIDX(V, mu, s, a, b)] * Y[b + 3 * np];
+                            }
+                            UX[a] = tx;
+                            UY[a] = ty;
+                        }
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++)
+                                G[UIDX(V, mu, s, a, b)] = -0.5 * eta * sg * (UX[a] * conj(Y[b + 3 * s]) + X[a + 3 * s] * conj(UY[b]));
+                    }
+                }
+}

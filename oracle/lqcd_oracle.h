@@ -72,6 +72,16 @@ int orc_wilson_bicgstab_eo(double* x, const double* U, const double* b, const in
 int orc_multishift_cg(int kind, double* x0, double* xs, const double* U, const double* b, const int L[4], double kappa_or_mass,
                       double r, const int bc[4], const double* sigma, int ns, double eps, int maxiter, int* iters, double* final_rr);
 
+/* pseudofermion action S_f = eta^+ (D^+D)^-1 eta (evaluate_FermiAction, src/updates/standardHMC.jl:71) by CG from a zero
+ * guess; also returns X = (D^+D)^-1 eta and, if Y != NULL, Y = D X.  *status: 0 converged, 1 not. */
+double orc_fermi_action(int kind, double* X, double* Y, const double* U, const double* eta, const int L[4], double kappa_or_mass,
+                        double r, const int bc[4], double eps, int maxiter, int* iters, int* status);
+/* fermion force G_mu(n) = "U dS_f/dU" (calc_UdSfdU!, src/md/AbstractMD.jl:129), gauge layout, defined by
+ *   d/d eps S_f[U_mu(n) -> exp(i eps T) U_mu(n)] = -2 Im tr(T G_mu(n))  for Hermitian T   (formulas: lqcd_oracle.c) */
+void orc_wilson_force(double* G, const double* U, const double* X, const double* Y, const int L[4], double kappa, double r,
+                      const int bc[4]);
+void orc_staggered_force(double* G, const double* U, const double* X, const double* Y, const int L[4], const int bc[4]);
+
 /* fixed-length CG window with the exit test disabled (timing only): runs exactly niter iterations */
 void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4],
                         double kappa_or_mass, double r, const int bc[4], int niter);

@@ -36,6 +36,7 @@ def lib():
         _LIB = C.CDLL(so)
         _LIB.orc_plaquette.restype = C.c_double
         _LIB.orc_unitarity_dev.restype = C.c_double
+        _LIB.orc_fermi_action.restype = C.c_double
     return _LIB
 
 
@@ -129,6 +130,25 @@ def multishift_cg(kind, U, b, L, km, sigmas, r=1.0, bc=(1, 1, 1, -1), eps=1e-19,
     st = lib().orc_multishift_cg(int(kind), _p(x0), _p(xs), _p(U), _p(b), _i4(L), C.c_double(km), C.c_double(r), _i4(bc),
                                  _p(sig), len(sig), C.c_double(eps), int(maxiter), C.byref(it), C.byref(rr))
     return x0, [xs[j] for j in range(len(sig))], it.value, rr.value, st
+
+
+def fermi_action(kind, U, eta, L, km, r=1.0, bc=(1, 1, 1, -1), eps=1e-19, maxiter=3000):
+    """S_f = eta^+ (D^+D)^-1 eta.  Returns (S_f, X, Y, iters, status) with X = (D^+D)^-1 eta, Y = D X."""
+    X, Y = np.zeros_like(eta), np.zeros_like(eta)
+    it, st = C.c_int(0), C.c_int(0)
+    S = lib().orc_fermi_action(int(kind), _p(X), _p(Y), _p(U), _p(eta), _i4(L), C.c_double(km), C.c_double(r), _i4(bc),
+                               C.c_double(eps), int(maxiter), C.byref(it), C.byref(st))
+    return S, X, Y, it.value, st.value
+
+
+def fermion_force(kind, U, X, Y, L, km, r=1.0, bc=(1, 1, 1, -1)):
+    """G_mu(n) = "U dS_f/dU" in the gauge layout: dS_f/d eps under U_mu(n) -> exp(i eps T) U_mu(n) is -2 Im tr(T G_mu(n))."""
+    G = np.zeros(gauge_shape(L), dtype=np.complex128)
+    if kind == WILSON:
+        lib().orc_wilson_force(_p(G), _p(U), _p(X), _p(Y), _i4(L), C.c_double(km), C.c_double(r), _i4(bc))
+    else:
+        lib().orc_staggered_force(_p(G), _p(U), _p(X), _p(Y), _i4(L), _i4(bc))
+    return G
 
 
 def bicgstab(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000, x0=None):

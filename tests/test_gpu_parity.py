@@ -562,3 +562,75 @@ def test_c_abi_from_plain_c(gpu, tmp_path):
     assert r.returncode == 0, r.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "C_ABI_OK" in run.stdout, run.stdout + run.stderr
+
+
+# ------------------------------------------------------------------ pseudofermion action and force
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+@pytest.mark.parametrize("L,bc,r", [((4, 4, 4, 4), BC, 1.0), ((8, 4, 6, 4), (1, 1, 1, 1), 1.0), ((4, 6, 4, 8), (-1, 1, -1, -1), 0.7)])
+def test_fermion_force_matches_oracle(gpu, orc, kind_name, L, bc, r):
+    """Device force against the oracle's (whose definition is pinned to finite differences of S_f in the CPU suite)."""
+    lq = gpu
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    okind = orc.WILSON if kind == lq.WILSON else orc.STAGGERED
+    km = KAPPA if kind == lq.WILSON else MASS
+    lat, Uh, Ud, D = setup(lq, orc, L, kind, seed=81, bc=bc, r=r)
+    # (a) the sweep alone on arbitrary X, Y
+    Xh, Yh = host_spinor(orc, lat, kind, 82), host_spinor(orc, lat, kind, 83)
+    X, Y = lq.Fermionfields(lat, kind).upload(Xh), lq.Fermionfields(lat, kind).upload(Yh)
+    G = lq.Gaugefields(lat)
+    lq.fermion_force_(G, D, X, Y)
+    Go = orc.fermion_force(okind, Uh, Xh, Yh, L, km, r=r, bc=bc)
+    assert rel_err(G.download(), Go) < 1e-13
+    # (b) the whole chain eta -> S_f, X, Y -> force
+    eta_h = host_spinor(orc, lat, kind, 84)
+    eta = lq.Fermionfields(lat, kind).upload(eta_h)
+    fa = lq.FermiAction(D)
+    S, it = lq.evaluate_FermiAction(fa, Ud, eta, return_info=True)
+    So, Xo, Yo, ito, st = orc.fermi_action(okind, Uh, eta_h, L, km, r=r, bc=bc, eps=1e-19)
+    assert st == 0 and abs(S - So) < 1e-9 * abs(So) and abs(it - ito) <= 1
+    assert rel_err(fa._temporary_fermionfields[0].download(), Xo) < 1e-9
+    assert rel_err(fa._temporary_fermionfields[1].download(), Yo) < 1e-9
+    S2 = lq.calc_UdSfdU_(G, fa, Ud, eta)
+    assert abs(S2 - S) < 1e-12 * abs(S)
+    assert rel_err(G.download(), orc.fermion_force(okind, Uh, Xo, Yo, L, km, r=r, bc=bc)) < 1e-8
+
+
+def test_fermion_force_is_derivative_of_action_on_device(gpu, orc):
+    """Oracle-free: central differences of the device S_f under U_mu(n) -> exp(+-i eps T) U_mu(n) against -2 Im tr(T G)."""
+    from scipy.linalg import expm
+    lq = gpu
+    L = (8, 8, 8, 8)
+    lat, Uh, Ud, D = setup(lq, orc, L, lq.WILSON, seed=91)
+    D.eps_CG = 1e-24
+    eta = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(eta, 92)
+    fa = lq.FermiAction(D)
+    G = lq.Gaugefields(lat)
+    lq.calc_UdSfdU_(G, fa, Ud, eta)
+    Gh = G.download()
+    rng = np.random.default_rng(93)
+    eps = 1e-4
+    U2 = lq.Gaugefields(lat)
+    for (mu, t, z, y, x) in [(0, 1, 2, 3, 7), (3, 7, 0, 1, 3), (2, 4, 7, 6, 1)]:
+        m = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+        T = 0.5 * (m + m.conj().T)
+        vals = []
+        for sgn in (+1, -1):
+            Up = Uh.copy()
+            Up[mu, t, z, y, x] = (expm(1j * sgn * eps * T) @ Uh[mu, t, z, y, x].T).T
+            U2.upload(Up)
+            vals.append(lq.evaluate_FermiAction(fa, U2, eta))
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = -2.0 * np.trace(T @ Gh[mu, t, z, y, x].T).imag
+        assert abs(fd - an) < 1e-6 * max(1.0, abs(an)), (fd, an)
+    fa.D(Ud)
+
+
+def test_fermion_force_rejects_partitioned_and_bad_arguments(gpu, orc):
+    lq = gpu
+    lat, Uh, Ud, D = setup(lq, orc, (4, 4, 4, 4), lq.WILSON, seed=95)
+    X = lq.Fermionfields(lat, lq.WILSON)
+    with pytest.raises(lq.LQCDError):
+        lq.fermion_force_(Ud, D, X, X.similar())            # out must not be the operator's own links
+    with pytest.raises(lq.LQCDError):
+        lq.FermiAction(D, {"Nf": 3})

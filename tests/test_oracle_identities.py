@@ -215,3 +215,41 @@ def test_multishift_cg_true_residuals(orc, kind_name):
     assert rel_err(xs[0], x0) < 1e-12                      # sigma = 0 reproduces the base solve
     xcg, itcg, rrcg, stcg = orc.cg_DdagD(kind, U, b, L, km, eps=1e-20)
     assert rel_err(x0, xcg) < 1e-9 and abs(it - itcg) <= 1
+
+
+def _random_hermitian(rng):
+    m = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+    return 0.5 * (m + m.conj().T)
+
+
+@pytest.mark.parametrize("kind_name", ["wilson", "staggered"])
+@pytest.mark.parametrize("bc", [(1, 1, 1, -1), (1, 1, 1, 1)])
+def test_fermion_force_is_the_derivative_of_the_action(orc, kind_name, bc):
+    """The force field is defined by dS_f/d eps [U_mu(n) -> exp(i eps T) U_mu(n)] = -2 Im tr(T G_mu(n)); check it against
+    central differences of S_f = eta^+ (D^+D)^-1 eta itself (no convention enters), including links that cross the boundary."""
+    from scipy.linalg import expm
+    L = (4, 4, 4, 4)
+    U = orc.hot_gauge(L, 71)
+    kind, km, shape = (orc.WILSON, KAPPA, orc.wilson_shape(L)) if kind_name == "wilson" else (orc.STAGGERED, MASS, orc.staggered_shape(L))
+    eta = orc.gaussian_spinor(shape, 72)
+    S0, X, Y, it, st = orc.fermi_action(kind, U, eta, L, km, bc=bc, eps=1e-26)
+    assert st == 0 and S0 > 0
+    G = orc.fermion_force(kind, U, X, Y, L, km, bc=bc)
+    rng = np.random.default_rng(73)
+    eps = 1e-4
+    links = [(0, 1, 2, 3, 0), (3, 3, 0, 1, 3), (1, 3, 3, 0, 2), (2, 0, 3, 2, 1), (3, 2, 1, 3, 0)]   # (mu, t, z, y, x); incl. wraps
+    for (mu, t, z, y, x) in links:
+        T = _random_hermitian(rng)
+        Uab = U[mu, t, z, y, x].T.copy()           # oracle layout stores [b, a]
+        vals = []
+        for sgn in (+1, -1):
+            Up = U.copy()
+            Up[mu, t, z, y, x] = (expm(1j * sgn * eps * T) @ Uab).T
+            S, _, _, _, st = orc.fermi_action(kind, Up, eta, L, km, bc=bc, eps=1e-26)
+            assert st == 0
+            vals.append(S)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        Gab = G[mu, t, z, y, x].T
+        an = -2.0 * np.trace(T @ Gab).imag
+        assert abs(fd - an) < 1e-6 * max(1.0, abs(an)), (mu, t, z, y, x, fd, an)
+        assert abs(an) > 1e-6                      # the check is not vacuous
