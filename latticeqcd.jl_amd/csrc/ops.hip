@@ -373,7 +373,7 @@ static int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps,
 // One iteration = 2 operator applications + 5 streaming kernels + 4 single-block reductions, all enqueued without a host
 // round trip; complex alpha/omega/beta live in d_scal[B_*] (scalar steps: blas.hip cg_scalar_step ops 3..6).  The host
 // polls the done flag every few iterations.  Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and
-// iteration count as the oracle's orc_bicgstab.
+// iteration count as the textbook van der Vorst loop the parity tests compare against.
 typedef std::function<int(double2* out, const double2* in)> ApplyFn;
 
 template <int NV>
