@@ -150,8 +150,11 @@ int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t X, lqcd_spi
 /* the outer-product sweep of calc_UdSfdU!(UdSfdU, fa, U, eta) (src/md/AbstractMD.jl:129): out_mu(n) = "U dS_f/dU", a general
  * 3x3 matrix per link in a gauge-shaped field, DEFINED by
  *     d/d eps S_f[ U_mu(n) -> exp(i eps T) U_mu(n) ] = -2 Im tr( T out_mu(n) )      for every Hermitian T
- * (checked against finite differences of S_f in the tests).  Download with lqcd_gauge_download.  Single-GPU contexts only. */
+ * (checked against finite differences of S_f in the tests).  Download with lqcd_gauge_download.  Collective on a partitioned
+ * lattice: one exchange of the lower-face X, Y spinors (RCCL) feeds the links of the upper faces. */
 int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y);
+/* the same sequence on an in-process PE grid (lqcd_ctx_link_local; tests): arrays ordered by rank */
+int lqcd_mdom_fermion_force(int n, lqcd_op_t* ops, lqcd_gauge_t* outs, lqcd_spinor_t* X, lqcd_spinor_t* Y);
 /* calc_UdSfdU! in one call: solve, Y = D X and the sweep, all resident; Sf and iters may be NULL */
 int lqcd_calc_UdSfdU(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t eta, double eps, int maxiter, double* Sf, int* iters);
 

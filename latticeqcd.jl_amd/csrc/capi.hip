@@ -191,6 +191,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     for (lqcd_spinor_s* s : c->scratch) { hipFree(s->data); delete s; }
     for (int mu = 0; mu < 4; mu++) {
         hipFree(c->send_fwd[mu]); hipFree(c->send_bwd[mu]); hipFree(c->recv_fwd[mu]); hipFree(c->recv_bwd[mu]);
+        hipFree(c->force_send[mu]); hipFree(c->force_recv[mu]);
     }
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     hipFree(c->d_partial); hipFree(c->d_scal); hipHostFree(c->h_scal);

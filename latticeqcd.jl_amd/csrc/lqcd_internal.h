@@ -229,6 +229,9 @@ struct lqcd_ctx_s {
     // halo buffers (sized for Wilson full-lattice: 2 parities * 6 comps * Fh)
     double2* send_fwd[4] = {}, *send_bwd[4] = {}, *recv_fwd[4] = {}, *recv_bwd[4] = {};
     size_t halo_elems[4] = {};
+    // fermion-force halos (force.hip): full X and Y spinors of the lower face, allocated on first use
+    double2* force_send[4] = {}, *force_recv[4] = {};
+    int force_ncomp = 0;
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;
@@ -322,8 +325,12 @@ enum { B_RHO = 24, B_R0V = 26, B_ALPHA = 28, B_SS = 30, B_TS = 31, B_TT = 33, B_
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);
+// force.hip: pack the lower-face X, Y spinors of every partitioned direction / exchange them / the outer-product sweep
+int launch_force_pack(lqcd_ctx_s* c, int kind, lqcd_spinor_s* X, lqcd_spinor_s* Y);
+int force_halo_exchange_rccl(lqcd_ctx_s* c, int kind);
+int force_halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind);
 int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
-                         double r);   // force.hip
+                         double r);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path)
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);

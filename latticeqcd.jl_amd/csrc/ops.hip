@@ -811,10 +811,11 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
 
 // ---------------------------------------------------------------------------------- pseudofermion action and force
 // (evaluate_FermiAction standardHMC.jl:71, calc_UdSfdU! AbstractMD.jl:129)
+static int mdom_check(int n, lqcd_ctx_s* c0);
 static int force_check(lqcd_op_s* op, const char* who) {
-    if (any_partitioned(op->ctx)) {
-        set_error(std::string(who) + ": the fermion force is not available on a partitioned lattice yet (single-GPU contexts only)");
-        return LQCD_ERR_UNSUPPORTED;
+    if (any_partitioned(op->ctx) && !op->ctx->local_peers.empty()) {
+        set_error(std::string(who) + ": this context belongs to an in-process PE grid: use lqcd_mdom_fermion_force");
+        return LQCD_ERR_ARG;
     }
     return LQCD_OK;
 }
@@ -844,8 +845,31 @@ extern "C" int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t 
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     apply_bc(c, op->bc);
+    if (any_partitioned(c)) {   // one exchange step: lower-face X, Y -> the -mu neighbours
+        LQCHK(launch_force_pack(c, op->kind, X, Y));
+        LQCHK(force_halo_exchange_rccl(c, op->kind));
+    }
     LQCHK(launch_fermion_force(c, op->kind, op->gauge, out, X, Y, op->km, op->r));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+// in-process PE-grid emulation of the same sequence (tests): ops/outs/X/Y ordered by rank
+extern "C" int lqcd_mdom_fermion_force(int n, lqcd_op_t* ops, lqcd_gauge_t* outs, lqcd_spinor_t* X, lqcd_spinor_t* Y) {
+    ARGCHK(ops && outs && X && Y && n >= 1, "lqcd_mdom_fermion_force: null");
+    LQCHK(mdom_check(n, ops[0]->ctx));
+    std::vector<lqcd_ctx_s*> ctxs(n);
+    for (int r = 0; r < n; r++) {
+        LQCHK(check_full(ops[r], X[r], Y[r], "lqcd_mdom_fermion_force"));
+        ARGCHK(outs[r] && outs[r]->ctx == ops[r]->ctx && outs[r] != ops[r]->gauge, "lqcd_mdom_fermion_force: bad output field");
+        ctxs[r] = ops[r]->ctx;
+        ARGCHK(ctxs[r]->rank == r, "lqcd_mdom_fermion_force: ops must be ordered by rank");
+        apply_bc(ctxs[r], ops[r]->bc);
+    }
+    for (int r = 0; r < n; r++) LQCHK(launch_force_pack(ctxs[r], ops[r]->kind, X[r], Y[r]));
+    LQCHK(force_halo_exchange_local_all(ctxs.data(), n, ops[0]->kind));
+    for (int r = 0; r < n; r++) LQCHK(launch_fermion_force(ctxs[r], ops[r]->kind, ops[r]->gauge, outs[r], X[r], Y[r], ops[r]->km, ops[r]->r));
+    for (int r = 0; r < n; r++) HIPCHK(hipStreamSynchronize(ctxs[r]->stream));
     return LQCD_OK;
 }
 

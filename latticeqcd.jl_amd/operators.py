@@ -406,6 +406,10 @@ def mdom_mul_(ys, Ds, xs):
     check(_l.lib().lqcd_mdom_op_apply(len(Ds), _harr(Ds), _harr(ys), _harr(xs), int(Ds[0].dagger)))
 
 
+def mdom_fermion_force_(Gs, Ds, Xs, Ys):
+    check(_l.lib().lqcd_mdom_fermion_force(len(Ds), _harr(Ds), _harr(Gs), _harr(Xs), _harr(Ys)))
+
+
 def mdom_dot(As, Bs):
     re, im = C.c_double(0), C.c_double(0)
     check(_l.lib().lqcd_mdom_dot(len(As), _harr(As), _harr(Bs), C.byref(re), C.byref(im)))

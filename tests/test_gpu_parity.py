@@ -471,6 +471,10 @@ def test_rccl_self_partition_dslash_and_cg(gpu, orc):
             it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
             xo, ito, rro, st = orc.cg_DdagD(kind, U, psi, L, km, 1.0, BC, eps=1e-19)
             assert st == 0 and abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (name, it, ito)
+            G = lq.Gaugefields(lat)                      # fermion force with the X/Y face exchange over RCCL
+            lq.fermion_force_(G, D, x, y)
+            Go = orc.fermion_force(kind, U, psi, y.download(), L, km, 1.0, BC)
+            assert np.abs(G.download() - Go).max() / np.abs(Go).max() < 1e-13, (name, "force")
         assert abs(lq.calculate_Plaquette(Ud) - orc.plaquette(U, L)) < 1e-13
         assert abs(lq.dot(x, x) - np.vdot(psi, psi)) < 1e-9
         print("RCCL_SELF_OK")
@@ -634,3 +638,32 @@ def test_fermion_force_rejects_partitioned_and_bad_arguments(gpu, orc):
         lq.fermion_force_(Ud, D, X, X.similar())            # out must not be the operator's own links
     with pytest.raises(lq.LQCDError):
         lq.FermiAction(D, {"Nf": 3})
+
+
+@pytest.mark.parametrize("pe", [(1, 1, 1, 2), (1, 1, 2, 2), (1, 2, 2, 2), (2, 2, 2, 2)])
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+def test_partitioned_fermion_force_equals_single_domain(gpu, orc, pe, kind_name):
+    """N-domain force (lower-face X, Y exchange feeding the upper-face links) == oracle force on the global lattice."""
+    lq = gpu
+    gL = (8, 8, 8, 16)
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    okind = orc.WILSON if kind == lq.WILSON else orc.STAGGERED
+    n = int(np.prod(pe))
+    U = orc.hot_gauge(gL, 111)
+    shape = orc.wilson_shape(gL) if kind == lq.WILSON else orc.staggered_shape(gL)
+    lead = 1 if kind == lq.WILSON else 0
+    Xh, Yh = orc.gaussian_spinor(shape, 112), orc.gaussian_spinor(shape, 113)
+    km, r = (KAPPA, 0.8) if kind == lq.WILSON else (MASS, 1.0)        # general r: the exchange carries full spinors
+    lats = [lq.Lattice(gL, pe, rk) for rk in range(n)]
+    lq.link_local(lats)
+    Ds, Gs, Xs, Ys = [], [], [], []
+    for lat in lats:
+        Ud = lq.Gaugefields(lat).upload(lq.pegrid.local_view(U, lat.local_L, lat.origin, lead=1))
+        Ds.append(lq.Dirac_operator(Ud, None, {"Dirac_operator": kind_name, "κ": KAPPA, "mass": MASS, "r": r, "boundarycondition": BC}))
+        Xs.append(lq.Fermionfields(lat, kind).upload(lq.pegrid.local_view(Xh, lat.local_L, lat.origin, lead=lead)))
+        Ys.append(lq.Fermionfields(lat, kind).upload(lq.pegrid.local_view(Yh, lat.local_L, lat.origin, lead=lead)))
+        Gs.append(lq.Gaugefields(lat))
+    lq.mdom_fermion_force_(Gs, Ds, Xs, Ys)
+    ref = orc.fermion_force(okind, U, Xh, Yh, gL, km, r=r, bc=BC)
+    for lat, G in zip(lats, Gs):
+        assert rel_err(G.download(), lq.pegrid.local_view(ref, lat.local_L, lat.origin, lead=1)) < 1e-13
