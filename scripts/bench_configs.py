@@ -85,6 +85,38 @@ def main():
     res.append({"config": "16^3x32 staggered multi-shift CG, 10 shifts, mass 0.05 (RHMC solver)", "iters": it, "resid": rr,
                 "ms": 1e3 * dt, "single_cg_iters": its, "single_cg_ms": 1e3 * dts,
                 "cost_vs_10_separate_solves": dt / (10 * dts)})
+    for o in (U, D, b, x0, *xs):
+        o.close()
+    # ---- fermion force sweep at 32^3x64 (Wilson) -- 1536 B/site compulsory
+    L = (32, 32, 32, 64)
+    V = 32 ** 3 * 64
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA})
+    X, Y = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(X, 1)
+    lq.gauss_distribution_fermion_(Y, 2)
+    G = lq.Gaugefields(lat)
+    lq.fermion_force_(G, D, X, Y)
+    dt, _ = timed(lambda: [lq.fermion_force_(G, D, X, Y) for _ in range(10)], reps=3)
+    ms = 1e3 * dt / 10
+    res.append({"config": "32^3x64 Wilson fermion-force sweep (calc_UdSfdU! after the solve)", "ms": ms,
+                "algorithmic_GBps_1536B": 1536 * V / ms / 1e6, "roofline_frac": 1536 * V / ms / 1e6 / 8000})
+    for o in (U, D, X, Y, G):
+        o.close()
+    # ---- configs[4] geometry on one GPU: 48^3x96 staggered Dslash and CG (fp64)
+    L = (48, 48, 48, 96)
+    V = 48 ** 3 * 96
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": MASS})
+    b = lq.Fermionfields(lat, lq.STAGGERED)
+    lq.gauss_distribution_fermion_(b, 112)
+    x, y = b.similar(), b.similar()
+    ms = lq.bench_dslash(D, y, b, warm=10, reps=100)
+    msi = lq.bench_cg(D, x, b, warm=3, niter=50)
+    res.append({"config": "48^3x96 staggered Dslash + CG window, fp64, one GPU", "dslash_ms": ms, "dslash_gflops": 570 * V / ms / 1e6,
+                "roofline_frac_672B": 672 * V / ms / 1e6 / 8000, "cg_iters_per_s": 1e3 / msi})
     for r in res:
         print(json.dumps(r))
 
