@@ -805,6 +805,57 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
 }
 
+// direction-split form (dslash_variant >= 1): 4 waves per 64 sites, wave = direction (forward + backward hop = 18 link + 6
+// spinor loads issued as one burst), the four colour-vector partials are combined through LDS and waves 0..2 write one
+// colour component each.  Same reasoning as wilson_dirsplit: short-lived, phase-aligned waves keep the 2x link and 8x
+// spinor re-use inside the L2 residency time, and the XCD tile sweep of map_block applies to 64-site chunks.
+__global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
+    __shared__ double2 part[4][3][64];
+    __shared__ double red[4];
+    if (upd_done(k)) return;
+    int chunk, p;
+    map_block(k, chunk, p);
+    const int Vh = sp_stride(k.g);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < k.g.Vh;
+    cd acc[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    cd xv = mk(0, 0);
+    if (valid && k.a != 0.0 && w < 3) xv = ld(k.xin[p] + sp_off(3, i) + (size_t)w * Vh);
+    if (valid) {
+        Nbr n;
+        int c[4];
+        neighbours(k.g, p, i, n, c);
+        const double2* __restrict__ psi = k.in[1 - p];
+        const int Us = glink_stride(k.g);
+        const double eta = stag_eta(c, w);
+        const int nf = w == 0 ? n.fwd[0] : w == 1 ? n.fwd[1] : w == 2 ? n.fwd[2] : n.fwd[3];
+        const int nb = w == 0 ? n.bwd[0] : w == 1 ? n.bwd[1] : w == 2 ? n.bwd[2] : n.bwd[3];
+        const double sf = w == 0 ? n.sf[0] : w == 1 ? n.sf[1] : w == 2 ? n.sf[2] : n.sf[3];
+        const double sb = w == 0 ? n.sb[0] : w == 1 ? n.sb[1] : w == 2 ? n.sb[2] : n.sb[3];
+        if (sf != 0.0) stag_hop(acc, psi + sp_off(3, nf), k.gauge + glink_off(k.g, p, w, i), Vh, Us, eta * sf, false);
+        if (sb != 0.0) stag_hop(acc, psi + sp_off(3, nb), k.gauge + glink_off(k.g, 1 - p, w, nb), Vh, Us, -eta * sb, true);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) part[w][j][lane] = make_double2(acc[j].re, acc[j].im);
+    __syncthreads();
+    double nrm = 0.0;
+    if (valid && w < 3) {
+        const double2 s0 = part[0][w][lane], s1 = part[1][w][lane], s2 = part[2][w][lane], s3 = part[3][w][lane];
+        cd v = k.b * mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
+        emit(k, p, (size_t)w * Vh + sp_off(3, i), v, nrm);
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ halo: pack
 // blockIdx.y = 2*mu + side.  side 0: lower face (x_mu = 0) -> send_bwd[mu] = P psi   (receiver's forward hop)
 //                            side 1: upper face (x_mu = L-1) -> send_fwd[mu] = U^+ P psi (receiver's backward hop)
@@ -1131,7 +1182,8 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
 }
 
 static bool use_dirsplit(lqcd_ctx_s* c, int kind, double r) {   // variants 1/2/3 work on 64-site chunks
-    return (c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 3) && kind == LQCD_WILSON && r == 1.0;
+    if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 3)) return false;
+    return kind == LQCD_STAGGERED || r == 1.0;   // Wilson: the split kernels use the r = 1 projectors
 }
 static int persist_grid(lqcd_ctx_s* c, int nvirt) {
     int g = c->num_cu * (c->tun.persist_per_cu > 0 ? c->tun.persist_per_cu : 2);
@@ -1144,7 +1196,7 @@ static int persist_grid(lqcd_ctx_s* c, int nvirt) {
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
     const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
     const int nvirt = ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
-    if (use_dirsplit(c, kind, r) && c->tun.dslash_variant == 3) return persist_grid(c, nvirt);
+    if (use_dirsplit(c, kind, r) && kind == LQCD_WILSON && c->tun.dslash_variant == 3) return persist_grid(c, nvirt);
     return nvirt;
 }
 
@@ -1173,7 +1225,9 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
     if (use_dirsplit(c, s.kind, s.r)) {
         KArgs k = make_kargs(c, s, 64);
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
-        if (c->tun.dslash_variant == 3) {
+        if (s.kind == LQCD_STAGGERED) {
+            hipLaunchKernelGGL(staggered_dirsplit, dim3(k.nblocks), dim3(256), pad, c->stream, k);
+        } else if (c->tun.dslash_variant == 3) {
             dim3 grid(persist_grid(c, k.nblocks)), block(512);
             if (s.dagger) hipLaunchKernelGGL((wilson_hopsplit_persist<true>), grid, block, pad, c->stream, k, k.nblocks);
             else hipLaunchKernelGGL((wilson_hopsplit_persist<false>), grid, block, pad, c->stream, k, k.nblocks);
