@@ -142,6 +142,14 @@ int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int d
  * Zero initial guesses; stops when rr * max(1, max_j zeta_j^2) < eps. */
 int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
                              double eps, int maxiter, int* iters, double* final_rr);
+/* mixed-precision CG on D^+D (SURVEY.md 8(b) "later solve_mixed_cg", 8(f) rank 3; BASELINE configs[4]): fp32 inner CG (fp32
+ * copies of the links and work vectors, fp32 build of the stencil) inside an fp64 defect correction.  Same contract as
+ * lqcd_solve_cg_DdagD -- solve_DinvX!(y, DdagD, x) -- except that the stopping rule real(r.r) < eps is enforced on the TRUE
+ * residual b - D^+D x recomputed in fp64.  x holds the initial guess.  inner_tol: relative residual asked of each fp32 solve
+ * (<= 0: 1e-4).  iters: total inner iterations (+ fp64 iterations if the fall-back ran); outer: correction steps. */
+int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
+                              int* outer, double* final_rr);
+
 /* ---------------------------------------------------------------- pseudofermion action and force */
 /* evaluate_FermiAction(fa, U, eta) (src/updates/standardHMC.jl:71): S_f = eta^+ (D^+D)^-1 eta by CG from a zero guess.
  * X receives (D^+D)^-1 eta; Y (may be NULL) receives D X.  Both stay on the device for lqcd_fermion_force. */

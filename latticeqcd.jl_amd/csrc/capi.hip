@@ -193,6 +193,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
         hipFree(c->send_fwd[mu]); hipFree(c->send_bwd[mu]); hipFree(c->recv_fwd[mu]); hipFree(c->recv_bwd[mu]);
         hipFree(c->force_send[mu]); hipFree(c->force_recv[mu]);
     }
+    for (void* b : c->mix_buf) hipFree(b);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     hipFree(c->d_partial); hipFree(c->d_scal); hipHostFree(c->h_scal);
     hipEventDestroy(c->ev_pack); hipEventDestroy(c->ev_comm); hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);

@@ -3,9 +3,12 @@
 // Device data layout (HBM), chosen for coalesced 16-B/lane loads (one complex fp64 per lane, 1 KiB per
 // wave64 instruction):
 //   * sites are checkerboarded: parity p = (x+y+z+t)&1, cb = (x>>1) + XH*(y + LY*(z + LZ*t)), XH = LX/2
-//   * spinor  [parity][comp][cb]   comp = spin*3 + colour (Wilson, 12)  or colour (staggered, 3); element = double2
-//   * gauge   [parity][mu][a*3+b][cb]                                    element = double2 (row a, column b)
-// i.e. structure-of-arrays with the site index fastest; an EVEN/ODD spinor is one [comp][cb] block.
+//   * chunk-blocked (default): spinor [parity][chunk = cb/64][comp][cb%64], gauge [parity][chunk][mu][a*3+b][cb%64]
+//     (comp = spin*3 + colour (Wilson, 12) or colour (staggered, 3); element = one complex number, row a, column b of U_mu(n))
+//   * an EVEN/ODD spinor is one parity block.
+//
+// Precision: the stencil translation unit is compiled twice -- fp64 (namespace lqcd::p64, the default everything else sees)
+// and, with -DLQCD_F32, fp32 (lqcd::p32; same layouts with float2 elements) for the inner solver of the mixed-precision CG.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -16,6 +19,20 @@
 #include "../../include/lqcd_hip.h"
 
 namespace lqcd {
+
+#ifdef LQCD_F32
+typedef float real;
+typedef float2 real2;
+#define LQCD_PNS p32
+inline namespace p32 {}
+namespace p64 {}
+#else
+typedef double real;
+typedef double2 real2;
+#define LQCD_PNS p64
+inline namespace p64 {}
+namespace p32 {}
+#endif
 
 // exact division of 0 <= n < 2^31 by a run-time constant d >= 1 as mulhi + shift:  q = (n * M) >> (31 + s),
 // s = ceil(log2 d), M = floor(2^(31+s) / d) + 1 (fits 32 bits; exact because n * (M*d - 2^(31+s)) < 2^(31+s) for n < 2^31).
@@ -148,16 +165,18 @@ __host__ __device__ inline int coords_to_face(const Geom& g, int mu, const int c
     return (c[d0] >> 1) + (g.L[d0] / 2) * (c[d1] + g.L[d1] * c[d2]);
 }
 
-// ---------------------------------------------------------------- complex fp64 helpers
+// ---------------------------------------------------------------- complex helpers (precision of the translation unit)
+inline namespace LQCD_PNS {
 struct cd {
-    double re, im;
+    real re, im;
 };
-__host__ __device__ inline cd mk(double a, double b) { cd r = {a, b}; return r; }
-__device__ inline cd ld(const double2* p) { double2 v = *p; return mk(v.x, v.y); }
-__device__ inline void st(double2* p, cd v) { *p = make_double2(v.re, v.im); }
+__host__ __device__ inline cd mk(real a, real b) { cd r = {a, b}; return r; }
+__host__ __device__ inline real2 mk2(real a, real b) { real2 t; t.x = a; t.y = b; return t; }
+__device__ inline cd ld(const real2* p) { real2 v = *p; return mk(v.x, v.y); }
+__device__ inline void st(real2* p, cd v) { real2 t; t.x = v.re; t.y = v.im; *p = t; }
 __device__ inline cd operator+(cd a, cd b) { return mk(a.re + b.re, a.im + b.im); }
 __device__ inline cd operator-(cd a, cd b) { return mk(a.re - b.re, a.im - b.im); }
-__device__ inline cd operator*(double s, cd a) { return mk(s * a.re, s * a.im); }
+__device__ inline cd operator*(real s, cd a) { return mk(s * a.re, s * a.im); }
 __device__ inline cd cmul(cd a, cd b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
 // acc += a*b
 __device__ inline void cfma(cd& acc, cd a, cd b) {
@@ -177,6 +196,7 @@ template <int K> __device__ inline cd mul_ipow(cd a) {
     else if constexpr (k == 2) return mk(-a.re, -a.im);
     else return mk(a.im, -a.re);
 }
+}  // inline namespace
 
 // gamma_mu (mu = 0,1,2) has one entry per row: row a -> column PERM[mu][a], value i^GK[mu][a]  (SURVEY.md Appendix A);
 // gamma_4 = diag(1,1,-1,-1)
@@ -232,6 +252,9 @@ struct lqcd_ctx_s {
     // fermion-force halos (force.hip): full X and Y spinors of the lower face, allocated on first use
     double2* force_send[4] = {}, *force_recv[4] = {};
     int force_ncomp = 0;
+    // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
+    void* mix_buf[5] = {};
+    size_t mix_bytes[5] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;
@@ -316,23 +339,38 @@ struct StencilCall {
     // scalar block (upd_scal[S_ALPHA]); the kernel is a no-op once upd_scal[S_DONE] is set.  q = D^+ D p is never written.
     const double* upd_scal = nullptr;
     double2* upd[2] = {nullptr, nullptr};
+    int prec = 0;                 // 0: fp64 fields, 1: fp32 fields (pointers are float2 data, see p32)
 };
 // slots of the device scalar block d_scal used by the solvers
 enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16 };
 // BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
 enum { B_RHO = 24, B_R0V = 26, B_ALPHA = 28, B_SS = 30, B_TS = 31, B_TT = 33, B_OMEGA = 34, B_RR = 36, B_RHO1 = 37, B_BETA = 39,
        B_DONE = 41, B_ITERS = 42, B_EPS = 43, B_HALF = 44, B_RES = 45, B_END = 46 };
+// stencil.hip, once per precision (p64 is the inline namespace everywhere except in the fp32 build of stencil.hip).
+// With prec = 1 the field pointers of a StencilCall address float2 data (cast), scalars stay double.
+namespace p64 {
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);
+}
+namespace p32 {
+int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
+int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
+int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);
+}
 // force.hip: pack the lower-face X, Y spinors of every partitioned direction / exchange them / the outer-product sweep
 int launch_force_pack(lqcd_ctx_s* c, int kind, lqcd_spinor_s* X, lqcd_spinor_s* Y);
 int force_halo_exchange_rccl(lqcd_ctx_s* c, int kind);
 int force_halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind);
 int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
                          double r);
-int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path)
-int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode);
+int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec);
+StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger);
+void apply_bc(lqcd_ctx_s* c, const int bc[4]);
+int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial);
+int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr);
+bool any_partitioned(lqcd_ctx_s* c);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode);
 int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode);

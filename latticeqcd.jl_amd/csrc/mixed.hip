@@ -1,0 +1,235 @@
+// mixed.hip -- mixed-precision CG on D^+D: fp32 inner solver, fp64 outer defect correction (SURVEY.md 8(f) rank 3 and 8(b)
+// "later solve_mixed_cg"; BASELINE.json configs[4] "mixed-precision fp32 inner / fp64 outer CG").  The reference has no such
+// solver (its solve_DinvX! is fp64 throughout); the contract kept here is the reference's stopping rule on the TRUE fp64
+// residual: on return |b - D^+D x|^2 < eps, recomputed in fp64.
+//
+//   outer (fp64):  r = b - A x ;  while |r|^2 >= eps:   e ~ A^-1 (r/|r|) in fp32 ;  x += |r| e ;  r = b - A x
+//   inner (fp32):  the same fused CG iteration as the fp64 solver (ops.hip) -- D p with |.|^2 partials, D^+ in update mode,
+//                  fused x/p update, device-resident scalars -- on float2 copies of the links and of four spinors, through the
+//                  fp32 build of the stencil (lqcd::p32, stencil.hip compiled with -DLQCD_F32).  Half the bytes per iteration.
+// The residual is normalised before it is rounded to fp32, so the inner solver never sees the absolute scale.  If an outer
+// step fails to reduce the true residual by 2x (fp32 accuracy exhausted) the solve is finished by the fp64 CG from the
+// current iterate.  Partitioned lattices: the fp32 halos go through the same pack / RCCL / exterior sequence (ncclFloat).
+#include "lqcd_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace lqcd {
+
+constexpr int MB = 256;
+
+__global__ __launch_bounds__(MB) void cvt_to_f32(float2* __restrict__ dst, const double2* __restrict__ src, size_t n, double scale) {
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
+        const double2 v = src[i];
+        dst[i] = make_float2((float)(v.x * scale), (float)(v.y * scale));
+    }
+}
+// y (fp64) += a * x (fp32)
+__global__ __launch_bounds__(MB) void axpy_from_f32(double2* __restrict__ y, const float2* __restrict__ x, double a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
+        const float2 xv = x[i];
+        double2 yv = y[i];
+        yv.x = fma(a, (double)xv.x, yv.x);
+        yv.y = fma(a, (double)xv.y, yv.y);
+        y[i] = yv;
+    }
+}
+// r = b - q  (fp64) with |r|^2 block partials
+__global__ __launch_bounds__(MB) void residual_kernel(double2* __restrict__ r, const double2* __restrict__ b, const double2* __restrict__ q, size_t n,
+                                                       double* partial) {
+    __shared__ double red[MB / 64];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
+        const double2 bv = b[i], qv = q[i];
+        const double2 rv = make_double2(bv.x - qv.x, bv.y - qv.y);
+        r[i] = rv;
+        acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < MB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+// fp32 tail of a CG iteration: x += alpha p ; p = r + beta p   (same flag protocol as cg_update_xp in ops.hip)
+__global__ __launch_bounds__(MB) void cg32_update_xp(const double* __restrict__ s, float2* __restrict__ x, float2* __restrict__ p,
+                                                      const float2* __restrict__ r, size_t n) {
+    if (s[S_XDONE] != 0.0) return;
+    const float al = (float)s[S_ALPHA], be = (float)s[S_BETA];
+    const bool cont = s[S_DONE] == 0.0;
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
+        float2 pv = p[i], xv = x[i];
+        xv.x = fmaf(al, pv.x, xv.x); xv.y = fmaf(al, pv.y, xv.y);
+        x[i] = xv;
+        if (cont) {
+            const float2 rv = r[i];
+            pv.x = fmaf(be, pv.x, rv.x); pv.y = fmaf(be, pv.y, rv.y);
+            p[i] = pv;
+        }
+    }
+}
+
+static int mix_alloc(lqcd_ctx_s* c, int slot, size_t bytes) {
+    if (c->mix_bytes[slot] >= bytes) return LQCD_OK;
+    if (c->mix_buf[slot]) HIPCHK(hipFree(c->mix_buf[slot]));
+    c->mix_buf[slot] = nullptr; c->mix_bytes[slot] = 0;
+    HIPCHK(hipMalloc(&c->mix_buf[slot], bytes));
+    c->mix_bytes[slot] = bytes;
+    return LQCD_OK;
+}
+
+struct Mix32 {
+    float2 *gauge, *x, *r, *p, *t;
+    size_t blk;   // elements per parity block
+};
+
+// a StencilCall on fp32 fields (pointers travel as double2*, stencil_apply dispatches on prec)
+static StencilCall call32(lqcd_op_s* op, const Mix32& m, float2* out, float2* in, int dagger) {
+    StencilCall s;
+    s.kind = op->kind;
+    s.gauge = (const double2*)m.gauge;
+    for (int p = 0; p < 2; p++) {
+        s.out[p] = (double2*)(out + p * m.blk);
+        s.in[p] = (const double2*)(in + p * m.blk);
+        s.xin[p] = (const double2*)(in + p * m.blk);
+    }
+    if (op->kind == LQCD_WILSON) { s.a = 1.0; s.b = -op->km; }
+    else { s.a = op->km; s.b = dagger ? -0.5 : 0.5; }
+    s.r = op->r;
+    s.dagger = dagger;
+    s.parity_mode = 2;
+    s.prec = 1;
+    return s;
+}
+
+// fp32 CG on A e = rhs (|rhs|^2 = 1, e starts at 0) until the recursive residual drops below eps2 or maxiter; returns iterations
+static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int maxiter, int* iters, double* rr_out) {
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipMemsetAsync(m.x, 0, n * sizeof(float2), c->stream));
+    HIPCHK(hipMemcpyAsync(m.p, m.r, n * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+    double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
+    HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n), check_every = 8;
+    int it = 0;
+    double rr = 1.0;
+    bool done = false;
+    while (!done && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        for (int k = 0; k < burst; k++) {
+            apply_bc(c, op->bc);
+            StencilCall s1 = call32(op, m, m.t, m.p, 0);
+            s1.norm_partial = c->d_partial;
+            LQCHK(stencil_apply(c, s1));
+            LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));
+            StencilCall s2 = call32(op, m, m.t, m.t, 1);      // update mode: nothing is written to out
+            s2.norm_partial = c->d_partial;
+            s2.upd_scal = c->d_scal;
+            s2.upd[0] = (double2*)m.r;
+            s2.upd[1] = (double2*)(m.r + m.blk);
+            LQCHK(stencil_apply(c, s2));
+            LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
+            hipLaunchKernelGGL(cg32_update_xp, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, m.x, m.p, m.r, n);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rr = c->h_scal[0];
+        it = (int)c->h_scal[S_ITERS - S_RR];
+        done = c->h_scal[S_DONE - S_RR] != 0.0;
+        if (!std::isfinite(rr)) break;
+    }
+    *iters = it;
+    *rr_out = rr;
+    return LQCD_OK;
+}
+
+}  // namespace lqcd
+
+using namespace lqcd;
+
+// Mixed-precision CG for D^+D x = b.  x holds the initial guess.  eps: absolute bound on the TRUE squared residual (the
+// reference's rule real(r.r) < eps, evaluated in fp64); inner_tol: relative residual norm requested from each fp32 solve
+// (<= 0 selects 1e-4).  iters = total fp32 iterations (+ fp64 iterations of the fall-back, if it ran); outer = defect-correction steps.
+extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
+                                         int* outer, double* final_rr) {
+    ARGCHK(op && x && b && x->ctx == op->ctx && b->ctx == op->ctx && x->kind == op->kind && b->kind == op->kind && x->subset == LQCD_FULL &&
+               b->subset == LQCD_FULL && x != b && maxiter >= 0,
+           "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (inner_tol <= 0.0) inner_tol = 1e-4;
+    const size_t n = x->elems, ng = op->gauge->elems;
+    LQCHK(mix_alloc(c, 0, ng * sizeof(float2)));
+    for (int k = 1; k <= 4; k++) LQCHK(mix_alloc(c, k, n * sizeof(float2)));
+    Mix32 m;
+    m.gauge = (float2*)c->mix_buf[0];
+    m.x = (float2*)c->mix_buf[1]; m.r = (float2*)c->mix_buf[2]; m.p = (float2*)c->mix_buf[3]; m.t = (float2*)c->mix_buf[4];
+    m.blk = n / 2;
+    lqcd_spinor_s* r = scratch_get(c, x->kind, LQCD_FULL);
+    lqcd_spinor_s* q = scratch_get(c, x->kind, LQCD_FULL);
+    lqcd_spinor_s* t = scratch_get(c, x->kind, LQCD_FULL);
+    auto release = [&]() { scratch_put(r); scratch_put(q); scratch_put(t); };
+    if (!(r && q && t)) { release(); return LQCD_ERR_HIP; }
+    int total = 0, nout = 0, st = LQCD_OK;
+    double rr = 0;
+    auto true_residual = [&]() -> int {     // r = b - D^+D x, rr = |r|^2 (all ranks)
+        LQCHK(op_apply_async(op, t, x, 0, nullptr));
+        LQCHK(op_apply_async(op, q, t, 1, nullptr));
+        const int nb = stream_grid(c, n);
+        hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(MB), 0, c->stream, r->data, b->data, q->data, n, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 1, S_RED0, true, 0));
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rr = c->h_scal[0];
+        return LQCD_OK;
+    };
+    auto run = [&]() -> int {
+        hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
+        HIPCHK(hipGetLastError());
+        LQCHK(true_residual());
+        bool fallback = false;
+        while (rr >= eps && total < maxiter) {
+            if (!std::isfinite(rr)) { set_error("mixed CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
+            const double nrm = std::sqrt(rr);
+            hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, m.r, r->data, n, 1.0 / nrm);
+            HIPCHK(hipGetLastError());
+            // no tighter than needed to reach eps (with a 10x margin), no tighter than fp32 can deliver
+            const double eps2 = std::max(inner_tol * inner_tol, 0.1 * eps / rr);
+            int it = 0;
+            double rin = 0;
+            LQCHK(inner_cg32(op, m, n, eps2, maxiter - total, &it, &rin));
+            total += it;
+            nout++;
+            hipLaunchKernelGGL(axpy_from_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, x->data, m.x, nrm, n);
+            HIPCHK(hipGetLastError());
+            const double rr_old = rr;
+            LQCHK(true_residual());
+            if (!(rr < 0.5 * rr_old)) { fallback = rr >= eps; break; }   // fp32 accuracy exhausted
+        }
+        if (fallback && total < maxiter) {
+            int it64 = 0;
+            const int s64 = cg_run(op, x, b, eps, maxiter - total, false, &it64, nullptr);
+            total += it64;
+            if (s64 != LQCD_OK && s64 != LQCD_ERR_NOT_CONVERGED) return s64;
+            LQCHK(true_residual());
+        }
+        return LQCD_OK;
+    };
+    st = run();
+    release();
+    if (iters) *iters = total;
+    if (outer) *outer = nout;
+    if (final_rr) *final_rr = rr;
+    if (st != LQCD_OK) return st;
+    if (!(rr < eps)) {
+        set_error("The mixed-precision CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}

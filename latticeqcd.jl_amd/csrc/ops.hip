@@ -22,7 +22,8 @@ static size_t halo_count(lqcd_ctx_s* c, int mu, int kind, int parity_mode) {
 
 // RCCL path: one grouped send/recv per partitioned direction and face, on the communication stream, so the
 // transfer over xGMI overlaps the interior stencil running on the compute stream.
-int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode) {
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec) {
+    const ncclDataType_t dt = prec ? ncclFloat : ncclDouble;   // same element counts, float2 instead of double2 elements
     ARGCHK(c->has_comm, "halo exchange: communicator not initialised (call lqcd_ctx_comm_init)");
     HIPCHK(hipEventRecord(c->ev_pack, c->stream));
     HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
@@ -30,10 +31,10 @@ int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode) {
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
         const size_t n = halo_count(c, mu, kind, parity_mode) * 2;  // doubles
-        NCCLCHK(ncclSend(c->send_fwd[mu], n, ncclDouble, c->nbr_fwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclSend(c->send_bwd[mu], n, ncclDouble, c->nbr_bwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclRecv(c->recv_bwd[mu], n, ncclDouble, c->nbr_bwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclRecv(c->recv_fwd[mu], n, ncclDouble, c->nbr_fwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclSend(c->send_fwd[mu], n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclSend(c->send_bwd[mu], n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclRecv(c->recv_bwd[mu], n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclRecv(c->recv_fwd[mu], n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
     }
     NCCLCHK(ncclGroupEnd());
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
@@ -57,25 +58,25 @@ int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode)
     return LQCD_OK;
 }
 
-static bool any_partitioned(lqcd_ctx_s* c) {
+bool any_partitioned(lqcd_ctx_s* c) {
     return c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3];
 }
 
 // full stencil on one rank: pack -> (exchange || interior) -> exterior
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     HIPCHK(hipSetDevice(c->device));
-    if (!any_partitioned(c)) return launch_stencil_interior(c, s);
+    if (!any_partitioned(c)) return s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s);
     if (s.kind == LQCD_WILSON && s.r != 1.0) {
         set_error("Wilson r != 1 is not supported on a partitioned lattice (halos carry spin-projected half spinors)");
         return LQCD_ERR_UNSUPPORTED;
     }
     ARGCHK(c->local_peers.empty(), "this context belongs to an in-process PE grid: use the lqcd_mdom_* collectives");
-    LQCHK(launch_stencil_pack(c, s));
-    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode));
+    LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec));
     // norm partials: the interior writes |.|^2 of what it produced, the exterior appends the corrections of the sites it updates
-    LQCHK(launch_stencil_interior(c, s));
+    LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
-    return launch_stencil_exterior(c, s);
+    return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
 }
 
 // ---------------------------------------------------------------------------------- operator -> stencil calls
@@ -329,7 +330,7 @@ static int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w
     return LQCD_OK;
 }
 
-static int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr) {
+int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr) {
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     CgWork w;

@@ -19,14 +19,15 @@
 #include <algorithm>
 
 namespace lqcd {
+inline namespace LQCD_PNS {
 
 struct KArgs {
     Geom g;
-    const double2* gauge;
-    double2* out[2];
-    const double2* in[2];
-    const double2* xin[2];
-    double a, b, r;
+    const real2* gauge;
+    real2* out[2];
+    const real2* in[2];
+    const real2* xin[2];
+    real a, b, r;
     int parity_mode;
     int nblocks;
     int remap;
@@ -39,14 +40,14 @@ struct KArgs {
     int dbg;     // timing ablations only (wrong results): 1 skip x-hop spinor loads, 2 skip x-hop link loads, 3 skip mat-vec
     double* norm_partial;
     const double* upd_scal;   // update mode (see StencilCall)
-    double2* upd[2];
+    real2* upd[2];
 };
 
 // final store of one output component: plain (out = v) or CG update mode (r -= alpha v); accumulates the squared norm
-__device__ inline void emit(const KArgs& k, int p, size_t off, cd v, double& nrm) {
+__device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm) {
     if (k.upd_scal) {
-        const double al = k.upd_scal[S_ALPHA];
-        double2* rp = k.upd[p] + off;
+        const real al = k.upd_scal[S_ALPHA];
+        real2* rp = k.upd[p] + off;
         cd r = ld(rp);
         r.re = fma(-al, v.re, r.re); r.im = fma(-al, v.im, r.im);
         nrm = fma(r.re, r.re, nrm); nrm = fma(r.im, r.im, nrm);
@@ -60,22 +61,22 @@ __device__ inline bool upd_done(const KArgs& k) { return k.upd_scal && k.upd_sca
 
 struct HArgs {  // halo kernels
     Geom g;
-    const double2* gauge;
-    double2* out[2];
-    const double2* in[2];
-    double b;
+    const real2* gauge;
+    real2* out[2];
+    const real2* in[2];
+    real b;
     int parity_mode;
     int dagger;
-    double2* send_fwd[4];
-    double2* send_bwd[4];
-    const double2* recv_fwd[4];
-    const double2* recv_bwd[4];
-    double sign_fwd[4];  // bc sign if this rank sits on the global upper boundary, else 1
-    double sign_bwd[4];
+    real2* send_fwd[4];
+    real2* send_bwd[4];
+    const real2* recv_fwd[4];
+    const real2* recv_bwd[4];
+    real sign_fwd[4];  // bc sign if this rank sits on the global upper boundary, else 1
+    real sign_bwd[4];
     double* norm_partial;     // if non-null: per-block CORRECTIONS sum(|v_after|^2 - |v_before|^2) go to norm_partial[partial_offset + block]
     int partial_offset;
     const double* upd_scal;   // CG update mode: target is upd (r) and the coefficient is -alpha*b
-    double2* upd[2];
+    real2* upd[2];
 };
 
 // workgroup -> (chunk of consecutive checkerboard sites, parity).  Observed (not contractual) dispatch: block b runs on
@@ -134,14 +135,14 @@ __device__ inline void su3_mv(cd (&chi)[3], const cd (&u)[9], const cd (&h)[3]) 
     }
 }
 
-__device__ inline void load_link(cd (&u)[9], const double2* __restrict__ U, int Vh) {
+__device__ inline void load_link(cd (&u)[9], const real2* __restrict__ U, int Vh) {
 #pragma unroll
     for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * Vh);
 }
 
 // spin projection h = rows 0,1 of (1 - S*gamma_mu) psi   (mu = 3: the two non-zero rows, factor 2 included)
 template <int MU, int S>
-__device__ inline void project(cd (&h0)[3], cd (&h1)[3], const double2* __restrict__ psi, int Vh) {
+__device__ inline void project(cd (&h0)[3], cd (&h1)[3], const real2* __restrict__ psi, int Vh) {
     if constexpr (MU < 3) {
         constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
         constexpr int k0 = GK[MU][0] + (S > 0 ? 2 : 0), k1 = GK[MU][1] + (S > 0 ? 2 : 0);
@@ -185,8 +186,8 @@ __device__ inline void reconstruct(cd (&acc)[12], const cd (&chi0)[3], const cd 
 
 // one hop, r = 1:  acc += (1 - S gamma_mu) [U or U^+] psi(nb) * sign
 template <int MU, int S, bool ADJ>
-__device__ inline void wilson_hop(cd (&acc)[12], const double2* __restrict__ psi, const double2* __restrict__ U,
-                                  int Vh, int Us, double sign) {
+__device__ inline void wilson_hop(cd (&acc)[12], const real2* __restrict__ psi, const real2* __restrict__ U,
+                                  int Vh, int Us, real sign) {
     cd h0[3], h1[3], chi0[3], chi1[3], u[9];
     project<MU, S>(h0, h1, psi, Vh);
     load_link(u, U, Us);
@@ -199,8 +200,8 @@ __device__ inline void wilson_hop(cd (&acc)[12], const double2* __restrict__ psi
 
 // one hop, general r:  acc += (r - S gamma_mu) [U or U^+] psi(nb) * sign
 template <int MU, int S, bool ADJ>
-__device__ inline void wilson_hop_rgen(cd (&acc)[12], const double2* __restrict__ psi, const double2* __restrict__ U,
-                                       int Vh, int Us, double sign, double r) {
+__device__ inline void wilson_hop_rgen(cd (&acc)[12], const real2* __restrict__ psi, const real2* __restrict__ U,
+                                       int Vh, int Us, real sign, real r) {
     cd u[9], t[4][3];
     load_link(u, U, Us);
 #pragma unroll
@@ -228,8 +229,8 @@ __device__ inline void wilson_hop_rgen(cd (&acc)[12], const double2* __restrict_
     } else {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            double d = (s < 2) ? 1.0 : -1.0;
-            double f = r - (double)S * d;
+            real d = (s < 2) ? 1.0 : -1.0;
+            real f = r - (real)S * d;
 #pragma unroll
             for (int c = 0; c < 3; c++) acc[s * 3 + c] = acc[s * 3 + c] + f * t[s][c];
         }
@@ -239,7 +240,7 @@ __device__ inline void wilson_hop_rgen(cd (&acc)[12], const double2* __restrict_
 // neighbour bookkeeping for one site
 struct Nbr {
     int fwd[4], bwd[4];
-    double sf[4], sb[4];   // sign (0 => hop is off-rank, skipped by the interior kernel)
+    real sf[4], sb[4];   // sign (0 => hop is off-rank, skipped by the interior kernel)
 };
 
 __device__ inline void neighbours(const Geom& g, int p, int i, Nbr& n, int c[4]) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const int i = chunk * TB + threadIdx.x;
     const bool valid = i < k.g.Vh;
-    double nrm = 0.0;
+    real nrm = 0.0;
     if (valid) {
         Nbr n;
         int c[4];
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
 #pragma unroll
             for (int j = 0; j < 12; j++) xv[j] = mk(0.0, 0.0);
         }
-        const double2* __restrict__ psi = k.in[1 - p];
+        const real2* __restrict__ psi = k.in[1 - p];
         const int Us = glink_stride(k.g);
         constexpr int SF = DAG ? -1 : 1;  // forward hop: (r - gamma) for D, (r + gamma) for D^+
 #define HOP(MU)                                                                                                  \
@@ -340,9 +341,9 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     int c[4];
     neighbours(k.g, p, i, n, c);
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
-    const double2* __restrict__ psi = k.in[1 - p];
-    const double2* __restrict__ Uf = k.gauge + glink_off(k.g, p, MU, i);
-    const double2* __restrict__ Ub = k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
+    const real2* __restrict__ psi = k.in[1 - p];
+    const real2* __restrict__ Uf = k.gauge + glink_off(k.g, p, MU, i);
+    const real2* __restrict__ Ub = k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
     const int Us = glink_stride(k.g);
     constexpr int SF = DAG ? -1 : 1;
     if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU]);
@@ -351,7 +352,7 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
 
 template <bool DAG>
 __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
-    __shared__ double2 part[4][12][64];  // 48 KiB
+    __shared__ real2 part[4][12][64];  // 48 KiB
     __shared__ double red[4];
     if (upd_done(k)) return;
     int chunk, p;
@@ -379,14 +380,14 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 12; j++) part[w][j][lane] = make_double2(acc[j].re, acc[j].im);
+    for (int j = 0; j < 12; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
     __syncthreads();
-    double nrm = 0.0;
+    real nrm = 0.0;
     if (valid) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
             const int j = 3 * w + cc;
-            const double2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
+            const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
             cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
             cd v = k.b * s;
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
@@ -414,16 +415,16 @@ struct Recon {  // contribution of hop (MU, S) to spin row ROW: src half-spinor 
 };
 
 template <int MU, int S, int ROW>
-__device__ inline void add_hop(cd& sum, const double2 (*half)[6][64], int h, int c, int lane) {
+__device__ inline void add_hop(cd& sum, const real2 (*half)[6][64], int h, int c, int lane) {
     constexpr int src = Recon<MU, S, ROW>::src;
     if constexpr (src >= 0) {
-        const double2 v = half[h][src * 3 + c][lane];
+        const real2 v = half[h][src * 3 + c][lane];
         sum = sum + mul_ipow<Recon<MU, S, ROW>::kpow>(mk(v.x, v.y));
     }
 }
 
 template <int J, bool DAG>
-__device__ inline cd combine_comp(const double2 (*half)[6][64], int lane) {
+__device__ inline cd combine_comp(const real2 (*half)[6][64], int lane) {
     constexpr int ROW = J / 3, c = J % 3, SF = DAG ? -1 : 1;
     cd s0 = mk(0, 0), s1 = mk(0, 0);
     add_hop<0, SF, ROW>(s0, half, 0, c, lane); add_hop<0, -SF, ROW>(s1, half, 1, c, lane);
@@ -433,15 +434,15 @@ __device__ inline cd combine_comp(const double2 (*half)[6][64], int lane) {
     return s0 + s1;
 }
 
-typedef double v2d __attribute__((ext_vector_type(2)));
-__device__ inline void load_link_nt(cd (&u)[9], const double2* __restrict__ U, int Vh) {
+typedef real v2d __attribute__((ext_vector_type(2)));
+__device__ inline void load_link_nt(cd (&u)[9], const real2* __restrict__ U, int Vh) {
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(U + (size_t)j * Vh));
         u[j] = mk(v.x, v.y);
     }
 }
-__device__ inline void st_nt(double2* p, cd v) {
+__device__ inline void st_nt(real2* p, cd v) {
     v2d t = {v.re, v.im};
     __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(p));
 }
@@ -465,22 +466,22 @@ __device__ inline void project_regs(cd (&h0)[3], cd (&h1)[3], const cd* sp) {
 // Buffer-addressed loads: the SRD (base, size) lives in SGPRs, every lane supplies ONE 32-bit byte offset and the component
 // stride goes into the scalar offset -- no per-load 64-bit address VGPR pair / v_lshl_add_u64 (21 of them per hop otherwise).
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-__device__ inline __amdgpu_buffer_rsrc_t mkbuf(const double2* p, size_t elems) {
+__device__ inline __amdgpu_buffer_rsrc_t mkbuf(const real2* p, size_t elems) {
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    const size_t bytes = elems * sizeof(double2);
+    const size_t bytes = elems * sizeof(real2);
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
                                              bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes, 0x00020000);
 }
 __device__ inline cd bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    double2 d;
+    real2 d;
     __builtin_memcpy(&d, &v, sizeof(d));
     return mk(d.x, d.y);
 }
 // raw spinor components a hop needs (12, or the 6 the t projector keeps) and the link, all issued back to back
 template <int MU, int S>
-__device__ inline void load_hop_regs(cd* sp, cd (&u)[9], const double2* psi_block, const double2* gauge, size_t gauge_n, unsigned Vs,
+__device__ inline void load_hop_regs(cd* sp, cd (&u)[9], const real2* psi_block, const real2* gauge, size_t gauge_n, unsigned Vs,
                                      unsigned Us, unsigned psi_site, unsigned link_off) {
     const __amdgpu_buffer_rsrc_t rp = mkbuf(psi_block, (size_t)0x0FFFFFFF), ru = mkbuf(gauge, gauge_n);
     const unsigned vp = psi_site * 16u, vu = link_off * 16u, cs = Vs * 16u, us = Us * 16u;
@@ -503,13 +504,13 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
     neighbours(k.g, p, i, n, c);
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
     constexpr int S = (DAG ? -1 : 1) * (BWD ? -1 : 1);
-    const double sign = BWD ? n.sb[MU] : n.sf[MU];
+    const real sign = BWD ? n.sb[MU] : n.sf[MU];
     const int nb = BWD ? n.bwd[MU] : n.fwd[MU];
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) { chi0[cc] = mk(0, 0); chi1[cc] = mk(0, 0); }
     if (sign != 0.0) {
-        const double2* __restrict__ psi = k.in[1 - p] + sp_off(12, nb);
-        const double2* __restrict__ U = k.gauge + (BWD ? glink_off(k.g, 1 - p, MU, nb) : glink_off(k.g, p, MU, i));
+        const real2* __restrict__ psi = k.in[1 - p] + sp_off(12, nb);
+        const real2* __restrict__ U = k.gauge + (BWD ? glink_off(k.g, 1 - p, MU, nb) : glink_off(k.g, p, MU, i));
         const int Us = glink_stride(k.g);
         cd h0[3], h1[3], u[9];
         constexpr bool USE_BUF = false;   // measured: buffer-addressed loads are ~5 % slower than flat loads here (profiles/)
@@ -550,7 +551,7 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
 template <bool DAG, int NT>
 __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
     constexpr bool NTG = (NT & 1) != 0, NTS = (NT & 2) != 0;
-    __shared__ double2 half[8][6][64];  // 48 KiB
+    __shared__ real2 half[8][6][64];  // 48 KiB
     __shared__ double red[8];
     int chunk, p;
     map_block(k, chunk, p);
@@ -586,11 +587,11 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
     }
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) {
-        half[w][cc][lane] = make_double2(chi0[cc].re, chi0[cc].im);
-        half[w][3 + cc][lane] = make_double2(chi1[cc].re, chi1[cc].im);
+        half[w][cc][lane] = mk2(chi0[cc].re, chi0[cc].im);
+        half[w][3 + cc][lane] = mk2(chi1[cc].re, chi1[cc].im);
     }
     __syncthreads();
-    double nrm = 0.0;
+    real nrm = 0.0;
     if (valid && w < 6) {
         cd s0, s1;
         switch (w) {
@@ -605,14 +606,14 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
         cd v1 = mk(fma(k.a, xv[1].re, k.b * s1.re), fma(k.a, xv[1].im, k.b * s1.im));
         if (k.upd_scal) {
             // CG update mode: r (prefetched at kernel start) <- r - alpha v ; q is never written
-            const double al = k.upd_scal[S_ALPHA];
+            const real al = k.upd_scal[S_ALPHA];
             cd r0 = mk(fma(-al, v0.re, rv[0].re), fma(-al, v0.im, rv[0].im));
             cd r1 = mk(fma(-al, v1.re, rv[1].re), fma(-al, v1.im, rv[1].im));
             nrm = r0.re * r0.re + r0.im * r0.im + r1.re * r1.re + r1.im * r1.im;
-            double2* __restrict__ o = k.upd[p] + sp_off(12, i) + (size_t)(2 * w) * Vh;
+            real2* __restrict__ o = k.upd[p] + sp_off(12, i) + (size_t)(2 * w) * Vh;
             st(o, r0); st(o + Vh, r1);
         } else {
-            double2* __restrict__ o = k.out[p] + sp_off(12, i) + (size_t)(2 * w) * Vh;
+            real2* __restrict__ o = k.out[p] + sp_off(12, i) + (size_t)(2 * w) * Vh;
             nrm = v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
             if constexpr (NTS) { st_nt(o, v0); st_nt(o + Vh, v1); } else { st(o, v0); st(o + Vh, v1); }
         }
@@ -634,15 +635,15 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
 // last one.  Here 2 workgroups per CU stay resident and walk the XCD's chunk sequence; every hop wave issues the 21 loads
 // of its NEXT chunk before it enters the barrier/combine of the current one, so the memory system always has work.
 template <int MU, bool BWD, bool DAG>
-__device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][64], double* red, int nvirt) {
+__device__ inline void hopsplit_persist_loop(const KArgs& k, real2 (*half)[6][64], double* red, int nvirt) {
     constexpr int W = 2 * MU + (BWD ? 1 : 0);
     constexpr int S = (DAG ? -1 : 1) * (BWD ? -1 : 1);
     constexpr int NS = (MU < 3) ? 12 : 6;   // spinor components this hop reads
     const int Vh = sp_stride(k.g);
     const int lane = threadIdx.x & 63;
-    double nrm = 0.0;
+    real nrm = 0.0;
     cd sp[NS], u[9];
-    double sign = 0.0;
+    real sign = 0.0;
     int i = 0, p = 0;
     bool valid = false;
 
@@ -684,8 +685,8 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
         const bool cvalid = valid;
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
-            half[W][cc][lane] = make_double2(chi0[cc].re, chi0[cc].im);
-            half[W][3 + cc][lane] = make_double2(chi1[cc].re, chi1[cc].im);
+            half[W][cc][lane] = mk2(chi0[cc].re, chi0[cc].im);
+            half[W][3 + cc][lane] = mk2(chi1[cc].re, chi1[cc].im);
         }
         // operands of THIS chunk's epilogue first (they return first), then the NEXT chunk's hop loads
         cd xv[2] = {mk(0, 0), mk(0, 0)}, rv[2] = {mk(0, 0), mk(0, 0)};
@@ -709,12 +710,12 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
                 cd v0 = mk(fma(k.a, xv[0].re, k.b * s0.re), fma(k.a, xv[0].im, k.b * s0.im));
                 cd v1 = mk(fma(k.a, xv[1].re, k.b * s1.re), fma(k.a, xv[1].im, k.b * s1.im));
                 if (k.upd_scal) {
-                    const double al = k.upd_scal[S_ALPHA];
+                    const real al = k.upd_scal[S_ALPHA];
                     v0 = mk(fma(-al, v0.re, rv[0].re), fma(-al, v0.im, rv[0].im));
                     v1 = mk(fma(-al, v1.re, rv[1].re), fma(-al, v1.im, rv[1].im));
                 }
                 nrm += v0.re * v0.re + v0.im * v0.im + v1.re * v1.re + v1.im * v1.im;
-                double2* __restrict__ o = (k.upd_scal ? k.upd[cp] : k.out[cp]) + sp_off(12, ci) + (size_t)(2 * W) * Vh;
+                real2* __restrict__ o = (k.upd_scal ? k.upd[cp] : k.out[cp]) + sp_off(12, ci) + (size_t)(2 * W) * Vh;
                 st(o, v0);
                 st(o + Vh, v1);
             }
@@ -735,7 +736,7 @@ __device__ inline void hopsplit_persist_loop(const KArgs& k, double2 (*half)[6][
 
 template <bool DAG>
 __global__ __launch_bounds__(512, 4) void wilson_hopsplit_persist(KArgs k, int nvirt) {
-    __shared__ double2 half[8][6][64];  // 48 KiB
+    __shared__ real2 half[8][6][64];  // 48 KiB
     __shared__ double red[8];
     if (upd_done(k)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -752,8 +753,8 @@ __global__ __launch_bounds__(512, 4) void wilson_hopsplit_persist(KArgs k, int n
 }
 
 // ------------------------------------------------------------------------------------------ staggered
-__device__ inline void stag_hop(cd (&acc)[3], const double2* __restrict__ psi, const double2* __restrict__ U, int Vh, int Us,
-                                double coef, bool adj) {
+__device__ inline void stag_hop(cd (&acc)[3], const real2* __restrict__ psi, const real2* __restrict__ U, int Vh, int Us,
+                                real coef, bool adj) {
     cd h[3], u[9], chi[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) h[c] = coef * ld(psi + (size_t)c * Vh);
@@ -764,7 +765,7 @@ __device__ inline void stag_hop(cd (&acc)[3], const double2* __restrict__ psi, c
 }
 
 // eta_mu(n) = (-1)^(x_0+...+x_{mu-1}), global coordinates (local == global parity since extents/origins are even)
-__device__ inline double stag_eta(const int c[4], int mu) {
+__device__ inline real stag_eta(const int c[4], int mu) {
     int e = 0;
     for (int j = 0; j < mu; j++) e += c[j];
     return (e & 1) ? -1.0 : 1.0;
@@ -778,17 +779,17 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const int i = chunk * TB + threadIdx.x;
     const bool valid = i < k.g.Vh;
-    double nrm = 0.0;
+    real nrm = 0.0;
     if (valid) {
         Nbr n;
         int c[4];
         neighbours(k.g, p, i, n, c);
         cd acc[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
-        const double2* __restrict__ psi = k.in[1 - p];
+        const real2* __restrict__ psi = k.in[1 - p];
         const int Us = glink_stride(k.g);
 #pragma unroll
         for (int mu = 0; mu < 4; mu++) {
-            const double eta = stag_eta(c, mu);
+            const real eta = stag_eta(c, mu);
             if (n.sf[mu] != 0.0) stag_hop(acc, psi + sp_off(3, n.fwd[mu]), k.gauge + glink_off(k.g, p, mu, i), Vh, Us, eta * n.sf[mu], false);
             if (n.sb[mu] != 0.0) stag_hop(acc, psi + sp_off(3, n.bwd[mu]), k.gauge + glink_off(k.g, 1 - p, mu, n.bwd[mu]), Vh, Us, -eta * n.sb[mu], true);
         }
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
 // colour component each.  Same reasoning as wilson_dirsplit: short-lived, phase-aligned waves keep the 2x link and 8x
 // spinor re-use inside the L2 residency time, and the XCD tile sweep of map_block applies to 64-site chunks.
 __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
-    __shared__ double2 part[4][3][64];
+    __shared__ real2 part[4][3][64];
     __shared__ double red[4];
     if (upd_done(k)) return;
     int chunk, p;
@@ -827,22 +828,22 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         Nbr n;
         int c[4];
         neighbours(k.g, p, i, n, c);
-        const double2* __restrict__ psi = k.in[1 - p];
+        const real2* __restrict__ psi = k.in[1 - p];
         const int Us = glink_stride(k.g);
-        const double eta = stag_eta(c, w);
+        const real eta = stag_eta(c, w);
         const int nf = w == 0 ? n.fwd[0] : w == 1 ? n.fwd[1] : w == 2 ? n.fwd[2] : n.fwd[3];
         const int nb = w == 0 ? n.bwd[0] : w == 1 ? n.bwd[1] : w == 2 ? n.bwd[2] : n.bwd[3];
-        const double sf = w == 0 ? n.sf[0] : w == 1 ? n.sf[1] : w == 2 ? n.sf[2] : n.sf[3];
-        const double sb = w == 0 ? n.sb[0] : w == 1 ? n.sb[1] : w == 2 ? n.sb[2] : n.sb[3];
+        const real sf = w == 0 ? n.sf[0] : w == 1 ? n.sf[1] : w == 2 ? n.sf[2] : n.sf[3];
+        const real sb = w == 0 ? n.sb[0] : w == 1 ? n.sb[1] : w == 2 ? n.sb[2] : n.sb[3];
         if (sf != 0.0) stag_hop(acc, psi + sp_off(3, nf), k.gauge + glink_off(k.g, p, w, i), Vh, Us, eta * sf, false);
         if (sb != 0.0) stag_hop(acc, psi + sp_off(3, nb), k.gauge + glink_off(k.g, 1 - p, w, nb), Vh, Us, -eta * sb, true);
     }
 #pragma unroll
-    for (int j = 0; j < 3; j++) part[w][j][lane] = make_double2(acc[j].re, acc[j].im);
+    for (int j = 0; j < 3; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
     __syncthreads();
-    double nrm = 0.0;
+    real nrm = 0.0;
     if (valid && w < 3) {
-        const double2 s0 = part[0][w][lane], s1 = part[1][w][lane], s2 = part[2][w][lane], s3 = part[3][w][lane];
+        const real2 s0 = part[0][w][lane], s1 = part[1][w][lane], s2 = part[2][w][lane], s3 = part[3][w][lane];
         cd v = k.b * mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
         emit(k, p, (size_t)w * Vh + sp_off(3, i), v, nrm);
@@ -876,9 +877,9 @@ __device__ inline void wilson_pack_dir(const HArgs& k, int side) {
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
     const int i = coords_to_cb(g, c);
-    const double2* __restrict__ psi = (ps ? k.in[1] : k.in[0]) + sp_off(12, i);
+    const real2* __restrict__ psi = (ps ? k.in[1] : k.in[0]) + sp_off(12, i);
     cd h0[3], h1[3];
-    double2* dst;
+    real2* dst;
     if (side == 0) {
         // receiver forward hop uses (1 - SF gamma), SF = dagger ? -1 : +1
         if (k.dagger) project<MU, -1>(h0, h1, psi, Vh); else project<MU, 1>(h0, h1, psi, Vh);
@@ -925,8 +926,8 @@ __device__ __forceinline__ void wilson_ext_add(cd (&acc)[12], const HArgs& k, co
     if (c[NU] == g.L[NU] - 1) {
         // forward hop at the upper face: ghost = P psi(n+nu) from the +nu neighbour; multiply by own U_nu(n)
         const int f = coords_to_face(g, NU, c);
-        const double2* __restrict__ src = k.recv_fwd[NU] + (size_t)slot * 6 * Fh + f;
-        const double sg = k.sign_fwd[NU];
+        const real2* __restrict__ src = k.recv_fwd[NU] + (size_t)slot * 6 * Fh + f;
+        const real sg = k.sign_fwd[NU];
         cd h0[3], h1[3], u[9], x0[3], x1[3];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
@@ -941,8 +942,8 @@ __device__ __forceinline__ void wilson_ext_add(cd (&acc)[12], const HArgs& k, co
     if (c[NU] == 0) {
         // backward hop at the lower face: ghost = U^+ P psi(n-nu) from the -nu neighbour
         const int f = coords_to_face(g, NU, c);
-        const double2* __restrict__ src = k.recv_bwd[NU] + (size_t)slot * 6 * Fh + f;
-        const double sg = k.sign_bwd[NU];
+        const real2* __restrict__ src = k.recv_bwd[NU] + (size_t)slot * 6 * Fh + f;
+        const real sg = k.sign_bwd[NU];
         cd h0[3], h1[3];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
@@ -966,7 +967,7 @@ __device__ inline bool ext_not_owner(const Geom& g, const int (&c)[4], int side)
 }
 
 template <int MU, bool DAG>
-__device__ __forceinline__ double wilson_ext_face(const HArgs& k, int side) {
+__device__ __forceinline__ real wilson_ext_face(const HArgs& k, int side) {
     const Geom& g = k.g;
     if (!g.part[MU]) return 0.0;
     const int Fh = g.Vh / g.L[MU], Vh = sp_stride(g);
@@ -986,13 +987,13 @@ __device__ __forceinline__ double wilson_ext_face(const HArgs& k, int side) {
     if (MU <= 1) wilson_ext_add<1, DAG>(acc, k, c, slot, pout, i);
     if (MU <= 2) wilson_ext_add<2, DAG>(acc, k, c, slot, pout, i);
     wilson_ext_add<3, DAG>(acc, k, c, slot, pout, i);
-    const double coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
-    double2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp_off(12, i);
-    double corr = 0.0;
+    const real coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
+    real2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp_off(12, i);
+    real corr = 0.0;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
         cd v = ld(o + (size_t)j * Vh);
-        const double before = v.re * v.re + v.im * v.im;
+        const real before = v.re * v.re + v.im * v.im;
         v.re = fma(coef, acc[j].re, v.re);
         v.im = fma(coef, acc[j].im, v.im);
         corr += (v.re * v.re + v.im * v.im) - before;
@@ -1002,7 +1003,7 @@ __device__ __forceinline__ double wilson_ext_face(const HArgs& k, int side) {
 }
 
 // block-level sum of the per-thread norm corrections of an exterior kernel (128 threads)
-__device__ inline void ext_partial(const HArgs& k, double corr) {
+__device__ inline void ext_partial(const HArgs& k, real corr) {
     if (!k.norm_partial) return;
     __shared__ double red[2];
 #pragma unroll
@@ -1016,7 +1017,7 @@ template <bool DAG>
 __global__ __launch_bounds__(128) void wilson_exterior(HArgs k) {
     if (k.upd_scal && k.upd_scal[S_DONE] != 0.0) return;
     const int side = blockIdx.y & 1;
-    double corr;
+    real corr;
     switch (blockIdx.y >> 1) {
     case 0: corr = wilson_ext_face<0, DAG>(k, side); break;
     case 1: corr = wilson_ext_face<1, DAG>(k, side); break;
@@ -1045,7 +1046,7 @@ __device__ inline void staggered_pack_dir(const HArgs& k, int side) {
     cd h[3];
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) h[cc] = ld((ps ? k.in[1] : k.in[0]) + sp_off(3, i) + (size_t)cc * Vh);
-    double2* dst;
+    real2* dst;
     if (side == 0) {
         dst = k.send_bwd[MU];
     } else {
@@ -1079,11 +1080,11 @@ __device__ __forceinline__ void staggered_ext_add(cd (&acc)[3], const HArgs& k, 
     int e = 0;
 #pragma unroll
     for (int j = 0; j < NU; j++) e += c[j];
-    const double eta = (e & 1) ? -1.0 : 1.0;
+    const real eta = (e & 1) ? -1.0 : 1.0;
     if (c[NU] == g.L[NU] - 1) {
         const int f = coords_to_face(g, NU, c);
-        const double2* src = k.recv_fwd[NU] + (size_t)slot * 3 * Fh + f;
-        const double cf = eta * k.sign_fwd[NU];
+        const real2* src = k.recv_fwd[NU] + (size_t)slot * 3 * Fh + f;
+        const real cf = eta * k.sign_fwd[NU];
         cd h[3], u[9], x[3];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) h[cc] = cf * ld(src + (size_t)cc * Fh);
@@ -1094,15 +1095,15 @@ __device__ __forceinline__ void staggered_ext_add(cd (&acc)[3], const HArgs& k, 
     }
     if (c[NU] == 0) {
         const int f = coords_to_face(g, NU, c);
-        const double2* src = k.recv_bwd[NU] + (size_t)slot * 3 * Fh + f;
-        const double cf = -eta * k.sign_bwd[NU];
+        const real2* src = k.recv_bwd[NU] + (size_t)slot * 3 * Fh + f;
+        const real cf = -eta * k.sign_bwd[NU];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) acc[cc] = acc[cc] + cf * ld(src + (size_t)cc * Fh);
     }
 }
 
 template <int MU>
-__device__ inline double staggered_ext_face(const HArgs& k, int side) {
+__device__ inline real staggered_ext_face(const HArgs& k, int side) {
     const Geom& g = k.g;
     if (!g.part[MU]) return 0.0;
     const int Fh = g.Vh / g.L[MU], Vh = sp_stride(g);
@@ -1120,13 +1121,13 @@ __device__ inline double staggered_ext_face(const HArgs& k, int side) {
     if (MU <= 1) staggered_ext_add<1>(acc, k, c, slot, pout, i);
     if (MU <= 2) staggered_ext_add<2>(acc, k, c, slot, pout, i);
     staggered_ext_add<3>(acc, k, c, slot, pout, i);
-    const double coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
-    double2* o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp_off(3, i);
-    double corr = 0.0;
+    const real coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
+    real2* o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp_off(3, i);
+    real corr = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         cd v = ld(o + (size_t)j * Vh);
-        const double before = v.re * v.re + v.im * v.im;
+        const real before = v.re * v.re + v.im * v.im;
         v.re = fma(coef, acc[j].re, v.re);
         v.im = fma(coef, acc[j].im, v.im);
         corr += (v.re * v.re + v.im * v.im) - before;
@@ -1138,7 +1139,7 @@ __device__ inline double staggered_ext_face(const HArgs& k, int side) {
 __global__ __launch_bounds__(128) void staggered_exterior(HArgs k) {
     if (k.upd_scal && k.upd_scal[S_DONE] != 0.0) return;
     const int side = blockIdx.y & 1;
-    double corr;
+    real corr;
     switch (blockIdx.y >> 1) {
     case 0: corr = staggered_ext_face<0>(k, side); break;
     case 1: corr = staggered_ext_face<1>(k, side); break;
@@ -1152,8 +1153,8 @@ __global__ __launch_bounds__(128) void staggered_exterior(HArgs k) {
 static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     KArgs k;
     k.g = c->geom;
-    k.gauge = s.gauge;
-    for (int p = 0; p < 2; p++) { k.out[p] = s.out[p]; k.in[p] = s.in[p]; k.xin[p] = s.xin[p]; }
+    k.gauge = (const real2*)s.gauge;
+    for (int p = 0; p < 2; p++) { k.out[p] = (real2*)s.out[p]; k.in[p] = (const real2*)s.in[p]; k.xin[p] = (const real2*)s.xin[p]; }
     k.a = s.a; k.b = s.b; k.r = s.r;
     k.parity_mode = s.parity_mode;
     const int chunks = (c->geom.Vh + TB - 1) / TB;
@@ -1177,11 +1178,11 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.d_ty = make_fastdiv(std::max(1, k.ty));
     k.norm_partial = s.norm_partial;
     k.upd_scal = s.upd_scal;
-    k.upd[0] = s.upd[0]; k.upd[1] = s.upd[1];
+    k.upd[0] = (real2*)s.upd[0]; k.upd[1] = (real2*)s.upd[1];
     return k;
 }
 
-static bool use_dirsplit(lqcd_ctx_s* c, int kind, double r) {   // variants 1/2/3 work on 64-site chunks
+static bool use_dirsplit(lqcd_ctx_s* c, int kind, real r) {   // variants 1/2/3 work on 64-site chunks
     if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 3)) return false;
     return kind == LQCD_STAGGERED || r == 1.0;   // Wilson: the split kernels use the r = 1 projectors
 }
@@ -1192,13 +1193,6 @@ static int persist_grid(lqcd_ctx_s* c, int nvirt) {
     return std::min(g, nvirt);
 }
 
-// number of |.|^2 block partials the interior kernel writes
-int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
-    const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
-    const int nvirt = ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
-    if (use_dirsplit(c, kind, r) && kind == LQCD_WILSON && c->tun.dslash_variant == 3) return persist_grid(c, nvirt);
-    return nvirt;
-}
 
 template <int TB>
 static int launch_interior_tb(lqcd_ctx_s* c, const StencilCall& s) {
@@ -1254,30 +1248,25 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
 }
 
 static int max_face_threads(lqcd_ctx_s* c, int parity_mode);
-// interior block partials + (partitioned lattice) the exterior kernel's correction partials
-int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
-    const int nt = max_face_threads(c, parity_mode);
-    return stencil_num_blocks(c, kind, r, parity_mode) + (nt > 0 ? ((nt + 127) / 128) * 8 : 0);
-}
 
 static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
     HArgs h;
     h.g = c->geom;
-    h.gauge = s.gauge;
-    for (int p = 0; p < 2; p++) { h.out[p] = s.out[p]; h.in[p] = s.in[p]; }
+    h.gauge = (const real2*)s.gauge;
+    for (int p = 0; p < 2; p++) { h.out[p] = (real2*)s.out[p]; h.in[p] = (const real2*)s.in[p]; }
     h.b = s.b;
     h.parity_mode = s.parity_mode;
     h.dagger = s.dagger;
     for (int mu = 0; mu < 4; mu++) {
-        h.send_fwd[mu] = c->send_fwd[mu]; h.send_bwd[mu] = c->send_bwd[mu];
-        h.recv_fwd[mu] = c->recv_fwd[mu]; h.recv_bwd[mu] = c->recv_bwd[mu];
+        h.send_fwd[mu] = (real2*)c->send_fwd[mu]; h.send_bwd[mu] = (real2*)c->send_bwd[mu];
+        h.recv_fwd[mu] = (const real2*)c->recv_fwd[mu]; h.recv_bwd[mu] = (const real2*)c->recv_bwd[mu];
         h.sign_fwd[mu] = (c->coord[mu] == c->pe[mu] - 1) ? c->geom.bc_fwd[mu] : 1.0;
         h.sign_bwd[mu] = (c->coord[mu] == 0) ? c->geom.bc_bwd[mu] : 1.0;
     }
     h.norm_partial = s.norm_partial;
     h.partial_offset = stencil_num_blocks(c, s.kind, s.r, s.parity_mode);   // corrections are appended to the interior's partials
     h.upd_scal = s.upd_scal;
-    h.upd[0] = s.upd[0]; h.upd[1] = s.upd[1];
+    h.upd[0] = (real2*)s.upd[0]; h.upd[1] = (real2*)s.upd[1];
     return h;
 }
 
@@ -1312,5 +1301,23 @@ int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
+
+}  // inline namespace (precision)
+
+#ifndef LQCD_F32
+// precision-independent launch geometry (shared by both builds of this file)
+// number of |.|^2 block partials the interior kernel writes
+int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
+    const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
+    const int nvirt = ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
+    if (use_dirsplit(c, kind, r) && kind == LQCD_WILSON && c->tun.dslash_variant == 3) return persist_grid(c, nvirt);
+    return nvirt;
+}
+// interior block partials + (partitioned lattice) the exterior kernel's correction partials
+int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
+    const int nt = max_face_threads(c, parity_mode);
+    return stencil_num_blocks(c, kind, r, parity_mode) + (nt > 0 ? ((nt + 127) / 128) * 8 : 0);
+}
+#endif
 
 }  // namespace lqcd

@@ -307,6 +307,18 @@ def solve_DinvX_(y, A, x, return_info=False):
     return (it.value, rr.value) if return_info else None
 
 
+def solve_mixed_DinvX_(y, A, x, inner_tol=1e-4, return_info=False):
+    """Mixed-precision variant of solve_DinvX!(y, A::DdagD_operator, x): fp32 inner CG, fp64 defect correction; y holds the
+    initial guess; the stopping rule real(r.r) < eps_CG is enforced on the true fp64 residual.
+    return_info -> (total inner iterations, outer steps, true |r|^2)."""
+    if not isinstance(A, DdagD_operator):
+        raise LQCDError(_l.ERR_ARG, "solve_mixed_DinvX_ needs a DdagD_operator")
+    it, out, rr = C.c_int(0), C.c_int(0), C.c_double(0)
+    check(_l.lib().lqcd_solve_mixed_cg_DdagD(A.D._h, y._h, x._h, C.c_double(A.eps_CG), A.MaxCGstep, C.c_double(inner_tol), C.byref(it),
+                                             C.byref(out), C.byref(rr)))
+    return (it.value, out.value, rr.value) if return_info else None
+
+
 def shiftedcg(vec_x, vec_beta, x, A, b, eps=None, maxsteps=None, return_info=False):
     """shiftedcg(vec_x, vec_β, x, A, b): (A + β_j) vec_x[j] = b for every shift and A x = b, A = D'D (RHMC; README.md:132).
     Zero initial guesses; raises NotConverged after maxsteps."""

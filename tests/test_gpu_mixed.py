@@ -1,0 +1,141 @@
+"""GPU parity of the mixed-precision CG (fp32 inner solver through the fp32 build of the stencil, fp64 defect correction).
+The contract is the fp64 one: the returned x satisfies |b - D^+D x|^2 < eps with the residual recomputed independently in
+fp64, and x equals the oracle's fp64 CG solution to the solver tolerance (1e-9 relative)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+KAPPA, MASS = 0.141139, 0.5
+BC = (1, 1, 1, -1)
+
+
+@pytest.fixture(scope="module")
+def gpu(lq):
+    assert lq.lib.device_count() > 0, "no HIP device visible: the product has no CPU fallback"
+    return lq
+
+
+def _setup(lq, orc, L, kind_name, seed, bc=BC, eps=1e-19):
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, seed)
+    Ud = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(Ud, None, {"Dirac_operator": kind_name, "κ": KAPPA, "mass": MASS, "boundarycondition": bc, "eps_CG": eps})
+    return lat, Uh, Ud, D
+
+
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+@pytest.mark.parametrize("L,bc", [((4, 4, 4, 8), BC), ((8, 4, 6, 4), (1, -1, 1, 1))])
+def test_mixed_cg_matches_oracle_fp64_solution(gpu, orc, kind_name, L, bc):
+    lq = gpu
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    okind = orc.WILSON if kind == lq.WILSON else orc.STAGGERED
+    km = KAPPA if kind == lq.WILSON else MASS
+    lat, Uh, Ud, D = _setup(lq, orc, L, kind_name, 101, bc)
+    b_h = orc.gaussian_spinor(lat.fermion_shape(kind), 102)
+    b = lq.Fermionfields(lat, kind).upload(b_h)
+    x = b.similar()
+    A = lq.DdagD_operator(D)
+    it, outer, rr = lq.solve_mixed_DinvX_(x, A, b, return_info=True)
+    assert rr < 1e-19 and outer >= 2          # more than one correction step is needed to get from fp32 to 1e-19
+    xo, ito, rro, st = orc.cg_DdagD(okind, Uh, b_h, L, km, 1.0, bc, eps=1e-19)
+    assert st == 0 and rel_err(x.download(), xo) < 1e-9
+    assert it < 3 * ito + 20                  # restarts cost iterations, but not many
+    # true residual recomputed with the fp64 operator, independently of the solver
+    r = b.similar()
+    lq.mul_(r, A, x)
+    lq.add_fermion_(r, -1.0, b)
+    assert lq.dot(r, r).real < 1e-19
+    # a good initial guess is used, not overwritten: restart from the solution -> zero outer steps
+    it2, outer2, rr2 = lq.solve_mixed_DinvX_(x, A, b, return_info=True)
+    assert outer2 == 0 and it2 == 0 and rr2 < 1e-19
+
+
+def test_mixed_cg_tight_and_loose_targets(gpu, orc):
+    lq = gpu
+    L = (8, 8, 8, 8)
+    for eps in (1e-8, 1e-24):
+        lat, Uh, Ud, D = _setup(lq, orc, L, "Wilson", 103, eps=eps)
+        b = lq.Fermionfields(lat, lq.WILSON)
+        lq.gauss_distribution_fermion_(b, 104)
+        x = b.similar()
+        A = lq.DdagD_operator(D)
+        it, outer, rr = lq.solve_mixed_DinvX_(x, A, b, return_info=True)
+        r = b.similar()
+        lq.mul_(r, A, x)
+        lq.add_fermion_(r, -1.0, b)
+        assert lq.dot(r, r).real < eps and rr < eps
+    # non-convergence raises like the fp64 solver
+    D.MaxCGstep = 3
+    A = lq.DdagD_operator(D)
+    lq.clear_fermion_(x)
+    with pytest.raises(lq.NotConverged):
+        lq.solve_mixed_DinvX_(x, A, b)
+    with pytest.raises(lq.LQCDError):
+        lq.solve_mixed_DinvX_(x, D, b)
+
+
+def test_mixed_cg_rccl_self_partition(gpu, orc):
+    """fp32 halos (pack / ncclFloat send-recv / exterior from the fp32 stencil build) on the real RCCL path, one GPU."""
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        from oracle import oracle as orc
+        L, K, BC = (8, 4, 6, 8), 0.141139, (1, 1, 1, -1)
+        lat = lq.Lattice(L)
+        lat.comm_init(lq.comm_unique_id())
+        U = orc.hot_gauge(L, 111)
+        Ud = lq.Gaugefields(lat).upload(U)
+        for name, kind, km in (("Wilson", lq.WILSON, K), ("Staggered", lq.STAGGERED, 0.5)):
+            D = lq.Dirac_operator(Ud, None, {"Dirac_operator": name, "κ": K, "mass": 0.5, "boundarycondition": BC, "eps_CG": 1e-19})
+            psi = orc.gaussian_spinor(lat.fermion_shape(kind), 112)
+            b = lq.Fermionfields(lat, kind).upload(psi)
+            x = b.similar()
+            it, outer, rr = lq.solve_mixed_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+            xo, ito, rro, st = orc.cg_DdagD(kind, U, psi, L, km, 1.0, BC, eps=1e-19)
+            assert st == 0 and rr < 1e-19 and np.abs(x.download() - xo).max() / np.abs(xo).max() < 1e-9, (name, it, outer, rr)
+        print("MIXED_SELF_OK")
+    """)
+    for mask in ("8", "14"):
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "MIXED_SELF_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_mixed_cg_full_size_is_faster_than_fp64(gpu):
+    """32^3x64 Wilson (BASELINE size): same true residual target, fewer milliseconds."""
+    import time
+    lq = gpu
+    L = (32, 32, 32, 64)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-16})
+    A = lq.DdagD_operator(D)
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    x = b.similar()
+    res = {}
+    for name, fn in (("fp64", lambda: lq.solve_DinvX_(x, A, b, return_info=True)), ("mixed", lambda: lq.solve_mixed_DinvX_(x, A, b, return_info=True))):
+        lq.clear_fermion_(x); fn()            # warm (allocations)
+        lq.clear_fermion_(x)
+        t0 = time.perf_counter(); info = fn(); dt = time.perf_counter() - t0
+        r = b.similar()
+        lq.mul_(r, A, x)
+        lq.add_fermion_(r, -1.0, b)
+        res[name] = (dt, info, lq.dot(r, r).real)
+        r.close()
+    print("fp64 %.1f ms %s true rr %.2e | mixed %.1f ms %s true rr %.2e" % (1e3 * res["fp64"][0], res["fp64"][1], res["fp64"][2],
+                                                                           1e3 * res["mixed"][0], res["mixed"][1], res["mixed"][2]))
+    assert res["mixed"][2] < 1e-16 and res["fp64"][2] < 2e-16
+    assert res["mixed"][0] < res["fp64"][0]
+    for o in (x, b, D, U):
+        o.close()
