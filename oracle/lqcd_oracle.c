@@ -663,3 +663,125 @@ void orc_staggered_force(double* Gd, const double* Ud, const double* Xd, const d
                     }
                 }
 }
+
+/* ------------------------------------------------------------------ gauge side of the MD step
+ * Reference callers: P_update!/U_update! src/md/AbstractMD.jl:78-118 (calc_dSdUmu!, Traceless_antihermitian_add!, exptU!),
+ * action bookkeeping S = p.p/2 - S_g/NC + S_f  src/updates/standardHMC.jl:49-56.  The packages that own those generics are
+ * not vendored, so the conventions below are this build's own, fixed by requiring dH/dtau = 0:
+ *   momenta P_mu(n): traceless anti-Hermitian 3x3 (link layout), kinetic term K = -sum tr P^2  (= p.p/2 for P = i p_a T_a);
+ *   links move as dU/dtau = P U  (U <- exp(dt P) U);
+ *   gauge action S_g = -(beta/3) sum_plaq Re tr U_p;
+ *   every force field G ("U dS/dU") is defined by dS/d eps [U -> exp(i eps T) U] = -2 Im tr(T G), so dS/dtau = 2 Re tr(P G)
+ *   and Hamilton's equation reads dP/dtau = TA(G), TA(G) = (G - G^+)/2 - tr(G - G^+)/6. */
+static void staple_sum(cplx A[3][3], const cplx* U, const int L[4], long V, const int c[4], int mu) {
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) A[a][b] = 0;
+    int w;
+    for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        cplx U1[3][3], U2[3][3], U3[3][3], T1[3][3], T2[3][3];
+        long s = site_of(L, c[0], c[1], c[2], c[3]);
+        long spm = neigh(L, c, mu, 1, &w), spn = neigh(L, c, nu, 1, &w), smn = neigh(L, c, nu, -1, &w);
+        /* upper: U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+ */
+        load_link(U1, U, V, nu, spm);
+        load_link(U2, U, V, mu, spn);
+        load_link(U3, U, V, nu, s);
+        mmd(T1, U1, U2);
+        mmd(T2, T1, U3);
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) A[a][b] += T2[a][b];
+        /* lower: U_nu(n+mu-nu)^+ U_mu(n-nu)^+ U_nu(n-nu) */
+        int cm[4] = {c[0], c[1], c[2], c[3]};
+        cm[nu] = (c[nu] - 1 + L[nu]) % L[nu];
+        long spmn = neigh(L, cm, mu, 1, &w);
+        load_link(U1, U, V, nu, spmn);
+        load_link(U2, U, V, mu, smn);
+        load_link(U3, U, V, nu, smn);
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                cplx t = 0;
+                for (int k = 0; k < 3; k++) t += conj(U1[k][a]) * conj(U2[b][k]);   /* (U1^+ U2^+)_{ab} */
+                T1[a][b] = t;
+            }
+        mm(T2, T1, U3);
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) A[a][b] += T2[a][b];
+    }
+}
+
+double orc_gauge_action(const double* Ud, const int L[4], double beta) {
+    return -beta * 6.0 * (double)vol(L) * orc_plaquette(Ud, L);
+}
+
+/* G_mu(n) = -(beta/6) U_mu(n) A_mu(n), A = sum of the six staples */
+void orc_gauge_force(double* Gd, const double* Ud, const int L[4], double beta) {
+    const cplx* U = (const cplx*)Ud;
+    cplx* G = (cplx*)Gd;
+    long V = vol(L);
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t};
+                    long s = site_of(L, x, y, z, t);
+                    for (int mu = 0; mu < 4; mu++) {
+                        cplx A[3][3], Um[3][3], T[3][3];
+                        staple_sum(A, U, L, V, c, mu);
+                        load_link(Um, U, V, mu, s);
+                        mm(T, Um, A);
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) G[UIDX(V, mu, s, a, b)] = -(beta / 6.0) * T[a][b];
+                    }
+                }
+}
+
+/* P += c * TA(G) on every link */
+void orc_momentum_add_ta(double* Pd, double cf, const double* Gd, const int L[4]) {
+    cplx* P = (cplx*)Pd;
+    const cplx* G = (const cplx*)Gd;
+    long V = vol(L);
+    for (int mu = 0; mu < 4; mu++)
+        for (long s = 0; s < V; s++) {
+            cplx M[3][3], tr = 0;
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) M[a][b] = 0.5 * (G[UIDX(V, mu, s, a, b)] - conj(G[UIDX(V, mu, s, b, a)]));
+            for (int a = 0; a < 3; a++) tr += M[a][a];
+            for (int a = 0; a < 3; a++) M[a][a] -= tr / 3.0;
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) P[UIDX(V, mu, s, a, b)] += cf * M[a][b];
+        }
+}
+
+/* K = - sum tr P^2 */
+double orc_momentum_action(const double* Pd, const int L[4]) {
+    const cplx* P = (const cplx*)Pd;
+    long V = vol(L);
+    double k = 0;
+    for (int mu = 0; mu < 4; mu++)
+        for (long s = 0; s < V; s++)
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) k -= creal(P[UIDX(V, mu, s, a, b)] * P[UIDX(V, mu, s, b, a)]);
+    return k;
+}
+
+/* U <- exp(dt P) U : Taylor series in Horner form (30 terms: exact to rounding for |dt P| < 4) */
+void orc_link_update(double* Ud, const double* Pd, double dt, const int L[4]) {
+    cplx* U = (cplx*)Ud;
+    const cplx* P = (const cplx*)Pd;
+    long V = vol(L);
+    for (int mu = 0; mu < 4; mu++)
+        for (long s = 0; s < V; s++) {
+            cplx X[3][3], E[3][3], T[3][3], Um[3][3];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) { X[a][b] = dt * P[UIDX(V, mu, s, a, b)]; E[a][b] = (a == b); }
+            for (int k = 30; k >= 1; k--) {      /* E = 1 + X E / k */
+                mm(T, X, E);
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) E[a][b] = (a == b ? 1.0 : 0.0) + T[a][b] / (double)k;
+            }
+            load_link(Um, U, V, mu, s);
+            mm(T, E, Um);
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) U[UIDX(V, mu, s, a, b)] = T[a][b];
+        }
+}

@@ -82,6 +82,15 @@ void orc_wilson_force(double* G, const double* U, const double* X, const double*
                       const int bc[4]);
 void orc_staggered_force(double* G, const double* U, const double* X, const double* Y, const int L[4], const int bc[4]);
 
+/* gauge side of the MD step (P_update!/U_update!, src/md/AbstractMD.jl:78-118; conventions: lqcd_oracle.c).
+ * Momenta P are traceless anti-Hermitian 3x3 matrices in the gauge layout; K = -sum tr P^2; dU/dtau = P U;
+ * S_g = -(beta/3) sum_plaq Re tr U_p; force fields G obey dS/d eps[U -> exp(i eps T)U] = -2 Im tr(T G); dP/dtau = TA(G). */
+double orc_gauge_action(const double* U, const int L[4], double beta);
+void orc_gauge_force(double* G, const double* U, const int L[4], double beta);      /* G = -(beta/6) U * staples */
+void orc_momentum_add_ta(double* P, double c, const double* G, const int L[4]);     /* P += c TA(G) */
+double orc_momentum_action(const double* P, const int L[4]);                        /* K = -sum tr P^2 */
+void orc_link_update(double* U, const double* P, double dt, const int L[4]);        /* U <- exp(dt P) U */
+
 /* fixed-length CG window with the exit test disabled (timing only): runs exactly niter iterations */
 void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4],
                         double kappa_or_mass, double r, const int bc[4], int niter);

@@ -37,6 +37,8 @@ def lib():
         _LIB.orc_plaquette.restype = C.c_double
         _LIB.orc_unitarity_dev.restype = C.c_double
         _LIB.orc_fermi_action.restype = C.c_double
+        _LIB.orc_gauge_action.restype = C.c_double
+        _LIB.orc_momentum_action.restype = C.c_double
     return _LIB
 
 
@@ -149,6 +151,49 @@ def fermion_force(kind, U, X, Y, L, km, r=1.0, bc=(1, 1, 1, -1)):
     else:
         lib().orc_staggered_force(_p(G), _p(U), _p(X), _p(Y), _i4(L), _i4(bc))
     return G
+
+
+def gauge_action(U, L, beta):
+    return lib().orc_gauge_action(_p(U), _i4(L), C.c_double(beta))
+
+
+def gauge_force(U, L, beta):
+    G = np.zeros(gauge_shape(L), dtype=np.complex128)
+    lib().orc_gauge_force(_p(G), _p(U), _i4(L), C.c_double(beta))
+    return G
+
+
+def momentum_add_ta(P, c, G, L):
+    lib().orc_momentum_add_ta(_p(P), C.c_double(c), _p(G), _i4(L))
+    return P
+
+
+def momentum_action(P, L):
+    return lib().orc_momentum_action(_p(P), _i4(L))
+
+
+def link_update(U, P, dt, L):
+    lib().orc_link_update(_p(U), _p(P), C.c_double(dt), _i4(L))
+    return U
+
+
+GELLMANN = np.zeros((8, 3, 3), dtype=np.complex128)
+GELLMANN[0][0, 1] = GELLMANN[0][1, 0] = 1
+GELLMANN[1][0, 1] = -1j; GELLMANN[1][1, 0] = 1j
+GELLMANN[2][0, 0] = 1; GELLMANN[2][1, 1] = -1
+GELLMANN[3][0, 2] = GELLMANN[3][2, 0] = 1
+GELLMANN[4][0, 2] = -1j; GELLMANN[4][2, 0] = 1j
+GELLMANN[5][1, 2] = GELLMANN[5][2, 1] = 1
+GELLMANN[6][1, 2] = -1j; GELLMANN[6][2, 1] = 1j
+GELLMANN[7] = np.diag([1, 1, -2]) / np.sqrt(3)
+
+
+def gaussian_momenta(L, seed):
+    """P = i sum_a pi_a lambda_a / 2 with pi_a ~ N(0,1): K = -sum tr P^2 = sum pi_a^2 / 2.  Oracle layout [.., b, a]."""
+    rng = np.random.default_rng(seed)
+    pi = rng.standard_normal((4, L[3], L[2], L[1], L[0], 8))
+    P = 1j * np.einsum("...a,aij->...ij", pi, GELLMANN / 2)          # [.., a, b]
+    return np.ascontiguousarray(np.swapaxes(P, -1, -2))
 
 
 def bicgstab(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000, x0=None):
