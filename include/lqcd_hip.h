@@ -166,6 +166,18 @@ int lqcd_mdom_fermion_force(int n, lqcd_op_t* ops, lqcd_gauge_t* outs, lqcd_spin
 /* calc_UdSfdU! in one call: solve, Y = D X and the sweep, all resident; Sf and iters may be NULL */
 int lqcd_calc_UdSfdU(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t eta, double eps, int maxiter, double* Sf, int* iters);
 
+/* ---------------------------------------------------------------- gauge side of the MD step
+ * Momenta are traceless anti-Hermitian 3x3 matrices held in a gauge-shaped field (lqcd_gauge_create).  Conventions (fixed by
+ * dH/dtau = 0, tested): K = -sum tr P^2 (= p.p/2 for P = i p_a T_a); dU/dtau = P U; S_g = -(beta/3) sum_plaq Re tr U_p; every
+ * force field G ("U dS/dU") obeys dS/d eps[U -> exp(i eps T) U] = -2 Im tr(T G), so dP/dtau = TA(G). */
+int lqcd_gauge_copy(lqcd_gauge_t dst, lqcd_gauge_t src);                  /* substitute_U!(Uold, U) (src/updates/standardHMC.jl:45) */
+int lqcd_gauge_action(lqcd_gauge_t U, double beta, double* Sg);          /* -evaluate_GaugeAction/NC (standardHMC.jl:50) */
+int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta);     /* calc_dSdUmu! + mul!(temp, U, dSdUmu) (src/md/AbstractMD.jl:108-109): -(beta/6) U * staples; single-GPU contexts */
+int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t G); /* Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131) */
+int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U */
+int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed);               /* gauss_distribution!(p) (src/md/standardMD.jl:86); keyed by GLOBAL site */
+int lqcd_momentum_action(lqcd_gauge_t P, double* K);                     /* p.p/2 (standardHMC.jl:49) */
+
 /* benchmarking window: exactly niter CG iterations, exit test disabled (SURVEY.md 8(d) timing protocol) */
 int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int niter);
 

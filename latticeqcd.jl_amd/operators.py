@@ -347,8 +347,11 @@ class FermiAction:
 
 
 def gauss_sampling_in_action_(xi, U, fa, randomseed=112):
-    """gauss_sampling_in_action!(xi, U, fa) (standardMD.jl:95): xi ~ N(0,1) complex, unit variance per complex component."""
+    """gauss_sampling_in_action!(xi, U, fa) (standardMD.jl:95): xi distributed as exp(-xi'xi), i.e. <|xi_i|^2> = 1 (re and im
+    of variance 1/2) -- NOT the unit-variance-per-real-part noise of gauss_distribution_fermion_; with the wrong variance the
+    pseudofermion weight is exp(-S_f/2) and the HMC equilibrates to the wrong plaquette (tests/test_gpu_md.py)."""
     gauss_distribution_fermion_(xi, randomseed)
+    check(_l.lib().lqcd_scale(C.c_double(np.sqrt(0.5)), C.c_double(0.0), xi._h))
     return xi
 
 
@@ -379,6 +382,51 @@ def fermion_force_(UdSfdU, D, X, Y):
     """The outer-product sweep alone, from resident X = (D'D)^-1 eta and Y = D X."""
     check(_l.lib().lqcd_fermion_force(D._h, UdSfdU._h, X._h, Y._h))
     return UdSfdU
+
+
+# ------------------------------------------------------------------------------------ gauge side of the MD step
+def substitute_U_(dst, src):
+    """substitute_U!(Uold, U) (standardHMC.jl:45)."""
+    check(_l.lib().lqcd_gauge_copy(dst._h, src._h))
+    return dst
+
+
+def evaluate_GaugeAction(U, beta):
+    """S_g = -(beta/3) sum_plaq Re tr U_p  (the '-evaluate_GaugeAction/NC' of standardHMC.jl:50)."""
+    s = C.c_double(0)
+    check(_l.lib().lqcd_gauge_action(U._h, C.c_double(beta), C.byref(s)))
+    return s.value
+
+
+def gauge_force_(G, U, beta):
+    """calc_dSdUmu! followed by mul!(temp, U, dSdUmu) (AbstractMD.jl:108-109): G = -(beta/6) U * staples."""
+    check(_l.lib().lqcd_gauge_force(G._h, U._h, C.c_double(beta)))
+    return G
+
+
+def Traceless_antihermitian_add_(p, factor, G):
+    """Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131)."""
+    check(_l.lib().lqcd_momentum_add_ta(p._h, C.c_double(factor), G._h))
+    return p
+
+
+def U_update_(U, p, dt):
+    """U_update!(U, p, eps, md) (AbstractMD.jl:78-97): U <- exp(dt p) U."""
+    check(_l.lib().lqcd_gauge_exp_update(U._h, C.c_double(dt), p._h))
+    return U
+
+
+def gauss_distribution_(p, randomseed=114):
+    """gauss_distribution!(md.p) (standardMD.jl:86)."""
+    check(_l.lib().lqcd_momentum_gaussian(p._h, C.c_uint64(randomseed)))
+    return p
+
+
+def momentum_action(p):
+    """md.p * md.p / 2 (standardHMC.jl:49)."""
+    k = C.c_double(0)
+    check(_l.lib().lqcd_momentum_action(p._h, C.byref(k)))
+    return k.value
 
 
 # ------------------------------------------------------------------------------------ timing helpers (bench.py)

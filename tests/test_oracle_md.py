@@ -92,3 +92,47 @@ def test_energy_conservation_and_reversibility(orc, lq, dynamical):
     assert 3.0 < abs(dH[0] / dH[1]) < 5.0                       # 4 for a second-order integrator
     U2, P2 = _leapfrog(orc, U1, -P1, L, beta, 0.025, 20, eta)
     assert np.abs(U2 - U).max() < 1e-9 and np.abs(P2 + P).max() < 1e-9
+
+
+def test_oracle_hmc_repeats_the_reference_wilson_test(orc, lq):
+    """Pins the ORACLE chain (Dslash, CG, fermion force, gauge force, integrator) to the reference's own end-to-end golden:
+    test/runtests.jl:88-99 with test/test_wilson.toml -- start from the reference's thermalised 4^4 configuration, beta = 5.7,
+    kappa = 0.141139, dtau = 0.05, 20 MD steps, Sexton-Weingarten N = 10, Nsteps = 10 trajectories; the final plaquette must be
+    within 10 % of test/debugplaqdata.txt line 7.  (The criterion is loose but not empty: tests/test_gpu_md.py shows that a
+    pseudofermion weight of exp(-S_f/2) fails it.)"""
+    import os
+    from conftest import GOLDEN
+    L, beta, dtau, mdsteps, nsw = (4, 4, 4, 4), 5.7, 0.05, 20, 10
+    ref_plaq = 0.5784043949012552                                   # /root/reference/test/debugplaqdata.txt:7
+    U = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L)
+    rng = np.random.default_rng(111)
+    dHs, acc = [], 0
+
+    def Sf_and_force(U, eta, want_force=True):
+        S, X, Y, it, st = orc.fermi_action(orc.WILSON, U, eta, L, KAPPA, bc=BC, eps=1e-19)
+        assert st == 0
+        return S, (orc.fermion_force(orc.WILSON, U, X, Y, L, KAPPA, bc=BC) if want_force else None)
+
+    for traj in range(10):
+        Uold = U.copy()
+        P = orc.gaussian_momenta(L, 1000 + traj)
+        xi = orc.gaussian_spinor(orc.wilson_shape(L), 2000 + traj) * np.sqrt(0.5)     # exp(-xi'xi): <|xi_i|^2> = 1
+        eta = orc.wilson_D(U, xi, L, KAPPA, 1.0, BC, dagger=True)
+        Hold = orc.momentum_action(P, L) + orc.gauge_action(U, L, beta) + np.vdot(xi, xi).real
+        for _ in range(mdsteps):                                                      # runMD_QPQ_sw! (standardMD.jl:146-166)
+            for half in range(2):
+                for _ in range(nsw // 2):
+                    orc.link_update(U, P, 0.5 / nsw * dtau, L)
+                    orc.momentum_add_ta(P, dtau / nsw, orc.gauge_force(U, L, beta), L)
+                    orc.link_update(U, P, 0.5 / nsw * dtau, L)
+                if half == 0:
+                    orc.momentum_add_ta(P, dtau, Sf_and_force(U, eta)[1], L)
+        Hnew = orc.momentum_action(P, L) + orc.gauge_action(U, L, beta) + Sf_and_force(U, eta, False)[0]
+        dHs.append(Hnew - Hold)
+        if np.exp(-(Hnew - Hold)) >= rng.random():
+            acc += 1
+        else:
+            U = Uold
+    plaq = orc.plaquette(U, L)
+    assert abs(plaq - ref_plaq) / ref_plaq < 0.1, (plaq, dHs)
+    assert acc >= 6 and np.abs(dHs).max() < 2.0, (acc, dHs)
