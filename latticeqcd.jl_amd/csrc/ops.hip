@@ -346,11 +346,34 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     if (st == LQCD_OK) st = cg_setup(op, x, b, w, fixed ? -1.0 : eps, &rr);
     if (st == LQCD_OK && !fixed && rr < eps) converged = true;
     const int check_every = 8;
+    // tunable "graph": a burst of check_every iterations is captured once into a hipGraph and replayed -- one launch per
+    // burst instead of 5 per iteration.  Pays on launch-bound (small) lattices; single-stream (unpartitioned) contexts only.
+    const bool use_graph = c->tun.graph != 0 && !any_partitioned(c);
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
     while (st == LQCD_OK && !converged && it < maxiter) {
         int burst = std::min(check_every, maxiter - it);
-        if (fixed) burst = maxiter - it;
-        for (int k = 0; k < burst && st == LQCD_OK; k++) st = cg_enqueue_iteration(op, x, w);
+        if (fixed && !use_graph) burst = maxiter - it;
+        if (use_graph && burst == check_every) {
+            if (!gexec) {
+                hipError_t ge = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+                if (ge != hipSuccess) { st = hip_fail(ge, "hipStreamBeginCapture", __FILE__, __LINE__); break; }
+                for (int k = 0; k < burst && st == LQCD_OK; k++) st = cg_enqueue_iteration(op, x, w);
+                ge = hipStreamEndCapture(c->stream, &graph);
+                if (st == LQCD_OK && ge != hipSuccess) st = hip_fail(ge, "hipStreamEndCapture", __FILE__, __LINE__);
+                if (st == LQCD_OK) {
+                    ge = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+                    if (ge != hipSuccess) st = hip_fail(ge, "hipGraphInstantiate", __FILE__, __LINE__);
+                }
+                if (st != LQCD_OK) break;
+            }
+            hipError_t ge = hipGraphLaunch(gexec, c->stream);
+            if (ge != hipSuccess) { st = hip_fail(ge, "hipGraphLaunch", __FILE__, __LINE__); break; }
+        } else {
+            for (int k = 0; k < burst && st == LQCD_OK; k++) st = cg_enqueue_iteration(op, x, w);
+        }
         if (st != LQCD_OK) break;
+        if (fixed && use_graph && it + burst < maxiter) { it += burst; continue; }   // timing window: no readback between bursts
         hipError_t e = hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { st = hip_fail(e, "cg scalar readback", __FILE__, __LINE__); break; }
@@ -359,6 +382,8 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
         if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
         if (!std::isfinite(rr)) { set_error("CG: residual is not finite"); st = LQCD_ERR_NOT_CONVERGED; }
     }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
     scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
     if (iters) *iters = it;
     if (final_rr) *final_rr = rr;
