@@ -189,6 +189,18 @@ def substitute_fermion_(dst, src):
     check(_l.lib().lqcd_spinor_copy(dst._h, src._h))
 
 
+def extract_fermion_(half, full):
+    """half (EVEN|ODD subset) <- the sites of that parity of a FULL field."""
+    check(_l.lib().lqcd_spinor_extract(half._h, full._h))
+    return half
+
+
+def insert_fermion_(full, half):
+    """The sites of half's parity of a FULL field <- half (the other parity is left untouched)."""
+    check(_l.lib().lqcd_spinor_insert(full._h, half._h))
+    return full
+
+
 def gauss_distribution_fermion_(x, randomseed=112):
     check(_l.lib().lqcd_spinor_gaussian(x._h, C.c_uint64(int(randomseed))))
 
