@@ -149,6 +149,22 @@ def main():
                      "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc},
     }
 
+    # ---- secondary (outside the timed region, not part of `value`): time to solution r.r < 1e-16, fp64 CG vs mixed-precision CG
+    if world == 1 and not force_dist:
+        D.eps_CG = 1e-16
+        A = lq.DdagD_operator(D)
+        tts = {}
+        for name, fn in (("fp64", lambda: lq.solve_DinvX_(x, A, b, return_info=True)),
+                         ("mixed", lambda: lq.solve_mixed_DinvX_(x, A, b, return_info=True))):
+            lq.clear_fermion_(x); fn()                      # warm (work-space allocation)
+            lq.clear_fermion_(x); device_sync()
+            t0 = time.perf_counter(); info = fn(); device_sync()
+            tts[name] = (1e3 * (time.perf_counter() - t0), info)
+        out["time_to_solution_1e-16"] = {"fp64_cg_ms": tts["fp64"][0], "fp64_iters": tts["fp64"][1][0],
+                                         "mixed_cg_ms": tts["mixed"][0], "mixed_inner_iters": tts["mixed"][1][0],
+                                         "mixed_outer_steps": tts["mixed"][1][1], "mixed_true_rr": tts["mixed"][1][2],
+                                         "speedup": tts["fp64"][0] / tts["mixed"][0]}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
     if rank == 0:
