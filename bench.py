@@ -149,6 +149,19 @@ def main():
                      "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc},
     }
 
+    # ---- secondary (outside the timed region, not part of `value`): the opt-in 12-real link compression (rows 0,1 stored, row 2
+    # rebuilt; only for links unitary to 1e-14 -- the hot start is).  Same operator, 768 instead of 960 bytes moved per site.
+    if world == 1 and not force_dist:
+        lat.set_param("gauge_recon", 12)
+        ms12 = lq.bench_dslash(D, y, b, warm=20, reps=args.dslash_reps)
+        msi12 = lq.bench_cg(D, x, b, warm=5, niter=50)
+        out["gauge_recon12_optin"] = {"active": lat.get_param("recon_active"), "dslash_ms": ms12,
+                                      "dslash_gflops": WILSON_FLOP_PER_SITE * V / (ms12 * 1e-3) / 1e9,
+                                      "moved_bytes_per_site": 768, "moved_GBps": 768 * Vloc / (ms12 * 1e-3) / 1e9,
+                                      "frac_of_peak_by_960B_accounting": WILSON_BYTES_PER_SITE * Vloc / (ms12 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "cg_iters_per_s": 1e3 / msi12}
+        lat.set_param("gauge_recon", 18)
+
     # ---- secondary (outside the timed region, not part of `value`): time to solution r.r < 1e-16, fp64 CG vs mixed-precision CG
     if world == 1 and not force_dist:
         D.eps_CG = 1e-16

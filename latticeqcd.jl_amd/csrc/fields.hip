@@ -3,6 +3,8 @@
 // calculate_Plaquette -- call sites /root/reference/src/system/universe.jl:41-77, src/system/lqcd.jl:187-193.)
 #include "lqcd_internal.h"
 
+#include <cstring>
+
 namespace lqcd {
 
 // ------------------------------------------------------------------ gauge reorder
@@ -249,6 +251,7 @@ extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
     if (!g) return LQCD_OK;
     hipSetDevice(g->ctx->device);
     hipFree(g->data);
+    hipFree(g->data12);
     delete g;
     return LQCD_OK;
 }
@@ -264,6 +267,7 @@ static int gauge_xfer(lqcd_gauge_t g, double* host, int layout, int to_device) {
     int st = LQCD_OK;
     const int nt = 2 * c->geom.Vh;
     if (to_device) {
+        g->version++;
         hipError_t e = hipMemcpyAsync(img, host, bytes, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) st = hip_fail(e, "H2D gauge", __FILE__, __LINE__);
     }
@@ -292,6 +296,7 @@ extern "C" int lqcd_gauge_unit(lqcd_gauge_t g) {
     lqcd_ctx_s* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int nt = 2 * c->geom.Vh * 4;
+    g->version++;
     hipLaunchKernelGGL(gauge_unit, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, g->data);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -303,6 +308,7 @@ extern "C" int lqcd_gauge_hot_start(lqcd_gauge_t g, uint64_t seed) {
     lqcd_ctx_s* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int nt = 2 * c->geom.Vh * 4;
+    g->version++;
     hipLaunchKernelGGL(gauge_hot, dim3((nt + 127) / 128), dim3(128), 0, c->stream, c->geom, g->data, seed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -371,6 +377,46 @@ extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
 
 namespace lqcd {
 // device pointer of the parity block p of a spinor (nullptr if the spinor does not hold that parity)
+// 12-real copy of the links: rows 0 and 1; *maxdev receives max |row2 - conj(row0 x row1)| (as the bit pattern of a
+// non-negative double, which orders like an unsigned integer)
+__global__ void gauge_compress12(Geom g, const double2* __restrict__ src, double2* __restrict__ dst, unsigned long long* maxdev) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * g.Vh * 4) return;
+    const int mu = t & 3, s = t >> 2, p = s / g.Vh, i = s % g.Vh;
+    const size_t so = glink_off(g, p, mu, i), d_o = glink12_off(g, p, mu, i);
+    const int Gs = glink_stride(g);
+    cd u[9];
+    for (int e = 0; e < 9; e++) u[e] = ld(src + so + (size_t)e * Gs);
+    for (int e = 0; e < 6; e++) st(dst + d_o + (size_t)e * 64, u[e]);
+    double dev = 0.0;
+    for (int b = 0; b < 3; b++) {
+        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+        const cd x = cmul(u[b1], u[3 + b2]) - cmul(u[b2], u[3 + b1]);      // (row0 x row1)_b
+        dev = fmax(dev, fmax(fabs(u[6 + b].re - x.re), fabs(u[6 + b].im + x.im)));
+    }
+    atomicMax(maxdev, (unsigned long long)__double_as_longlong(dev));
+}
+
+int gauge_ensure_recon12(lqcd_gauge_s* g) {
+    if (g->version12 == g->version && g->data12) return LQCD_OK;
+    lqcd_ctx_s* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (!g->data12) HIPCHK(hipMalloc((void**)&g->data12, gauge12_elems(c->geom) * sizeof(double2)));
+    unsigned long long* d_dev = (unsigned long long*)(c->d_scal + SCAL_DOUBLES - 9);
+    HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(unsigned long long), c->stream));
+    const int nt = 2 * c->geom.Vh * 4;
+    hipLaunchKernelGGL(gauge_compress12, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, g->data, g->data12, d_dev);
+    HIPCHK(hipGetLastError());
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, d_dev, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double dev;
+    memcpy(&dev, &bits, sizeof(dev));
+    g->recon_ok = dev <= 1e-14;
+    g->version12 = g->version;
+    return LQCD_OK;
+}
+
 double2* spinor_block(lqcd_spinor_s* s, int p) {
     const size_t blk = (size_t)s->ncomp * s->ctx->geom.Vs;
     if (s->subset == LQCD_FULL) return s->data + p * blk;

@@ -299,6 +299,7 @@ int force_halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind) {
 int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
                          double r) {
     FArgs k = make_fargs(c, kind, U, out, X, Y, km, r);
+    out->version++;
     const int nb = 2 * c->geom.nch;
     if (kind == LQCD_WILSON) hipLaunchKernelGGL(wilson_force_kernel, dim3(nb), dim3(256), 0, c->stream, k);
     else hipLaunchKernelGGL(staggered_force_kernel, dim3(nb), dim3(256), 0, c->stream, k);

@@ -104,6 +104,10 @@ __host__ __device__ inline size_t glink_off(const Geom& g, int p, int mu, int i)
     return ((size_t)(p * 4 + mu) * 9) * g.Vs + i;
 #endif
 }
+__host__ __device__ inline size_t glink12_off(const Geom& g, int p, int mu, int i) {   // 12-real copy: [parity][chunk][mu][6][64]
+    return ((((size_t)p * g.nch + (size_t)(i >> 6)) * 4 + mu) * 6) * 64 + (i & 63);
+}
+__host__ __device__ inline size_t gauge12_elems(const Geom& g) { return (size_t)2 * g.nch * 24 * 64; }
 __host__ __device__ inline int glink_stride(const Geom& g) {   // distance between consecutive components of one link
 #if LQCD_GAUGE_AOSOA
     return 64;
@@ -231,6 +235,9 @@ struct Tunables {
     int xcd_ysplit = 4;       // remap 2: tile the sub-domains in (y,z) instead of plain z-slabs
     int xcd_nsub = 16;       // remap 2: sub-domains per t-slice (multiple of 8)
     int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)
+    int gauge_recon = 18;     // 12: the Wilson dirsplit kernel reads 2 rows per link and rebuilds the third (only for links that
+                              // are unitary to 1e-14; otherwise the 18-real field is used).  Opt-in: bytes/site 960 -> 768.
+    int recon_active = 0;     // read-only: 1 if the last Wilson operator application used the 12-real links
 };
 
 }  // namespace lqcd
@@ -267,8 +274,13 @@ struct lqcd_ctx_s {
 
 struct lqcd_gauge_s {
     lqcd_ctx_s* ctx;
-    double2* data;  // [2][4][9][Vh]
+    double2* data;  // [parity][chunk][mu][9][64]
     size_t elems;
+    uint64_t version = 1;        // bumped by every entry point that writes the field
+    // optional 12-real copy (rows 0 and 1 of every link, [parity][chunk][mu][6][64]) for the opt-in compressed Dslash
+    double2* data12 = nullptr;
+    uint64_t version12 = 0;      // version of `data` the copy was made from
+    bool recon_ok = false;       // row 2 == conj(row 0 x row 1) to 1e-14 on every link of that version
 };
 
 struct lqcd_spinor_s {
@@ -339,6 +351,7 @@ struct StencilCall {
     // scalar block (upd_scal[S_ALPHA]); the kernel is a no-op once upd_scal[S_DONE] is set.  q = D^+ D p is never written.
     const double* upd_scal = nullptr;
     double2* upd[2] = {nullptr, nullptr};
+    const double2* gauge12 = nullptr;   // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
     int prec = 0;                 // 0: fp64 fields, 1: fp32 fields (pointers are float2 data, see p32)
 };
 // slots of the device scalar block d_scal used by the solvers
@@ -387,6 +400,7 @@ int stream_grid(lqcd_ctx_s* c, size_t n);
 
 // fields.hip
 double2* spinor_block(lqcd_spinor_s* s, int p);
+int gauge_ensure_recon12(lqcd_gauge_s* g);   // (re)builds the 12-real copy if the field changed; sets g->recon_ok
 int plaquette_local_sum(lqcd_gauge_s* g, const double2* const ghost[4], double* sum);
 int gauge_pack_face(lqcd_gauge_s* g, int mu, double2* dst);
 

@@ -229,6 +229,7 @@ extern "C" int lqcd_gauge_copy(lqcd_gauge_t dst, lqcd_gauge_t src) {      // sub
     LQCHK(same_ctx(dst, src, "lqcd_gauge_copy"));
     lqcd_ctx_s* c = dst->ctx;
     HIPCHK(hipSetDevice(c->device));
+    dst->version++;
     HIPCHK(hipMemcpyAsync(dst->data, src->data, src->elems * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
@@ -253,6 +254,7 @@ extern "C" int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta) {
         return LQCD_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(c->device));
+    out->version++;
     hipLaunchKernelGGL(gauge_force_kernel, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, out->data, -beta / 6.0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -264,6 +266,7 @@ extern "C" int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t 
     LQCHK(same_ctx(P, G, "lqcd_momentum_add_ta"));
     lqcd_ctx_s* c = P->ctx;
     HIPCHK(hipSetDevice(c->device));
+    P->version++;
     hipLaunchKernelGGL(momentum_add_ta_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, P->data, factor, G->data);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -275,6 +278,7 @@ extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) 
     LQCHK(same_ctx(U, P, "lqcd_gauge_exp_update"));
     lqcd_ctx_s* c = U->ctx;
     HIPCHK(hipSetDevice(c->device));
+    U->version++;
     hipLaunchKernelGGL(link_exp_update_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -286,6 +290,7 @@ extern "C" int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed) {
     ARGCHK(P, "lqcd_momentum_gaussian: null argument");
     lqcd_ctx_s* c = P->ctx;
     HIPCHK(hipSetDevice(c->device));
+    P->version++;
     hipLaunchKernelGGL(momentum_gaussian_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, P->data, seed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -85,6 +85,17 @@ static void fill_blocks(const double2* dst[2], lqcd_spinor_s* s) {
     dst[1] = s ? spinor_block(s, 1) : nullptr;
 }
 
+// opt-in 12-real links for the Wilson r = 1 split kernel (tunable gauge_recon = 12): lazily (re)built, used only when every
+// link of the current field is unitary to 1e-14, otherwise the 18-real field is read as usual
+static const double2* recon12_links(lqcd_op_s* op) {
+    lqcd_ctx_s* c = op->ctx;
+    c->tun.recon_active = 0;
+    if (c->tun.gauge_recon != 12 || op->kind != LQCD_WILSON || op->r != 1.0 || c->tun.dslash_variant != 1) return nullptr;
+    if (gauge_ensure_recon12(op->gauge) != LQCD_OK || !op->gauge->recon_ok) return nullptr;
+    c->tun.recon_active = 1;
+    return op->gauge->data12;
+}
+
 // out = D in  /  D^+ in on FULL spinors
 StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger) {
     StencilCall s;
@@ -100,6 +111,7 @@ StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in,
     s.dagger = dagger;
     s.parity_mode = 2;
     s.norm_partial = nullptr;
+    s.gauge12 = recon12_links(op);
     return s;
 }
 
@@ -118,6 +130,7 @@ StencilCall make_hop_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, 
     s.dagger = dagger;
     s.parity_mode = out->subset == LQCD_EVEN ? 0 : 1;
     s.norm_partial = nullptr;
+    s.gauge12 = recon12_links(op);
     return s;
 }
 

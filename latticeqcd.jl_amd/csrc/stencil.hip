@@ -24,6 +24,7 @@ inline namespace LQCD_PNS {
 struct KArgs {
     Geom g;
     const real2* gauge;
+    const real2* gauge12;   // 12-real links (rows 0,1) or nullptr
     real2* out[2];
     const real2* in[2];
     const real2* xin[2];
@@ -140,6 +141,22 @@ __device__ inline void load_link(cd (&u)[9], const real2* __restrict__ U, int Vh
     for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * Vh);
 }
 
+// 12-real links: rows 0 and 1 from memory, row 2 = conj(row 0 x row 1)  (exact for SU(3) to rounding)
+__device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) u[k] = ld(U + (size_t)k * 64);
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+        cd x = mk(0.0, 0.0);
+        cfma(x, u[b1], u[3 + b2]);
+        x.re = -x.re; x.im = -x.im;
+        cd y = mk(0.0, 0.0);
+        cfma(y, u[b2], u[3 + b1]);
+        u[6 + b] = mk(-(x.re + y.re), x.im + y.im);   // conj(u[b1] u[3+b2] - u[b2] u[3+b1])
+    }
+}
+
 // spin projection h = rows 0,1 of (1 - S*gamma_mu) psi   (mu = 3: the two non-zero rows, factor 2 included)
 template <int MU, int S>
 __device__ inline void project(cd (&h0)[3], cd (&h1)[3], const real2* __restrict__ psi, int Vh) {
@@ -185,12 +202,12 @@ __device__ inline void reconstruct(cd (&acc)[12], const cd (&chi0)[3], const cd 
 }
 
 // one hop, r = 1:  acc += (1 - S gamma_mu) [U or U^+] psi(nb) * sign
-template <int MU, int S, bool ADJ>
+template <int MU, int S, bool ADJ, bool R12 = false>
 __device__ inline void wilson_hop(cd (&acc)[12], const real2* __restrict__ psi, const real2* __restrict__ U,
                                   int Vh, int Us, real sign) {
     cd h0[3], h1[3], chi0[3], chi1[3], u[9];
     project<MU, S>(h0, h1, psi, Vh);
-    load_link(u, U, Us);
+    if constexpr (R12) load_link12(u, U); else load_link(u, U, Us);
 #pragma unroll
     for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
     su3_mv<ADJ>(chi0, u, h0);
@@ -335,22 +352,22 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
 // through LDS and wave w writes spin row w.  Compared with one-lane-does-all-8-hops this cuts the wave lifetime ~6x and
 // phase-aligns the waves that touch the same lines, so the re-use of psi (9x) and of the links (2x) falls inside the
 // residency time of the XCD's 4 MiB L2 (measured: profiles/).  r = 1 only.
-template <int MU, bool DAG>
+template <int MU, bool DAG, bool R12>
 __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i) {
     Nbr n;
     int c[4];
     neighbours(k.g, p, i, n, c);
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const real2* __restrict__ psi = k.in[1 - p];
-    const real2* __restrict__ Uf = k.gauge + glink_off(k.g, p, MU, i);
-    const real2* __restrict__ Ub = k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
+    const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(k.g, p, MU, i) : k.gauge + glink_off(k.g, p, MU, i);
+    const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
     const int Us = glink_stride(k.g);
     constexpr int SF = DAG ? -1 : 1;
-    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU]);
-    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU]);
+    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU]);
+    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU]);
 }
 
-template <bool DAG>
+template <bool DAG, bool R12 = false>
 __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     __shared__ real2 part[4][12][64];  // 48 KiB
     __shared__ double red[4];
@@ -373,10 +390,10 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     }
     if (valid) {
         switch (w) {
-        case 0: dirsplit_hops<0, DAG>(acc, k, p, i); break;
-        case 1: dirsplit_hops<1, DAG>(acc, k, p, i); break;
-        case 2: dirsplit_hops<2, DAG>(acc, k, p, i); break;
-        default: dirsplit_hops<3, DAG>(acc, k, p, i); break;
+        case 0: dirsplit_hops<0, DAG, R12>(acc, k, p, i); break;
+        case 1: dirsplit_hops<1, DAG, R12>(acc, k, p, i); break;
+        case 2: dirsplit_hops<2, DAG, R12>(acc, k, p, i); break;
+        default: dirsplit_hops<3, DAG, R12>(acc, k, p, i); break;
         }
     }
 #pragma unroll
@@ -1154,6 +1171,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     KArgs k;
     k.g = c->geom;
     k.gauge = (const real2*)s.gauge;
+    k.gauge12 = s.prec ? nullptr : (const real2*)s.gauge12;
     for (int p = 0; p < 2; p++) { k.out[p] = (real2*)s.out[p]; k.in[p] = (const real2*)s.in[p]; k.xin[p] = (const real2*)s.xin[p]; }
     k.a = s.a; k.b = s.b; k.r = s.r;
     k.parity_mode = s.parity_mode;
@@ -1234,8 +1252,13 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
 #undef LQ_HS
         } else {
             dim3 grid(k.nblocks), block(256);
-            if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true>), grid, block, pad, c->stream, k);
-            else hipLaunchKernelGGL((wilson_dirsplit<false>), grid, block, pad, c->stream, k);
+            if (k.gauge12) {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit<false, true>), grid, block, pad, c->stream, k);
+            } else {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit<false, false>), grid, block, pad, c->stream, k);
+            }
         }
         HIPCHK(hipGetLastError());
         return LQCD_OK;
