@@ -90,7 +90,9 @@ static void fill_blocks(const double2* dst[2], lqcd_spinor_s* s) {
 static const double2* recon12_links(lqcd_op_s* op) {
     lqcd_ctx_s* c = op->ctx;
     c->tun.recon_active = 0;
-    if (c->tun.gauge_recon != 12 || op->kind != LQCD_WILSON || op->r != 1.0 || c->tun.dslash_variant != 1) return nullptr;
+    if (c->tun.gauge_recon != 12) return nullptr;
+    if (op->kind == LQCD_WILSON && (op->r != 1.0 || c->tun.dslash_variant != 1)) return nullptr;   // only the direction-split kernels
+    if (op->kind == LQCD_STAGGERED && !(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 3)) return nullptr;
     if (gauge_ensure_recon12(op->gauge) != LQCD_OK || !op->gauge->recon_ok) return nullptr;
     c->tun.recon_active = 1;
     return op->gauge->data12;

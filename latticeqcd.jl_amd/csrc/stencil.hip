@@ -770,12 +770,13 @@ __global__ __launch_bounds__(512, 4) void wilson_hopsplit_persist(KArgs k, int n
 }
 
 // ------------------------------------------------------------------------------------------ staggered
+template <bool R12 = false>
 __device__ inline void stag_hop(cd (&acc)[3], const real2* __restrict__ psi, const real2* __restrict__ U, int Vh, int Us,
                                 real coef, bool adj) {
     cd h[3], u[9], chi[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) h[c] = coef * ld(psi + (size_t)c * Vh);
-    load_link(u, U, Us);
+    if constexpr (R12) load_link12(u, U); else load_link(u, U, Us);
     if (adj) su3_mv<true>(chi, u, h); else su3_mv<false>(chi, u, h);
 #pragma unroll
     for (int c = 0; c < 3; c++) acc[c] = acc[c] + chi[c];
@@ -827,6 +828,7 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
 // spinor loads issued as one burst), the four colour-vector partials are combined through LDS and waves 0..2 write one
 // colour component each.  Same reasoning as wilson_dirsplit: short-lived, phase-aligned waves keep the 2x link and 8x
 // spinor re-use inside the L2 residency time, and the XCD tile sweep of map_block applies to 64-site chunks.
+template <bool R12>
 __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
     __shared__ real2 part[4][3][64];
     __shared__ double red[4];
@@ -852,8 +854,10 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         const int nb = w == 0 ? n.bwd[0] : w == 1 ? n.bwd[1] : w == 2 ? n.bwd[2] : n.bwd[3];
         const real sf = w == 0 ? n.sf[0] : w == 1 ? n.sf[1] : w == 2 ? n.sf[2] : n.sf[3];
         const real sb = w == 0 ? n.sb[0] : w == 1 ? n.sb[1] : w == 2 ? n.sb[2] : n.sb[3];
-        if (sf != 0.0) stag_hop(acc, psi + sp_off(3, nf), k.gauge + glink_off(k.g, p, w, i), Vh, Us, eta * sf, false);
-        if (sb != 0.0) stag_hop(acc, psi + sp_off(3, nb), k.gauge + glink_off(k.g, 1 - p, w, nb), Vh, Us, -eta * sb, true);
+        const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(k.g, p, w, i) : k.gauge + glink_off(k.g, p, w, i);
+        const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, w, nb) : k.gauge + glink_off(k.g, 1 - p, w, nb);
+        if (sf != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nf), Uf, Vh, Us, eta * sf, false);
+        if (sb != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nb), Ub, Vh, Us, -eta * sb, true);
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
@@ -1238,7 +1242,8 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         KArgs k = make_kargs(c, s, 64);
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
         if (s.kind == LQCD_STAGGERED) {
-            hipLaunchKernelGGL(staggered_dirsplit, dim3(k.nblocks), dim3(256), pad, c->stream, k);
+            if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
+            else hipLaunchKernelGGL((staggered_dirsplit<false>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
         } else if (c->tun.dslash_variant == 3) {
             dim3 grid(persist_grid(c, k.nblocks)), block(512);
             if (s.dagger) hipLaunchKernelGGL((wilson_hopsplit_persist<true>), grid, block, pad, c->stream, k, k.nblocks);

@@ -71,3 +71,23 @@ def test_recon12_on_reference_fixture_stays_exact(lq, orc):
     lq.mul_(y, D, x)
     assert rel_err(y.download(), orc.wilson_D(Uh, psi, L, KAPPA, 1.0, BC)) < 1e-13
     print("fixture: recon_active =", lat.get_param("recon_active"), "unitarity dev", orc.unitarity_dev(Uh, L))
+
+
+def test_recon12_staggered_matches_oracle(lq, orc):
+    L = (8, 4, 6, 4)
+    lat = lq.Lattice(L)
+    lat.set_param("gauge_recon", 12)
+    Uh = orc.hot_gauge(L, 35)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": 0.5, "boundarycondition": BC, "eps_CG": 1e-19})
+    psi = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 36)
+    x = lq.Fermionfields(lat, lq.STAGGERED).upload(psi)
+    y = x.similar()
+    for dag in (False, True):
+        lq.mul_(y, D.adjoint() if dag else D, x)
+        assert lat.get_param("recon_active") == 1
+        assert rel_err(y.download(), orc.staggered_D(Uh, psi, L, 0.5, BC, dag)) < 1e-13
+    sol = x.similar()
+    it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+    xo, ito, rro, st = orc.cg_DdagD(orc.STAGGERED, Uh, psi, L, 0.5, 1.0, BC, eps=1e-19)
+    assert st == 0 and abs(it - ito) <= 1 and rel_err(sol.download(), xo) < 1e-9
