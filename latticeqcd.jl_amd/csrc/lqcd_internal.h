@@ -260,8 +260,8 @@ struct lqcd_ctx_s {
     double2* force_send[4] = {}, *force_recv[4] = {};
     int force_ncomp = 0;
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
-    void* mix_buf[5] = {};
-    size_t mix_bytes[5] = {};
+    void* mix_buf[6] = {};
+    size_t mix_bytes[6] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;

@@ -25,6 +25,19 @@ __global__ __launch_bounds__(MB) void cvt_to_f32(float2* __restrict__ dst, const
         dst[i] = make_float2((float)(v.x * scale), (float)(v.y * scale));
     }
 }
+// fp32 12-real copy of the links (rows 0,1) for the compressed split kernels of the inner solver.  The inner operator only has
+// to be close to the fp64 one -- the outer residual uses the 18 stored fp64 reals -- so this copy is used for any field.
+__global__ __launch_bounds__(MB) void cvt_gauge12_f32(Geom g, const double2* __restrict__ src, float2* __restrict__ dst) {
+    const int t = blockIdx.x * MB + threadIdx.x;
+    if (t >= 2 * g.Vh * 4) return;
+    const int mu = t & 3, s = t >> 2, p = s / g.Vh, i = s % g.Vh;
+    const size_t so = glink_off(g, p, mu, i), d_o = glink12_off(g, p, mu, i);
+    const int Gs = glink_stride(g);
+    for (int e = 0; e < 6; e++) {
+        const double2 v = src[so + (size_t)e * Gs];
+        dst[d_o + (size_t)e * 64] = make_float2((float)v.x, (float)v.y);
+    }
+}
 // y (fp64) += a * x (fp32)
 __global__ __launch_bounds__(MB) void axpy_from_f32(double2* __restrict__ y, const float2* __restrict__ x, double a, size_t n) {
     for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
@@ -84,7 +97,7 @@ static int mix_alloc(lqcd_ctx_s* c, int slot, size_t bytes) {
 }
 
 struct Mix32 {
-    float2 *gauge, *x, *r, *p, *t;
+    float2 *gauge, *gauge12, *x, *r, *p, *t;
     size_t blk;   // elements per parity block
 };
 
@@ -93,6 +106,7 @@ static StencilCall call32(lqcd_op_s* op, const Mix32& m, float2* out, float2* in
     StencilCall s;
     s.kind = op->kind;
     s.gauge = (const double2*)m.gauge;
+    s.gauge12 = (const double2*)m.gauge12;
     for (int p = 0; p < 2; p++) {
         s.out[p] = (double2*)(out + p * m.blk);
         s.in[p] = (const double2*)(in + p * m.blk);
@@ -166,8 +180,10 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     const size_t n = x->elems, ng = op->gauge->elems;
     LQCHK(mix_alloc(c, 0, ng * sizeof(float2)));
     for (int k = 1; k <= 4; k++) LQCHK(mix_alloc(c, k, n * sizeof(float2)));
+    LQCHK(mix_alloc(c, 5, gauge12_elems(c->geom) * sizeof(float2)));
     Mix32 m;
     m.gauge = (float2*)c->mix_buf[0];
+    m.gauge12 = (float2*)c->mix_buf[5];
     m.x = (float2*)c->mix_buf[1]; m.r = (float2*)c->mix_buf[2]; m.p = (float2*)c->mix_buf[3]; m.t = (float2*)c->mix_buf[4];
     m.blk = n / 2;
     lqcd_spinor_s* r = scratch_get(c, x->kind, LQCD_FULL);
@@ -191,6 +207,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     };
     auto run = [&]() -> int {
         hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
+        hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
         HIPCHK(hipGetLastError());
         LQCHK(true_residual());
         bool fallback = false;
