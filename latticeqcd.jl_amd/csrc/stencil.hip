@@ -363,6 +363,13 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
     const int Us = glink_stride(k.g);
     constexpr int SF = DAG ? -1 : 1;
+    if (k.dbg & (16 << MU)) return;   // traffic ablation (wrong results): drop both hops of direction MU
+    if (k.dbg >= 256) {               // traffic ablations (wrong results): redirect one stream of direction MU to chunk 0 (always L2-hot)
+        const int hot = i & 63;
+        if (k.dbg & (256 << MU)) { n.fwd[MU] = hot; n.bwd[MU] = hot; }
+        if (k.dbg & (4096 << MU)) Uf = R12 ? k.gauge12 + glink12_off(k.g, p, MU, hot) : k.gauge + glink_off(k.g, p, MU, hot);
+        if (k.dbg & (65536 << MU)) Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, hot) : k.gauge + glink_off(k.g, 1 - p, MU, hot);
+    }
     if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU]);
     if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU]);
 }
