@@ -175,4 +175,57 @@ function solve_DinvX!(y::HIPFermion, D::HIPDirac, x::HIPFermion)
     end
 end
 
+# shiftedcg(vec_x, vec_β, x, A, b): the RHMC solver (README.md:132)
+function shiftedcg(vec_x::Vector{HIPFermion}, vec_β::Vector{Float64}, x::HIPFermion, A::HIPDdagD, b::HIPFermion)
+    it, rr = Ref{Cint}(0), Ref{Float64}(0)
+    hs = [v.h for v in vec_x]
+    check(ccall((:lqcd_solve_multishift_cg, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Float64}, Cint, Float64, Cint, Ref{Cint}, Ref{Float64}),
+                A.D.h, x.h, hs, b.h, vec_β, length(vec_β), A.D.eps_CG, A.D.MaxCGstep, it, rr))
+end
+
+# mixed-precision variant of solve_DinvX!(y, DdagD, x): fp32 inner CG, stopping rule on the true fp64 residual
+function solve_mixed_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion; inner_tol = 1e-4)
+    it, out, rr = Ref{Cint}(0), Ref{Cint}(0), Ref{Float64}(0)
+    check(ccall((:lqcd_solve_mixed_cg_DdagD, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Float64, Ref{Cint}, Ref{Cint}, Ref{Float64}),
+                A.D.h, y.h, x.h, A.D.eps_CG, A.D.MaxCGstep, inner_tol, it, out, rr))
+end
+
+# ---- pseudofermion action / force and the gauge side of the MD step: everything src/md/AbstractMD.jl:78-135 and
+# src/updates/standardHMC.jl:41-91 call, with every field resident on the device
+struct HIPFermiAction            # FermiAction(D, Dict("Nf" => 2)) (universe.jl:138)
+    D::HIPDirac
+end
+function evaluate_FermiAction(fa::HIPFermiAction, U::HIPGaugefields, η::HIPFermion, X::HIPFermion, Y::HIPFermion)
+    S, it = Ref{Float64}(0), Ref{Cint}(0)
+    D = fa.D(U)
+    check(ccall((:lqcd_fermi_action, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ref{Float64}, Ref{Cint}),
+                D.h, η.h, X.h, Y.h, D.eps_CG, D.MaxCGstep, S, it))
+    S[]
+end
+function calc_UdSfdU!(UdSfdU::HIPGaugefields, fa::HIPFermiAction, U::HIPGaugefields, η::HIPFermion)
+    D = fa.D(U)
+    check(ccall((:lqcd_calc_UdSfdU, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Cint}),
+                D.h, UdSfdU.h, η.h, D.eps_CG, D.MaxCGstep, C_NULL, C_NULL))
+end
+gauge_force!(G::HIPGaugefields, U::HIPGaugefields, β) =
+    check(ccall((:lqcd_gauge_force, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), G.h, U.h, β))
+Traceless_antihermitian_add!(p::HIPGaugefields, factor, G::HIPGaugefields) =
+    check(ccall((:lqcd_momentum_add_ta, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), p.h, factor, G.h))
+U_update!(U::HIPGaugefields, p::HIPGaugefields, dt) =
+    check(ccall((:lqcd_gauge_exp_update, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), U.h, dt, p.h))
+gauss_distribution!(p::HIPGaugefields; seed = 114) =
+    check(ccall((:lqcd_momentum_gaussian, LIB), Cint, (Ptr{Cvoid}, UInt64), p.h, seed))
+substitute_U!(dst::HIPGaugefields, src::HIPGaugefields) =
+    check(ccall((:lqcd_gauge_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), dst.h, src.h))
+function momentum_action(p::HIPGaugefields)      # md.p * md.p / 2
+    k = Ref{Float64}(0)
+    check(ccall((:lqcd_momentum_action, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), p.h, k)); k[]
+end
+function evaluate_GaugeAction(U::HIPGaugefields, β)  # the -evaluate_GaugeAction/NC term of standardHMC.jl:50
+    s = Ref{Float64}(0)
+    check(ccall((:lqcd_gauge_action, LIB), Cint, (Ptr{Cvoid}, Float64, Ref{Float64}), U.h, β, s)); s[]
+end
+
 end # module
