@@ -102,7 +102,29 @@ def main():
     ms = 1e3 * dt / 10
     res.append({"config": "32^3x64 Wilson fermion-force sweep (calc_UdSfdU! after the solve)", "ms": ms,
                 "algorithmic_GBps_1536B": 1536 * V / ms / 1e6, "roofline_frac": 1536 * V / ms / 1e6 / 8000})
-    for o in (U, D, X, Y, G):
+    # ---- one MD step of the 2-flavour Wilson HMC at 32^3x64, everything resident (reference: runMD_QPQ_sw!, N_sw = 10)
+    beta, dtau, nsw = 5.7, 0.05, 10
+    p = lq.Gaugefields(lat)
+    lq.gauss_distribution_(p, 7)
+    eta = lq.Fermionfields(lat, lq.WILSON)
+    lq.sample_pseudofermions_(eta, U, lq.FermiAction(D), X)
+    fa = lq.FermiAction(D)
+    D.eps_CG = 1e-16
+
+    def tk(fn, reps=5):
+        fn()
+        return 1e3 * timed(lambda: [fn() for _ in range(reps)], reps=2)[0] / reps
+    t_gf = tk(lambda: lq.gauge_force_(G, U, beta))
+    t_ta = tk(lambda: lq.Traceless_antihermitian_add_(p, 1e-9, G))
+    t_up = tk(lambda: lq.U_update_(U, p, 1e-9))
+    t_ff = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
+    t_sf = tk(lambda: lq.evaluate_FermiAction(fa, U, eta), reps=2)
+    res.append({"config": "32^3x64 Wilson HMC, one MD step resident on the device (Sexton-Weingarten N = 10)",
+                "gauge_force_ms": t_gf, "gauge_force_GBps_1152B": 1152 * V / t_gf / 1e6, "momentum_add_ta_ms": t_ta, "link_exp_update_ms": t_up,
+                "calc_UdSfdU_ms (CG to 1e-16 + Y = D X + sweep)": t_ff, "evaluate_FermiAction_ms": t_sf,
+                "md_step_ms": nsw * (t_gf + t_ta + 2 * t_up) + t_ff + t_ta,
+                "note": "host<->device traffic per MD step: none (the reference path would move 1.2 GB of links + 2 spinors)"})
+    for o in (U, D, X, Y, G, p, eta):
         o.close()
     # ---- configs[4] geometry on one GPU: 48^3x96 staggered Dslash and CG (fp64)
     L = (48, 48, 48, 96)
