@@ -179,6 +179,7 @@ int lqcd_gauge_copy(lqcd_gauge_t dst, lqcd_gauge_t src);                  /* sub
 int lqcd_gauge_action(lqcd_gauge_t U, double beta, double* Sg);          /* -evaluate_GaugeAction/NC (standardHMC.jl:50) */
 int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta);     /* calc_dSdUmu! + mul!(temp, U, dSdUmu) (src/md/AbstractMD.jl:108-109): -(beta/6) U * staples; single-GPU contexts */
 int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t G); /* Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131) */
+int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta); /* P_update! (AbstractMD.jl:99-118) fused: P += factor TA(gauge force), the force field is never stored */
 int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U */
 int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed);               /* gauss_distribution!(p) (src/md/standardMD.jl:86); keyed by GLOBAL site */
 int lqcd_momentum_action(lqcd_gauge_t P, double* K);                     /* p.p/2 (standardHMC.jl:49) */

@@ -235,6 +235,7 @@ struct Tunables {
     int xcd_ysplit = 4;       // remap 2: tile the sub-domains in (y,z) instead of plain z-slabs
     int xcd_nsub = 16;       // remap 2: sub-domains per t-slice (multiple of 8)
     int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)
+    int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
     int gauge_recon = 18;     // 12: the Wilson dirsplit kernel reads 2 rows per link and rebuilds the third (only for links that
                               // are unitary to 1e-14; otherwise the 18-real field is used).  Opt-in: bytes/site 960 -> 768.
     int recon_active = 0;     // read-only: 1 if the last Wilson operator application used the 12-real links

@@ -70,7 +70,9 @@ __device__ __forceinline__ void shift(int (&d)[4], const Geom& g, int mu, int di
 
 // out_mu(n) = coef * U_mu(n) * sum_{nu != mu} [ U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+  +  U_nu(n+mu-nu)^+ U_mu(n-nu)^+ U_nu(n-nu) ]
 // workgroup = 64 sites of one parity x 4 waves (wave = mu); the 6 x 3 neighbour links are re-used across waves/sites through L2
-__global__ __launch_bounds__(256) void gauge_force_kernel(Geom g, const double2* __restrict__ U, double2* __restrict__ out, double coef) {
+// FUSE_TA = false: out = G.   FUSE_TA = true: out (the momenta) += factor * TA(G) -- P_update! in one pass, G never stored.
+template <bool FUSE_TA>
+__global__ __launch_bounds__(256) void gauge_force_kernel(Geom g, const double2* __restrict__ U, double2* __restrict__ out, double coef, double factor) {
     const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
     if (i >= g.Vh) return;
     const int Gs = glink_stride(g);
@@ -107,16 +109,32 @@ __global__ __launch_bounds__(256) void gauge_force_kernel(Geom g, const double2*
     load_m3(um, U + glink_off(g, p, mu, i), Gs);
     mm3(r, um, A);
     double2* o = out + glink_off(g, p, mu, i);
+    if constexpr (!FUSE_TA) {
 #pragma unroll
-    for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, mk(coef * r[e].re, coef * r[e].im));
+        for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, mk(coef * r[e].re, coef * r[e].im));
+    } else {
+        cd a[9];
+        const double f = 0.5 * coef * factor;
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int y = 0; y < 3; y++) a[x * 3 + y] = mk(f * (r[x * 3 + y].re - r[y * 3 + x].re), f * (r[x * 3 + y].im + r[y * 3 + x].im));
+        const double tr = (a[0].im + a[4].im + a[8].im) / 3.0;
+        a[0].im -= tr; a[4].im -= tr; a[8].im -= tr;
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            const cd pv = ld(o + (size_t)e * Gs);
+            st(o + (size_t)e * Gs, mk(pv.re + a[e].re, pv.im + a[e].im));
+        }
+    }
 }
 
-// one thread per link: t = ((p * Vh + i) * 4 + mu)
+// one thread per link; workgroup = 64 consecutive sites of one parity x 4 waves (wave = mu): every access of a wave is one
+// contiguous 1 KiB run of the chunk-blocked layout
 __device__ __forceinline__ bool link_of_thread(const Geom& g, size_t& off) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * g.Vh * 4) return false;
-    const int mu = t & 3, s = t >> 2;
-    off = glink_off(g, s / g.Vh, mu, s % g.Vh);
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    if (i >= g.Vh) return false;
+    off = glink_off(g, p, mu, i);
     return true;
 }
 
@@ -140,7 +158,8 @@ __global__ __launch_bounds__(256) void momentum_add_ta_kernel(Geom g, double2* _
     }
 }
 
-// U <- exp(dt P) U, Taylor series in Horner form (24 terms: exact to rounding for |dt P| < 2)
+// U <- exp(dt P) U, Taylor series in Horner form.  Terms: 12 when the max-abs-row-sum norm of dt P is below 0.2
+// (0.2^13/13! = 1e-19), otherwise 24 (exact to rounding up to norm 2); an MD step has |dt P| of a few 1e-2.
 __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* __restrict__ U, double dt, const double2* __restrict__ P) {
     size_t off;
     if (!link_of_thread(g, off)) return;
@@ -149,7 +168,11 @@ __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* _
     load_m3(x, P + off, Gs);
 #pragma unroll
     for (int k = 0; k < 9; k++) { x[k] = mk(dt * x[k].re, dt * x[k].im); e[k] = mk((k % 4 == 0) ? 1.0 : 0.0, 0.0); }
-    for (int n = 24; n >= 1; n--) {
+    double nrm = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        nrm = fmax(nrm, (fabs(x[a * 3].re) + fabs(x[a * 3].im)) + (fabs(x[a * 3 + 1].re) + fabs(x[a * 3 + 1].im)) + (fabs(x[a * 3 + 2].re) + fabs(x[a * 3 + 2].im)));
+    for (int n = nrm < 0.2 ? 12 : 24; n >= 1; n--) {
         mm3(t, x, e);
         const double inv = 1.0 / (double)n;
 #pragma unroll
@@ -170,9 +193,8 @@ __device__ inline void gauss2(uint64_t k, double& a, double& b) {
 }
 // P = i sum_a pi_a lambda_a / 2, pi_a ~ N(0,1) keyed by (seed, GLOBAL site, mu, a): identical for every decomposition
 __global__ __launch_bounds__(256) void momentum_gaussian_kernel(Geom g, double2* __restrict__ P, uint64_t seed) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * g.Vh * 4) return;
-    const int mu = t & 3, s = t >> 2, p = s / g.Vh, i = s % g.Vh;
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    if (i >= g.Vh) return;
     int c[4];
     cb_to_coords(g, p, i, c);
     const uint64_t x = c[0] + g.origin[0], y = c[1] + g.origin[1], z = c[2] + g.origin[2], tt = c[3] + g.origin[3];
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(256) void momentum_action_kernel(Geom g, const doub
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-static int link_grid(const Geom& g) { return (2 * g.Vh * 4 + 255) / 256; }
+static int link_grid(const Geom& g) { return 2 * g.nch; }
 
 }  // namespace lqcd
 
@@ -255,7 +277,23 @@ extern "C" int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta) {
     }
     HIPCHK(hipSetDevice(c->device));
     out->version++;
-    hipLaunchKernelGGL(gauge_force_kernel, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, out->data, -beta / 6.0);
+    hipLaunchKernelGGL(gauge_force_kernel<false>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, out->data, -beta / 6.0, 0.0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+// P_update!(U, p, eps, md) (AbstractMD.jl:99-118) in one pass:  P += factor * TA(-(beta/6) U * staples); the force field is never stored
+extern "C" int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta) {
+    LQCHK(same_ctx(P, U, "lqcd_momentum_add_gauge_force"));
+    lqcd_ctx_s* c = U->ctx;
+    if (any_partitioned(c)) {
+        set_error("lqcd_momentum_add_gauge_force: not available on a partitioned lattice yet (needs link halos in both directions)");
+        return LQCD_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    P->version++;
+    hipLaunchKernelGGL(gauge_force_kernel<true>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, P->data, -beta / 6.0, factor);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;

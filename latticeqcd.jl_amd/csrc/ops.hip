@@ -870,7 +870,8 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(X->data, 0, X->elems * sizeof(double2), c->stream));
-    LQCHK(cg_run(op, X, eta, eps, maxiter, false, iters, nullptr));
+    if (c->tun.mixed_action_solver) LQCHK(lqcd_solve_mixed_cg_DdagD(op, X, eta, eps, maxiter, 0.0, iters, nullptr, nullptr));
+    else LQCHK(cg_run(op, X, eta, eps, maxiter, false, iters, nullptr));
     if (Y) LQCHK(op_apply_async(op, Y, X, 0, nullptr));
     double re = 0, im = 0;
     LQCHK(blas_dot(c, eta->data, X->data, eta->elems, &re, &im, true));

@@ -422,6 +422,12 @@ def Traceless_antihermitian_add_(p, factor, G):
     return p
 
 
+def P_update_(U, p, factor, beta):
+    """P_update!(U, p, eps, md) (AbstractMD.jl:99-118) in one pass: p += factor * TA(-(beta/6) U staples)."""
+    check(_l.lib().lqcd_momentum_add_gauge_force(p._h, C.c_double(factor), U._h, C.c_double(beta)))
+    return p
+
+
 def U_update_(U, p, dt):
     """U_update!(U, p, eps, md) (AbstractMD.jl:78-97): U <- exp(dt p) U."""
     check(_l.lib().lqcd_gauge_exp_update(U._h, C.c_double(dt), p._h))

@@ -116,13 +116,21 @@ def main():
         return 1e3 * timed(lambda: [fn() for _ in range(reps)], reps=2)[0] / reps
     t_gf = tk(lambda: lq.gauge_force_(G, U, beta))
     t_ta = tk(lambda: lq.Traceless_antihermitian_add_(p, 1e-9, G))
+    t_pu = tk(lambda: lq.P_update_(U, p, 1e-9, beta))
     t_up = tk(lambda: lq.U_update_(U, p, 1e-9))
     t_ff = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
     t_sf = tk(lambda: lq.evaluate_FermiAction(fa, U, eta), reps=2)
+    lat.set_param("mixed_action_solver", 1)
+    t_ffm = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
+    lat.set_param("mixed_action_solver", 0)
     res.append({"config": "32^3x64 Wilson HMC, one MD step resident on the device (Sexton-Weingarten N = 10)",
-                "gauge_force_ms": t_gf, "gauge_force_GBps_1152B": 1152 * V / t_gf / 1e6, "momentum_add_ta_ms": t_ta, "link_exp_update_ms": t_up,
+                "gauge_force_ms": t_gf, "gauge_force_GBps_1152B": 1152 * V / t_gf / 1e6, "momentum_add_ta_ms": t_ta,
+                "P_update_fused_ms": t_pu, "P_update_fused_GBps_1728B": 1728 * V / t_pu / 1e6, "link_exp_update_ms": t_up,
+                "link_exp_update_GBps_1728B": 1728 * V / t_up / 1e6,
                 "calc_UdSfdU_ms (CG to 1e-16 + Y = D X + sweep)": t_ff, "evaluate_FermiAction_ms": t_sf,
-                "md_step_ms": nsw * (t_gf + t_ta + 2 * t_up) + t_ff + t_ta,
+                "calc_UdSfdU_mixed_precision_solver_ms": t_ffm,
+                "md_step_ms": nsw * (t_pu + 2 * t_up) + t_ff + t_ta,
+                "md_step_mixed_precision_solver_ms": nsw * (t_pu + 2 * t_up) + t_ffm + t_ta,
                 "note": "host<->device traffic per MD step: none (the reference path would move 1.2 GB of links + 2 spinors)"})
     for o in (U, D, X, Y, G, p, eta):
         o.close()

@@ -35,9 +35,12 @@ def test_md_kernels_match_oracle(gpu, orc, L):
     lq.gauge_force_(G, U, BETA)
     Gh = orc.gauge_force(Uh, L, BETA)
     assert rel_err(G.download(), Gh) < 1e-13
+    P2 = lq.Gaugefields(lat).upload(Ph)
     lq.Traceless_antihermitian_add_(P, -0.37, G)
     orc.momentum_add_ta(Ph, -0.37, Gh, L)
     assert rel_err(P.download(), Ph) < 1e-13
+    lq.P_update_(U, P2, -0.37, BETA)                  # fused force + projection + accumulate
+    assert rel_err(P2.download(), Ph) < 1e-13
     lq.U_update_(U, P, 0.11)
     orc.link_update(Uh, Ph, 0.11, L)
     assert rel_err(U.download(), Uh) < 1e-13
@@ -88,8 +91,7 @@ class DeviceHMC:
         self.lq.U_update_(self.U, self.p, eps * self.dtau)
 
     def P_update(self, eps):
-        self.lq.gauge_force_(self.G, self.U, self.beta)
-        self.lq.Traceless_antihermitian_add_(self.p, eps * self.dtau, self.G)
+        self.lq.P_update_(self.U, self.p, eps * self.dtau, self.beta)
 
     def P_update_fermion(self, eps):
         self.lq.calc_UdSfdU_(self.G, self.fa, self.U, self.eta)

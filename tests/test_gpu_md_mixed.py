@@ -1,0 +1,26 @@
+"""The reference's Wilson HMC test again, with every pseudofermion solve done by the mixed-precision CG (tunable
+mixed_action_solver): the stopping rule is enforced on the true fp64 residual, so the trajectory statistics are unchanged."""
+import numpy as np
+import pytest
+
+from test_gpu_md import BETA, KAPPA, REF_PLAQ_WILSON_HMC, DeviceHMC, _fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hmc_with_mixed_precision_action_solver(lq, orc):
+    assert lq.lib.device_count() > 0
+    L, Uh, U = _fixture(lq)
+    U.lattice.set_param("mixed_action_solver", 1)
+    h = DeviceHMC(lq, U, KAPPA, BETA, dtau=0.05, mdsteps=20, nsw=10, seed=111)
+    for _ in range(10):
+        h.update()
+    plaq = lq.calculate_Plaquette(U)
+    print("mixed-solver HMC: dH =", ["%.3f" % d for d in h.dH], "accepted", sum(h.accepted), "/ 10, plaquette", plaq)
+    assert abs(plaq - REF_PLAQ_WILSON_HMC) / REF_PLAQ_WILSON_HMC < 0.1
+    assert sum(h.accepted) >= 6 and np.abs(np.array(h.dH)).max() < 2.0
+    # same seeds, same integrator: the fp64-solver run of test_gpu_md.py gives dH within solver tolerance of these
+    U2 = _fixture(lq)[2]
+    h2 = DeviceHMC(lq, U2, KAPPA, BETA, dtau=0.05, mdsteps=20, nsw=10, seed=111)
+    h2.update()
+    assert abs(h2.dH[0] - h.dH[0]) < 1e-6
