@@ -53,6 +53,8 @@ int lqcd_version(void);
 const char* lqcd_last_error(void);
 /* number of HIP devices visible (0 if none) */
 int lqcd_device_count(void);
+/* free / total HBM of a device in bytes (diagnostics; the leak test of tests/test_gpu_lifecycle.py) */
+int lqcd_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
 /* reference site linearisation ix + NX*(iy + NY*(iz + NZ*it)) */
 int64_t lqcd_index_lex(const int L[4], int x, int y, int z, int t);
 /* device (checkerboard) position of a site: parity = (x+y+z+t)&1, cb = (x>>1) + (NX/2)*(y + NY*(z + NZ*t)) */

@@ -77,6 +77,16 @@ extern "C" int lqcd_device_count(void) {
     return n;
 }
 
+extern "C" int lqcd_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes) {
+    ARGCHK(free_bytes && total_bytes, "lqcd_device_mem_info: null argument");
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return LQCD_OK;
+}
+
 extern "C" int64_t lqcd_index_lex(const int L[4], int x, int y, int z, int t) {
     return x + (int64_t)L[0] * (y + (int64_t)L[1] * (z + (int64_t)L[2] * t));
 }

@@ -249,7 +249,7 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
 
 extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
     if (!g) return LQCD_OK;
-    hipSetDevice(g->ctx->device);
+    // (no hipSetDevice: the context may already be gone -- finalizers run in any order -- and hipFree does not need it)
     hipFree(g->data);
     hipFree(g->data12);
     delete g;
@@ -369,7 +369,7 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
 
 extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
     if (!s) return LQCD_OK;
-    hipSetDevice(s->ctx->device);
+    // (no hipSetDevice: see lqcd_gauge_destroy)
     hipFree(s->data);
     delete s;
     return LQCD_OK;

@@ -82,6 +82,12 @@ class Lattice:
             _l.lib().lqcd_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
+    def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def comm_unique_id():
     buf = (C.c_ubyte * 256)()
@@ -119,6 +125,12 @@ class Gaugefields:
         if self._h:
             _l.lib().lqcd_gauge_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def Initialize_Gaugefields(NC, Nwing, NX, NY, NZ, NT, condition="cold", lattice=None, randomseed=111, **kw):
@@ -171,6 +183,12 @@ class Fermionfields:
         if self._h:
             _l.lib().lqcd_spinor_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def Initialize_pseudofermion_fields(U, Dirac_operator, nowing=True, subset=FULL):
@@ -277,6 +295,12 @@ class Dirac_operator:
             _l.lib().lqcd_op_destroy(self._h)
             self._h = C.c_void_p()
 
+    def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class DdagD_operator:
     """DdagD_operator(D): A = D'D, solved with CG."""
@@ -356,6 +380,10 @@ class FermiAction:
         self.D = D
         kind = D.kind
         self._temporary_fermionfields = [Fermionfields(D.lattice, kind) for _ in range(2)]   # standardMD.jl:50-51
+
+    def close(self):
+        for f in self._temporary_fermionfields:
+            f.close()
 
 
 def gauss_sampling_in_action_(xi, U, fa, randomseed=112):

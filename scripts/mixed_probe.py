@@ -9,6 +9,9 @@ eps = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-16
 kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
 U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
 lat = U.lattice
+for kv in os.environ.get("LQCD_SET", "").split():
+    k, v = kv.split("=")
+    lat.set_param(k, int(v))
 D = lq.Dirac_operator(U, None, {"Dirac_operator": kind_name, "κ": 0.141139, "mass": 0.05, "eps_CG": eps})
 A = lq.DdagD_operator(D)
 b = lq.Fermionfields(lat, kind)
