@@ -286,7 +286,10 @@ class Dirac_operator:
         return self
 
     def adjoint(self):
-        return Dirac_operator(self.U, None, self.params, _dagger=not self.dagger, _share=self._h)
+        adj = Dirac_operator(self.U, None, self.params, _dagger=not self.dagger, _share=self._h)
+        adj._parent = self        # the handle belongs to the parent: keep it alive as long as the adjoint view is
+        adj.eps_CG, adj.MaxCGstep, adj.method_CG = self.eps_CG, self.MaxCGstep, self.method_CG
+        return adj
 
     H = property(adjoint)
 
