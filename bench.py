@@ -149,6 +149,25 @@ def main():
                      "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc},
     }
 
+    # ---- secondary, N > 1 (outside the timed region): where the time of a partitioned operator application goes on real links
+    if (world > 1 or force_dist) and any(p > 1 for p in pe) or (force_dist and os.environ.get("LQCD_FORCE_PARTITION")):
+        import ctypes as C
+        import torch
+        ph = (C.c_double * 6)()
+        us = C.c_double(0)
+        barrier()
+        lq.lib.check(lq.lib.lib().lqcd_bench_halo_phases(D._h, y._h, b._h, 0, 20, ph))
+        barrier()
+        lq.lib.check(lq.lib.lib().lqcd_bench_allreduce(lat._h, 200, C.byref(us)))
+        t = torch.tensor(list(ph) + [us.value], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        v = [float(z) for z in t]
+        out["halo_phases_ms_max_over_ranks"] = {"pack": v[0], "interior": v[1], "exchange_after_pack": v[2],
+                                                "idle_wait_for_exchange": v[3], "exterior": v[4], "total_synchronised": v[5]}
+        out["allreduce_latency_us"] = v[6]
+        face = [lat.local_L[0] * lat.local_L[1] * lat.local_L[2] * lat.local_L[3] // lat.local_L[mu] if pe[mu] > 1 else 0 for mu in range(4)]
+        out["halo_bytes_per_peer_and_direction"] = [96 * f for f in face]
+
     # ---- secondary (outside the timed region, not part of `value`): the opt-in 12-real link compression (rows 0,1 stored, row 2
     # rebuilt; only for links unitary to 1e-14 -- the hot start is).  Same operator, 768 instead of 960 bytes moved per site.
     if world == 1 and not force_dist:

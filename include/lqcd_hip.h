@@ -186,6 +186,12 @@ int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_up
 int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed);               /* gauss_distribution!(p) (src/md/standardMD.jl:86); keyed by GLOBAL site */
 int lqcd_momentum_action(lqcd_gauge_t P, double* K);                     /* p.p/2 (standardHMC.jl:49) */
 
+/* multi-GPU diagnostics (bench.py, N > 1): phase breakdown of one partitioned operator application -- ms[6] = pack, interior,
+ * exchange (pack end -> halos received), idle wait for the exchange after the interior, exterior, total -- and the latency of
+ * the one-double all-reduce (microseconds) */
+int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int reps, double* ms);
+int lqcd_bench_allreduce(lqcd_ctx_t ctx, int reps, double* us);
+
 /* benchmarking window: exactly niter CG iterations, exit test disabled (SURVEY.md 8(d) timing protocol) */
 int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int niter);
 

@@ -946,6 +946,68 @@ extern "C" int lqcd_bench_dslash(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t 
     return LQCD_OK;
 }
 
+// Phase breakdown of ONE partitioned operator application (mean over reps, each rep synchronised):
+//   ms[0] pack, ms[1] interior kernel (overlapping the exchange), ms[2] exchange = pack end -> last halo byte received (RCCL on the
+//   communication stream, incl. its launch latency), ms[3] compute stream idle waiting for the exchange after the interior,
+//   ms[4] exterior, ms[5] whole application.  What the N > 1 lines of bench.py report, so that the critical path of the halo
+//   exchange on real xGMI links is visible from the driver's multi-GPU runs.
+extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int reps, double* ms) {
+    LQCHK(check_full(op, out, in, "lqcd_bench_halo_phases"));
+    ARGCHK(reps > 0 && ms, "lqcd_bench_halo_phases: bad arguments");
+    lqcd_ctx_s* c = op->ctx;
+    ARGCHK(any_partitioned(c) && c->has_comm && c->local_peers.empty(), "lqcd_bench_halo_phases: needs a partitioned context with RCCL communicators");
+    HIPCHK(hipSetDevice(c->device));
+    hipEvent_t e[6];
+    for (auto& ev : e) HIPCHK(hipEventCreate(&ev));
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    apply_bc(c, op->bc);
+    StencilCall s = make_full_call(op, out, in, dagger ? 1 : 0);
+    for (int r = 0; r < reps + 2; r++) {          // two untimed warm-up applications
+        HIPCHK(hipEventRecord(e[0], c->stream));
+        LQCHK(launch_stencil_pack(c, s));
+        HIPCHK(hipEventRecord(e[1], c->stream));
+        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0));
+        HIPCHK(hipEventRecord(e[5], c->comm_stream));
+        LQCHK(launch_stencil_interior(c, s));
+        HIPCHK(hipEventRecord(e[2], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+        HIPCHK(hipEventRecord(e[3], c->stream));
+        LQCHK(launch_stencil_exterior(c, s));
+        HIPCHK(hipEventRecord(e[4], c->stream));
+        HIPCHK(hipEventSynchronize(e[4]));
+        HIPCHK(hipEventSynchronize(e[5]));
+        if (r < 2) continue;
+        float t;
+        HIPCHK(hipEventElapsedTime(&t, e[0], e[1])); acc[0] += t;
+        HIPCHK(hipEventElapsedTime(&t, e[1], e[2])); acc[1] += t;
+        HIPCHK(hipEventElapsedTime(&t, e[1], e[5])); acc[2] += t;
+        HIPCHK(hipEventElapsedTime(&t, e[2], e[3])); acc[3] += t;
+        HIPCHK(hipEventElapsedTime(&t, e[3], e[4])); acc[4] += t;
+        HIPCHK(hipEventElapsedTime(&t, e[0], e[4])); acc[5] += t;
+    }
+    for (int k = 0; k < 6; k++) ms[k] = acc[k] / reps;
+    for (auto& ev : e) (void)hipEventDestroy(ev);
+    return LQCD_OK;
+}
+
+// mean latency (microseconds) of the stream-ordered one-double all-reduce the solvers issue twice per CG iteration
+extern "C" int lqcd_bench_allreduce(lqcd_ctx_t c, int reps, double* us) {
+    ARGCHK(c && reps > 0 && us, "lqcd_bench_allreduce: bad arguments");
+    ARGCHK(c->has_comm, "lqcd_bench_allreduce: communicators not initialised");
+    HIPCHK(hipSetDevice(c->device));
+    double* d = c->d_scal + S_RED0;
+    HIPCHK(hipMemsetAsync(d, 0, sizeof(double), c->stream));   // 0 + 0 + ... stays finite however often it is summed
+    for (int i = 0; i < 5; i++) NCCLCHK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, c->comm_red, c->stream));
+    HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+    for (int i = 0; i < reps; i++) NCCLCHK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, c->comm_red, c->stream));
+    HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_t1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, c->ev_t0, c->ev_t1));
+    *us = 1e3 * (double)t / reps;
+    return LQCD_OK;
+}
+
 extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int warm, int niter, double* ms_per_iter) {
     LQCHK(check_full(op, x, b, "lqcd_bench_cg"));
     ARGCHK(niter > 0 && ms_per_iter, "lqcd_bench_cg: bad niter");
