@@ -156,12 +156,13 @@ def main():
         ph = (C.c_double * 6)()
         us = C.c_double(0)
         barrier()
-        lq.lib.check(lq.lib.lib().lqcd_bench_halo_phases(D._h, y._h, b._h, 0, 20, ph))
-        barrier()
-        lq.lib.check(lq.lib.lib().lqcd_bench_allreduce(lat._h, 200, C.byref(us)))
-        t = torch.tensor(list(ph) + [us.value], dtype=torch.float64)
+        st1 = lq.lib.lib().lqcd_bench_halo_phases(D._h, y._h, b._h, 0, 20, ph)     # diagnostics must never cost the bench line:
+        barrier()                                                                  # a failing rank reports NaN and still joins
+        st2 = lq.lib.lib().lqcd_bench_allreduce(lat._h, 200, C.byref(us))          # the reductions below
+        vals = (list(ph) if st1 == 0 else [float("nan")] * 6) + [us.value if st2 == 0 else float("nan")]
+        t = torch.tensor(vals, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        v = [float(z) for z in t]
+        v = [None if float(z) != float(z) else float(z) for z in t]   # NaN (a failed diagnostic) -> null, keeps the line valid JSON
         out["halo_phases_ms_max_over_ranks"] = {"pack": v[0], "interior": v[1], "exchange_after_pack": v[2],
                                                 "idle_wait_for_exchange": v[3], "exterior": v[4], "total_synchronised": v[5]}
         out["allreduce_latency_us"] = v[6]
@@ -171,6 +172,7 @@ def main():
     # ---- secondary (outside the timed region, not part of `value`): the opt-in 12-real link compression (rows 0,1 stored, row 2
     # rebuilt; only for links unitary to 1e-14 -- the hot start is).  Same operator, 768 instead of 960 bytes moved per site.
     if world == 1 and not force_dist:
+      try:
         lat.set_param("gauge_recon", 12)
         ms12 = lq.bench_dslash(D, y, b, warm=20, reps=args.dslash_reps)
         msi12 = lq.bench_cg(D, x, b, warm=5, niter=50)
@@ -179,10 +181,14 @@ def main():
                                       "moved_bytes_per_site": 768, "moved_GBps": 768 * Vloc / (ms12 * 1e-3) / 1e9,
                                       "frac_of_peak_by_960B_accounting": WILSON_BYTES_PER_SITE * Vloc / (ms12 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "cg_iters_per_s": 1e3 / msi12}
+      except Exception as e:                               # secondary numbers never cost the bench line
+        out["gauge_recon12_optin"] = {"error": str(e)}
+      finally:
         lat.set_param("gauge_recon", 18)
 
     # ---- secondary (outside the timed region, not part of `value`): time to solution r.r < 1e-16, fp64 CG vs mixed-precision CG
     if world == 1 and not force_dist:
+      try:
         D.eps_CG = 1e-16
         A = lq.DdagD_operator(D)
         tts = {}
@@ -196,6 +202,8 @@ def main():
                                          "mixed_cg_ms": tts["mixed"][0], "mixed_inner_iters": tts["mixed"][1][0],
                                          "mixed_outer_steps": tts["mixed"][1][1], "mixed_true_rr": tts["mixed"][1][2],
                                          "speedup": tts["fp64"][0] / tts["mixed"][0]}
+      except Exception as e:
+        out["time_to_solution_1e-16"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
