@@ -126,6 +126,11 @@ int lqcd_scale(double ar, double ai, lqcd_spinor_t x);
 int lqcd_op_create(lqcd_ctx_t ctx, lqcd_op_t* op, int kind, lqcd_gauge_t g, double kappa_or_mass, double r,
                    const int bc[4]);
 int lqcd_op_destroy(lqcd_op_t op);
+/* Dirac_operator = "WilsonClover", Clover_coefficient (src/system/parameter_structs.jl:125, test/test_wilsonclover.toml:9; the
+ * reference rejects the operator, universe.jl:129-131, so this is the textbook definition): D_sw = D + i kappa c_sw sum_{mu<nu}
+ * sigma_{mu nu} F_{mu nu}.  The term follows the links of the operator's gauge field; csw = 0 switches it off.  Supported by
+ * lqcd_op_apply / _DdagD, the CG, BiCGStab and multi-shift solvers on unpartitioned lattices. */
+int lqcd_op_set_clover(lqcd_op_t op, double csw);
 int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g);   /* the D(U) rebind idiom (unusedfiles/measure_chiral_condensate.jl:173) */
 /* mul!(y, D, x) / mul!(y, D', x) on FULL spinors */
 int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger);

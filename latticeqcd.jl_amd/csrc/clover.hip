@@ -1,0 +1,215 @@
+// clover.hip -- the clover (Sheikholeslami-Wohlert) term of the Wilson operator (BASELINE.json
+// configs[3] "Wilson-clover"; parameter names of the reference: Dirac_operator = "WilsonClover", Clover_coefficient,
+// /root/reference/src/system/parameter_structs.jl:125, test/test_wilsonclover.toml:9).  The reference itself rejects this
+// operator (src/system/universe.jl:129-131), so the definition is the textbook one (Luscher et al., hep-lat/9605038):
+//     D_sw = 1 - kappa H + A - 1,   A(x) = 1 + i kappa c_sw sum_{mu<nu} sigma_{mu nu} F_{mu nu}(x),
+//     sigma_{mu nu} = (i/2)[g_mu, g_nu],  F = (Q - Q^+)/8,  Q = the four plaquette loops around x in the mu-nu plane.
+// sigma commutes with gamma5, so in the chiral basis chi_(+-) = (psi_upper -+ psi_lower)/sqrt2 (gamma5 = -offdiag(1,1) here) A is
+// two Hermitian 6x6 blocks: 72 reals = 576 B/site, stored packed as 36 double2 per site,
+//     [parity][chunk][36][64]:  block b at 18 b:  3 double2 = the 6 real diagonals, then the 15 upper-triangle entries (i < j).
+// The term is applied as its own streaming pass tmp = A x (read 192 + 576, write 192 B/site) feeding the stencil's diagonal
+// input (out = tmp - kappa H x): 960 B/site on top of the Dslash's 960; folding it into the stencil epilogue (compulsory
+// 1536 B/site in total) is the obvious next step.
+#include "lqcd_internal.h"
+
+#include <complex>
+
+namespace lqcd {
+
+struct CloverTables {
+    double sr[6][2][2][2], si[6][2][2][2];   // sigma^b_plane[s][s'] (real, imaginary), b = 0: chi_+ block, 1: chi_- block
+};
+
+__host__ __device__ inline size_t clover_off(const Geom& g, int p, int i) { return (((size_t)p * g.nch + (size_t)(i >> 6)) * 36) * 64 + (i & 63); }
+size_t clover_elems(const Geom& g) { return (size_t)2 * g.nch * 36 * 64; }
+
+__device__ __forceinline__ void ldm(cd (&u)[9], const double2* __restrict__ U, const Geom& g, const int (&c)[4], int mu) {
+    const int p = (c[0] + c[1] + c[2] + c[3]) & 1;
+    const double2* b = U + glink_off(g, p, mu, coords_to_cb(g, c));
+    const int Gs = glink_stride(g);
+#pragma unroll
+    for (int e = 0; e < 9; e++) u[e] = ld(b + (size_t)e * Gs);
+}
+// C = op(A) op(B), op = identity or dagger
+template <bool DA, bool DB>
+__device__ __forceinline__ void mmx(cd (&C)[9], const cd (&A)[9], const cd (&B)[9]) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            cd t = mk(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                cd x = DA ? mk(A[k * 3 + a].re, -A[k * 3 + a].im) : A[a * 3 + k];
+                cd y = DB ? mk(B[b * 3 + k].re, -B[b * 3 + k].im) : B[k * 3 + b];
+                cfma(t, x, y);
+            }
+            C[a * 3 + b] = t;
+        }
+}
+__device__ __forceinline__ void step(int (&d)[4], const Geom& g, int mu, int dir) {
+    d[mu] += dir;
+    if (d[mu] == g.L[mu]) d[mu] = 0;
+    if (d[mu] < 0) d[mu] = g.L[mu] - 1;
+}
+
+// one thread per site: six field-strength matrices, then the two packed chiral blocks
+__global__ __launch_bounds__(64) void clover_build_kernel(Geom g, const double2* __restrict__ U, double2* __restrict__ clov, double coef, CloverTables tb) {
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (i >= g.Vh) return;
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    // blk[b][r][q] for r <= q: diagonal real, upper triangle complex
+    cd blk[2][6][6];
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) blk[b][r][q] = mk(r == q ? 1.0 : 0.0, 0.0);
+    int plane = 0;
+    for (int mu = 0; mu < 4; mu++)
+        for (int nu = mu + 1; nu < 4; nu++, plane++) {
+            cd A[9], B[9], C[9], D[9], t1[9], t2[9], t3[9], Q[9];
+            int xm[4] = {c[0], c[1], c[2], c[3]}, xn[4] = {c[0], c[1], c[2], c[3]}, xpm[4] = {c[0], c[1], c[2], c[3]}, xpn[4] = {c[0], c[1], c[2], c[3]};
+            step(xm, g, mu, -1); step(xn, g, nu, -1); step(xpm, g, mu, 1); step(xpn, g, nu, 1);
+            int xmpn[4] = {xm[0], xm[1], xm[2], xm[3]}, xmn[4] = {xm[0], xm[1], xm[2], xm[3]}, xnpm[4] = {xn[0], xn[1], xn[2], xn[3]};
+            step(xmpn, g, nu, 1); step(xmn, g, nu, -1); step(xnpm, g, mu, 1);
+            // 1: U_mu(x) U_nu(x+mu) U_mu^+(x+nu) U_nu^+(x)
+            ldm(A, U, g, c, mu); ldm(B, U, g, xpm, nu); ldm(C, U, g, xpn, mu); ldm(D, U, g, c, nu);
+            mmx<false, false>(t1, A, B); mmx<false, true>(t2, t1, C); mmx<false, true>(Q, t2, D);
+            // 2: U_nu(x) U_mu^+(x-mu+nu) U_nu^+(x-mu) U_mu(x-mu)
+            ldm(A, U, g, c, nu); ldm(B, U, g, xmpn, mu); ldm(C, U, g, xm, nu); ldm(D, U, g, xm, mu);
+            mmx<false, true>(t1, A, B); mmx<false, true>(t2, t1, C); mmx<false, false>(t3, t2, D);
+#pragma unroll
+            for (int e = 0; e < 9; e++) Q[e] = Q[e] + t3[e];
+            // 3: U_mu^+(x-mu) U_nu^+(x-mu-nu) U_mu(x-mu-nu) U_nu(x-nu)
+            ldm(A, U, g, xm, mu); ldm(B, U, g, xmn, nu); ldm(C, U, g, xmn, mu); ldm(D, U, g, xn, nu);
+            mmx<true, true>(t1, A, B); mmx<false, false>(t2, t1, C); mmx<false, false>(t3, t2, D);
+#pragma unroll
+            for (int e = 0; e < 9; e++) Q[e] = Q[e] + t3[e];
+            // 4: U_nu^+(x-nu) U_mu(x-nu) U_nu(x+mu-nu) U_mu^+(x)
+            ldm(A, U, g, xn, nu); ldm(B, U, g, xn, mu); ldm(C, U, g, xnpm, nu); ldm(D, U, g, c, mu);
+            mmx<true, false>(t1, A, B); mmx<false, false>(t2, t1, C); mmx<false, true>(t3, t2, D);
+#pragma unroll
+            for (int e = 0; e < 9; e++) Q[e] = Q[e] + t3[e];
+            // F = (Q - Q^+)/8 ;  blk_b += i coef sigma^b (x) F
+#pragma unroll
+            for (int ca = 0; ca < 3; ca++)
+#pragma unroll
+                for (int cb = 0; cb < 3; cb++) {
+                    const cd F = mk(0.125 * (Q[ca * 3 + cb].re - Q[cb * 3 + ca].re), 0.125 * (Q[ca * 3 + cb].im + Q[cb * 3 + ca].im));
+                    const cd iF = mk(-coef * F.im, coef * F.re);      // i coef F
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int s = 0; s < 2; s++)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; s2++) {
+                                const int r = s * 3 + ca, q = s2 * 3 + cb;
+                                if (r <= q) cfma(blk[b][r][q], mk(tb.sr[plane][b][s][s2], tb.si[plane][b][s][s2]), iF);
+                            }
+                }
+        }
+    double2* o = clov + clover_off(g, p, i);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) st(o + (size_t)(18 * b + k) * 64, mk(blk[b][2 * k][2 * k].re, blk[b][2 * k + 1][2 * k + 1].re));
+        int e = 3;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int q = r + 1; q < 6; q++, e++) st(o + (size_t)(18 * b + e) * 64, blk[b][r][q]);
+    }
+}
+
+// out = A in on FULL Wilson spinors (one thread per site)
+__global__ __launch_bounds__(64) void clover_apply_kernel(Geom g, const double2* __restrict__ clov, const double2* __restrict__ in0,
+                                                           const double2* __restrict__ in1, double2* __restrict__ out0, double2* __restrict__ out1) {
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (i >= g.Vh) return;
+    const int Vs = sp_stride(g);
+    const double2* __restrict__ x = (p ? in1 : in0) + sp_off(12, i);
+    double2* __restrict__ y = (p ? out1 : out0) + sp_off(12, i);
+    const double2* __restrict__ a = clov + clover_off(g, p, i);
+    cd psi[12], res[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) psi[j] = ld(x + (size_t)j * Vs);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const double sg = b == 0 ? -1.0 : 1.0;          // chi_+ = upper - lower, chi_- = upper + lower (normalised by the 1/2 below)
+        cd chi[6], ych[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) chi[k] = mk(psi[k].re + sg * psi[6 + k].re, psi[k].im + sg * psi[6 + k].im);
+        double dg[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const cd d = ld(a + (size_t)(18 * b + k) * 64); dg[2 * k] = d.re; dg[2 * k + 1] = d.im; }
+#pragma unroll
+        for (int r = 0; r < 6; r++) ych[r] = mk(dg[r] * chi[r].re, dg[r] * chi[r].im);
+        int e = 3;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int q = r + 1; q < 6; q++, e++) {
+                const cd m = ld(a + (size_t)(18 * b + e) * 64);
+                cfma(ych[r], m, chi[q]);          // upper triangle
+                cfma_conj(ych[q], m, chi[r]);     // lower triangle = conjugate
+            }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if (b == 0) { res[k] = mk(0.5 * ych[k].re, 0.5 * ych[k].im); res[6 + k] = mk(-0.5 * ych[k].re, -0.5 * ych[k].im); }
+            else { res[k] = mk(res[k].re + 0.5 * ych[k].re, res[k].im + 0.5 * ych[k].im); res[6 + k] = mk(res[6 + k].re + 0.5 * ych[k].re, res[6 + k].im + 0.5 * ych[k].im); }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) st(y + (size_t)j * Vs, res[j]);
+}
+
+// sigma_{mu nu} = (i/2)[g_mu, g_nu] in the chiral basis e^+_s = (e_s - e_{s+2})/sqrt2, e^-_s = (e_s + e_{s+2})/sqrt2
+static int clover_tables(CloverTables& tb) {
+    typedef std::complex<double> cx;
+    cx G[4][4][4] = {};
+    const cx ipow[4] = {cx(1, 0), cx(0, 1), cx(-1, 0), cx(0, -1)};
+    for (int mu = 0; mu < 3; mu++)
+        for (int a = 0; a < 4; a++) G[mu][a][PERM[mu][a]] = ipow[GK[mu][a] & 3];
+    for (int a = 0; a < 4; a++) G[3][a][a] = a < 2 ? 1.0 : -1.0;
+    int plane = 0;
+    for (int mu = 0; mu < 4; mu++)
+        for (int nu = mu + 1; nu < 4; nu++, plane++) {
+            cx S[4][4];
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) {
+                    cx t = 0;
+                    for (int k = 0; k < 4; k++) t += G[mu][a][k] * G[nu][k][b] - G[nu][a][k] * G[mu][k][b];
+                    S[a][b] = cx(0, 0.5) * t;
+                }
+            for (int s = 0; s < 2; s++)
+                for (int t = 0; t < 2; t++) {
+                    const cx pp = 0.5 * (S[s][t] - S[s][t + 2] - S[s + 2][t] + S[s + 2][t + 2]);
+                    const cx mm = 0.5 * (S[s][t] + S[s][t + 2] + S[s + 2][t] + S[s + 2][t + 2]);
+                    const cx pm = 0.5 * (S[s][t] + S[s][t + 2] - S[s + 2][t] - S[s + 2][t + 2]);   // <e^+_s| sigma |e^-_t> must vanish
+                    if (std::abs(pm) > 1e-14) { set_error("clover: sigma does not commute with gamma5 in this basis"); return LQCD_ERR_ARG; }
+                    tb.sr[plane][0][s][t] = pp.real(); tb.si[plane][0][s][t] = pp.imag();
+                    tb.sr[plane][1][s][t] = mm.real(); tb.si[plane][1][s][t] = mm.imag();
+                }
+        }
+    return LQCD_OK;
+}
+
+int clover_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, double2* clov, double kappa, double csw) {
+    CloverTables tb;
+    LQCHK(clover_tables(tb));
+    hipLaunchKernelGGL(clover_build_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, U->data, clov, kappa * csw, tb);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+int clover_apply(lqcd_ctx_s* c, const double2* clov, lqcd_spinor_s* out, lqcd_spinor_s* in) {
+    hipLaunchKernelGGL(clover_apply_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, clov, spinor_block(in, 0), spinor_block(in, 1),
+                       spinor_block(out, 0), spinor_block(out, 1));
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+}  // namespace lqcd

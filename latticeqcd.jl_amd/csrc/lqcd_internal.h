@@ -301,6 +301,11 @@ struct lqcd_op_s {
     double km;  // kappa or mass
     double r;
     int bc[4];
+    // clover term (clover.hip): csw != 0 turns D into D_sw = D + (A - 1); A is rebuilt lazily when the links change
+    double csw = 0.0;
+    double2* clover = nullptr;          // packed chiral blocks, [parity][chunk][36][64]
+    uint64_t clover_version = 0;        // gauge version A was built from
+    lqcd_spinor_s* clover_tmp = nullptr;   // A x, the diagonal input of the stencil
 };
 
 namespace lqcd {
@@ -398,6 +403,11 @@ int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n);
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n);
 int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0);
 int stream_grid(lqcd_ctx_s* c, size_t n);
+
+// clover.hip
+size_t clover_elems(const Geom& g);
+int clover_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, double2* clov, double kappa, double csw);
+int clover_apply(lqcd_ctx_s* c, const double2* clov, lqcd_spinor_s* out, lqcd_spinor_s* in);
 
 // fields.hip
 double2* spinor_block(lqcd_spinor_s* s, int p);

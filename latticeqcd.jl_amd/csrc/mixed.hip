@@ -175,6 +175,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
                b->subset == LQCD_FULL && x != b && maxiter >= 0,
            "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
     lqcd_ctx_s* c = op->ctx;
+    if (op->csw != 0.0) { set_error("lqcd_solve_mixed_cg_DdagD: not available for the Wilson-clover operator yet (no fp32 clover term)"); return LQCD_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(c->device));
     if (inner_tol <= 0.0) inner_tol = 1e-4;
     const size_t n = x->elems, ng = op->gauge->elems;

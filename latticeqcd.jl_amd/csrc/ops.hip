@@ -114,6 +114,16 @@ StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in,
     s.parity_mode = 2;
     s.norm_partial = nullptr;
     s.gauge12 = recon12_links(op);
+    if (op->csw != 0.0 && op->clover && op->clover_tmp) {
+        // Wilson-clover: the diagonal input of the stencil is A in (enqueued here, in front of the stencil every caller launches
+        // next); A follows the links lazily.  A failed launch surfaces at the caller's next HIP check.
+        if (op->clover_version != op->gauge->version) {
+            (void)clover_build(op->ctx, op->gauge, op->clover, op->km, op->csw);
+            op->clover_version = op->gauge->version;
+        }
+        (void)clover_apply(op->ctx, op->clover, op->clover_tmp, in);
+        fill_blocks(s.xin, op->clover_tmp);
+    }
     return s;
 }
 
@@ -587,10 +597,42 @@ extern "C" int lqcd_op_create(lqcd_ctx_t ctx, lqcd_op_t* op, int kind, lqcd_gaug
     *op = o;
     return LQCD_OK;
 }
-extern "C" int lqcd_op_destroy(lqcd_op_t op) { delete op; return LQCD_OK; }
+extern "C" int lqcd_op_destroy(lqcd_op_t op) {
+    if (!op) return LQCD_OK;
+    (void)hipFree(op->clover);
+    if (op->clover_tmp) lqcd_spinor_destroy(op->clover_tmp);
+    delete op;
+    return LQCD_OK;
+}
+
+// Dirac_operator = "WilsonClover", Clover_coefficient (parameter_structs.jl:125; test/test_wilsonclover.toml:9): D_sw = D + (A - 1),
+// A = 1 + i kappa c_sw sum_{mu<nu} sigma_{mu nu} F_{mu nu} (clover.hip).  csw = 0 switches the term off again.
+extern "C" int lqcd_op_set_clover(lqcd_op_t op, double csw) {
+    ARGCHK(op, "lqcd_op_set_clover: null argument");
+    ARGCHK(op->kind == LQCD_WILSON, "lqcd_op_set_clover: the clover term belongs to the Wilson operator");
+    lqcd_ctx_s* c = op->ctx;
+    if (csw != 0.0 && any_partitioned(c)) {
+        set_error("lqcd_op_set_clover: not available on a partitioned lattice yet (the clover leaves need link halos)");
+        return LQCD_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    op->csw = csw;
+    if (csw == 0.0) return LQCD_OK;
+    if (!op->clover) HIPCHK(hipMalloc((void**)&op->clover, clover_elems(c->geom) * sizeof(double2)));
+    if (!op->clover_tmp) LQCHK(lqcd_spinor_create(c, &op->clover_tmp, LQCD_WILSON, LQCD_FULL));
+    LQCHK(clover_build(c, op->gauge, op->clover, op->km, csw));
+    op->clover_version = op->gauge->version;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+static int no_clover(lqcd_op_s* op, const char* who) {
+    if (op->csw != 0.0) { set_error(std::string(who) + ": not available for the Wilson-clover operator yet"); return LQCD_ERR_UNSUPPORTED; }
+    return LQCD_OK;
+}
 extern "C" int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g) {
     ARGCHK(op && g && g->ctx == op->ctx, "lqcd_op_set_gauge: bad gauge field");
     op->gauge = g;
+    op->clover_version = 0;   // another field: the clover term is rebuilt at the next application
     return LQCD_OK;
 }
 
@@ -666,6 +708,7 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
                                       double* final_rr) {
     LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab_eo"));
     ARGCHK(op->kind == LQCD_WILSON, "lqcd_solve_bicgstab_eo: Wilson only");
+    LQCHK(no_clover(op, "lqcd_solve_bicgstab_eo (needs the inverse of the even-even clover block)"));
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     apply_bc(c, op->bc);
@@ -882,6 +925,7 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
 // G_mu(n) = "U dS_f/dU" from resident X = (D^+D)^-1 eta and Y = D X (force.hip); out is a link-shaped field
 extern "C" int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y) {
     LQCHK(check_full(op, X, Y, "lqcd_fermion_force"));
+    LQCHK(no_clover(op, "lqcd_fermion_force (the derivative of the clover term is not built)"));
     ARGCHK(out && out->ctx == op->ctx && out != op->gauge, "lqcd_fermion_force: out must be a gauge-shaped field of the same context, not the operator's links");
     LQCHK(force_check(op, "lqcd_fermion_force"));
     lqcd_ctx_s* c = op->ctx;

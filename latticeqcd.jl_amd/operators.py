@@ -23,7 +23,7 @@ import numpy as np
 from . import lib as _l
 from .lib import EVEN, FULL, ODD, STAGGERED, WILSON, LQCDError, NotConverged, check  # noqa: F401
 
-_KIND = {"wilson": WILSON, "staggered": STAGGERED}
+_KIND = {"wilson": WILSON, "staggered": STAGGERED, "wilsonclover": WILSON}
 
 
 def _ptr(a):
@@ -279,6 +279,9 @@ class Dirac_operator:
             self._h, self._owner = C.c_void_p(), True
             check(_l.lib().lqcd_op_create(self.lattice._h, C.byref(self._h), self.kind, U._h, C.c_double(self.km),
                                           C.c_double(self.r), _l.i4(self.bc)))
+            if key == "wilsonclover":     # Dirac_operator = "WilsonClover", Clover_coefficient (parameter_structs.jl:125)
+                self.csw = float(self.params.get("Clover_coefficient", 1.5612))
+                check(_l.lib().lqcd_op_set_clover(self._h, C.c_double(self.csw)))
 
     def __call__(self, U):
         check(_l.lib().lqcd_op_set_gauge(self._h, U._h))

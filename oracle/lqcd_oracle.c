@@ -785,3 +785,133 @@ void orc_link_update(double* Ud, const double* Pd, double dt, const int L[4]) {
                 for (int b = 0; b < 3; b++) U[UIDX(V, mu, s, a, b)] = T[a][b];
         }
 }
+
+/* ------------------------------------------------------------------ clover (Sheikholeslami-Wohlert) term, SURVEY.md 8(f) rank 2
+ * BASELINE.json configs[3] names a Wilson-clover operator; the reference itself rejects it (src/system/universe.jl:129-131,
+ * test/runtests.jl:153-158 commented out), so there is NO reference behaviour to match: this is the textbook definition
+ * (Luscher, Sint, Sommer, Weisz, hep-lat/9605038 eqs 2.5-2.7) in the hopping normalisation used above,
+ *     D_sw = 1 - kappa H + i kappa c_sw sum_{mu<nu} sigma_{mu nu} F_{mu nu},
+ *     sigma_{mu nu} = (i/2)[g_mu, g_nu],   F_{mu nu}(x) = (Q_{mu nu}(x) - Q_{mu nu}(x)^+)/8,
+ *     Q_{mu nu}(x) = sum of the four plaquette loops in the mu-nu plane that start and end at x (the "clover"),
+ * and is checked through identities only (Hermiticity, gamma5-hermiticity, gauge covariance, A = 1 on a pure-gauge field).
+ * clov holds the full 12x12 matrix A(x) = 1 + i kappa c_sw sum sigma F per site, index (s*3+c) row-major. */
+static void link_dag(cplx D[3][3], cplx A[3][3]) {
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) D[a][b] = conj(A[b][a]);
+}
+static void clover_leaves(cplx Q[3][3], const cplx* U, const int L[4], long V, const int c[4], int mu, int nu) {
+    int w;
+    cplx A[3][3], B[3][3], C[3][3], D[3][3], Ad[3][3], Bd[3][3], Cd[3][3], Dd[3][3], T1[3][3], T2[3][3], T3[3][3];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) Q[a][b] = 0;
+    long x = site_of(L, c[0], c[1], c[2], c[3]);
+    int cm[4] = {c[0], c[1], c[2], c[3]}, cn[4] = {c[0], c[1], c[2], c[3]}, cmn[4];
+    cm[mu] = (c[mu] - 1 + L[mu]) % L[mu];                 /* x - mu */
+    cn[nu] = (c[nu] - 1 + L[nu]) % L[nu];                 /* x - nu */
+    for (int k = 0; k < 4; k++) cmn[k] = cm[k];
+    cmn[nu] = (c[nu] - 1 + L[nu]) % L[nu];                /* x - mu - nu */
+    long xpm = neigh(L, c, mu, 1, &w), xpn = neigh(L, c, nu, 1, &w);
+    long xmm = site_of(L, cm[0], cm[1], cm[2], cm[3]), xmn = site_of(L, cn[0], cn[1], cn[2], cn[3]);
+    long xmmpn = neigh(L, cm, nu, 1, &w), xmnpm = neigh(L, cn, mu, 1, &w), xmmmn = site_of(L, cmn[0], cmn[1], cmn[2], cmn[3]);
+#define ADDQ(M) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Q[a][b] += M[a][b]
+    /* 1: U_mu(x) U_nu(x+mu) U_mu^+(x+nu) U_nu^+(x) */
+    load_link(A, U, V, mu, x); load_link(B, U, V, nu, xpm); load_link(C, U, V, mu, xpn); load_link(D, U, V, nu, x);
+    mm(T1, A, B); mmd(T2, T1, C); mmd(T3, T2, D); ADDQ(T3);
+    /* 2: U_nu(x) U_mu^+(x-mu+nu) U_nu^+(x-mu) U_mu(x-mu) */
+    load_link(A, U, V, nu, x); load_link(B, U, V, mu, xmmpn); load_link(C, U, V, nu, xmm); load_link(D, U, V, mu, xmm);
+    mmd(T1, A, B); mmd(T2, T1, C); mm(T3, T2, D); ADDQ(T3);
+    /* 3: U_mu^+(x-mu) U_nu^+(x-mu-nu) U_mu(x-mu-nu) U_nu(x-nu) */
+    load_link(A, U, V, mu, xmm); load_link(B, U, V, nu, xmmmn); load_link(C, U, V, mu, xmmmn); load_link(D, U, V, nu, xmn);
+    link_dag(Ad, A); link_dag(Bd, B); mm(T1, Ad, Bd); mm(T2, T1, C); mm(T3, T2, D); ADDQ(T3);
+    /* 4: U_nu^+(x-nu) U_mu(x-nu) U_nu(x+mu-nu) U_mu^+(x) */
+    load_link(A, U, V, nu, xmn); load_link(B, U, V, mu, xmn); load_link(C, U, V, nu, xmnpm); load_link(D, U, V, mu, x);
+    link_dag(Ad, A); mm(T1, Ad, B); mm(T2, T1, C); mmd(T3, T2, D); ADDQ(T3);
+#undef ADDQ
+    (void)Cd; (void)Dd; (void)Bd;
+}
+
+void orc_clover_build(double* clovd, const double* Ud, const int L[4], double kappa, double csw) {
+    const cplx* U = (const cplx*)Ud;
+    cplx* clov = (cplx*)clovd;
+    long V = vol(L);
+    cplx G[4][4][4], S[4][4];
+    for (int nu = 0; nu < 4; nu++) gamma_mat(nu, G[nu]);
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    int c[4] = {x, y, z, t};
+                    long s = site_of(L, x, y, z, t);
+                    cplx* A = clov + 144 * s;
+                    for (int i = 0; i < 144; i++) A[i] = 0;
+                    for (int i = 0; i < 12; i++) A[i * 12 + i] = 1.0;
+                    for (int mu = 0; mu < 4; mu++)
+                        for (int nu = mu + 1; nu < 4; nu++) {
+                            cplx Q[3][3], F[3][3];
+                            clover_leaves(Q, U, L, V, c, mu, nu);
+                            for (int a = 0; a < 3; a++)
+                                for (int b = 0; b < 3; b++) F[a][b] = (Q[a][b] - conj(Q[b][a])) / 8.0;
+                            for (int a = 0; a < 4; a++)       /* sigma = (i/2)(g_mu g_nu - g_nu g_mu) */
+                                for (int b = 0; b < 4; b++) {
+                                    cplx t1 = 0;
+                                    for (int k = 0; k < 4; k++) t1 += G[mu][a][k] * G[nu][k][b] - G[nu][a][k] * G[mu][k][b];
+                                    S[a][b] = 0.5 * I * t1;
+                                }
+                            for (int sa = 0; sa < 4; sa++)
+                                for (int sb = 0; sb < 4; sb++)
+                                    for (int ca = 0; ca < 3; ca++)
+                                        for (int cb = 0; cb < 3; cb++)
+                                            A[(sa * 3 + ca) * 12 + (sb * 3 + cb)] += I * kappa * csw * S[sa][sb] * F[ca][cb];
+                        }
+                }
+}
+
+/* out = D_sw in = Wilson D in + (A - 1) in   (dagger: A is Hermitian and commutes with gamma5, so D_sw^+ = gamma5 D_sw gamma5) */
+void orc_wilson_clover_D(double* outd, const double* Ud, const double* clovd, const double* ind, const int L[4], double kappa,
+                         double r, const int bc[4], int dagger) {
+    long V = vol(L);
+    orc_wilson_D(outd, Ud, ind, L, kappa, r, bc, dagger);
+    cplx* out = (cplx*)outd;
+    const cplx* in = (const cplx*)ind;
+    const cplx* clov = (const cplx*)clovd;
+    for (long s = 0; s < V; s++) {
+        const cplx* A = clov + 144 * s;
+        for (int i = 0; i < 12; i++) {
+            cplx t = 0;
+            for (int j = 0; j < 12; j++) t += (A[i * 12 + j] - (i == j ? 1.0 : 0.0)) * in[PIDX(V, s, j % 3, j / 3)];
+            out[PIDX(V, s, i % 3, i / 3)] += t;
+        }
+    }
+}
+
+/* CG on D_sw^+ D_sw (same loop and stopping rule as orc_cg_DdagD) */
+int orc_cg_clover(double* xd, const double* U, const double* clov, const double* bd, const int L[4], double kappa, double r,
+                  const int bc[4], double eps, int maxiter, int* iters, double* final_rr) {
+    long n = 12 * vol(L);
+    cplx *x = (cplx*)xd, *res = malloc(sizeof(cplx) * n), *p = malloc(sizeof(cplx) * n), *q = malloc(sizeof(cplx) * n),
+         *tmp = malloc(sizeof(cplx) * n);
+    const cplx* b = (const cplx*)bd;
+    int status = 1, it = 0;
+    orc_wilson_clover_D((double*)tmp, U, clov, (const double*)x, L, kappa, r, bc, 0);
+    orc_wilson_clover_D((double*)q, U, clov, (const double*)tmp, L, kappa, r, bc, 1);
+    for (long i = 0; i < n; i++) res[i] = b[i] - q[i];
+    memcpy(p, res, sizeof(cplx) * n);
+    double rnorm = norm2(res, n);
+    if (rnorm < eps) status = 0;
+    for (it = 1; status && it <= maxiter; it++) {
+        orc_wilson_clover_D((double*)tmp, U, clov, (const double*)p, L, kappa, r, bc, 0);
+        orc_wilson_clover_D((double*)q, U, clov, (const double*)tmp, L, kappa, r, bc, 1);
+        cplx alpha = rnorm / cdot(p, q, n);
+        for (long i = 0; i < n; i++) { x[i] += alpha * p[i]; res[i] -= alpha * q[i]; }
+        double c3 = norm2(res, n);
+        if (c3 < eps) { rnorm = c3; status = 0; break; }
+        double beta = c3 / rnorm;
+        for (long i = 0; i < n; i++) p[i] = beta * p[i] + res[i];
+        rnorm = c3;
+    }
+    if (it > maxiter) it = maxiter;
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rnorm;
+    free(res); free(p); free(q); free(tmp);
+    return status;
+}

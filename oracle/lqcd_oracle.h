@@ -97,6 +97,14 @@ void orc_momentum_add_ta(double* P, double c, const double* G, const int L[4]); 
 double orc_momentum_action(const double* P, const int L[4]);                        /* K = -sum tr P^2 */
 void orc_link_update(double* U, const double* P, double dt, const int L[4]);        /* U <- exp(dt P) U */
 
+/* clover term (no reference behaviour exists -- textbook definition, see lqcd_oracle.c):
+ * clov[V][12][12] = A(x) = 1 + i kappa c_sw sum_{mu<nu} sigma_{mu nu} F_{mu nu}(x), row-major in (s*3+c) */
+void orc_clover_build(double* clov, const double* U, const int L[4], double kappa, double csw);
+void orc_wilson_clover_D(double* out, const double* U, const double* clov, const double* in, const int L[4], double kappa,
+                         double r, const int bc[4], int dagger);
+int orc_cg_clover(double* x, const double* U, const double* clov, const double* b, const int L[4], double kappa, double r,
+                  const int bc[4], double eps, int maxiter, int* iters, double* final_rr);
+
 /* fixed-length CG window with the exit test disabled (timing only): runs exactly niter iterations */
 void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4],
                         double kappa_or_mass, double r, const int bc[4], int niter);

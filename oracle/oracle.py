@@ -196,6 +196,27 @@ def gaussian_momenta(L, seed):
     return np.ascontiguousarray(np.swapaxes(P, -1, -2))
 
 
+def clover_build(U, L, kappa, csw):
+    """A(x) = 1 + i kappa c_sw sum_{mu<nu} sigma_{mu nu} F_{mu nu}(x): array [t,z,y,x,12,12], row/column index s*3+c."""
+    A = np.zeros((L[3], L[2], L[1], L[0], 12, 12), dtype=np.complex128)
+    lib().orc_clover_build(_p(A), _p(U), _i4(L), C.c_double(kappa), C.c_double(csw))
+    return A
+
+
+def wilson_clover_D(U, A, psi, L, kappa, r=1.0, bc=(1, 1, 1, -1), dagger=False):
+    out = np.empty_like(psi)
+    lib().orc_wilson_clover_D(_p(out), _p(U), _p(A), _p(psi), _i4(L), C.c_double(kappa), C.c_double(r), _i4(bc), int(dagger))
+    return out
+
+
+def cg_clover(U, A, b, L, kappa, r=1.0, bc=(1, 1, 1, -1), eps=1e-19, maxiter=3000):
+    x = np.zeros_like(b)
+    it, rr = C.c_int(0), C.c_double(0)
+    st = lib().orc_cg_clover(_p(x), _p(U), _p(A), _p(b), _i4(L), C.c_double(kappa), C.c_double(r), _i4(bc), C.c_double(eps),
+                             int(maxiter), C.byref(it), C.byref(rr))
+    return x, it.value, rr.value, st
+
+
 def bicgstab(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000, x0=None):
     x = np.zeros_like(b) if x0 is None else x0.copy()
     it, rr = C.c_int(0), C.c_double(0)

@@ -1,0 +1,70 @@
+"""GPU parity of the Wilson-clover operator against the oracle's textbook definition."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+KAPPA, CSW = 0.141139, 1.5612
+BC = (1, 1, 1, -1)
+
+
+@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2)])
+def test_wilson_clover_matches_oracle(lq, orc, L):
+    assert lq.lib.device_count() > 0
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 501)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": CSW, "boundarycondition": BC,
+                                    "eps_CG": 1e-19})
+    A = orc.clover_build(Uh, L, KAPPA, CSW)
+    psi = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 502)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    y = x.similar()
+    for dag in (False, True):
+        lq.mul_(y, D.adjoint() if dag else D, x)
+        assert rel_err(y.download(), orc.wilson_clover_D(Uh, A, psi, L, KAPPA, 1.0, BC, dag)) < 1e-13
+    # D'D and the CG on it
+    lq.mul_(y, lq.DdagD_operator(D), x)
+    ref = orc.wilson_clover_D(Uh, A, orc.wilson_clover_D(Uh, A, psi, L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, True)
+    assert rel_err(y.download(), ref) < 1e-13
+    sol = x.similar()
+    it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+    xo, ito, rro, st = orc.cg_clover(Uh, A, psi, L, KAPPA, 1.0, BC, eps=1e-19)
+    assert st == 0 and abs(it - ito) <= 1 and rel_err(sol.download(), xo) < 1e-9
+    # BiCGStab on D_sw
+    D.method_CG = "bicgstab"
+    lq.clear_fermion_(sol)
+    lq.solve_DinvX_(sol, D, x)
+    lq.mul_(y, D, sol)
+    lq.add_fermion_(y, -1.0, x)
+    assert lq.dot(y, y).real < 1e-18
+    # the term follows the links: new links in the same handle
+    Uh2 = orc.hot_gauge(L, 503)
+    U.upload(Uh2)
+    lq.mul_(y, D, x)
+    assert rel_err(y.download(), orc.wilson_clover_D(Uh2, orc.clover_build(Uh2, L, KAPPA, CSW), psi, L, KAPPA, 1.0, BC)) < 1e-13
+    # what is not built yet fails loudly
+    D.method_CG = "bicgstab_evenodd"
+    with pytest.raises(lq.LQCDError):
+        lq.solve_DinvX_(sol, D, x)
+    with pytest.raises(lq.LQCDError):
+        lq.solve_mixed_DinvX_(sol, lq.DdagD_operator(D), x)
+    with pytest.raises(lq.LQCDError):
+        lq.calc_UdSfdU_(lq.Gaugefields(lat), lq.FermiAction(D), U, x)
+
+
+def test_clover_coefficient_zero_is_wilson(lq, orc):
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 504)
+    U = lq.Gaugefields(lat).upload(Uh)
+    psi = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 505)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    y, z = x.similar(), x.similar()
+    Dw = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA})
+    Dc = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": 0.0})
+    lq.mul_(y, Dw, x)
+    lq.mul_(z, Dc, x)
+    assert np.array_equal(y.download(), z.download())

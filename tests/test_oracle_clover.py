@@ -1,0 +1,69 @@
+"""Oracle self-checks of the clover (Sheikholeslami-Wohlert) term -- SURVEY.md 8(f) rank 2.  The reference rejects this operator
+(src/system/universe.jl:129-131), so there is nothing to be pinned against: the textbook definition is checked through its
+defining properties."""
+import numpy as np
+import pytest
+
+KAPPA, CSW = 0.141139, 1.3
+BC = (1, 1, 1, -1)
+
+
+def _random_gauge_transform(orc, L, seed):
+    rng = np.random.default_rng(seed)
+    V = L[0] * L[1] * L[2] * L[3]
+    return orc.random_su3(rng, V).reshape(L[3], L[2], L[1], L[0], 3, 3)       # g[t,z,y,x,a,b]
+
+
+def _transform_links(U, g, L):
+    """U_mu(x) -> g(x) U_mu(x) g(x+mu)^+   (oracle layout U[mu,t,z,y,x,b,a])."""
+    out = np.empty_like(U)
+    for mu in range(4):
+        Um = np.swapaxes(U[mu], -1, -2)                       # [.., a, b]
+        gs = np.roll(g, -1, axis=3 - mu)                      # g(x+mu)
+        out[mu] = np.swapaxes(g @ Um @ gs.conj().swapaxes(-1, -2), -1, -2)
+    return out
+
+
+def test_clover_matrix_properties(orc):
+    L = (4, 4, 4, 4)
+    U = orc.hot_gauge(L, 401)
+    A = orc.clover_build(U, L, KAPPA, CSW)
+    assert np.abs(A - A.conj().swapaxes(-1, -2)).max() < 1e-14                                      # Hermitian
+    g5 = np.kron(orc.GAMMA[4], np.eye(3))
+    assert np.abs(g5 @ A @ g5 - A).max() < 1e-14                                                    # commutes with gamma5
+    assert np.abs(np.trace(A, axis1=-2, axis2=-1) - 12.0).max() < 1e-13                             # sigma F is traceless
+    assert np.abs(A - np.eye(12)).max() > 1e-2                                                      # and not trivial
+    assert np.abs(orc.clover_build(U, L, KAPPA, 0.0) - np.eye(12)).max() == 0.0                     # c_sw = 0
+    assert np.abs(orc.clover_build(orc.unit_gauge(L), L, KAPPA, CSW) - np.eye(12)).max() < 1e-15    # F = 0 on a trivial field
+    # pure gauge U_mu(x) = g(x) g(x+mu)^+ has F = 0 as well
+    g = _random_gauge_transform(orc, L, 402)
+    Upg = _transform_links(orc.unit_gauge(L), g, L)
+    assert np.abs(orc.clover_build(Upg, L, KAPPA, CSW) - np.eye(12)).max() < 1e-13
+
+
+def test_clover_operator_identities(orc):
+    L = (4, 4, 4, 4)
+    U = orc.hot_gauge(L, 403)
+    A = orc.clover_build(U, L, KAPPA, CSW)
+    a = orc.gaussian_spinor(orc.wilson_shape(L), 404)
+    b = orc.gaussian_spinor(orc.wilson_shape(L), 405)
+    Db = orc.wilson_clover_D(U, A, b, L, KAPPA, 1.0, BC)
+    Dda = orc.wilson_clover_D(U, A, a, L, KAPPA, 1.0, BC, dagger=True)
+    assert abs(np.vdot(a, Db) - np.conj(np.vdot(b, Dda))) < 1e-10 * abs(np.vdot(a, Db))            # true adjoint
+    # c_sw = 0 is the Wilson operator
+    A0 = orc.clover_build(U, L, KAPPA, 0.0)
+    assert np.array_equal(orc.wilson_clover_D(U, A0, b, L, KAPPA, 1.0, BC), orc.wilson_D(U, b, L, KAPPA, 1.0, BC))
+    # gauge covariance: D[U^g] psi^g = (D[U] psi)^g  (periodic boundary conditions so that g need not respect the twist)
+    per = (1, 1, 1, 1)
+    g = _random_gauge_transform(orc, L, 406)
+    Ug = _transform_links(U, g, L)
+    Ag = orc.clover_build(Ug, L, KAPPA, CSW)
+    rot = lambda psi: np.einsum("tzyxab,stzyxb->stzyxa", g, psi)
+    lhs = orc.wilson_clover_D(Ug, Ag, np.ascontiguousarray(rot(b)), L, KAPPA, 1.0, per)
+    rhs = rot(orc.wilson_clover_D(U, A, b, L, KAPPA, 1.0, per))
+    assert np.abs(lhs - rhs).max() < 1e-12
+    # CG on D_sw^+ D_sw: true residual
+    x, it, rr, st = orc.cg_clover(U, A, b, L, KAPPA, 1.0, BC, eps=1e-20)
+    assert st == 0
+    r = orc.wilson_clover_D(U, A, orc.wilson_clover_D(U, A, x, L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True) - b
+    assert np.vdot(r, r).real < 2e-20
