@@ -29,7 +29,7 @@ for kv in a.set:
 U = lq.Gaugefields(lat)
 lq.lib.check(lq.lib.lib().lqcd_gauge_hot_start(U._h, ctypes.c_uint64(111)))
 D = lq.Dirac_operator(U, None, {"Dirac_operator": a.kind, "κ": 0.141139, "mass": 0.5})
-kind = lq.WILSON if a.kind == "Wilson" else lq.STAGGERED
+kind = lq.STAGGERED if a.kind == "Staggered" else lq.WILSON
 b = lq.Fermionfields(lat, kind)
 lq.gauss_distribution_fermion_(b, 112)
 y = b.similar()
@@ -37,6 +37,8 @@ Dd = D.adjoint() if a.dagger else D
 ms = lq.bench_dslash(Dd, y, b, warm=a.warm, reps=a.reps)
 V = L[0] * L[1] * L[2] * L[3]
 bps, fps = (960, 1320) if kind == lq.WILSON else (672, 570)
+if a.kind == "WilsonClover":
+    bps, fps = 1536, 1824
 print("dslash %s L=%s set=%s ms=%.4f GFLOPs=%.0f algGB/s=%.0f frac=%.3f" % (a.kind, L, a.set, ms, fps * V / ms / 1e6, bps * V / ms / 1e6, bps * V / ms / 1e6 / 8000))
 if a.cg:
     x = b.similar()
