@@ -184,7 +184,9 @@ int lqcd_calc_UdSfdU(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t eta, double e
  * force field G ("U dS/dU") obeys dS/d eps[U -> exp(i eps T) U] = -2 Im tr(T G), so dP/dtau = TA(G). */
 int lqcd_gauge_copy(lqcd_gauge_t dst, lqcd_gauge_t src);                  /* substitute_U!(Uold, U) (src/updates/standardHMC.jl:45) */
 int lqcd_gauge_action(lqcd_gauge_t U, double beta, double* Sg);          /* -evaluate_GaugeAction/NC (standardHMC.jl:50) */
-int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta);     /* calc_dSdUmu! + mul!(temp, U, dSdUmu) (src/md/AbstractMD.jl:108-109): -(beta/6) U * staples; single-GPU contexts */
+int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta);     /* calc_dSdUmu! + mul!(temp, U, dSdUmu) (src/md/AbstractMD.jl:108-109): -(beta/6) U * staples.  Collective on a
+                                                                          * partitioned lattice: forward ghost links, then the lower staples of the upper faces (two RCCL steps, no corners) */
+int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us, double beta, double factor, int fuse); /* the same on an in-process PE grid (tests) */
 int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t G); /* Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131) */
 int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta); /* P_update! (AbstractMD.jl:99-118) fused: P += factor TA(gauge force), the force field is never stored */
 int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U */

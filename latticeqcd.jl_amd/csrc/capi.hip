@@ -202,6 +202,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     for (int mu = 0; mu < 4; mu++) {
         hipFree(c->send_fwd[mu]); hipFree(c->send_bwd[mu]); hipFree(c->recv_fwd[mu]); hipFree(c->recv_bwd[mu]);
         hipFree(c->force_send[mu]); hipFree(c->force_recv[mu]);
+        hipFree(c->gf_ghost[mu]); hipFree(c->gf_gsend[mu]); hipFree(c->gf_wsend[mu]); hipFree(c->gf_wrecv[mu]);
     }
     for (void* b : c->mix_buf) hipFree(b);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }

@@ -260,6 +260,8 @@ struct lqcd_ctx_s {
     // fermion-force halos (force.hip): full X and Y spinors of the lower face, allocated on first use
     double2* force_send[4] = {}, *force_recv[4] = {};
     int force_ncomp = 0;
+    // staple-force halos (md.hip): forward ghost links (+ their send buffer) and the lower-staple faces, allocated on first use
+    double2* gf_ghost[4] = {}, *gf_gsend[4] = {}, *gf_wsend[4] = {}, *gf_wrecv[4] = {};
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
     void* mix_buf[6] = {};
     size_t mix_bytes[6] = {};

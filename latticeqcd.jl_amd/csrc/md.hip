@@ -10,7 +10,9 @@
 //   every force field G obeys dS/d eps [U -> exp(i eps T) U] = -2 Im tr(T G), hence dP/dtau = TA(G) = (G - G^+)/2 - tr(.)/3.
 #include "lqcd_internal.h"
 
+#include <algorithm>
 #include <cmath>
+#include <vector>
 
 namespace lqcd {
 
@@ -68,11 +70,54 @@ __device__ __forceinline__ void shift(int (&d)[4], const Geom& g, int mu, int di
     if (d[mu] < 0) d[mu] = g.L[mu] - 1;
 }
 
-// out_mu(n) = coef * U_mu(n) * sum_{nu != mu} [ U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+  +  U_nu(n+mu-nu)^+ U_mu(n-nu)^+ U_nu(n-nu) ]
+// arguments of the staple kernels.  Partitioned lattice: ghost[lam] = the x_lam = 0 slice of all links of the +lam neighbour
+// ([parity][nu][9][Fh], fields.hip gauge_face_pack), wrecv[nu] = the lower staples W_{mu nu} of the -nu neighbour's upper face
+// ([parity of that site][mu][9][Fh]); both null on a single GPU.
+struct GFArgs {
+    Geom g;
+    const double2* U;
+    double2* out;
+    double coef, factor;
+    const double2* ghost[4];
+    const double2* wrecv[4];
+    double2* wsend[4];
+};
+
+// U_nu at the site c + dir_hat: local, or from the forward ghost slice when the step leaves the rank
+__device__ __forceinline__ void link_fwd(cd (&u)[9], const GFArgs& k, const int (&c)[4], int dir, int nu) {
+    const Geom& g = k.g;
+    int d[4] = {c[0], c[1], c[2], c[3]};
+    d[dir] += 1;
+    if (d[dir] == g.L[dir]) {
+        d[dir] = 0;
+        if (g.part[dir]) {
+            const int p = (d[0] + d[1] + d[2] + d[3]) & 1, Fh = face_half_sites(g, dir), f = coords_to_face(g, dir, d);
+            const double2* b = k.ghost[dir] + ((size_t)(p * 4 + nu) * 9) * Fh + f;
+#pragma unroll
+            for (int e = 0; e < 9; e++) u[e] = ld(b + (size_t)e * Fh);
+            return;
+        }
+    }
+    load_m3(u, link_at(g, k.U, d, nu), glink_stride(g));
+}
+
+// lower staple seen from the site m = n - nu_hat:  W_{mu nu}(m) = U_nu(m+mu)^+ U_mu(m)^+ U_nu(m)
+__device__ __forceinline__ void lower_staple_at(cd (&w)[9], const GFArgs& k, const int (&m)[4], int mu, int nu) {
+    cd u1[9], u2[9], u3[9], t1[9];
+    const int Gs = glink_stride(k.g);
+    link_fwd(u1, k, m, mu, nu);
+    load_m3(u2, link_at(k.g, k.U, m, mu), Gs);
+    load_m3(u3, link_at(k.g, k.U, m, nu), Gs);
+    mm3_dd(t1, u1, u2);
+    mm3(w, t1, u3);
+}
+
+// out_mu(n) = coef * U_mu(n) * sum_{nu != mu} [ U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+  +  W_{mu nu}(n - nu) ]
 // workgroup = 64 sites of one parity x 4 waves (wave = mu); the 6 x 3 neighbour links are re-used across waves/sites through L2
 // FUSE_TA = false: out = G.   FUSE_TA = true: out (the momenta) += factor * TA(G) -- P_update! in one pass, G never stored.
 template <bool FUSE_TA>
-__global__ __launch_bounds__(256) void gauge_force_kernel(Geom g, const double2* __restrict__ U, double2* __restrict__ out, double coef, double factor) {
+__global__ __launch_bounds__(256) void gauge_force_kernel(GFArgs k) {
+    const Geom& g = k.g;
     const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
     if (i >= g.Vh) return;
     const int Gs = glink_stride(g);
@@ -81,40 +126,40 @@ __global__ __launch_bounds__(256) void gauge_force_kernel(Geom g, const double2*
     cd A[9];
 #pragma unroll
     for (int e = 0; e < 9; e++) A[e] = mk(0.0, 0.0);
-    int cpm[4] = {c[0], c[1], c[2], c[3]};
-    shift(cpm, g, mu, 1);
     for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
         cd u1[9], u2[9], u3[9], t1[9], t2[9];
-        int cpn[4] = {c[0], c[1], c[2], c[3]}, cmn[4] = {c[0], c[1], c[2], c[3]}, cpmn[4] = {cpm[0], cpm[1], cpm[2], cpm[3]};
-        shift(cpn, g, nu, 1);
-        shift(cmn, g, nu, -1);
-        shift(cpmn, g, nu, -1);
-        load_m3(u1, link_at(g, U, cpm, nu), Gs);
-        load_m3(u2, link_at(g, U, cpn, mu), Gs);
-        load_m3(u3, link_at(g, U, c, nu), Gs);
+        link_fwd(u1, k, c, mu, nu);                         // U_nu(n+mu)
+        link_fwd(u2, k, c, nu, mu);                         // U_mu(n+nu)
+        load_m3(u3, link_at(g, k.U, c, nu), Gs);
         mm3_nd(t1, u1, u2);
         mm3_nd(t2, t1, u3);
 #pragma unroll
         for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
-        load_m3(u1, link_at(g, U, cpmn, nu), Gs);
-        load_m3(u2, link_at(g, U, cmn, mu), Gs);
-        load_m3(u3, link_at(g, U, cmn, nu), Gs);
-        mm3_dd(t1, u1, u2);
-        mm3(t2, t1, u3);
+        if (c[nu] == 0 && g.part[nu]) {                     // n - nu lives on the -nu neighbour: its W arrived with the exchange
+            const int Fh = face_half_sites(g, nu), f = coords_to_face(g, nu, c);
+            const double2* b = k.wrecv[nu] + ((size_t)((1 - p) * 4 + mu) * 9) * Fh + f;
+#pragma unroll
+            for (int e = 0; e < 9; e++) t2[e] = ld(b + (size_t)e * Fh);
+        } else {
+            int m[4] = {c[0], c[1], c[2], c[3]};
+            shift(m, g, nu, -1);
+            lower_staple_at(t2, k, m, mu, nu);
+        }
 #pragma unroll
         for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
     }
     cd um[9], r[9];
-    load_m3(um, U + glink_off(g, p, mu, i), Gs);
+    load_m3(um, k.U + glink_off(g, p, mu, i), Gs);
     mm3(r, um, A);
-    double2* o = out + glink_off(g, p, mu, i);
+    double2* o = k.out + glink_off(g, p, mu, i);
+    const double coef = k.coef;
     if constexpr (!FUSE_TA) {
 #pragma unroll
         for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, mk(coef * r[e].re, coef * r[e].im));
     } else {
         cd a[9];
-        const double f = 0.5 * coef * factor;
+        const double f = 0.5 * coef * k.factor;
 #pragma unroll
         for (int x = 0; x < 3; x++)
 #pragma unroll
@@ -126,6 +171,28 @@ __global__ __launch_bounds__(256) void gauge_force_kernel(Geom g, const double2*
             const cd pv = ld(o + (size_t)e * Gs);
             st(o + (size_t)e * Gs, mk(pv.re + a[e].re, pv.im + a[e].im));
         }
+    }
+}
+
+// upper nu-face of a partitioned direction nu = blockIdx.y: W_{mu nu}(m) for the three mu != nu, packed for the +nu neighbour
+__global__ __launch_bounds__(128) void staple_face_kernel(GFArgs k) {
+    const Geom& g = k.g;
+    const int nu = blockIdx.y;
+    if (!g.part[nu]) return;
+    const int Fh = face_half_sites(g, nu);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * Fh) return;
+    const int p = t / Fh, f = t - p * Fh;
+    int m[4];
+    face_to_coords(g, nu, g.L[nu] - 1, p, f, m);
+    const int mc[4] = {m[0], m[1], m[2], m[3]};
+    for (int mu = 0; mu < 4; mu++) {
+        if (mu == nu) continue;
+        cd w[9];
+        lower_staple_at(w, k, mc, mu, nu);
+        double2* b = k.wsend[nu] + ((size_t)(p * 4 + mu) * 9) * Fh + f;
+#pragma unroll
+        for (int e = 0; e < 9; e++) st(b + (size_t)e * Fh, w[e]);
     }
 }
 
@@ -267,35 +334,132 @@ extern "C" int lqcd_gauge_action(lqcd_gauge_t U, double beta, double* Sg) {
     return LQCD_OK;
 }
 
+// ---- staple force on one rank / on a partitioned lattice
+// Partitioned: (1) the x_lam = 0 link slices travel to the -lam neighbours (forward ghosts); (2) every rank computes the lower
+// staples W_{mu nu} of its upper nu-faces (they need forward ghosts only) and sends them to the +nu neighbours; (3) the sweep
+// reads ghosts for n+mu / n+nu and the received W for n-nu.  No corner exchange, two grouped send/recv steps.
+static size_t gf_face_elems(lqcd_ctx_s* c, int mu) { return (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu); }
+
+static int gf_buffers(lqcd_ctx_s* c) {
+    for (int mu = 0; mu < 4; mu++) {
+        if (!c->geom.part[mu] || c->gf_ghost[mu]) continue;
+        const size_t bytes = gf_face_elems(c, mu) * sizeof(double2);
+        HIPCHK(hipMalloc((void**)&c->gf_ghost[mu], bytes));
+        HIPCHK(hipMalloc((void**)&c->gf_gsend[mu], bytes));
+        HIPCHK(hipMalloc((void**)&c->gf_wsend[mu], bytes));
+        HIPCHK(hipMalloc((void**)&c->gf_wrecv[mu], bytes));
+    }
+    return LQCD_OK;
+}
+
+static GFArgs make_gfargs(lqcd_ctx_s* c, lqcd_gauge_s* U, lqcd_gauge_s* out, double beta, double factor) {
+    GFArgs k;
+    k.g = c->geom;
+    k.U = U->data;
+    k.out = out->data;
+    k.coef = -beta / 6.0;
+    k.factor = factor;
+    for (int mu = 0; mu < 4; mu++) { k.ghost[mu] = c->gf_ghost[mu]; k.wrecv[mu] = c->gf_wrecv[mu]; k.wsend[mu] = c->gf_wsend[mu]; }
+    return k;
+}
+
+static int launch_staple_faces(lqcd_ctx_s* c, const GFArgs& k) {
+    int maxf = 0;
+    for (int mu = 0; mu < 4; mu++)
+        if (c->geom.part[mu]) maxf = std::max(maxf, face_half_sites(c->geom, mu));
+    if (!maxf) return LQCD_OK;
+    hipLaunchKernelGGL(staple_face_kernel, dim3((2 * maxf + 127) / 128, 4), dim3(128), 0, c->stream, k);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse) {
+    if (fuse) hipLaunchKernelGGL(gauge_force_kernel<true>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
+    else hipLaunchKernelGGL(gauge_force_kernel<false>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+// send `sendb[mu]` to one neighbour and receive into `recvb[mu]` from the opposite one, all partitioned directions in one group
+static int gf_exchange_rccl(lqcd_ctx_s* c, double2* const sendb[4], double2* const recvb[4], bool to_backward) {
+    ARGCHK(c->has_comm, "staple force: communicator not initialised (call lqcd_ctx_comm_init)");
+    NCCLCHK(ncclGroupStart());
+    for (int mu = 0; mu < 4; mu++) {
+        if (!c->geom.part[mu]) continue;
+        const size_t nd = gf_face_elems(c, mu) * 2;
+        NCCLCHK(ncclSend(sendb[mu], nd, ncclDouble, to_backward ? c->nbr_bwd[mu] : c->nbr_fwd[mu], c->comm_red, c->stream));
+        NCCLCHK(ncclRecv(recvb[mu], nd, ncclDouble, to_backward ? c->nbr_fwd[mu] : c->nbr_bwd[mu], c->comm_red, c->stream));
+    }
+    NCCLCHK(ncclGroupEnd());
+    return LQCD_OK;
+}
+
+static int staple_force(lqcd_gauge_s* out, lqcd_gauge_s* U, double beta, double factor, bool fuse) {
+    lqcd_ctx_s* c = U->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    out->version++;
+    if (any_partitioned(c)) {
+        ARGCHK(c->local_peers.empty(), "staple force: this context belongs to an in-process PE grid, use lqcd_mdom_momentum_add_gauge_force");
+        LQCHK(gf_buffers(c));
+        for (int mu = 0; mu < 4; mu++)
+            if (c->geom.part[mu]) LQCHK(gauge_pack_face(U, mu, c->gf_gsend[mu]));
+        LQCHK(gf_exchange_rccl(c, c->gf_gsend, c->gf_ghost, true));
+    }
+    GFArgs k = make_gfargs(c, U, out, beta, factor);
+    if (any_partitioned(c)) {
+        LQCHK(launch_staple_faces(c, k));
+        LQCHK(gf_exchange_rccl(c, c->gf_wsend, c->gf_wrecv, false));
+    }
+    LQCHK(launch_staple_sweep(c, k, fuse));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
 // G_mu(n) = -(beta/6) U_mu(n) * (sum of the six staples)      (calc_dSdUmu! + mul!(temp, U, dSdUmu), AbstractMD.jl:108-110)
 extern "C" int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta) {
     LQCHK(same_ctx(out, U, "lqcd_gauge_force"));
-    lqcd_ctx_s* c = U->ctx;
-    if (any_partitioned(c)) {
-        set_error("lqcd_gauge_force: not available on a partitioned lattice yet (needs link halos in both directions)");
-        return LQCD_ERR_UNSUPPORTED;
-    }
-    HIPCHK(hipSetDevice(c->device));
-    out->version++;
-    hipLaunchKernelGGL(gauge_force_kernel<false>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, out->data, -beta / 6.0, 0.0);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return LQCD_OK;
+    return staple_force(out, U, beta, 0.0, false);
 }
 
 // P_update!(U, p, eps, md) (AbstractMD.jl:99-118) in one pass:  P += factor * TA(-(beta/6) U * staples); the force field is never stored
 extern "C" int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta) {
     LQCHK(same_ctx(P, U, "lqcd_momentum_add_gauge_force"));
-    lqcd_ctx_s* c = U->ctx;
-    if (any_partitioned(c)) {
-        set_error("lqcd_momentum_add_gauge_force: not available on a partitioned lattice yet (needs link halos in both directions)");
-        return LQCD_ERR_UNSUPPORTED;
+    return staple_force(P, U, beta, factor, true);
+}
+
+// the same on an in-process PE grid (tests): arrays ordered by rank; fuse = 0 writes the force field, 1 accumulates into momenta
+extern "C" int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us, double beta, double factor, int fuse) {
+    ARGCHK(outs && Us && n >= 1, "lqcd_mdom_gauge_force: null");
+    lqcd_ctx_s* c0 = Us[0]->ctx;
+    ARGCHK((int)c0->local_peers.size() == n, "lqcd_mdom_gauge_force: contexts are not linked with lqcd_ctx_link_local (or wrong n)");
+    std::vector<GFArgs> ks(n);
+    for (int r = 0; r < n; r++) {
+        LQCHK(same_ctx(outs[r], Us[r], "lqcd_mdom_gauge_force"));
+        lqcd_ctx_s* c = Us[r]->ctx;
+        ARGCHK(c->rank == r, "lqcd_mdom_gauge_force: fields must be ordered by rank");
+        HIPCHK(hipSetDevice(c->device));
+        LQCHK(gf_buffers(c));
+        outs[r]->version++;
     }
-    HIPCHK(hipSetDevice(c->device));
-    P->version++;
-    hipLaunchKernelGGL(gauge_force_kernel<true>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, P->data, -beta / 6.0, factor);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < n; r++) {          // forward ghosts: the x_mu = 0 slice of the +mu neighbour
+        lqcd_ctx_s* c = Us[r]->ctx;
+        for (int mu = 0; mu < 4; mu++)
+            if (c->geom.part[mu]) LQCHK(gauge_pack_face(Us[c->nbr_fwd[mu]], mu, c->gf_ghost[mu]));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    for (int r = 0; r < n; r++) {
+        ks[r] = make_gfargs(Us[r]->ctx, Us[r], outs[r], beta, factor);
+        LQCHK(launch_staple_faces(Us[r]->ctx, ks[r]));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    for (int r = 0; r < n; r++) {          // lower staples of the upper nu-face -> the +nu neighbour
+        lqcd_ctx_s* c = Us[r]->ctx;
+        for (int mu = 0; mu < 4; mu++)
+            if (c->geom.part[mu])
+                HIPCHK(hipMemcpy(Us[c->nbr_fwd[mu]]->ctx->gf_wrecv[mu], c->gf_wsend[mu], gf_face_elems(c, mu) * sizeof(double2), hipMemcpyDeviceToDevice));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    for (int r = 0; r < n; r++) LQCHK(launch_staple_sweep(Us[r]->ctx, ks[r], fuse != 0));
+    HIPCHK(hipDeviceSynchronize());
     return LQCD_OK;
 }
 

@@ -522,6 +522,14 @@ def mdom_fermion_force_(Gs, Ds, Xs, Ys):
     check(_l.lib().lqcd_mdom_fermion_force(len(Ds), _harr(Ds), _harr(Gs), _harr(Xs), _harr(Ys)))
 
 
+def mdom_gauge_force_(Gs, Us, beta):
+    check(_l.lib().lqcd_mdom_gauge_force(len(Us), _harr(Gs), _harr(Us), C.c_double(beta), C.c_double(0.0), 0))
+
+
+def mdom_P_update_(Us, Ps, factor, beta):
+    check(_l.lib().lqcd_mdom_gauge_force(len(Us), _harr(Ps), _harr(Us), C.c_double(beta), C.c_double(factor), 1))
+
+
 def mdom_dot(As, Bs):
     re, im = C.c_double(0), C.c_double(0)
     check(_l.lib().lqcd_mdom_dot(len(As), _harr(As), _harr(Bs), C.byref(re), C.byref(im)))
