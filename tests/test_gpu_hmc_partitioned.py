@@ -1,0 +1,80 @@
+"""A molecular-dynamics trajectory of the 2-flavour Wilson HMC on an in-process PE grid (four domains of one device, every
+halo mechanism of the multi-GPU build active: Dslash halos in the CG, the X/Y face exchange of the fermion force, ghost links
+and lower-staple faces of the gauge force) against the same trajectory on one domain."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+KAPPA, BETA = 0.141139, 5.7
+BC = (1, 1, 1, -1)
+
+
+def _single(lq, Uh, xi_h, L, dtau, nsteps):
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "boundarycondition": BC, "eps_CG": 1e-22})
+    fa = lq.FermiAction(D)
+    p, G = lq.Gaugefields(lat), lq.Gaugefields(lat)
+    lq.gauss_distribution_(p, 901)
+    xi = lq.Fermionfields(lat, lq.WILSON).upload(xi_h)
+    eta = xi.similar()
+    lq.sample_pseudofermions_(eta, U, fa, xi)
+    H0 = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA) + lq.dot(xi, xi).real
+    for _ in range(nsteps):
+        lq.U_update_(U, p, 0.5 * dtau)
+        lq.P_update_(U, p, dtau, BETA)
+        lq.calc_UdSfdU_(G, fa, U, eta)
+        lq.Traceless_antihermitian_add_(p, dtau, G)
+        lq.U_update_(U, p, 0.5 * dtau)
+    H1 = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA) + lq.evaluate_FermiAction(fa, U, eta)
+    return U.download(), p.download(), H1 - H0
+
+
+def test_md_trajectory_on_four_domains_equals_one_domain(lq, orc):
+    assert lq.lib.device_count() > 0
+    L, pe, dtau, nsteps = (8, 8, 8, 8), (1, 1, 2, 2), 0.05, 3
+    # a mildly disordered start (exp(0.3 P) on a cold field) keeps the solves short
+    Uh = orc.unit_gauge(L)
+    Uh = orc.link_update(Uh, 0.3 * orc.gaussian_momenta(L, 899), 1.0, L)
+    xi_h = orc.gaussian_spinor(orc.wilson_shape(L), 902) * np.sqrt(0.5)
+    U1, P1, dH1 = _single(lq, Uh, xi_h, L, dtau, nsteps)
+
+    n = int(np.prod(pe))
+    lats = [lq.Lattice(L, pe, r) for r in range(n)]
+    lq.link_local(lats)
+    view = lambda a, lat, lead: lq.pegrid.local_view(a, lat.local_L, lat.origin, lead=lead)
+    Us = [lq.Gaugefields(lat).upload(view(Uh, lat, 1)) for lat in lats]
+    Ds = [lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "boundarycondition": BC}) for U in Us]
+    Dd = [D.adjoint() for D in Ds]
+    ps, Gs = [lq.Gaugefields(lat) for lat in lats], [lq.Gaugefields(lat) for lat in lats]
+    for p in ps:
+        lq.gauss_distribution_(p, 901)                       # keyed by the global site: identical momenta for every decomposition
+    xis = [lq.Fermionfields(lat, lq.WILSON).upload(view(xi_h, lat, 1)) for lat in lats]
+    etas, Xs, Ys = [x.similar() for x in xis], [x.similar() for x in xis], [x.similar() for x in xis]
+    lq.mdom_mul_(etas, Dd, xis)                              # eta = D' xi
+    K = lambda: sum(lq.momentum_action(p) for p in ps)
+    H0 = K() + (-BETA * 6 * np.prod(L) * lq.mdom_plaquette(Us)) + lq.mdom_dot(xis, xis).real
+    for _ in range(nsteps):
+        for U, p in zip(Us, ps):
+            lq.U_update_(U, p, 0.5 * dtau)
+        lq.mdom_P_update_(Us, ps, dtau, BETA)
+        for X in Xs:
+            lq.clear_fermion_(X)
+        lq.mdom_solve_cg(Ds, Xs, etas, eps=1e-22)
+        lq.mdom_mul_(Ys, Ds, Xs)
+        lq.mdom_fermion_force_(Gs, Ds, Xs, Ys)
+        for p, G in zip(ps, Gs):
+            lq.Traceless_antihermitian_add_(p, dtau, G)
+        for U, p in zip(Us, ps):
+            lq.U_update_(U, p, 0.5 * dtau)
+    for X in Xs:
+        lq.clear_fermion_(X)
+    lq.mdom_solve_cg(Ds, Xs, etas, eps=1e-22)
+    H1 = K() + (-BETA * 6 * np.prod(L) * lq.mdom_plaquette(Us)) + lq.mdom_dot(etas, Xs).real
+    for lat, U, p in zip(lats, Us, ps):
+        assert rel_err(U.download(), view(U1, lat, 1)) < 1e-10
+        assert rel_err(p.download(), view(P1, lat, 1)) < 1e-9
+    assert abs((H1 - H0) - dH1) < 1e-7          # the same energy change (the start is not thermalised, so it is not small)
