@@ -370,7 +370,7 @@ def test_argument_errors(gpu):
     lat = lq.Lattice((4, 4, 4, 4))
     U = lq.Initialize_Gaugefields(3, 0, 4, 4, 4, 4, lattice=lat)
     with pytest.raises(lq.LQCDError):
-        lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover"})     # universe.jl:129-131: error("not supported")
+        lq.Dirac_operator(U, None, {"Dirac_operator": "Domainwall"})      # not on this path: raises like universe.jl:129-131
     D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson"})
     w, s = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.STAGGERED)
     with pytest.raises(lq.LQCDError):
