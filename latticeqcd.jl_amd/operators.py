@@ -374,6 +374,22 @@ def shiftedcg(vec_x, vec_beta, x, A, b, eps=None, maxsteps=None, return_info=Fal
     return (it.value, rr.value) if return_info else None
 
 
+def apply_inverse_power_(y, A, x, alpha, lam_min, lam_max, tol=1e-10):
+    """y = (D'D)^(-alpha) x, 0 < alpha < 1, through ONE multi-shift solve with the partial fractions of rational.py -- the building
+    block of the RHMC action and heat bath (README.md:112,132).  [lam_min, lam_max] must enclose the spectrum of D'D
+    (staggered: [m^2, m^2 + 16]).  Returns the number of CG iterations."""
+    from . import rational
+    a0, res, poles, _ = rational.inverse_power_partial_fractions(alpha, lam_min, lam_max, tol)
+    xs = [x.similar() for _ in poles]
+    it, _ = shiftedcg(xs, list(poles), None, A, x, return_info=True)
+    substitute_fermion_(y, x)
+    check(_l.lib().lqcd_scale(C.c_double(a0), C.c_double(0.0), y._h))
+    for r, xk in zip(res, xs):
+        add_fermion_(y, float(r), xk)
+        xk.close()
+    return it
+
+
 # ------------------------------------------------------------------------------------ pseudofermion action and force
 class FermiAction:
     """FermiAction(D, Dict("Nf"=>2)) (universe.jl:138): the 2-flavour pseudofermion action S_f = eta' (D'D)^-1 eta.
