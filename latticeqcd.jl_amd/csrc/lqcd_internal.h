@@ -272,6 +272,7 @@ struct lqcd_ctx_s {
     // scratch spinors owned by the context (Temporalfields analogue)
     std::vector<lqcd_spinor_s*> scratch;
     lqcd::Tunables tun;
+    void* cg_session = nullptr;   // open timing session of lqcd_cg_session_* (ops.hip), if any
     int num_cu = 256;
 };
 

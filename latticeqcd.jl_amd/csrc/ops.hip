@@ -1078,37 +1078,46 @@ extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int
     return st;
 }
 
-// CG session (externally timed windows)
+// CG session (externally timed windows); the state lives in the context, one open session per context
 namespace lqcd {
 struct CgSession { lqcd_op_s* op = nullptr; lqcd_spinor_s* x = nullptr; CgWork w; };
-static CgSession g_session;
 }
 extern "C" int lqcd_cg_session_begin(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b) {
     LQCHK(check_full(op, x, b, "lqcd_cg_session_begin"));
-    ARGCHK(g_session.op == nullptr, "lqcd_cg_session_begin: a session is already open");
     lqcd_ctx_s* c = op->ctx;
+    ARGCHK(c->cg_session == nullptr, "lqcd_cg_session_begin: a session is already open on this context");
     HIPCHK(hipSetDevice(c->device));
-    CgWork& w = g_session.w;
+    CgSession* ses = new CgSession;
+    CgWork& w = ses->w;
     w.r = scratch_get(c, x->kind, LQCD_FULL); w.p = scratch_get(c, x->kind, LQCD_FULL);
     w.q = scratch_get(c, x->kind, LQCD_FULL); w.tmp = scratch_get(c, x->kind, LQCD_FULL);
-    if (!(w.r && w.p && w.q && w.tmp)) return LQCD_ERR_HIP;
+    int st = (w.r && w.p && w.q && w.tmp) ? LQCD_OK : LQCD_ERR_HIP;
     double rr;
-    LQCHK(cg_setup(op, x, b, w, -1.0, &rr));
-    g_session.op = op;
-    g_session.x = x;
+    if (st == LQCD_OK) st = cg_setup(op, x, b, w, -1.0, &rr);
+    if (st != LQCD_OK) {
+        scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+        delete ses;
+        return st;
+    }
+    ses->op = op;
+    ses->x = x;
+    c->cg_session = ses;
     return LQCD_OK;
 }
 extern "C" int lqcd_cg_session_iterate(lqcd_op_t op, int n) {
-    ARGCHK(op && g_session.op == op, "lqcd_cg_session_iterate: no open session for this operator");
-    for (int i = 0; i < n; i++) LQCHK(cg_enqueue_iteration(op, g_session.x, g_session.w));
+    ARGCHK(op && op->ctx->cg_session && static_cast<CgSession*>(op->ctx->cg_session)->op == op, "lqcd_cg_session_iterate: no open session for this operator");
+    CgSession* ses = static_cast<CgSession*>(op->ctx->cg_session);
+    for (int i = 0; i < n; i++) LQCHK(cg_enqueue_iteration(op, ses->x, ses->w));
     HIPCHK(hipStreamSynchronize(op->ctx->stream));
     return LQCD_OK;
 }
 extern "C" int lqcd_cg_session_end(lqcd_op_t op) {
-    ARGCHK(op && g_session.op == op, "lqcd_cg_session_end: no open session for this operator");
-    CgWork& w = g_session.w;
+    ARGCHK(op && op->ctx->cg_session && static_cast<CgSession*>(op->ctx->cg_session)->op == op, "lqcd_cg_session_end: no open session for this operator");
+    CgSession* ses = static_cast<CgSession*>(op->ctx->cg_session);
+    CgWork& w = ses->w;
     scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
-    g_session = CgSession();
+    delete ses;
+    op->ctx->cg_session = nullptr;
     return LQCD_OK;
 }
 
