@@ -91,7 +91,8 @@ def main():
 
     # ---- Dslash kernel timing (HIP events on the stream the kernel is launched on)
     barrier()
-    ms_dslash = lq.bench_dslash(D, y, b, warm=20, reps=args.dslash_reps)
+    ms_dslash = lq.bench_dslash(D, y, b, warm=20, reps=args.dslash_reps)              # mean over back-to-back launches
+    ms_median, _ = lq.bench_dslash_median(D, y, b, warm=5, reps=args.dslash_reps)       # per-launch events, median
     barrier()
     if dist is not None:
         import torch
@@ -144,6 +145,7 @@ def main():
                    "xcd_ysplit": lat.get_param("xcd_ysplit"), "cg_fused": lat.get_param("cg_fused")},
         "dslash_gflops": dslash_gflops,
         "dslash_ms": ms_dslash,
+        "dslash_ms_median_per_launch_events": ms_median,
         "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(lat.get_param("dslash_variant"), "wilson") + " (mul!(y,D,x))", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc},

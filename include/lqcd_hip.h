@@ -193,6 +193,9 @@ int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_up
 int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed);               /* gauss_distribution!(p) (src/md/standardMD.jl:86); keyed by GLOBAL site */
 int lqcd_momentum_action(lqcd_gauge_t P, double* K);                     /* p.p/2 (standardHMC.jl:49) */
 
+/* the SURVEY.md 8(d) protocol: every application between its own HIP events, median and mean over reps */
+int lqcd_bench_dslash_median(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps, double* median_ms,
+                             double* mean_ms);
 /* multi-GPU diagnostics (bench.py, N > 1): phase breakdown of one partitioned operator application -- ms[6] = pack, interior,
  * exchange (pack end -> halos received), idle wait for the exchange after the interior, exterior, total -- and the latency of
  * the one-double all-reduce (microseconds) */

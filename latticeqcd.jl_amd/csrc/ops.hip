@@ -5,6 +5,7 @@
 // /root/reference/src/md/AbstractMD.jl:129, src/updates/standardHMC.jl:71, src/md/standardMD.jl:95-96.
 #include "lqcd_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <functional>
@@ -987,6 +988,37 @@ extern "C" int lqcd_bench_dslash(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t 
     float t = 0;
     HIPCHK(hipEventElapsedTime(&t, c->ev_t0, c->ev_t1));
     *ms = (double)t / reps;
+    return LQCD_OK;
+}
+
+// SURVEY.md 8(d) timing protocol: every application bracketed by its own HIP events, median (and mean) over `reps`
+extern "C" int lqcd_bench_dslash_median(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps, double* median_ms,
+                                        double* mean_ms) {
+    LQCHK(check_full(op, out, in, "lqcd_bench_dslash_median"));
+    ARGCHK(reps > 0 && reps <= 4096 && median_ms, "lqcd_bench_dslash_median: bad reps");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<hipEvent_t> ev(reps + 1);
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    for (int i = 0; i < warm; i++) LQCHK(op_apply_async(op, out, in, dagger ? 1 : 0, nullptr));
+    HIPCHK(hipEventRecord(ev[0], c->stream));
+    for (int i = 0; i < reps; i++) {
+        LQCHK(op_apply_async(op, out, in, dagger ? 1 : 0, nullptr));
+        HIPCHK(hipEventRecord(ev[i + 1], c->stream));
+    }
+    HIPCHK(hipEventSynchronize(ev[reps]));
+    std::vector<double> t(reps);
+    double sum = 0;
+    for (int i = 0; i < reps; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        t[i] = ms;
+        sum += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    std::sort(t.begin(), t.end());
+    *median_ms = reps % 2 ? t[reps / 2] : 0.5 * (t[reps / 2 - 1] + t[reps / 2]);
+    if (mean_ms) *mean_ms = sum / reps;
     return LQCD_OK;
 }
 

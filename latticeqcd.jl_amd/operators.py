@@ -504,6 +504,13 @@ def bench_dslash(D, out, inp, warm=20, reps=200):
     return ms.value
 
 
+def bench_dslash_median(D, out, inp, warm=20, reps=200):
+    """every application between its own HIP events -> (median ms, mean ms)."""
+    med, mean = C.c_double(0), C.c_double(0)
+    check(_l.lib().lqcd_bench_dslash_median(D._h, out._h, inp._h, int(D.dagger), int(warm), int(reps), C.byref(med), C.byref(mean)))
+    return med.value, mean.value
+
+
 def bench_cg(D, x, b, warm=5, niter=50):
     ms = C.c_double(0)
     check(_l.lib().lqcd_bench_cg(D._h, x._h, b._h, int(warm), int(niter), C.byref(ms)))
