@@ -231,6 +231,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "graph")) return &c->tun.graph;
     if (!strcmp(key, "gauge_recon")) return &c->tun.gauge_recon;
     if (!strcmp(key, "mixed_action_solver")) return &c->tun.mixed_action_solver;
+    if (!strcmp(key, "clover_fused")) return &c->tun.clover_fused;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;
     if (!strcmp(key, "xcd_nsub")) return &c->tun.xcd_nsub;

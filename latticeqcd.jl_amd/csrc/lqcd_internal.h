@@ -235,6 +235,7 @@ struct Tunables {
     int xcd_ysplit = 4;       // remap 2: tile the sub-domains in (y,z) instead of plain z-slabs
     int xcd_nsub = 16;       // remap 2: sub-domains per t-slice (multiple of 8)
     int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)
+    int clover_fused = 1;     // Wilson-clover: apply A inside the direction-split kernel's epilogue (0: separate A x pass)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
     int gauge_recon = 18;     // 12: the Wilson dirsplit kernel reads 2 rows per link and rebuilds the third (only for links that
                               // are unitary to 1e-14; otherwise the 18-real field is used).  Opt-in: bytes/site 960 -> 768.
@@ -361,6 +362,7 @@ struct StencilCall {
     const double* upd_scal = nullptr;
     double2* upd[2] = {nullptr, nullptr};
     const double2* gauge12 = nullptr;   // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
+    const double2* clover = nullptr;    // packed clover blocks: the Wilson split kernel (variant 1) applies A to xin in its epilogue
     int prec = 0;                 // 0: fp64 fields, 1: fp32 fields (pointers are float2 data, see p32)
 };
 // slots of the device scalar block d_scal used by the solvers

@@ -122,8 +122,12 @@ StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in,
             (void)clover_build(op->ctx, op->gauge, op->clover, op->km, op->csw);
             op->clover_version = op->gauge->version;
         }
-        (void)clover_apply(op->ctx, op->clover, op->clover_tmp, in);
-        fill_blocks(s.xin, op->clover_tmp);
+        if (op->r == 1.0 && op->ctx->tun.dslash_variant == 1 && op->ctx->tun.clover_fused) {
+            s.clover = op->clover;            // fused: the direction-split kernel forms A in in its epilogue (one pass, 1536 B/site)
+        } else {
+            (void)clover_apply(op->ctx, op->clover, op->clover_tmp, in);      // separate streaming pass, then xin = A in
+            fill_blocks(s.xin, op->clover_tmp);
+        }
     }
     return s;
 }

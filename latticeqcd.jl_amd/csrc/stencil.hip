@@ -25,6 +25,7 @@ struct KArgs {
     Geom g;
     const real2* gauge;
     const real2* gauge12;   // 12-real links (rows 0,1) or nullptr
+    const real2* clover;    // packed chiral clover blocks (clover.hip) or nullptr: the diagonal term becomes a * (A xin)
     real2* out[2];
     const real2* in[2];
     const real2* xin[2];
@@ -374,7 +375,42 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU]);
 }
 
-template <bool DAG, bool R12 = false>
+// rows 3*W .. 3*W+2 of A x for the packed clover field (clover.hip: two Hermitian 6x6 blocks in the chiral basis chi_(-+) =
+// psi_upper -+ psi_lower; block b at 18 b: 3 elements = 6 real diagonals, then the upper triangle, entry (r,q) at
+// 3 + 5 r - r(r-1)/2 + (q - r - 1)).  Spin row W needs rows S1 = W & 1 of both blocks:
+//   (A x)_W = 1/2 [ -+ (A_+ chi_+)_{S1} + (A_- chi_-)_{S1} ]   (upper sign for W >= 2).
+template <int S1>
+__device__ inline void clover_rows(cd (&out)[3], const real2* __restrict__ a, const cd (&psi)[12], bool lower) {
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) out[cc] = mk(0.0, 0.0);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const real sg = b == 0 ? real(-1.0) : real(1.0);
+        cd chi[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) chi[q] = mk(psi[q].re + sg * psi[6 + q].re, psi[q].im + sg * psi[6 + q].im);
+        const real2* __restrict__ ab = a + (size_t)(18 * b) * 64;
+        const real wgt = real(0.5) * ((b == 0 && lower) ? real(-1.0) : real(1.0));
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int r = 3 * S1 + cc;
+            const cd dd = ld(ab + (size_t)(r >> 1) * 64);
+            const real d = (r & 1) ? dd.im : dd.re;
+            cd y = mk(d * chi[r].re, d * chi[r].im);
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                if (q == r) continue;
+                const int lo = q < r ? q : r, hi = q < r ? r : q;
+                const cd m = ld(ab + (size_t)(3 + 5 * lo - (lo * (lo - 1)) / 2 + (hi - lo - 1)) * 64);
+                if (q > r) cfma(y, m, chi[q]); else cfma_conj(y, m, chi[q]);
+            }
+            out[cc] = mk(out[cc].re + wgt * y.re, out[cc].im + wgt * y.im);
+        }
+    }
+}
+
+template <bool DAG, bool R12 = false, bool CLOV = false>
 __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     __shared__ real2 part[4][12][64];  // 48 KiB
     __shared__ double red[4];
@@ -391,9 +427,15 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
     // the diagonal term's loads are issued first so they are not a third dependent memory round trip after the barrier
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    cd cpsi[CLOV ? 12 : 1];
     if (valid && k.a != 0.0) {
+        if constexpr (CLOV) {       // Wilson-clover: all 12 components now (the loads overlap the hops), A xin after the hops
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp_off(12, i) + (size_t)(3 * w + cc) * Vh);
+            for (int j = 0; j < 12; j++) cpsi[j] = ld(k.xin[p] + sp_off(12, i) + (size_t)j * Vh);
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp_off(12, i) + (size_t)(3 * w + cc) * Vh);
+        }
     }
     if (valid) {
         switch (w) {
@@ -405,6 +447,11 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     }
 #pragma unroll
     for (int j = 0; j < 12; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
+    if constexpr (CLOV) if (valid && k.a != 0.0) {   // this wave's rows of A xin (its partial sums are already on their way to LDS)
+        const real2* __restrict__ ca = k.clover + (((size_t)p * k.g.nch + (size_t)(i >> 6)) * 36) * 64 + (i & 63);
+        if (w & 1) clover_rows<1>(xv, ca, cpsi, w >= 2);
+        else clover_rows<0>(xv, ca, cpsi, w >= 2);
+    }
     __syncthreads();
     real nrm = 0.0;
     if (valid) {
@@ -1183,6 +1230,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.g = c->geom;
     k.gauge = (const real2*)s.gauge;
     k.gauge12 = (const real2*)s.gauge12;   // elements of this build's precision (the caller matches prec)
+    k.clover = s.prec ? nullptr : (const real2*)s.clover;
     for (int p = 0; p < 2; p++) { k.out[p] = (real2*)s.out[p]; k.in[p] = (const real2*)s.in[p]; k.xin[p] = (const real2*)s.xin[p]; }
     k.a = s.a; k.b = s.b; k.r = s.r;
     k.parity_mode = s.parity_mode;
@@ -1264,7 +1312,10 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
 #undef LQ_HS
         } else {
             dim3 grid(k.nblocks), block(256);
-            if (k.gauge12) {
+            if (k.clover) {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, true>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit<false, false, true>), grid, block, pad, c->stream, k);
+            } else if (k.gauge12) {
                 if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true>), grid, block, pad, c->stream, k);
                 else hipLaunchKernelGGL((wilson_dirsplit<false, true>), grid, block, pad, c->stream, k);
             } else {
