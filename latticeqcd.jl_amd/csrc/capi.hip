@@ -185,10 +185,12 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
         if (!c->geom.part[mu]) continue;
         c->halo_elems[mu] = (size_t)2 * 6 * face_half_sites(c->geom, mu);
         const size_t bytes = c->halo_elems[mu] * sizeof(double2);
-        HIPCHK(hipMalloc((void**)&c->send_fwd[mu], bytes));
-        HIPCHK(hipMalloc((void**)&c->send_bwd[mu], bytes));
-        HIPCHK(hipMalloc((void**)&c->recv_fwd[mu], bytes));
-        HIPCHK(hipMalloc((void**)&c->recv_bwd[mu], bytes));
+        // [send_fwd | send_bwd] and [recv_bwd | recv_fwd] are adjacent: when both neighbours of a direction are the same rank
+        // (PE extent 2) a full-size exchange is ONE message each way instead of two (ops.hip halo_exchange_rccl)
+        HIPCHK(hipMalloc((void**)&c->send_fwd[mu], 2 * bytes));
+        c->send_bwd[mu] = c->send_fwd[mu] + c->halo_elems[mu];
+        HIPCHK(hipMalloc((void**)&c->recv_bwd[mu], 2 * bytes));
+        c->recv_fwd[mu] = c->recv_bwd[mu] + c->halo_elems[mu];
     }
     *out = c;
     return LQCD_OK;
@@ -200,7 +202,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     hipDeviceSynchronize();
     for (lqcd_spinor_s* s : c->scratch) { hipFree(s->data); delete s; }
     for (int mu = 0; mu < 4; mu++) {
-        hipFree(c->send_fwd[mu]); hipFree(c->send_bwd[mu]); hipFree(c->recv_fwd[mu]); hipFree(c->recv_bwd[mu]);
+        hipFree(c->send_fwd[mu]); hipFree(c->recv_bwd[mu]);   // send_bwd / recv_fwd are the second halves of these
         hipFree(c->force_send[mu]); hipFree(c->force_recv[mu]);
         hipFree(c->gf_ghost[mu]); hipFree(c->gf_gsend[mu]); hipFree(c->gf_wsend[mu]); hipFree(c->gf_wrecv[mu]);
     }
@@ -232,6 +234,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "gauge_recon")) return &c->tun.gauge_recon;
     if (!strcmp(key, "mixed_action_solver")) return &c->tun.mixed_action_solver;
     if (!strcmp(key, "clover_fused")) return &c->tun.clover_fused;
+    if (!strcmp(key, "halo_merge")) return &c->tun.halo_merge;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;
     if (!strcmp(key, "xcd_nsub")) return &c->tun.xcd_nsub;

@@ -32,6 +32,12 @@ int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec) {
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
         const size_t n = halo_count(c, mu, kind, parity_mode) * 2;  // doubles
+        if (c->tun.halo_merge && c->nbr_fwd[mu] == c->nbr_bwd[mu] && !prec && halo_count(c, mu, kind, parity_mode) == c->halo_elems[mu]) {
+            // PE extent 2: both faces go to the same rank -- one message each way ([send_fwd|send_bwd] -> its [recv_bwd|recv_fwd])
+            NCCLCHK(ncclSend(c->send_fwd[mu], 2 * n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
+            NCCLCHK(ncclRecv(c->recv_bwd[mu], 2 * n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
+            continue;
+        }
         NCCLCHK(ncclSend(c->send_fwd[mu], n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
         NCCLCHK(ncclSend(c->send_bwd[mu], n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
         NCCLCHK(ncclRecv(c->recv_bwd[mu], n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
