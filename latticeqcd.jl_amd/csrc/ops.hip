@@ -21,44 +21,49 @@ static size_t halo_count(lqcd_ctx_s* c, int mu, int kind, int parity_mode) {
     return (size_t)(parity_mode == 2 ? 2 : 1) * nh * face_half_sites(c->geom, mu);
 }
 
-// RCCL path: one grouped send/recv per partitioned direction and face, on the communication stream, so the
-// transfer over xGMI overlaps the interior stencil running on the compute stream.
+// Buffers: send = [fwd face | bwd face], recv = [from bwd | from fwd], packed back to back for the message size of the call
+// (stencil.hip make_hargs uses the same rule), elements of 16 bytes (fp64) or 8 bytes (fp32).
+// RCCL path: grouped send/recv on the communication stream, so the transfer over xGMI overlaps the interior stencil running
+// on the compute stream.  When both neighbours of a direction are the same rank (PE extent 2) the two faces are ONE message
+// each way: my [fwd | bwd] lands in its [from bwd | from fwd].
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec) {
     const ncclDataType_t dt = prec ? ncclFloat : ncclDouble;   // same element counts, float2 instead of double2 elements
+    const size_t esize = prec ? sizeof(float2) : sizeof(double2);
     ARGCHK(c->has_comm, "halo exchange: communicator not initialised (call lqcd_ctx_comm_init)");
     HIPCHK(hipEventRecord(c->ev_pack, c->stream));
     HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
     NCCLCHK(ncclGroupStart());
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
-        const size_t n = halo_count(c, mu, kind, parity_mode) * 2;  // doubles
-        if (c->tun.halo_merge && c->nbr_fwd[mu] == c->nbr_bwd[mu] && !prec && halo_count(c, mu, kind, parity_mode) == c->halo_elems[mu]) {
-            // PE extent 2: both faces go to the same rank -- one message each way ([send_fwd|send_bwd] -> its [recv_bwd|recv_fwd])
-            NCCLCHK(ncclSend(c->send_fwd[mu], 2 * n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
-            NCCLCHK(ncclRecv(c->recv_bwd[mu], 2 * n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
+        const size_t cnt = halo_count(c, mu, kind, parity_mode), n = cnt * 2;  // n: scalars per face
+        char* sf = (char*)c->send_fwd[mu];
+        char* rb = (char*)c->recv_bwd[mu];
+        if (c->tun.halo_merge && c->nbr_fwd[mu] == c->nbr_bwd[mu]) {
+            NCCLCHK(ncclSend(sf, 2 * n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
+            NCCLCHK(ncclRecv(rb, 2 * n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
             continue;
         }
-        NCCLCHK(ncclSend(c->send_fwd[mu], n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclSend(c->send_bwd[mu], n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclRecv(c->recv_bwd[mu], n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclRecv(c->recv_fwd[mu], n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclSend(sf, n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclSend(sf + cnt * esize, n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclRecv(rb, n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclRecv(rb + cnt * esize, n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
     }
     NCCLCHK(ncclGroupEnd());
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     return LQCD_OK;
 }
 
-// in-process emulation: every rank has packed; copy sender buffers into the peers' receive buffers
+// in-process emulation (fp64): every rank has packed; copy sender buffers into the peers' receive buffers
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode) {
     for (int r = 0; r < n; r++) HIPCHK(hipStreamSynchronize(ctxs[r]->stream));
     for (int r = 0; r < n; r++) {
         lqcd_ctx_s* c = ctxs[r];
         for (int mu = 0; mu < 4; mu++) {
             if (!c->geom.part[mu]) continue;
-            const size_t bytes = halo_count(c, mu, kind, parity_mode) * sizeof(double2);
-            // my send_fwd lands in the +mu neighbour's recv_bwd; my send_bwd in the -mu neighbour's recv_fwd
+            const size_t cnt = halo_count(c, mu, kind, parity_mode), bytes = cnt * sizeof(double2);
+            // my fwd face lands in the +mu neighbour's "from bwd" half; my bwd face in the -mu neighbour's "from fwd" half
             HIPCHK(hipMemcpy(ctxs[c->nbr_fwd[mu]]->recv_bwd[mu], c->send_fwd[mu], bytes, hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(ctxs[c->nbr_bwd[mu]]->recv_fwd[mu], c->send_bwd[mu], bytes, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(ctxs[c->nbr_bwd[mu]]->recv_bwd[mu] + cnt, c->send_fwd[mu] + cnt, bytes, hipMemcpyDeviceToDevice));
         }
     }
     HIPCHK(hipDeviceSynchronize());

@@ -1344,8 +1344,11 @@ static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
     h.parity_mode = s.parity_mode;
     h.dagger = s.dagger;
     for (int mu = 0; mu < 4; mu++) {
-        h.send_fwd[mu] = (real2*)c->send_fwd[mu]; h.send_bwd[mu] = (real2*)c->send_bwd[mu];
-        h.recv_fwd[mu] = (const real2*)c->recv_fwd[mu]; h.recv_bwd[mu] = (const real2*)c->recv_bwd[mu];
+        // [send_fwd | send_bwd] and [recv_bwd | recv_fwd] are packed back to back for THIS call's message size (elements of this
+        // build's precision), so that a pair of faces bound for the same rank is one contiguous message (ops.hip)
+        const size_t cnt = (size_t)(s.parity_mode == 2 ? 2 : 1) * (s.kind == LQCD_WILSON ? 6 : 3) * face_half_sites(c->geom, mu);
+        h.send_fwd[mu] = (real2*)c->send_fwd[mu]; h.send_bwd[mu] = (real2*)c->send_fwd[mu] + cnt;
+        h.recv_bwd[mu] = (const real2*)c->recv_bwd[mu]; h.recv_fwd[mu] = (const real2*)c->recv_bwd[mu] + cnt;
         h.sign_fwd[mu] = (c->coord[mu] == c->pe[mu] - 1) ? c->geom.bc_fwd[mu] : 1.0;
         h.sign_bwd[mu] = (c->coord[mu] == 0) ? c->geom.bc_bwd[mu] : 1.0;
     }

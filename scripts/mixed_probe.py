@@ -9,6 +9,8 @@ eps = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-16
 kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
 U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
 lat = U.lattice
+if os.environ.get("LQCD_FORCE_PARTITION"):
+    lat.comm_init(lq.comm_unique_id())          # world-size-1 communicators: the real RCCL path against this rank itself
 for kv in os.environ.get("LQCD_SET", "").split():
     k, v = kv.split("=")
     lat.set_param(k, int(v))
