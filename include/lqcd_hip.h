@@ -94,7 +94,11 @@ int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g);
 int lqcd_gauge_destroy(lqcd_gauge_t g);
 int lqcd_gauge_upload(lqcd_gauge_t g, const double* host, int layout);   /* substitute_U! / load_* (universe.jl:58-77) */
 int lqcd_gauge_download(lqcd_gauge_t g, double* host, int layout);
-int lqcd_gauge_unit(lqcd_gauge_t g);                                      /* condition = "cold" (universe.jl:41-49) */
+/* the same for host arrays that carry the reference's wing of width nwing (Initialize_Gaugefields(NC, Nwing, ...), universe.jl:41-49;
+ * test/test_wilson.toml has Nwing = 1): extents L + 2 nwing, only the interior is read / written */
+int lqcd_gauge_upload_wing(lqcd_gauge_t g, const double* host, int nwing);
+int lqcd_gauge_download_wing(lqcd_gauge_t g, double* host, int nwing);
+int lqcd_gauge_unit(lqcd_gauge_t g);                                     /* condition = "cold" (universe.jl:41-49) */
 int lqcd_gauge_hot_start(lqcd_gauge_t g, uint64_t seed);                  /* condition = "hot"; counter-based, keyed by GLOBAL site */
 int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq);                   /* calculate_Plaquette (lqcd.jl:187-193), normalised 1/(6 V NC) */
 
@@ -103,7 +107,9 @@ int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, int subset);
 int lqcd_spinor_destroy(lqcd_spinor_t s);
 int lqcd_spinor_upload(lqcd_spinor_t s, const double* host);    /* reference layout; FULL-lattice host array even for EVEN/ODD subsets */
 int lqcd_spinor_download(lqcd_spinor_t s, double* host);        /* EVEN/ODD subsets write only their sites */
-int lqcd_spinor_zero(lqcd_spinor_t s);                          /* clear_fermion! */
+int lqcd_spinor_upload_wing(lqcd_spinor_t s, const double* host, int nwing);   /* fields created without nowing = true (universe.jl:107) */
+int lqcd_spinor_download_wing(lqcd_spinor_t s, double* host, int nwing);
+int lqcd_spinor_zero(lqcd_spinor_t s);                         /* clear_fermion! */
 int lqcd_spinor_copy(lqcd_spinor_t dst, lqcd_spinor_t src);     /* substitute_fermion! */
 int lqcd_spinor_gaussian(lqcd_spinor_t s, uint64_t seed);       /* gauss_distribution_fermion!: re,im ~ N(0,1), keyed by GLOBAL site */
 int lqcd_spinor_z4(lqcd_spinor_t s, uint64_t seed);             /* Z4_distribution_fermi! (unusedfiles/measure_chiral_condensate.jl:180) */

@@ -67,9 +67,13 @@ function HIPGaugefields(lat::HIPLattice)
     return g
 end
 # substitute_U!(Udev, U): U is the reference's Vector of 4 Array{ComplexF64,6} (NC,NC,NX,NY,NZ,NT), Nwing = 0
-function substitute_U!(g::HIPGaugefields, U::Vector{<:AbstractArray{ComplexF64,6}})
-    buf = cat(U...; dims = 7)      # [a,b,x,y,z,t,mu] column-major == lqcd LAYOUT_REFERENCE
-    check(ccall((:lqcd_gauge_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), g.h, buf, LAYOUT_REFERENCE))
+function substitute_U!(g::HIPGaugefields, U::Vector{<:AbstractArray{ComplexF64,6}}; Nwing = 0)
+    buf = cat(U...; dims = 7)      # [a,b,x,y,z,t,mu] column-major == lqcd LAYOUT_REFERENCE (extents L .+ 2Nwing when the fields carry wings)
+    if Nwing == 0
+        check(ccall((:lqcd_gauge_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), g.h, buf, LAYOUT_REFERENCE))
+    else    # the reference's Initialize_Gaugefields(NC, Nwing, ...) arrays (test/test_wilson.toml: Nwing = 1): interior only
+        check(ccall((:lqcd_gauge_upload_wing, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), g.h, buf, Nwing))
+    end
     return g
 end
 function calculate_Plaquette(g::HIPGaugefields)

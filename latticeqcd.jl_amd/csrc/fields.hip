@@ -14,14 +14,23 @@ __device__ inline size_t host_gauge_index(int layout, size_t V, int mu, size_t s
                                            : ((site * 4 + mu) * 3 + a) * 3 + b;
 }
 
-__global__ void gauge_reorder(Geom g, double2* dev, double2* host_img, int layout, int to_device) {
+// host arrays may carry a wing of width w in every direction (the reference's Nwing: extents L + 2w, interior at offset w,
+// Initialize_Gaugefields(NC, Nwing, ...) universe.jl:41-49): only the interior is read / written
+__device__ inline size_t host_site(const Geom& g, const int c[4], int w) {
+    return (size_t)(c[0] + w) + (size_t)(g.L[0] + 2 * w) * ((size_t)(c[1] + w) + (size_t)(g.L[1] + 2 * w) * ((size_t)(c[2] + w) + (size_t)(g.L[2] + 2 * w) * (size_t)(c[3] + w)));
+}
+__host__ __device__ inline size_t host_volume(const Geom& g, int w) {
+    return (size_t)(g.L[0] + 2 * w) * (g.L[1] + 2 * w) * (g.L[2] + 2 * w) * (g.L[3] + 2 * w);
+}
+
+__global__ void gauge_reorder(Geom g, double2* dev, double2* host_img, int layout, int to_device, int w) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * g.Vh) return;
     const int p = t / g.Vh, i = t % g.Vh;
     int c[4];
     cb_to_coords(g, p, i, c);
-    const size_t V = 2 * (size_t)g.Vh;
-    const size_t site = c[0] + (size_t)g.L[0] * (c[1] + (size_t)g.L[1] * (c[2] + (size_t)g.L[2] * c[3]));
+    const size_t V = host_volume(g, w);
+    const size_t site = host_site(g, c, w);
     for (int mu = 0; mu < 4; mu++)
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) {
@@ -33,7 +42,7 @@ __global__ void gauge_reorder(Geom g, double2* dev, double2* host_img, int layou
 
 // ------------------------------------------------------------------ spinor reorder
 // host: ic + 3*(site + V*is)  (Wilson, is = 0..3)  /  ic + 3*site (staggered)
-__global__ void spinor_reorder(Geom g, double2* dev0, double2* dev1, double2* host_img, int nspin, int to_device) {
+__global__ void spinor_reorder(Geom g, double2* dev0, double2* dev1, double2* host_img, int nspin, int to_device, int w) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * g.Vh) return;
     const int p = t / g.Vh, i = t % g.Vh;
@@ -41,8 +50,8 @@ __global__ void spinor_reorder(Geom g, double2* dev0, double2* dev1, double2* ho
     if (!dev) return;
     int c[4];
     cb_to_coords(g, p, i, c);
-    const size_t V = 2 * (size_t)g.Vh;
-    const size_t site = c[0] + (size_t)g.L[0] * (c[1] + (size_t)g.L[1] * (c[2] + (size_t)g.L[2] * c[3]));
+    const size_t V = host_volume(g, w);
+    const size_t site = host_site(g, c, w);
     for (int s = 0; s < nspin; s++)
         for (int ic = 0; ic < 3; ic++) {
             double2* d = dev + sp_off(nspin * 3, i) + (size_t)(s * 3 + ic) * sp_stride(g);
@@ -256,23 +265,24 @@ extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
     return LQCD_OK;
 }
 
-static int gauge_xfer(lqcd_gauge_t g, double* host, int layout, int to_device) {
+static int gauge_xfer(lqcd_gauge_t g, double* host, int layout, int to_device, int wing = 0) {
     ARGCHK(g && host, "gauge upload/download: null argument");
     ARGCHK(layout == LQCD_LAYOUT_REFERENCE || layout == LQCD_LAYOUT_DISK, "gauge upload/download: bad layout tag");
+    ARGCHK(wing >= 0 && wing <= 4 && (wing == 0 || layout == LQCD_LAYOUT_REFERENCE), "gauge upload/download: wings exist in the reference layout only (width 0..4)");
     lqcd_ctx_s* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     double2* img = nullptr;
-    const size_t bytes = (size_t)2 * 4 * 9 * c->geom.Vh * sizeof(double2);  // host image is unpadded
+    const size_t bytes = (size_t)4 * 9 * host_volume(c->geom, wing) * sizeof(double2);  // host image: no stride padding, wings if any
     HIPCHK(hipMalloc((void**)&img, bytes));
     int st = LQCD_OK;
     const int nt = 2 * c->geom.Vh;
-    if (to_device) {
-        g->version++;
+    if (to_device || wing) {      // a download into a winged array starts from the caller's image so that the wings survive
+        if (to_device) g->version++;
         hipError_t e = hipMemcpyAsync(img, host, bytes, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) st = hip_fail(e, "H2D gauge", __FILE__, __LINE__);
     }
     if (st == LQCD_OK) {
-        hipLaunchKernelGGL(gauge_reorder, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, g->data, img, layout, to_device);
+        hipLaunchKernelGGL(gauge_reorder, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, g->data, img, layout, to_device, wing);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) st = hip_fail(e, "gauge_reorder", __FILE__, __LINE__);
     }
@@ -290,6 +300,11 @@ extern "C" int lqcd_gauge_upload(lqcd_gauge_t g, const double* host, int layout)
     return gauge_xfer(g, const_cast<double*>(host), layout, 1);
 }
 extern "C" int lqcd_gauge_download(lqcd_gauge_t g, double* host, int layout) { return gauge_xfer(g, host, layout, 0); }
+// the reference's arrays with Nwing > 0: (NC,NC,NX+2w,NY+2w,NZ+2w,NT+2w) per direction; only the interior is transferred
+extern "C" int lqcd_gauge_upload_wing(lqcd_gauge_t g, const double* host, int nwing) {
+    return gauge_xfer(g, const_cast<double*>(host), LQCD_LAYOUT_REFERENCE, 1, nwing);
+}
+extern "C" int lqcd_gauge_download_wing(lqcd_gauge_t g, double* host, int nwing) { return gauge_xfer(g, host, LQCD_LAYOUT_REFERENCE, 0, nwing); }
 
 extern "C" int lqcd_gauge_unit(lqcd_gauge_t g) {
     ARGCHK(g, "lqcd_gauge_unit: null");
@@ -425,23 +440,24 @@ double2* spinor_block(lqcd_spinor_s* s, int p) {
 }
 }  // namespace lqcd
 
-static int spinor_xfer(lqcd_spinor_t s, double* host, int to_device) {
+static int spinor_xfer(lqcd_spinor_t s, double* host, int to_device, int wing = 0) {
     ARGCHK(s && host, "spinor upload/download: null argument");
+    ARGCHK(wing >= 0 && wing <= 4, "spinor upload/download: wing width 0..4");
     lqcd_ctx_s* c = s->ctx;
     HIPCHK(hipSetDevice(c->device));
-    const size_t full = (size_t)s->ncomp * 2 * c->geom.Vh;
+    const size_t full = (size_t)s->ncomp * host_volume(c->geom, wing);
     const size_t bytes = full * sizeof(double2);
     double2* img = nullptr;
     HIPCHK(hipMalloc((void**)&img, bytes));
     int st = LQCD_OK;
     hipError_t e = hipSuccess;
     // download of a half field: start from the caller's array so the other parity is preserved
-    if (to_device || s->subset != LQCD_FULL) e = hipMemcpyAsync(img, host, bytes, hipMemcpyHostToDevice, c->stream);
+    if (to_device || s->subset != LQCD_FULL || wing) e = hipMemcpyAsync(img, host, bytes, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) st = hip_fail(e, "H2D spinor", __FILE__, __LINE__);
     if (st == LQCD_OK) {
         const int nt = 2 * c->geom.Vh;
         hipLaunchKernelGGL(spinor_reorder, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, spinor_block(s, 0),
-                           spinor_block(s, 1), img, s->ncomp / 3, to_device);
+                           spinor_block(s, 1), img, s->ncomp / 3, to_device, wing);
         e = hipGetLastError();
         if (e != hipSuccess) st = hip_fail(e, "spinor_reorder", __FILE__, __LINE__);
     }
@@ -457,6 +473,9 @@ static int spinor_xfer(lqcd_spinor_t s, double* host, int to_device) {
 
 extern "C" int lqcd_spinor_upload(lqcd_spinor_t s, const double* host) { return spinor_xfer(s, const_cast<double*>(host), 1); }
 extern "C" int lqcd_spinor_download(lqcd_spinor_t s, double* host) { return spinor_xfer(s, host, 0); }
+// fields created without nowing = true carry a wing (the staggered fields of universe.jl:107): (NC,NX+2w,...,NT+2w,NG)
+extern "C" int lqcd_spinor_upload_wing(lqcd_spinor_t s, const double* host, int nwing) { return spinor_xfer(s, const_cast<double*>(host), 1, nwing); }
+extern "C" int lqcd_spinor_download_wing(lqcd_spinor_t s, double* host, int nwing) { return spinor_xfer(s, host, 0, nwing); }
 
 extern "C" int lqcd_spinor_zero(lqcd_spinor_t s) {
     ARGCHK(s, "lqcd_spinor_zero: null");

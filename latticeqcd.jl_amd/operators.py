@@ -110,13 +110,24 @@ class Gaugefields:
         self._h = C.c_void_p()
         check(_l.lib().lqcd_gauge_create(lattice._h, C.byref(self._h)))
 
-    def upload(self, U, layout=_l.LAYOUT_REFERENCE):
+    def upload(self, U, layout=_l.LAYOUT_REFERENCE, nwing=0):
+        """nwing > 0: U has the reference's winged shape (4, NT+2w, NZ+2w, NY+2w, NX+2w, 3, 3) (Nwing of universe.jl:41-49)."""
         U = np.ascontiguousarray(U, dtype=np.complex128)
+        if nwing:
+            l = self.lattice.local_L
+            assert U.shape == (4, l[3] + 2 * nwing, l[2] + 2 * nwing, l[1] + 2 * nwing, l[0] + 2 * nwing, 3, 3), U.shape
+            check(_l.lib().lqcd_gauge_upload_wing(self._h, _ptr(U), int(nwing)))
+            return self
         assert U.size == int(np.prod(self.lattice.gauge_shape)), (U.shape, self.lattice.gauge_shape)
         check(_l.lib().lqcd_gauge_upload(self._h, _ptr(U), int(layout)))
         return self
 
-    def download(self, layout=_l.LAYOUT_REFERENCE):
+    def download(self, layout=_l.LAYOUT_REFERENCE, nwing=0, into=None):
+        if nwing:
+            l = self.lattice.local_L
+            U = into if into is not None else np.zeros((4, l[3] + 2 * nwing, l[2] + 2 * nwing, l[1] + 2 * nwing, l[0] + 2 * nwing, 3, 3), dtype=np.complex128)
+            check(_l.lib().lqcd_gauge_download_wing(self._h, _ptr(U), int(nwing)))
+            return U
         U = np.empty(self.lattice.gauge_shape, dtype=np.complex128)
         check(_l.lib().lqcd_gauge_download(self._h, _ptr(U), int(layout)))
         return U
@@ -165,11 +176,19 @@ class Fermionfields:
         self._h = C.c_void_p()
         check(_l.lib().lqcd_spinor_create(lattice._h, C.byref(self._h), int(kind), int(subset)))
 
-    def upload(self, psi):
+    def upload(self, psi, nwing=0):
+        """nwing > 0: psi carries the reference's wing (fields created without nowing = true, universe.jl:107)."""
         psi = np.ascontiguousarray(psi, dtype=np.complex128)
+        if nwing:
+            check(_l.lib().lqcd_spinor_upload_wing(self._h, _ptr(psi), int(nwing)))
+            return self
         assert psi.shape == self.lattice.fermion_shape(self.kind), (psi.shape, self.lattice.fermion_shape(self.kind))
         check(_l.lib().lqcd_spinor_upload(self._h, _ptr(psi)))
         return self
+
+    def download_wing(self, into, nwing):
+        check(_l.lib().lqcd_spinor_download_wing(self._h, _ptr(into), int(nwing)))
+        return into
 
     def download(self, into=None):
         out = np.zeros(self.lattice.fermion_shape(self.kind), dtype=np.complex128) if into is None else into
