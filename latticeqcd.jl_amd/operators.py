@@ -411,20 +411,28 @@ def apply_inverse_power_(y, A, x, alpha, lam_min, lam_max, tol=1e-10):
 
 # ------------------------------------------------------------------------------------ pseudofermion action and force
 class FermiAction:
-    """FermiAction(D, Dict("Nf"=>2)) (universe.jl:138): the 2-flavour pseudofermion action S_f = eta' (D'D)^-1 eta.
-    Keeps X = (D'D)^-1 eta and Y = D X resident between evaluate_FermiAction and calc_UdSfdU_."""
+    """FermiAction(D, Dict("Nf"=>...)) (universe.jl:138): the pseudofermion action S_f = eta' (D'D)^-1 eta.
+    Wilson: Nf = 2.  Staggered: Nf = 8 (eta on every site) or Nf = 4 (the reference's "4 tastes", test/test_staggered.toml:
+    eta lives on the even sites only -- D'D = m^2 - D_hop^2 is block diagonal in parity, so the solve and the force are the same
+    kernels with the odd half of eta zero; sample_pseudofermions_ does the masking).  Other Nf need the rational path
+    (apply_inverse_power_ / shiftedcg).  Keeps X = (D'D)^-1 eta and Y = D X resident between evaluate_FermiAction and calc_UdSfdU_."""
 
     def __init__(self, D, params=None):
-        nf = (params or {}).get("Nf", 2)
-        if nf != 2:
-            raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Nf = {nf} needs the RHMC path (shiftedcg); only Nf = 2 is wired here")
-        self.D = D
         kind = D.kind
+        nf = (params or {}).get("Nf", 2 if kind == WILSON else 4)
+        if (kind == WILSON and nf != 2) or (kind == STAGGERED and nf not in (4, 8)):
+            raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Nf = {nf} needs the RHMC path (shiftedcg, apply_inverse_power_)")
+        self.D = D
+        self.Nf = nf
+        self.evensite = kind == STAGGERED and nf == 4
+        self._half = Fermionfields(D.lattice, kind, EVEN) if self.evensite else None
         self._temporary_fermionfields = [Fermionfields(D.lattice, kind) for _ in range(2)]   # standardMD.jl:50-51
 
     def close(self):
         for f in self._temporary_fermionfields:
             f.close()
+        if self._half is not None:
+            self._half.close()
 
 
 def gauss_sampling_in_action_(xi, U, fa, randomseed=112):
@@ -437,8 +445,14 @@ def gauss_sampling_in_action_(xi, U, fa, randomseed=112):
 
 
 def sample_pseudofermions_(eta, U, fa, xi):
-    """sample_pseudofermions!(eta, U, fa, xi) (standardMD.jl:96): eta = D' xi."""
-    return mul_(eta, fa.D(U).adjoint(), xi)
+    """sample_pseudofermions!(eta, U, fa, xi) (standardMD.jl:96): eta = D' xi (restricted to the even sites for 4 staggered tastes,
+    in which case the action at the start of a trajectory is evaluate_FermiAction(fa, U, eta), not xi'xi)."""
+    mul_(eta, fa.D(U).adjoint(), xi)
+    if fa.evensite:
+        extract_fermion_(fa._half, eta)
+        clear_fermion_(eta)
+        insert_fermion_(eta, fa._half)
+    return eta
 
 
 def evaluate_FermiAction(fa, U, eta, return_info=False):

@@ -25,10 +25,9 @@ def test_hmc_repeats_the_reference_staggered_test_on_device(lq, orc):
     U = lq.Gaugefields(lat).upload(Uh)
     start = lq.calculate_Plaquette(U)
     D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": MASS, "boundarycondition": BC, "eps_CG": 1e-19})
-    fa = lq.FermiAction(D)
+    fa = lq.FermiAction(D, {"Nf": 4})
     p, G, Uold = lq.Gaugefields(lat), lq.Gaugefields(lat), lq.Gaugefields(lat)
     xi, phi = lq.Fermionfields(lat, lq.STAGGERED), lq.Fermionfields(lat, lq.STAGGERED)
-    half = lq.Fermionfields(lat, lq.STAGGERED, lq.EVEN)
     dtau, mdsteps = 0.025, 40
     rng = np.random.default_rng(111)
     dHs, acc = [], 0
@@ -36,10 +35,7 @@ def test_hmc_repeats_the_reference_staggered_test_on_device(lq, orc):
         lq.substitute_U_(Uold, U)
         lq.gauss_distribution_(p, 500 + traj)
         lq.gauss_sampling_in_action_(xi, U, fa, 600 + traj)
-        lq.sample_pseudofermions_(phi, U, fa, xi)          # phi = D^+ xi ...
-        lq.extract_fermion_(half, phi)                     # ... restricted to the even sites (4 tastes)
-        lq.clear_fermion_(phi)
-        lq.insert_fermion_(phi, half)
+        lq.sample_pseudofermions_(phi, U, fa, xi)          # phi = (D^+ xi) restricted to the even sites (Nf = 4: 4 tastes)
         Hold = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA) + lq.evaluate_FermiAction(fa, U, phi)
         for _ in range(mdsteps):                           # runMD_QPQ!
             lq.U_update_(U, p, 0.5 * dtau)
