@@ -265,8 +265,8 @@ struct lqcd_ctx_s {
     // staple-force halos (md.hip): forward ghost links (+ their send buffer) and the lower-staple faces, allocated on first use
     double2* gf_ghost[4] = {}, *gf_gsend[4] = {}, *gf_wsend[4] = {}, *gf_wrecv[4] = {};
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
-    void* mix_buf[6] = {};
-    size_t mix_bytes[6] = {};
+    void* mix_buf[7] = {};
+    size_t mix_bytes[7] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;

@@ -97,7 +97,7 @@ static int mix_alloc(lqcd_ctx_s* c, int slot, size_t bytes) {
 }
 
 struct Mix32 {
-    float2 *gauge, *gauge12, *x, *r, *p, *t;
+    float2 *gauge, *gauge12, *clover, *x, *r, *p, *t;
     size_t blk;   // elements per parity block
 };
 
@@ -106,7 +106,8 @@ static StencilCall call32(lqcd_op_s* op, const Mix32& m, float2* out, float2* in
     StencilCall s;
     s.kind = op->kind;
     s.gauge = (const double2*)m.gauge;
-    s.gauge12 = (const double2*)m.gauge12;
+    s.gauge12 = m.clover ? nullptr : (const double2*)m.gauge12;   // the clover instance of the split kernel reads 18-real links
+    s.clover = (const double2*)m.clover;
     for (int p = 0; p < 2; p++) {
         s.out[p] = (double2*)(out + p * m.blk);
         s.in[p] = (const double2*)(in + p * m.blk);
@@ -175,7 +176,11 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
                b->subset == LQCD_FULL && x != b && maxiter >= 0,
            "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
     lqcd_ctx_s* c = op->ctx;
-    if (op->csw != 0.0) { set_error("lqcd_solve_mixed_cg_DdagD: not available for the Wilson-clover operator yet (no fp32 clover term)"); return LQCD_ERR_UNSUPPORTED; }
+    const bool clov = op->csw != 0.0 && op->clover != nullptr;
+    if (clov && !(op->r == 1.0 && c->tun.dslash_variant == 1)) {
+        set_error("lqcd_solve_mixed_cg_DdagD: the Wilson-clover operator needs the direction-split kernel (r = 1, dslash_variant = 1) in the fp32 inner solver");
+        return LQCD_ERR_UNSUPPORTED;
+    }
     HIPCHK(hipSetDevice(c->device));
     if (inner_tol <= 0.0) inner_tol = 1e-4;
     const size_t n = x->elems, ng = op->gauge->elems;
@@ -185,6 +190,11 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     Mix32 m;
     m.gauge = (float2*)c->mix_buf[0];
     m.gauge12 = (float2*)c->mix_buf[5];
+    m.clover = nullptr;
+    if (clov) {
+        LQCHK(mix_alloc(c, 6, clover_elems(c->geom) * sizeof(float2)));
+        m.clover = (float2*)c->mix_buf[6];
+    }
     m.x = (float2*)c->mix_buf[1]; m.r = (float2*)c->mix_buf[2]; m.p = (float2*)c->mix_buf[3]; m.t = (float2*)c->mix_buf[4];
     m.blk = n / 2;
     lqcd_spinor_s* r = scratch_get(c, x->kind, LQCD_FULL);
@@ -208,6 +218,14 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     };
     auto run = [&]() -> int {
         hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
+        if (clov) {     // fp32 copy of the packed clover blocks (same layout); A follows the links first
+            if (op->clover_version != op->gauge->version) {
+                LQCHK(clover_build(c, op->gauge, op->clover, op->km, op->csw));
+                op->clover_version = op->gauge->version;
+            }
+            const size_t nc = clover_elems(c->geom);
+            hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, m.clover, op->clover, nc, 1.0);
+        }
         hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
         HIPCHK(hipGetLastError());
         LQCHK(true_residual());

@@ -1230,7 +1230,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.g = c->geom;
     k.gauge = (const real2*)s.gauge;
     k.gauge12 = (const real2*)s.gauge12;   // elements of this build's precision (the caller matches prec)
-    k.clover = s.prec ? nullptr : (const real2*)s.clover;
+    k.clover = (const real2*)s.clover;     // elements of this build's precision (the caller matches prec)
     for (int p = 0; p < 2; p++) { k.out[p] = (real2*)s.out[p]; k.in[p] = (const real2*)s.in[p]; k.xin[p] = (const real2*)s.xin[p]; }
     k.a = s.a; k.b = s.b; k.r = s.r;
     k.parity_mode = s.parity_mode;

@@ -6,7 +6,7 @@ import latticeqcd_jl_amd as lq
 L = tuple(int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "32,32,32,64").split(","))
 kind_name = sys.argv[2] if len(sys.argv) > 2 else "Wilson"
 eps = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-16
-kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+kind = lq.WILSON if kind_name.startswith("Wilson") else lq.STAGGERED
 U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
 lat = U.lattice
 if os.environ.get("LQCD_FORCE_PARTITION"):
@@ -14,7 +14,7 @@ if os.environ.get("LQCD_FORCE_PARTITION"):
 for kv in os.environ.get("LQCD_SET", "").split():
     k, v = kv.split("=")
     lat.set_param(k, int(v))
-D = lq.Dirac_operator(U, None, {"Dirac_operator": kind_name, "κ": 0.141139, "mass": 0.05, "eps_CG": eps})
+D = lq.Dirac_operator(U, None, {"Dirac_operator": kind_name, "κ": 0.141139, "mass": 0.05, "eps_CG": eps, "Clover_coefficient": 1.0})
 A = lq.DdagD_operator(D)
 b = lq.Fermionfields(lat, kind)
 lq.gauss_distribution_fermion_(b, 112)

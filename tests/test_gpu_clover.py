@@ -45,12 +45,19 @@ def test_wilson_clover_matches_oracle(lq, orc, L):
     U.upload(Uh2)
     lq.mul_(y, D, x)
     assert rel_err(y.download(), orc.wilson_clover_D(Uh2, orc.clover_build(Uh2, L, KAPPA, CSW), psi, L, KAPPA, 1.0, BC)) < 1e-13
+    # mixed-precision CG (fp32 links and fp32 clover blocks inside, fp64 defect correction): same stopping rule on the true residual
+    A2 = orc.clover_build(Uh2, L, KAPPA, CSW)
+    lq.clear_fermion_(sol)
+    itm, outer, rrm = lq.solve_mixed_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+    xo2, _, _, st2 = orc.cg_clover(Uh2, A2, psi, L, KAPPA, 1.0, BC, eps=1e-19)
+    assert st2 == 0 and rrm < 1e-19 and outer >= 2 and rel_err(sol.download(), xo2) < 1e-8
+    lq.mul_(y, lq.DdagD_operator(D), sol)
+    lq.add_fermion_(y, -1.0, x)
+    assert lq.dot(y, y).real < 1e-19
     # what is not built yet fails loudly
     D.method_CG = "bicgstab_evenodd"
     with pytest.raises(lq.LQCDError):
         lq.solve_DinvX_(sol, D, x)
-    with pytest.raises(lq.LQCDError):
-        lq.solve_mixed_DinvX_(sol, lq.DdagD_operator(D), x)
     with pytest.raises(lq.LQCDError):
         lq.calc_UdSfdU_(lq.Gaugefields(lat), lq.FermiAction(D), U, x)
 
