@@ -183,6 +183,20 @@ int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spi
 int lqcd_mdom_fermion_force(int n, lqcd_op_t* ops, lqcd_gauge_t* outs, lqcd_spinor_t* X, lqcd_spinor_t* Y);
 /* calc_UdSfdU! in one call: solve, Y = D X and the sweep, all resident; Sf and iters may be NULL */
 int lqcd_calc_UdSfdU(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t eta, double eps, int maxiter, double* Sf, int* iters);
+/* lqcd_fermion_force with out = (accumulate ? out : 0) + scale * G -- sums over the poles of a rational action in place */
+int lqcd_fermion_force_acc(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y, double scale, int accumulate);
+/* General-Nf (RHMC) pseudofermion action of the reference's staggered runs (FermiAction(D, Dict("Nf" => 2 | 3)),
+ * src/system/universe.jl:109,138; test/test_Nf2.toml:8, test/test_Nf3.toml:8; README.md:132):
+ * S_f = phi^+ (D^+D)^(-Nf/8) phi with the partial fractions  x^(-alpha) ~= a0 + sum_k res[k] / (x + poles[k])  supplied by the host
+ * (poles >= 0).  One multi-shift solve per call, the shifted solutions stay in the context's scratch pool.
+ *   lqcd_rational_apply:  y = a0 x + sum_k res[k] (D^+D + poles[k])^-1 x     (evaluate_FermiAction: S_f = Re <phi, y>;
+ *                         heat bath of sample_pseudofermions!: phi = D^+D y with the fit of x^(Nf/16 - 1))
+ *   lqcd_rational_force:  out = sum_k res[k] G[X_k, D X_k], X_k = (D^+D + poles[k])^-1 phi  -- calc_UdSfdU! for this action, same
+ *                         convention as lqcd_fermion_force.  iters may be NULL. */
+int lqcd_rational_apply(lqcd_op_t op, lqcd_spinor_t y, lqcd_spinor_t x, double a0, int n, const double* res, const double* poles,
+                        double eps, int maxiter, int* iters);
+int lqcd_rational_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t phi, int n, const double* res, const double* poles, double eps,
+                        int maxiter, int* iters);
 
 /* ---------------------------------------------------------------- gauge side of the MD step
  * Momenta are traceless anti-Hermitian 3x3 matrices held in a gauge-shaped field (lqcd_gauge_create).  Conventions (fixed by

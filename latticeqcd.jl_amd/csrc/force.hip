@@ -34,6 +34,8 @@ struct FArgs {
     double coef;               // kappa (Wilson) or -1/2 (staggered)
     double r;
     int nc;                    // components per spinor: 12 | 3
+    double scale;              // out = (acc ? out : 0) + scale * G   (sums over the poles of a rational action)
+    int acc;
 };
 
 // (g_MU psi)[S][c] for a full 4-spinor held in registers
@@ -150,9 +152,13 @@ __device__ __forceinline__ void wilson_force_site(const FArgs& k, int p, int i, 
             outer_acc(C, x, w, -1.0);
         }
     }
-    const double f = k.coef * nb.sign;
+    const double f = k.coef * nb.sign * k.scale;
 #pragma unroll
-    for (int e = 0; e < 9; e++) st(k.out + go + (size_t)e * Gs, mk(f * C[e].re, f * C[e].im));
+    for (int e = 0; e < 9; e++) {
+        cd o = mk(f * C[e].re, f * C[e].im);
+        if (k.acc) { const cd old = ld(k.out + go + (size_t)e * Gs); o = mk(o.re + old.re, o.im + old.im); }
+        st(k.out + go + (size_t)e * Gs, o);
+    }
 }
 
 __global__ __launch_bounds__(256) void wilson_force_kernel(FArgs k) {
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void staggered_force_kernel(FArgs k) {
     const Nbr nb = fwd_neighbour(k, p, c, mu);
     int e = 0;                                   // eta_mu(n) = (-1)^(x_0 + ... + x_{mu-1}), GLOBAL coordinates
     for (int nu = 0; nu < mu; nu++) e += c[nu] + g.origin[nu];
-    const double f = k.coef * nb.sign * ((e & 1) ? -1.0 : 1.0);
+    const double f = k.coef * nb.sign * k.scale * ((e & 1) ? -1.0 : 1.0);
     const size_t go = glink_off(g, p, mu, i);
     cd u[9], C[9], xn[3], yn[3], xp[3], yp[3], ux[3], uy[3];
 #pragma unroll
@@ -196,7 +202,11 @@ __global__ __launch_bounds__(256) void staggered_force_kernel(FArgs k) {
     outer_acc(C, ux, yn, 1.0);
     outer_acc(C, xn, uy, 1.0);
 #pragma unroll
-    for (int q = 0; q < 9; q++) st(k.out + go + (size_t)q * Gs, mk(f * C[q].re, f * C[q].im));
+    for (int q = 0; q < 9; q++) {
+        cd o = mk(f * C[q].re, f * C[q].im);
+        if (k.acc) { const cd old = ld(k.out + go + (size_t)q * Gs); o = mk(o.re + old.re, o.im + old.im); }
+        st(k.out + go + (size_t)q * Gs, o);
+    }
 }
 
 // lower-face sites (x_mu = 0) of both parities: copy the full X and Y spinors into the send buffer of direction mu = blockIdx.y
@@ -247,6 +257,8 @@ static FArgs make_fargs(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gau
     k.coef = kind == LQCD_WILSON ? km : -0.5;
     k.r = r;
     k.nc = kind == LQCD_WILSON ? 12 : 3;
+    k.scale = 1.0;
+    k.acc = 0;
     return k;
 }
 
@@ -297,8 +309,10 @@ int force_halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind) {
 }
 
 int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
-                         double r) {
+                         double r, double scale, int accumulate) {
     FArgs k = make_fargs(c, kind, U, out, X, Y, km, r);
+    k.scale = scale;
+    k.acc = accumulate;
     out->version++;
     const int nb = 2 * c->geom.nch;
     if (kind == LQCD_WILSON) hipLaunchKernelGGL(wilson_force_kernel, dim3(nb), dim3(256), 0, c->stream, k);

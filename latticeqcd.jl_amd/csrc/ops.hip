@@ -938,8 +938,9 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
     return LQCD_OK;
 }
 
-// G_mu(n) = "U dS_f/dU" from resident X = (D^+D)^-1 eta and Y = D X (force.hip); out is a link-shaped field
-extern "C" int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y) {
+// G_mu(n) = "U dS_f/dU" from resident X = (D^+D)^-1 eta and Y = D X (force.hip); out is a link-shaped field.
+// out = (accumulate ? out : 0) + scale * G: the sum over the poles of a rational action is built in place.
+extern "C" int lqcd_fermion_force_acc(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y, double scale, int accumulate) {
     LQCHK(check_full(op, X, Y, "lqcd_fermion_force"));
     LQCHK(no_clover(op, "lqcd_fermion_force (the derivative of the clover term is not built)"));
     ARGCHK(out && out->ctx == op->ctx && out != op->gauge, "lqcd_fermion_force: out must be a gauge-shaped field of the same context, not the operator's links");
@@ -951,9 +952,12 @@ extern "C" int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t 
         LQCHK(launch_force_pack(c, op->kind, X, Y));
         LQCHK(force_halo_exchange_rccl(c, op->kind));
     }
-    LQCHK(launch_fermion_force(c, op->kind, op->gauge, out, X, Y, op->km, op->r));
+    LQCHK(launch_fermion_force(c, op->kind, op->gauge, out, X, Y, op->km, op->r, scale, accumulate ? 1 : 0));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
+}
+extern "C" int lqcd_fermion_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y) {
+    return lqcd_fermion_force_acc(op, out, X, Y, 1.0, 0);
 }
 
 // in-process PE-grid emulation of the same sequence (tests): ops/outs/X/Y ordered by rank
@@ -986,6 +990,57 @@ extern "C" int lqcd_calc_UdSfdU(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t et
     if (st == LQCD_OK) st = lqcd_fermi_action(op, eta, X, Y, eps, maxiter, Sf, iters);
     if (st == LQCD_OK) st = lqcd_fermion_force(op, out, X, Y);
     scratch_put(X); scratch_put(Y);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------- C API: rational (RHMC) action
+// The general-Nf pseudofermion action of the reference's staggered runs (test/test_Nf2.toml:8, test/test_Nf3.toml:8, README.md:132):
+// S_f = phi^+ (D^+D)^(-alpha) phi with (D^+D)^(-alpha) ~= a0 + sum_k res_k / (D^+D + pole_k).  One multi-shift solve gives every
+// X_k = (D^+D + pole_k)^-1 phi; the fields live in the context's scratch pool, nothing leaves the device.
+static int rational_solve(lqcd_op_s* op, lqcd_spinor_s* b, int n, const double* poles, double eps, int maxiter, std::vector<lqcd_spinor_s*>& xs,
+                          int* iters) {
+    lqcd_ctx_s* c = op->ctx;
+    xs.assign(n, nullptr);
+    for (int k = 0; k < n; k++) {
+        xs[k] = scratch_get(c, op->kind, LQCD_FULL);
+        if (!xs[k]) { set_error("rational action: out of device memory"); return LQCD_ERR_HIP; }
+    }
+    return lqcd_solve_multishift_cg(op, nullptr, xs.data(), b, poles, n, eps, maxiter, iters, nullptr);
+}
+
+// y = a0 x + sum_k res_k (D^+D + pole_k)^-1 x      (action: S_f = Re <phi, y>; heat bath: phi = D^+D y with the 1 - Nf/16 fit)
+extern "C" int lqcd_rational_apply(lqcd_op_t op, lqcd_spinor_t y, lqcd_spinor_t x, double a0, int n, const double* res, const double* poles,
+                                   double eps, int maxiter, int* iters) {
+    LQCHK(check_full(op, y, x, "lqcd_rational_apply"));
+    ARGCHK(n >= 1 && res && poles && y != x, "lqcd_rational_apply: need n >= 1 residues and poles and distinct fields");
+    lqcd_ctx_s* c = op->ctx;
+    std::vector<lqcd_spinor_s*> xs;
+    int st = rational_solve(op, x, n, poles, eps, maxiter, xs, iters);
+    if (st == LQCD_OK) {
+        st = lqcd_spinor_copy(y, x);
+        if (st == LQCD_OK) st = lqcd_scale(a0, 0.0, y);
+        for (int k = 0; k < n && st == LQCD_OK; k++) st = lqcd_axpy(res[k], 0.0, xs[k], y);
+    }
+    for (auto* s : xs) scratch_put(s);
+    (void)c;
+    return st;
+}
+
+// out = sum_k res_k G[X_k, D X_k]: the force of S_f = phi^+ r(D^+D) phi (d(A + p)^-1 = -(A + p)^-1 dA (A + p)^-1 term by term)
+extern "C" int lqcd_rational_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t phi, int n, const double* res, const double* poles, double eps,
+                                   int maxiter, int* iters) {
+    ARGCHK(op && phi && out && n >= 1 && res && poles, "lqcd_rational_force: null argument");
+    LQCHK(force_check(op, "lqcd_rational_force"));
+    lqcd_ctx_s* c = op->ctx;
+    std::vector<lqcd_spinor_s*> xs;
+    lqcd_spinor_s* Y = scratch_get(c, op->kind, LQCD_FULL);
+    int st = Y ? rational_solve(op, phi, n, poles, eps, maxiter, xs, iters) : LQCD_ERR_HIP;
+    for (int k = 0; k < n && st == LQCD_OK; k++) {
+        st = op_apply_async(op, Y, xs[k], 0, nullptr);
+        if (st == LQCD_OK) st = lqcd_fermion_force_acc(op, out, xs[k], Y, res[k], k > 0);
+    }
+    for (auto* s : xs) scratch_put(s);
+    scratch_put(Y);
     return st;
 }
 

@@ -414,17 +414,43 @@ class FermiAction:
     """FermiAction(D, Dict("Nf"=>...)) (universe.jl:138): the pseudofermion action S_f = eta' (D'D)^-1 eta.
     Wilson: Nf = 2.  Staggered: Nf = 8 (eta on every site) or Nf = 4 (the reference's "4 tastes", test/test_staggered.toml:
     eta lives on the even sites only -- D'D = m^2 - D_hop^2 is block diagonal in parity, so the solve and the force are the same
-    kernels with the odd half of eta zero; sample_pseudofermions_ does the masking).  Other Nf need the rational path
-    (apply_inverse_power_ / shiftedcg).  Keeps X = (D'D)^-1 eta and Y = D X resident between evaluate_FermiAction and calc_UdSfdU_."""
+    kernels with the odd half of eta zero; sample_pseudofermions_ does the masking).
+    Staggered with any other 0 < Nf < 8 (test/test_Nf2.toml:8, test/test_Nf3.toml:8) is the rational action
+    S_f = eta' (D'D)^(-Nf/8) eta: partial fractions from rational.py on the spectral interval [m^2, m^2 + 16] (|D_hop| <= 4), a
+    tighter fit for the action and the heat bath ("rhmc_tol_action", default 1e-12) than for the MD force ("rhmc_tol_MD", 1e-8),
+    one multi-shift solve per evaluation (lqcd_rational_apply / lqcd_rational_force).
+    Keeps X = (D'D)^-1 eta and Y = D X resident between evaluate_FermiAction and calc_UdSfdU_."""
 
     def __init__(self, D, params=None):
         kind = D.kind
-        nf = (params or {}).get("Nf", 2 if kind == WILSON else 4)
-        if (kind == WILSON and nf != 2) or (kind == STAGGERED and nf not in (4, 8)):
-            raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Nf = {nf} needs the RHMC path (shiftedcg, apply_inverse_power_)")
+        params = params or {}
+        nf = params.get("Nf", 2 if kind == WILSON else 4)
+        if kind == WILSON and nf != 2:
+            raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Wilson Nf = {nf} is not available (shiftedcg / apply_inverse_power_ are the building blocks)")
         self.D = D
         self.Nf = nf
         self.evensite = kind == STAGGERED and nf == 4
+        self.rational = kind == STAGGERED and nf not in (4, 8)
+        if self.rational:
+            if not (0 < nf < 8):
+                raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: staggered Nf = {nf} outside (0, 8)")
+            from . import rational
+            lo, hi = D.km * D.km, D.km * D.km + 16.0
+            lo, hi = lo * (1.0 - 1e-9), hi * (1.0 + 1e-9)
+            tol_a, tol_md = float(params.get("rhmc_tol_action", 1e-12)), float(params.get("rhmc_tol_MD", 1e-8))
+            self.alpha = nf / 8.0
+
+            def fit(alpha, tol):        # wide intervals (small masses) cost digits in double precision: loosen until the fit verifies
+                while True:
+                    try:
+                        return rational.inverse_power_partial_fractions(alpha, lo, hi, tol)[:3]
+                    except RuntimeError:
+                        if tol > 1e-7:
+                            raise
+                        tol *= 10.0
+            self.rhmc_action = fit(self.alpha, tol_a)                 # x^(-Nf/8)
+            self.rhmc_MD = fit(self.alpha, tol_md)
+            self.rhmc_sampling = fit(1.0 - nf / 16.0, tol_a)          # x^(Nf/16) = x * x^(Nf/16 - 1)
         self._half = Fermionfields(D.lattice, kind, EVEN) if self.evensite else None
         self._temporary_fermionfields = [Fermionfields(D.lattice, kind) for _ in range(2)]   # standardMD.jl:50-51
 
@@ -433,6 +459,19 @@ class FermiAction:
             f.close()
         if self._half is not None:
             self._half.close()
+
+
+def _darr(v):
+    return (C.c_double * len(v))(*[float(t) for t in v])
+
+
+def _rational_apply(D, y, x, coeffs):
+    """y = a0 x + sum_k res_k (D'D + pole_k)^-1 x on the device; returns the multi-shift iteration count."""
+    a0, res, poles = coeffs
+    it = C.c_int(0)
+    check(_l.lib().lqcd_rational_apply(D._h, y._h, x._h, C.c_double(a0), len(res), _darr(res), _darr(poles), C.c_double(D.eps_CG), D.MaxCGstep,
+                                       C.byref(it)))
+    return it.value
 
 
 def gauss_sampling_in_action_(xi, U, fa, randomseed=112):
@@ -447,6 +486,11 @@ def gauss_sampling_in_action_(xi, U, fa, randomseed=112):
 def sample_pseudofermions_(eta, U, fa, xi):
     """sample_pseudofermions!(eta, U, fa, xi) (standardMD.jl:96): eta = D' xi (restricted to the even sites for 4 staggered tastes,
     in which case the action at the start of a trajectory is evaluate_FermiAction(fa, U, eta), not xi'xi)."""
+    if fa.rational:        # eta = (D'D)^(Nf/16) xi, so that eta' (D'D)^(-Nf/8) eta = xi' xi
+        D = fa.D(U)
+        _rational_apply(D, fa._temporary_fermionfields[0], xi, fa.rhmc_sampling)
+        mul_(eta, DdagD_operator(D), fa._temporary_fermionfields[0])
+        return eta
     mul_(eta, fa.D(U).adjoint(), xi)
     if fa.evensite:
         extract_fermion_(fa._half, eta)
@@ -459,6 +503,10 @@ def evaluate_FermiAction(fa, U, eta, return_info=False):
     """evaluate_FermiAction(fa, U, eta) (standardHMC.jl:71): S_f = eta' (D'D)^-1 eta (CG from a zero guess)."""
     D = fa.D(U)
     X, Y = fa._temporary_fermionfields
+    if fa.rational:
+        it = _rational_apply(D, X, eta, fa.rhmc_action)
+        S = dot(eta, X).real
+        return (S, it) if return_info else S
     S, it = C.c_double(0), C.c_int(0)
     check(_l.lib().lqcd_fermi_action(D._h, eta._h, X._h, Y._h, C.c_double(D.eps_CG), D.MaxCGstep, C.byref(S), C.byref(it)))
     return (S.value, it.value) if return_info else S.value
@@ -468,14 +516,18 @@ def calc_UdSfdU_(UdSfdU, fa, U, eta):
     """calc_UdSfdU!(UdSfdU, fa, U, eta) (AbstractMD.jl:129): UdSfdU[mu](n) = "U dS_f/dU" with
     dS_f/d eps under U_mu(n) -> exp(i eps T) U_mu(n) equal to -2 Im tr(T UdSfdU_mu(n)).  UdSfdU is a Gaugefields-shaped field."""
     D = fa.D(U)
+    if fa.rational:
+        a0, res, poles = fa.rhmc_MD
+        check(_l.lib().lqcd_rational_force(D._h, UdSfdU._h, eta._h, len(res), _darr(res), _darr(poles), C.c_double(D.eps_CG), D.MaxCGstep, None))
+        return None
     S, it = C.c_double(0), C.c_int(0)
     check(_l.lib().lqcd_calc_UdSfdU(D._h, UdSfdU._h, eta._h, C.c_double(D.eps_CG), D.MaxCGstep, C.byref(S), C.byref(it)))
     return S.value
 
 
-def fermion_force_(UdSfdU, D, X, Y):
-    """The outer-product sweep alone, from resident X = (D'D)^-1 eta and Y = D X."""
-    check(_l.lib().lqcd_fermion_force(D._h, UdSfdU._h, X._h, Y._h))
+def fermion_force_(UdSfdU, D, X, Y, scale=1.0, accumulate=False):
+    """The outer-product sweep alone, from resident X = (D'D)^-1 eta and Y = D X; UdSfdU = (accumulate ? UdSfdU : 0) + scale * G."""
+    check(_l.lib().lqcd_fermion_force_acc(D._h, UdSfdU._h, X._h, Y._h, C.c_double(scale), int(bool(accumulate))))
     return UdSfdU
 
 

@@ -153,6 +153,41 @@ def fermion_force(kind, U, X, Y, L, km, r=1.0, bc=(1, 1, 1, -1)):
     return G
 
 
+def rational_apply(kind, U, x, L, km, a0, res, poles, r=1.0, bc=(1, 1, 1, -1), eps=1e-22, maxiter=3000):
+    """y = a0 x + sum_k res_k (D^+D + pole_k)^-1 x -- the rational (RHMC) action of the reference's general-Nf staggered runs
+    (test/test_Nf2.toml:8, test/test_Nf3.toml:8, README.md:132) composed from the multi-shift CG.  Returns (y, [X_k])."""
+    _, xs, _, _, st = multishift_cg(kind, U, x, L, km, poles, r, bc, eps, maxiter)
+    assert st == 0
+    y = a0 * x
+    for rk, xk in zip(res, xs):
+        y = y + rk * xk
+    return y, xs
+
+
+def rational_force(kind, U, phi, L, km, res, poles, r=1.0, bc=(1, 1, 1, -1), eps=1e-22, maxiter=3000):
+    """"U dS/dU" of S = phi^+ [a0 + sum_k res_k (D^+D + pole_k)^-1] phi: sum_k res_k G[X_k, D X_k] (term-by-term derivative)."""
+    _, xs, _, _, st = multishift_cg(kind, U, phi, L, km, poles, r, bc, eps, maxiter)
+    assert st == 0
+    G = np.zeros(gauge_shape(L), dtype=np.complex128)
+    for rk, xk in zip(res, xs):
+        G += rk * fermion_force(kind, U, xk, apply_D(kind, U, xk, L, km, r, bc), L, km, r, bc)
+    return G
+
+
+def dense_DdagD(kind, U, L, km, r=1.0, bc=(1, 1, 1, -1)):
+    """The matrix of D^+D on a small lattice, column by column (exact spectral functions for the rational-action tests)."""
+    shape = staggered_shape(L) if kind == STAGGERED else wilson_shape(L)
+    n = int(np.prod(shape))
+    A = np.zeros((n, n), dtype=np.complex128)
+    e = np.zeros(n, dtype=np.complex128)
+    for j in range(n):
+        e[:] = 0.0
+        e[j] = 1.0
+        v = apply_D(kind, U, e.reshape(shape), L, km, r, bc)
+        A[:, j] = apply_D(kind, U, v, L, km, r, bc, True).reshape(n)
+    return A
+
+
 def gauge_action(U, L, beta):
     return lib().orc_gauge_action(_p(U), _i4(L), C.c_double(beta))
 

@@ -32,6 +32,8 @@ SU3 = {
 COPY = {
     "confs_HMC_L04040404_beta5.7_Wilson_kappa0.141139/conf_00000100.ildg": "wilson_4x4x4x4.ildg",
     "confs_HMC_L04040404_beta5.7_Staggered_mass0.5/conf_00000100.ildg": "staggered_4x4x4x4.ildg",
+    "confs_HMC_L04040404_beta5.7_Staggered_mass0.5_Nf2/conf_00000100.ildg": "staggered_nf2_4x4x4x4.ildg",
+    "confs_HMC_L04040404_beta5.7_Staggered_mass0.5_Nf3/conf_00000100.ildg": "staggered_nf3_4x4x4x4.ildg",
     "confs_HMC_L04040404_beta5.7_Domainwall/conf_00000100.ildg": "domainwall_4x4x2x2.ildg",
     "confs_HMC_L04040404_beta5.7_Domainwall/conf_00000100.ildg.txt": "domainwall_4x4x2x2.ildg.txt",
 }

@@ -1,0 +1,103 @@
+"""The rational (RHMC) staggered action on the device: lqcd_rational_apply / lqcd_rational_force against the oracle's composition
+(multi-shift CG + per-pole force), and the reference's two general-Nf HMC tests (test/runtests.jl:114-130 with test/test_Nf2.toml
+and test/test_Nf3.toml: thermalised 4^4 configurations, beta = 5.7, mass = 0.5, dtau = 0.05, 20 MD steps, 10 trajectories; final
+plaquette within 10 % of test/debugplaqdata.txt lines 9 and 10)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+BETA, MASS = 5.7, 0.5
+BC = (1, 1, 1, -1)
+REF_PLAQ = {2: 0.56287171870089, 3: 0.5595757232711884}     # /root/reference/test/debugplaqdata.txt:9,10 (runtests.jl:116,125)
+
+
+@pytest.mark.parametrize("nf", [2, 3, 1])
+def test_rational_action_and_force_match_oracle(lq, orc, nf):
+    assert lq.lib.device_count() > 0
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 821)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": MASS, "boundarycondition": BC, "eps_CG": 1e-22})
+    fa = lq.FermiAction(D, {"Nf": nf})
+    assert fa.rational and len(fa.rhmc_MD[1]) < len(fa.rhmc_action[1])
+    phih = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 822)
+    phi = lq.Fermionfields(lat, lq.STAGGERED).upload(phih)
+    a0, res, poles = fa.rhmc_action
+    yo, _ = orc.rational_apply(orc.STAGGERED, Uh, phih, L, MASS, a0, res, poles, 1.0, BC)
+    S = lq.evaluate_FermiAction(fa, U, phi)
+    assert abs(S - np.vdot(phih, yo).real) < 1e-10 * abs(S)
+    assert rel_err(fa._temporary_fermionfields[0].download(), yo) < 1e-10
+    G = lq.Gaugefields(lat)
+    lq.calc_UdSfdU_(G, fa, U, phi)
+    Go = orc.rational_force(orc.STAGGERED, Uh, phih, L, MASS, fa.rhmc_MD[1], fa.rhmc_MD[2], 1.0, BC)
+    assert rel_err(G.download(), Go) < 1e-10
+    # heat bath: S_f(phi = (D'D)^(Nf/16) xi) = xi' xi
+    xi = lq.Fermionfields(lat, lq.STAGGERED)
+    lq.gauss_sampling_in_action_(xi, U, fa, 823)
+    lq.sample_pseudofermions_(phi, U, fa, xi)
+    assert abs(lq.evaluate_FermiAction(fa, U, phi) / lq.dot(xi, xi).real - 1.0) < 1e-9
+
+
+def test_fermion_force_acc_scales_and_accumulates(lq, orc):
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 824)
+    U = lq.Gaugefields(lat).upload(Uh)
+    for kind, name, km in ((lq.WILSON, "Wilson", 0.141139), (lq.STAGGERED, "Staggered", MASS)):
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": name, "κ": km, "mass": km, "boundarycondition": BC})
+        Xh, Yh = (orc.gaussian_spinor(lat.fermion_shape(kind), s) for s in (825, 826))
+        X, Y = lq.Fermionfields(lat, kind).upload(Xh), lq.Fermionfields(lat, kind).upload(Yh)
+        G = lq.Gaugefields(lat)
+        lq.fermion_force_(G, D, X, Y)
+        g1 = G.download()
+        assert rel_err(g1, orc.fermion_force(kind, Uh, Xh, Yh, L, km, 1.0, BC)) < 1e-13
+        lq.fermion_force_(G, D, X, Y, scale=0.25, accumulate=True)
+        assert rel_err(G.download(), 1.25 * g1) < 1e-14
+        lq.fermion_force_(G, D, X, Y, scale=-2.0)
+        assert rel_err(G.download(), -2.0 * g1) < 1e-14
+
+
+@pytest.mark.parametrize("nf", [2, 3])
+def test_hmc_repeats_the_reference_general_nf_tests_on_device(lq, orc, nf):
+    L = (4, 4, 4, 4)
+    Uh = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "staggered_nf%d_4x4x4x4.ildg" % nf), L)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    start = lq.calculate_Plaquette(U)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": MASS, "boundarycondition": BC, "eps_CG": 1e-19})
+    fa = lq.FermiAction(D, {"Nf": nf})
+    p, G, Uold = lq.Gaugefields(lat), lq.Gaugefields(lat), lq.Gaugefields(lat)
+    xi, phi = lq.Fermionfields(lat, lq.STAGGERED), lq.Fermionfields(lat, lq.STAGGERED)
+    dtau, mdsteps = 0.05, 20
+    rng = np.random.default_rng(131 + nf)
+    dHs, acc = [], 0
+    for traj in range(10):
+        lq.substitute_U_(Uold, U)
+        lq.gauss_distribution_(p, 700 + traj)
+        lq.gauss_sampling_in_action_(xi, U, fa, 800 + traj)
+        lq.sample_pseudofermions_(phi, U, fa, xi)
+        Hold = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA) + lq.evaluate_FermiAction(fa, U, phi)
+        for _ in range(mdsteps):                           # runMD_QPQ! (standardMD.jl:125-139)
+            lq.U_update_(U, p, 0.5 * dtau)
+            lq.gauge_force_(G, U, BETA)
+            lq.Traceless_antihermitian_add_(p, dtau, G)
+            lq.calc_UdSfdU_(G, fa, U, phi)
+            lq.Traceless_antihermitian_add_(p, dtau, G)
+            lq.U_update_(U, p, 0.5 * dtau)
+        dH = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA) + lq.evaluate_FermiAction(fa, U, phi) - Hold
+        dHs.append(dH)
+        if np.exp(-dH) >= rng.random():
+            acc += 1
+        else:
+            lq.substitute_U_(U, Uold)
+    plaq = lq.calculate_Plaquette(U)
+    print("staggered Nf = %d RHMC: dH =" % nf, ["%.3f" % d for d in dHs], "accepted", acc, "/ 10, plaquette %.6f (start %.6f)" % (plaq, start))
+    assert abs(plaq - REF_PLAQ[nf]) / REF_PLAQ[nf] < 0.1
+    assert acc >= 5 and np.abs(dHs).max() < 3.0
+    assert abs(plaq - start) > 1e-6 and orc.unitarity_dev(U.download(), L) < 1e-9
