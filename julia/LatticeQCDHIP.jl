@@ -213,6 +213,13 @@ function calc_UdSfdU!(UdSfdU::HIPGaugefields, fa::HIPFermiAction, U::HIPGaugefie
     check(ccall((:lqcd_calc_UdSfdU, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Cint}),
                 D.h, UdSfdU.h, η.h, D.eps_CG, D.MaxCGstep, C_NULL, C_NULL))
 end
+# general staggered Nf (test/test_Nf2.toml:8, test/test_Nf3.toml:8): rational action, coefficients (a0, res, poles) from the host
+rational_apply!(y::HIPFermion, D::HIPDirac, x::HIPFermion, a0, res::Vector{Float64}, poles::Vector{Float64}) =
+    check(ccall((:lqcd_rational_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Ptr{Cint}),
+                D.h, y.h, x.h, a0, length(res), res, poles, D.eps_CG, D.MaxCGstep, C_NULL))
+rational_force!(UdSfdU::HIPGaugefields, D::HIPDirac, φ::HIPFermion, res::Vector{Float64}, poles::Vector{Float64}) =
+    check(ccall((:lqcd_rational_force, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Ptr{Cint}),
+                D.h, UdSfdU.h, φ.h, length(res), res, poles, D.eps_CG, D.MaxCGstep, C_NULL))
 gauge_force!(G::HIPGaugefields, U::HIPGaugefields, β) =
     check(ccall((:lqcd_gauge_force, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), G.h, U.h, β))
 Traceless_antihermitian_add!(p::HIPGaugefields, factor, G::HIPGaugefields) =
