@@ -154,7 +154,8 @@ int lqcd_solve_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double e
 int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,
                         int* iters, double* final_rr);           /* solve_DinvX!(y, D | D', x) (standardHMC.jl:71) */
 int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,
-                           int* iters, double* final_rr);        /* even-odd preconditioned variant (Wilson) */
+                           int* iters, double* final_rr);        /* even-odd preconditioned variant (Wilson; with a clover term the
+                                                                  * Schur complement uses the inverse clover blocks, built on first use) */
 /* shiftedcg(vec_x, vec_beta, x, A, b) of the RHMC path (README.md:132; test/test_Nf2.toml:8, test_Nf3.toml:8):
  * (D^+D + sigma_j) xs[j] = b for all j < ns, plus the unshifted solution x0 (may be NULL), from ONE Krylov space.
  * Zero initial guesses; stops when rr * max(1, max_j zeta_j^2) < eps. */

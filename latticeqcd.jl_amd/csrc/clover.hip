@@ -124,14 +124,21 @@ __global__ __launch_bounds__(64) void clover_build_kernel(Geom g, const double2*
     }
 }
 
-// out = A in on FULL Wilson spinors (one thread per site)
-__global__ __launch_bounds__(64) void clover_apply_kernel(Geom g, const double2* __restrict__ clov, const double2* __restrict__ in0,
-                                                           const double2* __restrict__ in1, double2* __restrict__ out0, double2* __restrict__ out1) {
-    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+// out = sa (A in) + sz z on Wilson spinors, one thread per site.  pfix < 0: both parity blocks of FULL fields (blockIdx & 1 = parity);
+// pfix = 0 | 1: that parity only (in / out / z are then the single blocks of EVEN / ODD fields, passed in slot pfix).  z may be null.
+struct CloverApplyArgs {
+    const double2* in[2];
+    double2* out[2];
+    const double2* z[2];
+    double sa, sz;
+    int pfix;
+};
+__global__ __launch_bounds__(64) void clover_apply_kernel(Geom g, const double2* __restrict__ clov, CloverApplyArgs k) {
+    const int p = k.pfix < 0 ? (blockIdx.x & 1) : k.pfix, i = (k.pfix < 0 ? (blockIdx.x >> 1) : blockIdx.x) * 64 + threadIdx.x;
     if (i >= g.Vh) return;
     const int Vs = sp_stride(g);
-    const double2* __restrict__ x = (p ? in1 : in0) + sp_off(12, i);
-    double2* __restrict__ y = (p ? out1 : out0) + sp_off(12, i);
+    const double2* __restrict__ x = k.in[p] + sp_off(12, i);
+    double2* __restrict__ y = k.out[p] + sp_off(12, i);
     const double2* __restrict__ a = clov + clover_off(g, p, i);
     cd psi[12], res[12];
 #pragma unroll
@@ -162,8 +169,66 @@ __global__ __launch_bounds__(64) void clover_apply_kernel(Geom g, const double2*
             else { res[k] = mk(res[k].re + 0.5 * ych[k].re, res[k].im + 0.5 * ych[k].im); res[6 + k] = mk(res[6 + k].re + 0.5 * ych[k].re, res[6 + k].im + 0.5 * ych[k].im); }
         }
     }
+    if (k.z[p]) {
+        const double2* __restrict__ z = k.z[p] + sp_off(12, i);
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const cd zv = ld(z + (size_t)j * Vs);
+            res[j] = mk(fma(k.sa, res[j].re, k.sz * zv.re), fma(k.sa, res[j].im, k.sz * zv.im));
+        }
+    } else if (k.sa != 1.0) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) res[j] = mk(k.sa * res[j].re, k.sa * res[j].im);
+    }
 #pragma unroll
     for (int j = 0; j < 12; j++) st(y + (size_t)j * Vs, res[j]);
+}
+
+// inv = A^-1 block by block (the inverse of a Hermitian block is Hermitian: same packed format, same apply kernel).  In-place
+// Gauss-Jordan without pivoting, fully unrolled in registers; A = 1 + O(kappa c_sw F) is positive definite for every sensible c_sw.
+// One thread per (site, chiral block).
+__global__ __launch_bounds__(64) void clover_invert_kernel(Geom g, const double2* __restrict__ clov, double2* __restrict__ inv) {
+    const int p = blockIdx.x & 1, b = blockIdx.y, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (i >= g.Vh) return;
+    const double2* __restrict__ a = clov + clover_off(g, p, i) + (size_t)(18 * b) * 64;
+    double2* __restrict__ o = inv + clover_off(g, p, i) + (size_t)(18 * b) * 64;
+    cd m[6][6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const cd d = ld(a + (size_t)k * 64); m[2 * k][2 * k] = mk(d.re, 0.0); m[2 * k + 1][2 * k + 1] = mk(d.im, 0.0); }
+    {
+        int e = 3;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int q = r + 1; q < 6; q++, e++) { const cd v = ld(a + (size_t)e * 64); m[r][q] = v; m[q][r] = mk(v.re, -v.im); }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        // 1 / m[k][k] (complex in the intermediate steps)
+        const double dn = 1.0 / (m[k][k].re * m[k][k].re + m[k][k].im * m[k][k].im);
+        const cd piv = mk(m[k][k].re * dn, -m[k][k].im * dn);
+        m[k][k] = mk(1.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < 6; j++) { const cd t = m[k][j]; m[k][j] = mk(t.re * piv.re - t.im * piv.im, t.re * piv.im + t.im * piv.re); }
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            if (r == k) continue;
+            const cd f = m[r][k];
+            m[r][k] = mk(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) cfma(m[r][j], mk(-f.re, -f.im), m[k][j]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) st(o + (size_t)k * 64, mk(m[2 * k][2 * k].re, m[2 * k + 1][2 * k + 1].re));
+    {
+        int e = 3;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int q = r + 1; q < 6; q++, e++)      // symmetrise the round-off: (m[r][q] + conj(m[q][r])) / 2
+                st(o + (size_t)e * 64, mk(0.5 * (m[r][q].re + m[q][r].re), 0.5 * (m[r][q].im - m[q][r].im)));
+    }
 }
 
 // sigma_{mu nu} = (i/2)[g_mu, g_nu] in the chiral basis e^+_s = (e_s - e_{s+2})/sqrt2, e^-_s = (e_s + e_{s+2})/sqrt2
@@ -206,8 +271,26 @@ int clover_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, double2* clov, double kap
 }
 
 int clover_apply(lqcd_ctx_s* c, const double2* clov, lqcd_spinor_s* out, lqcd_spinor_s* in) {
-    hipLaunchKernelGGL(clover_apply_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, clov, spinor_block(in, 0), spinor_block(in, 1),
-                       spinor_block(out, 0), spinor_block(out, 1));
+    CloverApplyArgs k;
+    for (int p = 0; p < 2; p++) { k.in[p] = spinor_block(in, p); k.out[p] = spinor_block(out, p); k.z[p] = nullptr; }
+    k.sa = 1.0; k.sz = 0.0; k.pfix = -1;
+    hipLaunchKernelGGL(clover_apply_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, clov, k);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+// one parity block: out = sa (C in) + sz z with raw block pointers (the even-odd solver works on EVEN / ODD fields)
+int clover_apply_parity(lqcd_ctx_s* c, const double2* clov, int parity, double2* out, const double2* in, double sa, const double2* z, double sz) {
+    CloverApplyArgs k;
+    for (int p = 0; p < 2; p++) { k.in[p] = in; k.out[p] = out; k.z[p] = z; }
+    k.sa = sa; k.sz = sz; k.pfix = parity;
+    hipLaunchKernelGGL(clover_apply_kernel, dim3(c->geom.nch), dim3(64), 0, c->stream, c->geom, clov, k);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+int clover_invert(lqcd_ctx_s* c, const double2* clov, double2* inv) {
+    hipLaunchKernelGGL(clover_invert_kernel, dim3(2 * c->geom.nch, 2), dim3(64), 0, c->stream, c->geom, clov, inv);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }

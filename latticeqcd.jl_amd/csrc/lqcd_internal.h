@@ -311,6 +311,8 @@ struct lqcd_op_s {
     double2* clover = nullptr;          // packed chiral blocks, [parity][chunk][36][64]
     uint64_t clover_version = 0;        // gauge version A was built from
     lqcd_spinor_s* clover_tmp = nullptr;   // A x, the diagonal input of the stencil
+    double2* clover_inv = nullptr;      // A^-1 in the same packed format (even-odd solver), built on first use
+    uint64_t clover_inv_version = 0;
 };
 
 namespace lqcd {
@@ -414,6 +416,8 @@ int stream_grid(lqcd_ctx_s* c, size_t n);
 size_t clover_elems(const Geom& g);
 int clover_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, double2* clov, double kappa, double csw);
 int clover_apply(lqcd_ctx_s* c, const double2* clov, lqcd_spinor_s* out, lqcd_spinor_s* in);
+int clover_apply_parity(lqcd_ctx_s* c, const double2* clov, int parity, double2* out, const double2* in, double sa, const double2* z, double sz);
+int clover_invert(lqcd_ctx_s* c, const double2* clov, double2* inv);
 
 // fields.hip
 double2* spinor_block(lqcd_spinor_s* s, int p);

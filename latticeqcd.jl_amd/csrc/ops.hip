@@ -616,6 +616,7 @@ extern "C" int lqcd_op_create(lqcd_ctx_t ctx, lqcd_op_t* op, int kind, lqcd_gaug
 extern "C" int lqcd_op_destroy(lqcd_op_t op) {
     if (!op) return LQCD_OK;
     (void)hipFree(op->clover);
+    (void)hipFree(op->clover_inv);
     if (op->clover_tmp) lqcd_spinor_destroy(op->clover_tmp);
     delete op;
     return LQCD_OK;
@@ -720,14 +721,29 @@ extern "C" int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t 
 
 // even-odd (Schur) preconditioned BiCGStab, Wilson:
 //   (1 - k^2 H_eo H_oe) x_e = b_e + k H_eo b_o ;  x_o = b_o + k H_oe x_e
+// Wilson-clover (D_sw = A - k H, A block diagonal in parity): with the packed inverse blocks A^-1 (clover.hip)
+//   (1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe) x_e = A_ee^-1 (b_e + k H_eo A_oo^-1 b_o) ;  x_o = A_oo^-1 (b_o + k H_oe x_e)
+// (D_sw^+: H -> H^+ through the dagger flag of the hop, A is Hermitian).
 extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
                                       double* final_rr) {
     LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab_eo"));
     ARGCHK(op->kind == LQCD_WILSON, "lqcd_solve_bicgstab_eo: Wilson only");
-    LQCHK(no_clover(op, "lqcd_solve_bicgstab_eo (needs the inverse of the even-even clover block)"));
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     apply_bc(c, op->bc);
+    const bool clov = op->csw != 0.0 && op->clover;
+    if (clov) {     // A follows the links, A^-1 follows A
+        if (op->clover_version != op->gauge->version) {
+            LQCHK(clover_build(c, op->gauge, op->clover, op->km, op->csw));
+            op->clover_version = op->gauge->version;
+        }
+        if (!op->clover_inv) HIPCHK(hipMalloc((void**)&op->clover_inv, clover_elems(c->geom) * sizeof(double2)));
+        if (op->clover_inv_version != op->clover_version) {
+            LQCHK(clover_invert(c, op->clover, op->clover_inv));
+            op->clover_inv_version = op->clover_version;
+        }
+    }
+    const double2* Ai = op->clover_inv;
     const double k = op->km;
     const int dg = dagger ? 1 : 0;
     const size_t nh = x->elems / 2;
@@ -735,31 +751,61 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
     double2* wd[6];
     for (int i = 0; i < 6; i++) { w[i] = scratch_get(c, op->kind, LQCD_EVEN); if (!w[i]) return LQCD_ERR_HIP; wd[i] = w[i]->data; }
     lqcd_spinor_s* rhs = scratch_get(c, op->kind, LQCD_EVEN);
+    lqcd_spinor_s* te = clov ? scratch_get(c, op->kind, LQCD_EVEN) : nullptr;
     lqcd_spinor_s* to = scratch_get(c, op->kind, LQCD_ODD);
-    if (!rhs || !to) return LQCD_ERR_HIP;
+    lqcd_spinor_s* uo = clov ? scratch_get(c, op->kind, LQCD_ODD) : nullptr;
+    if (!rhs || !to || (clov && (!te || !uo))) return LQCD_ERR_HIP;
     // views of the even/odd halves of b and x
     lqcd_spinor_s be = *b, bo = *b, xe = *x, xo = *x;
     be.subset = xe.subset = LQCD_EVEN; bo.subset = xo.subset = LQCD_ODD;
     be.elems = bo.elems = xe.elems = xo.elems = nh;
     bo.data = b->data + nh; xo.data = x->data + nh;
     int st = LQCD_OK;
-    // rhs = b_e + k H_eo b_o
-    { StencilCall s = make_hop_call(op, rhs, &bo, &be, 1.0, k, dg); st = stencil_apply(c, s); }
-    lqcd_spinor_s vin = xe, vout = xe;
-    ApplyFn A = [&](double2* out, const double2* in) -> int {
-        vin.data = const_cast<double2*>(in);
-        vout.data = out;
-        StencilCall s1 = make_hop_call(op, to, &vin, nullptr, 0.0, 1.0, dg);         // t_o = H_oe in
-        LQCHK(stencil_apply(c, s1));
-        StencilCall s2 = make_hop_call(op, &vout, to, &vin, 1.0, -k * k, dg);        // out = in - k^2 H_eo t_o
-        return stencil_apply(c, s2);
+    auto run = [&]() -> int {
+        lqcd_spinor_s vin = xe, vout = xe;
+        ApplyFn A;
+        if (!clov) {
+            // rhs = b_e + k H_eo b_o
+            { StencilCall s = make_hop_call(op, rhs, &bo, &be, 1.0, k, dg); LQCHK(stencil_apply(c, s)); }
+            A = [&](double2* out, const double2* in) -> int {
+                vin.data = const_cast<double2*>(in);
+                vout.data = out;
+                StencilCall s1 = make_hop_call(op, to, &vin, nullptr, 0.0, 1.0, dg);         // t_o = H_oe in
+                LQCHK(stencil_apply(c, s1));
+                StencilCall s2 = make_hop_call(op, &vout, to, &vin, 1.0, -k * k, dg);        // out = in - k^2 H_eo t_o
+                return stencil_apply(c, s2);
+            };
+        } else {
+            // rhs = A_ee^-1 (b_e + k H_eo A_oo^-1 b_o)
+            LQCHK(clover_apply_parity(c, Ai, 1, uo->data, bo.data, 1.0, nullptr, 0.0));
+            { StencilCall s = make_hop_call(op, te, uo, &be, 1.0, k, dg); LQCHK(stencil_apply(c, s)); }
+            LQCHK(clover_apply_parity(c, Ai, 0, rhs->data, te->data, 1.0, nullptr, 0.0));
+            A = [&](double2* out, const double2* in) -> int {
+                vin.data = const_cast<double2*>(in);
+                StencilCall s1 = make_hop_call(op, to, &vin, nullptr, 0.0, 1.0, dg);         // t_o = H_oe in
+                LQCHK(stencil_apply(c, s1));
+                LQCHK(clover_apply_parity(c, Ai, 1, uo->data, to->data, 1.0, nullptr, 0.0)); // u_o = A_oo^-1 t_o
+                StencilCall s2 = make_hop_call(op, te, uo, nullptr, 0.0, 1.0, dg);           // t_e = H_eo u_o
+                LQCHK(stencil_apply(c, s2));
+                return clover_apply_parity(c, Ai, 0, out, te->data, -k * k, in, 1.0);        // out = in - k^2 A_ee^-1 t_e
+            };
+        }
+        const int sc = bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
+        // the odd half (also on non-convergence, so x is a consistent best effort)
+        if (!clov) {
+            StencilCall s = make_hop_call(op, &xo, &xe, &bo, 1.0, k, dg);                    // x_o = b_o + k H_oe x_e
+            LQCHK(stencil_apply(c, s));
+        } else {
+            StencilCall s = make_hop_call(op, to, &xe, &bo, 1.0, k, dg);
+            LQCHK(stencil_apply(c, s));
+            LQCHK(clover_apply_parity(c, Ai, 1, xo.data, to->data, 1.0, nullptr, 0.0));      // x_o = A_oo^-1 (b_o + k H_oe x_e)
+        }
+        return sc;
     };
-    if (st == LQCD_OK) st = bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
-    // x_o = b_o + k H_oe x_e   (also on non-convergence, so x is a consistent best effort)
-    { StencilCall s = make_hop_call(op, &xo, &xe, &bo, 1.0, k, dg); int s2 = stencil_apply(c, s); if (st == LQCD_OK) st = s2; }
+    st = run();
     hipError_t e = hipStreamSynchronize(c->stream);
     for (int i = 0; i < 6; i++) scratch_put(w[i]);
-    scratch_put(rhs); scratch_put(to);
+    scratch_put(rhs); scratch_put(to); scratch_put(te); scratch_put(uo);
     if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync bicgstab_eo", __FILE__, __LINE__);
     return st;
 }

@@ -915,3 +915,92 @@ int orc_cg_clover(double* xd, const double* U, const double* clov, const double*
     free(res); free(p); free(q); free(tmp);
     return status;
 }
+
+/* ------------------------------------------------------------------ even-odd preconditioning with the clover term
+ * D_sw = A - k H with A block diagonal in parity (SURVEY.md 8(f) rank 2 "even-odd clover inverse"; textbook, no reference behaviour):
+ *   (1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe) x_e = A_ee^-1 (b_e + k H_eo A_oo^-1 b_o) ;   x_o = A_oo^-1 (b_o + k H_oe x_e)
+ * inv[V][12][12] = A(x)^-1 by Gauss-Jordan elimination with partial pivoting. */
+void orc_clover_invert(double* invd, const double* clovd, const int L[4]) {
+    long V = vol(L);
+    const cplx* clov = (const cplx*)clovd;
+    cplx* inv = (cplx*)invd;
+    for (long s = 0; s < V; s++) {
+        cplx a[12][24];
+        for (int i = 0; i < 12; i++)
+            for (int j = 0; j < 12; j++) { a[i][j] = clov[144 * s + i * 12 + j]; a[i][12 + j] = (i == j) ? 1.0 : 0.0; }
+        for (int k = 0; k < 12; k++) {
+            int piv = k;
+            for (int i = k + 1; i < 12; i++)
+                if (cabs(a[i][k]) > cabs(a[piv][k])) piv = i;
+            if (piv != k)
+                for (int j = 0; j < 24; j++) { cplx t = a[k][j]; a[k][j] = a[piv][j]; a[piv][j] = t; }
+            cplx d = 1.0 / a[k][k];
+            for (int j = 0; j < 24; j++) a[k][j] *= d;
+            for (int i = 0; i < 12; i++) {
+                if (i == k) continue;
+                cplx f = a[i][k];
+                for (int j = 0; j < 24; j++) a[i][j] -= f * a[k][j];
+            }
+        }
+        for (int i = 0; i < 12; i++)
+            for (int j = 0; j < 12; j++) inv[144 * s + i * 12 + j] = a[i][12 + j];
+    }
+}
+/* out(s) = M(s) in(s) on the sites of one parity, zero on the others */
+static void site_mat_parity(cplx* out, const cplx* M, const cplx* in, const int L[4], int parity) {
+    long V = vol(L);
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    long s = site_of(L, x, y, z, t);
+                    int keep = ((x + y + z + t) & 1) == parity;
+                    for (int i = 0; i < 12; i++) {
+                        cplx acc = 0;
+                        if (keep)
+                            for (int j = 0; j < 12; j++) acc += M[144 * s + i * 12 + j] * in[PIDX(V, s, j % 3, j / 3)];
+                        out[PIDX(V, s, i % 3, i / 3)] = acc;
+                    }
+                }
+}
+typedef struct { const double* U; const cplx* Ainv; const int* L; double kappa, r; const int* bc; int dagger; long V; cplx *w1, *w2; } eoc_ctx;
+static void apply_schur_clover(void* c, cplx* out, const cplx* in) {
+    eoc_ctx* e = (eoc_ctx*)c;
+    long n = 12 * e->V;
+    orc_wilson_hop_parity((double*)e->w1, e->U, (const double*)in, e->L, e->r, e->bc, e->dagger, 1);   /* H_oe in */
+    site_mat_parity(e->w2, e->Ainv, e->w1, e->L, 1);                                                  /* A_oo^-1 */
+    orc_wilson_hop_parity((double*)e->w1, e->U, (const double*)e->w2, e->L, e->r, e->bc, e->dagger, 0); /* H_eo */
+    site_mat_parity(e->w2, e->Ainv, e->w1, e->L, 0);                                                  /* A_ee^-1 */
+    double k2 = e->kappa * e->kappa;
+    for (long i = 0; i < n; i++) out[i] = in[i] - k2 * e->w2[i];
+}
+int orc_wilson_clover_bicgstab_eo(double* xd, const double* U, const double* clov, const double* bd, const int L[4], double kappa, double r,
+                                  const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr) {
+    long V = vol(L), n = 12 * V;
+    cplx* x = (cplx*)xd;
+    const cplx* b = (const cplx*)bd;
+    cplx* Ainv = (cplx*)malloc(sizeof(cplx) * 144 * V);
+    orc_clover_invert((double*)Ainv, clov, L);
+    cplx* be = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* bo = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* xe = (cplx*)calloc(n, sizeof(cplx));
+    cplx* w = (cplx*)malloc(sizeof(cplx) * n);
+    cplx* w2 = (cplx*)malloc(sizeof(cplx) * n);
+    eoc_ctx e = {U, Ainv, L, kappa, r, bc, dagger, V, (cplx*)malloc(sizeof(cplx) * n), (cplx*)malloc(sizeof(cplx) * n)};
+    memcpy(be, b, sizeof(cplx) * n); mask_parity(be, L, 0);
+    memcpy(bo, b, sizeof(cplx) * n); mask_parity(bo, L, 1);
+    /* rhs_e = A_ee^-1 (b_e + k H_eo A_oo^-1 b_o) */
+    site_mat_parity(w2, Ainv, bo, L, 1);
+    orc_wilson_hop_parity((double*)w, U, (const double*)w2, L, r, bc, dagger, 0);
+    for (long i = 0; i < n; i++) w[i] = be[i] + kappa * w[i];
+    site_mat_parity(be, Ainv, w, L, 0);
+    memcpy(xe, x, sizeof(cplx) * n); mask_parity(xe, L, 0);
+    int st = bicgstab_core(apply_schur_clover, &e, n, xe, be, eps, maxiter, iters, final_rr);
+    /* x_o = A_oo^-1 (b_o + k H_oe x_e) */
+    orc_wilson_hop_parity((double*)w, U, (const double*)xe, L, r, bc, dagger, 1);
+    for (long i = 0; i < n; i++) w[i] = bo[i] + kappa * w[i];
+    site_mat_parity(w2, Ainv, w, L, 1);
+    for (long i = 0; i < n; i++) x[i] = xe[i] + w2[i];
+    free(Ainv); free(be); free(bo); free(xe); free(w); free(w2); free(e.w1); free(e.w2);
+    return st;
+}

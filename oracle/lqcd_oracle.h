@@ -105,6 +105,11 @@ void orc_wilson_clover_D(double* out, const double* U, const double* clov, const
 int orc_cg_clover(double* x, const double* U, const double* clov, const double* b, const int L[4], double kappa, double r,
                   const int bc[4], double eps, int maxiter, int* iters, double* final_rr);
 
+/* A^-1 site by site, and the even-odd (Schur) preconditioned BiCGStab for D_sw (or D_sw^+) built on it */
+void orc_clover_invert(double* inv, const double* clov, const int L[4]);
+int orc_wilson_clover_bicgstab_eo(double* x, const double* U, const double* clov, const double* b, const int L[4], double kappa, double r,
+                                  const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr);
+
 /* fixed-length CG window with the exit test disabled (timing only): runs exactly niter iterations */
 void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4],
                         double kappa_or_mass, double r, const int bc[4], int niter);

@@ -252,6 +252,21 @@ def cg_clover(U, A, b, L, kappa, r=1.0, bc=(1, 1, 1, -1), eps=1e-19, maxiter=300
     return x, it.value, rr.value, st
 
 
+def clover_invert(A, L):
+    inv = np.zeros_like(A)
+    lib().orc_clover_invert(_p(inv), _p(A), _i4(L))
+    return inv
+
+
+def wilson_clover_bicgstab_eo(U, A, b, L, kappa, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000):
+    """Even-odd preconditioned BiCGStab for D_sw x = b (or D_sw^+).  Returns (x, iters, resid of the Schur system, status)."""
+    x = np.zeros_like(b)
+    it, rr = C.c_int(0), C.c_double(0)
+    st = lib().orc_wilson_clover_bicgstab_eo(_p(x), _p(U), _p(A), _p(b), _i4(L), C.c_double(kappa), C.c_double(r), _i4(bc),
+                                             int(bool(dagger)), C.c_double(eps), int(maxiter), C.byref(it), C.byref(rr))
+    return x, it.value, rr.value, st
+
+
 def bicgstab(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000, x0=None):
     x = np.zeros_like(b) if x0 is None else x0.copy()
     it, rr = C.c_int(0), C.c_double(0)

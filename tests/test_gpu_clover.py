@@ -54,10 +54,18 @@ def test_wilson_clover_matches_oracle(lq, orc, L):
     lq.mul_(y, lq.DdagD_operator(D), sol)
     lq.add_fermion_(y, -1.0, x)
     assert lq.dot(y, y).real < 1e-19
-    # what is not built yet fails loudly
+    # even-odd preconditioned BiCGStab with the inverse clover blocks: same algorithm as the oracle's, D_sw and D_sw^+
     D.method_CG = "bicgstab_evenodd"
-    with pytest.raises(lq.LQCDError):
-        lq.solve_DinvX_(sol, D, x)
+    for dag in (False, True):
+        Dd = D.adjoint() if dag else D
+        lq.clear_fermion_(sol)
+        ite, rre = lq.solve_DinvX_(sol, Dd, x, return_info=True)
+        xo3, ito3, _, st3 = orc.wilson_clover_bicgstab_eo(Uh2, A2, psi, L, KAPPA, 1.0, BC, dag, eps=1e-19)
+        assert st3 == 0 and abs(ite - ito3) <= 2 and rel_err(sol.download(), xo3) < 1e-9
+        lq.mul_(y, Dd, sol)
+        lq.add_fermion_(y, -1.0, x)
+        assert lq.dot(y, y).real < 1e-17
+    # what is not built yet fails loudly
     with pytest.raises(lq.LQCDError):
         lq.calc_UdSfdU_(lq.Gaugefields(lat), lq.FermiAction(D), U, x)
 

@@ -67,3 +67,31 @@ def test_clover_operator_identities(orc):
     assert st == 0
     r = orc.wilson_clover_D(U, A, orc.wilson_clover_D(U, A, x, L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True) - b
     assert np.vdot(r, r).real < 2e-20
+
+
+@pytest.mark.parametrize("dagger", [False, True])
+def test_clover_even_odd_solve_equals_dense_solve(orc, dagger):
+    """Schur identity with the clover term: the preconditioned solve gives D_sw^-1 b of the dense matrix."""
+    L = (4, 2, 2, 2)
+    U = orc.hot_gauge(L, 411)
+    A = orc.clover_build(U, L, KAPPA, CSW)
+    Ainv = orc.clover_invert(A, L)
+    assert np.abs(A @ Ainv - np.eye(12)).max() < 1e-13
+    shape = orc.wilson_shape(L)
+    n = int(np.prod(shape))
+    M = np.zeros((n, n), dtype=np.complex128)
+    e = np.zeros(n, dtype=np.complex128)
+    for j in range(n):
+        e[:] = 0
+        e[j] = 1
+        M[:, j] = orc.wilson_clover_D(U, A, e.reshape(shape), L, KAPPA, 1.0, BC, dagger).reshape(n)
+    b = orc.gaussian_spinor(shape, 412)
+    x, it, rr, st = orc.wilson_clover_bicgstab_eo(U, A, b, L, KAPPA, 1.0, BC, dagger, eps=1e-24)
+    assert st == 0 and it > 3
+    xd = np.linalg.solve(M, b.reshape(n)).reshape(shape)
+    assert np.abs(x - xd).max() < 1e-10 * np.abs(xd).max()
+    # c_sw = 0 reduces to the Wilson even-odd solver, iteration for iteration
+    A0 = orc.clover_build(U, L, KAPPA, 0.0)
+    x0, it0, _, st0 = orc.wilson_clover_bicgstab_eo(U, A0, b, L, KAPPA, 1.0, BC, dagger, eps=1e-24)
+    xw, itw, _, stw = orc.wilson_bicgstab_eo(U, b, L, KAPPA, 1.0, BC, dagger, eps=1e-24)
+    assert st0 == 0 and stw == 0 and it0 == itw and np.abs(x0 - xw).max() < 1e-13
