@@ -295,4 +295,199 @@ int clover_invert(lqcd_ctx_s* c, const double2* clov, double2* inv) {
     return LQCD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ force of the clover term
+// S_f = phi^+ (D_sw^+ D_sw)^-1 phi, X = (D_sw^+ D_sw)^-1 phi, Y = D_sw X (2-flavour Wilson-clover HMC, BASELINE.json configs[3]).  The
+// hopping part of dS_f is the Wilson force sweep (force.hip); the clover part is
+//     dS = (kappa c_sw / 4) sum_x sum_{mu<nu} Im tr( dQ_{mu nu}(x) Lambda^{mu nu}(x) ),
+//     Lambda^{mu nu}(x) = M + M^+,  M = sum_{s} sigma^{mu nu}_{s s'} X_{s'}(x) Y_s(x)^+   (colour outer products; one s' per row s).
+// Pass 1 builds the six Hermitian Lambda matrices per site ([parity][chunk][plane][9][64]).  Pass 2 is a gather per link (z, rho):
+// for every nu != rho and both sides s = +-nu the plaquette through the link is a leaf of Q at each of its four corners c, so with
+// the loop  z -> z+rho -> z+rho+s nu -> z+s nu -> z  (links U A B C)
+//     W = U (Lambda(c1) A B C + A Lambda(c2) B C + A B Lambda(c3) C + A B C Lambda(c0)),
+// and, o = s * sign(rho < nu) being the orientation of that loop relative to the counter-clockwise leaves,
+//     G_rho(z) += -i (kappa c_sw / 8) W   (o = +1)        G_rho(z) += +i (kappa c_sw / 8) W^+   (o = -1)
+// in the convention of the other force fields (dS/d eps[U -> exp(i eps T) U] = -2 Im tr(T G)).  The oracle computes the same field
+// as a scatter over (site, plane, leaf, step).
+struct SigmaTab { int col[6][4]; double re[6][4], im[6][4]; };
+
+__host__ __device__ inline size_t lambda_off(const Geom& g, int p, int i, int plane) {
+    return ((((size_t)p * g.nch + (size_t)(i >> 6)) * 6 + plane) * 9) * 64 + (i & 63);
+}
+size_t clover_lambda_elems(const Geom& g) { return (size_t)2 * g.nch * 54 * 64; }
+
+__global__ __launch_bounds__(64) void clover_lambda_kernel(Geom g, const double2* __restrict__ X0, const double2* __restrict__ X1,
+                                                            const double2* __restrict__ Y0, const double2* __restrict__ Y1,
+                                                            double2* __restrict__ lam, SigmaTab tb) {
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (i >= g.Vh) return;
+    const int Vs = sp_stride(g);
+    const double2* __restrict__ xp = (p ? X1 : X0) + sp_off(12, i);
+    const double2* __restrict__ yp = (p ? Y1 : Y0) + sp_off(12, i);
+    cd x[12], y[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { x[j] = ld(xp + (size_t)j * Vs); y[j] = ld(yp + (size_t)j * Vs); }
+#pragma unroll
+    for (int plane = 0; plane < 6; plane++) {
+        cd M[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) M[e] = mk(0.0, 0.0);
+#pragma unroll
+        for (int sp = 0; sp < 4; sp++) {
+            const cd sg = mk(tb.re[plane][sp], tb.im[plane][sp]);
+            const int s2 = tb.col[plane][sp];
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                // sigma_{s s2} X_{s2 b}: s2 is a table entry, select without dynamic register indexing
+                cd xv = x[b];
+                if (s2 == 1) xv = x[3 + b];
+                if (s2 == 2) xv = x[6 + b];
+                if (s2 == 3) xv = x[9 + b];
+                cd sx = mk(0.0, 0.0);
+                cfma(sx, sg, xv);
+#pragma unroll
+                for (int a = 0; a < 3; a++) cfma_conj(M[b * 3 + a], y[sp * 3 + a], sx);      // += conj(Y_{s a}) * (sigma X)_b
+            }
+        }
+        double2* o = lam + lambda_off(g, p, i, plane);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) st(o + (size_t)(a * 3 + b) * 64, mk(M[a * 3 + b].re + M[b * 3 + a].re, M[a * 3 + b].im - M[b * 3 + a].im));
+    }
+}
+
+__device__ __forceinline__ void ldlam(cd (&l)[9], const double2* __restrict__ lam, const Geom& g, const int (&c)[4], int plane) {
+    const int p = (c[0] + c[1] + c[2] + c[3]) & 1;
+    const double2* b = lam + lambda_off(g, p, coords_to_cb(g, c), plane);
+#pragma unroll
+    for (int e = 0; e < 9; e++) l[e] = ld(b + (size_t)e * 64);
+}
+__device__ __forceinline__ void dag9(cd (&u)[9]) {
+    cd t[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) t[a * 3 + b] = mk(u[b * 3 + a].re, -u[b * 3 + a].im);
+#pragma unroll
+    for (int e = 0; e < 9; e++) u[e] = t[e];
+}
+// T = T R + P L  (all 3x3)
+__device__ __forceinline__ void horner(cd (&T)[9], const cd (&R)[9], const cd (&P)[9], const cd (&Lm)[9]) {
+    cd o[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            cd t = mk(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { cfma(t, T[a * 3 + k], R[k * 3 + b]); cfma(t, P[a * 3 + k], Lm[k * 3 + b]); }
+            o[a * 3 + b] = t;
+        }
+#pragma unroll
+    for (int e = 0; e < 9; e++) T[e] = o[e];
+}
+
+// one thread per link: blockDim = 256 = 64 sites x 4 directions
+__global__ __launch_bounds__(256) void clover_force_kernel(Geom g, const double2* __restrict__ U, const double2* __restrict__ lam,
+                                                            double2* __restrict__ out, double cf, double scale, int acc) {
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), rho = threadIdx.x >> 6;
+    if (i >= g.Vh) return;
+    int z[4];
+    cb_to_coords(g, p, i, z);
+    cd Wp[9], Wm[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) { Wp[e] = mk(0.0, 0.0); Wm[e] = mk(0.0, 0.0); }
+    int zr[4] = {z[0], z[1], z[2], z[3]};
+    step(zr, g, rho, 1);                                   // c1 = z + rho
+    for (int nu = 0; nu < 4; nu++) {
+        if (nu == rho) continue;
+        const int mu0 = rho < nu ? rho : nu, nu0 = rho < nu ? nu : rho;
+        const int plane = mu0 == 0 ? nu0 - 1 : (mu0 == 1 ? nu0 + 1 : 5);      // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+        for (int sd = 1; sd >= -1; sd -= 2) {
+            int c2[4] = {zr[0], zr[1], zr[2], zr[3]}, c3[4] = {z[0], z[1], z[2], z[3]};
+            step(c2, g, nu, sd);                           // z + rho + s nu
+            step(c3, g, nu, sd);                           // z + s nu
+            cd A[9], B[9], L[9], T[9], P[9], Q[9];
+            if (sd > 0) ldm(A, U, g, zr, nu);              // A: z+rho -> z+rho+s nu
+            else { ldm(A, U, g, c2, nu); dag9(A); }
+            ldlam(L, lam, g, zr, plane);
+            mmx<false, false>(T, L, A);                    // Lambda(c1) A
+            ldlam(L, lam, g, c2, plane);
+            mmx<false, false>(Q, A, L);                    // A Lambda(c2)
+#pragma unroll
+            for (int e = 0; e < 9; e++) T[e] = mk(T[e].re + Q[e].re, T[e].im + Q[e].im);
+            ldm(B, U, g, c3, rho);                         // B: z+rho+s nu -> z+s nu  = U_rho(z + s nu)^+
+            dag9(B);
+            mmx<false, false>(P, A, B);                    // A B
+            ldlam(L, lam, g, c3, plane);
+            horner(T, B, P, L);                            // (..) B + A B Lambda(c3)
+            if (sd > 0) { ldm(B, U, g, z, nu); dag9(B); }  // C: z+s nu -> z
+            else ldm(B, U, g, c3, nu);
+            mmx<false, false>(Q, P, B);                    // A B C
+            ldlam(L, lam, g, z, plane);
+            horner(T, B, Q, L);                            // (..) C + A B C Lambda(c0)
+            ldm(A, U, g, z, rho);
+            mmx<false, false>(Q, A, T);                    // W = U (..)
+            const int o = sd * (rho < nu ? 1 : -1);
+#pragma unroll
+            for (int e = 0; e < 9; e++) {
+                if (o > 0) Wp[e] = mk(Wp[e].re + Q[e].re, Wp[e].im + Q[e].im);
+                else Wm[e] = mk(Wm[e].re + Q[e].re, Wm[e].im + Q[e].im);
+            }
+        }
+    }
+    // G = -i cf Wp + i cf Wm^+ ;  out = (acc ? out : 0) + scale G
+    double2* o = out + glink_off(g, p, rho, i);
+    const int Gs = glink_stride(g);
+    const double f = cf * scale;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const cd wp = Wp[a * 3 + b], wm = Wm[b * 3 + a];              // (Wm^+)_{ab} = conj(Wm_{ba})
+            // -i wp = (wp.im, -wp.re);  +i conj(wm) = i (wm.re - i wm.im) = (wm.im, wm.re)
+            cd v = mk(f * (wp.im + wm.im), f * (-wp.re + wm.re));
+            if (acc) { const cd old = ld(o + (size_t)(a * 3 + b) * Gs); v = mk(v.re + old.re, v.im + old.im); }
+            st(o + (size_t)(a * 3 + b) * Gs, v);
+        }
+}
+
+static int sigma_table(SigmaTab& tb) {
+    typedef std::complex<double> cx;
+    cx G[4][4][4] = {};
+    const cx ipow[4] = {cx(1, 0), cx(0, 1), cx(-1, 0), cx(0, -1)};
+    for (int mu = 0; mu < 3; mu++)
+        for (int a = 0; a < 4; a++) G[mu][a][PERM[mu][a]] = ipow[GK[mu][a] & 3];
+    for (int a = 0; a < 4; a++) G[3][a][a] = a < 2 ? 1.0 : -1.0;
+    int plane = 0;
+    for (int mu = 0; mu < 4; mu++)
+        for (int nu = mu + 1; nu < 4; nu++, plane++)
+            for (int a = 0; a < 4; a++) {
+                int found = 0;
+                for (int b = 0; b < 4; b++) {
+                    cx t = 0;
+                    for (int k = 0; k < 4; k++) t += G[mu][a][k] * G[nu][k][b] - G[nu][a][k] * G[mu][k][b];
+                    t *= cx(0, 0.5);
+                    if (std::abs(t) > 1e-14) { tb.col[plane][a] = b; tb.re[plane][a] = t.real(); tb.im[plane][a] = t.imag(); found++; }
+                }
+                if (found != 1) { set_error("clover force: sigma is not a generalised permutation matrix in this basis"); return LQCD_ERR_ARG; }
+            }
+    return LQCD_OK;
+}
+
+// out = (accumulate ? out : 0) + scale * (clover part of "U dS_f/dU"); lam = scratch of clover_lambda_elems() elements
+int clover_force(lqcd_ctx_s* c, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double2* lam, double kappa,
+                 double csw, double scale, int accumulate) {
+    SigmaTab tb;
+    LQCHK(sigma_table(tb));
+    hipLaunchKernelGGL(clover_lambda_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, spinor_block(X, 0), spinor_block(X, 1),
+                       spinor_block(Y, 0), spinor_block(Y, 1), lam, tb);
+    HIPCHK(hipGetLastError());
+    out->version++;
+    hipLaunchKernelGGL(clover_force_kernel, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, lam, out->data,
+                       kappa * csw / 8.0, scale, accumulate);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
 }  // namespace lqcd

@@ -313,6 +313,7 @@ struct lqcd_op_s {
     lqcd_spinor_s* clover_tmp = nullptr;   // A x, the diagonal input of the stencil
     double2* clover_inv = nullptr;      // A^-1 in the same packed format (even-odd solver), built on first use
     uint64_t clover_inv_version = 0;
+    double2* clover_lambda = nullptr;   // six Hermitian 3x3 matrices per site: scratch of the clover force
 };
 
 namespace lqcd {
@@ -418,6 +419,9 @@ int clover_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, double2* clov, double kap
 int clover_apply(lqcd_ctx_s* c, const double2* clov, lqcd_spinor_s* out, lqcd_spinor_s* in);
 int clover_apply_parity(lqcd_ctx_s* c, const double2* clov, int parity, double2* out, const double2* in, double sa, const double2* z, double sz);
 int clover_invert(lqcd_ctx_s* c, const double2* clov, double2* inv);
+size_t clover_lambda_elems(const Geom& g);
+int clover_force(lqcd_ctx_s* c, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double2* lam, double kappa,
+                 double csw, double scale, int accumulate);
 
 // fields.hip
 double2* spinor_block(lqcd_spinor_s* s, int p);

@@ -617,6 +617,7 @@ extern "C" int lqcd_op_destroy(lqcd_op_t op) {
     if (!op) return LQCD_OK;
     (void)hipFree(op->clover);
     (void)hipFree(op->clover_inv);
+    (void)hipFree(op->clover_lambda);
     if (op->clover_tmp) lqcd_spinor_destroy(op->clover_tmp);
     delete op;
     return LQCD_OK;
@@ -640,10 +641,6 @@ extern "C" int lqcd_op_set_clover(lqcd_op_t op, double csw) {
     LQCHK(clover_build(c, op->gauge, op->clover, op->km, csw));
     op->clover_version = op->gauge->version;
     HIPCHK(hipStreamSynchronize(c->stream));
-    return LQCD_OK;
-}
-static int no_clover(lqcd_op_s* op, const char* who) {
-    if (op->csw != 0.0) { set_error(std::string(who) + ": not available for the Wilson-clover operator yet"); return LQCD_ERR_UNSUPPORTED; }
     return LQCD_OK;
 }
 extern "C" int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g) {
@@ -988,7 +985,6 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
 // out = (accumulate ? out : 0) + scale * G: the sum over the poles of a rational action is built in place.
 extern "C" int lqcd_fermion_force_acc(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t X, lqcd_spinor_t Y, double scale, int accumulate) {
     LQCHK(check_full(op, X, Y, "lqcd_fermion_force"));
-    LQCHK(no_clover(op, "lqcd_fermion_force (the derivative of the clover term is not built)"));
     ARGCHK(out && out->ctx == op->ctx && out != op->gauge, "lqcd_fermion_force: out must be a gauge-shaped field of the same context, not the operator's links");
     LQCHK(force_check(op, "lqcd_fermion_force"));
     lqcd_ctx_s* c = op->ctx;
@@ -999,6 +995,10 @@ extern "C" int lqcd_fermion_force_acc(lqcd_op_t op, lqcd_gauge_t out, lqcd_spino
         LQCHK(force_halo_exchange_rccl(c, op->kind));
     }
     LQCHK(launch_fermion_force(c, op->kind, op->gauge, out, X, Y, op->km, op->r, scale, accumulate ? 1 : 0));
+    if (op->csw != 0.0 && op->clover) {      // Wilson-clover: + the derivative of the clover term (clover.hip), added in place
+        if (!op->clover_lambda) HIPCHK(hipMalloc((void**)&op->clover_lambda, clover_lambda_elems(c->geom) * sizeof(double2)));
+        LQCHK(clover_force(c, op->gauge, out, X, Y, op->clover_lambda, op->km, op->csw, scale, 1));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
 }

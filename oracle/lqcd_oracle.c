@@ -1004,3 +1004,94 @@ int orc_wilson_clover_bicgstab_eo(double* xd, const double* U, const double* clo
     free(Ainv); free(be); free(bo); free(xe); free(w); free(w2); free(e.w1); free(e.w2);
     return st;
 }
+
+/* ------------------------------------------------------------------ force of the clover term (2-flavour Wilson-clover HMC, BASELINE.json configs[3])
+ * S_f = phi^+ (D_sw^+ D_sw)^-1 phi, X = (D_sw^+ D_sw)^-1 phi, Y = D_sw X:  dS_f = -2 Re(Y^+ dD_sw X), dD_sw = -kappa dH + dA.  The hopping
+ * part is orc_wilson_force; this adds the part of dA = i kappa c_sw sum_{mu<nu} sigma_{mu nu} dF_{mu nu}:
+ *   Y^+ sigma F X = tr_c(F M),  M^{mu nu}(x) = sum_{s s'} sigma_{s s'} X_{s'}(x) Y_s(x)^+,   Lambda = M + M^+  (Hermitian)
+ *   dS_clover = (kappa c_sw / 4) sum_x sum_{mu<nu} Im tr( dQ_{mu nu}(x) Lambda^{mu nu}(x) )
+ * Every leaf of Q is a closed 4-step path; for the link at step k (leaf = P1 L_k P2), with the convention of the other force fields
+ * (dS/d eps[U -> exp(i eps T) U] = -2 Im tr(T G)):
+ *   forward  step, L_k = U_rho(z):    G_rho(z) += -i (kappa c_sw / 8) U_rho(z) P2 Lambda P1
+ *   backward step, L_k = U_rho(z)^+:  G_rho(z) += +i (kappa c_sw / 8) P2 Lambda P1 U_rho(z)^+
+ * Written as a scatter over (site, plane, leaf, step) with generic path stepping -- deliberately not the gather the device uses. */
+static const int LEAF_STEPS[4][4][2] = {   /* {0 = mu | 1 = nu, sign} */
+    {{0, 1}, {1, 1}, {0, -1}, {1, -1}},
+    {{1, 1}, {0, -1}, {1, -1}, {0, 1}},
+    {{0, -1}, {1, -1}, {0, 1}, {1, 1}},
+    {{1, -1}, {0, 1}, {1, 1}, {0, -1}}};
+void orc_clover_force(double* Gd, const double* Ud, const double* Xd, const double* Yd, const int L[4], double kappa, double csw,
+                      int accumulate) {
+    const cplx* U = (const cplx*)Ud;
+    const cplx* X = (const cplx*)Xd;
+    const cplx* Y = (const cplx*)Yd;
+    cplx* G = (cplx*)Gd;
+    long V = vol(L);
+    if (!accumulate) memset(G, 0, sizeof(cplx) * 36 * V);
+    cplx Gm[4][4][4];
+    for (int nu = 0; nu < 4; nu++) gamma_mat(nu, Gm[nu]);
+    const double cf = kappa * csw / 8.0;
+    cplx (*Lam)[6][3][3] = malloc(sizeof(cplx) * 54 * V);
+    for (long s = 0; s < V; s++) {
+        int plane = 0;
+        for (int mu = 0; mu < 4; mu++)
+            for (int nu = mu + 1; nu < 4; nu++, plane++) {
+                cplx S[4][4], M[3][3];
+                for (int a = 0; a < 4; a++)
+                    for (int b = 0; b < 4; b++) {
+                        cplx t1 = 0;
+                        for (int k = 0; k < 4; k++) t1 += Gm[mu][a][k] * Gm[nu][k][b] - Gm[nu][a][k] * Gm[mu][k][b];
+                        S[a][b] = 0.5 * I * t1;
+                    }
+                for (int b = 0; b < 3; b++)
+                    for (int a = 0; a < 3; a++) {
+                        cplx t = 0;
+                        for (int sa = 0; sa < 4; sa++)
+                            for (int sb = 0; sb < 4; sb++) t += S[sa][sb] * X[PIDX(V, s, b, sb)] * conj(Y[PIDX(V, s, a, sa)]);
+                        M[b][a] = t;
+                    }
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) Lam[s][plane][a][b] = M[a][b] + conj(M[b][a]);
+            }
+    }
+    for (int t = 0; t < L[3]; t++)
+        for (int z = 0; z < L[2]; z++)
+            for (int y = 0; y < L[1]; y++)
+                for (int x = 0; x < L[0]; x++) {
+                    long s = site_of(L, x, y, z, t);
+                    int plane = 0;
+                    for (int mu = 0; mu < 4; mu++)
+                        for (int nu = mu + 1; nu < 4; nu++, plane++)
+                            for (int leaf = 0; leaf < 4; leaf++) {
+                                cplx Lk[4][3][3];
+                                long zs[4];
+                                int rho[4], fwd[4];
+                                int c[4] = {x, y, z, t};
+                                for (int k = 0; k < 4; k++) {
+                                    int d = LEAF_STEPS[leaf][k][0] ? nu : mu, sg = LEAF_STEPS[leaf][k][1], w;
+                                    rho[k] = d;
+                                    fwd[k] = sg > 0;
+                                    long here = site_of(L, c[0], c[1], c[2], c[3]);
+                                    long next = neigh(L, c, d, sg, &w);
+                                    c[d] = (c[d] + sg + L[d]) % L[d];
+                                    zs[k] = sg > 0 ? here : next;            /* the site the link U_d lives on */
+                                    cplx Um[3][3];
+                                    load_link(Um, U, V, d, zs[k]);
+                                    if (sg > 0) memcpy(Lk[k], Um, sizeof(Um));
+                                    else link_dag(Lk[k], Um);
+                                }
+                                for (int k = 0; k < 4; k++) {
+                                    cplx P1[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, P2[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, T1[3][3], T2[3][3], W[3][3];
+                                    for (int j = 0; j < k; j++) { mm(T1, P1, Lk[j]); memcpy(P1, T1, sizeof(T1)); }
+                                    for (int j = k + 1; j < 4; j++) { mm(T1, P2, Lk[j]); memcpy(P2, T1, sizeof(T1)); }
+                                    mm(T1, P2, Lam[s][plane]);
+                                    mm(T2, T1, P1);                           /* P2 Lambda P1 */
+                                    if (fwd[k]) mm(W, Lk[k], T2); else mm(W, T2, Lk[k]);
+                                    const cplx f = fwd[k] ? -I * cf : I * cf;
+                                    for (int a = 0; a < 3; a++)
+                                        for (int b = 0; b < 3; b++) G[UIDX(V, rho[k], zs[k], a, b)] += f * W[a][b];
+                                }
+                            }
+                }
+    free(Lam);
+}

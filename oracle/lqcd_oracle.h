@@ -110,6 +110,10 @@ void orc_clover_invert(double* inv, const double* clov, const int L[4]);
 int orc_wilson_clover_bicgstab_eo(double* x, const double* U, const double* clov, const double* b, const int L[4], double kappa, double r,
                                   const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr);
 
+/* "U dS/dU" of the clover term for S_f = phi^+ (D_sw^+ D_sw)^-1 phi (X = (D_sw^+ D_sw)^-1 phi, Y = D_sw X); add orc_wilson_force for the
+ * hopping part.  Same convention as the other force fields. */
+void orc_clover_force(double* G, const double* U, const double* X, const double* Y, const int L[4], double kappa, double csw, int accumulate);
+
 /* fixed-length CG window with the exit test disabled (timing only): runs exactly niter iterations */
 void orc_cg_DdagD_fixed(int kind, double* x, const double* U, const double* b, const int L[4],
                         double kappa_or_mass, double r, const int bc[4], int niter);

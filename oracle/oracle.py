@@ -252,6 +252,16 @@ def cg_clover(U, A, b, L, kappa, r=1.0, bc=(1, 1, 1, -1), eps=1e-19, maxiter=300
     return x, it.value, rr.value, st
 
 
+def clover_fermion_force(U, A, phi, L, kappa, csw, r=1.0, bc=(1, 1, 1, -1), eps=1e-22):
+    """S_f = phi^+ (D_sw^+ D_sw)^-1 phi and its "U dS/dU": hopping part (orc_wilson_force) + clover part.  Returns (S_f, G, X, Y)."""
+    X, _, _, st = cg_clover(U, A, phi, L, kappa, r, bc, eps=eps)
+    assert st == 0
+    Y = wilson_clover_D(U, A, X, L, kappa, r, bc)
+    G = fermion_force(WILSON, U, X, Y, L, kappa, r, bc)
+    lib().orc_clover_force(_p(G), _p(U), _p(X), _p(Y), _i4(L), C.c_double(kappa), C.c_double(csw), 1)
+    return np.vdot(phi, X).real, G, X, Y
+
+
 def clover_invert(A, L):
     inv = np.zeros_like(A)
     lib().orc_clover_invert(_p(inv), _p(A), _i4(L))

@@ -65,9 +65,18 @@ def test_wilson_clover_matches_oracle(lq, orc, L):
         lq.mul_(y, Dd, sol)
         lq.add_fermion_(y, -1.0, x)
         assert lq.dot(y, y).real < 1e-17
-    # what is not built yet fails loudly
-    with pytest.raises(lq.LQCDError):
-        lq.calc_UdSfdU_(lq.Gaugefields(lat), lq.FermiAction(D), U, x)
+    # fermion force of S_f = phi^+ (D_sw^+ D_sw)^-1 phi: hopping part + derivative of the clover term, against the oracle's scatter
+    D.eps_CG = 1e-22
+    G = lq.Gaugefields(lat)
+    Sf = lq.calc_UdSfdU_(G, lq.FermiAction(D), U, x)
+    So, Go, Xo, Yo = orc.clover_fermion_force(Uh2, A2, psi, L, KAPPA, CSW, 1.0, BC, eps=1e-22)
+    assert abs(Sf - So) < 1e-10 * So and rel_err(G.download(), Go) < 1e-9
+    # the sweep alone from resident X, Y, scaled and accumulated
+    X, Y = lq.Fermionfields(lat, lq.WILSON).upload(Xo), lq.Fermionfields(lat, lq.WILSON).upload(Yo)
+    lq.fermion_force_(G, D, X, Y)
+    assert rel_err(G.download(), Go) < 1e-13
+    lq.fermion_force_(G, D, X, Y, scale=0.5, accumulate=True)
+    assert rel_err(G.download(), 1.5 * Go) < 1e-13
 
 
 def test_clover_coefficient_zero_is_wilson(lq, orc):

@@ -76,10 +76,11 @@ def test_momentum_sampling(gpu, orc):
 class DeviceHMC:
     """The reference's update!(::StandardHMC) + runMD_QPQ_sw! (standardHMC.jl:41-91, standardMD.jl:146-166), every field resident."""
 
-    def __init__(self, lq, U, kappa, beta, dtau, mdsteps, nsw, seed):
+    def __init__(self, lq, U, kappa, beta, dtau, mdsteps, nsw, seed, dirac="Wilson", csw=0.0):
         self.lq, self.U, self.beta, self.dtau, self.mdsteps, self.nsw = lq, U, beta, dtau, mdsteps, nsw
         lat = U.lattice
-        self.D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": kappa, "boundarycondition": BC, "eps_CG": 1e-19})
+        self.D = lq.Dirac_operator(U, None, {"Dirac_operator": dirac, "κ": kappa, "Clover_coefficient": csw, "boundarycondition": BC,
+                                            "eps_CG": 1e-19})
         self.fa = lq.FermiAction(self.D)
         self.p, self.G, self.Uold = lq.Gaugefields(lat), lq.Gaugefields(lat), lq.Gaugefields(lat)
         self.xi, self.eta = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.WILSON)
@@ -132,13 +133,16 @@ def _fixture(lq):
     return L, Uh, lq.Gaugefields(lq.Lattice(L)).upload(Uh)
 
 
-def test_hmc_energy_conservation_and_reversibility_on_device(gpu, orc):
+@pytest.mark.parametrize("dirac,csw", [("Wilson", 0.0), ("WilsonClover", 1.0)])
+def test_hmc_energy_conservation_and_reversibility_on_device(gpu, orc, dirac, csw):
+    """Wilson: the reference's 2-flavour HMC.  WilsonClover (BASELINE.json configs[3]; the reference rejects the operator): the same
+    trajectory with the clover term in the action and its derivative in the force -- the integrator stays second order and reversible."""
     lq = gpu
     L, Uh, U = _fixture(lq)
     dH = []
     for mdsteps in (10, 20):
         U.upload(Uh)
-        h = DeviceHMC(lq, U, KAPPA, BETA, 0.5 / mdsteps, mdsteps, 10, seed=400)
+        h = DeviceHMC(lq, U, KAPPA, BETA, 0.5 / mdsteps, mdsteps, 10, seed=400, dirac=dirac, csw=csw)
         lq.gauss_distribution_(h.p, 401)
         lq.gauss_distribution_fermion_(h.xi, 402)
         lq.sample_pseudofermions_(h.eta, U, h.fa, h.xi)

@@ -95,3 +95,42 @@ def test_clover_even_odd_solve_equals_dense_solve(orc, dagger):
     x0, it0, _, st0 = orc.wilson_clover_bicgstab_eo(U, A0, b, L, KAPPA, 1.0, BC, dagger, eps=1e-24)
     xw, itw, _, stw = orc.wilson_bicgstab_eo(U, b, L, KAPPA, 1.0, BC, dagger, eps=1e-24)
     assert st0 == 0 and stw == 0 and it0 == itw and np.abs(x0 - xw).max() < 1e-13
+
+
+@pytest.mark.parametrize("csw", [CSW, 0.0])
+def test_clover_fermion_force_is_the_derivative_of_the_action(orc, csw):
+    """dS_f/d eps [U_mu(n) -> exp(i eps T) U_mu(n)] = -2 Im tr(T G_mu(n)) for S_f = phi^+ (D_sw^+ D_sw)^-1 phi, hopping + clover part,
+    against central differences of the action itself (A is rebuilt from the varied links)."""
+    from scipy.linalg import expm
+    L = (4, 4, 4, 4)
+    U = orc.hot_gauge(L, 421)
+    phi = orc.gaussian_spinor(orc.wilson_shape(L), 422)
+
+    def action(Ut):
+        At = orc.clover_build(Ut, L, KAPPA, csw)
+        X, _, _, st = orc.cg_clover(Ut, At, phi, L, KAPPA, 1.0, BC, eps=1e-26)
+        assert st == 0
+        return np.vdot(phi, X).real
+
+    A = orc.clover_build(U, L, KAPPA, csw)
+    S0, G, X, Y = orc.clover_fermion_force(U, A, phi, L, KAPPA, csw, 1.0, BC, eps=1e-26)
+    assert abs(S0 - action(U)) < 1e-10 * S0
+    if csw == 0.0:
+        assert np.array_equal(G, orc.fermion_force(orc.WILSON, U, X, Y, L, KAPPA, 1.0, BC))
+    else:
+        Gc = G - orc.fermion_force(orc.WILSON, U, X, Y, L, KAPPA, 1.0, BC)
+        assert np.abs(Gc).max() > 1e-3 * np.abs(G).max()          # the clover part is not negligible in this check
+    rng = np.random.default_rng(423)
+    eps = 1e-4
+    for (mu, t, z, y, x) in [(0, 1, 2, 3, 0), (3, 3, 0, 1, 3), (1, 3, 3, 0, 2), (2, 0, 3, 2, 1)]:       # incl. links on the wrap
+        T = sum(c * g for c, g in zip(rng.normal(size=8), orc.GELLMANN))
+        Uab = U[mu, t, z, y, x].T.copy()
+        vals = []
+        for sgn in (+1, -1):
+            Up = U.copy()
+            Up[mu, t, z, y, x] = (expm(1j * sgn * eps * T) @ Uab).T
+            vals.append(action(Up))
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = -2.0 * np.trace(T @ G[mu, t, z, y, x].T).imag
+        assert abs(fd - an) < 1e-6 * max(1.0, abs(an)), (mu, t, z, y, x, fd, an)
+        assert abs(an) > 1e-6
