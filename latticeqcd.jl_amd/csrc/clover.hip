@@ -306,8 +306,8 @@ int clover_invert(lqcd_ctx_s* c, const double2* clov, double2* inv) {
 //     W = U (Lambda(c1) A B C + A Lambda(c2) B C + A B Lambda(c3) C + A B C Lambda(c0)),
 // and, o = s * sign(rho < nu) being the orientation of that loop relative to the counter-clockwise leaves,
 //     G_rho(z) += -i (kappa c_sw / 8) W   (o = +1)        G_rho(z) += +i (kappa c_sw / 8) W^+   (o = -1)
-// in the convention of the other force fields (dS/d eps[U -> exp(i eps T) U] = -2 Im tr(T G)).  The oracle computes the same field
-// as a scatter over (site, plane, leaf, step).
+// in the convention of the other force fields (dS/d eps[U -> exp(i eps T) U] = -2 Im tr(T G)).  The CPU check in tests/ computes the
+// same field as a scatter over (site, plane, leaf, step).
 struct SigmaTab { int col[6][4]; double re[6][4], im[6][4]; };
 
 __host__ __device__ inline size_t lambda_off(const Geom& g, int p, int i, int plane) {
