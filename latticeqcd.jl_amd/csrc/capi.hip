@@ -207,6 +207,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
         hipFree(c->gf_ghost[mu]); hipFree(c->gf_gsend[mu]); hipFree(c->gf_wsend[mu]); hipFree(c->gf_wrecv[mu]);
     }
     for (void* b : c->mix_buf) hipFree(b);
+    hipFree(c->clover_q[0]); hipFree(c->clover_q[1]);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     hipFree(c->d_partial); hipFree(c->d_scal); hipHostFree(c->h_scal);
     hipEventDestroy(c->ev_pack); hipEventDestroy(c->ev_comm); hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
@@ -234,6 +235,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "gauge_recon")) return &c->tun.gauge_recon;
     if (!strcmp(key, "mixed_action_solver")) return &c->tun.mixed_action_solver;
     if (!strcmp(key, "clover_fused")) return &c->tun.clover_fused;
+    if (!strcmp(key, "clover_transport")) return &c->tun.clover_transport;
     if (!strcmp(key, "halo_merge")) return &c->tun.halo_merge;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;

@@ -14,6 +14,10 @@
 
 #include <complex>
 
+// exchange hooks of the staple force (md.hip): buffers of 4 matrices per face site and grouped send / recv
+int gf_buffers(lqcd_ctx_s* c);
+int gf_exchange_rccl(lqcd_ctx_s* c, double2* const sendb[4], double2* const recvb[4], bool to_backward);
+
 namespace lqcd {
 
 struct CloverTables {
@@ -22,6 +26,11 @@ struct CloverTables {
 
 __host__ __device__ inline size_t clover_off(const Geom& g, int p, int i) { return (((size_t)p * g.nch + (size_t)(i >> 6)) * 36) * 64 + (i & 63); }
 size_t clover_elems(const Geom& g) { return (size_t)2 * g.nch * 36 * 64; }
+// six 3x3 matrices per site, one per plane (0,1) (0,2) (0,3) (1,2) (1,3) (2,3): [parity][chunk][plane][9][64]
+__host__ __device__ inline size_t lambda_off(const Geom& g, int p, int i, int plane) {
+    return ((((size_t)p * g.nch + (size_t)(i >> 6)) * 6 + plane) * 9) * 64 + (i & 63);
+}
+size_t clover_lambda_elems(const Geom& g) { return (size_t)2 * g.nch * 54 * 64; }
 
 __device__ __forceinline__ void ldm(cd (&u)[9], const double2* __restrict__ U, const Geom& g, const int (&c)[4], int mu) {
     const int p = (c[0] + c[1] + c[2] + c[3]) & 1;
@@ -54,7 +63,11 @@ __device__ __forceinline__ void step(int (&d)[4], const Geom& g, int mu, int dir
 }
 
 // one thread per site: six field-strength matrices, then the two packed chiral blocks
-__global__ __launch_bounds__(64) void clover_build_kernel(Geom g, const double2* __restrict__ U, double2* __restrict__ clov, double coef, CloverTables tb) {
+// FROMQ: the clover sums Q_{mu nu}(x) come from qbuf ([parity][chunk][plane][9][64], built by the transport passes below -- the
+// partitioned lattice); otherwise the four leaves are multiplied out here from local links.
+template <bool FROMQ>
+__global__ __launch_bounds__(64) void clover_build_kernel(Geom g, const double2* __restrict__ U, double2* __restrict__ clov, double coef, CloverTables tb,
+                                                           const double2* __restrict__ qbuf) {
     const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
     if (i >= g.Vh) return;
     int c[4];
@@ -70,7 +83,13 @@ __global__ __launch_bounds__(64) void clover_build_kernel(Geom g, const double2*
     int plane = 0;
     for (int mu = 0; mu < 4; mu++)
         for (int nu = mu + 1; nu < 4; nu++, plane++) {
-            cd A[9], B[9], C[9], D[9], t1[9], t2[9], t3[9], Q[9];
+            cd Q[9];
+            if constexpr (FROMQ) {
+                const double2* qb = qbuf + ((((size_t)p * g.nch + (size_t)(i >> 6)) * 6 + plane) * 9) * 64 + (i & 63);
+#pragma unroll
+                for (int e = 0; e < 9; e++) Q[e] = ld(qb + (size_t)e * 64);
+            } else {
+            cd A[9], B[9], C[9], D[9], t1[9], t2[9], t3[9];
             int xm[4] = {c[0], c[1], c[2], c[3]}, xn[4] = {c[0], c[1], c[2], c[3]}, xpm[4] = {c[0], c[1], c[2], c[3]}, xpn[4] = {c[0], c[1], c[2], c[3]};
             step(xm, g, mu, -1); step(xn, g, nu, -1); step(xpm, g, mu, 1); step(xpn, g, nu, 1);
             int xmpn[4] = {xm[0], xm[1], xm[2], xm[3]}, xmn[4] = {xm[0], xm[1], xm[2], xm[3]}, xnpm[4] = {xn[0], xn[1], xn[2], xn[3]};
@@ -93,6 +112,7 @@ __global__ __launch_bounds__(64) void clover_build_kernel(Geom g, const double2*
             mmx<true, false>(t1, A, B); mmx<false, false>(t2, t1, C); mmx<false, true>(t3, t2, D);
 #pragma unroll
             for (int e = 0; e < 9; e++) Q[e] = Q[e] + t3[e];
+            }
             // F = (Q - Q^+)/8 ;  blk_b += i coef sigma^b (x) F
 #pragma unroll
             for (int ca = 0; ca < 3; ca++)
@@ -262,10 +282,178 @@ static int clover_tables(CloverTables& tb) {
     return LQCD_OK;
 }
 
+// ---- the clover sums on a partitioned lattice (or with the tunable clover_transport = 1): Q = (1 + T_nu)(1 + T_mu) P with the
+// elementary plaquette P_{mu nu}(y) = U_mu(y) U_nu(y+mu) U_mu^+(y+nu) U_nu^+(y) and the backward transport
+// T_d[M](x) = U_d^+(x-d) M(x-d) U_d(x-d): P needs forward link ghosts only (the ones the staple force exchanges), every transport is
+// one face exchange of 3x3 matrices to the +d neighbour (the sender conjugates with its own links) -- no corner exchange.
+struct CloverQArgs {
+    Geom g;
+    const double2* U;
+    const double2* ghost[4];   // x_d = 0 link slices of the +d neighbours ([parity][nu][9][Fh]); null when unpartitioned
+    const double2* in;         // [parity][chunk][plane][9][64]
+    double2* out;
+    double2* wsend[4];         // transported upper-face matrices for the +d neighbour: [parity of the sender site][slot][9][Fh]
+    const double2* wrecv[4];
+    int stage;                 // 0: transport along the first index of each plane, 1: along the second
+};
+__device__ __forceinline__ size_t qoff(const Geom& g, int p, int i, int plane) { return lambda_off(g, p, i, plane); }
+__device__ __forceinline__ void ld_link_fwd(cd (&u)[9], const CloverQArgs& k, const int (&c)[4], int dir, int nu) {
+    const Geom& g = k.g;
+    int d[4] = {c[0], c[1], c[2], c[3]};
+    d[dir] += 1;
+    if (d[dir] == g.L[dir]) {
+        d[dir] = 0;
+        if (g.part[dir]) {
+            const int p = (d[0] + d[1] + d[2] + d[3]) & 1, Fh = face_half_sites(g, dir), f = coords_to_face(g, dir, d);
+            const double2* b = k.ghost[dir] + ((size_t)(p * 4 + nu) * 9) * Fh + f;
+#pragma unroll
+            for (int e = 0; e < 9; e++) u[e] = ld(b + (size_t)e * Fh);
+            return;
+        }
+    }
+    ldm(u, k.U, g, d, nu);
+}
+__device__ __forceinline__ void plane_dirs(int plane, int& mu, int& nu) {
+    mu = plane < 3 ? 0 : (plane < 5 ? 1 : 2);
+    nu = plane < 3 ? plane + 1 : (plane < 5 ? plane - 1 : 3);
+}
+// slot of `plane` in the face buffer of direction d for this stage (-1: d does not transport this plane in this stage)
+__device__ __forceinline__ int plane_slot(int plane, int d, int stage) {
+    int mu, nu;
+    plane_dirs(plane, mu, nu);
+    if (stage == 0) return mu == d ? nu - d - 1 : -1;     // planes (d, nu), nu > d
+    return nu == d ? mu : -1;                             // planes (mu, d), mu < d
+}
+__global__ __launch_bounds__(64) void clover_plaq_kernel(CloverQArgs k) {
+    const Geom& g = k.g;
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (i >= g.Vh) return;
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    for (int plane = 0; plane < 6; plane++) {
+        int mu, nu;
+        plane_dirs(plane, mu, nu);
+        cd A[9], B[9], t1[9], t2[9];
+        ldm(A, k.U, g, c, mu);
+        ld_link_fwd(B, k, c, mu, nu);
+        mmx<false, false>(t1, A, B);
+        ld_link_fwd(A, k, c, nu, mu);
+        mmx<false, true>(t2, t1, A);
+        ldm(B, k.U, g, c, nu);
+        mmx<false, true>(t1, t2, B);
+        double2* o = k.out + qoff(g, p, i, plane);
+#pragma unroll
+        for (int e = 0; e < 9; e++) st(o + (size_t)e * 64, t1[e]);
+    }
+}
+// W = U_d^+(y) M(y) U_d(y)
+__device__ __forceinline__ void conj_transport(cd (&W)[9], const CloverQArgs& k, const int (&y)[4], int d, int plane) {
+    const Geom& g = k.g;
+    const int py = (y[0] + y[1] + y[2] + y[3]) & 1;
+    cd Ud[9], M[9], t[9];
+    ldm(Ud, k.U, g, y, d);
+    const double2* m = k.in + qoff(g, py, coords_to_cb(g, y), plane);
+#pragma unroll
+    for (int e = 0; e < 9; e++) M[e] = ld(m + (size_t)e * 64);
+    mmx<true, false>(t, Ud, M);
+    mmx<false, false>(W, t, Ud);
+}
+// upper faces (y_d = L_d - 1) of the partitioned directions d = blockIdx.y
+__global__ __launch_bounds__(128) void clover_transport_face_kernel(CloverQArgs k) {
+    const Geom& g = k.g;
+    const int d = blockIdx.y;
+    if (!g.part[d]) return;
+    const int Fh = face_half_sites(g, d), t = blockIdx.x * 128 + threadIdx.x;
+    if (t >= 2 * Fh) return;
+    const int py = t / Fh, f = t - py * Fh;
+    int y[4];
+    face_to_coords(g, d, g.L[d] - 1, py, f, y);
+    for (int plane = 0; plane < 6; plane++) {
+        const int slot = plane_slot(plane, d, k.stage);
+        if (slot < 0) continue;
+        cd W[9];
+        conj_transport(W, k, y, d, plane);
+        double2* o = k.wsend[d] + ((size_t)(py * 4 + slot) * 9) * Fh + f;
+#pragma unroll
+        for (int e = 0; e < 9; e++) st(o + (size_t)e * Fh, W[e]);
+    }
+}
+__global__ __launch_bounds__(64) void clover_transport_kernel(CloverQArgs k) {
+    const Geom& g = k.g;
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (i >= g.Vh) return;
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    for (int plane = 0; plane < 6; plane++) {
+        int mu, nu;
+        plane_dirs(plane, mu, nu);
+        const int d = k.stage == 0 ? mu : nu;
+        cd W[9];
+        if (c[d] == 0 && g.part[d]) {
+            const int Fh = face_half_sites(g, d), f = coords_to_face(g, d, c), slot = plane_slot(plane, d, k.stage);
+            const double2* b = k.wrecv[d] + ((size_t)((1 - p) * 4 + slot) * 9) * Fh + f;      // the sender site y = x - d has the other parity
+#pragma unroll
+            for (int e = 0; e < 9; e++) W[e] = ld(b + (size_t)e * Fh);
+        } else {
+            int y[4] = {c[0], c[1], c[2], c[3]};
+            step(y, g, d, -1);
+            conj_transport(W, k, y, d, plane);
+        }
+        const double2* m = k.in + qoff(g, p, i, plane);
+        double2* o = k.out + qoff(g, p, i, plane);
+#pragma unroll
+        for (int e = 0; e < 9; e++) { const cd v = ld(m + (size_t)e * 64); st(o + (size_t)e * 64, mk(v.re + W[e].re, v.im + W[e].im)); }
+    }
+}
+
+static int clover_q_transport(lqcd_ctx_s* c, const lqcd_gauge_s* U, double2* q0, double2* q1) {
+    const bool part = any_partitioned(c);
+    if (part) {
+        ARGCHK(c->local_peers.empty(), "clover term: not available on an in-process PE grid");
+        LQCHK(gf_buffers(c));
+        for (int mu = 0; mu < 4; mu++)
+            if (c->geom.part[mu]) LQCHK(gauge_pack_face(const_cast<lqcd_gauge_s*>(U), mu, c->gf_gsend[mu]));
+        LQCHK(gf_exchange_rccl(c, c->gf_gsend, c->gf_ghost, true));
+    }
+    CloverQArgs k;
+    k.g = c->geom;
+    k.U = U->data;
+    int maxf = 0;
+    for (int mu = 0; mu < 4; mu++) {
+        k.ghost[mu] = c->gf_ghost[mu]; k.wsend[mu] = c->gf_wsend[mu]; k.wrecv[mu] = c->gf_wrecv[mu];
+        if (c->geom.part[mu]) maxf = std::max(maxf, face_half_sites(c->geom, mu));
+    }
+    k.in = nullptr; k.out = q0; k.stage = 0;
+    hipLaunchKernelGGL(clover_plaq_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, k);
+    HIPCHK(hipGetLastError());
+    for (int stage = 0; stage < 2; stage++) {
+        k.stage = stage;
+        k.in = stage == 0 ? q0 : q1;
+        k.out = stage == 0 ? q1 : q0;
+        if (part) {
+            hipLaunchKernelGGL(clover_transport_face_kernel, dim3((2 * maxf + 127) / 128, 4), dim3(128), 0, c->stream, k);
+            HIPCHK(hipGetLastError());
+            LQCHK(gf_exchange_rccl(c, c->gf_wsend, c->gf_wrecv, false));
+        }
+        hipLaunchKernelGGL(clover_transport_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, k);
+        HIPCHK(hipGetLastError());
+    }
+    return LQCD_OK;       // Q in q0
+}
+
 int clover_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, double2* clov, double kappa, double csw) {
     CloverTables tb;
     LQCHK(clover_tables(tb));
-    hipLaunchKernelGGL(clover_build_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, U->data, clov, kappa * csw, tb);
+    if (any_partitioned(c) || c->tun.clover_transport) {
+        for (int j = 0; j < 2; j++)
+            if (!c->clover_q[j]) HIPCHK(hipMalloc((void**)&c->clover_q[j], clover_lambda_elems(c->geom) * sizeof(double2)));
+        LQCHK(clover_q_transport(c, U, c->clover_q[0], c->clover_q[1]));
+        hipLaunchKernelGGL(clover_build_kernel<true>, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, U->data, clov, kappa * csw, tb,
+                           c->clover_q[0]);
+    } else {
+        hipLaunchKernelGGL(clover_build_kernel<false>, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, U->data, clov, kappa * csw, tb,
+                           (const double2*)nullptr);
+    }
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
@@ -310,10 +498,6 @@ int clover_invert(lqcd_ctx_s* c, const double2* clov, double2* inv) {
 // same field as a scatter over (site, plane, leaf, step).
 struct SigmaTab { int col[6][4]; double re[6][4], im[6][4]; };
 
-__host__ __device__ inline size_t lambda_off(const Geom& g, int p, int i, int plane) {
-    return ((((size_t)p * g.nch + (size_t)(i >> 6)) * 6 + plane) * 9) * 64 + (i & 63);
-}
-size_t clover_lambda_elems(const Geom& g) { return (size_t)2 * g.nch * 54 * 64; }
 
 __global__ __launch_bounds__(64) void clover_lambda_kernel(Geom g, const double2* __restrict__ X0, const double2* __restrict__ X1,
                                                             const double2* __restrict__ Y0, const double2* __restrict__ Y1,

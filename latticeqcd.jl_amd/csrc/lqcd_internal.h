@@ -237,6 +237,7 @@ struct Tunables {
     int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)
     int halo_merge = 1;       // PE extent 2 in a direction: both faces travel to the same rank as ONE message each way
     int clover_fused = 1;     // Wilson-clover: apply A inside the direction-split kernel's epilogue (0: separate A x pass)
+    int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
     int gauge_recon = 18;     // 12: the Wilson dirsplit kernel reads 2 rows per link and rebuilds the third (only for links that
                               // are unitary to 1e-14; otherwise the 18-real field is used).  Opt-in: bytes/site 960 -> 768.
@@ -264,6 +265,7 @@ struct lqcd_ctx_s {
     int force_ncomp = 0;
     // staple-force halos (md.hip): forward ghost links (+ their send buffer) and the lower-staple faces, allocated on first use
     double2* gf_ghost[4] = {}, *gf_gsend[4] = {}, *gf_wsend[4] = {}, *gf_wrecv[4] = {};
+    double2* clover_q[2] = {};          // clover sums / transport ping-pong, six 3x3 matrices per site (clover.hip)
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
     void* mix_buf[7] = {};
     size_t mix_bytes[7] = {};

@@ -340,7 +340,7 @@ extern "C" int lqcd_gauge_action(lqcd_gauge_t U, double beta, double* Sg) {
 // reads ghosts for n+mu / n+nu and the received W for n-nu.  No corner exchange, two grouped send/recv steps.
 static size_t gf_face_elems(lqcd_ctx_s* c, int mu) { return (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu); }
 
-static int gf_buffers(lqcd_ctx_s* c) {
+int gf_buffers(lqcd_ctx_s* c) {
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu] || c->gf_ghost[mu]) continue;
         const size_t bytes = gf_face_elems(c, mu) * sizeof(double2);
@@ -380,7 +380,7 @@ static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse) {
 }
 
 // send `sendb[mu]` to one neighbour and receive into `recvb[mu]` from the opposite one, all partitioned directions in one group
-static int gf_exchange_rccl(lqcd_ctx_s* c, double2* const sendb[4], double2* const recvb[4], bool to_backward) {
+int gf_exchange_rccl(lqcd_ctx_s* c, double2* const sendb[4], double2* const recvb[4], bool to_backward) {
     ARGCHK(c->has_comm, "staple force: communicator not initialised (call lqcd_ctx_comm_init)");
     NCCLCHK(ncclGroupStart());
     for (int mu = 0; mu < 4; mu++) {

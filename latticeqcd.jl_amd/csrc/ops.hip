@@ -629,8 +629,8 @@ extern "C" int lqcd_op_set_clover(lqcd_op_t op, double csw) {
     ARGCHK(op, "lqcd_op_set_clover: null argument");
     ARGCHK(op->kind == LQCD_WILSON, "lqcd_op_set_clover: the clover term belongs to the Wilson operator");
     lqcd_ctx_s* c = op->ctx;
-    if (csw != 0.0 && any_partitioned(c)) {
-        set_error("lqcd_op_set_clover: not available on a partitioned lattice yet (the clover leaves need link halos)");
+    if (csw != 0.0 && any_partitioned(c) && !c->local_peers.empty()) {
+        set_error("lqcd_op_set_clover: not available on an in-process PE grid (RCCL ranks only)");
         return LQCD_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(c->device));
@@ -988,6 +988,10 @@ extern "C" int lqcd_fermion_force_acc(lqcd_op_t op, lqcd_gauge_t out, lqcd_spino
     ARGCHK(out && out->ctx == op->ctx && out != op->gauge, "lqcd_fermion_force: out must be a gauge-shaped field of the same context, not the operator's links");
     LQCHK(force_check(op, "lqcd_fermion_force"));
     lqcd_ctx_s* c = op->ctx;
+    if (op->csw != 0.0 && any_partitioned(c)) {
+        set_error("lqcd_fermion_force: the derivative of the clover term is not available on a partitioned lattice yet");
+        return LQCD_ERR_UNSUPPORTED;
+    }
     HIPCHK(hipSetDevice(c->device));
     apply_bc(c, op->bc);
     if (any_partitioned(c)) {   // one exchange step: lower-face X, Y -> the -mu neighbours

@@ -92,3 +92,68 @@ def test_clover_coefficient_zero_is_wilson(lq, orc):
     lq.mul_(y, Dw, x)
     lq.mul_(z, Dc, x)
     assert np.array_equal(y.download(), z.download())
+
+
+def test_clover_sums_by_plaquette_transport_equal_the_direct_leaves(lq, orc):
+    """The partitioned build (plaquettes + two backward transports) run on an unpartitioned lattice (tunable clover_transport)."""
+    L = (8, 4, 6, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 506)
+    U = lq.Gaugefields(lat).upload(Uh)
+    psi = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 507)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    y = x.similar()
+    lat.set_param("clover_transport", 1)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": CSW, "boundarycondition": BC})
+    lq.mul_(y, D, x)
+    ref = orc.wilson_clover_D(Uh, orc.clover_build(Uh, L, KAPPA, CSW), psi, L, KAPPA, 1.0, BC)
+    assert rel_err(y.download(), ref) < 1e-13
+
+
+def test_rccl_self_partition_clover(lq, orc):
+    """Wilson-clover on a partitioned lattice (BASELINE.json configs[3]): LQCD_FORCE_PARTITION + world-size-1 RCCL communicators run the
+    link-ghost exchange, the two matrix-face exchanges of the clover sums and the halo'ed Dslash with the fused clover epilogue exactly
+    as at N > 1; operator, CG, even-odd BiCGStab and the mixed-precision CG must equal the oracle."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        from oracle import oracle as orc
+        L, K, CSW, BC = (8, 4, 6, 8), 0.141139, 1.5612, (1, 1, 1, -1)
+        lat = lq.Lattice(L)
+        lat.comm_init(lq.comm_unique_id())
+        Uh = orc.hot_gauge(L, 111)
+        U = lq.Gaugefields(lat).upload(Uh)
+        A = orc.clover_build(Uh, L, K, CSW)
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": K, "Clover_coefficient": CSW, "boundarycondition": BC, "eps_CG": 1e-19})
+        psi = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 112)
+        x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+        y, sol = x.similar(), x.similar()
+        rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+        for dag in (False, True):
+            lq.mul_(y, D.adjoint() if dag else D, x)
+            assert rel(y.download(), orc.wilson_clover_D(Uh, A, psi, L, K, 1.0, BC, dag)) < 1e-13, dag
+        xo, ito, _, st = orc.cg_clover(Uh, A, psi, L, K, 1.0, BC, eps=1e-19)
+        it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+        assert st == 0 and abs(it - ito) <= 1 and rel(sol.download(), xo) < 1e-9
+        lq.clear_fermion_(sol)
+        lq.solve_mixed_DinvX_(sol, lq.DdagD_operator(D), x)
+        assert rel(sol.download(), xo) < 1e-8
+        D.method_CG = "bicgstab_evenodd"
+        lq.clear_fermion_(sol)
+        lq.solve_DinvX_(sol, D, x)
+        xe, _, _, st = orc.wilson_clover_bicgstab_eo(Uh, A, psi, L, K, 1.0, BC, False, eps=1e-19)
+        assert st == 0 and rel(sol.download(), xe) < 1e-9
+        try:
+            lq.calc_UdSfdU_(lq.Gaugefields(lat), lq.FermiAction(D), U, x)
+            raise SystemExit("the clover force must be refused on a partitioned lattice")
+        except lq.LQCDError:
+            pass
+        print("RCCL_SELF_CLOVER_OK")
+    """)
+    for mask in ("8", "14", "15"):
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "RCCL_SELF_CLOVER_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
