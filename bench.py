@@ -76,6 +76,7 @@ def main():
         box = [lq.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         lat.comm_init(box[0])
+        _flush_c_stdio()
 
     def device_sync():
         lat.sync()   # hipStreamSynchronize on the library's compute and communication streams
@@ -170,6 +171,11 @@ def main():
         out["allreduce_latency_us"] = v[6]
         face = [lat.local_L[0] * lat.local_L[1] * lat.local_L[2] * lat.local_L[3] // lat.local_L[mu] if pe[mu] > 1 else 0 for mu in range(4)]
         out["halo_bytes_per_peer_and_direction"] = [96 * f for f in face]
+        try:        # which schedule the library's one-off timing picked on rank 0 (0: exchange on the 2nd stream, 1: interior on it)
+            out["halo_stream_mode_rank0"] = {"chosen": lat.get_param("halo_stream_mode"),
+                                             "us_per_application": [lat.get_param("halo_tuned_us0"), lat.get_param("halo_tuned_us1")]}
+        except Exception:
+            pass
 
     # ---- secondary (outside the timed region, not part of `value`): the opt-in 12-real link compression (rows 0,1 stored, row 2
     # rebuilt; only for links unitary to 1e-14 -- the hot start is).  Same operator, 768 instead of 960 bytes moved per site.
@@ -209,11 +215,24 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # The JSON line must be the LAST thing on the job's stdout: RCCL writes its version banner through C stdio at communicator
+    # creation, where it would sit in the C buffer until exit -- every rank flushes C stdio right after comm_init and again here.
+    _flush_c_stdio()
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+    _flush_c_stdio()
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def cpu_baseline(lq, U, b, gL):

@@ -236,6 +236,9 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "mixed_action_solver")) return &c->tun.mixed_action_solver;
     if (!strcmp(key, "clover_fused")) return &c->tun.clover_fused;
     if (!strcmp(key, "clover_transport")) return &c->tun.clover_transport;
+    if (!strcmp(key, "halo_stream_mode")) return &c->tun.halo_stream_mode;
+    if (!strcmp(key, "halo_tuned_us0")) return &c->tun.halo_tuned_us[0];
+    if (!strcmp(key, "halo_tuned_us1")) return &c->tun.halo_tuned_us[1];
     if (!strcmp(key, "halo_merge")) return &c->tun.halo_merge;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;

@@ -237,6 +237,10 @@ struct Tunables {
     int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)
     int halo_merge = 1;       // PE extent 2 in a direction: both faces travel to the same rank as ONE message each way
     int clover_fused = 1;     // Wilson-clover: apply A inside the direction-split kernel's epilogue (0: separate A x pass)
+    int halo_stream_mode = -1; // partitioned stencil: 0 = exchange on the communication stream, interior on the compute stream;
+                               // 1 = pack -> exchange -> exterior in order on the compute stream, interior on the second stream
+                               // (no queue hop on the message path; pays when the exchange is the longer leg); -1 = time both once
+    int halo_tuned_us[2] = {0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
     int gauge_recon = 18;     // 12: the Wilson dirsplit kernel reads 2 rows per link and rebuilds the third (only for links that
@@ -395,7 +399,7 @@ int force_halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind);
 int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
                          double r, double scale = 1.0, int accumulate = 0);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
-int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec);
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, bool in_order);
 StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger);
 void apply_bc(lqcd_ctx_s* c, const int bc[4]);
 int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial);

@@ -26,12 +26,17 @@ static size_t halo_count(lqcd_ctx_s* c, int mu, int kind, int parity_mode) {
 // RCCL path: grouped send/recv on the communication stream, so the transfer over xGMI overlaps the interior stencil running
 // on the compute stream.  When both neighbours of a direction are the same rank (PE extent 2) the two faces are ONE message
 // each way: my [fwd | bwd] lands in its [from bwd | from fwd].
-int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec) {
+// in_order = false: the exchange runs on the communication stream behind an event of the pack kernel and signals ev_comm;
+// in_order = true: it is enqueued on the compute stream itself, right behind the pack kernel (halo_stream_mode = 1)
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, bool in_order) {
     const ncclDataType_t dt = prec ? ncclFloat : ncclDouble;   // same element counts, float2 instead of double2 elements
     const size_t esize = prec ? sizeof(float2) : sizeof(double2);
     ARGCHK(c->has_comm, "halo exchange: communicator not initialised (call lqcd_ctx_comm_init)");
-    HIPCHK(hipEventRecord(c->ev_pack, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+    hipStream_t xs = in_order ? c->stream : c->comm_stream;
+    if (!in_order) {
+        HIPCHK(hipEventRecord(c->ev_pack, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+    }
     NCCLCHK(ncclGroupStart());
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
@@ -39,17 +44,17 @@ int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec) {
         char* sf = (char*)c->send_fwd[mu];
         char* rb = (char*)c->recv_bwd[mu];
         if (c->tun.halo_merge && c->nbr_fwd[mu] == c->nbr_bwd[mu]) {
-            NCCLCHK(ncclSend(sf, 2 * n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
-            NCCLCHK(ncclRecv(rb, 2 * n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
+            NCCLCHK(ncclSend(sf, 2 * n, dt, c->nbr_fwd[mu], c->comm, xs));
+            NCCLCHK(ncclRecv(rb, 2 * n, dt, c->nbr_bwd[mu], c->comm, xs));
             continue;
         }
-        NCCLCHK(ncclSend(sf, n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclSend(sf + cnt * esize, n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclRecv(rb, n, dt, c->nbr_bwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclRecv(rb + cnt * esize, n, dt, c->nbr_fwd[mu], c->comm, c->comm_stream));
+        NCCLCHK(ncclSend(sf, n, dt, c->nbr_fwd[mu], c->comm, xs));
+        NCCLCHK(ncclSend(sf + cnt * esize, n, dt, c->nbr_bwd[mu], c->comm, xs));
+        NCCLCHK(ncclRecv(rb, n, dt, c->nbr_bwd[mu], c->comm, xs));
+        NCCLCHK(ncclRecv(rb + cnt * esize, n, dt, c->nbr_fwd[mu], c->comm, xs));
     }
     NCCLCHK(ncclGroupEnd());
-    HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
+    if (!in_order) HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     return LQCD_OK;
 }
 
@@ -83,9 +88,51 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         return LQCD_ERR_UNSUPPORTED;
     }
     ARGCHK(c->local_peers.empty(), "this context belongs to an in-process PE grid: use the lqcd_mdom_* collectives");
-    LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
-    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec));
     // norm partials: the interior writes |.|^2 of what it produced, the exterior appends the corrections of the sites it updates
+    if (c->tun.halo_stream_mode < 0) {
+        // auto: time both schedules once on the first plain full-lattice application (idempotent: it only rewrites `out`).  Every rank
+        // issues the same exchanges whichever schedule it ends up with, so the choice is local.
+        if (s.parity_mode != 2 || s.upd_scal || s.upd[0] || s.upd[1]) {
+            c->tun.halo_stream_mode = 0;
+            const int st = stencil_apply(c, s);
+            c->tun.halo_stream_mode = -1;
+            return st;
+        }
+        float ms[2] = {0.f, 0.f};
+        for (int mode = 0; mode < 2; mode++) {
+            c->tun.halo_stream_mode = mode;
+            LQCHK(stencil_apply(c, s));
+            HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+            for (int k = 0; k < 4; k++) LQCHK(stencil_apply(c, s));
+            HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+            HIPCHK(hipEventSynchronize(c->ev_t1));
+            HIPCHK(hipEventElapsedTime(&ms[mode], c->ev_t0, c->ev_t1));
+        }
+        c->tun.halo_stream_mode = ms[1] < ms[0] ? 1 : 0;
+        c->tun.halo_tuned_us[0] = (int)(250.f * ms[0]);
+        c->tun.halo_tuned_us[1] = (int)(250.f * ms[1]);
+        return LQCD_OK;      // `out` holds the result of the last tuning application
+    }
+    if (c->tun.halo_stream_mode == 1) {
+        // pack -> exchange -> exterior stay in order on the compute stream (no queue hop on the path that carries the messages);
+        // the interior runs beside them on the second stream, forked and joined by events
+        HIPCHK(hipEventRecord(c->ev_pack, c->stream));                 // the inputs of this call are complete
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+        {
+            hipStream_t main_stream = c->stream;
+            c->stream = c->comm_stream;                                // the launchers enqueue on c->stream
+            const int st = s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s);
+            c->stream = main_stream;
+            LQCHK(st);
+        }
+        HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
+        LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, true));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+        return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+    }
+    LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, false));
     LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
@@ -397,6 +444,7 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
         if (fixed && !use_graph) burst = maxiter - it;
         if (use_graph && burst == check_every) {
             if (!gexec) {
+                if (c->tun.halo_stream_mode < 0) c->tun.halo_stream_mode = 0;    // the auto-tuning pass synchronises: not inside a capture
                 hipError_t ge = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
                 if (ge != hipSuccess) { st = hip_fail(ge, "hipStreamBeginCapture", __FILE__, __LINE__); break; }
                 for (int k = 0; k < burst && st == LQCD_OK; k++) st = cg_enqueue_iteration(op, x, w);
@@ -1162,7 +1210,7 @@ extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spin
         HIPCHK(hipEventRecord(e[0], c->stream));
         LQCHK(launch_stencil_pack(c, s));
         HIPCHK(hipEventRecord(e[1], c->stream));
-        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0));
+        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0, false));
         HIPCHK(hipEventRecord(e[5], c->comm_stream));
         LQCHK(launch_stencil_interior(c, s));
         HIPCHK(hipEventRecord(e[2], c->stream));
