@@ -3,6 +3,8 @@
 // calculate_Plaquette -- call sites /root/reference/src/system/universe.jl:41-77, src/system/lqcd.jl:187-193.)
 #include "lqcd_internal.h"
 
+#include <atomic>
+
 #include <cstring>
 
 namespace lqcd {
@@ -246,6 +248,10 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
     HIPCHK(hipSetDevice(ctx->device));
     lqcd_gauge_s* x = new lqcd_gauge_s;
     x->ctx = ctx;
+    // versions are unique across handles (handle epoch in the upper 32 bits, writes counted in the lower): caches keyed on a
+    // version (12-real copy, clover term, fp32 copies of the mixed-precision solver) can never match a recycled handle address
+    static std::atomic<uint64_t> epoch{0};
+    x->version = (++epoch << 32) | 1u;
     x->elems = gauge_elems(ctx->geom);
     x->data = nullptr;
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));

@@ -271,6 +271,8 @@ struct lqcd_ctx_s {
     double2* gf_ghost[4] = {}, *gf_gsend[4] = {}, *gf_wsend[4] = {}, *gf_wrecv[4] = {};
     double2* clover_q[2] = {};          // clover sums / transport ping-pong, six 3x3 matrices per site (clover.hip)
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
+    const void* mix_gauge_of = nullptr;  // gauge handle / version the fp32 link copies in mix_buf[0], mix_buf[5] were made from
+    uint64_t mix_gauge_version = 0;
     void* mix_buf[7] = {};
     size_t mix_bytes[7] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)

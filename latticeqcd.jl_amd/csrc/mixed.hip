@@ -217,7 +217,9 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
         return LQCD_OK;
     };
     auto run = [&]() -> int {
-        hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
+        // the fp32 link copies follow the field (handle, version): a sequence of solves on the same links converts once
+        const bool links_cached = c->mix_gauge_of == (const void*)op->gauge && c->mix_gauge_version == op->gauge->version;
+        if (!links_cached) hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
         if (clov) {     // fp32 copy of the packed clover blocks (same layout); A follows the links first
             if (op->clover_version != op->gauge->version) {
                 LQCHK(clover_build(c, op->gauge, op->clover, op->km, op->csw));
@@ -226,7 +228,11 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
             const size_t nc = clover_elems(c->geom);
             hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, m.clover, op->clover, nc, 1.0);
         }
-        hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
+        if (!links_cached) {
+            hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
+            c->mix_gauge_of = (const void*)op->gauge;
+            c->mix_gauge_version = op->gauge->version;
+        }
         HIPCHK(hipGetLastError());
         LQCHK(true_residual());
         bool fallback = false;

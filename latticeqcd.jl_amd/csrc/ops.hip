@@ -866,9 +866,19 @@ __global__ void ms_zeta(const double* __restrict__ sc, double* __restrict__ ms, 
     const double alpha = sc[S_ALPHA], beta = sc[S_BETA], alpha_m = ms[6 * ns], beta_m = ms[6 * ns + 1];
     for (int j = threadIdx.x; j < ns; j += blockDim.x) {
         const double sigma = ms[j], zm = ms[ns + j], z0 = ms[2 * ns + j];
+        if (fabs(z0) < 1e-100) {      // this shift converged long ago (its residual is zeta^2 |r|^2): freeze it before zeta underflows to 0/0
+            ms[3 * ns + j] = 0.0; ms[4 * ns + j] = 0.0; ms[5 * ns + j] = 0.0;
+            continue;
+        }
         const double den = zm * alpha_m * (1.0 + alpha * sigma) + alpha * beta_m * (zm - z0);
         const double zp = z0 * zm * alpha_m / den, ratio = zp / z0;
         ms[3 * ns + j] = ratio * alpha;
+        if (zp * zp * sc[S_RR] < sc[S_EPS]) {
+            // the residual of this shift, zeta^2 |r|^2, is below the target once x_j has taken this step: last update, then the
+            // shift is frozen (p_j = 0, no further traffic) -- large shifts drop out after a few tens of iterations
+            ms[4 * ns + j] = 0.0; ms[5 * ns + j] = 0.0; ms[ns + j] = 0.0; ms[2 * ns + j] = 0.0;
+            continue;
+        }
         ms[4 * ns + j] = ratio * ratio * beta;
         ms[5 * ns + j] = zp;
         ms[ns + j] = z0;
@@ -886,7 +896,10 @@ __global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ s
     const int j = blockIdx.y;
     double a, bb, z;
     double2 *x, *p;
-    if (j < ns) { a = ms[3 * ns + j]; bb = ms[4 * ns + j]; z = ms[5 * ns + j]; x = ptr[j]; p = ptr[ns + j]; }
+    if (j < ns) {
+        a = ms[3 * ns + j]; bb = ms[4 * ns + j]; z = ms[5 * ns + j]; x = ptr[j]; p = ptr[ns + j];
+        if (a == 0.0 && bb == 0.0 && z == 0.0) return;       // frozen shift
+    }
     else { a = sc[S_ALPHA]; bb = sc[S_BETA]; z = 1.0; x = x0; p = p0; }
     for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
         double2 pv = p[i], xv = x[i];
@@ -1102,6 +1115,22 @@ static int rational_solve(lqcd_op_s* op, lqcd_spinor_s* b, int n, const double* 
     for (int k = 0; k < n; k++) {
         xs[k] = scratch_get(c, op->kind, LQCD_FULL);
         if (!xs[k]) { set_error("rational action: out of device memory"); return LQCD_ERR_HIP; }
+    }
+    if (c->tun.mixed_action_solver && op->kind == LQCD_STAGGERED) {
+        // staggered: D^+D + sigma = (m^2 + sigma) - D_hop^2 is the operator of mass sqrt(m^2 + sigma), so every pole is a plain
+        // mixed-precision solve (fp32 inner CG, fp64 defect correction, true-residual stopping rule) -- the shifted iterates of a
+        // multi-shift CG cost 240 B/site per pole against 2 x 672 for the two Dslashes, so sharing the Krylov space buys little here
+        int total = 0;
+        for (int k = 0; k < n; k++) {
+            lqcd_op_s shifted = *op;        // a view: same links, other mass; nothing is owned
+            shifted.km = std::sqrt(op->km * op->km + poles[k]);
+            LQCHK(lqcd_spinor_zero(xs[k]));
+            int it = 0;
+            LQCHK(lqcd_solve_mixed_cg_DdagD(&shifted, xs[k], b, eps, maxiter, 0.0, &it, nullptr, nullptr));
+            total += it;
+        }
+        if (iters) *iters = total;
+        return LQCD_OK;
     }
     return lqcd_solve_multishift_cg(op, nullptr, xs.data(), b, poles, n, eps, maxiter, iters, nullptr);
 }

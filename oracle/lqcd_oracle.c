@@ -539,6 +539,7 @@ int orc_multishift_cg(int kind, double* x0d, double* xsd, const double* U, const
         for (long i = 0; i < n; i++) p[i] = beta * p[i] + res[i];
         double zmax = 0.0;
         for (int j = 0; j < ns; j++) {
+            if (fabs(z0[j]) < 1e-100) { zp[j] = z0[j]; continue; }   /* converged long ago; frozen before zeta underflows to 0/0 */
             double den = zm[j] * alpha_m * (1.0 + alpha * sigma[j]) + alpha * beta_m * (zm[j] - z0[j]);
             zp[j] = z0[j] * zm[j] * alpha_m / den;
             double aj = (zp[j] / z0[j]) * alpha;
@@ -548,6 +549,7 @@ int orc_multishift_cg(int kind, double* x0d, double* xsd, const double* U, const
             for (long i = 0; i < n; i++) xj[i] += aj * pj[i];
             for (long i = 0; i < n; i++) pj[i] = bj * pj[i] + zp[j] * res[i];
             if (fabs(zp[j]) > zmax) zmax = fabs(zp[j]);
+            if (zp[j] * zp[j] * rrn < eps) zp[j] = 0.0;   /* residual of this shift below the target: frozen from the next iteration on */
         }
         for (int j = 0; j < ns; j++) { zm[j] = z0[j]; z0[j] = zp[j]; }
         alpha_m = alpha; beta_m = beta; rr = rrn;

@@ -556,6 +556,25 @@ def test_multishift_cg_matches_oracle(gpu, orc, kind_name):
         lq.shiftedcg(xs[:1], [-1.0], x0, A, b)
 
 
+def test_multishift_cg_survives_zeta_underflow(gpu, orc):
+    """Shifts that converged hundreds of iterations ago must be frozen before their zeta underflows (0/0 -> NaN in every field)."""
+    lq = gpu
+    L = (4, 4, 4, 4)
+    lat, Uh, Ud, _ = setup(lq, orc, L, lq.STAGGERED, seed=73)
+    D = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Staggered", "mass": 0.01, "boundarycondition": BC, "eps_CG": 1e-22})
+    b_h = host_spinor(orc, lat, lq.STAGGERED, 74)
+    b = lq.Fermionfields(lat, lq.STAGGERED).upload(b_h)
+    sig = [0.0, 1e-4, 30.0, 3000.0]
+    xs = [b.similar() for _ in sig]
+    A = lq.DdagD_operator(D)
+    it, resid = lq.shiftedcg(xs, sig, None, A, b, eps=1e-22, return_info=True)
+    _, oxs, oit, _, st = orc.multishift_cg(orc.STAGGERED, Uh, b_h, L, 0.01, sig, bc=BC, eps=1e-22)
+    assert st == 0 and it > 120 and abs(it - oit) <= 2
+    for x, ox in zip(xs, oxs):
+        xh = x.download()
+        assert np.isfinite(xh).all() and rel_err(xh, ox) < 1e-8
+
+
 def test_c_abi_from_plain_c(gpu, tmp_path):
     """liblqcd_hip.so driven from a plain C program (tests/c_abi_smoke.c): cold plaquette, free-field D, gamma5-hermiticity,
     CG with an independent residual, error path."""

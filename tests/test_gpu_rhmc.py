@@ -44,6 +44,39 @@ def test_rational_action_and_force_match_oracle(lq, orc, nf):
     assert abs(lq.evaluate_FermiAction(fa, U, phi) / lq.dot(xi, xi).real - 1.0) < 1e-9
 
 
+def test_rational_action_with_per_pole_mixed_precision_solves(lq, orc):
+    """Tunable mixed_action_solver: every pole is a mixed-precision solve with the staggered operator of mass sqrt(m^2 + pole)
+    (BASELINE.json configs[4]: RHMC with an fp32 inner / fp64 outer CG); same action and force as the fp64 multi-shift CG."""
+    L = (8, 4, 6, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 831)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": 0.1, "boundarycondition": BC, "eps_CG": 1e-20})
+    fa = lq.FermiAction(D, {"Nf": 3})
+    phih = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 832)
+    phi = lq.Fermionfields(lat, lq.STAGGERED).upload(phih)
+    G = lq.Gaugefields(lat)
+    S0 = lq.evaluate_FermiAction(fa, U, phi)
+    lq.calc_UdSfdU_(G, fa, U, phi)
+    G0 = G.download()
+    lat.set_param("mixed_action_solver", 1)
+    S1 = lq.evaluate_FermiAction(fa, U, phi)
+    lq.calc_UdSfdU_(G, fa, U, phi)
+    lat.set_param("mixed_action_solver", 0)
+    assert abs(S1 - S0) < 1e-9 * abs(S0) and rel_err(G.download(), G0) < 1e-8
+    a0, res, poles = fa.rhmc_action
+    yo, _ = orc.rational_apply(orc.STAGGERED, Uh, phih, L, 0.1, a0, res, poles, 1.0, BC)
+    assert abs(S1 - np.vdot(phih, yo).real) < 1e-9 * abs(S1)
+    # new links in the same handle: the cached fp32 copies must follow
+    Uh2 = orc.hot_gauge(L, 833)
+    U.upload(Uh2)
+    lat.set_param("mixed_action_solver", 1)
+    S2 = lq.evaluate_FermiAction(fa, U, phi)
+    lat.set_param("mixed_action_solver", 0)
+    yo2, _ = orc.rational_apply(orc.STAGGERED, Uh2, phih, L, 0.1, a0, res, poles, 1.0, BC)
+    assert abs(S2 - np.vdot(phih, yo2).real) < 1e-9 * abs(S2)
+
+
 def test_fermion_force_acc_scales_and_accumulates(lq, orc):
     L = (4, 4, 4, 4)
     lat = lq.Lattice(L)

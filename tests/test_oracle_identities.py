@@ -217,6 +217,20 @@ def test_multishift_cg_true_residuals(orc, kind_name):
     assert rel_err(x0, xcg) < 1e-9 and abs(it - itcg) <= 1
 
 
+def test_multishift_cg_survives_zeta_underflow(orc):
+    """A large shift converges within a few iterations and its zeta keeps shrinking geometrically: after a few hundred iterations of the
+    base system it underflows; the recurrences must freeze that shift instead of producing 0/0 (seen at 48^3x96 with 18 poles)."""
+    L = (4, 4, 4, 4)
+    U = orc.hot_gauge(L, 63)
+    b = orc.gaussian_spinor(orc.staggered_shape(L), 64)
+    sig = [0.0, 1e-4, 30.0, 3000.0]
+    x0, xs, it, resid, st = orc.multishift_cg(orc.STAGGERED, U, b, L, 0.01, sig, eps=1e-22)
+    assert st == 0 and it > 120 and all(np.isfinite(x).all() for x in xs) and np.isfinite(x0).all()
+    for s, x in zip(sig, xs):
+        res = orc.staggered_D(U, orc.staggered_D(U, x, L, 0.01), L, 0.01, dagger=True) + s * x - b
+        assert np.vdot(res, res).real < 1e-20, s
+
+
 def _random_hermitian(rng):
     m = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
     return 0.5 * (m + m.conj().T)
