@@ -73,9 +73,9 @@ int lqcd_ctx_destroy(lqcd_ctx_t ctx);
 int lqcd_ctx_sync(lqcd_ctx_t ctx);
 /* tuning knobs (kernel variants); unknown key -> LQCD_ERR_ARG.  Keys: dslash_variant (0 site-per-lane, 1 direction split
  * [default], 2 hop split, 3 persistent), dslash_block, xcd_remap, xcd_nsub, xcd_ysplit, cg_fused (0 reference form, 1, 2 fused
- * [default]), graph (1: hipGraph replay of CG bursts), gauge_recon (18 [default] | 12: the Wilson r = 1 split kernel reads two
- * rows per link and rebuilds the third -- applied only to fields that are unitary to 1e-14, results within the fp64 Dslash
- * tolerance), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge, nt_store,
+ * [default]), graph (1: hipGraph replay of CG bursts), gauge_recon (12 [default]: the split kernels read two rows per link and rebuild the
+ * third -- applied only while every link of the field is unitary to 1e-14, results within the fp64 Dslash tolerance; 18: all
+ * 18 stored reals are always read), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge, nt_store,
  * lds_pad_kb, persist_per_cu, dbg (timing ablations). */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
 int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);

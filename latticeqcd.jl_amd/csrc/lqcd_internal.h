@@ -243,8 +243,9 @@ struct Tunables {
     int halo_tuned_us[2] = {0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
-    int gauge_recon = 18;     // 12: the Wilson dirsplit kernel reads 2 rows per link and rebuilds the third (only for links that
-                              // are unitary to 1e-14; otherwise the 18-real field is used).  Opt-in: bytes/site 960 -> 768.
+    int gauge_recon = 12;     // 12 (default): the direction-split kernels read 2 rows per link and rebuild the third -- only while every
+                              // link of the field is unitary to 1e-14 (checked per gauge version), otherwise the 18 stored reals are
+                              // read; bytes/site 960 -> 768 (Wilson), 672 -> 480 (staggered).  18: always read all 18 reals.
     int recon_active = 0;     // read-only: 1 if the last Wilson operator application used the 12-real links
 };
 

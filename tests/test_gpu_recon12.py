@@ -1,4 +1,4 @@
-"""Opt-in 12-real link compression of the Wilson Dslash (tunable gauge_recon = 12): rows 0 and 1 are read, row 2 is rebuilt as
+"""12-real link compression of the split Dslash kernels (tunable gauge_recon = 12, the default): rows 0 and 1 are read, row 2 is rebuilt as
 conj(row0 x row1).  Used only when every link of the current field is unitary to 1e-14, so the result stays within the
 fp64 Dslash tolerance (1e-13) of the oracle; anything else silently reads the 18-real field."""
 import os
