@@ -106,7 +106,7 @@ static StencilCall call32(lqcd_op_s* op, const Mix32& m, float2* out, float2* in
     StencilCall s;
     s.kind = op->kind;
     s.gauge = (const double2*)m.gauge;
-    s.gauge12 = m.clover ? nullptr : (const double2*)m.gauge12;   // the clover instance of the split kernel reads 18-real links
+    s.gauge12 = (const double2*)m.gauge12;
     s.clover = (const double2*)m.clover;
     for (int p = 0; p < 2; p++) {
         s.out[p] = (double2*)(out + p * m.blk);

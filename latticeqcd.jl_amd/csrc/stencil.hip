@@ -1312,7 +1312,10 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
 #undef LQ_HS
         } else {
             dim3 grid(k.nblocks), block(256);
-            if (k.clover) {
+            if (k.clover && k.gauge12) {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, true>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit<false, true, true>), grid, block, pad, c->stream, k);
+            } else if (k.clover) {
                 if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, true>), grid, block, pad, c->stream, k);
                 else hipLaunchKernelGGL((wilson_dirsplit<false, false, true>), grid, block, pad, c->stream, k);
             } else if (k.gauge12) {
