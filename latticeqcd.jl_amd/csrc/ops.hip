@@ -740,17 +740,32 @@ extern "C" int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     return cg_run(op, x, b, 0.0, niter, true, nullptr, nullptr);
 }
 
+// scratch fields of one call: returned to the context's pool on every exit path
+struct ScratchScope {
+    lqcd_ctx_s* c;
+    std::vector<lqcd_spinor_s*> held;
+    explicit ScratchScope(lqcd_ctx_s* c_) : c(c_) {}
+    ScratchScope(const ScratchScope&) = delete;
+    ScratchScope& operator=(const ScratchScope&) = delete;
+    lqcd_spinor_s* get(int kind, int subset) {
+        lqcd_spinor_s* s = scratch_get(c, kind, subset);
+        if (s) held.push_back(s);
+        return s;
+    }
+    ~ScratchScope() { for (lqcd_spinor_s* s : held) scratch_put(s); }
+};
+
 extern "C" int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
                                    double* final_rr) {
     LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab"));
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
-    lqcd_spinor_s* w[6];
+    ScratchScope pool(c);
     double2* wd[6];
     for (int i = 0; i < 6; i++) {
-        w[i] = scratch_get(c, op->kind, LQCD_FULL);
-        if (!w[i]) return LQCD_ERR_HIP;
-        wd[i] = w[i]->data;
+        lqcd_spinor_s* wi = pool.get(op->kind, LQCD_FULL);
+        if (!wi) return LQCD_ERR_HIP;
+        wd[i] = wi->data;
     }
     // the stencil works on spinor handles; wrap raw pointers of the scratch fields
     lqcd_spinor_s vin = *x, vout = *x;
@@ -759,9 +774,7 @@ extern "C" int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t 
         vout.data = out;
         return op_apply_async(op, &vout, &vin, dagger ? 1 : 0, nullptr);
     };
-    int st = bicgstab_core(c, A, x->elems, x->data, b->data, wd, eps, maxiter, iters, final_rr);
-    for (int i = 0; i < 6; i++) scratch_put(w[i]);
-    return st;
+    return bicgstab_core(c, A, x->elems, x->data, b->data, wd, eps, maxiter, iters, final_rr);
 }
 
 // even-odd (Schur) preconditioned BiCGStab, Wilson:
@@ -792,13 +805,17 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
     const double k = op->km;
     const int dg = dagger ? 1 : 0;
     const size_t nh = x->elems / 2;
-    lqcd_spinor_s* w[6];
+    ScratchScope pool(c);
     double2* wd[6];
-    for (int i = 0; i < 6; i++) { w[i] = scratch_get(c, op->kind, LQCD_EVEN); if (!w[i]) return LQCD_ERR_HIP; wd[i] = w[i]->data; }
-    lqcd_spinor_s* rhs = scratch_get(c, op->kind, LQCD_EVEN);
-    lqcd_spinor_s* te = clov ? scratch_get(c, op->kind, LQCD_EVEN) : nullptr;
-    lqcd_spinor_s* to = scratch_get(c, op->kind, LQCD_ODD);
-    lqcd_spinor_s* uo = clov ? scratch_get(c, op->kind, LQCD_ODD) : nullptr;
+    for (int i = 0; i < 6; i++) {
+        lqcd_spinor_s* wi = pool.get(op->kind, LQCD_EVEN);
+        if (!wi) return LQCD_ERR_HIP;
+        wd[i] = wi->data;
+    }
+    lqcd_spinor_s* rhs = pool.get(op->kind, LQCD_EVEN);
+    lqcd_spinor_s* te = clov ? pool.get(op->kind, LQCD_EVEN) : nullptr;
+    lqcd_spinor_s* to = pool.get(op->kind, LQCD_ODD);
+    lqcd_spinor_s* uo = clov ? pool.get(op->kind, LQCD_ODD) : nullptr;
     if (!rhs || !to || (clov && (!te || !uo))) return LQCD_ERR_HIP;
     // views of the even/odd halves of b and x
     lqcd_spinor_s be = *b, bo = *b, xe = *x, xo = *x;
@@ -848,9 +865,7 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
         return sc;
     };
     st = run();
-    hipError_t e = hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 6; i++) scratch_put(w[i]);
-    scratch_put(rhs); scratch_put(to); scratch_put(te); scratch_put(uo);
+    hipError_t e = hipStreamSynchronize(c->stream);      // before the scratch fields go back to the pool
     if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync bicgstab_eo", __FILE__, __LINE__);
     return st;
 }
