@@ -400,22 +400,29 @@ namespace lqcd {
 // device pointer of the parity block p of a spinor (nullptr if the spinor does not hold that parity)
 // 12-real copy of the links: rows 0 and 1; *maxdev receives max |row2 - conj(row0 x row1)| (as the bit pattern of a
 // non-negative double, which orders like an unsigned integer)
-__global__ void gauge_compress12(Geom g, const double2* __restrict__ src, double2* __restrict__ dst, unsigned long long* maxdev) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * g.Vh * 4) return;
-    const int mu = t & 3, s = t >> 2, p = s / g.Vh, i = s % g.Vh;
-    const size_t so = glink_off(g, p, mu, i), d_o = glink12_off(g, p, mu, i);
-    const int Gs = glink_stride(g);
-    cd u[9];
-    for (int e = 0; e < 9; e++) u[e] = ld(src + so + (size_t)e * Gs);
-    for (int e = 0; e < 6; e++) st(dst + d_o + (size_t)e * 64, u[e]);
+__global__ __launch_bounds__(256) void gauge_compress12(Geom g, const double2* __restrict__ src, double2* __restrict__ dst, unsigned long long* maxdev) {
+    // lane = site (coalesced 1 KiB rows in both layouts), blockIdx.y = (parity, mu); one atomic per wave
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y >> 2, mu = blockIdx.y & 3;
     double dev = 0.0;
-    for (int b = 0; b < 3; b++) {
-        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
-        const cd x = cmul(u[b1], u[3 + b2]) - cmul(u[b2], u[3 + b1]);      // (row0 x row1)_b
-        dev = fmax(dev, fmax(fabs(u[6 + b].re - x.re), fabs(u[6 + b].im + x.im)));
+    if (i < g.Vh) {
+        const size_t so = glink_off(g, p, mu, i), d_o = glink12_off(g, p, mu, i);
+        const int Gs = glink_stride(g);
+        cd u[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) u[e] = ld(src + so + (size_t)e * Gs);
+#pragma unroll
+        for (int e = 0; e < 6; e++) st(dst + d_o + (size_t)e * 64, u[e]);
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+            const cd x = cmul(u[b1], u[3 + b2]) - cmul(u[b2], u[3 + b1]);      // (row0 x row1)_b
+            const double d1 = fabs(u[6 + b].re - x.re), d2 = fabs(u[6 + b].im + x.im);
+            dev = (d1 <= 1e300 && d2 <= 1e300) ? fmax(dev, fmax(d1, d2)) : 1e300;      // NaN / inf links are not unitary
+        }
     }
-    atomicMax(maxdev, (unsigned long long)__double_as_longlong(dev));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_down(dev, off, 64));
+    if ((threadIdx.x & 63) == 0 && dev > 0.0) atomicMax(maxdev, (unsigned long long)__double_as_longlong(dev));
 }
 
 int gauge_ensure_recon12(lqcd_gauge_s* g) {
@@ -425,8 +432,7 @@ int gauge_ensure_recon12(lqcd_gauge_s* g) {
     if (!g->data12) HIPCHK(hipMalloc((void**)&g->data12, gauge12_elems(c->geom) * sizeof(double2)));
     unsigned long long* d_dev = (unsigned long long*)(c->d_scal + SCAL_DOUBLES - 9);
     HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(unsigned long long), c->stream));
-    const int nt = 2 * c->geom.Vh * 4;
-    hipLaunchKernelGGL(gauge_compress12, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, g->data, g->data12, d_dev);
+    hipLaunchKernelGGL(gauge_compress12, dim3((c->geom.Vh + 255) / 256, 8), dim3(256), 0, c->stream, c->geom, g->data, g->data12, d_dev);
     HIPCHK(hipGetLastError());
     unsigned long long bits = 0;
     HIPCHK(hipMemcpyAsync(&bits, d_dev, sizeof(bits), hipMemcpyDeviceToHost, c->stream));

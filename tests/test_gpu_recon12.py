@@ -51,6 +51,12 @@ def test_recon12_dslash_and_cg_match_oracle(lq, orc, L):
     lq.mul_(y, D, x)
     assert lat.get_param("recon_active") == 0
     assert rel_err(y.download(), orc.wilson_D(Uh3, psi, L, KAPPA, 1.0, BC)) < 1e-13
+    # a NaN in a link is "not unitary" as well (the comparison must not let it pass)
+    Uh4 = Uh2.copy()
+    Uh4[1, 0, 1, 0, 1, 2, 2] = np.nan
+    U.upload(Uh4)
+    lq.mul_(y, D, x)
+    assert lat.get_param("recon_active") == 0
     # general r has no split kernel -> no compression
     D2 = lq.Dirac_operator(U.upload(Uh2), None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 0.7, "boundarycondition": BC})
     lq.mul_(y, D2, x)
