@@ -135,7 +135,9 @@ int lqcd_op_destroy(lqcd_op_t op);
 /* Dirac_operator = "WilsonClover", Clover_coefficient (src/system/parameter_structs.jl:125, test/test_wilsonclover.toml:9; the
  * reference rejects the operator, universe.jl:129-131, so this is the textbook definition): D_sw = D + i kappa c_sw sum_{mu<nu}
  * sigma_{mu nu} F_{mu nu}.  The term follows the links of the operator's gauge field; csw = 0 switches it off.  Supported by
- * lqcd_op_apply / _DdagD, the CG, BiCGStab and multi-shift solvers on unpartitioned lattices. */
+ * lqcd_op_apply / _DdagD, the CG, BiCGStab, even-odd BiCGStab (inverse clover blocks), multi-shift and mixed-precision solvers,
+ * also on a partitioned lattice (RCCL ranks; the clover sums are built with two matrix-face exchanges), and by the fermion
+ * force (lqcd_fermion_force / lqcd_calc_UdSfdU add the derivative of the clover term) on an unpartitioned lattice. */
 int lqcd_op_set_clover(lqcd_op_t op, double csw);
 int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g);   /* the D(U) rebind idiom (unusedfiles/measure_chiral_condensate.jl:173) */
 /* mul!(y, D, x) / mul!(y, D', x) on FULL spinors */
