@@ -115,7 +115,7 @@ __device__ __forceinline__ Nbr fwd_neighbour(const FArgs& k, int p, const int (&
     return n;
 }
 
-template <int MU>
+template <int MU, bool ACC>
 __device__ __forceinline__ void wilson_force_site(const FArgs& k, int p, int i, const int (&c)[4]) {
     const Geom& g = k.g;
     const int Vs = sp_stride(g), Gs = glink_stride(g);
@@ -156,11 +156,13 @@ __device__ __forceinline__ void wilson_force_site(const FArgs& k, int p, int i, 
 #pragma unroll
     for (int e = 0; e < 9; e++) {
         cd o = mk(f * C[e].re, f * C[e].im);
-        if (k.acc) { const cd old = ld(k.out + go + (size_t)e * Gs); o = mk(o.re + old.re, o.im + old.im); }
+        if constexpr (ACC) { const cd old = ld(k.out + go + (size_t)e * Gs); o = mk(o.re + old.re, o.im + old.im); }
         st(k.out + go + (size_t)e * Gs, o);
     }
 }
 
+// ACC is a template parameter: as a run-time branch the nine read-modify-write pairs cost 90 VGPRs (occupancy 3 -> 1)
+template <bool ACC>
 __global__ __launch_bounds__(256) void wilson_force_kernel(FArgs k) {
     const Geom& g = k.g;
     const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
@@ -168,13 +170,14 @@ __global__ __launch_bounds__(256) void wilson_force_kernel(FArgs k) {
     int c[4];
     cb_to_coords(g, p, i, c);
     switch (mu) {
-    case 0: wilson_force_site<0>(k, p, i, c); break;
-    case 1: wilson_force_site<1>(k, p, i, c); break;
-    case 2: wilson_force_site<2>(k, p, i, c); break;
-    default: wilson_force_site<3>(k, p, i, c); break;
+    case 0: wilson_force_site<0, ACC>(k, p, i, c); break;
+    case 1: wilson_force_site<1, ACC>(k, p, i, c); break;
+    case 2: wilson_force_site<2, ACC>(k, p, i, c); break;
+    default: wilson_force_site<3, ACC>(k, p, i, c); break;
     }
 }
 
+template <bool ACC>
 __global__ __launch_bounds__(256) void staggered_force_kernel(FArgs k) {
     const Geom& g = k.g;
     const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void staggered_force_kernel(FArgs k) {
 #pragma unroll
     for (int q = 0; q < 9; q++) {
         cd o = mk(f * C[q].re, f * C[q].im);
-        if (k.acc) { const cd old = ld(k.out + go + (size_t)q * Gs); o = mk(o.re + old.re, o.im + old.im); }
+        if constexpr (ACC) { const cd old = ld(k.out + go + (size_t)q * Gs); o = mk(o.re + old.re, o.im + old.im); }
         st(k.out + go + (size_t)q * Gs, o);
     }
 }
@@ -315,8 +318,13 @@ int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_ga
     k.acc = accumulate;
     out->version++;
     const int nb = 2 * c->geom.nch;
-    if (kind == LQCD_WILSON) hipLaunchKernelGGL(wilson_force_kernel, dim3(nb), dim3(256), 0, c->stream, k);
-    else hipLaunchKernelGGL(staggered_force_kernel, dim3(nb), dim3(256), 0, c->stream, k);
+    if (kind == LQCD_WILSON) {
+        if (accumulate) hipLaunchKernelGGL(wilson_force_kernel<true>, dim3(nb), dim3(256), 0, c->stream, k);
+        else hipLaunchKernelGGL(wilson_force_kernel<false>, dim3(nb), dim3(256), 0, c->stream, k);
+    } else {
+        if (accumulate) hipLaunchKernelGGL(staggered_force_kernel<true>, dim3(nb), dim3(256), 0, c->stream, k);
+        else hipLaunchKernelGGL(staggered_force_kernel<false>, dim3(nb), dim3(256), 0, c->stream, k);
+    }
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
