@@ -198,20 +198,20 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
 
 extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     if (!c) return LQCD_OK;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
-    for (lqcd_spinor_s* s : c->scratch) { hipFree(s->data); delete s; }
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (lqcd_spinor_s* s : c->scratch) { (void)hipFree(s->data); delete s; }
     for (int mu = 0; mu < 4; mu++) {
-        hipFree(c->send_fwd[mu]); hipFree(c->recv_bwd[mu]);   // send_bwd / recv_fwd are the second halves of these
-        hipFree(c->force_send[mu]); hipFree(c->force_recv[mu]);
-        hipFree(c->gf_ghost[mu]); hipFree(c->gf_gsend[mu]); hipFree(c->gf_wsend[mu]); hipFree(c->gf_wrecv[mu]);
+        (void)hipFree(c->send_fwd[mu]); (void)hipFree(c->recv_bwd[mu]);   // send_bwd / recv_fwd are the second halves of these
+        (void)hipFree(c->force_send[mu]); (void)hipFree(c->force_recv[mu]);
+        (void)hipFree(c->gf_ghost[mu]); (void)hipFree(c->gf_gsend[mu]); (void)hipFree(c->gf_wsend[mu]); (void)hipFree(c->gf_wrecv[mu]);
     }
-    for (void* b : c->mix_buf) hipFree(b);
-    hipFree(c->clover_q[0]); hipFree(c->clover_q[1]);
+    for (void* b : c->mix_buf) (void)hipFree(b);
+    (void)hipFree(c->clover_q[0]); (void)hipFree(c->clover_q[1]);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
-    hipFree(c->d_partial); hipFree(c->d_scal); hipHostFree(c->h_scal);
-    hipEventDestroy(c->ev_pack); hipEventDestroy(c->ev_comm); hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
-    hipStreamDestroy(c->stream); hipStreamDestroy(c->comm_stream);
+    (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipHostFree(c->h_scal);
+    (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1);
+    (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->comm_stream);
     delete c;
     return LQCD_OK;
 }
@@ -336,7 +336,7 @@ extern "C" int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq) {
     }
     double sum = 0;
     if (st == LQCD_OK) st = plaquette_local_sum(g, ghost, &sum);
-    for (int mu = 0; mu < 4; mu++) { if (ghost[mu]) hipFree(ghost[mu]); if (sendb[mu]) hipFree(sendb[mu]); }
+    for (int mu = 0; mu < 4; mu++) { if (ghost[mu]) (void)hipFree(ghost[mu]); if (sendb[mu]) (void)hipFree(sendb[mu]); }
     if (st != LQCD_OK) return st;
     LQCHK(allreduce_host(c, &sum, 1));
     const double V = (double)c->gL[0] * c->gL[1] * c->gL[2] * c->gL[3];

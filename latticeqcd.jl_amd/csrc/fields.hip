@@ -257,7 +257,7 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
     if (e != hipSuccess) { delete x; return hip_fail(e, "hipMalloc(gauge)", __FILE__, __LINE__); }
     e = hipMemsetAsync(x->data, 0, x->elems * sizeof(double2), ctx->stream);  // stride padding stays zero
-    if (e != hipSuccess) { hipFree(x->data); delete x; return hip_fail(e, "memset(gauge)", __FILE__, __LINE__); }
+    if (e != hipSuccess) { (void)hipFree(x->data); delete x; return hip_fail(e, "memset(gauge)", __FILE__, __LINE__); }
     *g = x;
     return LQCD_OK;
 }
@@ -265,8 +265,8 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
 extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
     if (!g) return LQCD_OK;
     // (no hipSetDevice: the context may already be gone -- finalizers run in any order -- and hipFree does not need it)
-    hipFree(g->data);
-    hipFree(g->data12);
+    (void)hipFree(g->data);
+    (void)hipFree(g->data12);
     delete g;
     return LQCD_OK;
 }
@@ -298,7 +298,7 @@ static int gauge_xfer(lqcd_gauge_t g, double* host, int layout, int to_device, i
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync gauge xfer", __FILE__, __LINE__);
-    hipFree(img);
+    (void)hipFree(img);
     return st;
 }
 
@@ -383,7 +383,7 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
     if (e != hipSuccess) { delete x; return hip_fail(e, "hipMalloc(spinor)", __FILE__, __LINE__); }
     e = hipMemsetAsync(x->data, 0, x->elems * sizeof(double2), ctx->stream);
-    if (e != hipSuccess) { hipFree(x->data); delete x; return hip_fail(e, "memset(spinor)", __FILE__, __LINE__); }
+    if (e != hipSuccess) { (void)hipFree(x->data); delete x; return hip_fail(e, "memset(spinor)", __FILE__, __LINE__); }
     *s = x;
     return LQCD_OK;
 }
@@ -391,7 +391,7 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
 extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
     if (!s) return LQCD_OK;
     // (no hipSetDevice: see lqcd_gauge_destroy)
-    hipFree(s->data);
+    (void)hipFree(s->data);
     delete s;
     return LQCD_OK;
 }
@@ -479,7 +479,7 @@ static int spinor_xfer(lqcd_spinor_t s, double* host, int to_device, int wing = 
     }
     e = hipStreamSynchronize(c->stream);
     if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync spinor xfer", __FILE__, __LINE__);
-    hipFree(img);
+    (void)hipFree(img);
     return st;
 }
 

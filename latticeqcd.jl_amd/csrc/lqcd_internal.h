@@ -385,12 +385,19 @@ enum { B_RHO = 24, B_R0V = 26, B_ALPHA = 28, B_SS = 30, B_TS = 31, B_TT = 33, B_
        B_DONE = 41, B_ITERS = 42, B_EPS = 43, B_HALF = 44, B_RES = 45, B_END = 46 };
 // stencil.hip, once per precision (p64 is the inline namespace everywhere except in the fp32 build of stencil.hip).
 // With prec = 1 the field pointers of a StencilCall address float2 data (cast), scalars stay double.
-namespace p64 {
+#ifdef LQCD_F32      // reopen each namespace the way it was declared at the top of this header
+#define LQCD_REOPEN_P64 namespace p64
+#define LQCD_REOPEN_P32 inline namespace p32
+#else
+#define LQCD_REOPEN_P64 inline namespace p64
+#define LQCD_REOPEN_P32 namespace p32
+#endif
+LQCD_REOPEN_P64 {
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);
 }
-namespace p32 {
+LQCD_REOPEN_P32 {
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s);
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s);

@@ -1309,9 +1309,9 @@ extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int
     int st = cg_setup(op, x, b, w, -1.0, &rr);
     for (int i = 0; i < warm && st == LQCD_OK; i++) st = cg_enqueue_iteration(op, x, w);
     if (st == LQCD_OK) {
-        hipEventRecord(c->ev_t0, c->stream);
+        (void)hipEventRecord(c->ev_t0, c->stream);
         for (int i = 0; i < niter && st == LQCD_OK; i++) st = cg_enqueue_iteration(op, x, w);
-        hipEventRecord(c->ev_t1, c->stream);
+        (void)hipEventRecord(c->ev_t1, c->stream);
         hipError_t e = hipEventSynchronize(c->ev_t1);
         float t = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&t, c->ev_t0, c->ev_t1);
@@ -1432,7 +1432,7 @@ extern "C" int lqcd_mdom_plaquette(int n, lqcd_gauge_t* g, double* plaq) {
         st = plaquette_local_sum(g[r], gp, &s);
         total += s;
     }
-    for (int r = 0; r < n; r++) for (int mu = 0; mu < 4; mu++) if (ghost[r][mu]) hipFree(ghost[r][mu]);
+    for (int r = 0; r < n; r++) for (int mu = 0; mu < 4; mu++) if (ghost[r][mu]) (void)hipFree(ghost[r][mu]);
     if (st != LQCD_OK) return st;
     lqcd_ctx_s* c0 = g[0]->ctx;
     const double V = (double)c0->gL[0] * c0->gL[1] * c0->gL[2] * c0->gL[3];
@@ -1453,7 +1453,7 @@ extern "C" int lqcd_mdom_solve_cg_DdagD(int n, lqcd_op_t* ops, lqcd_spinor_t* x,
         if (!(r[k] && p[k] && q[k] && tmp[k])) return LQCD_ERR_HIP;
     }
     auto release = [&]() { for (int k = 0; k < n; k++) { scratch_put(r[k]); scratch_put(p[k]); scratch_put(q[k]); scratch_put(tmp[k]); } };
-    auto sync_all = [&]() { for (int k = 0; k < n; k++) hipStreamSynchronize(ops[k]->ctx->stream); };
+    auto sync_all = [&]() { for (int k = 0; k < n; k++) (void)hipStreamSynchronize(ops[k]->ctx->stream); };
     int st = lqcd_mdom_op_apply(n, ops, tmp.data(), x, 0);
     if (st == LQCD_OK) st = lqcd_mdom_op_apply(n, ops, q.data(), tmp.data(), 1);
     for (int k = 0; k < n && st == LQCD_OK; k++) {
