@@ -208,6 +208,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     }
     for (void* b : c->mix_buf) (void)hipFree(b);
     (void)hipFree(c->clover_q[0]); (void)hipFree(c->clover_q[1]);
+    (void)hipFree(c->clover_ext); (void)hipFree(c->clover_ext_buf[0]); (void)hipFree(c->clover_ext_buf[1]);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipHostFree(c->h_scal);
     (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1);

@@ -571,9 +571,90 @@ __device__ __forceinline__ void horner(cd (&T)[9], const cd (&R)[9], const cd (&
     for (int e = 0; e < 9; e++) T[e] = o[e];
 }
 
+// ---- partitioned lattice: the gather above reaches z+rho+-nu, i.e. corners of the neighbouring ranks.  The links and the Lambda
+// matrices are copied into one halo-extended block ext[m][9][E0*E1*E2*E3] (m = 0..3 links, 4..9 planes; extents E = L + 2,
+// local site x at x + 1) whose depth-1 halos are filled direction by direction: the boundary layers exchanged for direction d span
+// the full extended cross-section, so they carry the halos of the directions done before -- corners arrive without a corner
+// message.  Unpartitioned directions take the same pack / unpack with a device copy instead of a message.  Once per MD step.
+struct ExtGeom {
+    int L[4], E[4];
+    size_t n;          // E0 E1 E2 E3
+};
+__host__ __device__ inline size_t ext_site(const ExtGeom& eg, const int (&c)[4]) {      // c = local coordinates in [-1, L]
+    return (size_t)(c[0] + 1) + (size_t)eg.E[0] * ((size_t)(c[1] + 1) + (size_t)eg.E[1] * ((size_t)(c[2] + 1) + (size_t)eg.E[2] * (size_t)(c[3] + 1)));
+}
+__global__ __launch_bounds__(64) void clover_ext_fill_kernel(Geom g, ExtGeom eg, const double2* __restrict__ U, const double2* __restrict__ lam,
+                                                              double2* __restrict__ ext) {
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (i >= g.Vh) return;
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    const size_t e = ext_site(eg, c);
+    const int Gs = glink_stride(g);
+    for (int m = 0; m < 10; m++) {
+        const double2* src = m < 4 ? U + glink_off(g, p, m, i) : lam + lambda_off(g, p, i, m - 4);
+        const int st_ = m < 4 ? Gs : 64;
+#pragma unroll
+        for (int q = 0; q < 9; q++) st(ext + ((size_t)m * 9 + q) * eg.n + e, ld(src + (size_t)q * st_));
+    }
+}
+// cross-section index f of direction d <-> extended coordinates (the other three run over their full extended range)
+__device__ __forceinline__ size_t ext_face_site(const ExtGeom& eg, int d, size_t f, int layer) {
+    int e[4];
+    for (int k = 0; k < 4; k++) {
+        if (k == d) { e[k] = layer; continue; }
+        e[k] = (int)(f % (size_t)eg.E[k]);
+        f /= (size_t)eg.E[k];
+    }
+    return (size_t)e[0] + (size_t)eg.E[0] * ((size_t)e[1] + (size_t)eg.E[1] * ((size_t)e[2] + (size_t)eg.E[2] * (size_t)e[3]));
+}
+// pack = true: buf[side][m*9+q][f] <- ext at layer (side 0: e_d = 1, the lower boundary layer; side 1: e_d = L_d, the upper one)
+// pack = false: ext at halo layer (side 0: e_d = 0 ; side 1: e_d = L_d + 1) <- buf[side]
+__global__ __launch_bounds__(256) void clover_ext_face_kernel(ExtGeom eg, int d, size_t F, double2* __restrict__ ext, double2* __restrict__ buf, int pack) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int side = blockIdx.y;
+    if (f >= F) return;
+    const int layer = pack ? (side ? eg.L[d] : 1) : (side ? eg.L[d] + 1 : 0);
+    const size_t e = ext_face_site(eg, d, f, layer);
+    double2* b = buf + (size_t)side * 90 * F + f;
+    for (int j = 0; j < 90; j++) {
+        if (pack) st(b + (size_t)j * F, ld(ext + (size_t)j * eg.n + e));
+        else st(ext + (size_t)j * eg.n + e, ld(b + (size_t)j * F));
+    }
+}
+
+// sources of the gather: the local fields (periodic wrap) or the extended block (no wrap)
+struct ForceSrc {
+    const double2* U;
+    const double2* lam;
+    const double2* ext;
+    ExtGeom eg;
+};
+template <bool EXT>
+__device__ __forceinline__ void fstep(int (&d)[4], const Geom& g, int mu, int dir) {
+    if constexpr (EXT) d[mu] += dir;
+    else step(d, g, mu, dir);
+}
+template <bool EXT>
+__device__ __forceinline__ void get_link(cd (&u)[9], const ForceSrc& s, const Geom& g, const int (&c)[4], int mu) {
+    if constexpr (EXT) {
+        const double2* b = s.ext + (size_t)mu * 9 * s.eg.n + ext_site(s.eg, c);
+#pragma unroll
+        for (int e = 0; e < 9; e++) u[e] = ld(b + (size_t)e * s.eg.n);
+    } else ldm(u, s.U, g, c, mu);
+}
+template <bool EXT>
+__device__ __forceinline__ void get_lam(cd (&l)[9], const ForceSrc& s, const Geom& g, const int (&c)[4], int plane) {
+    if constexpr (EXT) {
+        const double2* b = s.ext + (size_t)(4 + plane) * 9 * s.eg.n + ext_site(s.eg, c);
+#pragma unroll
+        for (int e = 0; e < 9; e++) l[e] = ld(b + (size_t)e * s.eg.n);
+    } else ldlam(l, s.lam, g, c, plane);
+}
+
 // one thread per link: blockDim = 256 = 64 sites x 4 directions
-__global__ __launch_bounds__(256) void clover_force_kernel(Geom g, const double2* __restrict__ U, const double2* __restrict__ lam,
-                                                            double2* __restrict__ out, double cf, double scale, int acc) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void clover_force_kernel(Geom g, ForceSrc src, double2* __restrict__ out, double cf, double scale, int acc) {
     const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), rho = threadIdx.x >> 6;
     if (i >= g.Vh) return;
     int z[4];
@@ -582,35 +663,35 @@ __global__ __launch_bounds__(256) void clover_force_kernel(Geom g, const double2
 #pragma unroll
     for (int e = 0; e < 9; e++) { Wp[e] = mk(0.0, 0.0); Wm[e] = mk(0.0, 0.0); }
     int zr[4] = {z[0], z[1], z[2], z[3]};
-    step(zr, g, rho, 1);                                   // c1 = z + rho
+    fstep<EXT>(zr, g, rho, 1);                                   // c1 = z + rho
     for (int nu = 0; nu < 4; nu++) {
         if (nu == rho) continue;
         const int mu0 = rho < nu ? rho : nu, nu0 = rho < nu ? nu : rho;
         const int plane = mu0 == 0 ? nu0 - 1 : (mu0 == 1 ? nu0 + 1 : 5);      // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
         for (int sd = 1; sd >= -1; sd -= 2) {
             int c2[4] = {zr[0], zr[1], zr[2], zr[3]}, c3[4] = {z[0], z[1], z[2], z[3]};
-            step(c2, g, nu, sd);                           // z + rho + s nu
-            step(c3, g, nu, sd);                           // z + s nu
+            fstep<EXT>(c2, g, nu, sd);                           // z + rho + s nu
+            fstep<EXT>(c3, g, nu, sd);                           // z + s nu
             cd A[9], B[9], L[9], T[9], P[9], Q[9];
-            if (sd > 0) ldm(A, U, g, zr, nu);              // A: z+rho -> z+rho+s nu
-            else { ldm(A, U, g, c2, nu); dag9(A); }
-            ldlam(L, lam, g, zr, plane);
+            if (sd > 0) get_link<EXT>(A, src, g, zr, nu);              // A: z+rho -> z+rho+s nu
+            else { get_link<EXT>(A, src, g, c2, nu); dag9(A); }
+            get_lam<EXT>(L, src, g, zr, plane);
             mmx<false, false>(T, L, A);                    // Lambda(c1) A
-            ldlam(L, lam, g, c2, plane);
+            get_lam<EXT>(L, src, g, c2, plane);
             mmx<false, false>(Q, A, L);                    // A Lambda(c2)
 #pragma unroll
             for (int e = 0; e < 9; e++) T[e] = mk(T[e].re + Q[e].re, T[e].im + Q[e].im);
-            ldm(B, U, g, c3, rho);                         // B: z+rho+s nu -> z+s nu  = U_rho(z + s nu)^+
+            get_link<EXT>(B, src, g, c3, rho);                         // B: z+rho+s nu -> z+s nu  = U_rho(z + s nu)^+
             dag9(B);
             mmx<false, false>(P, A, B);                    // A B
-            ldlam(L, lam, g, c3, plane);
+            get_lam<EXT>(L, src, g, c3, plane);
             horner(T, B, P, L);                            // (..) B + A B Lambda(c3)
-            if (sd > 0) { ldm(B, U, g, z, nu); dag9(B); }  // C: z+s nu -> z
-            else ldm(B, U, g, c3, nu);
+            if (sd > 0) { get_link<EXT>(B, src, g, z, nu); dag9(B); }  // C: z+s nu -> z
+            else get_link<EXT>(B, src, g, c3, nu);
             mmx<false, false>(Q, P, B);                    // A B C
-            ldlam(L, lam, g, z, plane);
+            get_lam<EXT>(L, src, g, z, plane);
             horner(T, B, Q, L);                            // (..) C + A B C Lambda(c0)
-            ldm(A, U, g, z, rho);
+            get_link<EXT>(A, src, g, z, rho);
             mmx<false, false>(Q, A, T);                    // W = U (..)
             const int o = sd * (rho < nu ? 1 : -1);
 #pragma unroll
@@ -659,6 +740,59 @@ static int sigma_table(SigmaTab& tb) {
     return LQCD_OK;
 }
 
+// halo-extended copy of the links and the Lambda matrices (partitioned lattice)
+static int clover_ext_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, const double2* lam, ExtGeom& eg) {
+    for (int k = 0; k < 4; k++) { eg.L[k] = c->geom.L[k]; eg.E[k] = c->geom.L[k] + 2; }
+    eg.n = (size_t)eg.E[0] * eg.E[1] * eg.E[2] * eg.E[3];
+    size_t Fmax = 0;
+    for (int d = 0; d < 4; d++) Fmax = std::max(Fmax, eg.n / (size_t)eg.E[d]);
+    const size_t ext_bytes = 90 * eg.n * sizeof(double2), buf_bytes = 2 * 90 * Fmax * sizeof(double2);
+    if (c->clover_ext_bytes < ext_bytes) {
+        (void)hipFree(c->clover_ext);
+        c->clover_ext = nullptr; c->clover_ext_bytes = 0;
+        HIPCHK(hipMalloc((void**)&c->clover_ext, ext_bytes));
+        c->clover_ext_bytes = ext_bytes;
+    }
+    for (int j = 0; j < 2; j++)
+        if (c->clover_ext_buf_bytes[j] < buf_bytes) {
+            (void)hipFree(c->clover_ext_buf[j]);
+            c->clover_ext_buf[j] = nullptr; c->clover_ext_buf_bytes[j] = 0;
+            HIPCHK(hipMalloc((void**)&c->clover_ext_buf[j], buf_bytes));
+            c->clover_ext_buf_bytes[j] = buf_bytes;
+        }
+    double2* ext = c->clover_ext;
+    double2 *sendb = c->clover_ext_buf[0], *recvb = c->clover_ext_buf[1];
+    hipLaunchKernelGGL(clover_ext_fill_kernel, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, c->geom, eg, U->data, lam, ext);
+    HIPCHK(hipGetLastError());
+    for (int d = 0; d < 4; d++) {
+        const size_t F = eg.n / (size_t)eg.E[d];
+        const dim3 grid((unsigned)((F + 255) / 256), 2);
+        hipLaunchKernelGGL(clover_ext_face_kernel, grid, dim3(256), 0, c->stream, eg, d, F, ext, sendb, 1);
+        HIPCHK(hipGetLastError());
+        double2* src = sendb;
+        if (c->geom.part[d]) {
+            // my lower boundary layer (side 0) is the -d neighbour's upper halo (side 1), my upper layer its +d neighbour's lower halo
+            ARGCHK(c->has_comm, "clover force: communicator not initialised (call lqcd_ctx_comm_init)");
+            const size_t nd = 90 * F * 2;     // doubles per side
+            NCCLCHK(ncclGroupStart());
+            NCCLCHK(ncclSend(sendb, nd, ncclDouble, c->nbr_bwd[d], c->comm_red, c->stream));
+            NCCLCHK(ncclSend(sendb + 90 * F, nd, ncclDouble, c->nbr_fwd[d], c->comm_red, c->stream));
+            NCCLCHK(ncclRecv(recvb + 90 * F, nd, ncclDouble, c->nbr_fwd[d], c->comm_red, c->stream));   // their lower layer -> my upper halo
+            NCCLCHK(ncclRecv(recvb, nd, ncclDouble, c->nbr_bwd[d], c->comm_red, c->stream));            // their upper layer -> my lower halo
+            NCCLCHK(ncclGroupEnd());
+            src = recvb;
+        } else {
+            // periodic wrap on this rank: lower halo <- own upper layer, upper halo <- own lower layer
+            HIPCHK(hipMemcpyAsync(recvb, sendb + 90 * F, 90 * F * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(recvb + 90 * F, sendb, 90 * F * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+            src = recvb;
+        }
+        hipLaunchKernelGGL(clover_ext_face_kernel, grid, dim3(256), 0, c->stream, eg, d, F, ext, src, 0);
+        HIPCHK(hipGetLastError());
+    }
+    return LQCD_OK;
+}
+
 // out = (accumulate ? out : 0) + scale * (clover part of "U dS_f/dU"); lam = scratch of clover_lambda_elems() elements
 int clover_force(lqcd_ctx_s* c, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double2* lam, double kappa,
                  double csw, double scale, int accumulate) {
@@ -668,8 +802,19 @@ int clover_force(lqcd_ctx_s* c, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_s
                        spinor_block(Y, 0), spinor_block(Y, 1), lam, tb);
     HIPCHK(hipGetLastError());
     out->version++;
-    hipLaunchKernelGGL(clover_force_kernel, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, U->data, lam, out->data,
-                       kappa * csw / 8.0, scale, accumulate);
+    ForceSrc src;
+    src.U = U->data; src.lam = lam; src.ext = nullptr;
+    src.eg = ExtGeom();
+    if (any_partitioned(c) || c->tun.clover_transport) {
+        ARGCHK(c->local_peers.empty(), "clover force: not available on an in-process PE grid");
+        LQCHK(clover_ext_build(c, U, lam, src.eg));
+        src.ext = c->clover_ext;
+        hipLaunchKernelGGL(clover_force_kernel<true>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, src, out->data, kappa * csw / 8.0, scale,
+                           accumulate);
+    } else {
+        hipLaunchKernelGGL(clover_force_kernel<false>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, src, out->data, kappa * csw / 8.0, scale,
+                           accumulate);
+    }
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }

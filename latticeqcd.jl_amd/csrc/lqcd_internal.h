@@ -271,6 +271,10 @@ struct lqcd_ctx_s {
     // staple-force halos (md.hip): forward ghost links (+ their send buffer) and the lower-staple faces, allocated on first use
     double2* gf_ghost[4] = {}, *gf_gsend[4] = {}, *gf_wsend[4] = {}, *gf_wrecv[4] = {};
     double2* clover_q[2] = {};          // clover sums / transport ping-pong, six 3x3 matrices per site (clover.hip)
+    double2* clover_ext = nullptr;      // halo-extended links + Lambda matrices of the partitioned clover force, and its face buffers
+    size_t clover_ext_bytes = 0;
+    double2* clover_ext_buf[2] = {};
+    size_t clover_ext_buf_bytes[2] = {};
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
     const void* mix_gauge_of = nullptr;  // gauge handle / version the fp32 link copies in mix_buf[0], mix_buf[5] were made from
     uint64_t mix_gauge_version = 0;

@@ -1064,10 +1064,6 @@ extern "C" int lqcd_fermion_force_acc(lqcd_op_t op, lqcd_gauge_t out, lqcd_spino
     ARGCHK(out && out->ctx == op->ctx && out != op->gauge, "lqcd_fermion_force: out must be a gauge-shaped field of the same context, not the operator's links");
     LQCHK(force_check(op, "lqcd_fermion_force"));
     lqcd_ctx_s* c = op->ctx;
-    if (op->csw != 0.0 && any_partitioned(c)) {
-        set_error("lqcd_fermion_force: the derivative of the clover term is not available on a partitioned lattice yet");
-        return LQCD_ERR_UNSUPPORTED;
-    }
     HIPCHK(hipSetDevice(c->device));
     apply_bc(c, op->bc);
     if (any_partitioned(c)) {   // one exchange step: lower-face X, Y -> the -mu neighbours

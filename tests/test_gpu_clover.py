@@ -104,16 +104,23 @@ def test_clover_sums_by_plaquette_transport_equal_the_direct_leaves(lq, orc):
     x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
     y = x.similar()
     lat.set_param("clover_transport", 1)
-    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": CSW, "boundarycondition": BC})
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": CSW, "boundarycondition": BC,
+                                    "eps_CG": 1e-22})
     lq.mul_(y, D, x)
-    ref = orc.wilson_clover_D(Uh, orc.clover_build(Uh, L, KAPPA, CSW), psi, L, KAPPA, 1.0, BC)
+    A = orc.clover_build(Uh, L, KAPPA, CSW)
+    ref = orc.wilson_clover_D(Uh, A, psi, L, KAPPA, 1.0, BC)
     assert rel_err(y.download(), ref) < 1e-13
+    # the same tunable sends the clover force through the halo-extended block (the partitioned path; halos by local wrap here)
+    G = lq.Gaugefields(lat)
+    lq.calc_UdSfdU_(G, lq.FermiAction(D), U, x)
+    _, Go, _, _ = orc.clover_fermion_force(Uh, A, psi, L, KAPPA, CSW, 1.0, BC, eps=1e-22)
+    assert rel_err(G.download(), Go) < 1e-9
 
 
 def test_rccl_self_partition_clover(lq, orc):
     """Wilson-clover on a partitioned lattice (BASELINE.json configs[3]): LQCD_FORCE_PARTITION + world-size-1 RCCL communicators run the
     link-ghost exchange, the two matrix-face exchanges of the clover sums and the halo'ed Dslash with the fused clover epilogue exactly
-    as at N > 1; operator, CG, even-odd BiCGStab and the mixed-precision CG must equal the oracle."""
+    as at N > 1; operator, CG, even-odd BiCGStab, the mixed-precision CG and the fermion force must equal the oracle."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent("""
         import os, sys, numpy as np
@@ -145,11 +152,11 @@ def test_rccl_self_partition_clover(lq, orc):
         lq.solve_DinvX_(sol, D, x)
         xe, _, _, st = orc.wilson_clover_bicgstab_eo(Uh, A, psi, L, K, 1.0, BC, False, eps=1e-19)
         assert st == 0 and rel(sol.download(), xe) < 1e-9
-        try:
-            lq.calc_UdSfdU_(lq.Gaugefields(lat), lq.FermiAction(D), U, x)
-            raise SystemExit("the clover force must be refused on a partitioned lattice")
-        except lq.LQCDError:
-            pass
+        D.eps_CG = 1e-22
+        G = lq.Gaugefields(lat)
+        lq.calc_UdSfdU_(G, lq.FermiAction(D), U, x)                 # hopping force with its X, Y face exchange + clover force through
+        _, Go, _, _ = orc.clover_fermion_force(Uh, A, psi, L, K, CSW, 1.0, BC, eps=1e-22)       # the halo-extended links / Lambda block
+        assert rel(G.download(), Go) < 1e-9
         print("RCCL_SELF_CLOVER_OK")
     """)
     for mask in ("8", "14", "15"):

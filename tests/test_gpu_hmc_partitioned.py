@@ -78,3 +78,58 @@ def test_md_trajectory_on_four_domains_equals_one_domain(lq, orc):
         assert rel_err(U.download(), view(U1, lat, 1)) < 1e-10
         assert rel_err(p.download(), view(P1, lat, 1)) < 1e-9
     assert abs((H1 - H0) - dH1) < 1e-7          # the same energy change (the start is not thermalised, so it is not small)
+
+
+def test_wilson_clover_md_trajectory_self_partitioned_equals_one_domain(lq, orc, tmp_path):
+    """BASELINE.json configs[3] in small: a 2-flavour Wilson-clover MD trajectory on a partitioned lattice (LQCD_FORCE_PARTITION = y,z,t
+    with world-size-1 RCCL communicators: Dslash halos, clover sums by transport, X/Y faces of the hopping force, the halo-extended
+    block of the clover force, ghost links and staple faces of the gauge force) against the same trajectory on one domain."""
+    import os, subprocess, sys, textwrap
+    L, dtau, nsteps, csw = (8, 4, 6, 8), 0.05, 3, 1.0
+    Uh = orc.unit_gauge(L)
+    Uh = orc.link_update(Uh, 0.3 * orc.gaussian_momenta(L, 911), 1.0, L)
+    xi_h = orc.gaussian_spinor(orc.wilson_shape(L), 912) * np.sqrt(0.5)
+    np.save(tmp_path / "U.npy", Uh)
+    np.save(tmp_path / "xi.npy", xi_h)
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        d, L, dtau, nsteps, csw = sys.argv[1], (8, 4, 6, 8), 0.05, 3, 1.0
+        Uh, xi_h = np.load(d + "/U.npy"), np.load(d + "/xi.npy")
+        lat = lq.Lattice(L)
+        if os.environ.get("LQCD_FORCE_PARTITION"):
+            lat.comm_init(lq.comm_unique_id())
+        U = lq.Gaugefields(lat).upload(Uh)
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": 0.141139, "Clover_coefficient": csw,
+                                        "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-22})
+        fa = lq.FermiAction(D)
+        p, G = lq.Gaugefields(lat), lq.Gaugefields(lat)
+        lq.gauss_distribution_(p, 913)
+        xi = lq.Fermionfields(lat, lq.WILSON).upload(xi_h)
+        eta = xi.similar()
+        lq.sample_pseudofermions_(eta, U, fa, xi)
+        H0 = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, 5.7) + lq.dot(xi, xi).real
+        for _ in range(nsteps):
+            lq.U_update_(U, p, 0.5 * dtau)
+            lq.P_update_(U, p, dtau, 5.7)
+            lq.calc_UdSfdU_(G, fa, U, eta)
+            lq.Traceless_antihermitian_add_(p, dtau, G)
+            lq.U_update_(U, p, 0.5 * dtau)
+        H1 = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, 5.7) + lq.evaluate_FermiAction(fa, U, eta)
+        np.save(d + "/out_" + sys.argv[2] + ".npy", np.concatenate([U.download().ravel(), p.download().ravel(), [H1 - H0]]))
+        print("TRAJ_OK")
+    """)
+    res = {}
+    for tag, mask in (("single", None), ("part", "14")):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("LQCD_FORCE_PARTITION", None)
+        if mask:
+            env["LQCD_FORCE_PARTITION"] = mask
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path), tag], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "TRAJ_OK" in r.stdout, (tag, r.stdout[-2000:], r.stderr[-3000:])
+        res[tag] = np.load(tmp_path / ("out_%s.npy" % tag))
+    a, b = res["single"], res["part"]
+    assert np.abs(a[:-1] - b[:-1]).max() < 1e-9 * np.abs(a[:-1]).max()
+    assert abs(a[-1] - b[-1]) < 1e-7 and np.isfinite(a[-1])
