@@ -10,7 +10,7 @@ KAPPA, CSW = 0.141139, 1.5612
 BC = (1, 1, 1, -1)
 
 
-@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2)])
+@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2), (6, 6, 4, 2)])       # the last one: a partially filled chunk
 def test_wilson_clover_matches_oracle(lq, orc, L):
     assert lq.lib.device_count() > 0
     lat = lq.Lattice(L)
@@ -94,9 +94,9 @@ def test_clover_coefficient_zero_is_wilson(lq, orc):
     assert np.array_equal(y.download(), z.download())
 
 
-def test_clover_sums_by_plaquette_transport_equal_the_direct_leaves(lq, orc):
+@pytest.mark.parametrize("L", [(8, 4, 6, 4), (6, 6, 4, 2)])
+def test_clover_sums_by_plaquette_transport_equal_the_direct_leaves(lq, orc, L):
     """The partitioned build (plaquettes + two backward transports) run on an unpartitioned lattice (tunable clover_transport)."""
-    L = (8, 4, 6, 4)
     lat = lq.Lattice(L)
     Uh = orc.hot_gauge(L, 506)
     U = lq.Gaugefields(lat).upload(Uh)

@@ -47,7 +47,7 @@ def test_rational_action_and_force_match_oracle(lq, orc, nf):
 def test_rational_action_with_per_pole_mixed_precision_solves(lq, orc):
     """Tunable mixed_action_solver: every pole is a mixed-precision solve with the staggered operator of mass sqrt(m^2 + pole)
     (BASELINE.json configs[4]: RHMC with an fp32 inner / fp64 outer CG); same action and force as the fp64 multi-shift CG."""
-    L = (8, 4, 6, 4)
+    L = (6, 6, 4, 2)          # a partially filled chunk
     lat = lq.Lattice(L)
     Uh = orc.hot_gauge(L, 831)
     U = lq.Gaugefields(lat).upload(Uh)
