@@ -153,6 +153,12 @@ int lqcd_op_hop(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger);
  * parameter_structs.jl:174-175).  x holds the initial guess on entry.  iters/final_rr may be NULL. */
 int lqcd_solve_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, int* iters,
                         double* final_rr);                       /* solve_DinvX!(y, DdagD, x) -> cg (AbstractMD.jl:129 via calc_UdSfdU!) */
+/* staggered only: the parity block (D^+D)_pp = m^2 - H_pq H_qp of the block-diagonal D^+D, solved for the parity-p (0 even, 1 odd)
+ * halves of the FULL fields x and b with half-lattice vectors; the other half of x is not touched.  The solve behind the
+ * reference's 4-taste staggered action (pseudofermion on the even sites, test/test_staggered.toml); lqcd_fermi_action and
+ * lqcd_calc_UdSfdU take it by themselves when the odd half of eta is exactly zero (tunable staggered_parity_solve). */
+int lqcd_solve_cg_DdagD_parity(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int parity, double eps, int maxiter, int* iters,
+                               double* final_rr);
 int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,
                         int* iters, double* final_rr);           /* solve_DinvX!(y, D | D', x) (standardHMC.jl:71) */
 int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,

@@ -241,6 +241,8 @@ struct Tunables {
                                // 1 = pack -> exchange -> exterior in order on the compute stream, interior on the second stream
                                // (no queue hop on the message path; pays when the exchange is the longer leg); -1 = time both once
     int halo_tuned_us[2] = {0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
+    int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
+                                     // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
     int gauge_recon = 12;     // 12 (default): the direction-split kernels read 2 rows per link and rebuild the third -- only while every

@@ -755,6 +755,89 @@ struct ScratchScope {
     ~ScratchScope() { for (lqcd_spinor_s* s : held) scratch_put(s); }
 };
 
+// CG with device-resident scalars for a Hermitian positive operator given as an enqueue function (reference form:
+// alpha = rr / <p, A p>); x holds the initial guess, work = three fields of n elements.  Used where the fused full-lattice
+// iteration of cg_run does not apply (parity blocks).
+static int cg_generic(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* r, double2* p, double2* q, double eps,
+                      int maxiter, int* iters, double* final_rr) {
+    LQCHK(A(q, x));
+    HIPCHK(hipMemcpyAsync(r, b, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, q, r, n));
+    HIPCHK(hipMemcpyAsync(p, r, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    double rr = 0;
+    LQCHK(blas_norm2(c, r, n, &rr, true));
+    double init[9] = {rr, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
+    HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int it = 0;
+    bool converged = rr < eps;
+    const int nb = stream_grid(c, n), check_every = 8;
+    while (!converged && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        for (int k = 0; k < burst; k++) {
+            LQCHK(A(q, p));
+            hipLaunchKernelGGL(redot_partial_kernel, dim3(nb), dim3(UB), 0, c->stream, p, q, n, c->d_partial);
+            HIPCHK(hipGetLastError());
+            LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+            hipLaunchKernelGGL(cg_scalar_alpha, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+            hipLaunchKernelGGL(cg_update_xr, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, x, r, p, q, n, c->d_partial);
+            HIPCHK(hipGetLastError());
+            LQCHK(reduce_to_slot(c, nb, 1, S_RRNEW, true));
+            hipLaunchKernelGGL(cg_scalar_beta, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+            hipLaunchKernelGGL(cg_update_p, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, p, r, n);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rr = c->h_scal[0];
+        it = (int)c->h_scal[S_ITERS - S_RR];
+        if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
+        if (!std::isfinite(rr)) { set_error("CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
+    }
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (!converged) {
+        set_error("The CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}
+
+// Staggered D^+D = m^2 - H^2 is block diagonal in parity: (D^+D)_pp = m^2 - H_pq H_qp.  Solves that block for the parity-p halves of
+// the FULL fields x (initial guess / solution) and b with half-lattice vectors -- one Dslash-equivalent per iteration instead of
+// two.  The other parity of x is not touched.  This is the solve behind the reference's "4 tastes" (Nf = 4) staggered action, whose
+// pseudofermion lives on the even sites (test/test_staggered.toml).
+extern "C" int lqcd_solve_cg_DdagD_parity(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int parity, double eps, int maxiter, int* iters,
+                                          double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_cg_DdagD_parity"));
+    ARGCHK(op->kind == LQCD_STAGGERED && (parity == 0 || parity == 1) && maxiter >= 0,
+           "lqcd_solve_cg_DdagD_parity: staggered operators only, parity 0 (even) or 1 (odd)");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    apply_bc(c, op->bc);
+    const size_t nh = x->elems / 2;
+    const int mine = parity ? LQCD_ODD : LQCD_EVEN, other = parity ? LQCD_EVEN : LQCD_ODD;
+    ScratchScope pool(c);
+    lqcd_spinor_s *r = pool.get(op->kind, mine), *p = pool.get(op->kind, mine), *q = pool.get(op->kind, mine), *t = pool.get(op->kind, other);
+    if (!(r && p && q && t)) return LQCD_ERR_HIP;
+    lqcd_spinor_s xv = *x, bv = *b;
+    xv.subset = bv.subset = mine;
+    xv.elems = bv.elems = nh;
+    xv.data = x->data + (size_t)parity * nh;
+    bv.data = b->data + (size_t)parity * nh;
+    lqcd_spinor_s vin = xv, vout = xv;
+    const double m2 = op->km * op->km;
+    ApplyFn A = [&](double2* out, const double2* in) -> int {
+        vin.data = const_cast<double2*>(in);
+        vout.data = out;
+        StencilCall s1 = make_hop_call(op, t, &vin, nullptr, 0.0, 1.0, 0);          // t = H in (other parity)
+        LQCHK(stencil_apply(c, s1));
+        StencilCall s2 = make_hop_call(op, &vout, t, &vin, m2, -1.0, 0);            // out = m^2 in - H t
+        return stencil_apply(c, s2);
+    };
+    return cg_generic(c, A, nh, xv.data, bv.data, r->data, p->data, q->data, eps, maxiter, iters, final_rr);
+}
+
 extern "C" int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
                                    double* final_rr) {
     LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab"));
@@ -1048,7 +1131,16 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(X->data, 0, X->elems * sizeof(double2), c->stream));
-    if (c->tun.mixed_action_solver) LQCHK(lqcd_solve_mixed_cg_DdagD(op, X, eta, eps, maxiter, 0.0, iters, nullptr, nullptr));
+    bool even_only = false;
+    if (op->kind == LQCD_STAGGERED && c->tun.staggered_parity_solve) {
+        // a pseudofermion that lives on the even sites (the reference's 4-taste action): D^+D is block diagonal in parity, X stays
+        // on the even sites and the half-lattice CG does the same solve at half the cost
+        double odd2 = 0;
+        LQCHK(blas_norm2(c, eta->data + eta->elems / 2, eta->elems / 2, &odd2, true));
+        even_only = odd2 == 0.0;
+    }
+    if (even_only) LQCHK(lqcd_solve_cg_DdagD_parity(op, X, eta, 0, eps, maxiter, iters, nullptr));
+    else if (c->tun.mixed_action_solver) LQCHK(lqcd_solve_mixed_cg_DdagD(op, X, eta, eps, maxiter, 0.0, iters, nullptr, nullptr));
     else LQCHK(cg_run(op, X, eta, eps, maxiter, false, iters, nullptr));
     if (Y) LQCHK(op_apply_async(op, Y, X, 0, nullptr));
     double re = 0, im = 0;

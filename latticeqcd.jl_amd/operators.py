@@ -380,6 +380,16 @@ def solve_mixed_DinvX_(y, A, x, inner_tol=1e-4, return_info=False):
     return (it.value, out.value, rr.value) if return_info else None
 
 
+def solve_parity_DinvX_(y, A, x, parity=0, return_info=False):
+    """Staggered only: y_p = ((D'D)_pp)^-1 x_p on the sites of one parity (0 even, 1 odd) of the FULL fields y (initial guess) and x,
+    with half-lattice vectors -- D'D = m^2 - D_hop^2 is block diagonal in parity.  The other half of y is left alone."""
+    if not isinstance(A, DdagD_operator):
+        raise LQCDError(_l.ERR_ARG, "solve_parity_DinvX_ needs a DdagD_operator")
+    it, rr = C.c_int(0), C.c_double(0)
+    check(_l.lib().lqcd_solve_cg_DdagD_parity(A.D._h, y._h, x._h, int(parity), C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr)))
+    return (it.value, rr.value) if return_info else None
+
+
 def shiftedcg(vec_x, vec_beta, x, A, b, eps=None, maxsteps=None, return_info=False):
     """shiftedcg(vec_x, vec_β, x, A, b): (A + β_j) vec_x[j] = b for every shift and A x = b, A = D'D (RHMC; README.md:132).
     Zero initial guesses; raises NotConverged after maxsteps."""

@@ -82,3 +82,61 @@ def test_iteration_cap_is_exact(lq, maxit):
     lq.clear_fermion_(x)
     with pytest.raises(lq.NotConverged):
         lq.solve_DinvX_(x, D, b)
+
+
+@pytest.mark.parametrize("parity", [0, 1])
+def test_staggered_parity_block_solve_matches_oracle(lq, orc, parity):
+    """D'D of the staggered operator is block diagonal in parity: the half-lattice CG on one block equals the full-lattice oracle CG
+    on a source that lives on that parity; the other half of the solution field is left alone."""
+    L = (8, 4, 6, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 941)
+    U = lq.Gaugefields(lat).upload(Uh)
+    mass, bc = 0.1, (1, 1, 1, -1)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": mass, "boundarycondition": bc, "eps_CG": 1e-20})
+    bh = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 942)
+    t, z, y, x = np.meshgrid(range(L[3]), range(L[2]), range(L[1]), range(L[0]), indexing="ij")
+    mask = ((x + y + z + t) & 1) == parity                       # host layout [.., t, z, y, x, c] -> see fermion_shape
+    bp = bh.copy()
+    bp.reshape(-1, L[3], L[2], L[1], L[0], 3)[:, ~mask, :] = 0.0
+    b = lq.Fermionfields(lat, lq.STAGGERED).upload(bp)
+    marker = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 943)
+    mk = marker.copy()
+    mk.reshape(-1, L[3], L[2], L[1], L[0], 3)[:, mask, :] = 0.0  # initial guess: zero on the solved parity, a marker on the other
+    sol = lq.Fermionfields(lat, lq.STAGGERED).upload(mk)
+    it, rr = lq.solve_parity_DinvX_(sol, lq.DdagD_operator(D), b, parity, return_info=True)
+    xo, ito, _, st = orc.cg_DdagD(orc.STAGGERED, Uh, bp, L, mass, 1.0, bc, eps=1e-20)
+    assert st == 0 and rr < 1e-20 and abs(it - ito) <= 2
+    got = sol.download().reshape(-1, L[3], L[2], L[1], L[0], 3)
+    ref = xo.reshape(-1, L[3], L[2], L[1], L[0], 3)
+    assert np.abs(got[:, mask, :] - ref[:, mask, :]).max() < 1e-9 * np.abs(ref).max()
+    assert np.abs(ref[:, ~mask, :]).max() < 1e-12 * np.abs(ref).max()            # the exact solution has no component there
+    assert np.array_equal(got[:, ~mask, :], mk.reshape(-1, L[3], L[2], L[1], L[0], 3)[:, ~mask, :])
+    with pytest.raises(lq.LQCDError):
+        Dw = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.141139})
+        w = lq.Fermionfields(lat, lq.WILSON)
+        lq.solve_parity_DinvX_(w.similar(), lq.DdagD_operator(Dw), w, 0)
+
+
+def test_four_taste_action_takes_the_half_lattice_solve(lq, orc):
+    """FermiAction(Nf = 4): eta lives on the even sites; lqcd_fermi_action / lqcd_calc_UdSfdU notice the empty odd half and solve on
+    half-lattice vectors -- same S_f and force as with the full-lattice CG (tunable staggered_parity_solve = 0)."""
+    L = (8, 4, 6, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 944)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": 0.1, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-22})
+    fa = lq.FermiAction(D, {"Nf": 4})
+    xi, phi = lq.Fermionfields(lat, lq.STAGGERED), lq.Fermionfields(lat, lq.STAGGERED)
+    lq.gauss_sampling_in_action_(xi, U, fa, 945)
+    lq.sample_pseudofermions_(phi, U, fa, xi)
+    G = lq.Gaugefields(lat)
+    out = {}
+    for mode in (1, 0):
+        lat.set_param("staggered_parity_solve", mode)
+        S, it = lq.evaluate_FermiAction(fa, U, phi, return_info=True)
+        lq.calc_UdSfdU_(G, fa, U, phi)
+        out[mode] = (S, it, G.download())
+    lat.set_param("staggered_parity_solve", 1)
+    assert abs(out[1][0] - out[0][0]) < 1e-10 * abs(out[0][0]) and abs(out[1][1] - out[0][1]) <= 2
+    assert np.abs(out[1][2] - out[0][2]).max() < 1e-9 * np.abs(out[0][2]).max()
