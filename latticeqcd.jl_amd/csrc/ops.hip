@@ -985,26 +985,32 @@ __global__ void ms_zeta(const double* __restrict__ sc, double* __restrict__ ms, 
     __syncthreads();
     if (threadIdx.x == 0) { ms[6 * ns] = alpha; ms[6 * ns + 1] = beta; }
 }
-// blockIdx.y = j < ns: shifted system j (x_j += a_j p_j ; p_j = b_j p_j + z_j r);  blockIdx.y = ns: base system
-// (x += alpha p ; p = r + beta p).  x is still updated in the iteration that converges; nothing is touched afterwards.
+// base system (x += alpha p ; p = r + beta p) and every active shifted system j (x_j += a_j p_j ; p_j = b_j p_j + z_j r) in one pass:
+// r is read once per element, frozen shifts cost nothing.  x is still updated in the iteration that converges; nothing is touched
+// afterwards.
 __global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ sc, const double* __restrict__ ms, double2* const* __restrict__ ptr,
                                                      double2* __restrict__ x0, double2* __restrict__ p0, const double2* __restrict__ r, size_t n,
                                                      int ns) {
     if (sc[S_XDONE] != 0.0) return;
-    const int j = blockIdx.y;
-    double a, bb, z;
-    double2 *x, *p;
-    if (j < ns) {
-        a = ms[3 * ns + j]; bb = ms[4 * ns + j]; z = ms[5 * ns + j]; x = ptr[j]; p = ptr[ns + j];
-        if (a == 0.0 && bb == 0.0 && z == 0.0) return;       // frozen shift
-    }
-    else { a = sc[S_ALPHA]; bb = sc[S_BETA]; z = 1.0; x = x0; p = p0; }
+    const double al = sc[S_ALPHA], be = sc[S_BETA];
     for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
-        double2 pv = p[i], xv = x[i];
         const double2 rv = r[i];
-        xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y);
-        pv.x = fma(bb, pv.x, z * rv.x); pv.y = fma(bb, pv.y, z * rv.y);
-        x[i] = xv; p[i] = pv;
+        {
+            double2 pv = p0[i], xv = x0[i];
+            xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+            pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
+            x0[i] = xv; p0[i] = pv;
+        }
+        for (int j = 0; j < ns; j++) {
+            const double a = ms[3 * ns + j], bb = ms[4 * ns + j], z = ms[5 * ns + j];
+            if (a == 0.0 && bb == 0.0 && z == 0.0) continue;       // frozen shift
+            double2* __restrict__ x = ptr[j];
+            double2* __restrict__ p = ptr[ns + j];
+            double2 pv = p[i], xv = x[i];
+            xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y);
+            pv.x = fma(bb, pv.x, z * rv.x); pv.y = fma(bb, pv.y, z * rv.y);
+            x[i] = xv; p[i] = pv;
+        }
     }
 }
 }  // namespace lqcd
@@ -1085,7 +1091,7 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
                 LQCHK(stencil_apply(c, s2));
                 LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
                 if (ns) hipLaunchKernelGGL(ms_zeta, dim3(1), dim3(64), 0, c->stream, c->d_scal, d_ms, ns);
-                hipLaunchKernelGGL(ms_update_all, dim3(nbu, ns + 1), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase->data, p->data,
+                hipLaunchKernelGGL(ms_update_all, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase->data, p->data,
                                    r->data, n, ns);
                 HIPCHK(hipGetLastError());
             }
