@@ -380,7 +380,9 @@ struct StencilCall {
     // scalar block (upd_scal[S_ALPHA]); the kernel is a no-op once upd_scal[S_DONE] is set.  q = D^+ D p is never written.
     const double* upd_scal = nullptr;
     double2* upd[2] = {nullptr, nullptr};
-    const double2* gauge12 = nullptr;   // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
+    const double* skip_flag = nullptr;  // device scalar block: the interior launch is a no-op once skip_flag[S_DONE] is set (iterations
+                                        // enqueued behind the converging one in a burst)
+    const double2* gauge12 = nullptr;  // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
     const double2* clover = nullptr;    // packed clover blocks: the Wilson split kernel (variant 1) applies A to xin in its epilogue
     int prec = 0;                 // 0: fp64 fields, 1: fp32 fields (pointers are float2 data, see p32)
 };
@@ -418,7 +420,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. 
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, bool in_order);
 StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger);
 void apply_bc(lqcd_ctx_s* c, const int bc[4]);
-int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial);
+int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial, const double* skip_flag = nullptr);
 int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr);
 bool any_partitioned(lqcd_ctx_s* c);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);

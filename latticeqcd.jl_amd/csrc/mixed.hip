@@ -139,6 +139,7 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
             apply_bc(c, op->bc);
             StencilCall s1 = call32(op, m, m.t, m.p, 0);
             s1.norm_partial = c->d_partial;
+            s1.skip_flag = c->d_scal;                        // a no-op once the inner solve has converged inside a burst
             LQCHK(stencil_apply(c, s1));
             LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));
             StencilCall s2 = call32(op, m, m.t, m.t, 1);      // update mode: nothing is written to out

@@ -226,10 +226,11 @@ static int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const c
     return LQCD_OK;
 }
 
-int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial) {
+int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial, const double* skip_flag) {
     apply_bc(op->ctx, op->bc);
     StencilCall s = make_full_call(op, out, in, dagger);
     s.norm_partial = norm_partial;
+    s.skip_flag = skip_flag;
     return stencil_apply(op->ctx, s);
 }
 
@@ -354,7 +355,7 @@ static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w
         //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
         //   beta, convergence ; x += alpha p, p = r + beta p
         const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
-        LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial));
+        LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial, c->d_scal));     // a no-op once the solve has converged inside a burst
         LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);
         StencilCall s2 = make_full_call(op, w.q, w.tmp, 1);
@@ -1080,7 +1081,7 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
             const int burst = std::min(check_every, maxiter - it);
             for (int k = 0; k < burst; k++) {
                 // tmp = D p, alpha = rr / |tmp|^2 ; r -= alpha D^+ tmp in the stencil epilogue, beta = rr'/rr
-                LQCHK(op_apply_async(op, tmp, p, 0, c->d_partial));
+                LQCHK(op_apply_async(op, tmp, p, 0, c->d_partial, c->d_scal));
                 LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));
                 apply_bc(c, op->bc);
                 StencilCall s2 = make_full_call(op, q, tmp, 1);

@@ -43,6 +43,7 @@ struct KArgs {
     double* norm_partial;
     const double* upd_scal;   // update mode (see StencilCall)
     real2* upd[2];
+    const double* skip;       // scalar block whose S_DONE flag turns the launch into a no-op (the solver has converged)
 };
 
 // final store of one output component: plain (out = v) or CG update mode (r -= alpha v); accumulates the squared norm
@@ -59,7 +60,9 @@ __device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm) 
         st(k.out[p] + off, v);
     }
 }
-__device__ inline bool upd_done(const KArgs& k) { return k.upd_scal && k.upd_scal[S_DONE] != 0.0; }
+__device__ inline bool upd_done(const KArgs& k) {
+    return (k.upd_scal && k.upd_scal[S_DONE] != 0.0) || (k.skip && k.skip[S_DONE] != 0.0);
+}
 
 struct HArgs {  // halo kernels
     Geom g;
@@ -1256,6 +1259,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.norm_partial = s.norm_partial;
     k.upd_scal = s.upd_scal;
     k.upd[0] = (real2*)s.upd[0]; k.upd[1] = (real2*)s.upd[1];
+    k.skip = s.skip_flag;
     return k;
 }
 
