@@ -134,13 +134,16 @@ end
 # Dirac_operator(U, x, params::Dict)  (universe.jl:137; keys universe.jl:103-135)
 function Dirac_operator(U::HIPGaugefields, x::HIPFermion, params::Dict)
     name = params["Dirac_operator"]
-    kind = name == "Wilson" ? WILSON : name == "Staggered" ? STAGGERED : error("$name is not supported")
+    kind = name in ("Wilson", "WilsonClover") ? WILSON : name in ("Staggered", "staggered") ? STAGGERED : error("$name is not supported")
     km = kind == WILSON ? Float64(params["κ"]) : Float64(get(params, "mass", 0.5))
     r = Float64(get(params, "r", 1.0))
     bc = Cint[get(params, "boundarycondition", [1, 1, 1, -1])...]
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lqcd_op_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Float64, Float64, Ptr{Cint}),
                 U.lat.h, h, kind, U.h, km, r, bc))
+    if name == "WilsonClover"      # Clover_coefficient (src/system/parameter_structs.jl:125)
+        check(ccall((:lqcd_op_set_clover, LIB), Cint, (Ptr{Cvoid}, Float64), h[], Float64(get(params, "Clover_coefficient", 1.5612))))
+    end
     D = HIPDirac(h[], U, false, Float64(get(params, "eps_CG", 1e-19)), Int(get(params, "MaxCGstep", 3000)),
                  String(get(params, "method_CG", "bicgstab")), true)
     finalizer(d -> d.owner && ccall((:lqcd_op_destroy, LIB), Cint, (Ptr{Cvoid},), d.h), D)
@@ -188,6 +191,13 @@ function shiftedcg(vec_x::Vector{HIPFermion}, vec_β::Vector{Float64}, x::HIPFer
                 A.D.h, x.h, hs, b.h, vec_β, length(vec_β), A.D.eps_CG, A.D.MaxCGstep, it, rr))
 end
 
+# staggered: the parity block (D'D)_pp on half-lattice vectors (the 4-taste action of test/test_staggered.toml lives on the even sites)
+function solve_parity_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion, parity::Integer = 0)
+    it, rr = Ref{Cint}(0), Ref{Float64}(0)
+    check(ccall((:lqcd_solve_cg_DdagD_parity, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Ref{Cint}, Ref{Float64}),
+                A.D.h, y.h, x.h, parity, A.D.eps_CG, A.D.MaxCGstep, it, rr))
+    y
+end
 # mixed-precision variant of solve_DinvX!(y, DdagD, x): fp32 inner CG, stopping rule on the true fp64 residual
 function solve_mixed_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion; inner_tol = 1e-4)
     it, out, rr = Ref{Cint}(0), Ref{Cint}(0), Ref{Float64}(0)
