@@ -243,6 +243,7 @@ struct Tunables {
     int halo_tuned_us[2] = {0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
+    int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
     int gauge_recon = 12;     // 12 (default): the direction-split kernels read 2 rows per link and rebuild the third -- only while every

@@ -355,7 +355,7 @@ static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w
         //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
         //   beta, convergence ; x += alpha p, p = r + beta p
         const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
-        LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial, c->d_scal));     // a no-op once the solve has converged inside a burst
+        LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial, c->tun.cg_skip_done ? c->d_scal : nullptr));   // a no-op once the solve has converged inside a burst
         LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);
         StencilCall s2 = make_full_call(op, w.q, w.tmp, 1);
