@@ -426,7 +426,10 @@ class FermiAction:
     eta lives on the even sites only -- D'D = m^2 - D_hop^2 is block diagonal in parity, so the solve and the force are the same
     kernels with the odd half of eta zero; sample_pseudofermions_ does the masking).
     Staggered with any other 0 < Nf < 8 (test/test_Nf2.toml:8, test/test_Nf3.toml:8) is the rational action
-    S_f = eta' (D'D)^(-Nf/8) eta: partial fractions from rational.py on the spectral interval [m^2, m^2 + 16] (|D_hop| <= 4), a
+    S_f = eta' (D'D)^(-Nf/8) eta; Wilson / Wilson-clover with 0 < Nf < 2 (Nf = 1: the strange quark of a 2+1 run) is
+    S_f = eta' (D'D)^(-Nf/2) eta on an interval from "rhmc_lambda_min" / "rhmc_lambda_max" or from a Lanczos estimate
+    (estimate_spectrum) on the links at construction, with margins 0.5 / 1.2 -- the staggered interval is analytic.
+    Partial fractions from rational.py on the spectral interval [m^2, m^2 + 16] (|D_hop| <= 4), a
     tighter fit for the action and the heat bath ("rhmc_tol_action", default 1e-12) than for the MD force ("rhmc_tol_MD", 1e-8),
     one multi-shift solve per evaluation (lqcd_rational_apply / lqcd_rational_force).
     Keeps X = (D'D)^-1 eta and Y = D X resident between evaluate_FermiAction and calc_UdSfdU_."""
@@ -435,20 +438,26 @@ class FermiAction:
         kind = D.kind
         params = params or {}
         nf = params.get("Nf", 2 if kind == WILSON else 4)
-        if kind == WILSON and nf != 2:
-            raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Wilson Nf = {nf} is not available (shiftedcg / apply_inverse_power_ are the building blocks)")
         self.D = D
         self.Nf = nf
         self.evensite = kind == STAGGERED and nf == 4
-        self.rational = kind == STAGGERED and nf not in (4, 8)
+        # D'D carries 2 Wilson flavours / 8 staggered tastes: anything else is S_f = eta' (D'D)^(-Nf/n0) eta
+        n0 = 2 if kind == WILSON else 8
+        self.rational = (kind == WILSON and nf != 2) or (kind == STAGGERED and nf not in (4, 8))
         if self.rational:
-            if not (0 < nf < 8):
-                raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: staggered Nf = {nf} outside (0, 8)")
+            if not (0 < nf < n0):
+                raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Nf = {nf} outside (0, {n0}) for this operator")
             from . import rational
-            lo, hi = D.km * D.km, D.km * D.km + 16.0
-            lo, hi = lo * (1.0 - 1e-9), hi * (1.0 + 1e-9)
+            if "rhmc_lambda_min" in params and "rhmc_lambda_max" in params:
+                lo, hi = float(params["rhmc_lambda_min"]), float(params["rhmc_lambda_max"])
+            elif kind == STAGGERED:       # D'D = m^2 - D_hop^2 with |D_hop| <= 4
+                lo, hi = D.km * D.km * (1.0 - 1e-9), (D.km * D.km + 16.0) * (1.0 + 1e-9)
+            else:                         # Wilson(-clover): no analytic lower bound -- Lanczos estimate on the current links with a margin
+                tmin, tmax = estimate_spectrum(DdagD_operator(D), steps=int(params.get("rhmc_lanczos_steps", 60)))
+                lo, hi = float(params.get("rhmc_lambda_min", 0.5 * tmin)), float(params.get("rhmc_lambda_max", 1.2 * tmax))
+            self.spectral_interval = (lo, hi)
             tol_a, tol_md = float(params.get("rhmc_tol_action", 1e-12)), float(params.get("rhmc_tol_MD", 1e-8))
-            self.alpha = nf / 8.0
+            self.alpha = nf / float(n0)
 
             def fit(alpha, tol):        # wide intervals (small masses) cost digits in double precision: loosen until the fit verifies
                 while True:
@@ -458,9 +467,9 @@ class FermiAction:
                         if tol > 1e-7:
                             raise
                         tol *= 10.0
-            self.rhmc_action = fit(self.alpha, tol_a)                 # x^(-Nf/8)
+            self.rhmc_action = fit(self.alpha, tol_a)                 # x^(-Nf/n0)
             self.rhmc_MD = fit(self.alpha, tol_md)
-            self.rhmc_sampling = fit(1.0 - nf / 16.0, tol_a)          # x^(Nf/16) = x * x^(Nf/16 - 1)
+            self.rhmc_sampling = fit(1.0 - 0.5 * self.alpha, tol_a)   # x^(alpha/2) = x * x^(alpha/2 - 1)
         self._half = Fermionfields(D.lattice, kind, EVEN) if self.evensite else None
         self._temporary_fermionfields = [Fermionfields(D.lattice, kind) for _ in range(2)]   # standardMD.jl:50-51
 
@@ -473,6 +482,41 @@ class FermiAction:
 
 def _darr(v):
     return (C.c_double * len(v))(*[float(t) for t in v])
+
+
+def estimate_spectrum(A, steps=60, randomseed=4711):
+    """Extreme Ritz values (theta_min, theta_max) of the Hermitian positive A = D'D from `steps` Lanczos iterations on the device
+    (scalars on the host): theta_max converges to the largest eigenvalue from below, theta_min to the smallest from above -- use
+    them with a margin.  The Wilson rational action takes its fit interval from here when none is given."""
+    if not isinstance(A, DdagD_operator):
+        raise LQCDError(_l.ERR_ARG, "estimate_spectrum needs a DdagD_operator")
+    lat, kind = A.D.lattice, A.D.kind
+    v, vp, w = Fermionfields(lat, kind), Fermionfields(lat, kind), Fermionfields(lat, kind)
+    gauss_distribution_fermion_(v, randomseed)
+    n0 = np.sqrt(dot(v, v).real)
+    check(_l.lib().lqcd_scale(C.c_double(1.0 / n0), C.c_double(0.0), v._h))
+    clear_fermion_(vp)
+    alphas, betas = [], []
+    beta = 0.0
+    for j in range(steps):
+        mul_(w, A, v)
+        a = dot(v, w).real
+        add_fermion_(w, -a, v)
+        if j:
+            add_fermion_(w, -beta, vp)
+        alphas.append(a)
+        beta = np.sqrt(max(dot(w, w).real, 0.0))
+        if beta < 1e-12 * abs(a) or j == steps - 1:
+            break
+        betas.append(beta)
+        substitute_fermion_(vp, v)
+        substitute_fermion_(v, w)
+        check(_l.lib().lqcd_scale(C.c_double(1.0 / beta), C.c_double(0.0), v._h))
+    T = np.diag(alphas) + np.diag(betas[:len(alphas) - 1], 1) + np.diag(betas[:len(alphas) - 1], -1)
+    th = np.linalg.eigvalsh(T)
+    for f in (v, vp, w):
+        f.close()
+    return float(th[0]), float(th[-1])
 
 
 def _rational_apply(D, y, x, coeffs):

@@ -134,3 +134,63 @@ def test_hmc_repeats_the_reference_general_nf_tests_on_device(lq, orc, nf):
     assert abs(plaq - REF_PLAQ[nf]) / REF_PLAQ[nf] < 0.1
     assert acc >= 5 and np.abs(dHs).max() < 3.0
     assert abs(plaq - start) > 1e-6 and orc.unitarity_dev(U.download(), L) < 1e-9
+
+
+@pytest.mark.parametrize("dirac,csw", [("Wilson", 0.0), ("WilsonClover", 1.0)])
+def test_wilson_one_flavour_rational_action(lq, orc, dirac, csw):
+    """Wilson / Wilson-clover Nf = 1 (the odd flavour of a 2+1 run): S_f = phi^+ (D^+D)^(-1/2) phi on the interval estimated by the
+    device Lanczos; action and force against the oracle's composition, heat-bath identity, and the interval encloses the spectrum."""
+    L, kappa = (4, 4, 4, 4), 0.141139
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 851)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": dirac, "κ": kappa, "Clover_coefficient": csw, "boundarycondition": BC, "eps_CG": 1e-22})
+    tmin, tmax = lq.estimate_spectrum(lq.DdagD_operator(D), steps=80)
+    fa = lq.FermiAction(D, {"Nf": 1})
+    lo, hi = fa.spectral_interval
+    assert fa.rational and abs(fa.alpha - 0.5) < 1e-15 and lo < tmin < tmax < hi
+    if csw == 0.0:      # exact extreme eigenvalues of the 3072 x 3072 matrix are affordable here through the oracle's operator
+        import scipy.sparse.linalg as sla
+        shape = lat.fermion_shape(lq.WILSON)
+        n = int(np.prod(shape))
+        mv = lambda v: orc.wilson_D(Uh, orc.wilson_D(Uh, np.ascontiguousarray(v.reshape(shape)), L, kappa, 1.0, BC), L, kappa, 1.0, BC, True).reshape(n)
+        op = sla.LinearOperator((n, n), matvec=mv, dtype=np.complex128)
+        emax = sla.eigsh(op, k=1, which="LA", return_eigenvectors=False, tol=1e-8)[0]
+        emin = sla.eigsh(op, k=1, which="SA", return_eigenvectors=False, tol=1e-8)[0]
+        assert lo < emin and emax < hi and tmin < 1.3 * emin and tmax > 0.95 * emax
+    phih = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 852)
+    phi = lq.Fermionfields(lat, lq.WILSON).upload(phih)
+    S = lq.evaluate_FermiAction(fa, U, phi)
+    G = lq.Gaugefields(lat)
+    lq.calc_UdSfdU_(G, fa, U, phi)
+    if csw == 0.0:
+        a0, res, poles = fa.rhmc_action
+        yo, _ = orc.rational_apply(orc.WILSON, Uh, phih, L, kappa, a0, res, poles, 1.0, BC)
+        assert abs(S - np.vdot(phih, yo).real) < 1e-10 * abs(S)
+        Go = orc.rational_force(orc.WILSON, Uh, phih, L, kappa, fa.rhmc_MD[1], fa.rhmc_MD[2], 1.0, BC)
+        assert rel_err(G.download(), Go) < 1e-9
+    # heat bath: S_f((D'D)^(1/4) xi) = xi' xi   (both operators)
+    xi = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_sampling_in_action_(xi, U, fa, 853)
+    lq.sample_pseudofermions_(phi, U, fa, xi)
+    assert abs(lq.evaluate_FermiAction(fa, U, phi) / lq.dot(xi, xi).real - 1.0) < 1e-8
+    # the force is the derivative of the device action (central differences along one generator on one link)
+    lq.calc_UdSfdU_(G, fa, U, phi)
+    Gh = G.download()
+    from scipy.linalg import expm
+    rng = np.random.default_rng(854)
+    T = sum(c * g for c, g in zip(rng.normal(size=8), orc.GELLMANN))
+    mu, t, z, y, x = 2, 1, 3, 0, 2
+    vals = []
+    fa_acc = lq.FermiAction(D, {"Nf": 1, "rhmc_lambda_min": lo, "rhmc_lambda_max": hi, "rhmc_tol_action": 1e-8})   # the MD fit as the action
+    fa_acc.rhmc_action = fa.rhmc_MD
+    U2 = lq.Gaugefields(lat)
+    for sgn in (+1, -1):
+        Up = Uh.copy()
+        Up[mu, t, z, y, x] = (expm(1j * sgn * 1e-4 * T) @ Uh[mu, t, z, y, x].T).T
+        U2.upload(Up)
+        vals.append(lq.evaluate_FermiAction(fa_acc, U2, phi))
+    fa.D(U)
+    fd = (vals[0] - vals[1]) / 2e-4
+    an = -2.0 * np.trace(T @ Gh[mu, t, z, y, x].T).imag
+    assert abs(fd - an) < 2e-6 * max(1.0, abs(an)), (fd, an)

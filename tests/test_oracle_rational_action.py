@@ -82,3 +82,37 @@ def orc_fd(orc, action, U, site, T, eps):
         Ut[site] = (E @ U[site].T).T
         out.append(action(Ut))
     return (out[0] - out[1]) / (2 * eps)
+
+
+def test_wilson_one_flavour_rational_action_and_force(lq, orc):
+    """Wilson Nf = 1: S_f = phi^+ (D^+D)^(-1/2) phi.  Partial fractions on the exact spectral interval of the dense D^+D (768 x 768),
+    action and heat bath against the exact spectral function, force against central differences of the exact action."""
+    from scipy.linalg import expm
+    Lw, kappa = (4, 2, 2, 2), 0.141139
+    U = orc.hot_gauge(Lw, 841)
+    A = orc.dense_DdagD(orc.WILSON, U, Lw, kappa, 1.0, BC)
+    w, V = np.linalg.eigh(A)
+    lo, hi = 0.8 * w.min(), 1.2 * w.max()
+    phi = orc.gaussian_spinor(orc.wilson_shape(Lw), 842)
+    a0, res, poles, _ = lq.rational.inverse_power_partial_fractions(0.5, lo, hi, 1e-11)
+    y, _ = orc.rational_apply(orc.WILSON, U, phi, Lw, kappa, a0, res, poles, 1.0, BC)
+    ex = exact_power(w, V, phi, -0.5)
+    assert np.abs(y - ex).max() < 1e-9 * np.abs(ex).max()
+    b0, bres, bpoles, _ = lq.rational.inverse_power_partial_fractions(0.75, lo, hi, 1e-11)       # x^(1/4) = x * x^(-3/4)
+    xi = orc.gaussian_spinor(orc.wilson_shape(Lw), 843)
+    t, _ = orc.rational_apply(orc.WILSON, U, xi, Lw, kappa, b0, bres, bpoles, 1.0, BC)
+    hb = orc.wilson_D(U, orc.wilson_D(U, t, Lw, kappa, 1.0, BC), Lw, kappa, 1.0, BC, True)
+    S, _ = orc.rational_apply(orc.WILSON, U, hb, Lw, kappa, a0, res, poles, 1.0, BC)
+    assert abs(np.vdot(hb, S).real / np.vdot(xi, xi).real - 1.0) < 1e-9
+    G = orc.rational_force(orc.WILSON, U, phi, Lw, kappa, res, poles, 1.0, BC)
+
+    def action(Ut):
+        wt, Vt = np.linalg.eigh(orc.dense_DdagD(orc.WILSON, Ut, Lw, kappa, 1.0, BC))
+        return np.vdot(phi, exact_power(wt, Vt, phi, -0.5)).real
+
+    rng = np.random.default_rng(844)
+    for site in [(0, 1, 1, 0, 3), (3, 1, 0, 1, 2)]:                  # (mu, t, z, y, x); the second one crosses the t boundary
+        T = sum(c * g for c, g in zip(rng.normal(size=8), orc.GELLMANN))
+        fd = orc_fd(orc, action, U, site, T, 1e-4)
+        an = -2.0 * np.trace(T @ orc_mat(G[site])).imag
+        assert abs(fd - an) < 2e-6 * max(1.0, abs(an)), (site, fd, an)
