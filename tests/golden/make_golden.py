@@ -34,6 +34,7 @@ COPY = {
     "confs_HMC_L04040404_beta5.7_Staggered_mass0.5/conf_00000100.ildg": "staggered_4x4x4x4.ildg",
     "confs_HMC_L04040404_beta5.7_Staggered_mass0.5_Nf2/conf_00000100.ildg": "staggered_nf2_4x4x4x4.ildg",
     "confs_HMC_L04040404_beta5.7_Staggered_mass0.5_Nf3/conf_00000100.ildg": "staggered_nf3_4x4x4x4.ildg",
+    "confs_HMC_L04040404_beta5.7_quenched_su3/conf_00000100.ildg": "quenched_su3_4x4x4x4.ildg",
     "confs_HMC_L04040404_beta5.7_Domainwall/conf_00000100.ildg": "domainwall_4x4x2x2.ildg",
     "confs_HMC_L04040404_beta5.7_Domainwall/conf_00000100.ildg.txt": "domainwall_4x4x2x2.ildg.txt",
 }
@@ -51,7 +52,7 @@ for d, L in SU3.items():
 
 # the reference's loose end-to-end goldens (test/debugplaqdata.txt:7-11), recorded for a future Julia-hosted run
 gold["reference_end_of_run_plaquettes_10pct"] = {
-    "wilson": 0.5784043949012552, "staggered_nf4": 0.5734383856968012, "staggered_nf2": 0.56287171870089,
+    "quenched_su3_hmc": 0.55783720583739, "wilson": 0.5784043949012552, "staggered_nf4": 0.5734383856968012, "staggered_nf2": 0.56287171870089,
     "staggered_nf3": 0.5595757232711884, "domainwall": 0.5757839405690621}
 for src, dst in COPY.items():
     shutil.copyfile(os.path.join(REF, src), os.path.join(HERE, dst))

@@ -192,3 +192,38 @@ def test_reference_criterion_discriminates_a_wrong_pseudofermion_weight(gpu, orc
         lq.gauss_sampling_in_action_ = good
     plaq = lq.calculate_Plaquette(U)
     assert abs(plaq - REF_PLAQ_WILSON_HMC) / REF_PLAQ_WILSON_HMC > 0.1, plaq
+
+
+def test_hmc_repeats_the_reference_quenched_su3_test_on_device(gpu, orc):
+    """runtests.jl:31-38 with test/test01.toml: quenched SU(3) HMC, beta = 5.7, dtau = 1/15, 15 MD steps, 10 trajectories from the
+    reference's thermalised configuration; final plaquette within 10 % of debugplaqdata.txt line 2 -- the gauge side of the MD step
+    (momenta, staple force fused into the momentum update, link exponential, actions) alone against the reference's golden."""
+    lq = gpu
+    L, dtau, mdsteps = (4, 4, 4, 4), 1.0 / 15.0, 15
+    ref_plaq = 0.55783720583739                                     # /root/reference/test/debugplaqdata.txt:2
+    Uh = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "quenched_su3_4x4x4x4.ildg"), L)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    p, Uold = lq.Gaugefields(lat), lq.Gaugefields(lat)
+    start = lq.calculate_Plaquette(U)
+    rng = np.random.default_rng(113)
+    dHs, acc = [], 0
+    for traj in range(10):
+        lq.substitute_U_(Uold, U)
+        lq.gauss_distribution_(p, 5000 + traj)
+        Hold = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA)
+        for _ in range(mdsteps):
+            lq.U_update_(U, p, 0.5 * dtau)
+            lq.P_update_(U, p, dtau, BETA)
+            lq.U_update_(U, p, 0.5 * dtau)
+        dH = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA) - Hold
+        dHs.append(dH)
+        if np.exp(-dH) >= rng.random():
+            acc += 1
+        else:
+            lq.substitute_U_(U, Uold)
+    plaq = lq.calculate_Plaquette(U)
+    print("quenched SU(3) HMC: dH =", ["%.3f" % d for d in dHs], "accepted", acc, "/ 10, plaquette %.6f (start %.6f)" % (plaq, start))
+    assert abs(plaq - ref_plaq) / ref_plaq < 0.1
+    assert acc >= 6 and np.abs(dHs).max() < 2.0 and abs(plaq - start) > 1e-6
+    assert orc.unitarity_dev(U.download(), L) < 1e-9

@@ -136,3 +136,34 @@ def test_oracle_hmc_repeats_the_reference_wilson_test(orc, lq):
     plaq = orc.plaquette(U, L)
     assert abs(plaq - ref_plaq) / ref_plaq < 0.1, (plaq, dHs)
     assert acc >= 6 and np.abs(dHs).max() < 2.0, (acc, dHs)
+
+
+def test_oracle_hmc_repeats_the_reference_quenched_su3_test(orc, lq):
+    """The gauge side alone, pinned to the reference's golden: test/runtests.jl:31-38 with test/test01.toml -- quenched SU(3) HMC from
+    the reference's thermalised 4^4 configuration, beta = 5.7, dtau = 1/15, 15 MD steps (plain QPQ leapfrog), 10 trajectories; final
+    plaquette within 10 % of test/debugplaqdata.txt line 2."""
+    import os
+    from conftest import GOLDEN
+    L, beta, dtau, mdsteps = (4, 4, 4, 4), 5.7, 1.0 / 15.0, 15
+    ref_plaq = 0.55783720583739                                     # /root/reference/test/debugplaqdata.txt:2
+    U = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "quenched_su3_4x4x4x4.ildg"), L)
+    start = orc.plaquette(U, L)
+    rng = np.random.default_rng(112)
+    dHs, acc = [], 0
+    for traj in range(10):
+        Uold = U.copy()
+        P = orc.gaussian_momenta(L, 3000 + traj)
+        Hold = orc.momentum_action(P, L) + orc.gauge_action(U, L, beta)
+        for _ in range(mdsteps):
+            orc.link_update(U, P, 0.5 * dtau, L)
+            orc.momentum_add_ta(P, dtau, orc.gauge_force(U, L, beta), L)
+            orc.link_update(U, P, 0.5 * dtau, L)
+        dH = orc.momentum_action(P, L) + orc.gauge_action(U, L, beta) - Hold
+        dHs.append(dH)
+        if np.exp(-dH) >= rng.random():
+            acc += 1
+        else:
+            U = Uold
+    plaq = orc.plaquette(U, L)
+    assert abs(plaq - ref_plaq) / ref_plaq < 0.1, (plaq, start, dHs)
+    assert acc >= 6 and np.abs(dHs).max() < 2.0 and abs(plaq - start) > 1e-6, (acc, dHs)
