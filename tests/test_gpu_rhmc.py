@@ -194,3 +194,50 @@ def test_wilson_one_flavour_rational_action(lq, orc, dirac, csw):
     fd = (vals[0] - vals[1]) / 2e-4
     an = -2.0 * np.trace(T @ Gh[mu, t, z, y, x].T).imag
     assert abs(fd - an) < 2e-6 * max(1.0, abs(an)), (fd, an)
+
+
+def test_two_plus_one_flavour_wilson_clover_trajectory(lq, orc):
+    """2+1 flavours of Wilson-clover quarks: a 2-flavour pseudofermion (S = eta'(D'D)^-1 eta, light kappa) and a rational 1-flavour one
+    (S = phi'(D'D)^(-1/2) phi, heavier kappa) in one leapfrog trajectory -- second-order energy conservation and reversibility."""
+    L = (4, 4, 4, 4)
+    Uh = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    par = {"Dirac_operator": "WilsonClover", "Clover_coefficient": 1.0, "boundarycondition": BC, "eps_CG": 1e-20}
+    Dl = lq.Dirac_operator(U, None, dict(par, **{"κ": 0.141139}))
+    Ds = lq.Dirac_operator(U, None, dict(par, **{"κ": 0.13}))
+    fl, fs = lq.FermiAction(Dl), lq.FermiAction(Ds, {"Nf": 1, "rhmc_tol_MD": 1e-10})
+    p, G = lq.Gaugefields(lat), lq.Gaugefields(lat)
+    xil, xis = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.WILSON)
+    etal, etas = xil.similar(), xis.similar()
+
+    def H():
+        return (lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA) + lq.evaluate_FermiAction(fl, U, etal)
+                + lq.evaluate_FermiAction(fs, U, etas))
+
+    def leapfrog(dtau, n):
+        for _ in range(n):
+            lq.U_update_(U, p, 0.5 * dtau)
+            lq.P_update_(U, p, dtau, BETA)
+            for fa, eta in ((fl, etal), (fs, etas)):
+                lq.calc_UdSfdU_(G, fa, U, eta)
+                lq.Traceless_antihermitian_add_(p, dtau, G)
+            lq.U_update_(U, p, 0.5 * dtau)
+
+    dH = []
+    for n in (8, 16):
+        U.upload(Uh)
+        lq.gauss_distribution_(p, 861)
+        lq.gauss_sampling_in_action_(xil, U, fl, 862)
+        lq.gauss_sampling_in_action_(xis, U, fs, 863)
+        lq.sample_pseudofermions_(etal, U, fl, xil)
+        lq.sample_pseudofermions_(etas, U, fs, xis)
+        H0 = H()
+        assert abs(lq.evaluate_FermiAction(fs, U, etas) / lq.dot(xis, xis).real - 1.0) < 1e-8
+        leapfrog(0.4 / n, n)
+        dH.append(H() - H0)
+    assert abs(dH[1]) < abs(dH[0]) < 3.0 and 3.0 < abs(dH[0] / dH[1]) < 5.0, dH
+    P = p.download()
+    p.upload(-P)
+    leapfrog(0.4 / 16, 16)
+    assert np.abs(U.download() - Uh).max() < 1e-8
