@@ -997,10 +997,14 @@ __global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ s
     for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
         const double2 rv = r[i];
         {
-            double2 pv = p0[i], xv = x0[i];
-            xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+            double2 pv = p0[i];
+            if (x0) {          // the unshifted solution is optional (a rational action only wants the shifted ones)
+                double2 xv = x0[i];
+                xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+                x0[i] = xv;
+            }
             pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
-            x0[i] = xv; p0[i] = pv;
+            p0[i] = pv;
         }
         for (int j = 0; j < ns; j++) {
             const double a = ms[3 * ns + j], bb = ms[4 * ns + j], z = ms[5 * ns + j];
@@ -1033,19 +1037,18 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     const size_t n = b->elems, bytes = n * sizeof(double2);
-    lqcd_spinor_s* xbase = x0 ? x0 : scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* xbase = x0;          // may stay null: then the base system only drives the Krylov space
     lqcd_spinor_s* r = scratch_get(c, op->kind, LQCD_FULL);
     lqcd_spinor_s* p = scratch_get(c, op->kind, LQCD_FULL);
     lqcd_spinor_s* q = scratch_get(c, op->kind, LQCD_FULL);
     lqcd_spinor_s* tmp = scratch_get(c, op->kind, LQCD_FULL);
     std::vector<lqcd_spinor_s*> ps(ns, nullptr);
-    bool ok = xbase && r && p && q && tmp;
+    bool ok = r && p && q && tmp;
     for (int j = 0; j < ns && ok; j++) { ps[j] = scratch_get(c, op->kind, LQCD_FULL); ok = ps[j] != nullptr; }
     const size_t ms_doubles = 6 * (size_t)ns + 2, ms_bytes = ms_doubles * sizeof(double) + 2 * (size_t)ns * sizeof(double2*);
     char* d_blk = nullptr;
     if (ok && hipMalloc((void**)&d_blk, ms_bytes) != hipSuccess) ok = false;
     auto release = [&]() {
-        if (!x0) scratch_put(xbase);
         scratch_put(r); scratch_put(p); scratch_put(q); scratch_put(tmp);
         for (auto* s : ps) scratch_put(s);
         if (d_blk) (void)hipFree(d_blk);
@@ -1054,7 +1057,7 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
     double* d_ms = (double*)d_blk;
     double2** d_ptr = (double2**)(d_blk + ms_doubles * sizeof(double));
     auto run = [&]() -> int {
-        HIPCHK(hipMemsetAsync(xbase->data, 0, bytes, c->stream));
+        if (xbase) HIPCHK(hipMemsetAsync(xbase->data, 0, bytes, c->stream));
         HIPCHK(hipMemcpyAsync(r->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(p->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
         std::vector<double> hms(ms_doubles, 1.0);    // zeta_{-1} = zeta_0 = 1, alpha_{-1} = 1
@@ -1092,7 +1095,7 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
                 LQCHK(stencil_apply(c, s2));
                 LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
                 if (ns) hipLaunchKernelGGL(ms_zeta, dim3(1), dim3(64), 0, c->stream, c->d_scal, d_ms, ns);
-                hipLaunchKernelGGL(ms_update_all, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase->data, p->data,
+                hipLaunchKernelGGL(ms_update_all, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase ? xbase->data : (double2*)nullptr, p->data,
                                    r->data, n, ns);
                 HIPCHK(hipGetLastError());
             }
