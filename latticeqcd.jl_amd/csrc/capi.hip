@@ -242,6 +242,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "staggered_parity_solve")) return &c->tun.staggered_parity_solve;
     if (!strcmp(key, "halo_tuned_us0")) return &c->tun.halo_tuned_us[0];
     if (!strcmp(key, "halo_tuned_us1")) return &c->tun.halo_tuned_us[1];
+    if (!strcmp(key, "halo_tuned_us2")) return &c->tun.halo_tuned_us[2];
     if (!strcmp(key, "halo_merge")) return &c->tun.halo_merge;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;

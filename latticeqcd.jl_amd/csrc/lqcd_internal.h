@@ -239,8 +239,10 @@ struct Tunables {
     int clover_fused = 1;     // Wilson-clover: apply A inside the direction-split kernel's epilogue (0: separate A x pass)
     int halo_stream_mode = -1; // partitioned stencil: 0 = exchange on the communication stream, interior on the compute stream;
                                // 1 = pack -> exchange -> exterior in order on the compute stream, interior on the second stream
-                               // (no queue hop on the message path; pays when the exchange is the longer leg); -1 = time both once
-    int halo_tuned_us[2] = {0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
+                               // (no queue hop on the message path; pays when the exchange is the longer leg);
+                               // 2 = interior enqueued first on the compute stream and in order with the exterior, pack -> exchange on the
+                               // second stream (pays when the interior is the longer leg); -1 = time all three once
+    int halo_tuned_us[3] = {0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
@@ -418,7 +420,7 @@ int force_halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind);
 int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
                          double r, double scale = 1.0, int accumulate = 0);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
-int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, bool in_order);
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);
 StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger);
 void apply_bc(lqcd_ctx_s* c, const int bc[4]);
 int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial, const double* skip_flag = nullptr);

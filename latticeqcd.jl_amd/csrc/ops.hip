@@ -26,14 +26,16 @@ static size_t halo_count(lqcd_ctx_s* c, int mu, int kind, int parity_mode) {
 // RCCL path: grouped send/recv on the communication stream, so the transfer over xGMI overlaps the interior stencil running
 // on the compute stream.  When both neighbours of a direction are the same rank (PE extent 2) the two faces are ONE message
 // each way: my [fwd | bwd] lands in its [from bwd | from fwd].
-// in_order = false: the exchange runs on the communication stream behind an event of the pack kernel and signals ev_comm;
-// in_order = true: it is enqueued on the compute stream itself, right behind the pack kernel (halo_stream_mode = 1)
-int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, bool in_order) {
+// where = 0: the exchange runs on the communication stream behind an event of the pack kernel (compute stream) and signals ev_comm;
+// where = 1: it is enqueued on the compute stream itself, right behind the pack kernel (halo_stream_mode = 1);
+// where = 2: on the communication stream, which already holds the pack kernel (halo_stream_mode = 2); signals ev_comm
+int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where) {
+    const bool in_order = where == 1;
     const ncclDataType_t dt = prec ? ncclFloat : ncclDouble;   // same element counts, float2 instead of double2 elements
     const size_t esize = prec ? sizeof(float2) : sizeof(double2);
     ARGCHK(c->has_comm, "halo exchange: communicator not initialised (call lqcd_ctx_comm_init)");
     hipStream_t xs = in_order ? c->stream : c->comm_stream;
-    if (!in_order) {
+    if (where == 0) {
         HIPCHK(hipEventRecord(c->ev_pack, c->stream));
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
     }
@@ -98,8 +100,8 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             c->tun.halo_stream_mode = -1;
             return st;
         }
-        float ms[2] = {0.f, 0.f};
-        for (int mode = 0; mode < 2; mode++) {
+        float ms[3] = {0.f, 0.f, 0.f};
+        for (int mode = 0; mode < 3; mode++) {
             c->tun.halo_stream_mode = mode;
             LQCHK(stencil_apply(c, s));
             HIPCHK(hipEventRecord(c->ev_t0, c->stream));
@@ -108,9 +110,11 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             HIPCHK(hipEventSynchronize(c->ev_t1));
             HIPCHK(hipEventElapsedTime(&ms[mode], c->ev_t0, c->ev_t1));
         }
-        c->tun.halo_stream_mode = ms[1] < ms[0] ? 1 : 0;
-        c->tun.halo_tuned_us[0] = (int)(250.f * ms[0]);
-        c->tun.halo_tuned_us[1] = (int)(250.f * ms[1]);
+        int best = 0;
+        for (int mode = 1; mode < 3; mode++)
+            if (ms[mode] < ms[best]) best = mode;
+        c->tun.halo_stream_mode = best;
+        for (int mode = 0; mode < 3; mode++) c->tun.halo_tuned_us[mode] = (int)(250.f * ms[mode]);
         return LQCD_OK;      // `out` holds the result of the last tuning application
     }
     if (c->tun.halo_stream_mode == 1) {
@@ -127,12 +131,30 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         }
         HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
         LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
-        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, true));
+        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 1));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+        return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+    }
+    if (c->tun.halo_stream_mode == 2) {
+        // the interior is enqueued FIRST on the compute stream (the GPU starts it while the host is still busy issuing the RCCL group)
+        // and stays in order with the exterior; pack -> exchange run on the second stream behind an event -- the schedule for an
+        // exchange that is shorter than the interior: the fork / join latencies hide behind the interior kernel
+        HIPCHK(hipEventRecord(c->ev_pack, c->stream));                 // the inputs of this call are complete
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+        LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
+        {
+            hipStream_t main_stream = c->stream;
+            c->stream = c->comm_stream;
+            const int st = s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s);
+            c->stream = main_stream;
+            LQCHK(st);
+        }
+        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
     }
     LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
-    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, false));
+    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 0));
     LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
@@ -1352,7 +1374,7 @@ extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spin
         HIPCHK(hipEventRecord(e[0], c->stream));
         LQCHK(launch_stencil_pack(c, s));
         HIPCHK(hipEventRecord(e[1], c->stream));
-        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0, false));
+        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0, 0));
         HIPCHK(hipEventRecord(e[5], c->comm_stream));
         LQCHK(launch_stencil_interior(c, s));
         HIPCHK(hipEventRecord(e[2], c->stream));
