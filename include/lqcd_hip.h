@@ -76,7 +76,14 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * [default]), graph (1: hipGraph replay of CG bursts), gauge_recon (12 [default]: the split kernels read two rows per link and rebuild the
  * third -- applied only while every link of the field is unitary to 1e-14, results within the fp64 Dslash tolerance; 18: all
  * 18 stored reals are always read), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge, nt_store,
- * lds_pad_kb, persist_per_cu, dbg (timing ablations). */
+ * lds_pad_kb, persist_per_cu, dbg (timing ablations);
+ * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
+ * mixed-precision CG), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
+ * cg_skip_done, clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
+ * construction of the clover term / force also on one rank);
+ * partitioned lattices: halo_merge (1 [default]: one message per peer when both faces go to the same rank), halo_stream_mode
+ * (-1 [default]: time the three stream schedules of the halo exchange once; 0 | 1 | 2 force one), halo_tuned_us0..2 (read-only:
+ * the times that choice was made from). */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
 int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);
 
