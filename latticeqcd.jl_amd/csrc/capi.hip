@@ -176,6 +176,8 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev_t0));
     HIPCHK(hipEventCreate(&c->ev_t1));
+    HIPCHK(hipEventCreate(&c->ev_tune0));
+    HIPCHK(hipEventCreate(&c->ev_tune1));
     const size_t npart = (size_t)2 * c->geom.Vh / 64 + 4096 + 8 * ((size_t)2 * c->geom.Vh / 128 + 8);  // interior + exterior partials
     HIPCHK(hipMalloc((void**)&c->d_partial, npart * 2 * sizeof(double)));
     HIPCHK(hipMalloc((void**)&c->d_scal, SCAL_DOUBLES * sizeof(double)));
@@ -212,6 +214,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipHostFree(c->h_scal);
     (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1);
+    (void)hipEventDestroy(c->ev_tune0); (void)hipEventDestroy(c->ev_tune1);
     (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->comm_stream);
     delete c;
     return LQCD_OK;

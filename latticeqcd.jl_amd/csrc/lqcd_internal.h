@@ -263,6 +263,7 @@ struct lqcd_ctx_s {
     lqcd::Geom geom;
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_tune0 = nullptr, ev_tune1 = nullptr;   // the halo-schedule tuner's own timing events (ev_t0 / ev_t1 belong to the bench entry points)
     // reductions
     double* d_partial = nullptr;  // [MAX_PARTIAL_BLOCKS * 4]
     double* d_scal = nullptr;     // small device scalar block (solver state)

@@ -104,11 +104,11 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         for (int mode = 0; mode < 3; mode++) {
             c->tun.halo_stream_mode = mode;
             LQCHK(stencil_apply(c, s));
-            HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+            HIPCHK(hipEventRecord(c->ev_tune0, c->stream));
             for (int k = 0; k < 4; k++) LQCHK(stencil_apply(c, s));
-            HIPCHK(hipEventRecord(c->ev_t1, c->stream));
-            HIPCHK(hipEventSynchronize(c->ev_t1));
-            HIPCHK(hipEventElapsedTime(&ms[mode], c->ev_t0, c->ev_t1));
+            HIPCHK(hipEventRecord(c->ev_tune1, c->stream));
+            HIPCHK(hipEventSynchronize(c->ev_tune1));
+            HIPCHK(hipEventElapsedTime(&ms[mode], c->ev_tune0, c->ev_tune1));
         }
         int best = 0;
         for (int mode = 1; mode < 3; mode++)
