@@ -226,8 +226,10 @@ struct Tunables {
     int dslash_block = 128;   // threads per workgroup of the stencil kernels
     int xcd_remap = 2;        // workgroup -> lattice map (stencil.hip map_block): 2 = per-XCD (y,z) tile swept through t
     int dslash_variant = 1;   // Wilson r=1 kernel: 0 site-per-lane, 1 dirsplit (4 waves/64 sites), 2 hopsplit (8 waves/64 sites)
-    int nt_gauge = 0;         // non-temporal loads for gauge links
-    int nt_store = 0;         // non-temporal stores for the output spinor
+    int nt_gauge = 1;         // split kernels: bit 0 = the BACKWARD use of a link (its second and last) is a non-temporal load, bit 1 = the forward use
+                              // too.  Measured at 32^3x64 (profiles/r02_nt_sweep.log): bit 0 -1.5..2.5 %, bit 1 +40 % (the second use then misses
+                              // the Infinity Cache as well)
+    int nt_store = 1;         // output spinor stored non-temporally (it is not read again by this kernel: keeps its lines out of the L2) -1..3 %
     int cg_fused = 2;         // 0: reference form (c1 = p.q), 1: |Dp|^2 from the stencil, 2: + r-update fused into D^+, x/p updates merged
     int graph = 0;            // capture solver iterations in a hipGraph
     int persist_per_cu = 2;   // variant 3: resident workgroups per CU
@@ -284,6 +286,7 @@ struct lqcd_ctx_s {
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
     const void* mix_gauge_of = nullptr;  // gauge handle / version the fp32 link copies in mix_buf[0], mix_buf[5] were made from
     uint64_t mix_gauge_version = 0;
+    bool mix_gauge12_valid = false;      // the 12-real fp32 copy (mix_buf[5]) was made for that version
     void* mix_buf[7] = {};
     size_t mix_bytes[7] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
@@ -422,7 +425,8 @@ int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_ga
                          double r, double scale = 1.0, int accumulate = 0);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);
-StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger);
+int make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, StencilCall& s);
+int op_refresh_clover(lqcd_op_s* op);   // rebuilds A when the links moved; clover_version follows only a successful build
 void apply_bc(lqcd_ctx_s* c, const int bc[4]);
 int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial, const double* skip_flag = nullptr);
 int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr);

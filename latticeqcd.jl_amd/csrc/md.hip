@@ -81,6 +81,7 @@ struct GFArgs {
     const double2* ghost[4];
     const double2* wrecv[4];
     double2* wsend[4];
+    int mu_only, mu_out;     // MODE 2 (calc_dSdUmu!): only direction mu_only, staple sum written to direction slot mu_out of `out`
 };
 
 // U_nu at the site c + dir_hat: local, or from the forward ghost slice when the step leaves the rank
@@ -114,11 +115,14 @@ __device__ __forceinline__ void lower_staple_at(cd (&w)[9], const GFArgs& k, con
 
 // out_mu(n) = coef * U_mu(n) * sum_{nu != mu} [ U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+  +  W_{mu nu}(n - nu) ]
 // workgroup = 64 sites of one parity x 4 waves (wave = mu); the 6 x 3 neighbour links are re-used across waves/sites through L2
-// FUSE_TA = false: out = G.   FUSE_TA = true: out (the momenta) += factor * TA(G) -- P_update! in one pass, G never stored.
-template <bool FUSE_TA>
+// MODE 0: out = G.   MODE 1: out (the momenta) += factor * TA(G) -- P_update! in one pass, G never stored.
+// MODE 2 (64-thread blocks, one direction): out[mu_out] = coef * (sum of the six staples of direction mu_only) -- the reference's
+// calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108); the caller multiplies by U[mu] itself (mul!, :109).
+template <int MODE>
 __global__ __launch_bounds__(256) void gauge_force_kernel(GFArgs k) {
+    constexpr bool FUSE_TA = MODE == 1;
     const Geom& g = k.g;
-    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = MODE == 2 ? k.mu_only : (int)(threadIdx.x >> 6);
     if (i >= g.Vh) return;
     const int Gs = glink_stride(g);
     int c[4];
@@ -149,11 +153,17 @@ __global__ __launch_bounds__(256) void gauge_force_kernel(GFArgs k) {
 #pragma unroll
         for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
     }
+    const double coef = k.coef;
+    if constexpr (MODE == 2) {
+        double2* o2 = k.out + glink_off(g, p, k.mu_out, i);
+#pragma unroll
+        for (int e = 0; e < 9; e++) st(o2 + (size_t)e * Gs, mk(coef * A[e].re, coef * A[e].im));
+        return;
+    }
     cd um[9], r[9];
     load_m3(um, k.U + glink_off(g, p, mu, i), Gs);
     mm3(r, um, A);
     double2* o = k.out + glink_off(g, p, mu, i);
-    const double coef = k.coef;
     if constexpr (!FUSE_TA) {
 #pragma unroll
         for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, mk(coef * r[e].re, coef * r[e].im));
@@ -227,12 +237,8 @@ __global__ __launch_bounds__(256) void momentum_add_ta_kernel(Geom g, double2* _
 
 // U <- exp(dt P) U, Taylor series in Horner form.  Terms: 12 when the max-abs-row-sum norm of dt P is below 0.2
 // (0.2^13/13! = 1e-19), otherwise 24 (exact to rounding up to norm 2); an MD step has |dt P| of a few 1e-2.
-__global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* __restrict__ U, double dt, const double2* __restrict__ P) {
-    size_t off;
-    if (!link_of_thread(g, off)) return;
-    const int Gs = glink_stride(g);
-    cd x[9], e[9], t[9], u[9];
-    load_m3(x, P + off, Gs);
+__device__ __forceinline__ void exp_m3(cd (&e)[9], cd (&x)[9], double dt) {     // e = exp(dt x); x is scaled in place
+    cd t[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) { x[k] = mk(dt * x[k].re, dt * x[k].im); e[k] = mk((k % 4 == 0) ? 1.0 : 0.0, 0.0); }
     double nrm = 0.0;
@@ -245,6 +251,14 @@ __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* _
 #pragma unroll
         for (int k = 0; k < 9; k++) e[k] = mk(((k % 4 == 0) ? 1.0 : 0.0) + inv * t[k].re, inv * t[k].im);
     }
+}
+__global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* __restrict__ U, double dt, const double2* __restrict__ P) {
+    size_t off;
+    if (!link_of_thread(g, off)) return;
+    const int Gs = glink_stride(g);
+    cd x[9], e[9], t[9], u[9];
+    load_m3(x, P + off, Gs);
+    exp_m3(e, x, dt);
     load_m3(u, U + off, Gs);
     mm3(t, e, u);
 #pragma unroll
@@ -305,6 +319,50 @@ __global__ __launch_bounds__(256) void momentum_action_kernel(Geom g, const doub
 
 static int link_grid(const Geom& g) { return 2 * g.nch; }
 
+// ---- single-direction forms: one 64-thread block per 64 sites of one parity, the direction slots are arguments.  They serve the
+// reference's callers literally (U[mu], p[mu], one temporary link field at a time: AbstractMD.jl:78-135); the fused four-direction
+// kernels above remain the fast path.
+__device__ __forceinline__ bool site_of_thread(const Geom& g, int& p, int& i) {
+    p = blockIdx.x & 1; i = (blockIdx.x >> 1) * 64 + threadIdx.x;
+    return i < g.Vh;
+}
+// op 0: C = A (substitute_U!)   op 1: C = exp(t A) (exptU!)   op 2: C = A B (mul!)   op 3: C += t * TA(A) (Traceless_antihermitian_add!)
+template <int OP>
+__global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* __restrict__ C, int mc, const double2* __restrict__ A, int ma,
+                                                     const double2* __restrict__ B, int mb, double t) {
+    int p, i;
+    if (!site_of_thread(g, p, i)) return;
+    const int Gs = glink_stride(g);
+    cd a[9], r[9];
+    load_m3(a, A + glink_off(g, p, ma, i), Gs);
+    double2* o = C + glink_off(g, p, mc, i);
+    if constexpr (OP == 0) {
+#pragma unroll
+        for (int e = 0; e < 9; e++) r[e] = a[e];
+    } else if constexpr (OP == 1) {
+        exp_m3(r, a, t);
+    } else if constexpr (OP == 2) {
+        cd b[9];
+        load_m3(b, B + glink_off(g, p, mb, i), Gs);
+        mm3(r, a, b);
+    } else {
+        cd h[9];
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int y = 0; y < 3; y++) h[x * 3 + y] = mk(0.5 * (a[x * 3 + y].re - a[y * 3 + x].re), 0.5 * (a[x * 3 + y].im + a[y * 3 + x].im));
+        const double tr = (h[0].im + h[4].im + h[8].im) / 3.0;
+        h[0].im -= tr; h[4].im -= tr; h[8].im -= tr;
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            const cd pv = ld(o + (size_t)e * Gs);
+            r[e] = mk(fma(t, h[e].re, pv.re), fma(t, h[e].im, pv.im));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, r[e]);
+}
+
 }  // namespace lqcd
 
 using namespace lqcd;
@@ -359,6 +417,7 @@ static GFArgs make_gfargs(lqcd_ctx_s* c, lqcd_gauge_s* U, lqcd_gauge_s* out, dou
     k.out = out->data;
     k.coef = -beta / 6.0;
     k.factor = factor;
+    k.mu_only = -1; k.mu_out = 0;
     for (int mu = 0; mu < 4; mu++) { k.ghost[mu] = c->gf_ghost[mu]; k.wrecv[mu] = c->gf_wrecv[mu]; k.wsend[mu] = c->gf_wsend[mu]; }
     return k;
 }
@@ -373,8 +432,9 @@ static int launch_staple_faces(lqcd_ctx_s* c, const GFArgs& k) {
     return LQCD_OK;
 }
 static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse) {
-    if (fuse) hipLaunchKernelGGL(gauge_force_kernel<true>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
-    else hipLaunchKernelGGL(gauge_force_kernel<false>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
+    if (k.mu_only >= 0) hipLaunchKernelGGL(gauge_force_kernel<2>, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, k);
+    else if (fuse) hipLaunchKernelGGL(gauge_force_kernel<1>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
+    else hipLaunchKernelGGL(gauge_force_kernel<0>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
@@ -393,18 +453,20 @@ int gf_exchange_rccl(lqcd_ctx_s* c, double2* const sendb[4], double2* const recv
     return LQCD_OK;
 }
 
-static int staple_force(lqcd_gauge_s* out, lqcd_gauge_s* U, double beta, double factor, bool fuse) {
+static int staple_force(lqcd_gauge_s* out, lqcd_gauge_s* U, double beta, double factor, bool fuse, int mu_only = -1, int mu_out = 0,
+                        double coef_override = 0.0) {
     lqcd_ctx_s* c = U->ctx;
     HIPCHK(hipSetDevice(c->device));
-    out->version++;
     if (any_partitioned(c)) {
-        ARGCHK(c->local_peers.empty(), "staple force: this context belongs to an in-process PE grid, use lqcd_mdom_momentum_add_gauge_force");
+        ARGCHK(c->local_peers.empty(), "staple force: this context belongs to an in-process PE grid, use lqcd_mdom_gauge_force (fuse = 1 adds it to the momenta)");
         LQCHK(gf_buffers(c));
         for (int mu = 0; mu < 4; mu++)
             if (c->geom.part[mu]) LQCHK(gauge_pack_face(U, mu, c->gf_gsend[mu]));
         LQCHK(gf_exchange_rccl(c, c->gf_gsend, c->gf_ghost, true));
     }
+    out->version++;     // arguments are valid: the field is about to be written
     GFArgs k = make_gfargs(c, U, out, beta, factor);
+    if (mu_only >= 0) { k.mu_only = mu_only; k.mu_out = mu_out; k.coef = coef_override; }
     if (any_partitioned(c)) {
         LQCHK(launch_staple_faces(c, k));
         LQCHK(gf_exchange_rccl(c, c->gf_wsend, c->gf_wrecv, false));
@@ -412,6 +474,57 @@ static int staple_force(lqcd_gauge_s* out, lqcd_gauge_s* U, double beta, double 
     LQCHK(launch_staple_sweep(c, k, fuse));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
+}
+
+// ---- single-direction entry points (the interface the reference's unchanged callers use, AbstractMD.jl:78-135)
+static int link_args(lqcd_gauge_t a, int ma, lqcd_gauge_t b, int mb, const char* who) {
+    if (!(a && b && a->ctx == b->ctx && ma >= 0 && ma < 4 && mb >= 0 && mb < 4)) {
+        set_error(std::string(who) + ": need gauge-shaped fields of one context and direction slots in 0..3");
+        return LQCD_ERR_ARG;
+    }
+    return LQCD_OK;
+}
+template <int OP>
+static int link_op(lqcd_gauge_t C, int mc, lqcd_gauge_t A, int ma, lqcd_gauge_t B, int mb, double t) {
+    lqcd_ctx_s* c = C->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    C->version++;
+    hipLaunchKernelGGL(link_op_kernel<OP>, dim3(link_grid(c->geom)), dim3(64), 0, c->stream, c->geom, C->data, mc, A->data, ma,
+                       B ? B->data : (const double2*)nullptr, mb, t);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+// substitute_U!(U[mu], W) (AbstractMD.jl:93): one direction of dst <- one direction of src (the same field is allowed)
+extern "C" int lqcd_link_copy(lqcd_gauge_t dst, int mu_dst, lqcd_gauge_t src, int mu_src) {
+    LQCHK(link_args(dst, mu_dst, src, mu_src, "lqcd_link_copy"));
+    if (dst == src && mu_dst == mu_src) return LQCD_OK;
+    return link_op<0>(dst, mu_dst, src, mu_src, nullptr, 0, 0.0);
+}
+// exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): E[mu_e] = exp(t P[mu_p]), the Taylor-Horner series of lqcd_gauge_exp_update
+extern "C" int lqcd_link_exp(lqcd_gauge_t E, int mu_e, double t, lqcd_gauge_t P, int mu_p) {
+    LQCHK(link_args(E, mu_e, P, mu_p, "lqcd_link_exp"));
+    return link_op<1>(E, mu_e, P, mu_p, nullptr, 0, t);
+}
+// mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): C[mu_c](n) = A[mu_a](n) B[mu_b](n), site by site
+extern "C" int lqcd_link_mul(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_gauge_t B, int mu_b) {
+    LQCHK(link_args(C, mu_c, A, mu_a, "lqcd_link_mul"));
+    LQCHK(link_args(C, mu_c, B, mu_b, "lqcd_link_mul"));
+    return link_op<2>(C, mu_c, A, mu_a, B, mu_b, 0.0);
+}
+// Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131): P[mu_p] += factor * TA(G[mu_g])
+extern "C" int lqcd_link_add_ta(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t G, int mu_g) {
+    LQCHK(link_args(P, mu_p, G, mu_g, "lqcd_link_add_ta"));
+    ARGCHK(!(P == G && mu_p == mu_g), "lqcd_link_add_ta: P and G are the same link field");
+    return link_op<3>(P, mu_p, G, mu_g, nullptr, 0, factor);
+}
+// calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108) for the plaquette action pushed with coefficient beta/2
+// (universe.jl:92-95): out[mu_out](n) = (beta/2) * sum of the six staples of U_mu(n), so that U_mu(n) out(n) is the plaquette
+// sum whose -1/NC-weighted traceless anti-Hermitian part P_update! adds to p[mu].  Collective on a partitioned lattice.
+extern "C" int lqcd_link_staple(lqcd_gauge_t out, int mu_out, lqcd_gauge_t U, int mu, double beta) {
+    LQCHK(link_args(out, mu_out, U, mu, "lqcd_link_staple"));
+    ARGCHK(out != U, "lqcd_link_staple: out must not be the link field itself");
+    return staple_force(out, U, beta, 0.0, false, mu, mu_out, 0.5 * beta);
 }
 
 // G_mu(n) = -(beta/6) U_mu(n) * (sum of the six staples)      (calc_dSdUmu! + mul!(temp, U, dSdUmu), AbstractMD.jl:108-110)

@@ -190,7 +190,11 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     LQCHK(mix_alloc(c, 5, gauge12_elems(c->geom) * sizeof(float2)));
     Mix32 m;
     m.gauge = (float2*)c->mix_buf[0];
-    m.gauge12 = (float2*)c->mix_buf[5];
+    // 12-real fp32 links only under the rule of the fp64 path: tunable gauge_recon = 12 AND every link of this field version unitary to
+    // 1e-14 (gauge_ensure_recon12).  For anything else (non-unitary test fields, smeared links) the inner operator reads the 18-real
+    // fp32 copy -- a rebuilt third row would differ from the outer operator by O(1) and the defect correction would stall.
+    const bool use12 = c->tun.gauge_recon == 12 && gauge_ensure_recon12(op->gauge) == LQCD_OK && op->gauge->recon_ok;
+    m.gauge12 = use12 ? (float2*)c->mix_buf[5] : nullptr;
     m.clover = nullptr;
     if (clov) {
         LQCHK(mix_alloc(c, 6, clover_elems(c->geom) * sizeof(float2)));
@@ -219,7 +223,8 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     };
     auto run = [&]() -> int {
         // the fp32 link copies follow the field (handle, version): a sequence of solves on the same links converts once
-        const bool links_cached = c->mix_gauge_of == (const void*)op->gauge && c->mix_gauge_version == op->gauge->version;
+        const bool links_cached = c->mix_gauge_of == (const void*)op->gauge && c->mix_gauge_version == op->gauge->version &&
+                                  (!use12 || c->mix_gauge12_valid);
         if (!links_cached) hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
         if (clov) {     // fp32 copy of the packed clover blocks (same layout); A follows the links first
             if (op->clover_version != op->gauge->version) {
@@ -229,10 +234,13 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
             const size_t nc = clover_elems(c->geom);
             hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, m.clover, op->clover, nc, 1.0);
         }
-        if (!links_cached) {
+        if (!links_cached && use12) {
             hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
+        }
+        if (!links_cached) {
             c->mix_gauge_of = (const void*)op->gauge;
             c->mix_gauge_version = op->gauge->version;
+            c->mix_gauge12_valid = use12;
         }
         HIPCHK(hipGetLastError());
         LQCHK(true_residual());

@@ -172,16 +172,18 @@ static const double2* recon12_links(lqcd_op_s* op) {
     lqcd_ctx_s* c = op->ctx;
     c->tun.recon_active = 0;
     if (c->tun.gauge_recon != 12) return nullptr;
-    if (op->kind == LQCD_WILSON && (op->r != 1.0 || c->tun.dslash_variant != 1)) return nullptr;   // only the direction-split kernels
-    if (op->kind == LQCD_STAGGERED && !(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 3)) return nullptr;
+    if (op->kind == LQCD_WILSON && (op->r != 1.0 || (c->tun.dslash_variant != 1 && c->tun.dslash_variant < 4))) return nullptr;   // only the direction-split kernels
+    if (op->kind == LQCD_STAGGERED && !(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 5)) return nullptr;
     if (gauge_ensure_recon12(op->gauge) != LQCD_OK || !op->gauge->recon_ok) return nullptr;
     c->tun.recon_active = 1;
     return op->gauge->data12;
 }
 
-// out = D in  /  D^+ in on FULL spinors
-StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger) {
-    StencilCall s;
+// out = D in  /  D^+ in on FULL spinors.  Wilson-clover: A follows the links lazily (rebuilt here when the field's version moved;
+// clover_version changes only if the build succeeded) and, unless the split kernel applies it in its epilogue, A in is formed by
+// a separate pass enqueued here -- both return their status to the caller.
+int make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, StencilCall& s) {
+    s = StencilCall();
     s.kind = op->kind;
     s.gauge = op->gauge->data;
     s.out[0] = spinor_block(out, 0);
@@ -196,20 +198,23 @@ StencilCall make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in,
     s.norm_partial = nullptr;
     s.gauge12 = recon12_links(op);
     if (op->csw != 0.0 && op->clover && op->clover_tmp) {
-        // Wilson-clover: the diagonal input of the stencil is A in (enqueued here, in front of the stencil every caller launches
-        // next); A follows the links lazily.  A failed launch surfaces at the caller's next HIP check.
-        if (op->clover_version != op->gauge->version) {
-            (void)clover_build(op->ctx, op->gauge, op->clover, op->km, op->csw);
-            op->clover_version = op->gauge->version;
-        }
+        LQCHK(op_refresh_clover(op));
         if (op->r == 1.0 && op->ctx->tun.dslash_variant == 1 && op->ctx->tun.clover_fused) {
             s.clover = op->clover;            // fused: the direction-split kernel forms A in in its epilogue (one pass, 1536 B/site)
         } else {
-            (void)clover_apply(op->ctx, op->clover, op->clover_tmp, in);      // separate streaming pass, then xin = A in
+            LQCHK(clover_apply(op->ctx, op->clover, op->clover_tmp, in));      // separate streaming pass, then xin = A in
             fill_blocks(s.xin, op->clover_tmp);
         }
     }
-    return s;
+    return LQCD_OK;
+}
+
+int op_refresh_clover(lqcd_op_s* op) {
+    if (op->csw != 0.0 && op->clover && op->clover_version != op->gauge->version) {
+        LQCHK(clover_build(op->ctx, op->gauge, op->clover, op->km, op->csw));
+        op->clover_version = op->gauge->version;       // only a successful build marks A as current
+    }
+    return LQCD_OK;
 }
 
 // out(parity subset) = a*xin + b*H in, in of the opposite subset
@@ -250,7 +255,8 @@ static int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const c
 
 int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial, const double* skip_flag) {
     apply_bc(op->ctx, op->bc);
-    StencilCall s = make_full_call(op, out, in, dagger);
+    StencilCall s;
+    LQCHK(make_full_call(op, out, in, dagger, s));
     s.norm_partial = norm_partial;
     s.skip_flag = skip_flag;
     return stencil_apply(op->ctx, s);
@@ -380,7 +386,8 @@ static int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w
         LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial, c->tun.cg_skip_done ? c->d_scal : nullptr));   // a no-op once the solve has converged inside a burst
         LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);
-        StencilCall s2 = make_full_call(op, w.q, w.tmp, 1);
+        StencilCall s2;
+        LQCHK(make_full_call(op, w.q, w.tmp, 1, s2));
         s2.norm_partial = c->d_partial;
         s2.upd_scal = c->d_scal;
         s2.upd[0] = spinor_block(w.r, 0);
@@ -709,6 +716,8 @@ extern "C" int lqcd_op_set_clover(lqcd_op_t op, double csw) {
     if (csw == 0.0) return LQCD_OK;
     if (!op->clover) HIPCHK(hipMalloc((void**)&op->clover, clover_elems(c->geom) * sizeof(double2)));
     if (!op->clover_tmp) LQCHK(lqcd_spinor_create(c, &op->clover_tmp, LQCD_WILSON, LQCD_FULL));
+    op->clover_version = 0;
+    op->clover_inv_version = 0;      // A^-1 of the even-odd solver belongs to the previous (links, csw): rebuilt at its next use
     LQCHK(clover_build(c, op->gauge, op->clover, op->km, csw));
     op->clover_version = op->gauge->version;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -718,6 +727,7 @@ extern "C" int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g) {
     ARGCHK(op && g && g->ctx == op->ctx, "lqcd_op_set_gauge: bad gauge field");
     op->gauge = g;
     op->clover_version = 0;   // another field: the clover term is rebuilt at the next application
+    op->clover_inv_version = 0;
     return LQCD_OK;
 }
 
@@ -1109,7 +1119,8 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
                 LQCHK(op_apply_async(op, tmp, p, 0, c->d_partial, c->d_scal));
                 LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));
                 apply_bc(c, op->bc);
-                StencilCall s2 = make_full_call(op, q, tmp, 1);
+                StencilCall s2;
+                LQCHK(make_full_call(op, q, tmp, 1, s2));
                 s2.norm_partial = c->d_partial;
                 s2.upd_scal = c->d_scal;
                 s2.upd[0] = spinor_block(r, 0);
@@ -1369,7 +1380,8 @@ extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spin
     for (auto& ev : e) HIPCHK(hipEventCreate(&ev));
     double acc[6] = {0, 0, 0, 0, 0, 0};
     apply_bc(c, op->bc);
-    StencilCall s = make_full_call(op, out, in, dagger ? 1 : 0);
+    StencilCall s;
+    LQCHK(make_full_call(op, out, in, dagger ? 1 : 0, s));
     for (int r = 0; r < reps + 2; r++) {          // two untimed warm-up applications
         HIPCHK(hipEventRecord(e[0], c->stream));
         LQCHK(launch_stencil_pack(c, s));
@@ -1506,7 +1518,7 @@ extern "C" int lqcd_mdom_op_apply(int n, lqcd_op_t* ops, lqcd_spinor_t* outs, lq
         ctxs[r] = ops[r]->ctx;
         ARGCHK(ctxs[r]->rank == r, "lqcd_mdom_op_apply: ops must be ordered by rank");
         apply_bc(ctxs[r], ops[r]->bc);
-        calls[r] = make_full_call(ops[r], outs[r], ins[r], dagger ? 1 : 0);
+        LQCHK(make_full_call(ops[r], outs[r], ins[r], dagger ? 1 : 0, calls[r]));
         if (ops[r]->kind == LQCD_WILSON && ops[r]->r != 1.0) { set_error("r != 1 unsupported on a partitioned lattice"); return LQCD_ERR_UNSUPPORTED; }
     }
     for (int r = 0; r < n; r++) LQCHK(launch_stencil_pack(ctxs[r], calls[r]));

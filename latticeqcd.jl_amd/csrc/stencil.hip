@@ -39,12 +39,29 @@ struct KArgs {
     int ysplit;  // sub-domains are (y,z) tiles: ysplit tiles across y (1 = plain z-slabs)
     int cpr, ty, tz;                              // derived tile sizes (chunks)
     FastDiv d_perpass, d_cpr, d_ysplit, d_ty;     // magic numbers for the block -> chunk map
-    int dbg;     // timing ablations only (wrong results): 1 skip x-hop spinor loads, 2 skip x-hop link loads, 3 skip mat-vec
+#ifdef LQCD_ABLATE
+    int dbg;     // timing ablations only (wrong results; -DLQCD_ABLATE builds): see dirsplit_hops / hop_half
+#endif
+    int nt;      // bit 0: non-temporal backward-link loads, bit 1: non-temporal forward-link loads, bit 2: non-temporal output stores
     double* norm_partial;
     const double* upd_scal;   // update mode (see StencilCall)
     real2* upd[2];
     const double* skip;       // scalar block whose S_DONE flag turns the launch into a no-op (the solver has converged)
 };
+
+typedef real v2d __attribute__((ext_vector_type(2)));
+__device__ inline cd ld_nt(const real2* p) {
+    v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
+    return mk(v.x, v.y);
+}
+__device__ inline void load_link_nt(cd (&u)[9], const real2* __restrict__ U, int Vh) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) u[j] = ld_nt(U + (size_t)j * Vh);
+}
+__device__ inline void st_nt(real2* p, cd v) {
+    v2d t = {v.re, v.im};
+    __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(p));
+}
 
 // final store of one output component: plain (out = v) or CG update mode (r -= alpha v); accumulates the squared norm
 __device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm) {
@@ -57,7 +74,7 @@ __device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm) 
         st(rp, r);
     } else {
         nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
-        st(k.out[p] + off, v);
+        if (k.nt & 4) st_nt(k.out[p] + off, v); else st(k.out[p] + off, v);
     }
 }
 __device__ inline bool upd_done(const KArgs& k) {
@@ -146,9 +163,14 @@ __device__ inline void load_link(cd (&u)[9], const real2* __restrict__ U, int Vh
 }
 
 // 12-real links: rows 0 and 1 from memory, row 2 = conj(row 0 x row 1)  (exact for SU(3) to rounding)
-__device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U) {
+__device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U, bool nt = false) {
+    if (nt) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) u[k] = ld(U + (size_t)k * 64);
+        for (int k = 0; k < 6; k++) u[k] = ld_nt(U + (size_t)k * 64);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) u[k] = ld(U + (size_t)k * 64);
+    }
 #pragma unroll
     for (int b = 0; b < 3; b++) {
         const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
@@ -208,10 +230,11 @@ __device__ inline void reconstruct(cd (&acc)[12], const cd (&chi0)[3], const cd 
 // one hop, r = 1:  acc += (1 - S gamma_mu) [U or U^+] psi(nb) * sign
 template <int MU, int S, bool ADJ, bool R12 = false>
 __device__ inline void wilson_hop(cd (&acc)[12], const real2* __restrict__ psi, const real2* __restrict__ U,
-                                  int Vh, int Us, real sign) {
+                                  int Vh, int Us, real sign, bool nt = false) {
     cd h0[3], h1[3], chi0[3], chi1[3], u[9];
     project<MU, S>(h0, h1, psi, Vh);
-    if constexpr (R12) load_link12(u, U); else load_link(u, U, Us);
+    if constexpr (R12) load_link12(u, U, nt);
+    else { if (nt) load_link_nt(u, U, Us); else load_link(u, U, Us); }
 #pragma unroll
     for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
     su3_mv<ADJ>(chi0, u, h0);
@@ -367,6 +390,7 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
     const int Us = glink_stride(k.g);
     constexpr int SF = DAG ? -1 : 1;
+#ifdef LQCD_ABLATE
     if (k.dbg & (16 << MU)) return;   // traffic ablation (wrong results): drop both hops of direction MU
     if (k.dbg >= 256) {               // traffic ablations (wrong results): redirect one stream of direction MU to chunk 0 (always L2-hot)
         const int hot = i & 63;
@@ -374,8 +398,9 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
         if (k.dbg & (4096 << MU)) Uf = R12 ? k.gauge12 + glink12_off(k.g, p, MU, hot) : k.gauge + glink_off(k.g, p, MU, hot);
         if (k.dbg & (65536 << MU)) Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, hot) : k.gauge + glink_off(k.g, 1 - p, MU, hot);
     }
-    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU]);
-    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU]);
+#endif
+    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU], (k.nt & 2) != 0);
+    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0);
 }
 
 // rows 3*W .. 3*W+2 of A x for the packed clover field (clover.hip: two Hermitian 6x6 blocks in the chiral basis chi_(-+) =
@@ -477,6 +502,325 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ Wilson, lane-split
+// Variant 4 ("lanesplit"): the four directions of a site live in the four 16-lane rows of ONE wavefront -- lane = row * 16 + site,
+// row 0 = x, 1 = z, 2 = y, 3 = t -- so a wave owns 16 consecutive checkerboard sites (one x-row at XH = 16) and a workgroup of four
+// waves the same 64-site chunk as the other variants.  Every lane does what a lane of the direction-split kernel does (forward +
+// backward hop of its direction), but the four partial spinors of a site are combined INSIDE the wave by two
+// v_permlane{32,16}_swap reduce-scatter steps (36 swaps + 18 adds per lane) instead of 48 KiB of LDS and a workgroup barrier:
+// no LDS, no s_barrier, occupancy is limited by VGPRs only, and lane (row r, site s) ends up with spin row r of site s and
+// stores it.  The direction of a lane is data (per-lane projector rows and unit phases), the instruction stream is uniform; the
+// t rows simply mask the six spinor loads their projector does not need.  Association of the four-direction sum and of every hop
+// is the direction-split kernel's, so the two variants agree bit for bit.  r = 1 only.
+__device__ inline void lane_swap32(real& a, real& b) {   // a.upper32 <-> b.lower32 (v_permlane32_swap_b32)
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+#ifdef LQCD_F32
+    u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+#else
+    u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+#endif
+}
+__device__ inline void lane_swap16(real& a, real& b) {   // odd 16-lane rows of a <-> even 16-lane rows of b (v_permlane16_swap_b32)
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+#ifdef LQCD_F32
+    u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+#else
+    u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+#endif
+}
+
+// one hop of a lane whose direction is run-time data: chi_r = [U or U^+] sign (ca psi[a_r] + (pr_r + i pi_r) psi[b_r]),  r = 0, 1
+template <bool ADJ, bool R12>
+__device__ inline void lane_hop(cd (&chi0)[3], cd (&chi1)[3], const real2* __restrict__ psi, const real2* __restrict__ U, int Us,
+                                bool spatial, int a0, int b0, int b1, real ca, real pr0, real pi0, real pr1, real pi1, real sign, bool nt) {
+    cd h0[3], h1[3], u[9];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const cd A0 = ld(psi + (size_t)(a0 * 3 + c) * 64), A1 = ld(psi + (size_t)(a0 * 3 + 3 + c) * 64);
+        cd B0 = mk(0, 0), B1 = mk(0, 0);
+        if (spatial) { B0 = ld(psi + (size_t)(b0 * 3 + c) * 64); B1 = ld(psi + (size_t)(b1 * 3 + c) * 64); }
+        h0[c] = mk(ca * A0.re + (pr0 * B0.re - pi0 * B0.im), ca * A0.im + (pr0 * B0.im + pi0 * B0.re));
+        h1[c] = mk(ca * A1.re + (pr1 * B1.re - pi1 * B1.im), ca * A1.im + (pr1 * B1.im + pi1 * B1.re));
+    }
+    if constexpr (R12) load_link12(u, U, nt);
+    else { if (nt) load_link_nt(u, U, Us); else load_link(u, U, Us); }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
+    su3_mv<ADJ>(chi0, u, h0);
+    su3_mv<ADJ>(chi1, u, h1);
+}
+
+template <bool DAG, bool R12>
+__global__ __launch_bounds__(256) void wilson_lanesplit(KArgs k) {
+    __shared__ double red[4];
+    if (upd_done(k)) return;
+    int chunk, p;
+    map_block(k, chunk, p);
+    const Geom& g = k.g;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int lr = lane >> 4;                      // lane row = output spin row this lane stores
+    const int mu = ((lr & 1) << 1) | (lr >> 1);    // direction of this lane: rows 0,1,2,3 = x,z,y,t  ->  (x + y) + (z + t) like dirsplit
+    const int i = chunk * 64 + w * 16 + (lane & 15);
+    const bool valid = i < g.Vh;
+    constexpr int SF = DAG ? -1 : 1;
+    cd cf0[3], cf1[3], cb0[3], cb1[3], xv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { cf0[c] = cf1[c] = cb0[c] = cb1[c] = xv[c] = mk(0, 0); }
+    const bool spatial = mu < 3;
+    if (valid) {
+        if (k.a != 0.0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) xv[c] = ld(k.xin[p] + sp_off(12, i) + (size_t)(3 * lr + c) * 64);
+        }
+        // neighbours of this lane's direction
+        int cc[4];
+        cb_to_coords(g, p, i, cc);
+        int nf, nb;
+        real sf, sb;
+        {
+            // per-direction geometry selected by VALUE (readfirstlane makes the kernel arguments opaque scalars: a select between
+            // loads of neighbouring struct fields would be rewritten into a per-lane indexed load of the by-value struct = scratch)
+            const int L0 = __builtin_amdgcn_readfirstlane(g.L[0]), L1 = __builtin_amdgcn_readfirstlane(g.L[1]);
+            const int L2 = __builtin_amdgcn_readfirstlane(g.L[2]), L3 = __builtin_amdgcn_readfirstlane(g.L[3]);
+            const int XH = __builtin_amdgcn_readfirstlane(g.XH);
+            const int q = cc[0] & 1;
+            const int s1 = XH, s2 = XH * L1, s3 = s2 * L2;
+            const int stride = mu == 1 ? s1 : (mu == 2 ? s2 : s3);
+            const int Lm = mu == 0 ? L0 : (mu == 1 ? L1 : (mu == 2 ? L2 : L3));
+            const int cm = mu == 0 ? cc[0] : (mu == 1 ? cc[1] : (mu == 2 ? cc[2] : cc[3]));
+            const bool wf = cm == Lm - 1, wb = cm == 0;
+            if (mu == 0) {
+                nf = q ? (wf ? i - (XH - 1) : i + 1) : i;
+                nb = q ? i : (wb ? i + (XH - 1) : i - 1);
+            } else {
+                nf = wf ? i - (Lm - 1) * stride : i + stride;
+                nb = wb ? i + (Lm - 1) * stride : i - stride;
+            }
+            // sign of a wrapping hop: 0 = off-rank (partitioned direction), else the boundary condition (an integer sign, lqcd_op_create)
+            const int f0 = __builtin_amdgcn_readfirstlane(g.part[0] ? 0 : (int)g.bc_fwd[0]), f1 = __builtin_amdgcn_readfirstlane(g.part[1] ? 0 : (int)g.bc_fwd[1]);
+            const int f2 = __builtin_amdgcn_readfirstlane(g.part[2] ? 0 : (int)g.bc_fwd[2]), f3 = __builtin_amdgcn_readfirstlane(g.part[3] ? 0 : (int)g.bc_fwd[3]);
+            const int r0 = __builtin_amdgcn_readfirstlane(g.part[0] ? 0 : (int)g.bc_bwd[0]), r1 = __builtin_amdgcn_readfirstlane(g.part[1] ? 0 : (int)g.bc_bwd[1]);
+            const int r2 = __builtin_amdgcn_readfirstlane(g.part[2] ? 0 : (int)g.bc_bwd[2]), r3 = __builtin_amdgcn_readfirstlane(g.part[3] ? 0 : (int)g.bc_bwd[3]);
+            const int bfi = mu == 0 ? f0 : (mu == 1 ? f1 : (mu == 2 ? f2 : f3));
+            const int bbi = mu == 0 ? r0 : (mu == 1 ? r1 : (mu == 2 ? r2 : r3));
+            sf = wf ? real(bfi) : real(1.0);
+            sb = wb ? real(bbi) : real(1.0);
+        }
+        // projector data of the lane (tables PERM / GK, lqcd_internal.h): partner rows b0, b1 of rows 0, 1 and the powers of i
+        const int b0 = mu == 2 ? 2 : 3, b1 = mu == 2 ? 3 : 2;
+        const int k0 = mu == 1 ? 2 : 3, k1 = mu == 0 ? 3 : (mu == 1 ? 0 : 1);    // GK[mu][0], GK[mu][1]
+        auto unit = [](int kk, real& pr, real& pi) {   // i^kk
+            kk &= 3;
+            pr = kk == 0 ? real(1) : (kk == 2 ? real(-1) : real(0));
+            pi = kk == 1 ? real(1) : (kk == 3 ? real(-1) : real(0));
+        };
+        const real ca = spatial ? real(1) : real(2);
+        const real2* __restrict__ psi = k.in[1 - p];
+        const int Us = glink_stride(g);
+        const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(g, p, mu, i) : k.gauge + glink_off(g, p, mu, i);
+        const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(g, 1 - p, mu, nb) : k.gauge + glink_off(g, 1 - p, mu, nb);
+        if (sf != 0.0) {   // forward hop: (1 - SF gamma_mu) U psi(n + mu)
+            real pr0 = 0, pi0 = 0, pr1 = 0, pi1 = 0;
+            if (spatial) { unit(k0 + (SF > 0 ? 2 : 0), pr0, pi0); unit(k1 + (SF > 0 ? 2 : 0), pr1, pi1); }
+            lane_hop<false, R12>(cf0, cf1, psi + sp_off(12, nf), Uf, Us, spatial, spatial ? 0 : (SF > 0 ? 2 : 0), b0, b1, ca, pr0, pi0, pr1, pi1,
+                                 sf, (k.nt & 2) != 0);
+        }
+        if (sb != 0.0) {   // backward hop: (1 + SF gamma_mu) U^+(n - mu) psi(n - mu)
+            real pr0 = 0, pi0 = 0, pr1 = 0, pi1 = 0;
+            if (spatial) { unit(k0 + (SF > 0 ? 0 : 2), pr0, pi0); unit(k1 + (SF > 0 ? 0 : 2), pr1, pi1); }
+            lane_hop<true, R12>(cb0, cb1, psi + sp_off(12, nb), Ub, Us, spatial, spatial ? 0 : (SF > 0 ? 0 : 2), b0, b1, ca, pr0, pi0, pr1, pi1,
+                                sb, (k.nt & 1) != 0);
+        }
+    }
+    // the lane's partial spinor, spin rows 0..3 (3 colours each).  Spatial directions: rows 0,1 = chi_f + chi_b, rows b0,b1 = q (chi_f - chi_b)
+    // with q = i^(-GK + (SF > 0 ? 2 : 0)); t: the hop whose projector keeps rows 0,1 goes there, the other one to rows 2,3.
+    cd A[6], B[6];
+    {
+        const int mu_ = mu;
+        const int k0 = mu_ == 1 ? 2 : 3, k1 = mu_ == 0 ? 3 : (mu_ == 1 ? 0 : 1);
+        const int e0 = (-k0 + (SF > 0 ? 2 : 0)) & 3, e1 = (-k1 + (SF > 0 ? 2 : 0)) & 3;
+        const real qr0 = e0 == 0 ? real(1) : (e0 == 2 ? real(-1) : real(0)), qi0 = e0 == 1 ? real(1) : (e0 == 3 ? real(-1) : real(0));
+        const real qr1 = e1 == 0 ? real(1) : (e1 == 2 ? real(-1) : real(0)), qi1 = e1 == 1 ? real(1) : (e1 == 3 ? real(-1) : real(0));
+        const bool swap = mu_ < 2;          // x, y: row 3 <- chi0 part, row 2 <- chi1 part;  z (and t): row 2 <- chi0, row 3 <- chi1
+        constexpr bool F_LOW = SF < 0;      // t: forward hop keeps rows (SF > 0 ? 2 : 0)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const cd f0 = cf0[c], f1 = cf1[c], g0 = cb0[c], g1 = cb1[c];
+            const cd sum0 = f0 + g0, sum1 = f1 + g1, dif0 = f0 - g0, dif1 = f1 - g1;
+            A[c] = spatial ? sum0 : (F_LOW ? f0 : g0);
+            A[3 + c] = spatial ? sum1 : (F_LOW ? f1 : g1);
+            const cd E0 = spatial ? mk(qr0 * dif0.re - qi0 * dif0.im, qr0 * dif0.im + qi0 * dif0.re) : (F_LOW ? g0 : f0);
+            const cd E1 = spatial ? mk(qr1 * dif1.re - qi1 * dif1.im, qr1 * dif1.im + qi1 * dif1.re) : (F_LOW ? g1 : f1);
+            B[c] = swap ? E1 : E0;
+            B[3 + c] = swap ? E0 : E1;
+        }
+    }
+    // reduce-scatter over the four lane rows: rows {0,1} keep spin rows 0,1 and rows {2,3} spin rows 2,3, then each row its own
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        lane_swap32(A[j].re, B[j].re);
+        lane_swap32(A[j].im, B[j].im);
+        A[j] = A[j] + B[j];
+    }
+    cd F[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        lane_swap16(A[c].re, A[3 + c].re);
+        lane_swap16(A[c].im, A[3 + c].im);
+        F[c] = A[c] + A[3 + c];
+    }
+    real nrm = 0.0;
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            cd v = k.b * F[c];
+            v = mk(fma(k.a, xv[c].re, v.re), fma(k.a, xv[c].im, v.im));
+            emit(k, p, (size_t)(3 * lr + c) * 64 + sp_off(12, i), v, nrm);
+        }
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------ Wilson, direction-split, 4 workgroups per CU
+// Variant 5: the direction-split kernel with the footprint of FOUR resident workgroups per CU instead of three: (i) a wave keeps
+// the spin row it stores in registers and leaves only the nine components bound for the other three waves in LDS (36 KiB per
+// workgroup, 4 x 36 <= 160 KiB); (ii) each hop is carried as the two colour-multiplied projector rows (6 complex) and expanded
+// to spin rows only on the way to LDS, which removes the 12-component accumulator from the live set while the loads of the
+// backward hop are in flight (<= 128 VGPRs, __launch_bounds__(256, 4)).  Same arithmetic and summation order as variant 1.
+template <int MU, int S, bool ADJ, bool R12>
+__device__ inline void wilson_hop_chi(cd (&chi0)[3], cd (&chi1)[3], const real2* __restrict__ psi, const real2* __restrict__ U, int Vh, int Us,
+                                      real sign, bool nt) {
+    cd h0[3], h1[3], u[9];
+    project<MU, S>(h0, h1, psi, Vh);
+    if constexpr (R12) load_link12(u, U, nt);
+    else { if (nt) load_link_nt(u, U, Us); else load_link(u, U, Us); }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
+    su3_mv<ADJ>(chi0, u, h0);
+    su3_mv<ADJ>(chi1, u, h1);
+}
+
+// spin row ROW (3 colours) of  reconstruct<MU, SF>(chi_f) + reconstruct<MU, -SF>(chi_b)  in the accumulation order of wilson_hop
+template <int MU, int SF, int ROW>
+__device__ inline void recon_row(cd (&out)[3], const cd (&f0)[3], const cd (&f1)[3], const cd (&b0)[3], const cd (&b1)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        cd a = mk(0.0, 0.0);
+        if constexpr (MU < 3) {
+            constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
+            constexpr int kf0 = -GK[MU][0] + (SF > 0 ? 2 : 0) + 8, kf1 = -GK[MU][1] + (SF > 0 ? 2 : 0) + 8;
+            constexpr int kb0 = -GK[MU][0] + (SF > 0 ? 0 : 2) + 8, kb1 = -GK[MU][1] + (SF > 0 ? 0 : 2) + 8;
+            if constexpr (ROW == 0) a = (a + f0[c]) + b0[c];
+            else if constexpr (ROW == 1) a = (a + f1[c]) + b1[c];
+            else if constexpr (ROW == p0) a = (a + mul_ipow<kf0>(f0[c])) + mul_ipow<kb0>(b0[c]);
+            else a = (a + mul_ipow<kf1>(f1[c])) + mul_ipow<kb1>(b1[c]);
+        } else {
+            constexpr int bf = SF > 0 ? 2 : 0, bb = SF > 0 ? 0 : 2;   // forward hop S = SF keeps rows bf, bf+1; backward hop rows bb, bb+1
+            if constexpr (ROW == bf) a = a + f0[c];
+            else if constexpr (ROW == bf + 1) a = a + f1[c];
+            else if constexpr (ROW == bb) a = a + b0[c];
+            else a = a + b1[c];
+        }
+        out[c] = a;
+    }
+}
+
+template <int MU, bool DAG, bool R12>
+__device__ inline void dirsplit4_body(const KArgs& k, int p, int i, int lane, bool valid, real2 (*part)[3][3][64], cd (&own)[3]) {
+    constexpr int SF = DAG ? -1 : 1;
+    cd f0[3], f1[3], b0[3], b1[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { f0[c] = f1[c] = b0[c] = b1[c] = mk(0.0, 0.0); }
+    if (valid) {
+        Nbr n;
+        int c[4];
+        neighbours(k.g, p, i, n, c);
+        const int Vh = sp_stride(k.g);
+        const real2* __restrict__ psi = k.in[1 - p];
+        const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(k.g, p, MU, i) : k.gauge + glink_off(k.g, p, MU, i);
+        const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
+        const int Us = glink_stride(k.g);
+        if (n.sf[MU] != 0.0) wilson_hop_chi<MU, SF, false, R12>(f0, f1, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU], (k.nt & 2) != 0);
+        if (n.sb[MU] != 0.0) wilson_hop_chi<MU, -SF, true, R12>(b0, b1, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0);
+    }
+    // spin row r goes to wave r: slot (MU < r ? MU : MU - 1) of its three source slots; the own row stays in registers
+    cd row[3];
+#define LQ_ROW(R)                                                                      \
+    recon_row<MU, SF, R>(row, f0, f1, b0, b1);                                         \
+    if constexpr (R == MU) { own[0] = row[0]; own[1] = row[1]; own[2] = row[2]; }      \
+    else {                                                                             \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) part[R][MU < R ? MU : MU - 1][c][lane] = mk2(row[c].re, row[c].im); \
+    }
+    LQ_ROW(0) LQ_ROW(1) LQ_ROW(2) LQ_ROW(3)
+#undef LQ_ROW
+}
+
+template <bool DAG, bool R12>
+__global__ __launch_bounds__(256, 4) void wilson_dirsplit4(KArgs k) {
+    __shared__ real2 part[4][3][3][64];  // [destination wave = spin row][source slot][colour][lane]: 36 KiB
+    __shared__ double red[4];
+    if (upd_done(k)) return;
+    int chunk, p;
+    map_block(k, chunk, p);
+    const int Vh = sp_stride(k.g);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < k.g.Vh;
+    cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    if (valid && k.a != 0.0) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp_off(12, i) + (size_t)(3 * w + cc) * Vh);
+    }
+    cd own[3];
+    switch (w) {
+    case 0: dirsplit4_body<0, DAG, R12>(k, p, i, lane, valid, part, own); break;
+    case 1: dirsplit4_body<1, DAG, R12>(k, p, i, lane, valid, part, own); break;
+    case 2: dirsplit4_body<2, DAG, R12>(k, p, i, lane, valid, part, own); break;
+    default: dirsplit4_body<3, DAG, R12>(k, p, i, lane, valid, part, own); break;
+    }
+    __syncthreads();
+    real nrm = 0.0;
+    if (valid) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            // (s0 + s1) + (s2 + s3) with s_w the partial of wave w: the own one from registers, the others from their slots
+            cd sv[4];
+#pragma unroll
+            for (int src = 0; src < 4; src++) {
+                if (src == w) sv[src] = own[cc];
+                else { const real2 t = part[w][src < w ? src : src - 1][cc][lane]; sv[src] = mk(t.x, t.y); }
+            }
+            cd s = mk((sv[0].re + sv[1].re) + (sv[2].re + sv[3].re), (sv[0].im + sv[1].im) + (sv[2].im + sv[3].im));
+            cd v = k.b * s;
+            v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
+            emit(k, p, (size_t)(3 * w + cc) * Vh + sp_off(12, i), v, nrm);
+        }
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ Wilson, hop-split
 // Variant 2 ("hopsplit"): 8 waves per 64 sites, one per hop (direction x sign).  Every wave issues its 21 loads
 // (12 spinor + 9 link; 15 for the t hops) as ONE burst -- a workgroup has a single memory round trip -- and leaves the
@@ -506,19 +850,6 @@ __device__ inline cd combine_comp(const real2 (*half)[6][64], int lane) {
     add_hop<2, SF, ROW>(s0, half, 4, c, lane); add_hop<2, -SF, ROW>(s1, half, 5, c, lane);
     add_hop<3, SF, ROW>(s0, half, 6, c, lane); add_hop<3, -SF, ROW>(s1, half, 7, c, lane);
     return s0 + s1;
-}
-
-typedef real v2d __attribute__((ext_vector_type(2)));
-__device__ inline void load_link_nt(cd (&u)[9], const real2* __restrict__ U, int Vh) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(U + (size_t)j * Vh));
-        u[j] = mk(v.x, v.y);
-    }
-}
-__device__ inline void st_nt(real2* p, cd v) {
-    v2d t = {v.re, v.im};
-    __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(p));
 }
 
 template <int MU, int S>
@@ -588,36 +919,21 @@ __device__ inline void hop_half(cd (&chi0)[3], cd (&chi1)[3], const KArgs& k, in
         const int Us = glink_stride(k.g);
         cd h0[3], h1[3], u[9];
         constexpr bool USE_BUF = false;   // measured: buffer-addressed loads are ~5 % slower than flat loads here (profiles/)
-        if (USE_BUF && k.dbg == 0 && !(BWD && NTG)) {
+        if (USE_BUF && !(BWD && NTG)) {
             cd sp[MU < 3 ? 12 : 6];
             const int pp = BWD ? 1 - p : p;
             load_hop_regs<MU, S>(sp, u, k.in[1 - p], k.gauge, gauge_elems(k.g), (unsigned)Vh, (unsigned)Us, (unsigned)sp_off(12, nb),
                                  (unsigned)glink_off(k.g, pp, MU, BWD ? nb : i));
             project_regs<MU, S>(h0, h1, sp);
         } else {
-            if (MU == 0 && k.dbg == 1) {
-#pragma unroll
-                for (int cc = 0; cc < 3; cc++) { h0[cc] = mk(1.0 + nb, 2.0); h1[cc] = mk(3.0, 4.0 + nb); }
-            } else {
-                project<MU, S>(h0, h1, psi, Vh);
-            }
-            if (MU == 0 && k.dbg == 2) {
-#pragma unroll
-                for (int j = 0; j < 9; j++) u[j] = mk(1.0 + j, nb);
-            } else {
-                // the backward hop is the LAST of the two uses of a link: optionally load it non-temporally
-                if constexpr (BWD && NTG) load_link_nt(u, U, Us); else load_link(u, U, Us);
-            }
+            project<MU, S>(h0, h1, psi, Vh);
+            // the backward hop is the LAST of the two uses of a link: optionally load it non-temporally
+            if constexpr (BWD && NTG) load_link_nt(u, U, Us); else load_link(u, U, Us);
         }
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) { h0[cc] = sign * h0[cc]; h1[cc] = sign * h1[cc]; }
-        if (k.dbg == 3) {
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) { chi0[cc] = h0[cc] + u[cc] + u[3 + cc]; chi1[cc] = h1[cc] + u[6 + cc]; }
-        } else {
-            su3_mv<BWD>(chi0, u, h0);
-            su3_mv<BWD>(chi1, u, h1);
-        }
+        su3_mv<BWD>(chi0, u, h0);
+        su3_mv<BWD>(chi1, u, h1);
     }
 }
 
@@ -829,11 +1145,12 @@ __global__ __launch_bounds__(512, 4) void wilson_hopsplit_persist(KArgs k, int n
 // ------------------------------------------------------------------------------------------ staggered
 template <bool R12 = false>
 __device__ inline void stag_hop(cd (&acc)[3], const real2* __restrict__ psi, const real2* __restrict__ U, int Vh, int Us,
-                                real coef, bool adj) {
+                                real coef, bool adj, bool nt = false) {
     cd h[3], u[9], chi[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) h[c] = coef * ld(psi + (size_t)c * Vh);
-    if constexpr (R12) load_link12(u, U); else load_link(u, U, Us);
+    if constexpr (R12) load_link12(u, U, nt);
+    else { if (nt) load_link_nt(u, U, Us); else load_link(u, U, Us); }
     if (adj) su3_mv<true>(chi, u, h); else su3_mv<false>(chi, u, h);
 #pragma unroll
     for (int c = 0; c < 3; c++) acc[c] = acc[c] + chi[c];
@@ -913,8 +1230,8 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         const real sb = w == 0 ? n.sb[0] : w == 1 ? n.sb[1] : w == 2 ? n.sb[2] : n.sb[3];
         const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(k.g, p, w, i) : k.gauge + glink_off(k.g, p, w, i);
         const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, w, nb) : k.gauge + glink_off(k.g, 1 - p, w, nb);
-        if (sf != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nf), Uf, Vh, Us, eta * sf, false);
-        if (sb != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nb), Ub, Vh, Us, -eta * sb, true);
+        if (sf != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nf), Uf, Vh, Us, eta * sf, false, (k.nt & 2) != 0);
+        if (sb != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nb), Ub, Vh, Us, -eta * sb, true, (k.nt & 1) != 0);
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
@@ -1246,7 +1563,10 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     const int plane = c->geom.XH * c->geom.L[1];
     k.cpp = (plane % TB == 0) ? plane / TB : 0;
     k.ysplit = 1;
+#ifdef LQCD_ABLATE
     k.dbg = c->tun.dbg;
+#endif
+    k.nt = (c->tun.nt_gauge & 3) | (c->tun.nt_store ? 4 : 0);
     const int ys = c->tun.xcd_ysplit;
     if (ys > 1 && k.cps > 0 && k.cpp > 0 && k.cpp % ys == 0 && k.nsub % ys == 0 && c->geom.L[2] % (k.nsub / ys) == 0) k.ysplit = ys;
     k.cpr = k.cps > 0 ? k.cps / k.nsub : 1;
@@ -1264,7 +1584,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
 }
 
 static bool use_dirsplit(lqcd_ctx_s* c, int kind, real r) {   // variants 1/2/3 work on 64-site chunks
-    if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 3)) return false;
+    if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 5)) return false;
     return kind == LQCD_STAGGERED || r == 1.0;   // Wilson: the split kernels use the r = 1 projectors
 }
 static int persist_grid(lqcd_ctx_s* c, int nvirt) {
@@ -1303,6 +1623,24 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         if (s.kind == LQCD_STAGGERED) {
             if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
+        } else if (c->tun.dslash_variant == 5 && !k.clover) {
+            dim3 grid(k.nblocks), block(256);
+            if (k.gauge12) {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit4<true, true>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit4<false, true>), grid, block, pad, c->stream, k);
+            } else {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit4<true, false>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit4<false, false>), grid, block, pad, c->stream, k);
+            }
+        } else if (c->tun.dslash_variant == 4 && !k.clover) {
+            dim3 grid(k.nblocks), block(256);
+            if (k.gauge12) {
+                if (s.dagger) hipLaunchKernelGGL((wilson_lanesplit<true, true>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_lanesplit<false, true>), grid, block, pad, c->stream, k);
+            } else {
+                if (s.dagger) hipLaunchKernelGGL((wilson_lanesplit<true, false>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_lanesplit<false, false>), grid, block, pad, c->stream, k);
+            }
         } else if (c->tun.dslash_variant == 3) {
             dim3 grid(persist_grid(c, k.nblocks)), block(512);
             if (s.dagger) hipLaunchKernelGGL((wilson_hopsplit_persist<true>), grid, block, pad, c->stream, k, k.nblocks);
