@@ -144,7 +144,8 @@ int lqcd_op_destroy(lqcd_op_t op);
  * sigma_{mu nu} F_{mu nu}.  The term follows the links of the operator's gauge field; csw = 0 switches it off.  Supported by
  * lqcd_op_apply / _DdagD, the CG, BiCGStab, even-odd BiCGStab (inverse clover blocks), multi-shift and mixed-precision solvers,
  * also on a partitioned lattice (RCCL ranks; the clover sums are built with two matrix-face exchanges), and by the fermion
- * force (lqcd_fermion_force / lqcd_calc_UdSfdU add the derivative of the clover term) on an unpartitioned lattice. */
+ * force (lqcd_fermion_force / lqcd_calc_UdSfdU add the derivative of the clover term; on a partitioned lattice through a
+ * halo-extended copy of the links and Lambda matrices, RCCL ranks only). */
 int lqcd_op_set_clover(lqcd_op_t op, double csw);
 int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g);   /* the D(U) rebind idiom (unusedfiles/measure_chiral_condensate.jl:173) */
 /* mul!(y, D, x) / mul!(y, D', x) on FULL spinors */
@@ -173,7 +174,8 @@ int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int d
                                                                   * Schur complement uses the inverse clover blocks, built on first use) */
 /* shiftedcg(vec_x, vec_beta, x, A, b) of the RHMC path (README.md:132; test/test_Nf2.toml:8, test_Nf3.toml:8):
  * (D^+D + sigma_j) xs[j] = b for all j < ns, plus the unshifted solution x0 (may be NULL), from ONE Krylov space.
- * Zero initial guesses; stops when rr * max(1, max_j zeta_j^2) < eps. */
+ * Zero initial guesses; stops when the residual of the UNSHIFTED system obeys |r|^2 < eps (every shifted residual zeta_j^2 |r|^2 is
+ * smaller; a shift whose own residual has reached eps is frozen earlier). */
 int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
                              double eps, int maxiter, int* iters, double* final_rr);
 /* mixed-precision CG on D^+D (SURVEY.md 8(b) "later solve_mixed_cg", 8(f) rank 3; BASELINE configs[4]): fp32 inner CG (fp32
@@ -228,6 +230,18 @@ int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U,
 int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U */
 int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed);               /* gauss_distribution!(p) (src/md/standardMD.jl:86); keyed by GLOBAL site */
 int lqcd_momentum_action(lqcd_gauge_t P, double* K);                     /* p.p/2 (standardHMC.jl:49) */
+
+/* Single-direction forms: the reference's unchanged callers hold its Vector of link fields one direction at a time -- U[mu], p[mu]
+ * and temporary link fields (src/md/AbstractMD.jl:78-135).  A "link field" here is (gauge-shaped field, direction slot 0..3); nothing
+ * is copied to form one.  The four-direction calls above are the fused fast path of the same arithmetic. */
+int lqcd_link_copy(lqcd_gauge_t dst, int mu_dst, lqcd_gauge_t src, int mu_src);          /* substitute_U!(U[mu], W) (AbstractMD.jl:93) */
+int lqcd_link_scaled_copy(lqcd_gauge_t dst, int mu_dst, double s, lqcd_gauge_t src, int mu_src);  /* dst = s * src; s = -1 turns the force field G of lqcd_calc_UdSfdU into the
+                                                                                           * "U dS_f/dU" = -G the caller's factor = -eps dtau expects (AbstractMD.jl:127-132) */
+int lqcd_link_exp(lqcd_gauge_t E, int mu_e, double t, lqcd_gauge_t P, int mu_p);          /* exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): E = exp(t P) */
+int lqcd_link_mul(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_gauge_t B, int mu_b);   /* mul!(W, expU, U[mu]), mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109) */
+int lqcd_link_add_ta(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t G, int mu_g);  /* Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131) */
+int lqcd_link_staple(lqcd_gauge_t out, int mu_out, lqcd_gauge_t U, int mu, double beta);  /* calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108) for the plaquette
+                                                                                           * action of universe.jl:92-95: (beta/2) * sum of the six staples.  Collective on a partitioned lattice */
 
 /* the SURVEY.md 8(d) protocol: every application between its own HIP events, median and mean over reps */
 int lqcd_bench_dslash_median(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps, double* median_ms,

@@ -326,7 +326,7 @@ __device__ __forceinline__ bool site_of_thread(const Geom& g, int& p, int& i) {
     p = blockIdx.x & 1; i = (blockIdx.x >> 1) * 64 + threadIdx.x;
     return i < g.Vh;
 }
-// op 0: C = A (substitute_U!)   op 1: C = exp(t A) (exptU!)   op 2: C = A B (mul!)   op 3: C += t * TA(A) (Traceless_antihermitian_add!)
+// op 0: C = t A (substitute_U! with t = 1)   op 1: C = exp(t A) (exptU!)   op 2: C = A B (mul!)   op 3: C += t * TA(A) (Traceless_antihermitian_add!)
 template <int OP>
 __global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* __restrict__ C, int mc, const double2* __restrict__ A, int ma,
                                                      const double2* __restrict__ B, int mb, double t) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* __restrict
     double2* o = C + glink_off(g, p, mc, i);
     if constexpr (OP == 0) {
 #pragma unroll
-        for (int e = 0; e < 9; e++) r[e] = a[e];
+        for (int e = 0; e < 9; e++) r[e] = mk(t * a[e].re, t * a[e].im);
     } else if constexpr (OP == 1) {
         exp_m3(r, a, t);
     } else if constexpr (OP == 2) {
@@ -499,7 +499,13 @@ static int link_op(lqcd_gauge_t C, int mc, lqcd_gauge_t A, int ma, lqcd_gauge_t 
 extern "C" int lqcd_link_copy(lqcd_gauge_t dst, int mu_dst, lqcd_gauge_t src, int mu_src) {
     LQCHK(link_args(dst, mu_dst, src, mu_src, "lqcd_link_copy"));
     if (dst == src && mu_dst == mu_src) return LQCD_OK;
-    return link_op<0>(dst, mu_dst, src, mu_src, nullptr, 0, 0.0);
+    return link_op<0>(dst, mu_dst, src, mu_src, nullptr, 0, 1.0);
+}
+// dst[mu_dst] = s * src[mu_src]: hands one direction of a force field to the reference's caller in ITS sign convention
+// (calc_UdSfdU! fills "U dS_f/dU" = -G, P_update_fermion! adds factor = -eps dtau times its TA part: AbstractMD.jl:127-132)
+extern "C" int lqcd_link_scaled_copy(lqcd_gauge_t dst, int mu_dst, double s, lqcd_gauge_t src, int mu_src) {
+    LQCHK(link_args(dst, mu_dst, src, mu_src, "lqcd_link_scaled_copy"));
+    return link_op<0>(dst, mu_dst, src, mu_src, nullptr, 0, s);
 }
 // exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): E[mu_e] = exp(t P[mu_p]), the Taylor-Horner series of lqcd_gauge_exp_update
 extern "C" int lqcd_link_exp(lqcd_gauge_t E, int mu_e, double t, lqcd_gauge_t P, int mu_p) {

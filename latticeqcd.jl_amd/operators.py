@@ -132,6 +132,24 @@ class Gaugefields:
         check(_l.lib().lqcd_gauge_download(self._h, _ptr(U), int(layout)))
         return U
 
+    # -- the reference indexes its Vector of link fields one direction at a time: U[mu], p[mu], mu = 1..Dim (AbstractMD.jl:90-93)
+    def __getitem__(self, mu):
+        if not 1 <= int(mu) <= 4:
+            raise IndexError("link fields are indexed mu = 1..4 like the reference's U[mu]")
+        return LinkView(self, int(mu) - 1)
+
+    def __len__(self):
+        return 4
+
+    def similar(self):
+        return Gaugefields(self.lattice)
+
+    def __mul__(self, other):
+        """md.p * md.p (standardHMC.jl:49) for a momentum field: sum_a p_a^2 = 2 K."""
+        if other is not self:
+            raise LQCDError(_l.ERR_UNSUPPORTED, "only p * p (the kinetic term of standardHMC.jl:49) is defined")
+        return 2.0 * momentum_action(self)
+
     def close(self):
         if self._h:
             _l.lib().lqcd_gauge_destroy(self._h)
@@ -142,6 +160,19 @@ class Gaugefields:
             self.close()
         except Exception:
             pass
+
+
+class LinkView:
+    """One direction of a gauge-shaped device field: what the reference's callers hold as U[mu], p[mu] or a temporary link field
+    (AbstractMD.jl:78-135).  Nothing is copied: the C ABI's single-direction entry points take (field, direction slot)."""
+
+    def __init__(self, field, slot):
+        self.field, self.slot = field, slot
+        self.NC = 3
+        self.lattice = field.lattice
+
+    def download(self):
+        return self.field.download()[self.slot]
 
 
 def Initialize_Gaugefields(NC, Nwing, NX, NY, NZ, NT, condition="cold", lattice=None, randomseed=111, **kw):
@@ -335,8 +366,16 @@ class DdagD_operator:
         self.eps_CG, self.MaxCGstep = D.eps_CG, D.MaxCGstep
 
 
+def _mul_links(C_, A, B):
+    """mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): 3x3 products site by site."""
+    check(_l.lib().lqcd_link_mul(C_.field._h, C_.slot, A.field._h, A.slot, B.field._h, B.slot))
+    return C_
+
+
 def mul_(y, A, x):
-    """LinearAlgebra.mul!(y, A, x) for A = D, D' or D'D."""
+    """LinearAlgebra.mul!(y, A, x) for A = D, D' or D'D; on link fields mul!(W, A, B) = the site-wise 3x3 product."""
+    if isinstance(y, LinkView):
+        return _mul_links(y, A, x)
     if isinstance(A, DdagD_operator):
         check(_l.lib().lqcd_op_apply_DdagD(A.D._h, y._h, x._h))
     else:
@@ -443,35 +482,68 @@ class FermiAction:
         self.evensite = kind == STAGGERED and nf == 4
         # D'D carries 2 Wilson flavours / 8 staggered tastes: anything else is S_f = eta' (D'D)^(-Nf/n0) eta
         n0 = 2 if kind == WILSON else 8
-        self.rational = (kind == WILSON and nf != 2) or (kind == STAGGERED and nf not in (4, 8))
+        # "force_rational": the rational form also where an exact one exists (staggered Nf = 4 / 8, Wilson Nf = 2) -- the statistical
+        # cross-check of the rational path against the exact action (tests/test_gpu_hmc_statistics.py)
+        self.rational = (kind == WILSON and nf != 2) or (kind == STAGGERED and nf not in (4, 8)) or bool(params.get("force_rational", False))
+        if self.rational:
+            self.evensite = False
         if self.rational:
             if not (0 < nf < n0):
                 raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Nf = {nf} outside (0, {n0}) for this operator")
             from . import rational
-            if "rhmc_lambda_min" in params and "rhmc_lambda_max" in params:
+            self._explicit_interval = "rhmc_lambda_min" in params and "rhmc_lambda_max" in params
+            self._lanczos_steps = int(params.get("rhmc_lanczos_steps", 60))
+            self._fit_tols = (float(params.get("rhmc_tol_action", 1e-12)), float(params.get("rhmc_tol_MD", 1e-8)))
+            self.interval_refits = 0
+            if self._explicit_interval:
                 lo, hi = float(params["rhmc_lambda_min"]), float(params["rhmc_lambda_max"])
             elif kind == STAGGERED:       # D'D = m^2 - D_hop^2 with |D_hop| <= 4
                 lo, hi = D.km * D.km * (1.0 - 1e-9), (D.km * D.km + 16.0) * (1.0 + 1e-9)
             else:                         # Wilson(-clover): no analytic lower bound -- Lanczos estimate on the current links with a margin
                 tmin, tmax = estimate_spectrum(DdagD_operator(D), steps=int(params.get("rhmc_lanczos_steps", 60)))
                 lo, hi = float(params.get("rhmc_lambda_min", 0.5 * tmin)), float(params.get("rhmc_lambda_max", 1.2 * tmax))
-            self.spectral_interval = (lo, hi)
-            tol_a, tol_md = float(params.get("rhmc_tol_action", 1e-12)), float(params.get("rhmc_tol_MD", 1e-8))
             self.alpha = nf / float(n0)
-
-            def fit(alpha, tol):        # wide intervals (small masses) cost digits in double precision: loosen until the fit verifies
-                while True:
-                    try:
-                        return rational.inverse_power_partial_fractions(alpha, lo, hi, tol)[:3]
-                    except RuntimeError:
-                        if tol > 1e-7:
-                            raise
-                        tol *= 10.0
-            self.rhmc_action = fit(self.alpha, tol_a)                 # x^(-Nf/n0)
-            self.rhmc_MD = fit(self.alpha, tol_md)
-            self.rhmc_sampling = fit(1.0 - 0.5 * self.alpha, tol_a)   # x^(alpha/2) = x * x^(alpha/2 - 1)
+            self._fit(lo, hi)
         self._half = Fermionfields(D.lattice, kind, EVEN) if self.evensite else None
         self._temporary_fermionfields = [Fermionfields(D.lattice, kind) for _ in range(2)]   # standardMD.jl:50-51
+
+    def _fit(self, lo, hi):
+        from . import rational
+        self.spectral_interval = (lo, hi)
+        tol_a, tol_md = self._fit_tols
+
+        def fit(alpha, tol):        # wide intervals (small masses) cost digits in double precision: loosen until the fit verifies
+            while True:
+                try:
+                    return rational.inverse_power_partial_fractions(alpha, lo, hi, tol)[:3]
+                except RuntimeError:
+                    if tol > 1e-7:
+                        raise
+                    tol *= 10.0
+        self.rhmc_action = fit(self.alpha, tol_a)                 # x^(-Nf/n0)
+        self.rhmc_MD = fit(self.alpha, tol_md)
+        self.rhmc_sampling = fit(1.0 - 0.5 * self.alpha, tol_a)   # x^(alpha/2) = x * x^(alpha/2 - 1)
+
+    def check_interval(self, U):
+        """Wilson(-clover) rational action: the spectrum of D'D has no analytic bound and drifts along the HMC stream, and partial
+        fractions used outside their fit interval silently bias S_f, the heat bath and the force.  Called at the heat bath and at
+        every evaluation of the action: a Lanczos run on the CURRENT links.  An interval that came from the estimate (margins 0.5 /
+        1.2 at the fit; the smallest Ritz value converges from above) is refitted as soon as its lower edge exceeds 0.6 x the smallest
+        Ritz value or its upper edge falls below 1.1 x the largest; an interval the caller fixed with rhmc_lambda_min /
+        rhmc_lambda_max raises once a Ritz value lies outside it."""
+        if not (self.rational and self.D.kind == WILSON):
+            return
+        tmin, tmax = estimate_spectrum(DdagD_operator(self.D(U)), steps=self._lanczos_steps)
+        lo, hi = self.spectral_interval
+        if self._explicit_interval:
+            if lo <= tmin and tmax <= hi:
+                return
+            raise LQCDError(_l.ERR_ARG, f"FermiAction: the spectrum of D'D on the current links, Ritz values [{tmin:.3e}, {tmax:.3e}], is not inside "
+                                        f"the fit interval [{lo:.3e}, {hi:.3e}] given by rhmc_lambda_min / rhmc_lambda_max")
+        if lo <= 0.6 * tmin and hi >= 1.1 * tmax:
+            return
+        self._fit(min(lo, 0.4 * tmin), max(hi, 1.25 * tmax))
+        self.interval_refits += 1
 
     def close(self):
         for f in self._temporary_fermionfields:
@@ -541,6 +613,7 @@ def sample_pseudofermions_(eta, U, fa, xi):
     """sample_pseudofermions!(eta, U, fa, xi) (standardMD.jl:96): eta = D' xi (restricted to the even sites for 4 staggered tastes,
     in which case the action at the start of a trajectory is evaluate_FermiAction(fa, U, eta), not xi'xi)."""
     if fa.rational:        # eta = (D'D)^(Nf/16) xi, so that eta' (D'D)^(-Nf/8) eta = xi' xi
+        fa.check_interval(U)
         D = fa.D(U)
         _rational_apply(D, fa._temporary_fermionfields[0], xi, fa.rhmc_sampling)
         mul_(eta, DdagD_operator(D), fa._temporary_fermionfields[0])
@@ -558,6 +631,7 @@ def evaluate_FermiAction(fa, U, eta, return_info=False):
     D = fa.D(U)
     X, Y = fa._temporary_fermionfields
     if fa.rational:
+        fa.check_interval(U)
         it = _rational_apply(D, X, eta, fa.rhmc_action)
         S = dot(eta, X).real
         return (S, it) if return_info else S
@@ -568,7 +642,18 @@ def evaluate_FermiAction(fa, U, eta, return_info=False):
 
 def calc_UdSfdU_(UdSfdU, fa, U, eta):
     """calc_UdSfdU!(UdSfdU, fa, U, eta) (AbstractMD.jl:129): UdSfdU[mu](n) = "U dS_f/dU" with
-    dS_f/d eps under U_mu(n) -> exp(i eps T) U_mu(n) equal to -2 Im tr(T UdSfdU_mu(n)).  UdSfdU is a Gaugefields-shaped field."""
+    dS_f/d eps under U_mu(n) -> exp(i eps T) U_mu(n) equal to -2 Im tr(T UdSfdU_mu(n)).  UdSfdU is a Gaugefields-shaped field, or
+    the reference's Vector of Dim temporary link fields (get_temp(temps, Dim), AbstractMD.jl:123): the sweep then writes a field
+    owned by the action and each direction is handed over with one device copy IN THE CALLER'S SIGN CONVENTION: the reference
+    adds factor = -eps dtau times the traceless anti-Hermitian part (AbstractMD.jl:127-132), i.e. its "U dS_f/dU" is -G of the C ABI
+    (just as its U dS_g/dU = U[mu] calc_dSdUmu! is -NC times the gauge force field G of lqcd_gauge_force)."""
+    if isinstance(UdSfdU, (list, tuple)):
+        if getattr(fa, "_force_field", None) is None:
+            fa._force_field = Gaugefields(fa.D.lattice)
+        r = calc_UdSfdU_(fa._force_field, fa, U, eta)
+        for mu, view in enumerate(UdSfdU):
+            check(_l.lib().lqcd_link_scaled_copy(view.field._h, view.slot, C.c_double(-1.0), fa._force_field._h, mu))
+        return r
     D = fa.D(U)
     if fa.rational:
         a0, res, poles = fa.rhmc_MD
@@ -587,15 +672,108 @@ def fermion_force_(UdSfdU, D, X, Y, scale=1.0, accumulate=False):
 
 # ------------------------------------------------------------------------------------ gauge side of the MD step
 def substitute_U_(dst, src):
-    """substitute_U!(Uold, U) (standardHMC.jl:45)."""
+    """substitute_U!(Uold, U) (standardHMC.jl:45) on the Vector of link fields, substitute_U!(U[mu], W) (AbstractMD.jl:93) on one."""
+    if isinstance(dst, LinkView):
+        check(_l.lib().lqcd_link_copy(dst.field._h, dst.slot, src.field._h, src.slot))
+        return dst
     check(_l.lib().lqcd_gauge_copy(dst._h, src._h))
     return dst
 
 
-def evaluate_GaugeAction(U, beta):
-    """S_g = -(beta/3) sum_plaq Re tr U_p  (the '-evaluate_GaugeAction/NC' of standardHMC.jl:50)."""
+class GaugeAction:
+    """GaugeAction(U) + push!(gauge_action, beta/2, plaqloop) (universe.jl:88-96): the plaquette action of the reference's runs.
+    Owns the temporary link fields P_update! / U_update! borrow (get_temporary_gaugefields, AbstractMD.jl:79,101,122)."""
+
+    def __init__(self, U):
+        self.lattice = U.lattice
+        self.beta_inp = 0.0
+        self._temps = Temporalfields(U.lattice)
+
+    def push_(self, beta_inp, loops):
+        if loops != make_loops_fromname("plaquette") + make_loops_fromname("plaquette", adjoint=True):
+            raise LQCDError(_l.ERR_UNSUPPORTED, "only the plaquette loop and its adjoint (universe.jl:92-95) are supported on the HIP path")
+        self.beta_inp += float(beta_inp)
+        return self
+
+    @property
+    def beta(self):            # beta/2 on the loop and on its adjoint
+        return 2.0 * self.beta_inp
+
+
+def make_loops_fromname(name, Dim=4, adjoint=False):
+    """make_loops_fromname("plaquette", Dim=Dim) (universe.jl:92); append!(plaqloop, plaqloop') adds the adjoint loops."""
+    if name != "plaquette":
+        raise LQCDError(_l.ERR_UNSUPPORTED, f"loop {name} is not supported")
+    return [("plaquette-adjoint" if adjoint else "plaquette", mu, nu) for mu in range(1, Dim + 1) for nu in range(mu + 1, Dim + 1)]
+
+
+class Temporalfields:
+    """Gaugefields.Temporalfields_module: a pool of single-direction link fields, get_temp / unused! (AbstractMD.jl:80-97)."""
+
+    def __init__(self, lattice):
+        self.lattice = lattice
+        self._fields, self._free, self._used = [], [], set()
+
+    def _grow(self):
+        f = Gaugefields(self.lattice)
+        self._fields.append(f)
+        base = 4 * (len(self._fields) - 1)
+        self._free.extend(range(base, base + 4))
+
+    def _view(self, it):
+        return LinkView(self._fields[it // 4], it % 4)
+
+
+def get_temporary_gaugefields(gauge_action):
+    return gauge_action._temps
+
+
+def get_temp(temps, n=None):
+    """get_temp(temps) -> (field, index); get_temp(temps, Dim) -> (fields, indices) (AbstractMD.jl:80-83,123)."""
+    def one():
+        if not temps._free:
+            temps._grow()
+        it = temps._free.pop(0)
+        temps._used.add(it)
+        return temps._view(it), it
+    if n is None:
+        return one()
+    pairs = [one() for _ in range(n)]
+    return [v for v, _ in pairs], [i for _, i in pairs]
+
+
+def unused_(temps, it):
+    for i in (it if isinstance(it, (list, tuple)) else [it]):
+        temps._used.discard(i)
+        temps._free.append(i)
+    temps._free.sort()
+
+
+def initialize_TA_Gaugefields(U):
+    """initialize_TA_Gaugefields(U) (standardMD.jl:34): the traceless anti-Hermitian momenta p[mu], one device object."""
+    return Gaugefields(U.lattice)
+
+
+def exptU_(expU, t, p_mu, temps=None):
+    """exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): expU = exp(t p[mu]) site by site."""
+    check(_l.lib().lqcd_link_exp(expU.field._h, expU.slot, C.c_double(t), p_mu.field._h, p_mu.slot))
+    return expU
+
+
+def calc_dSdUmu_(dSdUmu, gauge_action, mu, U):
+    """calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): beta_inp * (sum of the staples of U[μ]), μ = 1..4."""
+    check(_l.lib().lqcd_link_staple(dSdUmu.field._h, dSdUmu.slot, U._h, int(mu) - 1, C.c_double(gauge_action.beta)))
+    return dSdUmu
+
+
+def evaluate_GaugeAction(a, b):
+    """Reference form evaluate_GaugeAction(gauge_action, U) (standardHMC.jl:50; S_g = -that/NC), and the direct
+    evaluate_GaugeAction(U, beta) = S_g = -(beta/3) sum_plaq Re tr U_p."""
     s = C.c_double(0)
-    check(_l.lib().lqcd_gauge_action(U._h, C.c_double(beta), C.byref(s)))
+    if isinstance(a, GaugeAction):
+        check(_l.lib().lqcd_gauge_action(b._h, C.c_double(a.beta), C.byref(s)))
+        return -3.0 * s.value
+    check(_l.lib().lqcd_gauge_action(a._h, C.c_double(b), C.byref(s)))
     return s.value
 
 
@@ -606,7 +784,10 @@ def gauge_force_(G, U, beta):
 
 
 def Traceless_antihermitian_add_(p, factor, G):
-    """Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131)."""
+    """Traceless_antihermitian_add!(p[mu], factor, temp) (AbstractMD.jl:110,131) on one direction; on whole fields all four at once."""
+    if isinstance(p, LinkView):
+        check(_l.lib().lqcd_link_add_ta(p.field._h, p.slot, C.c_double(factor), G.field._h, G.slot))
+        return p
     check(_l.lib().lqcd_momentum_add_ta(p._h, C.c_double(factor), G._h))
     return p
 

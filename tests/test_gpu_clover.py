@@ -164,3 +164,27 @@ def test_rccl_self_partition_clover(lq, orc):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "RCCL_SELF_CLOVER_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_changing_csw_invalidates_the_inverse_clover_blocks(lq, orc):
+    """lqcd_op_set_clover(csw2) on an operator that already holds A^-1 for csw1 (same links) must rebuild A^-1: the
+    even-odd solver would otherwise converge silently to the solution of the wrong Schur system."""
+    import ctypes as C
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 801)
+    U = lq.Gaugefields(lat).upload(Uh)
+    psi = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 802)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    sol, y = x.similar(), x.similar()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": 1.0, "boundarycondition": BC,
+                                    "eps_CG": 1e-19, "method_CG": "bicgstab_evenodd"})
+    lq.solve_DinvX_(sol, D, x)                                   # builds A^-1 for csw = 1
+    lq.lib.check(lq.lib.lib().lqcd_op_set_clover(D._h, C.c_double(1.7)))      # same links, new coefficient
+    lq.clear_fermion_(sol)
+    lq.solve_DinvX_(sol, D, x)
+    xo, _, _, st = orc.wilson_clover_bicgstab_eo(Uh, orc.clover_build(Uh, L, KAPPA, 1.7), psi, L, KAPPA, 1.0, BC, False, eps=1e-19)
+    assert st == 0 and rel_err(sol.download(), xo) < 1e-9
+    lq.mul_(y, D, sol)                                            # true residual with the csw = 1.7 operator
+    lq.add_fermion_(y, -1.0, x)
+    assert lq.dot(y, y).real < 1e-17

@@ -139,3 +139,23 @@ def test_mixed_cg_full_size_is_faster_than_fp64(gpu):
     assert res["mixed"][0] < res["fp64"][0]
     for o in (x, b, D, U):
         o.close()
+
+
+def test_mixed_cg_on_non_unitary_links_uses_the_18_real_inner_operator(gpu, orc):
+    """with links that fail the unitarity check the fp32 inner operator must read all 18 reals like the fp64 one (a
+    rebuilt third row would differ by O(1) and every outer step would stall into the fp64 fall-back)."""
+    lq = gpu
+    L = (4, 4, 4, 8)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 131) * (1.0 + 0.05 * orc.gaussian_spinor((4, L[3], L[2], L[1], L[0], 3, 3), 133).real)   # not SU(3)
+    Ud = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": 0.12, "boundarycondition": BC, "eps_CG": 1e-18})
+    b_h = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 132)
+    b = lq.Fermionfields(lat, lq.WILSON).upload(b_h)
+    x = b.similar()
+    A = lq.DdagD_operator(D)
+    it, outer, rr = lq.solve_mixed_DinvX_(x, A, b, return_info=True)
+    xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, Uh, b_h, L, 0.12, 1.0, BC, eps=1e-18)
+    assert st == 0 and rr < 1e-18 and rel_err(x.download(), xo) < 1e-8
+    assert lat.get_param("recon_active") == 0
+    assert outer >= 2 and it < 3 * ito + 20          # defect correction converges in fp32 steps: no stall, no fp64 fall-back

@@ -1,0 +1,239 @@
+"""The reference's UNCHANGED callers, transliterated line by line on top of the per-direction interface they really use
+(U[mu], p[mu], one temporary link field at a time), must reproduce the fused four-direction trajectory of tests/test_gpu_md.py.
+
+Transliterated (Julia `!` -> `_`, `μ = 1:Dim` kept 1-based, everything else verbatim):
+  U_update!, P_update!, P_update_fermion!        /root/reference/src/md/AbstractMD.jl:78-135
+  StandardMD, initialize_MD!, runMD_QPQ_sw!      /root/reference/src/md/standardMD.jl:5-166
+  update!(::StandardHMC)                         /root/reference/src/updates/standardHMC.jl:41-91
+  the construction of gauge_action / fermi_action  /root/reference/src/system/universe.jl:88-138
+The only liberties: the random numbers (the device generators are counter based and take a seed; the accept test draws from
+numpy) -- the reference's own RNG stream is not reproducible outside Julia either."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+from test_gpu_md import BC, BETA, KAPPA, DeviceHMC
+
+pytestmark = pytest.mark.gpu
+Dim = 4
+
+
+class StandardMD:
+    """struct StandardMD + its constructor (standardMD.jl:5-80)."""
+
+    def __init__(self, lq, U, gauge_action, quench, dtau, MDsteps, fermi_action=None, QPQ=True, SextonWeingargten=False, Nsw=2):
+        self.lq = lq
+        self.p = lq.initialize_TA_Gaugefields(U)      # p = initialize_TA_Gaugefields(U)
+        if quench:
+            self.eta = self.xi = None
+            if SextonWeingargten:
+                raise RuntimeError("The quench update does not need the SextonWeingargten method. Put SextonWeingargten = false")
+        elif fermi_action is None:
+            self.eta = self.xi = None
+        else:
+            self.eta = fermi_action._temporary_fermionfields[0].similar()    # η = similar(fermi_action._temporary_fermionfields[1])
+            self.xi = self.eta.similar()                                      # ξ = similar(η)
+        assert Nsw % 2 == 0, f"Nsw should be even number! now Nsw = {Nsw}"
+        self.gauge_action, self.quench, self.dtau, self.MDsteps = gauge_action, quench, dtau, MDsteps
+        self.QPQ, self.fermi_action, self.SextonWeingargten, self.Nsw = QPQ, fermi_action, SextonWeingargten, Nsw
+        self.seed = 0
+
+
+def U_update_(U, p, eps, md):                                   # AbstractMD.jl:78-98
+    lq = md.lq
+    temps = lq.get_temporary_gaugefields(md.gauge_action)
+    temp1, it_temp1 = lq.get_temp(temps)
+    temp2, it_temp2 = lq.get_temp(temps)
+    expU, it_expU = lq.get_temp(temps)
+    W, it_W = lq.get_temp(temps)
+    for mu in range(1, Dim + 1):
+        lq.exptU_(expU, eps * md.dtau, p[mu], [temp1, temp2])
+        lq.mul_(W, expU, U[mu])
+        lq.substitute_U_(U[mu], W)
+    lq.unused_(temps, it_temp1)
+    lq.unused_(temps, it_temp2)
+    lq.unused_(temps, it_expU)
+    lq.unused_(temps, it_W)
+
+
+def P_update_(U, p, eps, md):                                   # AbstractMD.jl:100-118   p -> p + factor*U*dSdUμ
+    lq = md.lq
+    NC = U[1].NC
+    temps = lq.get_temporary_gaugefields(md.gauge_action)
+    dSdUmu, its_dSdUmu = lq.get_temp(temps)
+    factor = -eps * md.dtau / NC
+    temp1, it_temp1 = lq.get_temp(temps)
+    for mu in range(1, Dim + 1):
+        lq.calc_dSdUmu_(dSdUmu, md.gauge_action, mu, U)
+        lq.mul_(temp1, U[mu], dSdUmu)                          # U*dSdUμ
+        lq.Traceless_antihermitian_add_(p[mu], factor, temp1)
+    lq.unused_(temps, its_dSdUmu)
+    lq.unused_(temps, it_temp1)
+
+
+def P_update_fermion_(U, p, eps, md):                           # AbstractMD.jl:120-135
+    lq = md.lq
+    temps = lq.get_temporary_gaugefields(md.gauge_action)
+    UdSfdUmu, its_UdSfdUmu = lq.get_temp(temps, Dim)
+    factor = -eps * md.dtau
+    lq.calc_UdSfdU_(UdSfdUmu, md.fermi_action, U, md.eta)
+    for mu in range(1, Dim + 1):
+        lq.Traceless_antihermitian_add_(p[mu], factor, UdSfdUmu[mu - 1])
+    lq.unused_(temps, its_UdSfdUmu)
+
+
+def initialize_MD_(U, md):                                      # standardMD.jl:82-101
+    lq = md.lq
+    md.seed += 3
+    lq.gauss_distribution_(md.p, md.seed)                       # gauss_distribution!(md.p)  #initial momentum
+    if not md.quench:
+        lq.gauss_sampling_in_action_(md.xi, U, md.fermi_action, md.seed + 1)
+        lq.sample_pseudofermions_(md.eta, U, md.fermi_action, md.xi)
+
+
+def runMD_QPQ_sw_(U, md):                                       # standardMD.jl:146-166
+    p = md.p
+    for itrj in range(md.MDsteps):
+        for isw in range(md.Nsw // 2):
+            U_update_(U, p, 0.5 / md.Nsw, md)
+            P_update_(U, p, 1.0 / md.Nsw, md)
+            U_update_(U, p, 0.5 / md.Nsw, md)
+        if not md.quench:
+            P_update_fermion_(U, p, 1.0, md)
+        for isw in range(md.Nsw // 2):
+            U_update_(U, p, 0.5 / md.Nsw, md)
+            P_update_(U, p, 1.0 / md.Nsw, md)
+            U_update_(U, p, 0.5 / md.Nsw, md)
+
+
+def runMD_QPQ_(U, md):                                          # standardMD.jl:127-144
+    p = md.p
+    for itrj in range(md.MDsteps):
+        U_update_(U, p, 0.5, md)
+        P_update_(U, p, 1.0, md)
+        if not md.quench:
+            P_update_fermion_(U, p, 1.0, md)
+        U_update_(U, p, 0.5, md)
+
+
+def runMD_(U, md):                                              # standardMD.jl:103-125
+    if md.QPQ:
+        if md.SextonWeingargten:
+            runMD_QPQ_sw_(U, md)
+        else:
+            runMD_QPQ_(U, md)
+    else:
+        raise RuntimeError("PQP update is not transliterated")
+
+
+class StandardHMC:                                              # standardHMC.jl:1-38
+    def __init__(self, lq, U, gauge_action, quench, dtau, MDsteps, fermi_action, SextonWeingargten=False, QPQ=True, Nsw=2, seed=0):
+        self.md = StandardMD(lq, U, gauge_action, quench, dtau, MDsteps, fermi_action, QPQ=QPQ, SextonWeingargten=SextonWeingargten, Nsw=Nsw)
+        self.md.seed = seed
+        self.Uold = U.similar()
+        self.rng = np.random.default_rng(seed)
+        self.dH = []
+
+
+def update_(updatemethod, U):                                   # standardHMC.jl:41-91
+    md = updatemethod.md
+    lq = md.lq
+    NC = U[1].NC
+    Uold = updatemethod.Uold
+    lq.substitute_U_(Uold, U)                                   # previous configuration
+    initialize_MD_(U, md)
+    Sp = md.p * md.p / 2
+    Sg = -lq.evaluate_GaugeAction(md.gauge_action, U) / NC
+    Sold = Sp + Sg
+    if not md.quench:
+        Sfold = lq.dot(md.xi, md.xi).real
+        Sold += Sfold
+    runMD_(U, md)
+    Sp = md.p * md.p / 2
+    Sg = -lq.evaluate_GaugeAction(md.gauge_action, U) / NC
+    Snew = Sp + Sg
+    if not md.quench:
+        Sfnew = lq.evaluate_FermiAction(md.fermi_action, U, md.eta)
+        Snew += Sfnew
+    updatemethod.dH.append(Snew - Sold)
+    accept = np.exp(Sold - Snew) >= updatemethod.rng.random()
+    if not accept:
+        lq.substitute_U_(U, Uold)                               # back to previous configuration
+    return accept
+
+
+def _universe(lq, U, kappa, beta):
+    """universe.jl:88-138: gauge_action = GaugeAction(U); push!(gauge_action, beta/2, plaqloop + plaqloop'); D; FermiAction(D, Dict())."""
+    gauge_action = lq.GaugeAction(U)
+    plaqloop = lq.make_loops_fromname("plaquette", Dim=Dim)
+    plaqloop = plaqloop + lq.make_loops_fromname("plaquette", Dim=Dim, adjoint=True)      # append!(plaqloop, plaqloop')
+    gauge_action.push_(beta / 2, plaqloop)
+    x = lq.Initialize_pseudofermion_fields(U[1], "Wilson", nowing=True)
+    params = {"Dirac_operator": "Wilson", "κ": kappa, "r": 1.0, "faster version": True, "eps_CG": 1e-19, "verbose_level": 2,
+              "MaxCGstep": 3000, "boundarycondition": BC}
+    D = lq.Dirac_operator(U, x, params)
+    fermi_action = lq.FermiAction(D, {})
+    return gauge_action, fermi_action
+
+
+def _fixture(lq):
+    L = (4, 4, 4, 4)
+    Uh = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L)
+    return L, Uh
+
+
+def test_single_direction_entry_points_match_the_fused_ones(lq, orc):
+    """P_update! / U_update! written with U[mu], p[mu] and temporaries (5 single-direction C entry points) = the fused kernels."""
+    L = (8, 4, 6, 4)
+    lat = lq.Lattice(L)
+    Uh, Ph = orc.hot_gauge(L, 31), orc.gaussian_momenta(L, 32)
+    U1, P1 = lq.Gaugefields(lat).upload(Uh), lq.Gaugefields(lat).upload(Ph)
+    U2, P2 = lq.Gaugefields(lat).upload(Uh), lq.Gaugefields(lat).upload(Ph)
+    ga = lq.GaugeAction(U1)
+    ga.push_(BETA / 2, lq.make_loops_fromname("plaquette") + lq.make_loops_fromname("plaquette", adjoint=True))
+
+    class MD:
+        pass
+    md = MD()
+    md.lq, md.gauge_action, md.dtau = lq, ga, 0.05
+    P_update_(U1, P1, 0.3, md)
+    lq.P_update_(U2, P2, 0.3 * 0.05, BETA)
+    assert rel_err(P1.download(), P2.download()) < 1e-14
+    U_update_(U1, P1, 0.7, md)
+    lq.U_update_(U2, P2, 0.7 * 0.05)
+    assert rel_err(U1.download(), U2.download()) < 1e-14
+    # staple alone against the oracle's force:  G = -(beta/6) U * A  and  dSdUmu = (beta/2) A
+    G = lq.Gaugefields(lat)
+    lq.gauge_force_(G, U2, BETA)
+    Gh, U2h = G.download(), U2.download()
+    temps = lq.get_temporary_gaugefields(ga)
+    dS, it = lq.get_temp(temps)
+    T, it2 = lq.get_temp(temps)
+    for mu in range(1, 5):
+        lq.calc_dSdUmu_(dS, ga, mu, U2)
+        lq.mul_(T, U2[mu], dS)
+        assert rel_err(-T.download() / 3.0, Gh[mu - 1]) < 1e-13
+    lq.unused_(temps, [it, it2])
+    assert abs(-lq.evaluate_GaugeAction(ga, U2) / 3 - lq.evaluate_GaugeAction(U2, BETA)) < 1e-9
+    assert abs(P1 * P1 / 2 - lq.momentum_action(P1)) < 1e-9
+
+
+def test_transliterated_reference_callers_reproduce_the_fused_trajectory(lq):
+    """update!(::StandardHMC) exactly as the reference wrote it, on U[mu] / p[mu], against DeviceHMC (fused kernels): same seeds,
+    same momenta and noise, so the trajectories must agree to rounding (1e-12 on the links, 1e-9 on dH)."""
+    L, Uh = _fixture(lq)
+    dtau, mdsteps, nsw, seed = 0.05, 20, 10, 1234
+    Ua = lq.Gaugefields(lq.Lattice(L)).upload(Uh)
+    Ub = lq.Gaugefields(lq.Lattice(L)).upload(Uh)
+    fused = DeviceHMC(lq, Ua, KAPPA, BETA, dtau, mdsteps, nsw, seed)
+    gauge_action, fermi_action = _universe(lq, Ub, KAPPA, BETA)
+    hmc = StandardHMC(lq, Ub, gauge_action, False, dtau, mdsteps, fermi_action, SextonWeingargten=True, Nsw=nsw, seed=seed)
+    for traj in range(2):
+        acc_a = fused.update()
+        acc_b = update_(hmc, Ub)
+        assert acc_a == acc_b
+        assert abs(fused.dH[-1] - hmc.dH[-1]) < 1e-8, (fused.dH[-1], hmc.dH[-1])
+        assert rel_err(Ub.download(), Ua.download()) < 1e-12
+    assert abs(lq.calculate_Plaquette(Ua) - lq.calculate_Plaquette(Ub)) < 1e-13

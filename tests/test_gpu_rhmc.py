@@ -241,3 +241,33 @@ def test_two_plus_one_flavour_wilson_clover_trajectory(lq, orc):
     p.upload(-P)
     leapfrog(0.4 / 16, 16)
     assert np.abs(U.download() - Uh).max() < 1e-8
+
+
+def test_wilson_rational_interval_follows_the_links(lq, orc):
+    """the fit interval of the Wilson Nf = 1 action is re-checked on the current links at every heat bath / action
+    evaluation: an estimated interval is refitted when the spectrum has left it, a caller-fixed one raises."""
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    U_free = lq.Initialize_Gaugefields(3, 0, *L, condition="cold", lattice=lat)          # free field: lambda_min = (1 - 8 kappa)^2-ish, far above ...
+    U_hot = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 871))                            # ... the hot-start spectrum's lower edge
+    D = lq.Dirac_operator(U_hot, None, {"Dirac_operator": "Wilson", "κ": 0.125, "boundarycondition": BC, "eps_CG": 1e-20})
+    t_hot = lq.estimate_spectrum(lq.DdagD_operator(D))
+    t_free = lq.estimate_spectrum(lq.DdagD_operator(D(U_free)))
+    D(U_hot)
+    assert t_free[0] < 0.3 * t_hot[0] or t_free[1] > 1.3 * t_hot[1]                      # the two spectra really differ
+    fa = lq.FermiAction(D, {"Nf": 1})
+    lo0, hi0 = fa.spectral_interval
+    phi = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(phi, 872)
+    lq.evaluate_FermiAction(fa, U_hot, phi)
+    assert fa.interval_refits == 0 and fa.spectral_interval == (lo0, hi0)
+    S = lq.evaluate_FermiAction(fa, U_free, phi)                                         # spectrum left the interval: refit, then evaluate
+    lo1, hi1 = fa.spectral_interval
+    assert fa.interval_refits == 1 and lo1 <= 0.6 * t_free[0] and hi1 >= 1.1 * t_free[1]
+    X = phi.similar()                                                                    # S_f = phi^+ (D^+D)^(-1/2) phi by an independent fit on the new interval
+    lq.apply_inverse_power_(X, lq.DdagD_operator(D(U_free)), phi, 0.5, lo1, hi1, tol=1e-11)
+    assert abs(lq.dot(phi, X).real / S - 1.0) < 1e-8
+    fixed = lq.FermiAction(D(U_hot), {"Nf": 1, "rhmc_lambda_min": lo0, "rhmc_lambda_max": hi0})
+    lq.evaluate_FermiAction(fixed, U_hot, phi)
+    with pytest.raises(lq.LQCDError):
+        lq.evaluate_FermiAction(fixed, U_free, phi)
