@@ -28,7 +28,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 WILSON_FLOP_PER_SITE = 1320
 WILSON_BYTES_PER_SITE = 960    # read psi 192 + 4 links 576 + write 192
 KAPPA = 0.141139
-KERNEL_NAMES = {0: "wilson_interior", 1: "wilson_dirsplit", 2: "wilson_hopsplit", 3: "wilson_hopsplit_persist"}
+KERNEL_NAMES = {0: "wilson_interior", 1: "wilson_dirsplit", 2: "wilson_hopsplit", 3: "wilson_hopsplit_persist", 4: "wilson_lanesplit",
+                5: "wilson_dirsplit4"}
 
 
 def main():
@@ -41,7 +42,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pe-grid", type=str, default="")
     ap.add_argument("--set", action="append", default=[], help="library tunable key=value")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,13 +126,13 @@ def main():
         dt = float(t.item())
     iters_per_s = args.steps / dt
 
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get("wilson_dslash_bytes_per_launch_%dx%dx%dx%d" % gL)
-        except Exception:
-            traffic = None
+    # ---- roofline.traffic: HBM/fabric bytes of ONE launch of the dominant kernel, measured in THIS run: two separate rocprofv3
+    # --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel trace only) over a child process that applies the same operator to the same
+    # synthetic configuration, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-B request of a 16-B/lane
+    # read on gfx950: doubled; both counters are KiB).  N = 1 only; null with a reason when rocprofv3 is unavailable.
+    traffic, traffic18, traffic_source = None, None, "not measured (N > 1)"
+    if world == 1 and not force_dist:
+        traffic, traffic18, traffic_source = (None, None, "skipped (--no-pmc)") if args.no_pmc else measure_traffic(args)
 
     out = {
         "metric": "CG iters/sec (D^+D) & Dslash GFLOP/s, %d^3x%d SU(3) Wilson fp64" % (gL[0], gL[3]),
@@ -151,7 +156,8 @@ def main():
         "dslash_ms": ms_dslash,
         "dslash_ms_median_per_launch_events": ms_median,
         "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(lat.get_param("dslash_variant"), "wilson") + (("<false,true,false>" if recon_active else "<false,false,false>") if lat.get_param("dslash_variant") == 1 else "") + " (mul!(y,D,x))", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_over_bytes_moved": (traffic / (moved_per_site * Vloc)) if traffic else None,
                      "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc,
                      # the default kernel rebuilds the third row of every (unitary) link: it MOVES 768 B/site for the 960 algorithmic ones
                      "compulsory_bytes_moved_per_site": moved_per_site,
@@ -196,6 +202,8 @@ def main():
                                                "dslash_gflops": WILSON_FLOP_PER_SITE * V / (ms18 * 1e-3) / 1e9,
                                                "moved_bytes_per_site": WILSON_BYTES_PER_SITE,
                                                "frac_of_peak": WILSON_BYTES_PER_SITE * Vloc / (ms18 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "traffic": traffic18,
+                                               "traffic_over_bytes_moved": (traffic18 / (WILSON_BYTES_PER_SITE * Vloc)) if traffic18 else None,
                                                "cg_iters_per_s": 1e3 / msi18}
       except Exception as e:                               # secondary numbers never cost the bench line
         out["gauge_recon18_all_reals_read"] = {"error": str(e)}
@@ -243,31 +251,111 @@ def _flush_c_stdio():
         pass
 
 
+def pmc_child(args):
+    """Child of measure_traffic(): a few applications of the Wilson operator with the default links (12-real when unitary) and with all
+    18 reals, nothing else -- the process rocprofv3 counts."""
+    import ctypes
+    import latticeqcd_jl_amd as lq
+    gL = tuple(int(v) for v in args.lattice.split(","))
+    lat = lq.Lattice(gL)
+    for kv in args.set:
+        k, v = kv.split("=")
+        lat.set_param(k, int(v))
+    U = lq.Gaugefields(lat)
+    lq.lib.check(lq.lib.lib().lqcd_gauge_hot_start(U._h, ctypes.c_uint64(111)))
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": (1, 1, 1, -1)})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    y = b.similar()
+    recon0 = lat.get_param("gauge_recon")
+    for recon in (recon0, 18):
+        lat.set_param("gauge_recon", recon)
+        for _ in range(6):
+            lq.mul_(y, D, b)
+    lat.sync()
+
+
+def measure_traffic(args):
+    """(bytes per launch of the default Dslash kernel, the same for the all-18-reals kernel, source string)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, None, "unavailable: rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="lqcd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):       # separate passes: the two do not fit the TCC counter slots together
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--lattice", args.lattice] + sum((["--set", kv] for kv in args.set), [])
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
+            if r.returncode != 0:
+                return None, None, "unavailable: rocprofv3 --pmc %s exited %d" % (counter, r.returncode)
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and "wilson_" in row["Kernel_Name"]:
+                        a = acc.setdefault(row["Kernel_Name"], [0.0, 0])
+                        a[0] += float(row["Counter_Value"]); a[1] += 1
+            vals[counter] = {k: v[0] / v[1] for k, v in acc.items()}
+    except Exception as e:                                   # secondary: never costs the bench line
+        return None, None, "unavailable: %s" % e
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def per_kernel(match):
+        ks = [k for k in vals.get("FETCH_SIZE", {}) if match(k) and k in vals.get("WRITE_SIZE", {})]
+        if not ks:
+            return None
+        k = ks[0]
+        return (2.0 * vals["FETCH_SIZE"][k] + vals["WRITE_SIZE"][k]) * 1024.0
+    is18 = lambda k: "<false, false" in k.replace("(bool)0", "false").replace("(bool)1", "true")
+    t18 = per_kernel(is18)
+    tdef = per_kernel(lambda k: not is18(k)) or t18
+    src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only) over 6 launches of the kernel; "
+           "(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 64 B per 128-B request)")
+    return tdef, t18, src
+
+
 def cpu_baseline(lq, U, b, gL):
-    """The oracle (a port of the reference algorithm, NOT the reference itself -- Julia is not installed) timed on this
-    box's host cores on a bounded sample: CG windows of 1 and 0 iterations on the SAME 32^3x64 configuration; their
-    difference is one full CG iteration (2 Dslash + BLAS-1), single thread like the reference's serial Julia loop."""
+    """The CPU path timed on this box's host cores on a bounded sample of the same workload.  Preferred:
+    the reference itself, if `julia` and its packages happen to be installed here (probed at run time, there is no network) --
+    scripts/ref_cpu_baseline.jl, kind "reference".  Otherwise (the expected case): the oracle, a port of the reference algorithm,
+    CG windows of 1 and 0 iterations on the SAME configuration; their difference is one full CG iteration (2 Dslash + BLAS-1), on
+    ONE thread like the reference's serial Julia loop (kind "port")."""
+    import shutil
+    import subprocess
+    probe = "julia not found on PATH"
+    jl = shutil.which("julia")
+    if jl:
+        try:
+            r = subprocess.run([jl, os.path.join(ROOT, "scripts", "ref_cpu_baseline.jl"), *[str(v) for v in gL], str(KAPPA)],
+                               capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and line:
+                ref = json.loads(line[-1])
+                return {"value": ref["cg_iter_per_s"], "unit": "iter/s", "cores": 1, "kind": "reference",
+                        "sample": "LatticeDiracOperators.jl on the host: %s" % ref.get("sample", ""), "dslash_gflops": ref.get("dslash_gflops"),
+                        "julia_probe": "julia + packages found, reference timed"}
+            probe = "julia found but the reference packages did not run (exit %d): %s" % (r.returncode, (r.stderr or "").strip()[-200:])
+        except Exception as e:
+            probe = "julia found but the reference run failed: %s" % e
     from oracle import oracle as orc
     Uh, bh = U.download(), b.download()
     bc = (1, 1, 1, -1)
-    res = {}
-    for label, threads in (("1core", 1), ("allcores", os.cpu_count() or 1)):
-        orc.set_threads(threads)
-        t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=0); t_setup = time.perf_counter() - t0
-        t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=1); t_one = time.perf_counter() - t0
-        per_iter = max(t_one - t_setup, 1e-9)
-        t0 = time.perf_counter(); orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc); t_d = time.perf_counter() - t0
-        res[label] = {"iter_per_s": 1.0 / per_iter, "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / t_d / 1e9,
-                      "cores": threads}
-        if threads == 1 and (os.cpu_count() or 1) == 1:
-            break
-    one = res["1core"]
-    out = {"value": one["iter_per_s"], "unit": "iter/s", "cores": 1, "kind": "port",
-           "sample": "oracle CG on the same %dx%dx%dx%d configuration: time(1 iteration) - time(0 iterations), 1 thread" % gL,
-           "dslash_gflops": one["dslash_gflops"]}
-    if "allcores" in res:
-        out["allcores"] = res["allcores"]
-    return out
+    orc.set_threads(1)
+    t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=0); t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=1); t_one = time.perf_counter() - t0
+    per_iter = max(t_one - t_setup, 1e-9)
+    t0 = time.perf_counter(); orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc); t_d = time.perf_counter() - t0
+    return {"value": 1.0 / per_iter, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": "oracle CG on the same %dx%dx%dx%d configuration: time(1 iteration) - time(0 iterations), 1 thread" % gL,
+            "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / t_d / 1e9, "julia_probe": probe}
 
 
 if __name__ == "__main__":

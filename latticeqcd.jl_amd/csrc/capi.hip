@@ -251,7 +251,9 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;
     if (!strcmp(key, "xcd_nsub")) return &c->tun.xcd_nsub;
     if (!strcmp(key, "xcd_ysplit")) return &c->tun.xcd_ysplit;
+#ifdef LQCD_ABLATE     /* timing ablations (wrong results): only in -DLQCD_ABLATE builds of the library, never in the shipped one */
     if (!strcmp(key, "dbg")) return &c->tun.dbg;
+#endif
     if (!strcmp(key, "persist_per_cu")) return &c->tun.persist_per_cu;
     return nullptr;
 }

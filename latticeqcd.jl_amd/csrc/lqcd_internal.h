@@ -233,7 +233,9 @@ struct Tunables {
     int cg_fused = 2;         // 0: reference form (c1 = p.q), 1: |Dp|^2 from the stencil, 2: + r-update fused into D^+, x/p updates merged
     int graph = 0;            // capture solver iterations in a hipGraph
     int persist_per_cu = 2;   // variant 3: resident workgroups per CU
-    int dbg = 0;              // timing ablations (results are wrong when non-zero)
+#ifdef LQCD_ABLATE
+    int dbg = 0;              // timing ablations (results are wrong when non-zero); -DLQCD_ABLATE builds only
+#endif
     int xcd_ysplit = 4;       // remap 2: tile the sub-domains in (y,z) instead of plain z-slabs
     int xcd_nsub = 16;       // remap 2: sub-domains per t-slice (multiple of 8)
     int lds_pad_kb = 0;       // dynamic LDS added to the site-per-lane stencil launch (occupancy limiter, experiments)

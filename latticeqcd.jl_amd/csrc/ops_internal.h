@@ -1,0 +1,44 @@
+// ops_internal.h -- declarations shared by apply.hip / solvers.hip / actions.hip / bench_api.hip / mdom.hip (the former ops.hip).
+#pragma once
+#include "lqcd_internal.h"
+
+#include <functional>
+#include <vector>
+
+namespace lqcd {
+
+double2* spinor_block(lqcd_spinor_s* s, int p);
+int stream_grid(lqcd_ctx_s* c, size_t n);
+
+// apply.hip
+StencilCall make_hop_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* xin, double a, double b, int dagger);
+int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* who);
+
+// solvers.hip
+constexpr int UB = 256;     // block size of the solvers' streaming kernels
+struct CgWork {
+    lqcd_spinor_s *r, *p, *q, *tmp;
+};
+int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w);
+int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0);
+typedef std::function<int(double2* out, const double2* in)> ApplyFn;
+
+// scratch fields of one call: returned to the context's pool on every exit path
+struct ScratchScope {
+    lqcd_ctx_s* c;
+    std::vector<lqcd_spinor_s*> held;
+    explicit ScratchScope(lqcd_ctx_s* c_) : c(c_) {}
+    ScratchScope(const ScratchScope&) = delete;
+    ScratchScope& operator=(const ScratchScope&) = delete;
+    lqcd_spinor_s* get(int kind, int subset) {
+        lqcd_spinor_s* s = scratch_get(c, kind, subset);
+        if (s) held.push_back(s);
+        return s;
+    }
+    ~ScratchScope() { for (lqcd_spinor_s* s : held) scratch_put(s); }
+};
+
+// mdom.hip
+int mdom_check(int n, lqcd_ctx_s* c0);
+
+}  // namespace lqcd

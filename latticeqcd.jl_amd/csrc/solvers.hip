@@ -1,0 +1,803 @@
+// solvers.hip -- Krylov solvers with device-resident scalars: CG on D^+D (fused iteration), BiCGStab and its even-odd (Schur) form,
+// the parity-block CG and the multi-shift CG of the RHMC path.
+//
+// Replaces, behind the C ABI, LatticeDiracOperators.jl's solve_DinvX! (cg / bicgstab / even-odd bicgstab / shiftedcg) -- SURVEY.md
+// 8(a) a4-a5, 8(f) rank 3; reference call sites /root/reference/src/md/AbstractMD.jl:129, src/updates/standardHMC.jl:71.
+#include "ops_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <functional>
+
+namespace lqcd {
+
+// ---------------------------------------------------------------------------------- CG with device-resident scalars
+
+__global__ void cg_scalar_alpha(double* s) {
+    if (s[S_DONE] != 0.0) { s[S_XDONE] = 1.0; return; }   // the iterate of the converging iteration has been written
+    s[S_ALPHA] = s[S_RR] / s[S_PQ];
+}
+__global__ void cg_scalar_beta(double* s) {
+    if (s[S_DONE] != 0.0) return;
+    const double rrn = s[S_RRNEW];
+    s[S_BETA] = rrn / s[S_RR];
+    s[S_RR] = rrn;
+    s[S_ITERS] += 1.0;
+    if (rrn < s[S_EPS]) s[S_DONE] = 1.0;
+}
+
+// x += alpha p ; r -= alpha q ; partial |r|^2
+__global__ __launch_bounds__(UB) void cg_update_xr(const double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ r,
+                                                    const double2* __restrict__ p, const double2* __restrict__ q, size_t n,
+                                                    double* partial) {
+    __shared__ double red[UB / 64];
+    double acc = 0;
+    if (s[S_DONE] == 0.0) {
+        const double al = s[S_ALPHA];
+        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+            const double2 pv = p[i], qv = q[i];
+            double2 xv = x[i], rv = r[i];
+            xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+            rv.x = fma(-al, qv.x, rv.x); rv.y = fma(-al, qv.y, rv.y);
+            x[i] = xv; r[i] = rv;
+            acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < UB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+// fused tail of an iteration:  x += alpha p ;  p = r + beta p   (x is still updated in the iteration that converges,
+// p only while the solve continues; nothing is touched in later, overshooting launches)
+__global__ __launch_bounds__(UB) void cg_update_xp(const double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ p,
+                                                    const double2* __restrict__ r, size_t n) {
+    if (s[S_XDONE] != 0.0) return;
+    const double al = s[S_ALPHA], be = s[S_BETA];
+    const bool cont = s[S_DONE] == 0.0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        double2 pv = p[i], xv = x[i];
+        xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+        x[i] = xv;
+        if (cont) {
+            const double2 rv = r[i];
+            pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
+            p[i] = pv;
+        }
+    }
+}
+// p = r + beta p
+__global__ __launch_bounds__(UB) void cg_update_p(const double* __restrict__ s, double2* __restrict__ p, const double2* __restrict__ r, size_t n) {
+    if (s[S_DONE] != 0.0) return;
+    const double be = s[S_BETA];
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 rv = r[i];
+        double2 pv = p[i];
+        pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
+        p[i] = pv;
+    }
+}
+__global__ __launch_bounds__(UB) void norm2_partial_kernel(const double2* __restrict__ a, size_t n, double* partial) {
+    __shared__ double red[UB / 64];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 v = a[i];
+        acc = fma(v.x, v.x, acc); acc = fma(v.y, v.y, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < UB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+// re(p.q) partials (unfused reference form c1 = p.q)
+__global__ __launch_bounds__(UB) void redot_partial_kernel(const double2* __restrict__ a, const double2* __restrict__ b, size_t n, double* partial) {
+    __shared__ double red[UB / 64];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 x = a[i], y = b[i];
+        acc = fma(x.x, y.x, acc); acc = fma(x.y, y.y, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < UB / 64; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+
+// enqueue one CG iteration on the compute stream (no host synchronisation)
+int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
+    lqcd_ctx_s* c = op->ctx;
+    const size_t n = x->elems;
+    if (c->tun.cg_fused >= 2) {
+        // fully fused form: 10 spinor passes per iteration instead of 13, q = D^+ D p is never written
+        //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
+        //   beta, convergence ; x += alpha p, p = r + beta p
+        const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
+        LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial, c->tun.cg_skip_done ? c->d_scal : nullptr));   // a no-op once the solve has converged inside a burst
+        LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
+        apply_bc(c, op->bc);
+        StencilCall s2;
+        LQCHK(make_full_call(op, w.q, w.tmp, 1, s2));
+        s2.norm_partial = c->d_partial;
+        s2.upd_scal = c->d_scal;
+        s2.upd[0] = spinor_block(w.r, 0);
+        s2.upd[1] = spinor_block(w.r, 1);
+        LQCHK(stencil_apply(c, s2));
+        LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));   // + beta, convergence flag
+        const int nbu = stream_grid(c, n);
+        hipLaunchKernelGGL(cg_update_xp, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
+        HIPCHK(hipGetLastError());
+        return LQCD_OK;
+    }
+    const bool fuse = c->tun.cg_fused && !any_partitioned(c);
+    // tmp = D p  (|tmp|^2 block partials fused into the stencil when the lattice is not partitioned)
+    LQCHK(op_apply_async(op, w.tmp, w.p, 0, fuse ? c->d_partial : nullptr));
+    int nb;
+    if (fuse) {
+        nb = stencil_num_blocks(c, op->kind, op->r, 2);
+        LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+        LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+    } else if (c->tun.cg_fused) {
+        nb = stream_grid(c, n);
+        hipLaunchKernelGGL(norm2_partial_kernel, dim3(nb), dim3(UB), 0, c->stream, w.tmp->data, n, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+        LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+    } else {
+        // reference form: c1 = p . q
+        LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+        nb = stream_grid(c, n);
+        hipLaunchKernelGGL(redot_partial_kernel, dim3(nb), dim3(UB), 0, c->stream, w.p->data, w.q->data, n, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+    }
+    hipLaunchKernelGGL(cg_scalar_alpha, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+    nb = stream_grid(c, n);
+    hipLaunchKernelGGL(cg_update_xr, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, x->data, w.r->data, w.p->data, w.q->data, n, c->d_partial);
+    HIPCHK(hipGetLastError());
+    LQCHK(reduce_to_slot(c, nb, 1, S_RRNEW, true));
+    hipLaunchKernelGGL(cg_scalar_beta, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+    hipLaunchKernelGGL(cg_update_p, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, w.p->data, w.r->data, n);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0) {
+    lqcd_ctx_s* c = op->ctx;
+    const size_t n = x->elems;
+    // r = b - D^+ D x ; p = r
+    LQCHK(op_apply_async(op, w.tmp, x, 0, nullptr));
+    LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
+    HIPCHK(hipMemcpyAsync(w.r->data, b->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, w.q->data, w.r->data, n));
+    HIPCHK(hipMemcpyAsync(w.p->data, w.r->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_norm2(c, w.r->data, n, rr0, true));
+    double init[9] = {*rr0, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
+    HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr) {
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    CgWork w;
+    w.r = scratch_get(c, x->kind, LQCD_FULL);
+    w.p = scratch_get(c, x->kind, LQCD_FULL);
+    w.q = scratch_get(c, x->kind, LQCD_FULL);
+    w.tmp = scratch_get(c, x->kind, LQCD_FULL);
+    int st = LQCD_OK;
+    double rr = 0;
+    int it = 0;
+    bool converged = false;
+    if (!(w.r && w.p && w.q && w.tmp)) st = LQCD_ERR_HIP;
+    if (st == LQCD_OK) st = cg_setup(op, x, b, w, fixed ? -1.0 : eps, &rr);
+    if (st == LQCD_OK && !fixed && rr < eps) converged = true;
+    const int check_every = 8;
+    // tunable "graph": a burst of check_every iterations is captured once into a hipGraph and replayed -- one launch per
+    // burst instead of 5 per iteration.  Pays on launch-bound (small) lattices; single-stream (unpartitioned) contexts only.
+    const bool use_graph = c->tun.graph != 0 && !any_partitioned(c);
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    while (st == LQCD_OK && !converged && it < maxiter) {
+        int burst = std::min(check_every, maxiter - it);
+        if (fixed && !use_graph) burst = maxiter - it;
+        if (use_graph && burst == check_every) {
+            if (!gexec) {
+                if (c->tun.halo_stream_mode < 0) c->tun.halo_stream_mode = 0;    // the auto-tuning pass synchronises: not inside a capture
+                hipError_t ge = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+                if (ge != hipSuccess) { st = hip_fail(ge, "hipStreamBeginCapture", __FILE__, __LINE__); break; }
+                for (int k = 0; k < burst && st == LQCD_OK; k++) st = cg_enqueue_iteration(op, x, w);
+                ge = hipStreamEndCapture(c->stream, &graph);
+                if (st == LQCD_OK && ge != hipSuccess) st = hip_fail(ge, "hipStreamEndCapture", __FILE__, __LINE__);
+                if (st == LQCD_OK) {
+                    ge = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+                    if (ge != hipSuccess) st = hip_fail(ge, "hipGraphInstantiate", __FILE__, __LINE__);
+                }
+                if (st != LQCD_OK) break;
+            }
+            hipError_t ge = hipGraphLaunch(gexec, c->stream);
+            if (ge != hipSuccess) { st = hip_fail(ge, "hipGraphLaunch", __FILE__, __LINE__); break; }
+        } else {
+            for (int k = 0; k < burst && st == LQCD_OK; k++) st = cg_enqueue_iteration(op, x, w);
+        }
+        if (st != LQCD_OK) break;
+        if (fixed && use_graph && it + burst < maxiter) { it += burst; continue; }   // timing window: no readback between bursts
+        hipError_t e = hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { st = hip_fail(e, "cg scalar readback", __FILE__, __LINE__); break; }
+        rr = c->h_scal[S_RR - S_RR];
+        it = (int)c->h_scal[S_ITERS - S_RR];
+        if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
+        if (!std::isfinite(rr)) { set_error("CG: residual is not finite"); st = LQCD_ERR_NOT_CONVERGED; }
+    }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (st != LQCD_OK) return st;
+    if (!fixed && !converged) {
+        set_error("The CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}
+
+// ---------------------------------------------------------------------------------- BiCGStab (device-resident scalars)
+// One iteration = 2 operator applications + 5 streaming kernels + 4 single-block reductions, all enqueued without a host
+// round trip; complex alpha/omega/beta live in d_scal[B_*] (scalar steps: blas.hip cg_scalar_step ops 3..6).  The host
+// polls the done flag every few iterations.  Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and
+// iteration count as the textbook van der Vorst loop the parity tests compare against.
+
+template <int NV>
+__device__ inline void block_reduce_nv(double (&a)[NV], double* partial) {
+    __shared__ double red[NV][UB / 64];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[v] += __shfl_down(a[v], off, 64);
+        if ((threadIdx.x & 63) == 0) red[v][threadIdx.x >> 6] = a[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < UB / 64; w++) t += red[threadIdx.x][w];
+        partial[blockIdx.x * NV + threadIdx.x] = t;
+    }
+}
+// <a,b> = sum conj(a) b
+__global__ __launch_bounds__(UB) void bicg_dot(const double* __restrict__ sc, const double2* __restrict__ a, const double2* __restrict__ b, size_t n,
+                                                double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    double acc[2] = {0, 0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 x = a[i], y = b[i];
+        acc[0] = fma(x.x, y.x, acc[0]); acc[0] = fma(x.y, y.y, acc[0]);
+        acc[1] = fma(x.x, y.y, acc[1]); acc[1] = fma(-x.y, y.x, acc[1]);
+    }
+    block_reduce_nv<2>(acc, partial);
+}
+// s = r - alpha v ; partial |s|^2
+__global__ __launch_bounds__(UB) void bicg_s(const double* __restrict__ sc, double2* __restrict__ s, const double2* __restrict__ r,
+                                              const double2* __restrict__ v, size_t n, double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    const double ar = sc[B_ALPHA], ai = sc[B_ALPHA + 1];
+    double acc[1] = {0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 vv = v[i];
+        double2 sv = r[i];
+        sv.x = fma(-ar, vv.x, sv.x); sv.x = fma(ai, vv.y, sv.x);
+        sv.y = fma(-ar, vv.y, sv.y); sv.y = fma(-ai, vv.x, sv.y);
+        s[i] = sv;
+        acc[0] = fma(sv.x, sv.x, acc[0]); acc[0] = fma(sv.y, sv.y, acc[0]);
+    }
+    block_reduce_nv<1>(acc, partial);
+}
+// partials of <t,s> (2 values) and |t|^2
+__global__ __launch_bounds__(UB) void bicg_ts(const double* __restrict__ sc, const double2* __restrict__ t, const double2* __restrict__ s, size_t n,
+                                               double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    double acc[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 x = t[i], y = s[i];
+        acc[0] = fma(x.x, y.x, acc[0]); acc[0] = fma(x.y, y.y, acc[0]);
+        acc[1] = fma(x.x, y.y, acc[1]); acc[1] = fma(-x.y, y.x, acc[1]);
+        acc[2] = fma(x.x, x.x, acc[2]); acc[2] = fma(x.y, x.y, acc[2]);
+    }
+    block_reduce_nv<3>(acc, partial);
+}
+// x += alpha p + omega s ; r = s - omega t ; partials |r|^2, <r0,r>
+__global__ __launch_bounds__(UB) void bicg_xr(const double* __restrict__ sc, double2* __restrict__ x, double2* __restrict__ r,
+                                               const double2* __restrict__ p, const double2* __restrict__ s, const double2* __restrict__ t,
+                                               const double2* __restrict__ r0, size_t n, double* partial) {
+    if (sc[B_DONE] != 0.0) return;
+    const double ar = sc[B_ALPHA], ai = sc[B_ALPHA + 1], wr = sc[B_OMEGA], wi = sc[B_OMEGA + 1];
+    double acc[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 pv = p[i], sv = s[i], tv = t[i], zv = r0[i];
+        double2 xv = x[i], rv = sv;
+        xv.x = fma(ar, pv.x, xv.x); xv.x = fma(-ai, pv.y, xv.x);
+        xv.y = fma(ar, pv.y, xv.y); xv.y = fma(ai, pv.x, xv.y);
+        xv.x = fma(wr, sv.x, xv.x); xv.x = fma(-wi, sv.y, xv.x);
+        xv.y = fma(wr, sv.y, xv.y); xv.y = fma(wi, sv.x, xv.y);
+        rv.x = fma(-wr, tv.x, rv.x); rv.x = fma(wi, tv.y, rv.x);
+        rv.y = fma(-wr, tv.y, rv.y); rv.y = fma(-wi, tv.x, rv.y);
+        x[i] = xv; r[i] = rv;
+        acc[0] = fma(rv.x, rv.x, acc[0]); acc[0] = fma(rv.y, rv.y, acc[0]);
+        acc[1] = fma(zv.x, rv.x, acc[1]); acc[1] = fma(zv.y, rv.y, acc[1]);
+        acc[2] = fma(zv.x, rv.y, acc[2]); acc[2] = fma(-zv.y, rv.x, acc[2]);
+    }
+    block_reduce_nv<3>(acc, partial);
+}
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(UB) void bicg_p(const double* __restrict__ sc, double2* __restrict__ p, const double2* __restrict__ r,
+                                              const double2* __restrict__ v, size_t n) {
+    if (sc[B_DONE] != 0.0) return;
+    const double br = sc[B_BETA], bi = sc[B_BETA + 1], wr = sc[B_OMEGA], wi = sc[B_OMEGA + 1];
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 vv = v[i], rv = r[i];
+        double2 pv = p[i];
+        pv.x = fma(-wr, vv.x, pv.x); pv.x = fma(wi, vv.y, pv.x);
+        pv.y = fma(-wr, vv.y, pv.y); pv.y = fma(-wi, vv.x, pv.y);
+        double2 o;
+        o.x = fma(br, pv.x, rv.x); o.x = fma(-bi, pv.y, o.x);
+        o.y = fma(br, pv.y, rv.y); o.y = fma(bi, pv.x, o.y);
+        p[i] = o;
+    }
+}
+
+static int bicgstab_core(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* const w[6], double eps,
+                         int maxiter, int* iters, double* final_rr) {
+    double2 *r = w[0], *r0 = w[1], *p = w[2], *v = w[3], *s = w[4], *t = w[5];
+    const size_t bytes = n * sizeof(double2);
+    LQCHK(A(v, x));
+    HIPCHK(hipMemcpyAsync(r, b, bytes, hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, v, r, n));
+    HIPCHK(hipMemcpyAsync(r0, r, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(p, r, bytes, hipMemcpyDeviceToDevice, c->stream));
+    double rr;
+    LQCHK(blas_norm2(c, r, n, &rr, true));
+    double init[B_END - B_RHO] = {0};
+    init[B_RHO - B_RHO] = rr;
+    init[B_EPS - B_RHO] = eps;
+    init[B_RES - B_RHO] = rr;
+    HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int it = 0, st = LQCD_ERR_NOT_CONVERGED;
+    bool breakdown = false;
+    if (rr < eps) st = LQCD_OK;
+    const int nb = stream_grid(c, n), check_every = 4;
+    const double* sc = c->d_scal;
+    while (st != LQCD_OK && !breakdown && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        for (int k = 0; k < burst; k++) {
+            LQCHK(A(v, p));
+            hipLaunchKernelGGL(bicg_dot, dim3(nb), dim3(UB), 0, c->stream, sc, r0, v, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 2, B_R0V, true, 3));
+            hipLaunchKernelGGL(bicg_s, dim3(nb), dim3(UB), 0, c->stream, sc, s, r, v, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 1, B_SS, true, 4));
+            LQCHK(A(t, s));
+            hipLaunchKernelGGL(bicg_ts, dim3(nb), dim3(UB), 0, c->stream, sc, t, s, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 3, B_TS, true, 5));
+            hipLaunchKernelGGL(bicg_xr, dim3(nb), dim3(UB), 0, c->stream, sc, x, r, p, s, t, r0, n, c->d_partial);
+            LQCHK(reduce_to_slot(c, nb, 3, B_RR, true, 6));
+            hipLaunchKernelGGL(bicg_p, dim3(nb), dim3(UB), 0, c->stream, sc, p, r, v, n);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + B_RHO, (B_END - B_RHO) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        it = (int)c->h_scal[B_ITERS - B_RHO];
+        rr = c->h_scal[B_RES - B_RHO];
+        const double done = c->h_scal[B_DONE - B_RHO];
+        if (done == 1.0) st = LQCD_OK;
+        else if (done != 0.0) breakdown = true;
+    }
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (breakdown) { set_error("BiCGStab: residual is not finite (breakdown)"); return LQCD_ERR_NOT_CONVERGED; }
+    if (st != LQCD_OK) {
+        set_error("The BiCGStab is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}
+
+}  // namespace lqcd
+
+using namespace lqcd;
+
+// ---------------------------------------------------------------------------------- C API: solvers
+extern "C" int lqcd_solve_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, int* iters, double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_cg_DdagD"));
+    ARGCHK(maxiter >= 0, "lqcd_solve_cg_DdagD: maxiter < 0");
+    return cg_run(op, x, b, eps, maxiter, false, iters, final_rr);
+}
+extern "C" int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int niter) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_cg_DdagD_fixed"));
+    return cg_run(op, x, b, 0.0, niter, true, nullptr, nullptr);
+}
+
+
+// CG with device-resident scalars for a Hermitian positive operator given as an enqueue function (reference form:
+// alpha = rr / <p, A p>); x holds the initial guess, work = three fields of n elements.  Used where the fused full-lattice
+// iteration of cg_run does not apply (parity blocks).
+static int cg_generic(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* r, double2* p, double2* q, double eps,
+                      int maxiter, int* iters, double* final_rr) {
+    LQCHK(A(q, x));
+    HIPCHK(hipMemcpyAsync(r, b, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, q, r, n));
+    HIPCHK(hipMemcpyAsync(p, r, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    double rr = 0;
+    LQCHK(blas_norm2(c, r, n, &rr, true));
+    double init[9] = {rr, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
+    HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int it = 0;
+    bool converged = rr < eps;
+    const int nb = stream_grid(c, n), check_every = 8;
+    while (!converged && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        for (int k = 0; k < burst; k++) {
+            LQCHK(A(q, p));
+            hipLaunchKernelGGL(redot_partial_kernel, dim3(nb), dim3(UB), 0, c->stream, p, q, n, c->d_partial);
+            HIPCHK(hipGetLastError());
+            LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
+            hipLaunchKernelGGL(cg_scalar_alpha, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+            hipLaunchKernelGGL(cg_update_xr, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, x, r, p, q, n, c->d_partial);
+            HIPCHK(hipGetLastError());
+            LQCHK(reduce_to_slot(c, nb, 1, S_RRNEW, true));
+            hipLaunchKernelGGL(cg_scalar_beta, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+            hipLaunchKernelGGL(cg_update_p, dim3(nb), dim3(UB), 0, c->stream, c->d_scal, p, r, n);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rr = c->h_scal[0];
+        it = (int)c->h_scal[S_ITERS - S_RR];
+        if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
+        if (!std::isfinite(rr)) { set_error("CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
+    }
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (!converged) {
+        set_error("The CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}
+
+// Staggered D^+D = m^2 - H^2 is block diagonal in parity: (D^+D)_pp = m^2 - H_pq H_qp.  Solves that block for the parity-p halves of
+// the FULL fields x (initial guess / solution) and b with half-lattice vectors -- one Dslash-equivalent per iteration instead of
+// two.  The other parity of x is not touched.  This is the solve behind the reference's "4 tastes" (Nf = 4) staggered action, whose
+// pseudofermion lives on the even sites (test/test_staggered.toml).
+extern "C" int lqcd_solve_cg_DdagD_parity(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int parity, double eps, int maxiter, int* iters,
+                                          double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_cg_DdagD_parity"));
+    ARGCHK(op->kind == LQCD_STAGGERED && (parity == 0 || parity == 1) && maxiter >= 0,
+           "lqcd_solve_cg_DdagD_parity: staggered operators only, parity 0 (even) or 1 (odd)");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    apply_bc(c, op->bc);
+    const size_t nh = x->elems / 2;
+    const int mine = parity ? LQCD_ODD : LQCD_EVEN, other = parity ? LQCD_EVEN : LQCD_ODD;
+    ScratchScope pool(c);
+    lqcd_spinor_s *r = pool.get(op->kind, mine), *p = pool.get(op->kind, mine), *q = pool.get(op->kind, mine), *t = pool.get(op->kind, other);
+    if (!(r && p && q && t)) return LQCD_ERR_HIP;
+    lqcd_spinor_s xv = *x, bv = *b;
+    xv.subset = bv.subset = mine;
+    xv.elems = bv.elems = nh;
+    xv.data = x->data + (size_t)parity * nh;
+    bv.data = b->data + (size_t)parity * nh;
+    lqcd_spinor_s vin = xv, vout = xv;
+    const double m2 = op->km * op->km;
+    ApplyFn A = [&](double2* out, const double2* in) -> int {
+        vin.data = const_cast<double2*>(in);
+        vout.data = out;
+        StencilCall s1 = make_hop_call(op, t, &vin, nullptr, 0.0, 1.0, 0);          // t = H in (other parity)
+        LQCHK(stencil_apply(c, s1));
+        StencilCall s2 = make_hop_call(op, &vout, t, &vin, m2, -1.0, 0);            // out = m^2 in - H t
+        return stencil_apply(c, s2);
+    };
+    return cg_generic(c, A, nh, xv.data, bv.data, r->data, p->data, q->data, eps, maxiter, iters, final_rr);
+}
+
+extern "C" int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
+                                   double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab"));
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    ScratchScope pool(c);
+    double2* wd[6];
+    for (int i = 0; i < 6; i++) {
+        lqcd_spinor_s* wi = pool.get(op->kind, LQCD_FULL);
+        if (!wi) return LQCD_ERR_HIP;
+        wd[i] = wi->data;
+    }
+    // the stencil works on spinor handles; wrap raw pointers of the scratch fields
+    lqcd_spinor_s vin = *x, vout = *x;
+    ApplyFn A = [&](double2* out, const double2* in) -> int {
+        vin.data = const_cast<double2*>(in);
+        vout.data = out;
+        return op_apply_async(op, &vout, &vin, dagger ? 1 : 0, nullptr);
+    };
+    return bicgstab_core(c, A, x->elems, x->data, b->data, wd, eps, maxiter, iters, final_rr);
+}
+
+// even-odd (Schur) preconditioned BiCGStab, Wilson:
+//   (1 - k^2 H_eo H_oe) x_e = b_e + k H_eo b_o ;  x_o = b_o + k H_oe x_e
+// Wilson-clover (D_sw = A - k H, A block diagonal in parity): with the packed inverse blocks A^-1 (clover.hip)
+//   (1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe) x_e = A_ee^-1 (b_e + k H_eo A_oo^-1 b_o) ;  x_o = A_oo^-1 (b_o + k H_oe x_e)
+// (D_sw^+: H -> H^+ through the dagger flag of the hop, A is Hermitian).
+extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
+                                      double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_bicgstab_eo"));
+    ARGCHK(op->kind == LQCD_WILSON, "lqcd_solve_bicgstab_eo: Wilson only");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    apply_bc(c, op->bc);
+    const bool clov = op->csw != 0.0 && op->clover;
+    if (clov) {     // A follows the links, A^-1 follows A
+        if (op->clover_version != op->gauge->version) {
+            LQCHK(clover_build(c, op->gauge, op->clover, op->km, op->csw));
+            op->clover_version = op->gauge->version;
+        }
+        if (!op->clover_inv) HIPCHK(hipMalloc((void**)&op->clover_inv, clover_elems(c->geom) * sizeof(double2)));
+        if (op->clover_inv_version != op->clover_version) {
+            LQCHK(clover_invert(c, op->clover, op->clover_inv));
+            op->clover_inv_version = op->clover_version;
+        }
+    }
+    const double2* Ai = op->clover_inv;
+    const double k = op->km;
+    const int dg = dagger ? 1 : 0;
+    const size_t nh = x->elems / 2;
+    ScratchScope pool(c);
+    double2* wd[6];
+    for (int i = 0; i < 6; i++) {
+        lqcd_spinor_s* wi = pool.get(op->kind, LQCD_EVEN);
+        if (!wi) return LQCD_ERR_HIP;
+        wd[i] = wi->data;
+    }
+    lqcd_spinor_s* rhs = pool.get(op->kind, LQCD_EVEN);
+    lqcd_spinor_s* te = clov ? pool.get(op->kind, LQCD_EVEN) : nullptr;
+    lqcd_spinor_s* to = pool.get(op->kind, LQCD_ODD);
+    lqcd_spinor_s* uo = clov ? pool.get(op->kind, LQCD_ODD) : nullptr;
+    if (!rhs || !to || (clov && (!te || !uo))) return LQCD_ERR_HIP;
+    // views of the even/odd halves of b and x
+    lqcd_spinor_s be = *b, bo = *b, xe = *x, xo = *x;
+    be.subset = xe.subset = LQCD_EVEN; bo.subset = xo.subset = LQCD_ODD;
+    be.elems = bo.elems = xe.elems = xo.elems = nh;
+    bo.data = b->data + nh; xo.data = x->data + nh;
+    int st = LQCD_OK;
+    auto run = [&]() -> int {
+        lqcd_spinor_s vin = xe, vout = xe;
+        ApplyFn A;
+        if (!clov) {
+            // rhs = b_e + k H_eo b_o
+            { StencilCall s = make_hop_call(op, rhs, &bo, &be, 1.0, k, dg); LQCHK(stencil_apply(c, s)); }
+            A = [&](double2* out, const double2* in) -> int {
+                vin.data = const_cast<double2*>(in);
+                vout.data = out;
+                StencilCall s1 = make_hop_call(op, to, &vin, nullptr, 0.0, 1.0, dg);         // t_o = H_oe in
+                LQCHK(stencil_apply(c, s1));
+                StencilCall s2 = make_hop_call(op, &vout, to, &vin, 1.0, -k * k, dg);        // out = in - k^2 H_eo t_o
+                return stencil_apply(c, s2);
+            };
+        } else {
+            // rhs = A_ee^-1 (b_e + k H_eo A_oo^-1 b_o)
+            LQCHK(clover_apply_parity(c, Ai, 1, uo->data, bo.data, 1.0, nullptr, 0.0));
+            { StencilCall s = make_hop_call(op, te, uo, &be, 1.0, k, dg); LQCHK(stencil_apply(c, s)); }
+            LQCHK(clover_apply_parity(c, Ai, 0, rhs->data, te->data, 1.0, nullptr, 0.0));
+            A = [&](double2* out, const double2* in) -> int {
+                vin.data = const_cast<double2*>(in);
+                StencilCall s1 = make_hop_call(op, to, &vin, nullptr, 0.0, 1.0, dg);         // t_o = H_oe in
+                LQCHK(stencil_apply(c, s1));
+                LQCHK(clover_apply_parity(c, Ai, 1, uo->data, to->data, 1.0, nullptr, 0.0)); // u_o = A_oo^-1 t_o
+                StencilCall s2 = make_hop_call(op, te, uo, nullptr, 0.0, 1.0, dg);           // t_e = H_eo u_o
+                LQCHK(stencil_apply(c, s2));
+                return clover_apply_parity(c, Ai, 0, out, te->data, -k * k, in, 1.0);        // out = in - k^2 A_ee^-1 t_e
+            };
+        }
+        const int sc = bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
+        // the odd half (also on non-convergence, so x is a consistent best effort)
+        if (!clov) {
+            StencilCall s = make_hop_call(op, &xo, &xe, &bo, 1.0, k, dg);                    // x_o = b_o + k H_oe x_e
+            LQCHK(stencil_apply(c, s));
+        } else {
+            StencilCall s = make_hop_call(op, to, &xe, &bo, 1.0, k, dg);
+            LQCHK(stencil_apply(c, s));
+            LQCHK(clover_apply_parity(c, Ai, 1, xo.data, to->data, 1.0, nullptr, 0.0));      // x_o = A_oo^-1 (b_o + k H_oe x_e)
+        }
+        return sc;
+    };
+    st = run();
+    hipError_t e = hipStreamSynchronize(c->stream);      // before the scratch fields go back to the pool
+    if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync bicgstab_eo", __FILE__, __LINE__);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------- multi-shift CG (RHMC solver)
+namespace lqcd {
+// per-shift coefficient block in device memory: [sigma | zeta_{n-1} | zeta_n | a | b | z] (ns doubles each), alpha_{n-1}, beta_{n-1}
+// zeta recurrence (Jegerlehner hep-lat/9612014) after the base system's alpha_n, beta_n are known:
+//   zeta_{n+1} = zeta_n zeta_{n-1} alpha_{n-1} / (zeta_{n-1} alpha_{n-1} (1 + alpha_n sigma) + alpha_n beta_{n-1} (zeta_{n-1} - zeta_n))
+//   x_j += (zeta_{n+1}/zeta_n) alpha_n p_j ;  p_j = (zeta_{n+1}/zeta_n)^2 beta_n p_j + zeta_{n+1} r
+__global__ void ms_zeta(const double* __restrict__ sc, double* __restrict__ ms, int ns) {
+    if (sc[S_XDONE] != 0.0) return;
+    const double alpha = sc[S_ALPHA], beta = sc[S_BETA], alpha_m = ms[6 * ns], beta_m = ms[6 * ns + 1];
+    for (int j = threadIdx.x; j < ns; j += blockDim.x) {
+        const double sigma = ms[j], zm = ms[ns + j], z0 = ms[2 * ns + j];
+        if (fabs(z0) < 1e-100) {      // this shift converged long ago (its residual is zeta^2 |r|^2): freeze it before zeta underflows to 0/0
+            ms[3 * ns + j] = 0.0; ms[4 * ns + j] = 0.0; ms[5 * ns + j] = 0.0;
+            continue;
+        }
+        const double den = zm * alpha_m * (1.0 + alpha * sigma) + alpha * beta_m * (zm - z0);
+        const double zp = z0 * zm * alpha_m / den, ratio = zp / z0;
+        ms[3 * ns + j] = ratio * alpha;
+        if (zp * zp * sc[S_RR] < sc[S_EPS]) {
+            // the residual of this shift, zeta^2 |r|^2, is below the target once x_j has taken this step: last update, then the
+            // shift is frozen (p_j = 0, no further traffic) -- large shifts drop out after a few tens of iterations
+            ms[4 * ns + j] = 0.0; ms[5 * ns + j] = 0.0; ms[ns + j] = 0.0; ms[2 * ns + j] = 0.0;
+            continue;
+        }
+        ms[4 * ns + j] = ratio * ratio * beta;
+        ms[5 * ns + j] = zp;
+        ms[ns + j] = z0;
+        ms[2 * ns + j] = zp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { ms[6 * ns] = alpha; ms[6 * ns + 1] = beta; }
+}
+// base system (x += alpha p ; p = r + beta p) and every active shifted system j (x_j += a_j p_j ; p_j = b_j p_j + z_j r) in one pass:
+// r is read once per element, frozen shifts cost nothing.  x is still updated in the iteration that converges; nothing is touched
+// afterwards.
+__global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ sc, const double* __restrict__ ms, double2* const* __restrict__ ptr,
+                                                     double2* __restrict__ x0, double2* __restrict__ p0, const double2* __restrict__ r, size_t n,
+                                                     int ns) {
+    if (sc[S_XDONE] != 0.0) return;
+    const double al = sc[S_ALPHA], be = sc[S_BETA];
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 rv = r[i];
+        {
+            double2 pv = p0[i];
+            if (x0) {          // the unshifted solution is optional (a rational action only wants the shifted ones)
+                double2 xv = x0[i];
+                xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+                x0[i] = xv;
+            }
+            pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
+            p0[i] = pv;
+        }
+        for (int j = 0; j < ns; j++) {
+            const double a = ms[3 * ns + j], bb = ms[4 * ns + j], z = ms[5 * ns + j];
+            if (a == 0.0 && bb == 0.0 && z == 0.0) continue;       // frozen shift
+            double2* __restrict__ x = ptr[j];
+            double2* __restrict__ p = ptr[ns + j];
+            double2 pv = p[i], xv = x[i];
+            xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y);
+            pv.x = fma(bb, pv.x, z * rv.x); pv.y = fma(bb, pv.y, z * rv.y);
+            x[i] = xv; p[i] = pv;
+        }
+    }
+}
+}  // namespace lqcd
+
+// (D^+D + sigma_j) x_j = b for all j < ns, plus the unshifted solution x0 (may be NULL): one Krylov space, the shifted
+// iterates follow from the zeta recurrences, which run on the device next to the CG scalars (no host round trip inside an
+// iteration; the host polls the convergence flag every 8 iterations).  Zero initial guesses.  Stops when |r|^2 < eps
+// (for sigma_j >= 0 every |zeta_j| <= 1, so the shifted residuals zeta_j r are then below eps as well).
+extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
+                                        double eps, int maxiter, int* iters, double* final_rr) {
+    ARGCHK(op && b && ns >= 0 && ns <= 1024 && (ns == 0 || (xs && sigma)), "lqcd_solve_multishift_cg: null argument or more than 1024 shifts");
+    ARGCHK(b->ctx == op->ctx && b->kind == op->kind && b->subset == LQCD_FULL, "lqcd_solve_multishift_cg: b must be a FULL spinor of the operator");
+    for (int j = 0; j < ns; j++) {
+        ARGCHK(xs[j] && xs[j]->ctx == op->ctx && xs[j]->kind == op->kind && xs[j]->subset == LQCD_FULL && xs[j] != b,
+               "lqcd_solve_multishift_cg: xs[j] must be distinct FULL spinors of the operator");
+        ARGCHK(sigma[j] >= 0.0, "lqcd_solve_multishift_cg: shifts must be non-negative");
+    }
+    if (x0) LQCHK(check_full(op, x0, b, "lqcd_solve_multishift_cg"));
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = b->elems, bytes = n * sizeof(double2);
+    lqcd_spinor_s* xbase = x0;          // may stay null: then the base system only drives the Krylov space
+    lqcd_spinor_s* r = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* p = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* q = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* tmp = scratch_get(c, op->kind, LQCD_FULL);
+    std::vector<lqcd_spinor_s*> ps(ns, nullptr);
+    bool ok = r && p && q && tmp;
+    for (int j = 0; j < ns && ok; j++) { ps[j] = scratch_get(c, op->kind, LQCD_FULL); ok = ps[j] != nullptr; }
+    const size_t ms_doubles = 6 * (size_t)ns + 2, ms_bytes = ms_doubles * sizeof(double) + 2 * (size_t)ns * sizeof(double2*);
+    char* d_blk = nullptr;
+    if (ok && hipMalloc((void**)&d_blk, ms_bytes) != hipSuccess) ok = false;
+    auto release = [&]() {
+        scratch_put(r); scratch_put(p); scratch_put(q); scratch_put(tmp);
+        for (auto* s : ps) scratch_put(s);
+        if (d_blk) (void)hipFree(d_blk);
+    };
+    if (!ok) { release(); set_error("lqcd_solve_multishift_cg: out of device memory"); return LQCD_ERR_HIP; }
+    double* d_ms = (double*)d_blk;
+    double2** d_ptr = (double2**)(d_blk + ms_doubles * sizeof(double));
+    auto run = [&]() -> int {
+        if (xbase) HIPCHK(hipMemsetAsync(xbase->data, 0, bytes, c->stream));
+        HIPCHK(hipMemcpyAsync(r->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(p->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+        std::vector<double> hms(ms_doubles, 1.0);    // zeta_{-1} = zeta_0 = 1, alpha_{-1} = 1
+        std::vector<double2*> hptr(2 * (size_t)ns);
+        for (int j = 0; j < ns; j++) {
+            HIPCHK(hipMemsetAsync(xs[j]->data, 0, bytes, c->stream));
+            HIPCHK(hipMemcpyAsync(ps[j]->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+            hms[j] = sigma[j];
+            hptr[j] = xs[j]->data;
+            hptr[ns + j] = ps[j]->data;
+        }
+        hms[6 * (size_t)ns + 1] = 0.0;               // beta_{-1} = 0
+        HIPCHK(hipMemcpyAsync(d_ms, hms.data(), ms_doubles * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (ns) HIPCHK(hipMemcpyAsync(d_ptr, hptr.data(), 2 * (size_t)ns * sizeof(double2*), hipMemcpyHostToDevice, c->stream));
+        double rr = 0.0;
+        LQCHK(blas_norm2(c, r->data, n, &rr, true));
+        double init[9] = {rr, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
+        HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int it = 0;
+        bool converged = rr < eps;
+        const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n), check_every = 8;
+        while (!converged && it < maxiter) {
+            const int burst = std::min(check_every, maxiter - it);
+            for (int k = 0; k < burst; k++) {
+                // tmp = D p, alpha = rr / |tmp|^2 ; r -= alpha D^+ tmp in the stencil epilogue, beta = rr'/rr
+                LQCHK(op_apply_async(op, tmp, p, 0, c->d_partial, c->d_scal));
+                LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));
+                apply_bc(c, op->bc);
+                StencilCall s2;
+                LQCHK(make_full_call(op, q, tmp, 1, s2));
+                s2.norm_partial = c->d_partial;
+                s2.upd_scal = c->d_scal;
+                s2.upd[0] = spinor_block(r, 0);
+                s2.upd[1] = spinor_block(r, 1);
+                LQCHK(stencil_apply(c, s2));
+                LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
+                if (ns) hipLaunchKernelGGL(ms_zeta, dim3(1), dim3(64), 0, c->stream, c->d_scal, d_ms, ns);
+                hipLaunchKernelGGL(ms_update_all, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase ? xbase->data : (double2*)nullptr, p->data,
+                                   r->data, n, ns);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            rr = c->h_scal[S_RR - S_RR];
+            it = (int)c->h_scal[S_ITERS - S_RR];
+            if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
+            if (!std::isfinite(rr)) { set_error("multi-shift CG: residual is not finite"); break; }
+        }
+        if (iters) *iters = it;
+        if (final_rr) *final_rr = rr;
+        if (!converged) {
+            if (std::isfinite(rr))
+                set_error("The shifted CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+            return LQCD_ERR_NOT_CONVERGED;
+        }
+        return LQCD_OK;
+    };
+    const int st = run();
+    (void)hipStreamSynchronize(c->stream);
+    release();
+    return st;
+}

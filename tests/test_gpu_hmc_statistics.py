@@ -1,0 +1,75 @@
+"""Statistical parity pins that need no Julia: long HMC streams on the device, 4^4, from the reference's own
+thermalised fixtures with the parameters of its test/*.toml files, binned errors.
+
+ (i)   the rational path at Nf = 4 (full-lattice S_f = phi^+ (D^+D)^(-1/2) phi, heat bath and force through the partial fractions)
+       samples the same ensemble as the exact even-site 4-taste action: <P> agrees within 3 sigma;
+ (ii)  <P> is monotone in the number of staggered flavours, quenched < Nf = 2 < 3 < 4, within errors, and the end-to-end
+       difference is significant;
+ (iii) <exp(-dH)> = 1 within errors for every action (quenched, Wilson Nf = 2, staggered Nf = 4 exact and rational, Nf = 2, Nf = 3):
+       heat bath, action and force belong to the SAME Hamiltonian (a wrong exponent in the heat bath, a force that is not the
+       derivative of the action, or a missing term shows up here).
+The long-run means are recorded next to the reference's single-configuration values (test/debugplaqdata.txt:2,7-10) in DESIGN.md
+section 4; round 1's "+5 %" Nf = 2 / 3 plaquettes were single configurations after 10 trajectories (sigma per configuration ~0.012)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hmc_harness as hh
+
+pytestmark = pytest.mark.gpu
+
+THERM = 20
+NTRAJ = {"quenched": 300, "wilson_nf2": 200, "staggered_nf4_evensite": 200, "staggered_nf4_rational": 200, "staggered_nf2": 500, "staggered_nf3": 500}
+REF_SINGLE_CONFIG = {"quenched": 0.55783720583739, "wilson_nf2": 0.5784043949012552, "staggered_nf4_evensite": 0.5734383856968012,
+                     "staggered_nf2": 0.56287171870089, "staggered_nf3": 0.5595757232711884}        # /root/reference/test/debugplaqdata.txt:2,7,8,9,10
+
+
+@pytest.fixture(scope="module")
+def streams(lq):
+    assert lq.lib.device_count() > 0, "no HIP device visible: the product has no CPU fallback"
+    out = {}
+    for act, n in NTRAJ.items():
+        r = hh.run_stream(lq, act, THERM + n, seed=11)
+        P, eP = hh.binned(r["plaq"][THERM:])
+        E, eE = hh.binned(np.exp(-r["dH"][THERM:]))
+        out[act] = {"P": P, "eP": eP, "E": E, "eE": eE, "acc": float(r["accepted"][THERM:].mean()), "ntraj": n}
+        print("%-24s <P> = %.5f +- %.5f  <exp(-dH)> = %.4f +- %.4f  acceptance %.2f" % (act, P, eP, E, eE, out[act]["acc"]))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(out, open(os.path.join("gpurun_out", "hmc_statistics_test.json"), "w"), indent=1)
+    except OSError:
+        pass
+    return out
+
+
+def test_rational_nf4_samples_the_ensemble_of_the_exact_four_taste_action(streams):
+    a, b = streams["staggered_nf4_rational"], streams["staggered_nf4_evensite"]
+    sigma = np.hypot(a["eP"], b["eP"])
+    assert abs(a["P"] - b["P"]) < 3.0 * sigma, (a, b)
+    assert sigma < 0.004                              # the comparison has resolving power: a missing taste shifts <P> by ~0.006
+
+
+def test_plaquette_is_monotone_in_the_number_of_flavours(streams):
+    q, n2, n3, n4 = (streams[k] for k in ("quenched", "staggered_nf2", "staggered_nf3", "staggered_nf4_evensite"))
+    for lo, hi in ((q, n2), (n2, n3), (n3, n4)):
+        assert lo["P"] < hi["P"] + 2.0 * np.hypot(lo["eP"], hi["eP"]), (lo, hi)          # monotone within errors
+    assert n4["P"] - n2["P"] > 3.0 * np.hypot(n4["eP"], n2["eP"])                        # and the flavour dependence is resolved
+    assert n2["P"] - q["P"] > 3.0 * np.hypot(n2["eP"], q["eP"])
+
+
+@pytest.mark.parametrize("action", list(NTRAJ))
+def test_exp_minus_dH_averages_to_one(streams, action):
+    s = streams[action]
+    assert abs(s["E"] - 1.0) < 3.5 * s["eE"] + 0.002, s
+    assert s["acc"] > 0.8
+
+
+@pytest.mark.parametrize("action", list(REF_SINGLE_CONFIG))
+def test_long_run_mean_is_compatible_with_the_reference_single_configurations(streams, action):
+    """The reference records ONE configuration per action (after 10 trajectories); the spread of single 4^4 configurations around the
+    ensemble mean is ~0.012 (binned error x sqrt(N)), so a recorded value must lie within 3.5 of those -- a much tighter statement than
+    the reference's own 10 % (0.057) criterion."""
+    s = streams[action]
+    assert abs(s["P"] - REF_SINGLE_CONFIG[action]) < 3.5 * 0.012 + 3.0 * s["eP"], (s, REF_SINGLE_CONFIG[action])
