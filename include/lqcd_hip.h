@@ -80,7 +80,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * non-temporal output stores), lds_pad_kb, persist_per_cu;
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
  * mixed-precision CG), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
- * cg_skip_done, clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
+ * cg_skip_done, cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
+ * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
  * construction of the clover term / force also on one rank);
  * partitioned lattices: halo_merge (1 [default]: one message per peer when both faces go to the same rank), halo_stream_mode
  * (-1 [default]: time the three stream schedules of the halo exchange once; 0 | 1 | 2 force one), halo_tuned_us0..2 (read-only:
@@ -170,6 +171,8 @@ int lqcd_solve_cg_DdagD_parity(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, i
                                double* final_rr);
 int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,
                         int* iters, double* final_rr);           /* solve_DinvX!(y, D | D', x) (standardHMC.jl:71) */
+int lqcd_solve_bicg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters,
+                    double* final_rr);                               /* method_CG = "bicg", the reference's default: host-scalar BiCG with D and D^+ */
 int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter,
                            int* iters, double* final_rr);        /* even-odd preconditioned variant (Wilson; with a clover term the
                                                                   * Schur complement uses the inverse clover blocks, built on first use) */

@@ -274,8 +274,10 @@ function solve_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion)
 end
 function solve_DinvX!(y::HIPFermion, D::HIPDirac, x::HIPFermion)
     it, rr = Ref{Cint}(0), Ref{Float64}(0)
-    f = D.method_CG == "bicgstab_evenodd" ? :lqcd_solve_bicgstab_eo : :lqcd_solve_bicgstab
-    if f == :lqcd_solve_bicgstab_eo
+    if D.method_CG == "bicg"               # the reference's default method_CG
+        check(ccall((:lqcd_solve_bicg, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Ref{Cint}, Ref{Float64}),
+                    D.h, y.h, x.h, D.dagger, D.eps_CG, D.MaxCGstep, it, rr))
+    elseif D.method_CG == "bicgstab_evenodd"
         check(ccall((:lqcd_solve_bicgstab_eo, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Ref{Cint}, Ref{Float64}),
                     D.h, y.h, x.h, D.dagger, D.eps_CG, D.MaxCGstep, it, rr))
     else

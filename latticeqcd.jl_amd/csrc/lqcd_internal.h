@@ -207,6 +207,22 @@ template <int K> __device__ inline cd mul_ipow(cd a) {
 constexpr int PERM[3][4] = {{3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}};
 constexpr int GK[3][4] = {{3, 3, 1, 1}, {2, 0, 0, 2}, {3, 1, 1, 3}};
 
+// sum of n <= 1024 block partials in EXACTLY the order of reduce_final (blas.hip) for such n: sixteen groups of 64 partials, a wave
+// shuffle tree over each, then the group sums in sequence -- every wave of every workgroup gets the same bits the one-block kernel would
+// have produced.  All 64 lanes of the calling wave must be active.
+__device__ inline double sum_partials_small(const double* __restrict__ partial, int n) {
+    const int lane = threadIdx.x & 63;
+    double t = 0.0;
+    for (int v = 0; v * 64 < n; v++) {
+        const int i = v * 64 + lane;
+        double s = i < n ? partial[i] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        t += __shfl(s, 0, 64);
+    }
+    return t;
+}
+
 // ---------------------------------------------------------------- counter-based RNG (identical bits on every rank / decomposition)
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -249,6 +265,8 @@ struct Tunables {
     int halo_tuned_us[3] = {0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
+    int cg_small = 1;         // fused CG on an unpartitioned lattice with <= 1024 stencil workgroups: the two reduction launches of an iteration are folded
+                              // into the prologues of the kernels that consume them (3 dependent launches per iteration instead of 5)
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
@@ -391,12 +409,17 @@ struct StencilCall {
     double2* upd[2] = {nullptr, nullptr};
     const double* skip_flag = nullptr;  // device scalar block: the interior launch is a no-op once skip_flag[S_DONE] is set (iterations
                                         // enqueued behind the converging one in a burst)
+    // small lattices (cg_small): no separate reduction launches.  The update-mode kernel sums the <= 1024 block partials of the previous
+    // kernel itself (every wave, in reduce_final's order: identical iterates) and forms alpha = rr / pq in its prologue.
+    const double* alpha_partials = nullptr;
+    int alpha_n = 0;
+    double* scal_w = nullptr;     // the device scalar block, writable: block 0 records pq, alpha and the rr this iteration started from
     const double2* gauge12 = nullptr;  // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
     const double2* clover = nullptr;    // packed clover blocks: the Wilson split kernel (variant 1) applies A to xin in its epilogue
     int prec = 0;                 // 0: fp64 fields, 1: fp32 fields (pointers are float2 data, see p32)
 };
 // slots of the device scalar block d_scal used by the solvers
-enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16 };
+enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17 };
 // BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
 enum { B_RHO = 24, B_R0V = 26, B_ALPHA = 28, B_SS = 30, B_TS = 31, B_TT = 33, B_OMEGA = 34, B_RR = 36, B_RHO1 = 37, B_BETA = 39,
        B_DONE = 41, B_ITERS = 42, B_EPS = 43, B_HALF = 44, B_RES = 45, B_END = 46 };

@@ -72,6 +72,33 @@ __global__ __launch_bounds__(UB) void cg_update_xp(const double* __restrict__ s,
         }
     }
 }
+// cg_small: the same tail with the second reduction folded in.  Every wave sums the block partials of |r|^2 the update-mode stencil left
+// (reduce_final's order), forms beta = rr' / rr (rr = the value this iteration started from, S_RROLD: nobody writes it here) and the
+// convergence test itself; block 0 records rr', beta, the iteration count and the done flag for the kernels behind this one.
+__global__ __launch_bounds__(UB) void cg_update_xp_small(double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ p,
+                                                          const double2* __restrict__ r, size_t n, const double* __restrict__ part, int nb) {
+    if (s[S_XDONE] != 0.0) return;
+    const double rrn = sum_partials_small(part, nb);
+    const double al = s[S_ALPHA], be = rrn / s[S_RROLD];
+    const bool cont = !(rrn < s[S_EPS]);
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        double2 pv = p[i], xv = x[i];
+        xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+        x[i] = xv;
+        if (cont) {
+            const double2 rv = r[i];
+            pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
+            p[i] = pv;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s[S_RRNEW] = rrn;
+        s[S_BETA] = be;
+        s[S_RR] = rrn;
+        s[S_ITERS] += 1.0;
+        if (!cont) s[S_DONE] = 1.0;
+    }
+}
 // p = r + beta p
 __global__ __launch_bounds__(UB) void cg_update_p(const double* __restrict__ s, double2* __restrict__ p, const double2* __restrict__ r, size_t n) {
     if (s[S_DONE] != 0.0) return;
@@ -120,10 +147,41 @@ __global__ __launch_bounds__(UB) void redot_partial_kernel(const double2* __rest
 }
 
 
+// cg_small applies when the reductions are local (no communicator), at most 1024 block partials exist, and the stencil kernel in use
+// takes alpha from emit()'s argument (every variant but the hop-split ones)
+static bool cg_small_ok(lqcd_op_s* op, int nbs) {
+    lqcd_ctx_s* c = op->ctx;
+    if (any_partitioned(c) || c->has_comm || nbs > 1024) return false;
+    const int v = c->tun.dslash_variant;
+    if (op->kind == LQCD_WILSON && op->r == 1.0 && (v == 2 || v == 3)) return false;
+    return true;
+}
+
 // enqueue one CG iteration on the compute stream (no host synchronisation)
 int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n = x->elems;
+    const int nbs_small = stencil_num_partials(c, op->kind, op->r, 2);
+    if (c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, nbs_small)) {
+        // small lattices: launch latency is the cost.  Same arithmetic as the fused form below, but the two single-block reductions
+        // are folded into the prologues of their consumers -- 3 dependent launches per iteration instead of 5, identical iterates.
+        double* part_a = c->d_partial;            // |D p|^2 block partials
+        double* part_b = c->d_partial + 2048;     // |r|^2 block partials (the update-mode kernel reads part_a while its blocks write these)
+        LQCHK(op_apply_async(op, w.tmp, w.p, 0, part_a, c->tun.cg_skip_done ? c->d_scal : nullptr));
+        apply_bc(c, op->bc);
+        StencilCall s2;
+        LQCHK(make_full_call(op, w.q, w.tmp, 1, s2));
+        s2.norm_partial = part_b;
+        s2.upd_scal = c->d_scal;
+        s2.upd[0] = spinor_block(w.r, 0);
+        s2.upd[1] = spinor_block(w.r, 1);
+        s2.alpha_partials = part_a; s2.alpha_n = nbs_small; s2.scal_w = c->d_scal;
+        LQCHK(stencil_apply(c, s2));
+        const int nbu = stream_grid(c, n);
+        hipLaunchKernelGGL(cg_update_xp_small, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n, part_b, nbs_small);
+        HIPCHK(hipGetLastError());
+        return LQCD_OK;
+    }
     if (c->tun.cg_fused >= 2) {
         // fully fused form: 10 spinor passes per iteration instead of 13, q = D^+ D p is never written
         //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
@@ -539,6 +597,58 @@ extern "C" int lqcd_solve_bicgstab(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t 
         return op_apply_async(op, &vout, &vin, dagger ? 1 : 0, nullptr);
     };
     return bicgstab_core(c, A, x->elems, x->data, b->data, wd, eps, maxiter, iters, final_rr);
+}
+
+// BiCG (`bicg`, the default method_CG of solve_DinvX!(y, D, x): SURVEY.md 3.3): coupled recurrences with A and A^+, shadow residual
+// r~_0 = r_0, stopping rule real(r.r) < eps.  Offered for completeness of the reference's solver list: the scalars go through the host
+// (three synchronising reductions per iteration); the hot paths use the device-scalar CG / BiCGStab above.  x holds the initial guess.
+extern "C" int lqcd_solve_bicg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int dagger, double eps, int maxiter, int* iters, double* final_rr) {
+    LQCHK(check_full(op, x, b, "lqcd_solve_bicg"));
+    ARGCHK(maxiter >= 0, "lqcd_solve_bicg: maxiter < 0");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    ScratchScope pool(c);
+    lqcd_spinor_s* w[6];
+    for (auto& f : w) { f = pool.get(op->kind, LQCD_FULL); if (!f) return LQCD_ERR_HIP; }
+    lqcd_spinor_s *r = w[0], *rt = w[1], *p = w[2], *pt = w[3], *q = w[4], *qt = w[5];
+    const size_t n = x->elems, bytes = n * sizeof(double2);
+    const int dg = dagger ? 1 : 0;
+    LQCHK(op_apply_async(op, q, x, dg, nullptr));
+    HIPCHK(hipMemcpyAsync(r->data, b->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, q->data, r->data, n));
+    for (lqcd_spinor_s* f : {rt, p, pt}) HIPCHK(hipMemcpyAsync(f->data, r->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+    double rr = 0, im = 0;
+    LQCHK(blas_norm2(c, r->data, n, &rr, true));
+    std::complex<double> rho(rr, 0.0);      // <r~, r> with r~ = r
+    int it = 0;
+    bool converged = rr < eps;
+    while (!converged && it < maxiter) {
+        it++;
+        LQCHK(op_apply_async(op, q, p, dg, nullptr));
+        LQCHK(op_apply_async(op, qt, pt, 1 - dg, nullptr));
+        double dr = 0, di = 0;
+        LQCHK(blas_dot(c, pt->data, q->data, n, &dr, &di, true));
+        const std::complex<double> alpha = rho / std::complex<double>(dr, di);
+        if (!std::isfinite(alpha.real()) || !std::isfinite(alpha.imag())) { set_error("BiCG: breakdown (<p~, A p> = 0)"); return LQCD_ERR_NOT_CONVERGED; }
+        LQCHK(blas_axpy(c, alpha.real(), alpha.imag(), p->data, x->data, n));
+        LQCHK(blas_axpy(c, -alpha.real(), -alpha.imag(), q->data, r->data, n));
+        LQCHK(blas_axpy(c, -alpha.real(), alpha.imag(), qt->data, rt->data, n));        // r~ -= conj(alpha) A^+ p~
+        LQCHK(blas_norm2(c, r->data, n, &rr, true));
+        if (rr < eps) { converged = true; break; }
+        LQCHK(blas_dot(c, rt->data, r->data, n, &dr, &im, true));
+        const std::complex<double> rho1(dr, im), beta = rho1 / rho;
+        LQCHK(blas_axpby(c, 1.0, 0.0, r->data, beta.real(), beta.imag(), p->data, n));          // p = r + beta p
+        LQCHK(blas_axpby(c, 1.0, 0.0, rt->data, beta.real(), -beta.imag(), pt->data, n));       // p~ = r~ + conj(beta) p~
+        rho = rho1;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (!converged) {
+        set_error("The BiCG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
 }
 
 // even-odd (Schur) preconditioned BiCGStab, Wilson:

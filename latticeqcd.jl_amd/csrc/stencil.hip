@@ -47,6 +47,9 @@ struct KArgs {
     const double* upd_scal;   // update mode (see StencilCall)
     real2* upd[2];
     const double* skip;       // scalar block whose S_DONE flag turns the launch into a no-op (the solver has converged)
+    const double* alpha_partials;   // cg_small (see StencilCall): block partials of |D p|^2 to be summed in the prologue, or nullptr
+    int alpha_n;
+    double* scal_w;
 };
 
 typedef real v2d __attribute__((ext_vector_type(2)));
@@ -64,9 +67,8 @@ __device__ inline void st_nt(real2* p, cd v) {
 }
 
 // final store of one output component: plain (out = v) or CG update mode (r -= alpha v); accumulates the squared norm
-__device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm) {
+__device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm, real al) {
     if (k.upd_scal) {
-        const real al = k.upd_scal[S_ALPHA];
         real2* rp = k.upd[p] + off;
         cd r = ld(rp);
         r.re = fma(-al, v.re, r.re); r.im = fma(-al, v.im, r.im);
@@ -78,7 +80,22 @@ __device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm) 
     }
 }
 __device__ inline bool upd_done(const KArgs& k) {
-    return (k.upd_scal && k.upd_scal[S_DONE] != 0.0) || (k.skip && k.skip[S_DONE] != 0.0);
+    const bool done = (k.upd_scal && k.upd_scal[S_DONE] != 0.0) || (k.skip && k.skip[S_DONE] != 0.0);
+    // cg_small: the update-mode launch of an overshooting iteration tells the x/p update behind it that the converging iterate is complete
+    if (done && k.alpha_partials && blockIdx.x == 0 && threadIdx.x == 0) k.scal_w[S_XDONE] = 1.0;
+    return done;
+}
+// alpha of the CG update mode: from the scalar block, or (cg_small) rr / sum of the previous kernel's block partials, formed by every wave
+__device__ inline real update_alpha(const KArgs& k) {
+    if (!k.upd_scal) return real(0);
+    if (k.alpha_partials) {
+        const double pq = sum_partials_small(k.alpha_partials, k.alpha_n);
+        const double rr = k.upd_scal[S_RR];
+        const double al = rr / pq;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { k.scal_w[S_PQ] = pq; k.scal_w[S_ALPHA] = al; k.scal_w[S_RROLD] = rr; }
+        return (real)al;
+    }
+    return (real)k.upd_scal[S_ALPHA];
 }
 
 struct HArgs {  // halo kernels
@@ -185,7 +202,18 @@ __device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U, bool
 
 // spin projection h = rows 0,1 of (1 - S*gamma_mu) psi   (mu = 3: the two non-zero rows, factor 2 included)
 template <int MU, int S>
-__device__ inline void project(cd (&h0)[3], cd (&h1)[3], const real2* __restrict__ psi, int Vh) {
+__device__ inline void project(cd (&h0)[3], cd (&h1)[3], const real2* __restrict__ psi, int Vh, bool nt = false) {
+    if constexpr (MU == 3) {
+        if (nt) {       // last use of these spinor lines in the t-sweep of the workgroup map: stream them
+            constexpr int base = S > 0 ? 2 : 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                h0[c] = 2.0 * ld_nt(psi + (size_t)(base * 3 + c) * Vh);
+                h1[c] = 2.0 * ld_nt(psi + (size_t)((base + 1) * 3 + c) * Vh);
+            }
+            return;
+        }
+    }
     if constexpr (MU < 3) {
         constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
         constexpr int k0 = GK[MU][0] + (S > 0 ? 2 : 0), k1 = GK[MU][1] + (S > 0 ? 2 : 0);
@@ -230,9 +258,9 @@ __device__ inline void reconstruct(cd (&acc)[12], const cd (&chi0)[3], const cd 
 // one hop, r = 1:  acc += (1 - S gamma_mu) [U or U^+] psi(nb) * sign
 template <int MU, int S, bool ADJ, bool R12 = false>
 __device__ inline void wilson_hop(cd (&acc)[12], const real2* __restrict__ psi, const real2* __restrict__ U,
-                                  int Vh, int Us, real sign, bool nt = false) {
+                                  int Vh, int Us, real sign, bool nt = false, bool nt_psi = false) {
     cd h0[3], h1[3], chi0[3], chi1[3], u[9];
-    project<MU, S>(h0, h1, psi, Vh);
+    project<MU, S>(h0, h1, psi, Vh, nt_psi);
     if constexpr (R12) load_link12(u, U, nt);
     else { if (nt) load_link_nt(u, U, Us); else load_link(u, U, Us); }
 #pragma unroll
@@ -329,6 +357,7 @@ __device__ inline void block_norm_partial(double v, double* partial) {
 template <int TB, bool DAG, bool RGEN>
 __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
@@ -367,7 +396,7 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             cd v = mk(fma(k.b, acc[j].re, k.a * xv[j].re), fma(k.b, acc[j].im, k.a * xv[j].im));
-            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm);
+            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm, al_upd);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
@@ -400,7 +429,7 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     }
 #endif
     if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU], (k.nt & 2) != 0);
-    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0);
+    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0, (k.nt & 8) != 0);
 }
 
 // rows 3*W .. 3*W+2 of A x for the packed clover field (clover.hip: two Hermitian 6x6 blocks in the chiral basis chi_(-+) =
@@ -443,6 +472,7 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     __shared__ real2 part[4][12][64];  // 48 KiB
     __shared__ double red[4];
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
@@ -490,7 +520,7 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
             cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
             cd v = k.b * s;
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
-            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm);
+            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm, al_upd);
         }
     }
     if (k.norm_partial) {
@@ -561,6 +591,7 @@ template <bool DAG, bool R12>
 __global__ __launch_bounds__(256) void wilson_lanesplit(KArgs k) {
     __shared__ double red[4];
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
     const Geom& g = k.g;
@@ -683,7 +714,7 @@ __global__ __launch_bounds__(256) void wilson_lanesplit(KArgs k) {
         for (int c = 0; c < 3; c++) {
             cd v = k.b * F[c];
             v = mk(fma(k.a, xv[c].re, v.re), fma(k.a, xv[c].im, v.im));
-            emit(k, p, (size_t)(3 * lr + c) * 64 + sp_off(12, i), v, nrm);
+            emit(k, p, (size_t)(3 * lr + c) * 64 + sp_off(12, i), v, nrm, al_upd);
         }
     }
     if (k.norm_partial) {
@@ -775,6 +806,7 @@ __global__ __launch_bounds__(256, 4) void wilson_dirsplit4(KArgs k) {
     __shared__ real2 part[4][3][3][64];  // [destination wave = spin row][source slot][colour][lane]: 36 KiB
     __shared__ double red[4];
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
     const int Vh = sp_stride(k.g);
@@ -809,7 +841,7 @@ __global__ __launch_bounds__(256, 4) void wilson_dirsplit4(KArgs k) {
             cd s = mk((sv[0].re + sv[1].re) + (sv[2].re + sv[3].re), (sv[0].im + sv[1].im) + (sv[2].im + sv[3].im));
             cd v = k.b * s;
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
-            emit(k, p, (size_t)(3 * w + cc) * Vh + sp_off(12, i), v, nrm);
+            emit(k, p, (size_t)(3 * w + cc) * Vh + sp_off(12, i), v, nrm, al_upd);
         }
     }
     if (k.norm_partial) {
@@ -951,6 +983,7 @@ __global__ __launch_bounds__(512) void wilson_hopsplit(KArgs k) {
     const int i = chunk * 64 + lane;
     const bool valid = i < k.g.Vh;
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     cd xv[2] = {mk(0, 0), mk(0, 0)}, rv[2] = {mk(0, 0), mk(0, 0)};
     if (valid && w < 6 && k.a != 0.0) {
         xv[0] = ld(k.xin[p] + sp_off(12, i) + (size_t)(2 * w) * Vh);
@@ -1129,6 +1162,7 @@ __global__ __launch_bounds__(512, 4) void wilson_hopsplit_persist(KArgs k, int n
     __shared__ real2 half[8][6][64];  // 48 KiB
     __shared__ double red[8];
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (w) {
     case 0: hopsplit_persist_loop<0, false, DAG>(k, half, red, nvirt); break;
@@ -1166,6 +1200,7 @@ __device__ inline real stag_eta(const int c[4], int mu) {
 template <int TB>
 __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
@@ -1192,7 +1227,7 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
                 cd xv = ld(k.xin[p] + sp_off(3, i) + (size_t)j * Vh);
                 v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
             }
-            emit(k, p, (size_t)j * Vh + sp_off(3, i), v, nrm);
+            emit(k, p, (size_t)j * Vh + sp_off(3, i), v, nrm, al_upd);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
@@ -1207,6 +1242,7 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
     __shared__ real2 part[4][3][64];
     __shared__ double red[4];
     if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
     const int Vh = sp_stride(k.g);
@@ -1241,7 +1277,7 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         const real2 s0 = part[0][w][lane], s1 = part[1][w][lane], s2 = part[2][w][lane], s3 = part[3][w][lane];
         cd v = k.b * mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
-        emit(k, p, (size_t)w * Vh + sp_off(3, i), v, nrm);
+        emit(k, p, (size_t)w * Vh + sp_off(3, i), v, nrm, al_upd);
     }
     if (k.norm_partial) {
 #pragma unroll
@@ -1566,7 +1602,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
 #ifdef LQCD_ABLATE
     k.dbg = c->tun.dbg;
 #endif
-    k.nt = (c->tun.nt_gauge & 3) | (c->tun.nt_store ? 4 : 0);
+    k.nt = (c->tun.nt_gauge & 3) | (c->tun.nt_store ? 4 : 0) | ((c->tun.nt_gauge & 4) ? 8 : 0);
     const int ys = c->tun.xcd_ysplit;
     if (ys > 1 && k.cps > 0 && k.cpp > 0 && k.cpp % ys == 0 && k.nsub % ys == 0 && c->geom.L[2] % (k.nsub / ys) == 0) k.ysplit = ys;
     k.cpr = k.cps > 0 ? k.cps / k.nsub : 1;
@@ -1580,6 +1616,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.upd_scal = s.upd_scal;
     k.upd[0] = (real2*)s.upd[0]; k.upd[1] = (real2*)s.upd[1];
     k.skip = s.skip_flag;
+    k.alpha_partials = s.alpha_partials; k.alpha_n = s.alpha_n; k.scal_w = s.scal_w;
     return k;
 }
 

@@ -391,7 +391,7 @@ def hop_(y, D, x):
 
 def solve_DinvX_(y, A, x, return_info=False):
     """solve_DinvX!(y, A, x): y = A^{-1} x.  A::DdagD_operator -> CG; A::Dirac_operator -> BiCGStab
-    ("bicgstab") or its even-odd preconditioned form ("bicgstab_evenodd").  Stopping rule real(r.r) < eps_CG;
+    ("bicgstab"), its even-odd preconditioned form ("bicgstab_evenodd") or BiCG ("bicg", the reference's default).  Stopping rule real(r.r) < eps_CG;
     raises NotConverged after MaxCGstep (the reference raises error(...))."""
     it, rr = C.c_int(0), C.c_double(0)
     L = _l.lib()
@@ -399,7 +399,9 @@ def solve_DinvX_(y, A, x, return_info=False):
         st = L.lqcd_solve_cg_DdagD(A.D._h, y._h, x._h, C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr))
     elif A.method_CG in ("bicgstab_evenodd", "preconditiond_bicgstab"):
         st = L.lqcd_solve_bicgstab_eo(A._h, y._h, x._h, int(A.dagger), C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr))
-    elif A.method_CG in ("bicgstab", "bicg"):
+    elif A.method_CG == "bicg":
+        st = L.lqcd_solve_bicg(A._h, y._h, x._h, int(A.dagger), C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr))
+    elif A.method_CG == "bicgstab":
         st = L.lqcd_solve_bicgstab(A._h, y._h, x._h, int(A.dagger), C.c_double(A.eps_CG), A.MaxCGstep, C.byref(it), C.byref(rr))
     else:
         raise LQCDError(_l.ERR_ARG, f"method_CG = {A.method_CG} is not supported")

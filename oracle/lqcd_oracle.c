@@ -450,6 +450,42 @@ int orc_bicgstab(int kind, double* x, const double* U, const double* b, const in
     return bicgstab_core(apply_full, &f, o.n, (cplx*)x, (const cplx*)b, eps, maxiter, iters, final_rr);
 }
 
+/* BiCG (Fletcher) for A x = b -- `bicg`, the default method_CG of solve_DinvX!(y, D, x) (SURVEY.md 3.3, Appendix A "Solvers"):
+ * two coupled recurrences with A and A^+, shadow residual r~_0 = r_0, stop on real(r.r) < eps. */
+int orc_bicg(int kind, double* xd, const double* U, const double* bd, const int L[4], double km, double r_w, const int bc[4], int dagger,
+             double eps, int maxiter, int* iters, double* final_rr) {
+    op_t o = mk_op(kind, U, L, km, r_w, bc);
+    const long n = o.n;
+    cplx* x = (cplx*)xd;
+    const cplx* b = (const cplx*)bd;
+    cplx *r = malloc(sizeof(cplx) * n), *rt = malloc(sizeof(cplx) * n), *p = malloc(sizeof(cplx) * n), *pt = malloc(sizeof(cplx) * n),
+         *q = malloc(sizeof(cplx) * n), *qt = malloc(sizeof(cplx) * n);
+    int status = 1, it = 0;
+    op_D(&o, q, x, dagger);
+    for (long i = 0; i < n; i++) { r[i] = b[i] - q[i]; rt[i] = r[i]; p[i] = r[i]; pt[i] = r[i]; }
+    double rr = norm2(r, n);
+    cplx rho = cdot(rt, r, n);
+    if (rr < eps) { status = 0; goto done; }
+    for (it = 1; it <= maxiter; it++) {
+        op_D(&o, q, p, dagger);
+        op_D(&o, qt, pt, !dagger);
+        cplx alpha = rho / cdot(pt, q, n);
+        for (long i = 0; i < n; i++) { x[i] += alpha * p[i]; r[i] -= alpha * q[i]; rt[i] -= conj(alpha) * qt[i]; }
+        rr = norm2(r, n);
+        if (rr < eps) { status = 0; break; }
+        cplx rho1 = cdot(rt, r, n);
+        cplx beta = rho1 / rho;
+        for (long i = 0; i < n; i++) { p[i] = r[i] + beta * p[i]; pt[i] = rt[i] + conj(beta) * pt[i]; }
+        rho = rho1;
+    }
+    if (it > maxiter) it = maxiter;
+done:
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    free(r); free(rt); free(p); free(pt); free(q); free(qt);
+    return status;
+}
+
 /* even-odd preconditioning, Wilson:  D = [[1, -k H_eo], [-k H_oe, 1]]
  *   (1 - k^2 H_eo H_oe) x_e = b_e + k H_eo b_o ;   x_o = b_o + k H_oe x_e
  * Vectors stay full-lattice sized here; the "even" system lives on even sites with odd sites zero. */

@@ -67,6 +67,8 @@ void orc_axpy(double ar, double ai, const double* x, double* y, long n);       /
  * x holds the initial guess on entry.  Return 0 = converged, 1 = not converged. */
 int orc_cg_DdagD(int kind, double* x, const double* U, const double* b, const int L[4], double kappa_or_mass,
                  double r, const int bc[4], double eps, int maxiter, int* iters, double* final_rr);
+int orc_bicg(int kind, double* x, const double* U, const double* b, const int L[4], double kappa_or_mass, double r, const int bc[4],
+             int dagger, double eps, int maxiter, int* iters, double* final_rr);
 int orc_bicgstab(int kind, double* x, const double* U, const double* b, const int L[4], double kappa_or_mass,
                  double r, const int bc[4], int dagger, double eps, int maxiter, int* iters, double* final_rr);
 /* even-odd (Schur) preconditioned BiCGStab for Wilson D x = b (full-lattice in/out) */

@@ -277,6 +277,14 @@ def wilson_clover_bicgstab_eo(U, A, b, L, kappa, r=1.0, bc=(1, 1, 1, -1), dagger
     return x, it.value, rr.value, st
 
 
+def bicg(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000):
+    x = np.zeros_like(b)
+    it, rr = C.c_int(0), C.c_double(0)
+    st = lib().orc_bicg(int(kind), _p(x), _p(U), _p(b), _i4(L), C.c_double(km), C.c_double(r), _i4(bc), int(bool(dagger)), C.c_double(eps),
+                        int(maxiter), C.byref(it), C.byref(rr))
+    return x, it.value, rr.value, st
+
+
 def bicgstab(kind, U, b, L, km, r=1.0, bc=(1, 1, 1, -1), dagger=False, eps=1e-19, maxiter=3000, x0=None):
     x = np.zeros_like(b) if x0 is None else x0.copy()
     it, rr = C.c_int(0), C.c_double(0)

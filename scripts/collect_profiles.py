@@ -1,40 +1,101 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/profile_r01 (rocprofv3 csv output) into the tracked files under profiles/."""
-import csv, glob, json, os, shutil, sys
+"""Condense gpurun_out/profile_<tag> (scripts/gpu_profile_round.sh) into the tracked files under profiles/ and regenerate the
+auto-generated table of profiles/README.md from them, so that every number quoted there is read from a committed file.
+usage: collect_profiles.py [tag]"""
+import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/profile_r01"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join("gpurun_out", "profile_" + tag)
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
+V = 32 * 32 * 32 * 64
+
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copyfile(f, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 for name in ("bench_n1.json", "trace_bench.json"):
     p = os.path.join(src, name)
-    if os.path.exists(p):
+    if os.path.exists(p) and os.path.getsize(p):
         shutil.copyfile(p, os.path.join(dst, f"{tag}_{name}"))
+
 acc = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        acc[(row["Kernel_Name"], row["Counter_Name"])][0] += float(row["Counter_Value"])
-        acc[(row["Kernel_Name"], row["Counter_Name"])][1] += 1
+        if "wilson" in row["Kernel_Name"]:
+            k = (row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Counter_Name"])
+            acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
 rows = [(k[0], k[1], v[0] / v[1], v[1]) for k, v in sorted(acc.items())]
-with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
-    f.write("kernel,counter,mean_per_launch,launches\n")
+if rows:
+    with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
+        f.write("kernel,counter,mean_per_launch,launches\n")
+        for r in rows:
+            f.write('"%s",%s,%.6g,%d\n' % r)
+
+# ---- the generated table
+lines = []
+def stat_row(kernel_substr):
+    p = os.path.join(dst, f"{tag}_bench_kernel_stats.csv")
+    if not os.path.exists(p):
+        return None
+    for row in csv.DictReader(open(p)):
+        if kernel_substr in row["Name"]:
+            return row
+    return None
+
+def pm(kernel_substr, counter):
     for r in rows:
-        f.write('"%s",%s,%.6g,%d\n' % r)
-m = {r[1]: r[2] for r in rows if "wilson_hopsplit<false" in r[0] or "wilson_interior<" in r[0] or "wilson_dirsplit<false" in r[0]}
-if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
-    # MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a 16-B/lane coalesced read -> doubled;
-    # both counters are in KiB.
-    traffic = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
-    out = {"wilson_dslash_bytes_per_launch_32x32x32x64": traffic, "FETCH_SIZE_KiB": m["FETCH_SIZE"], "WRITE_SIZE_KiB": m["WRITE_SIZE"],
-           "note": "HBM/fabric bytes per Wilson Dslash launch = (2*FETCH_SIZE + WRITE_SIZE) KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md",
-           "algorithmic_bytes": 960 * 32 * 32 * 32 * 64,
-           "kernel": [r[0] for r in rows if "wilson_dirsplit<false" in r[0] or "wilson_hopsplit<false" in r[0] or "wilson_interior<" in r[0]][0],
-           "compulsory_bytes_moved": "768 B/site when the kernel is wilson_dirsplit<false, true, ...> (12-real links, third row rebuilt), 960 otherwise"}
-    for k2 in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"):
-        if k2 in m:
-            out[k2] = m[k2]
-    json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(out))
-print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read()[:1500])
+        if kernel_substr in r[0] and r[1] == counter:
+            return r[2]
+    return None
+
+bench = trace = None
+try:
+    bench = json.loads(open(os.path.join(dst, f"{tag}_bench_n1.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+try:
+    trace = json.loads(open(os.path.join(dst, f"{tag}_trace_bench.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+lines.append(f"<!-- BEGIN GENERATED {tag} (scripts/collect_profiles.py {tag}) -->")
+lines.append(f"### {tag}: 32³×64 Wilson fp64 on one MI355X — every number below is read from the named file by `scripts/collect_profiles.py`")
+lines.append("")
+lines.append("| quantity | value | file |")
+lines.append("|---|---|---|")
+if bench:
+    r = bench["roofline"]; g = bench.get("gauge_recon18_all_reals_read", {})
+    lines.append(f"| CG iterations/s (`value`), ms per iteration | {bench['value']:.1f}, {bench['ms_per_step']:.4f} | `{tag}_bench_n1.json` |")
+    lines.append(f"| default Dslash kernel `{r['kernel']}`: HIP-event mean / per-launch median | {bench['dslash_ms']:.4f} / {bench['dslash_ms_median_per_launch_events']:.4f} ms | `{tag}_bench_n1.json` |")
+    lines.append(f"| `roofline.frac` (960 B/site algorithmic ÷ time ÷ 8 TB/s) / by the {r['compulsory_bytes_moved_per_site']} B/site it moves | {r['frac']:.3f} / {r['frac_by_bytes_moved']:.3f} | `{tag}_bench_n1.json` |")
+    if r.get("traffic"):
+        lines.append(f"| `roofline.traffic` measured in that run (live `--pmc` child passes) | {r['traffic'] / 1e9:.3f} GB per launch = {r['traffic_over_bytes_moved']:.3f} × the bytes moved | `{tag}_bench_n1.json` |")
+    if g and "dslash_ms" in g:
+        lines.append(f"| all 18 reals of every link read (`gauge_recon = 18`): Dslash, fraction of 8 TB/s on 960 B/site, CG | {g['dslash_ms']:.4f} ms, {g['frac_of_peak']:.3f}, {g['cg_iters_per_s']:.1f} iter/s | `{tag}_bench_n1.json` |")
+        if g.get("traffic"):
+            lines.append(f"| … its measured traffic | {g['traffic'] / 1e9:.3f} GB per launch = {g['traffic_over_bytes_moved']:.3f} × 960 B/site | `{tag}_bench_n1.json` |")
+    c = bench.get("cpu_baseline")
+    if c:
+        lines.append(f"| CPU baseline ({c['kind']}, {c['cores']} core) | {c['value']:.3f} iter/s, Dslash {c['dslash_gflops']:.2f} GFLOP/s | `{tag}_bench_n1.json` |")
+for sub, label in (("wilson_dirsplit<false, true, false>", "12-real D"), ("wilson_dirsplit<true, true, false>", "12-real D† (CG update mode)"),
+                   ("wilson_dirsplit<false, false, false>", "18-real D"), ("cg_update_xp", "x, p update"), ("reduce_final", "final reduction")):
+    s = stat_row(sub)
+    if s:
+        lines.append(f"| rocprofv3 `--kernel-trace --stats` of the same command: {label} `{sub}` | {float(s['AverageNs']) / 1e3:.1f} µs average over {s['Calls']} calls | `{tag}_bench_kernel_stats.csv` |")
+if trace:
+    lines.append(f"| `bench.py`'s HIP-event Dslash figure in that profiled run | {trace['dslash_ms']:.4f} ms | `{tag}_trace_bench.json` |")
+for sub, label in (("wilson_dirsplit<false, true, false>", "12-real kernel"), ("wilson_dirsplit<false, false, false>", "18-real kernel")):
+    fs, ws = pm(sub, "FETCH_SIZE"), pm(sub, "WRITE_SIZE")
+    if fs and ws:
+        tr = (2 * fs + ws) * 1024
+        moved = (768 if "true, false" in sub else 960) * V
+        hit, miss = pm(sub, "TCC_HIT_sum"), pm(sub, "TCC_MISS_sum")
+        lines.append(f"| PMC passes (separate): {label}: FETCH_SIZE, WRITE_SIZE → (2·FETCH + WRITE) KiB | {fs:.4g} KiB, {ws:.4g} KiB → {tr / 1e9:.3f} GB = {tr / moved:.3f} × bytes moved"
+                     + (f"; TCC hit {hit / (hit + miss):.3f}" if hit and miss else "") + f" | `{tag}_pmc_summary.csv` |")
+lines.append(f"<!-- END GENERATED {tag} -->")
+block = "\n".join(lines) + "\n"
+readme = os.path.join(dst, "README.md")
+text = open(readme).read() if os.path.exists(readme) else ""
+pat = re.compile(r"<!-- BEGIN GENERATED %s .*?<!-- END GENERATED %s -->\n" % (tag, tag), re.S)
+text = pat.sub(block, text) if pat.search(text) else block + "\n" + text
+open(readme, "w").write(text)
+print(block)

@@ -1,6 +1,7 @@
 """Solver edge cases: zero right-hand side, exact initial guess, non-finite input, iteration caps that are not a multiple of the
 polling burst -- for the CG, BiCGStab (plain and even-odd), multi-shift and mixed-precision solvers."""
 import numpy as np
+from conftest import rel_err
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -140,3 +141,63 @@ def test_four_taste_action_takes_the_half_lattice_solve(lq, orc):
     lat.set_param("staggered_parity_solve", 1)
     assert abs(out[1][0] - out[0][0]) < 1e-10 * abs(out[0][0]) and abs(out[1][1] - out[0][1]) <= 2
     assert np.abs(out[1][2] - out[0][2]).max() < 1e-9 * np.abs(out[0][2]).max()
+
+
+@pytest.mark.parametrize("kind_name,L", [("Staggered", (8, 8, 8, 8)), ("Wilson", (8, 8, 8, 8)), ("Wilson", (4, 4, 4, 4)), ("Staggered", (16, 8, 8, 8))])
+def test_small_lattice_cg_without_reduction_launches_gives_identical_iterates(lq, orc, kind_name, L):
+    """cg_small (default on small unpartitioned lattices): the reductions of a fused CG iteration run in the prologues of the kernels
+    that consume them, in reduce_final's summation order -- the solution must be bit-identical to the 5-launch iteration's, with the
+    same iteration count and residual, for to-tolerance solves and for the fixed-length window."""
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 941))
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": kind_name, "κ": 0.141139, "mass": 0.5, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-18})
+    b = lq.Fermionfields(lat, kind)
+    lq.gauss_distribution_fermion_(b, 942)
+    A = lq.DdagD_operator(D)
+    sols, infos = [], []
+    for small in (0, 1):
+        lat.set_param("cg_small", small)
+        x = b.similar()
+        infos.append(lq.solve_DinvX_(x, A, b, return_info=True))
+        sols.append(x.download())
+    assert infos[0][0] == infos[1][0] and infos[0][1] == infos[1][1] and infos[1][1] < 1e-18
+    assert np.array_equal(sols[0], sols[1])
+    wins = []
+    for small in (0, 1):
+        lat.set_param("cg_small", small)
+        x = b.similar()
+        lq.lib.check(lq.lib.lib().lqcd_solve_cg_DdagD_fixed(D._h, x._h, b._h, 7))
+        wins.append(x.download())
+    assert np.array_equal(wins[0], wins[1])
+    # a converged start: zero iterations either way
+    lat.set_param("cg_small", 1)
+    x = lq.Fermionfields(lat, kind).upload(sols[1])
+    it, rr = lq.solve_DinvX_(x, A, b, return_info=True)
+    assert it == 0 and rr < 1e-18
+
+
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+@pytest.mark.parametrize("dagger", [False, True])
+def test_bicg_matches_oracle(lq, orc, kind_name, dagger):
+    """method_CG = "bicg" (the reference's default for solve_DinvX!(y, D, x)): device BiCG = the oracle's, iteration for iteration,
+    and the true residual obeys the absolute stopping rule."""
+    L, bc = (4, 4, 4, 8), (1, 1, 1, -1)
+    kind, okind, km = (lq.WILSON, orc.WILSON, 0.12) if kind_name == "Wilson" else (lq.STAGGERED, orc.STAGGERED, 0.5)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 951)
+    U = lq.Gaugefields(lat).upload(Uh)
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": kind_name, "κ": km, "mass": km, "boundarycondition": bc, "eps_CG": 1e-18, "method_CG": "bicg"})
+    bh = orc.gaussian_spinor(lat.fermion_shape(kind), 952)
+    b = lq.Fermionfields(lat, kind).upload(bh)
+    x, y = b.similar(), b.similar()
+    Dd = D.adjoint() if dagger else D
+    it, rr = lq.solve_DinvX_(x, Dd, b, return_info=True)
+    xo, ito, rro, st = orc.bicg(okind, Uh, bh, L, km, 1.0, bc, dagger, eps=1e-18)
+    assert st == 0 and abs(it - ito) <= 1 and rr < 1e-18 and rel_err(x.download(), xo) < 1e-8
+    lq.mul_(y, Dd, x)
+    lq.add_fermion_(y, -1.0, b)
+    assert lq.dot(y, y).real < 1e-17
+    Dd.MaxCGstep = 3
+    with pytest.raises(lq.NotConverged):
+        lq.solve_DinvX_(x.similar(), Dd, b)
