@@ -80,7 +80,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * non-temporal output stores), lds_pad_kb, persist_per_cu;
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
  * mixed-precision CG), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
- * cg_skip_done, cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
+ * cg_skip_done, cg_defer_x (1 [default]: the fused CG updates x every second iteration with both search directions, p alternating between
+ * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates), cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
  * construction of the clover term / force also on one rank);
  * partitioned lattices: halo_merge (1 [default]: one message per peer when both faces go to the same rank), halo_stream_mode

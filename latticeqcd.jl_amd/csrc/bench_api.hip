@@ -141,6 +141,8 @@ extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int
         if (e != hipSuccess && st == LQCD_OK) st = hip_fail(e, "bench_cg timing", __FILE__, __LINE__);
         *ms_per_iter = (double)t / niter;
     }
+    if (st == LQCD_OK) st = cg_flush_x(op, x, w);
+    (void)hipStreamSynchronize(c->stream);
     scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
     return st;
 }
@@ -182,6 +184,8 @@ extern "C" int lqcd_cg_session_end(lqcd_op_t op) {
     ARGCHK(op && op->ctx->cg_session && static_cast<CgSession*>(op->ctx->cg_session)->op == op, "lqcd_cg_session_end: no open session for this operator");
     CgSession* ses = static_cast<CgSession*>(op->ctx->cg_session);
     CgWork& w = ses->w;
+    (void)cg_flush_x(op, ses->x, w);
+    (void)hipStreamSynchronize(op->ctx->stream);
     scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
     delete ses;
     op->ctx->cg_session = nullptr;

@@ -18,8 +18,10 @@ int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* wh
 constexpr int UB = 256;     // block size of the solvers' streaming kernels
 struct CgWork {
     lqcd_spinor_s *r, *p, *q, *tmp;
+    int k = 0;          // iterations enqueued so far (parity selects the p buffer when the x update is deferred: p_k lives in p for even k, in q for odd k)
 };
-int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w);
+int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);
+int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);    // applies a pending deferred x update (end of a window that stopped on an even iteration)
 int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0);
 typedef std::function<int(double2* out, const double2* in)> ApplyFn;
 

@@ -99,6 +99,62 @@ __global__ __launch_bounds__(UB) void cg_update_xp_small(double* __restrict__ s,
         if (!cont) s[S_DONE] = 1.0;
     }
 }
+// Deferred x update (cg_defer_x): iteration k even:  p_{k+1} = r + beta p_k into the OTHER buffer, x untouched, alpha_k kept;
+//                                    iteration k odd:   x += alpha_{k-1} p_{k-1} + alpha_k p_k (same order of operations as two single
+// updates: identical bits), p_{k+1} = r + beta p_k over the dead p_{k-1}.  3 + 6 streams per pair of iterations instead of 5 + 5.  The
+// iteration that converges completes x itself; nothing is touched in later, overshooting launches.
+__global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk,
+                                                      double2* __restrict__ pnext, const double2* __restrict__ r, size_t n) {
+    if (s[S_XDONE] != 0.0) return;
+    const double al = s[S_ALPHA], be = s[S_BETA];
+    const bool cont = s[S_DONE] == 0.0;
+    if (cont) {
+        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+            const double2 pv = pk[i], rv = r[i];
+            double2 o;
+            o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
+            pnext[i] = o;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) s[S_APREV] = al;
+    } else {
+        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+            const double2 pv = pk[i];
+            double2 xv = x[i];
+            xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+            x[i] = xv;
+        }
+    }
+}
+__global__ __launch_bounds__(UB) void cg_update_odd(const double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ pprev,
+                                                     const double2* __restrict__ pk, const double2* __restrict__ r, size_t n) {
+    if (s[S_XDONE] != 0.0) return;
+    const double ap = s[S_APREV], al = s[S_ALPHA], be = s[S_BETA];
+    const bool cont = s[S_DONE] == 0.0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 pp = pprev[i], pv = pk[i];
+        double2 xv = x[i];
+        xv.x = fma(ap, pp.x, xv.x); xv.y = fma(ap, pp.y, xv.y);
+        xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+        x[i] = xv;
+        if (cont) {
+            const double2 rv = r[i];
+            double2 o;
+            o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
+            pprev[i] = o;
+        }
+    }
+}
+// x += alpha_k p_k for a window that ended (unconverged) on an even iteration
+__global__ __launch_bounds__(UB) void cg_flush_kernel(const double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk, size_t n) {
+    if (s[S_DONE] != 0.0) return;
+    const double ap = s[S_APREV];
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 pv = pk[i];
+        double2 xv = x[i];
+        xv.x = fma(ap, pv.x, xv.x); xv.y = fma(ap, pv.y, xv.y);
+        x[i] = xv;
+    }
+}
 // p = r + beta p
 __global__ __launch_bounds__(UB) void cg_update_p(const double* __restrict__ s, double2* __restrict__ p, const double2* __restrict__ r, size_t n) {
     if (s[S_DONE] != 0.0) return;
@@ -158,7 +214,22 @@ static bool cg_small_ok(lqcd_op_s* op, int nbs) {
 }
 
 // enqueue one CG iteration on the compute stream (no host synchronisation)
-int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
+static bool cg_defers_x(lqcd_op_s* op) {
+    lqcd_ctx_s* c = op->ctx;
+    if (!(c->tun.cg_fused >= 2 && c->tun.cg_defer_x)) return false;
+    return !(c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2)));
+}
+int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
+    lqcd_ctx_s* c = op->ctx;
+    if (!cg_defers_x(op) || !(w.k & 1)) return LQCD_OK;
+    const size_t n = x->elems;
+    hipLaunchKernelGGL(cg_flush_kernel, dim3(stream_grid(c, n)), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, n);   // p_k of an even k lives in w.p
+    HIPCHK(hipGetLastError());
+    w.k++;      // nothing pending any more (a window is never continued after its flush)
+    return LQCD_OK;
+}
+
+int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n = x->elems;
     const int nbs_small = stencil_num_partials(c, op->kind, op->r, 2);
@@ -187,11 +258,14 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
         //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
         //   beta, convergence ; x += alpha p, p = r + beta p
         const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
-        LQCHK(op_apply_async(op, w.tmp, w.p, 0, c->d_partial, c->tun.cg_skip_done ? c->d_scal : nullptr));   // a no-op once the solve has converged inside a burst
+        const bool defer = c->tun.cg_defer_x != 0;
+        lqcd_spinor_s* pk = (defer && (w.k & 1)) ? w.q : w.p;        // q = D^+D p is never written in this form: its buffer is the second p
+        lqcd_spinor_s* po = (defer && (w.k & 1)) ? w.p : w.q;
+        LQCHK(op_apply_async(op, w.tmp, pk, 0, c->d_partial, c->tun.cg_skip_done ? c->d_scal : nullptr));   // a no-op once the solve has converged inside a burst
         LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);
         StencilCall s2;
-        LQCHK(make_full_call(op, w.q, w.tmp, 1, s2));
+        LQCHK(make_full_call(op, po, w.tmp, 1, s2));          // update mode writes r only: `out` is a placeholder (the buffer that is dead until the p update)
         s2.norm_partial = c->d_partial;
         s2.upd_scal = c->d_scal;
         s2.upd[0] = spinor_block(w.r, 0);
@@ -199,8 +273,11 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, const CgWork& w) {
         LQCHK(stencil_apply(c, s2));
         LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));   // + beta, convergence flag
         const int nbu = stream_grid(c, n);
-        hipLaunchKernelGGL(cg_update_xp, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
+        if (!defer) hipLaunchKernelGGL(cg_update_xp, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
+        else if (w.k & 1) hipLaunchKernelGGL(cg_update_odd, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, po->data, pk->data, w.r->data, n);
+        else hipLaunchKernelGGL(cg_update_even, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, pk->data, po->data, w.r->data, n);
         HIPCHK(hipGetLastError());
+        w.k++;
         return LQCD_OK;
     }
     const bool fuse = c->tun.cg_fused && !any_partitioned(c);
@@ -307,6 +384,10 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
+    if (st == LQCD_OK && !converged) {          // a window / an exhausted solve that stopped on an even iteration: complete x
+        st = cg_flush_x(op, x, w);
+        if (st == LQCD_OK) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) st = hip_fail(e, "cg flush", __FILE__, __LINE__); }
+    }
     scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
     if (iters) *iters = it;
     if (final_rr) *final_rr = rr;

@@ -428,6 +428,20 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
         if (k.dbg & (65536 << MU)) Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, hot) : k.gauge + glink_off(k.g, 1 - p, MU, hot);
     }
 #endif
+#ifdef LQCD_ABLATE
+    if (MU < 2 && (k.dbg & ((1 << 20) << MU))) {     // ablation (wrong results): NO neighbour-spinor loads for this direction (upper bound of what LDS staging can save)
+        cd h0[3], h1[3], chi0[3], chi1[3], u[9];
+#pragma unroll
+        for (int hop = 0; hop < 2; hop++) {
+            if constexpr (R12) load_link12(u, hop ? Ub : Uf, hop ? (k.nt & 1) != 0 : false); else load_link(u, hop ? Ub : Uf, Us);
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) { h0[cc] = mk(real(1 + cc + i), real(2)); h1[cc] = mk(real(3), real(4 + hop)); }
+            if (hop) { su3_mv<true>(chi0, u, h0); su3_mv<true>(chi1, u, h1); reconstruct<MU, -SF>(acc, chi0, chi1); }
+            else { su3_mv<false>(chi0, u, h0); su3_mv<false>(chi1, u, h1); reconstruct<MU, SF>(acc, chi0, chi1); }
+        }
+        return;
+    }
+#endif
     if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU], (k.nt & 2) != 0);
     if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0, (k.nt & 8) != 0);
 }

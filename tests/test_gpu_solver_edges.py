@@ -201,3 +201,39 @@ def test_bicg_matches_oracle(lq, orc, kind_name, dagger):
     Dd.MaxCGstep = 3
     with pytest.raises(lq.NotConverged):
         lq.solve_DinvX_(x.similar(), Dd, b)
+
+
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
+    """cg_defer_x (default): x is updated every second iteration with both search directions, p ping-pongs between two buffers.  Same
+    operations in the same order per element: the solution, the iteration count and windows of odd AND even length (the odd one ends with
+    a pending update that must be flushed) are bit-identical to the plain fused iteration."""
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    L = (8, 8, 8, 8)
+    lat = lq.Lattice(L)
+    lat.set_param("cg_small", 0)
+    U = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 961))
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": kind_name, "κ": 0.141139, "mass": 0.5, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-18})
+    b = lq.Fermionfields(lat, kind)
+    lq.gauss_distribution_fermion_(b, 962)
+    A = lq.DdagD_operator(D)
+    res = {}
+    for defer in (0, 1):
+        lat.set_param("cg_defer_x", defer)
+        x = b.similar()
+        info = lq.solve_DinvX_(x, A, b, return_info=True)
+        wins = []
+        for niter in (1, 4, 5, 9, 16):
+            xw = b.similar()
+            lq.lib.check(lq.lib.lib().lqcd_solve_cg_DdagD_fixed(D._h, xw._h, b._h, niter))
+            wins.append(xw.download())
+        A.MaxCGstep = 7                                     # exhausted solve on an odd count: x still holds the 7-iteration iterate
+        xe = b.similar()
+        with pytest.raises(lq.NotConverged):
+            lq.solve_DinvX_(xe, A, b)
+        A.MaxCGstep = 3000
+        res[defer] = (info, x.download(), wins, xe.download())
+    assert res[0][0] == res[1][0] and res[1][0][1] < 1e-18
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][3], res[1][3])
+    for a, c in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, c)
