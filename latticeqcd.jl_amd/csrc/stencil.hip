@@ -17,6 +17,7 @@
 // kernels from spin-projected halos packed by pack kernels (see halo layout in lqcd_internal.h).
 #include "lqcd_internal.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace lqcd {
 inline namespace LQCD_PNS {
@@ -867,6 +868,72 @@ __global__ __launch_bounds__(256, 4) void wilson_dirsplit4(KArgs k) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ Wilson, direction-split, both parities of a chunk in one workgroup
+// Variant 7: the even and the odd sites of a 64-site chunk in ONE 512-thread workgroup (waves 0-3: parity 0, waves 4-7: parity 1, each
+// group exactly variant 5).  Every x link and three quarters of the y links are used forward by one group and backward by the other, and
+// each group's x / y neighbour spinors are the other group's centre chunk: with both in the same workgroup those second uses coincide in
+// time on one CU instead of depending on how two workgroups happen to be scheduled.  72 KiB of LDS, <= 128 VGPRs: two workgroups = 16 waves
+// per CU.  Full-lattice applications with 12-real links only (the 18-real instance needs more than 128 registers); block partials are
+// written at the indices variant 1 uses, so solver iterates do not change.
+template <bool DAG, bool R12>
+__global__ __launch_bounds__(512, 4) void wilson_pair4(KArgs k) {
+    __shared__ real2 part[2][4][3][3][64];  // 72 KiB
+    __shared__ double red[8];
+    if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = wave & 3;
+    int p = wave >> 2, chunk, vb;
+    if (k.remap == 2 && k.cps > 0) {        // the two virtual blocks of variant 1's map that hold (chunk, 0) and (chunk, 1)
+        vb = (blockIdx.x & 7) + 8 * (p + 2 * (blockIdx.x >> 3));
+        map_block_v(k, vb, chunk, p);
+    } else {
+        chunk = blockIdx.x;
+        vb = 2 * blockIdx.x + p;
+    }
+    const int Vh = sp_stride(k.g);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < k.g.Vh;
+    cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    if (valid && k.a != 0.0) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp_off(12, i) + (size_t)(3 * w + cc) * Vh);
+    }
+    cd own[3];
+    switch (w) {
+    case 0: dirsplit4_body<0, DAG, R12>(k, p, i, lane, valid, part[p], own); break;
+    case 1: dirsplit4_body<1, DAG, R12>(k, p, i, lane, valid, part[p], own); break;
+    case 2: dirsplit4_body<2, DAG, R12>(k, p, i, lane, valid, part[p], own); break;
+    default: dirsplit4_body<3, DAG, R12>(k, p, i, lane, valid, part[p], own); break;
+    }
+    __syncthreads();
+    real nrm = 0.0;
+    if (valid) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            cd sv[4];
+#pragma unroll
+            for (int src = 0; src < 4; src++) {
+                if (src == w) sv[src] = own[cc];
+                else { const real2 t = part[p][w][src < w ? src : src - 1][cc][lane]; sv[src] = mk(t.x, t.y); }
+            }
+            cd s = mk((sv[0].re + sv[1].re) + (sv[2].re + sv[3].re), (sv[0].im + sv[1].im) + (sv[2].im + sv[3].im));
+            cd v = k.b * s;
+            v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
+            emit(k, p, (size_t)(3 * w + cc) * Vh + sp_off(12, i), v, nrm, al_upd);
+        }
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[wave] = nrm;
+        __syncthreads();
+        if ((threadIdx.x & 255) == 0) k.norm_partial[vb] = (red[4 * p] + red[4 * p + 1]) + (red[4 * p + 2] + red[4 * p + 3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ Wilson, hop-split
 // Variant 2 ("hopsplit"): 8 waves per 64 sites, one per hop (direction x sign).  Every wave issues its 21 loads
 // (12 spinor + 9 link; 15 for the t hops) as ONE burst -- a workgroup has a single memory round trip -- and leaves the
@@ -911,6 +978,218 @@ __device__ inline void project_regs(cd (&h0)[3], cd (&h1)[3], const cd* sp) {
     } else {
 #pragma unroll
         for (int c = 0; c < 3; c++) { h0[c] = 2.0 * sp[c]; h1[c] = 2.0 * sp[3 + c]; }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------ Wilson, direction-split, neighbour spinors through LDS
+// Variant 6: the x and y neighbours of a site of chunk c (64 consecutive checkerboard sites = 64 / XH x-rows) are sites of THE SAME chunk
+// of the other parity -- all of them in x (the row wraps onto itself), all but one boundary row per direction in y.  The four waves load
+// that chunk once (3 components each, 12 loads per workgroup), leave it in 12 KiB of LDS, and the x and y waves take both their hops from
+// there (ds_read_b128 with the neighbour's lane index: the LDS moves 256 B/clk where the texture path moves 64); a lane of the y wave
+// whose neighbour lies in the next / previous chunk has loaded that ONE spinor into registers beforehand.  Per workgroup 180 -> 150
+// 16-B/lane global loads (x: 45 -> 24, y: 45 -> 36 of which 12 quarter-masked, z, t: +3 each).  Schedule: every wave issues its staging
+// loads FIRST, then the loads that do not depend on the staged data (x, y: both links [+ the edge spinor]; z, t: link and spinor of the
+// forward hop), writes its staged components and arrives at a raw s_barrier behind an lgkmcnt(0) only -- the other loads stay in flight
+// across the barrier, nobody pays a second dependent memory round trip.  Partial sums as in variant 5 (own spin row in registers, 36 KiB);
+// 48 KiB of LDS in ONE array, three workgroups per CU.  Needs 64 % XH == 0 and at least two rows per chunk (XH <= 32); the launcher
+// falls back to variant 1 otherwise.  Same arithmetic and summation order as variant 1: bit-identical results.
+template <bool R12, bool NT>      // NT is a compile-time choice: a run-time branch around the loads would end in register copies that wait for them
+__device__ inline void load_link_raw(cd (&u)[9], const real2* __restrict__ U, int Us) {
+    constexpr int N = R12 ? 6 : 9;
+    const int st = R12 ? 64 : Us;
+#pragma unroll
+    for (int j = 0; j < N; j++) u[j] = NT ? ld_nt(U + (size_t)j * st) : ld(U + (size_t)j * st);
+}
+template <bool R12>
+__device__ inline void finish_link(cd (&u)[9]) {      // 12-real links: row 2 = conj(row 0 x row 1), the arithmetic of load_link12
+    if constexpr (R12) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+            cd x = mk(0.0, 0.0);
+            cfma(x, u[b1], u[3 + b2]);
+            x.re = -x.re; x.im = -x.im;
+            cd y = mk(0.0, 0.0);
+            cfma(y, u[b2], u[3 + b1]);
+            u[6 + b] = mk(-(x.re + y.re), x.im + y.im);
+        }
+    }
+}
+__device__ inline void lds_stage_and_barrier(real2 (*nbr)[64], const cd (&stg)[3], int w, int lane) {
+    __builtin_amdgcn_sched_barrier(0);     // arithmetic on the loads issued above must not be hoisted in front of the barrier (it would wait for them there)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) nbr[3 * w + cc][lane] = mk2(stg[cc].re, stg[cc].im);
+    // LDS writes complete, then the workgroup barrier; global loads issued above stay in flight (no vmcnt wait here)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// identity the optimiser cannot see through: arithmetic on values loaded BEFORE the barrier must not be scheduled in front of it
+// (pure arithmetic is not ordered by the barrier's memory clobber; it would drag the wait for those loads in front of the barrier)
+template <int N>
+__device__ inline void pin_after_barrier(cd (&a)[N], int n = N) {
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        if (j < n) asm volatile("" : "+v"(a[j].re), "+v"(a[j].im));
+}
+template <int MU, int S, bool ADJ>
+__device__ inline void hop_from_regs(cd (&chi0)[3], cd (&chi1)[3], const cd* sp, const cd (&u)[9], real sign) {
+    cd h0[3], h1[3];
+    project_regs<MU, S>(h0, h1, sp);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
+    su3_mv<ADJ>(chi0, u, h0);
+    su3_mv<ADJ>(chi1, u, h1);
+}
+
+template <int MU, bool DAG, bool R12, bool NTB>
+__device__ inline void dslds_body(const KArgs& k, int p, int chunk, int ic, int lane, real2* lds, cd (&own)[3], const cd (&stg)[3], cd (&xv)[3], int w) {
+    // ic: the lane's site, clamped to a valid one -- between the staging loads and the barrier there is NO control flow (a branch around
+    // a load makes the static vmcnt of the staging data wait for everything); skipped hops (off-rank neighbours) are multiplied by sign 0
+    constexpr int SF = DAG ? -1 : 1;
+    real2 (*part)[3][3][64] = reinterpret_cast<real2 (*)[3][3][64]>(lds);
+    real2 (*nbr)[64] = reinterpret_cast<real2 (*)[64]>(lds + 4 * 3 * 3 * 64);
+    cd f0[3], f1[3], b0[3], b1[3];
+    Nbr n;
+    int c[4];
+    neighbours(k.g, p, ic, n, c);
+    const int Vh = sp_stride(k.g);
+    const int Us = glink_stride(k.g);
+    const real2* __restrict__ psi = k.in[1 - p];
+    const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(k.g, p, MU, ic) : k.gauge + glink_off(k.g, p, MU, ic);
+    const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
+    auto load_xin = [&]() {       // the diagonal term's components: issued right behind the barrier (an a == 0 hop-only call has no xin)
+        if (k.a != 0.0) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp_off(12, ic) + (size_t)(3 * w + cc) * Vh);
+        }
+    };
+    if constexpr (MU < 2) {
+        cd uf[9], ub[9];
+        const bool f_in = (n.fwd[MU] >> 6) == chunk, b_in = (n.bwd[MU] >> 6) == chunk;
+        load_link_raw<R12, false>(uf, Uf, Us);
+        load_link_raw<R12, NTB>(ub, Ub, Us);
+        lds_stage_and_barrier(nbr, stg, w, lane);
+        load_xin();
+        // spinor component j of the neighbour: from the staged chunk, or (y: the boundary row of the chunk) from the neighbouring chunk in memory
+        auto hop = [&](auto adj, auto sgn, cd (&c0)[3], cd (&c1)[3], cd (&u)[9], int nb_, bool in_lds, real sign) {
+            constexpr bool ADJ = decltype(adj)::value;
+            constexpr int S = decltype(sgn)::value;
+            constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
+            constexpr int k0 = GK[MU][0] + (S > 0 ? 2 : 0), k1 = GK[MU][1] + (S > 0 ? 2 : 0);
+            const int l = nb_ & 63;
+            const real2* __restrict__ e = psi + sp_off(12, nb_);
+            auto get = [&](int j) -> cd {
+                if (MU == 1 && !in_lds) return ld(e + (size_t)j * Vh);
+                const real2 t = nbr[j][l];
+                return mk(t.x, t.y);
+            };
+            cd h0[3], h1[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                h0[cc] = get(cc) + mul_ipow<k0>(get(p0 * 3 + cc));
+                h1[cc] = get(3 + cc) + mul_ipow<k1>(get(p1 * 3 + cc));
+            }
+            finish_link<R12>(u);
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) { h0[cc] = sign * h0[cc]; h1[cc] = sign * h1[cc]; }
+            su3_mv<ADJ>(c0, u, h0);
+            su3_mv<ADJ>(c1, u, h1);
+        };
+        pin_after_barrier(uf, R12 ? 6 : 9);
+        pin_after_barrier(ub, R12 ? 6 : 9);
+        hop(std::false_type{}, std::integral_constant<int, SF>{}, f0, f1, uf, n.fwd[MU], f_in, n.sf[MU]);
+        if constexpr (MU == 1) __builtin_amdgcn_sched_barrier(0);
+        hop(std::true_type{}, std::integral_constant<int, -SF>{}, b0, b1, ub, n.bwd[MU], b_in, n.sb[MU]);
+    } else {
+        constexpr int NS = MU < 3 ? 12 : 6;
+        constexpr int basef = (MU == 3 && SF > 0) ? 2 : 0;      // rows the t projector of the forward hop keeps
+        cd uf[9], sp[NS];
+        load_link_raw<R12, false>(uf, Uf, Us);
+        {
+            const real2* __restrict__ e = psi + sp_off(12, n.fwd[MU]);
+#pragma unroll
+            for (int j = 0; j < NS; j++) sp[j] = ld(e + (size_t)(basef * 3 + j) * Vh);
+        }
+        lds_stage_and_barrier(nbr, stg, w, lane);
+        load_xin();
+        pin_after_barrier(uf, R12 ? 6 : 9);
+        pin_after_barrier(sp);
+        finish_link<R12>(uf);
+        hop_from_regs<MU, SF, false>(f0, f1, sp, uf, n.sf[MU]);
+        // The backward hop's 21 loads must not be issued while the forward hop's 21 registers are still live (register budget of 3 waves
+        // per SIMD): an empty asm makes the backward neighbour index depend on the forward result.
+        int nbw = n.bwd[MU];
+        asm volatile("" : "+v"(nbw), "+v"(f0[0].re), "+v"(f0[0].im), "+v"(f0[1].re), "+v"(f0[1].im), "+v"(f0[2].re), "+v"(f0[2].im),
+                          "+v"(f1[0].re), "+v"(f1[0].im), "+v"(f1[1].re), "+v"(f1[1].im), "+v"(f1[2].re), "+v"(f1[2].im));
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { b0[cc] = b1[cc] = mk(0.0, 0.0); }
+        const real2* __restrict__ Ub2 = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, nbw) : k.gauge + glink_off(k.g, 1 - p, MU, nbw);
+        if (n.sb[MU] != 0.0) wilson_hop_chi<MU, -SF, true, R12>(b0, b1, psi + sp_off(12, nbw), Ub2, Vh, Us, n.sb[MU], NTB);
+    }
+    cd row[3];
+#define LQ_ROW(R)                                                                      \
+    recon_row<MU, SF, R>(row, f0, f1, b0, b1);                                         \
+    if constexpr (R == MU) { own[0] = row[0]; own[1] = row[1]; own[2] = row[2]; }      \
+    else {                                                                             \
+        _Pragma("unroll") for (int cc = 0; cc < 3; cc++) part[R][MU < R ? MU : MU - 1][cc][lane] = mk2(row[cc].re, row[cc].im); \
+    }
+    LQ_ROW(0) LQ_ROW(1) LQ_ROW(2) LQ_ROW(3)
+#undef LQ_ROW
+}
+
+#ifndef LQCD_V6_OCC
+#define LQCD_V6_OCC 3
+#endif
+template <bool DAG, bool R12, bool NTB>
+__global__ __launch_bounds__(256, LQCD_V6_OCC) void wilson_dirsplit_lds(KArgs k) {
+    __shared__ real2 lds[4 * 3 * 3 * 64 + 12 * 64 + 4];   // partial rows (36 KiB) | staged neighbour chunk (12 KiB) | norm partials
+    if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
+    int chunk, p;
+    map_block(k, chunk, p);
+    const int Vh = sp_stride(k.g);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < k.g.Vh;
+    const int ic = valid ? i : chunk * 64;       // a lane beyond the last site works on the first site of the chunk and stores nothing
+    cd stg[3], xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) stg[cc] = ld(k.in[1 - p] + sp_off(12, ic) + (size_t)(3 * w + cc) * Vh);    // the staged chunk FIRST: its data must arrive first
+    __builtin_amdgcn_sched_barrier(0);      // nothing is scheduled across this point: the staging loads stay the OLDEST in the in-order vmcnt queue
+    cd own[3];
+    switch (w) {
+    case 0: dslds_body<0, DAG, R12, NTB>(k, p, chunk, ic, lane, lds, own, stg, xv, w); break;
+    case 1: dslds_body<1, DAG, R12, NTB>(k, p, chunk, ic, lane, lds, own, stg, xv, w); break;
+    case 2: dslds_body<2, DAG, R12, NTB>(k, p, chunk, ic, lane, lds, own, stg, xv, w); break;
+    default: dslds_body<3, DAG, R12, NTB>(k, p, chunk, ic, lane, lds, own, stg, xv, w); break;
+    }
+    __syncthreads();
+    real2 (*part)[3][3][64] = reinterpret_cast<real2 (*)[3][3][64]>(lds);
+    real nrm = 0.0;
+    if (valid) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            cd sv[4];
+#pragma unroll
+            for (int src = 0; src < 4; src++) {
+                if (src == w) sv[src] = own[cc];
+                else { const real2 t = part[w][src < w ? src : src - 1][cc][lane]; sv[src] = mk(t.x, t.y); }
+            }
+            cd s = mk((sv[0].re + sv[1].re) + (sv[2].re + sv[3].re), (sv[0].im + sv[1].im) + (sv[2].im + sv[3].im));
+            cd v = k.b * s;
+            v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
+            emit(k, p, (size_t)(3 * w + cc) * Vh + sp_off(12, i), v, nrm, al_upd);
+        }
+    }
+    if (k.norm_partial) {
+        double* red = reinterpret_cast<double*>(lds + 4 * 3 * 3 * 64 + 12 * 64);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -1635,7 +1914,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
 }
 
 static bool use_dirsplit(lqcd_ctx_s* c, int kind, real r) {   // variants 1/2/3 work on 64-site chunks
-    if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 5)) return false;
+    if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 7)) return false;
     return kind == LQCD_STAGGERED || r == 1.0;   // Wilson: the split kernels use the r = 1 projectors
 }
 static int persist_grid(lqcd_ctx_s* c, int nvirt) {
@@ -1674,6 +1953,18 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         if (s.kind == LQCD_STAGGERED) {
             if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
+        } else if (c->tun.dslash_variant == 7 && !k.clover && k.gauge12 && s.parity_mode == 2) {
+            dim3 grid(k.nblocks / 2), block(512);
+            if (s.dagger) hipLaunchKernelGGL((wilson_pair4<true, true>), grid, block, pad, c->stream, k);
+            else hipLaunchKernelGGL((wilson_pair4<false, true>), grid, block, pad, c->stream, k);
+        } else if (c->tun.dslash_variant == 6 && !k.clover && 64 % c->geom.XH == 0 && c->geom.XH <= 32) {
+            dim3 grid(k.nblocks), block(256);
+            const bool ntb = (k.nt & 1) != 0;     // backward-link loads non-temporal (tunable nt_gauge bit 0); bit 1 is not offered by this variant
+#define LQ_V6(D, R) do { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_lds<D, R, true>), grid, block, pad, c->stream, k); \
+                         else hipLaunchKernelGGL((wilson_dirsplit_lds<D, R, false>), grid, block, pad, c->stream, k); } while (0)
+            if (k.gauge12) { if (s.dagger) LQ_V6(true, true); else LQ_V6(false, true); }
+            else { if (s.dagger) LQ_V6(true, false); else LQ_V6(false, false); }
+#undef LQ_V6
         } else if (c->tun.dslash_variant == 5 && !k.clover) {
             dim3 grid(k.nblocks), block(256);
             if (k.gauge12) {
