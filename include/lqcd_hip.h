@@ -74,13 +74,14 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
 /* tuning knobs (kernel variants); unknown key -> LQCD_ERR_ARG.  Keys: dslash_variant (0 site-per-lane, 1 direction split
  * [default], 2 hop split, 3 persistent hop split, 4 lane split = four directions in the four 16-lane rows of a wave combined by
  * v_permlane swaps, 5 direction split with the footprint of four workgroups per CU, 6 direction split with the x / y neighbour spinors staged
- * through LDS), dslash_block, xcd_remap, xcd_nsub, xcd_ysplit, cg_fused (0 reference form, 1, 2 fused
+ * through LDS, 7 both parities of a chunk in one 512-thread workgroup), dslash_block, xcd_remap, xcd_nsub, xcd_ysplit, cg_fused (0 reference form, 1, 2 fused
  * [default]), graph (1: hipGraph replay of CG bursts), gauge_recon (12 [default]: the split kernels read two rows per link and rebuild the
  * third -- applied only while every link of the field is unitary to 1e-14, results within the fp64 Dslash tolerance; 18: all
  * 18 stored reals are always read), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge (bit 0 [default]: the backward = last use of a link is a non-temporal load; bit 1: the forward use too), nt_store (1 [default]:
  * non-temporal output stores), lds_pad_kb, persist_per_cu;
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
  * mixed-precision CG), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
+ * md_remap (1 [default]: the staple sweep follows the stencil's XCD-aware workgroup map), nt_blas (1: non-temporal loads / stores in the CG update kernels),
  * cg_skip_done, cg_defer_x (1 [default]: the fused CG updates x every second iteration with both search directions, p alternating between
  * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates), cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice

@@ -235,6 +235,62 @@ __host__ __device__ inline uint64_t rng_key(uint64_t seed, uint64_t site, uint64
 }
 __host__ __device__ inline double u01(uint64_t k) { return ((k >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
 
+// ---------------------------------------------------------------- workgroup -> lattice map shared by the sweeps outside stencil.hip
+// The XCD-aware tile sweep of the Dslash kernels (stencil.hip map_block_v, same arithmetic): block b runs on XCD b % 8 (observed, not
+// contractual: the map only changes speed); XCD k owns (y,z) tiles k, k + 8, ... of every t-slice and sweeps t, the even and the odd half
+// of a 64-site chunk are dispatched back to back.  Falls back to the plain order when the slice does not tile.
+struct BlockMap {
+    int nblocks, remap, cps, cpp, ysplit, cpr, ty, tz, LT;
+    FastDiv d_perpass, d_cpr, d_ysplit, d_ty;
+};
+inline BlockMap make_block_map(const Geom& g, int remap, int nsub_in, int ysplit_in) {
+    BlockMap m;
+    const int TB = 64;
+    const int chunks = (g.Vh + TB - 1) / TB;
+    m.nblocks = 2 * chunks;
+    m.remap = remap;
+    m.LT = g.L[3];
+    const int slice = g.XH * g.L[1] * g.L[2];
+    const int nsub = (nsub_in >= 8 && nsub_in % 8 == 0) ? nsub_in : 8;
+    m.cps = (slice % TB == 0 && (slice / TB) % nsub == 0) ? slice / TB : 0;
+    const int plane = g.XH * g.L[1];
+    m.cpp = (plane % TB == 0) ? plane / TB : 0;
+    m.ysplit = 1;
+    if (ysplit_in > 1 && m.cps > 0 && m.cpp > 0 && m.cpp % ysplit_in == 0 && nsub % ysplit_in == 0 && g.L[2] % (nsub / ysplit_in) == 0) m.ysplit = ysplit_in;
+    m.cpr = m.cps > 0 ? m.cps / nsub : 1;
+    m.ty = m.ysplit > 1 ? m.cpp / m.ysplit : 1;
+    m.tz = m.cpr / m.ty;
+    m.d_perpass = make_fastdiv(m.cpr * g.L[3] > 1 ? m.cpr * g.L[3] : 1);
+    m.d_cpr = make_fastdiv(m.cpr > 1 ? m.cpr : 1);
+    m.d_ysplit = make_fastdiv(m.ysplit > 1 ? m.ysplit : 1);
+    m.d_ty = make_fastdiv(m.ty > 1 ? m.ty : 1);
+    return m;
+}
+__host__ __device__ inline void block_map(const BlockMap& m, int b, int& chunk, int& p) {
+    if (m.remap == 2 && m.cps > 0) {
+        const int xcd = b & 7;
+        int j = b >> 3;
+        p = j & 1; j >>= 1;
+        const int per_pass = m.cpr * m.LT;
+        const int pass = fdiv(j, m.d_perpass);
+        j -= pass * per_pass;
+        const int t = fdiv(j, m.d_cpr), mm = j - t * m.cpr, sd = xcd + 8 * pass;
+        int s;
+        if (m.ysplit > 1) {
+            const int sz = fdiv(sd, m.d_ysplit), sy = sd - sz * m.ysplit;
+            const int zz = fdiv(mm, m.d_ty), yy = mm - zz * m.ty;
+            s = (sz * m.tz + zz) * m.cpp + sy * m.ty + yy;
+        } else {
+            s = sd * m.cpr + mm;
+        }
+        chunk = t * m.cps + s;
+        return;
+    }
+    int lb = b;
+    if (m.remap && !(m.nblocks & 7)) lb = (b & 7) * (m.nblocks >> 3) + (b >> 3);
+    chunk = lb >> 1; p = lb & 1;
+}
+
 // ---------------------------------------------------------------- runtime objects
 struct Ctx;
 
@@ -265,6 +321,8 @@ struct Tunables {
     int halo_tuned_us[3] = {0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
+    int nt_blas = 0;          // deferred-x CG update kernels with non-temporal loads / stores (experiment)
+    int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
     int cg_defer_x = 1;       // fused CG: x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
                               // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates
     int cg_small = 1;         // fused CG on an unpartitioned lattice with <= 1024 stencil workgroups: the two reduction launches of an iteration are folded

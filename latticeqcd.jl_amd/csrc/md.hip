@@ -81,17 +81,19 @@ struct GFArgs {
     const double2* ghost[4];
     const double2* wrecv[4];
     double2* wsend[4];
+    BlockMap bm;             // workgroup -> chunk map of the sweep (tunable md_remap: 1 = the Dslash kernels' XCD tile sweep, 0 = plain order)
     int mu_only, mu_out;     // MODE 2 (calc_dSdUmu!): only direction mu_only, staple sum written to direction slot mu_out of `out`
 };
 
 // U_nu at the site c + dir_hat: local, or from the forward ghost slice when the step leaves the rank
+template <bool PART = true>
 __device__ __forceinline__ void link_fwd(cd (&u)[9], const GFArgs& k, const int (&c)[4], int dir, int nu) {
     const Geom& g = k.g;
     int d[4] = {c[0], c[1], c[2], c[3]};
     d[dir] += 1;
     if (d[dir] == g.L[dir]) {
         d[dir] = 0;
-        if (g.part[dir]) {
+        if (PART && g.part[dir]) {
             const int p = (d[0] + d[1] + d[2] + d[3]) & 1, Fh = face_half_sites(g, dir), f = coords_to_face(g, dir, d);
             const double2* b = k.ghost[dir] + ((size_t)(p * 4 + nu) * 9) * Fh + f;
 #pragma unroll
@@ -103,23 +105,21 @@ __device__ __forceinline__ void link_fwd(cd (&u)[9], const GFArgs& k, const int 
 }
 
 // lower staple seen from the site m = n - nu_hat:  W_{mu nu}(m) = U_nu(m+mu)^+ U_mu(m)^+ U_nu(m)
+template <bool PART = true>
 __device__ __forceinline__ void lower_staple_at(cd (&w)[9], const GFArgs& k, const int (&m)[4], int mu, int nu) {
     cd u1[9], u2[9], u3[9], t1[9];
     const int Gs = glink_stride(k.g);
-    link_fwd(u1, k, m, mu, nu);
+    link_fwd<PART>(u1, k, m, mu, nu);
     load_m3(u2, link_at(k.g, k.U, m, mu), Gs);
     load_m3(u3, link_at(k.g, k.U, m, nu), Gs);
     mm3_dd(t1, u1, u2);
     mm3(w, t1, u3);
 }
 
-// out_mu(n) = coef * U_mu(n) * sum_{nu != mu} [ U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+  +  W_{mu nu}(n - nu) ]
-// workgroup = 64 sites of one parity x 4 waves (wave = mu); the 6 x 3 neighbour links are re-used across waves/sites through L2
-// MODE 0: out = G.   MODE 1: out (the momenta) += factor * TA(G) -- P_update! in one pass, G never stored.
-// MODE 2 (64-thread blocks, one direction): out[mu_out] = coef * (sum of the six staples of direction mu_only) -- the reference's
-// calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108); the caller multiplies by U[mu] itself (mul!, :109).
+// The partitioned-lattice instance: direction and plane stay run-time values here -- with the ghost-link and received-staple branches the
+// fully templated body below needs > 256 registers (1000+ spilled); this form holds them in 256 without scratch.
 template <int MODE>
-__global__ __launch_bounds__(256) void gauge_force_kernel(GFArgs k) {
+__global__ __launch_bounds__(256) void gauge_force_kernel_part(GFArgs k) {
     constexpr bool FUSE_TA = MODE == 1;
     const Geom& g = k.g;
     const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = MODE == 2 ? k.mu_only : (int)(threadIdx.x >> 6);
@@ -181,6 +181,127 @@ __global__ __launch_bounds__(256) void gauge_force_kernel(GFArgs k) {
             const cd pv = ld(o + (size_t)e * Gs);
             st(o + (size_t)e * Gs, mk(pv.re + a[e].re, pv.im + a[e].im));
         }
+    }
+}
+
+// one plane (MU, NU) of the staple sum of link (n, MU): upper staple U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+ and lower staple W_{mu nu}(n - nu).
+// MU and NU are compile-time: every index into the by-value argument struct and the coordinate arrays is static.
+template <int MODE, int MU, int NU, bool PART>
+__device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&c)[4], int p, int lane, const double2 (*own)[9][64]) {
+    if constexpr (MU != NU) {
+        const Geom& g = k.g;
+        const int Gs = glink_stride(g);
+        cd u1[9], u2[9], u3[9], t1[9], t2[9];
+        link_fwd<PART>(u1, k, c, MU, NU);                   // U_nu(n+mu)
+        link_fwd<PART>(u2, k, c, NU, MU);                   // U_mu(n+nu)
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int e = 0; e < 9; e++) { const double2 t = own[NU][e][lane]; u3[e] = mk(t.x, t.y); }
+        } else {
+            load_m3(u3, link_at(g, k.U, c, NU), Gs);
+        }
+        mm3_nd(t1, u1, u2);
+        mm3_nd(t2, t1, u3);
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+        if (PART && c[NU] == 0 && g.part[NU]) {             // n - nu lives on the -nu neighbour: its W arrived with the exchange
+            const int Fh = face_half_sites(g, NU), f = coords_to_face(g, NU, c);
+            const double2* b = k.wrecv[NU] + ((size_t)((1 - p) * 4 + MU) * 9) * Fh + f;
+#pragma unroll
+            for (int e = 0; e < 9; e++) t2[e] = ld(b + (size_t)e * Fh);
+        } else {
+            int m[4] = {c[0], c[1], c[2], c[3]};
+            shift(m, g, NU, -1);
+            lower_staple_at<PART>(t2, k, m, MU, NU);
+        }
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+        // the next plane's five link loads wait for this plane's sum: without the tie the scheduler hoists all fifteen of a direction (and
+        // spills hundreds of registers); one plane in flight per wave, the other waves of the CU cover its latency
+        asm volatile("" : "+v"(c[0]), "+v"(A[0].re), "+v"(A[0].im), "+v"(A[4].re), "+v"(A[4].im), "+v"(A[8].re), "+v"(A[8].im));
+    }
+}
+
+template <int MODE, int MU, bool PART>
+__device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int lane, const double2 (*own)[9][64]) {
+    constexpr bool FUSE_TA = MODE == 1;
+    const Geom& g = k.g;
+    const int Gs = glink_stride(g);
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    cd A[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) A[e] = mk(0.0, 0.0);
+    staple_plane<MODE, MU, 0, PART>(A, k, c, p, lane, own);
+    staple_plane<MODE, MU, 1, PART>(A, k, c, p, lane, own);
+    staple_plane<MODE, MU, 2, PART>(A, k, c, p, lane, own);
+    staple_plane<MODE, MU, 3, PART>(A, k, c, p, lane, own);
+    const double coef = k.coef;
+    if constexpr (MODE == 2) {
+        double2* o2 = k.out + glink_off(g, p, k.mu_out, i);
+#pragma unroll
+        for (int e = 0; e < 9; e++) st(o2 + (size_t)e * Gs, mk(coef * A[e].re, coef * A[e].im));
+        return;
+    }
+    cd um[9], r[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) { const double2 t = own[MU][e][lane]; um[e] = mk(t.x, t.y); }      // U_mu(n) from LDS
+    mm3(r, um, A);
+    double2* o = k.out + glink_off(g, p, MU, i);
+    if constexpr (!FUSE_TA) {
+#pragma unroll
+        for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, mk(coef * r[e].re, coef * r[e].im));
+    } else {
+        cd a[9];
+        const double f = 0.5 * coef * k.factor;
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int y = 0; y < 3; y++) a[x * 3 + y] = mk(f * (r[x * 3 + y].re - r[y * 3 + x].re), f * (r[x * 3 + y].im + r[y * 3 + x].im));
+        const double tr = (a[0].im + a[4].im + a[8].im) / 3.0;
+        a[0].im -= tr; a[4].im -= tr; a[8].im -= tr;
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            const cd pv = ld(o + (size_t)e * Gs);
+            st(o + (size_t)e * Gs, mk(pv.re + a[e].re, pv.im + a[e].im));
+        }
+    }
+}
+
+// out_mu(n) = coef * U_mu(n) * sum_{nu != mu} [ U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+  +  W_{mu nu}(n - nu) ]
+// workgroup = 64 sites of one parity x 4 waves (wave = mu, dispatched to a compile-time direction); the four links of the site go through
+// LDS once (each wave loads its own direction: 36 KiB), the 6 x 2 neighbour links of a plane are re-used across waves/sites through L2.
+// MODE 0: out = G.   MODE 1: out (the momenta) += factor * TA(G) -- P_update! in one pass, G never stored.
+// MODE 2 (64-thread blocks, one direction): out[mu_out] = coef * (sum of the six staples of direction mu_only) -- the reference's
+// calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108); the caller multiplies by U[mu] itself (mul!, :109).
+#ifndef LQCD_STAPLE_OCC
+#define LQCD_STAPLE_OCC 2
+#endif
+template <int MODE, bool PART>
+__global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArgs k) {
+    const Geom& g = k.g;
+    int chunk, p;
+    block_map(k.bm, blockIdx.x, chunk, p);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const int mu = MODE == 2 ? k.mu_only : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool valid = i < g.Vh;
+    __shared__ double2 own[MODE == 2 ? 1 : 4][9][64];
+    if constexpr (MODE != 2) {
+        if (valid) {
+            cd um[9];
+            load_m3(um, k.U + glink_off(g, p, mu, i), glink_stride(g));
+#pragma unroll
+            for (int e = 0; e < 9; e++) own[mu][e][lane] = mk2(um[e].re, um[e].im);
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    switch (mu) {
+    case 0: staple_links<MODE, 0, PART>(k, p, i, lane, own); break;
+    case 1: staple_links<MODE, 1, PART>(k, p, i, lane, own); break;
+    case 2: staple_links<MODE, 2, PART>(k, p, i, lane, own); break;
+    default: staple_links<MODE, 3, PART>(k, p, i, lane, own); break;
     }
 }
 
@@ -418,6 +539,7 @@ static GFArgs make_gfargs(lqcd_ctx_s* c, lqcd_gauge_s* U, lqcd_gauge_s* out, dou
     k.coef = -beta / 6.0;
     k.factor = factor;
     k.mu_only = -1; k.mu_out = 0;
+    k.bm = make_block_map(c->geom, c->tun.md_remap ? c->tun.xcd_remap : 0, c->tun.xcd_nsub, c->tun.xcd_ysplit);
     for (int mu = 0; mu < 4; mu++) { k.ghost[mu] = c->gf_ghost[mu]; k.wrecv[mu] = c->gf_wrecv[mu]; k.wsend[mu] = c->gf_wsend[mu]; }
     return k;
 }
@@ -432,9 +554,16 @@ static int launch_staple_faces(lqcd_ctx_s* c, const GFArgs& k) {
     return LQCD_OK;
 }
 static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse) {
-    if (k.mu_only >= 0) hipLaunchKernelGGL(gauge_force_kernel<2>, dim3(2 * c->geom.nch), dim3(64), 0, c->stream, k);
-    else if (fuse) hipLaunchKernelGGL(gauge_force_kernel<1>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
-    else hipLaunchKernelGGL(gauge_force_kernel<0>, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, k);
+    const dim3 grid(2 * c->geom.nch);
+    if (any_partitioned(c)) {       // the instance with the ghost-link / received-staple branches
+        if (k.mu_only >= 0) hipLaunchKernelGGL(gauge_force_kernel_part<2>, grid, dim3(64), 0, c->stream, k);
+        else if (fuse) hipLaunchKernelGGL(gauge_force_kernel_part<1>, grid, dim3(256), 0, c->stream, k);
+        else hipLaunchKernelGGL(gauge_force_kernel_part<0>, grid, dim3(256), 0, c->stream, k);
+    } else {
+        if (k.mu_only >= 0) hipLaunchKernelGGL((gauge_force_kernel<2, false>), grid, dim3(64), 0, c->stream, k);
+        else if (fuse) hipLaunchKernelGGL((gauge_force_kernel<1, false>), grid, dim3(256), 0, c->stream, k);
+        else hipLaunchKernelGGL((gauge_force_kernel<0, false>), grid, dim3(256), 0, c->stream, k);
+    }
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }

@@ -99,10 +99,20 @@ __global__ __launch_bounds__(UB) void cg_update_xp_small(double* __restrict__ s,
         if (!cont) s[S_DONE] = 1.0;
     }
 }
+typedef double v2dd __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ inline double2 ldx(const double2* p) {
+    if constexpr (NT) { v2dd v = __builtin_nontemporal_load(reinterpret_cast<const v2dd*>(p)); double2 r; r.x = v.x; r.y = v.y; return r; }
+    else return *p;
+}
+template <bool NT> __device__ inline void stx(double2* p, double2 v) {
+    if constexpr (NT) { v2dd t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<v2dd*>(p)); }
+    else *p = v;
+}
 // Deferred x update (cg_defer_x): iteration k even:  p_{k+1} = r + beta p_k into the OTHER buffer, x untouched, alpha_k kept;
 //                                    iteration k odd:   x += alpha_{k-1} p_{k-1} + alpha_k p_k (same order of operations as two single
 // updates: identical bits), p_{k+1} = r + beta p_k over the dead p_{k-1}.  3 + 6 streams per pair of iterations instead of 5 + 5.  The
 // iteration that converges completes x itself; nothing is touched in later, overshooting launches.
+template <bool NT>      // NT: streaming (non-temporal) loads and stores for fields that are not re-used before they fall out of every cache
 __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk,
                                                       double2* __restrict__ pnext, const double2* __restrict__ r, size_t n) {
     if (s[S_XDONE] != 0.0) return;
@@ -110,10 +120,10 @@ __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, dou
     const bool cont = s[S_DONE] == 0.0;
     if (cont) {
         for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
-            const double2 pv = pk[i], rv = r[i];
+            const double2 pv = ldx<NT>(pk + i), rv = ldx<NT>(r + i);
             double2 o;
             o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
-            pnext[i] = o;
+            stx<NT>(pnext + i, o);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) s[S_APREV] = al;
     } else {
@@ -125,22 +135,23 @@ __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, dou
         }
     }
 }
+template <bool NT>
 __global__ __launch_bounds__(UB) void cg_update_odd(const double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ pprev,
                                                      const double2* __restrict__ pk, const double2* __restrict__ r, size_t n) {
     if (s[S_XDONE] != 0.0) return;
     const double ap = s[S_APREV], al = s[S_ALPHA], be = s[S_BETA];
     const bool cont = s[S_DONE] == 0.0;
     for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
-        const double2 pp = pprev[i], pv = pk[i];
-        double2 xv = x[i];
+        const double2 pp = ldx<NT>(pprev + i), pv = ldx<NT>(pk + i);
+        double2 xv = ldx<NT>(x + i);
         xv.x = fma(ap, pp.x, xv.x); xv.y = fma(ap, pp.y, xv.y);
         xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
-        x[i] = xv;
+        stx<NT>(x + i, xv);
         if (cont) {
-            const double2 rv = r[i];
+            const double2 rv = ldx<NT>(r + i);
             double2 o;
             o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
-            pprev[i] = o;
+            stx<NT>(pprev + i, o);
         }
     }
 }
@@ -274,8 +285,13 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));   // + beta, convergence flag
         const int nbu = stream_grid(c, n);
         if (!defer) hipLaunchKernelGGL(cg_update_xp, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
-        else if (w.k & 1) hipLaunchKernelGGL(cg_update_odd, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, po->data, pk->data, w.r->data, n);
-        else hipLaunchKernelGGL(cg_update_even, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, pk->data, po->data, w.r->data, n);
+        else if (w.k & 1) {
+            if (c->tun.nt_blas) hipLaunchKernelGGL(cg_update_odd<true>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, po->data, pk->data, w.r->data, n);
+            else hipLaunchKernelGGL(cg_update_odd<false>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, po->data, pk->data, w.r->data, n);
+        } else {
+            if (c->tun.nt_blas) hipLaunchKernelGGL(cg_update_even<true>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, pk->data, po->data, w.r->data, n);
+            else hipLaunchKernelGGL(cg_update_even<false>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, pk->data, po->data, w.r->data, n);
+        }
         HIPCHK(hipGetLastError());
         w.k++;
         return LQCD_OK;
