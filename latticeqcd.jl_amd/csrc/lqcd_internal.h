@@ -321,7 +321,8 @@ struct Tunables {
     int halo_tuned_us[3] = {0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
-    int nt_blas = 0;          // deferred-x CG update kernels with non-temporal loads / stores (experiment)
+    int cg_fold_scalars = 1;  // several ranks: the scalar steps behind the two all-reduces of a CG iteration run in the consumers' prologues (no one-thread kernels)
+    int nt_blas = 1;          // deferred-x CG update kernels stream their fields with non-temporal loads / stores: 842 -> 868 iter/s at 32^3x64
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
     int cg_defer_x = 1;       // fused CG: x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
                               // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates

@@ -112,12 +112,42 @@ template <bool NT> __device__ inline void stx(double2* p, double2 v) {
 //                                    iteration k odd:   x += alpha_{k-1} p_{k-1} + alpha_k p_k (same order of operations as two single
 // updates: identical bits), p_{k+1} = r + beta p_k over the dead p_{k-1}.  3 + 6 streams per pair of iterations instead of 5 + 5.  The
 // iteration that converges completes x itself; nothing is touched in later, overshooting launches.
-template <bool NT>      // NT: streaming (non-temporal) loads and stores for fields that are not re-used before they fall out of every cache
+// FOLD (several ranks): the scalar step behind the second all-reduce (beta = rr'/rr, rr = rr', iteration count, convergence flag) is done here --
+// every block forms beta and the test from the all-reduced rr' (S_RRNEW) and the rr this iteration started from (S_RROLD, written by the
+// update-mode stencil), block 0 records the results -- instead of by a one-thread kernel between the all-reduce and this launch.
+struct FoldBeta { double be; bool cont; };
+template <bool FOLD>
+__device__ inline FoldBeta cg_beta(double* s) {
+    FoldBeta f;
+    if constexpr (FOLD) {
+        const double rrn = s[S_RRNEW];
+        f.be = rrn / s[S_RROLD];
+        f.cont = !(rrn < s[S_EPS]);
+    } else {
+        f.be = s[S_BETA];
+        f.cont = s[S_DONE] == 0.0;
+    }
+    return f;
+}
+template <bool FOLD>
+__device__ inline void cg_beta_commit(double* s, const FoldBeta& f) {
+    if constexpr (FOLD) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const double rrn = s[S_RRNEW];
+            s[S_BETA] = f.be;
+            s[S_RR] = rrn;
+            s[S_ITERS] += 1.0;
+            if (!f.cont) s[S_DONE] = 1.0;
+        }
+    }
+}
+template <bool NT, bool FOLD>      // NT: streaming (non-temporal) loads and stores for fields that are not re-used before they fall out of every cache
 __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk,
                                                       double2* __restrict__ pnext, const double2* __restrict__ r, size_t n) {
     if (s[S_XDONE] != 0.0) return;
-    const double al = s[S_ALPHA], be = s[S_BETA];
-    const bool cont = s[S_DONE] == 0.0;
+    const FoldBeta fb = cg_beta<FOLD>(s);
+    const double al = s[S_ALPHA], be = fb.be;
+    const bool cont = fb.cont;
     if (cont) {
         for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
             const double2 pv = ldx<NT>(pk + i), rv = ldx<NT>(r + i);
@@ -134,13 +164,15 @@ __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, dou
             x[i] = xv;
         }
     }
+    cg_beta_commit<FOLD>(s, fb);
 }
-template <bool NT>
-__global__ __launch_bounds__(UB) void cg_update_odd(const double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ pprev,
+template <bool NT, bool FOLD>
+__global__ __launch_bounds__(UB) void cg_update_odd(double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ pprev,
                                                      const double2* __restrict__ pk, const double2* __restrict__ r, size_t n) {
     if (s[S_XDONE] != 0.0) return;
-    const double ap = s[S_APREV], al = s[S_ALPHA], be = s[S_BETA];
-    const bool cont = s[S_DONE] == 0.0;
+    const FoldBeta fb = cg_beta<FOLD>(s);
+    const double ap = s[S_APREV], al = s[S_ALPHA], be = fb.be;
+    const bool cont = fb.cont;
     for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
         const double2 pp = ldx<NT>(pprev + i), pv = ldx<NT>(pk + i);
         double2 xv = ldx<NT>(x + i);
@@ -154,6 +186,7 @@ __global__ __launch_bounds__(UB) void cg_update_odd(const double* __restrict__ s
             stx<NT>(pprev + i, o);
         }
     }
+    cg_beta_commit<FOLD>(s, fb);
 }
 // x += alpha_k p_k for a window that ended (unconverged) on an even iteration
 __global__ __launch_bounds__(UB) void cg_flush_kernel(const double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk, size_t n) {
@@ -273,25 +306,31 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         lqcd_spinor_s* pk = (defer && (w.k & 1)) ? w.q : w.p;        // q = D^+D p is never written in this form: its buffer is the second p
         lqcd_spinor_s* po = (defer && (w.k & 1)) ? w.p : w.q;
         LQCHK(op_apply_async(op, w.tmp, pk, 0, c->d_partial, c->tun.cg_skip_done ? c->d_scal : nullptr));   // a no-op once the solve has converged inside a burst
-        LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));      // + alpha = rr / pq
+        // several ranks: reduce_final -> all-reduce -> one-thread scalar kernel are three dependent launches per reduction; with `fold` the scalar
+        // steps move into the prologues of the kernels that consume them (deferred-x form only)
+        const bool fold = c->has_comm && defer && c->tun.cg_fold_scalars;
+        LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, fold ? 0 : 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);
         StencilCall s2;
         LQCHK(make_full_call(op, po, w.tmp, 1, s2));          // update mode writes r only: `out` is a placeholder (the buffer that is dead until the p update)
         s2.norm_partial = c->d_partial;
+        if (fold) s2.scal_w = c->d_scal;
         s2.upd_scal = c->d_scal;
         s2.upd[0] = spinor_block(w.r, 0);
         s2.upd[1] = spinor_block(w.r, 1);
         LQCHK(stencil_apply(c, s2));
-        LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));   // + beta, convergence flag
+        LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, fold ? 0 : 2));   // + beta, convergence flag
         const int nbu = stream_grid(c, n);
-        if (!defer) hipLaunchKernelGGL(cg_update_xp, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
-        else if (w.k & 1) {
-            if (c->tun.nt_blas) hipLaunchKernelGGL(cg_update_odd<true>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, po->data, pk->data, w.r->data, n);
-            else hipLaunchKernelGGL(cg_update_odd<false>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, po->data, pk->data, w.r->data, n);
-        } else {
-            if (c->tun.nt_blas) hipLaunchKernelGGL(cg_update_even<true>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, pk->data, po->data, w.r->data, n);
-            else hipLaunchKernelGGL(cg_update_even<false>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, x->data, pk->data, po->data, w.r->data, n);
-        }
+        const dim3 ug(nbu), ub(UB);
+#define LQ_UPD(KERN, A, B, C) do { \
+            if (c->tun.nt_blas) { if (fold) hipLaunchKernelGGL((KERN<true, true>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); \
+                                  else hipLaunchKernelGGL((KERN<true, false>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); } \
+            else { if (fold) hipLaunchKernelGGL((KERN<false, true>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); \
+                   else hipLaunchKernelGGL((KERN<false, false>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); } } while (0)
+        if (!defer) hipLaunchKernelGGL(cg_update_xp, ug, ub, 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
+        else if (w.k & 1) LQ_UPD(cg_update_odd, po->data, pk->data, w.r->data);
+        else LQ_UPD(cg_update_even, pk->data, po->data, w.r->data);
+#undef LQ_UPD
         HIPCHK(hipGetLastError());
         w.k++;
         return LQCD_OK;

@@ -83,7 +83,7 @@ __device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm, 
 __device__ inline bool upd_done(const KArgs& k) {
     const bool done = (k.upd_scal && k.upd_scal[S_DONE] != 0.0) || (k.skip && k.skip[S_DONE] != 0.0);
     // cg_small: the update-mode launch of an overshooting iteration tells the x/p update behind it that the converging iterate is complete
-    if (done && k.alpha_partials && blockIdx.x == 0 && threadIdx.x == 0) k.scal_w[S_XDONE] = 1.0;
+    if (done && k.scal_w && blockIdx.x == 0 && threadIdx.x == 0) k.scal_w[S_XDONE] = 1.0;
     return done;
 }
 // alpha of the CG update mode: from the scalar block, or (cg_small) rr / sum of the previous kernel's block partials, formed by every wave
@@ -94,6 +94,12 @@ __device__ inline real update_alpha(const KArgs& k) {
         const double rr = k.upd_scal[S_RR];
         const double al = rr / pq;
         if (blockIdx.x == 0 && threadIdx.x == 0) { k.scal_w[S_PQ] = pq; k.scal_w[S_ALPHA] = al; k.scal_w[S_RROLD] = rr; }
+        return (real)al;
+    }
+    if (k.scal_w) {      // folded scalar step (several ranks): pq has been all-reduced into the scalar block, alpha is formed here instead of by a
+        const double rr = k.upd_scal[S_RR];            // one-thread kernel between the all-reduce and this launch
+        const double al = rr / k.upd_scal[S_PQ];
+        if (blockIdx.x == 0 && threadIdx.x == 0) { k.scal_w[S_ALPHA] = al; k.scal_w[S_RROLD] = rr; }
         return (real)al;
     }
     return (real)k.upd_scal[S_ALPHA];
