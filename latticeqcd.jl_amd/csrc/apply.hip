@@ -74,6 +74,26 @@ int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode)
     return LQCD_OK;
 }
 
+// Wilson, r != 1, as two r = 1 calls (see stencil_apply): the first forms a xin + b (1+r)/2 H in, the second adds b (r-1)/2 H' in, H' being
+// the hop sum with the opposite projector sign (the dagger form).  Plain mode: the second call reads its diagonal term from `out`
+// (each thread reads its own site before it writes it; the exterior kernel read-modify-writes).  CG update mode (r -= alpha v is
+// linear in v): the second call runs with a = 0.  The |.|^2 partials of the second call are those of the complete result.
+void split_general_r(const StencilCall& s, StencilCall& s1, StencilCall& s2) {
+    s1 = s; s2 = s;
+    s1.r = 1.0; s2.r = 1.0;
+    s1.b = s.b * 0.5 * (1.0 + s.r);
+    s2.b = s.b * 0.5 * (s.r - 1.0);
+    s2.dagger = s.dagger ? 0 : 1;
+    s1.gauge12 = nullptr; s2.gauge12 = nullptr;
+    if (s.upd_scal) {
+        s2.a = 0.0;
+    } else {
+        s2.a = 1.0;
+        s2.xin[0] = s.out[0]; s2.xin[1] = s.out[1];
+        s2.clover = nullptr;           // a fused clover term belongs to the first call's diagonal term only
+    }
+}
+
 bool any_partitioned(lqcd_ctx_s* c) {
     return c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3];
 }
@@ -83,8 +103,13 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     HIPCHK(hipSetDevice(c->device));
     if (!any_partitioned(c)) return s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s);
     if (s.kind == LQCD_WILSON && s.r != 1.0) {
-        set_error("Wilson r != 1 is not supported on a partitioned lattice (halos carry spin-projected half spinors)");
-        return LQCD_ERR_UNSUPPORTED;
+        // general r on a partitioned lattice: the halos carry spin-projected half spinors, i.e. r = 1 hops.  r -+ gamma is a combination
+        // of the two projectors, (r - gamma) = (1+r)/2 (1 - gamma) + (r-1)/2 (1 + gamma), so the general-r hop sum is
+        // (1+r)/2 H + (r-1)/2 H^dagger-form: two r = 1 applications through the same pack / exchange / exterior sequence.
+        StencilCall s1, s2;
+        split_general_r(s, s1, s2);
+        LQCHK(stencil_apply(c, s1));
+        return stencil_apply(c, s2);
     }
     ARGCHK(c->local_peers.empty(), "this context belongs to an in-process PE grid: use the lqcd_mdom_* collectives");
     // norm partials: the interior writes |.|^2 of what it produced, the exterior appends the corrections of the sites it updates

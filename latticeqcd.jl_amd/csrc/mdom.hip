@@ -24,20 +24,28 @@ extern "C" int lqcd_mdom_op_apply(int n, lqcd_op_t* ops, lqcd_spinor_t* outs, lq
     ARGCHK(ops && outs && ins && n >= 1, "lqcd_mdom_op_apply: null");
     LQCHK(mdom_check(n, ops[0]->ctx));
     std::vector<lqcd_ctx_s*> ctxs(n);
-    std::vector<StencilCall> calls(n);
+    std::vector<StencilCall> calls(n), calls2(n);
+    bool general_r = false;
     for (int r = 0; r < n; r++) {
         LQCHK(check_full(ops[r], outs[r], ins[r], "lqcd_mdom_op_apply"));
         ctxs[r] = ops[r]->ctx;
         ARGCHK(ctxs[r]->rank == r, "lqcd_mdom_op_apply: ops must be ordered by rank");
         apply_bc(ctxs[r], ops[r]->bc);
         LQCHK(make_full_call(ops[r], outs[r], ins[r], dagger ? 1 : 0, calls[r]));
-        if (ops[r]->kind == LQCD_WILSON && ops[r]->r != 1.0) { set_error("r != 1 unsupported on a partitioned lattice"); return LQCD_ERR_UNSUPPORTED; }
+        if (ops[r]->kind == LQCD_WILSON && ops[r]->r != 1.0) {      // two r = 1 passes (apply.hip, split_general_r)
+            const StencilCall full = calls[r];
+            split_general_r(full, calls[r], calls2[r]);
+            general_r = true;
+        }
     }
-    for (int r = 0; r < n; r++) LQCHK(launch_stencil_pack(ctxs[r], calls[r]));
-    LQCHK(halo_exchange_local_all(ctxs.data(), n, ops[0]->kind, 2));
-    for (int r = 0; r < n; r++) LQCHK(launch_stencil_interior(ctxs[r], calls[r]));
-    for (int r = 0; r < n; r++) LQCHK(launch_stencil_exterior(ctxs[r], calls[r]));
-    for (int r = 0; r < n; r++) HIPCHK(hipStreamSynchronize(ctxs[r]->stream));
+    for (int pass = 0; pass < (general_r ? 2 : 1); pass++) {
+        std::vector<StencilCall>& cs = pass ? calls2 : calls;
+        for (int r = 0; r < n; r++) LQCHK(launch_stencil_pack(ctxs[r], cs[r]));
+        LQCHK(halo_exchange_local_all(ctxs.data(), n, ops[0]->kind, 2));
+        for (int r = 0; r < n; r++) LQCHK(launch_stencil_interior(ctxs[r], cs[r]));
+        for (int r = 0; r < n; r++) LQCHK(launch_stencil_exterior(ctxs[r], cs[r]));
+        for (int r = 0; r < n; r++) HIPCHK(hipStreamSynchronize(ctxs[r]->stream));
+    }
     return LQCD_OK;
 }
 

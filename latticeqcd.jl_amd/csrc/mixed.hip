@@ -25,17 +25,43 @@ __global__ __launch_bounds__(MB) void cvt_to_f32(float2* __restrict__ dst, const
         dst[i] = make_float2((float)(v.x * scale), (float)(v.y * scale));
     }
 }
-// fp32 12-real copy of the links (rows 0,1) for the compressed split kernels of the inner solver.  The inner operator only has
-// to be close to the fp64 one -- the outer residual uses the 18 stored fp64 reals -- so this copy is used for any field.
+// Wilson spinors: the fp32 fields of the inner solver keep two consecutive components of a site in one 16-byte word,
+// [chunk][component pair 0..5][lane][2] (stencil.hip, sp12_off / co12: the 8-byte accesses of a plain float2 copy of the fp64
+// arrangement run at 0.54-0.70x the 16-byte rate).  One thread converts one pair: two coalesced 16-byte loads, one 16-byte store.
+// n2 = number of pairs = elements / 2 (a parity block is a whole number of 64-site chunks, so chunks run across both blocks).
+__global__ __launch_bounds__(MB) void cvt_wilson_to_f32(float4* __restrict__ dst, const double2* __restrict__ src, size_t n2, double scale) {
+    for (size_t t = (size_t)blockIdx.x * MB + threadIdx.x; t < n2; t += (size_t)gridDim.x * MB) {
+        const size_t lane = t & 63, q = (t >> 6) % 6, chunk = t / 384;
+        const double2 a = src[chunk * 768 + (2 * q) * 64 + lane], b = src[chunk * 768 + (2 * q + 1) * 64 + lane];
+        dst[t] = make_float4((float)(a.x * scale), (float)(a.y * scale), (float)(b.x * scale), (float)(b.y * scale));
+    }
+}
+// y (fp64, [chunk][12][64]) += a * x (fp32, paired)
+__global__ __launch_bounds__(MB) void axpy_from_wilson_f32(double2* __restrict__ y, const float4* __restrict__ x, double a, size_t n2) {
+    for (size_t t = (size_t)blockIdx.x * MB + threadIdx.x; t < n2; t += (size_t)gridDim.x * MB) {
+        const size_t lane = t & 63, q = (t >> 6) % 6, chunk = t / 384;
+        const float4 xv = x[t];
+        double2* y0 = y + chunk * 768 + (2 * q) * 64 + lane;
+        double2* y1 = y0 + 64;
+        double2 u = *y0, v = *y1;
+        u.x = fma(a, (double)xv.x, u.x); u.y = fma(a, (double)xv.y, u.y);
+        v.x = fma(a, (double)xv.z, v.x); v.y = fma(a, (double)xv.w, v.y);
+        *y0 = u; *y1 = v;
+    }
+}
+// fp32 12-real copy of the links (rows 0,1) for the compressed split kernels of the inner solver, two elements per 16-byte word:
+// [parity][chunk][mu][pair 0..2][lane][2] (stencil.hip, gl12_off).
 __global__ __launch_bounds__(MB) void cvt_gauge12_f32(Geom g, const double2* __restrict__ src, float2* __restrict__ dst) {
     const int t = blockIdx.x * MB + threadIdx.x;
     if (t >= 2 * g.Vh * 4) return;
     const int mu = t & 3, s = t >> 2, p = s / g.Vh, i = s % g.Vh;
-    const size_t so = glink_off(g, p, mu, i), d_o = glink12_off(g, p, mu, i);
+    const size_t so = glink_off(g, p, mu, i);
+    const size_t d_o = ((((size_t)p * g.nch + (size_t)(i >> 6)) * 4 + mu) * 6) * 64 + (size_t)(i & 63) * 2;
     const int Gs = glink_stride(g);
-    for (int e = 0; e < 6; e++) {
-        const double2 v = src[so + (size_t)e * Gs];
-        dst[d_o + (size_t)e * 64] = make_float2((float)v.x, (float)v.y);
+    float4* d4 = reinterpret_cast<float4*>(dst + d_o);
+    for (int q = 0; q < 3; q++) {
+        const double2 a = src[so + (size_t)(2 * q) * Gs], b = src[so + (size_t)(2 * q + 1) * Gs];
+        d4[(size_t)q * 64] = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
     }
 }
 // y (fp64) += a * x (fp32)
@@ -70,18 +96,18 @@ __global__ __launch_bounds__(MB) void residual_kernel(double2* __restrict__ r, c
     }
 }
 // fp32 tail of a CG iteration: x += alpha p ; p = r + beta p   (same flag protocol as cg_update_xp in ops.hip)
-__global__ __launch_bounds__(MB) void cg32_update_xp(const double* __restrict__ s, float2* __restrict__ x, float2* __restrict__ p,
-                                                      const float2* __restrict__ r, size_t n) {
+__global__ __launch_bounds__(MB) void cg32_update_xp(const double* __restrict__ s, float4* __restrict__ x, float4* __restrict__ p,
+                                                      const float4* __restrict__ r, size_t n4) {
     if (s[S_XDONE] != 0.0) return;
     const float al = (float)s[S_ALPHA], be = (float)s[S_BETA];
     const bool cont = s[S_DONE] == 0.0;
-    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
-        float2 pv = p[i], xv = x[i];
-        xv.x = fmaf(al, pv.x, xv.x); xv.y = fmaf(al, pv.y, xv.y);
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
+        float4 pv = p[i], xv = x[i];
+        xv.x = fmaf(al, pv.x, xv.x); xv.y = fmaf(al, pv.y, xv.y); xv.z = fmaf(al, pv.z, xv.z); xv.w = fmaf(al, pv.w, xv.w);
         x[i] = xv;
         if (cont) {
-            const float2 rv = r[i];
-            pv.x = fmaf(be, pv.x, rv.x); pv.y = fmaf(be, pv.y, rv.y);
+            const float4 rv = r[i];
+            pv.x = fmaf(be, pv.x, rv.x); pv.y = fmaf(be, pv.y, rv.y); pv.z = fmaf(be, pv.z, rv.z); pv.w = fmaf(be, pv.w, rv.w);
             p[i] = pv;
         }
     }
@@ -129,7 +155,7 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
     HIPCHK(hipMemcpyAsync(m.p, m.r, n * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n), check_every = 8;
+    const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n / 2), check_every = 8;
     int it = 0;
     double rr = 1.0;
     bool done = false;
@@ -149,7 +175,7 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
             s2.upd[1] = (double2*)(m.r + m.blk);
             LQCHK(stencil_apply(c, s2));
             LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
-            hipLaunchKernelGGL(cg32_update_xp, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, m.x, m.p, m.r, n);
+            hipLaunchKernelGGL(cg32_update_xp, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)m.p, (const float4*)m.r, n / 2);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -178,13 +204,21 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
            "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
     lqcd_ctx_s* c = op->ctx;
     const bool clov = op->csw != 0.0 && op->clover != nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    if (inner_tol <= 0.0) inner_tol = 1e-4;
+    const size_t n = x->elems, ng = op->gauge->elems;
+    const bool wil = op->kind == LQCD_WILSON;     // Wilson spinors are paired in fp32 (cvt_wilson_to_f32)
+    // the fp32 build of the stencil has the site-per-lane and the direction-split kernels: pin the variant for this solve (the fp64
+    // applications of the outer loop are bit-identical across the split variants)
+    struct VariantPin {
+        lqcd_ctx_s* c; int saved;
+        explicit VariantPin(lqcd_ctx_s* c_) : c(c_), saved(c_->tun.dslash_variant) { if (saved >= 2) c->tun.dslash_variant = 1; }
+        ~VariantPin() { c->tun.dslash_variant = saved; }
+    } pin(c);
     if (clov && !(op->r == 1.0 && c->tun.dslash_variant == 1)) {
         set_error("lqcd_solve_mixed_cg_DdagD: the Wilson-clover operator needs the direction-split kernel (r = 1, dslash_variant = 1) in the fp32 inner solver");
         return LQCD_ERR_UNSUPPORTED;
     }
-    HIPCHK(hipSetDevice(c->device));
-    if (inner_tol <= 0.0) inner_tol = 1e-4;
-    const size_t n = x->elems, ng = op->gauge->elems;
     LQCHK(mix_alloc(c, 0, ng * sizeof(float2)));
     for (int k = 1; k <= 4; k++) LQCHK(mix_alloc(c, k, n * sizeof(float2)));
     LQCHK(mix_alloc(c, 5, gauge12_elems(c->geom) * sizeof(float2)));
@@ -248,7 +282,8 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
         while (rr >= eps && total < maxiter) {
             if (!std::isfinite(rr)) { set_error("mixed CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
             const double nrm = std::sqrt(rr);
-            hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, m.r, r->data, n, 1.0 / nrm);
+            if (wil) hipLaunchKernelGGL(cvt_wilson_to_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, (float4*)m.r, r->data, n / 2, 1.0 / nrm);
+            else hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, m.r, r->data, n, 1.0 / nrm);
             HIPCHK(hipGetLastError());
             // no tighter than needed to reach eps (with a 10x margin), no tighter than fp32 can deliver
             const double eps2 = std::max(inner_tol * inner_tol, 0.1 * eps / rr);
@@ -257,7 +292,8 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
             LQCHK(inner_cg32(op, m, n, eps2, maxiter - total, &it, &rin));
             total += it;
             nout++;
-            hipLaunchKernelGGL(axpy_from_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, x->data, m.x, nrm, n);
+            if (wil) hipLaunchKernelGGL(axpy_from_wilson_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, x->data, (const float4*)m.x, nrm, n / 2);
+            else hipLaunchKernelGGL(axpy_from_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, x->data, m.x, nrm, n);
             HIPCHK(hipGetLastError());
             const double rr_old = rr;
             LQCHK(true_residual());

@@ -13,6 +13,7 @@ int stream_grid(lqcd_ctx_s* c, size_t n);
 // apply.hip
 StencilCall make_hop_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* xin, double a, double b, int dagger);
 int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* who);
+void split_general_r(const StencilCall& s, StencilCall& s1, StencilCall& s2);   // Wilson r != 1 on a partitioned lattice = two r = 1 calls
 
 // solvers.hip
 constexpr int UB = 256;     // block size of the solvers' streaming kernels

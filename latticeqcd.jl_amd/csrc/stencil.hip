@@ -67,6 +67,43 @@ __device__ inline void st_nt(real2* p, cd v) {
     __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(p));
 }
 
+// Addressing of a Wilson (12-component) spinor and of a 12-real link inside their 64-site chunks.
+//   fp64 build: component j of a site at sp_off(12, i) + j * 64 -- one 16-byte element per lane and load instruction.
+//   fp32 build: an element is 8 bytes, and 8-byte accesses run at 0.54-0.70x the 16-byte rate on this memory pipeline
+//   (MI355X_MICROARCH.md, cache-policy table), so the fp32 fields of the mixed-precision solver keep TWO consecutive components
+//   in one 16-byte word: [chunk][component pair][lane][2].  A hop then issues 6 + 3 loads of 16 bytes instead of 12 + 6 of 8.
+//   (Staggered 3-component spinors and the 18-real fp32 links keep the fp64 arrangement.)
+#ifdef LQCD_F32
+__device__ inline size_t sp12_off(int i) { return (size_t)(i >> 6) * (12 * 64) + (size_t)(i & 63) * 2; }
+__device__ constexpr size_t co12(int j) { return (size_t)(j >> 1) * 128 + (size_t)(j & 1); }
+__device__ inline size_t gl12_off(const Geom& g, int p, int mu, int i) {
+    return ((((size_t)p * g.nch + (size_t)(i >> 6)) * 4 + mu) * 6) * 64 + (size_t)(i & 63) * 2;
+}
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ inline void ld_pair(cd& a, cd& b, const real2* p) {
+    const v4f* q = reinterpret_cast<const v4f*>(p);
+    v4f v;
+    if constexpr (NT) v = __builtin_nontemporal_load(q); else v = *q;
+    a = mk(v.x, v.y); b = mk(v.z, v.w);
+}
+#else
+__device__ inline size_t sp12_off(int i) { return sp_off(12, i); }
+__device__ constexpr size_t co12(int j) { return (size_t)j * 64; }
+__device__ inline size_t gl12_off(const Geom& g, int p, int mu, int i) { return glink12_off(g, p, mu, i); }
+#endif
+// components FIRST .. FIRST+N-1 of a Wilson spinor (FIRST and N even)
+template <int FIRST, int N, bool NT>
+__device__ inline void load_comps12(cd* sp, const real2* __restrict__ psi) {
+#ifdef LQCD_F32
+#pragma unroll
+    for (int q = 0; q < N / 2; q++) ld_pair<NT>(sp[2 * q], sp[2 * q + 1], psi + co12(FIRST + 2 * q));
+#else
+#pragma unroll
+    for (int j = 0; j < N; j++) sp[j] = NT ? ld_nt(psi + co12(FIRST + j)) : ld(psi + co12(FIRST + j));
+#endif
+}
+
 // final store of one output component: plain (out = v) or CG update mode (r -= alpha v); accumulates the squared norm
 __device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm, real al) {
     if (k.upd_scal) {
@@ -75,6 +112,17 @@ __device__ inline void emit(const KArgs& k, int p, size_t off, cd v, real& nrm, 
         r.re = fma(-al, v.re, r.re); r.im = fma(-al, v.im, r.im);
         nrm = fma(r.re, r.re, nrm); nrm = fma(r.im, r.im, nrm);
         st(rp, r);
+    } else {
+        nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+        if (k.nt & 4) st_nt(k.out[p] + off, v); else st(k.out[p] + off, v);
+    }
+}
+// the same with the old value of r already in registers (its load was issued ahead of the hops: one dependent memory round trip less)
+__device__ inline void emit_pre(const KArgs& k, int p, size_t off, cd v, real& nrm, real al, cd r) {
+    if (k.upd_scal) {
+        r.re = fma(-al, v.re, r.re); r.im = fma(-al, v.im, r.im);
+        nrm = fma(r.re, r.re, nrm); nrm = fma(r.im, r.im, nrm);
+        st(k.upd[p] + off, r);
     } else {
         nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
         if (k.nt & 4) st_nt(k.out[p] + off, v); else st(k.out[p] + off, v);
@@ -188,6 +236,15 @@ __device__ inline void load_link(cd (&u)[9], const real2* __restrict__ U, int Vh
 
 // 12-real links: rows 0 and 1 from memory, row 2 = conj(row 0 x row 1)  (exact for SU(3) to rounding)
 __device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U, bool nt = false) {
+#ifdef LQCD_F32
+    if (nt) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) ld_pair<true>(u[2 * q], u[2 * q + 1], U + (size_t)q * 128);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; q++) ld_pair<false>(u[2 * q], u[2 * q + 1], U + (size_t)q * 128);
+    }
+#else
     if (nt) {
 #pragma unroll
         for (int k = 0; k < 6; k++) u[k] = ld_nt(U + (size_t)k * 64);
@@ -195,6 +252,7 @@ __device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U, bool
 #pragma unroll
         for (int k = 0; k < 6; k++) u[k] = ld(U + (size_t)k * 64);
     }
+#endif
 #pragma unroll
     for (int b = 0; b < 3; b++) {
         const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
@@ -210,6 +268,26 @@ __device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U, bool
 // spin projection h = rows 0,1 of (1 - S*gamma_mu) psi   (mu = 3: the two non-zero rows, factor 2 included)
 template <int MU, int S>
 __device__ inline void project(cd (&h0)[3], cd (&h1)[3], const real2* __restrict__ psi, int Vh, bool nt = false) {
+#ifdef LQCD_F32
+    if constexpr (MU < 3) {
+        constexpr int p0 = PERM[MU][0], p1 = PERM[MU][1];
+        constexpr int k0 = GK[MU][0] + (S > 0 ? 2 : 0), k1 = GK[MU][1] + (S > 0 ? 2 : 0);
+        cd sp[12];
+        load_comps12<0, 12, false>(sp, psi);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            h0[c] = sp[c] + mul_ipow<k0>(sp[p0 * 3 + c]);
+            h1[c] = sp[3 + c] + mul_ipow<k1>(sp[p1 * 3 + c]);
+        }
+    } else {
+        constexpr int base = S > 0 ? 2 : 0;
+        cd sp[6];
+        if (nt) load_comps12<base * 3, 6, true>(sp, psi); else load_comps12<base * 3, 6, false>(sp, psi);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { h0[c] = 2.0 * sp[c]; h1[c] = 2.0 * sp[3 + c]; }
+    }
+    return;
+#endif
     if constexpr (MU == 3) {
         if (nt) {       // last use of these spinor lines in the t-sweep of the workgroup map: stream them
             constexpr int base = S > 0 ? 2 : 0;
@@ -287,7 +365,7 @@ __device__ inline void wilson_hop_rgen(cd (&acc)[12], const real2* __restrict__ 
     for (int s = 0; s < 4; s++) {
         cd h[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) h[c] = sign * ld(psi + (size_t)(s * 3 + c) * Vh);
+        for (int c = 0; c < 3; c++) h[c] = sign * ld(psi + co12(s * 3 + c));
         su3_mv<ADJ>(t[s], u, h);
     }
     if constexpr (MU < 3) {
@@ -381,7 +459,7 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
         // diagonal term: issue its loads first so they overlap the hops instead of forming a ninth dependent round trip
         if (k.a != 0.0) {
 #pragma unroll
-            for (int j = 0; j < 12; j++) xv[j] = ld(k.xin[p] + sp_off(12, i) + (size_t)j * Vh);
+            for (int j = 0; j < 12; j++) xv[j] = ld(k.xin[p] + sp12_off(i) + co12(j));
         } else {
 #pragma unroll
             for (int j = 0; j < 12; j++) xv[j] = mk(0.0, 0.0);
@@ -391,19 +469,19 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
         constexpr int SF = DAG ? -1 : 1;  // forward hop: (r - gamma) for D, (r + gamma) for D^+
 #define HOP(MU)                                                                                                  \
     if (n.sf[MU] != 0.0) {                                                                                       \
-        if constexpr (RGEN) wilson_hop_rgen<MU, SF, false>(acc, psi + sp_off(12, n.fwd[MU]), k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU], k.r); \
-        else wilson_hop<MU, SF, false>(acc, psi + sp_off(12, n.fwd[MU]), k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU]);            \
+        if constexpr (RGEN) wilson_hop_rgen<MU, SF, false>(acc, psi + sp12_off(n.fwd[MU]), k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU], k.r); \
+        else wilson_hop<MU, SF, false>(acc, psi + sp12_off(n.fwd[MU]), k.gauge + glink_off(k.g, p, MU, i), Vh, Us, n.sf[MU]);            \
     }                                                                                                            \
     if (n.sb[MU] != 0.0) {                                                                                       \
-        if constexpr (RGEN) wilson_hop_rgen<MU, -SF, true>(acc, psi + sp_off(12, n.bwd[MU]), k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU], k.r); \
-        else wilson_hop<MU, -SF, true>(acc, psi + sp_off(12, n.bwd[MU]), k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU]); \
+        if constexpr (RGEN) wilson_hop_rgen<MU, -SF, true>(acc, psi + sp12_off(n.bwd[MU]), k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU], k.r); \
+        else wilson_hop<MU, -SF, true>(acc, psi + sp12_off(n.bwd[MU]), k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]), Vh, Us, n.sb[MU]); \
     }
         HOP(0) HOP(1) HOP(2) HOP(3)
 #undef HOP
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             cd v = mk(fma(k.b, acc[j].re, k.a * xv[j].re), fma(k.b, acc[j].im, k.a * xv[j].im));
-            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm, al_upd);
+            emit(k, p, co12(j) + sp12_off(i), v, nrm, al_upd);
         }
     }
     if (k.norm_partial) block_norm_partial<TB>(nrm, k.norm_partial);
@@ -422,8 +500,8 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     neighbours(k.g, p, i, n, c);
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const real2* __restrict__ psi = k.in[1 - p];
-    const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(k.g, p, MU, i) : k.gauge + glink_off(k.g, p, MU, i);
-    const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
+    const real2* __restrict__ Uf = R12 ? k.gauge12 + gl12_off(k.g, p, MU, i) : k.gauge + glink_off(k.g, p, MU, i);
+    const real2* __restrict__ Ub = R12 ? k.gauge12 + gl12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
     const int Us = glink_stride(k.g);
     constexpr int SF = DAG ? -1 : 1;
 #ifdef LQCD_ABLATE
@@ -431,8 +509,8 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
     if (k.dbg >= 256) {               // traffic ablations (wrong results): redirect one stream of direction MU to chunk 0 (always L2-hot)
         const int hot = i & 63;
         if (k.dbg & (256 << MU)) { n.fwd[MU] = hot; n.bwd[MU] = hot; }
-        if (k.dbg & (4096 << MU)) Uf = R12 ? k.gauge12 + glink12_off(k.g, p, MU, hot) : k.gauge + glink_off(k.g, p, MU, hot);
-        if (k.dbg & (65536 << MU)) Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, MU, hot) : k.gauge + glink_off(k.g, 1 - p, MU, hot);
+        if (k.dbg & (4096 << MU)) Uf = R12 ? k.gauge12 + gl12_off(k.g, p, MU, hot) : k.gauge + glink_off(k.g, p, MU, hot);
+        if (k.dbg & (65536 << MU)) Ub = R12 ? k.gauge12 + gl12_off(k.g, 1 - p, MU, hot) : k.gauge + glink_off(k.g, 1 - p, MU, hot);
     }
 #endif
 #ifdef LQCD_ABLATE
@@ -449,8 +527,8 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
         return;
     }
 #endif
-    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp_off(12, n.fwd[MU]), Uf, Vh, Us, n.sf[MU], (k.nt & 2) != 0);
-    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp_off(12, n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0, (k.nt & 8) != 0);
+    if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp12_off(n.fwd[MU]), Uf, Vh, Us, n.sf[MU], (k.nt & 2) != 0);
+    if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp12_off(n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0, (k.nt & 8) != 0);
 }
 
 // rows 3*W .. 3*W+2 of A x for the packed clover field (clover.hip: two Hermitian 6x6 blocks in the chiral basis chi_(-+) =
@@ -488,8 +566,18 @@ __device__ inline void clover_rows(cd (&out)[3], const real2* __restrict__ a, co
     }
 }
 
+// fp32 build: half-size registers and 24 KiB of LDS leave room for 5 workgroups per CU if the compiler stays within 96 VGPRs (it does,
+// without spilling, except for the clover instances, which keep the default)
+#ifdef LQCD_F32
+#ifndef LQCD_DS_OCC
+#define LQCD_DS_OCC 5
+#endif
+#define LQCD_DS_BOUNDS __launch_bounds__(256, CLOV ? 1 : LQCD_DS_OCC)
+#else
+#define LQCD_DS_BOUNDS __launch_bounds__(256)
+#endif
 template <bool DAG, bool R12 = false, bool CLOV = false>
-__global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
+__global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
     __shared__ real2 part[4][12][64];  // 48 KiB
     __shared__ double red[4];
     if (upd_done(k)) return;
@@ -507,13 +595,28 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
     // the diagonal term's loads are issued first so they are not a third dependent memory round trip after the barrier
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     cd cpsi[CLOV ? 12 : 1];
+    cd rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+#ifndef LQCD_UPD_PREFETCH      // fp32 build: the three extra live values spill under its 96-VGPR cap (LQCD_DS_OCC) -- off there (LQCD_UPD_PREFETCH32)
+#ifdef LQCD_F32
+#ifndef LQCD_UPD_PREFETCH32
+#define LQCD_UPD_PREFETCH32 0
+#endif
+#define LQCD_UPD_PREFETCH LQCD_UPD_PREFETCH32
+#else
+#define LQCD_UPD_PREFETCH 1
+#endif
+#endif
+    if (LQCD_UPD_PREFETCH && valid && k.upd_scal) {      // CG update mode: the old r is read now, not after the barrier
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) rv[cc] = ld(k.upd[p] + sp12_off(i) + co12(3 * w + cc));
+    }
     if (valid && k.a != 0.0) {
         if constexpr (CLOV) {       // Wilson-clover: all 12 components now (the loads overlap the hops), A xin after the hops
 #pragma unroll
-            for (int j = 0; j < 12; j++) cpsi[j] = ld(k.xin[p] + sp_off(12, i) + (size_t)j * Vh);
+            for (int j = 0; j < 12; j++) cpsi[j] = ld(k.xin[p] + sp12_off(i) + co12(j));
         } else {
 #pragma unroll
-            for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp_off(12, i) + (size_t)(3 * w + cc) * Vh);
+            for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp12_off(i) + co12(3 * w + cc));
         }
     }
     if (valid) {
@@ -541,7 +644,8 @@ __global__ __launch_bounds__(256) void wilson_dirsplit(KArgs k) {
             cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
             cd v = k.b * s;
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
-            emit(k, p, (size_t)j * Vh + sp_off(12, i), v, nrm, al_upd);
+            if (LQCD_UPD_PREFETCH) emit_pre(k, p, co12(j) + sp12_off(i), v, nrm, al_upd, rv[cc]);
+            else emit(k, p, co12(j) + sp12_off(i), v, nrm, al_upd);
         }
     }
     if (k.norm_partial) {
@@ -1552,6 +1656,8 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
     cd acc[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     cd xv = mk(0, 0);
     if (valid && k.a != 0.0 && w < 3) xv = ld(k.xin[p] + sp_off(3, i) + (size_t)w * Vh);
+    cd rv = mk(0, 0);
+    if (valid && k.upd_scal && w < 3) rv = ld(k.upd[p] + sp_off(3, i) + (size_t)w * Vh);    // CG update mode: the old r is read ahead of the hops
     if (valid) {
         Nbr n;
         int c[4];
@@ -1563,8 +1669,8 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         const int nb = w == 0 ? n.bwd[0] : w == 1 ? n.bwd[1] : w == 2 ? n.bwd[2] : n.bwd[3];
         const real sf = w == 0 ? n.sf[0] : w == 1 ? n.sf[1] : w == 2 ? n.sf[2] : n.sf[3];
         const real sb = w == 0 ? n.sb[0] : w == 1 ? n.sb[1] : w == 2 ? n.sb[2] : n.sb[3];
-        const real2* __restrict__ Uf = R12 ? k.gauge12 + glink12_off(k.g, p, w, i) : k.gauge + glink_off(k.g, p, w, i);
-        const real2* __restrict__ Ub = R12 ? k.gauge12 + glink12_off(k.g, 1 - p, w, nb) : k.gauge + glink_off(k.g, 1 - p, w, nb);
+        const real2* __restrict__ Uf = R12 ? k.gauge12 + gl12_off(k.g, p, w, i) : k.gauge + glink_off(k.g, p, w, i);
+        const real2* __restrict__ Ub = R12 ? k.gauge12 + gl12_off(k.g, 1 - p, w, nb) : k.gauge + glink_off(k.g, 1 - p, w, nb);
         if (sf != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nf), Uf, Vh, Us, eta * sf, false, (k.nt & 2) != 0);
         if (sb != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nb), Ub, Vh, Us, -eta * sb, true, (k.nt & 1) != 0);
     }
@@ -1576,7 +1682,7 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         const real2 s0 = part[0][w][lane], s1 = part[1][w][lane], s2 = part[2][w][lane], s3 = part[3][w][lane];
         cd v = k.b * mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         v = mk(fma(k.a, xv.re, v.re), fma(k.a, xv.im, v.im));
-        emit(k, p, (size_t)w * Vh + sp_off(3, i), v, nrm, al_upd);
+        emit_pre(k, p, (size_t)w * Vh + sp_off(3, i), v, nrm, al_upd, rv);
     }
     if (k.norm_partial) {
 #pragma unroll
@@ -1607,7 +1713,7 @@ __device__ inline void wilson_pack_dir(const HArgs& k, int side) {
     int c[4];
     face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
     const int i = coords_to_cb(g, c);
-    const real2* __restrict__ psi = (ps ? k.in[1] : k.in[0]) + sp_off(12, i);
+    const real2* __restrict__ psi = (ps ? k.in[1] : k.in[0]) + sp12_off(i);
     cd h0[3], h1[3];
     real2* dst;
     if (side == 0) {
@@ -1718,16 +1824,16 @@ __device__ __forceinline__ real wilson_ext_face(const HArgs& k, int side) {
     if (MU <= 2) wilson_ext_add<2, DAG>(acc, k, c, slot, pout, i);
     wilson_ext_add<3, DAG>(acc, k, c, slot, pout, i);
     const real coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
-    real2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp_off(12, i);
+    real2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp12_off(i);
     real corr = 0.0;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
-        cd v = ld(o + (size_t)j * Vh);
+        cd v = ld(o + co12(j));
         const real before = v.re * v.re + v.im * v.im;
         v.re = fma(coef, acc[j].re, v.re);
         v.im = fma(coef, acc[j].im, v.im);
         corr += (v.re * v.re + v.im * v.im) - before;
-        st(o + (size_t)j * Vh, v);
+        st(o + co12(j), v);
     }
     return corr;
 }
@@ -1921,7 +2027,9 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
 
 static bool use_dirsplit(lqcd_ctx_s* c, int kind, real r) {   // variants 1/2/3 work on 64-site chunks
     if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 7)) return false;
-    return kind == LQCD_STAGGERED || r == 1.0;   // Wilson: the split kernels use the r = 1 projectors
+    // Wilson: the split kernels use the r = 1 projectors.  On a partitioned lattice a general-r application runs as two r = 1 calls
+    // (apply.hip, split_general_r), so the launch geometry (number of |.|^2 partials) is the r = 1 one there for every r.
+    return kind == LQCD_STAGGERED || r == 1.0 || c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3];
 }
 static int persist_grid(lqcd_ctx_s* c, int nvirt) {
     int g = c->num_cu * (c->tun.persist_per_cu > 0 ? c->tun.persist_per_cu : 2);
@@ -1959,6 +2067,8 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         if (s.kind == LQCD_STAGGERED) {
             if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
+#ifndef LQCD_F32   // the fp32 build (paired-component fields, see sp12_off) has the direction-split and site-per-lane kernels only;
+                   // the mixed-precision solver pins dslash_variant to 0/1 for the duration of a solve (mixed.hip)
         } else if (c->tun.dslash_variant == 7 && !k.clover && k.gauge12 && s.parity_mode == 2) {
             dim3 grid(k.nblocks / 2), block(512);
             if (s.dagger) hipLaunchKernelGGL((wilson_pair4<true, true>), grid, block, pad, c->stream, k);
@@ -2000,6 +2110,7 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             if (s.dagger) { switch (nt) { case 1: LQ_HS(true, 1); break; case 2: LQ_HS(true, 2); break; case 3: LQ_HS(true, 3); break; default: LQ_HS(true, 0); } }
             else { switch (nt) { case 1: LQ_HS(false, 1); break; case 2: LQ_HS(false, 2); break; case 3: LQ_HS(false, 3); break; default: LQ_HS(false, 0); } }
 #undef LQ_HS
+#endif
         } else {
             dim3 grid(k.nblocks), block(256);
             if (k.clover && k.gauge12) {

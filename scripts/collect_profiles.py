@@ -77,7 +77,8 @@ if bench:
     if c:
         lines.append(f"| CPU baseline ({c['kind']}, {c['cores']} core) | {c['value']:.3f} iter/s, Dslash {c['dslash_gflops']:.2f} GFLOP/s | `{tag}_bench_n1.json` |")
 for sub, label in (("wilson_dirsplit<false, true, false>", "12-real D"), ("wilson_dirsplit<true, true, false>", "12-real D† (CG update mode)"),
-                   ("wilson_dirsplit<false, false, false>", "18-real D"), ("cg_update_xp", "x, p update"), ("reduce_final", "final reduction")):
+                   ("wilson_dirsplit<false, false, false>", "18-real D"), ("cg_update_even", "p update, even iterations (x deferred)"),
+                   ("cg_update_odd", "x (two terms) and p update, odd iterations"), ("cg_update_xp", "x, p update"), ("reduce_final", "final reduction")):
     s = stat_row(sub)
     if s:
         lines.append(f"| rocprofv3 `--kernel-trace --stats` of the same command: {label} `{sub}` | {float(s['AverageNs']) / 1e3:.1f} µs average over {s['Calls']} calls | `{tag}_bench_kernel_stats.csv` |")

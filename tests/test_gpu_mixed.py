@@ -82,6 +82,27 @@ def test_mixed_cg_tight_and_loose_targets(gpu, orc):
         lq.solve_mixed_DinvX_(x, D, b)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 3, 5])
+def test_mixed_cg_under_every_stencil_variant_setting(gpu, orc, variant):
+    """The fp32 build of the stencil keeps Wilson spinors and 12-real links as 16-byte component pairs and only has the
+    site-per-lane (0) and direction-split (1) kernels; any other dslash_variant is pinned to 1 for the duration of the solve
+    and restored afterwards.  Results agree with the oracle's fp64 solution under all of them."""
+    lq = gpu
+    L = (8, 8, 4, 8)
+    lat, Uh, Ud, D = _setup(lq, orc, L, "Wilson", 141)
+    lat.set_param("dslash_variant", variant)
+    try:
+        b_h = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 142)
+        b = lq.Fermionfields(lat, lq.WILSON).upload(b_h)
+        x = b.similar()
+        it, outer, rr = lq.solve_mixed_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+        assert lat.get_param("dslash_variant") == variant
+        xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, Uh, b_h, L, KAPPA, 1.0, BC, eps=1e-19)
+        assert st == 0 and rr < 1e-19 and rel_err(x.download(), xo) < 1e-9
+    finally:
+        lat.set_param("dslash_variant", 1)
+
+
 def test_mixed_cg_rccl_self_partition(gpu, orc):
     """fp32 halos (pack / ncclFloat send-recv / exterior from the fp32 stencil build) on the real RCCL path, one GPU."""
     code = textwrap.dedent("""

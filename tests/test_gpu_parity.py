@@ -424,6 +424,77 @@ def test_partitioned_dslash_equals_single_domain(gpu, orc, pe, kind_name):
     assert abs(lq.mdom_plaquette(Us) - orc.plaquette(U, gL)) < 1e-13
 
 
+@pytest.mark.parametrize("pe", [(1, 1, 1, 2), (1, 2, 2, 2), (2, 1, 1, 2)])
+@pytest.mark.parametrize("r", [0.7, 0.0, 1.6])
+def test_partitioned_wilson_general_r_equals_oracle(gpu, orc, pe, r):
+    """Wilson parameter r != 1 on a partitioned lattice.  The halos carry spin-projected (r = 1) half spinors; r -+ gamma is
+    (1+r)/2 (1 -+ gamma) + (r-1)/2 (1 +- gamma), so the operator runs as two r = 1 passes through the same exchange
+    (apply.hip split_general_r).  N-domain D and D^+ == oracle on the global lattice."""
+    lq = gpu
+    gL = (8, 8, 8, 16)
+    n = int(np.prod(pe))
+    U = orc.hot_gauge(gL, 121)
+    psi = orc.gaussian_spinor(orc.wilson_shape(gL), 122)
+    lats = [lq.Lattice(gL, pe, rk) for rk in range(n)]
+    lq.link_local(lats)
+    Ds, xs, ys = [], [], []
+    for lat in lats:
+        Ud = lq.Gaugefields(lat).upload(lq.pegrid.local_view(U, lat.local_L, lat.origin, lead=1))
+        Ds.append(lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": r, "boundarycondition": BC}))
+        xs.append(lq.Fermionfields(lat, lq.WILSON).upload(lq.pegrid.local_view(psi, lat.local_L, lat.origin, lead=1)))
+        ys.append(lq.Fermionfields(lat, lq.WILSON))
+    for dagger in (False, True):
+        lq.mdom_mul_(ys, [D.adjoint() if dagger else D for D in Ds], xs)
+        ref = orc.apply_D(lq.WILSON, U, psi, gL, KAPPA, r, BC, dagger)
+        for lat, y in zip(lats, ys):
+            assert rel_err(y.download(), lq.pegrid.local_view(ref, lat.local_L, lat.origin, lead=1)) < DSLASH_TOL
+
+
+def test_rccl_self_partition_general_r_solvers(gpu, orc):
+    """r != 1 through the real RCCL path (self-partition): Dslash, the fused CG (update-mode second pass with a = 0, |r|^2 partials
+    of the complete result), the mixed-precision CG (fp32 halos) and BiCGStab equal the oracle."""
+    lq = gpu
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        from oracle import oracle as orc
+        L, K, BC, R = (8, 4, 6, 8), 0.125, (1, 1, 1, -1), 0.6
+        lat = lq.Lattice(L)
+        lat.comm_init(lq.comm_unique_id())
+        U = orc.hot_gauge(L, 131)
+        Ud = lq.Gaugefields(lat).upload(U)
+        D = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": K, "r": R, "boundarycondition": BC, "eps_CG": 1e-19})
+        psi = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 132)
+        x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+        y = x.similar()
+        for dag in (False, True):
+            lq.mul_(y, D.adjoint() if dag else D, x)
+            ref = orc.apply_D(lq.WILSON, U, psi, L, K, R, BC, dag)
+            err = np.abs(y.download() - ref).max() / np.abs(ref).max()
+            assert err < 1e-13, (dag, err)
+        xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, K, R, BC, eps=1e-19)
+        assert st == 0
+        sol = x.similar()
+        it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+        assert abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (it, ito)
+        lq.clear_fermion_(sol)
+        itm, outer, rrm = lq.solve_mixed_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+        assert rrm < 1e-19 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (itm, outer, rrm)
+        lq.clear_fermion_(sol)
+        lq.solve_DinvX_(sol, D, x)                 # BiCGStab on D
+        lq.mul_(y, D, sol)
+        assert np.abs(y.download() - psi).max() < 1e-8
+        print("RCCL_SELF_R_OK")
+    """)
+    for mask in ("8", "14"):
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "RCCL_SELF_R_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_partitioned_cg_equals_single_domain(gpu, orc):
     lq = gpu
     gL, pe = (4, 4, 8, 8), (1, 1, 2, 2)
