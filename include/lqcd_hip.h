@@ -80,8 +80,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * 18 stored reals are always read), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge (bit 0 [default]: the backward = last use of a link is a non-temporal load; bit 1: the forward use too), nt_store (1 [default]:
  * non-temporal output stores), lds_pad_kb, persist_per_cu;
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
- * mixed-precision CG), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
- * md_remap (1 [default]: the staple sweep follows the stencil's XCD-aware workgroup map), nt_blas (1: non-temporal loads / stores in the CG update kernels),
+ * mixed-precision CG; 2: the same, and every rational entry solves all its poles with lqcd_solve_multishift_mixed_cg), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
+ * md_remap (1 [default]: the staple sweep follows the stencil's XCD-aware workgroup map), nt_blas (1 [default]: non-temporal loads / stores in the CG update kernels),
  * cg_skip_done, cg_defer_x (1 [default]: the fused CG updates x every second iteration with both search directions, p alternating between
  * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates), cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
@@ -192,6 +192,15 @@ int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, 
  * (<= 0: 1e-4).  iters: total inner iterations (+ fp64 iterations if the fall-back ran); outer: correction steps. */
 int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
                               int* outer, double* final_rr);
+
+/* mixed-precision shiftedcg (BASELINE configs[4] "RHMC ... mixed-precision fp32 inner / fp64 outer CG"; the
+ * reference's shiftedcg, README.md:132, is fp64 throughout).  Same contract as lqcd_solve_multishift_cg -- zero initial guesses, x0
+ * may be NULL -- with the stopping rule enforced on the TRUE fp64 residual of every system: |b - (D^+D + sigma_j) xs[j]|^2 < eps.
+ * Phase 1: one fp32 multi-shift CG for all systems (relative residual inner_tol, <= 0: 1e-6); phase 2: fp64 defect correction of each
+ * system on its own with fp32 one-shift solves (a multi-shift recurrence cannot be restarted).  iters: all fp32 iterations (+ fp64 ones
+ * of fall-backs); outer: fp32 correction solves; final_rr: the largest true residual. */
+int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
+                                   double eps, int maxiter, double inner_tol, int* iters, int* outer, double* final_rr);
 
 /* ---------------------------------------------------------------- pseudofermion action and force */
 /* evaluate_FermiAction(fa, U, eta) (src/updates/standardHMC.jl:71): S_f = eta^+ (D^+D)^-1 eta by CG from a zero guess.

@@ -295,6 +295,15 @@ function shiftedcg(vec_x::Vector{HIPFermion}, vec_β::Vector{Float64}, x::HIPFer
                 A.D.h, x.h, hs, b.h, vec_β, length(vec_β), A.D.eps_CG, A.D.MaxCGstep, it, rr))
 end
 
+# mixed-precision shiftedcg (fp32 multi-shift pass + fp64 defect correction per shift; the stopping rule holds for the true fp64 residuals)
+function shiftedcg_mixed(vec_x::Vector{HIPFermion}, vec_β::Vector{Float64}, x::HIPFermion, A::HIPDdagD, b::HIPFermion; inner_tol = 0.0)
+    it, outer, rr = Ref{Cint}(0), Ref{Cint}(0), Ref{Float64}(0)
+    hs = [v.h for v in vec_x]
+    check(ccall((:lqcd_solve_multishift_mixed_cg, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Float64}, Cint, Float64, Cint, Float64, Ref{Cint}, Ref{Cint}, Ref{Float64}),
+                A.D.h, x.h, hs, b.h, vec_β, length(vec_β), A.D.eps_CG, A.D.MaxCGstep, inner_tol, it, outer, rr))
+end
+
 # staggered: the parity block (D'D)_pp on half-lattice vectors (the 4-taste action of test/test_staggered.toml lives on the even sites)
 function solve_parity_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion, parity::Integer = 0)
     it, rr = Ref{Cint}(0), Ref{Float64}(0)

@@ -117,6 +117,8 @@ static int rational_solve(lqcd_op_s* op, lqcd_spinor_s* b, int n, const double* 
         xs[k] = scratch_get(c, op->kind, LQCD_FULL);
         if (!xs[k]) { set_error("rational action: out of device memory"); return LQCD_ERR_HIP; }
     }
+    if (c->tun.mixed_action_solver == 2)     // one fp32 multi-shift pass for all poles, fp64 defect correction per pole (mixed.hip)
+        return lqcd_solve_multishift_mixed_cg(op, nullptr, xs.data(), b, poles, n, eps, maxiter, 0.0, iters, nullptr, nullptr);
     if (c->tun.mixed_action_solver && op->kind == LQCD_STAGGERED) {
         // staggered: D^+D + sigma = (m^2 + sigma) - D_hop^2 is the operator of mass sqrt(m^2 + sigma), so every pole is a plain
         // mixed-precision solve (fp32 inner CG, fp64 defect correction, true-residual stopping rule) -- the shifted iterates of a

@@ -330,7 +330,8 @@ struct Tunables {
                               // into the prologues of the kernels that consume them (3 dependent launches per iteration instead of 5)
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
-    int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule)
+    int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule);
+                                  // 2: the same, and the rational actions solve all poles with the mixed-precision multi-shift CG
     int gauge_recon = 12;     // 12 (default): the direction-split kernels read 2 rows per link and rebuild the third -- only while every
                               // link of the field is unitary to 1e-14 (checked per gauge version), otherwise the 18 stored reals are
                               // read; bytes/site 960 -> 768 (Wilson), 672 -> 480 (staggered).  18: always read all 18 reals.
@@ -368,8 +369,8 @@ struct lqcd_ctx_s {
     const void* mix_gauge_of = nullptr;  // gauge handle / version the fp32 link copies in mix_buf[0], mix_buf[5] were made from
     uint64_t mix_gauge_version = 0;
     bool mix_gauge12_valid = false;      // the 12-real fp32 copy (mix_buf[5]) was made for that version
-    void* mix_buf[7] = {};
-    size_t mix_bytes[7] = {};
+    void* mix_buf[8] = {};     // 7: fp32 x_j / p_j pool of the mixed-precision multi-shift solver
+    size_t mix_bytes[8] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;

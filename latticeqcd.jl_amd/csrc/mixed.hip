@@ -10,7 +10,7 @@
 // The residual is normalised before it is rounded to fp32, so the inner solver never sees the absolute scale.  If an outer
 // step fails to reduce the true residual by 2x (fp32 accuracy exhausted) the solve is finished by the fp64 CG from the
 // current iterate.  Partitioned lattices: the fp32 halos go through the same pack / RCCL / exterior sequence (ncclFloat).
-#include "lqcd_internal.h"
+#include "ops_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -74,14 +74,15 @@ __global__ __launch_bounds__(MB) void axpy_from_f32(double2* __restrict__ y, con
         y[i] = yv;
     }
 }
-// r = b - q  (fp64) with |r|^2 block partials
-__global__ __launch_bounds__(MB) void residual_kernel(double2* __restrict__ r, const double2* __restrict__ b, const double2* __restrict__ q, size_t n,
-                                                       double* partial) {
+// r = b - q - sigma x  (fp64) with |r|^2 block partials  (sigma = 0: x is not read)
+__global__ __launch_bounds__(MB) void residual_kernel(double2* __restrict__ r, const double2* __restrict__ b, const double2* __restrict__ q,
+                                                       const double2* __restrict__ x, double sigma, size_t n, double* partial) {
     __shared__ double red[MB / 64];
     double acc = 0;
     for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
         const double2 bv = b[i], qv = q[i];
-        const double2 rv = make_double2(bv.x - qv.x, bv.y - qv.y);
+        double2 rv = make_double2(bv.x - qv.x, bv.y - qv.y);
+        if (sigma != 0.0) { const double2 xv = x[i]; rv.x = fma(-sigma, xv.x, rv.x); rv.y = fma(-sigma, xv.y, rv.y); }
         r[i] = rv;
         acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
     }
@@ -109,6 +110,38 @@ __global__ __launch_bounds__(MB) void cg32_update_xp(const double* __restrict__ 
             const float4 rv = r[i];
             pv.x = fmaf(be, pv.x, rv.x); pv.y = fmaf(be, pv.y, rv.y); pv.z = fmaf(be, pv.z, rv.z); pv.w = fmaf(be, pv.w, rv.w);
             p[i] = pv;
+        }
+    }
+}
+
+// fp32 multi-shift update (solvers.hip ms_update_all on float4 = two elements): base system x += alpha p (optional), p = r + beta p, and
+// every active shift x_j += a_j p_j ; p_j = b_j p_j + z_j r in one pass; frozen shifts cost nothing
+__global__ __launch_bounds__(MB) void ms32_update_all(const double* __restrict__ sc, const double* __restrict__ ms, float4* const* __restrict__ ptr,
+                                                       float4* __restrict__ x0, float4* __restrict__ p0, const float4* __restrict__ r, size_t n4, int ns) {
+    if (sc[S_XDONE] != 0.0) return;
+    const float al = (float)sc[S_ALPHA], be = (float)sc[S_BETA];
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
+        const float4 rv = r[i];
+        {
+            float4 pv = p0[i];
+            if (x0) {
+                float4 xv = x0[i];
+                xv.x = fmaf(al, pv.x, xv.x); xv.y = fmaf(al, pv.y, xv.y); xv.z = fmaf(al, pv.z, xv.z); xv.w = fmaf(al, pv.w, xv.w);
+                x0[i] = xv;
+            }
+            pv.x = fmaf(be, pv.x, rv.x); pv.y = fmaf(be, pv.y, rv.y); pv.z = fmaf(be, pv.z, rv.z); pv.w = fmaf(be, pv.w, rv.w);
+            p0[i] = pv;
+        }
+        for (int j = 0; j < ns; j++) {
+            const double ad = ms[3 * ns + j], bd = ms[4 * ns + j], zd = ms[5 * ns + j];
+            if (ad == 0.0 && bd == 0.0 && zd == 0.0) continue;       // frozen shift
+            const float a = (float)ad, bb = (float)bd, z = (float)zd;
+            float4* __restrict__ x = ptr[j];
+            float4* __restrict__ p = ptr[ns + j];
+            float4 pv = p[i], xv = x[i];
+            xv.x = fmaf(a, pv.x, xv.x); xv.y = fmaf(a, pv.y, xv.y); xv.z = fmaf(a, pv.z, xv.z); xv.w = fmaf(a, pv.w, xv.w);
+            pv.x = fmaf(bb, pv.x, z * rv.x); pv.y = fmaf(bb, pv.y, z * rv.y); pv.z = fmaf(bb, pv.z, z * rv.z); pv.w = fmaf(bb, pv.w, z * rv.w);
+            x[i] = xv; p[i] = pv;
         }
     }
 }
@@ -190,39 +223,28 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
     return LQCD_OK;
 }
 
-}  // namespace lqcd
+// the fp32 build of the stencil has the site-per-lane and the direction-split kernels: the variant is pinned for the duration of a
+// mixed-precision solve (the fp64 applications of the outer loop are bit-identical across the split variants)
+struct VariantPin {
+    lqcd_ctx_s* c; int saved;
+    explicit VariantPin(lqcd_ctx_s* c_) : c(c_), saved(c_->tun.dslash_variant) { if (saved >= 2) c->tun.dslash_variant = 1; }
+    ~VariantPin() { c->tun.dslash_variant = saved; }
+};
 
-using namespace lqcd;
-
-// Mixed-precision CG for D^+D x = b.  x holds the initial guess.  eps: absolute bound on the TRUE squared residual (the
-// reference's rule real(r.r) < eps, evaluated in fp64); inner_tol: relative residual norm requested from each fp32 solve
-// (<= 0 selects 1e-4).  iters = total fp32 iterations (+ fp64 iterations of the fall-back, if it ran); outer = defect-correction steps.
-extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
-                                         int* outer, double* final_rr) {
-    ARGCHK(op && x && b && x->ctx == op->ctx && b->ctx == op->ctx && x->kind == op->kind && b->kind == op->kind && x->subset == LQCD_FULL &&
-               b->subset == LQCD_FULL && x != b && maxiter >= 0,
-           "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
+// fp32 copies of the operator's links (18 reals, and 12 reals under the fp64 path's rule) and clover blocks, and the four fp32 work
+// vectors, shared by the mixed-precision CG and the mixed-precision multi-shift CG.  The link copies follow the field
+// (handle, version): a sequence of solves on the same links converts once.
+static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
     lqcd_ctx_s* c = op->ctx;
     const bool clov = op->csw != 0.0 && op->clover != nullptr;
-    HIPCHK(hipSetDevice(c->device));
-    if (inner_tol <= 0.0) inner_tol = 1e-4;
-    const size_t n = x->elems, ng = op->gauge->elems;
-    const bool wil = op->kind == LQCD_WILSON;     // Wilson spinors are paired in fp32 (cvt_wilson_to_f32)
-    // the fp32 build of the stencil has the site-per-lane and the direction-split kernels: pin the variant for this solve (the fp64
-    // applications of the outer loop are bit-identical across the split variants)
-    struct VariantPin {
-        lqcd_ctx_s* c; int saved;
-        explicit VariantPin(lqcd_ctx_s* c_) : c(c_), saved(c_->tun.dslash_variant) { if (saved >= 2) c->tun.dslash_variant = 1; }
-        ~VariantPin() { c->tun.dslash_variant = saved; }
-    } pin(c);
     if (clov && !(op->r == 1.0 && c->tun.dslash_variant == 1)) {
-        set_error("lqcd_solve_mixed_cg_DdagD: the Wilson-clover operator needs the direction-split kernel (r = 1, dslash_variant = 1) in the fp32 inner solver");
+        set_error("mixed-precision solvers: the Wilson-clover operator needs the direction-split kernel (r = 1, dslash_variant = 1) in the fp32 inner solver");
         return LQCD_ERR_UNSUPPORTED;
     }
+    const size_t ng = op->gauge->elems;
     LQCHK(mix_alloc(c, 0, ng * sizeof(float2)));
     for (int k = 1; k <= 4; k++) LQCHK(mix_alloc(c, k, n * sizeof(float2)));
     LQCHK(mix_alloc(c, 5, gauge12_elems(c->geom) * sizeof(float2)));
-    Mix32 m;
     m.gauge = (float2*)c->mix_buf[0];
     // 12-real fp32 links only under the rule of the fp64 path: tunable gauge_recon = 12 AND every link of this field version unitary to
     // 1e-14 (gauge_ensure_recon12).  For anything else (non-unitary test fields, smeared links) the inner operator reads the 18-real
@@ -236,6 +258,124 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     }
     m.x = (float2*)c->mix_buf[1]; m.r = (float2*)c->mix_buf[2]; m.p = (float2*)c->mix_buf[3]; m.t = (float2*)c->mix_buf[4];
     m.blk = n / 2;
+    const bool links_cached = c->mix_gauge_of == (const void*)op->gauge && c->mix_gauge_version == op->gauge->version &&
+                              (!use12 || c->mix_gauge12_valid);
+    if (!links_cached) hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
+    if (clov) {     // fp32 copy of the packed clover blocks (same layout); A follows the links first
+        if (op->clover_version != op->gauge->version) {
+            LQCHK(clover_build(c, op->gauge, op->clover, op->km, op->csw));
+            op->clover_version = op->gauge->version;
+        }
+        const size_t nc = clover_elems(c->geom);
+        hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, m.clover, op->clover, nc, 1.0);
+    }
+    if (!links_cached && use12)
+        hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
+    if (!links_cached) {
+        c->mix_gauge_of = (const void*)op->gauge;
+        c->mix_gauge_version = op->gauge->version;
+        c->mix_gauge12_valid = use12;
+    }
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+// fp64 -> fp32 (scaled) and y (fp64) += a * x (fp32) in the layout of the field kind (Wilson: component pairs)
+static int to_f32(lqcd_ctx_s* c, bool wil, float2* dst, const double2* src, size_t n, double scale) {
+    if (wil) hipLaunchKernelGGL(cvt_wilson_to_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, (float4*)dst, src, n / 2, scale);
+    else hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, dst, src, n, scale);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+static int add_from_f32(lqcd_ctx_s* c, bool wil, double2* y, const float2* x, double a, size_t n) {
+    if (wil) hipLaunchKernelGGL(axpy_from_wilson_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, y, (const float4*)x, a, n / 2);
+    else hipLaunchKernelGGL(axpy_from_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, y, x, a, n);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
+// fp32 multi-shift CG: (A + sigma_j) e_j = rhs, j < ns, and A e = rhs if xbase is given; rhs in m.r with |rhs|^2 = 1, zero guesses.
+// The loop of inner_cg32 with the zeta recurrences (solvers.hip ms_zeta, double precision scalars) and one fused update pass.  A shift
+// is frozen once zeta_j^2 |r|^2 < eps2; without xbase the solve ends when every shift is frozen, with it when |r|^2 < eps2.
+static int inner_ms32(lqcd_op_s* op, const Mix32& m, float2* xbase, const std::vector<float2*>& xj, const std::vector<float2*>& pj,
+                      const double* sigma, int ns, char* d_blk, size_t n, double eps2, int maxiter, int* iters, double* rr_out) {
+    lqcd_ctx_s* c = op->ctx;
+    const size_t bytes = n * sizeof(float2), ms_doubles = 6 * (size_t)ns + 2;
+    double* d_ms = (double*)d_blk;
+    float4** d_ptr = (float4**)(d_blk + ms_doubles * sizeof(double));
+    if (xbase) HIPCHK(hipMemsetAsync(xbase, 0, bytes, c->stream));
+    HIPCHK(hipMemcpyAsync(m.p, m.r, bytes, hipMemcpyDeviceToDevice, c->stream));
+    std::vector<double> hms(ms_doubles, 1.0);    // zeta_{-1} = zeta_0 = 1, alpha_{-1} = 1
+    std::vector<float4*> hptr(2 * (size_t)ns);
+    for (int j = 0; j < ns; j++) {
+        HIPCHK(hipMemsetAsync(xj[j], 0, bytes, c->stream));
+        HIPCHK(hipMemcpyAsync(pj[j], m.r, bytes, hipMemcpyDeviceToDevice, c->stream));
+        hms[j] = sigma[j];
+        hptr[j] = (float4*)xj[j];
+        hptr[ns + j] = (float4*)pj[j];
+    }
+    hms[6 * (size_t)ns + 1] = 0.0;               // beta_{-1} = 0
+    HIPCHK(hipMemcpyAsync(d_ms, hms.data(), ms_doubles * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (ns) HIPCHK(hipMemcpyAsync(d_ptr, hptr.data(), 2 * (size_t)ns * sizeof(float4*), hipMemcpyHostToDevice, c->stream));
+    double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
+    HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));     // hms / hptr are stack-owned host buffers
+    const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n / 2), check_every = 8;
+    int it = 0;
+    double rr = 1.0;
+    bool done = false;
+    while (!done && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        for (int k = 0; k < burst; k++) {
+            apply_bc(c, op->bc);
+            StencilCall s1 = call32(op, m, m.t, m.p, 0);
+            s1.norm_partial = c->d_partial;
+            s1.skip_flag = c->d_scal;
+            LQCHK(stencil_apply(c, s1));
+            LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, 1));
+            StencilCall s2 = call32(op, m, m.t, m.t, 1);
+            s2.norm_partial = c->d_partial;
+            s2.upd_scal = c->d_scal;
+            s2.upd[0] = (double2*)m.r;
+            s2.upd[1] = (double2*)(m.r + m.blk);
+            LQCHK(stencil_apply(c, s2));
+            LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
+            if (ns) LQCHK(ms_zeta_launch(c, d_ms, ns, xbase ? 0 : 1));
+            hipLaunchKernelGGL(ms32_update_all, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, d_ms, d_ptr, (float4*)xbase, (float4*)m.p,
+                               (const float4*)m.r, n / 2, ns);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rr = c->h_scal[0];
+        it = (int)c->h_scal[S_ITERS - S_RR];
+        done = c->h_scal[S_DONE - S_RR] != 0.0;
+        if (!std::isfinite(rr)) break;
+    }
+    *iters = it;
+    *rr_out = rr;
+    return LQCD_OK;
+}
+
+}  // namespace lqcd
+
+using namespace lqcd;
+
+// Mixed-precision CG for D^+D x = b.  x holds the initial guess.  eps: absolute bound on the TRUE squared residual (the
+// reference's rule real(r.r) < eps, evaluated in fp64); inner_tol: relative residual norm requested from each fp32 solve
+// (<= 0 selects 1e-4).  iters = total fp32 iterations (+ fp64 iterations of the fall-back, if it ran); outer = defect-correction steps.
+extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
+                                         int* outer, double* final_rr) {
+    ARGCHK(op && x && b && x->ctx == op->ctx && b->ctx == op->ctx && x->kind == op->kind && b->kind == op->kind && x->subset == LQCD_FULL &&
+               b->subset == LQCD_FULL && x != b && maxiter >= 0,
+           "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (inner_tol <= 0.0) inner_tol = 1e-4;
+    const size_t n = x->elems;
+    const bool wil = op->kind == LQCD_WILSON;     // Wilson spinors are paired in fp32 (cvt_wilson_to_f32)
+    VariantPin pin(c);
+    Mix32 m;
+    LQCHK(mix_prepare(op, n, m));
     lqcd_spinor_s* r = scratch_get(c, x->kind, LQCD_FULL);
     lqcd_spinor_s* q = scratch_get(c, x->kind, LQCD_FULL);
     lqcd_spinor_s* t = scratch_get(c, x->kind, LQCD_FULL);
@@ -247,7 +387,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
         LQCHK(op_apply_async(op, t, x, 0, nullptr));
         LQCHK(op_apply_async(op, q, t, 1, nullptr));
         const int nb = stream_grid(c, n);
-        hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(MB), 0, c->stream, r->data, b->data, q->data, n, c->d_partial);
+        hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(MB), 0, c->stream, r->data, b->data, q->data, (const double2*)nullptr, 0.0, n, c->d_partial);
         HIPCHK(hipGetLastError());
         LQCHK(reduce_to_slot(c, nb, 1, S_RED0, true, 0));
         HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -256,35 +396,12 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
         return LQCD_OK;
     };
     auto run = [&]() -> int {
-        // the fp32 link copies follow the field (handle, version): a sequence of solves on the same links converts once
-        const bool links_cached = c->mix_gauge_of == (const void*)op->gauge && c->mix_gauge_version == op->gauge->version &&
-                                  (!use12 || c->mix_gauge12_valid);
-        if (!links_cached) hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
-        if (clov) {     // fp32 copy of the packed clover blocks (same layout); A follows the links first
-            if (op->clover_version != op->gauge->version) {
-                LQCHK(clover_build(c, op->gauge, op->clover, op->km, op->csw));
-                op->clover_version = op->gauge->version;
-            }
-            const size_t nc = clover_elems(c->geom);
-            hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, m.clover, op->clover, nc, 1.0);
-        }
-        if (!links_cached && use12) {
-            hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
-        }
-        if (!links_cached) {
-            c->mix_gauge_of = (const void*)op->gauge;
-            c->mix_gauge_version = op->gauge->version;
-            c->mix_gauge12_valid = use12;
-        }
-        HIPCHK(hipGetLastError());
         LQCHK(true_residual());
         bool fallback = false;
         while (rr >= eps && total < maxiter) {
             if (!std::isfinite(rr)) { set_error("mixed CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
             const double nrm = std::sqrt(rr);
-            if (wil) hipLaunchKernelGGL(cvt_wilson_to_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, (float4*)m.r, r->data, n / 2, 1.0 / nrm);
-            else hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, m.r, r->data, n, 1.0 / nrm);
-            HIPCHK(hipGetLastError());
+            LQCHK(to_f32(c, wil, m.r, r->data, n, 1.0 / nrm));
             // no tighter than needed to reach eps (with a 10x margin), no tighter than fp32 can deliver
             const double eps2 = std::max(inner_tol * inner_tol, 0.1 * eps / rr);
             int it = 0;
@@ -292,9 +409,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
             LQCHK(inner_cg32(op, m, n, eps2, maxiter - total, &it, &rin));
             total += it;
             nout++;
-            if (wil) hipLaunchKernelGGL(axpy_from_wilson_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, x->data, (const float4*)m.x, nrm, n / 2);
-            else hipLaunchKernelGGL(axpy_from_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, x->data, m.x, nrm, n);
-            HIPCHK(hipGetLastError());
+            LQCHK(add_from_f32(c, wil, x->data, m.x, nrm, n));
             const double rr_old = rr;
             LQCHK(true_residual());
             if (!(rr < 0.5 * rr_old)) { fallback = rr >= eps; break; }   // fp32 accuracy exhausted
@@ -316,6 +431,135 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     if (st != LQCD_OK) return st;
     if (!(rr < eps)) {
         set_error("The mixed-precision CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
+}
+
+// Mixed-precision multi-shift CG: (D^+D + sigma_j) xs[j] = b for j < ns and (x0 != NULL) D^+D x0 = b.  Same contract as
+// lqcd_solve_multishift_cg (zero initial guesses, shiftedcg of the RHMC path, README.md:132) with the stopping rule enforced on the TRUE
+// fp64 residual of EVERY system: on return |b - (D^+D + sigma_j) xs[j]|^2 < eps for all j.
+//   phase 1: one fp32 multi-shift CG on b/|b| -- one Krylov space for all shifts, half the bytes per iteration -- to the relative
+//            residual inner_tol (<= 0: 1e-6; or to eps with a 10x margin, whichever is looser) on every system;
+//   phase 2: a multi-shift recurrence cannot be restarted (the shifted residuals stop being collinear), so each system is finished on
+//            its own by fp64 defect correction: r_j = b - (A + sigma_j) x_j in fp64, (A + sigma_j) e = r_j/|r_j| by the fp32 solver
+//            (a one-shift multi-shift CG: the Krylov space of A, stopped when the shifted residual is below its target),
+//            x_j += |r_j| e, until |r_j|^2 < eps.  A correction that fails to halve the residual is redone in fp64.
+// Worth it when the target is loose enough for phase 1 to do most of the work (MD-force tolerances); at 1e-10 relative and tighter
+// the per-shift corrections cost about what the shared Krylov space saved.  iters: fp32 iterations of phase 1 + all
+// corrections (+ fp64 iterations of fall-backs); outer: number of fp32 correction solves; final_rr: the largest true residual.
+extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
+                                              double eps, int maxiter, double inner_tol, int* iters, int* outer, double* final_rr) {
+    ARGCHK(op && b && ns >= 0 && ns <= 1024 && (ns == 0 || (xs && sigma)) && maxiter >= 0,
+           "lqcd_solve_multishift_mixed_cg: null argument or more than 1024 shifts");
+    ARGCHK(b->ctx == op->ctx && b->kind == op->kind && b->subset == LQCD_FULL, "lqcd_solve_multishift_mixed_cg: b must be a FULL spinor of the operator");
+    for (int j = 0; j < ns; j++) {
+        ARGCHK(xs[j] && xs[j]->ctx == op->ctx && xs[j]->kind == op->kind && xs[j]->subset == LQCD_FULL && xs[j] != b,
+               "lqcd_solve_multishift_mixed_cg: xs[j] must be distinct FULL spinors of the operator");
+        ARGCHK(sigma[j] >= 0.0, "lqcd_solve_multishift_mixed_cg: shifts must be non-negative");
+    }
+    if (x0) LQCHK(check_full(op, x0, b, "lqcd_solve_multishift_mixed_cg"));
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (inner_tol <= 0.0) inner_tol = 1e-6;     // about as far as an fp32 recurrence follows the true residual
+    const size_t n = b->elems, bytes64 = n * sizeof(double2);
+    const bool wil = op->kind == LQCD_WILSON;
+    VariantPin pin(c);
+    Mix32 m;
+    LQCHK(mix_prepare(op, n, m));
+    // fp32 pool: x_j, p_j for every shift (+ the base solution), and the coefficient block of the recurrences
+    const size_t ms_bytes = (6 * (size_t)ns + 2) * sizeof(double) + 2 * (size_t)std::max(ns, 1) * sizeof(float4*);
+    LQCHK(mix_alloc(c, 7, (2 * (size_t)ns + 1) * n * sizeof(float2) + ms_bytes + 256));
+    char* pool = (char*)c->mix_buf[7];
+    std::vector<float2*> xj(ns), pj(ns);
+    for (int j = 0; j < ns; j++) { xj[j] = (float2*)pool + (size_t)(2 * j) * n; pj[j] = (float2*)pool + (size_t)(2 * j + 1) * n; }
+    float2* xb32 = (float2*)pool + (size_t)(2 * ns) * n;
+    char* d_blk = pool + (2 * (size_t)ns + 1) * n * sizeof(float2);
+    d_blk += (256 - ((size_t)d_blk & 255)) & 255;
+    ScratchScope sc(c);
+    lqcd_spinor_s* r = sc.get(op->kind, LQCD_FULL);
+    lqcd_spinor_s* q = sc.get(op->kind, LQCD_FULL);
+    lqcd_spinor_s* t = sc.get(op->kind, LQCD_FULL);
+    lqcd_spinor_s* e64 = nullptr;       // fp64 correction of a fall-back (allocated on first use)
+    if (!(r && q && t)) { set_error("lqcd_solve_multishift_mixed_cg: out of device memory"); return LQCD_ERR_HIP; }
+    int total = 0, nout = 0;
+    double worst = 0.0, rr = 0.0;
+    auto true_residual = [&](lqcd_spinor_s* x, double sg) -> int {     // r = b - (D^+D + sg) x, rr = |r|^2 (all ranks)
+        LQCHK(op_apply_async(op, t, x, 0, nullptr));
+        LQCHK(op_apply_async(op, q, t, 1, nullptr));
+        const int nb = stream_grid(c, n);
+        hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(MB), 0, c->stream, r->data, b->data, q->data, (const double2*)x->data, sg, n, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 1, S_RED0, true, 0));
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rr = c->h_scal[0];
+        return LQCD_OK;
+    };
+    auto run = [&]() -> int {
+        double bb = 0.0;
+        LQCHK(blas_norm2(c, b->data, n, &bb, true));
+        if (x0) HIPCHK(hipMemsetAsync(x0->data, 0, bytes64, c->stream));
+        for (int j = 0; j < ns; j++) HIPCHK(hipMemsetAsync(xs[j]->data, 0, bytes64, c->stream));
+        if (!(bb >= eps)) { worst = bb; return LQCD_OK; }            // the zero vectors already satisfy the stopping rule
+        if (!std::isfinite(bb)) { set_error("mixed multi-shift CG: the right-hand side is not finite"); return LQCD_ERR_NOT_CONVERGED; }
+        // ---- phase 1
+        const double nb_ = std::sqrt(bb);
+        LQCHK(to_f32(c, wil, m.r, b->data, n, 1.0 / nb_));
+        int it = 0;
+        double rin = 0;
+        LQCHK(inner_ms32(op, m, x0 ? xb32 : nullptr, xj, pj, sigma, ns, d_blk, n, std::max(inner_tol * inner_tol, 0.1 * eps / bb), maxiter, &it, &rin));
+        total += it;
+        if (x0) LQCHK(add_from_f32(c, wil, x0->data, xb32, nb_, n));
+        for (int j = 0; j < ns; j++) LQCHK(add_from_f32(c, wil, xs[j]->data, xj[j], nb_, n));
+        // ---- phase 2: every system on its own
+        for (int j = (x0 ? -1 : 0); j < ns; j++) {
+            lqcd_spinor_s* x = j < 0 ? x0 : xs[j];
+            const double sg = j < 0 ? 0.0 : sigma[j];
+            LQCHK(true_residual(x, sg));
+            while (rr >= eps && total < maxiter) {
+                if (!std::isfinite(rr)) { set_error("mixed multi-shift CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
+                const double nrm = std::sqrt(rr), rr_old = rr;
+                LQCHK(to_f32(c, wil, m.r, r->data, n, 1.0 / nrm));
+                const double eps2 = std::max(inner_tol * inner_tol, 0.1 * eps / rr);
+                it = 0;
+                const std::vector<float2*> x1(1, xj.empty() ? xb32 : xj[0]), p1(1, pj.empty() ? xb32 : pj[0]);
+                if (j < 0) LQCHK(inner_ms32(op, m, xb32, xj, pj, sigma, 0, d_blk, n, eps2, maxiter - total, &it, &rin));
+                else LQCHK(inner_ms32(op, m, nullptr, x1, p1, &sg, 1, d_blk, n, eps2, maxiter - total, &it, &rin));
+                total += it;
+                nout++;
+                LQCHK(add_from_f32(c, wil, x->data, j < 0 ? xb32 : x1[0], nrm, n));
+                LQCHK(true_residual(x, sg));
+                if (rr < 0.5 * rr_old) continue;
+                if (rr < eps) break;
+                // fp32 accuracy exhausted: the correction (A + sg) e = r in fp64 (zero guess), x += e
+                if (!e64) e64 = sc.get(op->kind, LQCD_FULL);
+                if (!e64) { set_error("lqcd_solve_multishift_mixed_cg: out of device memory"); return LQCD_ERR_HIP; }
+                int it64 = 0;
+                double r64 = 0;
+                lqcd_spinor_s* rhs = q;      // r is overwritten by nothing in the fp64 solver, but keep an own copy of the right-hand side
+                HIPCHK(hipMemcpyAsync(rhs->data, r->data, bytes64, hipMemcpyDeviceToDevice, c->stream));
+                lqcd_spinor_t ex[1] = {e64};
+                const int s64 = j < 0 ? lqcd_solve_multishift_cg(op, e64, nullptr, rhs, nullptr, 0, eps, maxiter - total, &it64, &r64)
+                                      : lqcd_solve_multishift_cg(op, nullptr, ex, rhs, &sg, 1, eps, maxiter - total, &it64, &r64);
+                total += it64;
+                if (s64 != LQCD_OK && s64 != LQCD_ERR_NOT_CONVERGED) return s64;
+                LQCHK(blas_axpy(c, 1.0, 0.0, e64->data, x->data, n));
+                LQCHK(true_residual(x, sg));
+                break;
+            }
+            worst = std::max(worst, rr);
+        }
+        return LQCD_OK;
+    };
+    const int st = run();
+    (void)hipStreamSynchronize(c->stream);
+    if (iters) *iters = total;
+    if (outer) *outer = nout;
+    if (final_rr) *final_rr = worst;
+    if (st != LQCD_OK) return st;
+    if (!(worst < eps)) {
+        set_error("The mixed-precision shifted CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(worst));
         return LQCD_ERR_NOT_CONVERGED;
     }
     return LQCD_OK;

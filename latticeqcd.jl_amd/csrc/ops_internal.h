@@ -25,6 +25,9 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);
 int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);    // applies a pending deferred x update (end of a window that stopped on an even iteration)
 int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0);
 typedef std::function<int(double2* out, const double2* in)> ApplyFn;
+// multi-shift coefficient step (zeta recurrences next to the CG scalars): d_ms = [sigma | zeta_{n-1} | zeta_n | a | b | z] (ns doubles each),
+// alpha_{n-1}, beta_{n-1}; stop_when_frozen raises S_DONE once every shift has converged (no unshifted solution wanted)
+int ms_zeta_launch(lqcd_ctx_s* c, double* d_ms, int ns, int stop_when_frozen);
 
 // scratch fields of one call: returned to the context's pool on every exit path
 struct ScratchScope {

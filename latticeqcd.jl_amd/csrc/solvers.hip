@@ -886,7 +886,12 @@ namespace lqcd {
 // zeta recurrence (Jegerlehner hep-lat/9612014) after the base system's alpha_n, beta_n are known:
 //   zeta_{n+1} = zeta_n zeta_{n-1} alpha_{n-1} / (zeta_{n-1} alpha_{n-1} (1 + alpha_n sigma) + alpha_n beta_{n-1} (zeta_{n-1} - zeta_n))
 //   x_j += (zeta_{n+1}/zeta_n) alpha_n p_j ;  p_j = (zeta_{n+1}/zeta_n)^2 beta_n p_j + zeta_{n+1} r
-__global__ void ms_zeta(const double* __restrict__ sc, double* __restrict__ ms, int ns) {
+// stop_when_frozen: the base system only drives the Krylov space (no unshifted solution is wanted): once every shift is frozen the
+// solve is complete -- S_DONE is raised here, the update kernel behind this launch applies the last x_j steps, later launches are no-ops.
+__global__ void ms_zeta(double* __restrict__ sc, double* __restrict__ ms, int ns, int stop_when_frozen) {
+    __shared__ int active;
+    if (threadIdx.x == 0) active = 0;
+    __syncthreads();
     if (sc[S_XDONE] != 0.0) return;
     const double alpha = sc[S_ALPHA], beta = sc[S_BETA], alpha_m = ms[6 * ns], beta_m = ms[6 * ns + 1];
     for (int j = threadIdx.x; j < ns; j += blockDim.x) {
@@ -908,9 +913,18 @@ __global__ void ms_zeta(const double* __restrict__ sc, double* __restrict__ ms, 
         ms[5 * ns + j] = zp;
         ms[ns + j] = z0;
         ms[2 * ns + j] = zp;
+        active = 1;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { ms[6 * ns] = alpha; ms[6 * ns + 1] = beta; }
+    if (threadIdx.x == 0) {
+        ms[6 * ns] = alpha; ms[6 * ns + 1] = beta;
+        if (stop_when_frozen && !active) sc[S_DONE] = 1.0;
+    }
+}
+int ms_zeta_launch(lqcd_ctx_s* c, double* d_ms, int ns, int stop_when_frozen) {
+    hipLaunchKernelGGL(ms_zeta, dim3(1), dim3(64), 0, c->stream, c->d_scal, d_ms, ns, stop_when_frozen);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
 }
 // base system (x += alpha p ; p = r + beta p) and every active shifted system j (x_j += a_j p_j ; p_j = b_j p_j + z_j r) in one pass:
 // r is read once per element, frozen shifts cost nothing.  x is still updated in the iteration that converges; nothing is touched
@@ -1021,7 +1035,7 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
                 s2.upd[1] = spinor_block(r, 1);
                 LQCHK(stencil_apply(c, s2));
                 LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
-                if (ns) hipLaunchKernelGGL(ms_zeta, dim3(1), dim3(64), 0, c->stream, c->d_scal, d_ms, ns);
+                if (ns) LQCHK(ms_zeta_launch(c, d_ms, ns, 0));
                 hipLaunchKernelGGL(ms_update_all, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase ? xbase->data : (double2*)nullptr, p->data,
                                    r->data, n, ns);
                 HIPCHK(hipGetLastError());

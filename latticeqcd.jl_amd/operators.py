@@ -444,6 +444,22 @@ def shiftedcg(vec_x, vec_beta, x, A, b, eps=None, maxsteps=None, return_info=Fal
     return (it.value, rr.value) if return_info else None
 
 
+def shiftedcg_mixed(vec_x, vec_beta, x, A, b, eps=None, maxsteps=None, inner_tol=0.0, return_info=False):
+    """Mixed-precision shiftedcg (BASELINE configs[4]; no counterpart in the reference, whose shiftedcg is fp64): same arguments and
+    contract as shiftedcg, the stopping rule real(r.r) < eps holds for the TRUE fp64 residual of every shifted system.  One fp32
+    multi-shift CG for all shifts, then fp64 defect correction per shift (lqcd_solve_multishift_mixed_cg).
+    return_info: (fp32 iterations, fp32 correction solves, largest true residual)."""
+    if not isinstance(A, DdagD_operator):
+        raise LQCDError(_l.ERR_ARG, "shiftedcg_mixed needs a DdagD_operator")
+    sig = (C.c_double * len(vec_beta))(*[float(v) for v in vec_beta])
+    it, outer, rr = C.c_int(0), C.c_int(0), C.c_double(0)
+    check(_l.lib().lqcd_solve_multishift_mixed_cg(A.D._h, x._h if x is not None else None, _harr(vec_x), b._h, sig, len(vec_beta),
+                                                  C.c_double(A.eps_CG if eps is None else eps),
+                                                  int(A.MaxCGstep if maxsteps is None else maxsteps), C.c_double(inner_tol),
+                                                  C.byref(it), C.byref(outer), C.byref(rr)))
+    return (it.value, outer.value, rr.value) if return_info else None
+
+
 def apply_inverse_power_(y, A, x, alpha, lam_min, lam_max, tol=1e-10):
     """y = (D'D)^(-alpha) x, 0 < alpha < 1, through ONE multi-shift solve with the partial fractions of rational.py -- the building
     block of the RHMC action and heat bath (README.md:112,132).  [lam_min, lam_max] must enclose the spectrum of D'D

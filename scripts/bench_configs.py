@@ -82,9 +82,17 @@ def main():
     A = lq.DdagD_operator(D)
     dt, (it, rr) = timed(lambda: lq.shiftedcg(xs, sig, x0, A, b, return_info=True))
     dts, (its, rrs) = timed(lambda: (lq.clear_fermion_(x0), lq.solve_DinvX_(x0, A, b, return_info=True))[1])
-    res.append({"config": "16^3x32 staggered multi-shift CG, 10 shifts, mass 0.05 (RHMC solver)", "iters": it, "resid": rr,
-                "ms": 1e3 * dt, "single_cg_iters": its, "single_cg_ms": 1e3 * dts,
-                "cost_vs_10_separate_solves": dt / (10 * dts)})
+    row = {"config": "16^3x32 staggered multi-shift CG, 10 shifts, mass 0.05 (RHMC solver)", "iters": it, "resid": rr,
+           "ms": 1e3 * dt, "single_cg_iters": its, "single_cg_ms": 1e3 * dts,
+           "cost_vs_10_separate_solves": dt / (10 * dts)}
+    # the mixed-precision form (fp32 multi-shift pass + fp64 defect correction per shift) at the same target and at an MD-force target
+    bb = lq.dot(b, b).real
+    for tag, eps in (("mixed_same_target", 1e-16), ("mixed_force_target_rel1e-6", 1e-12 * bb)):
+        dtm, (itm, outm, rrm) = timed(lambda: lq.shiftedcg_mixed(xs, sig, None, A, b, eps=eps, return_info=True))
+        dt64, (it64, rr64) = timed(lambda: lq.shiftedcg(xs, sig, None, A, b, eps=eps, return_info=True))
+        row[tag] = {"eps": eps, "ms": 1e3 * dtm, "fp32_iters": itm, "correction_solves": outm, "worst_true_rr": rrm,
+                    "fp64_ms_same_eps": 1e3 * dt64, "fp64_iters": it64, "speedup": dt64 / dtm}
+    res.append(row)
     for o in (U, D, b, x0, *xs):
         o.close()
     # ---- fermion force sweep at 32^3x64 (Wilson) -- 1536 B/site compulsory

@@ -103,6 +103,78 @@ def test_mixed_cg_under_every_stencil_variant_setting(gpu, orc, variant):
         lat.set_param("dslash_variant", 1)
 
 
+@pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
+@pytest.mark.parametrize("with_base", [True, False])
+def test_mixed_multishift_matches_oracle_and_true_residuals(gpu, orc, kind_name, with_base):
+    """Mixed-precision shiftedcg: one fp32 multi-shift pass, then fp64 defect correction per shift.  Contract of the fp64 solver:
+    every shifted solution equals the oracle's fp64 multi-shift CG to 1e-9 and |b - (D^+D + sigma_j) x_j|^2 < eps, the residual
+    recomputed here with the fp64 operator, independently of the solver."""
+    lq = gpu
+    L = (4, 4, 4, 8)
+    kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
+    okind = orc.WILSON if kind == lq.WILSON else orc.STAGGERED
+    km = KAPPA if kind == lq.WILSON else MASS
+    lat, Uh, Ud, D = _setup(lq, orc, L, kind_name, 151)
+    b_h = orc.gaussian_spinor(lat.fermion_shape(kind), 152)
+    b = lq.Fermionfields(lat, kind).upload(b_h)
+    sig = [0.0, 0.004, 0.06, 0.9, 4.0]
+    xs = [b.similar() for _ in sig]
+    for x in xs:
+        lq.gauss_distribution_fermion_(x, 153)          # zero initial guesses are the solver's business: garbage in the outputs is ignored
+    x0 = b.similar() if with_base else None
+    A = lq.DdagD_operator(D)
+    it, outer, worst = lq.shiftedcg_mixed(xs, sig, x0, A, b, eps=1e-20, return_info=True)
+    assert worst < 1e-20 and outer >= len(sig)           # fp32 cannot reach 1e-20: every system needs at least one correction
+    o0, oxs, oit, oresid, st = orc.multishift_cg(okind, Uh, b_h, L, km, sig, eps=1e-20)
+    assert st == 0
+    if with_base:
+        assert rel_err(x0.download(), o0) < 1e-9
+    r = b.similar()
+    for x, ox, s_ in zip(xs, oxs, sig):
+        assert rel_err(x.download(), ox) < 1e-9
+        lq.mul_(r, A, x)
+        lq.add_fermion_(r, s_, x, -1.0, b)
+        assert lq.dot(r, r).real < 1e-20
+    # a loose target is met by the fp32 pass alone (plus the verification of the true residuals): no correction solves
+    loose = 1e-9 * lq.dot(b, b).real                       # relative residual 3e-5: within reach of the fp32 recurrence
+    it2, outer2, worst2 = lq.shiftedcg_mixed(xs, sig, x0, A, b, eps=loose, return_info=True)
+    assert outer2 == 0 and worst2 < loose and it2 < it
+    # error paths of the fp64 solver
+    with pytest.raises(lq.NotConverged):
+        lq.shiftedcg_mixed(xs, sig, x0, A, b, eps=1e-30, maxsteps=3)
+    with pytest.raises(lq.LQCDError):
+        lq.shiftedcg_mixed(xs[:1], [-1.0], x0, A, b)
+    # zero right-hand side: zero solutions, no iterations
+    z = b.similar()
+    lq.clear_fermion_(z)
+    it3, outer3, worst3 = lq.shiftedcg_mixed(xs[:2], sig[:2], None, A, z, eps=1e-20, return_info=True)
+    assert it3 == 0 and outer3 == 0 and worst3 == 0.0 and np.abs(xs[0].download()).max() == 0.0
+
+
+def test_mixed_multishift_rhmc_poles_and_zeta_underflow(gpu, orc):
+    """The shifts of a real rational approximation (x^(-1/4) on the staggered spectrum: poles over five decades) and shifts large
+    enough to underflow zeta: frozen shifts must neither stall the fp32 pass nor poison the fields."""
+    lq = gpu
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    Uh = orc.hot_gauge(L, 161)
+    Ud = lq.Gaugefields(lat).upload(Uh)
+    m = 0.05
+    D = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Staggered", "mass": m, "boundarycondition": BC, "eps_CG": 1e-18})
+    b_h = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 162)
+    b = lq.Fermionfields(lat, lq.STAGGERED).upload(b_h)
+    a0, res, poles, _ = lq.rational.inverse_power_partial_fractions(0.25, m * m, m * m + 16.0, 1e-9)
+    sig = [float(p_) for p_ in poles] + [3000.0]
+    xs = [b.similar() for _ in sig]
+    A = lq.DdagD_operator(D)
+    it, outer, worst = lq.shiftedcg_mixed(xs, sig, None, A, b, eps=1e-18, return_info=True)
+    _, oxs, oit, _, st = orc.multishift_cg(orc.STAGGERED, Uh, b_h, L, m, sig, bc=BC, eps=1e-18)
+    assert st == 0 and worst < 1e-18
+    for x, ox in zip(xs, oxs):
+        xh = x.download()
+        assert np.isfinite(xh).all() and rel_err(xh, ox) < 1e-8
+
+
 def test_mixed_cg_rccl_self_partition(gpu, orc):
     """fp32 halos (pack / ncclFloat send-recv / exterior from the fp32 stencil build) on the real RCCL path, one GPU."""
     code = textwrap.dedent("""

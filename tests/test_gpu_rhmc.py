@@ -44,8 +44,10 @@ def test_rational_action_and_force_match_oracle(lq, orc, nf):
     assert abs(lq.evaluate_FermiAction(fa, U, phi) / lq.dot(xi, xi).real - 1.0) < 1e-9
 
 
-def test_rational_action_with_per_pole_mixed_precision_solves(lq, orc):
-    """Tunable mixed_action_solver: every pole is a mixed-precision solve with the staggered operator of mass sqrt(m^2 + pole)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_rational_action_with_per_pole_mixed_precision_solves(lq, orc, mode):
+    """Tunable mixed_action_solver = 1: every pole is a mixed-precision solve with the staggered operator of mass sqrt(m^2 + pole);
+    = 2: all poles through the mixed-precision multi-shift CG (one fp32 pass + fp64 defect correction per pole)
     (BASELINE.json configs[4]: RHMC with an fp32 inner / fp64 outer CG); same action and force as the fp64 multi-shift CG."""
     L = (6, 6, 4, 2)          # a partially filled chunk
     lat = lq.Lattice(L)
@@ -59,7 +61,7 @@ def test_rational_action_with_per_pole_mixed_precision_solves(lq, orc):
     S0 = lq.evaluate_FermiAction(fa, U, phi)
     lq.calc_UdSfdU_(G, fa, U, phi)
     G0 = G.download()
-    lat.set_param("mixed_action_solver", 1)
+    lat.set_param("mixed_action_solver", mode)
     S1 = lq.evaluate_FermiAction(fa, U, phi)
     lq.calc_UdSfdU_(G, fa, U, phi)
     lat.set_param("mixed_action_solver", 0)
@@ -70,7 +72,7 @@ def test_rational_action_with_per_pole_mixed_precision_solves(lq, orc):
     # new links in the same handle: the cached fp32 copies must follow
     Uh2 = orc.hot_gauge(L, 833)
     U.upload(Uh2)
-    lat.set_param("mixed_action_solver", 1)
+    lat.set_param("mixed_action_solver", mode)
     S2 = lq.evaluate_FermiAction(fa, U, phi)
     lat.set_param("mixed_action_solver", 0)
     yo2, _ = orc.rational_apply(orc.STAGGERED, Uh2, phih, L, 0.1, a0, res, poles, 1.0, BC)
