@@ -29,7 +29,7 @@ WILSON_FLOP_PER_SITE = 1320
 WILSON_BYTES_PER_SITE = 960    # read psi 192 + 4 links 576 + write 192
 KAPPA = 0.141139
 KERNEL_NAMES = {0: "wilson_interior", 1: "wilson_dirsplit", 2: "wilson_hopsplit", 3: "wilson_hopsplit_persist", 4: "wilson_lanesplit",
-                5: "wilson_dirsplit4", 6: "wilson_dirsplit_lds", 7: "wilson_pair4"}
+                5: "wilson_dirsplit4", 6: "wilson_dirsplit_lds", 7: "wilson_pair4", 8: "wilson_dirsplit_both"}
 
 
 def main():

@@ -195,7 +195,7 @@ static const double2* recon12_links(lqcd_op_s* op) {
     c->tun.recon_active = 0;
     if (c->tun.gauge_recon != 12) return nullptr;
     if (op->kind == LQCD_WILSON && (op->r != 1.0 || (c->tun.dslash_variant != 1 && c->tun.dslash_variant < 4))) return nullptr;   // only the direction-split kernels
-    if (op->kind == LQCD_STAGGERED && !(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 7)) return nullptr;
+    if (op->kind == LQCD_STAGGERED && !(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 8)) return nullptr;
     if (gauge_ensure_recon12(op->gauge) != LQCD_OK || !op->gauge->recon_ok) return nullptr;
     c->tun.recon_active = 1;
     return op->gauge->data12;

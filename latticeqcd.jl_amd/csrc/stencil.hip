@@ -1152,6 +1152,112 @@ __device__ inline void hop_from_regs(cd (&chi0)[3], cd (&chi1)[3], const cd* sp,
     su3_mv<ADJ>(chi1, u, h1);
 }
 
+// ------------------------------------------------------------------------------------------ Wilson, direction-split, both hops in flight
+// Variant 8: variant 1 issues the loads of the forward hop, waits, computes, and only then issues the loads of the backward hop -- the
+// `if (sign != 0)` around each hop is control flow, and the compiler may not move a load across it -- so every wave pays TWO dependent
+// memory round trips.  On an unpartitioned lattice no hop is ever skipped: this variant has no branch in the body, all 36 (t: 24) loads
+// of the direction are issued back to back and the arithmetic follows (same operations in the same order as variant 1: bit-identical
+// results).  More registers live at the peak (both half-sets of operands).
+template <bool R12, bool NT>
+__device__ inline void load_link_any(cd (&u)[9], const real2* __restrict__ U, int Us) {
+#ifdef LQCD_F32
+    if constexpr (R12) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) ld_pair<NT>(u[2 * q], u[2 * q + 1], U + (size_t)q * 128);
+        return;
+    }
+#endif
+    load_link_raw<R12, NT>(u, U, Us);
+}
+template <int MU, bool DAG, bool R12, bool NTB>
+__device__ inline void dirsplit_hops_both(cd (&acc)[12], const KArgs& k, int p, int i) {
+    Nbr n;
+    int c[4];
+    neighbours(k.g, p, i, n, c);
+    const real2* __restrict__ psi = k.in[1 - p];
+    const real2* __restrict__ Uf = R12 ? k.gauge12 + gl12_off(k.g, p, MU, i) : k.gauge + glink_off(k.g, p, MU, i);
+    const real2* __restrict__ Ub = R12 ? k.gauge12 + gl12_off(k.g, 1 - p, MU, n.bwd[MU]) : k.gauge + glink_off(k.g, 1 - p, MU, n.bwd[MU]);
+    const int Us = glink_stride(k.g);
+    constexpr int SF = DAG ? -1 : 1;
+    constexpr int NS = MU == 3 ? 6 : 12;                       // t: only the two rows the projector keeps
+    constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;         // first component of the forward / backward hop's rows
+    constexpr int FB = MU == 3 ? (SF > 0 ? 0 : 6) : 0;
+    cd sf[NS], sb[NS], uf[9], ub[9];
+    load_comps12<FF, NS, false>(sf, psi + sp12_off(n.fwd[MU]));
+    load_link_any<R12, false>(uf, Uf, Us);
+    load_comps12<FB, NS, false>(sb, psi + sp12_off(n.bwd[MU]));
+    load_link_any<R12, NTB>(ub, Ub, Us);
+    cd chi0[3], chi1[3];
+    finish_link<R12>(uf);
+    hop_from_regs<MU, SF, false>(chi0, chi1, sf, uf, n.sf[MU]);
+    reconstruct<MU, SF>(acc, chi0, chi1);
+    finish_link<R12>(ub);
+    hop_from_regs<MU, -SF, true>(chi0, chi1, sb, ub, n.sb[MU]);
+    reconstruct<MU, -SF>(acc, chi0, chi1);
+}
+#ifndef LQCD_V8_OCC
+#ifdef LQCD_F32
+#define LQCD_V8_OCC 3
+#else
+#define LQCD_V8_OCC 2
+#endif
+#endif
+template <bool DAG, bool R12, bool NTB>
+__global__ __launch_bounds__(256, LQCD_V8_OCC) void wilson_dirsplit_both(KArgs k) {
+    __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
+    __shared__ double red[4];
+    if (upd_done(k)) return;
+    const real al_upd = update_alpha(k);
+    int chunk, p;
+    map_block(k, chunk, p);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < k.g.Vh;
+    const int ic = valid ? i : 0;          // no control flow around the loads: lanes past the end work on site 0 and do not store
+    cd acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+    cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    cd rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    if (k.upd_scal) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) rv[cc] = ld(k.upd[p] + sp12_off(ic) + co12(3 * w + cc));
+    }
+    if (k.a != 0.0) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(k.xin[p] + sp12_off(ic) + co12(3 * w + cc));
+    }
+    switch (w) {
+    case 0: dirsplit_hops_both<0, DAG, R12, NTB>(acc, k, p, ic); break;
+    case 1: dirsplit_hops_both<1, DAG, R12, NTB>(acc, k, p, ic); break;
+    case 2: dirsplit_hops_both<2, DAG, R12, NTB>(acc, k, p, ic); break;
+    default: dirsplit_hops_both<3, DAG, R12, NTB>(acc, k, p, ic); break;
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
+    __syncthreads();
+    real nrm = 0.0;
+    if (valid) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const int j = 3 * w + cc;
+            const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
+            cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+            cd v = k.b * s;
+            v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
+            emit_pre(k, p, co12(j) + sp12_off(i), v, nrm, al_upd, rv[cc]);
+        }
+    }
+    if (k.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 template <int MU, bool DAG, bool R12, bool NTB>
 __device__ inline void dslds_body(const KArgs& k, int p, int chunk, int ic, int lane, real2* lds, cd (&own)[3], const cd (&stg)[3], cd (&xv)[3], int w) {
     // ic: the lane's site, clamped to a valid one -- between the staging loads and the barrier there is NO control flow (a branch around
@@ -2026,7 +2132,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
 }
 
 static bool use_dirsplit(lqcd_ctx_s* c, int kind, real r) {   // variants 1/2/3 work on 64-site chunks
-    if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 7)) return false;
+    if (!(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 8)) return false;
     // Wilson: the split kernels use the r = 1 projectors.  On a partitioned lattice a general-r application runs as two r = 1 calls
     // (apply.hip, split_general_r), so the launch geometry (number of |.|^2 partials) is the r = 1 one there for every r.
     return kind == LQCD_STAGGERED || r == 1.0 || c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3];
@@ -2067,6 +2173,14 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         if (s.kind == LQCD_STAGGERED) {
             if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
+        } else if (c->tun.dslash_variant == 8 && !k.clover && !(c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3])) {
+            dim3 grid(k.nblocks), block(256);
+            const bool ntb = (k.nt & 1) != 0;
+#define LQ_V8(D, R) do { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_both<D, R, true>), grid, block, pad, c->stream, k); \
+                         else hipLaunchKernelGGL((wilson_dirsplit_both<D, R, false>), grid, block, pad, c->stream, k); } while (0)
+            if (k.gauge12) { if (s.dagger) LQ_V8(true, true); else LQ_V8(false, true); }
+            else { if (s.dagger) LQ_V8(true, false); else LQ_V8(false, false); }
+#undef LQ_V8
 #ifndef LQCD_F32   // the fp32 build (paired-component fields, see sp12_off) has the direction-split and site-per-lane kernels only;
                    // the mixed-precision solver pins dslash_variant to 0/1 for the duration of a solve (mixed.hip)
         } else if (c->tun.dslash_variant == 7 && !k.clover && k.gauge12 && s.parity_mode == 2) {

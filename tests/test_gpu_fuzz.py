@@ -15,7 +15,7 @@ def _case(seed):
         L = (L[0], L[1], 2, 4)
     bc = tuple(int(rng.choice([-1, 1])) for _ in range(4))
     return dict(L=L, bc=bc, r=float(rng.choice([1.0, 1.0, 0.6])), kappa=float(rng.uniform(0.05, 0.15)), mass=float(rng.uniform(0.05, 1.0)),
-                variant=int(rng.integers(0, 8)), remap=int(rng.integers(0, 3)), nsub=int(rng.choice([8, 16, 32])), ysplit=int(rng.choice([1, 2, 4])),
+                variant=int(rng.integers(0, 9)), remap=int(rng.integers(0, 3)), nsub=int(rng.choice([8, 16, 32])), ysplit=int(rng.choice([1, 2, 4])),
                 block=int(rng.choice([64, 128, 256])), recon=int(rng.choice([18, 12])), dagger=bool(rng.integers(0, 2)), seed=seed)
 
 

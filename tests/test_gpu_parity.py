@@ -138,7 +138,7 @@ def test_wilson_dslash_kernel_variants(gpu, orc, block, remap):
 @pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2), (16, 8, 4, 4), (6, 2, 2, 2)])
 @pytest.mark.parametrize("dagger", [False, True])
 @pytest.mark.parametrize("remap", [0, 1, 2])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_wilson_dirsplit_variant_matches_oracle(gpu, orc, L, dagger, remap, variant):
     """dslash_variant = 1: four waves per 64 sites (one per direction); 2: eight waves (one per hop); LDS combine; 3: persistent hop split;
     4: lane split (four directions in the 16-lane rows of one wave, v_permlane reduce-scatter, no LDS); 5: direction split with 36 KiB of
