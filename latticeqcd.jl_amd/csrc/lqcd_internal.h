@@ -330,6 +330,7 @@ struct Tunables {
                               // into the prologues of the kernels that consume them (3 dependent launches per iteration instead of 5)
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
+    int stag_both = 0;            // 1: staggered split kernel issues the loads of both hops of a direction back to back (unpartitioned lattices)
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule);
                                   // 2: the same, and the rational actions solve all poles with the mixed-precision multi-shift CG
     int gauge_recon = 12;     // 12 (default): the direction-split kernels read 2 rows per link and rebuild the third -- only while every

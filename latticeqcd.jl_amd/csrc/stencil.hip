@@ -1746,7 +1746,10 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
 // spinor loads issued as one burst), the four colour-vector partials are combined through LDS and waves 0..2 write one
 // colour component each.  Same reasoning as wilson_dirsplit: short-lived, phase-aligned waves keep the 2x link and 8x
 // spinor re-use inside the L2 residency time, and the XCD tile sweep of map_block applies to 64-site chunks.
-template <bool R12>
+// BOTH (unpartitioned lattices: no hop is ever skipped): no branch in the body, the loads of the forward AND the backward hop are issued
+// back to back -- one memory round trip per wave instead of two -- and the arithmetic follows in stag_hop's order (bit-identical results).
+// The staggered kernel is light on registers, so unlike the Wilson variant 8 this costs little occupancy.
+template <bool R12, bool BOTH = false, bool NTB = false>
 __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
     __shared__ real2 part[4][3][64];
     __shared__ double red[4];
@@ -1764,6 +1767,41 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
     if (valid && k.a != 0.0 && w < 3) xv = ld(k.xin[p] + sp_off(3, i) + (size_t)w * Vh);
     cd rv = mk(0, 0);
     if (valid && k.upd_scal && w < 3) rv = ld(k.upd[p] + sp_off(3, i) + (size_t)w * Vh);    // CG update mode: the old r is read ahead of the hops
+    if constexpr (BOTH) {
+        const int ic = valid ? i : 0;      // lanes past the end work on site 0 and do not store
+        Nbr n;
+        int c[4];
+        neighbours(k.g, p, ic, n, c);
+        const real2* __restrict__ psi = k.in[1 - p];
+        const int Us = glink_stride(k.g);
+        const real eta = stag_eta(c, w);
+        const int nf = w == 0 ? n.fwd[0] : w == 1 ? n.fwd[1] : w == 2 ? n.fwd[2] : n.fwd[3];
+        const int nb = w == 0 ? n.bwd[0] : w == 1 ? n.bwd[1] : w == 2 ? n.bwd[2] : n.bwd[3];
+        const real sf = w == 0 ? n.sf[0] : w == 1 ? n.sf[1] : w == 2 ? n.sf[2] : n.sf[3];
+        const real sb = w == 0 ? n.sb[0] : w == 1 ? n.sb[1] : w == 2 ? n.sb[2] : n.sb[3];
+        const real2* __restrict__ Uf = R12 ? k.gauge12 + gl12_off(k.g, p, w, ic) : k.gauge + glink_off(k.g, p, w, ic);
+        const real2* __restrict__ Ub = R12 ? k.gauge12 + gl12_off(k.g, 1 - p, w, nb) : k.gauge + glink_off(k.g, 1 - p, w, nb);
+        cd hf[3], hb[3], uf[9], ub[9], chi[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) hf[cc] = ld(psi + sp_off(3, nf) + (size_t)cc * Vh);
+        load_link_any<R12, false>(uf, Uf, Us);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) hb[cc] = ld(psi + sp_off(3, nb) + (size_t)cc * Vh);
+        load_link_any<R12, NTB>(ub, Ub, Us);
+        const real cf = eta * sf, cb = -eta * sb;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) hf[cc] = cf * hf[cc];
+        finish_link<R12>(uf);
+        su3_mv<false>(chi, uf, hf);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) acc[cc] = acc[cc] + chi[cc];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) hb[cc] = cb * hb[cc];
+        finish_link<R12>(ub);
+        su3_mv<true>(chi, ub, hb);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) acc[cc] = acc[cc] + chi[cc];
+    } else
     if (valid) {
         Nbr n;
         int c[4];
@@ -2171,8 +2209,17 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         KArgs k = make_kargs(c, s, 64);
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
         if (s.kind == LQCD_STAGGERED) {
-            if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
-            else hipLaunchKernelGGL((staggered_dirsplit<false>), dim3(k.nblocks), dim3(256), pad, c->stream, k);
+            const bool both = c->tun.stag_both && !(c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3]);
+            const dim3 sg(k.nblocks), sb_(256);
+            if (both) {
+                const bool ntb = (k.nt & 1) != 0;
+                if (k.gauge12) { if (ntb) hipLaunchKernelGGL((staggered_dirsplit<true, true, true>), sg, sb_, pad, c->stream, k);
+                                 else hipLaunchKernelGGL((staggered_dirsplit<true, true, false>), sg, sb_, pad, c->stream, k); }
+                else { if (ntb) hipLaunchKernelGGL((staggered_dirsplit<false, true, true>), sg, sb_, pad, c->stream, k);
+                       else hipLaunchKernelGGL((staggered_dirsplit<false, true, false>), sg, sb_, pad, c->stream, k); }
+            }
+            else if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), sg, sb_, pad, c->stream, k);
+            else hipLaunchKernelGGL((staggered_dirsplit<false>), sg, sb_, pad, c->stream, k);
         } else if (c->tun.dslash_variant == 8 && !k.clover && !(c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3])) {
             dim3 grid(k.nblocks), block(256);
             const bool ntb = (k.nt & 1) != 0;

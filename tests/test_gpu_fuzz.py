@@ -16,7 +16,8 @@ def _case(seed):
     bc = tuple(int(rng.choice([-1, 1])) for _ in range(4))
     return dict(L=L, bc=bc, r=float(rng.choice([1.0, 1.0, 0.6])), kappa=float(rng.uniform(0.05, 0.15)), mass=float(rng.uniform(0.05, 1.0)),
                 variant=int(rng.integers(0, 9)), remap=int(rng.integers(0, 3)), nsub=int(rng.choice([8, 16, 32])), ysplit=int(rng.choice([1, 2, 4])),
-                block=int(rng.choice([64, 128, 256])), recon=int(rng.choice([18, 12])), dagger=bool(rng.integers(0, 2)), seed=seed)
+                block=int(rng.choice([64, 128, 256])), recon=int(rng.choice([18, 12])), dagger=bool(rng.integers(0, 2)), seed=seed,
+                stag_both=int(rng.integers(0, 2)))
 
 
 @pytest.mark.parametrize("seed", list(range(40)))
@@ -26,7 +27,7 @@ def test_random_configuration_matches_oracle(lq, orc, seed):
     L, bc = k["L"], k["bc"]
     lat = lq.Lattice(L)
     for key, val in (("dslash_variant", k["variant"]), ("xcd_remap", k["remap"]), ("xcd_nsub", k["nsub"]), ("xcd_ysplit", k["ysplit"]),
-                     ("dslash_block", k["block"]), ("gauge_recon", k["recon"])):
+                     ("dslash_block", k["block"]), ("gauge_recon", k["recon"]), ("stag_both", k["stag_both"])):
         lat.set_param(key, val)
     Uh = orc.hot_gauge(L, 1000 + seed)
     U = lq.Gaugefields(lat).upload(Uh)
