@@ -400,13 +400,20 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     if (st == LQCD_OK) st = cg_setup(op, x, b, w, fixed ? -1.0 : eps, &rr);
     if (st == LQCD_OK && !fixed && rr < eps) converged = true;
     const int check_every = 8;
+    // Launch-bound lattices (the cg_small regime: <= 1024 stencil workgroups, an iteration is three ~5 us launches): every readback of the
+    // scalar block is a host synchronisation worth about two iterations, an iteration enqueued behind the converging one only three no-op
+    // launches.  There the burst length follows the observed convergence rate -- enough iterations to reach eps by the rate of the last
+    // burst, at most 32 -- instead of a fixed 8.  The returned iterate and count do not depend on the burst length (done-flag protocol).
+    const bool adaptive = !fixed && c->tun.graph == 0 && c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2));
+    int next_burst = check_every, it_prev = 0;
+    double rr_prev = rr;
     // tunable "graph": a burst of check_every iterations is captured once into a hipGraph and replayed -- one launch per
     // burst instead of 5 per iteration.  Pays on launch-bound (small) lattices; single-stream (unpartitioned) contexts only.
     const bool use_graph = c->tun.graph != 0 && !any_partitioned(c);
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     while (st == LQCD_OK && !converged && it < maxiter) {
-        int burst = std::min(check_every, maxiter - it);
+        int burst = std::min(adaptive ? next_burst : check_every, maxiter - it);
         if (fixed && !use_graph) burst = maxiter - it;
         if (use_graph && burst == check_every) {
             if (!gexec) {
@@ -436,6 +443,14 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
         it = (int)c->h_scal[S_ITERS - S_RR];
         if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
         if (!std::isfinite(rr)) { set_error("CG: residual is not finite"); st = LQCD_ERR_NOT_CONVERGED; }
+        if (adaptive && !converged && it > it_prev && rr > 0.0 && rr < rr_prev) {
+            const double per_it = std::log(rr / rr_prev) / (double)(it - it_prev);     // < 0
+            const double need = std::log(eps / rr) / per_it;
+            next_burst = (int)std::min(32.0, std::max(2.0, std::ceil(need)));
+        } else if (adaptive) {
+            next_burst = check_every;
+        }
+        it_prev = it; rr_prev = rr;
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);

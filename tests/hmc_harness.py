@@ -23,14 +23,16 @@ ACTIONS = {
 }
 
 
-def run_stream(lq, action, ntraj, seed, dtau=None, mdsteps=None):
+def run_stream(lq, action, ntraj, seed, dtau=None, mdsteps=None, params=None):
     """Returns dict(plaq = plaquette after every trajectory, dH, accepted) for `ntraj` trajectories from the reference's thermalised
-    fixture of that action."""
+    fixture of that action.  params: library tunables to set on the lattice context (e.g. {"mixed_action_solver": 2})."""
     fixture, op_par, fa_par, dt0, n0, nsw = ACTIONS[action]
     dtau = dt0 if dtau is None else dtau
     mdsteps = n0 if mdsteps is None else mdsteps
     Uh = lq.gauge_io.load_ildg(os.path.join(GOLDEN, fixture), L4)
     lat = lq.Lattice(L4)
+    for key, val in (params or {}).items():
+        lat.set_param(key, val)
     U = lq.Gaugefields(lat).upload(Uh)
     p, G, Uold = lq.Gaugefields(lat), lq.Gaugefields(lat), lq.Gaugefields(lat)
     fa = xi = phi = None

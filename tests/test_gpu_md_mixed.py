@@ -24,3 +24,17 @@ def test_hmc_with_mixed_precision_action_solver(lq, orc):
     h2 = DeviceHMC(lq, U2, KAPPA, BETA, dtau=0.05, mdsteps=20, nsw=10, seed=111)
     h2.update()
     assert abs(h2.dH[0] - h.dH[0]) < 1e-6
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_rhmc_trajectories_with_mixed_precision_pole_solves(lq, orc, mode):
+    """The reference's Nf = 3 staggered RHMC stream (test/test_Nf3.toml) with every pole solved in mixed precision -- mode 1: one
+    mixed-precision CG per pole; mode 2: the mixed-precision multi-shift CG (one fp32 pass for all poles + fp64 defect correction per
+    pole).  The stopping rule holds for the true fp64 residuals, so dH and the plaquettes of the stream are those of the fp64 run."""
+    from hmc_harness import run_stream
+    assert lq.lib.device_count() > 0
+    ref = run_stream(lq, "staggered_nf3", 2, seed=5)
+    mix = run_stream(lq, "staggered_nf3", 2, seed=5, params={"mixed_action_solver": mode})
+    assert np.array_equal(ref["accepted"], mix["accepted"])
+    assert np.abs(ref["dH"] - mix["dH"]).max() < 1e-6
+    assert np.abs(ref["plaq"] - mix["plaq"]).max() < 1e-9
