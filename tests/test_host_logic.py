@@ -152,3 +152,91 @@ def test_bench_control_path_two_processes(lq, tmp_path):
     pattern = bytes((37 * i + 11) % 256 for i in range(256))
     assert ids[0][:256] == pattern and ids[1][:256] == pattern     # both ranks initialised their communicators with rank 0's id
     assert b"pe=1,1,1,2 nranks=2 device=0" in ids[0] and b"device=1" in ids[1]   # one device per local rank
+
+
+# ------------------------------------------------------------------ the Julia binding against the header (no Julia in the image)
+def _split_top(s):
+    """split at top-level commas (parentheses, brackets and braces nest)"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _c_prototypes():
+    import re
+    txt = open(os.path.join(ROOT, "include", "lqcd_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|int64_t|const char\s*\*|void|double)\s+(lqcd_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        ret, name, params = m.group(1).replace(" ", ""), m.group(2), " ".join(m.group(3).split())
+        protos[name] = (ret, [] if params in ("", "void") else _split_top(params))
+    return protos
+
+
+def _julia_ccalls():
+    """every ccall((:sym, LIB), Ret, (types...), args...) of julia/LatticeQCDHIP.jl as (line, sym, ret, [types], [args])"""
+    src = open(os.path.join(ROOT, "julia", "LatticeQCDHIP.jl")).read()
+    calls, pos = [], 0
+    while True:
+        i = src.find("ccall(", pos)
+        if i < 0:
+            break
+        j, depth = i + len("ccall("), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        body = src[i + len("ccall("):j - 1]
+        pos = j
+        line = src.count("\n", 0, i) + 1
+        if src.rfind("\n", 0, i) < src.rfind("#", 0, i) and "\n" not in src[src.rfind("#", 0, i):i]:
+            continue                                   # inside a comment
+        parts = _split_top(body)
+        sym = parts[0].strip("()").split(",")[0].strip().lstrip(":")
+        types = _split_top(parts[2].strip()[1:-1]) if parts[2].strip() != "()" else []
+        calls.append((line, sym, parts[1], [t for t in types if t], parts[3:]))
+    return calls
+
+
+def test_julia_binding_matches_the_c_header():
+    """There is no Julia here, so the binding cannot run; what can be checked statically is that it cannot drift from the C ABI: every
+    ccall of julia/LatticeQCDHIP.jl names a function declared in include/lqcd_hip.h, passes as many argument types as the C prototype
+    has parameters and as many values as types, returns the declared type, and maps every parameter to a Julia type of the same width
+    and kind (handles and arrays -> pointers, int -> Cint, double -> Float64/Cdouble, uint64_t -> UInt64)."""
+    protos = _c_prototypes()
+    calls = _julia_ccalls()
+    assert len(calls) >= 50 and len(protos) >= 80
+    ok_types = {
+        "int": {"Cint"}, "double": {"Float64", "Cdouble"}, "uint64_t": {"UInt64"}, "int64_t": {"Int64"}, "size_t": {"Csize_t"},
+    }
+    used = set()
+    for line, sym, ret, types, args in calls:
+        assert sym in protos, f"julia/LatticeQCDHIP.jl:{line}: {sym} is not declared in include/lqcd_hip.h"
+        cret, params = protos[sym]
+        used.add(sym)
+        assert len(types) == len(params), f"line {line}: {sym} takes {len(params)} parameters, the ccall passes {len(types)} types"
+        assert len(args) == len(types), f"line {line}: {sym}: {len(types)} types but {len(args)} values"
+        want_ret = {"int": "Cint", "constchar*": "Cstring", "int64_t": "Int64", "double": "Float64"}.get(cret)
+        assert want_ret is None or ret.strip() == want_ret, f"line {line}: {sym} returns {cret}, the ccall says {ret}"
+        for k, (ctype, jtype) in enumerate(zip(params, types)):
+            ctype = ctype.replace("const ", "").strip()
+            base = ctype.rsplit(" ", 1)[0].strip() if " " in ctype else ctype
+            is_ptr = "*" in ctype or base.endswith("_t") and base.startswith("lqcd_") or "[" in ctype
+            if is_ptr:
+                assert jtype.startswith(("Ptr{", "Ref{")) or jtype in ("Cstring",), f"line {line}: {sym} argument {k} ({ctype}) -> {jtype}"
+            else:
+                assert jtype in ok_types.get(base, {jtype}), f"line {line}: {sym} argument {k} ({ctype}) -> {jtype}"
+    # the per-direction entry points and the solvers the reference's callers need are all bound
+    for need in ("lqcd_link_exp", "lqcd_link_mul", "lqcd_link_copy", "lqcd_link_add_ta", "lqcd_link_staple", "lqcd_solve_cg_DdagD",
+                 "lqcd_solve_bicgstab", "lqcd_solve_bicg", "lqcd_solve_multishift_cg", "lqcd_solve_multishift_mixed_cg", "lqcd_fermi_action",
+                 "lqcd_calc_UdSfdU", "lqcd_op_apply"):
+        assert need in used, need
