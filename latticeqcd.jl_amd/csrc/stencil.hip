@@ -215,13 +215,27 @@ __device__ inline void map_block(const KArgs& k, int& chunk, int& p) { map_block
 // (SURVEY.md Appendix A).  gamma_4 = diag(1,1,-1,-1).
 // (tables PERM / GK: lqcd_internal.h)
 
+// first term of a complex accumulation chain: the operation sequence of cfma / cfma_conj on a zero accumulator with the leading
+// fma(x, y, 0) written as x * y (the same value up to the sign of an exact zero) -- no register clear, one v_mul instead of v_mov + v_fma
+__device__ inline cd cmul_first(cd a, cd b) {
+    cd t;
+    t.re = a.re * b.re; t.re = fma(-a.im, b.im, t.re);
+    t.im = a.re * b.im; t.im = fma(a.im, b.re, t.im);
+    return t;
+}
+__device__ inline cd cmul_conj_first(cd a, cd b) {
+    cd t;
+    t.re = a.re * b.re; t.re = fma(a.im, b.im, t.re);
+    t.im = a.re * b.im; t.im = fma(-a.im, b.re, t.im);
+    return t;
+}
 template <bool ADJ>
 __device__ inline void su3_mv(cd (&chi)[3], const cd (&u)[9], const cd (&h)[3]) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        cd t = mk(0.0, 0.0);
+        cd t = ADJ ? cmul_conj_first(u[a], h[0]) : cmul_first(u[a * 3], h[0]);
 #pragma unroll
-        for (int b = 0; b < 3; b++) {
+        for (int b = 1; b < 3; b++) {
             if constexpr (ADJ) cfma_conj(t, u[b * 3 + a], h[b]);
             else cfma(t, u[a * 3 + b], h[b]);
         }
@@ -232,6 +246,25 @@ __device__ inline void su3_mv(cd (&chi)[3], const cd (&u)[9], const cd (&h)[3]) 
 __device__ inline void load_link(cd (&u)[9], const real2* __restrict__ U, int Vh) {
 #pragma unroll
     for (int k = 0; k < 9; k++) u[k] = ld(U + (size_t)k * Vh);
+}
+
+// third row of an SU(3) matrix from the first two: u[6+b] = conj(u[b1] u[3+b2] - u[b2] u[3+b1]), one accumulation chain per real part
+// (8 fp64 instructions per element; every 12-real path of this file uses this one function, so the variants agree bit for bit)
+__device__ inline void recon_row2(cd (&u)[9]) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+        const cd a = u[b1], bb = u[3 + b2], c = u[b2], d = u[3 + b1];
+        real wr = a.re * bb.re;
+        wr = fma(-a.im, bb.im, wr);
+        wr = fma(-c.re, d.re, wr);
+        wr = fma(c.im, d.im, wr);
+        real wi = a.re * bb.im;
+        wi = fma(a.im, bb.re, wi);
+        wi = fma(-c.re, d.im, wi);
+        wi = fma(-c.im, d.re, wi);
+        u[6 + b] = mk(wr, -wi);
+    }
 }
 
 // 12-real links: rows 0 and 1 from memory, row 2 = conj(row 0 x row 1)  (exact for SU(3) to rounding)
@@ -253,16 +286,7 @@ __device__ inline void load_link12(cd (&u)[9], const real2* __restrict__ U, bool
         for (int k = 0; k < 6; k++) u[k] = ld(U + (size_t)k * 64);
     }
 #endif
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
-        cd x = mk(0.0, 0.0);
-        cfma(x, u[b1], u[3 + b2]);
-        x.re = -x.re; x.im = -x.im;
-        cd y = mk(0.0, 0.0);
-        cfma(y, u[b2], u[3 + b1]);
-        u[6 + b] = mk(-(x.re + y.re), x.im + y.im);   // conj(u[b1] u[3+b2] - u[b2] u[3+b1])
-    }
+    recon_row2(u);
 }
 
 // spin projection h = rows 0,1 of (1 - S*gamma_mu) psi   (mu = 3: the two non-zero rows, factor 2 included)
@@ -341,6 +365,8 @@ __device__ inline void reconstruct(cd (&acc)[12], const cd (&chi0)[3], const cd 
 }
 
 // one hop, r = 1:  acc += (1 - S gamma_mu) [U or U^+] psi(nb) * sign
+// The boundary sign is +1 for every lane of almost every wave (periodic directions; interior of the antiperiodic one): the twelve
+// multiplications by it are skipped under a wave-uniform test.  x * 1 = x, so the results do not change.
 template <int MU, int S, bool ADJ, bool R12 = false>
 __device__ inline void wilson_hop(cd (&acc)[12], const real2* __restrict__ psi, const real2* __restrict__ U,
                                   int Vh, int Us, real sign, bool nt = false, bool nt_psi = false) {
@@ -348,8 +374,10 @@ __device__ inline void wilson_hop(cd (&acc)[12], const real2* __restrict__ psi, 
     project<MU, S>(h0, h1, psi, Vh, nt_psi);
     if constexpr (R12) load_link12(u, U, nt);
     else { if (nt) load_link_nt(u, U, Us); else load_link(u, U, Us); }
+    if (__builtin_amdgcn_ballot_w64(sign != real(1.0)) != 0) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
+        for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
+    }
     su3_mv<ADJ>(chi0, u, h0);
     su3_mv<ADJ>(chi1, u, h1);
     reconstruct<MU, S>(acc, chi0, chi1);
@@ -1113,18 +1141,7 @@ __device__ inline void load_link_raw(cd (&u)[9], const real2* __restrict__ U, in
 }
 template <bool R12>
 __device__ inline void finish_link(cd (&u)[9]) {      // 12-real links: row 2 = conj(row 0 x row 1), the arithmetic of load_link12
-    if constexpr (R12) {
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-            const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
-            cd x = mk(0.0, 0.0);
-            cfma(x, u[b1], u[3 + b2]);
-            x.re = -x.re; x.im = -x.im;
-            cd y = mk(0.0, 0.0);
-            cfma(y, u[b2], u[3 + b1]);
-            u[6 + b] = mk(-(x.re + y.re), x.im + y.im);
-        }
-    }
+    if constexpr (R12) recon_row2(u);
 }
 __device__ inline void lds_stage_and_barrier(real2 (*nbr)[64], const cd (&stg)[3], int w, int lane) {
     __builtin_amdgcn_sched_barrier(0);     // arithmetic on the loads issued above must not be hoisted in front of the barrier (it would wait for them there)
