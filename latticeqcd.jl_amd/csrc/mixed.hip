@@ -223,11 +223,11 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
     return LQCD_OK;
 }
 
-// the fp32 build of the stencil has the site-per-lane and the direction-split kernels (variants 0, 1, 8): the variant is pinned for the duration of a
+// the fp32 build of the stencil has the site-per-lane and the direction-split kernels (variants 0, 1): the variant is pinned for the duration of a
 // mixed-precision solve (the fp64 applications of the outer loop are bit-identical across the split variants)
 struct VariantPin {
     lqcd_ctx_s* c; int saved;
-    explicit VariantPin(lqcd_ctx_s* c_) : c(c_), saved(c_->tun.dslash_variant) { if (saved >= 2 && saved != 8) c->tun.dslash_variant = 1; }
+    explicit VariantPin(lqcd_ctx_s* c_) : c(c_), saved(c_->tun.dslash_variant) { if (saved >= 2) c->tun.dslash_variant = 1; }
     ~VariantPin() { c->tun.dslash_variant = saved; }
 };
 
