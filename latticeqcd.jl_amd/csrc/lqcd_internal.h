@@ -251,12 +251,15 @@ inline BlockMap make_block_map(const Geom& g, int remap, int nsub_in, int ysplit
     m.remap = remap;
     m.LT = g.L[3];
     const int slice = g.XH * g.L[1] * g.L[2];
-    const int nsub = (nsub_in >= 8 && nsub_in % 8 == 0) ? nsub_in : 8;
+    int nsub = (nsub_in >= 8 && nsub_in % 8 == 0) ? nsub_in : 8;
+    if (slice % TB == 0)
+        while (nsub > 8 && (slice / TB) % nsub != 0) nsub -= 8;      // largest admissible multiple of 8 (stencil.hip make_kargs)
     m.cps = (slice % TB == 0 && (slice / TB) % nsub == 0) ? slice / TB : 0;
     const int plane = g.XH * g.L[1];
     m.cpp = (plane % TB == 0) ? plane / TB : 0;
     m.ysplit = 1;
-    if (ysplit_in > 1 && m.cps > 0 && m.cpp > 0 && m.cpp % ysplit_in == 0 && nsub % ysplit_in == 0 && g.L[2] % (nsub / ysplit_in) == 0) m.ysplit = ysplit_in;
+    for (int ys = ysplit_in; ys > 1; ys--)      // the requested (y,z) split or the largest smaller one the geometry admits (stencil.hip make_kargs)
+        if (m.cps > 0 && m.cpp > 0 && m.cpp % ys == 0 && nsub % ys == 0 && g.L[2] % (nsub / ys) == 0) { m.ysplit = ys; break; }
     m.cpr = m.cps > 0 ? m.cps / nsub : 1;
     m.ty = m.ysplit > 1 ? m.cpp / m.ysplit : 1;
     m.tz = m.cpr / m.ty;

@@ -699,6 +699,10 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.remap = c->tun.xcd_remap;
     const int slice = c->geom.XH * c->geom.L[1] * c->geom.L[2];  // sites per parity per t-slice
     k.nsub = (c->tun.xcd_nsub >= 8 && c->tun.xcd_nsub % 8 == 0) ? c->tun.xcd_nsub : 8;
+    // the requested number of sub-domains per t-slice, or the largest smaller multiple of 8 that divides the chunks of a slice (the local
+    // volume 48 x 24 x 24 x 48 of an 8-way partitioned 48^3 x 96 has 216 = 8 x 27 chunks per slice: 16 becomes 8 and the map stays on)
+    if (slice % TB == 0)
+        while (k.nsub > 8 && (slice / TB) % k.nsub != 0) k.nsub -= 8;
     k.cps = (slice % TB == 0 && (slice / TB) % k.nsub == 0) ? slice / TB : 0;
     const int plane = c->geom.XH * c->geom.L[1];
     k.cpp = (plane % TB == 0) ? plane / TB : 0;
@@ -707,8 +711,10 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.dbg = c->tun.dbg;
 #endif
     k.nt = (c->tun.nt_gauge & 3) | (c->tun.nt_store ? 4 : 0) | ((c->tun.nt_gauge & 4) ? 8 : 0);
-    const int ys = c->tun.xcd_ysplit;
-    if (ys > 1 && k.cps > 0 && k.cpp > 0 && k.cpp % ys == 0 && k.nsub % ys == 0 && c->geom.L[2] % (k.nsub / ys) == 0) k.ysplit = ys;
+    // (y,z) tiling of the sub-domains: the requested split, or the largest smaller one the geometry admits (48^3 x 96: 18 chunks per z-plane,
+    // so 4 becomes 2 -- measured 1.11 -> 1.06 ms for the staggered kernel there, profiles/r02_staggered_map_sweep_48x96.log)
+    for (int ys = c->tun.xcd_ysplit; ys > 1; ys--)
+        if (k.cps > 0 && k.cpp > 0 && k.cpp % ys == 0 && k.nsub % ys == 0 && c->geom.L[2] % (k.nsub / ys) == 0) { k.ysplit = ys; break; }
     k.cpr = k.cps > 0 ? k.cps / k.nsub : 1;
     k.ty = k.ysplit > 1 ? k.cpp / k.ysplit : 1;
     k.tz = k.cpr / k.ty;
