@@ -178,17 +178,19 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     cd cpsi[CLOV ? 12 : 1];
     cd rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
-#ifndef LQCD_UPD_PREFETCH      // fp32 build: the three extra live values spill under its 96-VGPR cap (LQCD_DS_OCC) -- off there (LQCD_UPD_PREFETCH32)
+#ifndef LQCD_UPD_PREFETCH      // fp32 build: fits under its 96-VGPR cap (LQCD_DS_OCC) since the kernel lost a tenth of its instructions (88 VGPRs, no spill)
 #ifdef LQCD_F32
 #ifndef LQCD_UPD_PREFETCH32
-#define LQCD_UPD_PREFETCH32 0
+#define LQCD_UPD_PREFETCH32 1
 #endif
 #define LQCD_UPD_PREFETCH LQCD_UPD_PREFETCH32
 #else
 #define LQCD_UPD_PREFETCH 1
 #endif
 #endif
-    if (LQCD_UPD_PREFETCH && valid && k.upd_scal) {      // CG update mode: the old r is read now, not after the barrier
+    // 1: before the hops (fp64: +12 VGPRs, still 3 waves/SIMD); 2: after the hops, in front of the LDS exchange (no long live range: the
+    // fp32 build under its 96-VGPR cap), the barrier and the LDS round trip then cover the load
+    if (LQCD_UPD_PREFETCH == 1 && valid && k.upd_scal) {      // CG update mode: the old r is read now, not after the barrier
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) rv[cc] = ld(k.upd[p] + sp12_off(i) + co12(3 * w + cc));
     }
@@ -208,6 +210,10 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
         case 2: dirsplit_hops<2, DAG, R12>(acc, k, p, i); break;
         default: dirsplit_hops<3, DAG, R12>(acc, k, p, i); break;
         }
+    }
+    if (LQCD_UPD_PREFETCH == 2 && valid && k.upd_scal) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) rv[cc] = ld(k.upd[p] + sp12_off(i) + co12(3 * w + cc));
     }
 #pragma unroll
     for (int j = 0; j < 12; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
