@@ -113,6 +113,9 @@ int lqcd_gauge_download_wing(lqcd_gauge_t g, double* host, int nwing);
 int lqcd_gauge_unit(lqcd_gauge_t g);                                     /* condition = "cold" (universe.jl:41-49) */
 int lqcd_gauge_hot_start(lqcd_gauge_t g, uint64_t seed);                  /* condition = "hot"; counter-based, keyed by GLOBAL site */
 int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq);                   /* calculate_Plaquette (lqcd.jl:187-193), normalised 1/(6 V NC) */
+/* diagnostic, no reference counterpart: max over all links and elements of |row2 - conj(row0 x row1)| -- the quantity the 12-real link
+ * path (tunable gauge_recon) is gated on (<= 1e-14 on every link); this rank's sub-lattice only */
+int lqcd_gauge_unitarity_deviation(lqcd_gauge_t g, double* maxdev);
 
 /* ---------------------------------------------------------------- fermion fields (Initialize_pseudofermion_fields, universe.jl:107,112) */
 int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, int subset);

@@ -261,6 +261,10 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "dbg")) return &c->tun.dbg;
 #endif
     if (!strcmp(key, "persist_per_cu")) return &c->tun.persist_per_cu;
+    if (!strcmp(key, "dslash_pipe")) return &c->tun.dslash_pipe;
+    if (!strcmp(key, "pipe_per_cu")) return &c->tun.pipe_per_cu;
+    if (!strcmp(key, "pipe_grid")) return &c->tun.pipe_grid;
+    if (!strcmp(key, "pipe_min_chunks")) return &c->tun.pipe_min_chunks;
     return nullptr;
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {

@@ -396,6 +396,13 @@ extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
     return LQCD_OK;
 }
 
+extern "C" int lqcd_gauge_unitarity_deviation(lqcd_gauge_t g, double* maxdev) {
+    ARGCHK(g && maxdev, "lqcd_gauge_unitarity_deviation: null argument");
+    LQCHK(lqcd::gauge_ensure_recon12(g));      // measured by the pass that builds the 12-real copy (once per version of the field)
+    *maxdev = g->recon_dev;
+    return LQCD_OK;
+}
+
 namespace lqcd {
 // device pointer of the parity block p of a spinor (nullptr if the spinor does not hold that parity)
 // 12-real copy of the links: rows 0 and 1; *maxdev receives max |row2 - conj(row0 x row1)| (as the bit pattern of a
@@ -440,6 +447,7 @@ int gauge_ensure_recon12(lqcd_gauge_s* g) {
     double dev;
     memcpy(&dev, &bits, sizeof(dev));
     g->recon_ok = dev <= 1e-14;
+    g->recon_dev = dev;
     g->version12 = g->version;
     return LQCD_OK;
 }

@@ -308,6 +308,12 @@ struct Tunables {
     int cg_fused = 2;         // 0: reference form (c1 = p.q), 1: |Dp|^2 from the stencil, 2: + r-update fused into D^+, x/p updates merged
     int graph = 0;            // capture solver iterations in a hipGraph
     int persist_per_cu = 2;   // variant 3: resident workgroups per CU
+    int dslash_pipe = 0;      // Wilson r = 1, variant 1, large lattices: the persistent, software-pipelined form of the direction-split kernel
+                              // (stencil.hip wilson_dirsplit_pipe); bit-identical Dslash output, |.|^2 partials per persistent workgroup
+    int pipe_per_cu = 0;      // persistent kernel: resident workgroups per CU (0: what the
+                              // kernel's registers / LDS admit -- 3 in the fp64 build, 5 in the fp32 build)
+    int pipe_grid = 0;        // persistent kernel: explicit number of persistent workgroups (rounded down to a multiple of 8; tests), 0 = CUs x pipe_per_cu
+    int pipe_min_chunks = 8;  // the persistent kernel runs only where every persistent workgroup has at least this many chunks to walk
 #ifdef LQCD_ABLATE
     int dbg = 0;              // timing ablations (results are wrong when non-zero); -DLQCD_ABLATE builds only
 #endif
@@ -395,6 +401,7 @@ struct lqcd_gauge_s {
     double2* data12 = nullptr;
     uint64_t version12 = 0;      // version of `data` the copy was made from
     bool recon_ok = false;       // row 2 == conj(row 0 x row 1) to 1e-14 on every link of that version
+    double recon_dev = 0.0;      // max |row 2 - conj(row 0 x row 1)| measured when the copy was made
 };
 
 struct lqcd_spinor_s {
@@ -523,8 +530,14 @@ int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dag
 int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr);
 bool any_partitioned(lqcd_ctx_s* c);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
-int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode);
-int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode);
+int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec = 0, bool clover = false);
+bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, bool clover);   // the persistent kernel runs for this call (large lattices only)
+// the operator's full-lattice applications carry the packed clover blocks into the stencil (make_full_call's rule)
+inline bool op_fused_clover(const lqcd_op_s* op) {
+    return op->csw != 0.0 && op->clover && op->clover_tmp && op->r == 1.0 && op->ctx->tun.dslash_variant == 1 && op->ctx->tun.clover_fused;
+}
+int wilson_pipe_grid(lqcd_ctx_s* c, int nvirt, int prec);
+int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec = 0, bool clover = false);
 
 // BLAS-1 / reductions (blas.hip)
 int blas_dot(lqcd_ctx_s* c, const double2* a, const double2* b, size_t n, double* re, double* im, bool allreduce);

@@ -188,7 +188,7 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
     HIPCHK(hipMemcpyAsync(m.p, m.r, n * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n / 2), check_every = 8;
+    const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 1, op->csw != 0.0 && op->clover != nullptr), nbu = stream_grid(c, n / 2), check_every = 8;
     int it = 0;
     double rr = 1.0;
     bool done = false;
@@ -319,7 +319,7 @@ static int inner_ms32(lqcd_op_s* op, const Mix32& m, float2* xbase, const std::v
     double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));     // hms / hptr are stack-owned host buffers
-    const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n / 2), check_every = 8;
+    const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 1, op->csw != 0.0 && op->clover != nullptr), nbu = stream_grid(c, n / 2), check_every = 8;
     int it = 0;
     double rr = 1.0;
     bool done = false;

@@ -254,6 +254,7 @@ static bool cg_small_ok(lqcd_op_s* op, int nbs) {
     if (any_partitioned(c) || c->has_comm || nbs > 1024) return false;
     const int v = c->tun.dslash_variant;
     if (op->kind == LQCD_WILSON && op->r == 1.0 && (v == 2 || v == 3)) return false;
+    if (wilson_pipe_applies(c, op->kind, op->r, 2, op_fused_clover(op))) return false;    // persistent kernel: few partials, but a large lattice
     return true;
 }
 
@@ -261,7 +262,7 @@ static bool cg_small_ok(lqcd_op_s* op, int nbs) {
 static bool cg_defers_x(lqcd_op_s* op) {
     lqcd_ctx_s* c = op->ctx;
     if (!(c->tun.cg_fused >= 2 && c->tun.cg_defer_x)) return false;
-    return !(c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2)));
+    return !(c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op))));
 }
 int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
@@ -276,7 +277,7 @@ int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
 int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n = x->elems;
-    const int nbs_small = stencil_num_partials(c, op->kind, op->r, 2);
+    const int nbs_small = stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op));
     if (c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, nbs_small)) {
         // small lattices: launch latency is the cost.  Same arithmetic as the fused form below, but the two single-block reductions
         // are folded into the prologues of their consumers -- 3 dependent launches per iteration instead of 5, identical iterates.
@@ -301,7 +302,7 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         // fully fused form: 10 spinor passes per iteration instead of 13, q = D^+ D p is never written
         //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
         //   beta, convergence ; x += alpha p, p = r + beta p
-        const int nbs = stencil_num_partials(c, op->kind, op->r, 2);
+        const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op));
         const bool defer = c->tun.cg_defer_x != 0;
         lqcd_spinor_s* pk = (defer && (w.k & 1)) ? w.q : w.p;        // q = D^+D p is never written in this form: its buffer is the second p
         lqcd_spinor_s* po = (defer && (w.k & 1)) ? w.p : w.q;
@@ -340,7 +341,7 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
     LQCHK(op_apply_async(op, w.tmp, w.p, 0, fuse ? c->d_partial : nullptr));
     int nb;
     if (fuse) {
-        nb = stencil_num_blocks(c, op->kind, op->r, 2);
+        nb = stencil_num_blocks(c, op->kind, op->r, 2, 0, op_fused_clover(op));
         LQCHK(reduce_to_slot(c, nb, 1, S_PQ, true));
         LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
     } else if (c->tun.cg_fused) {
@@ -404,7 +405,7 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     // scalar block is a host synchronisation worth about two iterations, an iteration enqueued behind the converging one only three no-op
     // launches.  There the burst length follows the observed convergence rate -- enough iterations to reach eps by the rate of the last
     // burst, at most 32 -- instead of a fixed 8.  The returned iterate and count do not depend on the burst length (done-flag protocol).
-    const bool adaptive = !fixed && c->tun.graph == 0 && c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2));
+    const bool adaptive = !fixed && c->tun.graph == 0 && c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op)));
     int next_burst = check_every, it_prev = 0;
     double rr_prev = rr;
     // tunable "graph": a burst of check_every iterations is captured once into a hipGraph and replayed -- one launch per
@@ -1034,7 +1035,7 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
         HIPCHK(hipStreamSynchronize(c->stream));
         int it = 0;
         bool converged = rr < eps;
-        const int nbs = stencil_num_partials(c, op->kind, op->r, 2), nbu = stream_grid(c, n), check_every = 8;
+        const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op)), nbu = stream_grid(c, n), check_every = 8;
         while (!converged && it < maxiter) {
             const int burst = std::min(check_every, maxiter - it);
             for (int k = 0; k < burst; k++) {

@@ -246,6 +246,258 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
 }
 
 
+// ------------------------------------------------------------------------------------------ Wilson, direction-split, persistent + software-pipelined
+// The persistent form of variant 1 (tunable dslash_pipe).  Variant 1's workgroup lives ~4 us and spends it in one dependent chain: index arithmetic -> forward-hop loads ->
+// arithmetic -> backward-hop loads -> arithmetic -> LDS -> barrier -> LDS -> store; with every stream L2-hot the kernel still takes 0.27 ms of
+// its 0.36 (profiles/r02_hot_ablations_and_occupancy.log) -- a CU-side floor made of phases that do not overlap at 3 waves/SIMD.
+// Here a workgroup is persistent (3 per CU) and walks the virtual block list b, b + grid, ... of the same XCD-aware map:
+//   * the forward-hop operands of chunk c+1 (and the diagonal term / old r of chunk c) are issued BEFORE the barrier, the LDS combine and the
+//     stores of chunk c, and land in the registers chunk c's partial sums just left -- one of the two dependent memory round trips of a chunk
+//     overlaps the workgroup's synchronisation phase;
+//   * the map and neighbour arithmetic of chunk c+1 runs while the backward-hop loads of chunk c are in flight, most of it on the scalar unit:
+//     the kernel requires t-slices and z-planes made of whole 64-site chunks, so t, z and the y-chunk of a workgroup's sites are wave-uniform,
+//     the z and t neighbours of a chunk are whole chunks (scalar base address, scalar boundary sign) and only the x / y waves do per-lane
+//     index arithmetic (one magic-number division by XH);
+//   * no workgroup launch, kernel-argument load or 100-SGPR argument block between two chunks: the kernel takes a compact argument struct
+//     (PipeArgs), every index into it is static, every load is scalar base + 32-bit lane offset + immediate.
+// No branch around a load (a hop that leaves the rank is multiplied by its sign 0, like variant 8); same operations in the same order as variant 1 per
+// site => bit-identical Dslash output.  The |out|^2 partial of a workgroup is accumulated per lane over its chunks in double precision (one
+// partial per persistent workgroup: stencil_num_blocks).
+struct PipeArgs {
+    const real2* gauge;       // the 18-real field, or the 12-real copy (template R12)
+    real2* dst[2];            // out, or r in update mode (read and written)
+    const real2* in[2];
+    const real2* xin[2];
+    double* norm_partial;
+    const double* upd_scal;   // update mode (see StencilCall)
+    const double* skip;
+    double* scal_w;
+    real a, b;
+    int nt_store;
+    int nvirt, both, pmode;
+    int XH, L1, L2, LT, nch;
+    FastDiv dXH;
+    real sgn_f[4], sgn_b[4];  // sign a hop takes when it wraps the local lattice (0: the neighbour is on another rank)
+    int cps, cpp, cpr, per_pass, ty, tz, ysplit;
+    FastDiv d_perpass, d_cpr, d_ysplit, d_ty, d_cpp;
+};
+
+__device__ inline int fdiv_nb(int n, const FastDiv& f) {      // branch-free form for the scalar unit (s_mul_hi + shift + select)
+    const int q = (int)(__umulhi((unsigned)n, f.m) >> f.sh);
+    return f.d == 1 ? n : q;
+}
+
+// virtual block -> parity, t, z, chunk index inside the z-plane: the arithmetic of map_block_v (remap 2), all on wave-uniform values
+__device__ inline void pipe_map(const PipeArgs& a, int b, int& p, int& t, int& z, int& yc) {
+    const int xcd = b & 7;
+    int j = b >> 3;
+    p = a.both ? (j & 1) : a.pmode;
+    j = a.both ? (j >> 1) : j;
+    const int pass = fdiv_nb(j, a.d_perpass);
+    j -= pass * a.per_pass;
+    t = fdiv_nb(j, a.d_cpr);
+    const int m = j - t * a.cpr, sd = xcd + 8 * pass;
+    const int sz = fdiv_nb(sd, a.d_ysplit), sy = sd - sz * a.ysplit;
+    const int zz = fdiv_nb(m, a.d_ty), yy = m - zz * a.ty;
+    const int s = a.ysplit > 1 ? (sz * a.tz + zz) * a.cpp + sy * a.ty + yy : sd * a.cpr + m;
+    z = fdiv_nb(s, a.d_cpp);
+    yc = s - z * a.cpp;
+}
+
+// one chunk's addressing for the wave of direction MU: byte offsets (32-bit, inside a parity block) of the lane's own site, of its two
+// neighbours and of the two links, and the two boundary signs
+struct PipeSite {
+    unsigned own, nf, nb;      // spinor byte offsets: own site, forward / backward neighbour (other parity)
+    unsigned uf, ub;           // link byte offsets inside the gauge field's parity block
+    real sf, sb;
+    int p;
+};
+template <int MU, int NL>      // NL: 16-byte elements per link (9: 18 reals, 6: 12 reals)
+__device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
+    constexpr unsigned SPC = 12 * 64 * sizeof(real2);       // bytes of a spinor chunk
+    constexpr unsigned LKC = 4 * NL * 64 * sizeof(real2);   // bytes of a gauge chunk (4 directions)
+    constexpr unsigned LKM = NL * 64 * sizeof(real2);       // bytes of one direction inside it
+    PipeSite s;
+    int t, z, yc;
+    pipe_map(a, b, s.p, t, z, yc);
+    const int chunk = t * a.cps + z * a.cpp + yc;
+    s.own = (unsigned)chunk * SPC + (unsigned)lane * 16u;
+    s.uf = (unsigned)chunk * LKC + MU * LKM + (unsigned)lane * 16u;
+    if constexpr (MU >= 2) {      // the neighbour of a chunk is a chunk: everything but the lane term is wave-uniform
+        const int c = MU == 2 ? z : t, Lc = MU == 2 ? a.L2 : a.LT, st = MU == 2 ? a.cpp : a.cps;
+        const bool wf = c == Lc - 1, wb = c == 0;
+        const int cf = wf ? chunk - (Lc - 1) * st : chunk + st;
+        const int cb = wb ? chunk + (Lc - 1) * st : chunk - st;
+        s.nf = (unsigned)cf * SPC + (unsigned)lane * 16u;
+        s.nb = (unsigned)cb * SPC + (unsigned)lane * 16u;
+        s.ub = (unsigned)cb * LKC + MU * LKM + (unsigned)lane * 16u;
+        s.sf = wf ? a.sgn_f[MU] : real(1.0);
+        s.sb = wb ? a.sgn_b[MU] : real(1.0);
+    } else {
+        const int cbp = yc * 64 + lane;               // index inside the z-plane
+        const int y = fdiv(cbp, a.dXH), xh = cbp - y * a.XH;
+        const int i = chunk * 64 + lane;
+        int nf, nb;
+        bool wf, wb;
+        if constexpr (MU == 0) {
+            const int q = (y + z + t + s.p) & 1;      // x = 2 xh + q
+            wf = q && xh == a.XH - 1; wb = !q && xh == 0;
+            nf = q ? (wf ? i - (a.XH - 1) : i + 1) : i;
+            nb = q ? i : (wb ? i + (a.XH - 1) : i - 1);
+        } else {
+            wf = y == a.L1 - 1; wb = y == 0;
+            nf = wf ? i - (a.L1 - 1) * a.XH : i + a.XH;
+            nb = wb ? i + (a.L1 - 1) * a.XH : i - a.XH;
+        }
+        s.nf = (unsigned)(nf >> 6) * SPC + (unsigned)(nf & 63) * 16u;
+        s.nb = (unsigned)(nb >> 6) * SPC + (unsigned)(nb & 63) * 16u;
+        s.ub = (unsigned)(nb >> 6) * LKC + MU * LKM + (unsigned)(nb & 63) * 16u;
+        s.sf = wf ? a.sgn_f[MU] : real(1.0);
+        s.sb = wb ? a.sgn_b[MU] : real(1.0);
+    }
+    return s;
+}
+
+template <typename T>
+__device__ inline const real2* boff(const T* base, unsigned bytes) { return reinterpret_cast<const real2*>(reinterpret_cast<const char*>(base) + bytes); }
+
+// h *= sign, skipped when no lane of the wave has a sign other than 1 (x * 1 = x: same bits either way)
+__device__ inline void pipe_sign(cd (&h0)[3], cd (&h1)[3], real sign) {
+    if (__builtin_amdgcn_ballot_w64(sign != real(1.0)) != 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { h0[c] = sign * h0[c]; h1[c] = sign * h1[c]; }
+    }
+}
+
+template <int MU, bool DAG, bool R12, bool NTB>
+__device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], int lane, real al_upd, double& nrm_acc) {
+    constexpr int SF = DAG ? -1 : 1;
+    constexpr int NS = MU == 3 ? 6 : 12;                       // t: only the two rows the projector keeps
+    constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;         // first component of the forward / backward hop's rows
+    constexpr int FB = MU == 3 ? (SF > 0 ? 0 : 6) : 0;
+    constexpr int NL = R12 ? 6 : 9;
+    const int stride = gridDim.x;
+    const size_t gpar = (size_t)a.nch * 4 * NL * 64;           // elements of one parity block of the gauge field
+    int vb = blockIdx.x;
+    PipeSite s = pipe_site<MU, NL>(a, vb, lane);
+    cd sF[NS], uF[9];
+    load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
+    load_link_any<R12, false>(uF, boff(a.gauge + (s.p ? gpar : 0), s.uf), 64);
+    for (;;) {
+        cd acc[12], chi0[3], chi1[3], h0[3], h1[3];
+#pragma unroll
+        for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+        // forward hop: its operands were issued one stage ago (prologue, or in front of the previous chunk's barrier)
+        finish_link<R12>(uF);
+        project_regs<MU, SF>(h0, h1, sF);
+        pipe_sign(h0, h1, s.sf);
+        su3_mv<false>(chi0, uF, h0);
+        su3_mv<false>(chi1, uF, h1);
+        reconstruct<MU, SF>(acc, chi0, chi1);
+        __builtin_amdgcn_sched_barrier(0);
+        // backward hop's operands, into the registers the forward operands occupied
+        cd sB[NS], uB[9];
+        load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
+        load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        // while those are in flight: the next chunk's map and neighbour arithmetic (the last chunk computes itself again)
+        const int vbn = vb + stride;
+        const bool more = vbn < a.nvirt;
+        const PipeSite sn = pipe_site<MU, NL>(a, more ? vbn : vb, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        finish_link<R12>(uB);
+        project_regs<MU, -SF>(h0, h1, sB);
+        pipe_sign(h0, h1, s.sb);
+        su3_mv<true>(chi0, uB, h0);
+        su3_mv<true>(chi1, uB, h1);
+        reconstruct<MU, -SF>(acc, chi0, chi1);
+        __builtin_amdgcn_sched_barrier(0);
+        // every wave has consumed the previous chunk's partial sums (its LDS reads fed its stores): the array may be overwritten
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
+        __builtin_amdgcn_sched_barrier(0);
+        // this chunk's diagonal term / old r, then the NEXT chunk's forward operands: all in flight across the barrier and the LDS combine
+        cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+        if (a.upd_scal) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
+        }
+        if (a.a != real(0.0)) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
+        }
+        load_comps12<FF, NS, false>(sF, boff(sn.p ? a.in[0] : a.in[1], sn.nf));
+        load_link_any<R12, false>(uF, boff(a.gauge + (sn.p ? gpar : 0), sn.uf), 64);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS writes done; NO vmcnt wait: the loads above stay in flight
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            real nrm = 0.0;
+            real2* dstp = const_cast<real2*>(boff(s.p ? a.dst[1] : a.dst[0], s.own));
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                const int j = 3 * MU + cc;
+                const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
+                cd sm = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+                cd v = a.b * sm;
+                v = mk(fma(a.a, xv[cc].re, v.re), fma(a.a, xv[cc].im, v.im));
+                if (a.upd_scal) {
+                    cd r = rv[cc];
+                    r.re = fma(-al_upd, v.re, r.re); r.im = fma(-al_upd, v.im, r.im);
+                    nrm = fma(r.re, r.re, nrm); nrm = fma(r.im, r.im, nrm);
+                    st(dstp + co12(j), r);
+                } else {
+                    nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+                    if (a.nt_store) st_nt(dstp + co12(j), v); else st(dstp + co12(j), v);
+                }
+            }
+            nrm_acc += (double)nrm;
+        }
+        if (!more) break;
+        vb = vbn;
+        s = sn;
+    }
+}
+
+#ifndef LQCD_PIPE_OCC
+#ifdef LQCD_F32
+#define LQCD_PIPE_OCC (R12 ? 5 : 4)     // 95 VGPRs with the 12-real links (what the mixed-precision solvers use); the 18-real instance would spill at 96
+#else
+#define LQCD_PIPE_OCC 3
+#endif
+#endif
+template <bool DAG, bool R12, bool NTB>
+__global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeArgs a) {
+    __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
+    __shared__ double red[4];
+    if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) return;
+    real al_upd = real(0);
+    if (a.upd_scal) {
+        if (a.scal_w) {      // folded scalar step (several ranks): see update_alpha
+            const double rr = a.upd_scal[S_RR];
+            const double al = rr / a.upd_scal[S_PQ];
+            if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal_w[S_ALPHA] = al; a.scal_w[S_RROLD] = rr; }
+            al_upd = (real)al;
+        } else al_upd = (real)a.upd_scal[S_ALPHA];
+    }
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    double nrm = 0.0;
+    switch (w) {
+    case 0: pipe_wave<0, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    case 1: pipe_wave<1, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    case 2: pipe_wave<2, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    default: pipe_wave<3, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    }
+    if (a.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ staggered
 template <bool R12 = false>
 __device__ inline void stag_hop(cd (&acc)[3], const real2* __restrict__ psi, const real2* __restrict__ U, int Vh, int Us,
@@ -781,6 +1033,29 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             }
             else if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), sg, sb_, pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), sg, sb_, pad, c->stream, k);
+        } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr)) {
+            PipeArgs a;
+            a.gauge = k.gauge12 ? k.gauge12 : k.gauge;
+            const bool upd = k.upd_scal != nullptr;
+            for (int p = 0; p < 2; p++) { a.dst[p] = upd ? k.upd[p] : k.out[p]; a.in[p] = k.in[p]; a.xin[p] = k.xin[p]; }
+            a.norm_partial = k.norm_partial; a.upd_scal = k.upd_scal; a.skip = k.skip; a.scal_w = k.scal_w;
+            a.a = k.a; a.b = k.b;
+            a.nt_store = (k.nt & 4) != 0;
+            a.nvirt = k.nblocks; a.both = s.parity_mode == 2; a.pmode = s.parity_mode == 2 ? 0 : s.parity_mode;
+            a.XH = k.g.XH; a.L1 = k.g.L[1]; a.L2 = k.g.L[2]; a.LT = k.g.L[3]; a.nch = k.g.nch; a.dXH = k.g.dXH;
+            for (int mu = 0; mu < 4; mu++) {
+                a.sgn_f[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_fwd[mu]);
+                a.sgn_b[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_bwd[mu]);
+            }
+            a.cps = k.cps; a.cpp = k.cpp; a.cpr = k.cpr; a.per_pass = std::max(1, k.cpr * k.g.L[3]); a.ty = k.ty; a.tz = k.tz; a.ysplit = k.ysplit;
+            a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
+            const dim3 pg(wilson_pipe_grid(c, k.nblocks, s.prec)), pb(256);
+            const bool ntb = (k.nt & 1) != 0;
+#define LQ_PIPE(D, R) do { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, true>), pg, pb, 0, c->stream, a); \
+                           else hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, false>), pg, pb, 0, c->stream, a); } while (0)
+            if (k.gauge12) { if (s.dagger) LQ_PIPE(true, true); else LQ_PIPE(false, true); }
+            else { if (s.dagger) LQ_PIPE(true, false); else LQ_PIPE(false, false); }
+#undef LQ_PIPE
 #ifndef LQCD_F32   // opt-in variants 2-8 (stencil_alt.hip): fp64 only -- the fp32 build (paired-component fields) has the direction-split and the
                    // site-per-lane kernels, and the mixed-precision solvers pin dslash_variant to 0/1 for the duration of a solve (mixed.hip)
         } else if (c->tun.dslash_variant >= 2 && launch_wilson_alt(c, s, k, pad)) {
@@ -831,7 +1106,7 @@ static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
         h.sign_bwd[mu] = (c->coord[mu] == 0) ? c->geom.bc_bwd[mu] : 1.0;
     }
     h.norm_partial = s.norm_partial;
-    h.partial_offset = stencil_num_blocks(c, s.kind, s.r, s.parity_mode);   // corrections are appended to the interior's partials
+    h.partial_offset = stencil_num_blocks(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr);   // corrections are appended to the interior's partials
     h.upd_scal = s.upd_scal;
     h.upd[0] = (real2*)s.upd[0]; h.upd[1] = (real2*)s.upd[1];
     return h;
@@ -874,16 +1149,40 @@ int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
 #ifndef LQCD_F32
 // precision-independent launch geometry (shared by both builds of this file)
 // number of |.|^2 block partials the interior kernel writes
-int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
+int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
     const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
     const int nvirt = ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
     if (use_dirsplit(c, kind, r) && kind == LQCD_WILSON && c->tun.dslash_variant == 3) return persist_grid(c, nvirt);
+    if (wilson_pipe_applies(c, kind, r, parity_mode, clover)) return wilson_pipe_grid(c, nvirt, prec);
     return nvirt;
 }
+// variant 9: persistent workgroups, 3 per CU in the fp64 build (151..168 VGPRs, 48 KiB of LDS), 5 in the fp32 build; a multiple of 8 so that
+// virtual block b + k * grid stays on the XCD of block b.  prec = 1: the fp32 build (its callers ask stencil_num_partials with prec = 1 too).
+int wilson_pipe_grid(lqcd_ctx_s* c, int nvirt, int prec) {
+    int g = c->tun.pipe_grid > 0 ? c->tun.pipe_grid : c->num_cu * (c->tun.pipe_per_cu > 0 ? c->tun.pipe_per_cu : (prec ? 5 : 3));
+    g -= g % 8;
+    if (g < 8) g = 8;
+    return std::min(g, nvirt);
+}
+// The persistent form of variant 1 (tunable dslash_pipe): only where a persistent workgroup has at least pipe_min_chunks chunks to walk (below that the
+// tail imbalance eats the gain) and only the r = 1 Wilson operator; a call that carries the packed clover blocks (fused A x epilogue) keeps
+// the plain variant-1 kernel -- `clover` is that property of the call (StencilCall::clover != nullptr; solvers: op_fused_clover).
+bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, bool clover) {
+    if (c->tun.dslash_variant != 1 || !c->tun.dslash_pipe || clover || kind != LQCD_WILSON || !use_dirsplit(c, kind, r)) return false;
+    if (r != 1.0) return false;
+    // t-slices and z-planes of whole chunks (t, z, y-chunk of a workgroup's sites are wave-uniform), the XCD tile map, 32-bit byte offsets
+    // inside a parity block of the largest field (18-real links: 2304 B per site)
+    const Geom& g = c->geom;
+    const int plane = g.XH * g.L[1];
+    if (plane % 64 != 0 || c->tun.xcd_remap != 2 || (size_t)g.nch * 64 * 2304 >= ((size_t)1 << 32)) return false;
+    if ((plane * g.L[2] / 64) % 8 != 0) return false;      // the map needs the chunks of a t-slice to split over the 8 XCDs
+    const int nvirt = ((g.Vh + 63) / 64) * (parity_mode == 2 ? 2 : 1);
+    return nvirt >= std::max(1, c->tun.pipe_min_chunks) * wilson_pipe_grid(c, nvirt, 0);
+}
 // interior block partials + (partitioned lattice) the exterior kernel's correction partials
-int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode) {
+int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
     const int nt = max_face_threads(c, parity_mode);
-    return stencil_num_blocks(c, kind, r, parity_mode) + (nt > 0 ? ((nt + 127) / 128) * 8 : 0);
+    return stencil_num_blocks(c, kind, r, parity_mode, prec, clover) + (nt > 0 ? ((nt + 127) / 128) * 8 : 0);
 }
 #endif
 

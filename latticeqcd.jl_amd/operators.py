@@ -198,6 +198,13 @@ def calculate_Plaquette(U):
     return p.value
 
 
+def unitarity_deviation(U):
+    """max |row2 - conj(row0 x row1)| over all links (the gate of the 12-real link path); diagnostic, no reference counterpart."""
+    d = C.c_double(0)
+    check(_l.lib().lqcd_gauge_unitarity_deviation(U._h, C.byref(d)))
+    return d.value
+
+
 # ------------------------------------------------------------------------------------ fermion fields
 class Fermionfields:
     def __init__(self, lattice, kind, subset=FULL):
