@@ -78,10 +78,13 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * [default]), graph (1: hipGraph replay of CG bursts), gauge_recon (12 [default]: the split kernels read two rows per link and rebuild the
  * third -- applied only while every link of the field is unitary to 1e-14, results within the fp64 Dslash tolerance; 18: all
  * 18 stored reals are always read), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge (bit 0 [default]: the backward = last use of a link is a non-temporal load; bit 1: the forward use too), nt_store (1 [default]:
- * non-temporal output stores), lds_pad_kb, persist_per_cu;
+ * non-temporal output stores), lds_pad_kb, persist_per_cu, dslash_pipe (1: with dslash_variant 1 on large lattices the persistent, software-pipelined form of the
+ * direction-split kernel; pipe_per_cu / pipe_grid / pipe_min_chunks shape its grid), stag_both (1: the staggered split kernel issues the loads of both hops back to back);
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
  * mixed-precision CG; 2: the same, and every rational entry solves all its poles with lqcd_solve_multishift_mixed_cg), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
- * md_remap (1 [default]: the staple sweep follows the stencil's XCD-aware workgroup map), nt_blas (1 [default]: non-temporal loads / stores in the CG update kernels),
+ * md_remap (1 [default]: the staple sweep follows the stencil's XCD-aware workgroup map), md_reunitarize (1 [default]: lqcd_gauge_exp_update projects the updated
+ * links back onto SU(3) in the same pass; 0: the reference's literal update), cg_fold_scalars (1 [default]: several ranks, the scalar steps behind the two all-reduces of a
+ * CG iteration run in the consumers' prologues), nt_blas (1 [default]: non-temporal loads / stores in the CG update kernels),
  * cg_skip_done, cg_defer_x (1 [default]: the fused CG updates x every second iteration with both search directions, p alternating between
  * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates), cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
@@ -246,7 +249,8 @@ int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta);     /* calc
 int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us, double beta, double factor, int fuse); /* the same on an in-process PE grid (tests) */
 int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t G); /* Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131) */
 int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta); /* P_update! (AbstractMD.jl:99-118) fused: P += factor TA(gauge force), the force field is never stored */
-int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U */
+int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U (tunable md_reunitarize: projected back onto SU(3) in the same pass) */
+int lqcd_gauge_reunitarize(lqcd_gauge_t U);                              /* no reference counterpart: every link back onto SU(3) (Gram-Schmidt rows 0,1; row 2 = conj(row0 x row1)); once per trajectory keeps the 12-real Dslash alive under per-direction callers */
 int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed);               /* gauss_distribution!(p) (src/md/standardMD.jl:86); keyed by GLOBAL site */
 int lqcd_momentum_action(lqcd_gauge_t P, double* K);                     /* p.p/2 (standardHMC.jl:49) */
 

@@ -332,6 +332,8 @@ struct Tunables {
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
     int cg_fold_scalars = 1;  // several ranks: the scalar steps behind the two all-reduces of a CG iteration run in the consumers' prologues (no one-thread kernels)
     int nt_blas = 1;          // deferred-x CG update kernels stream their fields with non-temporal loads / stores: 842 -> 868 iter/s at 32^3x64
+    int md_reunitarize = 1;   // lqcd_gauge_exp_update (U_update!) projects the updated links back onto SU(3) in the same pass: rounding alone carries
+                              // max |row2 - conj(row0 x row1)| past the 12-real gate (1e-14) within ~280 link updates; 0 = the reference's literal update
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
     int cg_defer_x = 1;       // fused CG: x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
                               // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates
@@ -362,6 +364,7 @@ struct lqcd_ctx_s {
     double* d_partial = nullptr;  // [MAX_PARTIAL_BLOCKS * 4]
     double* d_scal = nullptr;     // small device scalar block (solver state)
     double* h_scal = nullptr;     // pinned mirror
+    unsigned* pipe_ctr = nullptr; // persistent stencil kernel: 8 per-XCD queue heads + 1 exit counter, 128 B apart; all zero between launches
     // halo buffers (sized for Wilson full-lattice: 2 parities * 6 comps * Fh)
     double2* send_fwd[4] = {}, *send_bwd[4] = {}, *recv_fwd[4] = {}, *recv_bwd[4] = {};
     size_t halo_elems[4] = {};

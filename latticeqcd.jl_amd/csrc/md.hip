@@ -373,6 +373,37 @@ __device__ __forceinline__ void exp_m3(cd (&e)[9], cd (&x)[9], double dt) {     
         for (int k = 0; k < 9; k++) e[k] = mk(((k % 4 == 0) ? 1.0 : 0.0) + inv * t[k].re, inv * t[k].im);
     }
 }
+// Back onto SU(3): rows 0 and 1 by Gram-Schmidt, row 2 = conj(row 0 x row 1) with the arithmetic of the 12-real gate (fields.hip
+// gauge_compress12), so a projected link passes that gate with deviation 0.  For a link that is unitary up to accumulated rounding the
+// change is of the order of that rounding.
+__device__ __forceinline__ void reunitarize_m3(cd (&u)[9]) {
+    double n0 = 0.0;
+#pragma unroll
+    for (int b = 0; b < 3; b++) n0 += u[b].re * u[b].re + u[b].im * u[b].im;
+    const double i0 = 1.0 / sqrt(n0);
+#pragma unroll
+    for (int b = 0; b < 3; b++) u[b] = mk(i0 * u[b].re, i0 * u[b].im);
+    cd d = mk(0.0, 0.0);      // <row0, row1>
+#pragma unroll
+    for (int b = 0; b < 3; b++) cfma_conj(d, u[b], u[3 + b]);
+    double n1 = 0.0;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const cd pr = cmul(d, u[b]);
+        u[3 + b] = mk(u[3 + b].re - pr.re, u[3 + b].im - pr.im);
+        n1 += u[3 + b].re * u[3 + b].re + u[3 + b].im * u[3 + b].im;
+    }
+    const double i1 = 1.0 / sqrt(n1);
+#pragma unroll
+    for (int b = 0; b < 3; b++) u[3 + b] = mk(i1 * u[3 + b].re, i1 * u[3 + b].im);
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+        const cd x = cmul(u[b1], u[3 + b2]) - cmul(u[b2], u[3 + b1]);
+        u[6 + b] = mk(x.re, -x.im);
+    }
+}
+template <bool REUNIT>
 __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* __restrict__ U, double dt, const double2* __restrict__ P) {
     size_t off;
     if (!link_of_thread(g, off)) return;
@@ -382,8 +413,19 @@ __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* _
     exp_m3(e, x, dt);
     load_m3(u, U + off, Gs);
     mm3(t, e, u);
+    if constexpr (REUNIT) reunitarize_m3(t);
 #pragma unroll
     for (int k = 0; k < 9; k++) st(U + off + (size_t)k * Gs, t[k]);
+}
+__global__ __launch_bounds__(256) void link_reunitarize_kernel(Geom g, double2* __restrict__ U) {
+    size_t off;
+    if (!link_of_thread(g, off)) return;
+    const int Gs = glink_stride(g);
+    cd u[9];
+    load_m3(u, U + off, Gs);
+    reunitarize_m3(u);
+#pragma unroll
+    for (int k = 0; k < 9; k++) st(U + off + (size_t)k * Gs, u[k]);
 }
 
 __device__ inline void gauss2(uint64_t k, double& a, double& b) {
@@ -729,7 +771,24 @@ extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) 
     lqcd_ctx_s* c = U->ctx;
     HIPCHK(hipSetDevice(c->device));
     U->version++;
-    hipLaunchKernelGGL(link_exp_update_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data);
+    // md_reunitarize (default): the updated link is projected back onto SU(3) in the same pass.  exp(dt P) U leaves the group only by
+    // rounding, but that rounding accumulates: max |row2 - conj(row0 x row1)| passes 1e-14 after ~280 updates (profiles/r03_unitarity_drift.log),
+    // i.e. inside the FIRST trajectory, and the 12-real Dslash would be lost for the rest of the run.  0 = the reference's literal U_update!.
+    if (c->tun.md_reunitarize) hipLaunchKernelGGL(link_exp_update_kernel<true>, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data);
+    else hipLaunchKernelGGL(link_exp_update_kernel<false>, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+// every link back onto SU(3) (Gram-Schmidt of rows 0, 1; row 2 = conj(row 0 x row 1)): for callers that update links through the
+// single-direction entry points (the reference's own U_update!), once per trajectory keeps the 12-real Dslash path alive
+extern "C" int lqcd_gauge_reunitarize(lqcd_gauge_t U) {
+    ARGCHK(U, "lqcd_gauge_reunitarize: null argument");
+    lqcd_ctx_s* c = U->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    U->version++;
+    hipLaunchKernelGGL(link_reunitarize_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;

@@ -250,7 +250,11 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
 // The persistent form of variant 1 (tunable dslash_pipe).  Variant 1's workgroup lives ~4 us and spends it in one dependent chain: index arithmetic -> forward-hop loads ->
 // arithmetic -> backward-hop loads -> arithmetic -> LDS -> barrier -> LDS -> store; with every stream L2-hot the kernel still takes 0.27 ms of
 // its 0.36 (profiles/r02_hot_ablations_and_occupancy.log) -- a CU-side floor made of phases that do not overlap at 3 waves/SIMD.
-// Here a workgroup is persistent (3 per CU) and walks the virtual block list b, b + grid, ... of the same XCD-aware map:
+// Here a workgroup is persistent (3 per CU) and pulls virtual blocks of the same XCD-aware map IN ORDER from the queue of the XCD it runs on
+// (one device-scope atomic per chunk, issued a chunk ahead; an XCD whose queue is empty helps the next one, so results never depend on
+// placement).  A static walk b, b + grid, ... was measured first (profiles/r03_pipe_static_walk.log): workgroups drift apart, the set in
+// flight on an XCD stops being a contiguous window of the sweep, the L2 hit rate falls from 0.64 to 0.46 and the kernel becomes
+// HBM-bound on 1.6x the traffic.  The in-order queue reproduces what the hardware dispatcher gives variant 1 for free.
 //   * the forward-hop operands of chunk c+1 (and the diagonal term / old r of chunk c) are issued BEFORE the barrier, the LDS combine and the
 //     stores of chunk c, and land in the registers chunk c's partial sums just left -- one of the two dependent memory round trips of a chunk
 //     overlaps the workgroup's synchronisation phase;
@@ -263,6 +267,12 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
 // No branch around a load (a hop that leaves the rank is multiplied by its sign 0, like variant 8); same operations in the same order as variant 1 per
 // site => bit-identical Dslash output.  The |out|^2 partial of a workgroup is accumulated per lane over its chunks in double precision (one
 // partial per persistent workgroup: stencil_num_blocks).
+#ifndef LQCD_PIPE_DEARLY
+#define LQCD_PIPE_DEARLY 0      // 1: the diagonal term / old r of a chunk are issued ahead of its backward-hop operands (live across the hop)
+#endif
+#ifndef LQCD_PIPE_NOPF
+#define LQCD_PIPE_NOPF 0        // 1 (experiment): no prefetch across the barrier
+#endif
 struct PipeArgs {
     const real2* gauge;       // the 18-real field, or the 12-real copy (template R12)
     real2* dst[2];            // out, or r in update mode (read and written)
@@ -280,7 +290,19 @@ struct PipeArgs {
     real sgn_f[4], sgn_b[4];  // sign a hop takes when it wraps the local lattice (0: the neighbour is on another rank)
     int cps, cpp, cpr, per_pass, ty, tz, ysplit;
     FastDiv d_perpass, d_cpr, d_ysplit, d_ty, d_cpp;
+    unsigned* ctr;            // queue heads (ctr[32 q], q = 0..7) and exit counter (ctr[256]); zero at launch, reset by the last workgroup
 };
+
+// next virtual block for this workgroup: from queue q (virtual blocks 8 j + q, j = 0 .. nvirt/8 - 1, handed out in order), moving on to the
+// next queue when one is exhausted; -1 when all eight are.  Called by ONE lane.
+__device__ inline int pipe_fetch(unsigned* ctr, int nper, int& q, int& tries) {
+    while (tries < 8) {
+        const unsigned j = __hip_atomic_fetch_add(ctr + 32 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j < (unsigned)nper) return 8 * (int)j + q;
+        q = (q + 1) & 7; tries++;
+    }
+    return -1;
+}
 
 __device__ inline int fdiv_nb(int n, const FastDiv& f) {      // branch-free form for the scalar unit (s_mul_hi + shift + select)
     const int q = (int)(__umulhi((unsigned)n, f.m) >> f.sh);
@@ -317,12 +339,14 @@ __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
     constexpr unsigned SPC = 12 * 64 * sizeof(real2);       // bytes of a spinor chunk
     constexpr unsigned LKC = 4 * NL * 64 * sizeof(real2);   // bytes of a gauge chunk (4 directions)
     constexpr unsigned LKM = NL * 64 * sizeof(real2);       // bytes of one direction inside it
+    // bytes per lane inside a link component: 16 (fp64 element; fp32 pair of the 12-real copy) or 8 (fp32 element of the 18-real field)
+    constexpr unsigned LKL = (NL == 6 || sizeof(real2) == 16) ? 16u : 8u;
     PipeSite s;
     int t, z, yc;
     pipe_map(a, b, s.p, t, z, yc);
     const int chunk = t * a.cps + z * a.cpp + yc;
     s.own = (unsigned)chunk * SPC + (unsigned)lane * 16u;
-    s.uf = (unsigned)chunk * LKC + MU * LKM + (unsigned)lane * 16u;
+    s.uf = (unsigned)chunk * LKC + MU * LKM + (unsigned)lane * LKL;
     if constexpr (MU >= 2) {      // the neighbour of a chunk is a chunk: everything but the lane term is wave-uniform
         const int c = MU == 2 ? z : t, Lc = MU == 2 ? a.L2 : a.LT, st = MU == 2 ? a.cpp : a.cps;
         const bool wf = c == Lc - 1, wb = c == 0;
@@ -330,7 +354,7 @@ __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
         const int cb = wb ? chunk + (Lc - 1) * st : chunk - st;
         s.nf = (unsigned)cf * SPC + (unsigned)lane * 16u;
         s.nb = (unsigned)cb * SPC + (unsigned)lane * 16u;
-        s.ub = (unsigned)cb * LKC + MU * LKM + (unsigned)lane * 16u;
+        s.ub = (unsigned)cb * LKC + MU * LKM + (unsigned)lane * LKL;
         s.sf = wf ? a.sgn_f[MU] : real(1.0);
         s.sb = wb ? a.sgn_b[MU] : real(1.0);
     } else {
@@ -351,7 +375,7 @@ __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
         }
         s.nf = (unsigned)(nf >> 6) * SPC + (unsigned)(nf & 63) * 16u;
         s.nb = (unsigned)(nb >> 6) * SPC + (unsigned)(nb & 63) * 16u;
-        s.ub = (unsigned)(nb >> 6) * LKC + MU * LKM + (unsigned)(nb & 63) * 16u;
+        s.ub = (unsigned)(nb >> 6) * LKC + MU * LKM + (unsigned)(nb & 63) * LKL;
         s.sf = wf ? a.sgn_f[MU] : real(1.0);
         s.sb = wb ? a.sgn_b[MU] : real(1.0);
     }
@@ -370,15 +394,16 @@ __device__ inline void pipe_sign(cd (&h0)[3], cd (&h1)[3], real sign) {
 }
 
 template <int MU, bool DAG, bool R12, bool NTB>
-__device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], int lane, real al_upd, double& nrm_acc) {
+__device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volatile int* nextvb, int vb, int vbn, int q, int tries, int lane,
+                                 real al_upd, double& nrm_acc) {
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;                       // t: only the two rows the projector keeps
     constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;         // first component of the forward / backward hop's rows
     constexpr int FB = MU == 3 ? (SF > 0 ? 0 : 6) : 0;
     constexpr int NL = R12 ? 6 : 9;
-    const int stride = gridDim.x;
+    const int nper = a.nvirt >> 3;
+    int slot = 2;              // the queue result travels through nextvb[2] / nextvb[3] alternately (a wave may be a barrier interval ahead of a reader)
     const size_t gpar = (size_t)a.nch * 4 * NL * 64;           // elements of one parity block of the gauge field
-    int vb = blockIdx.x;
     PipeSite s = pipe_site<MU, NL>(a, vb, lane);
     cd sF[NS], uF[9];
     load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
@@ -395,13 +420,28 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         su3_mv<false>(chi1, uF, h1);
         reconstruct<MU, SF>(acc, chi0, chi1);
         __builtin_amdgcn_sched_barrier(0);
+        cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+#if LQCD_PIPE_DEARLY
+        if (a.upd_scal) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
+        }
+        if (a.a != real(0.0)) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
+        }
+#endif
         // backward hop's operands, into the registers the forward operands occupied
         cd sB[NS], uB[9];
         load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
         load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        // the chunk after the next: one lane of the x wave pulls it from the queue now (the atomic returns with the loads above)
+        unsigned tick = 0;
+        if constexpr (MU == 0) {
+            if (lane == 0 && tries < 8) tick = __hip_atomic_fetch_add(a.ctr + 32 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // while those are in flight: the next chunk's map and neighbour arithmetic (the last chunk computes itself again)
-        const int vbn = vb + stride;
-        const bool more = vbn < a.nvirt;
+        const bool more = vbn >= 0;
         const PipeSite sn = pipe_site<MU, NL>(a, more ? vbn : vb, lane);
         __builtin_amdgcn_sched_barrier(0);
         finish_link<R12>(uB);
@@ -411,13 +451,23 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         su3_mv<true>(chi1, uB, h1);
         reconstruct<MU, -SF>(acc, chi0, chi1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MU == 0) {
+            if (lane == 0) {
+                int nx = -1;
+                if (tries < 8) {
+                    if (tick < (unsigned)nper) nx = 8 * (int)tick + q;
+                    else { q = (q + 1) & 7; tries++; nx = pipe_fetch(a.ctr, nper, q, tries); }      // queue exhausted: help the next XCD (tail only)
+                }
+                nextvb[slot] = nx;
+            }
+        }
         // every wave has consumed the previous chunk's partial sums (its LDS reads fed its stores): the array may be overwritten
         asm volatile("s_barrier" ::: "memory");
 #pragma unroll
         for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
         __builtin_amdgcn_sched_barrier(0);
         // this chunk's diagonal term / old r, then the NEXT chunk's forward operands: all in flight across the barrier and the LDS combine
-        cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+#if !LQCD_PIPE_DEARLY
         if (a.upd_scal) {
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
@@ -426,8 +476,11 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], int l
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
         }
+#endif
+#if !LQCD_PIPE_NOPF
         load_comps12<FF, NS, false>(sF, boff(sn.p ? a.in[0] : a.in[1], sn.nf));
         load_link_any<R12, false>(uF, boff(a.gauge + (sn.p ? gpar : 0), sn.uf), 64);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS writes done; NO vmcnt wait: the loads above stay in flight
         __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +508,13 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         }
         if (!more) break;
         vb = vbn;
+        vbn = __builtin_amdgcn_readfirstlane(nextvb[slot]);   // written in front of this chunk's first barrier; that slot is next written two chunks on
+        slot ^= 1;
         s = sn;
+#if LQCD_PIPE_NOPF      // experiment: persistent only, the forward operands are issued at the top of the chunk like variant 1
+        load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
+        load_link_any<R12, false>(uF, boff(a.gauge + (s.p ? gpar : 0), s.uf), 64);
+#endif
     }
 }
 
@@ -482,12 +541,32 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
     }
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    __shared__ int nextvb[4];
+    // the queue of the XCD this workgroup runs on (speed only: any value 0..7 gives the same results)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    int q = (int)(xcc & 7u), tries = 0;
+    if (threadIdx.x == 0) {
+        nextvb[0] = pipe_fetch(a.ctr, a.nvirt >> 3, q, tries);
+        nextvb[1] = pipe_fetch(a.ctr, a.nvirt >> 3, q, tries);
+    }
+    __syncthreads();
+    const int vb0 = __builtin_amdgcn_readfirstlane(nextvb[0]), vb1 = __builtin_amdgcn_readfirstlane(nextvb[1]);
     double nrm = 0.0;
-    switch (w) {
-    case 0: pipe_wave<0, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
-    case 1: pipe_wave<1, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
-    case 2: pipe_wave<2, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
-    default: pipe_wave<3, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    if (vb0 >= 0) {
+        switch (w) {
+        case 0: pipe_wave<0, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
+        case 1: pipe_wave<1, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
+        case 2: pipe_wave<2, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
+        default: pipe_wave<3, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
+        }
+    }
+    // this workgroup will not touch the queues again; the last one to say so zeroes them for the next launch (stream order)
+    if (threadIdx.x == 0) {
+        const unsigned d = __hip_atomic_fetch_add(a.ctr + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == gridDim.x - 1) {
+            for (int k = 0; k < 9; k++) __hip_atomic_store(a.ctr + 32 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (a.norm_partial) {
 #pragma unroll
@@ -1048,6 +1127,7 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                 a.sgn_b[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_bwd[mu]);
             }
             a.cps = k.cps; a.cpp = k.cpp; a.cpr = k.cpr; a.per_pass = std::max(1, k.cpr * k.g.L[3]); a.ty = k.ty; a.tz = k.tz; a.ysplit = k.ysplit;
+            a.ctr = c->pipe_ctr;
             a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
             const dim3 pg(wilson_pipe_grid(c, k.nblocks, s.prec)), pb(256);
             const bool ntb = (k.nt & 1) != 0;

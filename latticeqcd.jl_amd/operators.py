@@ -198,6 +198,11 @@ def calculate_Plaquette(U):
     return p.value
 
 
+def reunitarize_(U):
+    """Every link back onto SU(3) (lqcd_gauge_reunitarize; no reference counterpart)."""
+    check(_l.lib().lqcd_gauge_reunitarize(U._h))
+
+
 def unitarity_deviation(U):
     """max |row2 - conj(row0 x row1)| over all links (the gate of the 12-real link path); diagnostic, no reference counterpart."""
     d = C.c_double(0)

@@ -137,8 +137,7 @@ def test_pipe_rccl_self_partition(gpu, orc):
         L, K, BC = (16, 8, 8, 4), 0.141139, (1, 1, 1, -1)
         lat = lq.Lattice(L)
         lat.comm_init(lq.comm_unique_id())
-        lat.set_param("dslash_variant", 1)
-    lat.set_param("dslash_pipe", 1); lat.set_param("pipe_grid", 8); lat.set_param("pipe_min_chunks", 1)
+        lat.set_param("dslash_pipe", 1); lat.set_param("pipe_grid", 8); lat.set_param("pipe_min_chunks", 1)
         U = orc.hot_gauge(L, 111)
         Ud = lq.Gaugefields(lat).upload(U)
         D = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": K, "boundarycondition": BC, "eps_CG": 1e-19})
