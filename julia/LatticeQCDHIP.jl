@@ -1,25 +1,41 @@
 # LatticeQCDHIP.jl -- reference-side binding of liblqcd_hip.so (C ABI: include/lqcd_hip.h).
 #
-# STATUS: written against the documented LatticeDiracOperators.jl 0.6 / Gaugefields.jl 0.7 interface but NEVER EXECUTED:
-# there is no Julia in the build image (SURVEY.md section 0.3).  Everything below the `ccall`s is exercised through the
-# same C ABI by tests/ (Python ctypes).  The file is deliberately thin: every method is one ccall plus error translation.
+# STATUS: written against the interface the reference's own callers use (every generic and every struct-field constraint of
+# src/md/AbstractMD.jl:78-135, src/md/standardMD.jl:5-101, src/updates/standardHMC.jl:1-91, src/system/universe.jl:30-143 is listed in
+# tests/golden/ref_caller_inventory.json and checked against this file by tests/test_host_logic.py) but NEVER EXECUTED: there is no Julia
+# in the build image (SURVEY.md section 0.3).  Everything below the `ccall`s is exercised through the same C ABI by tests/ (Python ctypes).
+# The file is deliberately thin: every method is one ccall plus error translation.
 #
-# What it provides: device-backed field / operator / action types that dispatch EVERY generic the reference's unchanged callers use
-#   src/system/universe.jl:88-138    GaugeAction(U), push!(gauge_action, beta/2, loops), Initialize_pseudofermion_fields(U[1], ...),
-#                                    Dirac_operator(U, x, params), FermiAction(D, Dict)
-#   src/md/AbstractMD.jl:78-135      get_temporary_gaugefields, get_temp, unused!, exptU!, mul!(W, expU, U[mu]), substitute_U!(U[mu], W),
-#                                    calc_dSdUμ!, Traceless_antihermitian_add!(p[mu], ...), calc_UdSfdU!(UdSfdUμ::Vector, fa, U, η), U[1].NC
-#   src/md/standardMD.jl:34-101      initialize_TA_Gaugefields(U), fermi_action._temporary_fermionfields[1], similar,
-#                                    gauss_distribution!(md.p), gauss_sampling_in_action!, sample_pseudofermions!
-#   src/updates/standardHMC.jl:41-91 similar(U), substitute_U!(Uold, U), md.p * md.p, evaluate_GaugeAction, dot(ξ, ξ), evaluate_FermiAction(fa, U, η)
-# and, below them, mul!(y, D, x), mul!(y, D', x), solve_DinvX!, shiftedcg, dot, clear_fermion!, add_fermion!, ... (SURVEY.md 8(a), 8(b)).
-# The per-direction objects U[mu], p[mu] and the temporaries are VIEWS (field, direction slot) into four-direction device fields;
-# tests/test_gpu_reference_callers.py runs the same callers, transliterated line by line, through the same C entry points.
+# How it plugs in.  The reference has no FFI; its seam is multiple dispatch on types of Gaugefields.jl / LatticeDiracOperators.jl.  This
+# module therefore EXTENDS the packages' own generic functions (`import Gaugefields: substitute_U!, ...`) with methods on device-backed
+# types, so that the unchanged callers -- which call Gaugefields.substitute_U!, LatticeDiracOperators.calc_UdSfdU!, ... -- land here:
+#
+#   U, Uold, dSdU :: Vector{HIPLink}     four views (one per direction) of ONE device field; HIPLink <: AbstractGaugefields{3,4}, so
+#                                        `U::Vector{TG}`, `Uold::Vector{TG}` (universe.jl:12, standardHMC.jl:3) hold with TG = HIPLink and
+#                                        the package's own GaugeAction(U) builds a GaugeAction{4,HIPLink} (standardMD.jl:6,23)
+#   p             :: Vector{HIPTALink}   the same for the momenta (`p::Vector{TA}`, standardMD.jl:10)
+#   temporaries   :: HIPLink             similar(U[1]) -- the package's Temporalfields pool (get_temp / unused!) works unchanged on them
+#   x, η, ξ       :: HIPFermion          D :: HIPDirac, fermi_action :: HIPFermiAction
+#
+# The ONE edit in the reference: `Univ` (src/system/universe.jl:41-49) creates the links with Initialize_HIPGaugefields(NC, Nwing, L...;
+# condition = p.initial) instead of Initialize_Gaugefields (that function has no argument to dispatch on).  Nothing else changes
+# (INTEGRATION.md section 3).
 module LatticeQCDHIP
 
 using LinearAlgebra
+using Gaugefields
+using LatticeDiracOperators
 import LinearAlgebra: mul!, dot
-import Base: similar, adjoint, getindex, length, push!
+import Base: similar, adjoint
+import Gaugefields: AbstractGaugefields, GaugeAction, substitute_U!, exptU!, Traceless_antihermitian_add!, calc_dSdUμ!,
+    evaluate_GaugeAction, initialize_TA_Gaugefields, gauss_distribution!, calc_smearedU, println_verbose_level1,
+    println_verbose_level2, println_verbose_level3, get_myrank, calculate_Plaquette, load_BridgeText!, load_gaugefield!
+import LatticeDiracOperators: Dirac_operator, DdagD_operator, FermiAction, Initialize_pseudofermion_fields,
+    gauss_sampling_in_action!, sample_pseudofermions!, evaluate_FermiAction, calc_UdSfdU!, solve_DinvX!, shiftedcg,
+    clear_fermion!, substitute_fermion!, add_fermion!, gauss_distribution_fermion!, Z4_distribution_fermi!,
+    AbstractFermionfields_4D
+
+export Initialize_HIPGaugefields, HIPLattice, HIPLink, HIPTALink, HIPFermion, HIPDirac, HIPFermiAction, reunitarize!
 
 const LIB = get(ENV, "LQCD_HIP_LIB", joinpath(@__DIR__, "..", "latticeqcd.jl_amd", "csrc", "liblqcd_hip.so"))
 
@@ -28,6 +44,7 @@ const LQCD_ERR_NOT_CONVERGED = Cint(3)
 const WILSON, STAGGERED = Cint(0), Cint(1)
 const FULL, EVEN, ODD = Cint(0), Cint(1), Cint(2)
 const LAYOUT_REFERENCE = Cint(0)
+const VERBOSE_LEVEL = Ref(2)          # println_verbose_level2/3(U[1], ...) print at or above this level (Univ: p.verboselevel)
 
 last_error() = unsafe_string(ccall((:lqcd_last_error, LIB), Cstring, ()))
 function check(st::Cint)
@@ -58,132 +75,188 @@ function comm_unique_id()
 end
 comm_init!(lat::HIPLattice, id::Vector{UInt8}) =
     check(ccall((:lqcd_ctx_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), lat.h, id, prod(lat.PEs)))
+set_param!(lat::HIPLattice, key::String, value::Integer) =
+    check(ccall((:lqcd_ctx_set_param, LIB), Cint, (Ptr{Cvoid}, Cstring, Cint), lat.h, key, value))
 
-# ------------------------------------------------------------------ gauge fields: the reference's U::Vector{TG} (U[1:4]) as ONE device object,
-# U[mu] / p[mu] / temporaries as views (field, direction slot)
-mutable struct HIPGaugefields   # stands where the reference holds Vector{<:Gaugefields.AbstractGaugefields{3,4}}
+# ------------------------------------------------------------------ gauge-shaped device storage and its per-direction views
+mutable struct HIPGaugeStorage      # one device allocation: four link-shaped slots [parity][chunk][slot][9][64] (lqcd_gauge_t)
     h::Ptr{Cvoid}
     lat::HIPLattice
-    NC::Int
+    used::Int                       # slots handed out by similar(::HIPLink) (temporaries share storages four at a time)
 end
-function HIPGaugefields(lat::HIPLattice)
+function HIPGaugeStorage(lat::HIPLattice)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lqcd_gauge_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), lat.h, h))
-    g = HIPGaugefields(h[], lat, 3)
+    g = HIPGaugeStorage(h[], lat, 0)
     finalizer(x -> ccall((:lqcd_gauge_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), g)
     return g
 end
-struct HIPLink                  # in the reference tree: <: Gaugefields.AbstractGaugefields{3,4}; one direction of a HIPGaugefields
-    parent::HIPGaugefields
-    slot::Cint                  # 0..3
-end
-Base.getproperty(l::HIPLink, s::Symbol) = s === :NC ? getfield(l, :parent).NC : getfield(l, s)      # U[1].NC (AbstractMD.jl:101)
-Base.getindex(U::HIPGaugefields, mu::Integer) = (1 <= mu <= 4 || throw(BoundsError(U, mu)); HIPLink(U, Cint(mu - 1)))
-Base.length(::HIPGaugefields) = 4
-Base.eltype(::Type{HIPGaugefields}) = HIPLink
-similar(U::HIPGaugefields) = HIPGaugefields(U.lat)                                                   # Uold = similar(U) (standardHMC.jl:32)
-Base.size(l::HIPLink) = (l.parent.NC, l.parent.NC, l.parent.lat.L...)
+const SPARE = Dict{Ptr{Cvoid},HIPGaugeStorage}()     # per context: the storage whose free slots the next temporaries take
 
-# upload: U is the reference's Vector of 4 Array{ComplexF64,6} (NC,NC,NX,NY,NZ,NT), Nwing = 0
-function substitute_U!(g::HIPGaugefields, U::Vector{<:AbstractArray{ComplexF64,6}}; Nwing = 0)
-    buf = cat(U...; dims = 7)      # [a,b,x,y,z,t,mu] column-major == lqcd LAYOUT_REFERENCE (extents L .+ 2Nwing when the fields carry wings)
-    if Nwing == 0
-        check(ccall((:lqcd_gauge_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), g.h, buf, LAYOUT_REFERENCE))
-    else    # the reference's Initialize_Gaugefields(NC, Nwing, ...) arrays (test/test_wilson.toml: Nwing = 1): interior only
-        check(ccall((:lqcd_gauge_upload_wing, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), g.h, buf, Nwing))
+# one direction of a gauge field: what the reference calls U[μ], a temporary, dSdUμ, expU, W ...
+struct HIPLink <: AbstractGaugefields{3,4}
+    parent::HIPGaugeStorage
+    slot::Cint                      # 0..3
+end
+# one direction of the momentum field p[μ] (traceless anti-Hermitian 3x3 per site, stored link-shaped)
+struct HIPTALink
+    parent::HIPGaugeStorage
+    slot::Cint
+end
+const AnyLink = Union{HIPLink,HIPTALink}
+function Base.getproperty(l::AnyLink, s::Symbol)        # U[1].NC (AbstractMD.jl:100, standardHMC.jl:42) and the package's generic accessors
+    s === :NC && return 3
+    s === :Nwing && return 0
+    s === :NX && return getfield(l, :parent).lat.L[1]
+    s === :NY && return getfield(l, :parent).lat.L[2]
+    s === :NZ && return getfield(l, :parent).lat.L[3]
+    s === :NT && return getfield(l, :parent).lat.L[4]
+    s === :NV && return prod(getfield(l, :parent).lat.L)
+    return getfield(l, s)
+end
+Base.size(l::AnyLink) = (3, 3, getfield(l, :parent).lat.L...)
+lattice(U::Vector{<:AnyLink}) = getfield(U[1], :parent).lat
+
+# the four directions of one storage, in order?  Whole-field entry points (copy, plaquette, operator, action, force) need that;
+# fields made by Initialize_HIPGaugefields / similar(U) / initialize_TA_Gaugefields(U) always are.
+function whole(U::Vector{<:AnyLink})
+    length(U) == 4 || error("the HIP path handles four-dimensional fields (length(U) == 4)")
+    g = getfield(U[1], :parent)
+    for μ = 1:4
+        (getfield(U[μ], :parent) === g && getfield(U[μ], :slot) == μ - 1) ||
+            error("U[1:4] must be the four directions of one device field (Initialize_HIPGaugefields, similar(U))")
     end
     return g
 end
-function Initialize_Gaugefields(NC, Nwing, L...; condition = "cold", lattice = nothing, randomseed = 111)    # universe.jl:41-49
+views(::Type{T}, g::HIPGaugeStorage) where {T<:AnyLink} = T[T(g, Cint(μ - 1)) for μ = 1:4]
+
+# Initialize_Gaugefields(NC, Nwing, L...; condition) (universe.jl:41-49) -> U::Vector{HIPLink}, the value `Univ` stores as U::Vector{TG}
+function Initialize_HIPGaugefields(NC, Nwing, L...; condition = "cold", lattice = nothing, randomseed = 111)::Vector{HIPLink}
     NC == 3 || error("only NC = 3 is supported on the HIP path")
-    U = HIPGaugefields(lattice === nothing ? HIPLattice(Tuple(L)) : lattice)
+    length(L) == 4 || error("only Dim = 4 is supported on the HIP path")
+    g = HIPGaugeStorage(lattice === nothing ? HIPLattice(Tuple(Int.(L))) : lattice)
+    g.used = 4
     if condition == "cold"
-        check(ccall((:lqcd_gauge_unit, LIB), Cint, (Ptr{Cvoid},), U.h))
+        check(ccall((:lqcd_gauge_unit, LIB), Cint, (Ptr{Cvoid},), g.h))
     elseif condition == "hot"
-        check(ccall((:lqcd_gauge_hot_start, LIB), Cint, (Ptr{Cvoid}, UInt64), U.h, randomseed))
+        check(ccall((:lqcd_gauge_hot_start, LIB), Cint, (Ptr{Cvoid}, UInt64), g.h, randomseed))
     else
         error("condition = $condition is not supported")
     end
+    return views(HIPLink, g)
+end
+# Uold = similar(U) (standardHMC.jl:32), dSdU = similar(U) (standardMD.jl:58): a fresh four-direction field
+function similar(U::Vector{HIPLink})::Vector{HIPLink}
+    g = HIPGaugeStorage(lattice(U))
+    g.used = 4
+    return views(HIPLink, g)
+end
+# similar(U[1]): ONE link-shaped temporary -- what the package's Temporalfields pool (get_temp / unused!, AbstractMD.jl:80-97) and
+# GaugeAction(U) allocate.  Four temporaries share one device storage.
+function similar(l::HIPLink)::HIPLink
+    lat = getfield(l, :parent).lat
+    g = get(SPARE, lat.h, nothing)
+    if g === nothing || g.used >= 4
+        g = HIPGaugeStorage(lat)
+        SPARE[lat.h] = g
+    end
+    g.used += 1
+    return HIPLink(g, Cint(g.used - 1))
+end
+get_myrank(l::AnyLink) = getfield(l, :parent).lat.rank                                   # universe.jl:52
+println_verbose_level1(l::AnyLink, val...) = (get_myrank(l) == 0 && println(val...); nothing)
+println_verbose_level2(l::AnyLink, val...) = (get_myrank(l) == 0 && VERBOSE_LEVEL[] >= 2 && println(val...); nothing)   # standardHMC.jl:75-86
+println_verbose_level3(l::AnyLink, val...) = (get_myrank(l) == 0 && VERBOSE_LEVEL[] >= 3 && println(val...); nothing)   # standardHMC.jl:51,55,63
+# calc_smearedU(U, md.cov_neural_net) with cov_neural_net = nothing: always reached from update! (standardHMC.jl:67 compares the VALUE
+# nothing with the TYPE Nothing, which is true) -- no smearing, the fermion action sees U itself
+calc_smearedU(U::Vector{HIPLink}, ::Nothing) = (U, nothing, nothing)
+
+# host <-> device.  U_host: the reference's Vector of 4 Array{ComplexF64,6} (NC,NC,NX,NY,NZ,NT) [+ wings]
+function substitute_U!(U::Vector{HIPLink}, Uh::Vector{<:AbstractArray{ComplexF64,6}}; Nwing = 0)
+    buf = cat(Uh...; dims = 7)     # [a,b,x,y,z,t,mu] column-major == LAYOUT_REFERENCE (extents L .+ 2Nwing when the fields carry wings)
+    if Nwing == 0
+        check(ccall((:lqcd_gauge_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), whole(U).h, buf, LAYOUT_REFERENCE))
+    else    # the reference's Initialize_Gaugefields(NC, Nwing, ...) arrays (test/test_wilson.toml: Nwing = 1): interior only
+        check(ccall((:lqcd_gauge_upload_wing, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), whole(U).h, buf, Nwing))
+    end
     return U
 end
-function calculate_Plaquette(g::HIPGaugefields)
+# load_BridgeText!(filename, U, L, NC) / load_gaugefield!(U, i, ildg, L, NC) (universe.jl:60-66): the package's readers fill a host
+# field, which is then uploaded
+function load_BridgeText!(filename::String, U::Vector{HIPLink}, L, NC)
+    Uh = Gaugefields.Initialize_Gaugefields(NC, 0, L..., condition = "cold")
+    load_BridgeText!(filename, Uh, L, NC)
+    substitute_U!(U, [Uh[μ].U for μ = 1:4])
+end
+function load_gaugefield!(U::Vector{HIPLink}, i, ildg, L, NC)
+    Uh = Gaugefields.Initialize_Gaugefields(NC, 0, L..., condition = "cold")
+    load_gaugefield!(Uh, i, ildg, L, NC)
+    substitute_U!(U, [Uh[μ].U for μ = 1:4])
+end
+function calculate_Plaquette(U::Vector{HIPLink})
     p = Ref{Float64}(0)
-    check(ccall((:lqcd_gauge_plaquette, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), g.h, p))
+    check(ccall((:lqcd_gauge_plaquette, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), whole(U).h, p))
     return p[]
 end
+# every link back onto SU(3): once per trajectory keeps the 12-real Dslash path alive when the links are updated through the per-direction
+# entry points (the fused lqcd_gauge_exp_update does it in the same pass)
+reunitarize!(U::Vector{HIPLink}) = check(ccall((:lqcd_gauge_reunitarize, LIB), Cint, (Ptr{Cvoid},), whole(U).h))
 
-# substitute_U!(Uold, U) (standardHMC.jl:45) and substitute_U!(U[mu], W) (AbstractMD.jl:93)
-substitute_U!(dst::HIPGaugefields, src::HIPGaugefields) =
-    check(ccall((:lqcd_gauge_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), dst.h, src.h))
+# substitute_U!(Uold, U) / substitute_U!(U, Uold) (standardHMC.jl:45,84) and substitute_U!(U[mu], W) (AbstractMD.jl:93)
+function substitute_U!(dst::Vector{HIPLink}, src::Vector{HIPLink})
+    check(ccall((:lqcd_gauge_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), whole(dst).h, whole(src).h))
+end
 substitute_U!(dst::HIPLink, src::HIPLink) =
-    check(ccall((:lqcd_link_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), dst.parent.h, dst.slot, src.parent.h, src.slot))
+    check(ccall((:lqcd_link_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), getfield(dst, :parent).h, getfield(dst, :slot), getfield(src, :parent).h, getfield(src, :slot)))
 # mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUμ) (AbstractMD.jl:92,109)
-mul!(C::HIPLink, A::HIPLink, B::HIPLink) =
-    (check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                 C.parent.h, C.slot, A.parent.h, A.slot, B.parent.h, B.slot)); C)
+function mul!(C::HIPLink, A::HIPLink, B::HIPLink)
+    check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                getfield(C, :parent).h, getfield(C, :slot), getfield(A, :parent).h, getfield(A, :slot), getfield(B, :parent).h, getfield(B, :slot)))
+    return C
+end
 # exptU!(expU, t, p[mu], [temp1, temp2]) (AbstractMD.jl:91)
-exptU!(expU::HIPLink, t::Number, p::HIPLink, temps = nothing) =
-    check(ccall((:lqcd_link_exp, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), expU.parent.h, expU.slot, Float64(t), p.parent.h, p.slot))
+exptU!(expU::HIPLink, t::Number, p::HIPTALink, temps) =
+    check(ccall((:lqcd_link_exp, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), getfield(expU, :parent).h, getfield(expU, :slot), Float64(t), getfield(p, :parent).h, getfield(p, :slot)))
 # Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131)
-Traceless_antihermitian_add!(p::HIPLink, factor::Number, G::HIPLink) =
-    check(ccall((:lqcd_link_add_ta, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), p.parent.h, p.slot, Float64(factor), G.parent.h, G.slot))
+Traceless_antihermitian_add!(p::HIPTALink, factor::Number, G::HIPLink) =
+    check(ccall((:lqcd_link_add_ta, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), getfield(p, :parent).h, getfield(p, :slot), Float64(factor), getfield(G, :parent).h, getfield(G, :slot)))
 
-# ---- momenta: initialize_TA_Gaugefields(U) (standardMD.jl:34), gauss_distribution!(md.p) (:86), md.p * md.p (standardHMC.jl:49)
-initialize_TA_Gaugefields(U::HIPGaugefields) = HIPGaugefields(U.lat)
-gauss_distribution!(p::HIPGaugefields; seed = rand(UInt64)) =
-    check(ccall((:lqcd_momentum_gaussian, LIB), Cint, (Ptr{Cvoid}, UInt64), p.h, seed))
-function Base.:*(p::HIPGaugefields, q::HIPGaugefields)
+# ---- momenta: initialize_TA_Gaugefields(U) (standardMD.jl:34), gauss_distribution!(md.p) (:86), md.p * md.p (standardHMC.jl:49,59)
+function initialize_TA_Gaugefields(U::Vector{HIPLink})::Vector{HIPTALink}
+    g = HIPGaugeStorage(lattice(U))
+    g.used = 4
+    return views(HIPTALink, g)
+end
+gauss_distribution!(p::Vector{HIPTALink}; seed = rand(UInt64)) =
+    check(ccall((:lqcd_momentum_gaussian, LIB), Cint, (Ptr{Cvoid}, UInt64), whole(p).h, seed))
+function Base.:*(p::Vector{HIPTALink}, q::Vector{HIPTALink})
     p === q || error("only p * p (the kinetic term of standardHMC.jl:49) is defined")
     k = Ref{Float64}(0)
-    check(ccall((:lqcd_momentum_action, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), p.h, k))
+    check(ccall((:lqcd_momentum_action, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), whole(p).h, k))
     return 2 * k[]            # lqcd_momentum_action returns p.p/2
 end
 
-# ---- temporaries: Gaugefields.Temporalfields_module (get_temp / unused!, AbstractMD.jl:80-97): a pool of link-field views
-mutable struct HIPTemporalfields
-    lat::HIPLattice
-    fields::Vector{HIPGaugefields}
-    free::Vector{Int}
+# ---- gauge action.  GaugeAction(U), push!(gauge_action, β/2, plaqloop ∪ plaqloop') (universe.jl:88-96), get_temporary_gaugefields,
+# get_temp and unused! are the PACKAGE's own: GaugeAction(U::Vector{<:AbstractGaugefields{NC,Dim}}) builds a GaugeAction{4,HIPLink}
+# whose temporaries are similar(U[1]) (above).  Specialised here are the two generics that do arithmetic.  The coupling is read from the
+# package's bookkeeping: dataset[i].β is the coefficient push! stored (β/2 for the plaquette and its adjoint together).
+function beta_inp(ga::GaugeAction{4,HIPLink})
+    all(d -> length(d.closedloops) == 12, ga.dataset) ||
+        error("the HIP staple kernel implements the plaquette action (make_loops_fromname(\"plaquette\") and its adjoint, universe.jl:92-93)")
+    return sum(d.β for d in ga.dataset)
 end
-HIPTemporalfields(lat::HIPLattice) = HIPTemporalfields(lat, HIPGaugefields[], Int[])
-function _grow!(t::HIPTemporalfields)
-    push!(t.fields, HIPGaugefields(t.lat))
-    base = 4 * (length(t.fields) - 1)
-    append!(t.free, base:base+3)
-end
-_view(t::HIPTemporalfields, it::Int) = HIPLink(t.fields[it ÷ 4 + 1], Cint(it % 4))
-function get_temp(t::HIPTemporalfields)
-    isempty(t.free) && _grow!(t)
-    it = popfirst!(t.free)
-    return _view(t, it), it
-end
-function get_temp(t::HIPTemporalfields, n::Integer)
-    pairs = [get_temp(t) for _ = 1:n]
-    return [p[1] for p in pairs], [p[2] for p in pairs]
-end
-unused!(t::HIPTemporalfields, it::Integer) = (push!(t.free, it); sort!(t.free); nothing)
-unused!(t::HIPTemporalfields, its::AbstractVector) = (foreach(i -> unused!(t, i), its); nothing)
-
-# ---- gauge action: GaugeAction(U); push!(gauge_action, beta/2, plaqloop ∪ plaqloop') (universe.jl:88-96)
-mutable struct HIPGaugeAction
-    beta_inp::Float64
-    temps::HIPTemporalfields
-end
-GaugeAction(U::HIPGaugefields) = HIPGaugeAction(0.0, HIPTemporalfields(U.lat))
-Base.push!(ga::HIPGaugeAction, beta_inp::Number, loops) = (ga.beta_inp += beta_inp; ga)   # plaquette + adjoint only: the loops of universe.jl:92-93
-get_temporary_gaugefields(ga::HIPGaugeAction) = ga.temps
-# calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): beta_inp * (sum of the staples of U[μ])
-calc_dSdUμ!(dSdUμ::HIPLink, ga::HIPGaugeAction, μ::Integer, U::HIPGaugefields) =
-    check(ccall((:lqcd_link_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), dSdUμ.parent.h, dSdUμ.slot, U.h, μ - 1, 2 * ga.beta_inp))
-# evaluate_GaugeAction(gauge_action, U) (standardHMC.jl:50; S_g = -that / NC): lqcd_gauge_action returns S_g itself
-function evaluate_GaugeAction(ga::HIPGaugeAction, U::HIPGaugefields)
+# calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): β_inp * (sum of the staples of U[μ])
+calc_dSdUμ!(dSdUμ::HIPLink, ga::GaugeAction{4,HIPLink}, μ::Integer, U::Vector{HIPLink}) =
+    check(ccall((:lqcd_link_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), getfield(dSdUμ, :parent).h, getfield(dSdUμ, :slot), whole(U).h, μ - 1, 2 * beta_inp(ga)))
+# evaluate_GaugeAction(gauge_action, U) (standardHMC.jl:50,60; S_g = -that / NC): lqcd_gauge_action returns S_g itself
+function evaluate_GaugeAction(ga::GaugeAction{4,HIPLink}, U::Vector{HIPLink})
     s = Ref{Float64}(0)
-    check(ccall((:lqcd_gauge_action, LIB), Cint, (Ptr{Cvoid}, Float64, Ref{Float64}), U.h, 2 * ga.beta_inp, s))
-    return -U.NC * s[]
+    check(ccall((:lqcd_gauge_action, LIB), Cint, (Ptr{Cvoid}, Float64, Ref{Float64}), whole(U).h, 2 * beta_inp(ga), s))
+    return -3 * s[]
 end
 
 # ------------------------------------------------------------------ fermion fields
-mutable struct HIPFermion       # in the reference tree: <: LatticeDiracOperators.AbstractFermionfields_4D{3}
+mutable struct HIPFermion <: AbstractFermionfields_4D{3}
     h::Ptr{Cvoid}
     lat::HIPLattice
     kind::Cint
@@ -195,10 +268,9 @@ function HIPFermion(lat::HIPLattice, kind::Cint)
     finalizer(x -> ccall((:lqcd_spinor_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), f)
     return f
 end
-# Initialize_pseudofermion_fields(U[1], "Wilson"; nowing = true)   (universe.jl:107,112)
-Initialize_pseudofermion_fields(U::HIPLink, name::String; kwargs...) =
-    HIPFermion(U.parent.lat, lowercase(name) == "wilson" ? WILSON : lowercase(name) == "staggered" ? STAGGERED : error("$name is not supported"))
-Initialize_pseudofermion_fields(U::HIPGaugefields, name::String; kwargs...) = Initialize_pseudofermion_fields(U[1], name; kwargs...)
+# Initialize_pseudofermion_fields(U[1], "Wilson"; nowing = true) / (U[1], "staggered")   (universe.jl:107,112)
+Initialize_pseudofermion_fields(u::HIPLink, name::String; kwargs...) =
+    HIPFermion(getfield(u, :parent).lat, lowercase(name) == "wilson" ? WILSON : lowercase(name) == "staggered" ? STAGGERED : error("$name is not supported"))
 similar(x::HIPFermion) = HIPFermion(x.lat, x.kind)
 clear_fermion!(x::HIPFermion) = check(ccall((:lqcd_spinor_zero, LIB), Cint, (Ptr{Cvoid},), x.h))
 substitute_fermion!(a::HIPFermion, b::HIPFermion) = check(ccall((:lqcd_spinor_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), a.h, b.h))
@@ -223,9 +295,9 @@ upload!(x::HIPFermion, a::Array{ComplexF64,6}) = check(ccall((:lqcd_spinor_uploa
 download!(a::Array{ComplexF64,6}, x::HIPFermion) = check(ccall((:lqcd_spinor_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), x.h, a))
 
 # ------------------------------------------------------------------ Dirac operator
-mutable struct HIPDirac         # in the reference tree: <: LatticeDiracOperators.Dirac_operator{4}
+mutable struct HIPDirac <: Dirac_operator{4}
     h::Ptr{Cvoid}
-    U::HIPGaugefields
+    U::Vector{HIPLink}
     x::HIPFermion               # the field Dirac_operator(U, x, params) was built from (kind; similar(x) for the action's temporaries)
     dagger::Bool
     eps_CG::Float64
@@ -234,15 +306,16 @@ mutable struct HIPDirac         # in the reference tree: <: LatticeDiracOperator
     owner::Bool
 end
 # Dirac_operator(U, x, params::Dict)  (universe.jl:137; keys universe.jl:103-135)
-function Dirac_operator(U::HIPGaugefields, x::HIPFermion, params::Dict)
+function Dirac_operator(U::Vector{HIPLink}, x::HIPFermion, params)
     name = params["Dirac_operator"]
     kind = name in ("Wilson", "WilsonClover") ? WILSON : name in ("Staggered", "staggered") ? STAGGERED : error("$name is not supported")
     km = kind == WILSON ? Float64(params["κ"]) : Float64(get(params, "mass", 0.5))
     r = Float64(get(params, "r", 1.0))
     bc = Cint[get(params, "boundarycondition", [1, 1, 1, -1])...]
+    g = whole(U)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lqcd_op_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Float64, Float64, Ptr{Cint}),
-                U.lat.h, h, kind, U.h, km, r, bc))
+                g.lat.h, h, kind, g.h, km, r, bc))
     if name == "WilsonClover"      # Clover_coefficient (src/system/parameter_structs.jl:125)
         check(ccall((:lqcd_op_set_clover, LIB), Cint, (Ptr{Cvoid}, Float64), h[], Float64(get(params, "Clover_coefficient", 1.5612))))
     end
@@ -252,8 +325,8 @@ function Dirac_operator(U::HIPGaugefields, x::HIPFermion, params::Dict)
     return D
 end
 # D(U): rebind links (unusedfiles/measure_chiral_condensate.jl:173)
-function (D::HIPDirac)(U::HIPGaugefields)
-    check(ccall((:lqcd_op_set_gauge, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), D.h, U.h)); D.U = U; D
+function (D::HIPDirac)(U::Vector{HIPLink})
+    check(ccall((:lqcd_op_set_gauge, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), D.h, whole(U).h)); D.U = U; D
 end
 adjoint(D::HIPDirac) = HIPDirac(D.h, D.U, D.x, !D.dagger, D.eps_CG, D.MaxCGstep, D.method_CG, false)
 struct HIPDdagD
@@ -323,26 +396,26 @@ end
 # standardHMC.jl:54,71 and AbstractMD.jl:129.  2-flavour Wilson(-clover) and the 4- / 8-taste staggered actions; for any other Nf the
 # reference's package brings Remez tables -- here the partial fractions come from the caller (rational_apply! / rational_force! below;
 # the Python mirror fits them with latticeqcd.jl_amd/rational.py).
-mutable struct HIPFermiAction
+mutable struct HIPFermiAction <: FermiAction{4,HIPDirac,HIPFermion,HIPLink}
     D::HIPDirac
     Nf::Int
     _temporary_fermionfields::Vector{HIPFermion}     # standardMD.jl:50: η = similar(fermi_action._temporary_fermionfields[1])
-    force::HIPGaugefields                            # G of lqcd_calc_UdSfdU, handed out per direction
+    force::Vector{HIPLink}                           # G of lqcd_calc_UdSfdU, handed out per direction
 end
-function FermiAction(D::HIPDirac, parameters_action::Dict = Dict())
+function FermiAction(D::HIPDirac, parameters_action)
     kind = D.x.kind
     Nf = get(parameters_action, "Nf", kind == WILSON ? 2 : 4)
     (kind == WILSON && Nf == 2) || (kind == STAGGERED && Nf in (4, 8)) ||
         error("FermiAction: Nf = $Nf needs the rational action (rational_apply! / rational_force! with partial fractions from the caller)")
-    return HIPFermiAction(D, Nf, [similar(D.x), similar(D.x)], HIPGaugefields(D.U.lat))
+    return HIPFermiAction(D, Nf, [similar(D.x), similar(D.x)], similar(D.U))
 end
 # gauss_sampling_in_action!(ξ, U, fa) (standardMD.jl:95): ξ ~ exp(-ξ†ξ), i.e. re and im of variance 1/2
-function gauss_sampling_in_action!(ξ::HIPFermion, U::HIPGaugefields, fa::HIPFermiAction; seed = rand(UInt64))
+function gauss_sampling_in_action!(ξ::HIPFermion, U::Vector{HIPLink}, fa::HIPFermiAction; seed = rand(UInt64))
     check(ccall((:lqcd_spinor_gaussian, LIB), Cint, (Ptr{Cvoid}, UInt64), ξ.h, seed))
     check(ccall((:lqcd_scale, LIB), Cint, (Float64, Float64, Ptr{Cvoid}), sqrt(0.5), 0.0, ξ.h))
 end
 # sample_pseudofermions!(η, U, fa, ξ) (standardMD.jl:96): η = D†ξ (4 staggered tastes: restricted to the even sites)
-function sample_pseudofermions!(η::HIPFermion, U::HIPGaugefields, fa::HIPFermiAction, ξ::HIPFermion)
+function sample_pseudofermions!(η::HIPFermion, U::Vector{HIPLink}, fa::HIPFermiAction, ξ::HIPFermion)
     mul!(η, fa.D(U)', ξ)
     if η.kind == STAGGERED && fa.Nf == 4
         half = Ref{Ptr{Cvoid}}(C_NULL)
@@ -354,8 +427,8 @@ function sample_pseudofermions!(η::HIPFermion, U::HIPGaugefields, fa::HIPFermiA
     end
     return η
 end
-# evaluate_FermiAction(fa, U, η) (standardHMC.jl:71): S_f = η†(D†D)^-1 η; X = (D†D)^-1 η and Y = D X stay in the action's temporaries
-function evaluate_FermiAction(fa::HIPFermiAction, U::HIPGaugefields, η::HIPFermion)
+# evaluate_FermiAction(fa, U, η) (standardHMC.jl:69,71): S_f = η†(D†D)^-1 η; X = (D†D)^-1 η and Y = D X stay in the action's temporaries
+function evaluate_FermiAction(fa::HIPFermiAction, U::Vector{HIPLink}, η::HIPFermion)
     S, it = Ref{Float64}(0), Ref{Cint}(0)
     D = fa.D(U)
     X, Y = fa._temporary_fermionfields
@@ -366,30 +439,31 @@ end
 # calc_UdSfdU!(UdSfdUμ, fa, U, η) (AbstractMD.jl:129) with UdSfdUμ = get_temp(temps, Dim): solve, Y = D X and the outer-product sweep run
 # resident into fa.force (= G, dS_f/dε[U -> exp(iεT)U] = -2 Im tr(T G)); each direction is handed over as "U dS_f/dU" = -G, the sign
 # the caller's factor = -ϵ Δτ expects (AbstractMD.jl:127-132)
-function calc_UdSfdU!(UdSfdUμ::Vector{HIPLink}, fa::HIPFermiAction, U::HIPGaugefields, η::HIPFermion)
+function calc_UdSfdU!(UdSfdUμ::Vector{HIPLink}, fa::HIPFermiAction, U::Vector{HIPLink}, η::HIPFermion)
     D = fa.D(U)
+    G = whole(fa.force)
     check(ccall((:lqcd_calc_UdSfdU, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Cint}),
-                D.h, fa.force.h, η.h, D.eps_CG, D.MaxCGstep, C_NULL, C_NULL))
+                D.h, G.h, η.h, D.eps_CG, D.MaxCGstep, C_NULL, C_NULL))
     for μ = 1:4
         check(ccall((:lqcd_link_scaled_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint),
-                    UdSfdUμ[μ].parent.h, UdSfdUμ[μ].slot, -1.0, fa.force.h, μ - 1))
+                    getfield(UdSfdUμ[μ], :parent).h, getfield(UdSfdUμ[μ], :slot), -1.0, G.h, μ - 1))
     end
 end
 # general staggered Nf (test/test_Nf2.toml:8, test/test_Nf3.toml:8): rational action, coefficients (a0, res, poles) from the caller
 rational_apply!(y::HIPFermion, D::HIPDirac, x::HIPFermion, a0, res::Vector{Float64}, poles::Vector{Float64}) =
     check(ccall((:lqcd_rational_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Ptr{Cint}),
                 D.h, y.h, x.h, a0, length(res), res, poles, D.eps_CG, D.MaxCGstep, C_NULL))
-rational_force!(G::HIPGaugefields, D::HIPDirac, φ::HIPFermion, res::Vector{Float64}, poles::Vector{Float64}) =
+rational_force!(G::Vector{HIPLink}, D::HIPDirac, φ::HIPFermion, res::Vector{Float64}, poles::Vector{Float64}) =
     check(ccall((:lqcd_rational_force, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Ptr{Cint}),
-                D.h, G.h, φ.h, length(res), res, poles, D.eps_CG, D.MaxCGstep, C_NULL))
+                D.h, whole(G).h, φ.h, length(res), res, poles, D.eps_CG, D.MaxCGstep, C_NULL))
 
 # ---- fused four-direction forms of the MD step (one kernel each; what a maintainer would call from a specialised
-# P_update!(U::HIPGaugefields, p, ϵ, md) / U_update! method to skip the per-direction temporaries)
-P_update_fused!(U::HIPGaugefields, p::HIPGaugefields, factor, β) =      # p += factor * TA(-(β/6) U * staples), the force field is never stored
-    check(ccall((:lqcd_momentum_add_gauge_force, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64), p.h, factor, U.h, β))
-U_update_fused!(U::HIPGaugefields, p::HIPGaugefields, dt) =             # U <- exp(dt p) U
-    check(ccall((:lqcd_gauge_exp_update, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), U.h, dt, p.h))
-momentum_add_ta_fused!(p::HIPGaugefields, factor, G::HIPGaugefields) =  # p += factor * TA(G), all four directions
-    check(ccall((:lqcd_momentum_add_ta, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), p.h, factor, G.h))
+# P_update!(U::Vector{HIPLink}, p, ϵ, md) / U_update! method to skip the per-direction temporaries)
+P_update_fused!(U::Vector{HIPLink}, p::Vector{HIPTALink}, factor, β) =      # p += factor * TA(-(β/6) U * staples), the force field is never stored
+    check(ccall((:lqcd_momentum_add_gauge_force, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64), whole(p).h, factor, whole(U).h, β))
+U_update_fused!(U::Vector{HIPLink}, p::Vector{HIPTALink}, dt) =             # U <- exp(dt p) U (reprojected onto SU(3): tunable md_reunitarize)
+    check(ccall((:lqcd_gauge_exp_update, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), whole(U).h, dt, whole(p).h))
+momentum_add_ta_fused!(p::Vector{HIPTALink}, factor, G::Vector{HIPLink}) =  # p += factor * TA(G), all four directions
+    check(ccall((:lqcd_momentum_add_ta, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), whole(p).h, factor, whole(G).h))
 
 end # module

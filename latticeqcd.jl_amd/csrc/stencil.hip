@@ -251,8 +251,8 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
 // arithmetic -> backward-hop loads -> arithmetic -> LDS -> barrier -> LDS -> store; with every stream L2-hot the kernel still takes 0.27 ms of
 // its 0.36 (profiles/r02_hot_ablations_and_occupancy.log) -- a CU-side floor made of phases that do not overlap at 3 waves/SIMD.
 // Here a workgroup is persistent (3 per CU) and pulls virtual blocks of the same XCD-aware map IN ORDER from the queue of the XCD it runs on
-// (one device-scope atomic per chunk, issued a chunk ahead; an XCD whose queue is empty helps the next one, so results never depend on
-// placement).  A static walk b, b + grid, ... was measured first (profiles/r03_pipe_static_walk.log): workgroups drift apart, the set in
+// (one device-scope atomic per chunk, issued alongside the backward-hop loads of the chunk before; an XCD whose queue is empty helps the
+// next one, so results never depend on placement).  A static walk b, b + grid, ... was measured first (profiles/r03_pipe_static_walk.log): workgroups drift apart, the set in
 // flight on an XCD stops being a contiguous window of the sweep, the L2 hit rate falls from 0.64 to 0.46 and the kernel becomes
 // HBM-bound on 1.6x the traffic.  The in-order queue reproduces what the hardware dispatcher gives variant 1 for free.
 //   * the forward-hop operands of chunk c+1 (and the diagonal term / old r of chunk c) are issued BEFORE the barrier, the LDS combine and the
@@ -394,7 +394,7 @@ __device__ inline void pipe_sign(cd (&h0)[3], cd (&h1)[3], real sign) {
 }
 
 template <int MU, bool DAG, bool R12, bool NTB>
-__device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volatile int* nextvb, int vb, int vbn, int q, int tries, int lane,
+__device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volatile int* nextvb, int vb, int q, int tries, int lane,
                                  real al_upd, double& nrm_acc) {
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;                       // t: only the two rows the projector keeps
@@ -402,7 +402,6 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
     constexpr int FB = MU == 3 ? (SF > 0 ? 0 : 6) : 0;
     constexpr int NL = R12 ? 6 : 9;
     const int nper = a.nvirt >> 3;
-    int slot = 2;              // the queue result travels through nextvb[2] / nextvb[3] alternately (a wave may be a barrier interval ahead of a reader)
     const size_t gpar = (size_t)a.nch * 4 * NL * 64;           // elements of one parity block of the gauge field
     PipeSite s = pipe_site<MU, NL>(a, vb, lane);
     cd sF[NS], uF[9];
@@ -412,7 +411,7 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
         cd acc[12], chi0[3], chi1[3], h0[3], h1[3];
 #pragma unroll
         for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
-        // forward hop: its operands were issued one stage ago (prologue, or in front of the previous chunk's barrier)
+        // forward hop: its operands were issued one stage ago (prologue, or in front of the previous chunk's second barrier)
         finish_link<R12>(uF);
         project_regs<MU, SF>(h0, h1, sF);
         pipe_sign(h0, h1, s.sf);
@@ -435,14 +434,13 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
         cd sB[NS], uB[9];
         load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
         load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
-        // the chunk after the next: one lane of the x wave pulls it from the queue now (the atomic returns with the loads above)
+        // the NEXT chunk: one lane of the x wave pulls it from the queue now -- as late as its answer can still arrive for free (it returns
+        // with the loads above).  Pulling earlier lets the order in which chunks are handed out drift away from the order in which their
+        // loads are issued, and the L2 hits of the sweep live on that order (profiles/r03_pipe_lookahead.log).
         unsigned tick = 0;
         if constexpr (MU == 0) {
             if (lane == 0 && tries < 8) tick = __hip_atomic_fetch_add(a.ctr + 32 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // while those are in flight: the next chunk's map and neighbour arithmetic (the last chunk computes itself again)
-        const bool more = vbn >= 0;
-        const PipeSite sn = pipe_site<MU, NL>(a, more ? vbn : vb, lane);
         __builtin_amdgcn_sched_barrier(0);
         finish_link<R12>(uB);
         project_regs<MU, -SF>(h0, h1, sB);
@@ -458,13 +456,17 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
                     if (tick < (unsigned)nper) nx = 8 * (int)tick + q;
                     else { q = (q + 1) & 7; tries++; nx = pipe_fetch(a.ctr, nper, q, tries); }      // queue exhausted: help the next XCD (tail only)
                 }
-                nextvb[slot] = nx;
+                nextvb[2] = nx;
             }
         }
         // every wave has consumed the previous chunk's partial sums (its LDS reads fed its stores): the array may be overwritten
-        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
+        // the next chunk's addressing (mostly scalar); the last chunk computes itself again and discards the loads
+        const int vbn = __builtin_amdgcn_readfirstlane(nextvb[2]);    // written in front of the barrier above, next written in front of the next chunk's
+        const bool more = vbn >= 0;
+        const PipeSite sn = pipe_site<MU, NL>(a, more ? vbn : vb, lane);
         __builtin_amdgcn_sched_barrier(0);
         // this chunk's diagonal term / old r, then the NEXT chunk's forward operands: all in flight across the barrier and the LDS combine
 #if !LQCD_PIPE_DEARLY
@@ -508,8 +510,6 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
         }
         if (!more) break;
         vb = vbn;
-        vbn = __builtin_amdgcn_readfirstlane(nextvb[slot]);   // written in front of this chunk's first barrier; that slot is next written two chunks on
-        slot ^= 1;
         s = sn;
 #if LQCD_PIPE_NOPF      // experiment: persistent only, the forward operands are issued at the top of the chunk like variant 1
         load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
@@ -529,7 +529,12 @@ template <bool DAG, bool R12, bool NTB>
 __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
     __shared__ double red[4];
-    if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) return;
+    if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) {
+        // folded scalar steps: the update-mode launch of an overshooting iteration tells the x/p update behind it that the converging iterate
+        // is complete (upd_done in stencil_common.h)
+        if (a.scal_w && blockIdx.x == 0 && threadIdx.x == 0) a.scal_w[S_XDONE] = 1.0;
+        return;
+    }
     real al_upd = real(0);
     if (a.upd_scal) {
         if (a.scal_w) {      // folded scalar step (several ranks): see update_alpha
@@ -546,19 +551,16 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     int q = (int)(xcc & 7u), tries = 0;
-    if (threadIdx.x == 0) {
-        nextvb[0] = pipe_fetch(a.ctr, a.nvirt >> 3, q, tries);
-        nextvb[1] = pipe_fetch(a.ctr, a.nvirt >> 3, q, tries);
-    }
+    if (threadIdx.x == 0) nextvb[0] = pipe_fetch(a.ctr, a.nvirt >> 3, q, tries);
     __syncthreads();
-    const int vb0 = __builtin_amdgcn_readfirstlane(nextvb[0]), vb1 = __builtin_amdgcn_readfirstlane(nextvb[1]);
+    const int vb0 = __builtin_amdgcn_readfirstlane(nextvb[0]);
     double nrm = 0.0;
     if (vb0 >= 0) {
         switch (w) {
-        case 0: pipe_wave<0, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
-        case 1: pipe_wave<1, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
-        case 2: pipe_wave<2, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
-        default: pipe_wave<3, DAG, R12, NTB>(a, part, nextvb, vb0, vb1, q, tries, lane, al_upd, nrm); break;
+        case 0: pipe_wave<0, DAG, R12, NTB>(a, part, nextvb, vb0, q, tries, lane, al_upd, nrm); break;
+        case 1: pipe_wave<1, DAG, R12, NTB>(a, part, nextvb, vb0, q, tries, lane, al_upd, nrm); break;
+        case 2: pipe_wave<2, DAG, R12, NTB>(a, part, nextvb, vb0, q, tries, lane, al_upd, nrm); break;
+        default: pipe_wave<3, DAG, R12, NTB>(a, part, nextvb, vb0, q, tries, lane, al_upd, nrm); break;
         }
     }
     // this workgroup will not touch the queues again; the last one to say so zeroes them for the next launch (stream order)

@@ -149,10 +149,14 @@ def test_pipe_rccl_self_partition(gpu, orc):
             ref = orc.wilson_D(U, psi, L, K, 1.0, BC, dag)
             err = np.abs(y.download() - ref).max() / np.abs(ref).max()
             assert err < 1e-13, (dag, err)
-        sol = x.similar()
-        it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
         xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, K, 1.0, BC, eps=1e-19)
-        assert st == 0 and abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (it, ito)
+        its = {}
+        for pipe in (1, 0):
+            lat.set_param("dslash_pipe", pipe)
+            sol = x.similar()
+            its[pipe], rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+            assert np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (pipe, its, ito)
+        assert st == 0 and abs(its[1] - ito) <= 1 and abs(its[0] - ito) <= 1, (its, ito)
         print("PIPE_SELF_OK")
     """)
     for mask in ("8", "14", "15"):
