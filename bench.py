@@ -231,6 +231,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
+        out["reference_parity"] = reference_parity(lq)
     # The JSON line must be the LAST thing on the job's stdout: RCCL writes its version banner through C stdio at communicator
     # creation, where it would sit in the C buffer until exit -- every rank flushes C stdio right after comm_init and again here.
     _flush_c_stdio()
@@ -356,6 +357,43 @@ def cpu_baseline(lq, U, b, gL):
     return {"value": 1.0 / per_iter, "unit": "iter/s", "cores": 1, "kind": "port",
             "sample": "oracle CG on the same %dx%dx%dx%d configuration: time(1 iteration) - time(0 iterations), 1 thread" % gL,
             "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / t_d / 1e9, "julia_probe": probe}
+
+
+def reference_parity(lq):
+    """Operator-level parity against the REFERENCE ITSELF when `julia` and its packages are installed on this box (probed at run time):
+    scripts/ref_parity_dump.jl writes mul!(y,D,x), mul!(y,D',x) and solve_DinvX! of LatticeDiracOperators.jl on the reference's 4^4
+    fixtures with a closed-form source, the HIP path is compared with them (tests/ref_vectors.py).  Reported, never timed."""
+    import shutil
+    import subprocess
+    import tempfile
+    jl = shutil.which("julia")
+    if not jl:
+        return {"status": "julia not found on PATH: reference vectors absent (operator-level parity stays pinned by the oracle only)"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_vectors as rv
+    out = tempfile.mkdtemp(prefix="lqcd_refvec_")
+    try:
+        r = subprocess.run([jl, os.path.join(ROOT, "scripts", "ref_parity_dump.jl"), out, rv.GOLDEN], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0 or not rv.available(out):
+            return {"status": "julia found but scripts/ref_parity_dump.jl did not run (exit %d): %s" % (r.returncode, (r.stderr or "").strip()[-200:])}
+        res = {"status": "reference vectors produced on this box"}
+        for kind in ("wilson", "staggered"):
+            lat = lq.Lattice(rv.L)
+            U = lq.Gaugefields(lat).upload(lq.gauge_io.load_ildg(os.path.join(rv.GOLDEN, rv.FIXTURE[kind]), rv.L))
+            D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson" if kind == "wilson" else "Staggered", "κ": rv.KAPPA, "mass": rv.MASS,
+                                            "boundarycondition": rv.BC, "eps_CG": 1e-19, "MaxCGstep": 3000})
+            x = lq.Fermionfields(lat, lq.WILSON if kind == "wilson" else lq.STAGGERED).upload(rv.closed_form_source(kind))
+            y = x.similar()
+            for op, which in ((D, "D"), (D.adjoint(), "Ddag")):
+                lq.mul_(y, op, x)
+                ref = rv.load(kind, which, out)
+                res["%s_%s_rel_err" % (kind, which)] = float(abs(y.download() - ref).max() / abs(ref).max())
+            lq.solve_DinvX_(y, lq.DdagD_operator(D), x)
+            ref = rv.load(kind, "cg_x", out)
+            res["%s_cg_solution_rel_err" % kind] = float(abs(y.download() - ref).max() / abs(ref).max())
+        return res
+    except Exception as e:
+        return {"status": "reference parity run failed: %s" % e}
 
 
 if __name__ == "__main__":
