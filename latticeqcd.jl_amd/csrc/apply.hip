@@ -123,11 +123,14 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             return st;
         }
         float ms[3] = {0.f, 0.f, 0.f};
+        StencilCall t = s;          // the timed applications pack for themselves and leave the fused tails alone
+        t.prepacked = 0; t.pack_next = -1; t.red_slot = -1;
+        const bool tails = s.pack_next >= 0 || s.red_slot >= 0;
         for (int mode = 0; mode < 3; mode++) {
             c->tun.halo_stream_mode = mode;
-            LQCHK(stencil_apply(c, s));
+            LQCHK(stencil_apply(c, t));
             HIPCHK(hipEventRecord(c->ev_tune0, c->stream));
-            for (int k = 0; k < 4; k++) LQCHK(stencil_apply(c, s));
+            for (int k = 0; k < 4; k++) LQCHK(stencil_apply(c, t));
             HIPCHK(hipEventRecord(c->ev_tune1, c->stream));
             HIPCHK(hipEventSynchronize(c->ev_tune1));
             HIPCHK(hipEventElapsedTime(&ms[mode], c->ev_tune0, c->ev_tune1));
@@ -137,6 +140,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             if (ms[mode] < ms[best]) best = mode;
         c->tun.halo_stream_mode = best;
         for (int mode = 0; mode < 3; mode++) c->tun.halo_tuned_us[mode] = (int)(250.f * ms[mode]);
+        if (tails) { t = s; t.prepacked = 0; return stencil_apply(c, t); }      // once more with the caller's tails (the send buffers hold this input's faces)
         return LQCD_OK;      // `out` holds the result of the last tuning application
     }
     if (c->tun.halo_stream_mode == 1) {
@@ -152,7 +156,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             LQCHK(st);
         }
         HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
-        LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+        if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
         LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
@@ -167,7 +171,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         {
             hipStream_t main_stream = c->stream;
             c->stream = c->comm_stream;
-            const int st = s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s);
+            const int st = s.prepacked ? LQCD_OK : (s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
             c->stream = main_stream;
             LQCHK(st);
         }
@@ -175,7 +179,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
     }
-    LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+    if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
     LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 0));
     LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));

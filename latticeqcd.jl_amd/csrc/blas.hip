@@ -165,6 +165,17 @@ int allreduce_host(lqcd_ctx_s* c, double* vals, int n) {
     return LQCD_OK;
 }
 
+// the part of reduce_to_slot behind the one-block sum, for a slot that the producing launch has already filled (the exterior kernel's last
+// block, halo_fuse bit 0): all-reduce over the ranks and the CG's scalar step
+int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op) {
+    if (c->has_comm) NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm_red, c->stream));
+    if (cg_op) {
+        hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
+        HIPCHK(hipGetLastError());
+    }
+    return LQCD_OK;
+}
+
 // device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks
 int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op) {
     const bool multi = allreduce && c->has_comm;   // also at world size 1 (self-partition tests exercise the collective)

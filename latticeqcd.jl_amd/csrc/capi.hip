@@ -182,8 +182,8 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     HIPCHK(hipMalloc((void**)&c->d_partial, npart * 2 * sizeof(double)));
     HIPCHK(hipMalloc((void**)&c->d_scal, SCAL_DOUBLES * sizeof(double)));
     HIPCHK(hipMemset(c->d_scal, 0, SCAL_DOUBLES * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&c->pipe_ctr, 9 * 32 * sizeof(unsigned)));      // work-queue heads of the persistent stencil kernel: zero between launches
-    HIPCHK(hipMemset(c->pipe_ctr, 0, 9 * 32 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&c->pipe_ctr, 10 * 32 * sizeof(unsigned)));      // work-queue heads of the persistent stencil kernel: zero between launches
+    HIPCHK(hipMemset(c->pipe_ctr, 0, 10 * 32 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&c->h_scal, SCAL_DOUBLES * sizeof(double), hipHostMallocDefault));
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
@@ -250,6 +250,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "md_reunitarize")) return &c->tun.md_reunitarize;
     if (!strcmp(key, "nt_blas")) return &c->tun.nt_blas;
     if (!strcmp(key, "cg_fold_scalars")) return &c->tun.cg_fold_scalars;
+    if (!strcmp(key, "halo_fuse")) return &c->tun.halo_fuse;
     if (!strcmp(key, "cg_defer_x")) return &c->tun.cg_defer_x;
     if (!strcmp(key, "staggered_parity_solve")) return &c->tun.staggered_parity_solve;
     if (!strcmp(key, "halo_tuned_us0")) return &c->tun.halo_tuned_us[0];

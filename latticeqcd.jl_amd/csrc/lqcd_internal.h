@@ -330,6 +330,8 @@ struct Tunables {
     int halo_tuned_us[3] = {0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
+    int halo_fuse = 3;        // partitioned fused CG (Wilson, fp64): bit 0 = the exterior's last block does the final reduction (no reduce_final launch),
+                              // bit 1 = the exterior of D p packs the faces D^+ needs and the x/p update packs the new p (no pack launches)
     int cg_fold_scalars = 1;  // several ranks: the scalar steps behind the two all-reduces of a CG iteration run in the consumers' prologues (no one-thread kernels)
     int nt_blas = 1;          // deferred-x CG update kernels stream their fields with non-temporal loads / stores: 842 -> 868 iter/s at 32^3x64
     int md_reunitarize = 1;   // lqcd_gauge_exp_update (U_update!) projects the updated links back onto SU(3) in the same pass: rounding alone carries
@@ -364,6 +366,7 @@ struct lqcd_ctx_s {
     double* d_partial = nullptr;  // [MAX_PARTIAL_BLOCKS * 4]
     double* d_scal = nullptr;     // small device scalar block (solver state)
     double* h_scal = nullptr;     // pinned mirror
+    uint64_t halo_epoch = 0;      // bumped by everything that writes the halo send buffers: a producer's pre-packed faces are valid only while it is unchanged
     unsigned* pipe_ctr = nullptr; // persistent stencil kernel: 8 per-XCD queue heads + 1 exit counter, 128 B apart; all zero between launches
     // halo buffers (sized for Wilson full-lattice: 2 parities * 6 comps * Fh)
     double2* send_fwd[4] = {}, *send_bwd[4] = {}, *recv_fwd[4] = {}, *recv_bwd[4] = {};
@@ -493,6 +496,10 @@ struct StencilCall {
     const double2* gauge12 = nullptr;  // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
     const double2* clover = nullptr;    // packed clover blocks: the Wilson split kernel (variant 1) applies A to xin in its epilogue
     int prec = 0;                 // 0: fp64 fields, 1: fp32 fields (pointers are float2 data, see p32)
+    // partitioned lattices, fused tails of the exterior launch (stencil.hip ext_partial / wilson_pack_site):
+    int red_slot = -1;            // >= 0: the exterior's last block sums all |.|^2 partials of this application into d_scal[red_slot]
+    int pack_next = -1;           // 0 / 1: the exterior also packs the faces of `out` for a following application with this dagger flag
+    int prepacked = 0;            // 1: the send buffers already hold this application's faces (packed by its producer): no pack launch
 };
 // slots of the device scalar block d_scal used by the solvers
 enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18 };
@@ -550,6 +557,7 @@ int blas_axpby(lqcd_ctx_s* c, double ar, double ai, const double2* x, double br,
 int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n);
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n);
 int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0);
+int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op);
 int stream_grid(lqcd_ctx_s* c, size_t n);
 
 // clover.hip

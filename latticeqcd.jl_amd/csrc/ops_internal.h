@@ -19,6 +19,8 @@ void split_general_r(const StencilCall& s, StencilCall& s1, StencilCall& s2);   
 constexpr int UB = 256;     // block size of the solvers' streaming kernels
 struct CgWork {
     lqcd_spinor_s *r, *p, *q, *tmp;
+    uint64_t pack_epoch = 0; // value of the context's halo_epoch right after that pack
+    bool p_packed = false;   // partitioned lattice, halo_fuse bit 1: the send buffers hold the faces of the current search direction (packed by the last x/p update)
     int k = 0;          // iterations enqueued so far (parity selects the p buffer when the x update is deferred: p_k lives in p for even k, in q for odd k)
 };
 int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);

@@ -4,6 +4,7 @@
 // Replaces, behind the C ABI, LatticeDiracOperators.jl's solve_DinvX! (cg / bicgstab / even-odd bicgstab / shiftedcg) -- SURVEY.md
 // 8(a) a4-a5, 8(f) rank 3; reference call sites /root/reference/src/md/AbstractMD.jl:129, src/updates/standardHMC.jl:71.
 #include "ops_internal.h"
+#include "stencil_common.h"      // HArgs, wilson_pack_axpy_block: pack blocks appended to the x/p update launch (partitioned lattices)
 
 #include <algorithm>
 #include <cmath>
@@ -141,15 +142,23 @@ __device__ inline void cg_beta_commit(double* s, const FoldBeta& f) {
         }
     }
 }
-template <bool NT, bool FOLD>      // NT: streaming (non-temporal) loads and stores for fields that are not re-used before they fall out of every cache
+// PACK (partitioned lattice, halo_fuse bit 1): blocks nbf .. gridDim.x - 1 are pack blocks -- they form p' = r + beta p at the face sites in
+// registers and write the send buffers of the next D p (stencil_common.h wilson_pack_axpy_block), so that application needs no pack launch.
+template <bool NT, bool FOLD, bool PACK = false>      // NT: streaming (non-temporal) loads and stores for fields that are not re-used before they fall out of every cache
 __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk,
-                                                      double2* __restrict__ pnext, const double2* __restrict__ r, size_t n) {
+                                                      double2* __restrict__ pnext, const double2* __restrict__ r, size_t n, int nbf, HArgs h, int npx) {
     if (s[S_XDONE] != 0.0) return;
     const FoldBeta fb = cg_beta<FOLD>(s);
     const double al = s[S_ALPHA], be = fb.be;
     const bool cont = fb.cont;
+    if constexpr (PACK) {
+        if ((int)blockIdx.x >= nbf) {
+            if (cont) wilson_pack_axpy_block(h, (int)blockIdx.x - nbf, npx, be);
+            return;
+        }
+    }
     if (cont) {
-        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
             const double2 pv = ldx<NT>(pk + i), rv = ldx<NT>(r + i);
             double2 o;
             o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, dou
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) s[S_APREV] = al;
     } else {
-        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
             const double2 pv = pk[i];
             double2 xv = x[i];
             xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
@@ -166,14 +175,20 @@ __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, dou
     }
     cg_beta_commit<FOLD>(s, fb);
 }
-template <bool NT, bool FOLD>
+template <bool NT, bool FOLD, bool PACK = false>
 __global__ __launch_bounds__(UB) void cg_update_odd(double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ pprev,
-                                                     const double2* __restrict__ pk, const double2* __restrict__ r, size_t n) {
+                                                     const double2* __restrict__ pk, const double2* __restrict__ r, size_t n, int nbf, HArgs h, int npx) {
     if (s[S_XDONE] != 0.0) return;
     const FoldBeta fb = cg_beta<FOLD>(s);
     const double ap = s[S_APREV], al = s[S_ALPHA], be = fb.be;
     const bool cont = fb.cont;
-    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+    if constexpr (PACK) {
+        if ((int)blockIdx.x >= nbf) {
+            if (cont) wilson_pack_axpy_block(h, (int)blockIdx.x - nbf, npx, be);
+            return;
+        }
+    }
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
         const double2 pp = ldx<NT>(pprev + i), pv = ldx<NT>(pk + i);
         double2 xv = ldx<NT>(x + i);
         xv.x = fma(ap, pp.x, xv.x); xv.y = fma(ap, pp.y, xv.y);
@@ -306,11 +321,26 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         const bool defer = c->tun.cg_defer_x != 0;
         lqcd_spinor_s* pk = (defer && (w.k & 1)) ? w.q : w.p;        // q = D^+D p is never written in this form: its buffer is the second p
         lqcd_spinor_s* po = (defer && (w.k & 1)) ? w.p : w.q;
-        LQCHK(op_apply_async(op, w.tmp, pk, 0, c->d_partial, c->tun.cg_skip_done ? c->d_scal : nullptr));   // a no-op once the solve has converged inside a burst
         // several ranks: reduce_final -> all-reduce -> one-thread scalar kernel are three dependent launches per reduction; with `fold` the scalar
         // steps move into the prologues of the kernels that consume them (deferred-x form only)
         const bool fold = c->has_comm && defer && c->tun.cg_fold_scalars;
-        LQCHK(reduce_to_slot(c, nbs, 1, S_PQ, true, fold ? 0 : 1));      // + alpha = rr / pq
+        // partitioned lattice (RCCL path): at small local volumes the iteration is a chain of short dependent launches.  halo_fuse bit 0: the
+        // exterior kernel's last block sums the |.|^2 partials (no reduce_final launch); bit 1: the exterior of D p packs the faces of
+        // tmp = D p for the D^+ that follows and the x/p update packs the new search direction for the next D p (no pack launches).
+        // Wilson r = 1 only (a general-r application is two r = 1 passes with different projectors).
+        const bool part = any_partitioned(c) && c->has_comm && c->local_peers.empty();
+        const bool fr = part && (c->tun.halo_fuse & 1);
+        const bool fp = part && defer && (c->tun.halo_fuse & 2) && op->kind == LQCD_WILSON && op->r == 1.0;
+        {
+            StencilCall s1;
+            LQCHK(make_full_call(op, w.tmp, pk, 0, s1));
+            s1.norm_partial = c->d_partial;
+            s1.skip_flag = c->tun.cg_skip_done ? c->d_scal : nullptr;      // a no-op once the solve has converged inside a burst
+            if (fr) s1.red_slot = S_PQ;
+            if (fp) { s1.pack_next = 1; s1.prepacked = (w.p_packed && w.pack_epoch == c->halo_epoch) ? 1 : 0; }
+            LQCHK(stencil_apply(c, s1));
+        }
+        LQCHK(fr ? reduce_tail(c, 1, S_PQ, fold ? 0 : 1) : reduce_to_slot(c, nbs, 1, S_PQ, true, fold ? 0 : 1));      // + alpha = rr / pq
         apply_bc(c, op->bc);
         StencilCall s2;
         LQCHK(make_full_call(op, po, w.tmp, 1, s2));          // update mode writes r only: `out` is a placeholder (the buffer that is dead until the p update)
@@ -319,19 +349,41 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         s2.upd_scal = c->d_scal;
         s2.upd[0] = spinor_block(w.r, 0);
         s2.upd[1] = spinor_block(w.r, 1);
+        if (fr) s2.red_slot = S_RRNEW;
+        if (fp) s2.prepacked = 1;
         LQCHK(stencil_apply(c, s2));
-        LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, fold ? 0 : 2));   // + beta, convergence flag
+        LQCHK(fr ? reduce_tail(c, 1, S_RRNEW, fold ? 0 : 2) : reduce_to_slot(c, nbs, 1, S_RRNEW, true, fold ? 0 : 2));   // + beta, convergence flag
         const int nbu = stream_grid(c, n);
-        const dim3 ug(nbu), ub(UB);
+        HArgs h = HArgs();
+        int npx = 0, npack = 0;
+        if (fp) {
+            int nt = 0;
+            for (int mu = 0; mu < 4; mu++)
+                if (c->geom.part[mu]) nt = std::max(nt, 2 * face_half_sites(c->geom, mu));
+            npx = (nt + UB - 1) / UB; npack = 8 * npx;
+            h.g = c->geom;
+            h.gauge = op->gauge->data;
+            h.parity_mode = 2; h.dagger = 0;
+            for (int q = 0; q < 2; q++) { h.in[q] = spinor_block(pk, q); h.upd[q] = spinor_block(w.r, q); }
+            for (int mu = 0; mu < 4; mu++) {
+                const size_t cnt = (size_t)2 * 6 * face_half_sites(c->geom, mu);      // [send_fwd | send_bwd] back to back (stencil.hip make_hargs)
+                h.send_fwd[mu] = c->send_fwd[mu]; h.send_bwd[mu] = c->send_fwd[mu] + cnt;
+            }
+        }
+        const dim3 ug(nbu + npack), ub(UB);
+#define LQ_UPD3(KERN, NT_, FO_, A, B, C) do { \
+            if (fp) hipLaunchKernelGGL((KERN<NT_, FO_, true>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n, nbu, h, npx); \
+            else hipLaunchKernelGGL((KERN<NT_, FO_, false>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n, nbu, h, npx); } while (0)
 #define LQ_UPD(KERN, A, B, C) do { \
-            if (c->tun.nt_blas) { if (fold) hipLaunchKernelGGL((KERN<true, true>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); \
-                                  else hipLaunchKernelGGL((KERN<true, false>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); } \
-            else { if (fold) hipLaunchKernelGGL((KERN<false, true>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); \
-                   else hipLaunchKernelGGL((KERN<false, false>), ug, ub, 0, c->stream, c->d_scal, x->data, A, B, C, n); } } while (0)
+            if (c->tun.nt_blas) { if (fold) LQ_UPD3(KERN, true, true, A, B, C); else LQ_UPD3(KERN, true, false, A, B, C); } \
+            else { if (fold) LQ_UPD3(KERN, false, true, A, B, C); else LQ_UPD3(KERN, false, false, A, B, C); } } while (0)
         if (!defer) hipLaunchKernelGGL(cg_update_xp, ug, ub, 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
         else if (w.k & 1) LQ_UPD(cg_update_odd, po->data, pk->data, w.r->data);
         else LQ_UPD(cg_update_even, pk->data, po->data, w.r->data);
 #undef LQ_UPD
+#undef LQ_UPD3
+        w.p_packed = fp;
+        if (fp) w.pack_epoch = ++c->halo_epoch;
         HIPCHK(hipGetLastError());
         w.k++;
         return LQCD_OK;

@@ -864,6 +864,7 @@ __device__ __forceinline__ real wilson_ext_face(const HArgs& k, int side) {
     const real coef = k.upd_scal ? -k.upd_scal[S_ALPHA] * k.b : k.b;
     real2* __restrict__ o = (k.upd_scal ? (pout ? k.upd[1] : k.upd[0]) : (pout ? k.out[1] : k.out[0])) + sp12_off(i);
     real corr = 0.0;
+    cd fin[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) {
         cd v = ld(o + co12(j));
@@ -872,19 +873,55 @@ __device__ __forceinline__ real wilson_ext_face(const HArgs& k, int side) {
         v.im = fma(coef, acc[j].im, v.im);
         corr += (v.re * v.re + v.im * v.im) - before;
         st(o + co12(j), v);
+        fin[j] = v;
+    }
+    if (k.pack_next >= 0) {
+        // the finished site is an input site of the next application: its packed faces belong to the slot of the RECEIVING parity 1 - pout
+        const int nslot = k.parity_mode == 2 ? 1 - pout : 0;
+        wilson_pack_site<0>(k, fin, c, nslot, pout, i, k.pack_next);
+        wilson_pack_site<1>(k, fin, c, nslot, pout, i, k.pack_next);
+        wilson_pack_site<2>(k, fin, c, nslot, pout, i, k.pack_next);
+        wilson_pack_site<3>(k, fin, c, nslot, pout, i, k.pack_next);
     }
     return corr;
 }
 
-// block-level sum of the per-thread norm corrections of an exterior kernel (128 threads)
+// block-level sum of the per-thread norm corrections of an exterior kernel (128 threads); with red_out the last block to arrive sums every
+// partial of the application (interior blocks + these corrections) in a fixed order -- the one-block reduce_final launch behind the
+// exterior disappears from the critical path of a partitioned CG iteration.  Visibility: release fence + device-scope arrival counter on
+// the producers, acquire fence on the last block (MI355X guide, inter-workgroup recipe); the interior's partials come from an earlier launch.
 __device__ inline void ext_partial(const HArgs& k, real corr) {
     if (!k.norm_partial) return;
     __shared__ double red[2];
+    __shared__ unsigned last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) corr += __shfl_down(corr, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = corr;
     __syncthreads();
-    if (threadIdx.x == 0) k.norm_partial[k.partial_offset + blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1];
+    if (threadIdx.x == 0) {
+        k.norm_partial[k.partial_offset + blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1];
+        if (k.red_out) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(k.red_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = t == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    if (!k.red_out) return;
+    __syncthreads();
+    if (!last) return;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < k.red_n; j += 128) s += __hip_atomic_load(k.norm_partial + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        k.red_out[0] = red[0] + red[1];
+        __hip_atomic_store(k.red_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <bool DAG>
@@ -1191,6 +1228,10 @@ static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
     h.partial_offset = stencil_num_blocks(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr);   // corrections are appended to the interior's partials
     h.upd_scal = s.upd_scal;
     h.upd[0] = (real2*)s.upd[0]; h.upd[1] = (real2*)s.upd[1];
+    h.red_out = (s.norm_partial && s.red_slot >= 0) ? c->d_scal + s.red_slot : nullptr;
+    h.red_ctr = c->pipe_ctr + 8 * 32 + 16;      // a word of its own next to the persistent kernel's exit counter
+    h.red_n = h.partial_offset + ((max_face_threads(c, s.parity_mode) + 127) / 128) * 8;
+    h.pack_next = s.pack_next;
     return h;
 }
 
@@ -1205,6 +1246,7 @@ int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s) {
     const int nt = max_face_threads(c, s.parity_mode);
     if (nt == 0) return LQCD_OK;
     HArgs h = make_hargs(c, s);
+    c->halo_epoch++;
     dim3 grid((nt + 127) / 128, 8), block(128);
     if (s.kind == LQCD_WILSON) hipLaunchKernelGGL(wilson_pack, grid, block, 0, c->stream, h);
     else hipLaunchKernelGGL(staggered_pack, grid, block, 0, c->stream, h);
@@ -1216,6 +1258,8 @@ int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
     const int nt = max_face_threads(c, s.parity_mode);
     if (nt == 0) return LQCD_OK;
     HArgs h = make_hargs(c, s);
+    if (s.kind != LQCD_WILSON) h.pack_next = -1;      // only the Wilson exterior packs for a following application
+    if (h.pack_next >= 0) c->halo_epoch++;
     dim3 grid((nt + 127) / 128, 8), block(128);
     if (s.kind == LQCD_WILSON) {
         if (s.dagger) hipLaunchKernelGGL(wilson_exterior<true>, grid, block, 0, c->stream, h);

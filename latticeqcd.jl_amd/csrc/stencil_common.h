@@ -158,6 +158,14 @@ struct HArgs {  // halo kernels
     int partial_offset;
     const double* upd_scal;   // CG update mode: target is upd (r) and the coefficient is -alpha*b
     real2* upd[2];
+    // fused tail of the launch (partitioned CG, critical path at small local volumes): the LAST block to finish sums every |.|^2 partial
+    // of this application (interior + exterior corrections, red_n of them) into red_out -- no separate one-block reduction launch
+    double* red_out;
+    unsigned* red_ctr;        // arrival counter, zero between launches (reset by the last block)
+    int red_n;
+    // >= 0: every owner thread also packs the faces of the site it just finished for the NEXT application (its dagger flag) -- the
+    // following stencil call skips its pack launch (StencilCall::prepacked)
+    int pack_next;
 };
 
 // workgroup -> (chunk of consecutive checkerboard sites, parity).  Observed (not contractual) dispatch: block b runs on
@@ -513,6 +521,89 @@ __device__ inline void load_link_any(cd (&u)[9], const real2* __restrict__ U, in
     }
 #endif
     load_link_raw<R12, NT>(u, U, Us);
+}
+
+// pack the faces a finished site lies on, from its 12 components in registers, for an application with dagger flag `dag`: the arithmetic of
+// wilson_pack_dir (lower face: P psi -> send_bwd; upper face: U^+ P psi -> send_fwd), so a prepacked application sees the same bits
+template <int NU>
+__device__ __forceinline__ void wilson_pack_site(const HArgs& k, const cd (&v)[12], const int (&c)[4], int slot, int ps, int i, int dag) {
+    const Geom& g = k.g;
+    if (!g.part[NU]) return;
+    const bool lo = c[NU] == 0, hi = c[NU] == g.L[NU] - 1;
+    if (!lo && !hi) return;
+    const int Fh = g.Vh / g.L[NU];
+    const int f = coords_to_face(g, NU, c);
+    if (lo) {
+        cd h0[3], h1[3];
+        if (NU == 3) { if (dag) project_regs<NU, -1>(h0, h1, v); else project_regs<NU, 1>(h0, h1, v + 6); }
+        else { if (dag) project_regs<NU, -1>(h0, h1, v); else project_regs<NU, 1>(h0, h1, v); }
+        real2* dst = k.send_bwd[NU] + (size_t)slot * 6 * Fh + f;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { st(dst + (size_t)cc * Fh, h0[cc]); st(dst + (size_t)(3 + cc) * Fh, h1[cc]); }
+    }
+    if (hi) {
+        cd h0[3], h1[3], u[9], x0[3], x1[3];
+        if (NU == 3) { if (dag) project_regs<NU, 1>(h0, h1, v + 6); else project_regs<NU, -1>(h0, h1, v); }
+        else { if (dag) project_regs<NU, 1>(h0, h1, v); else project_regs<NU, -1>(h0, h1, v); }
+        load_link(u, k.gauge + glink_off(g, ps, NU, i), glink_stride(g));
+        su3_mv<true>(x0, u, h0);
+        su3_mv<true>(x1, u, h1);
+        real2* dst = k.send_fwd[NU] + (size_t)slot * 6 * Fh + f;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { st(dst + (size_t)cc * Fh, x0[cc]); st(dst + (size_t)(3 + cc) * Fh, x1[cc]); }
+    }
+}
+
+// pack blocks appended to the CG's x/p update launch (solvers.hip): thread -> (direction, side, slot, face site) like wilson_pack_dir, the new
+// search direction p' = r + beta p at that site is formed in registers with the update kernel's own fma (same bits as the value the flat
+// part of the launch stores) and packed for the next D p.  k.in = p_k, k.upd = r (read only), pb = index of the pack block, npx = pack
+// blocks per (direction, side).
+template <int MU>
+__device__ inline void wilson_pack_axpy_dir(const HArgs& k, int side, int t, double be) {
+    const Geom& g = k.g;
+    if (!g.part[MU]) return;
+    const int Fh = g.Vh / g.L[MU];
+    if (t >= 2 * Fh) return;
+    const int slot = t / Fh, f = t - slot * Fh;       // slot = parity of the RECEIVING site
+    const int ps = 1 - slot;
+    int c[4];
+    face_to_coords(g, MU, side ? g.L[MU] - 1 : 0, ps, f, c);
+    const int i = coords_to_cb(g, c);
+    const real2* __restrict__ pp = (ps ? k.in[1] : k.in[0]) + sp12_off(i);
+    const real2* __restrict__ rp = (ps ? k.upd[1] : k.upd[0]) + sp12_off(i);
+    cd v[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const cd pv = ld(pp + co12(j)), rv = ld(rp + co12(j));
+        v[j] = mk(fma(be, pv.re, rv.re), fma(be, pv.im, rv.im));
+    }
+    // only this face: the site's other faces are packed by the threads of those faces
+    cd h0[3], h1[3];
+    if (side == 0) {
+        if (MU == 3) project_regs<MU, 1>(h0, h1, v + 6); else project_regs<MU, 1>(h0, h1, v);
+        real2* dst = k.send_bwd[MU] + (size_t)slot * 6 * Fh + f;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { st(dst + (size_t)cc * Fh, h0[cc]); st(dst + (size_t)(3 + cc) * Fh, h1[cc]); }
+    } else {
+        project_regs<MU, -1>(h0, h1, v);
+        cd u[9], x0[3], x1[3];
+        load_link(u, k.gauge + glink_off(g, ps, MU, i), glink_stride(g));
+        su3_mv<true>(x0, u, h0);
+        su3_mv<true>(x1, u, h1);
+        real2* dst = k.send_fwd[MU] + (size_t)slot * 6 * Fh + f;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { st(dst + (size_t)cc * Fh, x0[cc]); st(dst + (size_t)(3 + cc) * Fh, x1[cc]); }
+    }
+}
+__device__ inline void wilson_pack_axpy_block(const HArgs& k, int pb, int npx, double be) {
+    const int y = pb / npx, x = pb - y * npx;
+    const int side = y & 1, t = x * (int)blockDim.x + (int)threadIdx.x;
+    switch (y >> 1) {
+    case 0: wilson_pack_axpy_dir<0>(k, side, t, be); break;
+    case 1: wilson_pack_axpy_dir<1>(k, side, t, be); break;
+    case 2: wilson_pack_axpy_dir<2>(k, side, t, be); break;
+    default: wilson_pack_axpy_dir<3>(k, side, t, be); break;
+    }
 }
 
 inline int persist_grid(lqcd_ctx_s* c, int nvirt) {

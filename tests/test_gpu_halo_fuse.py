@@ -1,0 +1,70 @@
+"""Partitioned fused CG with the fused tails of the exterior / update launches (tunable halo_fuse): bit 0 = the
+exterior kernel's last block sums the |.|^2 partials (no reduce_final launch), bit 1 = the exterior of D p packs the faces D^+ needs and the
+x/p update packs the new search direction (no pack launches).  Run through the real RCCL path on one GPU (self-partition, world-size-1
+communicators).  Pre-packed faces carry the bits a pack launch would have produced, so bit 1 alone must not change a single bit of the
+solution; bit 0 changes the summation order of the norms (iterates differ in rounding only)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CODE = textwrap.dedent("""
+    import os, sys, numpy as np
+    sys.path.insert(0, os.getcwd())
+    import latticeqcd_jl_amd as lq
+    from oracle import oracle as orc
+    L, K, BC = %s, 0.141139, (1, 1, 1, -1)
+    lat = lq.Lattice(L)
+    lat.comm_init(lq.comm_unique_id())
+    U = orc.hot_gauge(L, 111)
+    Ud = lq.Gaugefields(lat).upload(U)
+    D = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": K, "boundarycondition": BC, "eps_CG": 1e-19})
+    psi = orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 112)
+    x = lq.Fermionfields(lat, lq.WILSON).upload(psi)
+    xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, K, 1.0, BC, eps=1e-19)
+    assert st == 0
+    sols = {}
+    for mode in (-1, 0, 1, 2):
+        for fold in (1, 0):
+            for fuse in (0, 1, 2, 3):
+                lat.set_param("halo_stream_mode", mode); lat.set_param("cg_fold_scalars", fold); lat.set_param("halo_fuse", fuse)
+                sol = x.similar()
+                it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+                s = sol.download()
+                err = np.abs(s - xo).max() / np.abs(xo).max()
+                assert abs(it - ito) <= 1 and rr < 1e-19 and err < 1e-9, (mode, fold, fuse, it, ito, rr, err)
+                sols[(mode, fold, fuse)] = s
+            assert np.array_equal(sols[(mode, fold, 0)], sols[(mode, fold, 2)]), ("pre-packed faces changed the solution", mode, fold)
+            assert np.array_equal(sols[(mode, fold, 1)], sols[(mode, fold, 3)]), ("pre-packed faces changed the solution", mode, fold)
+    # the staggered operator takes the fused reduction only
+    Ds = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Staggered", "mass": 0.5, "boundarycondition": BC, "eps_CG": 1e-19})
+    ps = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 113)
+    xs = lq.Fermionfields(lat, lq.STAGGERED).upload(ps)
+    xo, ito, rro, st = orc.cg_DdagD(orc.STAGGERED, U, ps, L, 0.5, 1.0, BC, eps=1e-19)
+    for fuse in (0, 3):
+        lat.set_param("halo_fuse", fuse)
+        sol = xs.similar()
+        it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(Ds), xs, return_info=True)
+        assert st == 0 and abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (fuse, it, ito)
+    # general r (two r = 1 passes per application): no pre-packing, same answer
+    Dr = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": 0.12, "r": 0.8, "boundarycondition": BC, "eps_CG": 1e-19})
+    xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, 0.12, 0.8, BC, eps=1e-19)
+    lat.set_param("halo_fuse", 3)
+    sol = x.similar()
+    it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(Dr), x, return_info=True)
+    assert st == 0 and abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (it, ito)
+    print("HALO_FUSE_OK")
+""")
+
+
+@pytest.mark.parametrize("L,mask", [((8, 4, 6, 8), "8"), ((8, 4, 6, 8), "14"), ((8, 4, 6, 8), "15"), ((16, 8, 8, 4), "14")])
+def test_fused_tails_on_the_rccl_path(lq, L, mask):
+    assert lq.lib.device_count() > 0, "no HIP device visible: the product has no CPU fallback"
+    env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", CODE % (L,)], capture_output=True, text=True, env=env, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "HALO_FUSE_OK" in r.stdout, (mask, r.stdout[-1500:], r.stderr[-3000:])
