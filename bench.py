@@ -35,8 +35,8 @@ KERNEL_NAMES = {0: "wilson_interior", 1: "wilson_dirsplit", 2: "wilson_hopsplit"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lattice", type=str, default="32,32,32,64")
     ap.add_argument("--dslash-reps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,7 +155,7 @@ def main():
         "dslash_gflops": dslash_gflops,
         "dslash_ms": ms_dslash,
         "dslash_ms_median_per_launch_events": ms_median,
-        "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(lat.get_param("dslash_variant"), "wilson") + (("<false,true,false>" if recon_active else "<false,false,false>") if lat.get_param("dslash_variant") == 1 else "") + " (mul!(y,D,x))", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": kernel_name(lat, recon_active) + " (mul!(y,D,x))", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_over_bytes_moved": (traffic / (moved_per_site * Vloc)) if traffic else None,
                      "algorithmic_bytes_per_site": WILSON_BYTES_PER_SITE, "sites_per_launch": Vloc,
@@ -321,6 +321,19 @@ def measure_traffic(args):
     src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only) over 6 launches of the kernel; "
            "(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 64 B per 128-B request)")
     return tdef, t18, src
+
+
+def kernel_name(lat, recon_active):
+    """name of the Dslash kernel the library launches under the current tunables (what a rocprofv3 kernel trace of this run shows)"""
+    v = lat.get_param("dslash_variant")
+    if v != 1:
+        return KERNEL_NAMES.get(v, "wilson")
+    pipe = lat.get_param("dslash_pipe")
+    if pipe == 1:
+        return "wilson_dirsplit_pipe<false,%s,true>" % ("true" if recon_active else "false")
+    if pipe == 2 and recon_active:
+        return "wilson_dirsplit_s<false,true,true>"
+    return "wilson_dirsplit<false,true,false>" if recon_active else "wilson_dirsplit<false,false,false>"
 
 
 def cpu_baseline(lq, U, b, gL):

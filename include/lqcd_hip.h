@@ -74,7 +74,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
 /* tuning knobs (kernel variants); unknown key -> LQCD_ERR_ARG.  Keys: dslash_variant (0 site-per-lane, 1 direction split
  * [default], 2 hop split, 3 persistent hop split, 4 lane split = four directions in the four 16-lane rows of a wave combined by
  * v_permlane swaps, 5 direction split with the footprint of four workgroups per CU, 6 direction split with the x / y neighbour spinors staged
- * through LDS, 7 both parities of a chunk in one 512-thread workgroup), dslash_block, xcd_remap, xcd_nsub, xcd_ysplit, cg_fused (0 reference form, 1, 2 fused
+ * through LDS, 7 both parities of a chunk in one 512-thread workgroup; variants 2-8 exist only in LQCD_VARIANTS=1 builds of the library --
+ * read-only key variants_built -- and run variant 1 otherwise), dslash_block, xcd_remap, xcd_nsub, xcd_ysplit, cg_fused (0 reference form, 1, 2 fused
  * [default]), graph (1: hipGraph replay of CG bursts), gauge_recon (12 [default]: the split kernels read two rows per link and rebuild the
  * third -- applied only while every link of the field is unitary to 1e-14, results within the fp64 Dslash tolerance; 18: all
  * 18 stored reals are always read), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge (bit 0 [default]: the backward = last use of a link is a non-temporal load; bit 1: the forward use too), nt_store (1 [default]:

@@ -184,10 +184,10 @@ extern "C" int lqcd_cg_session_end(lqcd_op_t op) {
     ARGCHK(op && op->ctx->cg_session && static_cast<CgSession*>(op->ctx->cg_session)->op == op, "lqcd_cg_session_end: no open session for this operator");
     CgSession* ses = static_cast<CgSession*>(op->ctx->cg_session);
     CgWork& w = ses->w;
-    (void)cg_flush_x(op, ses->x, w);
+    const int st = cg_flush_x(op, ses->x, w);       // a pending deferred x update; its status is the status of the session
     (void)hipStreamSynchronize(op->ctx->stream);
     scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
     delete ses;
     op->ctx->cg_session = nullptr;
-    return LQCD_OK;
+    return st;
 }

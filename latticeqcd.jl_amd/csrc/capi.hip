@@ -258,6 +258,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "halo_tuned_us2")) return &c->tun.halo_tuned_us[2];
     if (!strcmp(key, "halo_merge")) return &c->tun.halo_merge;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
+    if (!strcmp(key, "variants_built")) return &c->tun.variants_built;
     if (!strcmp(key, "lds_pad_kb")) return &c->tun.lds_pad_kb;
     if (!strcmp(key, "xcd_nsub")) return &c->tun.xcd_nsub;
     if (!strcmp(key, "xcd_ysplit")) return &c->tun.xcd_ysplit;
@@ -268,6 +269,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "dslash_pipe")) return &c->tun.dslash_pipe;
     if (!strcmp(key, "pipe_per_cu")) return &c->tun.pipe_per_cu;
     if (!strcmp(key, "pipe_grid")) return &c->tun.pipe_grid;
+    if (!strcmp(key, "pipe_chunks_per_wg")) return &c->tun.pipe_chunks_per_wg;
     if (!strcmp(key, "pipe_min_chunks")) return &c->tun.pipe_min_chunks;
     return nullptr;
 }

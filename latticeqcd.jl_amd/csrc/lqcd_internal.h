@@ -308,10 +308,13 @@ struct Tunables {
     int cg_fused = 2;         // 0: reference form (c1 = p.q), 1: |Dp|^2 from the stencil, 2: + r-update fused into D^+, x/p updates merged
     int graph = 0;            // capture solver iterations in a hipGraph
     int persist_per_cu = 2;   // variant 3: resident workgroups per CU
-    int dslash_pipe = 0;      // Wilson r = 1, variant 1, large lattices: the persistent, software-pipelined form of the direction-split kernel
-                              // (stencil.hip wilson_dirsplit_pipe); bit-identical Dslash output, |.|^2 partials per persistent workgroup
+    int dslash_pipe = 2;      // Wilson r = 1, variant 1, lattices whose z-planes are whole chunks: 1 = the persistent, software-pipelined form of the
+                              // direction-split kernel (stencil.hip wilson_dirsplit_pipe; |.|^2 partials per persistent workgroup), 2 = variant 1's
+                              // schedule on the persistent kernel's scalar addressing (wilson_dirsplit_s, default: 12-real links only, CG +1.6 % at
+                              // 32^3 x 64, profiles/r03_pipe_ab.log); both bit-identical to variant 1; 0 = variant 1 itself
     int pipe_per_cu = 0;      // persistent kernel: resident workgroups per CU (0: what the
                               // kernel's registers / LDS admit -- 3 in the fp64 build, 5 in the fp32 build)
+    int pipe_chunks_per_wg = 2;   // dslash_pipe = 3: consecutive virtual blocks one (non-persistent) workgroup walks with the pipelined loop
     int pipe_grid = 0;        // persistent kernel: explicit number of persistent workgroups (rounded down to a multiple of 8; tests), 0 = CUs x pipe_per_cu
     int pipe_min_chunks = 8;  // the persistent kernel runs only where every persistent workgroup has at least this many chunks to walk
 #ifdef LQCD_ABLATE
@@ -330,8 +333,10 @@ struct Tunables {
     int halo_tuned_us[3] = {0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
-    int halo_fuse = 3;        // partitioned fused CG (Wilson, fp64): bit 0 = the exterior's last block does the final reduction (no reduce_final launch),
-                              // bit 1 = the exterior of D p packs the faces D^+ needs and the x/p update packs the new p (no pack launches)
+    int halo_fuse = 2;        // partitioned fused CG (Wilson, fp64): bit 0 = the exterior's last block does the final reduction (no reduce_final launch),
+                              // bit 1 = the exterior of D p packs the faces D^+ needs and the x/p update packs the new p (no pack launches).
+                              // One-GPU proxy at the N = 8 local volume (profiles/r03_halo_fuse_proxy.log): bit 1 +1.2 %, bit 0 -7 % (the last
+                              // block's serial tail costs more than the 4 us launch it replaces) -> default 2
     int cg_fold_scalars = 1;  // several ranks: the scalar steps behind the two all-reduces of a CG iteration run in the consumers' prologues (no one-thread kernels)
     int nt_blas = 1;          // deferred-x CG update kernels stream their fields with non-temporal loads / stores: 842 -> 868 iter/s at 32^3x64
     int md_reunitarize = 1;   // lqcd_gauge_exp_update (U_update!) projects the updated links back onto SU(3) in the same pass: rounding alone carries
@@ -349,6 +354,11 @@ struct Tunables {
     int gauge_recon = 12;     // 12 (default): the direction-split kernels read 2 rows per link and rebuild the third -- only while every
                               // link of the field is unitary to 1e-14 (checked per gauge version), otherwise the 18 stored reals are
                               // read; bytes/site 960 -> 768 (Wilson), 672 -> 480 (staggered).  18: always read all 18 reals.
+#ifdef LQCD_VARIANTS
+    int variants_built = 1;   // read-only: the library carries the opt-in Wilson kernel variants 2-8 (stencil_alt.hip, -DLQCD_VARIANTS)
+#else
+    int variants_built = 0;   // read-only: dslash_variant >= 2 runs variant 1 (built without -DLQCD_VARIANTS)
+#endif
     int recon_active = 0;     // read-only: 1 if the last Wilson operator application used the 12-real links
 };
 
@@ -547,6 +557,7 @@ inline bool op_fused_clover(const lqcd_op_s* op) {
     return op->csw != 0.0 && op->clover && op->clover_tmp && op->r == 1.0 && op->ctx->tun.dslash_variant == 1 && op->ctx->tun.clover_fused;
 }
 int wilson_pipe_grid(lqcd_ctx_s* c, int nvirt, int prec);
+int wilson_pipe_per_wg(lqcd_ctx_s* c, int nvirt);
 int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec = 0, bool clover = false);
 
 // BLAS-1 / reductions (blas.hip)

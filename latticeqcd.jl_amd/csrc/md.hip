@@ -491,8 +491,9 @@ __device__ __forceinline__ bool site_of_thread(const Geom& g, int& p, int& i) {
 }
 // op 0: C = t A (substitute_U! with t = 1)   op 1: C = exp(t A) (exptU!)   op 2: C = A B (mul!)   op 3: C += t * TA(A) (Traceless_antihermitian_add!)
 template <int OP>
-__global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* __restrict__ C, int mc, const double2* __restrict__ A, int ma,
-                                                     const double2* __restrict__ B, int mb, double t) {
+// C, A and B may be slots of one allocation, and C may be A or B itself (substitute_U!(U, U), mul!(temp1, U[mu], dSdUmu) on slots of one
+// storage): no __restrict__ -- every thread loads all of its inputs before it stores, which is what makes the in-place forms well defined
+__global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* C, int mc, const double2* A, int ma, const double2* B, int mb, double t) {
     int p, i;
     if (!site_of_thread(g, p, i)) return;
     const int Gs = glink_stride(g);

@@ -457,6 +457,8 @@ extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lq
         ARGCHK(xs[j] && xs[j]->ctx == op->ctx && xs[j]->kind == op->kind && xs[j]->subset == LQCD_FULL && xs[j] != b,
                "lqcd_solve_multishift_mixed_cg: xs[j] must be distinct FULL spinors of the operator");
         ARGCHK(sigma[j] >= 0.0, "lqcd_solve_multishift_mixed_cg: shifts must be non-negative");
+        ARGCHK(xs[j] != x0, "lqcd_solve_multishift_mixed_cg: xs[j] and x0 must be different fields (every system is updated in place on its own handle)");
+        for (int i = 0; i < j; i++) ARGCHK(xs[i] != xs[j], "lqcd_solve_multishift_mixed_cg: the xs[j] must be pairwise different fields");
     }
     if (x0) LQCHK(check_full(op, x0, b, "lqcd_solve_multishift_mixed_cg"));
     lqcd_ctx_s* c = op->ctx;

@@ -21,6 +21,7 @@ struct CgWork {
     lqcd_spinor_s *r, *p, *q, *tmp;
     uint64_t pack_epoch = 0; // value of the context's halo_epoch right after that pack
     bool p_packed = false;   // partitioned lattice, halo_fuse bit 1: the send buffers hold the faces of the current search direction (packed by the last x/p update)
+    int form = -1;      // iteration form fixed at cg_setup (0 plain, 1 deferred x, 2 small-lattice): the tunables may change while a session is open
     int k = 0;          // iterations enqueued so far (parity selects the p buffer when the x update is deferred: p_k lives in p for even k, in q for odd k)
 };
 int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);

@@ -131,9 +131,9 @@ __device__ inline FoldBeta cg_beta(double* s) {
     return f;
 }
 template <bool FOLD>
-__device__ inline void cg_beta_commit(double* s, const FoldBeta& f) {
+__device__ inline void cg_beta_commit(double* s, const FoldBeta& f, bool first_block) {
     if constexpr (FOLD) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (first_block && threadIdx.x == 0) {
             const double rrn = s[S_RRNEW];
             s[S_BETA] = f.be;
             s[S_RR] = rrn;
@@ -142,8 +142,9 @@ __device__ inline void cg_beta_commit(double* s, const FoldBeta& f) {
         }
     }
 }
-// PACK (partitioned lattice, halo_fuse bit 1): blocks nbf .. gridDim.x - 1 are pack blocks -- they form p' = r + beta p at the face sites in
-// registers and write the send buffers of the next D p (stencil_common.h wilson_pack_axpy_block), so that application needs no pack launch.
+// PACK (partitioned lattice, halo_fuse bit 1): the FIRST npk blocks of the launch are pack blocks (dispatched first: the faces are what the next
+// launch on the critical path waits for) -- they form p' = r + beta p at the face sites in registers and write the send buffers of the next
+// D p (stencil_common.h wilson_pack_axpy_block), so that application needs no pack launch; the other nbf blocks do the flat update.
 template <bool NT, bool FOLD, bool PACK = false>      // NT: streaming (non-temporal) loads and stores for fields that are not re-used before they fall out of every cache
 __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk,
                                                       double2* __restrict__ pnext, const double2* __restrict__ r, size_t n, int nbf, HArgs h, int npx) {
@@ -151,29 +152,30 @@ __global__ __launch_bounds__(UB) void cg_update_even(double* __restrict__ s, dou
     const FoldBeta fb = cg_beta<FOLD>(s);
     const double al = s[S_ALPHA], be = fb.be;
     const bool cont = fb.cont;
+    const int npk = PACK ? 8 * npx : 0, fb0 = (int)blockIdx.x - npk;      // fb0: index among the flat blocks
     if constexpr (PACK) {
-        if ((int)blockIdx.x >= nbf) {
-            if (cont) wilson_pack_axpy_block(h, (int)blockIdx.x - nbf, npx, be);
+        if (fb0 < 0) {
+            if (cont) wilson_pack_axpy_block(h, (int)blockIdx.x, npx, be);
             return;
         }
     }
     if (cont) {
-        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
+        for (size_t i = (size_t)fb0 * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
             const double2 pv = ldx<NT>(pk + i), rv = ldx<NT>(r + i);
             double2 o;
             o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
             stx<NT>(pnext + i, o);
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) s[S_APREV] = al;
+        if (fb0 == 0 && threadIdx.x == 0) s[S_APREV] = al;
     } else {
-        for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
+        for (size_t i = (size_t)fb0 * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
             const double2 pv = pk[i];
             double2 xv = x[i];
             xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
             x[i] = xv;
         }
     }
-    cg_beta_commit<FOLD>(s, fb);
+    cg_beta_commit<FOLD>(s, fb, fb0 == 0);
 }
 template <bool NT, bool FOLD, bool PACK = false>
 __global__ __launch_bounds__(UB) void cg_update_odd(double* __restrict__ s, double2* __restrict__ x, double2* __restrict__ pprev,
@@ -182,13 +184,14 @@ __global__ __launch_bounds__(UB) void cg_update_odd(double* __restrict__ s, doub
     const FoldBeta fb = cg_beta<FOLD>(s);
     const double ap = s[S_APREV], al = s[S_ALPHA], be = fb.be;
     const bool cont = fb.cont;
+    const int npk = PACK ? 8 * npx : 0, fb0 = (int)blockIdx.x - npk;
     if constexpr (PACK) {
-        if ((int)blockIdx.x >= nbf) {
-            if (cont) wilson_pack_axpy_block(h, (int)blockIdx.x - nbf, npx, be);
+        if (fb0 < 0) {
+            if (cont) wilson_pack_axpy_block(h, (int)blockIdx.x, npx, be);
             return;
         }
     }
-    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
+    for (size_t i = (size_t)fb0 * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
         const double2 pp = ldx<NT>(pprev + i), pv = ldx<NT>(pk + i);
         double2 xv = ldx<NT>(x + i);
         xv.x = fma(ap, pp.x, xv.x); xv.y = fma(ap, pp.y, xv.y);
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(UB) void cg_update_odd(double* __restrict__ s, doub
             stx<NT>(pprev + i, o);
         }
     }
-    cg_beta_commit<FOLD>(s, fb);
+    cg_beta_commit<FOLD>(s, fb, fb0 == 0);
 }
 // x += alpha_k p_k for a window that ended (unconverged) on an even iteration
 __global__ __launch_bounds__(UB) void cg_flush_kernel(const double* __restrict__ s, double2* __restrict__ x, const double2* __restrict__ pk, size_t n) {
@@ -268,8 +271,11 @@ static bool cg_small_ok(lqcd_op_s* op, int nbs) {
     lqcd_ctx_s* c = op->ctx;
     if (any_partitioned(c) || c->has_comm || nbs > 1024) return false;
     const int v = c->tun.dslash_variant;
+#ifdef LQCD_VARIANTS
     if (op->kind == LQCD_WILSON && op->r == 1.0 && (v == 2 || v == 3)) return false;
-    if (wilson_pipe_applies(c, op->kind, op->r, 2, op_fused_clover(op))) return false;    // persistent kernel: few partials, but a large lattice
+#endif
+    (void)v;
+    if ((c->tun.dslash_pipe == 1 || c->tun.dslash_pipe == 3) && wilson_pipe_applies(c, op->kind, op->r, 2, op_fused_clover(op))) return false;    // pipelined kernels: no alpha_partials form
     return true;
 }
 
@@ -281,7 +287,8 @@ static bool cg_defers_x(lqcd_op_s* op) {
 }
 int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
-    if (!cg_defers_x(op) || !(w.k & 1)) return LQCD_OK;
+    const bool deferred = w.form >= 0 ? w.form == 1 : cg_defers_x(op);     // the form the iterations were enqueued in (recorded by cg_setup)
+    if (!deferred || !(w.k & 1)) return LQCD_OK;
     const size_t n = x->elems;
     hipLaunchKernelGGL(cg_flush_kernel, dim3(stream_grid(c, n)), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, n);   // p_k of an even k lives in w.p
     HIPCHK(hipGetLastError());
@@ -293,7 +300,9 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n = x->elems;
     const int nbs_small = stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op));
-    if (c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, nbs_small)) {
+    // the iteration form was fixed when the solve / session was set up (a tunable changed in between must not split a pending deferred update)
+    const int form = w.form >= 0 ? w.form : ((c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, nbs_small)) ? 2 : (cg_defers_x(op) ? 1 : 0));
+    if (c->tun.cg_fused >= 2 && form == 2) {
         // small lattices: launch latency is the cost.  Same arithmetic as the fused form below, but the two single-block reductions
         // are folded into the prologues of their consumers -- 3 dependent launches per iteration instead of 5, identical iterates.
         double* part_a = c->d_partial;            // |D p|^2 block partials
@@ -318,7 +327,7 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         //   tmp = D p [+ |tmp|^2 partials] ; alpha = rr / |tmp|^2 ; D^+ tmp with epilogue r -= alpha q [+ |r|^2 partials] ;
         //   beta, convergence ; x += alpha p, p = r + beta p
         const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op));
-        const bool defer = c->tun.cg_defer_x != 0;
+        const bool defer = form == 1;
         lqcd_spinor_s* pk = (defer && (w.k & 1)) ? w.q : w.p;        // q = D^+D p is never written in this form: its buffer is the second p
         lqcd_spinor_s* po = (defer && (w.k & 1)) ? w.p : w.q;
         // several ranks: reduce_final -> all-reduce -> one-thread scalar kernel are three dependent launches per reduction; with `fold` the scalar
@@ -434,6 +443,9 @@ int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, doubl
     double init[9] = {*rr0, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    w.k = 0; w.p_packed = false;
+    w.form = (c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op)))) ? 2
+             : (cg_defers_x(op) ? 1 : 0);
     return LQCD_OK;
 }
 
@@ -1040,6 +1052,8 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
         ARGCHK(xs[j] && xs[j]->ctx == op->ctx && xs[j]->kind == op->kind && xs[j]->subset == LQCD_FULL && xs[j] != b,
                "lqcd_solve_multishift_cg: xs[j] must be distinct FULL spinors of the operator");
         ARGCHK(sigma[j] >= 0.0, "lqcd_solve_multishift_cg: shifts must be non-negative");
+        ARGCHK(xs[j] != x0, "lqcd_solve_multishift_cg: xs[j] and x0 must be different fields (every system is updated in place on its own handle)");
+        for (int i = 0; i < j; i++) ARGCHK(xs[i] != xs[j], "lqcd_solve_multishift_cg: the xs[j] must be pairwise different fields");
     }
     if (x0) LQCHK(check_full(op, x0, b, "lqcd_solve_multishift_cg"));
     lqcd_ctx_s* c = op->ctx;

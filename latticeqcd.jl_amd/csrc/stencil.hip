@@ -290,7 +290,9 @@ struct PipeArgs {
     real sgn_f[4], sgn_b[4];  // sign a hop takes when it wraps the local lattice (0: the neighbour is on another rank)
     int cps, cpp, cpr, per_pass, ty, tz, ysplit;
     FastDiv d_perpass, d_cpr, d_ysplit, d_ty, d_cpp;
-    unsigned* ctr;            // queue heads (ctr[32 q], q = 0..7) and exit counter (ctr[256]); zero at launch, reset by the last workgroup
+    unsigned* ctr;            // queue heads (ctr[32 q], q = 0..7) and exit counter (ctr[256]); zero at launch, reset by the last workgroup;
+                              // nullptr: no queue -- workgroup b walks the per_wg consecutive virtual blocks b * per_wg .. (dslash_pipe = 3)
+    int per_wg;
 };
 
 // next virtual block for this workgroup: from queue q (virtual blocks 8 j + q, j = 0 .. nvirt/8 - 1, handed out in order), moving on to the
@@ -439,7 +441,7 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
         // loads are issued, and the L2 hits of the sweep live on that order (profiles/r03_pipe_lookahead.log).
         unsigned tick = 0;
         if constexpr (MU == 0) {
-            if (lane == 0 && tries < 8) tick = __hip_atomic_fetch_add(a.ctr + 32 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.ctr && lane == 0 && tries < 8) tick = __hip_atomic_fetch_add(a.ctr + 32 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_sched_barrier(0);
         finish_link<R12>(uB);
@@ -452,7 +454,9 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
         if constexpr (MU == 0) {
             if (lane == 0) {
                 int nx = -1;
-                if (tries < 8) {
+                if (!a.ctr) {                 // static walk of per_wg consecutive virtual blocks (hardware dispatch order between workgroups)
+                    nx = (vb + 1) % a.per_wg != 0 ? vb + 1 : -1;
+                } else if (tries < 8) {
                     if (tick < (unsigned)nper) nx = 8 * (int)tick + q;
                     else { q = (q + 1) & 7; tries++; nx = pipe_fetch(a.ctr, nper, q, tries); }      // queue exhausted: help the next XCD (tail only)
                 }
@@ -525,6 +529,11 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
 #define LQCD_PIPE_OCC 3
 #endif
 #endif
+#ifdef LQCD_F32
+#define LQCD_DS_BOUNDS_S __launch_bounds__(256, R12 ? 5 : 4)
+#else
+#define LQCD_DS_BOUNDS_S __launch_bounds__(256, 3)
+#endif
 template <bool DAG, bool R12, bool NTB>
 __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     int q = (int)(xcc & 7u), tries = 0;
-    if (threadIdx.x == 0) nextvb[0] = pipe_fetch(a.ctr, a.nvirt >> 3, q, tries);
+    if (threadIdx.x == 0) nextvb[0] = a.ctr ? pipe_fetch(a.ctr, a.nvirt >> 3, q, tries) : (int)blockIdx.x * a.per_wg;
     __syncthreads();
     const int vb0 = __builtin_amdgcn_readfirstlane(nextvb[0]);
     double nrm = 0.0;
@@ -564,11 +573,119 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
         }
     }
     // this workgroup will not touch the queues again; the last one to say so zeroes them for the next launch (stream order)
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && a.ctr) {
         const unsigned d = __hip_atomic_fetch_add(a.ctr + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d == gridDim.x - 1) {
             for (int k = 0; k < 9; k++) __hip_atomic_store(a.ctr + 32 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if (a.norm_partial) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        if (lane == 0) red[w] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Wilson, direction-split, scalar addressing
+// dslash_pipe = 2: variant 1's schedule (one workgroup per chunk, hardware dispatch order, the compiler's own hop-by-hop schedule) on the
+// persistent kernel's addressing: compact argument struct, t / z / y-chunk wave-uniform, scalar base + 32-bit lane offset + immediate for every
+// load, no branch around a load.  Per launch -20 % VALU and -42 % SALU instructions than variant 1 (profiles/r03_pmc_pipe_static.csv), i.e. a
+// shorter way from dispatch to the first load.  Same operations in the same order per site, same |.|^2 partial per workgroup: bit-identical to
+// variant 1 including the CG iterates.
+template <int MU, bool DAG, bool R12, bool NTB>
+__device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int lane, real al_upd, real& nrm) {
+    constexpr int SF = DAG ? -1 : 1;
+    constexpr int NS = MU == 3 ? 6 : 12;
+    constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;
+    constexpr int FB = MU == 3 ? (SF > 0 ? 0 : 6) : 0;
+    constexpr int NL = R12 ? 6 : 9;
+    const size_t gpar = (size_t)a.nch * 4 * NL * 64;
+    const PipeSite s = pipe_site<MU, NL>(a, blockIdx.x, lane);
+    cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
+    if (a.upd_scal) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
+    }
+    if (a.a != real(0.0)) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
+    }
+    cd acc[12], chi0[3], chi1[3], h0[3], h1[3];
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+    {
+        cd sF[NS], uF[9];
+        load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
+        load_link_any<R12, false>(uF, boff(a.gauge + (s.p ? gpar : 0), s.uf), 64);
+        finish_link<R12>(uF);
+        project_regs<MU, SF>(h0, h1, sF);
+        pipe_sign(h0, h1, s.sf);
+        su3_mv<false>(chi0, uF, h0);
+        su3_mv<false>(chi1, uF, h1);
+        reconstruct<MU, SF>(acc, chi0, chi1);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the backward operands take the registers of the forward ones (3 waves per SIMD)
+    {
+        cd sB[NS], uB[9];
+        load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
+        load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        finish_link<R12>(uB);
+        project_regs<MU, -SF>(h0, h1, sB);
+        pipe_sign(h0, h1, s.sb);
+        su3_mv<true>(chi0, uB, h0);
+        su3_mv<true>(chi1, uB, h1);
+        reconstruct<MU, -SF>(acc, chi0, chi1);
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
+    __syncthreads();
+    real2* dstp = const_cast<real2*>(boff(s.p ? a.dst[1] : a.dst[0], s.own));
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+        const int j = 3 * MU + cc;
+        const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
+        cd sm = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        cd v = a.b * sm;
+        v = mk(fma(a.a, xv[cc].re, v.re), fma(a.a, xv[cc].im, v.im));
+        if (a.upd_scal) {
+            cd r = rv[cc];
+            r.re = fma(-al_upd, v.re, r.re); r.im = fma(-al_upd, v.im, r.im);
+            nrm = fma(r.re, r.re, nrm); nrm = fma(r.im, r.im, nrm);
+            st(dstp + co12(j), r);
+        } else {
+            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+            if (a.nt_store) st_nt(dstp + co12(j), v); else st(dstp + co12(j), v);
+        }
+    }
+}
+
+template <bool DAG, bool R12, bool NTB>
+__global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
+    __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
+    __shared__ double red[4];
+    if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) {
+        if (a.scal_w && blockIdx.x == 0 && threadIdx.x == 0) a.scal_w[S_XDONE] = 1.0;
+        return;
+    }
+    real al_upd = real(0);
+    if (a.upd_scal) {
+        if (a.scal_w) {      // folded scalar step (several ranks): see update_alpha
+            const double rr = a.upd_scal[S_RR];
+            const double al = rr / a.upd_scal[S_PQ];
+            if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal_w[S_ALPHA] = al; a.scal_w[S_RROLD] = rr; }
+            al_upd = (real)al;
+        } else al_upd = (real)a.upd_scal[S_ALPHA];
+    }
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    real nrm = 0.0;
+    switch (w) {
+    case 0: sdir_wave<0, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    case 1: sdir_wave<1, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    case 2: sdir_wave<2, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    default: sdir_wave<3, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
     }
     if (a.norm_partial) {
 #pragma unroll
@@ -888,8 +1005,9 @@ __device__ __forceinline__ real wilson_ext_face(const HArgs& k, int side) {
 
 // block-level sum of the per-thread norm corrections of an exterior kernel (128 threads); with red_out the last block to arrive sums every
 // partial of the application (interior blocks + these corrections) in a fixed order -- the one-block reduce_final launch behind the
-// exterior disappears from the critical path of a partitioned CG iteration.  Visibility: release fence + device-scope arrival counter on
-// the producers, acquire fence on the last block (MI355X guide, inter-workgroup recipe); the interior's partials come from an earlier launch.
+// exterior disappears from the critical path of a partitioned CG iteration.  Visibility: the producers store their 8-byte partial write-through
+// (sc1), drain it and arrive on a device-scope counter; the last block reads every partial with sc1 loads (MI355X guide, inter-workgroup
+// recipe R1: sc1 stores AND sc1 loads need no fences); the interior's partials come from an earlier launch.
 __device__ inline void ext_partial(const HArgs& k, real corr) {
     if (!k.norm_partial) return;
     __shared__ double red[2];
@@ -899,20 +1017,29 @@ __device__ inline void ext_partial(const HArgs& k, real corr) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = corr;
     __syncthreads();
     if (threadIdx.x == 0) {
-        k.norm_partial[k.partial_offset + blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1];
+        double* slot = k.norm_partial + k.partial_offset + blockIdx.y * gridDim.x + blockIdx.x;
         if (k.red_out) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // write-through (sc1) store of the 8-byte partial, drained, then the arrival: no release fence -- a fence per block would write back
+            // every dirty line of the XCD's L2 (the whole output of this application) a few hundred times (measured: +37 us per launch)
+            __hip_atomic_store(slot, red[0] + red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned t = __hip_atomic_fetch_add(k.red_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = t == gridDim.x * gridDim.y - 1 ? 1u : 0u;
-            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
+        } else *slot = red[0] + red[1];
     }
     if (!k.red_out) return;
     __syncthreads();
     if (!last) return;
-    double s = 0.0;
-    for (int j = threadIdx.x; j < k.red_n; j += 128) s += __hip_atomic_load(k.norm_partial + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the interior's partials were written by an earlier launch: plain loads, four independent chains in flight per thread; only the
+    // exterior's own corrections (a few hundred) need the L1-bypassing loads
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = threadIdx.x;
+    for (; j + 384 < k.partial_offset; j += 512) {
+        s0 += k.norm_partial[j]; s1 += k.norm_partial[j + 128]; s2 += k.norm_partial[j + 256]; s3 += k.norm_partial[j + 384];
+    }
+    for (; j < k.partial_offset; j += 128) s0 += k.norm_partial[j];
+    for (j = k.partial_offset + threadIdx.x; j < k.red_n; j += 128) s1 += __hip_atomic_load(k.norm_partial + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     __syncthreads();
@@ -1151,7 +1278,8 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             }
             else if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), sg, sb_, pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), sg, sb_, pad, c->stream, k);
-        } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr)) {
+        } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr) &&
+                   (c->tun.dslash_pipe != 2 || k.gauge12)) {      // the scalar-addressing kernel pays with the 12-real links only (its 18-real instance spills at 3 waves/SIMD)
             PipeArgs a;
             a.gauge = k.gauge12 ? k.gauge12 : k.gauge;
             const bool upd = k.upd_scal != nullptr;
@@ -1166,16 +1294,20 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                 a.sgn_b[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_bwd[mu]);
             }
             a.cps = k.cps; a.cpp = k.cpp; a.cpr = k.cpr; a.per_pass = std::max(1, k.cpr * k.g.L[3]); a.ty = k.ty; a.tz = k.tz; a.ysplit = k.ysplit;
-            a.ctr = c->pipe_ctr;
+            a.ctr = c->pipe_ctr; a.per_wg = 1;
             a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
-            const dim3 pg(wilson_pipe_grid(c, k.nblocks, s.prec)), pb(256);
+            const bool persist = c->tun.dslash_pipe == 1 || c->tun.dslash_pipe == 3;
+            if (c->tun.dslash_pipe == 3) { a.ctr = nullptr; a.per_wg = wilson_pipe_per_wg(c, k.nblocks); }
+            const dim3 pg(c->tun.dslash_pipe == 1 ? wilson_pipe_grid(c, k.nblocks, s.prec) : c->tun.dslash_pipe == 3 ? k.nblocks / a.per_wg : k.nblocks), pb(256);
             const bool ntb = (k.nt & 1) != 0;
-#define LQ_PIPE(D, R) do { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, true>), pg, pb, 0, c->stream, a); \
-                           else hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, false>), pg, pb, 0, c->stream, a); } while (0)
+#define LQ_PIPE(D, R) do { if (persist) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, true>), pg, pb, 0, c->stream, a); \
+                                          else hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, false>), pg, pb, 0, c->stream, a); } \
+                           else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<D, R, true>), pg, pb, 0, c->stream, a); \
+                                  else hipLaunchKernelGGL((wilson_dirsplit_s<D, R, false>), pg, pb, 0, c->stream, a); } } while (0)
             if (k.gauge12) { if (s.dagger) LQ_PIPE(true, true); else LQ_PIPE(false, true); }
             else { if (s.dagger) LQ_PIPE(true, false); else LQ_PIPE(false, false); }
 #undef LQ_PIPE
-#ifndef LQCD_F32   // opt-in variants 2-8 (stencil_alt.hip): fp64 only -- the fp32 build (paired-component fields) has the direction-split and the
+#if !defined(LQCD_F32) && defined(LQCD_VARIANTS)   // opt-in variants 2-8 (stencil_alt.hip, -DLQCD_VARIANTS builds): fp64 only -- the fp32 build (paired-component fields) has the direction-split and the
                    // site-per-lane kernels, and the mixed-precision solvers pin dslash_variant to 0/1 for the duration of a solve (mixed.hip)
         } else if (c->tun.dslash_variant >= 2 && launch_wilson_alt(c, s, k, pad)) {
 #endif
@@ -1278,9 +1410,18 @@ int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
     const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
     const int nvirt = ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
+#ifdef LQCD_VARIANTS
     if (use_dirsplit(c, kind, r) && kind == LQCD_WILSON && c->tun.dslash_variant == 3) return persist_grid(c, nvirt);
-    if (wilson_pipe_applies(c, kind, r, parity_mode, clover)) return wilson_pipe_grid(c, nvirt, prec);
+#endif
+    if (c->tun.dslash_pipe == 1 && wilson_pipe_applies(c, kind, r, parity_mode, clover)) return wilson_pipe_grid(c, nvirt, prec);
+    if (c->tun.dslash_pipe == 3 && wilson_pipe_applies(c, kind, r, parity_mode, clover)) return nvirt / wilson_pipe_per_wg(c, nvirt);
     return nvirt;
+}
+// dslash_pipe = 3: consecutive virtual blocks per workgroup (the largest divisor of the block count not above pipe_chunks_per_wg)
+int wilson_pipe_per_wg(lqcd_ctx_s* c, int nvirt) {
+    int n = std::max(1, c->tun.pipe_chunks_per_wg);
+    while (n > 1 && nvirt % n != 0) n--;
+    return n;
 }
 // variant 9: persistent workgroups, 3 per CU in the fp64 build (151..168 VGPRs, 48 KiB of LDS), 5 in the fp32 build; a multiple of 8 so that
 // virtual block b + k * grid stays on the XCD of block b.  prec = 1: the fp32 build (its callers ask stencil_num_partials with prec = 1 too).
@@ -1303,6 +1444,7 @@ bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, boo
     if (plane % 64 != 0 || c->tun.xcd_remap != 2 || (size_t)g.nch * 64 * 2304 >= ((size_t)1 << 32)) return false;
     if ((plane * g.L[2] / 64) % 8 != 0) return false;      // the map needs the chunks of a t-slice to split over the 8 XCDs
     const int nvirt = ((g.Vh + 63) / 64) * (parity_mode == 2 ? 2 : 1);
+    if (c->tun.dslash_pipe == 2 || c->tun.dslash_pipe == 3) return true;      // hardware dispatch order: no minimum size
     return nvirt >= std::max(1, c->tun.pipe_min_chunks) * wilson_pipe_grid(c, nvirt, 0);
 }
 // interior block partials + (partitioned lattice) the exterior kernel's correction partials

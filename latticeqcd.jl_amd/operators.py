@@ -512,8 +512,9 @@ class FermiAction:
         self.evensite = kind == STAGGERED and nf == 4
         # D'D carries 2 Wilson flavours / 8 staggered tastes: anything else is S_f = eta' (D'D)^(-Nf/n0) eta
         n0 = 2 if kind == WILSON else 8
-        # "force_rational": the rational form also where an exact one exists (staggered Nf = 4 / 8, Wilson Nf = 2) -- the statistical
-        # cross-check of the rational path against the exact action (tests/test_gpu_hmc_statistics.py)
+        # "force_rational": the rational form also where an exact one exists.  The guard below admits 0 < Nf < n0 only, so this is the staggered
+        # Nf = 4 action through partial fractions (Wilson Nf = 2 and staggered Nf = 8 have alpha = 1, the plain inverse: no rational form) --
+        # the statistical cross-check of the rational path against the exact action (tests/test_gpu_hmc_statistics.py)
         self.rational = (kind == WILSON and nf != 2) or (kind == STAGGERED and nf not in (4, 8)) or bool(params.get("force_rational", False))
         if self.rational:
             self.evensite = False

@@ -18,6 +18,24 @@ for name in ("bench_n1.json", "trace_bench.json"):
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copyfile(p, os.path.join(dst, f"{tag}_{name}"))
 
+# per-kernel MEDIAN duration from the kernel trace of the profiled bench run.  The --stats average counts the no-op launches a burst enqueues
+# behind the converging iteration (10 us each) and is therefore biased low; launches shorter than a fifth of the kernel's median are
+# dropped here and both the median and the mean of the rest are reported.
+med_rows = {}
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    dur = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        dur[row["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    with open(os.path.join(dst, f"{tag}_bench_kernel_medians.csv"), "w") as out:
+        out.write("kernel,launches,noop_launches_dropped,median_us,mean_us_without_noops,min_us,max_us\n")
+        for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            v.sort()
+            med_all = v[len(v) // 2]
+            real = [x for x in v if x >= 0.2 * med_all]
+            med = real[len(real) // 2]
+            out.write('"%s",%d,%d,%.2f,%.2f,%.2f,%.2f\n' % (k, len(v), len(v) - len(real), med, sum(real) / len(real), real[0], real[-1]))
+            med_rows[k] = (len(v), len(v) - len(real), med, sum(real) / len(real))
+
 acc = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
@@ -77,8 +95,13 @@ if bench:
     if c:
         lines.append(f"| CPU baseline ({c['kind']}, {c['cores']} core) | {c['value']:.3f} iter/s, Dslash {c['dslash_gflops']:.2f} GFLOP/s | `{tag}_bench_n1.json` |")
 for sub, label in (("wilson_dirsplit<false, true, false>", "12-real D"), ("wilson_dirsplit<true, true, false>", "12-real D† (CG update mode)"),
-                   ("wilson_dirsplit<false, false, false>", "18-real D"), ("cg_update_even", "p update, even iterations (x deferred)"),
+                   ("wilson_dirsplit<false, false, false>", "18-real D"), ("wilson_dirsplit_pipe<false, true", "12-real D, persistent form"), ("cg_update_even", "p update, even iterations (x deferred)"),
                    ("cg_update_odd", "x (two terms) and p update, odd iterations"), ("cg_update_xp", "x, p update"), ("reduce_final", "final reduction")):
+    mk = [k for k in med_rows if sub in k]
+    if mk:
+        n, dropped, med, mean = med_rows[mk[0]]
+        lines.append(f"| rocprofv3 `--kernel-trace` of the same command: {label} `{sub}` | median {med:.1f} µs, mean {mean:.1f} µs over {n - dropped} launches ({dropped} no-op launches of converged bursts dropped) | `{tag}_bench_kernel_medians.csv` |")
+        continue
     s = stat_row(sub)
     if s:
         lines.append(f"| rocprofv3 `--kernel-trace --stats` of the same command: {label} `{sub}` | {float(s['AverageNs']) / 1e3:.1f} µs average over {s['Calls']} calls | `{tag}_bench_kernel_stats.csv` |")

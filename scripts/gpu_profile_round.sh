@@ -8,8 +8,8 @@
 cd "$(dirname "$0")/.."
 TAG=${1:-r02}
 R=$(pwd); O=$R/gpurun_out/profile_$TAG; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
-timeout 900 python bench.py --steps 100 --warmup 10 > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 300 $O/bench_n1.json
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc > $O/trace_bench.json 2> $O/trace.err)
+timeout 900 python bench.py --steps 400 --warmup 20 > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 300 $O/bench_n1.json
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-pmc > $O/trace_bench.json 2> $O/trace.err)
 for recon in 12 18; do
 for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   n=$(echo $pass | cut -d' ' -f1)
