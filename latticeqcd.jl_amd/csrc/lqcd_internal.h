@@ -339,7 +339,8 @@ struct Tunables {
                               // block's serial tail costs more than the 4 us launch it replaces) -> default 2
     int cg_fold_scalars = 1;  // several ranks: the scalar steps behind the two all-reduces of a CG iteration run in the consumers' prologues (no one-thread kernels)
     int nt_blas = 1;          // deferred-x CG update kernels stream their fields with non-temporal loads / stores: 842 -> 868 iter/s at 32^3x64
-    int md_reunitarize = 1;   // lqcd_gauge_exp_update (U_update!) projects the updated links back onto SU(3) in the same pass: rounding alone carries
+    int md_reunitarize = 1;   // lqcd_gauge_exp_update (U_update!) projects every updated link that is unitary to 1e-13 back onto SU(3) in the same pass
+                              // (a field that was never on the group to that precision, e.g. a text-file configuration, is not touched): rounding alone carries
                               // max |row2 - conj(row0 x row1)| past the 12-real gate (1e-14) within ~280 link updates; 0 = the reference's literal update
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
     int cg_defer_x = 1;       // fused CG: x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs

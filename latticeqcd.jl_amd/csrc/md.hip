@@ -413,7 +413,22 @@ __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* _
     exp_m3(e, x, dt);
     load_m3(u, U + off, Gs);
     mm3(t, e, u);
-    if constexpr (REUNIT) reunitarize_m3(t);
+    if constexpr (REUNIT) {
+        // only a link that IS on the group up to accumulated rounding (deviation <= 1e-13) is put back onto it: the projection then moves it by
+        // about that rounding.  A configuration read from a text file (the reference's fixtures are unitary to 9e-11) is left exactly as the
+        // reference's literal update leaves it.
+        cd v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = t[k];
+        reunitarize_m3(v);
+        double dev = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dev = fmax(dev, fmax(fabs(v[k].re - t[k].re), fabs(v[k].im - t[k].im)));
+        if (dev <= 1e-13) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) t[k] = v[k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 9; k++) st(U + off + (size_t)k * Gs, t[k]);
 }
@@ -772,7 +787,8 @@ extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) 
     lqcd_ctx_s* c = U->ctx;
     HIPCHK(hipSetDevice(c->device));
     U->version++;
-    // md_reunitarize (default): the updated link is projected back onto SU(3) in the same pass.  exp(dt P) U leaves the group only by
+    // md_reunitarize (default): an updated link that is unitary up to accumulated rounding (1e-13) is projected back onto SU(3) in the same
+    // pass (links of a configuration that was never on the group to that precision are left alone).  exp(dt P) U leaves the group only by
     // rounding, but that rounding accumulates: max |row2 - conj(row0 x row1)| passes 1e-14 after ~280 updates (profiles/r03_unitarity_drift.log),
     // i.e. inside the FIRST trajectory, and the 12-real Dslash would be lost for the rest of the run.  0 = the reference's literal U_update!.
     if (c->tun.md_reunitarize) hipLaunchKernelGGL(link_exp_update_kernel<true>, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data);

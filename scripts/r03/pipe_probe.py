@@ -47,8 +47,10 @@ def run(label, **params):
 
 
 for recon in (12, 18):
-    run("recon%d plain" % recon, gauge_recon=recon, dslash_pipe=0)
+    run("recon%d plain" % recon, gauge_recon=recon, dslash_pipe=0, pipe_per_cu=0)
     for per_cu in (3, 2):
         run("recon%d pipe %d/CU" % (recon, per_cu), gauge_recon=recon, dslash_pipe=1, pipe_per_cu=per_cu)
     run("recon%d scalar addressing" % recon, gauge_recon=recon, dslash_pipe=2, pipe_per_cu=0)
+    for n in (2, 4):
+        run("recon%d pipelined, %d chunks/WG" % (recon, n), gauge_recon=recon, dslash_pipe=3, pipe_chunks_per_wg=n)
     run("recon%d plain (again)" % recon, gauge_recon=recon, dslash_pipe=0, pipe_per_cu=0)

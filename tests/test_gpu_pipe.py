@@ -45,7 +45,7 @@ CASES = [((16, 8, 8, 4), 8), ((8, 16, 8, 8), 16), ((32, 4, 8, 4), 8), ((16, 16, 
 
 @pytest.mark.parametrize("L,grid", CASES)
 @pytest.mark.parametrize("recon", [12, 18])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_pipe_dslash_matches_oracle_and_variant1_bitwise(gpu, orc, L, grid, recon, mode):
     lq = gpu
     lat, Uh, Ud, D = make(lq, orc, L)
@@ -65,7 +65,7 @@ def test_pipe_dslash_matches_oracle_and_variant1_bitwise(gpu, orc, L, grid, reco
 
 
 @pytest.mark.parametrize("L,grid", [((16, 8, 8, 4), 8), ((16, 16, 16, 4), 16)])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_pipe_parity_hops_and_map_settings(gpu, orc, L, grid, mode):
     lq = gpu
     lat, Uh, Ud, D = make(lq, orc, L, seed=33)
@@ -87,7 +87,7 @@ def test_pipe_parity_hops_and_map_settings(gpu, orc, L, grid, mode):
 
 
 @pytest.mark.parametrize("L,grid", [((16, 8, 8, 4), 8), ((12, 32, 8, 2), 16)])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_pipe_cg_matches_oracle(gpu, orc, L, grid, mode):
     """fused CG on the persistent kernel: |Dp|^2 partials (one per persistent workgroup), update-mode D^+, deferred x"""
     lq = gpu
@@ -164,7 +164,7 @@ def test_pipe_rccl_self_partition(gpu, orc):
             assert err < 1e-13, (dag, err)
         xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, K, 1.0, BC, eps=1e-19)
         its = {}
-        for pipe in (1, 2, 0):
+        for pipe in (1, 2, 3, 0):
             lat.set_param("dslash_pipe", pipe)
             sol = x.similar()
             its[pipe], rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)

@@ -78,6 +78,26 @@ def test_trajectory_is_the_same_with_and_without_projection(gpu, orc):
     assert np.abs(out[1][2] - out[0][2]).max() < 1e-12
 
 
+def test_fields_that_were_never_on_the_group_are_left_alone(gpu, orc):
+    """the reference's fixtures are unitary to 9e-11 (text files): the default update must treat them exactly like the literal one"""
+    lq = gpu
+    import os
+    from conftest import GOLDEN
+    L = (4, 4, 4, 4)
+    Uh = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L)
+    out = {}
+    for mode in (1, 0):
+        lat = lq.Lattice(L)
+        lat.set_param("md_reunitarize", mode)
+        U = lq.Gaugefields(lat).upload(Uh)
+        assert lq.unitarity_deviation(U) > 1e-12
+        p = lq.Gaugefields(lat)
+        lq.gauss_distribution_(p, 21)
+        md_leg(lq, U, p, 10)
+        out[mode] = U.download()
+    assert np.array_equal(out[0], out[1])
+
+
 def test_reunitarize_entry_point(gpu, orc):
     lq = gpu
     L = (4, 4, 4, 4)
