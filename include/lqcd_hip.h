@@ -199,6 +199,10 @@ int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, 
  * (<= 0: 1e-4).  iters: total inner iterations (+ fp64 iterations if the fall-back ran); outer: correction steps. */
 int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
                               int* outer, double* final_rr);
+/* diagnostic, no reference counterpart: out = D in (D^+ in) through the fp32 operator the mixed-precision solvers use on this operator (fp32
+ * links, fp32 kernel and field layout; tunable mixed_pair32 selects the site-pair kernel where it applies), converted back to fp64;
+ * reps > 0 also returns the mean time of one fp32 application in ms */
+int lqcd_op_apply_f32(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int reps, double* ms);
 
 /* mixed-precision shiftedcg (BASELINE configs[4] "RHMC ... mixed-precision fp32 inner / fp64 outer CG"; the
  * reference's shiftedcg, README.md:132, is fp64 throughout).  Same contract as lqcd_solve_multishift_cg -- zero initial guesses, x0

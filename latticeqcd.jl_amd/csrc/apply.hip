@@ -101,6 +101,7 @@ bool any_partitioned(lqcd_ctx_s* c) {
 // full stencil on one rank: pack -> (exchange || interior) -> exterior
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     HIPCHK(hipSetDevice(c->device));
+    if (s.prec == 2) return launch_pair32_interior(c, s);      // fp32 site-pair fields (unpartitioned lattices only: checked by the launcher)
     if (!any_partitioned(c)) return s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s);
     if (s.kind == LQCD_WILSON && s.r != 1.0) {
         // general r on a partitioned lattice: the halos carry spin-projected half spinors, i.e. r = 1 hops.  r -+ gamma is a combination

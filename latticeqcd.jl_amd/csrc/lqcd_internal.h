@@ -350,6 +350,8 @@ struct Tunables {
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int stag_both = 0;            // 1: staggered split kernel issues the loads of both hops of a direction back to back (unpartitioned lattices)
+    int mixed_pair32 = 1;         // mixed-precision solvers, plain Wilson r = 1 on an unpartitioned lattice with 12-real links: the fp32 inner operator is the
+                                  // site-pair kernel (stencil_pair32.hip: two sites per lane, packed fp32 arithmetic); 0 = the one-site-per-lane fp32 build
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule);
                                   // 2: the same, and the rational actions solve all poles with the mixed-precision multi-shift CG
     int gauge_recon = 12;     // 12 (default): the direction-split kernels read 2 rows per link and rebuild the third -- only while every
@@ -360,6 +362,7 @@ struct Tunables {
 #else
     int variants_built = 0;   // read-only: dslash_variant >= 2 runs variant 1 (built without -DLQCD_VARIANTS)
 #endif
+    int pair32_active = 0;    // read-only: the last mixed-precision solve / lqcd_op_apply_f32 ran the fp32 site-pair kernel
     int recon_active = 0;     // read-only: 1 if the last Wilson operator application used the 12-real links
 };
 
@@ -396,6 +399,7 @@ struct lqcd_ctx_s {
     const void* mix_gauge_of = nullptr;  // gauge handle / version the fp32 link copies in mix_buf[0], mix_buf[5] were made from
     uint64_t mix_gauge_version = 0;
     bool mix_gauge12_valid = false;      // the 12-real fp32 copy (mix_buf[5]) was made for that version
+    int mix_gauge12_layout = 0;          // ... in which layout: 1 component pairs (stencil.hip fp32 build), 2 site pairs (stencil_pair32.hip)
     void* mix_buf[8] = {};     // 7: fp32 x_j / p_j pool of the mixed-precision multi-shift solver
     size_t mix_bytes[8] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
@@ -542,6 +546,13 @@ int force_halo_exchange_rccl(lqcd_ctx_s* c, int kind);
 int force_halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind);
 int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double km,
                          double r, double scale = 1.0, int accumulate = 0);
+// stencil_pair32.hip: fp32 Wilson Dslash on site pairs (StencilCall::prec == 2) and the conversions of its field layout
+bool pair32_geometry_ok(lqcd_ctx_s* c);
+int pair32_num_blocks(lqcd_ctx_s* c);
+int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale);
+int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a);
+int pair32_cvt_gauge12(lqcd_ctx_s* c, float2* dst, const double2* src12);
+int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);
 int make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, StencilCall& s);

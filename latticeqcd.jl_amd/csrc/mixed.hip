@@ -158,6 +158,7 @@ static int mix_alloc(lqcd_ctx_s* c, int slot, size_t bytes) {
 struct Mix32 {
     float2 *gauge, *gauge12, *clover, *x, *r, *p, *t;
     size_t blk;   // elements per parity block
+    int layout = 0;   // fp32 spinor layout: 0 plain (staggered), 1 Wilson component pairs (stencil.hip, LQCD_F32), 2 Wilson site pairs (stencil_pair32.hip)
 };
 
 // a StencilCall on fp32 fields (pointers travel as double2*, stencil_apply dispatches on prec)
@@ -177,7 +178,7 @@ static StencilCall call32(lqcd_op_s* op, const Mix32& m, float2* out, float2* in
     s.r = op->r;
     s.dagger = dagger;
     s.parity_mode = 2;
-    s.prec = 1;
+    s.prec = m.layout == 2 ? 2 : 1;
     return s;
 }
 
@@ -188,7 +189,7 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
     HIPCHK(hipMemcpyAsync(m.p, m.r, n * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 1, op->csw != 0.0 && op->clover != nullptr), nbu = stream_grid(c, n / 2), check_every = 8;
+    const int nbs = stencil_num_partials(c, op->kind, op->r, 2, m.layout == 2 ? 2 : 1, op->csw != 0.0 && op->clover != nullptr), nbu = stream_grid(c, n / 2), check_every = 8;
     int it = 0;
     double rr = 1.0;
     bool done = false;
@@ -258,8 +259,15 @@ static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
     }
     m.x = (float2*)c->mix_buf[1]; m.r = (float2*)c->mix_buf[2]; m.p = (float2*)c->mix_buf[3]; m.t = (float2*)c->mix_buf[4];
     m.blk = n / 2;
+    // site-pair fp32 kernel (stencil_pair32.hip; tunable mixed_pair32): plain Wilson r = 1 with 12-real links on an unpartitioned lattice whose
+    // geometry admits it; the fp32 fields of the solve (links in mix_buf[5], the four vectors) then live in the pair layout
+    const bool pair = op->kind == LQCD_WILSON && op->r == 1.0 && !clov && use12 && c->tun.mixed_pair32 && c->tun.dslash_variant == 1 &&
+                      pair32_geometry_ok(c) && n == (size_t)2 * 12 * c->geom.Vs;
+    m.layout = pair ? 2 : (op->kind == LQCD_WILSON ? 1 : 0);
+    c->tun.pair32_active = pair ? 1 : 0;
+    const int glayout = pair ? 2 : 1;
     const bool links_cached = c->mix_gauge_of == (const void*)op->gauge && c->mix_gauge_version == op->gauge->version &&
-                              (!use12 || c->mix_gauge12_valid);
+                              (!use12 || (c->mix_gauge12_valid && c->mix_gauge12_layout == glayout));
     if (!links_cached) hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
     if (clov) {     // fp32 copy of the packed clover blocks (same layout); A follows the links first
         if (op->clover_version != op->gauge->version) {
@@ -269,25 +277,30 @@ static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
         const size_t nc = clover_elems(c->geom);
         hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, m.clover, op->clover, nc, 1.0);
     }
-    if (!links_cached && use12)
-        hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
+    if (!links_cached && use12) {
+        if (pair) LQCHK(pair32_cvt_gauge12(c, m.gauge12, op->gauge->data12));
+        else hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
+    }
     if (!links_cached) {
         c->mix_gauge_of = (const void*)op->gauge;
         c->mix_gauge_version = op->gauge->version;
         c->mix_gauge12_valid = use12;
+        c->mix_gauge12_layout = glayout;
     }
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
 // fp64 -> fp32 (scaled) and y (fp64) += a * x (fp32) in the layout of the field kind (Wilson: component pairs)
-static int to_f32(lqcd_ctx_s* c, bool wil, float2* dst, const double2* src, size_t n, double scale) {
-    if (wil) hipLaunchKernelGGL(cvt_wilson_to_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, (float4*)dst, src, n / 2, scale);
+static int to_f32(lqcd_ctx_s* c, int layout, float2* dst, const double2* src, size_t n, double scale) {
+    if (layout == 2) return pair32_cvt_spinor(c, dst, src, scale);
+    if (layout == 1) hipLaunchKernelGGL(cvt_wilson_to_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, (float4*)dst, src, n / 2, scale);
     else hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, dst, src, n, scale);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
-static int add_from_f32(lqcd_ctx_s* c, bool wil, double2* y, const float2* x, double a, size_t n) {
-    if (wil) hipLaunchKernelGGL(axpy_from_wilson_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, y, (const float4*)x, a, n / 2);
+static int add_from_f32(lqcd_ctx_s* c, int layout, double2* y, const float2* x, double a, size_t n) {
+    if (layout == 2) return pair32_axpy_to_f64(c, y, x, a);
+    if (layout == 1) hipLaunchKernelGGL(axpy_from_wilson_f32, dim3(stream_grid(c, n / 2)), dim3(MB), 0, c->stream, y, (const float4*)x, a, n / 2);
     else hipLaunchKernelGGL(axpy_from_f32, dim3(stream_grid(c, n)), dim3(MB), 0, c->stream, y, x, a, n);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
@@ -319,7 +332,7 @@ static int inner_ms32(lqcd_op_s* op, const Mix32& m, float2* xbase, const std::v
     double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));     // hms / hptr are stack-owned host buffers
-    const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 1, op->csw != 0.0 && op->clover != nullptr), nbu = stream_grid(c, n / 2), check_every = 8;
+    const int nbs = stencil_num_partials(c, op->kind, op->r, 2, m.layout == 2 ? 2 : 1, op->csw != 0.0 && op->clover != nullptr), nbu = stream_grid(c, n / 2), check_every = 8;
     int it = 0;
     double rr = 1.0;
     bool done = false;
@@ -360,6 +373,39 @@ static int inner_ms32(lqcd_op_s* op, const Mix32& m, float2* xbase, const std::v
 
 using namespace lqcd;
 
+// out = D in (dagger: D^+ in) through the fp32 operator of the inner solver -- the fp32 copies of the links, the kernel and the field layout a
+// mixed-precision solve on this operator would use (tunable mixed_pair32) -- converted back to fp64.  Diagnostic / timing entry point (no
+// reference counterpart): parity tests of the fp32 kernels against the oracle at fp32 accuracy, and their time per application
+// (reps > 0: mean over reps applications between HIP events on the library's stream; 0: one application, no timing).
+extern "C" int lqcd_op_apply_f32(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int reps, double* ms) {
+    ARGCHK(op && out && in && out->ctx == op->ctx && in->ctx == op->ctx && out->kind == op->kind && in->kind == op->kind && out->subset == LQCD_FULL &&
+               in->subset == LQCD_FULL && out != in && reps >= 0,
+           "lqcd_op_apply_f32: need two distinct FULL spinors of the operator's kind on the operator's context");
+    lqcd_ctx_s* c = op->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = in->elems;
+    VariantPin pin(c);
+    Mix32 m;
+    LQCHK(mix_prepare(op, n, m));
+    LQCHK(to_f32(c, m.layout, m.p, in->data, n, 1.0));
+    apply_bc(c, op->bc);
+    StencilCall s1 = call32(op, m, m.t, m.p, dagger);
+    LQCHK(stencil_apply(c, s1));
+    if (reps > 0) {
+        HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+        for (int k = 0; k < reps; k++) LQCHK(stencil_apply(c, s1));
+        HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+        HIPCHK(hipEventSynchronize(c->ev_t1));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, c->ev_t0, c->ev_t1));
+        if (ms) *ms = (double)t / reps;
+    }
+    HIPCHK(hipMemsetAsync(out->data, 0, n * sizeof(double2), c->stream));
+    LQCHK(add_from_f32(c, m.layout, out->data, m.t, 1.0, n));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
 // Mixed-precision CG for D^+D x = b.  x holds the initial guess.  eps: absolute bound on the TRUE squared residual (the
 // reference's rule real(r.r) < eps, evaluated in fp64); inner_tol: relative residual norm requested from each fp32 solve
 // (<= 0 selects 1e-4).  iters = total fp32 iterations (+ fp64 iterations of the fall-back, if it ran); outer = defect-correction steps.
@@ -372,7 +418,6 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
     HIPCHK(hipSetDevice(c->device));
     if (inner_tol <= 0.0) inner_tol = 1e-4;
     const size_t n = x->elems;
-    const bool wil = op->kind == LQCD_WILSON;     // Wilson spinors are paired in fp32 (cvt_wilson_to_f32)
     VariantPin pin(c);
     Mix32 m;
     LQCHK(mix_prepare(op, n, m));
@@ -401,7 +446,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
         while (rr >= eps && total < maxiter) {
             if (!std::isfinite(rr)) { set_error("mixed CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
             const double nrm = std::sqrt(rr);
-            LQCHK(to_f32(c, wil, m.r, r->data, n, 1.0 / nrm));
+            LQCHK(to_f32(c, m.layout, m.r, r->data, n, 1.0 / nrm));
             // no tighter than needed to reach eps (with a 10x margin), no tighter than fp32 can deliver
             const double eps2 = std::max(inner_tol * inner_tol, 0.1 * eps / rr);
             int it = 0;
@@ -409,7 +454,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
             LQCHK(inner_cg32(op, m, n, eps2, maxiter - total, &it, &rin));
             total += it;
             nout++;
-            LQCHK(add_from_f32(c, wil, x->data, m.x, nrm, n));
+            LQCHK(add_from_f32(c, m.layout, x->data, m.x, nrm, n));
             const double rr_old = rr;
             LQCHK(true_residual());
             if (!(rr < 0.5 * rr_old)) { fallback = rr >= eps; break; }   // fp32 accuracy exhausted
@@ -465,7 +510,6 @@ extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lq
     HIPCHK(hipSetDevice(c->device));
     if (inner_tol <= 0.0) inner_tol = 1e-6;     // about as far as an fp32 recurrence follows the true residual
     const size_t n = b->elems, bytes64 = n * sizeof(double2);
-    const bool wil = op->kind == LQCD_WILSON;
     VariantPin pin(c);
     Mix32 m;
     LQCHK(mix_prepare(op, n, m));
@@ -507,13 +551,13 @@ extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lq
         if (!std::isfinite(bb)) { set_error("mixed multi-shift CG: the right-hand side is not finite"); return LQCD_ERR_NOT_CONVERGED; }
         // ---- phase 1
         const double nb_ = std::sqrt(bb);
-        LQCHK(to_f32(c, wil, m.r, b->data, n, 1.0 / nb_));
+        LQCHK(to_f32(c, m.layout, m.r, b->data, n, 1.0 / nb_));
         int it = 0;
         double rin = 0;
         LQCHK(inner_ms32(op, m, x0 ? xb32 : nullptr, xj, pj, sigma, ns, d_blk, n, std::max(inner_tol * inner_tol, 0.1 * eps / bb), maxiter, &it, &rin));
         total += it;
-        if (x0) LQCHK(add_from_f32(c, wil, x0->data, xb32, nb_, n));
-        for (int j = 0; j < ns; j++) LQCHK(add_from_f32(c, wil, xs[j]->data, xj[j], nb_, n));
+        if (x0) LQCHK(add_from_f32(c, m.layout, x0->data, xb32, nb_, n));
+        for (int j = 0; j < ns; j++) LQCHK(add_from_f32(c, m.layout, xs[j]->data, xj[j], nb_, n));
         // ---- phase 2: every system on its own
         for (int j = (x0 ? -1 : 0); j < ns; j++) {
             lqcd_spinor_s* x = j < 0 ? x0 : xs[j];
@@ -522,7 +566,7 @@ extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lq
             while (rr >= eps && total < maxiter) {
                 if (!std::isfinite(rr)) { set_error("mixed multi-shift CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
                 const double nrm = std::sqrt(rr), rr_old = rr;
-                LQCHK(to_f32(c, wil, m.r, r->data, n, 1.0 / nrm));
+                LQCHK(to_f32(c, m.layout, m.r, r->data, n, 1.0 / nrm));
                 const double eps2 = std::max(inner_tol * inner_tol, 0.1 * eps / rr);
                 it = 0;
                 const std::vector<float2*> x1(1, xj.empty() ? xb32 : xj[0]), p1(1, pj.empty() ? xb32 : pj[0]);
@@ -530,7 +574,7 @@ extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lq
                 else LQCHK(inner_ms32(op, m, nullptr, x1, p1, &sg, 1, d_blk, n, eps2, maxiter - total, &it, &rin));
                 total += it;
                 nout++;
-                LQCHK(add_from_f32(c, wil, x->data, j < 0 ? xb32 : x1[0], nrm, n));
+                LQCHK(add_from_f32(c, m.layout, x->data, j < 0 ? xb32 : x1[0], nrm, n));
                 LQCHK(true_residual(x, sg));
                 if (rr < 0.5 * rr_old) continue;
                 if (rr < eps) break;

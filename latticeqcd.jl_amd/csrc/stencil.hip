@@ -529,8 +529,19 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
 #define LQCD_PIPE_OCC 3
 #endif
 #endif
+#ifndef LQCD_SDIR_BOTH32
+#define LQCD_SDIR_BOTH32 0      // fp32 build: 1 = both hops' operands of a direction in flight at once (110 VGPRs, 4 waves per SIMD)
+#endif
+#if defined(LQCD_F32) && LQCD_SDIR_BOTH32
+#define LQCD_SDIR_BOTH 1
+#else
+#define LQCD_SDIR_BOTH 0
+#endif
 #ifdef LQCD_F32
-#define LQCD_DS_BOUNDS_S __launch_bounds__(256, R12 ? 5 : 4)
+#ifndef LQCD_SDIR_OCC32
+#define LQCD_SDIR_OCC32 (R12 ? 5 : 4)
+#endif
+#define LQCD_DS_BOUNDS_S __launch_bounds__(256, LQCD_SDIR_OCC32)
 #else
 #define LQCD_DS_BOUNDS_S __launch_bounds__(256, 3)
 #endif
@@ -615,6 +626,27 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     cd acc[12], chi0[3], chi1[3], h0[3], h1[3];
 #pragma unroll
     for (int j = 0; j < 12; j++) acc[j] = mk(0.0, 0.0);
+#if LQCD_SDIR_BOTH
+    {   // both hops' operands in flight at once (fp32 build: half-size registers leave the room at 4 waves per SIMD; twice the bytes in flight per wave)
+        cd sF[NS], uF[9], sB[NS], uB[9];
+        load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
+        load_link_any<R12, false>(uF, boff(a.gauge + (s.p ? gpar : 0), s.uf), 64);
+        load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
+        load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        finish_link<R12>(uF);
+        project_regs<MU, SF>(h0, h1, sF);
+        pipe_sign(h0, h1, s.sf);
+        su3_mv<false>(chi0, uF, h0);
+        su3_mv<false>(chi1, uF, h1);
+        reconstruct<MU, SF>(acc, chi0, chi1);
+        finish_link<R12>(uB);
+        project_regs<MU, -SF>(h0, h1, sB);
+        pipe_sign(h0, h1, s.sb);
+        su3_mv<true>(chi0, uB, h0);
+        su3_mv<true>(chi1, uB, h1);
+        reconstruct<MU, -SF>(acc, chi0, chi1);
+    }
+#else
     {
         cd sF[NS], uF[9];
         load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
@@ -638,6 +670,7 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         su3_mv<true>(chi1, uB, h1);
         reconstruct<MU, -SF>(acc, chi0, chi1);
     }
+#endif
 #pragma unroll
     for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
     __syncthreads();
@@ -1408,6 +1441,7 @@ int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
 // precision-independent launch geometry (shared by both builds of this file)
 // number of |.|^2 block partials the interior kernel writes
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
+    if (prec == 2) return pair32_num_blocks(c);       // fp32 site-pair kernel: one workgroup per 64 pairs
     const int TB = use_dirsplit(c, kind, r) ? 64 : c->tun.dslash_block;
     const int nvirt = ((c->geom.Vh + TB - 1) / TB) * (parity_mode == 2 ? 2 : 1);
 #ifdef LQCD_VARIANTS

@@ -433,6 +433,14 @@ def solve_mixed_DinvX_(y, A, x, inner_tol=1e-4, return_info=False):
     return (it.value, out.value, rr.value) if return_info else None
 
 
+def mul_f32_(y, D, x, reps=0):
+    """y = D x through the fp32 operator of the mixed-precision solvers (lqcd_op_apply_f32; diagnostic, no reference counterpart).
+    reps > 0 -> returns the mean time of one fp32 application in ms."""
+    ms = C.c_double(0)
+    check(_l.lib().lqcd_op_apply_f32(D._h, y._h, x._h, int(D.dagger), int(reps), C.byref(ms)))
+    return ms.value if reps else None
+
+
 def solve_parity_DinvX_(y, A, x, parity=0, return_info=False):
     """Staggered only: y_p = ((D'D)_pp)^-1 x_p on the sites of one parity (0 even, 1 odd) of the FULL fields y (initial guess) and x,
     with half-lattice vectors -- D'D = m^2 - D_hop^2 is block diagonal in parity.  The other half of y is left alone."""

@@ -16,7 +16,7 @@ phi = lq.Fermionfields(lat, lq.STAGGERED)
 lq.gauss_distribution_fermion_(phi, 112)
 G = lq.Gaugefields(lat)
 ref = None
-for mode in (0, 1):
+for mode in (0, 2, 1):
     lat.set_param("mixed_action_solver", mode)
     S = lq.evaluate_FermiAction(fa, U, phi)
     lat.sync(); t0 = time.perf_counter(); S, it = lq.evaluate_FermiAction(fa, U, phi, return_info=True); lat.sync(); ta = time.perf_counter() - t0
