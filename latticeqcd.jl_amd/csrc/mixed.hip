@@ -375,7 +375,7 @@ using namespace lqcd;
 
 // out = D in (dagger: D^+ in) through the fp32 operator of the inner solver -- the fp32 copies of the links, the kernel and the field layout a
 // mixed-precision solve on this operator would use (tunable mixed_pair32) -- converted back to fp64.  Diagnostic / timing entry point (no
-// reference counterpart): parity tests of the fp32 kernels against the oracle at fp32 accuracy, and their time per application
+// reference counterpart): parity tests of the fp32 kernels against the CPU restatement at fp32 accuracy, and their time per application
 // (reps > 0: mean over reps applications between HIP events on the library's stream; 0: one application, no timing).
 extern "C" int lqcd_op_apply_f32(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int reps, double* ms) {
     ARGCHK(op && out && in && out->ctx == op->ctx && in->ctx == op->ctx && out->kind == op->kind && in->kind == op->kind && out->subset == LQCD_FULL &&
