@@ -249,6 +249,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "cg_skip_done")) return &c->tun.cg_skip_done;
     if (!strcmp(key, "cg_small")) return &c->tun.cg_small;
     if (!strcmp(key, "md_remap")) return &c->tun.md_remap;
+    if (!strcmp(key, "staple_recon")) return &c->tun.staple_recon;
     if (!strcmp(key, "md_reunitarize")) return &c->tun.md_reunitarize;
     if (!strcmp(key, "nt_blas")) return &c->tun.nt_blas;
     if (!strcmp(key, "cg_fold_scalars")) return &c->tun.cg_fold_scalars;

@@ -318,6 +318,7 @@ extern "C" int lqcd_gauge_unit(lqcd_gauge_t g) {
     HIPCHK(hipSetDevice(c->device));
     const int nt = 2 * c->geom.Vh * 4;
     g->version++;
+    g->unitary_version = g->version;
     hipLaunchKernelGGL(gauge_unit, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, g->data);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -330,6 +331,7 @@ extern "C" int lqcd_gauge_hot_start(lqcd_gauge_t g, uint64_t seed) {
     HIPCHK(hipSetDevice(c->device));
     const int nt = 2 * c->geom.Vh * 4;
     g->version++;
+    g->unitary_version = g->version;      // rows 0, 1 by Gram-Schmidt, row 2 = conj(row 0 x row 1)
     hipLaunchKernelGGL(gauge_hot, dim3((nt + 127) / 128), dim3(128), 0, c->stream, c->geom, g->data, seed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -448,6 +450,7 @@ int gauge_ensure_recon12(lqcd_gauge_s* g) {
     memcpy(&dev, &bits, sizeof(dev));
     g->recon_ok = dev <= 1e-14;
     g->recon_dev = dev;
+    if (g->recon_ok) g->unitary_version = g->version;
     g->version12 = g->version;
     return LQCD_OK;
 }

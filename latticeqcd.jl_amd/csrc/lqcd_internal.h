@@ -342,6 +342,7 @@ struct Tunables {
     int md_reunitarize = 1;   // lqcd_gauge_exp_update (U_update!) projects every updated link that is unitary to 1e-13 back onto SU(3) in the same pass
                               // (a field that was never on the group to that precision, e.g. a text-file configuration, is not touched): rounding alone carries
                               // max |row2 - conj(row0 x row1)| past the 12-real gate (1e-14) within ~280 link updates; 0 = the reference's literal update
+    int staple_recon = 1;     // staple sweep on a field whose links are known to be on the group: rows 0, 1 are loaded, row 2 is rebuilt (2/3 of the L2 -> L1 bytes)
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
     int cg_defer_x = 1;       // fused CG: x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
                               // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates
@@ -423,6 +424,8 @@ struct lqcd_gauge_s {
     uint64_t version12 = 0;      // version of `data` the copy was made from
     bool recon_ok = false;       // row 2 == conj(row 0 x row 1) to 1e-14 on every link of that version
     double recon_dev = 0.0;      // max |row 2 - conj(row 0 x row 1)| measured when the copy was made
+    uint64_t unitary_version = 0;  // version of `data` whose links are all known to be on the group to rounding (generated on it, measured by the
+                                   // 12-real pass, or projected by the link update): kernels may then rebuild row 2 instead of loading it
 };
 
 struct lqcd_spinor_s {

@@ -17,6 +17,9 @@
 namespace lqcd {
 
 typedef cd m3[9];
+#ifndef LQCD_STAPLE_BURST
+#define LQCD_STAPLE_BURST 1     // two-row staple sweep: the five neighbour links of a plane in one load burst
+#endif
 
 __device__ __forceinline__ void load_m3(cd (&u)[9], const double2* __restrict__ base, int stride) {
 #pragma unroll
@@ -59,6 +62,21 @@ __device__ __forceinline__ void mm3_dd(cd (&C)[9], const cd (&A)[9], const cd (&
         }
 }
 
+// links of a field that is known to be on the group (lqcd_gauge_s::unitary_version): rows 0 and 1 from memory, row 2 = conj(row 0 x row 1) --
+// two thirds of the bytes through the L1 / L2 path, which is what bounds the staple sweep (60 neighbour-link loads per site)
+template <bool R2>
+__device__ __forceinline__ void load_u(cd (&u)[9], const double2* __restrict__ base, int stride) {
+    if constexpr (!R2) { load_m3(u, base, stride); return; }
+#pragma unroll
+    for (int e = 0; e < 6; e++) u[e] = ld(base + (size_t)e * stride);
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+        const cd x = cmul(u[b1], u[3 + b2]) - cmul(u[b2], u[3 + b1]);
+        u[6 + b] = mk(x.re, -x.im);
+    }
+}
+
 // link U_mu at the site with local coordinates c (periodic wrap; links carry no boundary sign)
 __device__ __forceinline__ const double2* link_at(const Geom& g, const double2* __restrict__ U, const int (&c)[4], int mu) {
     const int p = (c[0] + c[1] + c[2] + c[3]) & 1;
@@ -86,7 +104,7 @@ struct GFArgs {
 };
 
 // U_nu at the site c + dir_hat: local, or from the forward ghost slice when the step leaves the rank
-template <bool PART = true>
+template <bool PART = true, bool R2 = false>
 __device__ __forceinline__ void link_fwd(cd (&u)[9], const GFArgs& k, const int (&c)[4], int dir, int nu) {
     const Geom& g = k.g;
     int d[4] = {c[0], c[1], c[2], c[3]};
@@ -101,17 +119,17 @@ __device__ __forceinline__ void link_fwd(cd (&u)[9], const GFArgs& k, const int 
             return;
         }
     }
-    load_m3(u, link_at(g, k.U, d, nu), glink_stride(g));
+    load_u<R2>(u, link_at(g, k.U, d, nu), glink_stride(g));
 }
 
 // lower staple seen from the site m = n - nu_hat:  W_{mu nu}(m) = U_nu(m+mu)^+ U_mu(m)^+ U_nu(m)
-template <bool PART = true>
+template <bool PART = true, bool R2 = false>
 __device__ __forceinline__ void lower_staple_at(cd (&w)[9], const GFArgs& k, const int (&m)[4], int mu, int nu) {
     cd u1[9], u2[9], u3[9], t1[9];
     const int Gs = glink_stride(k.g);
-    link_fwd<PART>(u1, k, m, mu, nu);
-    load_m3(u2, link_at(k.g, k.U, m, mu), Gs);
-    load_m3(u3, link_at(k.g, k.U, m, nu), Gs);
+    link_fwd<PART, R2>(u1, k, m, mu, nu);
+    load_u<R2>(u2, link_at(k.g, k.U, m, mu), Gs);
+    load_u<R2>(u3, link_at(k.g, k.U, m, nu), Gs);
     mm3_dd(t1, u1, u2);
     mm3(w, t1, u3);
 }
@@ -186,19 +204,65 @@ __global__ __launch_bounds__(256) void gauge_force_kernel_part(GFArgs k) {
 
 // one plane (MU, NU) of the staple sum of link (n, MU): upper staple U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+ and lower staple W_{mu nu}(n - nu).
 // MU and NU are compile-time: every index into the by-value argument struct and the coordinate arrays is static.
-template <int MODE, int MU, int NU, bool PART>
+// rows 0, 1 of a link as they come from memory (row 2 is rebuilt when the link is used: finish_u)
+__device__ __forceinline__ void load_u_raw(cd (&u)[9], const double2* __restrict__ base, int stride) {
+#pragma unroll
+    for (int e = 0; e < 6; e++) u[e] = ld(base + (size_t)e * stride);
+}
+__device__ __forceinline__ void finish_u(cd (&u)[9]) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+        const cd x = cmul(u[b1], u[3 + b2]) - cmul(u[b2], u[3 + b1]);
+        u[6 + b] = mk(x.re, -x.im);
+    }
+}
+__device__ __forceinline__ const double2* link_at_shifted(const Geom& g, const double2* __restrict__ U, const int (&c)[4], int dir, int step, int mu) {
+    int d[4] = {c[0], c[1], c[2], c[3]};
+    shift(d, g, dir, step);
+    return link_at(g, U, d, mu);
+}
+
+template <int MODE, int MU, int NU, bool PART, bool R2>
 __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&c)[4], int p, int lane, const double2 (*own)[9][64]) {
+    if constexpr (MU != NU && R2 && !PART && MODE != 2 && LQCD_STAPLE_BURST) {
+        // single GPU, links on the group: the five neighbour links of the plane are issued as ONE burst of two-row loads (30 x 1 KiB per wave: one
+        // memory round trip per plane instead of two), row 2 is rebuilt as each link is consumed
+        const Geom& g = k.g;
+        const int Gs = glink_stride(g);
+        cd a1[9], a2[9], l1[9], l2[9], l3[9], u3[9], t1[9], t2[9];
+        int m[4] = {c[0], c[1], c[2], c[3]};
+        shift(m, g, NU, -1);
+        load_u_raw(a1, link_at_shifted(g, k.U, c, MU, 1, NU), Gs);      // U_nu(n+mu)
+        load_u_raw(a2, link_at_shifted(g, k.U, c, NU, 1, MU), Gs);      // U_mu(n+nu)
+        load_u_raw(l1, link_at_shifted(g, k.U, m, MU, 1, NU), Gs);      // U_nu(m+mu)
+        load_u_raw(l2, link_at(g, k.U, m, MU), Gs);                     // U_mu(m)
+        load_u_raw(l3, link_at(g, k.U, m, NU), Gs);                     // U_nu(m)
+#pragma unroll
+        for (int e = 0; e < 9; e++) { const double2 t = own[NU][e][lane]; u3[e] = mk(t.x, t.y); }
+        finish_u(a1); finish_u(a2);
+        mm3_nd(t1, a1, a2);
+        mm3_nd(t2, t1, u3);
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+        finish_u(l1); finish_u(l2); finish_u(l3);
+        mm3_dd(t1, l1, l2);
+        mm3(t2, t1, l3);
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+        asm volatile("" : "+v"(c[0]), "+v"(A[0].re), "+v"(A[0].im), "+v"(A[4].re), "+v"(A[4].im), "+v"(A[8].re), "+v"(A[8].im));
+    } else
     if constexpr (MU != NU) {
         const Geom& g = k.g;
         const int Gs = glink_stride(g);
         cd u1[9], u2[9], u3[9], t1[9], t2[9];
-        link_fwd<PART>(u1, k, c, MU, NU);                   // U_nu(n+mu)
-        link_fwd<PART>(u2, k, c, NU, MU);                   // U_mu(n+nu)
+        link_fwd<PART, R2>(u1, k, c, MU, NU);               // U_nu(n+mu)
+        link_fwd<PART, R2>(u2, k, c, NU, MU);               // U_mu(n+nu)
         if constexpr (MODE != 2) {
 #pragma unroll
             for (int e = 0; e < 9; e++) { const double2 t = own[NU][e][lane]; u3[e] = mk(t.x, t.y); }
         } else {
-            load_m3(u3, link_at(g, k.U, c, NU), Gs);
+            load_u<R2>(u3, link_at(g, k.U, c, NU), Gs);
         }
         mm3_nd(t1, u1, u2);
         mm3_nd(t2, t1, u3);
@@ -212,7 +276,7 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
         } else {
             int m[4] = {c[0], c[1], c[2], c[3]};
             shift(m, g, NU, -1);
-            lower_staple_at<PART>(t2, k, m, MU, NU);
+            lower_staple_at<PART, R2>(t2, k, m, MU, NU);
         }
 #pragma unroll
         for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
@@ -222,7 +286,7 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
     }
 }
 
-template <int MODE, int MU, bool PART>
+template <int MODE, int MU, bool PART, bool R2>
 __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int lane, const double2 (*own)[9][64]) {
     constexpr bool FUSE_TA = MODE == 1;
     const Geom& g = k.g;
@@ -232,10 +296,10 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
     cd A[9];
 #pragma unroll
     for (int e = 0; e < 9; e++) A[e] = mk(0.0, 0.0);
-    staple_plane<MODE, MU, 0, PART>(A, k, c, p, lane, own);
-    staple_plane<MODE, MU, 1, PART>(A, k, c, p, lane, own);
-    staple_plane<MODE, MU, 2, PART>(A, k, c, p, lane, own);
-    staple_plane<MODE, MU, 3, PART>(A, k, c, p, lane, own);
+    staple_plane<MODE, MU, 0, PART, R2>(A, k, c, p, lane, own);
+    staple_plane<MODE, MU, 1, PART, R2>(A, k, c, p, lane, own);
+    staple_plane<MODE, MU, 2, PART, R2>(A, k, c, p, lane, own);
+    staple_plane<MODE, MU, 3, PART, R2>(A, k, c, p, lane, own);
     const double coef = k.coef;
     if constexpr (MODE == 2) {
         double2* o2 = k.out + glink_off(g, p, k.mu_out, i);
@@ -277,7 +341,7 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
 #ifndef LQCD_STAPLE_OCC
 #define LQCD_STAPLE_OCC 2
 #endif
-template <int MODE, bool PART>
+template <int MODE, bool PART, bool R2 = false>
 __global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArgs k) {
     const Geom& g = k.g;
     int chunk, p;
@@ -290,7 +354,7 @@ __global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArg
     if constexpr (MODE != 2) {
         if (valid) {
             cd um[9];
-            load_m3(um, k.U + glink_off(g, p, mu, i), glink_stride(g));
+            load_u<R2>(um, k.U + glink_off(g, p, mu, i), glink_stride(g));
 #pragma unroll
             for (int e = 0; e < 9; e++) own[mu][e][lane] = mk2(um[e].re, um[e].im);
         }
@@ -298,10 +362,10 @@ __global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArg
     }
     if (!valid) return;
     switch (mu) {
-    case 0: staple_links<MODE, 0, PART>(k, p, i, lane, own); break;
-    case 1: staple_links<MODE, 1, PART>(k, p, i, lane, own); break;
-    case 2: staple_links<MODE, 2, PART>(k, p, i, lane, own); break;
-    default: staple_links<MODE, 3, PART>(k, p, i, lane, own); break;
+    case 0: staple_links<MODE, 0, PART, R2>(k, p, i, lane, own); break;
+    case 1: staple_links<MODE, 1, PART, R2>(k, p, i, lane, own); break;
+    case 2: staple_links<MODE, 2, PART, R2>(k, p, i, lane, own); break;
+    default: staple_links<MODE, 3, PART, R2>(k, p, i, lane, own); break;
     }
 }
 
@@ -404,7 +468,7 @@ __device__ __forceinline__ void reunitarize_m3(cd (&u)[9]) {
     }
 }
 template <bool REUNIT>
-__global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* __restrict__ U, double dt, const double2* __restrict__ P) {
+__global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* __restrict__ U, double dt, const double2* __restrict__ P, unsigned* notproj) {
     size_t off;
     if (!link_of_thread(g, off)) return;
     const int Gs = glink_stride(g);
@@ -427,6 +491,8 @@ __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* _
         if (dev <= 1e-13) {
 #pragma unroll
             for (int k = 0; k < 9; k++) t[k] = v[k];
+        } else {
+            *notproj = 1u;      // some link of this field is not on the group (benign race: every writer stores the same value)
         }
     }
 #pragma unroll
@@ -556,6 +622,7 @@ extern "C" int lqcd_gauge_copy(lqcd_gauge_t dst, lqcd_gauge_t src) {      // sub
     lqcd_ctx_s* c = dst->ctx;
     HIPCHK(hipSetDevice(c->device));
     dst->version++;
+    dst->unitary_version = src->unitary_version == src->version ? dst->version : 0;
     HIPCHK(hipMemcpyAsync(dst->data, src->data, src->elems * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
@@ -611,7 +678,7 @@ static int launch_staple_faces(lqcd_ctx_s* c, const GFArgs& k) {
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
-static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse) {
+static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse, bool two_rows) {
     const dim3 grid(2 * c->geom.nch);
     if (any_partitioned(c)) {       // the instance with the ghost-link / received-staple branches
         if (k.mu_only >= 0) hipLaunchKernelGGL(gauge_force_kernel_part<2>, grid, dim3(64), 0, c->stream, k);
@@ -619,8 +686,10 @@ static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse) {
         else hipLaunchKernelGGL(gauge_force_kernel_part<0>, grid, dim3(256), 0, c->stream, k);
     } else {
         if (k.mu_only >= 0) hipLaunchKernelGGL((gauge_force_kernel<2, false>), grid, dim3(64), 0, c->stream, k);
-        else if (fuse) hipLaunchKernelGGL((gauge_force_kernel<1, false>), grid, dim3(256), 0, c->stream, k);
-        else hipLaunchKernelGGL((gauge_force_kernel<0, false>), grid, dim3(256), 0, c->stream, k);
+        else if (fuse) { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<1, false, true>), grid, dim3(256), 0, c->stream, k);
+                         else hipLaunchKernelGGL((gauge_force_kernel<1, false>), grid, dim3(256), 0, c->stream, k); }
+        else { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<0, false, true>), grid, dim3(256), 0, c->stream, k);
+               else hipLaunchKernelGGL((gauge_force_kernel<0, false>), grid, dim3(256), 0, c->stream, k); }
     }
     HIPCHK(hipGetLastError());
     return LQCD_OK;
@@ -658,7 +727,8 @@ static int staple_force(lqcd_gauge_s* out, lqcd_gauge_s* U, double beta, double 
         LQCHK(launch_staple_faces(c, k));
         LQCHK(gf_exchange_rccl(c, c->gf_wsend, c->gf_wrecv, false));
     }
-    LQCHK(launch_staple_sweep(c, k, fuse));
+    // links known to be on the group (tracked per version: generated there, measured, or projected by the link update): two rows are loaded
+    LQCHK(launch_staple_sweep(c, k, fuse, c->tun.staple_recon && U->unitary_version == U->version));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
 }
@@ -764,7 +834,7 @@ extern "C" int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us
                 HIPCHK(hipMemcpy(Us[c->nbr_fwd[mu]]->ctx->gf_wrecv[mu], c->gf_wsend[mu], gf_face_elems(c, mu) * sizeof(double2), hipMemcpyDeviceToDevice));
     }
     HIPCHK(hipDeviceSynchronize());
-    for (int r = 0; r < n; r++) LQCHK(launch_staple_sweep(Us[r]->ctx, ks[r], fuse != 0));
+    for (int r = 0; r < n; r++) LQCHK(launch_staple_sweep(Us[r]->ctx, ks[r], fuse != 0, false));
     HIPCHK(hipDeviceSynchronize());
     return LQCD_OK;
 }
@@ -791,10 +861,16 @@ extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) 
     // pass (links of a configuration that was never on the group to that precision are left alone).  exp(dt P) U leaves the group only by
     // rounding, but that rounding accumulates: max |row2 - conj(row0 x row1)| passes 1e-14 after ~280 updates (profiles/r03_unitarity_drift.log),
     // i.e. inside the FIRST trajectory, and the 12-real Dslash would be lost for the rest of the run.  0 = the reference's literal U_update!.
-    if (c->tun.md_reunitarize) hipLaunchKernelGGL(link_exp_update_kernel<true>, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data);
-    else hipLaunchKernelGGL(link_exp_update_kernel<false>, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data);
+    unsigned* flag = c->pipe_ctr + 8 * 32 + 24;      // a spare word of the counter block
+    unsigned notproj = 1;
+    if (c->tun.md_reunitarize) {
+        HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(link_exp_update_kernel<true>, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data, flag);
+        HIPCHK(hipMemcpyAsync(&notproj, flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    } else hipLaunchKernelGGL(link_exp_update_kernel<false>, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data, dt, P->data, flag);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (!notproj) U->unitary_version = U->version;      // every link was projected: the field is on the group to rounding
     return LQCD_OK;
 }
 
@@ -805,6 +881,7 @@ extern "C" int lqcd_gauge_reunitarize(lqcd_gauge_t U) {
     lqcd_ctx_s* c = U->ctx;
     HIPCHK(hipSetDevice(c->device));
     U->version++;
+    U->unitary_version = U->version;
     hipLaunchKernelGGL(link_reunitarize_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, U->data);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -115,3 +115,29 @@ def test_reunitarize_entry_point(gpu, orc):
     assert np.abs(W.download() - Uh).max() < 2e-15    # an SU(3) field moves by rounding only
     assert np.abs(V - Uh).max() < 1e-8                # and the perturbed one comes back next to where it started
     assert abs(lq.calculate_Plaquette(U) - orc.plaquette(V, L)) < 1e-13
+
+
+def test_staple_sweep_with_two_row_link_loads(gpu, orc):
+    """links known to be on the group (tracked per field version) are read as rows 0, 1 + rebuilt row 2 by the staple sweep (tunable
+    staple_recon): same force as the full loads and as the oracle; an uploaded field (unknown provenance) takes the full loads"""
+    lq = gpu
+    L = (8, 4, 6, 4)
+    Uh = orc.hot_gauge(L, 14)
+    ref = orc.gauge_force(Uh, L, BETA)
+    out = {}
+    for recon in (1, 0):
+        lat = lq.Lattice(L)
+        lat.set_param("staple_recon", recon)
+        U = lq.Gaugefields(lat).upload(Uh)
+        lq.reunitarize_(U)                    # marks this version as on the group (moves an SU(3) field by rounding only)
+        G = lq.Gaugefields(lat)
+        lq.gauge_force_(G, U, BETA)
+        out[recon] = G.download()
+        assert np.abs(out[recon] - ref).max() / np.abs(ref).max() < 1e-13, recon
+        p = lq.Gaugefields(lat)
+        lq.gauss_distribution_(p, 15)
+        p0 = p.download()
+        lq.P_update_(U, p, 0.1, BETA)         # fused force + TA projection
+        out[("p", recon)] = p.download() - p0
+    assert np.abs(out[1] - out[0]).max() / np.abs(out[0]).max() < 1e-14
+    assert np.abs(out[("p", 1)] - out[("p", 0)]).max() / np.abs(out[("p", 0)]).max() < 1e-13
