@@ -545,6 +545,11 @@ __device__ inline void pipe_wave(const PipeArgs& a, real2 (*part)[12][64], volat
 #else
 #define LQCD_DS_BOUNDS_S __launch_bounds__(256, 3)
 #endif
+#ifdef LQCD_F32
+static constexpr bool kF32Build = true;
+#else
+static constexpr bool kF32Build = false;
+#endif
 template <bool DAG, bool R12, bool NTB>
 __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
@@ -1312,7 +1317,9 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             else if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), sg, sb_, pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), sg, sb_, pad, c->stream, k);
         } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr) &&
-                   (c->tun.dslash_pipe != 2 || k.gauge12)) {      // the scalar-addressing kernel pays with the 12-real links only (its 18-real instance spills at 3 waves/SIMD)
+                   (c->tun.dslash_pipe != 2 || (k.gauge12 && !kF32Build))) {      // the scalar-addressing kernel pays with the fp64 12-real links only: its 18-real
+                                                                                  // instance spills at 3 waves/SIMD, its one-site-per-lane fp32 instance measured 62.5 vs 57 ms of
+                                                                                  // variant 1 in the mixed CG (profiles/r03_mixed_precision.log) -- same grid, so the counts agree
             PipeArgs a;
             a.gauge = k.gauge12 ? k.gauge12 : k.gauge;
             const bool upd = k.upd_scal != nullptr;

@@ -98,3 +98,68 @@ def test_staggered_48x48x48x96_identities(lq):
     lq.sample_pseudofermions_(phi, U, fa, xi)
     S = lq.evaluate_FermiAction(fa, U, phi)
     assert abs(S / lq.dot(xi, xi).real - 1.0) < 1e-7
+
+
+def _leapfrog(lq, U, p, G, fa, phi, dtau, steps, beta):
+    """runMD_QPQ! (standardMD.jl:127-144) with the fused four-direction calls; dtau < 0 retraces the trajectory."""
+    for _ in range(steps):
+        lq.U_update_(U, p, 0.5 * dtau)
+        lq.P_update_(U, p, dtau, beta)
+        for f, ph in zip(fa, phi):
+            lq.calc_UdSfdU_(G, f, U, ph)
+            lq.Traceless_antihermitian_add_(p, dtau, G)
+        lq.U_update_(U, p, 0.5 * dtau)
+
+
+def _trajectory_checks(lq, L, op_pars, fa_pars, dtau, steps, halve, seed=5):
+    """One short HMC trajectory at a full-size lattice from a hot start: |dH| shrinks ~4x when dtau is halved at fixed length (leapfrog),
+    and the trajectory integrated back with -dtau returns to the starting links and energy."""
+    beta = 5.7
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    p, G, U0 = lq.Gaugefields(lat), lq.Gaugefields(lat), lq.Gaugefields(lat)
+    lq.substitute_U_(U0, U)
+    fa, phi = [], []
+    for k, (op_par, fa_par) in enumerate(zip(op_pars, fa_pars)):
+        D = lq.Dirac_operator(U, None, dict(op_par, boundarycondition=(1, 1, 1, -1)))
+        f = lq.FermiAction(D, fa_par)
+        xi, ph = lq.Fermionfields(lat, D.kind), lq.Fermionfields(lat, D.kind)
+        lq.gauss_sampling_in_action_(xi, U, f, seed + 10 * k)
+        lq.sample_pseudofermions_(ph, U, f, xi)
+        fa.append(f)
+        phi.append(ph)
+
+    def H():
+        return lq.momentum_action(p) + lq.evaluate_GaugeAction(U, beta) + sum(lq.evaluate_FermiAction(f, U, ph) for f, ph in zip(fa, phi))
+
+    dH = []
+    for div in ((1, 2) if halve else (1,)):
+        lq.substitute_U_(U, U0)
+        lq.gauss_distribution_(p, seed + 1)
+        H0 = H()
+        _leapfrog(lq, U, p, G, fa, phi, dtau / div, steps * div, beta)
+        dH.append(H() - H0)
+    assert lat.get_param("recon_active") == 1                  # the links stayed on the group through the trajectory (md_reunitarize)
+    if halve:
+        assert 2.5 < dH[0] / dH[1] < 6.0, dH                   # second-order integrator
+    assert abs(dH[-1]) < 1e-5 * abs(H0), (dH, H0)
+    div = 2 if halve else 1
+    _leapfrog(lq, U, p, G, fa, phi, -dtau / div, steps * div, beta)
+    assert abs(H() - H0) < 1e-9 * abs(H0)
+    assert np.max(np.abs(U.download() - U0.download())) < 1e-9
+    return dH
+
+
+def test_wilson_clover_32x32x32x64_short_trajectory(lq):
+    """configs[3] at full size on one GPU: two-flavour Wilson-clover HMC, 4 (8) leapfrog steps"""
+    dH = _trajectory_checks(lq, (32, 32, 32, 64), [{"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": CSW, "eps_CG": 1e-18, "MaxCGstep": 3000}],
+                            [{}], dtau=0.02, steps=4, halve=True)
+    print("32^3x64 clover dH(dtau), dH(dtau/2) =", dH)
+
+
+def test_staggered_rhmc_48x48x48x96_short_trajectory(lq):
+    """configs[4] at full size on one GPU: staggered RHMC Nf = 2 + 1 (two rational pseudofermion actions), 2 leapfrog steps and back"""
+    dH = _trajectory_checks(lq, (48, 48, 48, 96), [{"Dirac_operator": "Staggered", "mass": 0.05, "eps_CG": 1e-14, "MaxCGstep": 5000},
+                                                  {"Dirac_operator": "Staggered", "mass": 0.1, "eps_CG": 1e-14, "MaxCGstep": 5000}],
+                            [{"Nf": 2}, {"Nf": 1}], dtau=0.01, steps=2, halve=False)
+    print("48^3x96 staggered 2+1 dH =", dH)
