@@ -229,6 +229,30 @@ def main():
       except Exception as e:
         out["time_to_solution_1e-16"] = {"error": str(e)}
 
+    # ---- secondary (outside the timed region): the same CG window on links that went through molecular dynamics -- a copy of the field, 20 MD
+    # steps of the reference's Sexton-Weingarten gauge legs (standardMD.jl:146-166, N = 10, dtau = 0.05: 400 link updates from a Gaussian
+    # momentum), which is where the 12-real criterion (unitary to 1e-14) would be lost without the projection inside the link update
+    if world == 1 and not force_dist:
+      try:
+        U2, p2 = lq.Gaugefields(lat), lq.Gaugefields(lat)
+        lq.substitute_U_(U2, U)
+        lq.gauss_distribution_(p2, 4242)
+        nsw, dtau, steps = 10, 0.05, 20
+        for _ in range(steps * nsw):
+            eps = dtau / nsw
+            lq.U_update_(U2, p2, 0.5 * eps)
+            lq.P_update_(U2, p2, eps, 5.7)
+            lq.U_update_(U2, p2, 0.5 * eps)
+        D2 = lq.Dirac_operator(U2, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": (1, 1, 1, -1)})
+        ms_d2 = lq.bench_dslash(D2, y, b, warm=20, reps=args.dslash_reps)
+        msi2 = lq.bench_cg(D2, x, b, warm=5, niter=50)
+        out["after_md_trajectory"] = {"link_updates": 2 * steps * nsw, "md_reunitarize": lat.get_param("md_reunitarize"),
+                                      "max_unitarity_deviation": lq.unitarity_deviation(U2), "gauge_recon_active": lat.get_param("recon_active"),
+                                      "plaquette": lq.calculate_Plaquette(U2), "dslash_ms": ms_d2, "cg_iters_per_s": 1e3 / msi2}
+        p2.close(); U2.close()
+      except Exception as e:
+        out["after_md_trajectory"] = {"error": str(e)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
         out["reference_parity"] = reference_parity(lq)

@@ -79,10 +79,14 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * [default]), graph (1: hipGraph replay of CG bursts), gauge_recon (12 [default]: the split kernels read two rows per link and rebuild the
  * third -- applied only while every link of the field is unitary to 1e-14, results within the fp64 Dslash tolerance; 18: all
  * 18 stored reals are always read), recon_active (read-only: did the last Wilson application use the 12-real links), nt_gauge (bit 0 [default]: the backward = last use of a link is a non-temporal load; bit 1: the forward use too), nt_store (1 [default]:
- * non-temporal output stores), lds_pad_kb, persist_per_cu, dslash_pipe (1: with dslash_variant 1 on large lattices the persistent, software-pipelined form of the
- * direction-split kernel; pipe_per_cu / pipe_grid / pipe_min_chunks shape its grid), stag_both (1: the staggered split kernel issues the loads of both hops back to back);
+ * non-temporal output stores), lds_pad_kb, persist_per_cu, dslash_pipe (forms of the Wilson r = 1 direction-split kernel on lattices whose z-planes are whole chunks;
+ * all bit-identical: 2 [default]: scalar (wave-uniform) addressing, one workgroup per chunk, 12-real fp64 links only; 1: persistent workgroups with the next chunk's
+ * loads in flight across the barrier, per-XCD in-order queue -- pipe_per_cu / pipe_grid / pipe_min_chunks shape its grid; 3: pipe_chunks_per_wg consecutive chunks per
+ * workgroup, pipelined; 0: plain variant 1.  Forms 1 and 3 measured slower, DESIGN.md section 2 "Round 3"), mixed_pair32 (1 [default]: the mixed-precision Wilson
+ * solvers use the fp32 site-pair kernel on unpartitioned lattices with T % 4 == 0; read-only pair32_active), stag_both (1: the staggered split kernel issues the loads of both hops back to back);
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
- * mixed-precision CG; 2: the same, and every rational entry solves all its poles with lqcd_solve_multishift_mixed_cg), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
+ * mixed-precision CG; 2: the same, and every rational entry solves all its poles with lqcd_solve_multishift_mixed_cg -- measured slower than the fp64
+ * multi-shift CG at 48^3x96 with 18 poles, default 0), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),
  * md_remap (1 [default]: the staple sweep follows the stencil's XCD-aware workgroup map), md_reunitarize (1 [default]: lqcd_gauge_exp_update projects the updated
  * links back onto SU(3) in the same pass; 0: the reference's literal update), cg_fold_scalars (1 [default]: several ranks, the scalar steps behind the two all-reduces of a
  * CG iteration run in the consumers' prologues), nt_blas (1 [default]: non-temporal loads / stores in the CG update kernels),
@@ -91,8 +95,10 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
  * construction of the clover term / force also on one rank);
  * partitioned lattices: halo_merge (1 [default]: one message per peer when both faces go to the same rank), halo_stream_mode
- * (-1 [default]: time the three stream schedules of the halo exchange once; 0 | 1 | 2 force one), halo_tuned_us0..2 (read-only:
- * the times that choice was made from). */
+ * (-1 [default]: time the three stream schedules of the halo exchange once -- collectively: every rank adopts the schedule with the smallest time summed over
+ * the ranks; 0 | 1 | 2 force one and skip the timing), halo_tuned_us0..2 (read-only: the times that choice was made from), halo_fuse (bit 1 [default 2]: the
+ * exterior of D p packs the faces D^+ needs and the CG update packs the new search direction -- no separate pack launches; bit 0: the exterior's last
+ * block sums the |.|^2 partials -- measured slower, off), staple_recon (1 [default]: the staple sweep reads two rows of links known to be on the group). */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
 int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);
 

@@ -91,10 +91,22 @@ if bench:
         lines.append(f"| all 18 reals of every link read (`gauge_recon = 18`): Dslash, fraction of 8 TB/s on 960 B/site, CG | {g['dslash_ms']:.4f} ms, {g['frac_of_peak']:.3f}, {g['cg_iters_per_s']:.1f} iter/s | `{tag}_bench_n1.json` |")
         if g.get("traffic"):
             lines.append(f"| … its measured traffic | {g['traffic'] / 1e9:.3f} GB per launch = {g['traffic_over_bytes_moved']:.3f} × 960 B/site | `{tag}_bench_n1.json` |")
+    t = bench.get("time_to_solution_1e-16")
+    if t and "speedup" in t:
+        lines.append(f"| time to r·r < 1e-16: fp64 CG / mixed-precision CG (true residual {t['mixed_true_rr']:.1e}) | {t['fp64_cg_ms']:.1f} ms ({t['fp64_iters']} it) / {t['mixed_cg_ms']:.1f} ms ({t['mixed_inner_iters']} inner, {t['mixed_outer_steps']} outer) = {t['speedup']:.2f} × | `{tag}_bench_n1.json` |")
+    m = bench.get("after_md_trajectory")
+    if m and "cg_iters_per_s" in m:
+        lines.append(f"| after {m['link_updates']} link updates of MD (`md_reunitarize = {m['md_reunitarize']}`): max unitarity deviation, 12-real kernel active, Dslash, CG | {m['max_unitarity_deviation']:.1e}, {m['gauge_recon_active']}, {m['dslash_ms']:.4f} ms, {m['cg_iters_per_s']:.1f} iter/s | `{tag}_bench_n1.json` |")
     c = bench.get("cpu_baseline")
     if c:
         lines.append(f"| CPU baseline ({c['kind']}, {c['cores']} core) | {c['value']:.3f} iter/s, Dslash {c['dslash_gflops']:.2f} GFLOP/s | `{tag}_bench_n1.json` |")
-for sub, label in (("wilson_dirsplit<false, true, false>", "12-real D"), ("wilson_dirsplit<true, true, false>", "12-real D† (CG update mode)"),
+        a = c.get("all_cores")
+        if a:
+            lines.append(f"| … the same oracle window on all {a['cores']} host cores (OpenMP; first-touch by one thread, NUMA-limited) | {a['value']:.3f} iter/s, Dslash {a['dslash_gflops']:.2f} GFLOP/s | `{tag}_bench_n1.json` |")
+for sub, label in (("wilson_dirsplit_s<false, true", "12-real D, scalar-addressing instance (default since round 3)"), ("wilson_dirsplit_s<true, true", "12-real D† (CG update mode), scalar-addressing instance"),
+                   ("wilson_dirsplit_pair32<false", "fp32 site-pair D (inner solver of the mixed-precision CG)"), ("wilson_dirsplit_pair32<true", "fp32 site-pair D† (update mode)"),
+                   ("cg32_update_xp", "fp32 x, p update"),
+                   ("wilson_dirsplit<false, true, false>", "12-real D"), ("wilson_dirsplit<true, true, false>", "12-real D† (CG update mode)"),
                    ("wilson_dirsplit<false, false, false>", "18-real D"), ("wilson_dirsplit_pipe<false, true", "12-real D, persistent form"), ("cg_update_even", "p update, even iterations (x deferred)"),
                    ("cg_update_odd", "x (two terms) and p update, odd iterations"), ("cg_update_xp", "x, p update"), ("reduce_final", "final reduction")):
     mk = [k for k in med_rows if sub in k]
@@ -107,11 +119,11 @@ for sub, label in (("wilson_dirsplit<false, true, false>", "12-real D"), ("wilso
         lines.append(f"| rocprofv3 `--kernel-trace --stats` of the same command: {label} `{sub}` | {float(s['AverageNs']) / 1e3:.1f} µs average over {s['Calls']} calls | `{tag}_bench_kernel_stats.csv` |")
 if trace:
     lines.append(f"| `bench.py`'s HIP-event Dslash figure in that profiled run | {trace['dslash_ms']:.4f} ms | `{tag}_trace_bench.json` |")
-for sub, label in (("wilson_dirsplit<false, true, false>", "12-real kernel"), ("wilson_dirsplit<false, false, false>", "18-real kernel")):
+for sub, label in (("wilson_dirsplit_s<false, true", "12-real kernel (scalar addressing)"), ("wilson_dirsplit<false, true, false>", "12-real kernel"), ("wilson_dirsplit<false, false, false>", "18-real kernel")):
     fs, ws = pm(sub, "FETCH_SIZE"), pm(sub, "WRITE_SIZE")
     if fs and ws:
         tr = (2 * fs + ws) * 1024
-        moved = (768 if "true, false" in sub else 960) * V
+        moved = (768 if "<false, true" in sub else 960) * V
         hit, miss = pm(sub, "TCC_HIT_sum"), pm(sub, "TCC_MISS_sum")
         lines.append(f"| PMC passes (separate): {label}: FETCH_SIZE, WRITE_SIZE → (2·FETCH + WRITE) KiB | {fs:.4g} KiB, {ws:.4g} KiB → {tr / 1e9:.3f} GB = {tr / moved:.3f} × bytes moved"
                      + (f"; TCC hit {hit / (hit + miss):.3f}" if hit and miss else "") + f" | `{tag}_pmc_summary.csv` |")
