@@ -184,6 +184,8 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     HIPCHK(hipMemset(c->d_scal, 0, SCAL_DOUBLES * sizeof(double)));
     HIPCHK(hipMalloc((void**)&c->pipe_ctr, 10 * 32 * sizeof(unsigned)));      // work-queue heads of the persistent stencil kernel: zero between launches
     HIPCHK(hipMemset(c->pipe_ctr, 0, 10 * 32 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&c->cgp_ctr, 9 * 32 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->cgp_ctr, 0, 9 * 32 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&c->h_scal, SCAL_DOUBLES * sizeof(double), hipHostMallocDefault));
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
@@ -214,7 +216,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     (void)hipFree(c->clover_q[0]); (void)hipFree(c->clover_q[1]);
     (void)hipFree(c->clover_ext); (void)hipFree(c->clover_ext_buf[0]); (void)hipFree(c->clover_ext_buf[1]);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
-    (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipFree(c->pipe_ctr); (void)hipHostFree(c->h_scal);
+    (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipFree(c->pipe_ctr); (void)hipFree(c->cgp_ctr); (void)hipHostFree(c->h_scal);
     (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1);
     (void)hipEventDestroy(c->ev_tune0); (void)hipEventDestroy(c->ev_tune1);
     (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->comm_stream);
@@ -248,6 +250,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "halo_stream_mode")) return &c->tun.halo_stream_mode;
     if (!strcmp(key, "cg_skip_done")) return &c->tun.cg_skip_done;
     if (!strcmp(key, "cg_small")) return &c->tun.cg_small;
+    if (!strcmp(key, "cg_persist")) return &c->tun.cg_persist;
     if (!strcmp(key, "md_remap")) return &c->tun.md_remap;
     if (!strcmp(key, "staple_recon")) return &c->tun.staple_recon;
     if (!strcmp(key, "md_reunitarize")) return &c->tun.md_reunitarize;

@@ -346,6 +346,8 @@ struct Tunables {
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
     int cg_defer_x = 1;       // fused CG: x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
                               // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates
+    int cg_persist = 1;       // staggered CG on an unpartitioned lattice of <= 256 chunks: the whole solve is ONE launch (cg_persist.hip), two grid-wide
+                              // synchronisations per iteration instead of three dependent launches; 0: the cg_small launch chain
     int cg_small = 1;         // fused CG on an unpartitioned lattice with <= 1024 stencil workgroups: the two reduction launches of an iteration are folded
                               // into the prologues of the kernels that consume them (3 dependent launches per iteration instead of 5)
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
@@ -382,6 +384,9 @@ struct lqcd_ctx_s {
     double* d_scal = nullptr;     // small device scalar block (solver state)
     double* h_scal = nullptr;     // pinned mirror
     uint64_t halo_epoch = 0;      // bumped by everything that writes the halo send buffers: a producer's pre-packed faces are valid only while it is unchanged
+    unsigned* cgp_ctr = nullptr;  // one-launch CG (cg_persist.hip): 8 barrier counters 128 B apart, monotonic across launches
+    unsigned cgp_epoch = 0;       // barriers those counters have counted; cgp_nwg: for which grid (-1: unknown -> zero them first)
+    int cgp_nwg = -1;
     unsigned* pipe_ctr = nullptr; // persistent stencil kernel: 8 per-XCD queue heads + 1 exit counter, 128 B apart; all zero between launches
     // halo buffers (sized for Wilson full-lattice: 2 parities * 6 comps * Fh)
     double2* send_fwd[4] = {}, *send_bwd[4] = {}, *recv_fwd[4] = {}, *recv_bwd[4] = {};

@@ -462,8 +462,14 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     int it = 0;
     bool converged = false;
     if (!(w.r && w.p && w.q && w.tmp)) st = LQCD_ERR_HIP;
-    if (st == LQCD_OK) st = cg_setup(op, x, b, w, fixed ? -1.0 : eps, &rr);
-    if (st == LQCD_OK && !fixed && rr < eps) converged = true;
+    // launch-bound staggered lattices: initial residual and all iterations in one launch (cg_persist.hip); x is complete on return
+    const bool one_launch = st == LQCD_OK && maxiter > 0 && c->tun.graph == 0 && cg_persist_ok(op);
+    if (one_launch) {
+        st = cg_persist_run(op, x, b, w, fixed ? -1.0 : eps, maxiter, &it, &rr, &converged);
+        if (st == LQCD_OK && !std::isfinite(rr)) { set_error("CG: residual is not finite"); st = LQCD_ERR_NOT_CONVERGED; }
+    }
+    if (st == LQCD_OK && !one_launch) st = cg_setup(op, x, b, w, fixed ? -1.0 : eps, &rr);
+    if (st == LQCD_OK && !one_launch && !fixed && rr < eps) converged = true;
     const int check_every = 8;
     // Launch-bound lattices (the cg_small regime: <= 1024 stencil workgroups, an iteration is three ~5 us launches): every readback of the
     // scalar block is a host synchronisation worth about two iterations, an iteration enqueued behind the converging one only three no-op
@@ -477,7 +483,7 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     const bool use_graph = c->tun.graph != 0 && !any_partitioned(c);
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
-    while (st == LQCD_OK && !converged && it < maxiter) {
+    while (st == LQCD_OK && !one_launch && !converged && it < maxiter) {
         int burst = std::min(adaptive ? next_burst : check_every, maxiter - it);
         if (fixed && !use_graph) burst = maxiter - it;
         if (use_graph && burst == check_every) {
@@ -519,7 +525,7 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
-    if (st == LQCD_OK && !converged) {          // a window / an exhausted solve that stopped on an even iteration: complete x
+    if (st == LQCD_OK && !converged && !one_launch) {          // a window / an exhausted solve that stopped on an even iteration: complete x
         st = cg_flush_x(op, x, w);
         if (st == LQCD_OK) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) st = hip_fail(e, "cg flush", __FILE__, __LINE__); }
     }

@@ -150,6 +150,7 @@ def test_small_lattice_cg_without_reduction_launches_gives_identical_iterates(lq
     same iteration count and residual, for to-tolerance solves and for the fixed-length window."""
     kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
     lat = lq.Lattice(L)
+    lat.set_param("cg_persist", 0)        # this test is about the launch chain (the one-launch form: tests/test_gpu_cg_persist.py)
     U = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 941))
     D = lq.Dirac_operator(U, None, {"Dirac_operator": kind_name, "κ": 0.141139, "mass": 0.5, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-18})
     b = lq.Fermionfields(lat, kind)
