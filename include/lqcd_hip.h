@@ -92,7 +92,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * CG iteration run in the consumers' prologues), nt_blas (1 [default]: non-temporal loads / stores in the CG update kernels),
  * cg_skip_done, cg_defer_x (1 [default]: the fused CG updates x every second iteration with both search directions, p alternating between
  * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates), cg_persist (1 [default]: a staggered CG on an unpartitioned lattice of
- * at most 256 chunks of 64 sites runs as ONE launch -- initial residual and all iterations, two grid-wide synchronisations per iteration; 0: the launch chain), cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
+ * at most 256 chunks of 64 sites runs as ONE launch -- initial residual and all iterations, two grid-wide synchronisations per iteration, every wait bounded: if the workgroups are not all resident (a busy GPU) x is left untouched, the solve is
+ * repeated by the launch chain and the key drops to 0; 0: the launch chain; 2: test hook that forces that fall-back), cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
  * construction of the clover term / force also on one rank);
  * partitioned lattices: halo_merge (1 [default]: one message per peer when both faces go to the same rank), halo_stream_mode

@@ -19,7 +19,8 @@
 // published with relaxed agent-scope atomic stores (global_store ... sc1, write-through), every wave drains its stores (s_waitcnt vmcnt(0)),
 // lane 0 adds 1 to one of eight monotonic counters with a relaxed agent-scope atomic and lanes 0..7 poll them with relaxed loads; consumers read published data
 // with relaxed agent-scope atomic loads (global_load ... sc1).  No fences, no dependence on which XCD a workgroup runs on.  Every spin is
-// bounded (wall clock, 50 ms): a workgroup that gives up leaves -- then every workgroup does -- and the host reports LQCD_ERR_HIP.
+// bounded (wall clock, 50 ms): a workgroup that gives up leaves -- then every workgroup does --, x stays untouched and the host repeats the
+// solve with the launch chain (and stops using this form on the context).
 // Reductions: every workgroup sums the same <= 256 partials in the same order, so all of them take the same decisions.
 #include "ops_internal.h"
 #include "stencil_common.h"
@@ -43,6 +44,7 @@ struct PersistArgs {
     double* part;        // [0, 256): |t|^2 partials, [256, 512): |r|^2 partials
     unsigned* ctr;       // ctr[32 k], k < 8: barrier counters (monotonic across launches)
     int nwg, nch, maxiter;
+    int nexp;            // arrivals a barrier waits for: nwg (test hook cg_persist = 2: nwg + 1, so that every workgroup gives up)
     unsigned epoch0;
 };
 
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(64) void cg_persist_staggered(PersistArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) st_c(a.t[p] + own + (size_t)k * Ss, t[k]);
-    ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nwg);
+    ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nexp);
     {
         cd tn[8][3], q[3];
 #pragma unroll
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64) void cg_persist_staggered(PersistArgs a) {
         nr = wave_sum(nr);
         if (lane == 0) stc(a.part + 256 + blockIdx.x, nr);
     }
-    if (ok) ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nwg);
+    if (ok) ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nexp);
     double rr = 0.0, beta = 0.0;
     int it = -1;          // the initial residual plays the part of "iteration -1": its |r|^2 partials are summed at the top of the loop
     while (ok) {
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64) void cg_persist_staggered(PersistArgs a) {
         }
         nt = wave_sum(nt);
         if (lane == 0) stc(a.part + blockIdx.x, nt);
-        ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nwg);
+        ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nexp);
         if (!ok) break;
         // ---- phase B: the neighbours' t requested before the |t|^2 partials are read
         cd tn[8][3], q[3];
@@ -288,10 +290,12 @@ __global__ __launch_bounds__(64) void cg_persist_staggered(PersistArgs a) {
         }
         nr = wave_sum(nr);
         if (lane == 0) stc(a.part + 256 + blockIdx.x, nr);
-        ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nwg);
+        ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nexp);
     }
+    if (ok) {       // a solve that gave up leaves x as it found it (the caller repeats it with the launch chain)
 #pragma unroll
-    for (int k = 0; k < 3; k++) st(a.x[p] + own + (size_t)k * Ss, x[k]);
+        for (int k = 0; k < 3; k++) st(a.x[p] + own + (size_t)k * Ss, x[k]);
+    }
     if (blockIdx.x == 0 && lane == 0) {
         a.scal[S_RR] = rr;
         a.scal[S_ITERS] = (double)(it < 0 ? 0 : it);
@@ -315,7 +319,8 @@ bool cg_persist_ok(lqcd_op_s* op) {
 
 // The whole solve: r = b - D^+D x, then the iterations, until r.r < eps (eps < 0: exactly maxiter iterations) or maxiter.  The work vectors only
 // lend their storage (r, two p buffers, t); on return x is complete and rr / iteration count / done flag have been read back.
-int cg_persist_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, int maxiter, int* iters, double* rr, bool* converged) {
+int cg_persist_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, int maxiter, int* iters, double* rr, bool* converged, bool* gave_up) {
+    *gave_up = false;
     lqcd_ctx_s* c = op->ctx;
     apply_bc(c, op->bc);
     PersistArgs a;
@@ -333,6 +338,7 @@ int cg_persist_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w,
     a.nch = c->geom.Vh / 64;
     a.nwg = 2 * a.nch;
     a.maxiter = maxiter;
+    a.nexp = a.nwg + (c->tun.cg_persist == 2 ? 1 : 0);
     // a launch whose grid is not the one the counters have counted so far (another lattice cannot share a context, but the flat / sharded
     // forms differ) or an epoch count near the wrap starts from zeroed counters
     if (c->cgp_nwg != a.nwg || c->cgp_epoch > 100000000u) {
@@ -346,9 +352,9 @@ int cg_persist_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w,
     c->cgp_nwg = -1;          // until the barrier count of this launch is known the counters cannot be trusted
     HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->h_scal[S_DONE - S_RR] < 0.0) {
-        set_error("one-launch CG: a workgroup gave up waiting at a grid-wide synchronisation (are all workgroups resident?)");
-        return LQCD_ERR_HIP;
+    if (c->h_scal[S_DONE - S_RR] < 0.0) {      // a workgroup waited 50 ms at a synchronisation: not all of them were resident (a busy GPU)
+        *gave_up = true;                       // x is untouched; the caller falls back to the launch chain and stops asking for this form
+        return LQCD_OK;
     }
     c->cgp_epoch += (unsigned)c->h_scal[S_PQ - S_RR];
     c->cgp_nwg = a.nwg;

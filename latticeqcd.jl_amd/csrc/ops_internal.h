@@ -29,7 +29,7 @@ int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);    // applies a pend
 int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0);
 // cg_persist.hip: a staggered CG on a launch-bound lattice as ONE launch (initial residual included; the work vectors lend their storage)
 bool cg_persist_ok(lqcd_op_s* op);
-int cg_persist_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, int maxiter, int* iters, double* rr, bool* converged);
+int cg_persist_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, int maxiter, int* iters, double* rr, bool* converged, bool* gave_up);
 typedef std::function<int(double2* out, const double2* in)> ApplyFn;
 // multi-shift coefficient step (zeta recurrences next to the CG scalars): d_ms = [sigma | zeta_{n-1} | zeta_n | a | b | z] (ns doubles each),
 // alpha_{n-1}, beta_{n-1}; stop_when_frozen raises S_DONE once every shift has converged (no unshifted solution wanted)

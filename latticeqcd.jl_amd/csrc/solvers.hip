@@ -463,10 +463,12 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     bool converged = false;
     if (!(w.r && w.p && w.q && w.tmp)) st = LQCD_ERR_HIP;
     // launch-bound staggered lattices: initial residual and all iterations in one launch (cg_persist.hip); x is complete on return
-    const bool one_launch = st == LQCD_OK && maxiter > 0 && c->tun.graph == 0 && cg_persist_ok(op);
+    bool one_launch = st == LQCD_OK && maxiter > 0 && c->tun.graph == 0 && cg_persist_ok(op);
     if (one_launch) {
-        st = cg_persist_run(op, x, b, w, fixed ? -1.0 : eps, maxiter, &it, &rr, &converged);
-        if (st == LQCD_OK && !std::isfinite(rr)) { set_error("CG: residual is not finite"); st = LQCD_ERR_NOT_CONVERGED; }
+        bool gave_up = false;
+        st = cg_persist_run(op, x, b, w, fixed ? -1.0 : eps, maxiter, &it, &rr, &converged, &gave_up);
+        if (gave_up) { one_launch = false; it = 0; rr = 0; converged = false; c->tun.cg_persist = 0; }      // not all workgroups were resident: the chain from here on
+        else if (st == LQCD_OK && !std::isfinite(rr)) { set_error("CG: residual is not finite"); st = LQCD_ERR_NOT_CONVERGED; }
     }
     if (st == LQCD_OK && !one_launch) st = cg_setup(op, x, b, w, fixed ? -1.0 : eps, &rr);
     if (st == LQCD_OK && !one_launch && !fixed && rr < eps) converged = true;

@@ -97,3 +97,22 @@ def test_one_launch_cg_does_not_apply_where_it_must_not(lq, orc):
             ref = x2.download()
         else:
             assert rel_err(x2.download(), ref) < 1e-9
+
+
+def test_one_launch_cg_that_gives_up_falls_back_to_the_chain(lq, orc):
+    """cg_persist = 2 (test hook): the synchronisations wait for one workgroup more than the launch has, every workgroup gives up after the
+    50 ms bound, x is left untouched, the solve is repeated by the launch chain and the context stops asking for the one-launch form."""
+    lat, Uh, U, D, bh, b = _setup(lq, orc, (8, 8, 8, 8), 2151)
+    A = lq.DdagD_operator(D)
+    x0 = b.similar()
+    lat.set_param("cg_persist", 0)
+    it0, rr0 = lq.solve_DinvX_(x0, A, b, return_info=True)
+    lat.set_param("cg_persist", 2)
+    x = b.similar()
+    it, rr = lq.solve_DinvX_(x, A, b, return_info=True)
+    assert lat.get_param("cg_persist") == 0
+    assert it == it0 and np.array_equal(x.download(), x0.download())
+    lat.set_param("cg_persist", 1)                    # and it works again afterwards (counters are re-zeroed)
+    x2 = b.similar()
+    it2, rr2 = lq.solve_DinvX_(x2, A, b, return_info=True)
+    assert abs(it2 - it0) <= 1 and rel_err(x2.download(), x0.download()) < 1e-9
