@@ -2,7 +2,7 @@
 #
 # STATUS: written against the interface the reference's own callers use (every generic and every struct-field constraint of
 # src/md/AbstractMD.jl:78-135, src/md/standardMD.jl:5-101, src/updates/standardHMC.jl:1-91, src/system/universe.jl:30-143 is listed in
-# tests/golden/ref_caller_inventory.json and checked against this file by tests/test_host_logic.py) but NEVER EXECUTED: there is no Julia
+# tests/golden/ref_caller_inventory.json and checked against this file by tests/test_julia_binding_static.py) but NEVER EXECUTED: there is no Julia
 # in the build image (SURVEY.md section 0.3).  Everything below the `ccall`s is exercised through the same C ABI by tests/ (Python ctypes).
 # The file is deliberately thin: every method is one ccall plus error translation.
 #

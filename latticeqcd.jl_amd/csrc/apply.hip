@@ -138,10 +138,10 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         }
         // the choice is collective: every rank adopts the schedule with the smallest time summed over the ranks (one 12-byte all-reduce), so that
         // no two ranks interleave their sends and receives differently and a slow rank's view counts
-        if (c->has_comm && c->nranks > 1) {
+        if (c->has_comm) {      // (a one-rank communicator -- self-partition tests -- takes the same path: the all-reduce is then the identity)
             float* d_ms = (float*)c->d_partial;
             HIPCHK(hipMemcpyAsync(d_ms, ms, sizeof(ms), hipMemcpyHostToDevice, c->stream));
-            NCCLCHK(ncclAllReduce(d_ms, d_ms, 3, ncclFloat, ncclSum, c->comm, c->stream));
+            NCCLCHK(ncclAllReduce(d_ms, d_ms, 3, ncclFloat, ncclSum, c->comm_red, c->stream));      // the compute stream's communicator
             HIPCHK(hipMemcpyAsync(ms, d_ms, sizeof(ms), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             for (int mode = 0; mode < 3; mode++) ms[mode] /= (float)c->nranks;
