@@ -204,7 +204,8 @@ int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, 
  * copies of the links and work vectors, fp32 build of the stencil) inside an fp64 defect correction.  Same contract as
  * lqcd_solve_cg_DdagD -- solve_DinvX!(y, DdagD, x) -- except that the stopping rule real(r.r) < eps is enforced on the TRUE
  * residual b - D^+D x recomputed in fp64.  x holds the initial guess.  inner_tol: relative residual asked of each fp32 solve
- * (<= 0: 1e-4).  iters: total inner iterations (+ fp64 iterations if the fall-back ran); outer: correction steps. */
+ * (<= 0: chosen per step -- as few defect-correction steps as an fp32 recurrence supports, one per 1e-6 of the residual norm still to go, the
+ * required reduction split evenly over them).  iters: total inner iterations (+ fp64 iterations if the fall-back ran); outer: correction steps. */
 int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
                               int* outer, double* final_rr);
 /* diagnostic, no reference counterpart: out = D in (D^+ in) through the fp32 operator the mixed-precision solvers use on this operator (fp32

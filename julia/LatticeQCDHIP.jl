@@ -385,7 +385,7 @@ function solve_parity_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion, parity::
     y
 end
 # mixed-precision variant of solve_DinvX!(y, DdagD, x): fp32 inner CG, stopping rule on the true fp64 residual
-function solve_mixed_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion; inner_tol = 1e-4)
+function solve_mixed_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion; inner_tol = 0.0)
     it, out, rr = Ref{Cint}(0), Ref{Cint}(0), Ref{Float64}(0)
     check(ccall((:lqcd_solve_mixed_cg_DdagD, LIB), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Float64, Ref{Cint}, Ref{Cint}, Ref{Float64}),

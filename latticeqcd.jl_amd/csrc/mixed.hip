@@ -408,7 +408,7 @@ extern "C" int lqcd_op_apply_f32(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t 
 
 // Mixed-precision CG for D^+D x = b.  x holds the initial guess.  eps: absolute bound on the TRUE squared residual (the
 // reference's rule real(r.r) < eps, evaluated in fp64); inner_tol: relative residual norm requested from each fp32 solve
-// (<= 0 selects 1e-4).  iters = total fp32 iterations (+ fp64 iterations of the fall-back, if it ran); outer = defect-correction steps.
+// (<= 0 [default of the bindings]: chosen per step, see below).  iters = total fp32 iterations (+ fp64 iterations of the fall-back, if it ran); outer = defect-correction steps.
 extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
                                          int* outer, double* final_rr) {
     ARGCHK(op && x && b && x->ctx == op->ctx && b->ctx == op->ctx && x->kind == op->kind && b->kind == op->kind && x->subset == LQCD_FULL &&
@@ -416,7 +416,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
            "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
-    if (inner_tol <= 0.0) inner_tol = 1e-4;
+    const bool adaptive = inner_tol <= 0.0;       // default: the fewest defect-correction steps fp32 allows, the required reduction split evenly over them
     const size_t n = x->elems;
     VariantPin pin(c);
     Mix32 m;
@@ -447,8 +447,19 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
             if (!std::isfinite(rr)) { set_error("mixed CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
             const double nrm = std::sqrt(rr);
             LQCHK(to_f32(c, m.layout, m.r, r->data, n, 1.0 / nrm));
-            // no tighter than needed to reach eps (with a 10x margin), no tighter than fp32 can deliver
-            const double eps2 = std::max(inner_tol * inner_tol, 0.1 * eps / rr);
+            // no tighter than needed to reach eps (with a 10x margin), no tighter than fp32 can deliver.  Every defect-correction step costs a true
+            // residual (two fp64 Dslash + conversions ~ 1.2 ms at 32^3x64) and a restart of the Krylov space, so the default asks for as few as an
+            // fp32 recurrence can support -- one step per 1e-12 of |r|^2 still to go (1e-6 in norm) -- and splits what is left evenly over them
+            // (32^3x64 to 1e-16: 2 steps / 77 fp32 iterations instead of 3 / 79 with a fixed 1e-4: 52.1 -> 49.3 ms, profiles/r03_mixed_precision.log)
+            const double need = 0.1 * eps / rr;      // < 1 here
+            double eps2;
+            if (adaptive) {
+                const double floor2 = 1e-12;
+                const int steps = std::max(1, (int)std::ceil(std::log(eps / rr) / std::log(floor2) - 1e-9));      // counted without the margin
+                eps2 = std::max(floor2, std::pow(need, 1.0 / steps));
+            } else {
+                eps2 = std::max(inner_tol * inner_tol, need);
+            }
             int it = 0;
             double rin = 0;
             LQCHK(inner_cg32(op, m, n, eps2, maxiter - total, &it, &rin));

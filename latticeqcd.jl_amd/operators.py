@@ -421,7 +421,7 @@ def solve_DinvX_(y, A, x, return_info=False):
     return (it.value, rr.value) if return_info else None
 
 
-def solve_mixed_DinvX_(y, A, x, inner_tol=1e-4, return_info=False):
+def solve_mixed_DinvX_(y, A, x, inner_tol=0.0, return_info=False):
     """Mixed-precision variant of solve_DinvX!(y, A::DdagD_operator, x): fp32 inner CG, fp64 defect correction; y holds the
     initial guess; the stopping rule real(r.r) < eps_CG is enforced on the true fp64 residual.
     return_info -> (total inner iterations, outer steps, true |r|^2)."""
