@@ -353,6 +353,8 @@ struct Tunables {
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int stag_both = 0;            // 1: staggered split kernel issues the loads of both hops of a direction back to back (unpartitioned lattices)
+    int mixed_xfuse = 0;      // 1: fp32 site-pair solver forms x += alpha p in the epilogue of the update-mode D^+ (the update kernel then forms p only).  Bit-identical,
+                              // measured SLOWER (50.4 vs 48.4 ms at 32^3x64: the six extra loads sit behind the barrier of a kernel that is at its register limit): off
     int mixed_pair32 = 1;         // mixed-precision solvers, plain Wilson r = 1 on an unpartitioned lattice with 12-real links: the fp32 inner operator is the
                                   // site-pair kernel (stencil_pair32.hip: two sites per lane, packed fp32 arithmetic); 0 = the one-site-per-lane fp32 build
     int mixed_action_solver = 0;  // 1: lqcd_fermi_action / lqcd_calc_UdSfdU solve with the mixed-precision CG (true-residual stopping rule);
@@ -522,6 +524,8 @@ struct StencilCall {
     // partitioned lattices, fused tails of the exterior launch (stencil.hip ext_partial / wilson_pack_site):
     int red_slot = -1;            // >= 0: the exterior's last block sums all |.|^2 partials of this application into d_scal[red_slot]
     int pack_next = -1;           // 0 / 1: the exterior also packs the faces of `out` for a following application with this dagger flag
+    double2* xacc[2] = {nullptr, nullptr};      // update mode, fp32 site-pair kernel only: x += alpha p in the same epilogue (x = xacc, p = pacc; parity blocks)
+    const double2* pacc[2] = {nullptr, nullptr};
     int prepacked = 0;            // 1: the send buffers already hold this application's faces (packed by its producer): no pack launch
 };
 // slots of the device scalar block d_scal used by the solvers

@@ -114,6 +114,18 @@ __global__ __launch_bounds__(MB) void cg32_update_xp(const double* __restrict__ 
     }
 }
 
+// the same tail when x += alpha p has already been done in the epilogue of the update-mode D^+ (site-pair kernel): p = r + beta p only
+__global__ __launch_bounds__(MB) void cg32_update_p(const double* __restrict__ s, float4* __restrict__ p, const float4* __restrict__ r, size_t n4) {
+    if (s[S_DONE] != 0.0) return;
+    const float be = (float)s[S_BETA];
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
+        float4 pv = p[i];
+        const float4 rv = r[i];
+        pv.x = fmaf(be, pv.x, rv.x); pv.y = fmaf(be, pv.y, rv.y); pv.z = fmaf(be, pv.z, rv.z); pv.w = fmaf(be, pv.w, rv.w);
+        p[i] = pv;
+    }
+}
+
 // fp32 multi-shift update (solvers.hip ms_update_all on float4 = two elements): base system x += alpha p (optional), p = r + beta p, and
 // every active shift x_j += a_j p_j ; p_j = b_j p_j + z_j r in one pass; frozen shifts cost nothing
 __global__ __launch_bounds__(MB) void ms32_update_all(const double* __restrict__ sc, const double* __restrict__ ms, float4* const* __restrict__ ptr,
@@ -207,9 +219,13 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
             s2.upd_scal = c->d_scal;
             s2.upd[0] = (double2*)m.r;
             s2.upd[1] = (double2*)(m.r + m.blk);
+            const bool xfused = m.layout == 2 && c->tun.mixed_xfuse;      // site-pair kernel: x += alpha p in the epilogue of this launch
+            if (xfused)
+                for (int p = 0; p < 2; p++) { s2.xacc[p] = (double2*)(m.x + p * m.blk); s2.pacc[p] = (const double2*)(m.p + p * m.blk); }
             LQCHK(stencil_apply(c, s2));
             LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
-            hipLaunchKernelGGL(cg32_update_xp, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)m.p, (const float4*)m.r, n / 2);
+            if (xfused) hipLaunchKernelGGL(cg32_update_p, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.p, (const float4*)m.r, n / 2);
+            else hipLaunchKernelGGL(cg32_update_xp, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)m.p, (const float4*)m.r, n / 2);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -129,6 +129,8 @@ struct PairArgs {
     float4* dst[2];           // out, or r in update mode (read and written)
     const float4* in[2];
     const float4* xin[2];
+    float4* xacc[2];          // update mode: x += alpha p rides in the epilogue (nullptr: not asked for)
+    const float4* pacc[2];
     double* norm_partial;
     const double* upd_scal;
     const double* skip;
@@ -301,6 +303,17 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
     __syncthreads();
     float4* dstp = const_cast<float4*>(boff(s.p ? a.dst[1] : a.dst[0], s.own));
     const v2f av = splat(a.a), bv = splat(a.b), mal = splat(-al_upd);
+    // update mode with an x accumulator: x += alpha p for this wave's three components.  Its six loads are issued here, behind the barrier --
+    // the kernel sits at its register limit while the hops are in flight -- and land while the LDS partials are summed.
+    const bool xupd = a.upd_scal && a.xacc[0];
+    cx xs[3], ps[3];
+    float4* xsp = nullptr;
+    if (xupd) {
+        xsp = const_cast<float4*>(boff(s.p ? a.xacc[1] : a.xacc[0], s.own));
+        const float4* pp = boff(s.p ? a.pacc[1] : a.pacc[0], s.own);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { xs[cc] = ldx(xsp + (3 * MU + cc) * 64); ps[cc] = ldx(pp + (3 * MU + cc) * 64); }
+    }
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) {
         const int j = 3 * MU + cc;
@@ -313,6 +326,11 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
             r.re = vfma(mal, v.re, r.re); r.im = vfma(mal, v.im, r.im);
             nrm = vfma(r.re, r.re, nrm); nrm = vfma(r.im, r.im, nrm);
             stx(dstp + j * 64, r);
+            if (xupd) {
+                const v2f al = splat(al_upd);
+                cx xn = mkx(vfma(al, ps[cc].re, xs[cc].re), vfma(al, ps[cc].im, xs[cc].im));
+                stx(xsp + j * 64, xn);
+            }
         } else {
             nrm = vfma(v.re, v.re, nrm); nrm = vfma(v.im, v.im, nrm);
             if (a.nt_store) stx_nt(dstp + j * 64, v); else stx(dstp + j * 64, v);
@@ -428,6 +446,7 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     a.gauge = (const float4*)s.gauge12;
     const bool upd = s.upd_scal != nullptr;
     for (int p = 0; p < 2; p++) { a.dst[p] = (float4*)(upd ? s.upd[p] : s.out[p]); a.in[p] = (const float4*)s.in[p]; a.xin[p] = (const float4*)s.xin[p]; }
+    for (int p = 0; p < 2; p++) { a.xacc[p] = upd ? (float4*)s.xacc[p] : nullptr; a.pacc[p] = upd ? (const float4*)s.pacc[p] : nullptr; }
     a.norm_partial = s.norm_partial; a.upd_scal = s.upd_scal; a.skip = s.skip_flag;
     a.a = (float)s.a; a.b = (float)s.b;
     a.nt_store = c->tun.nt_store != 0;

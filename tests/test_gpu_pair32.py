@@ -117,3 +117,25 @@ def test_pair32_is_not_used_where_it_does_not_apply(gpu, orc):
         lq.mul_(r, lq.DdagD_operator(D), sol)
         lq.add_fermion_(r, -1.0, b)
         assert rr < 1e-16 and lq.dot(r, r).real < 1e-16, (L, extra)
+
+
+@pytest.mark.parametrize("L", [(16, 8, 8, 4), (16, 16, 16, 8)])
+def test_x_update_in_the_epilogue_of_the_update_mode_kernel_gives_identical_solutions(gpu, orc, L):
+    """mixed_xfuse = 1 (opt-in; measured slower than the separate update, profiles/r03_mixed_precision.log): the fp32 solver's x += alpha p rides in the epilogue of the update-mode D^+ launch of the site-pair kernel and the
+    update kernel forms p only -- same operations per element: iteration counts and solutions are bit-identical to the separate x/p update."""
+    lq = gpu
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 47))
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-18})
+    b = lq.Fermionfields(lat, lq.WILSON).upload(orc.gaussian_spinor(lat.fermion_shape(lq.WILSON), 48))
+    A = lq.DdagD_operator(D)
+    out = []
+    for fuse in (1, 0):
+        lat.set_param("mixed_xfuse", fuse)
+        x = b.similar()
+        info = lq.solve_mixed_DinvX_(x, A, b, return_info=True)
+        assert lat.get_param("pair32_active") == 1
+        out.append((info, x.download()))
+    lat.set_param("mixed_xfuse", 0)
+    assert out[0][0][:2] == out[1][0][:2] and out[0][0][2] < 1e-18
+    assert np.array_equal(out[0][1], out[1][1])
