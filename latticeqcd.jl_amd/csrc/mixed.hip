@@ -457,7 +457,15 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
         return LQCD_OK;
     };
     auto run = [&]() -> int {
-        LQCHK(true_residual());
+        // a zero initial guess (what the force and action evaluations pass): r = b without the two fp64 Dslash of a residual evaluation
+        double xx = 1.0;
+        LQCHK(blas_norm2(c, x->data, n, &xx, true));
+        if (xx == 0.0) {
+            HIPCHK(hipMemcpyAsync(r->data, b->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+            LQCHK(blas_norm2(c, r->data, n, &rr, true));
+        } else {
+            LQCHK(true_residual());
+        }
         bool fallback = false;
         while (rr >= eps && total < maxiter) {
             if (!std::isfinite(rr)) { set_error("mixed CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
