@@ -22,7 +22,8 @@ def _setup(lq, orc, L, seed, mass=0.1, bc=(1, 1, 1, -1), eps=1e-18):
     return lat, Uh, U, D, bh, b
 
 
-@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 8, 8, 8), (8, 8, 8, 16), (16, 8, 8, 16), (8, 4, 4, 8)])
+# 4 ... 256 workgroups; x extents with XH = 2, 3, 4, 6, 8 (rows of a chunk straddle y / z / t), odd chunk counts per parity
+@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 8, 8, 8), (8, 8, 8, 16), (16, 8, 8, 16), (8, 4, 4, 8), (6, 4, 4, 8), (12, 4, 4, 4), (4, 4, 4, 12)])
 @pytest.mark.parametrize("bc", [(1, 1, 1, -1), (1, 1, 1, 1), (-1, 1, -1, 1)])
 def test_one_launch_cg_equals_the_launch_chain(lq, orc, L, bc):
     lat, Uh, U, D, bh, b = _setup(lq, orc, L, 2101, bc=bc)
