@@ -12,6 +12,7 @@ def test_cg_with_graph_replay_is_bit_identical(lq, name):
     kind = lq.WILSON if name == "Wilson" else lq.STAGGERED
     U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=5)
     lat = U.lattice
+    lat.set_param("cg_persist", 0)       # graph replay is a form of the launch chain (the one-launch CG: tests/test_gpu_cg_persist.py)
     D = lq.Dirac_operator(U, None, {"Dirac_operator": name, "κ": 0.141139, "mass": 0.5, "eps_CG": 1e-19})
     A = lq.DdagD_operator(D)
     b = lq.Fermionfields(lat, kind)
