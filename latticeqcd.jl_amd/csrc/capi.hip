@@ -244,6 +244,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "mixed_action_solver")) return &c->tun.mixed_action_solver;
     if (!strcmp(key, "mixed_pair32")) return &c->tun.mixed_pair32;
     if (!strcmp(key, "mixed_xfuse")) return &c->tun.mixed_xfuse;
+    if (!strcmp(key, "mixed_defer_x")) return &c->tun.mixed_defer_x;
     if (!strcmp(key, "pair32_active")) return &c->tun.pair32_active;
     if (!strcmp(key, "stag_both")) return &c->tun.stag_both;
     if (!strcmp(key, "clover_fused")) return &c->tun.clover_fused;

@@ -353,6 +353,8 @@ struct Tunables {
     int cg_skip_done = 1;     // fused CG: the first Dslash of an iteration checks the convergence flag as well (0: only the second does)
     int clover_transport = 0; // 1: build the clover sums by the plaquette-transport passes also on an unpartitioned lattice (tests)
     int stag_both = 0;            // 1: staggered split kernel issues the loads of both hops of a direction back to back (unpartitioned lattices)
+    int mixed_defer_x = 1;    // fp32 CG of the mixed-precision solver: x updated every second iteration with both search directions (solvers.hip cg_update_even/odd in fp32):
+                              // 3 + 6 float streams per pair of iterations instead of 5 + 5, identical iterates
     int mixed_xfuse = 0;      // 1: fp32 site-pair solver forms x += alpha p in the epilogue of the update-mode D^+ (the update kernel then forms p only).  Bit-identical,
                               // measured SLOWER (50.4 vs 48.4 ms at 32^3x64: the six extra loads sit behind the barrier of a kernel that is at its register limit): off
     int mixed_pair32 = 1;         // mixed-precision solvers, plain Wilson r = 1 on an unpartitioned lattice with 12-real links: the fp32 inner operator is the
@@ -408,8 +410,8 @@ struct lqcd_ctx_s {
     uint64_t mix_gauge_version = 0;
     bool mix_gauge12_valid = false;      // the 12-real fp32 copy (mix_buf[5]) was made for that version
     int mix_gauge12_layout = 0;          // ... in which layout: 1 component pairs (stencil.hip fp32 build), 2 site pairs (stencil_pair32.hip)
-    void* mix_buf[8] = {};     // 7: fp32 x_j / p_j pool of the mixed-precision multi-shift solver
-    size_t mix_bytes[8] = {};
+    void* mix_buf[9] = {};     // 7: fp32 x_j / p_j pool of the mixed-precision multi-shift solver; 8: second search-direction buffer of the fp32 CG
+    size_t mix_bytes[9] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;

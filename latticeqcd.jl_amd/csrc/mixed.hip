@@ -114,6 +114,60 @@ __global__ __launch_bounds__(MB) void cg32_update_xp(const double* __restrict__ 
     }
 }
 
+// Deferred x update in fp32 (solvers.hip cg_update_even / cg_update_odd, same protocol): iteration k even: p_{k+1} = r + beta p_k into the
+// OTHER buffer, x untouched, alpha_k kept in S_APREV (the iteration that converges completes x itself); k odd: x += alpha_{k-1} p_{k-1} +
+// alpha_k p_k in the order of two single updates (identical bits), p_{k+1} = r + beta p_k over the dead p_{k-1}.
+__global__ __launch_bounds__(MB) void cg32_update_even(double* __restrict__ s, float4* __restrict__ x, const float4* __restrict__ pk,
+                                                        float4* __restrict__ pnext, const float4* __restrict__ r, size_t n4) {
+    if (s[S_XDONE] != 0.0) return;
+    const float al = (float)s[S_ALPHA], be = (float)s[S_BETA];
+    if (s[S_DONE] == 0.0) {
+        for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
+            const float4 pv = pk[i], rv = r[i];
+            float4 o;
+            o.x = fmaf(be, pv.x, rv.x); o.y = fmaf(be, pv.y, rv.y); o.z = fmaf(be, pv.z, rv.z); o.w = fmaf(be, pv.w, rv.w);
+            pnext[i] = o;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) s[S_APREV] = s[S_ALPHA];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
+            const float4 pv = pk[i];
+            float4 xv = x[i];
+            xv.x = fmaf(al, pv.x, xv.x); xv.y = fmaf(al, pv.y, xv.y); xv.z = fmaf(al, pv.z, xv.z); xv.w = fmaf(al, pv.w, xv.w);
+            x[i] = xv;
+        }
+    }
+}
+__global__ __launch_bounds__(MB) void cg32_update_odd(const double* __restrict__ s, float4* __restrict__ x, float4* __restrict__ pprev,
+                                                       const float4* __restrict__ pk, const float4* __restrict__ r, size_t n4) {
+    if (s[S_XDONE] != 0.0) return;
+    const float ap = (float)s[S_APREV], al = (float)s[S_ALPHA], be = (float)s[S_BETA];
+    const bool cont = s[S_DONE] == 0.0;
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
+        const float4 pp = pprev[i], pv = pk[i], rv = r[i];
+        float4 xv = x[i];
+        xv.x = fmaf(ap, pp.x, xv.x); xv.y = fmaf(ap, pp.y, xv.y); xv.z = fmaf(ap, pp.z, xv.z); xv.w = fmaf(ap, pp.w, xv.w);
+        xv.x = fmaf(al, pv.x, xv.x); xv.y = fmaf(al, pv.y, xv.y); xv.z = fmaf(al, pv.z, xv.z); xv.w = fmaf(al, pv.w, xv.w);
+        x[i] = xv;
+        if (cont) {
+            float4 o;
+            o.x = fmaf(be, pv.x, rv.x); o.y = fmaf(be, pv.y, rv.y); o.z = fmaf(be, pv.z, rv.z); o.w = fmaf(be, pv.w, rv.w);
+            pprev[i] = o;
+        }
+    }
+}
+// x += alpha_prev p_prev for a solve that stopped, unconverged, behind an even iteration
+__global__ __launch_bounds__(MB) void cg32_flush_x(const double* __restrict__ s, float4* __restrict__ x, const float4* __restrict__ pk, size_t n4) {
+    if (s[S_DONE] != 0.0) return;
+    const float ap = (float)s[S_APREV];
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
+        const float4 pv = pk[i];
+        float4 xv = x[i];
+        xv.x = fmaf(ap, pv.x, xv.x); xv.y = fmaf(ap, pv.y, xv.y); xv.z = fmaf(ap, pv.z, xv.z); xv.w = fmaf(ap, pv.w, xv.w);
+        x[i] = xv;
+    }
+}
+
 // the same tail when x += alpha p has already been done in the epilogue of the update-mode D^+ (site-pair kernel): p = r + beta p only
 __global__ __launch_bounds__(MB) void cg32_update_p(const double* __restrict__ s, float4* __restrict__ p, const float4* __restrict__ r, size_t n4) {
     if (s[S_DONE] != 0.0) return;
@@ -168,7 +222,7 @@ static int mix_alloc(lqcd_ctx_s* c, int slot, size_t bytes) {
 }
 
 struct Mix32 {
-    float2 *gauge, *gauge12, *clover, *x, *r, *p, *t;
+    float2 *gauge, *gauge12, *clover, *x, *r, *p, *t, *p2;      // p2: second search-direction buffer (deferred x update), or nullptr
     size_t blk;   // elements per parity block
     int layout = 0;   // fp32 spinor layout: 0 plain (staggered), 1 Wilson component pairs (stencil.hip, LQCD_F32), 2 Wilson site pairs (stencil_pair32.hip)
 };
@@ -202,14 +256,17 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
     double init[9] = {1.0, 0, 0, 0, 0, 0, eps2, 0, 0};   // S_RR .. S_XDONE
     HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     const int nbs = stencil_num_partials(c, op->kind, op->r, 2, m.layout == 2 ? 2 : 1, op->csw != 0.0 && op->clover != nullptr), nbu = stream_grid(c, n / 2), check_every = 8;
-    int it = 0;
+    int it = 0, kq = 0;      // kq: iterations enqueued (the device executes them until it converges)
     double rr = 1.0;
     bool done = false;
+    const bool defer = m.p2 != nullptr && !(m.layout == 2 && c->tun.mixed_xfuse);
     while (!done && it < maxiter) {
         const int burst = std::min(check_every, maxiter - it);
-        for (int k = 0; k < burst; k++) {
+        for (int k = 0; k < burst; k++, kq++) {
+            float2* pk = (defer && (kq & 1)) ? m.p2 : m.p;       // p_k of an even k lives in m.p
+            float2* po = (defer && (kq & 1)) ? m.p : m.p2;
             apply_bc(c, op->bc);
-            StencilCall s1 = call32(op, m, m.t, m.p, 0);
+            StencilCall s1 = call32(op, m, m.t, pk, 0);
             s1.norm_partial = c->d_partial;
             s1.skip_flag = c->d_scal;                        // a no-op once the inner solve has converged inside a burst
             LQCHK(stencil_apply(c, s1));
@@ -224,7 +281,9 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
                 for (int p = 0; p < 2; p++) { s2.xacc[p] = (double2*)(m.x + p * m.blk); s2.pacc[p] = (const double2*)(m.p + p * m.blk); }
             LQCHK(stencil_apply(c, s2));
             LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
-            if (xfused) hipLaunchKernelGGL(cg32_update_p, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.p, (const float4*)m.r, n / 2);
+            if (defer && !(kq & 1)) hipLaunchKernelGGL(cg32_update_even, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (const float4*)pk, (float4*)po, (const float4*)m.r, n / 2);
+            else if (defer) hipLaunchKernelGGL(cg32_update_odd, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)po, (const float4*)pk, (const float4*)m.r, n / 2);
+            else if (xfused) hipLaunchKernelGGL(cg32_update_p, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.p, (const float4*)m.r, n / 2);
             else hipLaunchKernelGGL(cg32_update_xp, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)m.p, (const float4*)m.r, n / 2);
             HIPCHK(hipGetLastError());
         }
@@ -234,6 +293,10 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
         it = (int)c->h_scal[S_ITERS - S_RR];
         done = c->h_scal[S_DONE - S_RR] != 0.0;
         if (!std::isfinite(rr)) break;
+    }
+    if (defer && !done && (kq & 1)) {      // stopped, unconverged, behind an even iteration: its alpha p is still owed to x (p_k of an even k lives in m.p)
+        hipLaunchKernelGGL(cg32_flush_x, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (const float4*)m.p, n / 2);
+        HIPCHK(hipGetLastError());
     }
     *iters = it;
     *rr_out = rr;
@@ -274,6 +337,8 @@ static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
         m.clover = (float2*)c->mix_buf[6];
     }
     m.x = (float2*)c->mix_buf[1]; m.r = (float2*)c->mix_buf[2]; m.p = (float2*)c->mix_buf[3]; m.t = (float2*)c->mix_buf[4];
+    m.p2 = nullptr;
+    if (c->tun.mixed_defer_x) { LQCHK(mix_alloc(c, 8, n * sizeof(float2))); m.p2 = (float2*)c->mix_buf[8]; }
     m.blk = n / 2;
     // site-pair fp32 kernel (stencil_pair32.hip; tunable mixed_pair32): plain Wilson r = 1 with 12-real links on an unpartitioned lattice whose
     // geometry admits it; the fp32 fields of the solve (links in mix_buf[5], the four vectors) then live in the pair layout

@@ -4,6 +4,7 @@ import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import latticeqcd_jl_amd as lq
 L = (32, 32, 32, 64)
+KEY = sys.argv[1] if len(sys.argv) > 1 else "mixed_xfuse"
 lat = lq.Lattice(L)
 U = lq.Gaugefields(lat)
 lq.lib.check(lq.lib.lib().lqcd_gauge_hot_start(U._h, ctypes.c_uint64(111)))
@@ -12,14 +13,14 @@ b = lq.Fermionfields(lat, lq.WILSON)
 lq.gauss_distribution_fermion_(b, 112)
 x = b.similar()
 A = lq.DdagD_operator(D)
-for fuse in (1, 0, 1, 0):
-    lat.set_param("mixed_xfuse", fuse)
+for fuse in (1, 0, 1, 0, 1, 0):
+    lat.set_param(KEY, fuse)
     best, info = 1e9, None
     for rep in range(5):
         lq.clear_fermion_(x); lat.sync()
         t0 = time.perf_counter(); info = lq.solve_mixed_DinvX_(x, A, b, return_info=True); lat.sync()
         best = min(best, 1e3 * (time.perf_counter() - t0))
-    print("mixed_xfuse %d: %.1f ms, inner %d, outer %d, true rr %.2e" % (fuse, best, info[0], info[1], info[2]), flush=True)
+    print(KEY + " %d: %.1f ms, inner %d, outer %d, true rr %.2e" % (fuse, best, info[0], info[1], info[2]), flush=True)
 lq.clear_fermion_(x); lat.sync()
 t0 = time.perf_counter(); i64 = lq.solve_DinvX_(x, A, b, return_info=True); lat.sync(); t64 = 1e3 * (time.perf_counter() - t0)
 lq.clear_fermion_(x); lat.sync()

@@ -252,3 +252,33 @@ def test_mixed_cg_on_non_unitary_links_uses_the_18_real_inner_operator(gpu, orc)
     assert st == 0 and rr < 1e-18 and rel_err(x.download(), xo) < 1e-8
     assert lat.get_param("recon_active") == 0
     assert outer >= 2 and it < 3 * ito + 20          # defect correction converges in fp32 steps: no stall, no fp64 fall-back
+
+
+@pytest.mark.parametrize("kind_name,L", [("Wilson", (16, 8, 8, 4)), ("Wilson", (4, 4, 4, 8)), ("Staggered", (8, 4, 6, 4)), ("WilsonClover", (4, 4, 4, 8))])
+@pytest.mark.parametrize("maxiter", [3000, 5, 6])
+def test_deferred_x_update_of_the_fp32_solver_gives_identical_results(gpu, orc, kind_name, L, maxiter):
+    """mixed_defer_x (default): the fp32 CG updates x every second iteration with both search directions (two p buffers) -- the same
+    operations per element in the same order, so a solve returns the same bits with it and without it, for every fp32 field layout (site pairs,
+    component pairs, plain), also when the fp32 solve is cut off behind an even or an odd iteration (the owed alpha p is flushed)."""
+    lq = gpu
+    kind = lq.STAGGERED if kind_name == "Staggered" else lq.WILSON
+    lat = lq.Lattice(L)
+    Ud = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 171))
+    par = {"Dirac_operator": kind_name, "κ": 0.12, "mass": MASS, "boundarycondition": BC, "eps_CG": 1e-18, "MaxCGstep": maxiter}
+    if kind_name == "WilsonClover":
+        par["Clover_coefficient"] = 1.0
+    D = lq.Dirac_operator(Ud, None, par)
+    b = lq.Fermionfields(lat, kind).upload(orc.gaussian_spinor(lat.fermion_shape(kind), 172))
+    A = lq.DdagD_operator(D)
+    out = []
+    for defer in (1, 0):
+        lat.set_param("mixed_defer_x", defer)
+        x = b.similar()
+        try:
+            info = lq.solve_mixed_DinvX_(x, A, b, return_info=True)
+        except lq.NotConverged:
+            info = None
+        out.append((info, x.download()))
+    lat.set_param("mixed_defer_x", 1)
+    assert (out[0][0] is None) == (maxiter < 100) and out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
