@@ -117,16 +117,27 @@ __global__ __launch_bounds__(MB) void cg32_update_xp(const double* __restrict__ 
 // Deferred x update in fp32 (solvers.hip cg_update_even / cg_update_odd, same protocol): iteration k even: p_{k+1} = r + beta p_k into the
 // OTHER buffer, x untouched, alpha_k kept in S_APREV (the iteration that converges completes x itself); k odd: x += alpha_{k-1} p_{k-1} +
 // alpha_k p_k in the order of two single updates (identical bits), p_{k+1} = r + beta p_k over the dead p_{k-1}.
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ inline float4 ld4(const float4* p) {
+    if constexpr (NT) { const v4f32 v = __builtin_nontemporal_load(reinterpret_cast<const v4f32*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    else return *p;
+}
+template <bool NT> __device__ inline void st4(float4* p, float4 v) {
+    if constexpr (NT) { const v4f32 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f32*>(p)); }
+    else *p = v;
+}
+// NT (tunable nt_blas, as in the fp64 update kernels): streaming loads / stores -- none of these fields is read again before it has left every cache
+template <bool NT>
 __global__ __launch_bounds__(MB) void cg32_update_even(double* __restrict__ s, float4* __restrict__ x, const float4* __restrict__ pk,
                                                         float4* __restrict__ pnext, const float4* __restrict__ r, size_t n4) {
     if (s[S_XDONE] != 0.0) return;
     const float al = (float)s[S_ALPHA], be = (float)s[S_BETA];
     if (s[S_DONE] == 0.0) {
         for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
-            const float4 pv = pk[i], rv = r[i];
+            const float4 pv = ld4<NT>(pk + i), rv = ld4<NT>(r + i);
             float4 o;
             o.x = fmaf(be, pv.x, rv.x); o.y = fmaf(be, pv.y, rv.y); o.z = fmaf(be, pv.z, rv.z); o.w = fmaf(be, pv.w, rv.w);
-            pnext[i] = o;
+            st4<NT>(pnext + i, o);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) s[S_APREV] = s[S_ALPHA];
     } else {
@@ -138,21 +149,22 @@ __global__ __launch_bounds__(MB) void cg32_update_even(double* __restrict__ s, f
         }
     }
 }
+template <bool NT>
 __global__ __launch_bounds__(MB) void cg32_update_odd(const double* __restrict__ s, float4* __restrict__ x, float4* __restrict__ pprev,
                                                        const float4* __restrict__ pk, const float4* __restrict__ r, size_t n4) {
     if (s[S_XDONE] != 0.0) return;
     const float ap = (float)s[S_APREV], al = (float)s[S_ALPHA], be = (float)s[S_BETA];
     const bool cont = s[S_DONE] == 0.0;
     for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n4; i += (size_t)gridDim.x * MB) {
-        const float4 pp = pprev[i], pv = pk[i], rv = r[i];
-        float4 xv = x[i];
+        const float4 pp = ld4<NT>(pprev + i), pv = ld4<NT>(pk + i), rv = ld4<NT>(r + i);
+        float4 xv = ld4<NT>(x + i);
         xv.x = fmaf(ap, pp.x, xv.x); xv.y = fmaf(ap, pp.y, xv.y); xv.z = fmaf(ap, pp.z, xv.z); xv.w = fmaf(ap, pp.w, xv.w);
         xv.x = fmaf(al, pv.x, xv.x); xv.y = fmaf(al, pv.y, xv.y); xv.z = fmaf(al, pv.z, xv.z); xv.w = fmaf(al, pv.w, xv.w);
-        x[i] = xv;
+        st4<NT>(x + i, xv);
         if (cont) {
             float4 o;
             o.x = fmaf(be, pv.x, rv.x); o.y = fmaf(be, pv.y, rv.y); o.z = fmaf(be, pv.z, rv.z); o.w = fmaf(be, pv.w, rv.w);
-            pprev[i] = o;
+            st4<NT>(pprev + i, o);
         }
     }
 }
@@ -281,8 +293,13 @@ static int inner_cg32(lqcd_op_s* op, const Mix32& m, size_t n, double eps2, int 
                 for (int p = 0; p < 2; p++) { s2.xacc[p] = (double2*)(m.x + p * m.blk); s2.pacc[p] = (const double2*)(m.p + p * m.blk); }
             LQCHK(stencil_apply(c, s2));
             LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
-            if (defer && !(kq & 1)) hipLaunchKernelGGL(cg32_update_even, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (const float4*)pk, (float4*)po, (const float4*)m.r, n / 2);
-            else if (defer) hipLaunchKernelGGL(cg32_update_odd, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)po, (const float4*)pk, (const float4*)m.r, n / 2);
+            if (defer && !(kq & 1)) {
+                if (c->tun.nt_blas) hipLaunchKernelGGL(cg32_update_even<true>, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (const float4*)pk, (float4*)po, (const float4*)m.r, n / 2);
+                else hipLaunchKernelGGL(cg32_update_even<false>, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (const float4*)pk, (float4*)po, (const float4*)m.r, n / 2);
+            } else if (defer) {
+                if (c->tun.nt_blas) hipLaunchKernelGGL(cg32_update_odd<true>, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)po, (const float4*)pk, (const float4*)m.r, n / 2);
+                else hipLaunchKernelGGL(cg32_update_odd<false>, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)po, (const float4*)pk, (const float4*)m.r, n / 2);
+            }
             else if (xfused) hipLaunchKernelGGL(cg32_update_p, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.p, (const float4*)m.r, n / 2);
             else hipLaunchKernelGGL(cg32_update_xp, dim3(nbu), dim3(MB), 0, c->stream, c->d_scal, (float4*)m.x, (float4*)m.p, (const float4*)m.r, n / 2);
             HIPCHK(hipGetLastError());

@@ -13,7 +13,7 @@ b = lq.Fermionfields(lat, lq.WILSON)
 lq.gauss_distribution_fermion_(b, 112)
 x = b.similar()
 A = lq.DdagD_operator(D)
-for fuse in (1, 0, 1, 0, 1, 0):
+for fuse in (0, 1, 0, 1, 0, 1):
     lat.set_param(KEY, fuse)
     best, info = 1e9, None
     for rep in range(5):
