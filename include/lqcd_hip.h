@@ -97,8 +97,10 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice
  * construction of the clover term / force also on one rank);
  * partitioned lattices: halo_merge (1 [default]: one message per peer when both faces go to the same rank), halo_stream_mode
- * (-1 [default]: time the three stream schedules of the halo exchange once -- collectively: every rank adopts the schedule with the smallest time summed over
- * the ranks; 0 | 1 | 2 force one and skip the timing), halo_tuned_us0..2 (read-only: the times that choice was made from), halo_fuse (bit 1 [default 2]: the
+ * (-1 [default]: time the four schedules of the halo exchange once -- collectively: every rank adopts the schedule with the smallest time summed over
+ * the ranks; 0 | 1 | 2 force one of the overlapping schedules (exchange / interior / pack + exchange on the second stream), 3 forces pack -> exchange ->
+ * interior -> exterior in order on one stream: no overlap and no cross-queue join, the faster one when the exchange is short), halo_tuned_us0..3 (read-only: the
+ * times that choice was made from), halo_fuse (bit 1 [default 2]: the
  * exterior of D p packs the faces D^+ needs and the CG update packs the new search direction -- no separate pack launches; bit 0: the exterior's last
  * block sums the |.|^2 partials -- measured slower, off), staple_recon (1 [default]: the staple sweep reads two rows of links known to be on the group). */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);

@@ -123,11 +123,11 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             c->tun.halo_stream_mode = -1;
             return st;
         }
-        float ms[3] = {0.f, 0.f, 0.f};
+        float ms[4] = {0.f, 0.f, 0.f, 0.f};
         StencilCall t = s;          // the timed applications pack for themselves and leave the fused tails alone
         t.prepacked = 0; t.pack_next = -1; t.red_slot = -1;
         const bool tails = s.pack_next >= 0 || s.red_slot >= 0;
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 4; mode++) {
             c->tun.halo_stream_mode = mode;
             LQCHK(stencil_apply(c, t));
             HIPCHK(hipEventRecord(c->ev_tune0, c->stream));
@@ -141,16 +141,16 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         if (c->has_comm) {      // (a one-rank communicator -- self-partition tests -- takes the same path: the all-reduce is then the identity)
             float* d_ms = (float*)c->d_partial;
             HIPCHK(hipMemcpyAsync(d_ms, ms, sizeof(ms), hipMemcpyHostToDevice, c->stream));
-            NCCLCHK(ncclAllReduce(d_ms, d_ms, 3, ncclFloat, ncclSum, c->comm_red, c->stream));      // the compute stream's communicator
+            NCCLCHK(ncclAllReduce(d_ms, d_ms, 4, ncclFloat, ncclSum, c->comm_red, c->stream));      // the compute stream's communicator
             HIPCHK(hipMemcpyAsync(ms, d_ms, sizeof(ms), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            for (int mode = 0; mode < 3; mode++) ms[mode] /= (float)c->nranks;
+            for (int mode = 0; mode < 4; mode++) ms[mode] /= (float)c->nranks;
         }
         int best = 0;
-        for (int mode = 1; mode < 3; mode++)
+        for (int mode = 1; mode < 4; mode++)
             if (ms[mode] < ms[best]) best = mode;
         c->tun.halo_stream_mode = best;
-        for (int mode = 0; mode < 3; mode++) c->tun.halo_tuned_us[mode] = (int)(250.f * ms[mode]);
+        for (int mode = 0; mode < 4; mode++) c->tun.halo_tuned_us[mode] = (int)(250.f * ms[mode]);
         if (tails) { t = s; t.prepacked = 0; return stencil_apply(c, t); }      // once more with the caller's tails (the send buffers hold this input's faces)
         return LQCD_OK;      // `out` holds the result of the last tuning application
     }
@@ -170,6 +170,15 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
         LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+        return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+    }
+    if (c->tun.halo_stream_mode == 3) {
+        // everything in order on the compute stream, no overlap and no cross-queue join: pack -> exchange -> interior -> exterior.  A join costs
+        // ~13 us (barrier packets) and the exchange kernel slows the interior it runs beside; at small local volumes with a short exchange that
+        // is more than the overlap hides
+        if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 1));
+        LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
     }
     if (c->tun.halo_stream_mode == 2) {

@@ -264,6 +264,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "halo_tuned_us0")) return &c->tun.halo_tuned_us[0];
     if (!strcmp(key, "halo_tuned_us1")) return &c->tun.halo_tuned_us[1];
     if (!strcmp(key, "halo_tuned_us2")) return &c->tun.halo_tuned_us[2];
+    if (!strcmp(key, "halo_tuned_us3")) return &c->tun.halo_tuned_us[3];
     if (!strcmp(key, "halo_merge")) return &c->tun.halo_merge;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
     if (!strcmp(key, "variants_built")) return &c->tun.variants_built;

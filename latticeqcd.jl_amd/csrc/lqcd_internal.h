@@ -329,8 +329,9 @@ struct Tunables {
                                // 1 = pack -> exchange -> exterior in order on the compute stream, interior on the second stream
                                // (no queue hop on the message path; pays when the exchange is the longer leg);
                                // 2 = interior enqueued first on the compute stream and in order with the exterior, pack -> exchange on the
-                               // second stream (pays when the interior is the longer leg); -1 = time all three once
-    int halo_tuned_us[3] = {0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
+                               // second stream (pays when the interior is the longer leg); 3 = everything in order on the compute stream (no overlap, no
+                               // ~13 us cross-queue join: pays when the exchange is short); -1 = time all four once, collectively
+    int halo_tuned_us[4] = {0, 0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
     int halo_fuse = 2;        // partitioned fused CG (Wilson, fp64): bit 0 = the exterior's last block does the final reduction (no reduce_final launch),

@@ -28,7 +28,7 @@ CODE = textwrap.dedent("""
     xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, K, 1.0, BC, eps=1e-19)
     assert st == 0
     sols = {}
-    for mode in (-1, 0, 1, 2):
+    for mode in (-1, 0, 1, 2, 3):
         for fold in (1, 0):
             for fuse in (0, 1, 2, 3):
                 lat.set_param("halo_stream_mode", mode); lat.set_param("cg_fold_scalars", fold); lat.set_param("halo_fuse", fuse)
