@@ -1017,6 +1017,8 @@ int ms_zeta_launch(lqcd_ctx_s* c, double* d_ms, int ns, int stop_when_frozen) {
 // base system (x += alpha p ; p = r + beta p) and every active shifted system j (x_j += a_j p_j ; p_j = b_j p_j + z_j r) in one pass:
 // r is read once per element, frozen shifts cost nothing.  x is still updated in the iteration that converges; nothing is touched
 // afterwards.
+// NT (tunable nt_blas): the shifted x_j, p_j are streamed -- an element is not touched again before 2 x (active shifts) fields have gone by
+template <bool NT>
 __global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ sc, const double* __restrict__ ms, double2* const* __restrict__ ptr,
                                                      double2* __restrict__ x0, double2* __restrict__ p0, const double2* __restrict__ r, size_t n,
                                                      int ns) {
@@ -1027,9 +1029,9 @@ __global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ s
         {
             double2 pv = p0[i];
             if (x0) {          // the unshifted solution is optional (a rational action only wants the shifted ones)
-                double2 xv = x0[i];
+                double2 xv = ldx<NT>(x0 + i);
                 xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
-                x0[i] = xv;
+                stx<NT>(x0 + i, xv);
             }
             pv.x = fma(be, pv.x, rv.x); pv.y = fma(be, pv.y, rv.y);
             p0[i] = pv;
@@ -1039,10 +1041,10 @@ __global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ s
             if (a == 0.0 && bb == 0.0 && z == 0.0) continue;       // frozen shift
             double2* __restrict__ x = ptr[j];
             double2* __restrict__ p = ptr[ns + j];
-            double2 pv = p[i], xv = x[i];
+            double2 pv = ldx<NT>(p + i), xv = ldx<NT>(x + i);
             xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y);
             pv.x = fma(bb, pv.x, z * rv.x); pv.y = fma(bb, pv.y, z * rv.y);
-            x[i] = xv; p[i] = pv;
+            stx<NT>(x + i, xv); stx<NT>(p + i, pv);
         }
     }
 }
@@ -1126,7 +1128,9 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
                 LQCHK(stencil_apply(c, s2));
                 LQCHK(reduce_to_slot(c, nbs, 1, S_RRNEW, true, 2));
                 if (ns) LQCHK(ms_zeta_launch(c, d_ms, ns, 0));
-                hipLaunchKernelGGL(ms_update_all, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase ? xbase->data : (double2*)nullptr, p->data,
+                if (c->tun.nt_blas) hipLaunchKernelGGL(ms_update_all<true>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase ? xbase->data : (double2*)nullptr, p->data,
+                                   r->data, n, ns);
+                else hipLaunchKernelGGL(ms_update_all<false>, dim3(nbu), dim3(UB), 0, c->stream, c->d_scal, d_ms, d_ptr, xbase ? xbase->data : (double2*)nullptr, p->data,
                                    r->data, n, ns);
                 HIPCHK(hipGetLastError());
             }
