@@ -281,6 +281,13 @@ int lqcd_link_mul(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_gauge
 int lqcd_link_add_ta(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t G, int mu_g);  /* Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131) */
 int lqcd_link_staple(lqcd_gauge_t out, int mu_out, lqcd_gauge_t U, int mu, double beta);  /* calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108) for the plaquette
                                                                                            * action of universe.jl:92-95: (beta/2) * sum of the six staples.  Collective on a partitioned lattice */
+/* The per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110) as ONE pass each; the bindings reach
+ * them by evaluating exptU! -> mul! -> substitute_U! and calc_dSdUmu! -> mul! -> Traceless_antihermitian_add! lazily, the callers stay unchanged:
+ *   W[mu_w] = exp(t P[mu_p]) U[mu_u]                      (W = U, mu_w = mu_u: the in-place update of one direction, projected back onto SU(3)
+ *                                                          under the rule of lqcd_gauge_exp_update when the tunable md_reunitarize is set)
+ *   P[mu_p] += factor * TA(U[mu] * (beta/2) * sum of the six staples of direction mu) */
+int lqcd_link_exp_mul(lqcd_gauge_t W, int mu_w, double t, lqcd_gauge_t P, int mu_p, lqcd_gauge_t U, int mu_u);
+int lqcd_link_add_ta_staple(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t U, int mu, double beta);
 
 /* the SURVEY.md 8(d) protocol: every application between its own HIP events, median and mean over reps */
 int lqcd_bench_dslash_median(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int warm, int reps, double* median_ms,

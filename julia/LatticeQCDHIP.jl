@@ -130,6 +130,42 @@ function whole(U::Vector{<:AnyLink})
 end
 views(::Type{T}, g::HIPGaugeStorage) where {T<:AnyLink} = T[T(g, Cint(μ - 1)) for μ = 1:4]
 
+# ---- lazy evaluation of the per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110).
+# exptU!(expU, t, p[μ]) -> mul!(W, expU, U[μ]) -> substitute_U!(U[μ], W) and calc_dSdUμ!(dSdUμ, ..) -> mul!(temp1, U[μ], dSdUμ) ->
+# Traceless_antihermitian_add!(p[μ], factor, temp1): the first two calls of a triple are RECORDED, the third launches one fused kernel
+# (lqcd_link_exp_mul, lqcd_link_add_ta_staple) -- 4 launches per update instead of 12, the callers unchanged.  Anything else that asks a
+# storage for its handle (`.h`: every other ccall of this file) first materialises the record with the plain single-direction calls, so a
+# temporary that IS read holds what the eager call would have put there; the temporaries of a completed triple are never written.
+const LAZY_LINKS = Ref(true)              # false: every call launches its own kernel
+const LAZY = Ref{Any}(nothing)            # the recorded call(s) of the open triple (a NamedTuple) or nothing
+rawh(l::AnyLink) = getfield(getfield(l, :parent), :h)
+rawh(g::HIPGaugeStorage) = getfield(g, :h)
+slotof(l::AnyLink) = getfield(l, :slot)
+samelink(a::AnyLink, b::AnyLink) = getfield(a, :parent) === getfield(b, :parent) && slotof(a) == slotof(b)
+function flush_links()
+    z = LAZY[]
+    z === nothing && return nothing
+    LAZY[] = nothing
+    if z.kind === :exp || z.kind === :expmul
+        check(ccall((:lqcd_link_exp, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), rawh(z.E), slotof(z.E), z.t, rawh(z.P), slotof(z.P)))
+        if z.kind === :expmul
+            check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                        rawh(z.W), slotof(z.W), rawh(z.E), slotof(z.E), rawh(z.U), slotof(z.U)))
+        end
+    else
+        check(ccall((:lqcd_link_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), rawh(z.S), slotof(z.S), rawh(z.Ug), z.mu, z.beta))
+        if z.kind === :ustaple
+            check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                        rawh(z.T), slotof(z.T), rawh(z.Ug), z.mu, rawh(z.S), slotof(z.S)))
+        end
+    end
+    return nothing
+end
+function Base.getproperty(g::HIPGaugeStorage, s::Symbol)
+    s === :h && LAZY[] !== nothing && flush_links()      # whoever asks for the handle is about to read or write the field
+    return getfield(g, s)
+end
+
 # Initialize_Gaugefields(NC, Nwing, L...; condition) (universe.jl:41-49) -> U::Vector{HIPLink}, the value `Univ` stores as U::Vector{TG}
 function Initialize_HIPGaugefields(NC, Nwing, L...; condition = "cold", lattice = nothing, randomseed = 111)::Vector{HIPLink}
     NC == 3 || error("only NC = 3 is supported on the HIP path")
@@ -206,20 +242,51 @@ reunitarize!(U::Vector{HIPLink}) = check(ccall((:lqcd_gauge_reunitarize, LIB), C
 function substitute_U!(dst::Vector{HIPLink}, src::Vector{HIPLink})
     check(ccall((:lqcd_gauge_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), whole(dst).h, whole(src).h))
 end
-substitute_U!(dst::HIPLink, src::HIPLink) =
+function substitute_U!(dst::HIPLink, src::HIPLink)
+    z = LAZY[]
+    if z !== nothing && z.kind === :expmul && samelink(src, z.W) && samelink(dst, z.U)
+        LAZY[] = nothing          # U[μ] <- exp(t p[μ]) U[μ] in one pass (in place; projected back onto SU(3) under the tunable md_reunitarize)
+        return check(ccall((:lqcd_link_exp_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                           rawh(dst), slotof(dst), z.t, rawh(z.P), slotof(z.P), rawh(dst), slotof(dst)))
+    end
     check(ccall((:lqcd_link_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), getfield(dst, :parent).h, getfield(dst, :slot), getfield(src, :parent).h, getfield(src, :slot)))
+end
 # mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUμ) (AbstractMD.jl:92,109)
 function mul!(C::HIPLink, A::HIPLink, B::HIPLink)
+    z = LAZY[]
+    if z !== nothing && z.kind === :exp && samelink(A, z.E) && !samelink(C, z.E)
+        LAZY[] = merge(z, (kind = :expmul, W = C, U = B))            # second call of the U_update! triple
+        return C
+    end
+    if z !== nothing && z.kind === :staple && samelink(B, z.S) && getfield(A, :parent) === z.Ug && slotof(A) == z.mu && !samelink(C, z.S) &&
+       getfield(C, :parent) !== z.Ug
+        LAZY[] = merge(z, (kind = :ustaple, T = C))                   # second call of the P_update! triple
+        return C
+    end
     check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
                 getfield(C, :parent).h, getfield(C, :slot), getfield(A, :parent).h, getfield(A, :slot), getfield(B, :parent).h, getfield(B, :slot)))
     return C
 end
 # exptU!(expU, t, p[mu], [temp1, temp2]) (AbstractMD.jl:91)
-exptU!(expU::HIPLink, t::Number, p::HIPTALink, temps) =
+function exptU!(expU::HIPLink, t::Number, p::HIPTALink, temps)
+    if LAZY_LINKS[] && getfield(expU, :parent) !== getfield(p, :parent)
+        flush_links()
+        LAZY[] = (kind = :exp, E = expU, t = Float64(t), P = p)       # first call of the U_update! triple: recorded
+        return nothing
+    end
     check(ccall((:lqcd_link_exp, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), getfield(expU, :parent).h, getfield(expU, :slot), Float64(t), getfield(p, :parent).h, getfield(p, :slot)))
+end
 # Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131)
-Traceless_antihermitian_add!(p::HIPTALink, factor::Number, G::HIPLink) =
+function Traceless_antihermitian_add!(p::HIPTALink, factor::Number, G::HIPLink)
+    z = LAZY[]
+    if z !== nothing && z.kind === :ustaple && samelink(G, z.T) && getfield(p, :parent) !== z.Ug && getfield(p, :parent) !== getfield(z.T, :parent) &&
+       getfield(p, :parent) !== getfield(z.S, :parent)
+        LAZY[] = nothing          # p[μ] += factor TA(U[μ] (β/2) staples) in one pass
+        return check(ccall((:lqcd_link_add_ta_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Float64),
+                           rawh(p), slotof(p), Float64(factor), rawh(z.Ug), z.mu, z.beta))
+    end
     check(ccall((:lqcd_link_add_ta, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), getfield(p, :parent).h, getfield(p, :slot), Float64(factor), getfield(G, :parent).h, getfield(G, :slot)))
+end
 
 # ---- momenta: initialize_TA_Gaugefields(U) (standardMD.jl:34), gauss_distribution!(md.p) (:86), md.p * md.p (standardHMC.jl:49,59)
 function initialize_TA_Gaugefields(U::Vector{HIPLink})::Vector{HIPTALink}
@@ -246,8 +313,14 @@ function beta_inp(ga::GaugeAction{4,HIPLink})
     return sum(d.β for d in ga.dataset)
 end
 # calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): β_inp * (sum of the staples of U[μ])
-calc_dSdUμ!(dSdUμ::HIPLink, ga::GaugeAction{4,HIPLink}, μ::Integer, U::Vector{HIPLink}) =
+function calc_dSdUμ!(dSdUμ::HIPLink, ga::GaugeAction{4,HIPLink}, μ::Integer, U::Vector{HIPLink})
+    if LAZY_LINKS[] && getfield(dSdUμ, :parent) !== whole(U)
+        flush_links()
+        LAZY[] = (kind = :staple, S = dSdUμ, Ug = whole(U), mu = Cint(μ - 1), beta = Float64(2 * beta_inp(ga)))      # first call of the P_update! triple
+        return nothing
+    end
     check(ccall((:lqcd_link_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), getfield(dSdUμ, :parent).h, getfield(dSdUμ, :slot), whole(U).h, μ - 1, 2 * beta_inp(ga)))
+end
 # evaluate_GaugeAction(gauge_action, U) (standardHMC.jl:50,60; S_g = -that / NC): lqcd_gauge_action returns S_g itself
 function evaluate_GaugeAction(ga::GaugeAction{4,HIPLink}, U::Vector{HIPLink})
     s = Ref{Float64}(0)

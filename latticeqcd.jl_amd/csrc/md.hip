@@ -138,9 +138,9 @@ __device__ __forceinline__ void lower_staple_at(cd (&w)[9], const GFArgs& k, con
 // fully templated body below needs > 256 registers (1000+ spilled); this form holds them in 256 without scratch.
 template <int MODE>
 __global__ __launch_bounds__(256) void gauge_force_kernel_part(GFArgs k) {
-    constexpr bool FUSE_TA = MODE == 1;
+    constexpr bool FUSE_TA = MODE == 1 || MODE == 3;
     const Geom& g = k.g;
-    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = MODE == 2 ? k.mu_only : (int)(threadIdx.x >> 6);
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = MODE >= 2 ? k.mu_only : (int)(threadIdx.x >> 6);
     if (i >= g.Vh) return;
     const int Gs = glink_stride(g);
     int c[4];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gauge_force_kernel_part(GFArgs k) {
     cd um[9], r[9];
     load_m3(um, k.U + glink_off(g, p, mu, i), Gs);
     mm3(r, um, A);
-    double2* o = k.out + glink_off(g, p, mu, i);
+    double2* o = k.out + glink_off(g, p, MODE == 3 ? k.mu_out : mu, i);
     if constexpr (!FUSE_TA) {
 #pragma unroll
         for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, mk(coef * r[e].re, coef * r[e].im));
@@ -225,7 +225,7 @@ __device__ __forceinline__ const double2* link_at_shifted(const Geom& g, const d
 
 template <int MODE, int MU, int NU, bool PART, bool R2>
 __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&c)[4], int p, int lane, const double2 (*own)[9][64]) {
-    if constexpr (MU != NU && R2 && !PART && MODE != 2 && LQCD_STAPLE_BURST) {
+    if constexpr (MU != NU && R2 && !PART && MODE < 2 && LQCD_STAPLE_BURST) {
         // single GPU, links on the group: the five neighbour links of the plane are issued as ONE burst of two-row loads (30 x 1 KiB per wave: one
         // memory round trip per plane instead of two), row 2 is rebuilt as each link is consumed
         const Geom& g = k.g;
@@ -258,7 +258,7 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
         cd u1[9], u2[9], u3[9], t1[9], t2[9];
         link_fwd<PART, R2>(u1, k, c, MU, NU);               // U_nu(n+mu)
         link_fwd<PART, R2>(u2, k, c, NU, MU);               // U_mu(n+nu)
-        if constexpr (MODE != 2) {
+        if constexpr (MODE < 2) {
 #pragma unroll
             for (int e = 0; e < 9; e++) { const double2 t = own[NU][e][lane]; u3[e] = mk(t.x, t.y); }
         } else {
@@ -288,7 +288,7 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
 
 template <int MODE, int MU, bool PART, bool R2>
 __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int lane, const double2 (*own)[9][64]) {
-    constexpr bool FUSE_TA = MODE == 1;
+    constexpr bool FUSE_TA = MODE == 1 || MODE == 3;
     const Geom& g = k.g;
     const int Gs = glink_stride(g);
     int c[4];
@@ -308,10 +308,13 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
         return;
     }
     cd um[9], r[9];
+    if constexpr (MODE == 3) load_m3(um, k.U + glink_off(g, p, MU, i), Gs);      // one direction per launch: the link comes from memory
+    else {
 #pragma unroll
-    for (int e = 0; e < 9; e++) { const double2 t = own[MU][e][lane]; um[e] = mk(t.x, t.y); }      // U_mu(n) from LDS
+        for (int e = 0; e < 9; e++) { const double2 t = own[MU][e][lane]; um[e] = mk(t.x, t.y); }      // U_mu(n) from LDS
+    }
     mm3(r, um, A);
-    double2* o = k.out + glink_off(g, p, MU, i);
+    double2* o = k.out + glink_off(g, p, MODE == 3 ? k.mu_out : MU, i);
     if constexpr (!FUSE_TA) {
 #pragma unroll
         for (int e = 0; e < 9; e++) st(o + (size_t)e * Gs, mk(coef * r[e].re, coef * r[e].im));
@@ -338,6 +341,8 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
 // MODE 0: out = G.   MODE 1: out (the momenta) += factor * TA(G) -- P_update! in one pass, G never stored.
 // MODE 2 (64-thread blocks, one direction): out[mu_out] = coef * (sum of the six staples of direction mu_only) -- the reference's
 // calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108); the caller multiplies by U[mu] itself (mul!, :109).
+// MODE 3 (64-thread blocks, one direction): out[mu_out] += factor * TA(coef U_mu * staples) -- the three calls of the reference's P_update! for one
+// direction (calc_dSdUmu!, mul!, Traceless_antihermitian_add!: AbstractMD.jl:108-110) in one pass (lqcd_link_add_ta_staple).
 #ifndef LQCD_STAPLE_OCC
 #define LQCD_STAPLE_OCC 2
 #endif
@@ -348,10 +353,10 @@ __global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArg
     block_map(k.bm, blockIdx.x, chunk, p);
     const int lane = threadIdx.x & 63;
     const int i = chunk * 64 + lane;
-    const int mu = MODE == 2 ? k.mu_only : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int mu = MODE >= 2 ? k.mu_only : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool valid = i < g.Vh;
-    __shared__ double2 own[MODE == 2 ? 1 : 4][9][64];
-    if constexpr (MODE != 2) {
+    __shared__ double2 own[MODE >= 2 ? 1 : 4][9][64];
+    if constexpr (MODE < 2) {
         if (valid) {
             cd um[9];
             load_u<R2>(um, k.U + glink_off(g, p, mu, i), glink_stride(g));
@@ -574,7 +579,7 @@ __device__ __forceinline__ bool site_of_thread(const Geom& g, int& p, int& i) {
 template <int OP>
 // C, A and B may be slots of one allocation, and C may be A or B itself (substitute_U!(U, U), mul!(temp1, U[mu], dSdUmu) on slots of one
 // storage): no __restrict__ -- every thread loads all of its inputs before it stores, which is what makes the in-place forms well defined
-__global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* C, int mc, const double2* A, int ma, const double2* B, int mb, double t) {
+__global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* C, int mc, const double2* A, int ma, const double2* B, int mb, double t, unsigned* notproj) {
     int p, i;
     if (!site_of_thread(g, p, i)) return;
     const int Gs = glink_stride(g);
@@ -590,6 +595,26 @@ __global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* C, int mc,
         cd b[9];
         load_m3(b, B + glink_off(g, p, mb, i), Gs);
         mm3(r, a, b);
+    } else if constexpr (OP == 4 || OP == 5) {      // exp(t A) B: exptU! + mul! of the reference's U_update! in one pass (C may be B: the in-place link update)
+        cd e[9], b[9];
+        exp_m3(e, a, t);
+        load_m3(b, B + glink_off(g, p, mb, i), Gs);
+        mm3(r, e, b);
+        if constexpr (OP == 5) {                   // the projection rule of link_exp_update_kernel<true>
+            cd v[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) v[k] = r[k];
+            reunitarize_m3(v);
+            double dev = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) dev = fmax(dev, fmax(fabs(v[k].re - r[k].re), fabs(v[k].im - r[k].im)));
+            if (dev <= 1e-13) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) r[k] = v[k];
+            } else {
+                *notproj = 1u;
+            }
+        }
     } else {
         cd h[9];
 #pragma unroll
@@ -681,11 +706,14 @@ static int launch_staple_faces(lqcd_ctx_s* c, const GFArgs& k) {
 static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse, bool two_rows) {
     const dim3 grid(2 * c->geom.nch);
     if (any_partitioned(c)) {       // the instance with the ghost-link / received-staple branches
-        if (k.mu_only >= 0) hipLaunchKernelGGL(gauge_force_kernel_part<2>, grid, dim3(64), 0, c->stream, k);
+        if (k.mu_only >= 0 && fuse) hipLaunchKernelGGL(gauge_force_kernel_part<3>, grid, dim3(64), 0, c->stream, k);
+        else if (k.mu_only >= 0) hipLaunchKernelGGL(gauge_force_kernel_part<2>, grid, dim3(64), 0, c->stream, k);
         else if (fuse) hipLaunchKernelGGL(gauge_force_kernel_part<1>, grid, dim3(256), 0, c->stream, k);
         else hipLaunchKernelGGL(gauge_force_kernel_part<0>, grid, dim3(256), 0, c->stream, k);
     } else {
-        if (k.mu_only >= 0) hipLaunchKernelGGL((gauge_force_kernel<2, false>), grid, dim3(64), 0, c->stream, k);
+        if (k.mu_only >= 0 && fuse) { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<3, false, true>), grid, dim3(64), 0, c->stream, k);
+                                      else hipLaunchKernelGGL((gauge_force_kernel<3, false>), grid, dim3(64), 0, c->stream, k); }
+        else if (k.mu_only >= 0) hipLaunchKernelGGL((gauge_force_kernel<2, false>), grid, dim3(64), 0, c->stream, k);
         else if (fuse) { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<1, false, true>), grid, dim3(256), 0, c->stream, k);
                          else hipLaunchKernelGGL((gauge_force_kernel<1, false>), grid, dim3(256), 0, c->stream, k); }
         else { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<0, false, true>), grid, dim3(256), 0, c->stream, k);
@@ -747,7 +775,7 @@ static int link_op(lqcd_gauge_t C, int mc, lqcd_gauge_t A, int ma, lqcd_gauge_t 
     HIPCHK(hipSetDevice(c->device));
     C->version++;
     hipLaunchKernelGGL(link_op_kernel<OP>, dim3(link_grid(c->geom)), dim3(64), 0, c->stream, c->geom, C->data, mc, A->data, ma,
-                       B ? B->data : (const double2*)nullptr, mb, t);
+                       B ? B->data : (const double2*)nullptr, mb, t, c->pipe_ctr + 8 * 32 + 24);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
@@ -788,6 +816,40 @@ extern "C" int lqcd_link_staple(lqcd_gauge_t out, int mu_out, lqcd_gauge_t U, in
     LQCHK(link_args(out, mu_out, U, mu, "lqcd_link_staple"));
     ARGCHK(out != U, "lqcd_link_staple: out must not be the link field itself");
     return staple_force(out, U, beta, 0.0, false, mu, mu_out, 0.5 * beta);
+}
+
+// The three per-direction calls of the reference's U_update! (AbstractMD.jl:91-93) -- exptU!(expU, t, p[mu]); mul!(W, expU, U[mu]);
+// substitute_U!(U[mu], W) -- as ONE pass: W[mu_w] = exp(t P[mu_p]) U[mu_u], W = U allowed (the in-place update of one direction).  The bindings
+// reach it by evaluating those three generics lazily (operators.py, LatticeQCDHIP.jl): no caller changes.  In place and with the tunable
+// md_reunitarize the updated links are projected back onto SU(3) under the rule of lqcd_gauge_exp_update (the field stays "on the group" if it was).
+extern "C" int lqcd_link_exp_mul(lqcd_gauge_t W, int mu_w, double t, lqcd_gauge_t P, int mu_p, lqcd_gauge_t U, int mu_u) {
+    LQCHK(link_args(W, mu_w, P, mu_p, "lqcd_link_exp_mul"));
+    LQCHK(link_args(W, mu_w, U, mu_u, "lqcd_link_exp_mul"));
+    ARGCHK(W != P && U != P, "lqcd_link_exp_mul: the momentum field must be a field of its own");
+    lqcd_ctx_s* c = W->ctx;
+    const bool inplace = W == U && mu_w == mu_u;
+    if (!(inplace && c->tun.md_reunitarize)) return link_op<4>(W, mu_w, P, mu_p, U, mu_u, t);
+    HIPCHK(hipSetDevice(c->device));
+    const bool was_on_group = U->unitary_version == U->version;
+    unsigned* flag = c->pipe_ctr + 8 * 32 + 24;
+    unsigned notproj = 1;
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+    U->version++;
+    hipLaunchKernelGGL(link_op_kernel<5>, dim3(link_grid(c->geom)), dim3(64), 0, c->stream, c->geom, U->data, mu_w, P->data, mu_p, U->data, mu_u, t, flag);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&notproj, flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (was_on_group && !notproj) U->unitary_version = U->version;      // the other three directions were on the group, this one was projected
+    return LQCD_OK;
+}
+
+// The three per-direction calls of the reference's P_update! (AbstractMD.jl:108-110) -- calc_dSdUmu!(dSdUmu, gauge_action, mu, U);
+// mul!(temp1, U[mu], dSdUmu); Traceless_antihermitian_add!(p[mu], factor, temp1) -- as ONE pass: P[mu_p] += factor * TA(U[mu] * (beta/2) * staples);
+// reached through lazy evaluation in the bindings like lqcd_link_exp_mul
+extern "C" int lqcd_link_add_ta_staple(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t U, int mu, double beta) {
+    LQCHK(link_args(P, mu_p, U, mu, "lqcd_link_add_ta_staple"));
+    ARGCHK(P != U, "lqcd_link_add_ta_staple: the momentum field must not be the link field itself");
+    return staple_force(P, U, beta, factor, true, mu, mu_p, 0.5 * beta);
 }
 
 // G_mu(n) = -(beta/6) U_mu(n) * (sum of the six staples)      (calc_dSdUmu! + mul!(temp, U, dSdUmu), AbstractMD.jl:108-110)

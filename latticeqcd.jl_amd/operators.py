@@ -45,6 +45,30 @@ class Lattice:
         self.local_L = tuple(lo)
         self.origin = tuple(org)
         self.nranks = int(np.prod(self.pe))
+        # Lazy evaluation of the per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110): the first two
+        # calls of a triple are recorded here, the third launches ONE fused kernel (lqcd_link_exp_mul / lqcd_link_add_ta_staple); anything else
+        # that touches a gauge-shaped field first materialises the record with the plain single-direction calls (Gaugefields._h).  The callers
+        # stay as they are; the temporaries of a fused triple (expU, W / dSdUmu, temp1) are then never written.  lazy_links = False: eager.
+        self.lazy_links = True
+        self._lazy = None
+
+    def _flush_links(self):
+        z, self._lazy = self._lazy, None
+        if z is None:
+            return
+        lib = _l.lib()
+        if z["kind"] in ("exp", "expmul"):
+            E, P = z["E"], z["P"]
+            check(lib.lqcd_link_exp(E.field._hh, E.slot, C.c_double(z["t"]), P.field._hh, P.slot))
+            if z["kind"] == "expmul":
+                W, U = z["W"], z["U"]
+                check(lib.lqcd_link_mul(W.field._hh, W.slot, E.field._hh, E.slot, U.field._hh, U.slot))
+        else:
+            S, U = z["S"], z["U"]
+            check(lib.lqcd_link_staple(S.field._hh, S.slot, U._hh, z["mu"], C.c_double(z["beta"])))
+            if z["kind"] == "ustaple":
+                T = z["T"]
+                check(lib.lqcd_link_mul(T.field._hh, T.slot, U._hh, z["mu"], S.field._hh, S.slot))
 
     # -- shapes of the local host arrays
     @property
@@ -107,8 +131,20 @@ class Gaugefields:
     def __init__(self, lattice):
         self.lattice = lattice
         self.NC = 3
-        self._h = C.c_void_p()
-        check(_l.lib().lqcd_gauge_create(lattice._h, C.byref(self._h)))
+        self._hh = C.c_void_p()
+        check(_l.lib().lqcd_gauge_create(lattice._h, C.byref(self._hh)))
+
+    @property
+    def _h(self):
+        """the C handle; whoever asks for it is about to read or write the field, so a recorded lazy link operation (Lattice._lazy) is
+        materialised first -- only the three fusing functions below go to _hh directly"""
+        if self.lattice._lazy is not None:
+            self.lattice._flush_links()
+        return self._hh
+
+    @_h.setter
+    def _h(self, v):
+        self._hh = v
 
     def upload(self, U, layout=_l.LAYOUT_REFERENCE, nwing=0):
         """nwing > 0: U has the reference's winged shape (4, NT+2w, NZ+2w, NY+2w, NX+2w, 3, 3) (Nwing of universe.jl:41-49)."""
@@ -151,9 +187,9 @@ class Gaugefields:
         return 2.0 * momentum_action(self)
 
     def close(self):
-        if self._h:
+        if self._hh:
             _l.lib().lqcd_gauge_destroy(self._h)
-            self._h = C.c_void_p()
+            self._hh = C.c_void_p()
 
     def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
         try:
@@ -378,8 +414,22 @@ class DdagD_operator:
         self.eps_CG, self.MaxCGstep = D.eps_CG, D.MaxCGstep
 
 
+def _same_link(a, b):
+    return a.field is b.field and a.slot == b.slot
+
+
 def _mul_links(C_, A, B):
-    """mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): 3x3 products site by site."""
+    """mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): 3x3 products site by site.  Second call of a lazy triple
+    (Lattice._lazy): recorded, not launched."""
+    lat = C_.lattice
+    z = lat._lazy
+    if z is not None and z["kind"] == "exp" and _same_link(A, z["E"]) and not _same_link(C_, z["E"]) and not _same_link(C_, z["P"]):
+        lat._lazy = dict(z, kind="expmul", W=C_, U=B)
+        return C_
+    if z is not None and z["kind"] == "staple" and _same_link(B, z["S"]) and A.field is z["U"] and A.slot == z["mu"] and not _same_link(C_, z["S"]) \
+            and C_.field is not z["U"]:
+        lat._lazy = dict(z, kind="ustaple", T=C_)
+        return C_
     check(_l.lib().lqcd_link_mul(C_.field._h, C_.slot, A.field._h, A.slot, B.field._h, B.slot))
     return C_
 
@@ -713,6 +763,14 @@ def fermion_force_(UdSfdU, D, X, Y, scale=1.0, accumulate=False):
 def substitute_U_(dst, src):
     """substitute_U!(Uold, U) (standardHMC.jl:45) on the Vector of link fields, substitute_U!(U[mu], W) (AbstractMD.jl:93) on one."""
     if isinstance(dst, LinkView):
+        lat = dst.lattice
+        z = lat._lazy
+        if z is not None and z["kind"] == "expmul" and _same_link(src, z["W"]) and _same_link(dst, z["U"]):
+            # exptU!(expU, t, p[mu]); mul!(W, expU, U[mu]); substitute_U!(U[mu], W) -> U[mu] <- exp(t p[mu]) U[mu] in one pass
+            lat._lazy = None
+            P = z["P"]
+            check(_l.lib().lqcd_link_exp_mul(dst.field._hh, dst.slot, C.c_double(z["t"]), P.field._hh, P.slot, dst.field._hh, dst.slot))
+            return dst
         check(_l.lib().lqcd_link_copy(dst.field._h, dst.slot, src.field._h, src.slot))
         return dst
     check(_l.lib().lqcd_gauge_copy(dst._h, src._h))
@@ -795,12 +853,22 @@ def initialize_TA_Gaugefields(U):
 
 def exptU_(expU, t, p_mu, temps=None):
     """exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): expU = exp(t p[mu]) site by site."""
+    lat = expU.lattice
+    if lat.lazy_links and expU.field is not p_mu.field:
+        lat._flush_links()
+        lat._lazy = {"kind": "exp", "E": expU, "t": float(t), "P": p_mu}      # first call of the U_update! triple: recorded
+        return expU
     check(_l.lib().lqcd_link_exp(expU.field._h, expU.slot, C.c_double(t), p_mu.field._h, p_mu.slot))
     return expU
 
 
 def calc_dSdUmu_(dSdUmu, gauge_action, mu, U):
     """calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): beta_inp * (sum of the staples of U[μ]), μ = 1..4."""
+    lat = dSdUmu.lattice
+    if lat.lazy_links and dSdUmu.field is not U:
+        lat._flush_links()
+        lat._lazy = {"kind": "staple", "S": dSdUmu, "U": U, "mu": int(mu) - 1, "beta": float(gauge_action.beta)}      # first call of the P_update! triple
+        return dSdUmu
     check(_l.lib().lqcd_link_staple(dSdUmu.field._h, dSdUmu.slot, U._h, int(mu) - 1, C.c_double(gauge_action.beta)))
     return dSdUmu
 
@@ -825,6 +893,14 @@ def gauge_force_(G, U, beta):
 def Traceless_antihermitian_add_(p, factor, G):
     """Traceless_antihermitian_add!(p[mu], factor, temp) (AbstractMD.jl:110,131) on one direction; on whole fields all four at once."""
     if isinstance(p, LinkView):
+        lat = p.lattice
+        z = lat._lazy
+        if z is not None and z["kind"] == "ustaple" and _same_link(G, z["T"]) and p.field is not z["U"] and p.field is not z["T"].field \
+                and p.field is not z["S"].field:
+            # calc_dSdUmu!; mul!(temp1, U[mu], dSdUmu); Traceless_antihermitian_add!(p[mu], factor, temp1) -> one pass
+            lat._lazy = None
+            check(_l.lib().lqcd_link_add_ta_staple(p.field._hh, p.slot, C.c_double(factor), z["U"]._hh, z["mu"], C.c_double(z["beta"])))
+            return p
         check(_l.lib().lqcd_link_add_ta(p.field._h, p.slot, C.c_double(factor), G.field._h, G.slot))
         return p
     check(_l.lib().lqcd_momentum_add_ta(p._h, C.c_double(factor), G._h))

@@ -237,3 +237,51 @@ def test_transliterated_reference_callers_reproduce_the_fused_trajectory(lq):
         assert abs(fused.dH[-1] - hmc.dH[-1]) < 1e-8, (fused.dH[-1], hmc.dH[-1])
         assert rel_err(Ub.download(), Ua.download()) < 1e-12
     assert abs(lq.calculate_Plaquette(Ua) - lq.calculate_Plaquette(Ub)) < 1e-13
+
+
+def test_lazy_per_direction_triples_equal_the_eager_calls(lq, orc):
+    """The bindings evaluate the reference's per-direction call triples lazily -- exptU! -> mul! -> substitute_U! becomes ONE lqcd_link_exp_mul,
+    calc_dSdUmu! -> mul! -> Traceless_antihermitian_add! ONE lqcd_link_add_ta_staple -- with the callers unchanged.  Same links and momenta as the
+    eager single-direction calls (rounding of the fused passes: 1e-14), also on a configuration that is not on the group (no projection there),
+    and a temporary that IS read in the middle of a triple holds what the eager call would have put there."""
+    L = (4, 4, 6, 8)
+    Uh = orc.hot_gauge(L, 31)
+    res = {}
+    for lazy in (True, False):
+        lat = lq.Lattice(L)
+        lat.lazy_links = lazy
+        U = lq.Gaugefields(lat).upload(Uh)
+        ga = lq.GaugeAction(U)
+        pl = lq.make_loops_fromname("plaquette", Dim=Dim)
+        ga.push_(5.7 / 2, pl + lq.make_loops_fromname("plaquette", Dim=Dim, adjoint=True))
+        md = StandardMD(lq, U, ga, True, 0.05, 20)
+        lq.gauss_distribution_(md.p, 33)
+        for _ in range(3):
+            U_update_(U, md.p, 0.5, md)
+            P_update_(U, md.p, 1.0, md)
+            U_update_(U, md.p, 0.5, md)
+        assert lat._lazy is None
+        res[lazy] = (U.download(), md.p.download(), lq.unitarity_deviation(U))
+    assert np.abs(res[True][0] - res[False][0]).max() < 1e-13 and np.abs(res[True][1] - res[False][1]).max() < 1e-12
+    assert res[True][2] == 0.0 and res[False][2] > 0.0          # the fused in-place update projects links that are on the group (md_reunitarize)
+    # a triple that is interrupted: the temporary is materialised exactly as the eager call leaves it
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    p = lq.initialize_TA_Gaugefields(U)
+    lq.gauss_distribution_(p, 34)
+    tmp, tmp2 = lq.Gaugefields(lat), lq.Gaugefields(lat)
+    lq.exptU_(tmp[1], 0.3, p[2])
+    assert lat._lazy is not None
+    lazy_val = tmp[1].download()                      # reading flushes
+    assert lat._lazy is None
+    lat.lazy_links = False
+    lq.exptU_(tmp2[1], 0.3, p[2])
+    assert np.array_equal(lazy_val, tmp2[1].download())
+    lat.lazy_links = True
+    lq.exptU_(tmp[1], 0.3, p[2])
+    lq.mul_(tmp[2], tmp[1], U[3])
+    lq.substitute_U_(tmp2[4], tmp[2])                 # not the in-place pattern: materialised, then copied
+    lat.lazy_links = False
+    lq.exptU_(tmp[3], 0.3, p[2])
+    lq.mul_(tmp[4], tmp[3], U[3])
+    assert np.array_equal(tmp2[4].download(), tmp[4].download())
