@@ -133,16 +133,69 @@ views(::Type{T}, g::HIPGaugeStorage) where {T<:AnyLink} = T[T(g, Cint(μ - 1)) f
 # ---- lazy evaluation of the per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110).
 # exptU!(expU, t, p[μ]) -> mul!(W, expU, U[μ]) -> substitute_U!(U[μ], W) and calc_dSdUμ!(dSdUμ, ..) -> mul!(temp1, U[μ], dSdUμ) ->
 # Traceless_antihermitian_add!(p[μ], factor, temp1): the first two calls of a triple are RECORDED, the third launches one fused kernel
-# (lqcd_link_exp_mul, lqcd_link_add_ta_staple) -- 4 launches per update instead of 12, the callers unchanged.  Anything else that asks a
+# (lqcd_link_exp_mul, lqcd_link_add_ta_staple), and four completed triples of one update become ONE fused four-direction call (below) --
+# 1 launch per update instead of 12, the callers unchanged.  Anything else that asks a
 # storage for its handle (`.h`: every other ccall of this file) first materialises the record with the plain single-direction calls, so a
 # temporary that IS read holds what the eager call would have put there; the temporaries of a completed triple are never written.
 const LAZY_LINKS = Ref(true)              # false: every call launches its own kernel
 const LAZY = Ref{Any}(nothing)            # the recorded call(s) of the open triple (a NamedTuple) or nothing
+# Completed triples are deferred once more: when the same update has been asked for all four directions (what U_update! / P_update! do) the four
+# become ONE call of the fused four-direction entry point (lqcd_gauge_exp_update / lqcd_momentum_add_gauge_force); otherwise they are launched one
+# by one (run_done) when anything else needs a field.  Entries: (kind = :U, F = storage of U, slot, a = t, G = storage of p, b = 0.0) or
+# (kind = :P, F = storage of p, slot, a = factor, G = storage of U, b = β_inp)
+const DONE = Any[]
 rawh(l::AnyLink) = getfield(getfield(l, :parent), :h)
 rawh(g::HIPGaugeStorage) = getfield(g, :h)
 slotof(l::AnyLink) = getfield(l, :slot)
 samelink(a::AnyLink, b::AnyLink) = getfield(a, :parent) === getfield(b, :parent) && slotof(a) == slotof(b)
+function run_done()
+    d = copy(DONE)
+    empty!(DONE)
+    for r in d
+        if r.kind === :U
+            check(ccall((:lqcd_link_exp_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                        rawh(r.F), r.slot, r.a, rawh(r.G), r.slot, rawh(r.F), r.slot))
+        else
+            check(ccall((:lqcd_link_add_ta_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Float64),
+                        rawh(r.F), r.slot, r.a, rawh(r.G), r.slot, r.b))
+        end
+    end
+    return nothing
+end
+function defer_done(r)
+    if !isempty(DONE)
+        d = DONE[1]
+        if d.kind !== r.kind || d.F !== r.F || d.G !== r.G || d.a != r.a || d.b != r.b || any(e -> e.slot == r.slot, DONE)
+            run_done()
+        end
+    end
+    push!(DONE, r)
+    if length(DONE) == 4
+        empty!(DONE)
+        if r.kind === :U
+            check(ccall((:lqcd_gauge_exp_update, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), rawh(r.F), r.a, rawh(r.G)))
+        else        # factor TA(U (β/2) staples) = (-3 factor) TA(-(β/6) U staples)
+            check(ccall((:lqcd_momentum_add_gauge_force, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64), rawh(r.F), -3 * r.a, rawh(r.G), r.b))
+        end
+    end
+    return nothing
+end
+# a new triple starts: deferred triples of the same kind stay deferred unless the new one writes one of their fields (its temporaries never are);
+# an open record is materialised
+function open_triple(kind::Symbol, tmp::HIPGaugeStorage)
+    if !isempty(DONE) && (DONE[1].kind !== kind || any(e -> e.F === tmp || e.G === tmp, DONE))
+        run_done()
+    end
+    if LAZY[] !== nothing
+        d = copy(DONE)
+        empty!(DONE)
+        flush_links()
+        append!(DONE, d)
+    end
+    return nothing
+end
 function flush_links()
+    isempty(DONE) || run_done()
     z = LAZY[]
     z === nothing && return nothing
     LAZY[] = nothing
@@ -162,7 +215,7 @@ function flush_links()
     return nothing
 end
 function Base.getproperty(g::HIPGaugeStorage, s::Symbol)
-    s === :h && LAZY[] !== nothing && flush_links()      # whoever asks for the handle is about to read or write the field
+    s === :h && (LAZY[] !== nothing || !isempty(DONE)) && flush_links()      # whoever asks for the handle is about to read or write the field
     return getfield(g, s)
 end
 
@@ -246,6 +299,9 @@ function substitute_U!(dst::HIPLink, src::HIPLink)
     z = LAZY[]
     if z !== nothing && z.kind === :expmul && samelink(src, z.W) && samelink(dst, z.U)
         LAZY[] = nothing          # U[μ] <- exp(t p[μ]) U[μ] in one pass (in place; projected back onto SU(3) under the tunable md_reunitarize)
+        if slotof(z.P) == slotof(dst)
+            return defer_done((kind = :U, F = getfield(dst, :parent), slot = slotof(dst), a = z.t, G = getfield(z.P, :parent), b = 0.0))      # maybe one of four
+        end
         return check(ccall((:lqcd_link_exp_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
                            rawh(dst), slotof(dst), z.t, rawh(z.P), slotof(z.P), rawh(dst), slotof(dst)))
     end
@@ -270,7 +326,7 @@ end
 # exptU!(expU, t, p[mu], [temp1, temp2]) (AbstractMD.jl:91)
 function exptU!(expU::HIPLink, t::Number, p::HIPTALink, temps)
     if LAZY_LINKS[] && getfield(expU, :parent) !== getfield(p, :parent)
-        flush_links()
+        open_triple(:U, getfield(expU, :parent))
         LAZY[] = (kind = :exp, E = expU, t = Float64(t), P = p)       # first call of the U_update! triple: recorded
         return nothing
     end
@@ -282,6 +338,9 @@ function Traceless_antihermitian_add!(p::HIPTALink, factor::Number, G::HIPLink)
     if z !== nothing && z.kind === :ustaple && samelink(G, z.T) && getfield(p, :parent) !== z.Ug && getfield(p, :parent) !== getfield(z.T, :parent) &&
        getfield(p, :parent) !== getfield(z.S, :parent)
         LAZY[] = nothing          # p[μ] += factor TA(U[μ] (β/2) staples) in one pass
+        if slotof(p) == z.mu
+            return defer_done((kind = :P, F = getfield(p, :parent), slot = slotof(p), a = Float64(factor), G = z.Ug, b = z.beta))
+        end
         return check(ccall((:lqcd_link_add_ta_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Float64),
                            rawh(p), slotof(p), Float64(factor), rawh(z.Ug), z.mu, z.beta))
     end
@@ -315,7 +374,7 @@ end
 # calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): β_inp * (sum of the staples of U[μ])
 function calc_dSdUμ!(dSdUμ::HIPLink, ga::GaugeAction{4,HIPLink}, μ::Integer, U::Vector{HIPLink})
     if LAZY_LINKS[] && getfield(dSdUμ, :parent) !== whole(U)
-        flush_links()
+        open_triple(:P, getfield(dSdUμ, :parent))
         LAZY[] = (kind = :staple, S = dSdUμ, Ug = whole(U), mu = Cint(μ - 1), beta = Float64(2 * beta_inp(ga)))      # first call of the P_update! triple
         return nothing
     end

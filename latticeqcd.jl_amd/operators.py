@@ -49,10 +49,49 @@ class Lattice:
         # calls of a triple are recorded here, the third launches ONE fused kernel (lqcd_link_exp_mul / lqcd_link_add_ta_staple); anything else
         # that touches a gauge-shaped field first materialises the record with the plain single-direction calls (Gaugefields._h).  The callers
         # stay as they are; the temporaries of a fused triple (expU, W / dSdUmu, temp1) are then never written.  lazy_links = False: eager.
+        # Completed triples are deferred once more: when the same update has been asked for all four directions (what U_update! / P_update! do) the
+        # four become ONE call of the fused four-direction entry point (lqcd_gauge_exp_update / lqcd_momentum_add_gauge_force); otherwise they are
+        # launched one by one when anything else needs a field.
         self.lazy_links = True
         self._lazy = None
+        self._done = []
+
+    def _defer(self, rec):
+        """a completed triple: ("U", Ufield, slot, t, Pfield) or ("P", Pfield, slot, factor, Ufield, beta) with p[mu] <-> U[mu]"""
+        d = self._done
+        if d and (d[0][0] != rec[0] or d[0][1] is not rec[1] or d[0][3:] != rec[3:] or any(e[2] == rec[2] for e in d)):
+            self._run_done()
+        self._done.append(rec)
+        if len(self._done) == 4:
+            d, self._done = self._done, []
+            if rec[0] == "U":
+                check(_l.lib().lqcd_gauge_exp_update(rec[1]._hh, C.c_double(rec[3]), rec[4]._hh))
+            else:       # factor TA(U (beta/2) staples) = (-3 factor) TA(-(beta/6) U staples)
+                check(_l.lib().lqcd_momentum_add_gauge_force(rec[1]._hh, C.c_double(-3.0 * rec[3]), rec[4]._hh, C.c_double(rec[5])))
+
+    def _open_triple(self, kind, touched):
+        """a new triple starts: an open record is materialised; deferred triples of the same kind stay deferred unless this triple writes one of
+        their fields (its temporaries never are)"""
+        if self._done and (self._done[0][0] != kind or any(f is e[1] or f is e[4] for e in self._done for f in touched)):
+            self._run_done()
+        z, self._lazy = self._lazy, None
+        if z is not None:
+            self._lazy = z
+            d, self._done = self._done, []
+            self._flush_links()
+            self._done = d
+
+    def _run_done(self):
+        d, self._done = self._done, []
+        for rec in d:
+            if rec[0] == "U":
+                check(_l.lib().lqcd_link_exp_mul(rec[1]._hh, rec[2], C.c_double(rec[3]), rec[4]._hh, rec[2], rec[1]._hh, rec[2]))
+            else:
+                check(_l.lib().lqcd_link_add_ta_staple(rec[1]._hh, rec[2], C.c_double(rec[3]), rec[4]._hh, rec[2], C.c_double(rec[5])))
 
     def _flush_links(self):
+        if self._done:
+            self._run_done()
         z, self._lazy = self._lazy, None
         if z is None:
             return
@@ -138,7 +177,7 @@ class Gaugefields:
     def _h(self):
         """the C handle; whoever asks for it is about to read or write the field, so a recorded lazy link operation (Lattice._lazy) is
         materialised first -- only the three fusing functions below go to _hh directly"""
-        if self.lattice._lazy is not None:
+        if self.lattice._lazy is not None or self.lattice._done:
             self.lattice._flush_links()
         return self._hh
 
@@ -769,7 +808,10 @@ def substitute_U_(dst, src):
             # exptU!(expU, t, p[mu]); mul!(W, expU, U[mu]); substitute_U!(U[mu], W) -> U[mu] <- exp(t p[mu]) U[mu] in one pass
             lat._lazy = None
             P = z["P"]
-            check(_l.lib().lqcd_link_exp_mul(dst.field._hh, dst.slot, C.c_double(z["t"]), P.field._hh, P.slot, dst.field._hh, dst.slot))
+            if P.slot == dst.slot and isinstance(P.field, Gaugefields):
+                lat._defer(("U", dst.field, dst.slot, z["t"], P.field))       # p[mu] with U[mu]: maybe one of four
+            else:
+                check(_l.lib().lqcd_link_exp_mul(dst.field._hh, dst.slot, C.c_double(z["t"]), P.field._hh, P.slot, dst.field._hh, dst.slot))
             return dst
         check(_l.lib().lqcd_link_copy(dst.field._h, dst.slot, src.field._h, src.slot))
         return dst
@@ -855,7 +897,7 @@ def exptU_(expU, t, p_mu, temps=None):
     """exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): expU = exp(t p[mu]) site by site."""
     lat = expU.lattice
     if lat.lazy_links and expU.field is not p_mu.field:
-        lat._flush_links()
+        lat._open_triple("U", (expU.field,))      # p[mu] is only read, by this triple and by the deferred ones
         lat._lazy = {"kind": "exp", "E": expU, "t": float(t), "P": p_mu}      # first call of the U_update! triple: recorded
         return expU
     check(_l.lib().lqcd_link_exp(expU.field._h, expU.slot, C.c_double(t), p_mu.field._h, p_mu.slot))
@@ -866,7 +908,7 @@ def calc_dSdUmu_(dSdUmu, gauge_action, mu, U):
     """calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): beta_inp * (sum of the staples of U[μ]), μ = 1..4."""
     lat = dSdUmu.lattice
     if lat.lazy_links and dSdUmu.field is not U:
-        lat._flush_links()
+        lat._open_triple("P", (dSdUmu.field,))
         lat._lazy = {"kind": "staple", "S": dSdUmu, "U": U, "mu": int(mu) - 1, "beta": float(gauge_action.beta)}      # first call of the P_update! triple
         return dSdUmu
     check(_l.lib().lqcd_link_staple(dSdUmu.field._h, dSdUmu.slot, U._h, int(mu) - 1, C.c_double(gauge_action.beta)))
@@ -899,7 +941,10 @@ def Traceless_antihermitian_add_(p, factor, G):
                 and p.field is not z["S"].field:
             # calc_dSdUmu!; mul!(temp1, U[mu], dSdUmu); Traceless_antihermitian_add!(p[mu], factor, temp1) -> one pass
             lat._lazy = None
-            check(_l.lib().lqcd_link_add_ta_staple(p.field._hh, p.slot, C.c_double(factor), z["U"]._hh, z["mu"], C.c_double(z["beta"])))
+            if p.slot == z["mu"]:
+                lat._defer(("P", p.field, p.slot, float(factor), z["U"], z["beta"]))
+            else:
+                check(_l.lib().lqcd_link_add_ta_staple(p.field._hh, p.slot, C.c_double(factor), z["U"]._hh, z["mu"], C.c_double(z["beta"])))
             return p
         check(_l.lib().lqcd_link_add_ta(p.field._h, p.slot, C.c_double(factor), G.field._h, G.slot))
         return p

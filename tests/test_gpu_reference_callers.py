@@ -262,6 +262,7 @@ def test_lazy_per_direction_triples_equal_the_eager_calls(lq, orc):
             U_update_(U, md.p, 0.5, md)
         assert lat._lazy is None
         res[lazy] = (U.download(), md.p.download(), lq.unitarity_deviation(U))
+        assert not lat._done
     assert np.abs(res[True][0] - res[False][0]).max() < 1e-13 and np.abs(res[True][1] - res[False][1]).max() < 1e-12
     assert res[True][2] == 0.0 and res[False][2] > 0.0          # the fused in-place update projects links that are on the group (md_reunitarize)
     # a triple that is interrupted: the temporary is materialised exactly as the eager call leaves it
@@ -281,6 +282,19 @@ def test_lazy_per_direction_triples_equal_the_eager_calls(lq, orc):
     lq.exptU_(tmp[1], 0.3, p[2])
     lq.mul_(tmp[2], tmp[1], U[3])
     lq.substitute_U_(tmp2[4], tmp[2])                 # not the in-place pattern: materialised, then copied
+    # three directions of an update, then something else: the deferred ones run one by one and give what four single calls give
+    Ua, Ub = lq.Gaugefields(lat), lq.Gaugefields(lat)
+    lq.substitute_U_(Ua, U); lq.substitute_U_(Ub, U)
+    for mu in (1, 2, 4):
+        lq.exptU_(tmp[1], 0.2, p[mu]); lq.mul_(tmp[2], tmp[1], Ua[mu]); lq.substitute_U_(Ua[mu], tmp[2])
+    assert len(lat._done) == 3
+    got = Ua.download()
+    assert not lat._done
+    lat.lazy_links = False
+    for mu in (1, 2, 4):
+        lq.exptU_(tmp[1], 0.2, p[mu]); lq.mul_(tmp[2], tmp[1], Ub[mu]); lq.substitute_U_(Ub[mu], tmp[2])
+    assert np.abs(got - Ub.download()).max() < 1e-13
+    lat.lazy_links = True
     lat.lazy_links = False
     lq.exptU_(tmp[3], 0.3, p[2])
     lq.mul_(tmp[4], tmp[3], U[3])
