@@ -55,6 +55,30 @@ def test_gauge_force_rccl_self_partition(lq, orc):
         lq.P_update_(Ud, Pd, 0.3, beta)
         Pref = orc.momentum_add_ta(P.copy(), 0.3, Gref, L)
         assert np.abs(Pd.download() - Pref).max() / np.abs(Pref).max() < 1e-13
+        # the per-direction interface of the unchanged callers on the partitioned lattice: eager calls, one fused kernel per direction (three
+        # directions only: the deferred triples run one by one), and all four (one fused four-direction call) give the same momenta
+        ga = lq.GaugeAction(Ud)
+        pl = lq.make_loops_fromname("plaquette", Dim=4)
+        ga.push_(beta / 2, pl + lq.make_loops_fromname("plaquette", Dim=4, adjoint=True))
+        tmp = lq.Gaugefields(lat)
+        out = {}
+        for mode, dirs in (("eager", (1, 2, 3, 4)), ("lazy4", (1, 2, 3, 4)), ("lazy3", (1, 2, 3))):
+            lat.lazy_links = mode != "eager"
+            Pm = lq.Gaugefields(lat).upload(P)
+            for mu in dirs:
+                lq.calc_dSdUmu_(tmp[1], ga, mu, Ud)
+                lq.mul_(tmp[2], Ud[mu], tmp[1])
+                lq.Traceless_antihermitian_add_(Pm[mu], -0.1, tmp[2])
+            if mode == "lazy3":
+                lat.lazy_links = False
+                lq.calc_dSdUmu_(tmp[1], ga, 4, Ud)
+                lq.mul_(tmp[2], Ud[4], tmp[1])
+                lq.Traceless_antihermitian_add_(Pm[4], -0.1, tmp[2])
+            out[mode] = Pm.download()
+        lat.lazy_links = True
+        Pref2 = orc.momentum_add_ta(P.copy(), 0.3, Gref, L)
+        for mode in ("eager", "lazy4", "lazy3"):
+            assert np.abs(out[mode] - Pref2).max() / np.abs(Pref2).max() < 1e-13, mode
         print("GF_SELF_OK")
     """)
     for mask in ("8", "14", "15"):
