@@ -88,7 +88,7 @@ function HIPGaugeStorage(lat::HIPLattice)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lqcd_gauge_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), lat.h, h))
     g = HIPGaugeStorage(h[], lat, 0)
-    finalizer(x -> ccall((:lqcd_gauge_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), g)
+    finalizer(x -> ccall((:lqcd_gauge_destroy, LIB), Cint, (Ptr{Cvoid},), getfield(x, :h)), g)      # getfield: a finalizer must not trigger the lazy-link flush of `.h`
     return g
 end
 const SPARE = Dict{Ptr{Cvoid},HIPGaugeStorage}()     # per context: the storage whose free slots the next temporaries take
