@@ -227,7 +227,13 @@ class Gaugefields:
 
     def close(self):
         if self._hh:
-            _l.lib().lqcd_gauge_destroy(self._h)
+            lat = self.lattice
+            z = lat._lazy
+            mine = any(e[1] is self or e[4] is self for e in lat._done) or (
+                z is not None and any(getattr(v, "field", v) is self for v in z.values() if isinstance(v, (LinkView, Gaugefields))))
+            if mine:                   # a recorded lazy link operation involves this field: it runs before the storage goes away
+                lat._flush_links()
+            _l.lib().lqcd_gauge_destroy(self._hh)
             self._hh = C.c_void_p()
 
     def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
