@@ -180,17 +180,12 @@ function defer_done(r)
     end
     return nothing
 end
-# a new triple starts: deferred triples of the same kind stay deferred unless the new one writes one of their fields (its temporaries never are);
-# an open record is materialised
+# a new triple starts: deferred triples of the same kind stay deferred unless the new one writes one of their fields (its temporaries never are)
 function open_triple(kind::Symbol, tmp::HIPGaugeStorage)
-    if !isempty(DONE) && (DONE[1].kind !== kind || any(e -> e.F === tmp || e.G === tmp, DONE))
-        run_done()
-    end
-    if LAZY[] !== nothing
-        d = copy(DONE)
-        empty!(DONE)
+    if LAZY[] !== nothing            # an interrupted triple: everything recorded so far runs, in the order it was asked for
         flush_links()
-        append!(DONE, d)
+    elseif !isempty(DONE) && (DONE[1].kind !== kind || any(e -> e.F === tmp || e.G === tmp, DONE))
+        run_done()
     end
     return nothing
 end

@@ -70,16 +70,12 @@ class Lattice:
                 check(_l.lib().lqcd_momentum_add_gauge_force(rec[1]._hh, C.c_double(-3.0 * rec[3]), rec[4]._hh, C.c_double(rec[5])))
 
     def _open_triple(self, kind, touched):
-        """a new triple starts: an open record is materialised; deferred triples of the same kind stay deferred unless this triple writes one of
-        their fields (its temporaries never are)"""
-        if self._done and (self._done[0][0] != kind or any(f is e[1] or f is e[4] for e in self._done for f in touched)):
-            self._run_done()
-        z, self._lazy = self._lazy, None
-        if z is not None:
-            self._lazy = z
-            d, self._done = self._done, []
+        """a new triple starts: deferred triples of the same kind stay deferred unless this triple writes one of their fields (its temporaries
+        never are)"""
+        if self._lazy is not None:          # an interrupted triple: everything recorded so far runs, in the order it was asked for
             self._flush_links()
-            self._done = d
+        elif self._done and (self._done[0][0] != kind or any(f is e[1] or f is e[4] for e in self._done for f in touched)):
+            self._run_done()
 
     def _run_done(self):
         d, self._done = self._done, []
