@@ -448,8 +448,13 @@ function Dirac_operator(U::Vector{HIPLink}, x::HIPFermion, params)
     end
     D = HIPDirac(h[], U, x, false, Float64(get(params, "eps_CG", 1e-19)), Int(get(params, "MaxCGstep", 3000)),
                  String(get(params, "method_CG", "bicgstab")), true)
-    finalizer(d -> d.owner && ccall((:lqcd_op_destroy, LIB), Cint, (Ptr{Cvoid},), d.h), D)
+    finalizer(d -> getfield(d, :owner) && ccall((:lqcd_op_destroy, LIB), Cint, (Ptr{Cvoid},), getfield(d, :h)), D)
     return D
+end
+# an application of the operator reads the links: recorded / deferred lazy link operations (LAZY, DONE) run before its handle is handed out
+function Base.getproperty(D::HIPDirac, s::Symbol)
+    s === :h && (LAZY[] !== nothing || !isempty(DONE)) && flush_links()
+    return getfield(D, s)
 end
 # D(U): rebind links (unusedfiles/measure_chiral_condensate.jl:173)
 function (D::HIPDirac)(U::Vector{HIPLink})

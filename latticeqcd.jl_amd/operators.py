@@ -413,14 +413,26 @@ class Dirac_operator:
             self.km = float(self.params.get("mass", 0.5))
             self.r = 1.0
         if _share is not None:
-            self._h, self._owner = _share, False
+            self._hh, self._owner = _share, False
         else:
-            self._h, self._owner = C.c_void_p(), True
-            check(_l.lib().lqcd_op_create(self.lattice._h, C.byref(self._h), self.kind, U._h, C.c_double(self.km),
+            self._hh, self._owner = C.c_void_p(), True
+            check(_l.lib().lqcd_op_create(self.lattice._h, C.byref(self._hh), self.kind, U._h, C.c_double(self.km),
                                           C.c_double(self.r), _l.i4(self.bc)))
             if key == "wilsonclover":     # Dirac_operator = "WilsonClover", Clover_coefficient (parameter_structs.jl:125)
                 self.csw = float(self.params.get("Clover_coefficient", 1.5612))
                 check(_l.lib().lqcd_op_set_clover(self._h, C.c_double(self.csw)))
+
+    @property
+    def _h(self):
+        """the operator handle; an application reads the links, so recorded / deferred lazy link operations (Lattice._lazy, _done) run first"""
+        lat = self.lattice
+        if lat._lazy is not None or lat._done:
+            lat._flush_links()
+        return self._hh
+
+    @_h.setter
+    def _h(self, v):
+        self._hh = v
 
     def __call__(self, U):
         check(_l.lib().lqcd_op_set_gauge(self._h, U._h))
@@ -436,9 +448,9 @@ class Dirac_operator:
     H = property(adjoint)
 
     def close(self):
-        if self._owner and self._h:
-            _l.lib().lqcd_op_destroy(self._h)
-            self._h = C.c_void_p()
+        if self._owner and self._hh:
+            _l.lib().lqcd_op_destroy(self._hh)
+            self._hh = C.c_void_p()
 
     def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
         try:

@@ -299,3 +299,29 @@ def test_lazy_per_direction_triples_equal_the_eager_calls(lq, orc):
     lq.exptU_(tmp[3], 0.3, p[2])
     lq.mul_(tmp[4], tmp[3], U[3])
     assert np.array_equal(tmp2[4].download(), tmp[4].download())
+
+
+def test_operator_application_sees_deferred_link_updates(lq, orc):
+    """Three directions of a per-direction link update are deferred (waiting for a fourth that would make them one fused call); applying the Dirac
+    operator asks for its handle, which runs them first: the result is the one of the eager calls."""
+    L = (4, 4, 4, 8)
+    Uh = orc.hot_gauge(L, 71)
+    out = []
+    for lazy in (True, False):
+        lat = lq.Lattice(L)
+        lat.lazy_links = lazy
+        U = lq.Gaugefields(lat).upload(Uh)
+        p = lq.initialize_TA_Gaugefields(U)
+        lq.gauss_distribution_(p, 72)
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.12})
+        x = lq.Fermionfields(lat, lq.WILSON)
+        lq.gauss_distribution_fermion_(x, 73)
+        y = x.similar()
+        tmp = lq.Gaugefields(lat)
+        for mu in (1, 3, 4):
+            lq.exptU_(tmp[1], 0.1, p[mu]); lq.mul_(tmp[2], tmp[1], U[mu]); lq.substitute_U_(U[mu], tmp[2])
+        assert len(lat._done) == (3 if lazy else 0)
+        lq.mul_(y, D, x)
+        assert not lat._done
+        out.append(y.download())
+    assert np.abs(out[0] - out[1]).max() < 1e-13 * np.abs(out[1]).max()
