@@ -33,6 +33,7 @@ typedef struct lqcd_ctx_s* lqcd_ctx_t;
 typedef struct lqcd_gauge_s* lqcd_gauge_t;
 typedef struct lqcd_spinor_s* lqcd_spinor_t;
 typedef struct lqcd_op_s* lqcd_op_t;
+typedef struct lqcd_action_s* lqcd_action_t;
 
 enum {
     LQCD_OK = 0,
@@ -253,6 +254,48 @@ int lqcd_rational_apply(lqcd_op_t op, lqcd_spinor_t y, lqcd_spinor_t x, double a
                         double eps, int maxiter, int* iters);
 int lqcd_rational_force(lqcd_op_t op, lqcd_gauge_t out, lqcd_spinor_t phi, int n, const double* res, const double* poles, double eps,
                         int maxiter, int* iters);
+
+/* The coefficients themselves (host-only numerics, no GPU needed): x^(-alpha) ~= a0 + sum_k res[k] / (x + poles[k]) on [lam_min, lam_max],
+ * 0 < alpha < 1, a0 >= 0, res[k] > 0, poles[k] > 0, max relative error <= tol on the interval (verified on a grid that is not the fit grid;
+ * returned in max_rel_err, may be NULL).  res / poles must hold max_poles entries, *n receives the count.  The reference's package ships Remez
+ * tables for its staggered Nf = 2 / 3 runs (test/test_Nf2.toml:8, test/test_Nf3.toml:8, README.md:112,132); here the fit is computed (AAA
+ * algorithm, csrc/rational.hip).  LQCD_ERR_NOT_CONVERGED: the requested accuracy is not reachable in double precision on this interval. */
+int lqcd_rational_fit(double alpha, double lam_min, double lam_max, double tol, int max_poles, double* a0, double* res, double* poles, int* n,
+                      double* max_rel_err);
+/* extreme Ritz values of D^+D from `steps` Lanczos iterations on the device: theta_max converges to the largest eigenvalue from below, theta_min to
+ * the smallest from above -- use them with a margin.  The Wilson rational action takes its fit interval from here when none is given. */
+int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, double* theta_min, double* theta_max);
+
+/* ---------------------------------------------------------------- FermiAction(D, Dict("Nf" => n)) as a handle (src/system/universe.jl:106-110,138)
+ * nf <= 0: the operator's default (Wilson 2, staggered 4).  Wilson Nf = 2 and staggered Nf = 8 (eta on every site) / 4 (eta on the even sites,
+ * test/test_staggered.toml) are the exact actions S_f = eta^+ (D^+D)^-1 eta; staggered 0 < Nf < 8 otherwise (test/test_Nf2.toml:8, test/test_Nf3.toml:8,
+ * test/runtests.jl:114-130) and Wilson(-clover) 0 < Nf < 2 are the rational action S_f = eta^+ (D^+D)^(-Nf/n0) eta, n0 = 8 | 2, with partial fractions
+ * fitted at creation on [m^2, m^2 + 16] (staggered) or on a Lanczos estimate of the spectrum with margins 0.5 / 1.2 (Wilson).  eps / maxiter:
+ * "eps_CG" / "MaxCGstep" of the operator's parameters (universe.jl:103-135).  Optional parameters as nparams (key, value) pairs:
+ * rhmc_lambda_min, rhmc_lambda_max (fix the interval), rhmc_tol_action (1e-12: action and heat bath), rhmc_tol_MD (1e-8: force),
+ * rhmc_lanczos_steps (60), force_rational (1: staggered Nf = 4 through partial fractions, a statistical cross-check).
+ * The operator must outlive the action.  U (may be NULL = the operator's links) is the `U` argument of the reference's generics: the operator is
+ * rebound to it first (the D(U) idiom). */
+int lqcd_action_create(lqcd_op_t op, double nf, double eps, int maxiter, int nparams, const char* const* keys, const double* values,
+                       lqcd_action_t* fa);
+int lqcd_action_destroy(lqcd_action_t fa);
+int lqcd_action_set_solver(lqcd_action_t fa, double eps, int maxiter);   /* the operator's eps_CG / MaxCGstep changed after the action was made */
+/* keys: rational, evensite, Nf, alpha, lambda_min, lambda_max, interval_refits, explicit_interval */
+int lqcd_action_get(lqcd_action_t fa, const char* key, double* value);
+/* which = 0: x^(-alpha) to rhmc_tol_action (the action), 1: the same to rhmc_tol_MD (the force), 2: x^(alpha/2 - 1) (heat bath).  res / poles may be
+ * NULL to query the count */
+int lqcd_action_coefficients(lqcd_action_t fa, int which, double* a0, double* res, double* poles, int capacity, int* n, double* max_rel_err);
+int lqcd_action_set_coefficients(lqcd_action_t fa, int which, double a0, int n, const double* res, const double* poles);   /* e.g. Remez tables */
+/* Wilson rational action: Lanczos on the current links; refits an estimated interval that has become too tight (interval_refits counts), raises
+ * LQCD_ERR_ARG when a Ritz value left an interval the caller fixed.  Called by sample / evaluate themselves. */
+int lqcd_action_check_interval(lqcd_action_t fa);
+int lqcd_action_gauss_sampling(lqcd_action_t fa, lqcd_spinor_t xi, uint64_t seed);                           /* gauss_sampling_in_action!(xi, U, fa) (src/md/standardMD.jl:95): <|xi_i|^2> = 1 */
+int lqcd_action_sample_pseudofermions(lqcd_action_t fa, lqcd_gauge_t U, lqcd_spinor_t eta, lqcd_spinor_t xi); /* sample_pseudofermions!(eta, U, fa, xi) (standardMD.jl:96) */
+/* evaluate_FermiAction(fa, U, eta) (src/updates/standardHMC.jl:69,71).  X, Y may be NULL (library scratch); otherwise X receives (D^+D)^-1 eta and Y = D X
+ * (exact actions) or X the rational image of eta */
+int lqcd_action_evaluate(lqcd_action_t fa, lqcd_gauge_t U, lqcd_spinor_t eta, lqcd_spinor_t X, lqcd_spinor_t Y, double* Sf, int* iters);
+/* calc_UdSfdU!(UdSfdU, fa, U, eta) (src/md/AbstractMD.jl:129): out = G in the convention of lqcd_fermion_force; Sf (exact actions only) and iters may be NULL */
+int lqcd_action_force(lqcd_action_t fa, lqcd_gauge_t U, lqcd_gauge_t out, lqcd_spinor_t eta, double* Sf, int* iters);
 
 /* ---------------------------------------------------------------- gauge side of the MD step
  * Momenta are traceless anti-Hermitian 3x3 matrices held in a gauge-shaped field (lqcd_gauge_create).  Conventions (fixed by

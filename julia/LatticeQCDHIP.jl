@@ -524,64 +524,84 @@ function solve_mixed_DinvX!(y::HIPFermion, A::HIPDdagD, x::HIPFermion; inner_tol
                 A.D.h, y.h, x.h, A.D.eps_CG, A.D.MaxCGstep, inner_tol, it, out, rr))
 end
 
-# ---- pseudofermion action and force: FermiAction(D, Dict) (universe.jl:138) and the generics of standardMD.jl:95-96,
-# standardHMC.jl:54,71 and AbstractMD.jl:129.  2-flavour Wilson(-clover) and the 4- / 8-taste staggered actions; for any other Nf the
-# reference's package brings Remez tables -- here the partial fractions come from the caller (rational_apply! / rational_force! below;
-# the Python mirror fits them with latticeqcd.jl_amd/rational.py).
+# ---- pseudofermion action and force: FermiAction(D, Dict("Nf" => n)) (universe.jl:106-110,138) and the generics of standardMD.jl:95-96,
+# standardHMC.jl:54,71 and AbstractMD.jl:129.  The action is a handle of the library (lqcd_action_*, csrc/rational.hip): which Nf is an exact action
+# (Wilson 2; staggered 8, and 4 on the even sites) and which is the rational action S_f = η†(D†D)^(-Nf/n0)η (staggered Nf = 2, 3 of test/test_Nf2.toml:8,
+# test/test_Nf3.toml:8, test/runtests.jl:114-130; Wilson Nf = 1), the spectral interval, the partial fractions (fitted by the library, where the
+# reference's package brings Remez tables) and their refits are decided below the C ABI -- every method here is one ccall.
 mutable struct HIPFermiAction <: FermiAction{4,HIPDirac,HIPFermion,HIPLink}
+    h::Ptr{Cvoid}
     D::HIPDirac
-    Nf::Int
+    Nf::Float64
     _temporary_fermionfields::Vector{HIPFermion}     # standardMD.jl:50: η = similar(fermi_action._temporary_fermionfields[1])
-    force::Vector{HIPLink}                           # G of lqcd_calc_UdSfdU, handed out per direction
+    force::Vector{HIPLink}                           # G of lqcd_action_force, handed out per direction
 end
+const ACTION_KEYS = ("force_rational", "rhmc_lambda_min", "rhmc_lambda_max", "rhmc_tol_action", "rhmc_tol_MD", "rhmc_lanczos_steps")
 function FermiAction(D::HIPDirac, parameters_action)
-    kind = D.x.kind
-    Nf = get(parameters_action, "Nf", kind == WILSON ? 2 : 4)
-    (kind == WILSON && Nf == 2) || (kind == STAGGERED && Nf in (4, 8)) ||
-        error("FermiAction: Nf = $Nf needs the rational action (rational_apply! / rational_force! with partial fractions from the caller)")
-    return HIPFermiAction(D, Nf, [similar(D.x), similar(D.x)], similar(D.U))
+    keys = String[k for k in ACTION_KEYS if haskey(parameters_action, k)]
+    vals = Float64[Float64(parameters_action[k]) for k in keys]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:lqcd_action_create, LIB), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Cint, Ptr{Cstring}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                D.h, Float64(get(parameters_action, "Nf", 0)), D.eps_CG, D.MaxCGstep, length(keys), keys, vals, h))
+    fa = HIPFermiAction(h[], D, action_get(h[], "Nf"), [similar(D.x), similar(D.x)], similar(D.U))
+    finalizer(a -> ccall((:lqcd_action_destroy, LIB), Cint, (Ptr{Cvoid},), getfield(a, :h)), fa)
+    return fa
 end
+function action_get(h::Ptr{Cvoid}, key::String)
+    v = Ref{Float64}(0)
+    check(ccall((:lqcd_action_get, LIB), Cint, (Ptr{Cvoid}, Cstring, Ref{Float64}), h, key, v))
+    return v[]
+end
+is_rational(fa::HIPFermiAction) = action_get(fa.h, "rational") != 0
+# the operator's stopping rule may have been changed after the action was made (HIPDirac is mutable)
+solver!(fa::HIPFermiAction) = check(ccall((:lqcd_action_set_solver, LIB), Cint, (Ptr{Cvoid}, Float64, Cint), fa.h, fa.D.eps_CG, fa.D.MaxCGstep))
 # gauss_sampling_in_action!(ξ, U, fa) (standardMD.jl:95): ξ ~ exp(-ξ†ξ), i.e. re and im of variance 1/2
-function gauss_sampling_in_action!(ξ::HIPFermion, U::Vector{HIPLink}, fa::HIPFermiAction; seed = rand(UInt64))
-    check(ccall((:lqcd_spinor_gaussian, LIB), Cint, (Ptr{Cvoid}, UInt64), ξ.h, seed))
-    check(ccall((:lqcd_scale, LIB), Cint, (Float64, Float64, Ptr{Cvoid}), sqrt(0.5), 0.0, ξ.h))
-end
-# sample_pseudofermions!(η, U, fa, ξ) (standardMD.jl:96): η = D†ξ (4 staggered tastes: restricted to the even sites)
+gauss_sampling_in_action!(ξ::HIPFermion, U::Vector{HIPLink}, fa::HIPFermiAction; seed = rand(UInt64)) =
+    check(ccall((:lqcd_action_gauss_sampling, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64), fa.h, ξ.h, seed))
+# sample_pseudofermions!(η, U, fa, ξ) (standardMD.jl:96): η = D†ξ (4 staggered tastes: restricted to the even sites); rational: η = (D†D)^(Nf/2n0) ξ
 function sample_pseudofermions!(η::HIPFermion, U::Vector{HIPLink}, fa::HIPFermiAction, ξ::HIPFermion)
-    mul!(η, fa.D(U)', ξ)
-    if η.kind == STAGGERED && fa.Nf == 4
-        half = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:lqcd_spinor_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint, Cint), η.lat.h, half, η.kind, EVEN))
-        check(ccall((:lqcd_spinor_extract, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), half[], η.h))
-        clear_fermion!(η)
-        check(ccall((:lqcd_spinor_insert, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), η.h, half[]))
-        ccall((:lqcd_spinor_destroy, LIB), Cint, (Ptr{Cvoid},), half[])
-    end
+    solver!(fa)
+    check(ccall((:lqcd_action_sample_pseudofermions, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), fa.h, whole(U).h, η.h, ξ.h))
+    fa.D.U = U
     return η
 end
-# evaluate_FermiAction(fa, U, η) (standardHMC.jl:69,71): S_f = η†(D†D)^-1 η; X = (D†D)^-1 η and Y = D X stay in the action's temporaries
+# evaluate_FermiAction(fa, U, η) (standardHMC.jl:69,71): S_f = η†(D†D)^-1 η or its rational form; X = (D†D)^-1 η and Y = D X stay in the action's temporaries
 function evaluate_FermiAction(fa::HIPFermiAction, U::Vector{HIPLink}, η::HIPFermion)
     S, it = Ref{Float64}(0), Ref{Cint}(0)
-    D = fa.D(U)
     X, Y = fa._temporary_fermionfields
-    check(ccall((:lqcd_fermi_action, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ref{Float64}, Ref{Cint}),
-                D.h, η.h, X.h, Y.h, D.eps_CG, D.MaxCGstep, S, it))
+    solver!(fa)
+    check(ccall((:lqcd_action_evaluate, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}, Ref{Cint}),
+                fa.h, whole(U).h, η.h, X.h, Y.h, S, it))
+    fa.D.U = U
     return S[]
 end
-# calc_UdSfdU!(UdSfdUμ, fa, U, η) (AbstractMD.jl:129) with UdSfdUμ = get_temp(temps, Dim): solve, Y = D X and the outer-product sweep run
+# calc_UdSfdU!(UdSfdUμ, fa, U, η) (AbstractMD.jl:129) with UdSfdUμ = get_temp(temps, Dim): solve(s), Y = D X and the outer-product sweep(s) run
 # resident into fa.force (= G, dS_f/dε[U -> exp(iεT)U] = -2 Im tr(T G)); each direction is handed over as "U dS_f/dU" = -G, the sign
 # the caller's factor = -ϵ Δτ expects (AbstractMD.jl:127-132)
 function calc_UdSfdU!(UdSfdUμ::Vector{HIPLink}, fa::HIPFermiAction, U::Vector{HIPLink}, η::HIPFermion)
-    D = fa.D(U)
     G = whole(fa.force)
-    check(ccall((:lqcd_calc_UdSfdU, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Cint}),
-                D.h, G.h, η.h, D.eps_CG, D.MaxCGstep, C_NULL, C_NULL))
+    solver!(fa)
+    check(ccall((:lqcd_action_force, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Cint}),
+                fa.h, whole(U).h, G.h, η.h, C_NULL, C_NULL))
+    fa.D.U = U
     for μ = 1:4
         check(ccall((:lqcd_link_scaled_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint),
                     getfield(UdSfdUμ[μ], :parent).h, getfield(UdSfdUμ[μ], :slot), -1.0, G.h, μ - 1))
     end
 end
-# general staggered Nf (test/test_Nf2.toml:8, test/test_Nf3.toml:8): rational action, coefficients (a0, res, poles) from the caller
+# the coefficients: fitted by the library (rational_fit), or brought by the caller (e.g. Remez tables) for the building blocks below
+function rational_fit(α, λmin, λmax; tol = 1e-10, max_poles = 40)
+    a0, n, err = Ref{Float64}(0), Ref{Cint}(0), Ref{Float64}(0)
+    res, poles = zeros(max_poles), zeros(max_poles)
+    check(ccall((:lqcd_rational_fit, LIB), Cint, (Float64, Float64, Float64, Float64, Cint, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Cint}, Ref{Float64}),
+                α, λmin, λmax, tol, max_poles, a0, res, poles, n, err))
+    return a0[], res[1:n[]], poles[1:n[]], err[]
+end
+function estimate_spectrum(A::HIPDdagD; steps = 60, seed = 4711)
+    lo, hi = Ref{Float64}(0), Ref{Float64}(0)
+    check(ccall((:lqcd_estimate_spectrum, LIB), Cint, (Ptr{Cvoid}, Cint, UInt64, Ref{Float64}, Ref{Float64}), A.D.h, steps, seed, lo, hi))
+    return lo[], hi[]
+end
 rational_apply!(y::HIPFermion, D::HIPDirac, x::HIPFermion, a0, res::Vector{Float64}, poles::Vector{Float64}) =
     check(ccall((:lqcd_rational_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Ptr{Cint}),
                 D.h, y.h, x.h, a0, length(res), res, poles, D.eps_CG, D.MaxCGstep, C_NULL))

@@ -614,84 +614,74 @@ class FermiAction:
     one multi-shift solve per evaluation (lqcd_rational_apply / lqcd_rational_force).
     Keeps X = (D'D)^-1 eta and Y = D X resident between evaluate_FermiAction and calc_UdSfdU_."""
 
+    _PARAM_KEYS = ("force_rational", "rhmc_lambda_min", "rhmc_lambda_max", "rhmc_tol_action", "rhmc_tol_MD", "rhmc_lanczos_steps")
+
     def __init__(self, D, params=None):
-        kind = D.kind
         params = params or {}
-        nf = params.get("Nf", 2 if kind == WILSON else 4)
         self.D = D
-        self.Nf = nf
-        self.evensite = kind == STAGGERED and nf == 4
-        # D'D carries 2 Wilson flavours / 8 staggered tastes: anything else is S_f = eta' (D'D)^(-Nf/n0) eta
-        n0 = 2 if kind == WILSON else 8
-        # "force_rational": the rational form also where an exact one exists.  The guard below admits 0 < Nf < n0 only, so this is the staggered
-        # Nf = 4 action through partial fractions (Wilson Nf = 2 and staggered Nf = 8 have alpha = 1, the plain inverse: no rational form) --
-        # the statistical cross-check of the rational path against the exact action (tests/test_gpu_hmc_statistics.py)
-        self.rational = (kind == WILSON and nf != 2) or (kind == STAGGERED and nf not in (4, 8)) or bool(params.get("force_rational", False))
-        if self.rational:
-            self.evensite = False
-        if self.rational:
-            if not (0 < nf < n0):
-                raise LQCDError(_l.ERR_UNSUPPORTED, f"FermiAction: Nf = {nf} outside (0, {n0}) for this operator")
-            from . import rational
-            self._explicit_interval = "rhmc_lambda_min" in params and "rhmc_lambda_max" in params
-            self._lanczos_steps = int(params.get("rhmc_lanczos_steps", 60))
-            self._fit_tols = (float(params.get("rhmc_tol_action", 1e-12)), float(params.get("rhmc_tol_MD", 1e-8)))
-            self.interval_refits = 0
-            if self._explicit_interval:
-                lo, hi = float(params["rhmc_lambda_min"]), float(params["rhmc_lambda_max"])
-            elif kind == STAGGERED:       # D'D = m^2 - D_hop^2 with |D_hop| <= 4
-                lo, hi = D.km * D.km * (1.0 - 1e-9), (D.km * D.km + 16.0) * (1.0 + 1e-9)
-            else:                         # Wilson(-clover): no analytic lower bound -- Lanczos estimate on the current links with a margin
-                tmin, tmax = estimate_spectrum(DdagD_operator(D), steps=int(params.get("rhmc_lanczos_steps", 60)))
-                lo, hi = float(params.get("rhmc_lambda_min", 0.5 * tmin)), float(params.get("rhmc_lambda_max", 1.2 * tmax))
-            self.alpha = nf / float(n0)
-            self._fit(lo, hi)
-        self._half = Fermionfields(D.lattice, kind, EVEN) if self.evensite else None
-        self._temporary_fermionfields = [Fermionfields(D.lattice, kind) for _ in range(2)]   # standardMD.jl:50-51
+        keys = [k for k in self._PARAM_KEYS if k in params]
+        ckeys = (C.c_char_p * max(len(keys), 1))(*[k.encode() for k in keys])
+        cvals = (C.c_double * max(len(keys), 1))(*[float(params[k]) for k in keys])
+        h = C.c_void_p()
+        # the whole construction -- which Nf is exact and which is rational, the spectral interval, the three fits -- happens below the C ABI
+        # (csrc/rational.hip lqcd_action_create); the Julia binding makes the same call
+        check(_l.lib().lqcd_action_create(D._h, C.c_double(float(params.get("Nf", 0))), C.c_double(D.eps_CG), int(D.MaxCGstep), len(keys), ckeys, cvals,
+                                          C.byref(h)))
+        self._fa = h
+        self.Nf = self._get("Nf")
+        if self.Nf == int(self.Nf):
+            self.Nf = int(self.Nf)
+        self.rational = bool(self._get("rational"))
+        self.evensite = bool(self._get("evensite"))
+        self.alpha = self._get("alpha")
+        self._temporary_fermionfields = [Fermionfields(D.lattice, D.kind) for _ in range(2)]   # standardMD.jl:50-51
 
-    def _fit(self, lo, hi):
-        from . import rational
-        self.spectral_interval = (lo, hi)
-        tol_a, tol_md = self._fit_tols
+    def _get(self, key):
+        v = C.c_double(0)
+        check(_l.lib().lqcd_action_get(self._fa, key.encode(), C.byref(v)))
+        return v.value
 
-        def fit(alpha, tol):        # wide intervals (small masses) cost digits in double precision: loosen until the fit verifies
-            while True:
-                try:
-                    return rational.inverse_power_partial_fractions(alpha, lo, hi, tol)[:3]
-                except RuntimeError:
-                    if tol > 1e-7:
-                        raise
-                    tol *= 10.0
-        self.rhmc_action = fit(self.alpha, tol_a)                 # x^(-Nf/n0)
-        self.rhmc_MD = fit(self.alpha, tol_md)
-        self.rhmc_sampling = fit(1.0 - 0.5 * self.alpha, tol_a)   # x^(alpha/2) = x * x^(alpha/2 - 1)
+    @property
+    def _h(self):          # the action handle, with the operator's CURRENT stopping rule (D.eps_CG / D.MaxCGstep are plain attributes)
+        check(_l.lib().lqcd_action_set_solver(self._fa, C.c_double(self.D.eps_CG), int(self.D.MaxCGstep)))
+        return self._fa
+
+    def _coeffs(self, which):
+        n, a0 = C.c_int(0), C.c_double(0)
+        check(_l.lib().lqcd_action_coefficients(self._fa, which, None, None, None, 0, C.byref(n), None))
+        res, poles = (C.c_double * n.value)(), (C.c_double * n.value)()
+        check(_l.lib().lqcd_action_coefficients(self._fa, which, C.byref(a0), res, poles, n.value, C.byref(n), None))
+        return a0.value, np.array(res[:]), np.array(poles[:])
+
+    def _set_coeffs(self, which, coeffs):
+        a0, res, poles = coeffs
+        check(_l.lib().lqcd_action_set_coefficients(self._fa, which, C.c_double(a0), len(res), _darr(res), _darr(poles)))
+
+    # (a0, residues, poles) of x^(-Nf/n0) for the action / for the MD force (looser) and of x^(Nf/2n0 - 1) for the heat bath
+    rhmc_action = property(lambda self: self._coeffs(0), lambda self, c: self._set_coeffs(0, c))
+    rhmc_MD = property(lambda self: self._coeffs(1), lambda self, c: self._set_coeffs(1, c))
+    rhmc_sampling = property(lambda self: self._coeffs(2), lambda self, c: self._set_coeffs(2, c))
+
+    @property
+    def spectral_interval(self):
+        return self._get("lambda_min"), self._get("lambda_max")
+
+    @property
+    def interval_refits(self):
+        return int(self._get("interval_refits"))
 
     def check_interval(self, U):
-        """Wilson(-clover) rational action: the spectrum of D'D has no analytic bound and drifts along the HMC stream, and partial
-        fractions used outside their fit interval silently bias S_f, the heat bath and the force.  Called at the heat bath and at
-        every evaluation of the action: a Lanczos run on the CURRENT links.  An interval that came from the estimate (margins 0.5 /
-        1.2 at the fit; the smallest Ritz value converges from above) is refitted as soon as its lower edge exceeds 0.6 x the smallest
-        Ritz value or its upper edge falls below 1.1 x the largest; an interval the caller fixed with rhmc_lambda_min /
-        rhmc_lambda_max raises once a Ritz value lies outside it."""
-        if not (self.rational and self.D.kind == WILSON):
-            return
-        tmin, tmax = estimate_spectrum(DdagD_operator(self.D(U)), steps=self._lanczos_steps)
-        lo, hi = self.spectral_interval
-        if self._explicit_interval:
-            if lo <= tmin and tmax <= hi:
-                return
-            raise LQCDError(_l.ERR_ARG, f"FermiAction: the spectrum of D'D on the current links, Ritz values [{tmin:.3e}, {tmax:.3e}], is not inside "
-                                        f"the fit interval [{lo:.3e}, {hi:.3e}] given by rhmc_lambda_min / rhmc_lambda_max")
-        if lo <= 0.6 * tmin and hi >= 1.1 * tmax:
-            return
-        self._fit(min(lo, 0.4 * tmin), max(hi, 1.25 * tmax))
-        self.interval_refits += 1
+        """Wilson(-clover) rational action: Lanczos on the CURRENT links; an estimated interval that has become too tight is refitted, a Ritz
+        value outside an interval fixed with rhmc_lambda_min / rhmc_lambda_max raises (lqcd_action_check_interval)."""
+        self.D(U)
+        check(_l.lib().lqcd_action_check_interval(self._h))
 
     def close(self):
         for f in self._temporary_fermionfields:
             f.close()
-        if self._half is not None:
-            self._half.close()
+        if self._fa is not None:
+            _l.lib().lqcd_action_destroy(self._fa)
+            self._fa = None
 
 
 def _darr(v):
@@ -700,37 +690,13 @@ def _darr(v):
 
 def estimate_spectrum(A, steps=60, randomseed=4711):
     """Extreme Ritz values (theta_min, theta_max) of the Hermitian positive A = D'D from `steps` Lanczos iterations on the device
-    (scalars on the host): theta_max converges to the largest eigenvalue from below, theta_min to the smallest from above -- use
+    (lqcd_estimate_spectrum): theta_max converges to the largest eigenvalue from below, theta_min to the smallest from above -- use
     them with a margin.  The Wilson rational action takes its fit interval from here when none is given."""
     if not isinstance(A, DdagD_operator):
         raise LQCDError(_l.ERR_ARG, "estimate_spectrum needs a DdagD_operator")
-    lat, kind = A.D.lattice, A.D.kind
-    v, vp, w = Fermionfields(lat, kind), Fermionfields(lat, kind), Fermionfields(lat, kind)
-    gauss_distribution_fermion_(v, randomseed)
-    n0 = np.sqrt(dot(v, v).real)
-    check(_l.lib().lqcd_scale(C.c_double(1.0 / n0), C.c_double(0.0), v._h))
-    clear_fermion_(vp)
-    alphas, betas = [], []
-    beta = 0.0
-    for j in range(steps):
-        mul_(w, A, v)
-        a = dot(v, w).real
-        add_fermion_(w, -a, v)
-        if j:
-            add_fermion_(w, -beta, vp)
-        alphas.append(a)
-        beta = np.sqrt(max(dot(w, w).real, 0.0))
-        if beta < 1e-12 * abs(a) or j == steps - 1:
-            break
-        betas.append(beta)
-        substitute_fermion_(vp, v)
-        substitute_fermion_(v, w)
-        check(_l.lib().lqcd_scale(C.c_double(1.0 / beta), C.c_double(0.0), v._h))
-    T = np.diag(alphas) + np.diag(betas[:len(alphas) - 1], 1) + np.diag(betas[:len(alphas) - 1], -1)
-    th = np.linalg.eigvalsh(T)
-    for f in (v, vp, w):
-        f.close()
-    return float(th[0]), float(th[-1])
+    lo, hi = C.c_double(0), C.c_double(0)
+    check(_l.lib().lqcd_estimate_spectrum(A.D._h, int(steps), C.c_uint64(randomseed), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
 
 
 def _rational_apply(D, y, x, coeffs):
@@ -746,39 +712,25 @@ def gauss_sampling_in_action_(xi, U, fa, randomseed=112):
     """gauss_sampling_in_action!(xi, U, fa) (standardMD.jl:95): xi distributed as exp(-xi'xi), i.e. <|xi_i|^2> = 1 (re and im
     of variance 1/2) -- NOT the unit-variance-per-real-part noise of gauss_distribution_fermion_; with the wrong variance the
     pseudofermion weight is exp(-S_f/2) and the HMC equilibrates to the wrong plaquette (tests/test_gpu_md.py)."""
-    gauss_distribution_fermion_(xi, randomseed)
-    check(_l.lib().lqcd_scale(C.c_double(np.sqrt(0.5)), C.c_double(0.0), xi._h))
+    check(_l.lib().lqcd_action_gauss_sampling(fa._fa, xi._h, C.c_uint64(randomseed)))
     return xi
 
 
 def sample_pseudofermions_(eta, U, fa, xi):
     """sample_pseudofermions!(eta, U, fa, xi) (standardMD.jl:96): eta = D' xi (restricted to the even sites for 4 staggered tastes,
-    in which case the action at the start of a trajectory is evaluate_FermiAction(fa, U, eta), not xi'xi)."""
-    if fa.rational:        # eta = (D'D)^(Nf/16) xi, so that eta' (D'D)^(-Nf/8) eta = xi' xi
-        fa.check_interval(U)
-        D = fa.D(U)
-        _rational_apply(D, fa._temporary_fermionfields[0], xi, fa.rhmc_sampling)
-        mul_(eta, DdagD_operator(D), fa._temporary_fermionfields[0])
-        return eta
-    mul_(eta, fa.D(U).adjoint(), xi)
-    if fa.evensite:
-        extract_fermion_(fa._half, eta)
-        clear_fermion_(eta)
-        insert_fermion_(eta, fa._half)
+    in which case the action at the start of a trajectory is evaluate_FermiAction(fa, U, eta), not xi'xi); rational action:
+    eta = (D'D)^(Nf/2n0) xi, so that eta' (D'D)^(-Nf/n0) eta = xi' xi."""
+    check(_l.lib().lqcd_action_sample_pseudofermions(fa._h, U._h, eta._h, xi._h))
+    fa.D.U = U
     return eta
 
 
 def evaluate_FermiAction(fa, U, eta, return_info=False):
-    """evaluate_FermiAction(fa, U, eta) (standardHMC.jl:71): S_f = eta' (D'D)^-1 eta (CG from a zero guess)."""
-    D = fa.D(U)
+    """evaluate_FermiAction(fa, U, eta) (standardHMC.jl:71): S_f = eta' (D'D)^-1 eta (CG from a zero guess) or its rational form."""
     X, Y = fa._temporary_fermionfields
-    if fa.rational:
-        fa.check_interval(U)
-        it = _rational_apply(D, X, eta, fa.rhmc_action)
-        S = dot(eta, X).real
-        return (S, it) if return_info else S
     S, it = C.c_double(0), C.c_int(0)
-    check(_l.lib().lqcd_fermi_action(D._h, eta._h, X._h, Y._h, C.c_double(D.eps_CG), D.MaxCGstep, C.byref(S), C.byref(it)))
+    check(_l.lib().lqcd_action_evaluate(fa._h, U._h, eta._h, X._h, Y._h, C.byref(S), C.byref(it)))
+    fa.D.U = U
     return (S.value, it.value) if return_info else S.value
 
 
@@ -796,14 +748,10 @@ def calc_UdSfdU_(UdSfdU, fa, U, eta):
         for mu, view in enumerate(UdSfdU):
             check(_l.lib().lqcd_link_scaled_copy(view.field._h, view.slot, C.c_double(-1.0), fa._force_field._h, mu))
         return r
-    D = fa.D(U)
-    if fa.rational:
-        a0, res, poles = fa.rhmc_MD
-        check(_l.lib().lqcd_rational_force(D._h, UdSfdU._h, eta._h, len(res), _darr(res), _darr(poles), C.c_double(D.eps_CG), D.MaxCGstep, None))
-        return None
     S, it = C.c_double(0), C.c_int(0)
-    check(_l.lib().lqcd_calc_UdSfdU(D._h, UdSfdU._h, eta._h, C.c_double(D.eps_CG), D.MaxCGstep, C.byref(S), C.byref(it)))
-    return S.value
+    check(_l.lib().lqcd_action_force(fa._h, U._h, UdSfdU._h, eta._h, C.byref(S), C.byref(it)))
+    fa.D.U = U
+    return None if fa.rational else S.value
 
 
 def fermion_force_(UdSfdU, D, X, Y, scale=1.0, accumulate=False):

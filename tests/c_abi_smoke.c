@@ -3,7 +3,9 @@
  * Built and run by tests/test_gpu_parity.py::test_c_abi_from_plain_c on the GPU box:
  *   gcc -std=c99 -I include tests/c_abi_smoke.c -o /tmp/c_abi_smoke -L latticeqcd.jl_amd/csrc -llqcd_hip -lm
  * Checks, without any oracle: cold-start plaquette = 1, free-field Wilson D on a constant spinor
- * (D psi = (1 - 8 kappa) psi for periodic BC and U = 1), gamma5-hermiticity on a hot start, CG true residual.
+ * (D psi = (1 - 8 kappa) psi for periodic BC and U = 1), gamma5-hermiticity on a hot start, CG true residual; and the reference's general-Nf
+ * staggered action (FermiAction(D, Dict("Nf" => 3)), universe.jl:106-110,138, test/test_Nf3.toml:8) through the action handle alone: the fit
+ * verifies on its interval with the right signs, the heat bath gives S_f = xi^+ xi, the force is finite.
  */
 #include <math.h>
 #include <stdio.h>
@@ -93,6 +95,52 @@ int main(void) {
     /* error path: maxiter too small -> LQCD_ERR_NOT_CONVERGED with a message */
     CHECK(lqcd_spinor_zero(x));
     if (lqcd_solve_cg_DdagD(D, x, b, 1e-19, 2, &iters, &rr) != LQCD_ERR_NOT_CONVERGED) { fprintf(stderr, "expected non-convergence\n"); return 1; }
+
+    /* FermiAction(D, Dict("Nf" => 3)) with the staggered operator of the reference's test_Nf3.toml (mass 0.5): everything through lqcd_action_* */
+    {
+        lqcd_op_t Ds;
+        lqcd_action_t fa;
+        lqcd_spinor_t xi, eta;
+        lqcd_gauge_t G;
+        double v = 0, a0 = 0, res[40], poles[40], err = 0, S = 0, xx = 0, xim = 0;
+        int np = 0;
+        CHECK(lqcd_op_create(ctx, &Ds, LQCD_STAGGERED, U, 0.5, 1.0, bc_apbc));
+        CHECK(lqcd_action_create(Ds, 3.0, 1e-20, 3000, 0, NULL, NULL, &fa));
+        CHECK(lqcd_action_get(fa, "rational", &v));
+        if (v != 1.0) { fprintf(stderr, "Nf = 3 staggered must be the rational action\n"); return 1; }
+        CHECK(lqcd_action_get(fa, "alpha", &v));
+        if (fabs(v - 3.0 / 8.0) > 1e-15) { fprintf(stderr, "alpha %.17g\n", v); return 1; }
+        CHECK(lqcd_action_coefficients(fa, 0, &a0, res, poles, 40, &np, &err));
+        if (!(np >= 6 && np <= 30 && err <= 1e-12 && a0 >= 0)) { fprintf(stderr, "fit: n %d err %.2e a0 %.3e\n", np, err, a0); return 1; }
+        for (int k = 0; k < np; k++)
+            if (!(res[k] > 0 && poles[k] > 0)) { fprintf(stderr, "fit: residue / pole %d has the wrong sign\n", k); return 1; }
+        for (int i = 0; i <= 1000; i++) {       /* x^(-3/8) on [0.25, 16.25] */
+            const double xv = 0.25 * pow(16.25 / 0.25, i / 1000.0);
+            double rv = a0;
+            for (int k = 0; k < np; k++) rv += res[k] / (xv + poles[k]);
+            if (fabs(rv * pow(xv, 0.375) - 1.0) > 1e-11) { fprintf(stderr, "fit off by %.2e at %.4f\n", fabs(rv * pow(xv, 0.375) - 1.0), xv); return 1; }
+        }
+        CHECK(lqcd_spinor_create(ctx, &xi, LQCD_STAGGERED, LQCD_FULL));
+        CHECK(lqcd_spinor_create(ctx, &eta, LQCD_STAGGERED, LQCD_FULL));
+        CHECK(lqcd_gauge_create(ctx, &G));
+        CHECK(lqcd_action_gauss_sampling(fa, xi, 77));
+        CHECK(lqcd_action_sample_pseudofermions(fa, U, eta, xi));
+        CHECK(lqcd_action_evaluate(fa, U, eta, NULL, NULL, &S, NULL));
+        CHECK(lqcd_dot(xi, xi, &xx, &xim));
+        if (fabs(S / xx - 1.0) > 1e-9) { fprintf(stderr, "heat bath: S_f %.15g, xi.xi %.15g\n", S, xx); return 1; }
+        CHECK(lqcd_action_force(fa, U, G, eta, NULL, NULL));
+        /* Nf outside (0, 8) is refused with the reference-style message; Nf = 4 is the exact even-site action */
+        lqcd_action_t bad;
+        if (lqcd_action_create(Ds, 9.0, 1e-20, 3000, 0, NULL, NULL, &bad) != LQCD_ERR_UNSUPPORTED) { fprintf(stderr, "Nf = 9 accepted\n"); return 1; }
+        CHECK(lqcd_action_create(Ds, 4.0, 1e-20, 3000, 0, NULL, NULL, &bad));
+        CHECK(lqcd_action_get(bad, "rational", &v));
+        if (v != 0.0) { fprintf(stderr, "Nf = 4 staggered is an exact action\n"); return 1; }
+        lqcd_action_destroy(bad);
+        lqcd_action_destroy(fa);
+        lqcd_spinor_destroy(xi); lqcd_spinor_destroy(eta);
+        lqcd_gauge_destroy(G);
+        lqcd_op_destroy(Ds);
+    }
 
     printf("C_ABI_OK plaquette=1 free-field maxerr=%.2e CG iters ok true-res=%.2e msg=\"%s\"\n", maxerr, res2, lqcd_last_error());
     free(host); free(out);

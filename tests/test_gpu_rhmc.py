@@ -273,3 +273,64 @@ def test_wilson_rational_interval_follows_the_links(lq, orc):
     lq.evaluate_FermiAction(fixed, U_hot, phi)
     with pytest.raises(lq.LQCDError):
         lq.evaluate_FermiAction(fixed, U_free, phi)
+
+
+@pytest.mark.parametrize("name,km,nf,alpha", [("Staggered", MASS, 2, 2 / 8), ("Staggered", MASS, 3, 3 / 8), ("Staggered", MASS, 1, 1 / 8), ("Wilson", 0.12, 1, 0.5)])
+def test_action_handle_decides_and_fits_below_the_c_abi(lq, orc, name, km, nf, alpha):
+    """FermiAction(D, Dict("Nf" => nf)) (universe.jl:106-110,138; test/test_Nf2.toml:8, test/test_Nf3.toml:8): the library alone -- no host-side
+    numerics of the binding -- classifies the action, chooses the interval and produces coefficients that verify to their tolerance on it with
+    the right signs; the three fits relate as x^(-alpha) (tight, loose) and x^(alpha/2 - 1)."""
+    import ctypes as C
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 861))
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": name, "κ": km, "mass": km, "boundarycondition": BC, "eps_CG": 1e-20})
+    fa = lq.FermiAction(D, {"Nf": nf})
+    assert fa.rational and not fa.evensite and abs(fa.alpha - alpha) < 1e-15 and fa.Nf == nf
+    lo, hi = fa.spectral_interval
+    if name == "Staggered":
+        assert abs(lo / km ** 2 - 1) < 1e-8 and abs(hi / (km ** 2 + 16) - 1) < 1e-8
+    else:
+        tmin, tmax = lq.estimate_spectrum(lq.DdagD_operator(D))
+        assert abs(lo / (0.5 * tmin) - 1) < 1e-12 and abs(hi / (1.2 * tmax) - 1) < 1e-12
+    x = np.exp(np.linspace(np.log(lo), np.log(hi), 9001))
+    for which, (power, tol) in enumerate(((alpha, 1e-12), (alpha, 1e-8), (1 - alpha / 2, 1e-12))):
+        a0, res, poles = (fa.rhmc_action, fa.rhmc_MD, fa.rhmc_sampling)[which]
+        err = C.c_double(0)
+        n = C.c_int(0)
+        lq.lib.check(lq.lib.lib().lqcd_action_coefficients(fa._fa, which, None, None, None, 0, C.byref(n), C.byref(err)))
+        assert n.value == len(poles) and a0 >= 0 and (res > 0).all() and (poles > 0).all()
+        measured = np.abs(lq.rational.evaluate(a0, res, poles, x) * x ** power - 1.0).max()
+        assert measured <= max(tol, 10 * err.value) and err.value <= 1e-10 * (1 if which != 1 else 1e3), (which, measured, err.value)
+    assert len(fa.rhmc_MD[1]) < len(fa.rhmc_action[1])
+    # the same coefficients from the stand-alone export on the same interval
+    a0, res, poles, _ = lq.rational.inverse_power_partial_fractions(alpha, lo, hi, 1e-12)
+    assert len(poles) == len(fa.rhmc_action[1]) and np.allclose(poles, fa.rhmc_action[2], rtol=1e-12) and np.allclose(res, fa.rhmc_action[1], rtol=1e-12)
+    fa.close()
+
+
+def test_action_handle_exact_actions_and_refusals(lq, orc):
+    L = (4, 4, 4, 4)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(orc.hot_gauge(L, 862))
+    Ds = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": MASS, "boundarycondition": BC})
+    Dw = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.12, "boundarycondition": BC})
+    for D, nf, even in ((Ds, 4, True), (Ds, 8, False), (Dw, 2, False)):
+        fa = lq.FermiAction(D, {"Nf": nf})
+        assert not fa.rational and fa.evensite == even and fa.Nf == nf
+        fa.close()
+    assert lq.FermiAction(Ds).Nf == 4 and lq.FermiAction(Dw).Nf == 2              # the reference's defaults when the Dict carries no Nf
+    for D, nf in ((Ds, 9), (Ds, 8.5), (Dw, 3)):
+        with pytest.raises(lq.LQCDError, match="outside"):
+            lq.FermiAction(D, {"Nf": nf})
+    with pytest.raises(lq.LQCDError, match="rhmc_lambda"):
+        lq.FermiAction(Ds, {"Nf": 2, "rhmc_lambda_min": 3.0, "rhmc_lambda_max": 1.0})
+    # an action follows later changes of the operator's stopping rule (D.eps_CG is a plain attribute of the binding)
+    fa = lq.FermiAction(Ds, {"Nf": 8})
+    eta = lq.Fermionfields(lat, lq.STAGGERED)
+    lq.gauss_distribution_fermion_(eta, 863)
+    Ds.MaxCGstep = 2
+    with pytest.raises(lq.NotConverged):
+        lq.evaluate_FermiAction(fa, U, eta)
+    Ds.MaxCGstep = 3000
+    assert lq.evaluate_FermiAction(fa, U, eta) > 0

@@ -212,3 +212,60 @@ def test_binding_has_no_leftovers_of_the_container_type_the_callers_cannot_hold(
     text = binding_text()
     assert not re.search(r"\bHIPGaugefields\b", text), "round 2's mutable struct HIPGaugefields could not be stored in U::Vector{TG} / Uold::Vector{TG}"
     assert "HIPTemporalfields" not in text, "the package's own Temporalfields pool serves get_temp / unused! (it only needs similar(::HIPLink))"
+
+
+def header_prototypes():
+    """name -> number of parameters, for every function declared in include/lqcd_hip.h."""
+    src = open(os.path.join(ROOT, "include", "lqcd_hip.h"), encoding="utf-8").read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(lqcd_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(gen.split_args(args)[0])
+    return protos
+
+
+def test_every_ccall_of_the_binding_names_a_declared_export_with_the_right_number_of_arguments():
+    """The binding cannot run here; what can be checked is that each `ccall((:sym, LIB), Ret, (T1, ..., Tn), a1, ..., an)` names a function
+    include/lqcd_hip.h declares, lists as many argument types as the prototype has parameters and passes as many values."""
+    text = binding_text()
+    protos = header_prototypes()
+    n = 0
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*LIB\)\s*,", text):
+        depth, j = 1, text.index("(", m.start()) + 1
+        while depth:
+            depth += text[j] in "([{"
+            depth -= text[j] in ")]}"
+            j += 1
+        items, _ = gen.split_args(text[text.index("(", m.start()) + 1:j - 1])
+        sym = m.group(1)
+        assert sym in protos, "ccall of %s: not declared in include/lqcd_hip.h" % sym
+        types = items[2].strip()
+        assert types.startswith("(") and types.endswith(")"), (sym, types)
+        inner = types[1:-1].strip().rstrip(",")
+        ntypes = 0 if not inner else len(gen.split_args(inner)[0])
+        assert ntypes == protos[sym], "ccall of %s lists %d argument types, the prototype has %d parameters" % (sym, ntypes, protos[sym])
+        assert len(items) - 3 == ntypes, "ccall of %s passes %d values for %d argument types" % (sym, len(items) - 3, ntypes)
+        n += 1
+    assert n > 60
+
+
+def test_fermi_action_of_any_nf_goes_through_the_library_handle():
+    """universe.jl:106-110 puts p.Nf into the Dict and :138 calls FermiAction(D, parameters_action); the reference's own test_Nf2.toml:8 /
+    test_Nf3.toml:8 (runtests.jl:114-130) pass Nf = 2, 3 with the staggered operator.  The binding must not reject any Nf itself: the decision
+    exact / rational and the coefficients belong to lqcd_action_create; the four generics of the action dispatch to the handle."""
+    text = binding_text()
+    methods = binding_methods(text)
+    fa = [m for m in methods["FermiAction"] if [t for _, t, _ in m["pos"]][:1] == ["HIPDirac"]]
+    assert len(fa) == 1
+    start = text.index("function FermiAction(D::HIPDirac")
+    body = text[start:text.index("\nend", start)]
+    assert "lqcd_action_create" in body and "error(" not in body and '"Nf"' in body
+    for generic, export in (("gauss_sampling_in_action!", "lqcd_action_gauss_sampling"), ("sample_pseudofermions!", "lqcd_action_sample_pseudofermions"),
+                            ("evaluate_FermiAction", "lqcd_action_evaluate"), ("calc_UdSfdU!", "lqcd_action_force")):
+        i = text.index(generic + "(")
+        while "HIPFermiAction" not in text[i:text.index("\n", i)]:
+            i = text.index(generic + "(", i + 1)
+        assert export in text[i:i + 900], generic
+    # no module-level rational-coefficient plumbing is left for the caller to do
+    assert "needs the rational action" not in text
