@@ -255,6 +255,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
+        # max |HIP - oracle| / max |oracle| of D b (default and 18-real kernel instances) and D^+ b on the bench lattice itself
+        out["fullsize_dslash_rel_err"] = out["cpu_baseline"].pop("fullsize_dslash_rel_err", None)
         out["reference_parity"] = reference_parity(lq)
     # The JSON line must be the LAST thing on the job's stdout: RCCL writes its version banner through C stdio at communicator
     # creation, where it would sit in the C buffer until exit -- every rank flushes C stdio right after comm_init and again here.
@@ -390,7 +392,31 @@ def cpu_baseline(lq, U, b, gL):
     t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=0); t_setup = time.perf_counter() - t0
     t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=1); t_one = time.perf_counter() - t0
     per_iter = max(t_one - t_setup, 1e-9)
-    t0 = time.perf_counter(); orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc); t_d = time.perf_counter() - t0
+    t0 = time.perf_counter(); ref_D = orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc); t_d = time.perf_counter() - t0
+    # the oracle's D b at the FULL bench lattice is also the parity check of the kernels this line times: the default (12-real when the links are
+    # unitary) and the all-18-reals instance, and D^+ (all host cores for that one)
+    parity = {}
+    try:
+        lat = U.lattice
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": bc})
+        y = b.similar()
+        scale = float(abs(ref_D).max())
+        recon0 = lat.get_param("gauge_recon")
+        for recon in (recon0, 18):
+            lat.set_param("gauge_recon", recon)
+            lq.mul_(y, D, b)
+            parity["recon%d_active%d" % (recon, lat.get_param("recon_active"))] = float(abs(y.download() - ref_D).max() / scale)
+        lat.set_param("gauge_recon", recon0)
+        orc.set_threads(os.cpu_count() or 1)
+        ref_Dd = orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc, dagger=True)
+        orc.set_threads(1)
+        lq.mul_(y, D.adjoint(), b)
+        parity["dagger"] = float(abs(y.download() - ref_Dd).max() / float(abs(ref_Dd).max()))
+        del ref_Dd
+        y.close()
+    except Exception as e:                                   # secondary: never costs the bench line
+        parity["error"] = str(e)
+    del ref_D
     # the same window with the oracle's OpenMP loops on every host core, reported beside the single-thread figure (the reference's loop is
     # serial: `value` stays the 1-thread number, this one says what the box's cores could do with the same arithmetic)
     ncores = os.cpu_count() or 1
@@ -406,7 +432,8 @@ def cpu_baseline(lq, U, b, gL):
                 "sample": "the same oracle window with OpenMP over all host cores: (time(2 iterations) - time(0)) / 2"}
     return {"value": 1.0 / per_iter, "unit": "iter/s", "cores": 1, "kind": "port",
             "sample": "oracle CG on the same %dx%dx%dx%d configuration: time(1 iteration) - time(0 iterations), 1 thread" % gL,
-            "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / t_d / 1e9, "all_cores": allc, "julia_probe": probe}
+            "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / t_d / 1e9, "all_cores": allc, "julia_probe": probe,
+            "fullsize_dslash_rel_err": parity}
 
 
 def reference_parity(lq):

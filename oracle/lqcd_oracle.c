@@ -872,12 +872,15 @@ void orc_clover_build(double* clovd, const double* Ud, const int L[4], double ka
     const cplx* U = (const cplx*)Ud;
     cplx* clov = (cplx*)clovd;
     long V = vol(L);
-    cplx G[4][4][4], S[4][4];
+    cplx G[4][4][4];
     for (int nu = 0; nu < 4; nu++) gamma_mat(nu, G[nu]);
+    /* sites are independent: threads only split the site loop (same arithmetic per site whatever the thread count) */
+#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(static)
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
             for (int y = 0; y < L[1]; y++)
                 for (int x = 0; x < L[0]; x++) {
+                    cplx S[4][4];
                     int c[4] = {x, y, z, t};
                     long s = site_of(L, x, y, z, t);
                     cplx* A = clov + 144 * s;
@@ -912,6 +915,7 @@ void orc_wilson_clover_D(double* outd, const double* Ud, const double* clovd, co
     cplx* out = (cplx*)outd;
     const cplx* in = (const cplx*)ind;
     const cplx* clov = (const cplx*)clovd;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (long s = 0; s < V; s++) {
         const cplx* A = clov + 144 * s;
         for (int i = 0; i < 12; i++) {

@@ -1,11 +1,120 @@
-"""BASELINE.json's full sizes through size-independent properties (the oracle does not finish these in seconds):
-configs[3] 32^3x64 Wilson-clover and configs[4] 48^3x96 staggered, hot start seed 111."""
+"""BASELINE.json's full sizes: one D and one D^+ per configuration AGAINST THE ORACLE (all host threads: 16^3x32 and 32^3x64 Wilson with the
+12-real and the 18-real kernel instance, the fp32 site-pair kernel, 32^3x64 Wilson-clover, 48^3x96 staggered, the CG solution at 16^3x32), and
+size-independent properties for what the oracle cannot afford (trajectories); hot start seed 111."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
 KAPPA, CSW = 0.141139, 1.0
+BC = (1, 1, 1, -1)
+
+
+@pytest.fixture()
+def orc_all_threads(orc):
+    orc.set_threads(os.cpu_count() or 1)       # the oracle's site loops are OpenMP-parallel: same arithmetic per site whatever the thread count
+    yield orc
+    orc.set_threads(1)
+
+
+@pytest.mark.parametrize("L", [(16, 16, 16, 32), (32, 32, 32, 64)])
+def test_wilson_dslash_matches_oracle_at_baseline_sizes(lq, orc_all_threads, L):
+    """configs[2] / configs[3] lattices, bench seeds: D b and D^+ b of BOTH kernel instances (12-real links, all 18 reals) against the oracle.  A
+    defect that is consistent across the kernel's own variants (index width, the workgroup map at many chunks per plane) cannot hide here."""
+    orc = orc_all_threads
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": BC})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    bh = b.download()
+    y = b.similar()
+    assert lat.get_param("dslash_variant") == 1 and lat.get_param("dslash_pipe") == 2
+    for dagger in (False, True):
+        ref = orc.wilson_D(Uh, bh, L, KAPPA, 1.0, BC, dagger=dagger)
+        for recon, active in ((12, 1), (18, 0)):
+            lat.set_param("gauge_recon", recon)
+            lq.mul_(y, D.adjoint() if dagger else D, b)
+            assert lat.get_param("recon_active") == active           # which instance ran: wilson_dirsplit_s<.,true,.> (12 reals) | wilson_dirsplit<.,false,.>
+            assert rel_err(y.download(), ref) < 1e-13, (L, dagger, recon)
+        lat.set_param("gauge_recon", 12)
+    if L == (32, 32, 32, 64):
+        # the fp32 site-pair kernel of the mixed-precision solvers (pairs sites t and t + T/2: a large-extent defect of that pairing shows here only)
+        ref = orc.wilson_D(Uh, bh, L, KAPPA, 1.0, BC)
+        for dagger in (False, True):
+            if dagger:
+                ref = orc.wilson_D(Uh, bh, L, KAPPA, 1.0, BC, dagger=True)
+            lq.mul_f32_(y, D.adjoint() if dagger else D, b)
+            assert lat.get_param("pair32_active") == 1
+            assert rel_err(y.download(), ref) < 5e-6, dagger
+
+
+def test_cg_solution_matches_oracle_16x16x16x32(lq, orc_all_threads):
+    """configs[2] lattice: the fused CG (D and the update-mode D^+ kernels, deferred x update) against the oracle's plain CG -- solution, iteration
+    count and the true residual."""
+    orc = orc_all_threads
+    L = (16, 16, 16, 32)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": BC, "eps_CG": 1e-19})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    bh = b.download()
+    x = b.similar()
+    it, rr = lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+    xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, Uh, bh, L, KAPPA, 1.0, BC, eps=1e-19)
+    assert st == 0 and rr < 1e-19 and abs(it - ito) <= 1
+    assert rel_err(x.download(), xo) < 1e-9
+    t = orc.wilson_D(Uh, orc.wilson_D(Uh, x.download(), L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True) - bh
+    assert np.vdot(t, t).real < 4e-19                       # the true residual, recomputed by the oracle
+
+
+def test_wilson_clover_dslash_matches_oracle_32x32x32x64(lq, orc_all_threads):
+    """configs[3]: D_sw b and D_sw^+ b (fused A x epilogue, 12-real links) against the oracle's clover term + Wilson D."""
+    orc = orc_all_threads
+    L = (32, 32, 32, 64)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": CSW, "boundarycondition": BC})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    bh = b.download()
+    y = b.similar()
+    A = orc.clover_build(Uh, L, KAPPA, CSW)
+    for dagger in (False, True):
+        lq.mul_(y, D.adjoint() if dagger else D, b)
+        assert lat.get_param("recon_active") == 1 and lat.get_param("clover_fused") == 1
+        assert rel_err(y.download(), orc.wilson_clover_D(Uh, A, bh, L, KAPPA, 1.0, BC, dagger=dagger)) < 1e-13, dagger
+
+
+def test_staggered_dslash_matches_oracle_48x48x48x96(lq, orc_all_threads):
+    """configs[4]: D b and D^+ b at 48^3 x 96 (18 chunks per z-plane: the workgroup map's non-power-of-two branch), 12- and 18-real links."""
+    orc = orc_all_threads
+    L = (48, 48, 48, 96)
+    mass = 0.05
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": mass, "boundarycondition": BC})
+    b = lq.Fermionfields(lat, lq.STAGGERED)
+    lq.gauss_distribution_fermion_(b, 112)
+    bh = b.download()
+    y = b.similar()
+    for dagger in (False, True):
+        ref = orc.staggered_D(Uh, bh, L, mass, BC, dagger=dagger)
+        for recon, active in ((12, 1), (18, 0)):
+            lat.set_param("gauge_recon", recon)
+            lq.mul_(y, D.adjoint() if dagger else D, b)
+            assert lat.get_param("recon_active") == active
+            assert rel_err(y.download(), ref) < 1e-13, (dagger, recon)
+        lat.set_param("gauge_recon", 12)
 
 
 def test_wilson_clover_32x32x32x64_identities(lq):
