@@ -8,7 +8,8 @@ export TMPDIR=/tmp
 case $stage in
   rhmc)       # the action handle, the full-size oracle parity tests and config 3's stopping rule
     timeout 1500 python -m pytest tests/test_gpu_rhmc.py tests/test_gpu_rational.py tests/test_gpu_fullsize.py tests/test_gpu_md_staggered.py tests/test_gpu_md_mixed.py \
-        "tests/test_gpu_parity.py::test_c_abi_from_plain_c" tests/test_gpu_parity.py -k "not variant" -q -x --durations=15 2>&1 | tail -40 > $out/pytest.log
+        tests/test_gpu_mixed.py tests/test_gpu_reference_callers.py -q -x --durations=15 2>&1 | tail -40 > $out/pytest.log
+    timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "evenodd or c_abi or bicgstab or fermi or force" 2>&1 | tail -15 >> $out/pytest.log
     tail -25 $out/pytest.log
     timeout 600 python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; tail -c 1500 $out/bench_n1.json
     ;;
