@@ -4,7 +4,8 @@
 # src/md/AbstractMD.jl:78-135, src/md/standardMD.jl:5-101, src/updates/standardHMC.jl:1-91, src/system/universe.jl:30-143 is listed in
 # tests/golden/ref_caller_inventory.json and checked against this file by tests/test_julia_binding_static.py) but NEVER EXECUTED: there is no Julia
 # in the build image (SURVEY.md section 0.3).  Everything below the `ccall`s is exercised through the same C ABI by tests/ (Python ctypes).
-# The file is deliberately thin: every method is one ccall plus error translation.
+# The file is deliberately thin: every method is one ccall plus error translation; there is NO module-level mutable state (the lazy fusion of the
+# callers' per-direction link-call triples lives below the C ABI, csrc/md.hip).
 #
 # How it plugs in.  The reference has no FFI; its seam is multiple dispatch on types of Gaugefields.jl / LatticeDiracOperators.jl.  This
 # module therefore EXTENDS the packages' own generic functions (`import Gaugefields: substitute_U!, ...`) with methods on device-backed
@@ -44,7 +45,6 @@ const LQCD_ERR_NOT_CONVERGED = Cint(3)
 const WILSON, STAGGERED = Cint(0), Cint(1)
 const FULL, EVEN, ODD = Cint(0), Cint(1), Cint(2)
 const LAYOUT_REFERENCE = Cint(0)
-const VERBOSE_LEVEL = Ref(2)          # println_verbose_level2/3(U[1], ...) print at or above this level (Univ: p.verboselevel)
 
 last_error() = unsafe_string(ccall((:lqcd_last_error, LIB), Cstring, ()))
 function check(st::Cint)
@@ -58,12 +58,14 @@ mutable struct HIPLattice
     L::NTuple{4,Int}
     PEs::NTuple{4,Int}
     rank::Int
+    verbose::Int        # println_verbose_level2/3(U[1], ...) print at or above this level (Univ: p.verboselevel)
+    spare::Any          # the HIPGaugeStorage whose free slots the next temporaries (similar(U[1])) take, or nothing -- per context, not per module
 end
 function HIPLattice(L::NTuple{4,Int}; PEs = (1, 1, 1, 1), rank = 0, device = 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lqcd_ctx_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cint}, Ptr{Cint}, Cint),
                 h, device, Cint[L...], Cint[PEs...], rank))
-    lat = HIPLattice(h[], L, PEs, rank)
+    lat = HIPLattice(h[], L, PEs, rank, 2, nothing)
     finalizer(l -> ccall((:lqcd_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), l.h), lat)
     return lat
 end
@@ -88,10 +90,9 @@ function HIPGaugeStorage(lat::HIPLattice)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lqcd_gauge_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), lat.h, h))
     g = HIPGaugeStorage(h[], lat, 0)
-    finalizer(x -> ccall((:lqcd_gauge_destroy, LIB), Cint, (Ptr{Cvoid},), getfield(x, :h)), g)      # getfield: a finalizer must not trigger the lazy-link flush of `.h`
+    finalizer(x -> ccall((:lqcd_gauge_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), g)      # the library runs recorded link operations that name the field before it frees it
     return g
 end
-const SPARE = Dict{Ptr{Cvoid},HIPGaugeStorage}()     # per context: the storage whose free slots the next temporaries take
 
 # one direction of a gauge field: what the reference calls U[μ], a temporary, dSdUμ, expU, W ...
 struct HIPLink <: AbstractGaugefields{3,4}
@@ -130,89 +131,15 @@ function whole(U::Vector{<:AnyLink})
 end
 views(::Type{T}, g::HIPGaugeStorage) where {T<:AnyLink} = T[T(g, Cint(μ - 1)) for μ = 1:4]
 
-# ---- lazy evaluation of the per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110).
+# ---- the per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110):
 # exptU!(expU, t, p[μ]) -> mul!(W, expU, U[μ]) -> substitute_U!(U[μ], W) and calc_dSdUμ!(dSdUμ, ..) -> mul!(temp1, U[μ], dSdUμ) ->
-# Traceless_antihermitian_add!(p[μ], factor, temp1): the first two calls of a triple are RECORDED, the third launches one fused kernel
-# (lqcd_link_exp_mul, lqcd_link_add_ta_staple), and four completed triples of one update become ONE fused four-direction call (below) --
-# 1 launch per update instead of 12, the callers unchanged.  Anything else that asks a
-# storage for its handle (`.h`: every other ccall of this file) first materialises the record with the plain single-direction calls, so a
-# temporary that IS read holds what the eager call would have put there; the temporaries of a completed triple are never written.
-const LAZY_LINKS = Ref(true)              # false: every call launches its own kernel
-const LAZY = Ref{Any}(nothing)            # the recorded call(s) of the open triple (a NamedTuple) or nothing
-# Completed triples are deferred once more: when the same update has been asked for all four directions (what U_update! / P_update! do) the four
-# become ONE call of the fused four-direction entry point (lqcd_gauge_exp_update / lqcd_momentum_add_gauge_force); otherwise they are launched one
-# by one (run_done) when anything else needs a field.  Entries: (kind = :U, F = storage of U, slot, a = t, G = storage of p, b = 0.0) or
-# (kind = :P, F = storage of p, slot, a = factor, G = storage of U, b = β_inp)
-const DONE = Any[]
-rawh(l::AnyLink) = getfield(getfield(l, :parent), :h)
-rawh(g::HIPGaugeStorage) = getfield(g, :h)
+# Traceless_antihermitian_add!(p[μ], factor, temp1).  Each generic below is ONE stateless ccall (lqcd_link_exp, lqcd_link_mul, lqcd_link_copy,
+# lqcd_link_staple, lqcd_link_add_ta); the LIBRARY records the first two calls of a triple per context, launches one fused kernel at the third and
+# turns four completed triples of one update into one four-direction launch (csrc/md.hip "lazy link triples", tunable lazy_links) -- every other
+# entry point that touches a gauge-shaped field runs what is recorded first.  The temporaries of a completed triple (expU, W, dSdUμ, temp1) are not
+# written; the callers return them to their pool unread.  set_param!(lattice, "lazy_links", 0) makes every call launch its own kernel.
 slotof(l::AnyLink) = getfield(l, :slot)
-samelink(a::AnyLink, b::AnyLink) = getfield(a, :parent) === getfield(b, :parent) && slotof(a) == slotof(b)
-function run_done()
-    d = copy(DONE)
-    empty!(DONE)
-    for r in d
-        if r.kind === :U
-            check(ccall((:lqcd_link_exp_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                        rawh(r.F), r.slot, r.a, rawh(r.G), r.slot, rawh(r.F), r.slot))
-        else
-            check(ccall((:lqcd_link_add_ta_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Float64),
-                        rawh(r.F), r.slot, r.a, rawh(r.G), r.slot, r.b))
-        end
-    end
-    return nothing
-end
-function defer_done(r)
-    if !isempty(DONE)
-        d = DONE[1]
-        if d.kind !== r.kind || d.F !== r.F || d.G !== r.G || d.a != r.a || d.b != r.b || any(e -> e.slot == r.slot, DONE)
-            run_done()
-        end
-    end
-    push!(DONE, r)
-    if length(DONE) == 4
-        empty!(DONE)
-        if r.kind === :U
-            check(ccall((:lqcd_gauge_exp_update, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), rawh(r.F), r.a, rawh(r.G)))
-        else        # factor TA(U (β/2) staples) = (-3 factor) TA(-(β/6) U staples)
-            check(ccall((:lqcd_momentum_add_gauge_force, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64), rawh(r.F), -3 * r.a, rawh(r.G), r.b))
-        end
-    end
-    return nothing
-end
-# a new triple starts: deferred triples of the same kind stay deferred unless the new one writes one of their fields (its temporaries never are)
-function open_triple(kind::Symbol, tmp::HIPGaugeStorage)
-    if LAZY[] !== nothing            # an interrupted triple: everything recorded so far runs, in the order it was asked for
-        flush_links()
-    elseif !isempty(DONE) && (DONE[1].kind !== kind || any(e -> e.F === tmp || e.G === tmp, DONE))
-        run_done()
-    end
-    return nothing
-end
-function flush_links()
-    isempty(DONE) || run_done()
-    z = LAZY[]
-    z === nothing && return nothing
-    LAZY[] = nothing
-    if z.kind === :exp || z.kind === :expmul
-        check(ccall((:lqcd_link_exp, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), rawh(z.E), slotof(z.E), z.t, rawh(z.P), slotof(z.P)))
-        if z.kind === :expmul
-            check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                        rawh(z.W), slotof(z.W), rawh(z.E), slotof(z.E), rawh(z.U), slotof(z.U)))
-        end
-    else
-        check(ccall((:lqcd_link_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), rawh(z.S), slotof(z.S), rawh(z.Ug), z.mu, z.beta))
-        if z.kind === :ustaple
-            check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                        rawh(z.T), slotof(z.T), rawh(z.Ug), z.mu, rawh(z.S), slotof(z.S)))
-        end
-    end
-    return nothing
-end
-function Base.getproperty(g::HIPGaugeStorage, s::Symbol)
-    s === :h && (LAZY[] !== nothing || !isempty(DONE)) && flush_links()      # whoever asks for the handle is about to read or write the field
-    return getfield(g, s)
-end
+hof(l::AnyLink) = getfield(l, :parent).h
 
 # Initialize_Gaugefields(NC, Nwing, L...; condition) (universe.jl:41-49) -> U::Vector{HIPLink}, the value `Univ` stores as U::Vector{TG}
 function Initialize_HIPGaugefields(NC, Nwing, L...; condition = "cold", lattice = nothing, randomseed = 111)::Vector{HIPLink}
@@ -239,18 +166,18 @@ end
 # GaugeAction(U) allocate.  Four temporaries share one device storage.
 function similar(l::HIPLink)::HIPLink
     lat = getfield(l, :parent).lat
-    g = get(SPARE, lat.h, nothing)
+    g = lat.spare
     if g === nothing || g.used >= 4
         g = HIPGaugeStorage(lat)
-        SPARE[lat.h] = g
+        lat.spare = g
     end
     g.used += 1
     return HIPLink(g, Cint(g.used - 1))
 end
 get_myrank(l::AnyLink) = getfield(l, :parent).lat.rank                                   # universe.jl:52
 println_verbose_level1(l::AnyLink, val...) = (get_myrank(l) == 0 && println(val...); nothing)
-println_verbose_level2(l::AnyLink, val...) = (get_myrank(l) == 0 && VERBOSE_LEVEL[] >= 2 && println(val...); nothing)   # standardHMC.jl:75-86
-println_verbose_level3(l::AnyLink, val...) = (get_myrank(l) == 0 && VERBOSE_LEVEL[] >= 3 && println(val...); nothing)   # standardHMC.jl:51,55,63
+println_verbose_level2(l::AnyLink, val...) = (get_myrank(l) == 0 && getfield(l, :parent).lat.verbose >= 2 && println(val...); nothing)   # standardHMC.jl:75-86
+println_verbose_level3(l::AnyLink, val...) = (get_myrank(l) == 0 && getfield(l, :parent).lat.verbose >= 3 && println(val...); nothing)   # standardHMC.jl:51,55,63
 # calc_smearedU(U, md.cov_neural_net) with cov_neural_net = nothing: always reached from update! (standardHMC.jl:67 compares the VALUE
 # nothing with the TYPE Nothing, which is true) -- no smearing, the fermion action sees U itself
 calc_smearedU(U::Vector{HIPLink}, ::Nothing) = (U, nothing, nothing)
@@ -290,57 +217,19 @@ reunitarize!(U::Vector{HIPLink}) = check(ccall((:lqcd_gauge_reunitarize, LIB), C
 function substitute_U!(dst::Vector{HIPLink}, src::Vector{HIPLink})
     check(ccall((:lqcd_gauge_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), whole(dst).h, whole(src).h))
 end
-function substitute_U!(dst::HIPLink, src::HIPLink)
-    z = LAZY[]
-    if z !== nothing && z.kind === :expmul && samelink(src, z.W) && samelink(dst, z.U)
-        LAZY[] = nothing          # U[μ] <- exp(t p[μ]) U[μ] in one pass (in place; projected back onto SU(3) under the tunable md_reunitarize)
-        if slotof(z.P) == slotof(dst)
-            return defer_done((kind = :U, F = getfield(dst, :parent), slot = slotof(dst), a = z.t, G = getfield(z.P, :parent), b = 0.0))      # maybe one of four
-        end
-        return check(ccall((:lqcd_link_exp_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                           rawh(dst), slotof(dst), z.t, rawh(z.P), slotof(z.P), rawh(dst), slotof(dst)))
-    end
-    check(ccall((:lqcd_link_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), getfield(dst, :parent).h, getfield(dst, :slot), getfield(src, :parent).h, getfield(src, :slot)))
-end
+substitute_U!(dst::HIPLink, src::HIPLink) =
+    check(ccall((:lqcd_link_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), hof(dst), slotof(dst), hof(src), slotof(src)))
 # mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUμ) (AbstractMD.jl:92,109)
 function mul!(C::HIPLink, A::HIPLink, B::HIPLink)
-    z = LAZY[]
-    if z !== nothing && z.kind === :exp && samelink(A, z.E) && !samelink(C, z.E)
-        LAZY[] = merge(z, (kind = :expmul, W = C, U = B))            # second call of the U_update! triple
-        return C
-    end
-    if z !== nothing && z.kind === :staple && samelink(B, z.S) && getfield(A, :parent) === z.Ug && slotof(A) == z.mu && !samelink(C, z.S) &&
-       getfield(C, :parent) !== z.Ug
-        LAZY[] = merge(z, (kind = :ustaple, T = C))                   # second call of the P_update! triple
-        return C
-    end
-    check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                getfield(C, :parent).h, getfield(C, :slot), getfield(A, :parent).h, getfield(A, :slot), getfield(B, :parent).h, getfield(B, :slot)))
+    check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), hof(C), slotof(C), hof(A), slotof(A), hof(B), slotof(B)))
     return C
 end
 # exptU!(expU, t, p[mu], [temp1, temp2]) (AbstractMD.jl:91)
-function exptU!(expU::HIPLink, t::Number, p::HIPTALink, temps)
-    if LAZY_LINKS[] && getfield(expU, :parent) !== getfield(p, :parent)
-        open_triple(:U, getfield(expU, :parent))
-        LAZY[] = (kind = :exp, E = expU, t = Float64(t), P = p)       # first call of the U_update! triple: recorded
-        return nothing
-    end
-    check(ccall((:lqcd_link_exp, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), getfield(expU, :parent).h, getfield(expU, :slot), Float64(t), getfield(p, :parent).h, getfield(p, :slot)))
-end
+exptU!(expU::HIPLink, t::Number, p::HIPTALink, temps) =
+    check(ccall((:lqcd_link_exp, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), hof(expU), slotof(expU), Float64(t), hof(p), slotof(p)))
 # Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131)
-function Traceless_antihermitian_add!(p::HIPTALink, factor::Number, G::HIPLink)
-    z = LAZY[]
-    if z !== nothing && z.kind === :ustaple && samelink(G, z.T) && getfield(p, :parent) !== z.Ug && getfield(p, :parent) !== getfield(z.T, :parent) &&
-       getfield(p, :parent) !== getfield(z.S, :parent)
-        LAZY[] = nothing          # p[μ] += factor TA(U[μ] (β/2) staples) in one pass
-        if slotof(p) == z.mu
-            return defer_done((kind = :P, F = getfield(p, :parent), slot = slotof(p), a = Float64(factor), G = z.Ug, b = z.beta))
-        end
-        return check(ccall((:lqcd_link_add_ta_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint, Float64),
-                           rawh(p), slotof(p), Float64(factor), rawh(z.Ug), z.mu, z.beta))
-    end
-    check(ccall((:lqcd_link_add_ta, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), getfield(p, :parent).h, getfield(p, :slot), Float64(factor), getfield(G, :parent).h, getfield(G, :slot)))
-end
+Traceless_antihermitian_add!(p::HIPTALink, factor::Number, G::HIPLink) =
+    check(ccall((:lqcd_link_add_ta, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Cint), hof(p), slotof(p), Float64(factor), hof(G), slotof(G)))
 
 # ---- momenta: initialize_TA_Gaugefields(U) (standardMD.jl:34), gauss_distribution!(md.p) (:86), md.p * md.p (standardHMC.jl:49,59)
 function initialize_TA_Gaugefields(U::Vector{HIPLink})::Vector{HIPTALink}
@@ -367,14 +256,8 @@ function beta_inp(ga::GaugeAction{4,HIPLink})
     return sum(d.β for d in ga.dataset)
 end
 # calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): β_inp * (sum of the staples of U[μ])
-function calc_dSdUμ!(dSdUμ::HIPLink, ga::GaugeAction{4,HIPLink}, μ::Integer, U::Vector{HIPLink})
-    if LAZY_LINKS[] && getfield(dSdUμ, :parent) !== whole(U)
-        open_triple(:P, getfield(dSdUμ, :parent))
-        LAZY[] = (kind = :staple, S = dSdUμ, Ug = whole(U), mu = Cint(μ - 1), beta = Float64(2 * beta_inp(ga)))      # first call of the P_update! triple
-        return nothing
-    end
-    check(ccall((:lqcd_link_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), getfield(dSdUμ, :parent).h, getfield(dSdUμ, :slot), whole(U).h, μ - 1, 2 * beta_inp(ga)))
-end
+calc_dSdUμ!(dSdUμ::HIPLink, ga::GaugeAction{4,HIPLink}, μ::Integer, U::Vector{HIPLink}) =
+    check(ccall((:lqcd_link_staple, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), hof(dSdUμ), slotof(dSdUμ), whole(U).h, μ - 1, 2 * beta_inp(ga)))
 # evaluate_GaugeAction(gauge_action, U) (standardHMC.jl:50,60; S_g = -that / NC): lqcd_gauge_action returns S_g itself
 function evaluate_GaugeAction(ga::GaugeAction{4,HIPLink}, U::Vector{HIPLink})
     s = Ref{Float64}(0)
@@ -448,13 +331,8 @@ function Dirac_operator(U::Vector{HIPLink}, x::HIPFermion, params)
     end
     D = HIPDirac(h[], U, x, false, Float64(get(params, "eps_CG", 1e-19)), Int(get(params, "MaxCGstep", 3000)),
                  String(get(params, "method_CG", "bicgstab")), true)
-    finalizer(d -> getfield(d, :owner) && ccall((:lqcd_op_destroy, LIB), Cint, (Ptr{Cvoid},), getfield(d, :h)), D)
+    finalizer(d -> d.owner && ccall((:lqcd_op_destroy, LIB), Cint, (Ptr{Cvoid},), d.h), D)
     return D
-end
-# an application of the operator reads the links: recorded / deferred lazy link operations (LAZY, DONE) run before its handle is handed out
-function Base.getproperty(D::HIPDirac, s::Symbol)
-    s === :h && (LAZY[] !== nothing || !isempty(DONE)) && flush_links()
-    return getfield(D, s)
 end
 # D(U): rebind links (unusedfiles/measure_chiral_condensate.jl:173)
 function (D::HIPDirac)(U::Vector{HIPLink})
@@ -544,7 +422,7 @@ function FermiAction(D::HIPDirac, parameters_action)
     check(ccall((:lqcd_action_create, LIB), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Cint, Ptr{Cstring}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
                 D.h, Float64(get(parameters_action, "Nf", 0)), D.eps_CG, D.MaxCGstep, length(keys), keys, vals, h))
     fa = HIPFermiAction(h[], D, action_get(h[], "Nf"), [similar(D.x), similar(D.x)], similar(D.U))
-    finalizer(a -> ccall((:lqcd_action_destroy, LIB), Cint, (Ptr{Cvoid},), getfield(a, :h)), fa)
+    finalizer(a -> ccall((:lqcd_action_destroy, LIB), Cint, (Ptr{Cvoid},), a.h), fa)
     return fa
 end
 function action_get(h::Ptr{Cvoid}, key::String)

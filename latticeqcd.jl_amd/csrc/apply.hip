@@ -296,7 +296,7 @@ int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* wh
         set_error(std::string(who) + ": need two distinct FULL spinors of the operator's kind on the operator's context");
         return LQCD_ERR_ARG;
     }
-    return LQCD_OK;
+    return links_flush_of(op);      // the operator reads its links: recorded single-direction link operations run first (md.hip)
 }
 
 int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial, const double* skip_flag) {
@@ -314,6 +314,7 @@ using namespace lqcd;
 
 // ---------------------------------------------------------------------------------- C API: operator
 extern "C" int lqcd_op_create(lqcd_ctx_t ctx, lqcd_op_t* op, int kind, lqcd_gauge_t g, double km, double r, const int bc[4]) {
+    LQCHK(lqcd::links_flush_of(g));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(ctx && op && g && bc, "lqcd_op_create: null argument");
     ARGCHK(kind == LQCD_WILSON || kind == LQCD_STAGGERED, "lqcd_op_create: Dirac_operator not supported");
     ARGCHK(g->ctx == ctx, "lqcd_op_create: gauge field belongs to another context");
@@ -337,6 +338,7 @@ extern "C" int lqcd_op_destroy(lqcd_op_t op) {
 // Dirac_operator = "WilsonClover", Clover_coefficient (parameter_structs.jl:125; test/test_wilsonclover.toml:9): D_sw = D + (A - 1),
 // A = 1 + i kappa c_sw sum_{mu<nu} sigma_{mu nu} F_{mu nu} (clover.hip).  csw = 0 switches the term off again.
 extern "C" int lqcd_op_set_clover(lqcd_op_t op, double csw) {
+    LQCHK(lqcd::links_flush_of(op));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(op, "lqcd_op_set_clover: null argument");
     ARGCHK(op->kind == LQCD_WILSON, "lqcd_op_set_clover: the clover term belongs to the Wilson operator");
     lqcd_ctx_s* c = op->ctx;
@@ -384,6 +386,7 @@ extern "C" int lqcd_op_apply_DdagD(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_
 }
 
 extern "C" int lqcd_op_hop(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger) {
+    LQCHK(lqcd::links_flush_of(op));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(op && out && in && out->ctx == op->ctx && in->ctx == op->ctx && out->kind == op->kind && in->kind == op->kind,
            "lqcd_op_hop: bad arguments");
     ARGCHK((out->subset == LQCD_EVEN && in->subset == LQCD_ODD) || (out->subset == LQCD_ODD && in->subset == LQCD_EVEN),

@@ -174,6 +174,7 @@ extern "C" int lqcd_cg_session_begin(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_
     return LQCD_OK;
 }
 extern "C" int lqcd_cg_session_iterate(lqcd_op_t op, int n) {
+    LQCHK(lqcd::links_flush_of(op));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(op && op->ctx->cg_session && static_cast<CgSession*>(op->ctx->cg_session)->op == op, "lqcd_cg_session_iterate: no open session for this operator");
     CgSession* ses = static_cast<CgSession*>(op->ctx->cg_session);
     for (int i = 0; i < n; i++) LQCHK(cg_enqueue_iteration(op, ses->x, ses->w));

@@ -3,7 +3,7 @@
 #   LQCD_EXTRA_FLAGS="-DLQCD_GAUGE_AOSOA=0" LQCD_OUT=liblqcd_hip_soa.so ./build.sh   builds an A/B variant
 set -e
 cd "$(dirname "$0")"
-ARCH=${LQCD_ARCH:-gfx950}
+ARCH=gfx950      # MI355X only: cg_persist.hip's 72 KiB of static LDS, the MFMA-free fp64 kernels and every tuning constant assume CDNA4
 OUT=${LQCD_OUT:-liblqcd_hip.so}
 BDIR=build/${OUT%.so}
 # LQCD_VARIANTS=1: also build the measured-and-slower Wilson kernel variants 2-8 (stencil_alt.hip, dslash_variant >= 2) -- experiments and their

@@ -10,6 +10,21 @@
 namespace lqcd {
 
 static thread_local std::string g_err;
+// contexts that exist: a gauge-shaped field checks here before it looks at its context's recorded link operations (finalizers run in any order)
+static std::mutex g_live_mu;
+static std::vector<const lqcd_ctx_s*> g_live;
+bool ctx_is_live(const lqcd_ctx_s* c) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (const lqcd_ctx_s* p : g_live)
+        if (p == c) return true;
+    return false;
+}
+static void ctx_set_live(const lqcd_ctx_s* c, bool live) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (size_t i = 0; i < g_live.size(); i++)
+        if (g_live[i] == c) { g_live.erase(g_live.begin() + i); break; }
+    if (live) g_live.push_back(c);
+}
 void set_error(const std::string& msg) { g_err = msg; }
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
@@ -182,8 +197,8 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     HIPCHK(hipMalloc((void**)&c->d_partial, npart * 2 * sizeof(double)));
     HIPCHK(hipMalloc((void**)&c->d_scal, SCAL_DOUBLES * sizeof(double)));
     HIPCHK(hipMemset(c->d_scal, 0, SCAL_DOUBLES * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&c->pipe_ctr, 10 * 32 * sizeof(unsigned)));      // work-queue heads of the persistent stencil kernel: zero between launches
-    HIPCHK(hipMemset(c->pipe_ctr, 0, 10 * 32 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&c->pipe_ctr, PIPE_CTR_WORDS * sizeof(unsigned)));      // work-queue heads of the persistent stencil kernel: zero between launches
+    HIPCHK(hipMemset(c->pipe_ctr, 0, PIPE_CTR_WORDS * sizeof(unsigned)));
     HIPCHK(hipMalloc((void**)&c->cgp_ctr, 9 * 32 * sizeof(unsigned)));
     HIPCHK(hipMemset(c->cgp_ctr, 0, 9 * 32 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&c->h_scal, SCAL_DOUBLES * sizeof(double), hipHostMallocDefault));
@@ -198,12 +213,14 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
         HIPCHK(hipMalloc((void**)&c->recv_bwd[mu], 2 * bytes));
         c->recv_fwd[mu] = c->recv_bwd[mu] + c->halo_elems[mu];
     }
+    ctx_set_live(c, true);
     *out = c;
     return LQCD_OK;
 }
 
 extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     if (!c) return LQCD_OK;
+    ctx_set_live(c, false);      // recorded link operations are dropped with the context: their fields cannot be used without it
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (lqcd_spinor_s* s : c->scratch) { (void)hipFree(s->data); delete s; }
@@ -226,6 +243,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
 
 extern "C" int lqcd_ctx_sync(lqcd_ctx_t c) {
     ARGCHK(c, "lqcd_ctx_sync: null");
+    LQCHK(links_flush_of(c));
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->comm_stream));
@@ -280,6 +298,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "pipe_grid")) return &c->tun.pipe_grid;
     if (!strcmp(key, "pipe_chunks_per_wg")) return &c->tun.pipe_chunks_per_wg;
     if (!strcmp(key, "pipe_min_chunks")) return &c->tun.pipe_min_chunks;
+    if (!strcmp(key, "lazy_links")) return &c->tun.lazy_links;
     return nullptr;
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
@@ -287,11 +306,15 @@ extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
     int* p = param_ptr(c, key);
     ARGCHK(p, std::string("lqcd_ctx_set_param: unknown key ") + key);
     if (!strcmp(key, "dslash_block")) ARGCHK(value == 64 || value == 128 || value == 256, "dslash_block must be 64, 128 or 256");
+    if (!strcmp(key, "lazy_links") && !value) LQCHK(links_flush_of(c));      // switching to eager calls: what is recorded runs now
     *p = value;
     return LQCD_OK;
 }
 extern "C" int lqcd_ctx_get_param(lqcd_ctx_t c, const char* key, int* value) {
     ARGCHK(c && key && value, "lqcd_ctx_get_param: null");
+    // read-only views of the recorded link operations (md.hip): the open triple (0 none, 1 exp, 2 exp + mul, 3 staple, 4 staple + mul), deferred triples
+    if (!strcmp(key, "lazy_open")) { *value = c->lazy.kind; return LQCD_OK; }
+    if (!strcmp(key, "lazy_deferred")) { *value = (int)c->lazy.done.size(); return LQCD_OK; }
     int* p = param_ptr(c, key);
     ARGCHK(p, std::string("lqcd_ctx_get_param: unknown key ") + key);
     *value = *p;
@@ -339,6 +362,7 @@ extern "C" int lqcd_ctx_link_local(lqcd_ctx_t* ctxs, int n) {
 
 // ---------------------------------------------------------------------------------- plaquette (single rank or RCCL ranks)
 extern "C" int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq) {
+    LQCHK(lqcd::links_flush_of(g));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(g && plaq, "lqcd_gauge_plaquette: null");
     lqcd_ctx_s* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));

@@ -54,6 +54,7 @@ __device__ inline cd ld_c(const double2* p) { return mk(ldc(&p->x), ldc(&p->y));
 __device__ inline void st_c(double2* p, cd v) { stc(&p->x, v.re); stc(&p->y, v.im); }
 
 constexpr unsigned long long kSpinLimit = 5000000ull;      // wall_clock64 ticks of 10 ns: 50 ms
+constexpr int kGaveUpWord = 8 * 32;      // ninth 128-B slot of the context's counter block (cgp_ctr): set by any workgroup whose wait ran out, zeroed by the host before a launch
 
 // All workgroups of the launch.  Above 16 workgroups the arrivals are spread over EIGHT counters 128 bytes apart (workgroup b adds to counter
 // b % 8: one memory-side atomic unit serialises ~12 ns per arrival -- 256 arrivals on one word cost 3 us per barrier); lanes 0..7 poll one
@@ -76,6 +77,9 @@ __device__ inline bool grid_sync(unsigned* ctr, unsigned epoch, int nwg) {
         if (wall_clock64() - t0 > kSpinLimit) { ok = 0; break; }
     }
     asm volatile("" ::: "memory");
+    // giving up is GLOBAL: the workgroups that were late still pass this barrier (this one did arrive) and may finish the solve, so the word the
+    // host reads is one any workgroup can raise, not one workgroup's view
+    if (!__builtin_amdgcn_readfirstlane(ok) && lane == 0) __hip_atomic_store(ctr + kGaveUpWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
@@ -292,9 +296,11 @@ __global__ __launch_bounds__(64) void cg_persist_staggered(PersistArgs a) {
         if (lane == 0) stc(a.part + 256 + blockIdx.x, nr);
         ok = grid_sync<SHARD>(a.ctr, ++nbar, a.nexp);
     }
-    if (ok) {       // a solve that gave up leaves x as it found it (the caller repeats it with the launch chain)
+    // The solution goes to the t vector, not to x: whether the solve stands is decided for the whole grid by the host (kGaveUpWord), which then copies
+    // it -- a solve that gave up anywhere leaves x exactly as it found it.  Nobody reads t any more: its last readers (phase B) are behind the last barrier.
+    if (ok) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) st(a.x[p] + own + (size_t)k * Ss, x[k]);
+        for (int k = 0; k < 3; k++) st(a.t[p] + own + (size_t)k * Ss, x[k]);
     }
     if (blockIdx.x == 0 && lane == 0) {
         a.scal[S_RR] = rr;
@@ -314,7 +320,18 @@ bool cg_persist_ok(lqcd_op_s* op) {
     const Geom& g = c->geom;
     if (g.Vh % 64 != 0) return false;
     const int nwg = 2 * (g.Vh / 64);
-    return nwg <= std::min(256, c->num_cu);
+    if (nwg > std::min(256, c->num_cu)) return false;
+    // every workgroup must be resident at once: the kernel's 72 KiB of LDS and its registers, asked of the runtime (once per process and form)
+    static int per_cu[2] = {-1, -1};
+    const int form = nwg > 16 ? 1 : 0;
+    if (per_cu[form] < 0) {
+        int nb = 0;
+        hipError_t e = form ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_persist_staggered<true>, 64, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_persist_staggered<false>, 64, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        per_cu[form] = nb;
+    }
+    return (long long)per_cu[form] * c->num_cu >= nwg;
 }
 
 // The whole solve: r = b - D^+D x, then the iterations, until r.r < eps (eps < 0: exactly maxiter iterations) or maxiter.  The work vectors only
@@ -346,16 +363,21 @@ int cg_persist_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w,
         c->cgp_epoch = 0; c->cgp_nwg = a.nwg;
     }
     a.epoch0 = c->cgp_epoch;
+    HIPCHK(hipMemsetAsync(a.ctr + kGaveUpWord, 0, sizeof(unsigned), c->stream));
     if (a.nwg > 16) hipLaunchKernelGGL(cg_persist_staggered<true>, dim3(a.nwg), dim3(64), 0, c->stream, a);
     else hipLaunchKernelGGL(cg_persist_staggered<false>, dim3(a.nwg), dim3(64), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     c->cgp_nwg = -1;          // until the barrier count of this launch is known the counters cannot be trusted
+    unsigned gave = 1;
     HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&gave, a.ctr + kGaveUpWord, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->h_scal[S_DONE - S_RR] < 0.0) {      // a workgroup waited 50 ms at a synchronisation: not all of them were resident (a busy GPU)
-        *gave_up = true;                       // x is untouched; the caller falls back to the launch chain and stops asking for this form
-        return LQCD_OK;
+    if (gave != 0 || c->h_scal[S_DONE - S_RR] < 0.0) {      // SOME workgroup waited 50 ms at a synchronisation: not all of them were resident (a busy GPU)
+        *gave_up = true;                       // x is untouched (the result of the workgroups that did finish sits in the t vector and is dropped);
+        return LQCD_OK;                        // the caller falls back to the launch chain and stops asking for this form
     }
+    HIPCHK(hipMemcpyAsync(x->data, w.tmp->data, x->elems * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     c->cgp_epoch += (unsigned)c->h_scal[S_PQ - S_RR];
     c->cgp_nwg = a.nwg;
     *rr = c->h_scal[0];

@@ -265,6 +265,7 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
 extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
     if (!g) return LQCD_OK;
     // (no hipSetDevice: the context may already be gone -- finalizers run in any order -- and hipFree does not need it)
+    if (lqcd::ctx_is_live(g->ctx)) (void)lqcd::links_flush_of(g);      // recorded link operations may name this field: they run before its storage goes
     (void)hipFree(g->data);
     (void)hipFree(g->data12);
     delete g;
@@ -273,6 +274,7 @@ extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
 
 static int gauge_xfer(lqcd_gauge_t g, double* host, int layout, int to_device, int wing = 0) {
     ARGCHK(g && host, "gauge upload/download: null argument");
+    LQCHK(lqcd::links_flush_of(g));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(layout == LQCD_LAYOUT_REFERENCE || layout == LQCD_LAYOUT_DISK, "gauge upload/download: bad layout tag");
     ARGCHK(wing >= 0 && wing <= 4 && (wing == 0 || layout == LQCD_LAYOUT_REFERENCE), "gauge upload/download: wings exist in the reference layout only (width 0..4)");
     lqcd_ctx_s* c = g->ctx;
@@ -313,6 +315,7 @@ extern "C" int lqcd_gauge_upload_wing(lqcd_gauge_t g, const double* host, int nw
 extern "C" int lqcd_gauge_download_wing(lqcd_gauge_t g, double* host, int nwing) { return gauge_xfer(g, host, LQCD_LAYOUT_REFERENCE, 0, nwing); }
 
 extern "C" int lqcd_gauge_unit(lqcd_gauge_t g) {
+    LQCHK(lqcd::links_flush_of(g));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(g, "lqcd_gauge_unit: null");
     lqcd_ctx_s* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -326,6 +329,7 @@ extern "C" int lqcd_gauge_unit(lqcd_gauge_t g) {
 }
 
 extern "C" int lqcd_gauge_hot_start(lqcd_gauge_t g, uint64_t seed) {
+    LQCHK(lqcd::links_flush_of(g));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(g, "lqcd_gauge_hot_start: null");
     lqcd_ctx_s* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -399,6 +403,7 @@ extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
 }
 
 extern "C" int lqcd_gauge_unitarity_deviation(lqcd_gauge_t g, double* maxdev) {
+    LQCHK(lqcd::links_flush_of(g));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(g && maxdev, "lqcd_gauge_unitarity_deviation: null argument");
     LQCHK(lqcd::gauge_ensure_recon12(g));      // measured by the pass that builds the 12-real copy (once per version of the field)
     *maxdev = g->recon_dev;

@@ -370,9 +370,40 @@ struct Tunables {
 #else
     int variants_built = 0;   // read-only: dslash_variant >= 2 runs variant 1 (built without -DLQCD_VARIANTS)
 #endif
+    int lazy_links = 1;       // the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,
+                              // lqcd_link_staple -> lqcd_link_mul -> lqcd_link_add_ta) are recorded and run as ONE fused launch each, four completed triples of one
+                              // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel
     int pair32_active = 0;    // read-only: the last mixed-precision solve / lqcd_op_apply_f32 ran the fp32 site-pair kernel
     int recon_active = 0;     // read-only: 1 if the last Wilson operator application used the 12-real links
 };
+
+// Recorded single-direction link operations of one context (md.hip "lazy link triples").  A record holds raw handles: every entry point that
+// reads, writes or destroys a gauge-shaped field runs the records first (links_flush), so none outlives a field it names.
+struct LinkRef {
+    lqcd_gauge_s* g = nullptr;
+    int mu = 0;
+    bool is(const lqcd_gauge_s* h, int m) const { return g == h && mu == m; }
+};
+struct LazyLinks {
+    int kind = 0;               // the open triple: 0 none, 1 exp recorded, 2 exp + mul, 3 staple recorded, 4 staple + mul
+    LinkRef E, P, W, U, S, T;   // expU, p[mu], W, U[mu] of the U_update! triple; dSdUmu, temp1 of the P_update! triple
+    lqcd_gauge_s* Ug = nullptr; // the link field of the staple
+    int mu = 0;
+    double t = 0.0, beta = 0.0;
+    struct Done {               // a completed triple, deferred once more: kind 1 F[slot] <- exp(a G[slot]) F[slot]; kind 2 F[slot] += a TA(G[slot] (b/2) staples)
+        int kind;
+        lqcd_gauge_s* F;
+        int slot;
+        double a;
+        lqcd_gauge_s* G;
+        double b;
+    };
+    std::vector<Done> done;
+    bool busy() const { return kind != 0 || !done.empty(); }
+};
+constexpr int PIPE_CTR_WORDS = 10 * 32;          // the context's counter block (pipe_ctr): 8 per-XCD queue heads + 1 exit counter of the persistent stencil
+constexpr int PIPE_CTR_RED_WORD = 8 * 32 + 16;   // kernel, 128 B apart; two more words of the exit counter's line: the exterior's reduction ticket (stencil.hip) ...
+constexpr int PIPE_CTR_NOTPROJ_WORD = 8 * 32 + 24;   // ... and the "some link was not projected" flag of the link updates (md.hip)
 
 }  // namespace lqcd
 
@@ -422,6 +453,7 @@ struct lqcd_ctx_s {
     lqcd::Tunables tun;
     void* cg_session = nullptr;   // open timing session of lqcd_cg_session_* (ops.hip), if any
     int num_cu = 256;
+    lqcd::LazyLinks lazy;         // recorded single-direction link operations (md.hip)
 };
 
 struct lqcd_gauge_s {
@@ -613,6 +645,13 @@ double2* spinor_block(lqcd_spinor_s* s, int p);
 int gauge_ensure_recon12(lqcd_gauge_s* g);   // (re)builds the 12-real copy if the field changed; sets g->recon_ok
 int plaquette_local_sum(lqcd_gauge_s* g, const double2* const ghost[4], double* sum);
 int gauge_pack_face(lqcd_gauge_s* g, int mu, double2* dst);
+
+// md.hip: run every recorded / deferred single-direction link operation of the context now (no-op when there is none)
+int links_flush(lqcd_ctx_s* c);
+bool ctx_is_live(const lqcd_ctx_s* c);     // capi.hip: finalizers run in any order -- a field may outlive its context
+inline int links_flush_of(lqcd_ctx_s* c) { return (c && c->lazy.busy()) ? links_flush(c) : LQCD_OK; }
+inline int links_flush_of(lqcd_gauge_s* g) { return g ? links_flush_of(g->ctx) : LQCD_OK; }
+inline int links_flush_of(lqcd_op_s* o) { return o ? links_flush_of(o->ctx) : LQCD_OK; }
 
 // scratch spinors
 lqcd_spinor_s* scratch_get(lqcd_ctx_s* c, int kind, int subset);

@@ -643,6 +643,7 @@ static int same_ctx(lqcd_gauge_t a, lqcd_gauge_t b, const char* who) {
 }
 
 extern "C" int lqcd_gauge_copy(lqcd_gauge_t dst, lqcd_gauge_t src) {      // substitute_U!(Uold, U) (standardHMC.jl:45)
+    LQCHK(lqcd::links_flush_of(dst));      // recorded single-direction link operations run first (md.hip)
     LQCHK(same_ctx(dst, src, "lqcd_gauge_copy"));
     lqcd_ctx_s* c = dst->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -655,6 +656,7 @@ extern "C" int lqcd_gauge_copy(lqcd_gauge_t dst, lqcd_gauge_t src) {      // sub
 
 // S_g = -(beta/3) sum_plaq Re tr U_p = -beta * 6 V_global * plaquette
 extern "C" int lqcd_gauge_action(lqcd_gauge_t U, double beta, double* Sg) {
+    LQCHK(lqcd::links_flush_of(U));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(U && Sg, "lqcd_gauge_action: null argument");
     double plaq = 0;
     LQCHK(lqcd_gauge_plaquette(U, &plaq));
@@ -775,14 +777,97 @@ static int link_op(lqcd_gauge_t C, int mc, lqcd_gauge_t A, int ma, lqcd_gauge_t 
     HIPCHK(hipSetDevice(c->device));
     C->version++;
     hipLaunchKernelGGL(link_op_kernel<OP>, dim3(link_grid(c->geom)), dim3(64), 0, c->stream, c->geom, C->data, mc, A->data, ma,
-                       B ? B->data : (const double2*)nullptr, mb, t, c->pipe_ctr + 8 * 32 + 24);
+                       B ? B->data : (const double2*)nullptr, mb, t, c->pipe_ctr + PIPE_CTR_NOTPROJ_WORD);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
 }
-// substitute_U!(U[mu], W) (AbstractMD.jl:93): one direction of dst <- one direction of src (the same field is allowed)
+// ---- lazy link triples.  The reference's unchanged U_update! / P_update! (AbstractMD.jl:89-93, 107-111) update links and momenta one direction at a
+// time through three generics each:
+//     exptU!(expU, t, p[mu]);  mul!(W, expU, U[mu]);  substitute_U!(U[mu], W)                       -> lqcd_link_exp, lqcd_link_mul, lqcd_link_copy
+//     calc_dSdUmu!(dSdUmu, ga, mu, U);  mul!(temp1, U[mu], dSdUmu);  Traceless_antihermitian_add!(p[mu], factor, temp1)
+//                                                                                                  -> lqcd_link_staple, lqcd_link_mul, lqcd_link_add_ta
+// The context RECORDS the first two calls of such a triple and launches ONE fused kernel at the third (link_exp_mul_now / link_add_ta_staple_now);
+// completed triples are deferred once more, and when the same update has been asked for all four directions (what U_update! / P_update! do) the four
+// become ONE launch of the fused four-direction kernel -- 1 launch per update instead of 12, callers and bindings unchanged (one ccall per generic).
+// Every other entry point that reads, writes or destroys a gauge-shaped field (or applies an operator built on one) calls links_flush first, which
+// runs what is recorded with the plain single-direction kernels in the order it was asked for: a temporary that IS read holds what the eager call
+// would have put there.  The temporaries of a COMPLETED fused triple (expU, W / dSdUmu, temp1) are never written -- the reference's callers hand them
+// back to their pool unread (unused!, AbstractMD.jl:95-97,113-117); a caller that does read them sets the tunable lazy_links = 0.
+// In-process PE grids (lqcd_ctx_link_local, tests) run eagerly: their collectives are issued through lqcd_mdom_*.
+static int link_exp_mul_now(lqcd_gauge_t W, int mu_w, double t, lqcd_gauge_t P, int mu_p, lqcd_gauge_t U, int mu_u);
+static int gauge_exp_update_now(lqcd_gauge_t U, double dt, lqcd_gauge_t P);
+static bool lazy_on(lqcd_ctx_s* c) { return c->tun.lazy_links && c->local_peers.empty(); }
+static LinkRef lref(lqcd_gauge_s* g, int mu) { LinkRef r; r.g = g; r.mu = mu; return r; }
+
+static int lazy_run_done(lqcd_ctx_s* c) {
+    std::vector<LazyLinks::Done> d;
+    d.swap(c->lazy.done);
+    for (const LazyLinks::Done& r : d) {
+        if (r.kind == 1) LQCHK(link_exp_mul_now(r.F, r.slot, r.a, r.G, r.slot, r.F, r.slot));
+        else LQCHK(staple_force(r.F, r.G, r.b, r.a, true, r.slot, r.slot, 0.5 * r.b));
+    }
+    return LQCD_OK;
+}
+// a completed triple: one of (up to) four of the same update, or run on its own
+static int lazy_defer(lqcd_ctx_s* c, const LazyLinks::Done& r) {
+    std::vector<LazyLinks::Done>& done = c->lazy.done;
+    if (!done.empty()) {
+        const LazyLinks::Done& d = done[0];
+        bool clash = d.kind != r.kind || d.F != r.F || d.G != r.G || d.a != r.a || d.b != r.b;
+        for (const LazyLinks::Done& e : done) clash = clash || e.slot == r.slot;
+        if (clash) LQCHK(lazy_run_done(c));
+    }
+    done.push_back(r);
+    if (done.size() == 4) {
+        done.clear();
+        if (r.kind == 1) return gauge_exp_update_now(r.F, r.a, r.G);
+        return staple_force(r.F, r.G, r.b, -3.0 * r.a, true);      // factor TA(U (beta/2) staples) = (-3 factor) TA(-(beta/6) U staples)
+    }
+    return LQCD_OK;
+}
+// a new triple starts: an interrupted one runs first; deferred triples of the same kind stay deferred unless the new one writes one of their fields
+static int lazy_open_triple(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* tmp) {
+    if (c->lazy.kind) return links_flush(c);
+    if (!c->lazy.done.empty()) {
+        bool run = c->lazy.done[0].kind != kind;
+        for (const LazyLinks::Done& e : c->lazy.done) run = run || e.F == tmp || e.G == tmp;
+        if (run) return lazy_run_done(c);
+    }
+    return LQCD_OK;
+}
+namespace lqcd {
+int links_flush(lqcd_ctx_s* c) {
+    if (!c->lazy.done.empty()) LQCHK(lazy_run_done(c));
+    LazyLinks z = c->lazy;
+    c->lazy.kind = 0;
+    if (z.kind == 1 || z.kind == 2) {
+        LQCHK(link_op<1>(z.E.g, z.E.mu, z.P.g, z.P.mu, nullptr, 0, z.t));
+        if (z.kind == 2) LQCHK(link_op<2>(z.W.g, z.W.mu, z.E.g, z.E.mu, z.U.g, z.U.mu, 0.0));
+    } else if (z.kind == 3 || z.kind == 4) {
+        LQCHK(staple_force(z.S.g, z.Ug, z.beta, 0.0, false, z.mu, z.S.mu, 0.5 * z.beta));
+        if (z.kind == 4) LQCHK(link_op<2>(z.T.g, z.T.mu, z.Ug, z.mu, z.S.g, z.S.mu, 0.0));
+    }
+    return LQCD_OK;
+}
+}  // namespace lqcd
+
+// substitute_U!(U[mu], W) (AbstractMD.jl:93): one direction of dst <- one direction of src (the same field is allowed).  Third call of the
+// U_update! triple: U[mu] <- exp(t p[mu]) U[mu] in one pass
 extern "C" int lqcd_link_copy(lqcd_gauge_t dst, int mu_dst, lqcd_gauge_t src, int mu_src) {
     LQCHK(link_args(dst, mu_dst, src, mu_src, "lqcd_link_copy"));
+    lqcd_ctx_s* c = dst->ctx;
+    LazyLinks& z = c->lazy;
+    if (z.kind == 2 && z.W.is(src, mu_src) && z.U.is(dst, mu_dst) && z.P.g != dst) {
+        const LazyLinks r = z;
+        z.kind = 0;
+        if (r.P.mu == mu_dst) {      // p[mu] with U[mu]: maybe one of four
+            LazyLinks::Done d = {1, dst, mu_dst, r.t, r.P.g, 0.0};
+            return lazy_defer(c, d);
+        }
+        return link_exp_mul_now(dst, mu_dst, r.t, r.P.g, r.P.mu, dst, mu_dst);
+    }
+    LQCHK(links_flush_of(c));
     if (dst == src && mu_dst == mu_src) return LQCD_OK;
     return link_op<0>(dst, mu_dst, src, mu_src, nullptr, 0, 1.0);
 }
@@ -790,48 +875,89 @@ extern "C" int lqcd_link_copy(lqcd_gauge_t dst, int mu_dst, lqcd_gauge_t src, in
 // (calc_UdSfdU! fills "U dS_f/dU" = -G, P_update_fermion! adds factor = -eps dtau times its TA part: AbstractMD.jl:127-132)
 extern "C" int lqcd_link_scaled_copy(lqcd_gauge_t dst, int mu_dst, double s, lqcd_gauge_t src, int mu_src) {
     LQCHK(link_args(dst, mu_dst, src, mu_src, "lqcd_link_scaled_copy"));
+    LQCHK(links_flush_of(dst));
     return link_op<0>(dst, mu_dst, src, mu_src, nullptr, 0, s);
 }
-// exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): E[mu_e] = exp(t P[mu_p]), the Taylor-Horner series of lqcd_gauge_exp_update
+// exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): E[mu_e] = exp(t P[mu_p]), the Taylor-Horner series of lqcd_gauge_exp_update.  First call of the
+// U_update! triple: recorded
 extern "C" int lqcd_link_exp(lqcd_gauge_t E, int mu_e, double t, lqcd_gauge_t P, int mu_p) {
     LQCHK(link_args(E, mu_e, P, mu_p, "lqcd_link_exp"));
+    lqcd_ctx_s* c = E->ctx;
+    if (lazy_on(c) && E != P) {
+        LQCHK(lazy_open_triple(c, 1, E));      // p[mu] is only read, by this triple and by the deferred ones
+        LazyLinks& z = c->lazy;
+        z.kind = 1; z.E = lref(E, mu_e); z.P = lref(P, mu_p); z.t = t;
+        return LQCD_OK;
+    }
+    LQCHK(links_flush_of(c));
     return link_op<1>(E, mu_e, P, mu_p, nullptr, 0, t);
 }
-// mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): C[mu_c](n) = A[mu_a](n) B[mu_b](n), site by site
+// mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): C[mu_c](n) = A[mu_a](n) B[mu_b](n), site by site.  Second call of
+// either triple: recorded
 extern "C" int lqcd_link_mul(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_gauge_t B, int mu_b) {
     LQCHK(link_args(C, mu_c, A, mu_a, "lqcd_link_mul"));
     LQCHK(link_args(C, mu_c, B, mu_b, "lqcd_link_mul"));
+    lqcd_ctx_s* c = C->ctx;
+    LazyLinks& z = c->lazy;
+    if (z.kind == 1 && z.E.is(A, mu_a) && !z.E.is(C, mu_c) && !z.P.is(C, mu_c)) {
+        z.kind = 2; z.W = lref(C, mu_c); z.U = lref(B, mu_b);
+        return LQCD_OK;
+    }
+    if (z.kind == 3 && z.S.is(B, mu_b) && A == z.Ug && mu_a == z.mu && !z.S.is(C, mu_c) && C != z.Ug) {
+        z.kind = 4; z.T = lref(C, mu_c);
+        return LQCD_OK;
+    }
+    LQCHK(links_flush_of(c));
     return link_op<2>(C, mu_c, A, mu_a, B, mu_b, 0.0);
 }
-// Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131): P[mu_p] += factor * TA(G[mu_g])
+// Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131): P[mu_p] += factor * TA(G[mu_g]).  Third call of the P_update! triple:
+// p[mu] += factor TA(U[mu] (beta/2) staples) in one pass
 extern "C" int lqcd_link_add_ta(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t G, int mu_g) {
     LQCHK(link_args(P, mu_p, G, mu_g, "lqcd_link_add_ta"));
     ARGCHK(!(P == G && mu_p == mu_g), "lqcd_link_add_ta: P and G are the same link field");
+    lqcd_ctx_s* c = P->ctx;
+    LazyLinks& z = c->lazy;
+    if (z.kind == 4 && z.T.is(G, mu_g) && P != z.Ug && P != z.T.g && P != z.S.g) {
+        const LazyLinks r = z;
+        z.kind = 0;
+        if (mu_p == r.mu) {
+            LazyLinks::Done d = {2, P, mu_p, factor, r.Ug, r.beta};
+            return lazy_defer(c, d);
+        }
+        return staple_force(P, r.Ug, r.beta, factor, true, r.mu, mu_p, 0.5 * r.beta);
+    }
+    LQCHK(links_flush_of(c));
     return link_op<3>(P, mu_p, G, mu_g, nullptr, 0, factor);
 }
 // calc_dSdUmu!(dSdUmu, gauge_action, mu, U) (AbstractMD.jl:108) for the plaquette action pushed with coefficient beta/2
 // (universe.jl:92-95): out[mu_out](n) = (beta/2) * sum of the six staples of U_mu(n), so that U_mu(n) out(n) is the plaquette
-// sum whose -1/NC-weighted traceless anti-Hermitian part P_update! adds to p[mu].  Collective on a partitioned lattice.
+// sum whose -1/NC-weighted traceless anti-Hermitian part P_update! adds to p[mu].  Collective on a partitioned lattice.  First call of the
+// P_update! triple: recorded
 extern "C" int lqcd_link_staple(lqcd_gauge_t out, int mu_out, lqcd_gauge_t U, int mu, double beta) {
     LQCHK(link_args(out, mu_out, U, mu, "lqcd_link_staple"));
     ARGCHK(out != U, "lqcd_link_staple: out must not be the link field itself");
+    lqcd_ctx_s* c = out->ctx;
+    if (lazy_on(c)) {
+        LQCHK(lazy_open_triple(c, 2, out));
+        LazyLinks& z = c->lazy;
+        z.kind = 3; z.S = lref(out, mu_out); z.Ug = U; z.mu = mu; z.beta = beta;
+        return LQCD_OK;
+    }
+    LQCHK(links_flush_of(c));
     return staple_force(out, U, beta, 0.0, false, mu, mu_out, 0.5 * beta);
 }
 
 // The three per-direction calls of the reference's U_update! (AbstractMD.jl:91-93) -- exptU!(expU, t, p[mu]); mul!(W, expU, U[mu]);
-// substitute_U!(U[mu], W) -- as ONE pass: W[mu_w] = exp(t P[mu_p]) U[mu_u], W = U allowed (the in-place update of one direction).  The bindings
-// reach it by evaluating those three generics lazily (operators.py, LatticeQCDHIP.jl): no caller changes.  In place and with the tunable
+// substitute_U!(U[mu], W) -- as ONE pass: W[mu_w] = exp(t P[mu_p]) U[mu_u], W = U allowed (the in-place update of one direction).  Reached by
+// the lazy triples above, or directly.  In place and with the tunable
 // md_reunitarize the updated links are projected back onto SU(3) under the rule of lqcd_gauge_exp_update (the field stays "on the group" if it was).
-extern "C" int lqcd_link_exp_mul(lqcd_gauge_t W, int mu_w, double t, lqcd_gauge_t P, int mu_p, lqcd_gauge_t U, int mu_u) {
-    LQCHK(link_args(W, mu_w, P, mu_p, "lqcd_link_exp_mul"));
-    LQCHK(link_args(W, mu_w, U, mu_u, "lqcd_link_exp_mul"));
-    ARGCHK(W != P && U != P, "lqcd_link_exp_mul: the momentum field must be a field of its own");
+static int link_exp_mul_now(lqcd_gauge_t W, int mu_w, double t, lqcd_gauge_t P, int mu_p, lqcd_gauge_t U, int mu_u) {
     lqcd_ctx_s* c = W->ctx;
     const bool inplace = W == U && mu_w == mu_u;
     if (!(inplace && c->tun.md_reunitarize)) return link_op<4>(W, mu_w, P, mu_p, U, mu_u, t);
     HIPCHK(hipSetDevice(c->device));
     const bool was_on_group = U->unitary_version == U->version;
-    unsigned* flag = c->pipe_ctr + 8 * 32 + 24;
+    unsigned* flag = c->pipe_ctr + PIPE_CTR_NOTPROJ_WORD;
     unsigned notproj = 1;
     HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
     U->version++;
@@ -842,24 +968,34 @@ extern "C" int lqcd_link_exp_mul(lqcd_gauge_t W, int mu_w, double t, lqcd_gauge_
     if (was_on_group && !notproj) U->unitary_version = U->version;      // the other three directions were on the group, this one was projected
     return LQCD_OK;
 }
+extern "C" int lqcd_link_exp_mul(lqcd_gauge_t W, int mu_w, double t, lqcd_gauge_t P, int mu_p, lqcd_gauge_t U, int mu_u) {
+    LQCHK(link_args(W, mu_w, P, mu_p, "lqcd_link_exp_mul"));
+    LQCHK(link_args(W, mu_w, U, mu_u, "lqcd_link_exp_mul"));
+    ARGCHK(W != P && U != P, "lqcd_link_exp_mul: the momentum field must be a field of its own");
+    LQCHK(links_flush_of(W));
+    return link_exp_mul_now(W, mu_w, t, P, mu_p, U, mu_u);
+}
 
 // The three per-direction calls of the reference's P_update! (AbstractMD.jl:108-110) -- calc_dSdUmu!(dSdUmu, gauge_action, mu, U);
 // mul!(temp1, U[mu], dSdUmu); Traceless_antihermitian_add!(p[mu], factor, temp1) -- as ONE pass: P[mu_p] += factor * TA(U[mu] * (beta/2) * staples);
-// reached through lazy evaluation in the bindings like lqcd_link_exp_mul
+// reached by the lazy triples above, or directly
 extern "C" int lqcd_link_add_ta_staple(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t U, int mu, double beta) {
     LQCHK(link_args(P, mu_p, U, mu, "lqcd_link_add_ta_staple"));
     ARGCHK(P != U, "lqcd_link_add_ta_staple: the momentum field must not be the link field itself");
+    LQCHK(links_flush_of(P));
     return staple_force(P, U, beta, factor, true, mu, mu_p, 0.5 * beta);
 }
 
 // G_mu(n) = -(beta/6) U_mu(n) * (sum of the six staples)      (calc_dSdUmu! + mul!(temp, U, dSdUmu), AbstractMD.jl:108-110)
 extern "C" int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta) {
+    LQCHK(lqcd::links_flush_of(out));      // recorded single-direction link operations run first (md.hip)
     LQCHK(same_ctx(out, U, "lqcd_gauge_force"));
     return staple_force(out, U, beta, 0.0, false);
 }
 
 // P_update!(U, p, eps, md) (AbstractMD.jl:99-118) in one pass:  P += factor * TA(-(beta/6) U * staples); the force field is never stored
 extern "C" int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta) {
+    LQCHK(lqcd::links_flush_of(P));      // recorded single-direction link operations run first (md.hip)
     LQCHK(same_ctx(P, U, "lqcd_momentum_add_gauge_force"));
     return staple_force(P, U, beta, factor, true);
 }
@@ -903,6 +1039,7 @@ extern "C" int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us
 
 // Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131):  P += factor * TA(G)
 extern "C" int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t G) {
+    LQCHK(lqcd::links_flush_of(P));      // recorded single-direction link operations run first (md.hip)
     LQCHK(same_ctx(P, G, "lqcd_momentum_add_ta"));
     lqcd_ctx_s* c = P->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -916,6 +1053,10 @@ extern "C" int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t 
 // U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U
 extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) {
     LQCHK(same_ctx(U, P, "lqcd_gauge_exp_update"));
+    LQCHK(links_flush_of(U));
+    return gauge_exp_update_now(U, dt, P);
+}
+static int gauge_exp_update_now(lqcd_gauge_t U, double dt, lqcd_gauge_t P) {
     lqcd_ctx_s* c = U->ctx;
     HIPCHK(hipSetDevice(c->device));
     U->version++;
@@ -923,7 +1064,7 @@ extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) 
     // pass (links of a configuration that was never on the group to that precision are left alone).  exp(dt P) U leaves the group only by
     // rounding, but that rounding accumulates: max |row2 - conj(row0 x row1)| passes 1e-14 after ~280 updates (profiles/r03_unitarity_drift.log),
     // i.e. inside the FIRST trajectory, and the 12-real Dslash would be lost for the rest of the run.  0 = the reference's literal U_update!.
-    unsigned* flag = c->pipe_ctr + 8 * 32 + 24;      // a spare word of the counter block
+    unsigned* flag = c->pipe_ctr + PIPE_CTR_NOTPROJ_WORD;      // a spare word of the counter block
     unsigned notproj = 1;
     if (c->tun.md_reunitarize) {
         HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
@@ -939,6 +1080,7 @@ extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) 
 // every link back onto SU(3) (Gram-Schmidt of rows 0, 1; row 2 = conj(row 0 x row 1)): for callers that update links through the
 // single-direction entry points (the reference's own U_update!), once per trajectory keeps the 12-real Dslash path alive
 extern "C" int lqcd_gauge_reunitarize(lqcd_gauge_t U) {
+    LQCHK(lqcd::links_flush_of(U));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(U, "lqcd_gauge_reunitarize: null argument");
     lqcd_ctx_s* c = U->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -952,6 +1094,7 @@ extern "C" int lqcd_gauge_reunitarize(lqcd_gauge_t U) {
 
 // gauss_distribution!(p) (standardMD.jl:86)
 extern "C" int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed) {
+    LQCHK(lqcd::links_flush_of(P));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(P, "lqcd_momentum_gaussian: null argument");
     lqcd_ctx_s* c = P->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -964,6 +1107,7 @@ extern "C" int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed) {
 
 // K = -sum tr P^2  (= md.p * md.p / 2, standardHMC.jl:49); summed over ranks
 extern "C" int lqcd_momentum_action(lqcd_gauge_t P, double* K) {
+    LQCHK(lqcd::links_flush_of(P));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(P && K, "lqcd_momentum_action: null argument");
     lqcd_ctx_s* c = P->ctx;
     HIPCHK(hipSetDevice(c->device));

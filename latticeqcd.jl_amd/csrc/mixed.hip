@@ -476,6 +476,7 @@ using namespace lqcd;
 // reference counterpart): parity tests of the fp32 kernels against the CPU restatement at fp32 accuracy, and their time per application
 // (reps > 0: mean over reps applications between HIP events on the library's stream; 0: one application, no timing).
 extern "C" int lqcd_op_apply_f32(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger, int reps, double* ms) {
+    LQCHK(lqcd::links_flush_of(op));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(op && out && in && out->ctx == op->ctx && in->ctx == op->ctx && out->kind == op->kind && in->kind == op->kind && out->subset == LQCD_FULL &&
                in->subset == LQCD_FULL && out != in && reps >= 0,
            "lqcd_op_apply_f32: need two distinct FULL spinors of the operator's kind on the operator's context");
@@ -509,6 +510,7 @@ extern "C" int lqcd_op_apply_f32(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t 
 // (<= 0 [default of the bindings]: chosen per step, see below).  iters = total fp32 iterations (+ fp64 iterations of the fall-back, if it ran); outer = defect-correction steps.
 extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, double inner_tol, int* iters,
                                          int* outer, double* final_rr) {
+    LQCHK(lqcd::links_flush_of(op));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(op && x && b && x->ctx == op->ctx && b->ctx == op->ctx && x->kind == op->kind && b->kind == op->kind && x->subset == LQCD_FULL &&
                b->subset == LQCD_FULL && x != b && maxiter >= 0,
            "lqcd_solve_mixed_cg_DdagD: need two distinct FULL spinors of the operator's kind on the operator's context");
@@ -612,6 +614,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
 // corrections (+ fp64 iterations of fall-backs); outer: number of fp32 correction solves; final_rr: the largest true residual.
 extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
                                               double eps, int maxiter, double inner_tol, int* iters, int* outer, double* final_rr) {
+    LQCHK(lqcd::links_flush_of(op));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(op && b && ns >= 0 && ns <= 1024 && (ns == 0 || (xs && sigma)) && maxiter >= 0,
            "lqcd_solve_multishift_mixed_cg: null argument or more than 1024 shifts");
     ARGCHK(b->ctx == op->ctx && b->kind == op->kind && b->subset == LQCD_FULL, "lqcd_solve_multishift_mixed_cg: b must be a FULL spinor of the operator");

@@ -341,6 +341,7 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         const bool fr = part && (c->tun.halo_fuse & 1);
         const bool fp = part && defer && (c->tun.halo_fuse & 2) && op->kind == LQCD_WILSON && op->r == 1.0;
         {
+            apply_bc(c, op->bc);      // another operator of this context (other boundary signs) may have been applied since the last iteration of an open session
             StencilCall s1;
             LQCHK(make_full_call(op, w.tmp, pk, 0, s1));
             s1.norm_partial = c->d_partial;
@@ -1056,6 +1057,7 @@ __global__ __launch_bounds__(UB) void ms_update_all(const double* __restrict__ s
 // (for sigma_j >= 0 every |zeta_j| <= 1, so the shifted residuals zeta_j r are then below eps as well).
 extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
                                         double eps, int maxiter, int* iters, double* final_rr) {
+    LQCHK(lqcd::links_flush_of(op));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(op && b && ns >= 0 && ns <= 1024 && (ns == 0 || (xs && sigma)), "lqcd_solve_multishift_cg: null argument or more than 1024 shifts");
     ARGCHK(b->ctx == op->ctx && b->kind == op->kind && b->subset == LQCD_FULL, "lqcd_solve_multishift_cg: b must be a FULL spinor of the operator");
     for (int j = 0; j < ns; j++) {

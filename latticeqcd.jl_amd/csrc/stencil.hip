@@ -1401,7 +1401,7 @@ static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
     h.upd_scal = s.upd_scal;
     h.upd[0] = (real2*)s.upd[0]; h.upd[1] = (real2*)s.upd[1];
     h.red_out = (s.norm_partial && s.red_slot >= 0) ? c->d_scal + s.red_slot : nullptr;
-    h.red_ctr = c->pipe_ctr + 8 * 32 + 16;      // a word of its own next to the persistent kernel's exit counter
+    h.red_ctr = c->pipe_ctr + PIPE_CTR_RED_WORD;      // a word of its own next to the persistent kernel's exit counter
     h.red_n = h.partial_offset + ((max_face_threads(c, s.parity_mode) + 127) / 128) * 8;
     h.pack_next = s.pack_next;
     return h;

@@ -45,65 +45,26 @@ class Lattice:
         self.local_L = tuple(lo)
         self.origin = tuple(org)
         self.nranks = int(np.prod(self.pe))
-        # Lazy evaluation of the per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110): the first two
-        # calls of a triple are recorded here, the third launches ONE fused kernel (lqcd_link_exp_mul / lqcd_link_add_ta_staple); anything else
-        # that touches a gauge-shaped field first materialises the record with the plain single-direction calls (Gaugefields._h).  The callers
-        # stay as they are; the temporaries of a fused triple (expU, W / dSdUmu, temp1) are then never written.  lazy_links = False: eager.
-        # Completed triples are deferred once more: when the same update has been asked for all four directions (what U_update! / P_update! do) the
-        # four become ONE call of the fused four-direction entry point (lqcd_gauge_exp_update / lqcd_momentum_add_gauge_force); otherwise they are
-        # launched one by one when anything else needs a field.
-        self.lazy_links = True
-        self._lazy = None
-        self._done = []
 
-    def _defer(self, rec):
-        """a completed triple: ("U", Ufield, slot, t, Pfield) or ("P", Pfield, slot, factor, Ufield, beta) with p[mu] <-> U[mu]"""
-        d = self._done
-        if d and (d[0][0] != rec[0] or d[0][1] is not rec[1] or d[0][3:] != rec[3:] or any(e[2] == rec[2] for e in d)):
-            self._run_done()
-        self._done.append(rec)
-        if len(self._done) == 4:
-            d, self._done = self._done, []
-            if rec[0] == "U":
-                check(_l.lib().lqcd_gauge_exp_update(rec[1]._hh, C.c_double(rec[3]), rec[4]._hh))
-            else:       # factor TA(U (beta/2) staples) = (-3 factor) TA(-(beta/6) U staples)
-                check(_l.lib().lqcd_momentum_add_gauge_force(rec[1]._hh, C.c_double(-3.0 * rec[3]), rec[4]._hh, C.c_double(rec[5])))
+    # The per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110) are recorded and fused BELOW the C ABI
+    # (csrc/md.hip "lazy link triples", tunable lazy_links); this binding makes one stateless call per generic.  The three attributes below only
+    # expose the library's state to the tests.
+    @property
+    def lazy_links(self):
+        return bool(self.get_param("lazy_links"))
 
-    def _open_triple(self, kind, touched):
-        """a new triple starts: deferred triples of the same kind stay deferred unless this triple writes one of their fields (its temporaries
-        never are)"""
-        if self._lazy is not None:          # an interrupted triple: everything recorded so far runs, in the order it was asked for
-            self._flush_links()
-        elif self._done and (self._done[0][0] != kind or any(f is e[1] or f is e[4] for e in self._done for f in touched)):
-            self._run_done()
+    @lazy_links.setter
+    def lazy_links(self, on):
+        self.set_param("lazy_links", 1 if on else 0)
 
-    def _run_done(self):
-        d, self._done = self._done, []
-        for rec in d:
-            if rec[0] == "U":
-                check(_l.lib().lqcd_link_exp_mul(rec[1]._hh, rec[2], C.c_double(rec[3]), rec[4]._hh, rec[2], rec[1]._hh, rec[2]))
-            else:
-                check(_l.lib().lqcd_link_add_ta_staple(rec[1]._hh, rec[2], C.c_double(rec[3]), rec[4]._hh, rec[2], C.c_double(rec[5])))
+    @property
+    def _lazy(self):
+        k = self.get_param("lazy_open")
+        return None if k == 0 else k
 
-    def _flush_links(self):
-        if self._done:
-            self._run_done()
-        z, self._lazy = self._lazy, None
-        if z is None:
-            return
-        lib = _l.lib()
-        if z["kind"] in ("exp", "expmul"):
-            E, P = z["E"], z["P"]
-            check(lib.lqcd_link_exp(E.field._hh, E.slot, C.c_double(z["t"]), P.field._hh, P.slot))
-            if z["kind"] == "expmul":
-                W, U = z["W"], z["U"]
-                check(lib.lqcd_link_mul(W.field._hh, W.slot, E.field._hh, E.slot, U.field._hh, U.slot))
-        else:
-            S, U = z["S"], z["U"]
-            check(lib.lqcd_link_staple(S.field._hh, S.slot, U._hh, z["mu"], C.c_double(z["beta"])))
-            if z["kind"] == "ustaple":
-                T = z["T"]
-                check(lib.lqcd_link_mul(T.field._hh, T.slot, U._hh, z["mu"], S.field._hh, S.slot))
+    @property
+    def _done(self):
+        return [None] * self.get_param("lazy_deferred")
 
     # -- shapes of the local host arrays
     @property
@@ -166,20 +127,8 @@ class Gaugefields:
     def __init__(self, lattice):
         self.lattice = lattice
         self.NC = 3
-        self._hh = C.c_void_p()
-        check(_l.lib().lqcd_gauge_create(lattice._h, C.byref(self._hh)))
-
-    @property
-    def _h(self):
-        """the C handle; whoever asks for it is about to read or write the field, so a recorded lazy link operation (Lattice._lazy) is
-        materialised first -- only the three fusing functions below go to _hh directly"""
-        if self.lattice._lazy is not None or self.lattice._done:
-            self.lattice._flush_links()
-        return self._hh
-
-    @_h.setter
-    def _h(self, v):
-        self._hh = v
+        self._h = C.c_void_p()
+        check(_l.lib().lqcd_gauge_create(lattice._h, C.byref(self._h)))
 
     def upload(self, U, layout=_l.LAYOUT_REFERENCE, nwing=0):
         """nwing > 0: U has the reference's winged shape (4, NT+2w, NZ+2w, NY+2w, NX+2w, 3, 3) (Nwing of universe.jl:41-49)."""
@@ -222,15 +171,9 @@ class Gaugefields:
         return 2.0 * momentum_action(self)
 
     def close(self):
-        if self._hh:
-            lat = self.lattice
-            z = lat._lazy
-            mine = any(e[1] is self or e[4] is self for e in lat._done) or (
-                z is not None and any(getattr(v, "field", v) is self for v in z.values() if isinstance(v, (LinkView, Gaugefields))))
-            if mine:                   # a recorded lazy link operation involves this field: it runs before the storage goes away
-                lat._flush_links()
-            _l.lib().lqcd_gauge_destroy(self._hh)
-            self._hh = C.c_void_p()
+        if self._h:
+            _l.lib().lqcd_gauge_destroy(self._h)      # recorded link operations that name this field run first (inside the library)
+            self._h = C.c_void_p()
 
     def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
         try:
@@ -413,26 +356,14 @@ class Dirac_operator:
             self.km = float(self.params.get("mass", 0.5))
             self.r = 1.0
         if _share is not None:
-            self._hh, self._owner = _share, False
+            self._h, self._owner = _share, False
         else:
-            self._hh, self._owner = C.c_void_p(), True
-            check(_l.lib().lqcd_op_create(self.lattice._h, C.byref(self._hh), self.kind, U._h, C.c_double(self.km),
+            self._h, self._owner = C.c_void_p(), True
+            check(_l.lib().lqcd_op_create(self.lattice._h, C.byref(self._h), self.kind, U._h, C.c_double(self.km),
                                           C.c_double(self.r), _l.i4(self.bc)))
             if key == "wilsonclover":     # Dirac_operator = "WilsonClover", Clover_coefficient (parameter_structs.jl:125)
                 self.csw = float(self.params.get("Clover_coefficient", 1.5612))
                 check(_l.lib().lqcd_op_set_clover(self._h, C.c_double(self.csw)))
-
-    @property
-    def _h(self):
-        """the operator handle; an application reads the links, so recorded / deferred lazy link operations (Lattice._lazy, _done) run first"""
-        lat = self.lattice
-        if lat._lazy is not None or lat._done:
-            lat._flush_links()
-        return self._hh
-
-    @_h.setter
-    def _h(self, v):
-        self._hh = v
 
     def __call__(self, U):
         check(_l.lib().lqcd_op_set_gauge(self._h, U._h))
@@ -448,9 +379,9 @@ class Dirac_operator:
     H = property(adjoint)
 
     def close(self):
-        if self._owner and self._hh:
-            _l.lib().lqcd_op_destroy(self._hh)
-            self._hh = C.c_void_p()
+        if self._owner and self._h:
+            _l.lib().lqcd_op_destroy(self._h)
+            self._h = C.c_void_p()
 
     def __del__(self):          # the Julia binding registers finalizers (julia/LatticeQCDHIP.jl); same ownership here
         try:
@@ -467,22 +398,9 @@ class DdagD_operator:
         self.eps_CG, self.MaxCGstep = D.eps_CG, D.MaxCGstep
 
 
-def _same_link(a, b):
-    return a.field is b.field and a.slot == b.slot
-
-
 def _mul_links(C_, A, B):
-    """mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): 3x3 products site by site.  Second call of a lazy triple
-    (Lattice._lazy): recorded, not launched."""
-    lat = C_.lattice
-    z = lat._lazy
-    if z is not None and z["kind"] == "exp" and _same_link(A, z["E"]) and not _same_link(C_, z["E"]) and not _same_link(C_, z["P"]):
-        lat._lazy = dict(z, kind="expmul", W=C_, U=B)
-        return C_
-    if z is not None and z["kind"] == "staple" and _same_link(B, z["S"]) and A.field is z["U"] and A.slot == z["mu"] and not _same_link(C_, z["S"]) \
-            and C_.field is not z["U"]:
-        lat._lazy = dict(z, kind="ustaple", T=C_)
-        return C_
+    """mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): 3x3 products site by site (second call of a lazy triple: the
+    library records it, csrc/md.hip)."""
     check(_l.lib().lqcd_link_mul(C_.field._h, C_.slot, A.field._h, A.slot, B.field._h, B.slot))
     return C_
 
@@ -762,19 +680,9 @@ def fermion_force_(UdSfdU, D, X, Y, scale=1.0, accumulate=False):
 
 # ------------------------------------------------------------------------------------ gauge side of the MD step
 def substitute_U_(dst, src):
-    """substitute_U!(Uold, U) (standardHMC.jl:45) on the Vector of link fields, substitute_U!(U[mu], W) (AbstractMD.jl:93) on one."""
+    """substitute_U!(Uold, U) (standardHMC.jl:45) on the Vector of link fields, substitute_U!(U[mu], W) (AbstractMD.jl:93) on one (third call of
+    the U_update! triple: the library turns exptU! -> mul! -> substitute_U! into one pass, csrc/md.hip)."""
     if isinstance(dst, LinkView):
-        lat = dst.lattice
-        z = lat._lazy
-        if z is not None and z["kind"] == "expmul" and _same_link(src, z["W"]) and _same_link(dst, z["U"]):
-            # exptU!(expU, t, p[mu]); mul!(W, expU, U[mu]); substitute_U!(U[mu], W) -> U[mu] <- exp(t p[mu]) U[mu] in one pass
-            lat._lazy = None
-            P = z["P"]
-            if P.slot == dst.slot and isinstance(P.field, Gaugefields):
-                lat._defer(("U", dst.field, dst.slot, z["t"], P.field))       # p[mu] with U[mu]: maybe one of four
-            else:
-                check(_l.lib().lqcd_link_exp_mul(dst.field._hh, dst.slot, C.c_double(z["t"]), P.field._hh, P.slot, dst.field._hh, dst.slot))
-            return dst
         check(_l.lib().lqcd_link_copy(dst.field._h, dst.slot, src.field._h, src.slot))
         return dst
     check(_l.lib().lqcd_gauge_copy(dst._h, src._h))
@@ -856,23 +764,14 @@ def initialize_TA_Gaugefields(U):
 
 
 def exptU_(expU, t, p_mu, temps=None):
-    """exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): expU = exp(t p[mu]) site by site."""
-    lat = expU.lattice
-    if lat.lazy_links and expU.field is not p_mu.field:
-        lat._open_triple("U", (expU.field,))      # p[mu] is only read, by this triple and by the deferred ones
-        lat._lazy = {"kind": "exp", "E": expU, "t": float(t), "P": p_mu}      # first call of the U_update! triple: recorded
-        return expU
+    """exptU!(expU, t, p[mu], temps) (AbstractMD.jl:91): expU = exp(t p[mu]) site by site (first call of the U_update! triple: recorded by the library)."""
     check(_l.lib().lqcd_link_exp(expU.field._h, expU.slot, C.c_double(t), p_mu.field._h, p_mu.slot))
     return expU
 
 
 def calc_dSdUmu_(dSdUmu, gauge_action, mu, U):
-    """calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): beta_inp * (sum of the staples of U[μ]), μ = 1..4."""
-    lat = dSdUmu.lattice
-    if lat.lazy_links and dSdUmu.field is not U:
-        lat._open_triple("P", (dSdUmu.field,))
-        lat._lazy = {"kind": "staple", "S": dSdUmu, "U": U, "mu": int(mu) - 1, "beta": float(gauge_action.beta)}      # first call of the P_update! triple
-        return dSdUmu
+    """calc_dSdUμ!(dSdUμ, gauge_action, μ, U) (AbstractMD.jl:108): beta_inp * (sum of the staples of U[μ]), μ = 1..4 (first call of the P_update!
+    triple: recorded by the library)."""
     check(_l.lib().lqcd_link_staple(dSdUmu.field._h, dSdUmu.slot, U._h, int(mu) - 1, C.c_double(gauge_action.beta)))
     return dSdUmu
 
@@ -895,19 +794,9 @@ def gauge_force_(G, U, beta):
 
 
 def Traceless_antihermitian_add_(p, factor, G):
-    """Traceless_antihermitian_add!(p[mu], factor, temp) (AbstractMD.jl:110,131) on one direction; on whole fields all four at once."""
+    """Traceless_antihermitian_add!(p[mu], factor, temp) (AbstractMD.jl:110,131) on one direction (third call of the P_update! triple: the library
+    runs calc_dSdUmu! -> mul! -> Traceless_antihermitian_add! as one pass); on whole fields all four at once."""
     if isinstance(p, LinkView):
-        lat = p.lattice
-        z = lat._lazy
-        if z is not None and z["kind"] == "ustaple" and _same_link(G, z["T"]) and p.field is not z["U"] and p.field is not z["T"].field \
-                and p.field is not z["S"].field:
-            # calc_dSdUmu!; mul!(temp1, U[mu], dSdUmu); Traceless_antihermitian_add!(p[mu], factor, temp1) -> one pass
-            lat._lazy = None
-            if p.slot == z["mu"]:
-                lat._defer(("P", p.field, p.slot, float(factor), z["U"], z["beta"]))
-            else:
-                check(_l.lib().lqcd_link_add_ta_staple(p.field._hh, p.slot, C.c_double(factor), z["U"]._hh, z["mu"], C.c_double(z["beta"])))
-            return p
         check(_l.lib().lqcd_link_add_ta(p.field._h, p.slot, C.c_double(factor), G.field._h, G.slot))
         return p
     check(_l.lib().lqcd_momentum_add_ta(p._h, C.c_double(factor), G._h))

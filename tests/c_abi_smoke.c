@@ -142,6 +142,52 @@ int main(void) {
         lqcd_op_destroy(Ds);
     }
 
+    /* The reference's U_update! (AbstractMD.jl:89-93) calls exptU! -> mul! -> substitute_U! per direction: the library records the first two and
+     * fuses at the third (tunable lazy_links).  An INTERRUPTED triple -- the temporary is read in between -- must hold what the eager calls put
+     * there, and a completed one must update the links like the eager sequence. */
+    {
+        lqcd_gauge_t P, T1, T2, Ua, Ub;
+        const long ng = 4L * V * 9;
+        double* g1 = (double*)malloc(sizeof(double) * 2 * ng);
+        double* g2 = (double*)malloc(sizeof(double) * 2 * ng);
+        int open = -1, deferred = -1;
+        CHECK(lqcd_gauge_create(ctx, &P)); CHECK(lqcd_gauge_create(ctx, &T1)); CHECK(lqcd_gauge_create(ctx, &T2));
+        CHECK(lqcd_gauge_create(ctx, &Ua)); CHECK(lqcd_gauge_create(ctx, &Ub));
+        CHECK(lqcd_momentum_gaussian(P, 9));
+        CHECK(lqcd_gauge_copy(Ua, U)); CHECK(lqcd_gauge_copy(Ub, U));
+        CHECK(lqcd_gauge_unit(T1)); CHECK(lqcd_gauge_unit(T2));
+        CHECK(lqcd_link_exp(T1, 0, 0.3, P, 1));                       /* recorded */
+        CHECK(lqcd_ctx_get_param(ctx, "lazy_open", &open));
+        if (open != 1) { fprintf(stderr, "lqcd_link_exp was not recorded (lazy_open = %d)\n", open); return 1; }
+        CHECK(lqcd_link_mul(T1, 1, T1, 0, Ua, 2));                    /* recorded: W = expU U[2] */
+        CHECK(lqcd_gauge_download(T1, g1, LQCD_LAYOUT_REFERENCE));    /* interruption: both run now, in order */
+        CHECK(lqcd_ctx_get_param(ctx, "lazy_open", &open));
+        if (open != 0) { fprintf(stderr, "reading a temporary did not flush the record\n"); return 1; }
+        CHECK(lqcd_ctx_set_param(ctx, "lazy_links", 0));
+        CHECK(lqcd_link_exp(T2, 0, 0.3, P, 1));
+        CHECK(lqcd_link_mul(T2, 1, T2, 0, Ub, 2));
+        CHECK(lqcd_gauge_download(T2, g2, LQCD_LAYOUT_REFERENCE));
+        for (long i = 0; i < 2 * ng; i++)
+            if (g1[i] != g2[i]) { fprintf(stderr, "interrupted triple differs from the eager calls at %ld\n", i); return 1; }
+        /* three directions eagerly on Ub; lazily on Ua (deferred, waiting for a fourth), then the plaquette asks for Ua: they run */
+        for (int mu = 0; mu < 3; mu++) {
+            CHECK(lqcd_link_exp(T2, 0, 0.1, P, mu)); CHECK(lqcd_link_mul(T2, 1, T2, 0, Ub, mu)); CHECK(lqcd_link_copy(Ub, mu, T2, 1));
+        }
+        CHECK(lqcd_ctx_set_param(ctx, "lazy_links", 1));
+        for (int mu = 0; mu < 3; mu++) {
+            CHECK(lqcd_link_exp(T1, 0, 0.1, P, mu)); CHECK(lqcd_link_mul(T1, 1, T1, 0, Ua, mu)); CHECK(lqcd_link_copy(Ua, mu, T1, 1));
+        }
+        CHECK(lqcd_ctx_get_param(ctx, "lazy_deferred", &deferred));
+        if (deferred != 3) { fprintf(stderr, "expected three deferred triples, found %d\n", deferred); return 1; }
+        double pa = 0, pb = 0;
+        CHECK(lqcd_gauge_plaquette(Ua, &pa));
+        CHECK(lqcd_gauge_plaquette(Ub, &pb));
+        CHECK(lqcd_ctx_get_param(ctx, "lazy_deferred", &deferred));
+        if (deferred != 0 || fabs(pa - pb) > 1e-13) { fprintf(stderr, "deferred triples: %d left, plaquettes %.16g vs %.16g\n", deferred, pa, pb); return 1; }
+        free(g1); free(g2);
+        lqcd_gauge_destroy(P); lqcd_gauge_destroy(T1); lqcd_gauge_destroy(T2); lqcd_gauge_destroy(Ua); lqcd_gauge_destroy(Ub);
+    }
+
     printf("C_ABI_OK plaquette=1 free-field maxerr=%.2e CG iters ok true-res=%.2e msg=\"%s\"\n", maxerr, res2, lqcd_last_error());
     free(host); free(out);
     lqcd_op_destroy(D);
