@@ -3,6 +3,7 @@
 // rank = px + PX*(py + PY*(pz + PZ*pt)); one process (one context) per GPU.
 #include "lqcd_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -340,11 +341,29 @@ extern "C" int lqcd_ctx_comm_init(lqcd_ctx_t c, const unsigned char id[256], int
     ARGCHK(nranks == c->nranks, "lqcd_ctx_comm_init: nranks does not match the PE grid");
     ARGCHK(!c->has_comm, "lqcd_ctx_comm_init: communicator already initialised");
     HIPCHK(hipSetDevice(c->device));
+    // The first thing a multi-GPU run does with the fabric.  A failure here must say WHO failed and WHAT RCCL said: the message goes to
+    // lqcd_last_error() and, because a job with a dead rank usually never gets to print it, to stderr as well.
+    auto fail = [&](const char* which, ncclResult_t e) {
+        char pci[32] = "?";
+        (void)hipDeviceGetPCIBusId(pci, sizeof pci, c->device);
+        const char* detail = ncclGetLastError(nullptr);
+        std::string msg = std::string("lqcd_ctx_comm_init: ncclCommInitRank (") + which + " communicator) failed on rank " + std::to_string(c->rank) + " of " +
+                          std::to_string(nranks) + ", PE grid " + std::to_string(c->pe[0]) + "x" + std::to_string(c->pe[1]) + "x" + std::to_string(c->pe[2]) + "x" +
+                          std::to_string(c->pe[3]) + ", HIP device " + std::to_string(c->device) + " (" + pci + "): " + ncclGetErrorString(e) +
+                          (detail && *detail ? std::string(" -- ") + detail : std::string("")) +
+                          "; check that every rank got the SAME 256-byte id from rank 0, one rank per GPU, and HSA_ENABLE_IPC_MODE_LEGACY=0";
+        fprintf(stderr, "%s\n", msg.c_str());
+        fflush(stderr);
+        set_error(msg);
+        return LQCD_ERR_COMM;
+    };
     ncclUniqueId u;
     memcpy(&u, id, 128);
-    NCCLCHK(ncclCommInitRank(&c->comm, nranks, u, c->rank));
+    ncclResult_t e = ncclCommInitRank(&c->comm, nranks, u, c->rank);
+    if (e != ncclSuccess) return fail("halo", e);
     memcpy(&u, id + 128, 128);
-    NCCLCHK(ncclCommInitRank(&c->comm_red, nranks, u, c->rank));
+    e = ncclCommInitRank(&c->comm_red, nranks, u, c->rank);
+    if (e != ncclSuccess) { ncclCommDestroy(c->comm); c->comm = nullptr; return fail("reduction", e); }
     c->has_comm = true;
     return LQCD_OK;
 }

@@ -220,13 +220,20 @@ def test_single_direction_entry_points_match_the_fused_ones(lq, orc):
     assert abs(P1 * P1 / 2 - lq.momentum_action(P1)) < 1e-9
 
 
-def test_transliterated_reference_callers_reproduce_the_fused_trajectory(lq):
+@pytest.mark.parametrize("reunit,lazy", [(1, 1), (0, 1), (0, 0)])
+def test_transliterated_reference_callers_reproduce_the_fused_trajectory(lq, reunit, lazy):
     """update!(::StandardHMC) exactly as the reference wrote it, on U[mu] / p[mu], against DeviceHMC (fused kernels): same seeds,
-    same momenta and noise, so the trajectories must agree to rounding (1e-12 on the links, 1e-9 on dH)."""
+    same momenta and noise, so the trajectories must agree to rounding (1e-12 on the links, 1e-9 on dH).  md_reunitarize = 0 is the reference's
+    LITERAL link update exp(t p) U (no projection anywhere), lazy_links = 0 its literal call sequence (every generic its own kernel): the defaults
+    (projection of on-group links inside the update pass, fused triples) are optimisations of THIS path and must not be the only one covered."""
     L, Uh = _fixture(lq)
     dtau, mdsteps, nsw, seed = 0.05, 20, 10, 1234
-    Ua = lq.Gaugefields(lq.Lattice(L)).upload(Uh)
-    Ub = lq.Gaugefields(lq.Lattice(L)).upload(Uh)
+    lata, latb = lq.Lattice(L), lq.Lattice(L)
+    for lat in (lata, latb):
+        lat.set_param("md_reunitarize", reunit)
+    latb.set_param("lazy_links", lazy)
+    Ua = lq.Gaugefields(lata).upload(Uh)
+    Ub = lq.Gaugefields(latb).upload(Uh)
     fused = DeviceHMC(lq, Ua, KAPPA, BETA, dtau, mdsteps, nsw, seed)
     gauge_action, fermi_action = _universe(lq, Ub, KAPPA, BETA)
     hmc = StandardHMC(lq, Ub, gauge_action, False, dtau, mdsteps, fermi_action, SextonWeingargten=True, Nsw=nsw, seed=seed)
