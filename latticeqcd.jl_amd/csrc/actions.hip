@@ -37,10 +37,34 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
         LQCHK(blas_norm2(c, eta->data + eta->elems / 2, eta->elems / 2, &odd2, true));
         even_only = odd2 == 0.0;
     }
+    bool have_Y = false;
     if (even_only) LQCHK(lqcd_solve_cg_DdagD_parity(op, X, eta, 0, eps, maxiter, iters, nullptr));
     else if (c->tun.mixed_action_solver) LQCHK(lqcd_solve_mixed_cg_DdagD(op, X, eta, eps, maxiter, 0.0, iters, nullptr, nullptr));
-    else LQCHK(cg_run(op, X, eta, eps, maxiter, false, iters, nullptr));
-    if (Y) LQCHK(op_apply_async(op, Y, X, 0, nullptr));
+    else {
+        // Wilson(-clover), tunable action_eo_solver: X = (D^+D)^-1 eta as TWO even-odd preconditioned BiCGStab solves, Y = D^-+ eta and X = D^-1 Y --
+        // the Schur complement converges in a fraction of the normal equations' iterations (32^3x64 hot start: 2 x ~13 iterations of 2 Dslash
+        // against 75 of 2), and Y = D X, which the force needs anyway, comes out of the first solve.  The reference's stopping rule is kept for the
+        // system it states it for: with |eta - D^+ Y|^2 < eps/4 and |Y - D X|^2 < eps / (4 |D|^2), |D| <= 1 + 8 kappa (+ 6 kappa c_sw),
+        // |eta - D^+D X| <= |eta - D^+ Y| + |D^+| |Y - D X| < sqrt(eps).  A BiCGStab that breaks down or stalls falls back to the CG.
+        lqcd_spinor_s* Yw = Y;
+        const bool try_eo = op->kind == LQCD_WILSON && c->tun.action_eo_solver && c->local_peers.empty();
+        if (try_eo && !Yw) Yw = scratch_get(c, op->kind, LQCD_FULL);
+        int st = LQCD_ERR_NOT_CONVERGED, it1 = 0, it2 = 0;
+        if (try_eo && Yw) {
+            const double nD = 1.0 + 8.0 * std::fabs(op->km) + (op->csw != 0.0 ? 6.0 * std::fabs(op->km * op->csw) : 0.0);
+            HIPCHK(hipMemsetAsync(Yw->data, 0, Yw->elems * sizeof(double2), c->stream));
+            st = lqcd_solve_bicgstab_eo(op, Yw, eta, 1, 0.25 * eps, maxiter, &it1, nullptr);
+            if (st == LQCD_OK) st = lqcd_solve_bicgstab_eo(op, X, Yw, 0, 0.25 * eps / (nD * nD), maxiter, &it2, nullptr);
+            if (st != LQCD_OK && st != LQCD_ERR_NOT_CONVERGED) { if (Yw != Y) scratch_put(Yw); return st; }
+        }
+        if (Yw && Yw != Y) scratch_put(Yw);
+        if (st == LQCD_OK) { have_Y = Y != nullptr; if (iters) *iters = it1 + it2; }
+        else {
+            HIPCHK(hipMemsetAsync(X->data, 0, X->elems * sizeof(double2), c->stream));
+            LQCHK(cg_run(op, X, eta, eps, maxiter, false, iters, nullptr));
+        }
+    }
+    if (Y && !have_Y) LQCHK(op_apply_async(op, Y, X, 0, nullptr));
     double re = 0, im = 0;
     LQCHK(blas_dot(c, eta->data, X->data, eta->elems, &re, &im, true));
     if (Sf) *Sf = re;

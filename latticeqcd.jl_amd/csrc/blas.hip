@@ -64,33 +64,43 @@ __device__ inline void cg_scalar_step(double* s, int op) {
         // 6 iters++, convergence / breakdown, beta = (rho'/rho)(alpha/omega), rho = rho'
         if (s[B_DONE] != 0.0) return;
         if (op == 3) {
-            const double ar = s[B_RHO], ai = s[B_RHO + 1], br = s[B_R0V], bi = s[B_R0V + 1], d = br * br + bi * bi;
-            s[B_ALPHA] = (ar * br + ai * bi) / d;
-            s[B_ALPHA + 1] = (ai * br - ar * bi) / d;
+            c2 rho = {s[B_RHO], s[B_RHO + 1]}, r0v = {s[B_R0V], s[B_R0V + 1]};
+            const c2 a = bicg_alpha(rho, r0v);
+            s[B_ALPHA] = a.re;
+            s[B_ALPHA + 1] = a.im;
         } else if (op == 4) {
             s[B_HALF] = (s[B_SS] < s[B_EPS]) ? 1.0 : 0.0;
         } else if (op == 5) {
-            if (s[B_HALF] != 0.0) { s[B_OMEGA] = 0.0; s[B_OMEGA + 1] = 0.0; }   // x += alpha p only, r = s
-            else { s[B_OMEGA] = s[B_TS] / s[B_TT]; s[B_OMEGA + 1] = s[B_TS + 1] / s[B_TT]; }
+            c2 ts = {s[B_TS], s[B_TS + 1]};
+            const c2 w = bicg_omega(ts, s[B_TT], s[B_HALF] != 0.0);     // half step: x += alpha p only, r = s
+            s[B_OMEGA] = w.re;
+            s[B_OMEGA + 1] = w.im;
         } else {
             s[B_ITERS] += 1.0;
             const double rr = (s[B_HALF] != 0.0) ? s[B_SS] : s[B_RR];
             s[B_RES] = rr;
             if (s[B_HALF] != 0.0 || rr < s[B_EPS]) { s[B_DONE] = 1.0; return; }
             if (!(fabs(rr) <= 1.79e308)) { s[B_DONE] = 2.0; return; }     // NaN / inf: breakdown
-            // beta = (rho1 / rho) * (alpha / omega)
-            const double r1r = s[B_RHO1], r1i = s[B_RHO1 + 1], r0r = s[B_RHO], r0i = s[B_RHO + 1], d0 = r0r * r0r + r0i * r0i;
-            const double qr = (r1r * r0r + r1i * r0i) / d0, qi = (r1i * r0r - r1r * r0i) / d0;
-            const double ar = s[B_ALPHA], ai = s[B_ALPHA + 1], wr = s[B_OMEGA], wi = s[B_OMEGA + 1], dw = wr * wr + wi * wi;
-            const double er = (ar * wr + ai * wi) / dw, ei = (ai * wr - ar * wi) / dw;
-            s[B_BETA] = qr * er - qi * ei;
-            s[B_BETA + 1] = qr * ei + qi * er;
-            s[B_RHO] = r1r; s[B_RHO + 1] = r1i;
+            c2 rho1 = {s[B_RHO1], s[B_RHO1 + 1]}, rho = {s[B_RHO], s[B_RHO + 1]}, al = {s[B_ALPHA], s[B_ALPHA + 1]}, om = {s[B_OMEGA], s[B_OMEGA + 1]};
+            const c2 b = bicg_beta(rho1, rho, al, om);
+            s[B_BETA] = b.re;
+            s[B_BETA + 1] = b.im;
+            s[B_RHO] = rho1.re; s[B_RHO + 1] = rho1.im;
         }
     }
 }
 __global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op) {
     __shared__ double red[FB / 64];
+    if (nblocks <= 1024) {      // small reductions: one wave, in the order the folded prologues use (sum_partials_small_nv) -- a latency chain of
+        if (threadIdx.x < 64) { //  16 loads + one DPP tree instead of a 1024-thread tree with two barriers per value
+            for (int v = 0; v < nvals; v++) {
+                const double t = sum_partials_small_nv(partial, nblocks, nvals, v);
+                if (threadIdx.x == 0) scal[slot + v] = t;
+            }
+            if (op && threadIdx.x == 0) cg_scalar_step(scal, op);
+        }
+        return;
+    }
     for (int v = 0; v < nvals; v++) {
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int i = threadIdx.x;
@@ -177,9 +187,9 @@ int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op) {
 }
 
 // device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks
-int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op) {
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op, const double* partial) {
     const bool multi = allreduce && c->has_comm;   // also at world size 1 (self-partition tests exercise the collective)
-    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, c->d_partial, nblocks, nvals, c->d_scal, slot, multi ? 0 : cg_op);
+    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, partial ? partial : c->d_partial, nblocks, nvals, c->d_scal, slot, multi ? 0 : cg_op);
     HIPCHK(hipGetLastError());
     if (multi) {
         NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm_red, c->stream));

@@ -300,6 +300,8 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "pipe_chunks_per_wg")) return &c->tun.pipe_chunks_per_wg;
     if (!strcmp(key, "pipe_min_chunks")) return &c->tun.pipe_min_chunks;
     if (!strcmp(key, "lazy_links")) return &c->tun.lazy_links;
+    if (!strcmp(key, "bicg_fused")) return &c->tun.bicg_fused;
+    if (!strcmp(key, "action_eo_solver")) return &c->tun.action_eo_solver;
     return nullptr;
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {

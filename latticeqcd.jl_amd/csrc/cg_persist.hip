@@ -83,26 +83,7 @@ __device__ inline bool grid_sync(unsigned* ctr, unsigned epoch, int nwg) {
     return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
-// Sum over the 64 lanes, the same value in every lane, without the LDS crossbar: four DPP exchanges inside the 16-lane rows (quad_perm
-// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the four row sums through v_readlane.  (A __shfl_xor butterfly on doubles is
-// 12 dependent ds_bpermute round trips: ~0.3 us, four times per iteration.)
-template <int CTRL>
-__device__ inline double dpp_get(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ inline double lane_get(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ inline double wave_sum(double v) {
-    v += dpp_get<0xB1>(v);
-    v += dpp_get<0x4E>(v);
-    v += dpp_get<0x141>(v);
-    v += dpp_get<0x140>(v);
-    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
-}
+// (wave_sum: DPP row exchanges + v_readlane, lqcd_internal.h)
 
 // sum of the nwg (<= 256) published partials, identical in every workgroup
 __device__ inline double sum_partials(const double* part, int nwg) {

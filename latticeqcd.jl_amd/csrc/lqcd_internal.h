@@ -207,20 +207,71 @@ template <int K> __device__ inline cd mul_ipow(cd a) {
 constexpr int PERM[3][4] = {{3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}};
 constexpr int GK[3][4] = {{3, 3, 1, 1}, {2, 0, 0, 2}, {3, 1, 1, 3}};
 
-// sum of n <= 1024 block partials in EXACTLY the order of reduce_final (blas.hip) for such n: sixteen groups of 64 partials, a wave
-// shuffle tree over each, then the group sums in sequence -- every wave of every workgroup gets the same bits the one-block kernel would
-// have produced.  All 64 lanes of the calling wave must be active.
-__device__ inline double sum_partials_small(const double* __restrict__ partial, int n) {
+// Sum over the 64 lanes of a wave, the same value in every lane, without the LDS crossbar: four DPP exchanges inside the 16-lane rows (quad_perm
+// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the four row sums through v_readlane.  (A __shfl butterfly on doubles is a chain of
+// dependent ds_bpermute round trips, ~0.3 us.)  All 64 lanes must be active.
+template <int CTRL>
+__device__ inline double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double lane_get(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline double wave_sum(double v) {
+    v += dpp_get<0xB1>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x141>(v);
+    v += dpp_get<0x140>(v);
+    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+
+// Sum of n <= 1024 block partials that hold nvals interleaved values per block ([block][nvals]), value v: THE summation order of small reductions.
+// Lane l adds partials l, l + 64, l + 128, ... in sequence (at most 16 independent loads in flight), one DPP wave sum at the end.  reduce_final
+// (blas.hip) uses this function for n <= 1024, the consumers that fold a reduction into their prologue (cg_small, the fused BiCGStab chain) call it
+// in every wave: the same bits everywhere.  All 64 lanes of the calling wave must be active.
+__device__ inline double sum_partials_small_nv(const double* __restrict__ partial, int n, int nvals, int v) {
     const int lane = threadIdx.x & 63;
-    double t = 0.0;
-    for (int v = 0; v * 64 < n; v++) {
-        const int i = v * 64 + lane;
-        double s = i < n ? partial[i] : 0.0;
+    double t[16];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        t += __shfl(s, 0, 64);
+    for (int k = 0; k < 16; k++) {      // all loads first (one memory round trip, not sixteen), then the additions in sequence; a missing partial is +0.0
+        const int i = lane + 64 * k;
+        t[k] = i < n ? partial[(size_t)i * nvals + v] : 0.0;
     }
-    return t;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += t[k];
+    return wave_sum(s);
+}
+__device__ inline double sum_partials_small(const double* __restrict__ partial, int n) { return sum_partials_small_nv(partial, n, 1, 0); }
+
+// ---------------------------------------------------------------- BiCGStab scalar steps (shared by the one-thread scalar kernels of blas.hip and the
+// prologues of the fused chain in solvers.hip: the same expressions, so the two forms produce the same bits)
+struct c2 { double re, im; };
+__device__ inline c2 bicg_alpha(c2 rho, c2 r0v) {            // alpha = rho / <r0, v>
+    const double d = r0v.re * r0v.re + r0v.im * r0v.im;
+    c2 a;
+    a.re = (rho.re * r0v.re + rho.im * r0v.im) / d;
+    a.im = (rho.im * r0v.re - rho.re * r0v.im) / d;
+    return a;
+}
+__device__ inline c2 bicg_omega(c2 ts, double tt, bool half) {   // omega = <t, s> / |t|^2; a half step (|s|^2 < eps) takes omega = 0: x += alpha p only, r = s
+    c2 w;
+    w.re = half ? 0.0 : ts.re / tt;
+    w.im = half ? 0.0 : ts.im / tt;
+    return w;
+}
+__device__ inline c2 bicg_beta(c2 rho1, c2 rho, c2 alpha, c2 omega) {   // beta = (rho' / rho) (alpha / omega)
+    const double d0 = rho.re * rho.re + rho.im * rho.im;
+    const double qr = (rho1.re * rho.re + rho1.im * rho.im) / d0, qi = (rho1.im * rho.re - rho1.re * rho.im) / d0;
+    const double dw = omega.re * omega.re + omega.im * omega.im;
+    const double er = (alpha.re * omega.re + alpha.im * omega.im) / dw, ei = (alpha.im * omega.re - alpha.re * omega.im) / dw;
+    c2 b;
+    b.re = qr * er - qi * ei;
+    b.im = qr * ei + qi * er;
+    return b;
 }
 
 // ---------------------------------------------------------------- counter-based RNG (identical bits on every rank / decomposition)
@@ -370,6 +421,12 @@ struct Tunables {
 #else
     int variants_built = 0;   // read-only: dslash_variant >= 2 runs variant 1 (built without -DLQCD_VARIANTS)
 #endif
+    int bicg_fused = 2;       // even-odd BiCGStab, plain Wilson r = 1 on an unpartitioned lattice: 1 = the inner products come from the epilogues of the Schur
+                              // operator's second hop (no dot-product passes), reductions and scalar steps as separate one-block launches; 2 [default] = on lattices of
+                              // <= 1024 chunks per parity the reductions and scalar steps also move into the prologues of the consumers (7 dependent launches per
+                              // iteration instead of 17, identical iterates); 0 = the generic chain (what the clover / full-lattice solvers run)
+    int action_eo_solver = 1; // lqcd_fermi_action / lqcd_calc_UdSfdU, Wilson(-clover): X = (D^+D)^-1 eta through two even-odd BiCGStab solves (Y = D^-+ eta, X = D^-1 Y)
+                              // instead of the CG on the normal equations (0: the reference's form); same stopping rule for the same residual (actions.hip)
     int lazy_links = 1;       // the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,
                               // lqcd_link_staple -> lqcd_link_mul -> lqcd_link_add_ta) are recorded and run as ONE fused launch each, four completed triples of one
                               // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel
@@ -495,6 +552,7 @@ struct lqcd_op_s {
     double2* clover_inv = nullptr;      // A^-1 in the same packed format (even-odd solver), built on first use
     uint64_t clover_inv_version = 0;
     double2* clover_lambda = nullptr;   // six Hermitian 3x3 matrices per site: scratch of the clover force
+    int bicg_hint = 0;                  // iterations the last even-odd BiCGStab solve with this operator took (polling schedule of the next one)
 };
 
 namespace lqcd {
@@ -562,12 +620,18 @@ struct StencilCall {
     double2* xacc[2] = {nullptr, nullptr};      // update mode, fp32 site-pair kernel only: x += alpha p in the same epilogue (x = xacc, p = pacc; parity blocks)
     const double2* pacc[2] = {nullptr, nullptr};
     int prepacked = 0;            // 1: the send buffers already hold this application's faces (packed by its producer): no pack launch
+    // dot mode (fused BiCGStab chain, Wilson r = 1 direction-split kernel, fp64, unpartitioned, no clover): the epilogue also forms, per workgroup,
+    // dot_partial[3 b + (0,1,2)] = Re <z, out>, Im <z, out>, |out|^2 (<a, b> = sum conj(a) b) with z = dot_z (parity blocks like out)
+    const double2* dot_z[2] = {nullptr, nullptr};
+    double* dot_partial = nullptr;
+    int dot_conj = 0;             // 1: <out, z> (the imaginary part changes sign)
 };
 // slots of the device scalar block d_scal used by the solvers
 enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18 };
 // BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
-enum { B_RHO = 24, B_R0V = 26, B_ALPHA = 28, B_SS = 30, B_TS = 31, B_TT = 33, B_OMEGA = 34, B_RR = 36, B_RHO1 = 37, B_BETA = 39,
-       B_DONE = 41, B_ITERS = 42, B_EPS = 43, B_HALF = 44, B_RES = 45, B_END = 46 };
+enum { B_RHO = 24, B_R0V = 26, B_VV = 28, B_ALPHA = 29, B_SS = 31, B_TS = 32, B_TT = 34, B_OMEGA = 35, B_RR = 37, B_RHO1 = 38, B_BETA = 40,
+       B_DONE = 42, B_ITERS = 43, B_EPS = 44, B_HALF = 45, B_RES = 46, B_RHOB = 47, B_END = 49 };      // B_R0V..B_VV, B_TS..B_TT and B_RR..B_RHO1 are filled by one
+                                                                                                     // 3-value reduction each; B_RHOB: second rho slot of the fused chain
 // stencil.hip, once per precision (p64 is the inline namespace everywhere except in the fp32 build of stencil.hip).
 // With prec = 1 the field pointers of a StencilCall address float2 data (cast), scalars stay double.
 #ifdef LQCD_F32      // reopen each namespace the way it was declared at the top of this header
@@ -626,7 +690,7 @@ int blas_axpy(lqcd_ctx_s* c, double ar, double ai, const double2* x, double2* y,
 int blas_axpby(lqcd_ctx_s* c, double ar, double ai, const double2* x, double br, double bi, double2* y, size_t n);
 int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n);
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n);
-int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0);
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0, const double* partial = nullptr);   // partial: default the context's d_partial
 int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op);
 int stream_grid(lqcd_ctx_s* c, size_t n);
 

@@ -703,6 +703,264 @@ static int bicgstab_core(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, 
     return LQCD_OK;
 }
 
+// ---------------------------------------------------------------------------------- even-odd BiCGStab, plain Wilson: the fused chain (tunable bicg_fused)
+// The Schur operator M = 1 - k^2 H_eo H_oe is two hops; its SECOND hop forms the inner product an iteration needs next in its epilogue
+// (StencilCall::dot_z: <r0, v> with v = M p, and <t, s>, |t|^2 with t = M s), so no pass over the vectors exists only to multiply them.
+// fold (lattices of <= 1024 chunks per parity, where an iteration is a chain of short dependent launches): the block partials of a producer are
+// summed by EVERY workgroup of the consumer in its prologue (sum_partials_small_nv: the order of the one-block reduction kernel) and the scalar
+// steps (bicg_alpha / bicg_omega / bicg_beta, shared with the scalar kernels of blas.hip) run there too:
+//     hop, hop+<r0,v> | s = r - alpha v, |s|^2 | hop, hop+<t,s>,|t|^2 | x += alpha p + omega s, r = s - omega t, |r|^2, <r0,r> | p = r + beta (p - omega v)
+// = 7 dependent launches per iteration instead of 17, the same bits in every vector as the unfolded form (partials, summation order and scalar
+// expressions are the same; tests/test_gpu_solver_edges.py).  rho lives in two slots used alternately: block 0 of the p update writes the new value
+// while the other workgroups still read the old one.
+// the NV sums of a producer's partials, the same bits in every thread of the workgroup: ONE wave loads and adds them (every wave doing so made the
+// prologue 5-9 us of texture-path time for 1024 workgroups), the others take the result from LDS
+template <int NV>
+__device__ inline void block_sum_partials(const double* __restrict__ partial, int n, double (&out)[NV]) {
+    __shared__ double sh[NV];
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const double t = sum_partials_small_nv(partial, n, NV, v);
+            if (threadIdx.x == 0) sh[v] = t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; v++) out[v] = sh[v];
+}
+struct BicgF {
+    double* sc;             // the context's device scalar block
+    int rho_in, rho_out;    // slots of rho for this iteration and the next (equal when the scalar kernels do the steps)
+    int fold;
+    const double* pin;      // fold: the producer's partials ...
+    int pin_n;              // ... of that many workgroups
+    const double* pin2;     // bicgf_xr: the |s|^2 partials of bicgf_s
+    int pin2_n;
+    double* pout;           // this kernel's partials
+};
+// The three streaming kernels request the first KE elements of every thread BEFORE the prologue (whose partial sums are a memory round trip of their
+// own and do not depend on them), then walk the rest of a large vector in the usual grid-stride loop: same element -> thread map, same order of the
+// per-thread additions, hence the same partials whether the prologue folds a reduction or not.
+constexpr int KE = 3;
+// s = r - alpha v ; partial |s|^2          (fold: alpha = rho / <r0, v> from the partials of the Schur operator's epilogue)
+__global__ __launch_bounds__(UB) void bicgf_s(BicgF a, double2* __restrict__ s, const double2* __restrict__ r, const double2* __restrict__ v, size_t n) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    double2 pr[KE], pv[KE];
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) { pr[e] = r[i]; pv[e] = v[i]; }
+    }
+    // the sums: from the producer's partials (fold) or from the slots a one-block reduction launch filled; the scalar step is formed HERE in both
+    // forms -- the same instructions, hence the same bits
+    c2 r0v, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]};
+    if (a.fold) {
+        double t3[3];
+        block_sum_partials<3>(a.pin, a.pin_n, t3);
+        r0v.re = t3[0]; r0v.im = t3[1];
+    } else { r0v.re = a.sc[B_R0V]; r0v.im = a.sc[B_R0V + 1]; }
+    const c2 al = bicg_alpha(rho, r0v);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc[B_R0V] = r0v.re; a.sc[B_R0V + 1] = r0v.im; a.sc[B_ALPHA] = al.re; a.sc[B_ALPHA + 1] = al.im; }
+    const double ar = al.re, ai = al.im;
+    double acc[1] = {0};
+    auto one = [&](size_t i, double2 sv, const double2 vv) {
+        sv.x = fma(-ar, vv.x, sv.x); sv.x = fma(ai, vv.y, sv.x);
+        sv.y = fma(-ar, vv.y, sv.y); sv.y = fma(-ai, vv.x, sv.y);
+        s[i] = sv;
+        acc[0] = fma(sv.x, sv.x, acc[0]); acc[0] = fma(sv.y, sv.y, acc[0]);
+    };
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) one(i, pr[e], pv[e]);
+    }
+    for (size_t i = i0 + KE * stride; i < n; i += stride) one(i, r[i], v[i]);
+    block_reduce_nv<1>(acc, a.pout);
+}
+// x += alpha p + omega s ; r = s - omega t ; partials |r|^2, <r0, r>       (fold: half-step test on |s|^2 and omega = <t, s> / |t|^2 in the prologue)
+__global__ __launch_bounds__(UB) void bicgf_xr(BicgF a, double2* __restrict__ x, double2* __restrict__ r, const double2* __restrict__ p,
+                                                const double2* __restrict__ s, const double2* __restrict__ t, const double2* __restrict__ r0, size_t n) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    double2 pp[KE], ps[KE], pt[KE], pz[KE], px[KE];
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) { pp[e] = p[i]; ps[e] = s[i]; pt[e] = t[i]; pz[e] = r0[i]; px[e] = x[i]; }
+    }
+    const double ar = a.sc[B_ALPHA], ai = a.sc[B_ALPHA + 1];
+    double ss, tt;
+    c2 ts;
+    if (a.fold) {
+        double t1[1], t3[3];
+        block_sum_partials<1>(a.pin2, a.pin2_n, t1);
+        block_sum_partials<3>(a.pin, a.pin_n, t3);
+        ss = t1[0]; ts.re = t3[0]; ts.im = t3[1]; tt = t3[2];
+    } else { ss = a.sc[B_SS]; ts.re = a.sc[B_TS]; ts.im = a.sc[B_TS + 1]; tt = a.sc[B_TT]; }
+    const bool half = ss < a.sc[B_EPS];
+    const c2 om = bicg_omega(ts, tt, half);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.sc[B_SS] = ss; a.sc[B_HALF] = half ? 1.0 : 0.0; a.sc[B_TS] = ts.re; a.sc[B_TS + 1] = ts.im; a.sc[B_TT] = tt;
+        a.sc[B_OMEGA] = om.re; a.sc[B_OMEGA + 1] = om.im;
+    }
+    const double wr = om.re, wi = om.im;
+    double acc[3] = {0, 0, 0};
+    auto one = [&](size_t i, const double2 pv, const double2 sv, const double2 tv, const double2 zv, double2 xv) {
+        double2 rv = sv;
+        xv.x = fma(ar, pv.x, xv.x); xv.x = fma(-ai, pv.y, xv.x);
+        xv.y = fma(ar, pv.y, xv.y); xv.y = fma(ai, pv.x, xv.y);
+        xv.x = fma(wr, sv.x, xv.x); xv.x = fma(-wi, sv.y, xv.x);
+        xv.y = fma(wr, sv.y, xv.y); xv.y = fma(wi, sv.x, xv.y);
+        rv.x = fma(-wr, tv.x, rv.x); rv.x = fma(wi, tv.y, rv.x);
+        rv.y = fma(-wr, tv.y, rv.y); rv.y = fma(-wi, tv.x, rv.y);
+        x[i] = xv; r[i] = rv;
+        acc[0] = fma(rv.x, rv.x, acc[0]); acc[0] = fma(rv.y, rv.y, acc[0]);
+        acc[1] = fma(zv.x, rv.x, acc[1]); acc[1] = fma(zv.y, rv.y, acc[1]);
+        acc[2] = fma(zv.x, rv.y, acc[2]); acc[2] = fma(-zv.y, rv.x, acc[2]);
+    };
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) one(i, pp[e], ps[e], pt[e], pz[e], px[e]);
+    }
+    for (size_t i = i0 + KE * stride; i < n; i += stride) one(i, p[i], s[i], t[i], r0[i], x[i]);
+    block_reduce_nv<3>(acc, a.pout);
+}
+// p = r + beta (p - omega v)       (fold: iteration count, convergence / breakdown and beta = (rho'/rho)(alpha/omega) in the prologue)
+__global__ __launch_bounds__(UB) void bicgf_p(BicgF a, double2* __restrict__ p, const double2* __restrict__ r, const double2* __restrict__ v, size_t n) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    double2 pv_[KE], pr[KE], pp[KE];
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) { pv_[e] = v[i]; pr[e] = r[i]; pp[e] = p[i]; }
+    }
+    const double wr = a.sc[B_OMEGA], wi = a.sc[B_OMEGA + 1];
+    const bool half = a.sc[B_HALF] != 0.0;
+    double rrn;
+    c2 rho1, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]}, al = {a.sc[B_ALPHA], a.sc[B_ALPHA + 1]}, om = {wr, wi};
+    if (a.fold) {
+        double t3[3];
+        block_sum_partials<3>(a.pin, a.pin_n, t3);
+        rrn = t3[0]; rho1.re = t3[1]; rho1.im = t3[2];
+    } else { rrn = a.sc[B_RR]; rho1.re = a.sc[B_RHO1]; rho1.im = a.sc[B_RHO1 + 1]; }
+    const double rr = half ? a.sc[B_SS] : rrn;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead) { a.sc[B_ITERS] += 1.0; a.sc[B_RES] = rr; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im; }
+    if (half || rr < a.sc[B_EPS]) { if (lead) a.sc[B_DONE] = 1.0; return; }
+    if (!(fabs(rr) <= 1.79e308)) { if (lead) a.sc[B_DONE] = 2.0; return; }      // NaN / inf: breakdown
+    const c2 be = bicg_beta(rho1, rho, al, om);
+    if (lead) { a.sc[B_BETA] = be.re; a.sc[B_BETA + 1] = be.im; a.sc[a.rho_out] = rho1.re; a.sc[a.rho_out + 1] = rho1.im; }
+    const double br = be.re, bi = be.im;
+    auto one = [&](size_t i, const double2 vv, const double2 rv, double2 pv) {
+        pv.x = fma(-wr, vv.x, pv.x); pv.x = fma(wi, vv.y, pv.x);
+        pv.y = fma(-wr, vv.y, pv.y); pv.y = fma(-wi, vv.x, pv.y);
+        double2 o;
+        o.x = fma(br, pv.x, rv.x); o.x = fma(-bi, pv.y, o.x);
+        o.y = fma(br, pv.y, rv.y); o.y = fma(bi, pv.x, o.y);
+        p[i] = o;
+    };
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) one(i, pv_[e], pr[e], pp[e]);
+    }
+    for (size_t i = i0 + KE * stride; i < n; i += stride) one(i, v[i], r[i], p[i]);
+}
+
+// xe = M^-1 rhs on the even sites, M = 1 - k^2 H_eo H_oe (dagger: H -> H^+).  w[0..5] = r, r0, p, v, s, t; to: an odd-parity work vector.
+// Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and iteration count as bicgstab_core.
+static int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
+                              int maxiter, int* iters, double* final_rr) {
+    lqcd_ctx_s* c = op->ctx;
+    const double k = op->km;
+    const size_t n = xe.elems, bytes = n * sizeof(double2);
+    lqcd_spinor_s *r = w[0], *r0 = w[1], *p = w[2], *v = w[3], *s = w[4], *t = w[5];
+    const int nbs = stencil_num_blocks(c, LQCD_WILSON, 1.0, 0);                 // workgroups (= partials) of one hop on one parity
+    const int nbk = (int)std::min<size_t>(1024, (n + UB - 1) / UB);             // streaming kernels: at most 1024 partials (one prologue sums them)
+    const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
+    double* P0 = c->d_partial;                  // <r0, v> (+ |v|^2)      [nbs x 3]
+    double* P1 = P0 + (size_t)3 * nbs;          // |s|^2                  [nbk]
+    double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]
+    double* P3 = P2 + (size_t)3 * nbs;          // |r|^2, <r0, r>         [nbk x 3]
+    const double* skip = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
+    auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj) -> int {
+        StencilCall s1 = make_hop_call(op, to, in, nullptr, 0.0, 1.0, dg);      // t_o = H_oe in
+        s1.skip_flag = skip;
+        LQCHK(stencil_apply(c, s1));
+        StencilCall s2 = make_hop_call(op, out, to, in, 1.0, -k * k, dg);       // out = in - k^2 H_eo t_o
+        s2.skip_flag = skip;
+        if (z) { s2.dot_z[0] = z->data; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
+        return stencil_apply(c, s2);
+    };
+    HIPCHK(hipMemsetAsync(c->d_scal + B_DONE, 0, sizeof(double), c->stream));      // the hops test this flag: the one the LAST solve left must not skip M x below
+    LQCHK(schur(v, &xe, nullptr, nullptr, 0));
+    HIPCHK(hipMemcpyAsync(r->data, rhs->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, v->data, r->data, n));
+    HIPCHK(hipMemcpyAsync(r0->data, r->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(p->data, r->data, bytes, hipMemcpyDeviceToDevice, c->stream));
+    double rr;
+    LQCHK(blas_norm2(c, r->data, n, &rr, true));
+    double init[B_END - B_RHO] = {0};
+    init[B_RHO - B_RHO] = rr;
+    init[B_RHOB - B_RHO] = rr;
+    init[B_EPS - B_RHO] = eps;
+    init[B_RES - B_RHO] = rr;
+    HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int it = 0, st = LQCD_ERR_NOT_CONVERGED, enq = 0;
+    bool breakdown = false;
+    if (rr < eps) st = LQCD_OK;
+    // Polling the done flag is a host round trip that idles the GPU for ~40 us: the first burst runs up to one iteration short of what the last
+    // solve with this operator took (successive solves of an MD trajectory take the same count within one or two; iterations enqueued behind the
+    // converging one are no-ops), later bursts are short.
+    int check_every = std::max(4, std::min(op->bicg_hint - 1, 64));
+    while (st != LQCD_OK && !breakdown && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        check_every = 2;
+        for (int q = 0; q < burst; q++, enq++) {
+            BicgF a;
+            a.sc = c->d_scal;
+            a.fold = fold ? 1 : 0;
+            a.rho_in = (enq & 1) ? B_RHOB : B_RHO;       // rho alternates between two slots: block 0 of the p update writes the next value while
+            a.rho_out = (enq & 1) ? B_RHO : B_RHOB;      // the other workgroups still read this one
+            a.pin2 = nullptr; a.pin2_n = 0;
+            LQCHK(schur(v, p, r0, P0, 0));                                                                   // v = M p, <r0, v>
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0));
+            a.pin = P0; a.pin_n = nbs; a.pout = P1;
+            hipLaunchKernelGGL(bicgf_s, dim3(nbk), dim3(UB), 0, c->stream, a, s->data, r->data, v->data, n);
+            if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
+            LQCHK(schur(t, s, s, P2, 1));                                                                    // t = M s, <t, s>, |t|^2
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
+            a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
+            hipLaunchKernelGGL(bicgf_xr, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, r0->data, n);
+            if (!fold) LQCHK(reduce_to_slot(c, nbk, 3, B_RR, true, 0, P3));
+            a.pin = P3; a.pin_n = nbk; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
+            hipLaunchKernelGGL(bicgf_p, dim3(nbk), dim3(UB), 0, c->stream, a, p->data, r->data, v->data, n);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + B_RHO, (B_END - B_RHO) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        it = (int)c->h_scal[B_ITERS - B_RHO];
+        rr = c->h_scal[B_RES - B_RHO];
+        const double done = c->h_scal[B_DONE - B_RHO];
+        if (done == 1.0) st = LQCD_OK;
+        else if (done != 0.0) breakdown = true;
+    }
+    if (iters) *iters = it;
+    if (final_rr) *final_rr = rr;
+    if (breakdown) { set_error("BiCGStab: residual is not finite (breakdown)"); return LQCD_ERR_NOT_CONVERGED; }
+    if (st != LQCD_OK) {
+        set_error("The BiCGStab is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    op->bicg_hint = it;
+    return LQCD_OK;
+}
+
 }  // namespace lqcd
 
 using namespace lqcd;
@@ -906,11 +1164,15 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
     const size_t nh = x->elems / 2;
     ScratchScope pool(c);
     double2* wd[6];
+    lqcd_spinor_s* wsp[6];
     for (int i = 0; i < 6; i++) {
         lqcd_spinor_s* wi = pool.get(op->kind, LQCD_EVEN);
         if (!wi) return LQCD_ERR_HIP;
         wd[i] = wi->data;
+        wsp[i] = wi;
     }
+    // plain Wilson r = 1 on an unpartitioned lattice: the chain whose inner products come from the Schur operator's epilogue (bicgstab_eo_wilson)
+    const bool fused = !clov && c->tun.bicg_fused >= 1 && op->r == 1.0 && c->tun.dslash_variant == 1 && !any_partitioned(c) && !c->has_comm && c->geom.Vh % 64 == 0;
     lqcd_spinor_s* rhs = pool.get(op->kind, LQCD_EVEN);
     lqcd_spinor_s* te = clov ? pool.get(op->kind, LQCD_EVEN) : nullptr;
     lqcd_spinor_s* to = pool.get(op->kind, LQCD_ODD);
@@ -951,7 +1213,8 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
                 return clover_apply_parity(c, Ai, 0, out, te->data, -k * k, in, 1.0);        // out = in - k^2 A_ee^-1 t_e
             };
         }
-        const int sc = bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
+        const int sc = fused ? bicgstab_eo_wilson(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr)
+                             : bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
         // the odd half (also on non-convergence, so x is a consistent best effort)
         if (!clov) {
             StencilCall s = make_hop_call(op, &xo, &xe, &bo, 1.0, k, dg);                    // x_o = b_o + k H_oe x_e

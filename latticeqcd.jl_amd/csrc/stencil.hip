@@ -158,10 +158,10 @@ __device__ inline void clover_rows(cd (&out)[3], const real2* __restrict__ a, co
 #else
 #define LQCD_DS_BOUNDS __launch_bounds__(256)
 #endif
-template <bool DAG, bool R12 = false, bool CLOV = false>
+template <bool DAG, bool R12 = false, bool CLOV = false, bool DOT = false>
 __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
     __shared__ real2 part[4][12][64];  // 48 KiB
-    __shared__ double red[4];
+    __shared__ double red[DOT ? 12 : 4];
     if (upd_done(k)) return;
     const real al_upd = update_alpha(k);
     int chunk, p;
@@ -215,6 +215,11 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) rv[cc] = ld(k.upd[p] + sp12_off(i) + co12(3 * w + cc));
     }
+    cd zv[DOT ? 3 : 1];
+    if constexpr (DOT) {            // dot mode: this wave's three components of z, requested behind the hops (no long live range: the kernel stays at
+#pragma unroll                      // 3 waves/SIMD); the LDS exchange and the barrier cover the load
+        for (int cc = 0; cc < 3; cc++) zv[cc] = !valid ? mk(0, 0) : (k.dotz[p] == k.xin[p] && k.a != 0.0) ? xv[cc] : ld(k.dotz[p] + sp12_off(i) + co12(3 * w + cc));
+    }                               // (z = the diagonal term's field -- <t, s> with t = M s -- is in registers already)
 #pragma unroll
     for (int j = 0; j < 12; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
     if constexpr (CLOV) if (valid && k.a != 0.0) {   // this wave's rows of A xin (its partial sums are already on their way to LDS)
@@ -223,7 +228,7 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
         else clover_rows<0>(xv, ca, cpsi, w >= 2);
     }
     __syncthreads();
-    real nrm = 0.0;
+    real nrm = 0.0, dre = 0.0, dim = 0.0;
     if (valid) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
@@ -234,7 +239,23 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
             if (LQCD_UPD_PREFETCH) emit_pre(k, p, co12(j) + sp12_off(i), v, nrm, al_upd, rv[cc]);
             else emit(k, p, co12(j) + sp12_off(i), v, nrm, al_upd);
+            if constexpr (DOT) {        // <z, v> = conj(z) v
+                dre = fma(zv[cc].re, v.re, dre); dre = fma(zv[cc].im, v.im, dre);
+                dim = fma(zv[cc].re, v.im, dim); dim = fma(-zv[cc].im, v.re, dim);
+            }
         }
+    }
+    if constexpr (DOT) {                // three sums per workgroup: a wave tree each, then the four waves in a fixed order
+        double t3[3] = {(double)dre, (double)(k.dot_conj ? -dim : dim), (double)nrm};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t3[q] += __shfl_down(t3[q], off, 64);
+            if (lane == 0) red[4 * q + w] = t3[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) k.dot_partial[3 * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        return;
     }
     if (k.norm_partial) {
 #pragma unroll
@@ -293,6 +314,9 @@ struct PipeArgs {
     unsigned* ctr;            // queue heads (ctr[32 q], q = 0..7) and exit counter (ctr[256]); zero at launch, reset by the last workgroup;
                               // nullptr: no queue -- workgroup b walks the per_wg consecutive virtual blocks b * per_wg .. (dslash_pipe = 3)
     int per_wg;
+    const real2* dotz[2];     // dot mode of the scalar-addressing kernel (StencilCall::dot_z, see KArgs)
+    double* dot_partial;
+    int dot_conj;
 };
 
 // next virtual block for this workgroup: from queue q (virtual blocks 8 j + q, j = 0 .. nvirt/8 - 1, handed out in order), moving on to the
@@ -610,8 +634,8 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
 // load, no branch around a load.  Per launch -20 % VALU and -42 % SALU instructions than variant 1 (profiles/r03_pmc_pipe_static.csv), i.e. a
 // shorter way from dispatch to the first load.  Same operations in the same order per site, same |.|^2 partial per workgroup: bit-identical to
 // variant 1 including the CG iterates.
-template <int MU, bool DAG, bool R12, bool NTB>
-__device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int lane, real al_upd, real& nrm) {
+template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false>
+__device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim) {
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;
     constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;
@@ -620,7 +644,13 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     const size_t gpar = (size_t)a.nch * 4 * NL * 64;
     const PipeSite s = pipe_site<MU, NL>(a, blockIdx.x, lane);
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
-    if (a.upd_scal) {
+    const bool z_is_x = DOT && (s.p ? a.dotz[1] == a.xin[1] : a.dotz[0] == a.xin[0]) && a.a != real(0.0);
+    if constexpr (DOT) {        // dot mode: z takes the registers the old r has in update mode (requested ahead of the hops, scalar base + lane offset)
+        if (!z_is_x) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dotz[1] : a.dotz[0], s.own) + co12(3 * MU + cc));
+        }
+    } else if (a.upd_scal) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
     }
@@ -687,7 +717,13 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         cd sm = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         cd v = a.b * sm;
         v = mk(fma(a.a, xv[cc].re, v.re), fma(a.a, xv[cc].im, v.im));
-        if (a.upd_scal) {
+        if constexpr (DOT) {        // <z, v> = conj(z) v next to |v|^2 (same expressions as wilson_dirsplit's dot epilogue)
+            const cd z = z_is_x ? xv[cc] : rv[cc];
+            nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
+            if (a.nt_store) st_nt(dstp + co12(j), v); else st(dstp + co12(j), v);
+            dre = fma(z.re, v.re, dre); dre = fma(z.im, v.im, dre);
+            dim = fma(z.re, v.im, dim); dim = fma(-z.im, v.re, dim);
+        } else if (a.upd_scal) {
             cd r = rv[cc];
             r.re = fma(-al_upd, v.re, r.re); r.im = fma(-al_upd, v.im, r.im);
             nrm = fma(r.re, r.re, nrm); nrm = fma(r.im, r.im, nrm);
@@ -699,10 +735,10 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     }
 }
 
-template <bool DAG, bool R12, bool NTB>
+template <bool DAG, bool R12, bool NTB, bool DOT = false>
 __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
-    __shared__ double red[4];
+    __shared__ double red[DOT ? 12 : 4];
     if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) {
         if (a.scal_w && blockIdx.x == 0 && threadIdx.x == 0) a.scal_w[S_XDONE] = 1.0;
         return;
@@ -718,12 +754,24 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     }
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    real nrm = 0.0;
+    real nrm = 0.0, dre = 0.0, dim = 0.0;
     switch (w) {
-    case 0: sdir_wave<0, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
-    case 1: sdir_wave<1, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
-    case 2: sdir_wave<2, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
-    default: sdir_wave<3, DAG, R12, NTB>(a, part, lane, al_upd, nrm); break;
+    case 0: sdir_wave<0, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 1: sdir_wave<1, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 2: sdir_wave<2, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    default: sdir_wave<3, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    }
+    if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue
+        double t3[3] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t3[q] += __shfl_down(t3[q], off, 64);
+            if (lane == 0) red[4 * q + w] = t3[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) a.dot_partial[3 * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        return;
     }
     if (a.norm_partial) {
 #pragma unroll
@@ -1268,6 +1316,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.upd[0] = (real2*)s.upd[0]; k.upd[1] = (real2*)s.upd[1];
     k.skip = s.skip_flag;
     k.alpha_partials = s.alpha_partials; k.alpha_n = s.alpha_n; k.scal_w = s.scal_w;
+    k.dotz[0] = (const real2*)s.dot_z[0]; k.dotz[1] = (const real2*)s.dot_z[1]; k.dot_partial = s.dot_partial; k.dot_conj = s.dot_conj;
     return k;
 }
 
@@ -1300,6 +1349,27 @@ static int launch_interior_tb(lqcd_ctx_s* c, const StencilCall& s) {
     return LQCD_OK;
 }
 
+static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall& s) {
+    PipeArgs a;
+    a.gauge = k.gauge12 ? k.gauge12 : k.gauge;
+    const bool upd = k.upd_scal != nullptr;
+    for (int p = 0; p < 2; p++) { a.dst[p] = upd ? k.upd[p] : k.out[p]; a.in[p] = k.in[p]; a.xin[p] = k.xin[p]; a.dotz[p] = k.dotz[p]; }
+    a.dot_partial = k.dot_partial; a.dot_conj = k.dot_conj;
+    a.norm_partial = k.norm_partial; a.upd_scal = k.upd_scal; a.skip = k.skip; a.scal_w = k.scal_w;
+    a.a = k.a; a.b = k.b;
+    a.nt_store = (k.nt & 4) != 0;
+    a.nvirt = k.nblocks; a.both = s.parity_mode == 2; a.pmode = s.parity_mode == 2 ? 0 : s.parity_mode;
+    a.XH = k.g.XH; a.L1 = k.g.L[1]; a.L2 = k.g.L[2]; a.LT = k.g.L[3]; a.nch = k.g.nch; a.dXH = k.g.dXH;
+    for (int mu = 0; mu < 4; mu++) {
+        a.sgn_f[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_fwd[mu]);
+        a.sgn_b[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_bwd[mu]);
+    }
+    a.cps = k.cps; a.cpp = k.cpp; a.cpr = k.cpr; a.per_pass = std::max(1, k.cpr * k.g.L[3]); a.ty = k.ty; a.tz = k.tz; a.ysplit = k.ysplit;
+    a.ctr = c->pipe_ctr; a.per_wg = 1;
+    a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
+    return a;
+}
+
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
     if (use_dirsplit(c, s.kind, s.r)) {
         KArgs k = make_kargs(c, s, 64);
@@ -1316,26 +1386,33 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             }
             else if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), sg, sb_, pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), sg, sb_, pad, c->stream, k);
+        } else if (s.kind == LQCD_WILSON && k.dot_partial) {      // dot mode (fused even-odd BiCGStab): the plain direction-split kernel with the inner-product epilogue
+#ifdef LQCD_F32
+            set_error("stencil: dot mode exists in the fp64 build only");
+            return LQCD_ERR_UNSUPPORTED;
+#else
+            if (k.clover || s.r != 1.0) { set_error("stencil: dot mode needs the plain Wilson r = 1 kernel"); return LQCD_ERR_UNSUPPORTED; }
+            dim3 grid(k.nblocks), block(256);
+            if (k.gauge12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {      // the scalar-addressing form
+                PipeArgs a = make_pipe_args(c, k, s);
+                const bool ntb = (k.nt & 1) != 0;
+                if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, true, true>), grid, block, 0, c->stream, a);
+                                else hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, true>), grid, block, 0, c->stream, a); }
+                else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<false, true, true, true>), grid, block, 0, c->stream, a);
+                       else hipLaunchKernelGGL((wilson_dirsplit_s<false, true, false, true>), grid, block, 0, c->stream, a); }
+            } else if (k.gauge12) {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, true>), grid, block, pad, c->stream, k);
+            } else {
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, true>), grid, block, pad, c->stream, k);
+                else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, true>), grid, block, pad, c->stream, k);
+            }
+#endif
         } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr) &&
                    (c->tun.dslash_pipe != 2 || (k.gauge12 && !kF32Build))) {      // the scalar-addressing kernel pays with the fp64 12-real links only: its 18-real
                                                                                   // instance spills at 3 waves/SIMD, its one-site-per-lane fp32 instance measured 62.5 vs 57 ms of
                                                                                   // variant 1 in the mixed CG (profiles/r03_mixed_precision.log) -- same grid, so the counts agree
-            PipeArgs a;
-            a.gauge = k.gauge12 ? k.gauge12 : k.gauge;
-            const bool upd = k.upd_scal != nullptr;
-            for (int p = 0; p < 2; p++) { a.dst[p] = upd ? k.upd[p] : k.out[p]; a.in[p] = k.in[p]; a.xin[p] = k.xin[p]; }
-            a.norm_partial = k.norm_partial; a.upd_scal = k.upd_scal; a.skip = k.skip; a.scal_w = k.scal_w;
-            a.a = k.a; a.b = k.b;
-            a.nt_store = (k.nt & 4) != 0;
-            a.nvirt = k.nblocks; a.both = s.parity_mode == 2; a.pmode = s.parity_mode == 2 ? 0 : s.parity_mode;
-            a.XH = k.g.XH; a.L1 = k.g.L[1]; a.L2 = k.g.L[2]; a.LT = k.g.L[3]; a.nch = k.g.nch; a.dXH = k.g.dXH;
-            for (int mu = 0; mu < 4; mu++) {
-                a.sgn_f[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_fwd[mu]);
-                a.sgn_b[mu] = k.g.part[mu] ? real(0.0) : real(k.g.bc_bwd[mu]);
-            }
-            a.cps = k.cps; a.cpp = k.cpp; a.cpr = k.cpr; a.per_pass = std::max(1, k.cpr * k.g.L[3]); a.ty = k.ty; a.tz = k.tz; a.ysplit = k.ysplit;
-            a.ctr = c->pipe_ctr; a.per_wg = 1;
-            a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
+            PipeArgs a = make_pipe_args(c, k, s);
             const bool persist = c->tun.dslash_pipe == 1 || c->tun.dslash_pipe == 3;
             if (c->tun.dslash_pipe == 3) { a.ctr = nullptr; a.per_wg = wilson_pipe_per_wg(c, k.nblocks); }
             const dim3 pg(c->tun.dslash_pipe == 1 ? wilson_pipe_grid(c, k.nblocks, s.prec) : c->tun.dslash_pipe == 3 ? k.nblocks / a.per_wg : k.nblocks), pb(256);

@@ -57,6 +57,17 @@ def main():
     V = 16 ** 3 * 32
     out = {"config": "16^3x32 Wilson Dslash + BiCGStab (even-odd preconditioned), fp64, hot start", "dslash_us": 1e3 * ms,
            "dslash_gflops": 1320 * V / ms / 1e6, "roofline_frac_960B": 960 * V / ms / 1e6 / 8000}
+    # even-odd BiCGStab in its three forms (tunable bicg_fused): 2 = inner products from the Schur operator's epilogue + reductions and scalar steps in the
+    # consumers' prologues (default), 1 = epilogue products with separate reduction launches, 0 = the generic chain
+    D.method_CG = "bicgstab_evenodd"
+    for mode in (0, 1, 2):
+        lat.set_param("bicg_fused", mode)
+
+        def solve_eo():
+            lq.clear_fermion_(x)
+            return lq.solve_DinvX_(x, D, b, return_info=True)
+        dt, (it, rr) = timed(solve_eo, reps=5)
+        out["bicgstab_evenodd_fused%d" % mode] = {"iters": it, "final_rr": rr, "ms": 1e3 * dt, "us_per_iteration": 1e6 * dt / max(it, 1)}
     for method in ("bicgstab_evenodd", "bicgstab"):
         D.method_CG = method
 
@@ -128,6 +139,11 @@ def main():
     t_up = tk(lambda: lq.U_update_(U, p, 1e-9))
     t_ff = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
     t_sf = tk(lambda: lq.evaluate_FermiAction(fa, U, eta), reps=2)
+    it_eo = lq.evaluate_FermiAction(fa, U, eta, return_info=True)[1]
+    lat.set_param("action_eo_solver", 0)        # the reference's form: CG on the normal equations
+    t_ff_cg = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
+    it_cg = lq.evaluate_FermiAction(fa, U, eta, return_info=True)[1]
+    lat.set_param("action_eo_solver", 1)
     lat.set_param("mixed_action_solver", 1)
     t_ffm = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
     lat.set_param("mixed_action_solver", 0)
@@ -135,7 +151,9 @@ def main():
                 "gauge_force_ms": t_gf, "gauge_force_GBps_1152B": 1152 * V / t_gf / 1e6, "momentum_add_ta_ms": t_ta,
                 "P_update_fused_ms": t_pu, "P_update_fused_GBps_1728B": 1728 * V / t_pu / 1e6, "link_exp_update_ms": t_up,
                 "link_exp_update_GBps_1728B": 1728 * V / t_up / 1e6,
-                "calc_UdSfdU_ms (CG to 1e-16 + Y = D X + sweep)": t_ff, "evaluate_FermiAction_ms": t_sf,
+                "calc_UdSfdU_ms (two even-odd BiCGStab solves to 1e-16 + sweep)": t_ff, "action_solver_iterations_evenodd_bicgstab": it_eo,
+                "calc_UdSfdU_ms_action_eo_solver0 (CG to 1e-16 + Y = D X + sweep)": t_ff_cg, "action_solver_iterations_cg": it_cg,
+                "evaluate_FermiAction_ms": t_sf,
                 "calc_UdSfdU_mixed_precision_solver_ms": t_ffm,
                 "md_step_ms": nsw * (t_pu + 2 * t_up) + t_ff + t_ta,
                 "md_step_mixed_precision_solver_ms": nsw * (t_pu + 2 * t_up) + t_ffm + t_ta,

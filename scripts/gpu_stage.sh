@@ -19,6 +19,21 @@ case $stage in
     timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "c_abi or cg" 2>&1 | tail -15 >> $out/pytest.log
     cat $out/pytest.log
     ;;
+  bicg)       # fused even-odd BiCGStab chain, action solves through it; config timings
+    timeout 900 python -m pytest tests/test_gpu_solver_edges.py tests/test_gpu_clover.py tests/test_gpu_md.py tests/test_gpu_hmc_partitioned.py -q 2>&1 | tail -15 > $out/pytest.log
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cg_persist.py tests/test_gpu_graph.py tests/test_gpu_halo_fuse.py -q 2>&1 | tail -15 >> $out/pytest.log
+    cat $out/pytest.log
+    timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; cut -c1-1500 $out/bench_configs.log; tail -5 $out/bench_configs.err
+    ;;
+  bicgprof)   # kernel traces of the even-odd BiCGStab chain in its forms + first differing iteration
+    python scripts/bicg_probe.py --repeat --L 8,8,8,16 2>&1 | tail -18 | tee $out/diff.log
+    python scripts/bicg_probe.py 0 1 2 2>&1 | tail -4 | tee $out/times.log
+    for m in 0 2; do
+      (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof$m -o p -- python $GRAFT_REPO_ROOT/scripts/bicg_probe.py $m --reps 10 2>&1 | tail -3)
+      f=$(find $out/prof$m -name "*kernel_stats.csv" | head -1); echo "== mode $m ($f)"; ls -R $out/prof$m | head -20
+      if [ -n "$f" ]; then head -14 "$f" | cut -d, -f1-6 | sed 's/"//g' | cut -c1-200; cp "$f" $out/kernel_stats_mode$m.csv; fi
+    done
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

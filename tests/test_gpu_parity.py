@@ -726,14 +726,21 @@ def test_fermion_force_matches_oracle(gpu, orc, kind_name, L, bc, r):
     eta_h = host_spinor(orc, lat, kind, 84)
     eta = lq.Fermionfields(lat, kind).upload(eta_h)
     fa = lq.FermiAction(D)
-    S, it = lq.evaluate_FermiAction(fa, Ud, eta, return_info=True)
     So, Xo, Yo, ito, st = orc.fermi_action(okind, Uh, eta_h, L, km, r=r, bc=bc, eps=1e-19)
-    assert st == 0 and abs(S - So) < 1e-9 * abs(So) and abs(it - ito) <= 1
-    assert rel_err(fa._temporary_fermionfields[0].download(), Xo) < 1e-9
-    assert rel_err(fa._temporary_fermionfields[1].download(), Yo) < 1e-9
-    S2 = lq.calc_UdSfdU_(G, fa, Ud, eta)
-    assert abs(S2 - S) < 1e-12 * abs(S)
-    assert rel_err(G.download(), orc.fermion_force(okind, Uh, Xo, Yo, L, km, r=r, bc=bc)) < 1e-8
+    # action_eo_solver = 0: the reference's form, CG on the normal equations (iteration count within one of the oracle's); 1 (default, Wilson): two
+    # even-odd BiCGStab solves, Y = D^-+ eta and X = D^-1 Y -- another route to the same X, Y under the same stopping rule for eta - D^+D X
+    for mode in ((0, 1) if kind == lq.WILSON else (0,)):
+        lat.set_param("action_eo_solver", mode)
+        S, it = lq.evaluate_FermiAction(fa, Ud, eta, return_info=True)
+        assert st == 0 and abs(S - So) < 1e-9 * abs(So) and (mode == 1 or abs(it - ito) <= 1)
+        Xd, Yd = fa._temporary_fermionfields[0].download(), fa._temporary_fermionfields[1].download()
+        assert rel_err(Xd, Xo) < 1e-9 and rel_err(Yd, Yo) < 1e-9
+        res = eta_h - orc.apply_D(okind, Uh, orc.apply_D(okind, Uh, Xd, L, km, r, bc), L, km, r, bc, dagger=True)
+        assert np.vdot(res, res).real < (1e-19 if mode == 1 else 2e-19)     # the reference's stopping rule on the TRUE residual of the normal equations, by the oracle's
+                                                                              # operator (the CG's recursive residual is what it tests: a factor for its drift)
+        S2 = lq.calc_UdSfdU_(G, fa, Ud, eta)
+        assert abs(S2 - S) < 1e-12 * abs(S)
+        assert rel_err(G.download(), orc.fermion_force(okind, Uh, Xo, Yo, L, km, r=r, bc=bc)) < 1e-8
 
 
 def test_fermion_force_is_derivative_of_action_on_device(gpu, orc):

@@ -238,3 +238,51 @@ def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][3], res[1][3])
     for a, c in zip(res[0][2], res[1][2]):
         assert np.array_equal(a, c)
+
+
+def test_evenodd_bicgstab_fused_chain_is_bit_identical_to_the_unfolded_one(lq, orc):
+    """Tunable bicg_fused.  1: the inner products of an iteration come from the epilogue of the Schur operator's second hop, reductions and scalar steps
+    are separate one-block launches; 2 (default): on lattices of <= 1024 chunks per parity they run in the consumers' prologues -- 7 dependent launches
+    per iteration instead of 17.  Same partials, same summation order, same scalar expressions: the same BITS in x, the same iteration count.  0 is
+    the generic chain (separate dot-product kernels, other partial sums): equal to rounding.  All against the oracle's solution."""
+    for L, dagger in (((8, 8, 8, 16), False), ((16, 16, 16, 32), True), ((4, 4, 4, 8), False)):
+        U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+        lat = U.lattice
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
+        Dd = D.adjoint() if dagger else D
+        Dd.method_CG = "bicgstab_evenodd"
+        b = lq.Fermionfields(lat, lq.WILSON)
+        lq.gauss_distribution_fermion_(b, 112)
+        out = {}
+        for mode in (2, 1, 0):
+            lat.set_param("bicg_fused", mode)
+            x = b.similar()
+            it, rr = lq.solve_DinvX_(x, Dd, b, return_info=True)
+            out[mode] = (x.download(), it, rr)
+            assert rr < 1e-19
+        lat.set_param("bicg_fused", 2)
+        assert out[2][1] == out[1][1] and out[2][2] == out[1][2] and np.array_equal(out[2][0], out[1][0]), L      # folded == unfolded, bit for bit
+        assert abs(out[0][1] - out[2][1]) <= 1 and rel_err(out[0][0], out[2][0]) < 1e-10
+        if L[0] <= 8:
+            xo, ito, rro, st = orc.wilson_bicgstab_eo(U.download(), b.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger, eps=1e-19)
+            assert st == 0 and abs(ito - out[2][1]) <= 1 and rel_err(out[2][0], xo) < 1e-9
+    # a solve that converges in the FIRST half step and one whose right-hand side is zero
+    L = (4, 4, 4, 4)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="cold")
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.01, "eps_CG": 1e-6, "MaxCGstep": 50})
+    D.method_CG = "bicgstab_evenodd"
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 7)
+    x = b.similar()
+    it, rr = lq.solve_DinvX_(x, D, b, return_info=True)
+    assert it <= 2 and rr < 1e-6
+    lq.clear_fermion_(b)
+    lq.clear_fermion_(x)
+    it, rr = lq.solve_DinvX_(x, D, b, return_info=True)
+    assert it == 0 and rr == 0.0 and np.abs(x.download()).max() == 0.0
+    D.MaxCGstep = 1
+    D.eps_CG = 1e-30
+    lq.gauss_distribution_fermion_(b, 8)
+    with pytest.raises(lq.NotConverged):
+        lq.solve_DinvX_(x, D, b)
