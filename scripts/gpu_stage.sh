@@ -34,6 +34,13 @@ case $stage in
       if [ -n "$f" ]; then head -14 "$f" | cut -d, -f1-6 | sed 's/"//g' | cut -c1-200; cp "$f" $out/kernel_stats_mode$m.csv; fi
     done
     ;;
+  sweep18)    # workgroup-map / cache-hint sweep of the all-18-reals Dslash (the kernel reference-format configurations take)
+    for set in "xcd_nsub=16 xcd_ysplit=4" "xcd_nsub=32 xcd_ysplit=4" "xcd_nsub=32 xcd_ysplit=8" "xcd_nsub=16 xcd_ysplit=2" "xcd_nsub=8 xcd_ysplit=2" "xcd_nsub=64 xcd_ysplit=8" \
+               "nt_gauge=0" "nt_gauge=3" "nt_store=0" "dslash_block=64"; do
+      args=""; for kv in $set; do args="$args --set $kv"; done
+      python scripts/dslash_probe.py --reps 200 --warm 20 --set gauge_recon=18 $args 2>&1 | tail -1
+    done | tee $out/sweep18.log
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log
