@@ -18,9 +18,10 @@
 #   temporaries   :: HIPLink             similar(U[1]) -- the package's Temporalfields pool (get_temp / unused!) works unchanged on them
 #   x, η, ξ       :: HIPFermion          D :: HIPDirac, fermi_action :: HIPFermiAction
 #
-# The ONE edit in the reference: `Univ` (src/system/universe.jl:41-49) creates the links with Initialize_HIPGaugefields(NC, Nwing, L...;
-# condition = p.initial) instead of Initialize_Gaugefields (that function has no argument to dispatch on).  Nothing else changes
-# (INTEGRATION.md section 3).
+# `Univ` (src/system/universe.jl:41-49) creates the links with Initialize_Gaugefields(NC, Nwing, L...; condition = ...), a function with no argument
+# to dispatch on.  Two ways in (INTEGRATION.md section 3): ONE edit -- write Initialize_HIPGaugefields there -- or NO edit: call
+# LatticeQCDHIP.activate!() once before Univ(p); it adds a method of the package's own Initialize_Gaugefields for four Int extents that is more
+# specific than the package's untyped one and returns device links (deactivate!() removes the redirection, the package's method was never replaced).
 module LatticeQCDHIP
 
 using LinearAlgebra
@@ -28,7 +29,7 @@ using Gaugefields
 using LatticeDiracOperators
 import LinearAlgebra: mul!, dot
 import Base: similar, adjoint
-import Gaugefields: AbstractGaugefields, GaugeAction, substitute_U!, exptU!, Traceless_antihermitian_add!, calc_dSdUμ!,
+import Gaugefields: AbstractGaugefields, GaugeAction, Initialize_Gaugefields, substitute_U!, exptU!, Traceless_antihermitian_add!, calc_dSdUμ!,
     evaluate_GaugeAction, initialize_TA_Gaugefields, gauss_distribution!, calc_smearedU, println_verbose_level1,
     println_verbose_level2, println_verbose_level3, get_myrank, calculate_Plaquette, load_BridgeText!, load_gaugefield!
 import LatticeDiracOperators: Dirac_operator, DdagD_operator, FermiAction, Initialize_pseudofermion_fields,
@@ -36,7 +37,7 @@ import LatticeDiracOperators: Dirac_operator, DdagD_operator, FermiAction, Initi
     clear_fermion!, substitute_fermion!, add_fermion!, gauss_distribution_fermion!, Z4_distribution_fermi!,
     AbstractFermionfields_4D
 
-export Initialize_HIPGaugefields, HIPLattice, HIPLink, HIPTALink, HIPFermion, HIPDirac, HIPFermiAction, reunitarize!
+export Initialize_HIPGaugefields, HIPLattice, HIPLink, HIPTALink, HIPFermion, HIPDirac, HIPFermiAction, reunitarize!, activate!, deactivate!
 
 const LIB = get(ENV, "LQCD_HIP_LIB", joinpath(@__DIR__, "..", "latticeqcd.jl_amd", "csrc", "liblqcd_hip.so"))
 
@@ -155,6 +156,24 @@ function Initialize_HIPGaugefields(NC, Nwing, L...; condition = "cold", lattice 
         error("condition = $condition is not supported")
     end
     return views(HIPLink, g)
+end
+# `Univ` unchanged (universe.jl:41-49 calls Initialize_Gaugefields(NC, Nwing, L...; condition = p.initial | "cold") with Int arguments): after
+# activate!() that call lands here for NC = 3 and four extents -- a method of the PACKAGE's function whose positional types (Int, Int, four Ints) are
+# more specific than the package's own untyped signature, so dispatch prefers it; every other call (other NC, Dim = 2, MPI keywords) is handed on to
+# the package's method through invoke.  The redirection is a method table entry, not module state: deactivate!() deletes it.
+function activate!()
+    @eval function Gaugefields.Initialize_Gaugefields(NC::Int, Nwing::Int, NX::Int, NY::Int, NZ::Int, NT::Int; condition = "cold", kwargs...)
+        if NC == 3 && isempty(kwargs) && condition in ("cold", "hot")
+            return Initialize_HIPGaugefields(NC, Nwing, NX, NY, NZ, NT; condition = condition)
+        end
+        return invoke(Gaugefields.Initialize_Gaugefields, Tuple{Any,Any,Vararg{Any}}, NC, Nwing, NX, NY, NZ, NT; condition = condition, kwargs...)
+    end
+    return nothing
+end
+function deactivate!()
+    m = which(Gaugefields.Initialize_Gaugefields, Tuple{Int,Int,Int,Int,Int,Int})
+    m.module === @__MODULE__() && Base.delete_method(m)
+    return nothing
 end
 # Uold = similar(U) (standardHMC.jl:32), dSdU = similar(U) (standardMD.jl:58): a fresh four-direction field
 function similar(U::Vector{HIPLink})::Vector{HIPLink}

@@ -628,6 +628,11 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
     }
 }
 
+#ifndef LQCD_SDIR_GLDS
+#define LQCD_SDIR_GLDS 0        // 1 (fp64 build, experiment of round 4): the backward neighbour's spinor travels global -> LDS with gfx950's asynchronous copy while the
+#endif                          // forward hop runs.  Bit-identical, and NO faster (0.3472 vs 0.3480 ms at 32^3x64, profiles/r04_glds_ab.log): with both hops' spinor
+                                // operands in flight at unchanged occupancy the kernel time does not move -- the launch is bound by the fabric's miss traffic
+                                // (5.4 TB/s of the ~6.3 TB/s achievable on 1.18x the compulsory bytes), not by a workgroup's dependent round trips
 // ------------------------------------------------------------------------------------------ Wilson, direction-split, scalar addressing
 // dslash_pipe = 2: variant 1's schedule (one workgroup per chunk, hardware dispatch order, the compiler's own hop-by-hop schedule) on the
 // persistent kernel's addressing: compact argument struct, t / z / y-chunk wave-uniform, scalar base + 32-bit lane offset + immediate for every
@@ -686,6 +691,19 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         cd sF[NS], uF[9];
         load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
         load_link_any<R12, false>(uF, boff(a.gauge + (s.p ? gpar : 0), s.uf), 64);
+#if LQCD_SDIR_GLDS
+        // The backward neighbour's spinor goes global -> LDS with the asynchronous copy of gfx950 (global_load_lds_dwordx4: wave-uniform LDS base +
+        // 16 B x lane, exactly the [component][lane] slab this wave owns in the partial-sum area, which nobody touches before the hops are done):
+        // both hops' spinor operands are in flight from the start at NO register cost -- the second dependent memory round trip of a workgroup
+        // shrinks to the backward link (the "both hops in flight" of variant 8 without its drop to 2 waves per SIMD).
+        {
+            const real2* gb = boff(s.p ? a.in[0] : a.in[1], s.nb);
+#pragma unroll
+            for (int j = 0; j < NS; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + co12(FB + j)),
+                                                 (__attribute__((address_space(3))) void*)(&part[MU][j][0]), 16, 0, 0);
+        }
+#endif
         finish_link<R12>(uF);
         project_regs<MU, SF>(h0, h1, sF);
         pipe_sign(h0, h1, s.sf);
@@ -696,8 +714,15 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     __builtin_amdgcn_sched_barrier(0);      // the backward operands take the registers of the forward ones (3 waves per SIMD)
     {
         cd sB[NS], uB[9];
+#if LQCD_SDIR_GLDS
+        load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS copies (issued long ago) and the link
+#pragma unroll
+        for (int j = 0; j < NS; j++) sB[j] = ld(&part[MU][j][lane]);
+#else
         load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
         load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+#endif
         finish_link<R12>(uB);
         project_regs<MU, -SF>(h0, h1, sB);
         pipe_sign(h0, h1, s.sb);

@@ -42,7 +42,7 @@ PACKAGE_GENERIC = {
     "Verbose_print": "Gaugefields' logger, no field argument",
     "ILDG": "Gaugefields' reader object, no field argument",
     "loadU": "JLD loader: replaces U by a host field -- not available on the HIP path (documented in INTEGRATION.md)",
-    "Initialize_Gaugefields": "THE one edit in Univ: Initialize_HIPGaugefields (the function has no argument to dispatch on)",
+    "Initialize_Gaugefields": "no argument to dispatch on: ONE edit in Univ (Initialize_HIPGaugefields) or none -- activate!() adds a more specific method of the package's function (checked below)",
 }
 # generics the binding specialises: name -> list of accepted signatures (positional argument types as written in the binding)
 EXPECTED = {
@@ -254,3 +254,21 @@ def test_binding_keeps_no_module_level_mutable_state():
         if body.startswith("function") or text[text.rfind("\n", 0, i) + 1:i].startswith("function"):
             body = text[i:text.index("\nend", i)]
         assert body.count("ccall") == 1 and export + "," in body, generic
+
+
+def test_univ_runs_unchanged_after_activate():
+    """universe.jl:41-49 calls Initialize_Gaugefields(NC, Nwing, L...; condition = ...) -- nothing to dispatch on.  activate!() defines a method of
+    the package's OWN function for (Int, Int, four Int extents; condition) that returns device links and hands every other call on with invoke; the
+    package's method is never replaced and deactivate!() deletes the redirection.  Here: the four call sites of the inventory use exactly the one
+    keyword the method names, the method is defined INTO Gaugefields, returns Initialize_HIPGaugefields' value for NC = 3, and falls through otherwise."""
+    inv = json.load(open(INVENTORY, encoding="utf-8"))
+    sites = [c for c in inv["calls"] if c["name"] == "Initialize_Gaugefields"]
+    assert len(sites) == 4 and all(c["file"] == "src/system/universe.jl" and c["kwargs"] == ["condition"] and c["nargs"] == 3 for c in sites)   # NC, Nwing, L...
+    text = binding_text()
+    i = text.index("function activate!()")
+    body = text[i:text.index("function deactivate!()")]
+    assert re.search(r"@eval function Gaugefields\.Initialize_Gaugefields\(NC::Int, Nwing::Int, NX::Int, NY::Int, NZ::Int, NT::Int; condition = \"cold\", kwargs\.\.\.\)", body)
+    assert "return Initialize_HIPGaugefields(NC, Nwing, NX, NY, NZ, NT; condition = condition)" in body
+    assert "invoke(Gaugefields.Initialize_Gaugefields, Tuple{Any,Any,Vararg{Any}}" in body            # everything else: the package's own method
+    assert "Base.delete_method" in text[text.index("function deactivate!()"):text.index("function deactivate!()") + 400]
+    assert imported_names(text).get("Initialize_Gaugefields") == "Gaugefields"
