@@ -83,7 +83,7 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * non-temporal output stores), lds_pad_kb, persist_per_cu, dslash_pipe (forms of the Wilson r = 1 direction-split kernel on lattices whose z-planes are whole chunks;
  * all bit-identical: 2 [default]: scalar (wave-uniform) addressing, one workgroup per chunk, 12-real fp64 links only; 1: persistent workgroups with the next chunk's
  * loads in flight across the barrier, per-XCD in-order queue -- pipe_per_cu / pipe_grid / pipe_min_chunks shape its grid; 3: pipe_chunks_per_wg consecutive chunks per
- * workgroup, pipelined; 0: plain variant 1.  Forms 1 and 3 measured slower, DESIGN.md section 2 "Round 3"), mixed_pair32 (1 [default]: the mixed-precision Wilson
+ * workgroup, pipelined; 0: plain variant 1.  Forms 1 and 3 measured slower, LABNOTES.md section 2 "Round 3"), mixed_pair32 (1 [default]: the mixed-precision Wilson
  * solvers use the fp32 site-pair kernel on unpartitioned lattices with T % 4 == 0; read-only pair32_active), stag_both (1: the staggered split kernel issues the loads of both hops back to back);
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
  * mixed-precision CG; 2: the same, and every rational entry solves all its poles with lqcd_solve_multishift_mixed_cg -- measured slower than the fp64

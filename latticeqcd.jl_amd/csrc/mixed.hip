@@ -610,7 +610,7 @@ extern "C" int lqcd_solve_mixed_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
 //            (a one-shift multi-shift CG: the Krylov space of A, stopped when the shifted residual is below its target),
 //            x_j += |r_j| e, until |r_j|^2 < eps.  A correction that fails to halve the residual is redone in fp64.
 // Worth it when the target is loose enough for phase 1 to do most of the work (MD-force tolerances); at 1e-10 relative and tighter
-// the per-shift corrections cost about what the shared Krylov space saved.  iters: fp32 iterations of phase 1 + all
+// the per-shift corrections cost about what the shared Krylov space saved (LABNOTES.md).  iters: fp32 iterations of phase 1 + all
 // corrections (+ fp64 iterations of fall-backs); outer: number of fp32 correction solves; final_rr: the largest true residual.
 extern "C" int lqcd_solve_multishift_mixed_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spinor_t* xs, lqcd_spinor_t b, const double* sigma, int ns,
                                               double eps, int maxiter, double inner_tol, int* iters, int* outer, double* final_rr) {

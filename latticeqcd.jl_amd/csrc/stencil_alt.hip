@@ -1,6 +1,6 @@
 // stencil_alt.hip -- the opt-in Wilson Dslash variants (tunable dslash_variant = 2..8): alternatives to the default direction-split
 // kernel of stencil.hip that were built, verified (4-8: bit-identical to variant 1; 2, 3: to the parity tolerance) and MEASURED -- none beats
-// variant 1 (DESIGN.md section 2 has the table; profiles/r0*_variant*.log the numbers).  They stay reachable for A/B runs and as
+// variant 1 (LABNOTES.md section 2 has the table; profiles/r0*_variant*.log the numbers).  They stay reachable for A/B runs and as
 // the record of what was tried; fp64 only.  Shared device helpers: stencil_common.h.
 #include "stencil_common.h"
 

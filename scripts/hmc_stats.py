@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Long HMC streams on the device for the statistical parity table of DESIGN.md section 4.
+"""Long HMC streams on the device for the statistical parity table of LABNOTES.md section 4.
 usage: hmc_stats.py [--ntraj 300] [--therm 30] [--actions a,b,...] [--out file.json]"""
 import argparse, json, os, sys, time
 import numpy as np
