@@ -158,6 +158,18 @@ def main():
                 "md_step_ms": nsw * (t_pu + 2 * t_up) + t_ff + t_ta,
                 "md_step_mixed_precision_solver_ms": nsw * (t_pu + 2 * t_up) + t_ffm + t_ta,
                 "note": "host<->device traffic per MD step: none (the reference path would move 1.2 GB of links + 2 spinors)"})
+    # ---- configs[3]: the same force evaluation with the Wilson-clover operator (even-odd solves through the inverse clover blocks vs CG)
+    Dc = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": 1.0, "eps_CG": 1e-16})
+    fac = lq.FermiAction(Dc)
+    lq.sample_pseudofermions_(eta, U, fac, X)
+    t_c1 = tk(lambda: lq.calc_UdSfdU_(G, fac, U, eta), reps=2)
+    it_c1 = lq.evaluate_FermiAction(fac, U, eta, return_info=True)[1]
+    lat.set_param("action_eo_solver", 0)
+    t_c0 = tk(lambda: lq.calc_UdSfdU_(G, fac, U, eta), reps=2)
+    it_c0 = lq.evaluate_FermiAction(fac, U, eta, return_info=True)[1]
+    lat.set_param("action_eo_solver", 1)
+    res.append({"config": "32^3x64 Wilson-clover (c_sw = 1) force evaluation calc_UdSfdU!, eps 1e-16", "two_evenodd_bicgstab_solves_ms": t_c1, "iterations": it_c1,
+                "cg_normal_equations_ms": t_c0, "cg_iterations": it_c0})
     for o in (U, D, X, Y, G, p, eta):
         o.close()
     # ---- configs[4] geometry on one GPU: 48^3x96 staggered Dslash and CG (fp64)

@@ -41,6 +41,11 @@ case $stage in
       python scripts/dslash_probe.py --reps 200 --warm 20 --set gauge_recon=18 $args 2>&1 | tail -1
     done | tee $out/sweep18.log
     ;;
+  round)      # full GPU suite, then the round's rocprofv3 evidence (scripts/gpu_profile_round.sh) and the configuration timings
+    timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -20 | tee $out/pytest.log
+    bash scripts/gpu_profile_round.sh ${2:-r04} 2>&1 | tail -5
+    timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; tail -3 $out/bench_configs.log | cut -c1-600
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

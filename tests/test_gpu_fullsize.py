@@ -272,3 +272,33 @@ def test_staggered_rhmc_48x48x48x96_short_trajectory(lq):
                                                   {"Dirac_operator": "Staggered", "mass": 0.1, "eps_CG": 1e-14, "MaxCGstep": 5000}],
                             [{"Nf": 2}, {"Nf": 1}], dtau=0.01, steps=2, halve=False)
     print("48^3x96 staggered 2+1 dH =", dH)
+
+
+def test_action_solve_32x32x32x64_evenodd_route_against_cg_and_oracle_residual(lq, orc_all_threads):
+    """configs[3]'s lattice, plain Wilson: evaluate_FermiAction / calc_UdSfdU! solve (D^+D) X = eta as Y = D^-+ eta, X = D^-1 Y through the even-odd
+    BiCGStab (action_eo_solver = 1; 16384 chunks per parity: inner products from the Schur operator's epilogue, reductions as separate launches --
+    the form the 1024-chunk tests do not reach).  Same X, Y and S_f as the CG on the normal equations, fewer than half its operator applications,
+    and the reference's stopping rule on the residual it is stated for, recomputed by the oracle."""
+    orc = orc_all_threads
+    L = (32, 32, 32, 64)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    eps = 1e-16
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "boundarycondition": BC, "eps_CG": eps})
+    fa = lq.FermiAction(D)
+    eta = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(eta, 113)
+    out = {}
+    for mode in (1, 0):
+        lat.set_param("action_eo_solver", mode)
+        S, it = lq.evaluate_FermiAction(fa, U, eta, return_info=True)
+        out[mode] = (S, it, fa._temporary_fermionfields[0].download(), fa._temporary_fermionfields[1].download())
+    lat.set_param("action_eo_solver", 1)
+    assert abs(out[1][0] - out[0][0]) < 1e-10 * abs(out[0][0])
+    assert 2 * out[1][1] < out[0][1]                                   # iterations of 2 Schur applications (= 2 Dslash) each, both routes
+    assert rel_err(out[1][2], out[0][2]) < 1e-9 and rel_err(out[1][3], out[0][3]) < 1e-9
+    etah = eta.download()
+    for mode in (1, 0):
+        res = etah - orc.wilson_D(Uh, orc.wilson_D(Uh, out[mode][2], L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True)
+        assert np.vdot(res, res).real < (eps if mode == 1 else 2 * eps), (mode, np.vdot(res, res).real)
