@@ -625,6 +625,8 @@ struct StencilCall {
     const double2* dot_z[2] = {nullptr, nullptr};
     double* dot_partial = nullptr;
     int dot_conj = 0;             // 1: <out, z> (the imaginary part changes sign)
+    int clover_on_hop = 0;        // 1 (fp64 direction-split kernel, r = 1): `clover` holds packed blocks that are applied to the HOP SUM, out = a xin + b C (H in) -- the
+                                  // inverse clover blocks of the even-odd Wilson-clover solver; the diagonal term stays plain
 };
 // slots of the device scalar block d_scal used by the solvers
 enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18 };

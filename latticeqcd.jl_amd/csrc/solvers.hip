@@ -873,8 +873,10 @@ __global__ __launch_bounds__(UB) void bicgf_p(BicgF a, double2* __restrict__ p, 
 
 // xe = M^-1 rhs on the even sites, M = 1 - k^2 H_eo H_oe (dagger: H -> H^+).  w[0..5] = r, r0, p, v, s, t; to: an odd-parity work vector.
 // Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and iteration count as bicgstab_core.
+// Ai != nullptr: Wilson-clover, M = 1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe with the packed inverse blocks applied to the hop sums inside the two hops
+// (StencilCall::clover_on_hop) -- still two launches per M, no intermediate field.
 static int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
-                              int maxiter, int* iters, double* final_rr) {
+                              int maxiter, int* iters, double* final_rr, const double2* Ai = nullptr) {
     lqcd_ctx_s* c = op->ctx;
     const double k = op->km;
     const size_t n = xe.elems, bytes = n * sizeof(double2);
@@ -888,11 +890,13 @@ static int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* r
     double* P3 = P2 + (size_t)3 * nbs;          // |r|^2, <r0, r>         [nbk x 3]
     const double* skip = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
     auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj) -> int {
-        StencilCall s1 = make_hop_call(op, to, in, nullptr, 0.0, 1.0, dg);      // t_o = H_oe in
+        StencilCall s1 = make_hop_call(op, to, in, nullptr, 0.0, 1.0, dg);      // t_o = [A_oo^-1] H_oe in
         s1.skip_flag = skip;
+        if (Ai) { s1.clover = Ai; s1.clover_on_hop = 1; }
         LQCHK(stencil_apply(c, s1));
-        StencilCall s2 = make_hop_call(op, out, to, in, 1.0, -k * k, dg);       // out = in - k^2 H_eo t_o
+        StencilCall s2 = make_hop_call(op, out, to, in, 1.0, -k * k, dg);       // out = in - k^2 [A_ee^-1] H_eo t_o
         s2.skip_flag = skip;
+        if (Ai) { s2.clover = Ai; s2.clover_on_hop = 1; }
         if (z) { s2.dot_z[0] = z->data; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
         return stencil_apply(c, s2);
     };
@@ -1172,7 +1176,7 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
         wsp[i] = wi;
     }
     // plain Wilson r = 1 on an unpartitioned lattice: the chain whose inner products come from the Schur operator's epilogue (bicgstab_eo_wilson)
-    const bool fused = !clov && c->tun.bicg_fused >= 1 && op->r == 1.0 && c->tun.dslash_variant == 1 && !any_partitioned(c) && !c->has_comm && c->geom.Vh % 64 == 0;
+    const bool fused = c->tun.bicg_fused >= 1 && op->r == 1.0 && c->tun.dslash_variant == 1 && !any_partitioned(c) && !c->has_comm && c->geom.Vh % 64 == 0;
     lqcd_spinor_s* rhs = pool.get(op->kind, LQCD_EVEN);
     lqcd_spinor_s* te = clov ? pool.get(op->kind, LQCD_EVEN) : nullptr;
     lqcd_spinor_s* to = pool.get(op->kind, LQCD_ODD);
@@ -1213,7 +1217,7 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
                 return clover_apply_parity(c, Ai, 0, out, te->data, -k * k, in, 1.0);        // out = in - k^2 A_ee^-1 t_e
             };
         }
-        const int sc = fused ? bicgstab_eo_wilson(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr)
+        const int sc = fused ? bicgstab_eo_wilson(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr, clov ? Ai : nullptr)
                              : bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
         // the odd half (also on non-convergence, so x is a consistent best effort)
         if (!clov) {

@@ -158,7 +158,10 @@ __device__ inline void clover_rows(cd (&out)[3], const real2* __restrict__ a, co
 #else
 #define LQCD_DS_BOUNDS __launch_bounds__(256)
 #endif
-template <bool DAG, bool R12 = false, bool CLOV = false, bool DOT = false>
+// CINV (even-odd Wilson-clover solver): the packed matrix k.clover (the INVERSE clover blocks of the output parity) is applied to the HOP SUM,
+// out = a xin + b C (H in), where CLOV applies it to the diagonal term -- the Schur operator 1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe becomes two launches
+// with no intermediate field (every wave rebuilds the 12 summed components from the four direction partials: 48 LDS reads instead of 12).
+template <bool DAG, bool R12 = false, bool CLOV = false, bool DOT = false, bool CINV = false>
 __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
     __shared__ real2 part[4][12][64];  // 48 KiB
     __shared__ double red[DOT ? 12 : 4];
@@ -229,12 +232,24 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
     }
     __syncthreads();
     real nrm = 0.0, dre = 0.0, dim = 0.0;
+    cd hs[CINV ? 3 : 1];
+    if constexpr (CINV) if (valid) {        // this wave's rows of C (H in): all 12 summed components, then the packed 6x6 blocks
+        cd v12[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
+            v12[j] = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        }
+        const real2* __restrict__ ca = k.clover + (((size_t)p * k.g.nch + (size_t)(i >> 6)) * 36) * 64 + (i & 63);
+        if (w & 1) clover_rows<1>(hs, ca, v12, w >= 2);
+        else clover_rows<0>(hs, ca, v12, w >= 2);
+    }
     if (valid) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
             const int j = 3 * w + cc;
             const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
-            cd s = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+            cd s = CINV ? hs[cc] : mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
             cd v = k.b * s;
             v = mk(fma(k.a, xv[cc].re, v.re), fma(k.a, xv[cc].im, v.im));
             if (LQCD_UPD_PREFETCH) emit_pre(k, p, co12(j) + sp12_off(i), v, nrm, al_upd, rv[cc]);
@@ -1416,9 +1431,14 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             set_error("stencil: dot mode exists in the fp64 build only");
             return LQCD_ERR_UNSUPPORTED;
 #else
-            if (k.clover || s.r != 1.0) { set_error("stencil: dot mode needs the plain Wilson r = 1 kernel"); return LQCD_ERR_UNSUPPORTED; }
+            if ((k.clover && !s.clover_on_hop) || s.r != 1.0) { set_error("stencil: dot mode needs the Wilson r = 1 kernel without a diagonal clover term"); return LQCD_ERR_UNSUPPORTED; }
             dim3 grid(k.nblocks), block(256);
-            if (k.gauge12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {      // the scalar-addressing form
+            if (s.clover_on_hop) {      // even-odd clover solver: inverse blocks on the hop sum + the inner-product epilogue
+                if (k.gauge12) { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true, true>), grid, block, pad, c->stream, k);
+                                 else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, true, true>), grid, block, pad, c->stream, k); }
+                else { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, true, true>), grid, block, pad, c->stream, k);
+                       else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, true, true>), grid, block, pad, c->stream, k); }
+            } else if (k.gauge12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {      // the scalar-addressing form
                 PipeArgs a = make_pipe_args(c, k, s);
                 const bool ntb = (k.nt & 1) != 0;
                 if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, true, true>), grid, block, 0, c->stream, a);
@@ -1432,6 +1452,18 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                 if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, true>), grid, block, pad, c->stream, k);
                 else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, true>), grid, block, pad, c->stream, k);
             }
+#endif
+        } else if (s.kind == LQCD_WILSON && s.clover_on_hop) {      // even-odd clover solver: out = a xin + b C (H in), C = the inverse clover blocks of the output parity
+#ifdef LQCD_F32
+            set_error("stencil: the clover-on-hop form exists in the fp64 build only");
+            return LQCD_ERR_UNSUPPORTED;
+#else
+            if (!k.clover || s.r != 1.0) { set_error("stencil: clover-on-hop needs the packed blocks and r = 1"); return LQCD_ERR_UNSUPPORTED; }
+            dim3 grid(k.nblocks), block(256);
+            if (k.gauge12) { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, false, true>), grid, block, pad, c->stream, k);
+                             else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, false, true>), grid, block, pad, c->stream, k); }
+            else { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, false, true>), grid, block, pad, c->stream, k);
+                   else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, false, true>), grid, block, pad, c->stream, k); }
 #endif
         } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr) &&
                    (c->tun.dslash_pipe != 2 || (k.gauge12 && !kF32Build))) {      // the scalar-addressing kernel pays with the fp64 12-real links only: its 18-real

@@ -17,7 +17,8 @@ reps = int(args[args.index("--reps") + 1]) if "--reps" in args else 20
 modes = [int(a) for a in args if a.isdigit() and len(a) == 1] or [2]
 U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
 lat = U.lattice
-D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.141139, "eps_CG": 1e-16, "MaxCGstep": 3000})
+csw = float(args[args.index("--csw") + 1]) if "--csw" in args else 0.0
+D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover" if csw else "Wilson", "Clover_coefficient": csw, "κ": 0.141139, "eps_CG": 1e-16, "MaxCGstep": 3000})
 D.method_CG = "bicgstab_evenodd"
 b = lq.Fermionfields(lat, lq.WILSON)
 lq.gauss_distribution_fermion_(b, 112)

@@ -20,7 +20,7 @@ case $stage in
     cat $out/pytest.log
     ;;
   bicg)       # fused even-odd BiCGStab chain, action solves through it; config timings
-    timeout 900 python -m pytest tests/test_gpu_solver_edges.py tests/test_gpu_clover.py tests/test_gpu_md.py tests/test_gpu_hmc_partitioned.py -q 2>&1 | tail -15 > $out/pytest.log
+    timeout 900 python -m pytest tests/test_gpu_solver_edges.py tests/test_gpu_clover.py tests/test_gpu_md.py tests/test_gpu_hmc_partitioned.py tests/test_gpu_fullsize.py -q 2>&1 | tail -15 > $out/pytest.log
     timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cg_persist.py tests/test_gpu_graph.py tests/test_gpu_halo_fuse.py -q 2>&1 | tail -15 >> $out/pytest.log
     cat $out/pytest.log
     timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; cut -c1-1500 $out/bench_configs.log; tail -5 $out/bench_configs.err
@@ -45,6 +45,12 @@ case $stage in
     timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -20 | tee $out/pytest.log
     bash scripts/gpu_profile_round.sh ${2:-r04} 2>&1 | tail -5
     timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; tail -3 $out/bench_configs.log | cut -c1-600
+    ;;
+  cloverprof) # kernel stats of the even-odd Wilson-clover BiCGStab at 32^3x64, fused and generic chain
+    for m in 0 2; do
+      (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof$m -o p -- python $GRAFT_REPO_ROOT/scripts/bicg_probe.py $m --reps 3 --L 32,32,32,64 --csw 1.0 2>&1 | grep bicg_fused)
+      f=$(find $out/prof$m -name "*kernel_stats.csv" | head -1); echo "== mode $m"; head -9 "$f" | cut -d, -f1-4 | sed 's/"//g' | cut -c1-150
+    done
     ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3

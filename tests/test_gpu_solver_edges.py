@@ -245,10 +245,11 @@ def test_evenodd_bicgstab_fused_chain_is_bit_identical_to_the_unfolded_one(lq, o
     are separate one-block launches; 2 (default): on lattices of <= 1024 chunks per parity they run in the consumers' prologues -- 7 dependent launches
     per iteration instead of 17.  Same partials, same summation order, same scalar expressions: the same BITS in x, the same iteration count.  0 is
     the generic chain (separate dot-product kernels, other partial sums): equal to rounding.  All against the oracle's solution."""
-    for L, dagger in (((8, 8, 8, 16), False), ((16, 16, 16, 32), True), ((4, 4, 4, 8), False)):
+    for L, dagger, csw in (((8, 8, 8, 16), False, 0.0), ((16, 16, 16, 32), True, 0.0), ((4, 4, 4, 8), False, 0.0), ((8, 8, 8, 16), True, 1.3), ((16, 16, 16, 32), False, 1.0)):
         U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
         lat = U.lattice
-        D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
+        # csw != 0: Wilson-clover, the inverse clover blocks applied to the hop sums inside the Schur operator's two launches (forms 1, 2) or by separate passes (form 0)
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover" if csw else "Wilson", "Clover_coefficient": csw, "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
         Dd = D.adjoint() if dagger else D
         Dd.method_CG = "bicgstab_evenodd"
         b = lq.Fermionfields(lat, lq.WILSON)
@@ -264,7 +265,11 @@ def test_evenodd_bicgstab_fused_chain_is_bit_identical_to_the_unfolded_one(lq, o
         assert out[2][1] == out[1][1] and out[2][2] == out[1][2] and np.array_equal(out[2][0], out[1][0]), L      # folded == unfolded, bit for bit
         assert abs(out[0][1] - out[2][1]) <= 1 and rel_err(out[0][0], out[2][0]) < 1e-10
         if L[0] <= 8:
-            xo, ito, rro, st = orc.wilson_bicgstab_eo(U.download(), b.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger, eps=1e-19)
+            Uh = U.download()
+            if csw:
+                xo, ito, rro, st = orc.wilson_clover_bicgstab_eo(Uh, orc.clover_build(Uh, L, KAPPA, csw), b.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger, eps=1e-19)
+            else:
+                xo, ito, rro, st = orc.wilson_bicgstab_eo(Uh, b.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger, eps=1e-19)
             assert st == 0 and abs(ito - out[2][1]) <= 1 and rel_err(out[2][0], xo) < 1e-9
     # a solve that converges in the FIRST half step and one whose right-hand side is zero
     L = (4, 4, 4, 4)
