@@ -103,7 +103,14 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * interior -> exterior in order on one stream: no overlap and no cross-queue join, the faster one when the exchange is short), halo_tuned_us0..3 (read-only: the
  * times that choice was made from), halo_fuse (bit 1 [default 2]: the
  * exterior of D p packs the faces D^+ needs and the CG update packs the new search direction -- no separate pack launches; bit 0: the exterior's last
- * block sums the |.|^2 partials -- measured slower, off), staple_recon (1 [default]: the staple sweep reads two rows of links known to be on the group). */
+ * block sums the |.|^2 partials -- measured slower, off), staple_recon (1 [default]: the staple sweep reads two rows of links known to be on the group);
+ * round 4: gauge_delta (1 [default]: a field that fails the 12-real gate but lies within 1e-9 of the group -- the reference's text / ILDG configurations -- is read by the
+ * scalar-addressing Wilson kernel as rows 0, 1 in fp64 + the fp32 deviation of row 2, 128 B per link; results equal the 18-real kernel's to fp64 rounding; recon_active reads 2),
+ * dslash_s18 (1 [default]: the scalar-addressing kernel also on the 18 stored reals), bicg_fused (even-odd BiCGStab of the Wilson / Wilson-clover operator: 2 [default] inner
+ * products from the Schur operator's epilogue and, up to 1024 chunks per parity, reductions and scalar steps in the consumers' prologues; 1 the same with separate reduction
+ * launches -- bit-identical to 2; 0 the generic chain), action_eo_solver (1 [default]: lqcd_fermi_action / lqcd_calc_UdSfdU / lqcd_action_* solve the Wilson(-clover) normal
+ * equations as two even-odd BiCGStab solves under the reference's stopping rule; 0: CG), lazy_links (1 [default]: the per-direction link-call triples are recorded and fused,
+ * see lqcd_link_*; read-only lazy_open, lazy_deferred). */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
 int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);
 

@@ -214,15 +214,27 @@ static void fill_blocks(const double2* dst[2], lqcd_spinor_s* s) {
 
 // opt-in 12-real links for the Wilson r = 1 split kernel (tunable gauge_recon = 12): lazily (re)built, used only when every
 // link of the current field is unitary to 1e-14, otherwise the 18-real field is read as usual
-static const double2* recon12_links(lqcd_op_s* op) {
+static const double2* recon12_links(lqcd_op_s* op, int* delta = nullptr) {
     lqcd_ctx_s* c = op->ctx;
     c->tun.recon_active = 0;
+    if (delta) *delta = 0;
     if (c->tun.gauge_recon != 12) return nullptr;
     if (op->kind == LQCD_WILSON && (op->r != 1.0 || (c->tun.dslash_variant != 1 && c->tun.dslash_variant < 4))) return nullptr;   // only the direction-split kernels
     if (op->kind == LQCD_STAGGERED && !(c->tun.dslash_variant >= 1 && c->tun.dslash_variant <= 8)) return nullptr;
-    if (gauge_ensure_recon12(op->gauge) != LQCD_OK || !op->gauge->recon_ok) return nullptr;
-    c->tun.recon_active = 1;
-    return op->gauge->data12;
+    if (gauge_ensure_recon12(op->gauge) != LQCD_OK) return nullptr;
+    if (op->gauge->recon_ok) {
+        c->tun.recon_active = 1;
+        return op->gauge->data12;
+    }
+    // not on the group to 1e-14 (a reference-format configuration): rows 0, 1 + the fp32 deviation of row 2, for the launches that can read it
+    // (the scalar-addressing Wilson kernel; stencil.hip declines for the others and reads the 18 stored reals)
+    if (delta && c->tun.gauge_delta && op->kind == LQCD_WILSON && c->tun.dslash_variant == 1 && c->tun.dslash_pipe == 2 && op->gauge->recon_dev <= 1e-9 &&
+        gauge_ensure_recon12d(op->gauge) == LQCD_OK && op->gauge->delta_ok) {
+        *delta = 1;
+        c->tun.recon_active = 2;
+        return op->gauge->data12d;
+    }
+    return nullptr;
 }
 
 // out = D in  /  D^+ in on FULL spinors.  Wilson-clover: A follows the links lazily (rebuilt here when the field's version moved;
@@ -242,7 +254,7 @@ int make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dag
     s.dagger = dagger;
     s.parity_mode = 2;
     s.norm_partial = nullptr;
-    s.gauge12 = recon12_links(op);
+    s.gauge12 = recon12_links(op, &s.gauge12_delta);
     if (op->csw != 0.0 && op->clover && op->clover_tmp) {
         LQCHK(op_refresh_clover(op));
         if (op->r == 1.0 && op->ctx->tun.dslash_variant == 1 && op->ctx->tun.clover_fused) {
@@ -278,7 +290,7 @@ StencilCall make_hop_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, 
     s.dagger = dagger;
     s.parity_mode = out->subset == LQCD_EVEN ? 0 : 1;
     s.norm_partial = nullptr;
-    s.gauge12 = recon12_links(op);
+    s.gauge12 = recon12_links(op, &s.gauge12_delta);
     return s;
 }
 

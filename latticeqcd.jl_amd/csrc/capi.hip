@@ -301,6 +301,8 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "pipe_min_chunks")) return &c->tun.pipe_min_chunks;
     if (!strcmp(key, "lazy_links")) return &c->tun.lazy_links;
     if (!strcmp(key, "bicg_fused")) return &c->tun.bicg_fused;
+    if (!strcmp(key, "gauge_delta")) return &c->tun.gauge_delta;
+    if (!strcmp(key, "dslash_s18")) return &c->tun.dslash_s18;
     if (!strcmp(key, "action_eo_solver")) return &c->tun.action_eo_solver;
     return nullptr;
 }

@@ -268,6 +268,7 @@ extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
     if (lqcd::ctx_is_live(g->ctx)) (void)lqcd::links_flush_of(g);      // recorded link operations may name this field: they run before its storage goes
     (void)hipFree(g->data);
     (void)hipFree(g->data12);
+    (void)hipFree(g->data12d);
     delete g;
     return LQCD_OK;
 }
@@ -457,6 +458,66 @@ int gauge_ensure_recon12(lqcd_gauge_s* g) {
     g->recon_dev = dev;
     if (g->recon_ok) g->unitary_version = g->version;
     g->version12 = g->version;
+    return LQCD_OK;
+}
+
+// "12 + delta" copy: words 0..5 = rows 0, 1; word 6 = (delta_0, delta_1), word 7 = (delta_2, 0) as fp32 complex pairs, delta = row 2 - conj(row 0 x row 1)
+// with the cross product formed by the SAME fma sequence the kernels use (stencil_common.h recon_row2); *maxdev: max |delta| (bit pattern, see above)
+__global__ __launch_bounds__(256) void gauge_compress12d(Geom g, const double2* __restrict__ src, double2* __restrict__ dst, unsigned long long* maxdev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y >> 2, mu = blockIdx.y & 3;
+    double dev = 0.0;
+    if (i < g.Vh) {
+        const size_t so = glink_off(g, p, mu, i);
+        const size_t d_o = ((((size_t)p * g.nch + (size_t)(i >> 6)) * 4 + mu) * 8) * 64 + (i & 63);
+        const int Gs = glink_stride(g);
+        cd u[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) u[e] = ld(src + so + (size_t)e * Gs);
+#pragma unroll
+        for (int e = 0; e < 6; e++) st(dst + d_o + (size_t)e * 64, u[e]);
+        float dl[6];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+            const cd a = u[b1], bb = u[3 + b2], c = u[b2], d = u[3 + b1];
+            double wr = a.re * bb.re;
+            wr = fma(-a.im, bb.im, wr); wr = fma(-c.re, d.re, wr); wr = fma(c.im, d.im, wr);
+            double wi = a.re * bb.im;
+            wi = fma(a.im, bb.re, wi); wi = fma(-c.re, d.im, wi); wi = fma(-c.im, d.re, wi);
+            const double dr = u[6 + b].re - wr, di = u[6 + b].im + wi;      // row 2 - conj(row 0 x row 1)
+            dl[2 * b] = (float)dr; dl[2 * b + 1] = (float)di;
+            const double d1 = fabs(dr), d2 = fabs(di);
+            dev = (d1 <= 1e300 && d2 <= 1e300) ? fmax(dev, fmax(d1, d2)) : 1e300;
+        }
+        double2 w6, w7;
+        w6.x = __hiloint2double(__float_as_int(dl[1]), __float_as_int(dl[0]));
+        w6.y = __hiloint2double(__float_as_int(dl[3]), __float_as_int(dl[2]));
+        w7.x = __hiloint2double(__float_as_int(dl[5]), __float_as_int(dl[4]));
+        w7.y = 0.0;
+        dst[d_o + 6 * 64] = w6;
+        dst[d_o + 7 * 64] = w7;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_down(dev, off, 64));
+    if ((threadIdx.x & 63) == 0 && dev > 0.0) atomicMax(maxdev, (unsigned long long)__double_as_longlong(dev));
+}
+
+int gauge_ensure_recon12d(lqcd_gauge_s* g) {
+    if (g->version12d == g->version && g->data12d) return LQCD_OK;
+    lqcd_ctx_s* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (!g->data12d) HIPCHK(hipMalloc((void**)&g->data12d, (size_t)2 * c->geom.nch * 4 * 8 * 64 * sizeof(double2)));
+    unsigned long long* d_dev = (unsigned long long*)(c->d_scal + SCAL_DOUBLES - 9);
+    HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(gauge_compress12d, dim3((c->geom.Vh + 255) / 256, 8), dim3(256), 0, c->stream, c->geom, g->data, g->data12d, d_dev);
+    HIPCHK(hipGetLastError());
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, d_dev, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double dev;
+    memcpy(&dev, &bits, sizeof(dev));
+    g->delta_ok = dev <= 1e-9;
+    g->version12d = g->version;
     return LQCD_OK;
 }
 

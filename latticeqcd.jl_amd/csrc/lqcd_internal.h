@@ -431,7 +431,11 @@ struct Tunables {
                               // lqcd_link_staple -> lqcd_link_mul -> lqcd_link_add_ta) are recorded and run as ONE fused launch each, four completed triples of one
                               // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel
     int pair32_active = 0;    // read-only: the last mixed-precision solve / lqcd_op_apply_f32 ran the fp32 site-pair kernel
-    int recon_active = 0;     // read-only: 1 if the last Wilson operator application used the 12-real links
+    int recon_active = 0;     // read-only: 1 if the last operator application used the 12-real links, 2: rows 0, 1 + the fp32 deviation of row 2 ("12 + delta")
+    int dslash_s18 = 1;       // dslash_pipe = 2: the scalar-addressing kernel also for the 18 stored reals (round 4: its instance no longer spills at 3 waves per SIMD --
+                              // the diagonal term and the old r of the update mode are requested behind the hops); 0: the plain direction-split kernel there
+    int gauge_delta = 1;      // fields that fail the 12-real gate but lie within 1e-9 of the group (reference-format configurations) take the "12 + delta" links in the
+                              // scalar-addressing Wilson kernel: 896 B/site moved instead of 960, results equal to the 18-real kernel's to fp64 rounding; 0: always 18 reals
 };
 
 // Recorded single-direction link operations of one context (md.hip "lazy link triples").  A record holds raw handles: every entry point that
@@ -523,6 +527,12 @@ struct lqcd_gauge_s {
     uint64_t version12 = 0;      // version of `data` the copy was made from
     bool recon_ok = false;       // row 2 == conj(row 0 x row 1) to 1e-14 on every link of that version
     double recon_dev = 0.0;      // max |row 2 - conj(row 0 x row 1)| measured when the copy was made
+    // "12 + delta" copy for fields that are close to the group but not on it (the reference's text / ILDG configurations: 8.8e-11): rows 0, 1 in fp64 and
+    // delta = row 2 - conj(row 0 x row 1) in fp32, [parity][chunk][mu][8][64]; built on demand when the 12-real gate fails, used by the scalar-addressing
+    // Wilson kernel only while max |delta| <= 1e-9 (its fp32 rounding is then below 1e-16)
+    double2* data12d = nullptr;
+    uint64_t version12d = 0;
+    bool delta_ok = false;
     uint64_t unitary_version = 0;  // version of `data` whose links are all known to be on the group to rounding (generated on it, measured by the
                                    // 12-real pass, or projected by the link update): kernels may then rebuild row 2 instead of loading it
 };
@@ -612,6 +622,8 @@ struct StencilCall {
     int alpha_n = 0;
     double* scal_w = nullptr;     // the device scalar block, writable: block 0 records pq, alpha and the rr this iteration started from
     const double2* gauge12 = nullptr;  // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
+    int gauge12_delta = 0;        // 1: gauge12 is the 8-word "12 + delta" copy (lqcd_gauge_s::data12d); only the scalar-addressing Wilson kernel reads it, every
+                                  // other launch of the call falls back to the 18 stored reals
     const double2* clover = nullptr;    // packed clover blocks: the Wilson split kernel (variant 1) applies A to xin in its epilogue
     int prec = 0;                 // 0: fp64 fields, 1: fp32 fields (pointers are float2 data, see p32)
     // partitioned lattices, fused tails of the exterior launch (stencil.hip ext_partial / wilson_pack_site):
@@ -709,6 +721,7 @@ int clover_force(lqcd_ctx_s* c, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_s
 // fields.hip
 double2* spinor_block(lqcd_spinor_s* s, int p);
 int gauge_ensure_recon12(lqcd_gauge_s* g);   // (re)builds the 12-real copy if the field changed; sets g->recon_ok
+int gauge_ensure_recon12d(lqcd_gauge_s* g);  // (re)builds the "12 + delta" copy; sets g->delta_ok
 int plaquette_local_sum(lqcd_gauge_s* g, const double2* const ghost[4], double* sum);
 int gauge_pack_face(lqcd_gauge_s* g, int mu, double2* dst);
 

@@ -654,13 +654,18 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
 // load, no branch around a load.  Per launch -20 % VALU and -42 % SALU instructions than variant 1 (profiles/r03_pmc_pipe_static.csv), i.e. a
 // shorter way from dispatch to the first load.  Same operations in the same order per site, same |.|^2 partial per workgroup: bit-identical to
 // variant 1 including the CG iterates.
-template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false>
+template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false>
 __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim) {
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;
     constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;
     constexpr int FB = MU == 3 ? (SF > 0 ? 0 : 6) : 0;
-    constexpr int NL = R12 ? 6 : 9;
+    constexpr int NL = DELTA ? 8 : (R12 ? 6 : 9);      // 16-byte words per link: 18 reals | rows 0, 1 | rows 0, 1 + the fp32 deviation of row 2 (add_delta_row2)
+#ifdef LQCD_F32
+    constexpr bool LATE_R = false;
+#else
+    constexpr bool LATE_R = DELTA || !R12;            // fp64: the instances that would spill at 3 waves per SIMD with the old r held across the hops
+#endif
     const size_t gpar = (size_t)a.nch * 4 * NL * 64;
     const PipeSite s = pipe_site<MU, NL>(a, blockIdx.x, lane);
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
@@ -670,11 +675,12 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dotz[1] : a.dotz[0], s.own) + co12(3 * MU + cc));
         }
-    } else if (a.upd_scal) {
+    } else if (!LATE_R && a.upd_scal) {    // (18-real and 12 + delta links: their extra words take these registers during the hops; the old r is requested behind them)
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
     }
-    if (a.a != real(0.0)) {
+    constexpr bool LATE_X = LATE_R && !R12 && !DOT;      // all 18 reals: the diagonal term's load moves behind the hops as well
+    if (!LATE_X && a.a != real(0.0)) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
     }
@@ -703,9 +709,10 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     }
 #else
     {
-        cd sF[NS], uF[9];
+        cd sF[NS], uF[9], dF[2];
         load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
         load_link_any<R12, false>(uF, boff(a.gauge + (s.p ? gpar : 0), s.uf), 64);
+        if constexpr (DELTA) { dF[0] = ld(boff(a.gauge + (s.p ? gpar : 0), s.uf) + 6 * 64); dF[1] = ld(boff(a.gauge + (s.p ? gpar : 0), s.uf) + 7 * 64); }
 #if LQCD_SDIR_GLDS
         // The backward neighbour's spinor goes global -> LDS with the asynchronous copy of gfx950 (global_load_lds_dwordx4: wave-uniform LDS base +
         // 16 B x lane, exactly the [component][lane] slab this wave owns in the partial-sum area, which nobody touches before the hops are done):
@@ -720,6 +727,9 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         }
 #endif
         finish_link<R12>(uF);
+#ifndef LQCD_F32
+        if constexpr (DELTA) add_delta_row2(uF, dF);
+#endif
         project_regs<MU, SF>(h0, h1, sF);
         pipe_sign(h0, h1, s.sf);
         su3_mv<false>(chi0, uF, h0);
@@ -728,7 +738,7 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     }
     __builtin_amdgcn_sched_barrier(0);      // the backward operands take the registers of the forward ones (3 waves per SIMD)
     {
-        cd sB[NS], uB[9];
+        cd sB[NS], uB[9], dB[2];
 #if LQCD_SDIR_GLDS
         load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS copies (issued long ago) and the link
@@ -738,7 +748,15 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
         load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
 #endif
+        if constexpr (DELTA) {
+            const real2* db = boff(a.gauge + (s.p ? 0 : gpar), s.ub);
+            dB[0] = NTB ? ld_nt(db + 6 * 64) : ld(db + 6 * 64);
+            dB[1] = NTB ? ld_nt(db + 7 * 64) : ld(db + 7 * 64);
+        }
         finish_link<R12>(uB);
+#ifndef LQCD_F32
+        if constexpr (DELTA) add_delta_row2(uB, dB);
+#endif
         project_regs<MU, -SF>(h0, h1, sB);
         pipe_sign(h0, h1, s.sb);
         su3_mv<true>(chi0, uB, h0);
@@ -746,6 +764,14 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         reconstruct<MU, -SF>(acc, chi0, chi1);
     }
 #endif
+    if constexpr (LATE_X) if (a.a != real(0.0)) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
+    }
+    if constexpr (LATE_R && !DOT) if (a.upd_scal) {       // the LDS exchange and the barrier cover this load
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
+    }
 #pragma unroll
     for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
     __syncthreads();
@@ -775,7 +801,7 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     }
 }
 
-template <bool DAG, bool R12, bool NTB, bool DOT = false>
+template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false>
 __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
     __shared__ double red[DOT ? 12 : 4];
@@ -796,10 +822,10 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     const int lane = threadIdx.x & 63;
     real nrm = 0.0, dre = 0.0, dim = 0.0;
     switch (w) {
-    case 0: sdir_wave<0, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 1: sdir_wave<1, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 2: sdir_wave<2, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
-    default: sdir_wave<3, DAG, R12, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
+    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
     }
     if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue
         double t3[3] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm};
@@ -1414,6 +1440,10 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
     if (use_dirsplit(c, s.kind, s.r)) {
         KArgs k = make_kargs(c, s, 64);
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
+        // "12 + delta" links are read by the scalar-addressing Wilson kernel alone: every other launch takes the 18 stored reals
+        const bool delta = s.gauge12_delta && !kF32Build && s.kind == LQCD_WILSON && k.gauge12 && !k.alpha_partials && !k.dot_partial && !s.clover_on_hop && !k.clover &&
+                           c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false);
+        if (s.gauge12_delta && !delta) { k.gauge12 = nullptr; c->tun.recon_active = 0; }
         if (s.kind == LQCD_STAGGERED) {
             const bool both = c->tun.stag_both && !(c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3]);
             const dim3 sg(k.nblocks), sb_(256);
@@ -1466,14 +1496,22 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                    else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, false, true>), grid, block, pad, c->stream, k); }
 #endif
         } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr) &&
-                   (c->tun.dslash_pipe != 2 || (k.gauge12 && !kF32Build))) {      // the scalar-addressing kernel pays with the fp64 12-real links only: its 18-real
-                                                                                  // instance spills at 3 waves/SIMD, its one-site-per-lane fp32 instance measured 62.5 vs 57 ms of
-                                                                                  // variant 1 in the mixed CG (profiles/r03_mixed_precision.log) -- same grid, so the counts agree
+                   (c->tun.dslash_pipe != 2 || ((k.gauge12 || c->tun.dslash_s18) && !kF32Build))) {      // the scalar-addressing kernel: fp64 only (its one-site-per-lane fp32
+                                                                                  // instance measured 62.5 vs 57 ms of variant 1 in the mixed CG, profiles/r03_mixed_precision.log); since
+                                                                                  // round 4 also for the 18 stored reals (no spill once the diagonal term / old r load behind the hops)
             PipeArgs a = make_pipe_args(c, k, s);
             const bool persist = c->tun.dslash_pipe == 1 || c->tun.dslash_pipe == 3;
             if (c->tun.dslash_pipe == 3) { a.ctr = nullptr; a.per_wg = wilson_pipe_per_wg(c, k.nblocks); }
             const dim3 pg(c->tun.dslash_pipe == 1 ? wilson_pipe_grid(c, k.nblocks, s.prec) : c->tun.dslash_pipe == 3 ? k.nblocks / a.per_wg : k.nblocks), pb(256);
             const bool ntb = (k.nt & 1) != 0;
+#ifndef LQCD_F32
+            if (delta) {       // rows 0, 1 + fp32 deviation of row 2 (reference-format configurations); plain loads for the backward link as well: the
+                               // non-temporal form measured 0.3962 against 0.3915 ms at 32^3x64 (profiles/r04_links_12_plus_delta.log)
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, false, true>), pg, pb, 0, c->stream, a);
+                else hipLaunchKernelGGL((wilson_dirsplit_s<false, true, false, false, true>), pg, pb, 0, c->stream, a);
+            } else
+#endif
+            {
 #define LQ_PIPE(D, R) do { if (persist) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, true>), pg, pb, 0, c->stream, a); \
                                           else hipLaunchKernelGGL((wilson_dirsplit_pipe<D, R, false>), pg, pb, 0, c->stream, a); } \
                            else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<D, R, true>), pg, pb, 0, c->stream, a); \
@@ -1481,6 +1519,7 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             if (k.gauge12) { if (s.dagger) LQ_PIPE(true, true); else LQ_PIPE(false, true); }
             else { if (s.dagger) LQ_PIPE(true, false); else LQ_PIPE(false, false); }
 #undef LQ_PIPE
+            }
 #if !defined(LQCD_F32) && defined(LQCD_VARIANTS)   // opt-in variants 2-8 (stencil_alt.hip, -DLQCD_VARIANTS builds): fp64 only -- the fp32 build (paired-component fields) has the direction-split and the
                    // site-per-lane kernels, and the mixed-precision solvers pin dslash_variant to 0/1 for the duration of a solve (mixed.hip)
         } else if (c->tun.dslash_variant >= 2 && launch_wilson_alt(c, s, k, pad)) {

@@ -495,6 +495,20 @@ __device__ inline void finish_link(cd (&u)[9]) {      // 12-real links: row 2 = 
     if constexpr (R12) recon_row2(u);
 }
 
+// "12 + delta" links (fp64 build): rows 0, 1 in fp64 and delta = row 2 - conj(row 0 x row 1) in fp32, three complex floats in words 6, 7 of the 8-word link
+// (word 6 = delta_0, delta_1; word 7 = delta_2, unused).  For a link within 1e-9 of SU(3) -- the reference's text and ILDG configurations: 8.8e-11 -- the fp32
+// rounding of delta is below 1e-16 of the O(1) matrix elements, i.e. row 2 comes back to fp64 rounding: 128 B per link instead of 144.
+#ifndef LQCD_F32
+__device__ inline void add_delta_row2(cd (&u)[9], const cd (&dw)[2]) {
+    const float d0r = __int_as_float(__double2loint(dw[0].re)), d0i = __int_as_float(__double2hiint(dw[0].re));
+    const float d1r = __int_as_float(__double2loint(dw[0].im)), d1i = __int_as_float(__double2hiint(dw[0].im));
+    const float d2r = __int_as_float(__double2loint(dw[1].re)), d2i = __int_as_float(__double2hiint(dw[1].re));
+    u[6].re += (double)d0r; u[6].im += (double)d0i;
+    u[7].re += (double)d1r; u[7].im += (double)d1i;
+    u[8].re += (double)d2r; u[8].im += (double)d2i;
+}
+#endif
+
 // identity the optimiser cannot see through: arithmetic on values loaded BEFORE the barrier must not be scheduled in front of it
 // (pure arithmetic is not ordered by the barrier's memory clobber; it would drag the wait for those loads in front of the barrier)
 template <int N>

@@ -52,6 +52,12 @@ case $stage in
       f=$(find $out/prof$m -name "*kernel_stats.csv" | head -1); echo "== mode $m"; head -9 "$f" | cut -d, -f1-4 | sed 's/"//g' | cut -c1-150
     done
     ;;
+  delta)      # "12 + delta" links for reference-format configurations: timing and parity
+    python scripts/delta_probe.py 2>&1 | tail -5 | tee $out/delta.log
+    python scripts/delta_probe.py --L 16,16,16,32 --dev 1e-9 2>&1 | tail -4 | tee -a $out/delta.log
+    timeout 600 python -m pytest tests/test_gpu_recon12.py tests/test_gpu_pipe.py tests/test_golden_io.py tests/test_gpu_parity.py -q -x 2>&1 | tail -8 | tee $out/pytest.log
+    timeout 600 python bench.py --no-pmc > $out/bench.json 2> $out/bench.err; python -c "import json; d=json.load(open('$out/bench.json')); print(d['value'], d['roofline']['frac'], d['gauge_recon18_all_reals_read'], d['reference_format_links'])"
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log
