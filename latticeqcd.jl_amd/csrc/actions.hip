@@ -39,7 +39,9 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
     }
     bool have_Y = false;
     if (even_only) LQCHK(lqcd_solve_cg_DdagD_parity(op, X, eta, 0, eps, maxiter, iters, nullptr));
-    else if (c->tun.mixed_action_solver) LQCHK(lqcd_solve_mixed_cg_DdagD(op, X, eta, eps, maxiter, 0.0, iters, nullptr, nullptr));
+    // mixed_action_solver: plain Wilson takes the even-odd route below with the fp32 inner chain (bicg_mixed); everything else the mixed-precision CG
+    else if (c->tun.mixed_action_solver && !(op->kind == LQCD_WILSON && c->tun.action_eo_solver && op->csw == 0.0 && op->r == 1.0 && !any_partitioned(c) && !c->has_comm))
+        LQCHK(lqcd_solve_mixed_cg_DdagD(op, X, eta, eps, maxiter, 0.0, iters, nullptr, nullptr));
     else {
         // Wilson(-clover), tunable action_eo_solver: X = (D^+D)^-1 eta as TWO even-odd preconditioned BiCGStab solves, Y = D^-+ eta and X = D^-1 Y --
         // the Schur complement converges in a fraction of the normal equations' iterations (32^3x64 hot start: 2 x ~13 iterations of 2 Dslash
@@ -53,8 +55,11 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
         if (try_eo && Yw) {
             const double nD = 1.0 + 8.0 * std::fabs(op->km) + (op->csw != 0.0 ? 6.0 * std::fabs(op->km * op->csw) : 0.0);
             HIPCHK(hipMemsetAsync(Yw->data, 0, Yw->elems * sizeof(double2), c->stream));
+            const int mixed0 = c->tun.bicg_mixed;
+            if (c->tun.mixed_action_solver) c->tun.bicg_mixed = 1;
             st = lqcd_solve_bicgstab_eo(op, Yw, eta, 1, 0.25 * eps, maxiter, &it1, nullptr);
             if (st == LQCD_OK) st = lqcd_solve_bicgstab_eo(op, X, Yw, 0, 0.25 * eps / (nD * nD), maxiter, &it2, nullptr);
+            c->tun.bicg_mixed = mixed0;
             if (st != LQCD_OK && st != LQCD_ERR_NOT_CONVERGED) { if (Yw != Y) scratch_put(Yw); return st; }
         }
         if (Yw && Yw != Y) scratch_put(Yw);

@@ -303,6 +303,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "bicg_fused")) return &c->tun.bicg_fused;
     if (!strcmp(key, "gauge_delta")) return &c->tun.gauge_delta;
     if (!strcmp(key, "dslash_s18")) return &c->tun.dslash_s18;
+    if (!strcmp(key, "bicg_mixed")) return &c->tun.bicg_mixed;
     if (!strcmp(key, "action_eo_solver")) return &c->tun.action_eo_solver;
     return nullptr;
 }

@@ -432,6 +432,8 @@ struct Tunables {
                               // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel
     int pair32_active = 0;    // read-only: the last mixed-precision solve / lqcd_op_apply_f32 ran the fp32 site-pair kernel
     int recon_active = 0;     // read-only: 1 if the last operator application used the 12-real links, 2: rows 0, 1 + the fp32 deviation of row 2 ("12 + delta")
+    int bicg_mixed = 0;       // 1: the even-odd BiCGStab of the plain Wilson operator (lqcd_solve_bicgstab_eo, and through it the action / force solves) runs the fp32 chain
+                              // inside an fp64 defect correction; the stopping rule holds for the true fp64 residual.  mixed_action_solver = 1 switches it on for the action solves
     int dslash_s18 = 1;       // dslash_pipe = 2: the scalar-addressing kernel also for the 18 stored reals (round 4: its instance no longer spills at 3 waves per SIMD --
                               // the diagonal term and the old r of the update mode are requested behind the hops); 0: the plain direction-split kernel there
     int gauge_delta = 1;      // fields that fail the 12-real gate but lie within 1e-9 of the group (reference-format configurations) take the "12 + delta" links in the

@@ -404,6 +404,243 @@ static int add_from_f32(lqcd_ctx_s* c, int layout, double2* y, const float2* x, 
     return LQCD_OK;
 }
 
+// ---------------------------------------------------------------------------------- mixed-precision even-odd BiCGStab (plain Wilson)
+// M x = rhs on the even sites, M = 1 - k^2 H_eo H_oe:  outer fp64 defect correction around the fused chain of solvers.hip run on fp32 copies --
+//     r = rhs - M x (fp64) ;  while |r|^2 >= eps:  e ~ M^-1 (r / |r|) by the fp32 chain to a relative residual tol ;  x += |r| e ;  r = rhs - M x
+// The inner chain is the fp64 one (bicgstab_eo_wilson) in structure: the Schur operator's second hop forms the next inner product in its epilogue
+// (fp32 build of the direction-split kernel, double partials), reductions and scalar steps (double) run in the prologues of the three streaming
+// kernels on lattices of <= 1024 chunks per parity.  Vectors are float4 words (two complex components: the component-pair layout is flat to them).
+// The stopping rule is enforced on the TRUE fp64 residual of the Schur system, so lqcd_solve_bicgstab_eo keeps its contract; a correction step that
+// fails to gain a factor 4 hands the rest of the solve to the fp64 chain.
+__device__ inline void cfma32(float& xr, float& xi, float ar, float ai, float br, float bi) {      // x += a b (complex)
+    xr = fmaf(ar, br, xr); xr = fmaf(-ai, bi, xr);
+    xi = fmaf(ar, bi, xi); xi = fmaf(ai, br, xi);
+}
+// s = r - alpha v ; partial |s|^2
+__global__ __launch_bounds__(UB) void bicgf32_s(BicgF a, float4* __restrict__ s, const float4* __restrict__ r, const float4* __restrict__ v, size_t n4) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    float4 pr[2], pv[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) { pr[e] = r[i]; pv[e] = v[i]; } }
+    c2 r0v, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]};
+    if (a.fold) { double t3[3]; block_sum_partials<3>(a.pin, a.pin_n, t3); r0v.re = t3[0]; r0v.im = t3[1]; }
+    else { r0v.re = a.sc[B_R0V]; r0v.im = a.sc[B_R0V + 1]; }
+    const c2 al = bicg_alpha(rho, r0v);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc[B_R0V] = r0v.re; a.sc[B_R0V + 1] = r0v.im; a.sc[B_ALPHA] = al.re; a.sc[B_ALPHA + 1] = al.im; }
+    const float ar = -(float)al.re, ai = -(float)al.im;
+    double acc[1] = {0};
+    auto one = [&](size_t i, float4 sv, const float4 vv) {
+        cfma32(sv.x, sv.y, ar, ai, vv.x, vv.y);
+        cfma32(sv.z, sv.w, ar, ai, vv.z, vv.w);
+        s[i] = sv;
+        acc[0] += (double)(sv.x * sv.x + sv.y * sv.y) + (double)(sv.z * sv.z + sv.w * sv.w);
+    };
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pr[e], pv[e]); }
+    for (size_t i = i0 + 2 * stride; i < n4; i += stride) one(i, r[i], v[i]);
+    block_reduce_nv<1>(acc, a.pout);
+}
+// x += alpha p + omega s ; r = s - omega t ; partials |r|^2, <r0, r>
+__global__ __launch_bounds__(UB) void bicgf32_xr(BicgF a, float4* __restrict__ x, float4* __restrict__ r, const float4* __restrict__ p, const float4* __restrict__ s,
+                                                  const float4* __restrict__ t, const float4* __restrict__ r0, size_t n4) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    float4 pp[2], ps[2], pt[2], pz[2], px[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) { pp[e] = p[i]; ps[e] = s[i]; pt[e] = t[i]; pz[e] = r0[i]; px[e] = x[i]; } }
+    const float ar = (float)a.sc[B_ALPHA], ai = (float)a.sc[B_ALPHA + 1];
+    double ss, tt;
+    c2 ts;
+    if (a.fold) {
+        double t1[1], t3[3];
+        block_sum_partials<1>(a.pin2, a.pin2_n, t1);
+        block_sum_partials<3>(a.pin, a.pin_n, t3);
+        ss = t1[0]; ts.re = t3[0]; ts.im = t3[1]; tt = t3[2];
+    } else { ss = a.sc[B_SS]; ts.re = a.sc[B_TS]; ts.im = a.sc[B_TS + 1]; tt = a.sc[B_TT]; }
+    const bool half = ss < a.sc[B_EPS];
+    const c2 om = bicg_omega(ts, tt, half);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.sc[B_SS] = ss; a.sc[B_HALF] = half ? 1.0 : 0.0; a.sc[B_TS] = ts.re; a.sc[B_TS + 1] = ts.im; a.sc[B_TT] = tt;
+        a.sc[B_OMEGA] = om.re; a.sc[B_OMEGA + 1] = om.im;
+    }
+    const float wr = (float)om.re, wi = (float)om.im;
+    double acc[3] = {0, 0, 0};
+    auto one = [&](size_t i, const float4 pv, const float4 sv, const float4 tv, const float4 zv, float4 xv) {
+        float4 rv = sv;
+        cfma32(xv.x, xv.y, ar, ai, pv.x, pv.y); cfma32(xv.z, xv.w, ar, ai, pv.z, pv.w);
+        cfma32(xv.x, xv.y, wr, wi, sv.x, sv.y); cfma32(xv.z, xv.w, wr, wi, sv.z, sv.w);
+        cfma32(rv.x, rv.y, -wr, -wi, tv.x, tv.y); cfma32(rv.z, rv.w, -wr, -wi, tv.z, tv.w);
+        x[i] = xv; r[i] = rv;
+        acc[0] += (double)(rv.x * rv.x + rv.y * rv.y) + (double)(rv.z * rv.z + rv.w * rv.w);
+        acc[1] += (double)(zv.x * rv.x + zv.y * rv.y) + (double)(zv.z * rv.z + zv.w * rv.w);        // <r0, r> = conj(r0) r
+        acc[2] += (double)(zv.x * rv.y - zv.y * rv.x) + (double)(zv.z * rv.w - zv.w * rv.z);
+    };
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pp[e], ps[e], pt[e], pz[e], px[e]); }
+    for (size_t i = i0 + 2 * stride; i < n4; i += stride) one(i, p[i], s[i], t[i], r0[i], x[i]);
+    block_reduce_nv<3>(acc, a.pout);
+}
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p, const float4* __restrict__ r, const float4* __restrict__ v, size_t n4) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    float4 pv_[2], pr[2], pp[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) { pv_[e] = v[i]; pr[e] = r[i]; pp[e] = p[i]; } }
+    const double wrd = a.sc[B_OMEGA], wid = a.sc[B_OMEGA + 1];
+    const bool half = a.sc[B_HALF] != 0.0;
+    double rrn;
+    c2 rho1, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]}, al = {a.sc[B_ALPHA], a.sc[B_ALPHA + 1]}, om = {wrd, wid};
+    if (a.fold) { double t3[3]; block_sum_partials<3>(a.pin, a.pin_n, t3); rrn = t3[0]; rho1.re = t3[1]; rho1.im = t3[2]; }
+    else { rrn = a.sc[B_RR]; rho1.re = a.sc[B_RHO1]; rho1.im = a.sc[B_RHO1 + 1]; }
+    const double rr = half ? a.sc[B_SS] : rrn;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead) { a.sc[B_ITERS] += 1.0; a.sc[B_RES] = rr; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im; }
+    if (half || rr < a.sc[B_EPS]) { if (lead) a.sc[B_DONE] = 1.0; return; }
+    if (!(fabs(rr) <= 1.79e308)) { if (lead) a.sc[B_DONE] = 2.0; return; }
+    const c2 be = bicg_beta(rho1, rho, al, om);
+    if (lead) { a.sc[B_BETA] = be.re; a.sc[B_BETA + 1] = be.im; a.sc[a.rho_out] = rho1.re; a.sc[a.rho_out + 1] = rho1.im; }
+    const float br = (float)be.re, bi = (float)be.im, wr = -(float)wrd, wi = -(float)wid;
+    auto one = [&](size_t i, const float4 vv, const float4 rv, float4 pv) {
+        cfma32(pv.x, pv.y, wr, wi, vv.x, vv.y); cfma32(pv.z, pv.w, wr, wi, vv.z, vv.w);      // p - omega v
+        float4 o = rv;
+        cfma32(o.x, o.y, br, bi, pv.x, pv.y); cfma32(o.z, o.w, br, bi, pv.z, pv.w);
+        p[i] = o;
+    };
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pv_[e], pr[e], pp[e]); }
+    for (size_t i = i0 + 2 * stride; i < n4; i += stride) one(i, v[i], r[i], p[i]);
+}
+// r = rhs - q (fp64) with |r|^2 partials is residual_kernel above (sigma = 0)
+
+struct Eo32 {
+    float2 *gauge, *gauge12;
+    float2 *x, *r, *r0, *p, *v, *s, *t, *to;      // half-lattice vectors, component-pair layout
+};
+// one Schur application on the fp32 fields: to = H_oe in, out = in - k^2 H_eo to [+ inner-product epilogue]
+static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const float2* z, double* dotp, int conj, int dg, const double* skip) {
+    lqcd_ctx_s* c = op->ctx;
+    StencilCall s1;
+    s1.kind = LQCD_WILSON; s1.gauge = (const double2*)m.gauge; s1.gauge12 = (const double2*)m.gauge12;
+    s1.out[0] = nullptr; s1.out[1] = (double2*)m.to; s1.in[0] = (const double2*)in; s1.in[1] = nullptr; s1.xin[0] = s1.xin[1] = nullptr;
+    s1.a = 0.0; s1.b = 1.0; s1.r = 1.0; s1.dagger = dg; s1.parity_mode = 1; s1.prec = 1; s1.skip_flag = skip;
+    LQCHK(stencil_apply(c, s1));
+    StencilCall s2;
+    s2.kind = LQCD_WILSON; s2.gauge = (const double2*)m.gauge; s2.gauge12 = (const double2*)m.gauge12;
+    s2.out[0] = (double2*)out; s2.out[1] = nullptr; s2.in[0] = nullptr; s2.in[1] = (const double2*)m.to; s2.xin[0] = (const double2*)in; s2.xin[1] = nullptr;
+    s2.a = 1.0; s2.b = -op->km * op->km; s2.r = 1.0; s2.dagger = dg; s2.parity_mode = 0; s2.prec = 1; s2.skip_flag = skip;
+    if (z) { s2.dot_z[0] = (const double2*)z; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
+    return stencil_apply(c, s2);
+}
+// e ~ M^-1 rhs32 (|rhs32|^2 = 1, zero guess) until the recursive residual is below eps2; m.r holds rhs32 on entry
+static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters) {
+    lqcd_ctx_s* c = op->ctx;
+    const size_t n4 = nh / 2, b32 = nh * sizeof(float2);
+    const int nbs = stencil_num_blocks(c, LQCD_WILSON, 1.0, 0, 1);
+    const int nbk = (int)std::min<size_t>(1024, (n4 + UB - 1) / UB);
+    const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
+    double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)3 * nbs;
+    const double* skip = c->d_scal + (B_DONE - S_DONE);
+    HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));
+    HIPCHK(hipMemcpyAsync(m.r0, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(m.p, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
+    double init[B_END - B_RHO] = {0};
+    init[B_RHO - B_RHO] = 1.0; init[B_RHOB - B_RHO] = 1.0; init[B_EPS - B_RHO] = eps2; init[B_RES - B_RHO] = 1.0;
+    HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    int it = 0, enq = 0, check_every = std::max(4, std::min(op->bicg_hint - 1, 64));
+    double done = 0.0;
+    while (done == 0.0 && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        check_every = 2;
+        for (int q = 0; q < burst; q++, enq++) {
+            BicgF a;
+            a.sc = c->d_scal; a.fold = fold ? 1 : 0;
+            a.rho_in = (enq & 1) ? B_RHOB : B_RHO; a.rho_out = (enq & 1) ? B_RHO : B_RHOB;
+            a.pin2 = nullptr; a.pin2_n = 0;
+            LQCHK(schur32(op, m, m.v, m.p, m.r0, P0, 0, dg, skip));
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0));
+            a.pin = P0; a.pin_n = nbs; a.pout = P1;
+            hipLaunchKernelGGL(bicgf32_s, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
+            if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
+            LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip));
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
+            a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
+            hipLaunchKernelGGL(bicgf32_xr, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (const float4*)m.p, (const float4*)m.s, (const float4*)m.t,
+                               (const float4*)m.r0, n4);
+            if (!fold) LQCHK(reduce_to_slot(c, nbk, 3, B_RR, true, 0, P3));
+            a.pin = P3; a.pin_n = nbk; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
+            hipLaunchKernelGGL(bicgf32_p, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + B_RHO, (B_END - B_RHO) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        it = (int)c->h_scal[B_ITERS - B_RHO];
+        done = c->h_scal[B_DONE - B_RHO];
+    }
+    *iters = it;
+    if (done == 2.0) { set_error("mixed-precision even-odd BiCGStab: the fp32 chain broke down"); return LQCD_ERR_NOT_CONVERGED; }
+    if (done == 1.0) op->bicg_hint = it;
+    return LQCD_OK;      // an inner solve that ran out of iterations still improves x: the outer loop decides
+}
+
+int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
+                             int maxiter, int* iters, double* final_rr) {
+    lqcd_ctx_s* c = op->ctx;
+    const size_t nh = xe.elems, nfull = 2 * nh;
+    // fp32 links and work space: the buffers of the mixed-precision CG (four full-lattice vectors = eight halves), component-pair layout
+    Mix32 mm;
+    const int pair0 = c->tun.mixed_pair32;
+    c->tun.mixed_pair32 = 0;                       // the site-pair kernel has no parity hops: this solve takes the fp32 build of the direction-split kernel
+    const int stp = mix_prepare(op, nfull, mm);
+    c->tun.mixed_pair32 = pair0;
+    LQCHK(stp);
+    Eo32 m;
+    m.gauge = mm.gauge; m.gauge12 = mm.gauge12;
+    m.x = mm.x; m.r = mm.x + nh; m.r0 = mm.r; m.p = mm.r + nh; m.v = mm.p; m.s = mm.p + nh; m.t = mm.t; m.to = mm.t + nh;
+    lqcd_spinor_s *r = w[0], *q = w[1];
+    const int nb = stream_grid(c, nh);
+    auto true_residual = [&](double* rr) -> int {      // r = rhs - M x in fp64
+        LQCHK(schur_wilson(op, q, &xe, to, dg));
+        hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(MB), 0, c->stream, r->data, rhs->data, q->data, (const double2*)nullptr, 0.0, nh, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 1, S_RED0, true, 0));
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *rr = c->h_scal[0];
+        return LQCD_OK;
+    };
+    double rr = 0, bb = 0;
+    LQCHK(blas_norm2(c, rhs->data, nh, &bb, true));
+    LQCHK(true_residual(&rr));
+    int total = 0, outer = 0;
+    while (rr >= eps && outer < 12 && total < maxiter) {
+        // as few correction steps as an fp32 recurrence supports: one per 1e-6 of the residual norm still to go, the reduction split evenly
+        const double togo = std::sqrt(eps / rr) * 0.5;
+        const int nsteps = std::max(1, (int)std::ceil(std::log10(1.0 / std::min(togo, 0.1)) / 6.0));
+        const double tol = std::max(std::pow(togo, 1.0 / nsteps), 2e-7);
+        LQCHK(to_f32(c, 1, m.r, r->data, nh, 1.0 / std::sqrt(rr)));
+        int it = 0;
+        LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol, maxiter - total, &it));
+        total += it;
+        LQCHK(add_from_f32(c, 1, xe.data, m.x, std::sqrt(rr), nh));
+        double rrn = 0;
+        LQCHK(true_residual(&rrn));
+        outer++;
+        const bool stalled = !(rrn < 0.0625 * rr);
+        rr = rrn;
+        if (stalled) break;
+    }
+    if (iters) *iters = total;
+    if (final_rr) *final_rr = rr;
+    if (rr < eps) return LQCD_OK;
+    // fp32 accuracy exhausted (or a breakdown of the fp32 recurrence): the fp64 chain finishes from the current iterate
+    int it64 = 0;
+    const int st = bicgstab_eo_wilson(op, xe, rhs, w, to, dg, eps, std::max(1, maxiter - total), &it64, final_rr);
+    if (iters) *iters = total + it64;
+    return st;
+}
+
 // fp32 multi-shift CG: (A + sigma_j) e_j = rhs, j < ns, and A e = rhs if xbase is given; rhs in m.r with |rhs|^2 = 1, zero guesses.
 // The loop of inner_cg32 with the zeta recurrences (solvers.hip ms_zeta, double precision scalars) and one fused update pass.  A shift
 // is frozen once zeta_j^2 |r|^2 < eps2; without xbase the solve ends when every shift is frozen, with it when |r|^2 < eps2.

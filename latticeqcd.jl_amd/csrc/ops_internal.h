@@ -35,6 +35,59 @@ typedef std::function<int(double2* out, const double2* in)> ApplyFn;
 // alpha_{n-1}, beta_{n-1}; stop_when_frozen raises S_DONE once every shift has converged (no unshifted solution wanted)
 int ms_zeta_launch(lqcd_ctx_s* c, double* d_ms, int ns, int stop_when_frozen);
 
+// ---- pieces shared by the fp64 (solvers.hip) and the mixed-precision (mixed.hip) even-odd BiCGStab chains
+#ifdef __HIPCC__
+template <int NV>
+__device__ inline void block_reduce_nv(double (&a)[NV], double* partial) {
+    __shared__ double red[NV][UB / 64];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[v] += __shfl_down(a[v], off, 64);
+        if ((threadIdx.x & 63) == 0) red[v][threadIdx.x >> 6] = a[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < UB / 64; w++) t += red[threadIdx.x][w];
+        partial[blockIdx.x * NV + threadIdx.x] = t;
+    }
+}
+// the NV sums of a producer's partials, the same bits in every thread of the workgroup: ONE wave loads and adds them (every wave doing so made the
+// prologue 5-9 us of texture-path time for 1024 workgroups), the others take the result from LDS
+template <int NV>
+__device__ inline void block_sum_partials(const double* __restrict__ partial, int n, double (&out)[NV]) {
+    __shared__ double sh[NV];
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const double t = sum_partials_small_nv(partial, n, NV, v);
+            if (threadIdx.x == 0) sh[v] = t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; v++) out[v] = sh[v];
+}
+struct BicgF {
+    double* sc;             // the context's device scalar block
+    int rho_in, rho_out;    // slots of rho for this iteration and the next (equal when the scalar kernels do the steps)
+    int fold;
+    const double* pin;      // fold: the producer's partials ...
+    int pin_n;              // ... of that many workgroups
+    const double* pin2;     // bicgf_xr: the |s|^2 partials of bicgf_s
+    int pin2_n;
+    double* pout;           // this kernel's partials
+};
+#endif
+int schur_wilson(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* to, int dg);      // out = (1 - k^2 H_eo H_oe) in on the even sites (fp64, plain Wilson)
+int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
+                       int maxiter, int* iters, double* final_rr, const double2* Ai = nullptr);
+// mixed.hip: the same solve with an fp32 inner chain and fp64 defect correction (plain Wilson, 12-real links); outer: correction steps
+int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
+                             int maxiter, int* iters, double* final_rr);
+
 // scratch fields of one call: returned to the context's pool on every exit path
 struct ScratchScope {
     lqcd_ctx_s* c;

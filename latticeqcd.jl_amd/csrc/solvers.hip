@@ -549,23 +549,6 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
 // polls the done flag every few iterations.  Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and
 // iteration count as the textbook van der Vorst loop the parity tests compare against.
 
-template <int NV>
-__device__ inline void block_reduce_nv(double (&a)[NV], double* partial) {
-    __shared__ double red[NV][UB / 64];
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a[v] += __shfl_down(a[v], off, 64);
-        if ((threadIdx.x & 63) == 0) red[v][threadIdx.x >> 6] = a[v];
-    }
-    __syncthreads();
-    if (threadIdx.x < NV) {
-        double t = 0;
-#pragma unroll
-        for (int w = 0; w < UB / 64; w++) t += red[threadIdx.x][w];
-        partial[blockIdx.x * NV + threadIdx.x] = t;
-    }
-}
 // <a,b> = sum conj(a) b
 __global__ __launch_bounds__(UB) void bicg_dot(const double* __restrict__ sc, const double2* __restrict__ a, const double2* __restrict__ b, size_t n,
                                                 double* partial) {
@@ -713,32 +696,6 @@ static int bicgstab_core(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, 
 // = 7 dependent launches per iteration instead of 17, the same bits in every vector as the unfolded form (partials, summation order and scalar
 // expressions are the same; tests/test_gpu_solver_edges.py).  rho lives in two slots used alternately: block 0 of the p update writes the new value
 // while the other workgroups still read the old one.
-// the NV sums of a producer's partials, the same bits in every thread of the workgroup: ONE wave loads and adds them (every wave doing so made the
-// prologue 5-9 us of texture-path time for 1024 workgroups), the others take the result from LDS
-template <int NV>
-__device__ inline void block_sum_partials(const double* __restrict__ partial, int n, double (&out)[NV]) {
-    __shared__ double sh[NV];
-    if (threadIdx.x < 64) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            const double t = sum_partials_small_nv(partial, n, NV, v);
-            if (threadIdx.x == 0) sh[v] = t;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < NV; v++) out[v] = sh[v];
-}
-struct BicgF {
-    double* sc;             // the context's device scalar block
-    int rho_in, rho_out;    // slots of rho for this iteration and the next (equal when the scalar kernels do the steps)
-    int fold;
-    const double* pin;      // fold: the producer's partials ...
-    int pin_n;              // ... of that many workgroups
-    const double* pin2;     // bicgf_xr: the |s|^2 partials of bicgf_s
-    int pin2_n;
-    double* pout;           // this kernel's partials
-};
 // The three streaming kernels request the first KE elements of every thread BEFORE the prologue (whose partial sums are a memory round trip of their
 // own and do not depend on them), then walk the rest of a large vector in the usual grid-stride loop: same element -> thread map, same order of the
 // per-thread additions, hence the same partials whether the prologue folds a reduction or not.
@@ -875,8 +832,15 @@ __global__ __launch_bounds__(UB) void bicgf_p(BicgF a, double2* __restrict__ p, 
 // Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and iteration count as bicgstab_core.
 // Ai != nullptr: Wilson-clover, M = 1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe with the packed inverse blocks applied to the hop sums inside the two hops
 // (StencilCall::clover_on_hop) -- still two launches per M, no intermediate field.
-static int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
-                              int maxiter, int* iters, double* final_rr, const double2* Ai = nullptr) {
+int schur_wilson(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* to, int dg) {      // out = (1 - k^2 H_eo H_oe) in, fp64, plain Wilson
+    lqcd_ctx_s* c = op->ctx;
+    StencilCall s1 = make_hop_call(op, to, in, nullptr, 0.0, 1.0, dg);
+    LQCHK(stencil_apply(c, s1));
+    StencilCall s2 = make_hop_call(op, out, to, in, 1.0, -op->km * op->km, dg);
+    return stencil_apply(c, s2);
+}
+int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
+                       int maxiter, int* iters, double* final_rr, const double2* Ai) {
     lqcd_ctx_s* c = op->ctx;
     const double k = op->km;
     const size_t n = xe.elems, bytes = n * sizeof(double2);
@@ -1217,7 +1181,9 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
                 return clover_apply_parity(c, Ai, 0, out, te->data, -k * k, in, 1.0);        // out = in - k^2 A_ee^-1 t_e
             };
         }
-        const int sc = fused ? bicgstab_eo_wilson(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr, clov ? Ai : nullptr)
+        const bool mixed = fused && !clov && c->tun.bicg_mixed;       // fp32 inner chain, fp64 defect correction (mixed.hip); same contract
+        const int sc = mixed ? bicgstab_eo_wilson_mixed(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr)
+                     : fused ? bicgstab_eo_wilson(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr, clov ? Ai : nullptr)
                              : bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
         // the odd half (also on non-convergence, so x is a consistent best effort)
         if (!clov) {

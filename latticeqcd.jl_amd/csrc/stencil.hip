@@ -1456,18 +1456,19 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             }
             else if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit<true>), sg, sb_, pad, c->stream, k);
             else hipLaunchKernelGGL((staggered_dirsplit<false>), sg, sb_, pad, c->stream, k);
-        } else if (s.kind == LQCD_WILSON && k.dot_partial) {      // dot mode (fused even-odd BiCGStab): the plain direction-split kernel with the inner-product epilogue
-#ifdef LQCD_F32
-            set_error("stencil: dot mode exists in the fp64 build only");
-            return LQCD_ERR_UNSUPPORTED;
-#else
+        } else if (s.kind == LQCD_WILSON && k.dot_partial) {      // dot mode (fused even-odd BiCGStab): a direction-split kernel with the inner-product epilogue
             if ((k.clover && !s.clover_on_hop) || s.r != 1.0) { set_error("stencil: dot mode needs the Wilson r = 1 kernel without a diagonal clover term"); return LQCD_ERR_UNSUPPORTED; }
             dim3 grid(k.nblocks), block(256);
+            bool launched = false;
+#ifdef LQCD_F32
+            if (s.clover_on_hop) { set_error("stencil: the clover-on-hop form exists in the fp64 build only"); return LQCD_ERR_UNSUPPORTED; }
+#else
             if (s.clover_on_hop) {      // even-odd clover solver: inverse blocks on the hop sum + the inner-product epilogue
                 if (k.gauge12) { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true, true>), grid, block, pad, c->stream, k);
                                  else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, true, true>), grid, block, pad, c->stream, k); }
                 else { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, true, true>), grid, block, pad, c->stream, k);
                        else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, true, true>), grid, block, pad, c->stream, k); }
+                launched = true;
             } else if (k.gauge12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {      // the scalar-addressing form
                 PipeArgs a = make_pipe_args(c, k, s);
                 const bool ntb = (k.nt & 1) != 0;
@@ -1475,14 +1476,18 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                                 else hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, true>), grid, block, 0, c->stream, a); }
                 else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<false, true, true, true>), grid, block, 0, c->stream, a);
                        else hipLaunchKernelGGL((wilson_dirsplit_s<false, true, false, true>), grid, block, 0, c->stream, a); }
-            } else if (k.gauge12) {
-                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true>), grid, block, pad, c->stream, k);
-                else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, true>), grid, block, pad, c->stream, k);
-            } else {
-                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, true>), grid, block, pad, c->stream, k);
-                else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, true>), grid, block, pad, c->stream, k);
+                launched = true;
             }
 #endif
+            if (!launched) {            // the plain direction-split kernel (fp32 build: the inner chain of the mixed-precision even-odd solver)
+                if (k.gauge12) {
+                    if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true>), grid, block, pad, c->stream, k);
+                    else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, true>), grid, block, pad, c->stream, k);
+                } else {
+                    if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, true>), grid, block, pad, c->stream, k);
+                    else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, true>), grid, block, pad, c->stream, k);
+                }
+            }
         } else if (s.kind == LQCD_WILSON && s.clover_on_hop) {      // even-odd clover solver: out = a xin + b C (H in), C = the inverse clover blocks of the output parity
 #ifdef LQCD_F32
             set_error("stencil: the clover-on-hop form exists in the fp64 build only");

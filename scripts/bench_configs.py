@@ -144,8 +144,12 @@ def main():
     t_ff_cg = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
     it_cg = lq.evaluate_FermiAction(fa, U, eta, return_info=True)[1]
     lat.set_param("action_eo_solver", 1)
-    lat.set_param("mixed_action_solver", 1)
+    lat.set_param("mixed_action_solver", 1)        # plain Wilson: the even-odd solves with the fp32 inner chain (bicg_mixed)
     t_ffm = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
+    it_mx = lq.evaluate_FermiAction(fa, U, eta, return_info=True)[1]
+    lat.set_param("action_eo_solver", 0)           # ... and the mixed-precision CG on the normal equations it replaces
+    t_ffm_cg = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
+    lat.set_param("action_eo_solver", 1)
     lat.set_param("mixed_action_solver", 0)
     res.append({"config": "32^3x64 Wilson HMC, one MD step resident on the device (Sexton-Weingarten N = 10)",
                 "gauge_force_ms": t_gf, "gauge_force_GBps_1152B": 1152 * V / t_gf / 1e6, "momentum_add_ta_ms": t_ta,
@@ -154,7 +158,7 @@ def main():
                 "calc_UdSfdU_ms (two even-odd BiCGStab solves to 1e-16 + sweep)": t_ff, "action_solver_iterations_evenodd_bicgstab": it_eo,
                 "calc_UdSfdU_ms_action_eo_solver0 (CG to 1e-16 + Y = D X + sweep)": t_ff_cg, "action_solver_iterations_cg": it_cg,
                 "evaluate_FermiAction_ms": t_sf,
-                "calc_UdSfdU_mixed_precision_solver_ms": t_ffm,
+                "calc_UdSfdU_mixed_precision_solver_ms": t_ffm, "mixed_evenodd_fp32_iterations": it_mx, "calc_UdSfdU_mixed_precision_cg_ms": t_ffm_cg,
                 "md_step_ms": nsw * (t_pu + 2 * t_up) + t_ff + t_ta,
                 "md_step_mixed_precision_solver_ms": nsw * (t_pu + 2 * t_up) + t_ffm + t_ta,
                 "note": "host<->device traffic per MD step: none (the reference path would move 1.2 GB of links + 2 spinors)"})

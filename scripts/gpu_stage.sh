@@ -58,6 +58,10 @@ case $stage in
     timeout 600 python -m pytest tests/test_gpu_recon12.py tests/test_gpu_pipe.py tests/test_golden_io.py tests/test_gpu_parity.py -q -x 2>&1 | tail -8 | tee $out/pytest.log
     timeout 600 python bench.py --no-pmc > $out/bench.json 2> $out/bench.err; python -c "import json; d=json.load(open('$out/bench.json')); print(d['value'], d['roofline']['frac'], d['gauge_recon18_all_reals_read'], d['reference_format_links'])"
     ;;
+  mixedeo)    # mixed-precision even-odd BiCGStab
+    timeout 900 python -m pytest tests/test_gpu_mixed.py tests/test_gpu_md_mixed.py tests/test_gpu_pair32.py -q -x 2>&1 | tail -12 | tee $out/pytest.log
+    timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; sed -n 5p $out/bench_configs.log | cut -c300-1900; tail -3 $out/bench_configs.err
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

@@ -282,3 +282,46 @@ def test_deferred_x_update_of_the_fp32_solver_gives_identical_results(gpu, orc, 
     lat.set_param("mixed_defer_x", 1)
     assert (out[0][0] is None) == (maxiter < 100) and out[0][0] == out[1][0]
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("L,dagger", [((8, 8, 8, 16), False), ((16, 16, 16, 32), True)])
+def test_mixed_precision_evenodd_bicgstab_keeps_the_stopping_rule(gpu, orc, L, dagger):
+    """Tunable bicg_mixed: the even-odd BiCGStab of the plain Wilson operator with an fp32 inner chain (same fused structure as the fp64 one) inside an
+    fp64 defect correction.  Contract of lqcd_solve_bicgstab_eo unchanged: r.r < eps for the TRUE fp64 residual -- recomputed here by the oracle --
+    and the fp64 solver's solution to solver accuracy; at least two correction steps at eps = 1e-19 (an fp32 recurrence gives ~1e-6 per step)."""
+    import os
+    lq = gpu
+    KAPPA = 0.141139
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
+    Dd = D.adjoint() if dagger else D
+    Dd.method_CG = "bicgstab_evenodd"
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    x64, x32 = b.similar(), b.similar()
+    it64, rr64 = lq.solve_DinvX_(x64, Dd, b, return_info=True)
+    lat.set_param("bicg_mixed", 1)
+    it32, rr32 = lq.solve_DinvX_(x32, Dd, b, return_info=True)
+    lat.set_param("bicg_mixed", 0)
+    assert rr32 < 1e-19 and it32 >= it64           # the fp32 iterations of all correction steps together
+    assert rel_err(x32.download(), x64.download()) < 1e-9
+    orc.set_threads(os.cpu_count() or 1)
+    try:
+        res = b.download() - orc.wilson_D(Uh, x32.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger)
+    finally:
+        orc.set_threads(1)
+    assert np.vdot(res, res).real < 1e-19
+    # through the action: mixed_action_solver = 1 takes this route for the plain Wilson operator
+    fa = lq.FermiAction(D)
+    eta = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(eta, 114)
+    S0 = lq.evaluate_FermiAction(fa, U, eta)
+    G0, G1 = lq.Gaugefields(lat), lq.Gaugefields(lat)
+    lq.calc_UdSfdU_(G0, fa, U, eta)
+    lat.set_param("mixed_action_solver", 1)
+    S1 = lq.evaluate_FermiAction(fa, U, eta)
+    lq.calc_UdSfdU_(G1, fa, U, eta)
+    lat.set_param("mixed_action_solver", 0)
+    assert abs(S1 - S0) < 1e-10 * abs(S0) and rel_err(G1.download(), G0.download()) < 1e-8
