@@ -8,7 +8,7 @@ thermalised fixtures with the parameters of its test/*.toml files, binned errors
  (iii) <exp(-dH)> = 1 within errors for every action (quenched, Wilson Nf = 2, staggered Nf = 4 exact and rational, Nf = 2, Nf = 3):
        heat bath, action and force belong to the SAME Hamiltonian (a wrong exponent in the heat bath, a force that is not the
        derivative of the action, or a missing term shows up here).
-The long-run means are recorded next to the reference's single-configuration values (test/debugplaqdata.txt:2,7-10) in DESIGN.md
+The long-run means are recorded next to the reference's single-configuration values (test/debugplaqdata.txt:2,7-10) in LABNOTES.md
 section 4; round 1's "+5 %" Nf = 2 / 3 plaquettes were single configurations after 10 trajectories (sigma per configuration ~0.012)."""
 import json
 import os

@@ -170,6 +170,21 @@ def test_pipe_rccl_self_partition(gpu, orc):
             its[pipe], rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
             assert np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (pipe, its, ito)
         assert st == 0 and all(abs(v - ito) <= 1 for v in its.values()), (its, ito)
+        # round 4: the scalar-addressing kernel on the 18 stored reals and on "12 + delta" links (a field at a text file's precision), partitioned
+        lat.set_param("dslash_pipe", 2)
+        lat.set_param("gauge_recon", 18)
+        for dag in (False, True):
+            lq.mul_(y, D.adjoint() if dag else D, x)
+            ref = orc.wilson_D(U, psi, L, K, 1.0, BC, dag)
+            assert lat.get_param("recon_active") == 0 and np.abs(y.download() - ref).max() / np.abs(ref).max() < 1e-13, ("s18", dag)
+        lat.set_param("gauge_recon", 12)
+        rng = np.random.default_rng(7)
+        Up = U + 1e-10 * (rng.standard_normal(U.shape) + 1j * rng.standard_normal(U.shape)) / 3.0
+        Ud.upload(Up)
+        for dag in (False, True):
+            lq.mul_(y, D.adjoint() if dag else D, x)
+            ref = orc.wilson_D(Up, psi, L, K, 1.0, BC, dag)
+            assert lat.get_param("recon_active") == 2 and np.abs(y.download() - ref).max() / np.abs(ref).max() < 1e-13, ("delta", dag, lat.get_param("recon_active"))
         print("PIPE_SELF_OK")
     """)
     for mask in ("8", "14", "15"):
