@@ -109,7 +109,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * dslash_s18 (1 [default]: the scalar-addressing kernel also on the 18 stored reals), bicg_fused (even-odd BiCGStab of the Wilson / Wilson-clover operator: 2 [default] inner
  * products from the Schur operator's epilogue and, up to 1024 chunks per parity, reductions and scalar steps in the consumers' prologues; 1 the same with separate reduction
  * launches -- bit-identical to 2; 0 the generic chain), action_eo_solver (1 [default]: lqcd_fermi_action / lqcd_calc_UdSfdU / lqcd_action_* solve the Wilson(-clover) normal
- * equations as two even-odd BiCGStab solves under the reference's stopping rule; 0: CG), lazy_links (1 [default]: the per-direction link-call triples are recorded and fused,
+ * equations as two even-odd BiCGStab solves under the reference's stopping rule; 0: CG), bicg_mixed (1: lqcd_solve_bicgstab_eo on the plain Wilson operator runs an fp32 inner
+ * chain inside an fp64 defect correction, the stopping rule holds for the true fp64 residual; mixed_action_solver = 1 switches it on for the action solves), lazy_links (1 [default]: the per-direction link-call triples are recorded and fused,
  * see lqcd_link_*; read-only lazy_open, lazy_deferred). */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
 int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);

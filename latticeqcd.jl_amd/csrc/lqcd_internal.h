@@ -676,8 +676,8 @@ int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_ga
 // stencil_pair32.hip: fp32 Wilson Dslash on site pairs (StencilCall::prec == 2) and the conversions of its field layout
 bool pair32_geometry_ok(lqcd_ctx_s* c);
 int pair32_num_blocks(lqcd_ctx_s* c);
-int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale);
-int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a);
+int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar = 2);      // npar = 1: one parity block
+int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a, int npar = 2);
 int pair32_cvt_gauge12(lqcd_ctx_s* c, float2* dst, const double2* src12);
 int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build

@@ -416,7 +416,26 @@ __device__ inline void cfma32(float& xr, float& xi, float ar, float ai, float br
     xr = fmaf(ar, br, xr); xr = fmaf(-ai, bi, xr);
     xi = fmaf(ar, bi, xi); xi = fmaf(ai, br, xi);
 }
+// the two complex numbers of a 16-byte word: component pairs (re0, im0, re1, im1) of the one-site-per-lane fp32 build, or the site pairs
+// (reA, reB, imA, imB) of stencil_pair32.hip
+template <bool PAIR>
+__device__ inline void cfma4(float4& x, float ar, float ai, const float4 b) {      // x += a b on both
+    if constexpr (PAIR) { cfma32(x.x, x.z, ar, ai, b.x, b.z); cfma32(x.y, x.w, ar, ai, b.y, b.w); }
+    else { cfma32(x.x, x.y, ar, ai, b.x, b.y); cfma32(x.z, x.w, ar, ai, b.z, b.w); }
+}
+__device__ inline double norm4(const float4 v) { return (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w); }
+template <bool PAIR>
+__device__ inline void cdot4(double& re, double& im, const float4 z, const float4 r) {      // += conj(z) r on both
+    if constexpr (PAIR) {
+        re += (double)(z.x * r.x + z.z * r.z) + (double)(z.y * r.y + z.w * r.w);
+        im += (double)(z.x * r.z - z.z * r.x) + (double)(z.y * r.w - z.w * r.y);
+    } else {
+        re += (double)(z.x * r.x + z.y * r.y) + (double)(z.z * r.z + z.w * r.w);
+        im += (double)(z.x * r.y - z.y * r.x) + (double)(z.z * r.w - z.w * r.z);
+    }
+}
 // s = r - alpha v ; partial |s|^2
+template <bool PAIR>
 __global__ __launch_bounds__(UB) void bicgf32_s(BicgF a, float4* __restrict__ s, const float4* __restrict__ r, const float4* __restrict__ v, size_t n4) {
     if (a.sc[B_DONE] != 0.0) return;
     const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
@@ -431,10 +450,9 @@ __global__ __launch_bounds__(UB) void bicgf32_s(BicgF a, float4* __restrict__ s,
     const float ar = -(float)al.re, ai = -(float)al.im;
     double acc[1] = {0};
     auto one = [&](size_t i, float4 sv, const float4 vv) {
-        cfma32(sv.x, sv.y, ar, ai, vv.x, vv.y);
-        cfma32(sv.z, sv.w, ar, ai, vv.z, vv.w);
+        cfma4<PAIR>(sv, ar, ai, vv);
         s[i] = sv;
-        acc[0] += (double)(sv.x * sv.x + sv.y * sv.y) + (double)(sv.z * sv.z + sv.w * sv.w);
+        acc[0] += norm4(sv);
     };
 #pragma unroll
     for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pr[e], pv[e]); }
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(UB) void bicgf32_s(BicgF a, float4* __restrict__ s,
     block_reduce_nv<1>(acc, a.pout);
 }
 // x += alpha p + omega s ; r = s - omega t ; partials |r|^2, <r0, r>
+template <bool PAIR>
 __global__ __launch_bounds__(UB) void bicgf32_xr(BicgF a, float4* __restrict__ x, float4* __restrict__ r, const float4* __restrict__ p, const float4* __restrict__ s,
                                                   const float4* __restrict__ t, const float4* __restrict__ r0, size_t n4) {
     if (a.sc[B_DONE] != 0.0) return;
@@ -468,13 +487,12 @@ __global__ __launch_bounds__(UB) void bicgf32_xr(BicgF a, float4* __restrict__ x
     double acc[3] = {0, 0, 0};
     auto one = [&](size_t i, const float4 pv, const float4 sv, const float4 tv, const float4 zv, float4 xv) {
         float4 rv = sv;
-        cfma32(xv.x, xv.y, ar, ai, pv.x, pv.y); cfma32(xv.z, xv.w, ar, ai, pv.z, pv.w);
-        cfma32(xv.x, xv.y, wr, wi, sv.x, sv.y); cfma32(xv.z, xv.w, wr, wi, sv.z, sv.w);
-        cfma32(rv.x, rv.y, -wr, -wi, tv.x, tv.y); cfma32(rv.z, rv.w, -wr, -wi, tv.z, tv.w);
+        cfma4<PAIR>(xv, ar, ai, pv);
+        cfma4<PAIR>(xv, wr, wi, sv);
+        cfma4<PAIR>(rv, -wr, -wi, tv);
         x[i] = xv; r[i] = rv;
-        acc[0] += (double)(rv.x * rv.x + rv.y * rv.y) + (double)(rv.z * rv.z + rv.w * rv.w);
-        acc[1] += (double)(zv.x * rv.x + zv.y * rv.y) + (double)(zv.z * rv.z + zv.w * rv.w);        // <r0, r> = conj(r0) r
-        acc[2] += (double)(zv.x * rv.y - zv.y * rv.x) + (double)(zv.z * rv.w - zv.w * rv.z);
+        acc[0] += norm4(rv);
+        cdot4<PAIR>(acc[1], acc[2], zv, rv);        // <r0, r> = conj(r0) r
     };
 #pragma unroll
     for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pp[e], ps[e], pt[e], pz[e], px[e]); }
@@ -482,6 +500,7 @@ __global__ __launch_bounds__(UB) void bicgf32_xr(BicgF a, float4* __restrict__ x
     block_reduce_nv<3>(acc, a.pout);
 }
 // p = r + beta (p - omega v)
+template <bool PAIR>
 __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p, const float4* __restrict__ r, const float4* __restrict__ v, size_t n4) {
     if (a.sc[B_DONE] != 0.0) return;
     const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
@@ -503,9 +522,9 @@ __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p,
     if (lead) { a.sc[B_BETA] = be.re; a.sc[B_BETA + 1] = be.im; a.sc[a.rho_out] = rho1.re; a.sc[a.rho_out + 1] = rho1.im; }
     const float br = (float)be.re, bi = (float)be.im, wr = -(float)wrd, wi = -(float)wid;
     auto one = [&](size_t i, const float4 vv, const float4 rv, float4 pv) {
-        cfma32(pv.x, pv.y, wr, wi, vv.x, vv.y); cfma32(pv.z, pv.w, wr, wi, vv.z, vv.w);      // p - omega v
+        cfma4<PAIR>(pv, wr, wi, vv);      // p - omega v
         float4 o = rv;
-        cfma32(o.x, o.y, br, bi, pv.x, pv.y); cfma32(o.z, o.w, br, bi, pv.z, pv.w);
+        cfma4<PAIR>(o, br, bi, pv);
         p[i] = o;
     };
 #pragma unroll
@@ -516,7 +535,8 @@ __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p,
 
 struct Eo32 {
     float2 *gauge, *gauge12;
-    float2 *x, *r, *r0, *p, *v, *s, *t, *to;      // half-lattice vectors, component-pair layout
+    float2 *x, *r, *r0, *p, *v, *s, *t, *to;      // half-lattice vectors
+    int layout;                                    // 1: component pairs (fp32 build of stencil.hip), 2: site pairs (stencil_pair32.hip: half the launches' latencies per site)
 };
 // one Schur application on the fp32 fields: to = H_oe in, out = in - k^2 H_eo to [+ inner-product epilogue]
 static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const float2* z, double* dotp, int conj, int dg, const double* skip) {
@@ -524,20 +544,20 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
     StencilCall s1;
     s1.kind = LQCD_WILSON; s1.gauge = (const double2*)m.gauge; s1.gauge12 = (const double2*)m.gauge12;
     s1.out[0] = nullptr; s1.out[1] = (double2*)m.to; s1.in[0] = (const double2*)in; s1.in[1] = nullptr; s1.xin[0] = s1.xin[1] = nullptr;
-    s1.a = 0.0; s1.b = 1.0; s1.r = 1.0; s1.dagger = dg; s1.parity_mode = 1; s1.prec = 1; s1.skip_flag = skip;
+    s1.a = 0.0; s1.b = 1.0; s1.r = 1.0; s1.dagger = dg; s1.parity_mode = 1; s1.prec = m.layout == 2 ? 2 : 1; s1.skip_flag = skip;
     LQCHK(stencil_apply(c, s1));
     StencilCall s2;
     s2.kind = LQCD_WILSON; s2.gauge = (const double2*)m.gauge; s2.gauge12 = (const double2*)m.gauge12;
     s2.out[0] = (double2*)out; s2.out[1] = nullptr; s2.in[0] = nullptr; s2.in[1] = (const double2*)m.to; s2.xin[0] = (const double2*)in; s2.xin[1] = nullptr;
-    s2.a = 1.0; s2.b = -op->km * op->km; s2.r = 1.0; s2.dagger = dg; s2.parity_mode = 0; s2.prec = 1; s2.skip_flag = skip;
+    s2.a = 1.0; s2.b = -op->km * op->km; s2.r = 1.0; s2.dagger = dg; s2.parity_mode = 0; s2.prec = m.layout == 2 ? 2 : 1; s2.skip_flag = skip;
     if (z) { s2.dot_z[0] = (const double2*)z; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
     return stencil_apply(c, s2);
 }
 // e ~ M^-1 rhs32 (|rhs32|^2 = 1, zero guess) until the recursive residual is below eps2; m.r holds rhs32 on entry
 static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters) {
     lqcd_ctx_s* c = op->ctx;
-    const size_t n4 = nh / 2, b32 = nh * sizeof(float2);
-    const int nbs = stencil_num_blocks(c, LQCD_WILSON, 1.0, 0, 1);
+    const size_t n4 = (size_t)6 * c->geom.Vh, b32 = nh * sizeof(float2);      // the sites only: the padding chunk of a parity block is not part of a pair field
+    const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : stencil_num_blocks(c, LQCD_WILSON, 1.0, 0, 1);
     const int nbk = (int)std::min<size_t>(1024, (n4 + UB - 1) / UB);
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
     double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)3 * nbs;
@@ -561,16 +581,20 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
             LQCHK(schur32(op, m, m.v, m.p, m.r0, P0, 0, dg, skip));
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0));
             a.pin = P0; a.pin_n = nbs; a.pout = P1;
-            hipLaunchKernelGGL(bicgf32_s, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
+            if (m.layout == 2) hipLaunchKernelGGL(bicgf32_s<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
+            else hipLaunchKernelGGL(bicgf32_s<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
             LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip));
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
             a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
-            hipLaunchKernelGGL(bicgf32_xr, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (const float4*)m.p, (const float4*)m.s, (const float4*)m.t,
-                               (const float4*)m.r0, n4);
+            if (m.layout == 2) hipLaunchKernelGGL(bicgf32_xr<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (const float4*)m.p, (const float4*)m.s,
+                                                  (const float4*)m.t, (const float4*)m.r0, n4);
+            else hipLaunchKernelGGL(bicgf32_xr<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (const float4*)m.p, (const float4*)m.s,
+                                    (const float4*)m.t, (const float4*)m.r0, n4);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 3, B_RR, true, 0, P3));
             a.pin = P3; a.pin_n = nbk; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
-            hipLaunchKernelGGL(bicgf32_p, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
+            if (m.layout == 2) hipLaunchKernelGGL(bicgf32_p<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
+            else hipLaunchKernelGGL(bicgf32_p<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + B_RHO, (B_END - B_RHO) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -590,12 +614,9 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
     const size_t nh = xe.elems, nfull = 2 * nh;
     // fp32 links and work space: the buffers of the mixed-precision CG (four full-lattice vectors = eight halves), component-pair layout
     Mix32 mm;
-    const int pair0 = c->tun.mixed_pair32;
-    c->tun.mixed_pair32 = 0;                       // the site-pair kernel has no parity hops: this solve takes the fp32 build of the direction-split kernel
-    const int stp = mix_prepare(op, nfull, mm);
-    c->tun.mixed_pair32 = pair0;
-    LQCHK(stp);
+    LQCHK(mix_prepare(op, nfull, mm));             // layout 2 (site pairs) where stencil_pair32.hip applies, else the component pairs of the fp32 build
     Eo32 m;
+    m.layout = mm.layout;
     m.gauge = mm.gauge; m.gauge12 = mm.gauge12;
     m.x = mm.x; m.r = mm.x + nh; m.r0 = mm.r; m.p = mm.r + nh; m.v = mm.p; m.s = mm.p + nh; m.t = mm.t; m.to = mm.t + nh;
     lqcd_spinor_s *r = w[0], *q = w[1];
@@ -610,20 +631,25 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         *rr = c->h_scal[0];
         return LQCD_OK;
     };
-    double rr = 0, bb = 0;
-    LQCHK(blas_norm2(c, rhs->data, nh, &bb, true));
-    LQCHK(true_residual(&rr));
+    double rr = 0, xx = 0;
+    LQCHK(blas_norm2(c, xe.data, nh, &xx, true));
+    if (xx == 0.0) {      // zero guess (what the action solves pass): r = rhs, no Schur application needed
+        HIPCHK(hipMemcpyAsync(r->data, rhs->data, nh * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+        LQCHK(blas_norm2(c, rhs->data, nh, &rr, true));
+    } else LQCHK(true_residual(&rr));
     int total = 0, outer = 0;
     while (rr >= eps && outer < 12 && total < maxiter) {
         // as few correction steps as an fp32 recurrence supports: one per 1e-6 of the residual norm still to go, the reduction split evenly
         const double togo = std::sqrt(eps / rr) * 0.5;
         const int nsteps = std::max(1, (int)std::ceil(std::log10(1.0 / std::min(togo, 0.1)) / 6.0));
         const double tol = std::max(std::pow(togo, 1.0 / nsteps), 2e-7);
-        LQCHK(to_f32(c, 1, m.r, r->data, nh, 1.0 / std::sqrt(rr)));
+        if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, r->data, 1.0 / std::sqrt(rr), 1));
+        else LQCHK(to_f32(c, 1, m.r, r->data, nh, 1.0 / std::sqrt(rr)));
         int it = 0;
         LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol, maxiter - total, &it));
         total += it;
-        LQCHK(add_from_f32(c, 1, xe.data, m.x, std::sqrt(rr), nh));
+        if (m.layout == 2) LQCHK(pair32_axpy_to_f64(c, xe.data, m.x, std::sqrt(rr), 1));
+        else LQCHK(add_from_f32(c, 1, xe.data, m.x, std::sqrt(rr), nh));
         double rrn = 0;
         LQCHK(true_residual(&rrn));
         outer++;

@@ -134,6 +134,9 @@ struct PairArgs {
     double* norm_partial;
     const double* upd_scal;
     const double* skip;
+    const float4* dotz[2];    // dot mode (StencilCall::dot_z): Re / Im <z, out> and |out|^2 per workgroup -> dot_partial[3 b ..]
+    double* dot_partial;
+    int dot_conj;
     float a, b;
     int nt_store;
     int both, pmode;
@@ -235,8 +238,8 @@ __device__ __forceinline__ void apply_sign(cx (&h0)[3], cx (&h1)[3], v2f sign) {
     }
 }
 
-template <int MU, bool DAG, bool NTB>
-__device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][64], int lane, float al_upd, v2f& nrm) {
+template <int MU, bool DAG, bool NTB, bool DOT = false>
+__device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][64], int lane, float al_upd, v2f& nrm, v2f& dre, v2f& dim) {
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;
     constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;
@@ -246,7 +249,13 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
     cx xv[3], rv[3];
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) { xv[cc] = mkx(splat(0.f), splat(0.f)); rv[cc] = xv[cc]; }
-    if (a.upd_scal) {
+    const bool z_is_x = DOT && (s.p ? a.dotz[1] == a.xin[1] : a.dotz[0] == a.xin[0]) && a.a != 0.f;
+    if constexpr (DOT) {        // dot mode: z takes the registers the old r has in update mode
+        if (!z_is_x) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) rv[cc] = ldx(boff(s.p ? a.dotz[1] : a.dotz[0], s.own) + (3 * MU + cc) * 64);
+        }
+    } else if (a.upd_scal) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) rv[cc] = ldx(boff(s.p ? a.dst[1] : a.dst[0], s.own) + (3 * MU + cc) * 64);
     }
@@ -321,7 +330,13 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
         const v2f sre = (v2f{s0.x, s0.y} + v2f{s1.x, s1.y}) + (v2f{s2.x, s2.y} + v2f{s3.x, s3.y});
         const v2f sim = (v2f{s0.z, s0.w} + v2f{s1.z, s1.w}) + (v2f{s2.z, s2.w} + v2f{s3.z, s3.w});
         cx v = mkx(vfma(av, xv[cc].re, bv * sre), vfma(av, xv[cc].im, bv * sim));
-        if (a.upd_scal) {
+        if constexpr (DOT) {        // <z, v> = conj(z) v per slot, next to |v|^2
+            const cx z = z_is_x ? xv[cc] : rv[cc];
+            nrm = vfma(v.re, v.re, nrm); nrm = vfma(v.im, v.im, nrm);
+            if (a.nt_store) stx_nt(dstp + j * 64, v); else stx(dstp + j * 64, v);
+            dre = vfma(z.re, v.re, dre); dre = vfma(z.im, v.im, dre);
+            dim = vfma(z.re, v.im, dim); dim = vfma(-z.im, v.re, dim);
+        } else if (a.upd_scal) {
             cx r = rv[cc];
             r.re = vfma(mal, v.re, r.re); r.im = vfma(mal, v.im, r.im);
             nrm = vfma(r.re, r.re, nrm); nrm = vfma(r.im, r.im, nrm);
@@ -338,20 +353,33 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
     }
 }
 
-template <bool DAG, bool NTB>
+template <bool DAG, bool NTB, bool DOT = false>
 __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
     __shared__ float4 part[4][12][64];  // 48 KiB
-    __shared__ double red[4];
+    __shared__ double red[DOT ? 12 : 4];
     if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) return;
     const float al_upd = a.upd_scal ? (float)a.upd_scal[S_ALPHA] : 0.f;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    v2f nrm = splat(0.f);
+    v2f nrm = splat(0.f), dre = splat(0.f), dim = splat(0.f);
     switch (w) {
-    case 0: pair_wave<0, DAG, NTB>(a, part, lane, al_upd, nrm); break;
-    case 1: pair_wave<1, DAG, NTB>(a, part, lane, al_upd, nrm); break;
-    case 2: pair_wave<2, DAG, NTB>(a, part, lane, al_upd, nrm); break;
-    default: pair_wave<3, DAG, NTB>(a, part, lane, al_upd, nrm); break;
+    case 0: pair_wave<0, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 1: pair_wave<1, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 2: pair_wave<2, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    default: pair_wave<3, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    }
+    if constexpr (DOT) {                // three sums per workgroup (both slots of a lane), the order of the fp64 kernels' dot epilogue
+        const double di = (double)dim.x + (double)dim.y;
+        double t3[3] = {(double)dre.x + (double)dre.y, a.dot_conj ? -di : di, (double)nrm.x + (double)nrm.y};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t3[q] += __shfl_down(t3[q], off, 64);
+            if (lane == 0) red[4 * q + w] = t3[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) a.dot_partial[3 * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        return;
     }
     if (a.norm_partial) {
         double s = (double)nrm.x + (double)nrm.y;
@@ -366,8 +394,8 @@ __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
 // ------------------------------------------------------------------------------------------ layout conversions
 // pair (p, i) of the half lattice <-> sites (p, i) and (p, i + Vh/2) of the full lattice; blk64 = fp64 elements of one parity block
 // (a parity block of either field is blk64 elements of its own type apart: the padding chunk of the fp64 layout stays unused in the pair field)
-__global__ __launch_bounds__(256) void cvt_wilson_to_pair32(float4* __restrict__ dst, const double2* __restrict__ src, int Vh, int nchp, size_t blk64, double scale) {
-    const size_t n = (size_t)2 * nchp * 768;
+__global__ __launch_bounds__(256) void cvt_wilson_to_pair32(float4* __restrict__ dst, const double2* __restrict__ src, int Vh, int nchp, size_t blk64, double scale, int npar) {
+    const size_t n = (size_t)npar * nchp * 768;       // npar = 1: ONE parity block (the even-odd solver's half-lattice vectors; dst / src point at it)
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
         const int lane = (int)(t & 63), j = (int)((t >> 6) % 12), chp = (int)((t / 768) % nchp), p = (int)(t / ((size_t)768 * nchp));
         const int iA = chp * 64 + lane, iB = iA + Vh / 2;
@@ -376,8 +404,8 @@ __global__ __launch_bounds__(256) void cvt_wilson_to_pair32(float4* __restrict__
     }
 }
 // y (fp64, full lattice) += a * x (pairs)
-__global__ __launch_bounds__(256) void axpy_from_pair32(double2* __restrict__ y, const float4* __restrict__ x, int Vh, int nchp, size_t blk64, double a) {
-    const size_t n = (size_t)2 * nchp * 768;
+__global__ __launch_bounds__(256) void axpy_from_pair32(double2* __restrict__ y, const float4* __restrict__ x, int Vh, int nchp, size_t blk64, double a, int npar) {
+    const size_t n = (size_t)npar * nchp * 768;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
         const int lane = (int)(t & 63), j = (int)((t >> 6) % 12), chp = (int)((t / 768) % nchp), p = (int)(t / ((size_t)768 * nchp));
         const int iA = chp * 64 + lane, iB = iA + Vh / 2;
@@ -415,17 +443,17 @@ bool pair32_geometry_ok(lqcd_ctx_s* c) {
 }
 int pair32_num_blocks(lqcd_ctx_s* c) { return c->geom.nch; }      // 2 parities x nch / 2 chunks of pairs
 
-int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale) {
+int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar) {
     const Geom& g = c->geom;
     hipLaunchKernelGGL(pair32::cvt_wilson_to_pair32, dim3(stream_grid(c, (size_t)g.nch * 768)), dim3(256), 0, c->stream, (float4*)dst, src, g.Vh, g.nch / 2,
-                       (size_t)12 * g.Vs, scale);
+                       (size_t)12 * g.Vs, scale, npar);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
-int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a) {
+int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a, int npar) {
     const Geom& g = c->geom;
     hipLaunchKernelGGL(pair32::axpy_from_pair32, dim3(stream_grid(c, (size_t)g.nch * 768)), dim3(256), 0, c->stream, y, (const float4*)x, g.Vh, g.nch / 2,
-                       (size_t)12 * g.Vs, a);
+                       (size_t)12 * g.Vs, a, npar);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
@@ -439,8 +467,9 @@ int pair32_cvt_gauge12(lqcd_ctx_s* c, float2* dst, const double2* src12) {
 // the launcher behind stencil_apply for StencilCall::prec == 2 (fields in pair layout; full-lattice applications only)
 int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     using namespace pair32;
-    ARGCHK(s.kind == LQCD_WILSON && s.r == 1.0 && s.parity_mode == 2 && s.gauge12 && !s.clover && !s.alpha_partials && pair32_geometry_ok(c),
-           "pair32 stencil: Wilson r = 1 full-lattice applications with 12-real links on an unpartitioned lattice only");
+    ARGCHK(s.kind == LQCD_WILSON && s.r == 1.0 && s.gauge12 && !s.clover && !s.alpha_partials && pair32_geometry_ok(c),
+           "pair32 stencil: Wilson r = 1 with 12-real links on an unpartitioned lattice only");
+    ARGCHK(!(s.dot_partial && s.upd_scal), "pair32 stencil: dot mode and update mode exclude each other");
     const Geom& g = c->geom;
     PairArgs a;
     a.gauge = (const float4*)s.gauge12;
@@ -448,9 +477,11 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     for (int p = 0; p < 2; p++) { a.dst[p] = (float4*)(upd ? s.upd[p] : s.out[p]); a.in[p] = (const float4*)s.in[p]; a.xin[p] = (const float4*)s.xin[p]; }
     for (int p = 0; p < 2; p++) { a.xacc[p] = upd ? (float4*)s.xacc[p] : nullptr; a.pacc[p] = upd ? (const float4*)s.pacc[p] : nullptr; }
     a.norm_partial = s.norm_partial; a.upd_scal = s.upd_scal; a.skip = s.skip_flag;
+    for (int p = 0; p < 2; p++) a.dotz[p] = (const float4*)s.dot_z[p];
+    a.dot_partial = s.dot_partial; a.dot_conj = s.dot_conj;
     a.a = (float)s.a; a.b = (float)s.b;
     a.nt_store = c->tun.nt_store != 0;
-    a.both = 1; a.pmode = 0;
+    a.both = s.parity_mode == 2 ? 1 : 0; a.pmode = s.parity_mode == 2 ? 0 : s.parity_mode;      // parity hops: the pairs of ONE parity (even-odd solvers)
     a.XH = g.XH; a.L1 = g.L[1]; a.L2 = g.L[2]; a.LTh = g.L[3] / 2; a.nchp = g.nch / 2; a.dXH = g.dXH;
     for (int mu = 0; mu < 4; mu++) { a.sgn_f[mu] = (float)g.bc_fwd[mu]; a.sgn_b[mu] = (float)g.bc_bwd[mu]; }
     // the XCD tile sweep of stencil.hip make_kargs on the half lattice
@@ -466,9 +497,14 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     a.per_pass = std::max(1, a.cpr * a.LTh);
     a.d_perpass = make_fastdiv(a.per_pass); a.d_cpr = make_fastdiv(std::max(1, a.cpr)); a.d_ysplit = make_fastdiv(std::max(1, a.ysplit));
     a.d_ty = make_fastdiv(std::max(1, a.ty)); a.d_cpp = make_fastdiv(std::max(1, a.cpp));
-    const dim3 grid(pair32_num_blocks(c)), block(256);
+    const dim3 grid(s.parity_mode == 2 ? pair32_num_blocks(c) : pair32_num_blocks(c) / 2), block(256);
     const bool ntb = (c->tun.nt_gauge & 1) != 0;
-    if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<true, true>), grid, block, 0, c->stream, a);
+    if (s.dot_partial) {
+        if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<true, true, true>), grid, block, 0, c->stream, a);
+                        else hipLaunchKernelGGL((wilson_dirsplit_pair32<true, false, true>), grid, block, 0, c->stream, a); }
+        else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<false, true, true>), grid, block, 0, c->stream, a);
+               else hipLaunchKernelGGL((wilson_dirsplit_pair32<false, false, true>), grid, block, 0, c->stream, a); }
+    } else if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<true, true>), grid, block, 0, c->stream, a);
                     else hipLaunchKernelGGL((wilson_dirsplit_pair32<true, false>), grid, block, 0, c->stream, a); }
     else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<false, true>), grid, block, 0, c->stream, a);
            else hipLaunchKernelGGL((wilson_dirsplit_pair32<false, false>), grid, block, 0, c->stream, a); }
