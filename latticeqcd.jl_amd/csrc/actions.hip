@@ -39,8 +39,8 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
     }
     bool have_Y = false;
     if (even_only) LQCHK(lqcd_solve_cg_DdagD_parity(op, X, eta, 0, eps, maxiter, iters, nullptr));
-    // mixed_action_solver: plain Wilson takes the even-odd route below with the fp32 inner chain (bicg_mixed); everything else the mixed-precision CG
-    else if (c->tun.mixed_action_solver && !(op->kind == LQCD_WILSON && c->tun.action_eo_solver && op->csw == 0.0 && op->r == 1.0 && !any_partitioned(c) && !c->has_comm))
+    // mixed_action_solver: Wilson and Wilson-clover (r = 1, one rank) take the even-odd route below with the fp32 inner chain (bicg_mixed); everything else the mixed-precision CG
+    else if (c->tun.mixed_action_solver && !(op->kind == LQCD_WILSON && c->tun.action_eo_solver && op->r == 1.0 && c->tun.dslash_variant == 1 && !any_partitioned(c) && !c->has_comm))
         LQCHK(lqcd_solve_mixed_cg_DdagD(op, X, eta, eps, maxiter, 0.0, iters, nullptr, nullptr));
     else {
         // Wilson(-clover), tunable action_eo_solver: X = (D^+D)^-1 eta as TWO even-odd preconditioned BiCGStab solves, Y = D^-+ eta and X = D^-1 Y --

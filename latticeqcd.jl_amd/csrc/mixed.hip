@@ -535,6 +535,7 @@ __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p,
 
 struct Eo32 {
     float2 *gauge, *gauge12;
+    const float2* ainv = nullptr;                  // Wilson-clover: fp32 copy of the packed inverse clover blocks (applied to the hop sums inside the hops)
     float2 *x, *r, *r0, *p, *v, *s, *t, *to;      // half-lattice vectors
     int layout;                                    // 1: component pairs (fp32 build of stencil.hip), 2: site pairs (stencil_pair32.hip: half the launches' latencies per site)
 };
@@ -545,11 +546,13 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
     s1.kind = LQCD_WILSON; s1.gauge = (const double2*)m.gauge; s1.gauge12 = (const double2*)m.gauge12;
     s1.out[0] = nullptr; s1.out[1] = (double2*)m.to; s1.in[0] = (const double2*)in; s1.in[1] = nullptr; s1.xin[0] = s1.xin[1] = nullptr;
     s1.a = 0.0; s1.b = 1.0; s1.r = 1.0; s1.dagger = dg; s1.parity_mode = 1; s1.prec = m.layout == 2 ? 2 : 1; s1.skip_flag = skip;
+    if (m.ainv) { s1.clover = (const double2*)m.ainv; s1.clover_on_hop = 1; }
     LQCHK(stencil_apply(c, s1));
     StencilCall s2;
     s2.kind = LQCD_WILSON; s2.gauge = (const double2*)m.gauge; s2.gauge12 = (const double2*)m.gauge12;
     s2.out[0] = (double2*)out; s2.out[1] = nullptr; s2.in[0] = nullptr; s2.in[1] = (const double2*)m.to; s2.xin[0] = (const double2*)in; s2.xin[1] = nullptr;
     s2.a = 1.0; s2.b = -op->km * op->km; s2.r = 1.0; s2.dagger = dg; s2.parity_mode = 0; s2.prec = m.layout == 2 ? 2 : 1; s2.skip_flag = skip;
+    if (m.ainv) { s2.clover = (const double2*)m.ainv; s2.clover_on_hop = 1; }
     if (z) { s2.dot_z[0] = (const double2*)z; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
     return stencil_apply(c, s2);
 }
@@ -609,7 +612,7 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
 }
 
 int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
-                             int maxiter, int* iters, double* final_rr) {
+                             int maxiter, int* iters, double* final_rr, const double2* Ai) {
     lqcd_ctx_s* c = op->ctx;
     const size_t nh = xe.elems, nfull = 2 * nh;
     // fp32 links and work space: the buffers of the mixed-precision CG (four full-lattice vectors = eight halves), component-pair layout
@@ -618,11 +621,18 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
     Eo32 m;
     m.layout = mm.layout;
     m.gauge = mm.gauge; m.gauge12 = mm.gauge12;
+    if (Ai) {      // Wilson-clover (layout 1: the site-pair kernel carries no clover term): the inverse blocks in fp32, rebuilt with the inverse
+        const size_t nc = clover_elems(c->geom);
+        LQCHK(mix_alloc(c, 6, nc * sizeof(float2)));      // the slot of the fp32 clover blocks of the mixed-precision CG (converted per solve there as well)
+        hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, (float2*)c->mix_buf[6], Ai, nc, 1.0);
+        HIPCHK(hipGetLastError());
+        m.ainv = (const float2*)c->mix_buf[6];
+    }
     m.x = mm.x; m.r = mm.x + nh; m.r0 = mm.r; m.p = mm.r + nh; m.v = mm.p; m.s = mm.p + nh; m.t = mm.t; m.to = mm.t + nh;
     lqcd_spinor_s *r = w[0], *q = w[1];
     const int nb = stream_grid(c, nh);
     auto true_residual = [&](double* rr) -> int {      // r = rhs - M x in fp64
-        LQCHK(schur_wilson(op, q, &xe, to, dg));
+        LQCHK(schur_wilson(op, q, &xe, to, dg, Ai));
         hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(MB), 0, c->stream, r->data, rhs->data, q->data, (const double2*)nullptr, 0.0, nh, c->d_partial);
         HIPCHK(hipGetLastError());
         LQCHK(reduce_to_slot(c, nb, 1, S_RED0, true, 0));
@@ -662,7 +672,7 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
     if (rr < eps) return LQCD_OK;
     // fp32 accuracy exhausted (or a breakdown of the fp32 recurrence): the fp64 chain finishes from the current iterate
     int it64 = 0;
-    const int st = bicgstab_eo_wilson(op, xe, rhs, w, to, dg, eps, std::max(1, maxiter - total), &it64, final_rr);
+    const int st = bicgstab_eo_wilson(op, xe, rhs, w, to, dg, eps, std::max(1, maxiter - total), &it64, final_rr, Ai);
     if (iters) *iters = total + it64;
     return st;
 }

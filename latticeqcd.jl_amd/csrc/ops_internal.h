@@ -81,12 +81,12 @@ struct BicgF {
     double* pout;           // this kernel's partials
 };
 #endif
-int schur_wilson(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* to, int dg);      // out = (1 - k^2 H_eo H_oe) in on the even sites (fp64, plain Wilson)
+int schur_wilson(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* to, int dg, const double2* Ai = nullptr);      // out = (1 - k^2 [A^-1] H_eo [A^-1] H_oe) in on the even sites (fp64)
 int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
                        int maxiter, int* iters, double* final_rr, const double2* Ai = nullptr);
 // mixed.hip: the same solve with an fp32 inner chain and fp64 defect correction (plain Wilson, 12-real links); outer: correction steps
 int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
-                             int maxiter, int* iters, double* final_rr);
+                             int maxiter, int* iters, double* final_rr, const double2* Ai = nullptr);
 
 // scratch fields of one call: returned to the context's pool on every exit path
 struct ScratchScope {

@@ -832,11 +832,13 @@ __global__ __launch_bounds__(UB) void bicgf_p(BicgF a, double2* __restrict__ p, 
 // Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and iteration count as bicgstab_core.
 // Ai != nullptr: Wilson-clover, M = 1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe with the packed inverse blocks applied to the hop sums inside the two hops
 // (StencilCall::clover_on_hop) -- still two launches per M, no intermediate field.
-int schur_wilson(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* to, int dg) {      // out = (1 - k^2 H_eo H_oe) in, fp64, plain Wilson
+int schur_wilson(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* to, int dg, const double2* Ai) {      // out = (1 - k^2 [A_ee^-1] H_eo [A_oo^-1] H_oe) in, fp64
     lqcd_ctx_s* c = op->ctx;
     StencilCall s1 = make_hop_call(op, to, in, nullptr, 0.0, 1.0, dg);
+    if (Ai) { s1.clover = Ai; s1.clover_on_hop = 1; }
     LQCHK(stencil_apply(c, s1));
     StencilCall s2 = make_hop_call(op, out, to, in, 1.0, -op->km * op->km, dg);
+    if (Ai) { s2.clover = Ai; s2.clover_on_hop = 1; }
     return stencil_apply(c, s2);
 }
 int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
@@ -1181,8 +1183,8 @@ extern "C" int lqcd_solve_bicgstab_eo(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor
                 return clover_apply_parity(c, Ai, 0, out, te->data, -k * k, in, 1.0);        // out = in - k^2 A_ee^-1 t_e
             };
         }
-        const bool mixed = fused && !clov && c->tun.bicg_mixed;       // fp32 inner chain, fp64 defect correction (mixed.hip); same contract
-        const int sc = mixed ? bicgstab_eo_wilson_mixed(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr)
+        const bool mixed = fused && c->tun.bicg_mixed;                // fp32 inner chain, fp64 defect correction (mixed.hip); same contract
+        const int sc = mixed ? bicgstab_eo_wilson_mixed(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr, clov ? Ai : nullptr)
                      : fused ? bicgstab_eo_wilson(op, xe, rhs, wsp, to, dg, eps, maxiter, iters, final_rr, clov ? Ai : nullptr)
                              : bicgstab_core(c, A, nh, xe.data, rhs->data, wd, eps, maxiter, iters, final_rr);
         // the odd half (also on non-convergence, so x is a consistent best effort)

@@ -154,7 +154,7 @@ __device__ inline void clover_rows(cd (&out)[3], const real2* __restrict__ a, co
 #ifndef LQCD_DS_OCC
 #define LQCD_DS_OCC 5
 #endif
-#define LQCD_DS_BOUNDS __launch_bounds__(256, CLOV ? 1 : LQCD_DS_OCC)
+#define LQCD_DS_BOUNDS __launch_bounds__(256, (CLOV || CINV) ? 1 : LQCD_DS_OCC)
 #else
 #define LQCD_DS_BOUNDS __launch_bounds__(256)
 #endif
@@ -1460,16 +1460,15 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             if ((k.clover && !s.clover_on_hop) || s.r != 1.0) { set_error("stencil: dot mode needs the Wilson r = 1 kernel without a diagonal clover term"); return LQCD_ERR_UNSUPPORTED; }
             dim3 grid(k.nblocks), block(256);
             bool launched = false;
-#ifdef LQCD_F32
-            if (s.clover_on_hop) { set_error("stencil: the clover-on-hop form exists in the fp64 build only"); return LQCD_ERR_UNSUPPORTED; }
-#else
-            if (s.clover_on_hop) {      // even-odd clover solver: inverse blocks on the hop sum + the inner-product epilogue
+            if (s.clover_on_hop) {      // even-odd clover solver: inverse blocks on the hop sum + the inner-product epilogue (both builds)
                 if (k.gauge12) { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true, true>), grid, block, pad, c->stream, k);
                                  else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, true, true>), grid, block, pad, c->stream, k); }
                 else { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, true, true>), grid, block, pad, c->stream, k);
                        else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, true, true>), grid, block, pad, c->stream, k); }
                 launched = true;
-            } else if (k.gauge12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {      // the scalar-addressing form
+            }
+#ifndef LQCD_F32
+            else if (k.gauge12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {      // the scalar-addressing form
                 PipeArgs a = make_pipe_args(c, k, s);
                 const bool ntb = (k.nt & 1) != 0;
                 if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, true, true>), grid, block, 0, c->stream, a);
@@ -1489,17 +1488,12 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                 }
             }
         } else if (s.kind == LQCD_WILSON && s.clover_on_hop) {      // even-odd clover solver: out = a xin + b C (H in), C = the inverse clover blocks of the output parity
-#ifdef LQCD_F32
-            set_error("stencil: the clover-on-hop form exists in the fp64 build only");
-            return LQCD_ERR_UNSUPPORTED;
-#else
             if (!k.clover || s.r != 1.0) { set_error("stencil: clover-on-hop needs the packed blocks and r = 1"); return LQCD_ERR_UNSUPPORTED; }
             dim3 grid(k.nblocks), block(256);
             if (k.gauge12) { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, false, true>), grid, block, pad, c->stream, k);
                              else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, false, true>), grid, block, pad, c->stream, k); }
             else { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, false, true>), grid, block, pad, c->stream, k);
                    else hipLaunchKernelGGL((wilson_dirsplit<false, false, false, false, true>), grid, block, pad, c->stream, k); }
-#endif
         } else if (s.kind == LQCD_WILSON && !k.alpha_partials && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, k.clover != nullptr) &&
                    (c->tun.dslash_pipe != 2 || ((k.gauge12 || c->tun.dslash_s18) && !kF32Build))) {      // the scalar-addressing kernel: fp64 only (its one-site-per-lane fp32
                                                                                   // instance measured 62.5 vs 57 ms of variant 1 in the mixed CG, profiles/r03_mixed_precision.log); since

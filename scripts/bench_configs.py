@@ -171,9 +171,14 @@ def main():
     lat.set_param("action_eo_solver", 0)
     t_c0 = tk(lambda: lq.calc_UdSfdU_(G, fac, U, eta), reps=2)
     it_c0 = lq.evaluate_FermiAction(fac, U, eta, return_info=True)[1]
+    lat.set_param("mixed_action_solver", 1)
+    t_cm0 = tk(lambda: lq.calc_UdSfdU_(G, fac, U, eta), reps=2)          # mixed-precision CG on the normal equations (action_eo_solver is still 0)
     lat.set_param("action_eo_solver", 1)
+    t_cm1 = tk(lambda: lq.calc_UdSfdU_(G, fac, U, eta), reps=2)          # even-odd solves with the fp32 inner chain
+    it_cm1 = lq.evaluate_FermiAction(fac, U, eta, return_info=True)[1]
+    lat.set_param("mixed_action_solver", 0)
     res.append({"config": "32^3x64 Wilson-clover (c_sw = 1) force evaluation calc_UdSfdU!, eps 1e-16", "two_evenodd_bicgstab_solves_ms": t_c1, "iterations": it_c1,
-                "cg_normal_equations_ms": t_c0, "cg_iterations": it_c0})
+                "cg_normal_equations_ms": t_c0, "cg_iterations": it_c0, "mixed_precision_cg_ms": t_cm0, "mixed_precision_evenodd_ms": t_cm1, "mixed_evenodd_fp32_iterations": it_cm1})
     for o in (U, D, X, Y, G, p, eta):
         o.close()
     # ---- configs[4] geometry on one GPU: 48^3x96 staggered Dslash and CG (fp64)

@@ -60,7 +60,7 @@ case $stage in
     ;;
   mixedeo)    # mixed-precision even-odd BiCGStab
     timeout 900 python -m pytest tests/test_gpu_mixed.py tests/test_gpu_md_mixed.py tests/test_gpu_pair32.py -q -x 2>&1 | tail -12 | tee $out/pytest.log
-    timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; sed -n 5p $out/bench_configs.log | cut -c300-1900; tail -3 $out/bench_configs.err
+    timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; sed -n 5p $out/bench_configs.log | cut -c800-1900; sed -n 6p $out/bench_configs.log; tail -3 $out/bench_configs.err
     ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3

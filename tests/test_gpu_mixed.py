@@ -284,6 +284,43 @@ def test_deferred_x_update_of_the_fp32_solver_gives_identical_results(gpu, orc, 
     assert np.array_equal(out[0][1], out[1][1])
 
 
+def test_mixed_precision_evenodd_bicgstab_wilson_clover(gpu, orc):
+    """The same route for the Wilson-clover operator (BASELINE configs[3]): fp32 copies of the packed INVERSE clover blocks applied to the hop sums inside the
+    fp32 hops (one-site-per-lane build: the site-pair kernel carries no clover term), fp64 defect correction on the clover Schur system."""
+    import os
+    lq = gpu
+    KAPPA, CSW = 0.141139, 1.2
+    L = (8, 8, 8, 16)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "Clover_coefficient": CSW, "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
+    D.method_CG = "bicgstab_evenodd"
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    A = orc.clover_build(Uh, L, KAPPA, CSW)
+    for dagger in (False, True):
+        Dd = D.adjoint() if dagger else D
+        Dd.method_CG = "bicgstab_evenodd"
+        x64, x32 = b.similar(), b.similar()
+        lq.solve_DinvX_(x64, Dd, b)
+        lat.set_param("bicg_mixed", 1)
+        it32, rr32 = lq.solve_DinvX_(x32, Dd, b, return_info=True)
+        lat.set_param("bicg_mixed", 0)
+        assert rr32 < 1e-19 and rel_err(x32.download(), x64.download()) < 1e-9
+        res = b.download() - orc.wilson_clover_D(Uh, A, x32.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger=dagger)
+        assert np.vdot(res, res).real < 1e-19
+    fa = lq.FermiAction(D)
+    eta = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(eta, 114)
+    G0, G1 = lq.Gaugefields(lat), lq.Gaugefields(lat)
+    S0 = lq.calc_UdSfdU_(G0, fa, U, eta)
+    lat.set_param("mixed_action_solver", 1)
+    S1 = lq.calc_UdSfdU_(G1, fa, U, eta)
+    lat.set_param("mixed_action_solver", 0)
+    assert abs(S1 - S0) < 1e-10 * abs(S0) and rel_err(G1.download(), G0.download()) < 1e-8
+
+
 @pytest.mark.parametrize("L,dagger", [((8, 8, 8, 16), False), ((16, 16, 16, 32), True)])
 def test_mixed_precision_evenodd_bicgstab_keeps_the_stopping_rule(gpu, orc, L, dagger):
     """Tunable bicg_mixed: the even-odd BiCGStab of the plain Wilson operator with an fp32 inner chain (same fused structure as the fp64 one) inside an
