@@ -96,7 +96,13 @@ def main():
     Vloc = V // world
 
     # ---- Dslash kernel timing (HIP events on the stream the kernel is launched on)
+    def settle(op=None, n=600):
+        # untimed: ~0.2-0.3 s of the kernel itself, so that a timing which follows an idle stretch (start-up, the --pmc child processes)
+        # starts at steady clocks -- r04: the first figure after the PMC passes read 0.52 ms for a 0.41 ms kernel
+        lq.bench_dslash(op or D, y, b, warm=n, reps=1)
+
     barrier()
+    settle()
     ms_dslash = lq.bench_dslash(D, y, b, warm=20, reps=args.dslash_reps)              # mean over back-to-back launches
     ms_median, _ = lq.bench_dslash_median(D, y, b, warm=5, reps=args.dslash_reps)       # per-launch events, median
     barrier()
@@ -133,6 +139,7 @@ def main():
     traffic, traffic18, traffic_source = None, None, "not measured (N > 1)"
     if world == 1 and not force_dist:
         traffic, traffic18, traffic_source = (None, None, "skipped (--no-pmc)") if args.no_pmc else measure_traffic(args)
+        settle()
 
     out = {
         "metric": "CG iters/sec (D^+D) & Dslash GFLOP/s, %d^3x%d SU(3) Wilson fp64" % (gL[0], gL[3]),
@@ -196,6 +203,7 @@ def main():
       recon0 = lat.get_param("gauge_recon")
       try:
         lat.set_param("gauge_recon", 18)
+        settle()
         ms18 = lq.bench_dslash(D, y, b, warm=20, reps=args.dslash_reps)
         msi18 = lq.bench_cg(D, x, b, warm=5, niter=50)
         out["gauge_recon18_all_reals_read"] = {"recon_active": lat.get_param("recon_active"), "dslash_ms": ms18,

@@ -232,6 +232,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     }
     for (void* b : c->mix_buf) (void)hipFree(b);
     (void)hipFree(c->clover_q[0]); (void)hipFree(c->clover_q[1]);
+    (void)hipFree(c->gauge_spare);
     (void)hipFree(c->clover_ext); (void)hipFree(c->clover_ext_buf[0]); (void)hipFree(c->clover_ext_buf[1]);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipFree(c->pipe_ctr); (void)hipFree(c->cgp_ctr); (void)hipHostFree(c->h_scal);
@@ -300,6 +301,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "pipe_chunks_per_wg")) return &c->tun.pipe_chunks_per_wg;
     if (!strcmp(key, "pipe_min_chunks")) return &c->tun.pipe_min_chunks;
     if (!strcmp(key, "lazy_links")) return &c->tun.lazy_links;
+    if (!strcmp(key, "lazy_merge")) return &c->tun.lazy_merge;
     if (!strcmp(key, "bicg_fused")) return &c->tun.bicg_fused;
     if (!strcmp(key, "gauge_delta")) return &c->tun.gauge_delta;
     if (!strcmp(key, "dslash_s18")) return &c->tun.dslash_s18;
@@ -312,7 +314,7 @@ extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
     int* p = param_ptr(c, key);
     ARGCHK(p, std::string("lqcd_ctx_set_param: unknown key ") + key);
     if (!strcmp(key, "dslash_block")) ARGCHK(value == 64 || value == 128 || value == 256, "dslash_block must be 64, 128 or 256");
-    if (!strcmp(key, "lazy_links") && !value) LQCHK(links_flush_of(c));      // switching to eager calls: what is recorded runs now
+    if ((!strcmp(key, "lazy_links") || !strcmp(key, "lazy_merge")) && !value) LQCHK(links_flush_of(c));      // switching to eager calls: what is recorded runs now
     *p = value;
     return LQCD_OK;
 }
@@ -320,7 +322,7 @@ extern "C" int lqcd_ctx_get_param(lqcd_ctx_t c, const char* key, int* value) {
     ARGCHK(c && key && value, "lqcd_ctx_get_param: null");
     // read-only views of the recorded link operations (md.hip): the open triple (0 none, 1 exp, 2 exp + mul, 3 staple, 4 staple + mul), deferred triples
     if (!strcmp(key, "lazy_open")) { *value = c->lazy.kind; return LQCD_OK; }
-    if (!strcmp(key, "lazy_deferred")) { *value = (int)c->lazy.done.size(); return LQCD_OK; }
+    if (!strcmp(key, "lazy_deferred")) { *value = (int)c->lazy.done.size() + (c->lazy.has_pend ? 4 : 0) + (c->lazy.has_pp ? 4 : 0); return LQCD_OK; }
     int* p = param_ptr(c, key);
     ARGCHK(p, std::string("lqcd_ctx_get_param: unknown key ") + key);
     *value = *p;

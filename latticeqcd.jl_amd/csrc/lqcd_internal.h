@@ -430,6 +430,11 @@ struct Tunables {
     int lazy_links = 1;       // the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,
                               // lqcd_link_staple -> lqcd_link_mul -> lqcd_link_add_ta) are recorded and run as ONE fused launch each, four completed triples of one
                               // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel
+    int lazy_merge = 2;       // (with lazy_links) a complete link update U <- exp(a P) U waits; the next one of the same U, P with nothing in between that reads U or
+                              // writes P adds its step: exp(b P) exp(a P) = exp((a + b) P), one pass instead of two (the back-to-back half steps of
+                              // runMD_QPQ_sw!, standardMD.jl:146-166: 11 link passes per MD step instead of 20); lqcd_gauge_exp_update takes part.  2 (default; one GPU): a complete
+                              // momentum update P_update! waits as well, and runs with the link update that follows it as ONE sweep (staple_force_expu: the new
+                              // links go to a second buffer that changes places with the field's).  0: every complete update is launched at once
     int pair32_active = 0;    // read-only: the last mixed-precision solve / lqcd_op_apply_f32 ran the fp32 site-pair kernel
     int recon_active = 0;     // read-only: 1 if the last operator application used the 12-real links, 2: rows 0, 1 + the fp32 deviation of row 2 ("12 + delta")
     int bicg_mixed = 0;       // 1: the even-odd BiCGStab of the plain Wilson operator (lqcd_solve_bicgstab_eo, and through it the action / force solves) runs the fp32 chain
@@ -462,7 +467,14 @@ struct LazyLinks {
         double b;
     };
     std::vector<Done> done;
-    bool busy() const { return kind != 0 || !done.empty(); }
+    // a complete four-direction link update F <- exp(a G) F that has not been launched yet: the next one of the same fields, with nothing that reads the
+    // links or writes the momenta in between, adds its step to it (runMD_QPQ_sw!'s back-to-back half steps, standardMD.jl:146-166)
+    bool has_pend = false;
+    Done pend = {0, nullptr, 0, 0.0, nullptr, 0.0};
+    // ... and a complete momentum update F += a TA(-(b/6) G staples) in front of it: the two run as one sweep (lazy_merge = 2, md.hip staple_force_expu)
+    bool has_pp = false;
+    Done pp = {0, nullptr, 0, 0.0, nullptr, 0.0};
+    bool busy() const { return kind != 0 || has_pend || has_pp || !done.empty(); }
 };
 constexpr int PIPE_CTR_WORDS = 10 * 32;          // the context's counter block (pipe_ctr): 8 per-XCD queue heads + 1 exit counter of the persistent stencil
 constexpr int PIPE_CTR_RED_WORD = 8 * 32 + 16;   // kernel, 128 B apart; two more words of the exit counter's line: the exterior's reduction ticket (stencil.hip) ...
@@ -495,6 +507,7 @@ struct lqcd_ctx_s {
     int force_ncomp = 0;
     // staple-force halos (md.hip): forward ghost links (+ their send buffer) and the lower-staple faces, allocated on first use
     double2* gf_ghost[4] = {}, *gf_gsend[4] = {}, *gf_wsend[4] = {}, *gf_wrecv[4] = {};
+    double2* gauge_spare = nullptr;     // second link buffer of the fused momentum + link update (md.hip staple_force_expu), allocated on first use
     double2* clover_q[2] = {};          // clover sums / transport ping-pong, six 3x3 matrices per site (clover.hip)
     double2* clover_ext = nullptr;      // halo-extended links + Lambda matrices of the partitioned clover force, and its face buffers
     size_t clover_ext_bytes = 0;

@@ -101,6 +101,11 @@ struct GFArgs {
     double2* wsend[4];
     BlockMap bm;             // workgroup -> chunk map of the sweep (tunable md_remap: 1 = the Dslash kernels' XCD tile sweep, 0 = plain order)
     int mu_only, mu_out;     // MODE 2 (calc_dSdUmu!): only direction mu_only, staple sum written to direction slot mu_out of `out`
+    // EXPU instances (P_update! and the U_update! that follows it in ONE sweep): uout <- exp(dt P_new) U, a second link buffer (the sweep still reads the old links)
+    double2* uout;
+    double dt;
+    unsigned* notproj;
+    int reunit;
 };
 
 // U_nu at the site c + dir_hat: local, or from the forward ghost slice when the step leaves the rank
@@ -202,6 +207,9 @@ __global__ __launch_bounds__(256) void gauge_force_kernel_part(GFArgs k) {
     }
 }
 
+__device__ __forceinline__ void exp_m3(cd (&e)[9], cd (&x)[9], double dt);
+__device__ __forceinline__ void project_if_on_group(cd (&t)[9], unsigned* notproj);
+
 // one plane (MU, NU) of the staple sum of link (n, MU): upper staple U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+ and lower staple W_{mu nu}(n - nu).
 // MU and NU are compile-time: every index into the by-value argument struct and the coordinate arrays is static.
 // rows 0, 1 of a link as they come from memory (row 2 is rebuilt when the link is used: finish_u)
@@ -286,7 +294,7 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
     }
 }
 
-template <int MODE, int MU, bool PART, bool R2>
+template <int MODE, int MU, bool PART, bool R2, bool EXPU = false>
 __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int lane, const double2 (*own)[9][64]) {
     constexpr bool FUSE_TA = MODE == 1 || MODE == 3;
     const Geom& g = k.g;
@@ -330,7 +338,17 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
 #pragma unroll
         for (int e = 0; e < 9; e++) {
             const cd pv = ld(o + (size_t)e * Gs);
-            st(o + (size_t)e * Gs, mk(pv.re + a[e].re, pv.im + a[e].im));
+            a[e] = mk(pv.re + a[e].re, pv.im + a[e].im);
+            st(o + (size_t)e * Gs, a[e]);
+        }
+        if constexpr (EXPU) {      // the link update that follows this momentum update: exp(dt P_new) U_mu(n) into the second link buffer
+            cd ex[9], t[9];
+            exp_m3(ex, a, k.dt);
+            mm3(t, ex, um);
+            if (k.reunit) project_if_on_group(t, k.notproj);
+            double2* uo = k.uout + glink_off(g, p, MU, i);
+#pragma unroll
+            for (int e = 0; e < 9; e++) st(uo + (size_t)e * Gs, t[e]);
         }
     }
 }
@@ -346,7 +364,7 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
 #ifndef LQCD_STAPLE_OCC
 #define LQCD_STAPLE_OCC 2
 #endif
-template <int MODE, bool PART, bool R2 = false>
+template <int MODE, bool PART, bool R2 = false, bool EXPU = false>
 __global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArgs k) {
     const Geom& g = k.g;
     int chunk, p;
@@ -367,10 +385,10 @@ __global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArg
     }
     if (!valid) return;
     switch (mu) {
-    case 0: staple_links<MODE, 0, PART, R2>(k, p, i, lane, own); break;
-    case 1: staple_links<MODE, 1, PART, R2>(k, p, i, lane, own); break;
-    case 2: staple_links<MODE, 2, PART, R2>(k, p, i, lane, own); break;
-    default: staple_links<MODE, 3, PART, R2>(k, p, i, lane, own); break;
+    case 0: staple_links<MODE, 0, PART, R2, EXPU>(k, p, i, lane, own); break;
+    case 1: staple_links<MODE, 1, PART, R2, EXPU>(k, p, i, lane, own); break;
+    case 2: staple_links<MODE, 2, PART, R2, EXPU>(k, p, i, lane, own); break;
+    default: staple_links<MODE, 3, PART, R2, EXPU>(k, p, i, lane, own); break;
     }
 }
 
@@ -425,16 +443,50 @@ __global__ __launch_bounds__(256) void momentum_add_ta_kernel(Geom g, double2* _
     }
 }
 
-// U <- exp(dt P) U, Taylor series in Horner form.  Terms: 12 when the max-abs-row-sum norm of dt P is below 0.2
-// (0.2^13/13! = 1e-19), otherwise 24 (exact to rounding up to norm 2); an MD step has |dt P| of a few 1e-2.
+// exp(dt P).  Below max-abs-row-sum norm 0.2 of X = dt P (an MD step has a few 1e-2) the Taylor series is summed through the Cayley-Hamilton identity
+// X^3 = t X^2 - s X + d I (t = tr X, s = (t^2 - tr X^2)/2, d = det X; true for every 3x3 matrix, nothing assumed about P): X^n = al_n I + be_n X + ga_n X^2
+// with the scalar recurrence al' = d ga, be' = al - s ga, ga' = be + t ga, so exp X = a0 I + a1 X + a2 X^2 costs ONE matrix product and a dozen scalar
+// steps instead of a matrix product per term (r04: the link update inside the staple sweep is ALU time, 1.78 -> 1.63 ms already from a shorter series).
+// Terms: until nrm^(n+1)/(n+1)! < 1e-18, two more for the n^2 growth of the coefficients.  Norm >= 0.2: 24 terms in Horner form (exact to rounding up to norm 2).
+#ifndef LQCD_EXP_CH
+#define LQCD_EXP_CH 1
+#endif
 __device__ __forceinline__ void exp_m3(cd (&e)[9], cd (&x)[9], double dt) {     // e = exp(dt x); x is scaled in place
     cd t[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) { x[k] = mk(dt * x[k].re, dt * x[k].im); e[k] = mk((k % 4 == 0) ? 1.0 : 0.0, 0.0); }
+    for (int k = 0; k < 9; k++) x[k] = mk(dt * x[k].re, dt * x[k].im);
     double nrm = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; a++)
         nrm = fmax(nrm, (fabs(x[a * 3].re) + fabs(x[a * 3].im)) + (fabs(x[a * 3 + 1].re) + fabs(x[a * 3 + 1].im)) + (fabs(x[a * 3 + 2].re) + fabs(x[a * 3 + 2].im)));
+#if LQCD_EXP_CH
+    if (nrm < 0.2) {
+        const int nt = (nrm < 0.009 ? 6 : nrm < 0.04 ? 8 : nrm < 0.11 ? 10 : 12) + 2;
+        mm3(t, x, x);
+        const cd tr = x[0] + x[4] + x[8], tr2 = t[0] + t[4] + t[8], trtr = cmul(tr, tr);
+        const cd s = mk(0.5 * (trtr.re - tr2.re), 0.5 * (trtr.im - tr2.im));
+        const cd d = cmul(x[0], cmul(x[4], x[8]) - cmul(x[5], x[7])) - cmul(x[1], cmul(x[3], x[8]) - cmul(x[5], x[6])) +
+                     cmul(x[2], cmul(x[3], x[7]) - cmul(x[4], x[6]));
+        cd al = mk(1.0, 0.0), be = mk(0.0, 0.0), ga = mk(0.0, 0.0), a0 = al, a1 = be, a2 = ga;
+        double f = 1.0;
+        for (int n = 1; n <= nt; n++) {
+            const cd al2 = cmul(d, ga), be2 = al - cmul(s, ga), ga2 = be + cmul(tr, ga);
+            al = al2; be = be2; ga = ga2;
+            f /= (double)n;
+            a0 = mk(fma(f, al.re, a0.re), fma(f, al.im, a0.im));
+            a1 = mk(fma(f, be.re, a1.re), fma(f, be.im, a1.im));
+            a2 = mk(fma(f, ga.re, a2.re), fma(f, ga.im, a2.im));
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            e[k] = cmul(a1, x[k]) + cmul(a2, t[k]);
+            if (k % 4 == 0) e[k] = e[k] + a0;
+        }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < 9; k++) e[k] = mk((k % 4 == 0) ? 1.0 : 0.0, 0.0);
     for (int n = nrm < 0.2 ? 12 : 24; n >= 1; n--) {
         mm3(t, x, e);
         const double inv = 1.0 / (double)n;
@@ -472,6 +524,24 @@ __device__ __forceinline__ void reunitarize_m3(cd (&u)[9]) {
         u[6 + b] = mk(x.re, -x.im);
     }
 }
+// only a link that IS on the group up to accumulated rounding (deviation <= 1e-13) is put back onto it: the projection then moves it by
+// about that rounding.  A configuration read from a text file (the reference's fixtures are unitary to 9e-11) is left exactly as the
+// reference's literal update leaves it.
+__device__ __forceinline__ void project_if_on_group(cd (&t)[9], unsigned* notproj) {
+    cd v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = t[k];
+    reunitarize_m3(v);
+    double dev = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) dev = fmax(dev, fmax(fabs(v[k].re - t[k].re), fabs(v[k].im - t[k].im)));
+    if (dev <= 1e-13) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) t[k] = v[k];
+    } else {
+        *notproj = 1u;      // some link of this field is not on the group (benign race: every writer stores the same value)
+    }
+}
 template <bool REUNIT>
 __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* __restrict__ U, double dt, const double2* __restrict__ P, unsigned* notproj) {
     size_t off;
@@ -482,24 +552,7 @@ __global__ __launch_bounds__(256) void link_exp_update_kernel(Geom g, double2* _
     exp_m3(e, x, dt);
     load_m3(u, U + off, Gs);
     mm3(t, e, u);
-    if constexpr (REUNIT) {
-        // only a link that IS on the group up to accumulated rounding (deviation <= 1e-13) is put back onto it: the projection then moves it by
-        // about that rounding.  A configuration read from a text file (the reference's fixtures are unitary to 9e-11) is left exactly as the
-        // reference's literal update leaves it.
-        cd v[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) v[k] = t[k];
-        reunitarize_m3(v);
-        double dev = 0.0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) dev = fmax(dev, fmax(fabs(v[k].re - t[k].re), fabs(v[k].im - t[k].im)));
-        if (dev <= 1e-13) {
-#pragma unroll
-            for (int k = 0; k < 9; k++) t[k] = v[k];
-        } else {
-            *notproj = 1u;      // some link of this field is not on the group (benign race: every writer stores the same value)
-        }
-    }
+    if constexpr (REUNIT) project_if_on_group(t, notproj);
 #pragma unroll
     for (int k = 0; k < 9; k++) st(U + off + (size_t)k * Gs, t[k]);
 }
@@ -691,6 +744,7 @@ static GFArgs make_gfargs(lqcd_ctx_s* c, lqcd_gauge_s* U, lqcd_gauge_s* out, dou
     k.coef = -beta / 6.0;
     k.factor = factor;
     k.mu_only = -1; k.mu_out = 0;
+    k.uout = nullptr; k.dt = 0.0; k.notproj = nullptr; k.reunit = 0;
     k.bm = make_block_map(c->geom, c->tun.md_remap ? c->tun.xcd_remap : 0, c->tun.xcd_nsub, c->tun.xcd_ysplit);
     for (int mu = 0; mu < 4; mu++) { k.ghost[mu] = c->gf_ghost[mu]; k.wrecv[mu] = c->gf_wrecv[mu]; k.wsend[mu] = c->gf_wsend[mu]; }
     return k;
@@ -763,6 +817,36 @@ static int staple_force(lqcd_gauge_s* out, lqcd_gauge_s* U, double beta, double 
     return LQCD_OK;
 }
 
+// P_update! followed by U_update! (what every Sexton-Weingarten block of runMD_QPQ_sw! asks for, standardMD.jl:150-152) in ONE sweep over the links, single
+// GPU: P += factor TA(-(beta/6) U staples), then U' = exp(dt P) U with the momentum still in registers -- U' goes to the context's spare link buffer (the sweep
+// reads the old links of the neighbours until its last workgroup) and the two buffers change places in the handle.  Moves 576 (U) + 1152 (P r/w) + 576 (U')
+// B/site where the two separate passes move 3456.
+static int staple_force_expu(lqcd_gauge_s* P, lqcd_gauge_s* U, double beta, double factor, double dt) {
+    lqcd_ctx_s* c = U->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->gauge_spare) {
+        HIPCHK(hipMalloc((void**)&c->gauge_spare, U->elems * sizeof(double2)));
+        HIPCHK(hipMemsetAsync(c->gauge_spare, 0, U->elems * sizeof(double2), c->stream));      // stride padding stays zero
+    }
+    GFArgs k = make_gfargs(c, U, P, beta, factor);
+    unsigned* flag = c->pipe_ctr + PIPE_CTR_NOTPROJ_WORD;
+    unsigned notproj = 1;
+    k.uout = c->gauge_spare; k.dt = dt; k.notproj = flag; k.reunit = c->tun.md_reunitarize;
+    const bool two_rows = c->tun.staple_recon && U->unitary_version == U->version;
+    P->version++;
+    if (k.reunit) HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+    const dim3 grid(2 * c->geom.nch);
+    if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<1, false, true, true>), grid, dim3(256), 0, c->stream, k);
+    else hipLaunchKernelGGL((gauge_force_kernel<1, false, false, true>), grid, dim3(256), 0, c->stream, k);
+    HIPCHK(hipGetLastError());
+    if (k.reunit) HIPCHK(hipMemcpyAsync(&notproj, flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::swap(U->data, c->gauge_spare);
+    U->version++;
+    if (k.reunit && !notproj) U->unitary_version = U->version;      // every link was projected: the field is on the group to rounding
+    return LQCD_OK;
+}
+
 // ---- single-direction entry points (the interface the reference's unchanged callers use, AbstractMD.jl:78-135)
 static int link_args(lqcd_gauge_t a, int ma, lqcd_gauge_t b, int mb, const char* who) {
     if (!(a && b && a->ctx == b->ctx && ma >= 0 && ma < 4 && mb >= 0 && mb < 4)) {
@@ -801,12 +885,52 @@ static bool lazy_on(lqcd_ctx_s* c) { return c->tun.lazy_links && c->local_peers.
 static LinkRef lref(lqcd_gauge_s* g, int mu) { LinkRef r; r.g = g; r.mu = mu; return r; }
 
 static int lazy_run_done(lqcd_ctx_s* c) {
+    // waiting complete updates are older than every deferred triple; a momentum update is older than the link update behind it
+    if (c->lazy.has_pp) {
+        const LazyLinks::Done q = c->lazy.pp, r = c->lazy.pend;
+        const bool both = c->lazy.has_pend && r.F == q.G && r.G == q.F && c->tun.lazy_merge > 1;
+        c->lazy.has_pp = false;
+        if (both) {
+            c->lazy.has_pend = false;
+            LQCHK(staple_force_expu(q.F, q.G, q.b, q.a, r.a));
+        } else LQCHK(staple_force(q.F, q.G, q.b, q.a, true));
+    }
+    if (c->lazy.has_pend) {
+        const LazyLinks::Done r = c->lazy.pend;
+        c->lazy.has_pend = false;
+        LQCHK(gauge_exp_update_now(r.F, r.a, r.G));
+    }
     std::vector<LazyLinks::Done> d;
     d.swap(c->lazy.done);
     for (const LazyLinks::Done& r : d) {
         if (r.kind == 1) LQCHK(link_exp_mul_now(r.F, r.slot, r.a, r.G, r.slot, r.F, r.slot));
         else LQCHK(staple_force(r.F, r.G, r.b, r.a, true, r.slot, r.slot, 0.5 * r.b));
     }
+    return LQCD_OK;
+}
+// a complete link update U <- exp(dt P) U: waits for a second one to merge with (tunable lazy_merge), or runs now
+static int lazy_full_update(lqcd_ctx_s* c, lqcd_gauge_t U, double dt, lqcd_gauge_t P) {
+    LazyLinks& z = c->lazy;
+    if (!c->tun.lazy_merge) {
+        if (z.has_pend || z.has_pp) LQCHK(lazy_run_done(c));
+        return gauge_exp_update_now(U, dt, P);
+    }
+    if (z.has_pend && z.pend.F == U && z.pend.G == P) { z.pend.a += dt; return LQCD_OK; }
+    if (z.has_pend || (z.has_pp && !(z.pp.F == P && z.pp.G == U))) LQCHK(lazy_run_done(c));
+    const LazyLinks::Done d = {1, U, 0, dt, P, 0.0};
+    z.pend = d;
+    z.has_pend = true;
+    return LQCD_OK;
+}
+// a complete momentum update P += factor TA(-(beta/6) U staples): everything that waits runs first (it reads the links); on one GPU it then waits itself
+// for the link update that follows it (lazy_merge = 2: staple_force_expu)
+static int lazy_full_pupdate(lqcd_ctx_s* c, lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta) {
+    LazyLinks& z = c->lazy;
+    if (z.has_pend || z.has_pp) LQCHK(lazy_run_done(c));
+    if (c->tun.lazy_merge < 2 || any_partitioned(c) || P == U) return staple_force(P, U, beta, factor, true);
+    const LazyLinks::Done d = {2, P, 0, factor, U, beta};
+    z.pp = d;
+    z.has_pp = true;
     return LQCD_OK;
 }
 // a completed triple: one of (up to) four of the same update, or run on its own
@@ -818,27 +942,33 @@ static int lazy_defer(lqcd_ctx_s* c, const LazyLinks::Done& r) {
         for (const LazyLinks::Done& e : done) clash = clash || e.slot == r.slot;
         if (clash) LQCHK(lazy_run_done(c));
     }
+    {
+        const LazyLinks& z = c->lazy;
+        const bool wait_ok = r.kind == 1 && (!z.has_pend || (r.F == z.pend.F && r.G == z.pend.G)) && (!z.has_pp || (r.F == z.pp.G && r.G == z.pp.F));
+        if ((z.has_pend || z.has_pp) && !wait_ok) LQCHK(lazy_run_done(c));
+    }
     done.push_back(r);
     if (done.size() == 4) {
         done.clear();
-        if (r.kind == 1) return gauge_exp_update_now(r.F, r.a, r.G);
-        return staple_force(r.F, r.G, r.b, -3.0 * r.a, true);      // factor TA(U (beta/2) staples) = (-3 factor) TA(-(beta/6) U staples)
+        if (r.kind == 1) return lazy_full_update(c, r.F, r.a, r.G);
+        return lazy_full_pupdate(c, r.F, -3.0 * r.a, r.G, r.b);      // factor TA(U (beta/2) staples) = (-3 factor) TA(-(beta/6) U staples)
     }
     return LQCD_OK;
 }
 // a new triple starts: an interrupted one runs first; deferred triples of the same kind stay deferred unless the new one writes one of their fields
 static int lazy_open_triple(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* tmp) {
     if (c->lazy.kind) return links_flush(c);
+    bool run = (c->lazy.has_pend && (kind != 1 || c->lazy.pend.F == tmp || c->lazy.pend.G == tmp)) ||
+               (c->lazy.has_pp && (kind != 1 || c->lazy.pp.F == tmp || c->lazy.pp.G == tmp));
     if (!c->lazy.done.empty()) {
-        bool run = c->lazy.done[0].kind != kind;
+        run = run || c->lazy.done[0].kind != kind;
         for (const LazyLinks::Done& e : c->lazy.done) run = run || e.F == tmp || e.G == tmp;
-        if (run) return lazy_run_done(c);
     }
-    return LQCD_OK;
+    return run ? lazy_run_done(c) : LQCD_OK;
 }
 namespace lqcd {
 int links_flush(lqcd_ctx_s* c) {
-    if (!c->lazy.done.empty()) LQCHK(lazy_run_done(c));
+    if (c->lazy.has_pend || c->lazy.has_pp || !c->lazy.done.empty()) LQCHK(lazy_run_done(c));
     LazyLinks z = c->lazy;
     c->lazy.kind = 0;
     if (z.kind == 1 || z.kind == 2) {
@@ -865,6 +995,7 @@ extern "C" int lqcd_link_copy(lqcd_gauge_t dst, int mu_dst, lqcd_gauge_t src, in
             LazyLinks::Done d = {1, dst, mu_dst, r.t, r.P.g, 0.0};
             return lazy_defer(c, d);
         }
+        if (c->lazy.has_pend || c->lazy.has_pp) LQCHK(lazy_run_done(c));
         return link_exp_mul_now(dst, mu_dst, r.t, r.P.g, r.P.mu, dst, mu_dst);
     }
     LQCHK(links_flush_of(c));
@@ -924,6 +1055,7 @@ extern "C" int lqcd_link_add_ta(lqcd_gauge_t P, int mu_p, double factor, lqcd_ga
             LazyLinks::Done d = {2, P, mu_p, factor, r.Ug, r.beta};
             return lazy_defer(c, d);
         }
+        if (c->lazy.has_pend || c->lazy.has_pp) LQCHK(lazy_run_done(c));
         return staple_force(P, r.Ug, r.beta, factor, true, r.mu, mu_p, 0.5 * r.beta);
     }
     LQCHK(links_flush_of(c));
@@ -995,8 +1127,13 @@ extern "C" int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta) {
 
 // P_update!(U, p, eps, md) (AbstractMD.jl:99-118) in one pass:  P += factor * TA(-(beta/6) U * staples); the force field is never stored
 extern "C" int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta) {
-    LQCHK(lqcd::links_flush_of(P));      // recorded single-direction link operations run first (md.hip)
     LQCHK(same_ctx(P, U, "lqcd_momentum_add_gauge_force"));
+    lqcd_ctx_s* c = P->ctx;
+    if (lazy_on(c) && c->tun.lazy_merge > 1) {      // waits for the link update that follows it (lazy_full_pupdate)
+        LQCHK(links_flush(c));
+        return lazy_full_pupdate(c, P, factor, U, beta);
+    }
+    LQCHK(lqcd::links_flush_of(P));      // recorded single-direction link operations run first
     return staple_force(P, U, beta, factor, true);
 }
 
@@ -1053,6 +1190,12 @@ extern "C" int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t 
 // U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U
 extern "C" int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P) {
     LQCHK(same_ctx(U, P, "lqcd_gauge_exp_update"));
+    lqcd_ctx_s* c = U->ctx;
+    if (lazy_on(c) && c->tun.lazy_merge && U != P) {      // waits for a second update of the same fields to merge with (lazy_full_update)
+        const LazyLinks& z = c->lazy;
+        if (z.kind || !z.done.empty()) LQCHK(links_flush(c));
+        return lazy_full_update(c, U, dt, P);
+    }
     LQCHK(links_flush_of(U));
     return gauge_exp_update_now(U, dt, P);
 }

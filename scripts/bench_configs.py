@@ -133,6 +133,7 @@ def main():
     def tk(fn, reps=5):
         fn()
         return 1e3 * timed(lambda: [fn() for _ in range(reps)], reps=2)[0] / reps
+    lat.set_param("lazy_merge", 0)                 # unit timings: every link update launches at once
     t_gf = tk(lambda: lq.gauge_force_(G, U, beta))
     t_ta = tk(lambda: lq.Traceless_antihermitian_add_(p, 1e-9, G))
     t_pu = tk(lambda: lq.P_update_(U, p, 1e-9, beta))
@@ -151,7 +152,27 @@ def main():
     t_ffm_cg = tk(lambda: lq.calc_UdSfdU_(G, fa, U, eta), reps=2)
     lat.set_param("action_eo_solver", 1)
     lat.set_param("mixed_action_solver", 0)
+
+    def md_step():                                 # runMD_QPQ_sw!, one itrj (standardMD.jl:146-166); steps of 1e-9 keep the configuration where it is
+        for half in range(2):
+            for _ in range(nsw // 2):
+                lq.U_update_(U, p, 0.5e-9)
+                lq.P_update_(U, p, 1e-9, beta)
+                lq.U_update_(U, p, 0.5e-9)
+            if half == 0:
+                lq.calc_UdSfdU_(G, fa, U, eta)
+                lq.Traceless_antihermitian_add_(p, 1e-9, G)
+    md_ms = {}
+    for merge in (0, 1):
+        lat.set_param("lazy_merge", merge)
+        for mixed in (0, 1):
+            lat.set_param("mixed_action_solver", mixed)
+            md_step(); lq.calculate_Plaquette(U)
+            md_ms[(merge, mixed)] = 1e3 * timed(lambda: [md_step(), md_step(), md_step(), lq.unitarity_deviation(U)], reps=2)[0] / 3
+    lat.set_param("mixed_action_solver", 0)
     res.append({"config": "32^3x64 Wilson HMC, one MD step resident on the device (Sexton-Weingarten N = 10)",
+                "md_step_measured_ms": md_ms[(1, 0)], "md_step_measured_mixed_precision_solver_ms": md_ms[(1, 1)],
+                "md_step_measured_lazy_merge0_ms": md_ms[(0, 0)], "md_step_measured_lazy_merge0_mixed_ms": md_ms[(0, 1)],
                 "gauge_force_ms": t_gf, "gauge_force_GBps_1152B": 1152 * V / t_gf / 1e6, "momentum_add_ta_ms": t_ta,
                 "P_update_fused_ms": t_pu, "P_update_fused_GBps_1728B": 1728 * V / t_pu / 1e6, "link_exp_update_ms": t_up,
                 "link_exp_update_GBps_1728B": 1728 * V / t_up / 1e6,
@@ -159,8 +180,8 @@ def main():
                 "calc_UdSfdU_ms_action_eo_solver0 (CG to 1e-16 + Y = D X + sweep)": t_ff_cg, "action_solver_iterations_cg": it_cg,
                 "evaluate_FermiAction_ms": t_sf,
                 "calc_UdSfdU_mixed_precision_solver_ms": t_ffm, "mixed_evenodd_fp32_iterations": it_mx, "calc_UdSfdU_mixed_precision_cg_ms": t_ffm_cg,
-                "md_step_ms": nsw * (t_pu + 2 * t_up) + t_ff + t_ta,
-                "md_step_mixed_precision_solver_ms": nsw * (t_pu + 2 * t_up) + t_ffm + t_ta,
+                "md_step_sum_of_parts_ms": nsw * (t_pu + 2 * t_up) + t_ff + t_ta,
+                "md_step_sum_of_parts_mixed_precision_solver_ms": nsw * (t_pu + 2 * t_up) + t_ffm + t_ta,
                 "note": "host<->device traffic per MD step: none (the reference path would move 1.2 GB of links + 2 spinors)"})
     # ---- configs[3]: the same force evaluation with the Wilson-clover operator (even-odd solves through the inverse clover blocks vs CG)
     Dc = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover", "κ": KAPPA, "Clover_coefficient": 1.0, "eps_CG": 1e-16})

@@ -62,6 +62,33 @@ case $stage in
     timeout 900 python -m pytest tests/test_gpu_mixed.py tests/test_gpu_md_mixed.py tests/test_gpu_pair32.py -q -x 2>&1 | tail -12 | tee $out/pytest.log
     timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; sed -n 5p $out/bench_configs.log | cut -c800-1900; sed -n 6p $out/bench_configs.log; tail -3 $out/bench_configs.err
     ;;
+  merge)      # waiting link / momentum updates (lazy_merge), measured MD step, bench.py after the settle change
+    timeout 1200 python -m pytest tests/test_gpu_reference_callers.py tests/test_gpu_md.py tests/test_gpu_md_partitioned.py tests/test_gpu_md_staggered.py tests/test_gpu_md_mixed.py \
+        tests/test_gpu_reunit.py tests/test_gpu_hmc_partitioned.py tests/test_gpu_lifecycle.py tests/test_gpu_clover.py -q -x --durations=5 2>&1 | tail -14 | tee $out/pytest.log
+    timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -k "c_abi" 2>&1 | tail -3 | tee -a $out/pytest.log
+    timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; sed -n 5p $out/bench_configs.log | cut -c1-900; tail -3 $out/bench_configs.err
+    timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; python -c "import json; d=json.load(open('$out/bench.json')); print(d['value'], d['dslash_ms'], d['roofline']['frac'], d['gauge_recon18_all_reals_read']['dslash_ms'], d['reference_format_links'])"; tail -2 $out/bench.err
+    ;;
+  pu)         # momentum + link update as one sweep vs two passes
+    timeout 600 python -m pytest tests/test_gpu_md.py tests/test_gpu_reunit.py tests/test_gpu_reference_callers.py -q -x 2>&1 | tail -3
+    python scripts/pu_probe.py 0.005 2>&1 | tail -1 | tee $out/pu.log
+    python scripts/pu_probe.py 0.05 2>&1 | tail -1 | tee -a $out/pu.log
+    if [ -f latticeqcd.jl_amd/csrc/liblqcd_hip_exp12.so ]; then LQCD_HIP_LIB=$PWD/latticeqcd.jl_amd/csrc/liblqcd_hip_exp12.so python scripts/pu_probe.py 0.005 2>&1 | tail -1 | sed 's/^/fixed 12 terms: /' | tee -a $out/pu.log; fi
+    ;;
+  forceprof)  # kernel stats of calc_UdSfdU! at 32^3x64, fp64 even-odd and mixed
+    for m in 0 1; do
+      (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof$m -o p -- python $GRAFT_REPO_ROOT/scripts/force_probe.py $m 3 2>&1 | tail -2)
+      f=$(find $out/prof$m -name "*kernel_stats.csv" | head -1); cp "$f" $out/kernel_stats_mixed$m.csv
+      python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel ms", tot / 1e6)
+for r in rows[:22]:
+    print("%-90s %6s calls %9.3f ms %5.1f%%" % (r["Name"][:90], r["Calls"], float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
+PY
+    done
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

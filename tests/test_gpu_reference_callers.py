@@ -332,3 +332,89 @@ def test_operator_application_sees_deferred_link_updates(lq, orc):
         assert not lat._done
         out.append(y.download())
     assert np.abs(out[0] - out[1]).max() < 1e-13 * np.abs(out[1]).max()
+
+
+def test_back_to_back_link_updates_merge(lq, orc):
+    """runMD_QPQ_sw! (standardMD.jl:146-166) ends one Sexton-Weingarten block with U_update!(0.5/N) and starts the next with the same call, the momenta
+    untouched in between: the library lets a complete link update wait and adds the next step to it (tunable lazy_merge) -- exp(b P) exp(a P) = exp((a + b) P).
+    Same links and momenta as the eager sequence; whatever reads U or writes P in between runs the waiting update first."""
+    L = (4, 4, 4, 8)
+    Uh = orc.hot_gauge(L, 81)
+    beta, dtau, nsw = 5.7, 0.05, 4
+    res = {}
+    for merge in (2, 1, 0):
+        lat = lq.Lattice(L)
+        lat.set_param("lazy_merge", merge)
+        U = lq.Gaugefields(lat).upload(Uh)
+        p = lq.initialize_TA_Gaugefields(U)
+        lq.gauss_distribution_(p, 82)
+        seen = []
+        for _ in range(2):
+            for _ in range(nsw // 2):
+                lq.U_update_(U, p, 0.5 / nsw * dtau)
+                seen.append(lat.get_param("lazy_deferred"))
+                lq.P_update_(U, p, -dtau / nsw, beta)
+                seen.append(lat.get_param("lazy_deferred"))
+                lq.U_update_(U, p, 0.5 / nsw * dtau)
+                seen.append(lat.get_param("lazy_deferred"))
+        # 2: the momentum update waits too, and runs with the (merged) link update behind it as one sweep; 1: only link updates wait; 0: nothing waits
+        assert seen == {2: [4, 4, 8] + [8, 4, 8] * (nsw - 1), 1: [4, 0, 4] * nsw, 0: [0, 0, 0] * nsw}[merge]
+        lq.calculate_Plaquette(U)      # reads the links: what waits runs
+        assert lat.get_param("lazy_deferred") == 0
+        res[merge] = (U.download(), p.download(), lq.unitarity_deviation(U))
+    for merge in (2, 1):
+        assert np.abs(res[merge][0] - res[0][0]).max() < 1e-13 and np.abs(res[merge][1] - res[0][1]).max() < 1e-12
+        assert res[merge][2] == 0.0      # projected in the same sweep (md_reunitarize), as the separate link update does
+    # a step forward and the same step back before anything looks: the links do not move at all
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    p = lq.initialize_TA_Gaugefields(U)
+    lq.gauss_distribution_(p, 83)
+    lat.set_param("md_reunitarize", 0)
+    lq.U_update_(U, p, 0.37)
+    lq.U_update_(U, p, -0.37)
+    assert np.array_equal(U.download(), Uh)
+    # the momentum field changes between two updates: no merge across that
+    out = []
+    for merge in (2, 0):
+        lat = lq.Lattice(L)
+        lat.set_param("lazy_merge", merge)
+        U = lq.Gaugefields(lat).upload(Uh)
+        p = lq.initialize_TA_Gaugefields(U)
+        lq.gauss_distribution_(p, 84)
+        lq.U_update_(U, p, 0.1)
+        lq.gauss_distribution_(p, 85)
+        lq.U_update_(U, p, 0.1)
+        out.append(U.download())
+    assert np.abs(out[0] - out[1]).max() < 1e-14
+
+
+def test_fused_momentum_and_link_update_on_reference_format_links(lq, orc):
+    """The one-sweep P_update! + U_update! (lazy_merge = 2) on links that are NOT on the group to 1e-13 (what the reference's text files hold): nothing is
+    projected, all three rows are read, and the result is the one of the two separate passes; then the operator built on the field sees the swapped buffer."""
+    L = (4, 4, 8, 8)
+    Uh = orc.hot_gauge(L, 91)
+    rng = np.random.default_rng(92)
+    Uh = Uh + 1e-10 * (rng.standard_normal(Uh.shape) + 1j * rng.standard_normal(Uh.shape))
+    out = []
+    for merge in (2, 0):
+        lat = lq.Lattice(L)
+        lat.set_param("lazy_merge", merge)
+        U = lq.Gaugefields(lat).upload(Uh)
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.12})
+        x = lq.Fermionfields(lat, lq.WILSON)
+        lq.gauss_distribution_fermion_(x, 93)
+        y = x.similar()
+        lq.mul_(y, D, x)                         # the operator has seen the field's first buffer
+        p = lq.initialize_TA_Gaugefields(U)
+        lq.gauss_distribution_(p, 94)
+        for _ in range(3):
+            lq.P_update_(U, p, -0.01, 5.7)
+            lq.U_update_(U, p, 0.02)
+        lq.mul_(y, D, x)
+        out.append((U.download(), p.download(), y.download(), lq.unitarity_deviation(U)))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-13 and np.abs(out[0][1] - out[1][1]).max() < 1e-12
+    assert np.abs(out[0][2] - out[1][2]).max() < 1e-12 * np.abs(out[1][2]).max()
+    assert out[0][3] > 1e-11 and abs(out[0][3] - out[1][3]) < 1e-13      # left off the group exactly as the literal update leaves them
+    yo = orc.wilson_D(out[1][0], x.download(), L, 0.12, 1.0, (1, 1, 1, -1))
+    assert np.abs(out[0][2] - yo).max() < 1e-13 * np.abs(yo).max()
