@@ -44,7 +44,8 @@ enum {
     LQCD_ERR_UNSUPPORTED = 5
 };
 
-enum { LQCD_WILSON = 0, LQCD_STAGGERED = 1 };        /* "Dirac_operator" => "Wilson" | "Staggered"  (src/system/universe.jl:103-116) */
+enum { LQCD_WILSON = 0, LQCD_STAGGERED = 1,          /* "Dirac_operator" => "Wilson" | "Staggered"  (src/system/universe.jl:103-116) */
+       LQCD_DOMAINWALL = 2 };                        /* ... | "Domainwall" (universe.jl:116-128): lqcd_op_create_domainwall, five-dimensional fields */
 enum { LQCD_FULL = 0, LQCD_EVEN = 1, LQCD_ODD = 2 }; /* site subset held by a spinor */
 enum { LQCD_LAYOUT_REFERENCE = 0, /* memory image of the Julia arrays, see above */
        LQCD_LAYOUT_DISK = 1 };    /* ILDG / BridgeText flat order t,z,y,x,mu,a,b */
@@ -180,6 +181,17 @@ int lqcd_op_destroy(lqcd_op_t op);
  * halo-extended copy of the links and Lambda matrices, RCCL ranks only). */
 int lqcd_op_set_clover(lqcd_op_t op, double csw);
 int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g);   /* the D(U) rebind idiom (unusedfiles/measure_chiral_condensate.jl:173) */
+/* Dirac_operator = "Domainwall" (src/system/universe.jl:116-128: params "mass" = Domainwall_m, "L5", "M" = Domainwall_M; test/test_domainwallhmc.toml;
+ * the fifth HMC fermion test of test/runtests.jl:132-137).  The arithmetic lives in LatticeDiracOperators.jl (not under the reference tree): this is the
+ * textbook Shamir operator in the library's Wilson conventions [EXT-RECALL, parity unpinned -- csrc/domainwall.hip states it],
+ *     (D5 psi)(s) = D4 psi(s) + psi(s) - P_- psi(s+1) - P_+ psi(s-1),  psi(L5+1) := -m psi(1), psi(0) := -m psi(L5),  D4 = Wilson operator of mass M (r = 1).
+ * Fields are five-dimensional (lqcd_spinor_create_5d; lqcd_spinor_slice hands out the reference's x.w[i5] as Wilson fields that alias the slices: upload,
+ * download and fills go through them, BLAS-1 takes the whole field).  Served for this operator: lqcd_op_apply, lqcd_op_apply_DdagD, lqcd_solve_cg_DdagD
+ * and the pseudofermion action -- S = phi^+ D_PV (D^+D)^-1 D_PV^+ phi with the Pauli-Villars operator D_PV = D5(m = 1) -- through lqcd_action_* (heat
+ * bath, action, force).  One GPU; every other entry point answers LQCD_ERR_UNSUPPORTED. */
+int lqcd_op_create_domainwall(lqcd_ctx_t ctx, lqcd_op_t* op, lqcd_gauge_t g, double M, double mass, int L5, const int bc[4]);
+int lqcd_spinor_create_5d(lqcd_ctx_t ctx, lqcd_spinor_t* s, int L5);      /* Initialize_pseudofermion_fields(U[1], "Domainwall", L5 = L5) (universe.jl:128) */
+int lqcd_spinor_slice(lqcd_spinor_t s5, int i5, lqcd_spinor_t* view);     /* 0-based; the view owns nothing and must not be used after its parent is destroyed */
 /* mul!(y, D, x) / mul!(y, D', x) on FULL spinors */
 int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger);
 /* mul!(y, DdagD_operator(D), x):  out = D^dagger D in  (tmp is library scratch) */

@@ -43,7 +43,7 @@ const LIB = get(ENV, "LQCD_HIP_LIB", joinpath(@__DIR__, "..", "latticeqcd.jl_amd
 
 const LQCD_OK = Cint(0)
 const LQCD_ERR_NOT_CONVERGED = Cint(3)
-const WILSON, STAGGERED = Cint(0), Cint(1)
+const WILSON, STAGGERED, DOMAINWALL = Cint(0), Cint(1), Cint(2)
 const FULL, EVEN, ODD = Cint(0), Cint(1), Cint(2)
 const LAYOUT_REFERENCE = Cint(0)
 
@@ -289,18 +289,35 @@ mutable struct HIPFermion <: AbstractFermionfields_4D{3}
     h::Ptr{Cvoid}
     lat::HIPLattice
     kind::Cint
+    L5::Int             # DOMAINWALL: extent of the fifth direction (L5 Wilson fields in one device allocation); 0 otherwise
+    parent::Any         # a slice view (slice(x, i5)) keeps its five-dimensional field alive; nothing otherwise
 end
-function HIPFermion(lat::HIPLattice, kind::Cint)
+function HIPFermion(lat::HIPLattice, kind::Cint; L5::Integer = 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:lqcd_spinor_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint, Cint), lat.h, h, kind, FULL))
-    f = HIPFermion(h[], lat, kind)
+    if kind == DOMAINWALL
+        check(ccall((:lqcd_spinor_create_5d, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint), lat.h, h, L5))
+    else
+        check(ccall((:lqcd_spinor_create, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint, Cint), lat.h, h, kind, FULL))
+    end
+    f = HIPFermion(h[], lat, kind, Int(L5), nothing)
     finalizer(x -> ccall((:lqcd_spinor_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), f)
     return f
 end
-# Initialize_pseudofermion_fields(U[1], "Wilson"; nowing = true) / (U[1], "staggered")   (universe.jl:107,112)
-Initialize_pseudofermion_fields(u::HIPLink, name::String; kwargs...) =
-    HIPFermion(getfield(u, :parent).lat, lowercase(name) == "wilson" ? WILSON : lowercase(name) == "staggered" ? STAGGERED : error("$name is not supported"))
-similar(x::HIPFermion) = HIPFermion(x.lat, x.kind)
+# x.w[i5] of the package's five-dimensional fields: a Wilson field that aliases slice i5 (1-based here) of x -- upload!, download! and fills go through it
+function slice(x::HIPFermion, i5::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:lqcd_spinor_slice, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), x.h, i5 - 1, h))
+    v = HIPFermion(h[], x.lat, WILSON, 0, x)
+    finalizer(y -> ccall((:lqcd_spinor_destroy, LIB), Cint, (Ptr{Cvoid},), y.h), v)      # frees the handle only: the storage belongs to the parent
+    return v
+end
+# Initialize_pseudofermion_fields(U[1], "Wilson"; nowing = true) / (U[1], "staggered") / (U[1], "Domainwall", L5 = L5, nowing = true)   (universe.jl:107,112,128)
+function Initialize_pseudofermion_fields(u::HIPLink, name::String; L5 = 0, kwargs...)
+    n = lowercase(name)
+    kind = n == "wilson" ? WILSON : n == "staggered" ? STAGGERED : n == "domainwall" ? DOMAINWALL : error("$name is not supported")
+    return HIPFermion(getfield(u, :parent).lat, kind; L5 = L5)
+end
+similar(x::HIPFermion) = HIPFermion(x.lat, x.kind; L5 = x.L5)
 clear_fermion!(x::HIPFermion) = check(ccall((:lqcd_spinor_zero, LIB), Cint, (Ptr{Cvoid},), x.h))
 substitute_fermion!(a::HIPFermion, b::HIPFermion) = check(ccall((:lqcd_spinor_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), a.h, b.h))
 function dot(a::HIPFermion, b::HIPFermion)
@@ -320,6 +337,8 @@ gauss_distribution_fermion!(x::HIPFermion; seed = rand(UInt64)) =
 Z4_distribution_fermi!(x::HIPFermion; seed = rand(UInt64)) =
     check(ccall((:lqcd_spinor_z4, LIB), Cint, (Ptr{Cvoid}, UInt64), x.h, seed))
 # host <-> device in the reference layout psi[ic,ix,iy,iz,it,is]
+upload!(x::HIPFermion, a::Vector{Array{ComplexF64,6}}) = foreach(i5 -> upload!(slice(x, i5), a[i5]), 1:x.L5)        # five-dimensional: one array per slice
+download!(a::Vector{Array{ComplexF64,6}}, x::HIPFermion) = foreach(i5 -> download!(a[i5], slice(x, i5)), 1:x.L5)
 upload!(x::HIPFermion, a::Array{ComplexF64,6}) = check(ccall((:lqcd_spinor_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), x.h, a))
 download!(a::Array{ComplexF64,6}, x::HIPFermion) = check(ccall((:lqcd_spinor_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), x.h, a))
 
@@ -337,6 +356,15 @@ end
 # Dirac_operator(U, x, params::Dict)  (universe.jl:137; keys universe.jl:103-135)
 function Dirac_operator(U::Vector{HIPLink}, x::HIPFermion, params)
     name = params["Dirac_operator"]
+    if name == "Domainwall"        # universe.jl:116-128: "mass" = Domainwall_m, "L5", "M" = Domainwall_M
+        g = whole(U)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:lqcd_op_create_domainwall, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Float64, Float64, Cint, Ptr{Cint}),
+                    g.lat.h, h, g.h, Float64(get(params, "M", -1.0)), Float64(params["mass"]), Cint(params["L5"]), Cint[get(params, "boundarycondition", [1, 1, 1, -1])...]))
+        D = HIPDirac(h[], U, x, false, Float64(get(params, "eps_CG", 1e-19)), Int(get(params, "MaxCGstep", 3000)), "cg", true)
+        finalizer(d -> d.owner && ccall((:lqcd_op_destroy, LIB), Cint, (Ptr{Cvoid},), d.h), D)
+        return D
+    end
     kind = name in ("Wilson", "WilsonClover") ? WILSON : name in ("Staggered", "staggered") ? STAGGERED : error("$name is not supported")
     km = kind == WILSON ? Float64(params["κ"]) : Float64(get(params, "mass", 0.5))
     r = Float64(get(params, "r", 1.0))

@@ -4,6 +4,7 @@
 // Replaces, behind the C ABI, LatticeDiracOperators.jl's mul!(y,D,x) / mul!(y,D',x) / DdagD_operator -- SURVEY.md 8(a) a1-a3, a7;
 // reference call sites /root/reference/src/system/universe.jl:103-137, src/md/standardMD.jl:95-96.
 #include "ops_internal.h"
+#include <cstring>
 
 #include <algorithm>
 #include <cmath>
@@ -304,9 +305,13 @@ void apply_bc(lqcd_ctx_s* c, const int bc[4]) {
 
 int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* who) {
     if (!(op && a && b && a->ctx == op->ctx && b->ctx == op->ctx && a->kind == op->kind && b->kind == op->kind &&
-          a->subset == LQCD_FULL && b->subset == LQCD_FULL && a != b)) {
+          a->subset == LQCD_FULL && b->subset == LQCD_FULL && a != b && a->data != b->data)) {
         set_error(std::string(who) + ": need two distinct FULL spinors of the operator's kind on the operator's context");
         return LQCD_ERR_ARG;
+    }
+    if (op->kind == LQCD_DOMAINWALL && strncmp(who, "dw:", 3) != 0) {      // (domainwall.hip passes its own names)
+        set_error(std::string(who) + ": not available for the Domainwall operator (mul!, DdagD, the CG and the action entry points are)");
+        return LQCD_ERR_UNSUPPORTED;
     }
     return links_flush_of(op);      // the operator reads its links: recorded single-direction link operations run first (md.hip)
 }
@@ -326,6 +331,7 @@ using namespace lqcd;
 
 // ---------------------------------------------------------------------------------- C API: operator
 extern "C" int lqcd_op_create(lqcd_ctx_t ctx, lqcd_op_t* op, int kind, lqcd_gauge_t g, double km, double r, const int bc[4]) {
+    ARGCHK(kind != LQCD_DOMAINWALL, "lqcd_op_create: the Domainwall operator is made by lqcd_op_create_domainwall (it needs M and L5)");
     LQCHK(lqcd::links_flush_of(g));      // recorded single-direction link operations run first (md.hip)
     ARGCHK(ctx && op && g && bc, "lqcd_op_create: null argument");
     ARGCHK(kind == LQCD_WILSON || kind == LQCD_STAGGERED, "lqcd_op_create: Dirac_operator not supported");
@@ -343,6 +349,8 @@ extern "C" int lqcd_op_destroy(lqcd_op_t op) {
     (void)hipFree(op->clover_inv);
     (void)hipFree(op->clover_lambda);
     if (op->clover_tmp) lqcd_spinor_destroy(op->clover_tmp);
+    if (op->dw_wilson) lqcd_op_destroy(op->dw_wilson);
+    for (lqcd_spinor_s* w : op->dw_work) if (w) lqcd_spinor_destroy(w);
     delete op;
     return LQCD_OK;
 }
@@ -373,12 +381,14 @@ extern "C" int lqcd_op_set_clover(lqcd_op_t op, double csw) {
 extern "C" int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g) {
     ARGCHK(op && g && g->ctx == op->ctx, "lqcd_op_set_gauge: bad gauge field");
     op->gauge = g;
+    if (op->dw_wilson) op->dw_wilson->gauge = g;
     op->clover_version = 0;   // another field: the clover term is rebuilt at the next application
     op->clover_inv_version = 0;
     return LQCD_OK;
 }
 
 extern "C" int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger) {
+    if (op && op->kind == LQCD_DOMAINWALL) return dw_op_apply(op, out, in, dagger);
     LQCHK(check_full(op, out, in, "lqcd_op_apply"));
     LQCHK(op_apply_async(op, out, in, dagger ? 1 : 0, nullptr));
     HIPCHK(hipStreamSynchronize(op->ctx->stream));
@@ -386,6 +396,7 @@ extern "C" int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, 
 }
 
 extern "C" int lqcd_op_apply_DdagD(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in) {
+    if (op && op->kind == LQCD_DOMAINWALL) return dw_op_apply_DdagD(op, out, in);
     LQCHK(check_full(op, out, in, "lqcd_op_apply_DdagD"));
     lqcd_spinor_s* tmp = scratch_get(op->ctx, op->kind, LQCD_FULL);
     if (!tmp) return LQCD_ERR_HIP;

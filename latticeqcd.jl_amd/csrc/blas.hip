@@ -254,7 +254,7 @@ int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n) {
 using namespace lqcd;
 
 static bool same_shape(lqcd_spinor_t a, lqcd_spinor_t b) {
-    return a && b && a->ctx == b->ctx && a->kind == b->kind && a->subset == b->subset;
+    return a && b && a->ctx == b->ctx && a->kind == b->kind && a->subset == b->subset && a->elems == b->elems;
 }
 
 extern "C" int lqcd_dot(lqcd_spinor_t a, lqcd_spinor_t b, double* re, double* im) {

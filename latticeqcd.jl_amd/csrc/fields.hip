@@ -398,7 +398,7 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
 extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
     if (!s) return LQCD_OK;
     // (no hipSetDevice: see lqcd_gauge_destroy)
-    (void)hipFree(s->data);
+    if (s->owner) (void)hipFree(s->data);
     delete s;
     return LQCD_OK;
 }
@@ -531,6 +531,7 @@ double2* spinor_block(lqcd_spinor_s* s, int p) {
 
 static int spinor_xfer(lqcd_spinor_t s, double* host, int to_device, int wing = 0) {
     ARGCHK(s && host, "spinor upload/download: null argument");
+    ARGCHK(s->ls == 1, "spinor upload/download: a five-dimensional field moves slice by slice (lqcd_spinor_slice)");
     ARGCHK(wing >= 0 && wing <= 4, "spinor upload/download: wing width 0..4");
     lqcd_ctx_s* c = s->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -576,7 +577,7 @@ extern "C" int lqcd_spinor_zero(lqcd_spinor_t s) {
 
 extern "C" int lqcd_spinor_copy(lqcd_spinor_t dst, lqcd_spinor_t src) {
     ARGCHK(dst && src, "lqcd_spinor_copy: null");
-    ARGCHK(dst->ctx == src->ctx && dst->kind == src->kind && dst->subset == src->subset, "lqcd_spinor_copy: shape mismatch");
+    ARGCHK(dst->ctx == src->ctx && dst->kind == src->kind && dst->subset == src->subset && dst->elems == src->elems, "lqcd_spinor_copy: shape mismatch");
     HIPCHK(hipSetDevice(dst->ctx->device));
     HIPCHK(hipMemcpyAsync(dst->data, src->data, dst->elems * sizeof(double2), hipMemcpyDeviceToDevice, dst->ctx->stream));
     HIPCHK(hipStreamSynchronize(dst->ctx->stream));
@@ -588,9 +589,13 @@ static int spinor_fill_mode(lqcd_spinor_t s, uint64_t seed, int mode) {
     lqcd_ctx_s* c = s->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int nt = 2 * c->geom.Vh;
-    hipLaunchKernelGGL(spinor_fill, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, spinor_block(s, 0),
-                       spinor_block(s, 1), s->ncomp, seed, mode);
-    HIPCHK(hipGetLastError());
+    // a five-dimensional field: slice i5 is the four-dimensional fill with seed + i5 (one stream per slice, keyed by the global site as ever)
+    const size_t slice = s->elems / s->ls;
+    for (int i5 = 0; i5 < s->ls; i5++) {
+        double2* base = s->data + (size_t)i5 * slice;
+        hipLaunchKernelGGL(spinor_fill, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, base, base + slice / 2, s->ncomp, seed + (uint64_t)i5, mode);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
 }

@@ -558,8 +558,10 @@ struct lqcd_spinor_s {
     int subset;  // LQCD_FULL | LQCD_EVEN | LQCD_ODD
     int ncomp;   // 12 | 3
     double2* data;
-    size_t elems;  // ncomp * Vh * (1|2)
+    size_t elems;  // ncomp * Vh * (1|2) [* ls]
     bool in_use = false;  // scratch-pool flag
+    int ls = 1;           // LQCD_DOMAINWALL: extent of the fifth direction, ls Wilson fields in one allocation (domainwall.hip)
+    bool owner = true;    // false: a slice view of a five-dimensional field (lqcd_spinor_slice) -- destroy frees the handle only
 };
 
 struct lqcd_op_s {
@@ -578,6 +580,11 @@ struct lqcd_op_s {
     uint64_t clover_inv_version = 0;
     double2* clover_lambda = nullptr;   // six Hermitian 3x3 matrices per site: scratch of the clover force
     int bicg_hint = 0;                  // iterations the last even-odd BiCGStab solve with this operator took (polling schedule of the next one)
+    // LQCD_DOMAINWALL (domainwall.hip): km = the fermion mass m; the 4-D Wilson operator of the slices (hop coefficient 1/2), five-dimensional work fields
+    int L5 = 0;
+    double dw_M = 0.0;
+    lqcd_op_s* dw_wilson = nullptr;
+    lqcd_spinor_s* dw_work[8] = {};
 };
 
 namespace lqcd {

@@ -12,7 +12,9 @@ int stream_grid(lqcd_ctx_s* c, size_t n);
 
 // apply.hip
 StencilCall make_hop_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* xin, double a, double b, int dagger);
-int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* who);
+int check_full(lqcd_op_s* op, lqcd_spinor_s* a, lqcd_spinor_s* b, const char* who);     // four-dimensional operators only
+int make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, StencilCall& s);
+void apply_bc(lqcd_ctx_s* c, const int bc[4]);
 void split_general_r(const StencilCall& s, StencilCall& s1, StencilCall& s2);   // Wilson r != 1 on a partitioned lattice = two r = 1 calls
 
 // solvers.hip
@@ -87,6 +89,17 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
 // mixed.hip: the same solve with an fp32 inner chain and fp64 defect correction (plain Wilson, 12-real links); outer: correction steps
 int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqcd_spinor_s* const w[6], lqcd_spinor_s* to, int dg, double eps,
                              int maxiter, int* iters, double* final_rr, const double2* Ai = nullptr);
+
+// CG for a Hermitian positive operator given as an enqueue function (solvers.hip); x holds the initial guess, r, p, q: work of n elements
+int cg_generic(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* r, double2* p, double2* q, double eps,
+               int maxiter, int* iters, double* final_rr);
+// domainwall.hip: the five-dimensional operator behind the entry points of the four-dimensional ones
+int dw_op_apply(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger);
+int dw_op_apply_DdagD(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in);
+int dw_solve_cg(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, int* iters, double* rr);
+int dw_sample(lqcd_op_s* op, lqcd_spinor_s* phi, lqcd_spinor_s* xi, double eps, int maxiter);
+int dw_action(lqcd_op_s* op, lqcd_spinor_s* phi, lqcd_spinor_s* X, lqcd_spinor_s* Y, double eps, int maxiter, double* Sf, int* iters);
+int dw_force(lqcd_op_s* op, lqcd_gauge_s* out, lqcd_spinor_s* phi, double eps, int maxiter, double* Sf, int* iters);
 
 // scratch fields of one call: returned to the context's pool on every exit path
 struct ScratchScope {

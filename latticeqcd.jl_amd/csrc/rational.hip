@@ -424,7 +424,7 @@ extern "C" int lqcd_action_create(lqcd_op_t op, double nf, double eps, int maxit
     fa->eps = eps;
     fa->maxiter = maxiter;
     const int kind = op->kind;
-    if (nf <= 0) nf = kind == LQCD_WILSON ? 2 : 4;       // the reference's defaults (universe.jl:106-110 passes p.Nf)
+    if (nf <= 0) nf = kind == LQCD_STAGGERED ? 4 : 2;    // the reference's defaults (universe.jl:106-110 passes p.Nf)
     fa->nf = nf;
     bool force_rational = false, have_lo = false, have_hi = false;
     double plo = 0, phi = 0;
@@ -440,6 +440,11 @@ extern "C" int lqcd_action_create(lqcd_op_t op, double nf, double eps, int maxit
     }
     // D^+D carries 2 Wilson flavours / 8 staggered tastes (4 when the pseudofermion lives on the even sites): anything else is
     // S_f = eta^+ (D^+D)^(-Nf/n0) eta
+    if (kind == LQCD_DOMAINWALL) {      // two flavours with the Pauli-Villars field (domainwall.hip); nothing to fit
+        if (nf != 2 || force_rational) { delete fa; set_error("FermiAction: the Domainwall action is the two-flavour one (Nf = 2)"); return LQCD_ERR_UNSUPPORTED; }
+        *out = fa;
+        return LQCD_OK;
+    }
     const double n0 = kind == LQCD_WILSON ? 2 : 8;
     fa->evensite = kind == LQCD_STAGGERED && nf == 4;
     fa->rational = (kind == LQCD_WILSON && nf != 2) || (kind == LQCD_STAGGERED && nf != 4 && nf != 8) || force_rational;
@@ -565,6 +570,7 @@ extern "C" int lqcd_action_sample_pseudofermions(lqcd_action_t fa, lqcd_gauge_t 
     ARGCHK(fa && eta && xi && eta != xi, "lqcd_action_sample_pseudofermions: need distinct fields");
     LQCHK(action_bind(fa, U));
     lqcd_op_s* op = fa->op;
+    if (op->kind == LQCD_DOMAINWALL) return dw_sample(op, eta, xi, fa->eps, fa->maxiter);
     LQCHK(check_full(op, eta, xi, "lqcd_action_sample_pseudofermions"));
     if (fa->rational) {
         LQCHK(lqcd_action_check_interval(fa));
@@ -590,6 +596,7 @@ extern "C" int lqcd_action_evaluate(lqcd_action_t fa, lqcd_gauge_t U, lqcd_spino
     ARGCHK(fa && eta, "lqcd_action_evaluate: null argument");
     LQCHK(action_bind(fa, U));
     lqcd_op_s* op = fa->op;
+    if (op->kind == LQCD_DOMAINWALL) return dw_action(op, eta, X, Y, fa->eps, fa->maxiter, Sf, iters);
     ScratchScope sc(op->ctx);
     if (!X) X = sc.get(op->kind, LQCD_FULL);
     if (!X) { set_error("evaluate_FermiAction: out of device memory"); return LQCD_ERR_HIP; }
@@ -612,6 +619,7 @@ extern "C" int lqcd_action_force(lqcd_action_t fa, lqcd_gauge_t U, lqcd_gauge_t 
     ARGCHK(fa && out && eta, "lqcd_action_force: null argument");
     LQCHK(action_bind(fa, U));
     lqcd_op_s* op = fa->op;
+    if (op->kind == LQCD_DOMAINWALL) return dw_force(op, out, eta, fa->eps, fa->maxiter, Sf, iters);
     if (fa->rational) {
         const Fit& f = fa->fit[1];
         if (Sf) *Sf = 0.0;

@@ -937,6 +937,7 @@ using namespace lqcd;
 
 // ---------------------------------------------------------------------------------- C API: solvers
 extern "C" int lqcd_solve_cg_DdagD(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, double eps, int maxiter, int* iters, double* final_rr) {
+    if (op && op->kind == LQCD_DOMAINWALL) return dw_solve_cg(op, x, b, eps, maxiter, iters, final_rr);
     LQCHK(check_full(op, x, b, "lqcd_solve_cg_DdagD"));
     ARGCHK(maxiter >= 0, "lqcd_solve_cg_DdagD: maxiter < 0");
     return cg_run(op, x, b, eps, maxiter, false, iters, final_rr);
@@ -950,8 +951,8 @@ extern "C" int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
 // CG with device-resident scalars for a Hermitian positive operator given as an enqueue function (reference form:
 // alpha = rr / <p, A p>); x holds the initial guess, work = three fields of n elements.  Used where the fused full-lattice
 // iteration of cg_run does not apply (parity blocks).
-static int cg_generic(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* r, double2* p, double2* q, double eps,
-                      int maxiter, int* iters, double* final_rr) {
+int lqcd::cg_generic(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* r, double2* p, double2* q, double eps,
+                     int maxiter, int* iters, double* final_rr) {
     LQCHK(A(q, x));
     HIPCHK(hipMemcpyAsync(r, b, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     LQCHK(blas_axpy(c, -1.0, 0.0, q, r, n));

@@ -10,7 +10,7 @@ SO_PATH = os.environ.get("LQCD_HIP_LIB", os.path.join(_HERE, "csrc", "liblqcd_hi
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "lqcd_hip.h")
 
 OK, ERR_ARG, ERR_HIP, ERR_NOT_CONVERGED, ERR_COMM, ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5
-WILSON, STAGGERED = 0, 1
+WILSON, STAGGERED, DOMAINWALL = 0, 1, 2
 FULL, EVEN, ODD = 0, 1, 2
 LAYOUT_REFERENCE, LAYOUT_DISK = 0, 1
 

@@ -6,7 +6,7 @@ behaviour (non-convergence and unsupported operators raise), everything forwarde
 
 Reference call sites mirrored (paths relative to /root/reference):
   Initialize_Gaugefields(NC, Nwing, L...; condition)            src/system/universe.jl:41-49
-  Initialize_pseudofermion_fields(U[1], "Wilson"|"staggered")   src/system/universe.jl:107,112
+  Initialize_pseudofermion_fields(U[1], "Wilson"|"staggered"|"Domainwall"; L5)   src/system/universe.jl:107,112,128
   Dirac_operator(U, x, params) / D(U) / D'                      src/system/universe.jl:103-137, unusedfiles/measure_chiral_condensate.jl:173
   DdagD_operator, mul!, solve_DinvX!                            SURVEY.md 8(a) a2-a5 (LatticeDiracOperators.jl)
   dot, clear_fermion!, add_fermion!, substitute_fermion!        src/updates/standardHMC.jl:54, src/md/standardMD.jl:50-51
@@ -21,9 +21,9 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _l
-from .lib import EVEN, FULL, ODD, STAGGERED, WILSON, LQCDError, NotConverged, check  # noqa: F401
+from .lib import DOMAINWALL, EVEN, FULL, ODD, STAGGERED, WILSON, LQCDError, NotConverged, check  # noqa: F401
 
-_KIND = {"wilson": WILSON, "staggered": STAGGERED, "wilsonclover": WILSON}
+_KIND = {"wilson": WILSON, "staggered": STAGGERED, "wilsonclover": WILSON, "domainwall": DOMAINWALL}
 
 
 def _ptr(a):
@@ -74,7 +74,7 @@ class Lattice:
 
     def fermion_shape(self, kind):
         l = self.local_L
-        return (4, l[3], l[2], l[1], l[0], 3) if kind == WILSON else (l[3], l[2], l[1], l[0], 3)
+        return (4, l[3], l[2], l[1], l[0], 3) if kind in (WILSON, DOMAINWALL) else (l[3], l[2], l[1], l[0], 3)      # Domainwall: per slice
 
     def local_slices(self):
         """numpy slices (t,z,y,x) selecting this rank's sub-lattice out of a global array."""
@@ -232,16 +232,41 @@ def unitarity_deviation(U):
 
 # ------------------------------------------------------------------------------------ fermion fields
 class Fermionfields:
-    def __init__(self, lattice, kind, subset=FULL):
+    """A pseudofermion field.  kind = DOMAINWALL: L5 Wilson fields in one allocation; `x.w[i5]` (the reference's name for a slice) is a Wilson field that
+    aliases slice i5, host arrays are [L5][s,t,z,y,x,c]."""
+
+    def __init__(self, lattice, kind, subset=FULL, L5=None, _slice_of=None):
         self.lattice = lattice
         self.kind = kind
         self.subset = subset
+        self.L5 = L5
         self._h = C.c_void_p()
-        check(_l.lib().lqcd_spinor_create(lattice._h, C.byref(self._h), int(kind), int(subset)))
+        self._parent = None
+        if _slice_of is not None:
+            parent, i5 = _slice_of
+            self._parent = parent           # the view owns nothing: the parent stays alive as long as the view does
+            check(_l.lib().lqcd_spinor_slice(parent._h, int(i5), C.byref(self._h)))
+        elif kind == DOMAINWALL:
+            if not L5:
+                raise LQCDError(_l.ERR_ARG, "a Domainwall field needs L5")
+            check(_l.lib().lqcd_spinor_create_5d(lattice._h, C.byref(self._h), int(L5)))
+        else:
+            check(_l.lib().lqcd_spinor_create(lattice._h, C.byref(self._h), int(kind), int(subset)))
+
+    @property
+    def w(self):
+        if self.kind != DOMAINWALL:
+            raise AttributeError("w: only five-dimensional fields have slices")
+        return [Fermionfields(self.lattice, WILSON, FULL, _slice_of=(self, i5)) for i5 in range(self.L5)]
 
     def upload(self, psi, nwing=0):
         """nwing > 0: psi carries the reference's wing (fields created without nowing = true, universe.jl:107)."""
         psi = np.ascontiguousarray(psi, dtype=np.complex128)
+        if self.kind == DOMAINWALL:
+            assert psi.shape == (self.L5,) + self.lattice.fermion_shape(WILSON), psi.shape
+            for i5, v in enumerate(self.w):
+                v.upload(psi[i5])
+            return self
         if nwing:
             check(_l.lib().lqcd_spinor_upload_wing(self._h, _ptr(psi), int(nwing)))
             return self
@@ -254,12 +279,17 @@ class Fermionfields:
         return into
 
     def download(self, into=None):
+        if self.kind == DOMAINWALL:
+            out = np.zeros((self.L5,) + self.lattice.fermion_shape(WILSON), dtype=np.complex128) if into is None else into
+            for i5, v in enumerate(self.w):
+                v.download(out[i5])
+            return out
         out = np.zeros(self.lattice.fermion_shape(self.kind), dtype=np.complex128) if into is None else into
         check(_l.lib().lqcd_spinor_download(self._h, _ptr(out)))
         return out
 
     def similar(self):
-        return Fermionfields(self.lattice, self.kind, self.subset)
+        return Fermionfields(self.lattice, self.kind, self.subset, L5=self.L5)
 
     def close(self):
         if self._h:
@@ -273,12 +303,12 @@ class Fermionfields:
             pass
 
 
-def Initialize_pseudofermion_fields(U, Dirac_operator, nowing=True, subset=FULL):
-    """Initialize_pseudofermion_fields(U[1], "Wilson" | "staggered"; nowing) (universe.jl:107,112)."""
+def Initialize_pseudofermion_fields(U, Dirac_operator, nowing=True, subset=FULL, L5=None):
+    """Initialize_pseudofermion_fields(U[1], "Wilson" | "staggered" | "Domainwall"; nowing, L5) (universe.jl:107,112,128)."""
     key = Dirac_operator.lower()
     if key not in _KIND:
         raise LQCDError(_l.ERR_UNSUPPORTED, f"{Dirac_operator} is not supported")
-    return Fermionfields(U.lattice, _KIND[key], subset)
+    return Fermionfields(U.lattice, _KIND[key], subset, L5=L5)
 
 
 def clear_fermion_(x):
@@ -349,9 +379,15 @@ class Dirac_operator:
         self.MaxCGstep = int(self.params.get("MaxCGstep", 3000))        # parameter_structs.jl:175
         self.method_CG = self.params.get("method_CG", "bicgstab")
         self.bc = tuple(self.params.get("boundarycondition", (1, 1, 1, -1)))  # parameter_structs.jl:133
+        self.L5 = None
         if self.kind == WILSON:
             self.km = float(self.params.get("κ", self.params.get("kappa", 0.141139)))  # parameter_structs.jl:126
             self.r = float(self.params.get("r", 1.0))
+        elif self.kind == DOMAINWALL:      # universe.jl:116-128: "mass" = Domainwall_m, "L5", "M" = Domainwall_M
+            self.km = float(self.params.get("mass", 0.25))
+            self.M = float(self.params.get("M", -1.0))
+            self.L5 = int(self.params.get("L5", 4))
+            self.r = 1.0
         else:
             self.km = float(self.params.get("mass", 0.5))
             self.r = 1.0
@@ -359,6 +395,10 @@ class Dirac_operator:
             self._h, self._owner = _share, False
         else:
             self._h, self._owner = C.c_void_p(), True
+            if self.kind == DOMAINWALL:
+                check(_l.lib().lqcd_op_create_domainwall(self.lattice._h, C.byref(self._h), U._h, C.c_double(self.M), C.c_double(self.km), self.L5,
+                                                         _l.i4(self.bc)))
+                return
             check(_l.lib().lqcd_op_create(self.lattice._h, C.byref(self._h), self.kind, U._h, C.c_double(self.km),
                                           C.c_double(self.r), _l.i4(self.bc)))
             if key == "wilsonclover":     # Dirac_operator = "WilsonClover", Clover_coefficient (parameter_structs.jl:125)
@@ -552,7 +592,7 @@ class FermiAction:
         self.rational = bool(self._get("rational"))
         self.evensite = bool(self._get("evensite"))
         self.alpha = self._get("alpha")
-        self._temporary_fermionfields = [Fermionfields(D.lattice, D.kind) for _ in range(2)]   # standardMD.jl:50-51
+        self._temporary_fermionfields = [Fermionfields(D.lattice, D.kind, L5=D.L5) for _ in range(2)]   # standardMD.jl:50-51
 
     def _get(self, key):
         v = C.c_double(0)

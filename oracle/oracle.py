@@ -344,3 +344,72 @@ def unit_gauge(L):
 def gaussian_spinor(shape, seed):
     rng = np.random.default_rng(seed)
     return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex128)
+
+
+# ---------------------------------------------------------------- Domainwall (Shamir) operator: numpy over the C Wilson operator
+# Restates the definition csrc/domainwall.hip gives (textbook Shamir operator in the conventions of SURVEY.md Appendix A; the reference's own
+# arithmetic is in LatticeDiracOperators.jl, not under the reference tree: [EXT-RECALL], parity unpinned like the Wilson operator underneath).
+# Call sites in the reference: src/system/universe.jl:116-128 (params "mass", "L5", "M"), test/test_domainwallhmc.toml, test/runtests.jl:132-137.
+# Five-dimensional fields: psi5[s5, spin, t, z, y, x, c].
+def _spin(M, psi):
+    return np.einsum("ab,b...->a...", M, psi)
+
+
+def domainwall_D(U, psi5, L, M, mass, bc=(1, 1, 1, -1), dagger=False):
+    """(D5 psi)(s) = D4 psi(s) + psi(s) - P_- psi(s+1) - P_+ psi(s-1), psi(L5+1) = -m psi(1), psi(0) = -m psi(L5); D4 = (4 + M) - H/2.
+    The adjoint exchanges P_+ and P_- in the fifth-direction hops."""
+    L5 = psi5.shape[0]
+    one = np.eye(4, dtype=np.complex128)
+    Pp, Pm = 0.5 * (one + GAMMA[4]), 0.5 * (one - GAMMA[4])
+    PA, PB = (Pp, Pm) if dagger else (Pm, Pp)
+    out = np.empty_like(psi5)
+    for s in range(L5):
+        out[s] = (4.0 + M) * psi5[s] + wilson_D(U, np.ascontiguousarray(psi5[s]), L, 0.5, 1.0, bc, dagger)      # wilson_D(kappa = 1/2) = psi - H psi / 2
+        cu = -1.0 if s + 1 < L5 else mass
+        cd = -1.0 if s >= 1 else mass
+        out[s] += cu * _spin(PA, psi5[(s + 1) % L5]) + cd * _spin(PB, psi5[(s - 1) % L5])
+    return out
+
+
+def domainwall_cg(U, b5, L, M, mass, bc=(1, 1, 1, -1), eps=1e-19, maxiter=3000):
+    """x = (D5^+ D5)^-1 b, CG from a zero guess with the reference's stopping rule real(r.r) < eps.  Returns (x, iterations, r.r)."""
+    A = lambda v: domainwall_D(U, domainwall_D(U, v, L, M, mass, bc), L, M, mass, bc, dagger=True)
+    x = np.zeros_like(b5)
+    r = b5.copy()
+    p = r.copy()
+    rr = np.vdot(r, r).real
+    it = 0
+    while rr >= eps and it < maxiter:
+        q = A(p)
+        alpha = rr / np.vdot(p, q).real
+        x += alpha * p
+        r -= alpha * q
+        rr_new = np.vdot(r, r).real
+        p = r + (rr_new / rr) * p
+        rr = rr_new
+        it += 1
+    return x, it, rr
+
+
+def domainwall_action(U, phi5, L, M, mass, bc=(1, 1, 1, -1), eps=1e-19):
+    """S = psi^+ (D^+D)^-1 psi, psi = D_PV^+ phi, D_PV = D5(m = 1).  Returns (S, X, Y = D X)."""
+    psi = domainwall_D(U, phi5, L, M, 1.0, bc, dagger=True)
+    X, _, _ = domainwall_cg(U, psi, L, M, mass, bc, eps)
+    return np.vdot(psi, X).real, X, domainwall_D(U, X, L, M, mass, bc)
+
+
+def domainwall_sample(U, xi5, L, M, mass, bc=(1, 1, 1, -1), eps=1e-22):
+    """phi = D_PV^-+ D^+ xi = D_PV (D_PV^+ D_PV)^-1 D^+ xi, so that S(phi) = xi^+ xi."""
+    w = domainwall_D(U, xi5, L, M, mass, bc, dagger=True)
+    z, _, _ = domainwall_cg(U, w, L, M, 1.0, bc, eps)
+    return domainwall_D(U, z, L, M, 1.0, bc)
+
+
+def domainwall_force(U, phi5, L, M, mass, bc=(1, 1, 1, -1), eps=1e-22):
+    """G in the convention of fermion_force: dS = -2 Re[(Y - phi)^+ dD X], only the four-dimensional hops (coefficient 1/2) carry links."""
+    _, X, Y = domainwall_action(U, phi5, L, M, mass, bc, eps)
+    Z = Y - phi5
+    G = np.zeros(gauge_shape(L), dtype=np.complex128)
+    for s in range(phi5.shape[0]):
+        G += fermion_force(WILSON, U, np.ascontiguousarray(X[s]), np.ascontiguousarray(Z[s]), L, 0.5, 1.0, bc)
+    return G

@@ -163,7 +163,7 @@ def main():
                 lq.calc_UdSfdU_(G, fa, U, eta)
                 lq.Traceless_antihermitian_add_(p, 1e-9, G)
     md_ms = {}
-    for merge in (0, 1):
+    for merge in (0, 1, 2):                        # 0: every update launches at once; 1: back-to-back link updates merge; 2 (default): + momentum and link update in one sweep
         lat.set_param("lazy_merge", merge)
         for mixed in (0, 1):
             lat.set_param("mixed_action_solver", mixed)
@@ -171,7 +171,8 @@ def main():
             md_ms[(merge, mixed)] = 1e3 * timed(lambda: [md_step(), md_step(), md_step(), lq.unitarity_deviation(U)], reps=2)[0] / 3
     lat.set_param("mixed_action_solver", 0)
     res.append({"config": "32^3x64 Wilson HMC, one MD step resident on the device (Sexton-Weingarten N = 10)",
-                "md_step_measured_ms": md_ms[(1, 0)], "md_step_measured_mixed_precision_solver_ms": md_ms[(1, 1)],
+                "md_step_measured_ms": md_ms[(2, 0)], "md_step_measured_mixed_precision_solver_ms": md_ms[(2, 1)],
+                "md_step_measured_lazy_merge1_ms": md_ms[(1, 0)], "md_step_measured_lazy_merge1_mixed_ms": md_ms[(1, 1)],
                 "md_step_measured_lazy_merge0_ms": md_ms[(0, 0)], "md_step_measured_lazy_merge0_mixed_ms": md_ms[(0, 1)],
                 "gauge_force_ms": t_gf, "gauge_force_GBps_1152B": 1152 * V / t_gf / 1e6, "momentum_add_ta_ms": t_ta,
                 "P_update_fused_ms": t_pu, "P_update_fused_GBps_1728B": 1728 * V / t_pu / 1e6, "link_exp_update_ms": t_up,

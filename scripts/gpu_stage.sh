@@ -64,7 +64,7 @@ case $stage in
     ;;
   merge)      # waiting link / momentum updates (lazy_merge), measured MD step, bench.py after the settle change
     timeout 1200 python -m pytest tests/test_gpu_reference_callers.py tests/test_gpu_md.py tests/test_gpu_md_partitioned.py tests/test_gpu_md_staggered.py tests/test_gpu_md_mixed.py \
-        tests/test_gpu_reunit.py tests/test_gpu_hmc_partitioned.py tests/test_gpu_lifecycle.py tests/test_gpu_clover.py -q -x --durations=5 2>&1 | tail -14 | tee $out/pytest.log
+        tests/test_gpu_reunit.py tests/test_gpu_hmc_partitioned.py tests/test_gpu_lifecycle.py tests/test_gpu_clover.py tests/test_gpu_domainwall.py -q -x --durations=5 2>&1 | tail -14 | tee $out/pytest.log
     timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -k "c_abi" 2>&1 | tail -3 | tee -a $out/pytest.log
     timeout 900 python scripts/bench_configs.py > $out/bench_configs.log 2> $out/bench_configs.err; sed -n 5p $out/bench_configs.log | cut -c1-900; tail -3 $out/bench_configs.err
     timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; python -c "import json; d=json.load(open('$out/bench.json')); print(d['value'], d['dslash_ms'], d['roofline']['frac'], d['gauge_recon18_all_reals_read']['dslash_ms'], d['reference_format_links'])"; tail -2 $out/bench.err
@@ -88,6 +88,9 @@ for r in rows[:22]:
     print("%-90s %6s calls %9.3f ms %5.1f%%" % (r["Name"][:90], r["Calls"], float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
 PY
     done
+    ;;
+  dw)         # Domainwall operator, action, force, the reference's test case
+    timeout 900 python -m pytest tests/test_gpu_domainwall.py -q -x --durations=6 2>&1 | tail -25 | tee $out/pytest.log
     ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3

@@ -188,6 +188,38 @@ int main(void) {
         lqcd_gauge_destroy(P); lqcd_gauge_destroy(T1); lqcd_gauge_destroy(T2); lqcd_gauge_destroy(Ua); lqcd_gauge_destroy(Ub);
     }
 
+    /* Dirac_operator = "Domainwall" (universe.jl:116-128) from plain C, no oracle: on unit links with periodic boundaries a field that is constant in all
+     * five directions has H psi = 8 psi, so D4 psi = (4 + M) psi - 4 psi = M psi; with m = -1 the fifth direction is periodic too and
+     * D5 psi = M psi + psi - P_- psi - P_+ psi = M psi.  Then the pseudofermion action through the handle: at m = 1 (the reference's test) D = D_PV and
+     * S = phi^+ phi on any links. */
+    {
+        const int L5 = 4;
+        lqcd_gauge_t Uc; lqcd_spinor_t p5, q5, v; lqcd_op_t D5; lqcd_action_t fa5;
+        CHECK(lqcd_gauge_create(ctx, &Uc)); CHECK(lqcd_gauge_unit(Uc));
+        CHECK(lqcd_spinor_create_5d(ctx, &p5, L5)); CHECK(lqcd_spinor_create_5d(ctx, &q5, L5));
+        /* `host` still holds the site-constant spinor of the free-field check above */
+        for (int i5 = 0; i5 < L5; i5++) { CHECK(lqcd_spinor_slice(p5, i5, &v)); CHECK(lqcd_spinor_upload(v, host)); CHECK(lqcd_spinor_destroy(v)); }
+        CHECK(lqcd_op_create_domainwall(ctx, &D5, Uc, -1.3, -1.0, L5, bc_per));
+        CHECK(lqcd_op_apply(D5, q5, p5, 0));
+        double dwerr = 0;
+        for (int i5 = 0; i5 < L5; i5++) {
+            CHECK(lqcd_spinor_slice(q5, i5, &v)); CHECK(lqcd_spinor_download(v, out)); CHECK(lqcd_spinor_destroy(v));
+            for (long i = 0; i < 2 * n; i++) { double e = fabs(out[i] + 1.3 * host[i]); if (e > dwerr) dwerr = e; }
+        }
+        if (dwerr > 1e-13) { fprintf(stderr, "Domainwall free-field check failed: %.3e\n", dwerr); return 1; }
+        CHECK(lqcd_op_destroy(D5));
+        CHECK(lqcd_op_create_domainwall(ctx, &D5, U, -1.0, 1.0, L5, bc_apbc));      /* hot links, m = 1 */
+        CHECK(lqcd_action_create(D5, 0.0, 1e-20, 3000, 0, NULL, NULL, &fa5));
+        CHECK(lqcd_spinor_gaussian(p5, 77));
+        double S5 = 0, n5 = 0; int it5 = 0;
+        CHECK(lqcd_action_evaluate(fa5, U, p5, NULL, NULL, &S5, &it5));
+        CHECK(lqcd_norm2(p5, &n5));
+        if (fabs(S5 - n5) > 1e-9 * n5) { fprintf(stderr, "Domainwall action at the Pauli-Villars mass: %.15g vs phi.phi %.15g\n", S5, n5); return 1; }
+        if (lqcd_solve_bicgstab(D5, q5, p5, 0, 1e-19, 100, NULL, NULL) != LQCD_ERR_UNSUPPORTED) { fprintf(stderr, "expected LQCD_ERR_UNSUPPORTED\n"); return 1; }
+        lqcd_action_destroy(fa5); lqcd_op_destroy(D5);
+        lqcd_spinor_destroy(p5); lqcd_spinor_destroy(q5); lqcd_gauge_destroy(Uc);
+    }
+
     printf("C_ABI_OK plaquette=1 free-field maxerr=%.2e CG iters ok true-res=%.2e msg=\"%s\"\n", maxerr, res2, lqcd_last_error());
     free(host); free(out);
     lqcd_op_destroy(D);

@@ -1,0 +1,153 @@
+"""Dirac_operator = "Domainwall" (universe.jl:116-128; test/test_domainwallhmc.toml; the fifth HMC fermion test of test/runtests.jl:132-137) against the
+oracle's restatement (oracle/oracle.py domainwall_*: numpy over the C Wilson operator, itself checked by identities in tests/test_oracle_domainwall.py), and
+the reference's test case -- Domainwall_m = 1 = the Pauli-Villars mass -- through the transliterated callers."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+BC = (1, 1, 1, -1)
+
+
+def _setup(lq, orc, L, L5, M, mass, seed=11, bc=BC, **kw):
+    Uh = orc.hot_gauge(L, seed)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    x = lq.Initialize_pseudofermion_fields(U[1], "Domainwall", L5=L5, nowing=True)
+    params = {"Dirac_operator": "Domainwall", "mass": mass, "L5": L5, "M": M, "eps_CG": 1e-19, "MaxCGstep": 3000, "boundarycondition": bc}
+    params.update(kw)
+    D = lq.Dirac_operator(U, x, params)
+    return Uh, lat, U, x, D
+
+
+def _rand5(orc, L, L5, seed):
+    rng = np.random.default_rng(seed)
+    shp = (L5,) + orc.wilson_shape(L)
+    return rng.standard_normal(shp) + 1j * rng.standard_normal(shp)
+
+
+@pytest.mark.parametrize("L,L5,M,mass,bc", [((4, 4, 4, 8), 4, -1.0, 0.25, BC), ((8, 4, 4, 4), 6, -1.4, 0.05, (1, 1, 1, 1)), ((4, 4, 4, 4), 2, -1.0, 1.0, (1, -1, 1, -1)),
+                                            ((16, 8, 8, 8), 3, -1.8, 0.1, BC)])
+def test_mul_matches_the_oracle(lq, orc, L, L5, M, mass, bc):
+    Uh, lat, U, x, D = _setup(lq, orc, L, L5, M, mass, bc=bc)
+    ph = _rand5(orc, L, L5, 3)
+    x.upload(ph)
+    assert np.array_equal(x.download(), ph)                          # slices go up and come down where they belong
+    assert np.array_equal(x.w[L5 - 1].download(), ph[L5 - 1])        # x.w[i5]: a Wilson field aliasing one slice
+    y = x.similar()
+    for dagger in (False, True):
+        lq.mul_(y, D.adjoint() if dagger else D, x)
+        ref = orc.domainwall_D(Uh, ph, L, M, mass, bc, dagger=dagger)
+        assert rel_err(y.download(), ref) < 1e-13
+    lq.mul_(y, lq.DdagD_operator(D), x)
+    ref = orc.domainwall_D(Uh, orc.domainwall_D(Uh, ph, L, M, mass, bc), L, M, mass, bc, dagger=True)
+    assert rel_err(y.download(), ref) < 1e-13
+    # BLAS-1 takes the five-dimensional field as one array
+    assert abs(lq.dot(x, x) - np.vdot(ph, ph)) < 1e-11 * abs(np.vdot(ph, ph))
+
+
+def test_cg_solution_matches_the_oracle(lq, orc):
+    L, L5, M, mass = (4, 4, 4, 8), 4, -1.0, 0.1
+    Uh, lat, U, b, D = _setup(lq, orc, L, L5, M, mass)
+    bh = _rand5(orc, L, L5, 4)
+    b.upload(bh)
+    x = b.similar()
+    it, rr = lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+    xo, ito, rro = orc.domainwall_cg(Uh, bh, L, M, mass, BC, eps=1e-19)
+    assert rr < 1e-19 and abs(it - ito) <= 2
+    xh = x.download()
+    assert rel_err(xh, xo) < 1e-9
+    res = bh - orc.domainwall_D(Uh, orc.domainwall_D(Uh, xh, L, M, mass, BC), L, M, mass, BC, dagger=True)
+    assert np.vdot(res, res).real < 4e-19                              # the true residual of the device solution, by the oracle's operator
+
+
+def test_action_heat_bath_and_force(lq, orc):
+    L, L5, M, mass = (4, 4, 4, 4), 4, -1.0, 0.2
+    Uh, lat, U, phi, D = _setup(lq, orc, L, L5, M, mass, eps_CG=1e-22)
+    fa = lq.FermiAction(D, {})
+    xi = phi.similar()
+    lq.gauss_sampling_in_action_(xi, U, fa, 21)
+    xih = xi.download()
+    assert 0.9 < np.vdot(xih, xih).real / xih.size < 1.1               # <|xi_i|^2> = 1 on every slice
+    assert abs(np.vdot(xih[0], xih[1])) < 0.2 * np.vdot(xih[0], xih[0]).real   # slices are independent streams
+    lq.sample_pseudofermions_(phi, U, fa, xi)
+    phh = phi.download()
+    assert rel_err(phh, orc.domainwall_sample(Uh, xih, L, M, mass, BC)) < 1e-9
+    S = lq.evaluate_FermiAction(fa, U, phi)
+    assert abs(S - np.vdot(xih, xih).real) < 1e-9 * S                   # the heat bath identity S(phi) = xi^+ xi
+    So, Xo, Yo = orc.domainwall_action(Uh, phh, L, M, mass, BC, eps=1e-24)
+    assert abs(S - So) < 1e-10 * So
+    G = lq.Gaugefields(lat)
+    lq.calc_UdSfdU_(G, fa, U, phi)
+    Go = orc.domainwall_force(Uh, phh, L, M, mass, BC, eps=1e-24)
+    assert rel_err(G.download(), Go) < 1e-8
+    # Nf other than 2 has no Domainwall action
+    with pytest.raises(lq.LQCDError):
+        lq.FermiAction(D, {"Nf": 1})
+    # entry points that do not serve the operator say so
+    y = phi.similar()
+    with pytest.raises(lq.LQCDError, match="Domainwall"):
+        D.method_CG = "bicgstab"
+        lq.solve_DinvX_(y, D, phi)
+
+
+def test_force_is_the_derivative_of_the_device_action(lq, orc):
+    import scipy.linalg as sla
+    L, L5, M, mass = (4, 4, 4, 4), 3, -1.2, 0.15
+    Uh, lat, U, phi, D = _setup(lq, orc, L, L5, M, mass, seed=31, eps_CG=1e-24)
+    fa = lq.FermiAction(D, {})
+    phi.upload(_rand5(orc, L, L5, 32))
+    G = lq.Gaugefields(lat)
+    lq.calc_UdSfdU_(G, fa, U, phi)
+    Gh = G.download()
+    rng = np.random.default_rng(33)
+    for _ in range(3):
+        mu, t, z, y, x = (int(rng.integers(n)) for n in (4, L[3], L[2], L[1], L[0]))
+        T = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+        T = T + T.conj().T
+        h, S = 1e-4, []
+        for e in (h, -h):
+            V = Uh.copy()
+            V[mu, t, z, y, x] = V[mu, t, z, y, x] @ sla.expm(1j * e * T).T      # host image [b, a]: the transpose of the matrix
+            U2 = lq.Gaugefields(lat).upload(V)
+            S.append(lq.evaluate_FermiAction(fa, U2, phi))
+        fd = (S[0] - S[1]) / (2 * h)
+        an = -2.0 * np.imag(np.trace(T @ Gh[mu, t, z, y, x].T))
+        assert abs(fd - an) < 2e-6 * max(1.0, abs(fd)), (fd, an)
+
+
+def test_reference_test_case_pauli_villars_mass_is_a_spectator(lq, orc):
+    """test/test_domainwallhmc.toml: Domainwall_m = 1.0 = the Pauli-Villars mass, M = -1, L5 = 4, beta 5.7, dtau 0.05, 20 MD steps, started from the
+    4x4x2x2 configuration of test/confs_HMC_L04040404_beta5.7_Domainwall.  D = D_PV: S_f = phi^+ phi for every gauge field and the fermion force vanishes, so the
+    trajectory is the quenched one with a spectator field -- through the reference's unchanged callers (transliterated in test_gpu_reference_callers.py)."""
+    import test_gpu_reference_callers as rc
+    L = (4, 4, 2, 2)
+    Uh = lq.gauge_io.load_BridgeText(os.path.join(GOLDEN, "domainwall_4x4x2x2.ildg.txt"), L)
+    plaq_file = orc.plaquette(Uh, L)
+    res = {}
+    for quench in (False, True):
+        lat = lq.Lattice(L)
+        U = lq.Gaugefields(lat).upload(Uh)
+        assert abs(lq.calculate_Plaquette(U) - plaq_file) < 1e-13
+        ga = lq.GaugeAction(U)
+        pl = lq.make_loops_fromname("plaquette", Dim=4)
+        ga.push_(5.7 / 2, pl + lq.make_loops_fromname("plaquette", Dim=4, adjoint=True))
+        fa = None
+        if not quench:
+            x = lq.Initialize_pseudofermion_fields(U[1], "Domainwall", L5=4, nowing=True)
+            D = lq.Dirac_operator(U, x, {"Dirac_operator": "Domainwall", "mass": 1.0, "L5": 4, "M": -1.0, "eps_CG": 1e-19, "verbose_level": 2,
+                                         "MaxCGstep": 3000, "boundarycondition": BC})
+            fa = lq.FermiAction(D, {})
+        hmc = rc.StandardHMC(lq, U, ga, quench, 0.05, 20, fa, seed=5)
+        acc = [rc.update_(hmc, U) for _ in range(2)]
+        res[quench] = (U.download(), hmc.dH, acc, lq.calculate_Plaquette(U))
+        if not quench:
+            md = hmc.md
+            S = lq.evaluate_FermiAction(fa, U, md.eta)
+            assert abs(S - lq.dot(md.eta, md.eta).real) < 1e-9 * S      # S_f = phi^+ phi on the evolved links
+    assert np.abs(res[False][0] - res[True][0]).max() < 1e-8            # the same links as the quenched trajectory (same momenta seeds) ...
+    assert np.abs(np.array(res[False][1]) - np.array(res[True][1])).max() < 1e-7      # ... and the same dH: the spectator's action does not move
+    assert all(abs(d) < 0.5 for d in res[False][1])

@@ -69,8 +69,9 @@ EXPECTED = {
     "load_BridgeText!": [["String", "Vector{HIPLink}", None, None]],
     "load_gaugefield!": [["Vector{HIPLink}", None, None, None, None]],
 }
-# calls that belong to paths the HIP binding does not serve (and says so): the Domainwall operator of universe.jl:116-128
-NOT_SERVED = {("Initialize_pseudofermion_fields", ("L5", "nowing"))}
+# calls that belong to paths the HIP binding does not serve (and says so) -- none since round 4: the Domainwall operator of universe.jl:116-128 is
+# served (csrc/domainwall.hip; Initialize_pseudofermion_fields(U[1], "Domainwall", L5 = L5, nowing = true) resolves like the others)
+NOT_SERVED = set()
 
 
 def binding_text():
@@ -233,6 +234,24 @@ def test_fermi_action_of_any_nf_goes_through_the_library_handle():
         assert export in text[i:i + 900], generic
     # no module-level rational-coefficient plumbing is left for the caller to do
     assert "needs the rational action" not in text
+
+
+def test_domainwall_operator_of_universe_jl_resolves():
+    """universe.jl:116-128: x = Initialize_pseudofermion_fields(U[1], "Domainwall", L5 = L5, nowing = true); params "Dirac_operator" => "Domainwall", "mass", "L5", "M";
+    D = Dirac_operator(U, x, params); FermiAction(D, parameters_action) (test/test_domainwallhmc.toml, runtests.jl:132-137).  The binding makes a
+    five-dimensional field, the operator through lqcd_op_create_domainwall, and the action through the same handle as every other operator."""
+    text = binding_text()
+    start = text.index("function Initialize_pseudofermion_fields(u::HIPLink")
+    body = text[start:text.index("\nend", start)]
+    assert '"domainwall"' in body and "DOMAINWALL" in body and "L5" in body
+    start = text.index("function Dirac_operator(U::Vector{HIPLink}")
+    body = text[start:text.index("\nend", start)]
+    assert 'name == "Domainwall"' in body and "lqcd_op_create_domainwall" in body
+    for key in ('"M"', '"mass"', '"L5"', '"boundarycondition"', '"eps_CG"', '"MaxCGstep"'):
+        assert key in body[:body.index("return D")], key
+    assert "lqcd_spinor_create_5d" in text and "lqcd_spinor_slice" in text
+    # similar(eta) of a five-dimensional field keeps L5 (standardMD.jl:50-51: eta = similar(fermi_action._temporary_fermionfields[1]); xi = similar(eta))
+    assert re.search(r"similar\(x::HIPFermion\)\s*=\s*HIPFermion\(x\.lat, x\.kind; L5 = x\.L5\)", text)
 
 
 def test_binding_keeps_no_module_level_mutable_state():
