@@ -327,6 +327,14 @@ int lqcd_gauge_action(lqcd_gauge_t U, double beta, double* Sg);          /* -eva
 int lqcd_gauge_force(lqcd_gauge_t out, lqcd_gauge_t U, double beta);     /* calc_dSdUmu! + mul!(temp, U, dSdUmu) (src/md/AbstractMD.jl:108-109): -(beta/6) U * staples.  Collective on a
                                                                           * partitioned lattice: forward ghost links, then the lower staples of the upper faces (two RCCL steps, no corners) */
 int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us, double beta, double factor, int fuse); /* the same on an in-process PE grid (tests) */
+/* Stout smearing of the links the fermion action sees, and the chain rule back to the thin links (src/system/universe.jl:147-171: CovNeuralnet(U),
+ * STOUT_Layer(p.stout_loops, p.stout_ρ, U); src/md/standardMD.jl:192-227: calc_smearedU, calc_UdSfdU! on the smeared links, back_prop;
+ * src/updates/standardHMC.jl:67-68).  One STOUT layer with the plaquette loop, Morningstar-Peardon's definition [EXT-RECALL: Gaugefields.jl is not under the
+ * reference tree]:  U'_mu(n) = exp(-rho TA(U_mu(n) A_mu(n))) U_mu(n), A = the six staples (those of lqcd_gauge_force).  Several layers = several calls,
+ * back-propagated in reverse order with the links each layer started from.  Force fields in the convention of lqcd_fermion_force.  One GPU. */
+int lqcd_link_mul_adj(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_gauge_t B, int mu_b);   /* mul!(C, A', B): C = A^+ B site by site (standardMD.jl:211) */
+int lqcd_stout_smear(lqcd_gauge_t out, lqcd_gauge_t U, double rho);                     /* out != U */
+int lqcd_stout_backprop(lqcd_gauge_t G, lqcd_gauge_t Gs, lqcd_gauge_t U, double rho);   /* G at the thin links U from Gs at the smeared links; G = Gs allowed */
 int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t G); /* Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131) */
 int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta); /* P_update! (AbstractMD.jl:99-118) fused: P += factor TA(gauge force), the force field is never stored */
 int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U (tunable md_reunitarize: projected back onto SU(3) in the same pass) */

@@ -31,7 +31,8 @@ import LinearAlgebra: mul!, dot
 import Base: similar, adjoint
 import Gaugefields: AbstractGaugefields, GaugeAction, Initialize_Gaugefields, substitute_U!, exptU!, Traceless_antihermitian_add!, calc_dSdUμ!,
     evaluate_GaugeAction, initialize_TA_Gaugefields, gauss_distribution!, calc_smearedU, println_verbose_level1,
-    println_verbose_level2, println_verbose_level3, get_myrank, calculate_Plaquette, load_BridgeText!, load_gaugefield!
+    println_verbose_level2, println_verbose_level3, get_myrank, calculate_Plaquette, load_BridgeText!, load_gaugefield!,
+    CovNeuralnet, CovLayer, STOUT_Layer, back_prop
 import LatticeDiracOperators: Dirac_operator, DdagD_operator, FermiAction, Initialize_pseudofermion_fields,
     gauss_sampling_in_action!, sample_pseudofermions!, evaluate_FermiAction, calc_UdSfdU!, solve_DinvX!, shiftedcg,
     clear_fermion!, substitute_fermion!, add_fermion!, gauss_distribution_fermion!, Z4_distribution_fermi!,
@@ -61,12 +62,13 @@ mutable struct HIPLattice
     rank::Int
     verbose::Int        # println_verbose_level2/3(U[1], ...) print at or above this level (Univ: p.verboselevel)
     spare::Any          # the HIPGaugeStorage whose free slots the next temporaries (similar(U[1])) take, or nothing -- per context, not per module
+    stout::Vector{Any}  # link fields of the stout layers (calc_smearedU: one per layer, then the two force fields of back_prop), made on first use
 end
 function HIPLattice(L::NTuple{4,Int}; PEs = (1, 1, 1, 1), rank = 0, device = 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lqcd_ctx_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cint}, Ptr{Cint}, Cint),
                 h, device, Cint[L...], Cint[PEs...], rank))
-    lat = HIPLattice(h[], L, PEs, rank, 2, nothing)
+    lat = HIPLattice(h[], L, PEs, rank, 2, nothing, Any[])
     finalizer(l -> ccall((:lqcd_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), l.h), lat)
     return lat
 end
@@ -200,6 +202,55 @@ println_verbose_level3(l::AnyLink, val...) = (get_myrank(l) == 0 && getfield(l, 
 # calc_smearedU(U, md.cov_neural_net) with cov_neural_net = nothing: always reached from update! (standardHMC.jl:67 compares the VALUE
 # nothing with the TYPE Nothing, which is true) -- no smearing, the fermion action sees U itself
 calc_smearedU(U::Vector{HIPLink}, ::Nothing) = (U, nothing, nothing)
+# ---- stout smearing of the links the fermion action sees (universe.jl:147-171; standardMD.jl:91, 192-227; standardHMC.jl:67-68).
+# Univ keeps the net in a field typed Union{Nothing,CovNeuralnet{Dim}} (universe.jl:15): the container is the package's own (CovNeuralnet(U) and push! are its
+# generic methods); the LAYER is ours -- STOUT_Layer dispatches on the links it is given -- and so are the two methods that touch links.  Served: the
+# plaquette loop with one rho per layer.  [EXT-RECALL: `CovLayer{Dim}` as the abstract layer type and `nn.layers` as the container's field are the
+# package's names as this file's author knows them; there is no Julia here to run them against.]
+struct HIPStoutLayer <: CovLayer{4}
+    ρ::Float64
+end
+function STOUT_Layer(loops, ρ, U::Vector{HIPLink})
+    (length(loops) == 1 && lowercase(String(loops[1])) == "plaquette" && length(ρ) == 1) ||
+        error("STOUT_Layer on device links: loops = $loops with ρ = $ρ are not supported (the plaquette loop with one ρ is)")
+    return HIPStoutLayer(Float64(ρ[1]))
+end
+function stout_field(lat::HIPLattice, k::Int, like::Vector{HIPLink})
+    while length(lat.stout) < k
+        push!(lat.stout, similar(like))
+    end
+    return lat.stout[k]::Vector{HIPLink}
+end
+function calc_smearedU(U::Vector{HIPLink}, nn::CovNeuralnet{4})
+    lat = lattice(U)
+    cur, multi = U, Vector{HIPLink}[]
+    for (k, layer) in enumerate(nn.layers)
+        out = stout_field(lat, k, U)
+        check(ccall((:lqcd_stout_smear, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), whole(out).h, whole(cur).h, (layer::HIPStoutLayer).ρ))
+        push!(multi, out)
+        cur = out
+    end
+    return cur, multi, nothing
+end
+# back_prop(md.dSdU, md.cov_neural_net, Uout_multi, U) (standardMD.jl:216): dSdU[μ] = Uout[μ]' (Uout dS/dUout)[μ] in, dSdUbare out with U[μ] dSdUbare[μ] = U dS/dU
+function back_prop(dSdU::Vector{HIPLink}, nn::CovNeuralnet{4}, Uout_multi, U::Vector{HIPLink})
+    n = length(nn.layers)
+    n == 0 && return dSdU
+    lat = lattice(U)
+    F, bare = stout_field(lat, n + 1, U), stout_field(lat, n + 2, U)
+    Uout = Uout_multi[n]
+    for μ = 1:4
+        mul!(F[μ], Uout[μ], dSdU[μ])
+    end
+    for k = n:-1:1
+        thin = k == 1 ? U : Uout_multi[k-1]
+        check(ccall((:lqcd_stout_backprop, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64), whole(F).h, whole(F).h, whole(thin).h, (nn.layers[k]::HIPStoutLayer).ρ))
+    end
+    for μ = 1:4
+        mul!(bare[μ], U[μ]', F[μ])
+    end
+    return bare
+end
 
 # host <-> device.  U_host: the reference's Vector of 4 Array{ComplexF64,6} (NC,NC,NX,NY,NZ,NT) [+ wings]
 function substitute_U!(U::Vector{HIPLink}, Uh::Vector{<:AbstractArray{ComplexF64,6}}; Nwing = 0)
@@ -241,6 +292,15 @@ substitute_U!(dst::HIPLink, src::HIPLink) =
 # mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUμ) (AbstractMD.jl:92,109)
 function mul!(C::HIPLink, A::HIPLink, B::HIPLink)
     check(ccall((:lqcd_link_mul, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), hof(C), slotof(C), hof(A), slotof(A), hof(B), slotof(B)))
+    return C
+end
+# mul!(md.dSdU[μ], Uout[μ]', UdSfdUμ[μ]) (standardMD.jl:211): the adjoint of a link as the first factor
+struct HIPLinkAdjoint
+    parent::HIPLink
+end
+adjoint(l::HIPLink) = HIPLinkAdjoint(l)
+function mul!(C::HIPLink, A::HIPLinkAdjoint, B::HIPLink)
+    check(ccall((:lqcd_link_mul_adj, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), hof(C), slotof(C), hof(A.parent), slotof(A.parent), hof(B), slotof(B)))
     return C
 end
 # exptU!(expU, t, p[mu], [temp1, temp2]) (AbstractMD.jl:91)

@@ -232,6 +232,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     }
     for (void* b : c->mix_buf) (void)hipFree(b);
     (void)hipFree(c->clover_q[0]); (void)hipFree(c->clover_q[1]);
+    for (lqcd_gauge_s*& t : c->stout_tmp) if (t) { (void)hipFree(t->data); (void)hipFree(t->data12); (void)hipFree(t->data12d); delete t; t = nullptr; }
     (void)hipFree(c->gauge_spare);
     (void)hipFree(c->clover_ext); (void)hipFree(c->clover_ext_buf[0]); (void)hipFree(c->clover_ext_buf[1]);
     if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }

@@ -507,6 +507,7 @@ struct lqcd_ctx_s {
     int force_ncomp = 0;
     // staple-force halos (md.hip): forward ghost links (+ their send buffer) and the lower-staple faces, allocated on first use
     double2* gf_ghost[4] = {}, *gf_gsend[4] = {}, *gf_wsend[4] = {}, *gf_wrecv[4] = {};
+    lqcd_gauge_s* stout_tmp[2] = {};    // W = U A and the N matrices of the stout back-propagation (md.hip), created on first use
     double2* gauge_spare = nullptr;     // second link buffer of the fused momentum + link update (md.hip staple_force_expu), allocated on first use
     double2* clover_q[2] = {};          // clover sums / transport ping-pong, six 3x3 matrices per site (clover.hip)
     double2* clover_ext = nullptr;      // halo-extended links + Lambda matrices of the partitioned clover force, and its face buffers

@@ -49,6 +49,18 @@ __device__ __forceinline__ void mm3_nd(cd (&C)[9], const cd (&A)[9], const cd (&
             C[a * 3 + b] = t;
         }
 }
+// C = A^+ B
+__device__ __forceinline__ void mm3_dn(cd (&C)[9], const cd (&A)[9], const cd (&B)[9]) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            cd t = mk(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) cfma_conj(t, A[k * 3 + a], B[k * 3 + b]);
+            C[a * 3 + b] = t;
+        }
+}
 // C = A^+ B^+ = (B A)^+
 __device__ __forceinline__ void mm3_dd(cd (&C)[9], const cd (&A)[9], const cd (&B)[9]) {
 #pragma unroll
@@ -648,6 +660,10 @@ __global__ __launch_bounds__(64) void link_op_kernel(Geom g, double2* C, int mc,
         cd b[9];
         load_m3(b, B + glink_off(g, p, mb, i), Gs);
         mm3(r, a, b);
+    } else if constexpr (OP == 6) {                 // A^+ B: mul!(dSdU[mu], Uout[mu]', UdSfdU[mu]) (standardMD.jl:211)
+        cd b[9];
+        load_m3(b, B + glink_off(g, p, mb, i), Gs);
+        mm3_dn(r, a, b);
     } else if constexpr (OP == 4 || OP == 5) {      // exp(t A) B: exptU! + mul! of the reference's U_update! in one pass (C may be B: the in-place link update)
         cd e[9], b[9];
         exp_m3(e, a, t);
@@ -1041,6 +1057,13 @@ extern "C" int lqcd_link_mul(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a,
     LQCHK(links_flush_of(c));
     return link_op<2>(C, mu_c, A, mu_a, B, mu_b, 0.0);
 }
+// mul!(C, A', B) on link fields (standardMD.jl:211: mul!(md.dSdU[mu], Uout[mu]', UdSfdUmu[mu])): C[mu_c](n) = A[mu_a](n)^+ B[mu_b](n)
+extern "C" int lqcd_link_mul_adj(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_gauge_t B, int mu_b) {
+    LQCHK(link_args(C, mu_c, A, mu_a, "lqcd_link_mul_adj"));
+    LQCHK(link_args(C, mu_c, B, mu_b, "lqcd_link_mul_adj"));
+    LQCHK(links_flush_of(C));
+    return link_op<6>(C, mu_c, A, mu_a, B, mu_b, 0.0);
+}
 // Traceless_antihermitian_add!(p[mu], factor, temp1) (AbstractMD.jl:110,131): P[mu_p] += factor * TA(G[mu_g]).  Third call of the P_update! triple:
 // p[mu] += factor TA(U[mu] (beta/2) staples) in one pass
 extern "C" int lqcd_link_add_ta(lqcd_gauge_t P, int mu_p, double factor, lqcd_gauge_t G, int mu_g) {
@@ -1262,5 +1285,233 @@ extern "C" int lqcd_momentum_action(lqcd_gauge_t P, double* K) {
     HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *K = c->h_scal[0];
+    return LQCD_OK;
+}
+
+// ---------------------------------------------------------------------------------- stout smearing and its back-propagation
+// The CovNeuralnet of the reference's fermion force (src/system/universe.jl:147-171: STOUT_Layer(p.stout_loops, p.stout_ρ, U); src/md/standardMD.jl:192-227:
+// calc_smearedU, calc_UdSfdU! on the smeared links, back_prop; src/updates/standardHMC.jl:67-68).  The arithmetic is Gaugefields.jl's, which is not under the
+// reference tree: this is Morningstar-Peardon's definition for the plaquette loop [EXT-RECALL, parity unpinned; the CPU restatement in the test
+// infrastructure is itself checked by finite differences, tests/test_cpu_stout_restatement.py],
+//     U'_mu(n) = exp(Z) U_mu(n),   Z = i Q = -rho TA(W),   W = U_mu(n) A_mu(n) (A: the six staples -- the staple sweep above with beta = -6),
+// and the chain rule with the Frechet derivative L(Z, .) of exp in place of the closed-form B matrices (the same linear map, no special cases):
+//     G_i = e^{-Z_i} G'_i e^{Z_i} + force of S~ = -2 rho sum_j Re tr(W_j N_j),   N_j = TA(L(Z_j, e^{-Z_j} G'_j)) held fixed,
+// where G' = "U' dS/dU'" at the smeared links and G = "U dS/dU" at the thin ones, both in the convention of lqcd_fermion_force.  S~ puts N_j at the start of each
+// of the 24 plaquette loops through a link: 6 plaquettes x the 4 links whose staple sums contain them (stout_gather_kernel).  One GPU.
+namespace lqcd {
+
+__device__ __forceinline__ void dag3(cd (&o)[9], const cd (&a)[9]) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) o[r * 3 + q] = mk(a[q * 3 + r].re, -a[q * 3 + r].im);
+}
+__device__ __forceinline__ void add3(cd (&o)[9], const cd (&a)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) o[k] = o[k] + a[k];
+}
+__device__ __forceinline__ void sub3(cd (&o)[9], const cd (&a)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) o[k] = o[k] - a[k];
+}
+// x = s TA(w),  TA(w) = (w - w^+)/2 - tr(w - w^+)/6
+__device__ __forceinline__ void ta3(cd (&x)[9], const cd (&w)[9], double s) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) x[r * 3 + q] = mk(0.5 * s * (w[r * 3 + q].re - w[q * 3 + r].re), 0.5 * s * (w[r * 3 + q].im + w[q * 3 + r].im));
+    const double tr = (x[0].im + x[4].im + x[8].im) / 3.0;
+    x[0].im -= tr; x[4].im -= tr; x[8].im -= tr;
+}
+__device__ __forceinline__ double rowsum_norm(const cd (&x)[9]) {
+    double nrm = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        nrm = fmax(nrm, (fabs(x[a * 3].re) + fabs(x[a * 3].im)) + (fabs(x[a * 3 + 1].re) + fabs(x[a * 3 + 1].im)) + (fabs(x[a * 3 + 2].re) + fabs(x[a * 3 + 2].im)));
+    return nrm;
+}
+// series length for exp and its Frechet derivative at norm nrm: n nrm^n / n! < 1e-18 (rho |TA(W)| of a stout layer is a few tenths; 3 is far outside)
+__device__ __forceinline__ int stout_terms(double nrm) { return nrm < 0.2 ? 14 : nrm < 0.5 ? 18 : nrm < 1.0 ? 23 : nrm < 2.0 ? 31 : 42; }
+// e = exp(x), Taylor-Horner
+__device__ __forceinline__ void exp_any3(cd (&e)[9], const cd (&x)[9]) {
+    cd t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) e[k] = mk((k % 4 == 0) ? 1.0 : 0.0, 0.0);
+    for (int n = stout_terms(rowsum_norm(x)); n >= 1; n--) {
+        mm3(t, x, e);
+        const double inv = 1.0 / (double)n;
+#pragma unroll
+        for (int k = 0; k < 9; k++) e[k] = mk(((k % 4 == 0) ? 1.0 : 0.0) + inv * t[k].re, inv * t[k].im);
+    }
+}
+// l = L(z, k) = sum_n D_n,  P_0 = 1, D_0 = 0,  D_n = (z D_{n-1} + k P_{n-1}) / n,  P_n = z P_{n-1} / n
+__device__ __forceinline__ void frechet3(cd (&l)[9], const cd (&z)[9], const cd (&k)[9]) {
+    cd P[9], D[9], t1[9], t2[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) { P[e] = mk((e % 4 == 0) ? 1.0 : 0.0, 0.0); D[e] = mk(0.0, 0.0); l[e] = mk(0.0, 0.0); }
+    const int nt = stout_terms(rowsum_norm(z));
+    for (int n = 1; n <= nt; n++) {
+        const double inv = 1.0 / (double)n;
+        mm3(t1, z, D);
+        mm3(t2, k, P);
+#pragma unroll
+        for (int e = 0; e < 9; e++) D[e] = mk(inv * (t1[e].re + t2[e].re), inv * (t1[e].im + t2[e].im));
+        mm3(t1, z, P);
+#pragma unroll
+        for (int e = 0; e < 9; e++) { P[e] = mk(inv * t1[e].re, inv * t1[e].im); l[e] = l[e] + D[e]; }
+    }
+}
+__device__ __forceinline__ void store_m3(double2* base, int stride, const cd (&a)[9]) {
+#pragma unroll
+    for (int e = 0; e < 9; e++) st(base + (size_t)e * stride, a[e]);
+}
+
+// out = exp(-rho TA(W)) U
+__global__ __launch_bounds__(256) void stout_smear_kernel(Geom g, double2* __restrict__ out, const double2* __restrict__ U, const double2* __restrict__ W, double rho) {
+    size_t off;
+    if (!link_of_thread(g, off)) return;
+    const int Gs = glink_stride(g);
+    cd w[9], z[9], e[9], u[9], r[9];
+    load_m3(w, W + off, Gs);
+    ta3(z, w, -rho);
+    exp_any3(e, z);
+    load_m3(u, U + off, Gs);
+    mm3(r, e, u);
+    store_m3(out + off, Gs, r);
+}
+// per link: Z = -rho TA(W); K = e^{-Z} G'; N = TA(L(Z, K)); G0 = K e^{Z}  (G0 may be written over G')
+__global__ __launch_bounds__(256) void stout_prep_kernel(Geom g, double2* __restrict__ N, double2* G0, const double2* Gp, const double2* __restrict__ W, double rho) {
+    size_t off;
+    if (!link_of_thread(g, off)) return;
+    const int Gs = glink_stride(g);
+    cd w[9], z[9], zm[9], em[9], gp[9], K[9], l[9], n[9], ep[9], g0[9];
+    load_m3(w, W + off, Gs);
+    ta3(z, w, -rho);
+#pragma unroll
+    for (int e = 0; e < 9; e++) zm[e] = mk(-z[e].re, -z[e].im);
+    exp_any3(em, zm);
+    load_m3(gp, Gp + off, Gs);
+    mm3(K, em, gp);
+    frechet3(l, z, K);
+    ta3(n, l, 1.0);
+    store_m3(N + off, Gs, n);
+    dag3(ep, em);                  // Z anti-Hermitian: e^{Z} = (e^{-Z})^+
+    mm3(g0, K, ep);
+    store_m3(G0 + off, Gs, g0);
+}
+// G_mu(n) += -rho * (the 24 loop terms through the link): thread = (site, mu)
+__global__ __launch_bounds__(256) void stout_gather_kernel(Geom g, double2* __restrict__ G, const double2* __restrict__ U, const double2* __restrict__ N, double rho) {
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    if (i >= g.Vh) return;
+    const int Gs = glink_stride(g);
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    cd a[9], Na[9], acc[9];
+    load_m3(a, link_at(g, U, c, mu), Gs);
+    load_m3(Na, link_at(g, N, c, mu), Gs);
+#pragma unroll
+    for (int e = 0; e < 9; e++) acc[e] = mk(0.0, 0.0);
+    for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        cd b[9], cc[9], d[9], Nb[9], Nc[9], Nd[9], t1[9], t2[9], t3[9], X[9];
+        int cm[4] = {c[0], c[1], c[2], c[3]}, cn[4] = {c[0], c[1], c[2], c[3]};
+        shift(cm, g, mu, 1);
+        shift(cn, g, nu, 1);
+        // the plaquette (n; mu, nu), this link as a: b = U_nu(n+mu), c = U_mu(n+nu), d = U_nu(n)
+        load_m3(b, link_at(g, U, cm, nu), Gs); load_m3(cc, link_at(g, U, cn, mu), Gs); load_m3(d, link_at(g, U, c, nu), Gs);
+        load_m3(Nb, link_at(g, N, cm, nu), Gs); load_m3(Nc, link_at(g, N, cn, mu), Gs); load_m3(Nd, link_at(g, N, c, nu), Gs);
+        mm3_nd(t1, b, cc);          // b c^+
+        mm3_nd(X, t1, d);           // X = b c^+ d^+
+        mm3(t2, X, Na);
+        mm3(t3, Nb, X);
+        add3(t2, t3);
+        mm3(t3, a, t2);             // a (X Na + Nb X)
+        add3(acc, t3);
+        mm3(t2, a, X);
+        dag3(t3, t2);               // (a X)^+ = d c b^+ a^+
+        mm3(t2, Nd, t3);
+        sub3(acc, t2);              // - Nd d c b^+ a^+
+        mm3(t2, a, t1);
+        dag3(t3, t2);               // (a b c^+)^+ = c b^+ a^+
+        mm3(t2, Nc, t3);
+        mm3(t3, d, t2);
+        sub3(acc, t3);              // - d Nc c b^+ a^+
+        // the plaquette (n - nu; mu, nu), this link as c: a2 = U_mu(m), b2 = U_nu(m + mu), d2 = U_nu(m), m = n - nu
+        int m[4] = {c[0], c[1], c[2], c[3]};
+        shift(m, g, nu, -1);
+        int mm[4] = {m[0], m[1], m[2], m[3]};
+        shift(mm, g, mu, 1);
+        load_m3(b, link_at(g, U, mm, nu), Gs); load_m3(cc, link_at(g, U, m, mu), Gs); load_m3(d, link_at(g, U, m, nu), Gs);       // b2, a2, d2
+        load_m3(Nb, link_at(g, N, mm, nu), Gs); load_m3(Nc, link_at(g, N, m, mu), Gs); load_m3(Nd, link_at(g, N, m, nu), Gs);     // Nb2, Na2, Nd2
+        mm3(t1, cc, b);             // a2 b2
+        dag3(X, t1);                // R = b2^+ a2^+
+        mm3(t1, Nd, d);
+        mm3(t2, d, Na);             // Nc of that plaquette is this link's own N
+        add3(t1, t2);               // Nd2 d2 + d2 Nc
+        mm3(t2, X, t1);
+        mm3(t3, a, t2);             // c R (Nd2 d2 + d2 Nc)
+        add3(acc, t3);
+        mm3(t1, Nc, cc);            // Na2 a2
+        mm3(t2, cc, Nb);            // a2 Nb2
+        add3(t1, t2);
+        mm3(t2, t1, b);             // (Na2 a2 + a2 Nb2) b2
+        mm3_nd(t1, t2, a);          // ... c^+
+        dag3(t3, d);
+        mm3(t2, t3, t1);            // d2^+ (...)
+        sub3(acc, t2);
+    }
+    double2* o = G + glink_off(g, p, mu, i);
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+        const cd v = ld(o + (size_t)e * Gs);
+        st(o + (size_t)e * Gs, mk(v.re - rho * acc[e].re, v.im - rho * acc[e].im));      // 0.5 * c0 = -rho
+    }
+}
+
+static int stout_tmp(lqcd_ctx_s* c, int i, lqcd_gauge_s** out) {
+    if (!c->stout_tmp[i]) LQCHK(lqcd_gauge_create(c, &c->stout_tmp[i]));
+    *out = c->stout_tmp[i];
+    return LQCD_OK;
+}
+
+}  // namespace lqcd
+
+// calc_smearedU(U, nn) for one STOUT_Layer(["plaquette"], [rho], U) (standardMD.jl:207, universe.jl:150-154): out = the smeared links; out must not be U
+extern "C" int lqcd_stout_smear(lqcd_gauge_t out, lqcd_gauge_t U, double rho) {
+    LQCHK(same_ctx(out, U, "lqcd_stout_smear"));
+    ARGCHK(out != U, "lqcd_stout_smear: the smeared links need a field of their own");
+    LQCHK(lqcd::links_flush_of(out));
+    lqcd_ctx_s* c = U->ctx;
+    ARGCHK(!any_partitioned(c), "lqcd_stout_smear: one GPU only");
+    HIPCHK(hipSetDevice(c->device));
+    lqcd_gauge_s* W;
+    LQCHK(stout_tmp(c, 0, &W));
+    LQCHK(staple_force(W, U, -6.0, 0.0, false));      // W = U A
+    out->version++;
+    hipLaunchKernelGGL(stout_smear_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, out->data, U->data, W->data, rho);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LQCD_OK;
+}
+
+// back_prop(dSdU, nn, Uout_multi, U) for that layer (standardMD.jl:216): G (thin links) from Gs = "U' dS/dU'" (smeared links), the convention of
+// lqcd_fermion_force on both sides; U = the thin links the layer smeared.  G = Gs is allowed (in place)
+extern "C" int lqcd_stout_backprop(lqcd_gauge_t G, lqcd_gauge_t Gs, lqcd_gauge_t U, double rho) {
+    LQCHK(same_ctx(G, U, "lqcd_stout_backprop"));
+    LQCHK(same_ctx(Gs, U, "lqcd_stout_backprop"));
+    ARGCHK(G != U && Gs != U, "lqcd_stout_backprop: the force fields must not be the link field");
+    LQCHK(lqcd::links_flush_of(G));
+    lqcd_ctx_s* c = U->ctx;
+    ARGCHK(!any_partitioned(c), "lqcd_stout_backprop: one GPU only");
+    HIPCHK(hipSetDevice(c->device));
+    lqcd_gauge_s *W, *N;
+    LQCHK(stout_tmp(c, 0, &W)); LQCHK(stout_tmp(c, 1, &N));
+    LQCHK(staple_force(W, U, -6.0, 0.0, false));
+    G->version++;
+    hipLaunchKernelGGL(stout_prep_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, N->data, G->data, Gs->data, W->data, rho);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(stout_gather_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, G->data, U->data, N->data, rho);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
 }

@@ -194,6 +194,17 @@ class LinkView:
     def download(self):
         return self.field.download()[self.slot]
 
+    def adjoint(self):
+        """U[mu]' as the first factor of mul!(C, U[mu]', B) (standardMD.jl:211)."""
+        return AdjointLinkView(self.field, self.slot)
+
+    H = property(adjoint)
+
+
+class AdjointLinkView:
+    def __init__(self, field, slot):
+        self.field, self.slot = field, slot
+
 
 def Initialize_Gaugefields(NC, Nwing, NX, NY, NZ, NT, condition="cold", lattice=None, randomseed=111, **kw):
     """Gaugefields.jl Initialize_Gaugefields(NC,Nwing,NX,NY,NZ,NT; condition) (universe.jl:41-49). NC = 3 only;
@@ -441,6 +452,9 @@ class DdagD_operator:
 def _mul_links(C_, A, B):
     """mul!(W, expU, U[mu]) / mul!(temp1, U[mu], dSdUmu) (AbstractMD.jl:92,109): 3x3 products site by site (second call of a lazy triple: the
     library records it, csrc/md.hip)."""
+    if isinstance(A, AdjointLinkView):
+        check(_l.lib().lqcd_link_mul_adj(C_.field._h, C_.slot, A.field._h, A.slot, B.field._h, B.slot))
+        return C_
     check(_l.lib().lqcd_link_mul(C_.field._h, C_.slot, A.field._h, A.slot, B.field._h, B.slot))
     return C_
 
@@ -727,6 +741,61 @@ def substitute_U_(dst, src):
         return dst
     check(_l.lib().lqcd_gauge_copy(dst._h, src._h))
     return dst
+
+
+# ------------------------------------------------------------------------------------ stout smearing of the fermion action's links
+class STOUT_Layer:
+    """STOUT_Layer(p.stout_loops, p.stout_ρ, U) (universe.jl:153): one stout layer.  Served: the plaquette loop (one rho)."""
+
+    def __init__(self, loops, rho, U=None):
+        loops = [loops] if isinstance(loops, str) else list(loops)
+        rho = [rho] if np.isscalar(rho) else list(rho)
+        if [l.lower() for l in loops] != ["plaquette"] or len(rho) != 1:
+            raise LQCDError(_l.ERR_UNSUPPORTED, f"STOUT_Layer: loops {loops} with rho {rho} are not supported (the plaquette loop with one rho is)")
+        self.rho = float(rho[0])
+
+
+class CovNeuralnet:
+    """CovNeuralnet(U) (universe.jl:150): the stack of smearing layers between the links of the MD and the links the fermion action sees."""
+
+    def __init__(self, U):
+        self.lattice = U.lattice
+        self.layers = []
+        self._out = []           # the links after each layer (Uout_multi), owned by the net
+        self._force = None       # force field carried back through the layers
+        self._bare = None
+
+    def push_(self, layer):
+        self.layers.append(layer)
+        self._out.append(Gaugefields(self.lattice))
+        return self
+
+
+def calc_smearedU(U, nn):
+    """calc_smearedU(U, cov_neural_net) (standardMD.jl:91,207; standardHMC.jl:68) -> (Uout, Uout_multi, nothing); Uout_multi[k] = the links after layer k + 1."""
+    cur = U
+    for layer, out in zip(nn.layers, nn._out):
+        check(_l.lib().lqcd_stout_smear(out._h, cur._h, C.c_double(layer.rho)))
+        cur = out
+    return cur, list(nn._out), None
+
+
+def back_prop(dSdU, nn, Uout_multi, U):
+    """back_prop(md.dSdU, cov_neural_net, Uout_multi, U) (standardMD.jl:216): dSdU[mu] = Uout[mu]' * (Uout dS/dUout)[mu] at the smeared links in, dSdUbare out, with
+    U[mu] * dSdUbare[mu] the same derivative with respect to the thin links (the caller multiplies and adds its traceless anti-Hermitian part to p[mu], :220-224)."""
+    if not nn.layers:
+        return dSdU
+    if nn._force is None:
+        nn._force, nn._bare = Gaugefields(nn.lattice), Gaugefields(nn.lattice)
+    Uout = Uout_multi[-1]
+    for mu in range(4):
+        check(_l.lib().lqcd_link_mul(nn._force._h, mu, Uout._h, mu, dSdU._h, mu))
+    for k in reversed(range(len(nn.layers))):
+        thin = U if k == 0 else Uout_multi[k - 1]
+        check(_l.lib().lqcd_stout_backprop(nn._force._h, nn._force._h, thin._h, C.c_double(nn.layers[k].rho)))
+    for mu in range(4):
+        check(_l.lib().lqcd_link_mul_adj(nn._bare._h, mu, U._h, mu, nn._force._h, mu))
+    return nn._bare
 
 
 class GaugeAction:

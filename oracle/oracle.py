@@ -413,3 +413,99 @@ def domainwall_force(U, phi5, L, M, mass, bc=(1, 1, 1, -1), eps=1e-22):
     for s in range(phi5.shape[0]):
         G += fermion_force(WILSON, U, np.ascontiguousarray(X[s]), np.ascontiguousarray(Z[s]), L, 0.5, 1.0, bc)
     return G
+
+
+# ---------------------------------------------------------------- stout smearing and its back-propagation (plaquette staples), pure numpy
+# Call sites in the reference: src/system/universe.jl:147-171 (CovNeuralnet(U), STOUT_Layer(p.stout_loops, p.stout_ρ, U), push!),
+# src/md/standardMD.jl:192-227 (P_update_fermion! with a CovNeuralnet: calc_smearedU, calc_UdSfdU! on the smeared links, back_prop),
+# src/updates/standardHMC.jl:67-68.  The arithmetic is Gaugefields.jl's (not under the reference tree); this is Morningstar-Peardon's definition,
+#     U'_mu(n) = exp(i Q_mu(n)) U_mu(n),   i Q = -rho TA(U_mu(n) A_mu(n)),   A = the six staples of the link (as in gauge_force),   TA(W) = (W - W^+)/2 - tr(W - W^+)/6,
+# and the chain rule written with Frechet derivatives of exp instead of the closed-form B matrices (the same linear map).  Matrices below are [.., a, b]
+# (the transpose of the host image [.., b, a]).
+def _mat(U):
+    return np.swapaxes(U, -1, -2)
+
+
+def _sh(F, L, nu, step):
+    """F(n + step nu_hat): axes of a link field F[t,z,y,x,a,b] are (t,z,y,x) = (3,2,1,0 in L order)."""
+    return np.roll(F, -step, axis=3 - nu)
+
+
+def _ta(W):
+    X = 0.5 * (W - np.conj(np.swapaxes(W, -1, -2)))
+    tr = np.trace(X, axis1=-2, axis2=-1) / 3.0
+    return X - tr[..., None, None] * np.eye(3)
+
+
+def _dag(A):
+    return np.conj(np.swapaxes(A, -1, -2))
+
+
+def _staple_sum(Um, L, mu):
+    """A_mu(n) = sum_{nu != mu} [ U_nu(n+mu) U_mu(n+nu)^+ U_nu(n)^+ + U_nu(n+mu-nu)^+ U_mu(n-nu)^+ U_nu(n-nu) ]  (periodic links)."""
+    A = np.zeros_like(Um[mu])
+    for nu in range(4):
+        if nu == mu:
+            continue
+        A += _sh(Um[nu], L, mu, 1) @ _dag(_sh(Um[mu], L, nu, 1)) @ _dag(Um[nu])
+        lo = _dag(_sh(Um[nu], L, mu, 1)) @ _dag(Um[mu]) @ Um[nu]          # at n: U_nu(n+mu)^+ U_mu(n)^+ U_nu(n); needed at n - nu
+        A += _sh(lo, L, nu, -1)
+    return A
+
+
+def _expm_batch(Z):
+    import scipy.linalg as sla
+    flat = Z.reshape(-1, 3, 3)
+    return np.stack([sla.expm(z) for z in flat]).reshape(Z.shape)
+
+
+def _expm_frechet_batch(Z, E):
+    import scipy.linalg as sla
+    fz, fe = Z.reshape(-1, 3, 3), E.reshape(-1, 3, 3)
+    return np.stack([sla.expm_frechet(z, e, compute_expm=False) for z, e in zip(fz, fe)]).reshape(Z.shape)
+
+
+def stout_smear(U, L, rho):
+    """One STOUT layer with plaquette staples.  Returns the smeared links in the host layout."""
+    Um = _mat(U)
+    out = np.empty_like(Um)
+    for mu in range(4):
+        Z = -rho * _ta(Um[mu] @ _staple_sum(Um, L, mu))
+        out[mu] = _expm_batch(Z) @ Um[mu]
+    return np.ascontiguousarray(_mat(out))
+
+
+def stout_backprop(Gs, U, L, rho):
+    """Gs = the force field "U' dS/dU'" at the smeared links (convention of fermion_force: dS/d eps under U' -> exp(i eps T) U' is -2 Im tr(T Gs));
+    returns G = "U dS/dU" at the thin links for the same S seen as a function of U.
+        G_i = e^{-Z_i} Gs_i e^{Z_i} + (force of  S~ = -2 rho sum_j Re tr(U_j A_j N_j),  N_j = TA(L(Z_j, e^{-Z_j} Gs_j))  held fixed),
+    L(Z, K) the Frechet derivative of exp at Z in direction K."""
+    Um, Gm = _mat(U), _mat(Gs)
+    Z = np.empty_like(Um)
+    N = np.empty_like(Um)
+    G = np.empty_like(Um)
+    for mu in range(4):
+        Z[mu] = -rho * _ta(Um[mu] @ _staple_sum(Um, L, mu))
+        Em = _expm_batch(-Z[mu])
+        K = Em @ Gm[mu]
+        N[mu] = _ta(_expm_frechet_batch(Z[mu], K))
+        G[mu] = K @ _dag(Em)                                   # e^{-Z} Gs e^{Z}  (Z anti-Hermitian: e^{Z} = (e^{-Z})^+)
+    c0 = -2.0 * rho
+    for mu in range(4):
+        a = Um[mu]
+        acc = np.zeros_like(a)
+        for nu in range(4):
+            if nu == mu:
+                continue
+            # the plaquette (n; mu, nu) with this link as `a`: b = U_nu(n+mu), c = U_mu(n+nu), d = U_nu(n)
+            b, c, d = _sh(Um[nu], L, mu, 1), _sh(Um[mu], L, nu, 1), Um[nu]
+            Na, Nb, Nc, Nd = N[mu], _sh(N[nu], L, mu, 1), _sh(N[mu], L, nu, 1), N[nu]
+            acc += a @ b @ _dag(c) @ _dag(d) @ Na + a @ Nb @ b @ _dag(c) @ _dag(d) - Nd @ d @ c @ _dag(b) @ _dag(a) - d @ Nc @ c @ _dag(b) @ _dag(a)
+            # the plaquette (n - nu; mu, nu) with this link as `c`: a' = U_mu(n-nu), b' = U_nu(n-nu+mu), d' = U_nu(n-nu)
+            a2, b2, d2 = _sh(Um[mu], L, nu, -1), _sh(_sh(Um[nu], L, mu, 1), L, nu, -1), _sh(Um[nu], L, nu, -1)
+            Na2, Nb2, Nd2, Nc2 = _sh(N[mu], L, nu, -1), _sh(_sh(N[nu], L, mu, 1), L, nu, -1), _sh(N[nu], L, nu, -1), N[mu]
+            cc = a
+            acc += cc @ _dag(b2) @ _dag(a2) @ Nd2 @ d2 + cc @ _dag(b2) @ _dag(a2) @ d2 @ Nc2 \
+                - _dag(d2) @ Na2 @ a2 @ b2 @ _dag(cc) - _dag(d2) @ a2 @ Nb2 @ b2 @ _dag(cc)
+        G[mu] += 0.5 * c0 * acc
+    return np.ascontiguousarray(_mat(G))

@@ -92,6 +92,9 @@ PY
   dw)         # Domainwall operator, action, force, the reference's test case
     timeout 900 python -m pytest tests/test_gpu_domainwall.py -q -x --durations=6 2>&1 | tail -25 | tee $out/pytest.log
     ;;
+  stout)      # stout smearing layer, back-propagation, the callers' CovNeuralnet path
+    timeout 900 python -m pytest tests/test_gpu_stout.py -q -x --durations=6 2>&1 | tail -25 | tee $out/pytest.log
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

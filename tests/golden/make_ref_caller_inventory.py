@@ -15,8 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REGIONS = [  # (file under the reference root, first line, last line): the callers SURVEY.md 8(a) names
     ("src/md/AbstractMD.jl", 78, 135),
     ("src/md/standardMD.jl", 5, 166),
+    ("src/md/standardMD.jl", 192, 227),      # P_update_fermion! with a CovNeuralnet (stout-smeared fermion action)
     ("src/updates/standardHMC.jl", 1, 91),
-    ("src/system/universe.jl", 30, 143),
+    ("src/system/universe.jl", 30, 191),     # ... including the construction of the stout net, :147-171
 ]
 STRUCTS = {"src/md/standardMD.jl": ["StandardMD"], "src/updates/standardHMC.jl": ["StandardHMC"], "src/system/universe.jl": ["Univ"]}
 KEYWORDS = {"if", "elseif", "for", "while", "function", "where", "return", "struct", "new", "begin", "let", "do", "in", "isa", "end"}

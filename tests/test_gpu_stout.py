@@ -1,0 +1,157 @@
+"""Stout smearing of the links the fermion action sees (universe.jl:147-171; standardMD.jl:82-101, 192-227; standardHMC.jl:67-68): the device layer and its
+back-propagation against the numpy restatement (oracle.stout_*, itself checked by finite differences in tests/test_cpu_stout_restatement.py), the fermion force
+through the smearing against finite differences of the device action, and energy conservation of the reference's unchanged callers -- the CovNeuralnet
+methods transliterated below as test_gpu_reference_callers.py transliterates the others."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+import test_gpu_reference_callers as rc
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+Dim = 4
+BC = (1, 1, 1, -1)
+
+
+def P_update_fermion_stout_(U, p, eps, md):                     # standardMD.jl:192-227 (TC <: CovNeuralnet)
+    lq = md.lq
+    temps = lq.get_temporary_gaugefields(md.gauge_action)
+    UdSfdUmu, its_UdSfdUmu = lq.get_temp(temps, Dim)
+    factor = -eps * md.dtau
+    Uout, Uout_multi, _ = lq.calc_smearedU(U, md.cov_neural_net)
+    for mu in range(1, Dim + 1):
+        lq.calc_UdSfdU_(UdSfdUmu, md.fermi_action, Uout, md.eta)
+        lq.mul_(md.dSdU[mu], Uout[mu].H, UdSfdUmu[mu - 1])
+    lq.unused_(temps, its_UdSfdUmu)
+    dSdUbare = lq.back_prop(md.dSdU, md.cov_neural_net, Uout_multi, U)
+    temp1, it_temp1 = lq.get_temp(temps)
+    for mu in range(1, Dim + 1):
+        lq.mul_(temp1, U[mu], dSdUbare[mu])                      # U*dSdUμ
+        lq.Traceless_antihermitian_add_(p[mu], factor, temp1)
+    lq.unused_(temps, it_temp1)
+
+
+def initialize_MD_stout_(U, md):                                 # standardMD.jl:82-101 (TC != Nothing)
+    lq = md.lq
+    md.seed += 3
+    lq.gauss_distribution_(md.p, md.seed)
+    Uout, Uout_multi, _ = lq.calc_smearedU(U, md.cov_neural_net)
+    lq.gauss_sampling_in_action_(md.xi, Uout, md.fermi_action, md.seed + 1)
+    lq.sample_pseudofermions_(md.eta, Uout, md.fermi_action, md.xi)
+
+
+def runMD_QPQ_stout_(U, md):                                     # standardMD.jl:127-144 with the CovNeuralnet method of P_update_fermion!
+    p = md.p
+    for itrj in range(md.MDsteps):
+        rc.U_update_(U, p, 0.5, md)
+        rc.P_update_(U, p, 1.0, md)
+        P_update_fermion_stout_(U, p, 1.0, md)
+        rc.U_update_(U, p, 0.5, md)
+
+
+def update_stout_(hmc, U):                                       # standardHMC.jl:41-91 with md.cov_neural_net set (:67-68)
+    md = hmc.md
+    lq = md.lq
+    NC = U[1].NC
+    lq.substitute_U_(hmc.Uold, U)
+    initialize_MD_stout_(U, md)
+    Sold = md.p * md.p / 2 - lq.evaluate_GaugeAction(md.gauge_action, U) / NC + lq.dot(md.xi, md.xi).real
+    runMD_QPQ_stout_(U, md)
+    Snew = md.p * md.p / 2 - lq.evaluate_GaugeAction(md.gauge_action, U) / NC
+    Uout, Uout_multi, _ = lq.calc_smearedU(U, md.cov_neural_net)
+    Snew += lq.evaluate_FermiAction(md.fermi_action, Uout, md.eta)
+    hmc.dH.append(Snew - Sold)
+    accept = np.exp(Sold - Snew) >= hmc.rng.random()
+    if not accept:
+        lq.substitute_U_(U, hmc.Uold)
+    return accept
+
+
+@pytest.mark.parametrize("L,rho", [((4, 4, 4, 8), 0.1), ((8, 4, 4, 4), 0.15)])
+def test_smearing_and_backpropagation_match_the_oracle(lq, orc, L, rho):
+    Uh = orc.hot_gauge(L, 7)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    nn = lq.CovNeuralnet(U)
+    nn.push_(lq.STOUT_Layer(["plaquette"], [rho], U))
+    Uout, multi, _ = lq.calc_smearedU(U, nn)
+    ref = orc.stout_smear(Uh, L, rho)
+    assert rel_err(Uout.download(), ref) < 1e-13
+    assert lq.unitarity_deviation(Uout) < 1e-13 and lq.calculate_Plaquette(Uout) > lq.calculate_Plaquette(U) + 0.05
+    rng = np.random.default_rng(8)
+    Gs = rng.standard_normal(orc.gauge_shape(L)) + 1j * rng.standard_normal(orc.gauge_shape(L))
+    Gd, G = lq.Gaugefields(lat).upload(Gs), lq.Gaugefields(lat)
+    lq.lib.check(lq.lib.lib().lqcd_stout_backprop(G._h, Gd._h, U._h, __import__("ctypes").c_double(rho)))
+    assert rel_err(G.download(), orc.stout_backprop(Gs, Uh, L, rho)) < 1e-12
+    assert np.array_equal(Gd.download(), Gs)                          # out of place: the input is left alone
+    lq.lib.check(lq.lib.lib().lqcd_stout_backprop(Gd._h, Gd._h, U._h, __import__("ctypes").c_double(rho)))
+    assert np.array_equal(Gd.download(), G.download())                # in place: the same bits
+    with pytest.raises(lq.LQCDError):
+        lq.STOUT_Layer(["plaquette", "rectangular"], [0.1, 0.05], U)
+
+
+def _universe_stout(lq, U, kappa, rhos):
+    ga, fa = rc._universe(lq, U, kappa, 5.7)
+    nn = lq.CovNeuralnet(U)                                           # universe.jl:150-171
+    for rho in rhos:
+        nn.push_(lq.STOUT_Layer(["plaquette"], [rho], U))
+    return ga, fa, nn
+
+
+def _md(lq, U, ga, fa, nn, dtau, steps, seed=0):
+    hmc = rc.StandardHMC(lq, U, ga, False, dtau, steps, fa, seed=seed)
+    hmc.md.cov_neural_net = nn
+    hmc.md.dSdU = U.similar()                                         # standardMD.jl:58: dSdU = similar(U)
+    return hmc
+
+
+@pytest.mark.parametrize("rhos", [(0.1,), (0.08, 0.12)])
+def test_fermion_force_through_the_smearing_is_the_derivative_of_the_action(lq, orc, rhos):
+    L = (4, 4, 4, 4)
+    Uh = orc.hot_gauge(L, 9)
+    lat = lq.Lattice(L)
+    U = lq.Gaugefields(lat).upload(Uh)
+    ga, fa, nn = _universe_stout(lq, U, 0.12, rhos)
+    fa.D.eps_CG = 1e-24
+    hmc = _md(lq, U, ga, fa, nn, 0.05, 1)
+    md = hmc.md
+    initialize_MD_stout_(U, md)
+    p0 = md.p.download()
+    P_update_fermion_stout_(U, md.p, 1.0, md)
+    dp = (md.p.download() - p0) / (-md.dtau)                          # = TA(U dS/dU) in the reference's sign (factor = -eps dtau)
+    rng = np.random.default_rng(10)
+
+    def S(V):
+        U2 = lq.Gaugefields(lat).upload(V)
+        Uout, _, _ = lq.calc_smearedU(U2, nn)
+        return lq.evaluate_FermiAction(fa, Uout, md.eta)
+
+    for _ in range(3):
+        idx = tuple(int(rng.integers(n)) for n in (4, L[3], L[2], L[1], L[0]))
+        T = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+        T = T + T.conj().T
+        T -= np.trace(T) / 3 * np.eye(3)
+        h, vals = 1e-4, []
+        for e in (h, -h):
+            V = Uh.copy()
+            V[idx] = V[idx] @ sla.expm(1j * e * T).T
+            vals.append(S(V))
+        fd = (vals[0] - vals[1]) / (2 * h)
+        # dS/d eps = -2 Im tr(T G) with G the C ABI's field = -(the reference's U dS/dU); dp = TA(reference field): for traceless Hermitian T, tr(T X) sees only TA(X)
+        an = 2.0 * np.imag(np.trace(T @ dp[idx].T))
+        assert abs(fd - an) < 5e-6 * max(1.0, abs(fd)), (fd, an)
+
+
+def test_hmc_with_stout_smeared_fermions_conserves_energy(lq, orc):
+    L = (4, 4, 4, 4)
+    Uh = orc.hot_gauge(L, 11)
+    dH = {}
+    for dtau, steps in ((0.02, 10), (0.01, 20)):
+        lat = lq.Lattice(L)
+        U = lq.Gaugefields(lat).upload(Uh)
+        ga, fa, nn = _universe_stout(lq, U, 0.12, (0.1,))
+        hmc = _md(lq, U, ga, fa, nn, dtau, steps, seed=3)
+        update_stout_(hmc, U)
+        dH[dtau] = hmc.dH[0]
+    assert abs(dH[0.02]) < 0.5 and abs(dH[0.01]) < 0.3 * abs(dH[0.02]) + 1e-3, dH      # second-order integrator: dH ~ dtau^2

@@ -34,7 +34,8 @@ BASE = {"Dict", "Tuple", "close", "eltype", "error", "exp", "length", "pwd", "ra
 # provided by the packages for any field type that satisfies the stated precondition (checked below)
 PACKAGE_GENERIC = {
     "GaugeAction": "Gaugefields' own constructor GaugeAction(U::Vector{<:AbstractGaugefields{NC,Dim}}): needs HIPLink <: AbstractGaugefields{3,4} and similar(::HIPLink)",
-    "push!": "push!(gauge_action, beta, loops) on the package's GaugeAction{4,HIPLink}",
+    "push!": "push!(gauge_action, beta, loops) on the package's GaugeAction{4,HIPLink}; push!(cov_neural_net, layer) on the package's CovNeuralnet with the binding's HIPStoutLayer <: CovLayer{4}",
+    "CovNeuralnet": "Gaugefields' own constructor CovNeuralnet(U): the container Univ's typed field holds (universe.jl:15); the layers in it are the binding's (STOUT_Layer dispatches on the links)",
     "make_loops_fromname": "Wilsonloop.jl, no field argument",
     "get_temporary_gaugefields": "accessor of the package's GaugeAction",
     "get_temp": "Temporalfields pool of the package's GaugeAction: allocates with similar(U[1])",
@@ -47,7 +48,9 @@ PACKAGE_GENERIC = {
 # generics the binding specialises: name -> list of accepted signatures (positional argument types as written in the binding)
 EXPECTED = {
     "exptU!": [["HIPLink", "Number", "HIPTALink", None]],
-    "mul!": [["HIPLink", "HIPLink", "HIPLink"]],
+    "mul!": [["HIPLink", "HIPLink", "HIPLink"], ["HIPLink", "HIPLinkAdjoint", "HIPLink"]],
+    "back_prop": [["Vector{HIPLink}", "CovNeuralnet{4}", None, "Vector{HIPLink}"]],
+    "STOUT_Layer": [[None, None, "Vector{HIPLink}"]],
     "substitute_U!": [["HIPLink", "HIPLink"], ["Vector{HIPLink}", "Vector{HIPLink}"]],
     "calc_dSdUμ!": [["HIPLink", "GaugeAction{4,HIPLink}", "Integer", "Vector{HIPLink}"]],
     "Traceless_antihermitian_add!": [["HIPTALink", "Number", "HIPLink"]],
@@ -55,7 +58,7 @@ EXPECTED = {
     "initialize_TA_Gaugefields": [["Vector{HIPLink}"]],
     "similar": [["Vector{HIPLink}"], ["HIPLink"], ["HIPFermion"]],
     "gauss_distribution!": [["Vector{HIPTALink}"]],
-    "calc_smearedU": [["Vector{HIPLink}", "Nothing"]],
+    "calc_smearedU": [["Vector{HIPLink}", "Nothing"], ["Vector{HIPLink}", "CovNeuralnet{4}"]],
     "gauss_sampling_in_action!": [["HIPFermion", "Vector{HIPLink}", "HIPFermiAction"]],
     "sample_pseudofermions!": [["HIPFermion", "Vector{HIPLink}", "HIPFermiAction", "HIPFermion"]],
     "evaluate_GaugeAction": [["GaugeAction{4,HIPLink}", "Vector{HIPLink}"]],
