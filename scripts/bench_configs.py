@@ -201,7 +201,34 @@ def main():
     lat.set_param("mixed_action_solver", 0)
     res.append({"config": "32^3x64 Wilson-clover (c_sw = 1) force evaluation calc_UdSfdU!, eps 1e-16", "two_evenodd_bicgstab_solves_ms": t_c1, "iterations": it_c1,
                 "cg_normal_equations_ms": t_c0, "cg_iterations": it_c0, "mixed_precision_cg_ms": t_cm0, "mixed_precision_evenodd_ms": t_cm1, "mixed_evenodd_fp32_iterations": it_cm1})
-    for o in (U, D, X, Y, G, p, eta):
+    # ---- beyond SURVEY 8: the stout layer of the fermion action's links and its back-propagation at 32^3x64; the Domainwall operator at 16^3x32 x L5 = 8
+    nn = lq.CovNeuralnet(U)
+    nn.push_(lq.STOUT_Layer(["plaquette"], [0.1], U))
+    t_sm = tk(lambda: lq.calc_smearedU(U, nn))
+    Uout, multi, _ = lq.calc_smearedU(U, nn)
+    dS = lq.Gaugefields(lat)
+    lq.gauss_distribution_(dS, 9)
+    t_bp = tk(lambda: lq.back_prop(dS, nn, multi, U))
+    res.append({"config": "32^3x64 stout layer (plaquette, rho 0.1) of the fermion action's links", "calc_smearedU_ms": t_sm, "back_prop_ms": t_bp,
+                "note": "smearing = staple sweep + exp; back_prop = 8 link products + staple sweep + Frechet-derivative pass + 24-loop gather"})
+    for o in (U, D, X, Y, G, p, eta, dS):
+        o.close()
+    L = (16, 16, 16, 32)
+    V5 = 16 ** 3 * 32
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    L5 = 8
+    x5 = lq.Initialize_pseudofermion_fields(U[1], "Domainwall", L5=L5)
+    D5 = lq.Dirac_operator(U, x5, {"Dirac_operator": "Domainwall", "mass": 0.05, "L5": L5, "M": -1.8, "eps_CG": 1e-16})
+    lq.gauss_distribution_fermion_(x5, 3)
+    y5 = x5.similar()
+    t_d5 = tk(lambda: lq.mul_(y5, D5, x5), reps=20)
+    z5 = x5.similar()
+    dt5, (it5, rr5) = timed(lambda: (lq.clear_fermion_(z5), lq.solve_DinvX_(z5, lq.DdagD_operator(D5), x5, return_info=True))[1], reps=2)
+    res.append({"config": "16^3x32 x L5 = 8 Domainwall (M = -1.8, m = 0.05): D5 application and CG on D5^+ D5 to 1e-16", "D5_ms": t_d5,
+                "D5_GBps_moved (L5 Wilson launches of 768 B/site + fifth-direction pass of ~1150 B per 5-d site)": L5 * V5 * (768 + 1150) / t_d5 / 1e6,
+                "cg_iters": it5, "cg_ms": 1e3 * dt5, "cg_final_rr": rr5})
+    for o in (U, D5, x5, y5, z5):
         o.close()
     # ---- configs[4] geometry on one GPU: 48^3x96 staggered Dslash and CG (fp64)
     L = (48, 48, 48, 96)

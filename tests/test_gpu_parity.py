@@ -417,7 +417,7 @@ def test_argument_errors(gpu):
     lat = lq.Lattice((4, 4, 4, 4))
     U = lq.Initialize_Gaugefields(3, 0, 4, 4, 4, 4, lattice=lat)
     with pytest.raises(lq.LQCDError):
-        lq.Dirac_operator(U, None, {"Dirac_operator": "Domainwall"})      # not on this path: raises like universe.jl:129-131
+        lq.Dirac_operator(U, None, {"Dirac_operator": "MobiusDomainwall"})      # not an operator of universe.jl:103-131: raises as its `else error("not supported")`
     D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson"})
     w, s = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.STAGGERED)
     with pytest.raises(lq.LQCDError):
