@@ -17,6 +17,8 @@
 //     force:      X = (D^+D)^-1 D_PV^+ phi, Y = D X:  dS = -2 Re[(Y - phi)^+ dD X]        (dD_PV = dD: only the 4-D hops carry links)
 //                 = the Wilson outer-product sweep (force.hip) of the pairs (X(s), Y(s) - phi(s)), summed over s.
 // With m = 1 (the reference's test) D = D_PV, S = phi^+ phi and the force vanishes identically -- the run is a quenched HMC with a spectator field.
+// Partitioned lattices (RCCL ranks): the slices go through the halo path of the Wilson operator as they are, the fifth direction is local to a site, the CG's
+// inner products are summed over ranks by the BLAS layer and the force sweep exchanges its faces per slice.
 #include "ops_internal.h"
 
 using namespace lqcd;
@@ -221,7 +223,7 @@ extern "C" int lqcd_spinor_slice(lqcd_spinor_t s5, int i5, lqcd_spinor_t* view) 
 // Dirac_operator(U, x, Dict("Dirac_operator" => "Domainwall", "mass" => m, "L5" => L5, "M" => M, ...)) (universe.jl:116-128, 137)
 extern "C" int lqcd_op_create_domainwall(lqcd_ctx_t ctx, lqcd_op_t* op, lqcd_gauge_t g, double M, double mass, int L5, const int bc[4]) {
     ARGCHK(ctx && op && g && bc && L5 >= 2, "lqcd_op_create_domainwall: need a context, a gauge field, boundary conditions and L5 >= 2");
-    ARGCHK(!any_partitioned(ctx), "lqcd_op_create_domainwall: one GPU only (the five-dimensional operator has no partitioned path yet)");
+    ARGCHK(ctx->local_peers.empty(), "lqcd_op_create_domainwall: not available on an in-process PE grid (RCCL ranks only)");
     lqcd_op_s* w = nullptr;
     LQCHK(lqcd_op_create(ctx, &w, LQCD_WILSON, g, 0.5, 1.0, bc));      // hop coefficient -1/2: D4 = (4 + M) - H/2
     lqcd_op_s* o = new lqcd_op_s;

@@ -151,3 +151,48 @@ def test_reference_test_case_pauli_villars_mass_is_a_spectator(lq, orc):
     assert np.abs(res[False][0] - res[True][0]).max() < 1e-8            # the same links as the quenched trajectory (same momenta seeds) ...
     assert np.abs(np.array(res[False][1]) - np.array(res[True][1])).max() < 1e-7      # ... and the same dH: the spectator's action does not move
     assert all(abs(d) < 0.5 for d in res[False][1])
+
+
+def test_rccl_self_partition_domainwall(lq, orc):
+    """The Domainwall operator on a partitioned lattice: LQCD_FORCE_PARTITION + a world-size-1 RCCL communicator run the halo path of the Wilson slices, the
+    rank-summed inner products of the CG and the face exchange of the force sweep exactly as at N > 1; operator, CG, action, heat bath and force equal the oracle."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        from oracle import oracle as orc
+        L, L5, M, MASS, BC = (8, 4, 6, 8), 3, -1.3, 0.2, (1, 1, 1, -1)
+        lat = lq.Lattice(L)
+        lat.comm_init(lq.comm_unique_id())
+        Uh = orc.hot_gauge(L, 111)
+        U = lq.Gaugefields(lat).upload(Uh)
+        x = lq.Initialize_pseudofermion_fields(U[1], "Domainwall", L5=L5)
+        D = lq.Dirac_operator(U, x, {"Dirac_operator": "Domainwall", "mass": MASS, "L5": L5, "M": M, "boundarycondition": BC, "eps_CG": 1e-20})
+        rng = np.random.default_rng(5)
+        shp = (L5,) + orc.wilson_shape(L)
+        ph = rng.standard_normal(shp) + 1j * rng.standard_normal(shp)
+        x.upload(ph)
+        y = x.similar()
+        rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+        for dag in (False, True):
+            lq.mul_(y, D.adjoint() if dag else D, x)
+            assert rel(y.download(), orc.domainwall_D(Uh, ph, L, M, MASS, BC, dagger=dag)) < 1e-13, dag
+        lq.clear_fermion_(y)                      # solve_DinvX! starts from what y holds
+        it, rr = lq.solve_DinvX_(y, lq.DdagD_operator(D), x, return_info=True)
+        xo, ito, _ = orc.domainwall_cg(Uh, ph, L, M, MASS, BC, eps=1e-20)
+        assert abs(it - ito) <= 2 and rel(y.download(), xo) < 1e-9
+        fa = lq.FermiAction(D, {})
+        S = lq.evaluate_FermiAction(fa, U, x)
+        So, _, _ = orc.domainwall_action(Uh, ph, L, M, MASS, BC, eps=1e-24)
+        assert abs(S - So) < 1e-9 * So
+        G = lq.Gaugefields(lat)
+        lq.calc_UdSfdU_(G, fa, U, x)
+        assert rel(G.download(), orc.domainwall_force(Uh, ph, L, M, MASS, BC, eps=1e-24)) < 1e-8
+        print("RCCL_SELF_DW_OK")
+    """)
+    for mask in ("8", "15"):
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "RCCL_SELF_DW_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
