@@ -17,6 +17,9 @@
 namespace lqcd {
 
 typedef cd m3[9];
+#ifndef LQCD_STAPLE_TWOROW
+#define LQCD_STAPLE_TWOROW 1    // ... and two-row products inside it (r04)
+#endif
 #ifndef LQCD_STAPLE_BURST
 #define LQCD_STAPLE_BURST 1     // two-row staple sweep: the five neighbour links of a plane in one load burst
 #endif
@@ -53,6 +56,40 @@ __device__ __forceinline__ void mm3_nd(cd (&C)[9], const cd (&A)[9], const cd (&
 __device__ __forceinline__ void mm3_dn(cd (&C)[9], const cd (&A)[9], const cd (&B)[9]) {
 #pragma unroll
     for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            cd t = mk(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) cfma_conj(t, A[k * 3 + a], B[k * 3 + b]);
+            C[a * 3 + b] = t;
+        }
+}
+// rows 0, 1 of C = A B / A B^+ / A^+ B (row 2 of C is left alone: a product of SU(3) matrices gets it from finish_u)
+__device__ __forceinline__ void mm2(cd (&C)[9], const cd (&A)[9], const cd (&B)[9]) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            cd t = mk(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) cfma(t, A[a * 3 + k], B[k * 3 + b]);
+            C[a * 3 + b] = t;
+        }
+}
+__device__ __forceinline__ void mm2_nd(cd (&C)[9], const cd (&A)[9], const cd (&B)[9]) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            cd t = mk(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) cfma_conj(t, B[b * 3 + k], A[a * 3 + k]);
+            C[a * 3 + b] = t;
+        }
+}
+__device__ __forceinline__ void mm2_dn(cd (&C)[9], const cd (&A)[9], const cd (&B)[9]) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) {
             cd t = mk(0.0, 0.0);
@@ -260,6 +297,22 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
         load_u_raw(l3, link_at(g, k.U, m, NU), Gs);                     // U_nu(m)
 #pragma unroll
         for (int e = 0; e < 9; e++) { const double2 t = own[NU][e][lane]; u3[e] = mk(t.x, t.y); }
+#if LQCD_STAPLE_TWOROW
+        // every staple is a product of SU(3) matrices: rows 0, 1 of each product (two thirds of the multiplications), row 2 rebuilt like a link's
+        finish_u(a2);
+        mm2_nd(t1, a1, a2);         // rows 0, 1 of a1 a2^+ need rows 0, 1 of a1 only
+        mm2_nd(t2, t1, u3);
+        finish_u(t2);
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+        finish_u(l1);
+        mm2(t1, l2, l1);            // Q = l2 l1, rows 0, 1
+        finish_u(t1); finish_u(l3);
+        mm2_dn(t2, t1, l3);         // rows 0, 1 of Q^+ l3 = l1^+ l2^+ l3
+        finish_u(t2);
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+#else
         finish_u(a1); finish_u(a2);
         mm3_nd(t1, a1, a2);
         mm3_nd(t2, t1, u3);
@@ -270,6 +323,7 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
         mm3(t2, t1, l3);
 #pragma unroll
         for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+#endif
         asm volatile("" : "+v"(c[0]), "+v"(A[0].re), "+v"(A[0].im), "+v"(A[4].re), "+v"(A[4].im), "+v"(A[8].re), "+v"(A[8].im));
     } else
     if constexpr (MU != NU) {
@@ -455,11 +509,12 @@ __global__ __launch_bounds__(256) void momentum_add_ta_kernel(Geom g, double2* _
     }
 }
 
-// exp(dt P).  Below max-abs-row-sum norm 0.2 of X = dt P (an MD step has a few 1e-2) the Taylor series is summed through the Cayley-Hamilton identity
+// exp(dt P).  Below max-abs-row-sum norm 2 of X = dt P (an MD step has a few 1e-2) the Taylor series is summed through the Cayley-Hamilton identity
 // X^3 = t X^2 - s X + d I (t = tr X, s = (t^2 - tr X^2)/2, d = det X; true for every 3x3 matrix, nothing assumed about P): X^n = al_n I + be_n X + ga_n X^2
 // with the scalar recurrence al' = d ga, be' = al - s ga, ga' = be + t ga, so exp X = a0 I + a1 X + a2 X^2 costs ONE matrix product and a dozen scalar
 // steps instead of a matrix product per term (r04: the link update inside the staple sweep is ALU time, 1.78 -> 1.63 ms already from a shorter series).
-// Terms: until nrm^(n+1)/(n+1)! < 1e-18, two more for the n^2 growth of the coefficients.  Norm >= 0.2: 24 terms in Horner form (exact to rounding up to norm 2).
+// Terms: until nrm^(n+1)/(n+1)! < 1e-18, two more for the n^2 growth of the coefficients (<= 6e-16 from scipy's expm up to norm 2, near-degenerate spectra included).
+// Norm >= 2: 24 terms in Horner form.
 #ifndef LQCD_EXP_CH
 #define LQCD_EXP_CH 1
 #endif
@@ -472,8 +527,8 @@ __device__ __forceinline__ void exp_m3(cd (&e)[9], cd (&x)[9], double dt) {     
     for (int a = 0; a < 3; a++)
         nrm = fmax(nrm, (fabs(x[a * 3].re) + fabs(x[a * 3].im)) + (fabs(x[a * 3 + 1].re) + fabs(x[a * 3 + 1].im)) + (fabs(x[a * 3 + 2].re) + fabs(x[a * 3 + 2].im)));
 #if LQCD_EXP_CH
-    if (nrm < 0.2) {
-        const int nt = (nrm < 0.009 ? 6 : nrm < 0.04 ? 8 : nrm < 0.11 ? 10 : 12) + 2;
+    if (nrm < 2.0) {
+        const int nt = (nrm < 0.009 ? 6 : nrm < 0.04 ? 8 : nrm < 0.11 ? 10 : nrm < 0.2 ? 12 : nrm < 0.5 ? 16 : nrm < 1.0 ? 20 : 28) + 2;
         mm3(t, x, x);
         const cd tr = x[0] + x[4] + x[8], tr2 = t[0] + t[4] + t[8], trtr = cmul(tr, tr);
         const cd s = mk(0.5 * (trtr.re - tr2.re), 0.5 * (trtr.im - tr2.im));
@@ -499,7 +554,7 @@ __device__ __forceinline__ void exp_m3(cd (&e)[9], cd (&x)[9], double dt) {     
 #endif
 #pragma unroll
     for (int k = 0; k < 9; k++) e[k] = mk((k % 4 == 0) ? 1.0 : 0.0, 0.0);
-    for (int n = nrm < 0.2 ? 12 : 24; n >= 1; n--) {
+    for (int n = nrm < 4.0 ? 36 : 60; n >= 1; n--) {
         mm3(t, x, e);
         const double inv = 1.0 / (double)n;
 #pragma unroll

@@ -70,10 +70,10 @@ case $stage in
     timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; python -c "import json; d=json.load(open('$out/bench.json')); print(d['value'], d['dslash_ms'], d['roofline']['frac'], d['gauge_recon18_all_reals_read']['dslash_ms'], d['reference_format_links'])"; tail -2 $out/bench.err
     ;;
   pu)         # momentum + link update as one sweep vs two passes
-    timeout 600 python -m pytest tests/test_gpu_md.py tests/test_gpu_reunit.py tests/test_gpu_reference_callers.py -q -x 2>&1 | tail -3
+    timeout 600 python -m pytest tests/test_gpu_md.py tests/test_gpu_reunit.py tests/test_gpu_reference_callers.py tests/test_gpu_stout.py -q -x 2>&1 | tail -3
     python scripts/pu_probe.py 0.005 2>&1 | tail -1 | tee $out/pu.log
     python scripts/pu_probe.py 0.05 2>&1 | tail -1 | tee -a $out/pu.log
-    if [ -f latticeqcd.jl_amd/csrc/liblqcd_hip_exp12.so ]; then LQCD_HIP_LIB=$PWD/latticeqcd.jl_amd/csrc/liblqcd_hip_exp12.so python scripts/pu_probe.py 0.005 2>&1 | tail -1 | sed 's/^/fixed 12 terms: /' | tee -a $out/pu.log; fi
+    if [ -f latticeqcd.jl_amd/csrc/liblqcd_hip_ab.so ]; then LQCD_HIP_LIB=$PWD/latticeqcd.jl_amd/csrc/liblqcd_hip_ab.so python scripts/pu_probe.py 0.005 2>&1 | tail -1 | sed 's/^/A-B build (LQCD_EXTRA_FLAGS of the day): /' | tee -a $out/pu.log; fi
     ;;
   forceprof)  # kernel stats of calc_UdSfdU! at 32^3x64, fp64 even-odd and mixed
     for m in 0 1; do
