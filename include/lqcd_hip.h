@@ -332,6 +332,9 @@ int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us, double be
  * src/updates/standardHMC.jl:67-68).  One STOUT layer with the plaquette loop, Morningstar-Peardon's definition [EXT-RECALL: Gaugefields.jl is not under the
  * reference tree]:  U'_mu(n) = exp(-rho TA(U_mu(n) A_mu(n))) U_mu(n), A = the six staples (those of lqcd_gauge_force).  Several layers = several calls,
  * back-propagated in reverse order with the links each layer started from.  Force fields in the convention of lqcd_fermion_force.  One GPU. */
+/* calculate_Polyakov_loop(U, temp1, temp2) (the Polyakov_loop measurement of every toml under test/; src/system/lqcd.jl:141 -> QCDMeasurements):
+ * 1/(NC NX NY NZ) sum_x tr prod_t U_4(x, t), summed over ranks; the time direction must not be partitioned */
+int lqcd_gauge_polyakov(lqcd_gauge_t U, double* re, double* im);
 int lqcd_link_mul_adj(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_gauge_t B, int mu_b);   /* mul!(C, A', B): C = A^+ B site by site (standardMD.jl:211) */
 int lqcd_stout_smear(lqcd_gauge_t out, lqcd_gauge_t U, double rho);                     /* out != U */
 int lqcd_stout_backprop(lqcd_gauge_t G, lqcd_gauge_t Gs, lqcd_gauge_t U, double rho);   /* G at the thin links U from Gs at the smeared links; G = Gs allowed */

@@ -31,7 +31,7 @@ import LinearAlgebra: mul!, dot
 import Base: similar, adjoint
 import Gaugefields: AbstractGaugefields, GaugeAction, Initialize_Gaugefields, substitute_U!, exptU!, Traceless_antihermitian_add!, calc_dSdUμ!,
     evaluate_GaugeAction, initialize_TA_Gaugefields, gauss_distribution!, calc_smearedU, println_verbose_level1,
-    println_verbose_level2, println_verbose_level3, get_myrank, calculate_Plaquette, load_BridgeText!, load_gaugefield!,
+    println_verbose_level2, println_verbose_level3, get_myrank, calculate_Plaquette, calculate_Polyakov_loop, load_BridgeText!, load_gaugefield!,
     CovNeuralnet, CovLayer, STOUT_Layer, back_prop
 import LatticeDiracOperators: Dirac_operator, DdagD_operator, FermiAction, Initialize_pseudofermion_fields,
     gauss_sampling_in_action!, sample_pseudofermions!, evaluate_FermiAction, calc_UdSfdU!, solve_DinvX!, shiftedcg,
@@ -281,6 +281,12 @@ function calculate_Plaquette(U::Vector{HIPLink})
 end
 # every link back onto SU(3): once per trajectory keeps the 12-real Dslash path alive when the links are updated through the per-direction
 # entry points (the fused lqcd_gauge_exp_update does it in the same pass)
+# calculate_Polyakov_loop(U, temp1, temp2): the second observable of every trajectory of the reference's runs (Polyakov_loop in test/*.toml)
+function calculate_Polyakov_loop(U::Vector{HIPLink}, temps...)
+    re, im_ = Ref{Float64}(0), Ref{Float64}(0)
+    check(ccall((:lqcd_gauge_polyakov, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}), whole(U).h, re, im_))
+    return complex(re[], im_[])
+end
 reunitarize!(U::Vector{HIPLink}) = check(ccall((:lqcd_gauge_reunitarize, LIB), Cint, (Ptr{Cvoid},), whole(U).h))
 
 # substitute_U!(Uold, U) / substitute_U!(U, Uold) (standardHMC.jl:45,84) and substitute_U!(U[mu], W) (AbstractMD.jl:93)

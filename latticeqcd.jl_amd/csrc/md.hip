@@ -1570,3 +1570,56 @@ extern "C" int lqcd_stout_backprop(lqcd_gauge_t G, lqcd_gauge_t Gs, lqcd_gauge_t
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;
 }
+
+// ---------------------------------------------------------------------------------- Polyakov loop
+// The second observable every trajectory of the reference's driver measures (measurement_methods Plaquette + Polyakov_loop in every test/*.toml;
+// src/system/lqcd.jl:141 -> QCDMeasurements' Polyakov_measurement -> Gaugefields' calculate_Polyakov_loop(U, temp1, temp2)):
+//     P = 1/(NC NX NY NZ) sum_x tr prod_{t = 0}^{NT-1} U_4(x, t)        [normalisation EXT-RECALL: the package's, as this file's author knows it]
+// One thread per spatial site walks the time direction (links carry no boundary sign).  The time direction must not be partitioned.
+namespace lqcd {
+__global__ __launch_bounds__(256) void polyakov_kernel(Geom g, const double2* __restrict__ U, double* __restrict__ partial) {
+    const int V3 = g.L[0] * g.L[1] * g.L[2];
+    const int s3 = blockIdx.x * 256 + threadIdx.x;
+    double re = 0.0, im = 0.0;
+    if (s3 < V3) {
+        int c[4] = {s3 % g.L[0], (s3 / g.L[0]) % g.L[1], s3 / (g.L[0] * g.L[1]), 0};
+        const int Gs = glink_stride(g);
+        cd acc[9], u[9], t[9];
+        load_m3(acc, link_at(g, U, c, 3), Gs);
+        for (c[3] = 1; c[3] < g.L[3]; c[3]++) {
+            load_m3(u, link_at(g, U, c, 3), Gs);
+            mm3(t, acc, u);
+#pragma unroll
+            for (int e = 0; e < 9; e++) acc[e] = t[e];
+        }
+        re = acc[0].re + acc[4].re + acc[8].re;
+        im = acc[0].im + acc[4].im + acc[8].im;
+    }
+    __shared__ double sh[2][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { re += __shfl_down(re, off, 64); im += __shfl_down(im, off, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = re; sh[1][threadIdx.x >> 6] = im; }
+    __syncthreads();
+    if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+}  // namespace lqcd
+
+extern "C" int lqcd_gauge_polyakov(lqcd_gauge_t U, double* re, double* im) {
+    LQCHK(lqcd::links_flush_of(U));
+    ARGCHK(U && re && im, "lqcd_gauge_polyakov: null argument");
+    lqcd_ctx_s* c = U->ctx;
+    ARGCHK(!c->geom.part[3], "lqcd_gauge_polyakov: the time direction is partitioned (the loop would cross ranks)");
+    ARGCHK(c->local_peers.empty(), "lqcd_gauge_polyakov: not available on an in-process PE grid");
+    HIPCHK(hipSetDevice(c->device));
+    const int V3 = c->geom.L[0] * c->geom.L[1] * c->geom.L[2], nb = (V3 + 255) / 256;
+    ARGCHK(nb <= MAX_PARTIAL_BLOCKS, "lqcd_gauge_polyakov: partial buffer too small");
+    hipLaunchKernelGGL(polyakov_kernel, dim3(nb), dim3(256), 0, c->stream, c->geom, U->data, c->d_partial);
+    HIPCHK(hipGetLastError());
+    LQCHK(reduce_to_slot(c, nb, 2, S_RED0, true, 0));
+    HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double norm = 1.0 / (3.0 * (double)c->gL[0] * (double)c->gL[1] * (double)c->gL[2]);
+    *re = norm * c->h_scal[0];
+    *im = norm * c->h_scal[1];
+    return LQCD_OK;
+}

@@ -229,6 +229,13 @@ def calculate_Plaquette(U):
     return p.value
 
 
+def calculate_Polyakov_loop(U, temp1=None, temp2=None):
+    """calculate_Polyakov_loop(U, temp1, temp2) (the Polyakov_loop measurement of the reference's runs): 1/(NC NX NY NZ) sum_x tr prod_t U_4(x, t)."""
+    re, im = C.c_double(0), C.c_double(0)
+    check(_l.lib().lqcd_gauge_polyakov(U._h, C.byref(re), C.byref(im)))
+    return complex(re.value, im.value)
+
+
 def reunitarize_(U):
     """Every link back onto SU(3) (lqcd_gauge_reunitarize; no reference counterpart)."""
     check(_l.lib().lqcd_gauge_reunitarize(U._h))

@@ -509,3 +509,12 @@ def stout_backprop(Gs, U, L, rho):
                 - _dag(d2) @ Na2 @ a2 @ b2 @ _dag(cc) - _dag(d2) @ a2 @ Nb2 @ b2 @ _dag(cc)
         G[mu] += 0.5 * c0 * acc
     return np.ascontiguousarray(_mat(G))
+
+
+def polyakov_loop(U, L):
+    """1/(NC NX NY NZ) sum_x tr prod_t U_4(x, t) (calculate_Polyakov_loop of the reference's Polyakov_loop measurement; periodic links)."""
+    Ut = _mat(U)[3]                      # [t, z, y, x, a, b]
+    acc = Ut[0]
+    for t in range(1, L[3]):
+        acc = acc @ Ut[t]
+    return complex(np.trace(acc, axis1=-2, axis2=-1).sum() / (3.0 * L[0] * L[1] * L[2]))

@@ -227,3 +227,29 @@ def test_hmc_repeats_the_reference_quenched_su3_test_on_device(gpu, orc):
     assert abs(plaq - ref_plaq) / ref_plaq < 0.1
     assert acc >= 6 and np.abs(dHs).max() < 2.0 and abs(plaq - start) > 1e-6
     assert orc.unitarity_dev(U.download(), L) < 1e-9
+
+
+def test_polyakov_loop(lq, orc):
+    """The second observable of every trajectory of the reference's runs (Polyakov_loop in every toml under test/): 1/(NC NX NY NZ) sum_x tr prod_t U_4(x, t).
+    Cold links give 1; a hot configuration and the reference's own 4^4 Wilson fixture against the numpy restatement; a centre transformation of one
+    time slice multiplies the loop by exp(2 pi i / 3) and leaves the plaquette alone."""
+    import os
+    from conftest import GOLDEN
+    L = (4, 6, 4, 8)
+    lat = lq.Lattice(L)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="cold", lattice=lat)
+    assert abs(lq.calculate_Polyakov_loop(U) - 1.0) < 1e-15
+    Uh = orc.hot_gauge(L, 17)
+    U.upload(Uh)
+    p = lq.calculate_Polyakov_loop(U)
+    assert abs(p - orc.polyakov_loop(Uh, L)) < 1e-14
+    z = np.exp(2j * np.pi / 3)
+    Uz = Uh.copy()
+    Uz[3, 5] *= z                                   # every time-like link of the slice t = 5
+    U.upload(Uz)
+    assert abs(lq.calculate_Polyakov_loop(U) - z * p) < 1e-14
+    assert abs(lq.calculate_Plaquette(U) - orc.plaquette(Uh, L)) < 1e-14
+    L4 = (4, 4, 4, 4)
+    Uf = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L4)
+    U4 = lq.Gaugefields(lq.Lattice(L4)).upload(Uf)
+    assert abs(lq.calculate_Polyakov_loop(U4) - orc.polyakov_loop(Uf, L4)) < 1e-14
