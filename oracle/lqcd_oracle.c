@@ -756,6 +756,7 @@ void orc_gauge_force(double* Gd, const double* Ud, const int L[4], double beta) 
     const cplx* U = (const cplx*)Ud;
     cplx* G = (cplx*)Gd;
     long V = vol(L);
+#pragma omp parallel for collapse(2)       /* same arithmetic per link whatever the thread count */
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
             for (int y = 0; y < L[1]; y++)
@@ -779,6 +780,7 @@ void orc_momentum_add_ta(double* Pd, double cf, const double* Gd, const int L[4]
     const cplx* G = (const cplx*)Gd;
     long V = vol(L);
     for (int mu = 0; mu < 4; mu++)
+#pragma omp parallel for
         for (long s = 0; s < V; s++) {
             cplx M[3][3], tr = 0;
             for (int a = 0; a < 3; a++)
@@ -808,6 +810,7 @@ void orc_link_update(double* Ud, const double* Pd, double dt, const int L[4]) {
     const cplx* P = (const cplx*)Pd;
     long V = vol(L);
     for (int mu = 0; mu < 4; mu++)
+#pragma omp parallel for
         for (long s = 0; s < V; s++) {
             cplx X[3][3], E[3][3], T[3][3], Um[3][3];
             for (int a = 0; a < 3; a++)

@@ -302,3 +302,33 @@ def test_action_solve_32x32x32x64_evenodd_route_against_cg_and_oracle_residual(l
     for mode in (1, 0):
         res = etah - orc.wilson_D(Uh, orc.wilson_D(Uh, out[mode][2], L, KAPPA, 1.0, BC), L, KAPPA, 1.0, BC, dagger=True)
         assert np.vdot(res, res).real < (eps if mode == 1 else 2 * eps), (mode, np.vdot(res, res).real)
+
+
+def test_momentum_and_link_update_match_oracle_32x32x32x64(lq, orc_all_threads):
+    """The gauge legs of an MD step at configs[3]'s size against the oracle: P_update! and U_update! as the library runs them by default (the momentum update and
+    the link update behind it in ONE sweep into the second link buffer, lazy_merge = 2; Cayley-Hamilton series for exp) and as two separate passes."""
+    orc = orc_all_threads
+    L = (32, 32, 32, 64)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    p = lq.initialize_TA_Gaugefields(U)
+    lq.gauss_distribution_(p, 5)
+    Ph = p.download()
+    beta, eps, dt = 5.7, -0.013, 0.021
+    Pref = orc.momentum_add_ta(Ph.copy(), eps, orc.gauge_force(Uh, L, beta), L)
+    Uref = orc.link_update(Uh.copy(), Pref, dt, L)
+    for merge in (2, 0):
+        lat.set_param("lazy_merge", merge)
+        lat.set_param("md_reunitarize", 0)          # the oracle's update is the literal one
+        U.upload(Uh); p.upload(Ph)
+        lq.P_update_(U, p, eps, beta)
+        lq.U_update_(U, p, dt)
+        assert lat.get_param("lazy_deferred") == (8 if merge else 0)
+        assert rel_err(U.download(), Uref) < 1e-13, merge
+        assert rel_err(p.download(), Pref) < 1e-13, merge
+    lat.set_param("md_reunitarize", 1)
+    U.upload(Uh); p.upload(Ph)
+    lq.P_update_(U, p, eps, beta)
+    lq.U_update_(U, p, dt)
+    assert rel_err(U.download(), Uref) < 1e-12 and lq.unitarity_deviation(U) == 0.0       # projected in the same sweep: within rounding of the literal update
