@@ -629,6 +629,7 @@ void orc_wilson_force(double* Gd, const double* Ud, const double* Xd, const doub
     long V = vol(L);
     cplx Gm[4][4][4];
     for (int nu = 0; nu < 4; nu++) gamma_mat(nu, Gm[nu]);
+#pragma omp parallel for collapse(2)
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
             for (int y = 0; y < L[1]; y++)
@@ -673,6 +674,7 @@ void orc_staggered_force(double* Gd, const double* Ud, const double* Xd, const d
     const cplx *U = (const cplx*)Ud, *X = (const cplx*)Xd, *Y = (const cplx*)Yd;
     cplx* G = (cplx*)Gd;
     long V = vol(L);
+#pragma omp parallel for collapse(2)
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
             for (int y = 0; y < L[1]; y++)

@@ -332,3 +332,22 @@ def test_momentum_and_link_update_match_oracle_32x32x32x64(lq, orc_all_threads):
     lq.P_update_(U, p, eps, beta)
     lq.U_update_(U, p, dt)
     assert rel_err(U.download(), Uref) < 1e-12 and lq.unitarity_deviation(U) == 0.0       # projected in the same sweep: within rounding of the literal update
+
+
+def test_fermion_force_sweeps_match_oracle_at_baseline_sizes(lq, orc_all_threads):
+    """The outer-product sweep of calc_UdSfdU! at configs[3]'s and configs[4]'s sizes against the oracle (Wilson 32^3x64, staggered 48^3x96), given fields X, Y."""
+    orc = orc_all_threads
+    for L, kind, name, km in (((32, 32, 32, 64), lq.WILSON, "Wilson", KAPPA), ((48, 48, 48, 96), lq.STAGGERED, "Staggered", 0.05)):
+        U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+        lat = U.lattice
+        Uh = U.download()
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": name, "κ": km, "mass": km, "r": 1.0, "boundarycondition": BC})
+        X, Y = lq.Fermionfields(lat, kind), lq.Fermionfields(lat, kind)
+        lq.gauss_distribution_fermion_(X, 7)
+        lq.gauss_distribution_fermion_(Y, 8)
+        G = lq.Gaugefields(lat)
+        lq.fermion_force_(G, D, X, Y)
+        ref = orc.fermion_force(orc.WILSON if kind == lq.WILSON else orc.STAGGERED, Uh, X.download(), Y.download(), L, km, 1.0, BC)
+        assert rel_err(G.download(), ref) < 1e-13, name
+        for o in (G, X, Y, D, U):
+            o.close()
