@@ -95,6 +95,20 @@ PY
   stout)      # stout smearing layer, back-propagation, the callers' CovNeuralnet path
     timeout 900 python -m pytest tests/test_gpu_stout.py -q -x --durations=6 2>&1 | tail -25 | tee $out/pytest.log
     ;;
+  mdprof)     # kernel stats of the MD step (one-sweep momentum + link update), the stout layer and the Domainwall operator
+    for m in 0 1; do
+      (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof$m -o p -- python $GRAFT_REPO_ROOT/scripts/md_probe.py $m 2>&1 | grep "MD step")
+      f=$(find $out/prof$m -name "*kernel_stats.csv" | head -1); cp "$f" $out/kernel_stats_mixed$m.csv
+      python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel ms", tot / 1e6)
+for r in rows[:26]:
+    print("%-100s %6s calls %9.3f ms avg %8.1f us %5.1f%%" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+PY
+    done
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

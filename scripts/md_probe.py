@@ -1,0 +1,55 @@
+"""A few Sexton-Weingarten MD steps (runMD_QPQ_sw!, standardMD.jl:146-166) of the 2-flavour Wilson HMC at 32^3x64, one stout layer forward / backward and a few
+Domainwall applications at 16^3x32 x 8 -- for rocprofv3 --kernel-trace --stats (gpurun helper).  usage: md_probe.py [mixed 0|1]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import latticeqcd_jl_amd as lq
+
+mixed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+L = (32, 32, 32, 64)
+U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+lat = U.lattice
+D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.141139, "eps_CG": 1e-16})
+fa = lq.FermiAction(D)
+eta = lq.Fermionfields(lat, lq.WILSON)
+X = eta.similar()
+lq.gauss_distribution_fermion_(X, 5)
+lq.sample_pseudofermions_(eta, U, fa, X)
+G = lq.Gaugefields(lat)
+p = lq.initialize_TA_Gaugefields(U)
+lq.gauss_distribution_(p, 7)
+lat.set_param("mixed_action_solver", mixed)
+nsw, beta = 10, 5.7
+
+
+def md_step():
+    for half in range(2):
+        for _ in range(nsw // 2):
+            lq.U_update_(U, p, 0.5e-9)
+            lq.P_update_(U, p, 1e-9, beta)
+            lq.U_update_(U, p, 0.5e-9)
+        if half == 0:
+            lq.calc_UdSfdU_(G, fa, U, eta)
+            lq.Traceless_antihermitian_add_(p, 1e-9, G)
+
+
+md_step(); lq.calculate_Plaquette(U)
+t0 = time.perf_counter()
+for _ in range(3):
+    md_step()
+lq.calculate_Plaquette(U)
+print("mixed", mixed, "MD step ms", 1e3 * (time.perf_counter() - t0) / 3)
+nn = lq.CovNeuralnet(U)
+nn.push_(lq.STOUT_Layer(["plaquette"], [0.1], U))
+for _ in range(3):
+    Uout, multi, _ = lq.calc_smearedU(U, nn)
+    lq.back_prop(G, nn, multi, U)
+for o in (eta, X, G, p, D, U):
+    o.close()
+L = (16, 16, 16, 32)
+U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+x5 = lq.Initialize_pseudofermion_fields(U[1], "Domainwall", L5=8)
+D5 = lq.Dirac_operator(U, x5, {"Dirac_operator": "Domainwall", "mass": 0.05, "L5": 8, "M": -1.8})
+lq.gauss_distribution_fermion_(x5, 3)
+y5 = x5.similar()
+for _ in range(10):
+    lq.mul_(y5, D5, x5)
