@@ -109,6 +109,15 @@ for r in rows[:26]:
 PY
     done
     ;;
+  stapleab)   # A/B builds and map settings of the staple sweep (P_update! / one-sweep momentum + link update)
+    for lib in "" _ab_OCC1 _ab_OCC3 _ab_BURST0; do
+      f=$PWD/latticeqcd.jl_amd/csrc/liblqcd_hip$lib.so; [ -f $f ] || continue
+      LQCD_HIP_LIB=$f python scripts/pu_probe.py 0.005 2>&1 | tail -1 | sed "s/^/lib$lib: /" | tee -a $out/stapleab.log
+    done
+    for set in "md_remap=0" "xcd_nsub=8" "xcd_nsub=32" "xcd_ysplit=2" "xcd_ysplit=8" "staple_recon=0"; do
+      python scripts/pu_probe.py 0.005 $set 2>&1 | tail -1 | tee -a $out/stapleab.log
+    done
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

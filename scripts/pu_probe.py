@@ -4,10 +4,13 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import latticeqcd_jl_amd as lq
 
-dt = float(sys.argv[1]) if len(sys.argv) > 1 else 0.005
+dt = float(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 0.005
+sets = [a.split("=") for a in sys.argv[1:] if "=" in a]          # library tunables key=value
 L = (32, 32, 32, 64)
 U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
 lat = U.lattice
+for k, v in sets:
+    lat.set_param(k, int(v))
 p = lq.initialize_TA_Gaugefields(U)
 lq.gauss_distribution_(p, 7)
 beta = 5.7
@@ -32,4 +35,4 @@ res["U_update"] = tk(lambda: lq.U_update_(U, p, dt * 1e-3) if False else lq.U_up
 res["P_then_U_separate"] = tk(lambda: (lq.P_update_(U, p, 1e-9, beta), lq.U_update_(U, p, dt)))
 lat.set_param("lazy_merge", 2)
 res["P_then_U_one_sweep"] = tk(lambda: (lq.P_update_(U, p, 1e-9, beta), lq.U_update_(U, p, dt)))
-print({k: round(v, 4) for k, v in res.items()}, "dt", dt, "unitarity", lq.unitarity_deviation(U))
+print({k: round(v, 4) for k, v in res.items()}, "dt", dt, "sets", sets, "unitarity", lq.unitarity_deviation(U))
