@@ -118,6 +118,23 @@ PY
       python scripts/pu_probe.py 0.005 $set 2>&1 | tail -1 | tee -a $out/stapleab.log
     done
     ;;
+  mappmc)     # fabric read traffic (FETCH_SIZE) and time of the default Dslash under workgroup-map settings
+    for set in "xcd_nsub=16 xcd_ysplit=4" "xcd_nsub=8 xcd_ysplit=2" "xcd_nsub=8 xcd_ysplit=4" "xcd_nsub=16 xcd_ysplit=2" "xcd_nsub=4 xcd_ysplit=2" "xcd_nsub=32 xcd_ysplit=4"; do
+      args=""; for kv in $set; do args="$args --set $kv"; done
+      t=$(python scripts/dslash_probe.py --reps 200 --warm 20 $args 2>&1 | tail -1)
+      (cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc -o p -- python $GRAFT_REPO_ROOT/scripts/dslash_probe.py --reps 5 --warm 1 $args > /dev/null 2>&1)
+      f=$(find $out/pmc -name "*counter_collection.csv" | head -1)
+      python - "$f" "$set" "$t" <<'PY' | tee -a $out/mappmc.log
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "wilson_dirsplit" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+v = [float(r["Counter_Value"]) for r in rows]
+fetch = sum(v) / len(v)
+tot = (2 * fetch + 393216.0) * 1024
+print("%-28s FETCH_SIZE %.4e KiB -> traffic %.3f GB = %.3f x 768 B/site | %s" % (sys.argv[2], fetch, tot / 1e9, tot / (768 * 2097152), sys.argv[3][:160]))
+PY
+      rm -rf $out/pmc
+    done
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log
