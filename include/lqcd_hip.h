@@ -188,7 +188,8 @@ int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g);   /* the D(U) rebind idiom 
  * Fields are five-dimensional (lqcd_spinor_create_5d; lqcd_spinor_slice hands out the reference's x.w[i5] as Wilson fields that alias the slices: upload,
  * download and fills go through them, BLAS-1 takes the whole field).  Served for this operator: lqcd_op_apply, lqcd_op_apply_DdagD, lqcd_solve_cg_DdagD
  * and the pseudofermion action -- S = phi^+ D_PV (D^+D)^-1 D_PV^+ phi with the Pauli-Villars operator D_PV = D5(m = 1) -- through lqcd_action_* (heat
- * bath, action, force).  RCCL ranks as the Wilson operator (no in-process PE grid); every other entry point answers LQCD_ERR_UNSUPPORTED. */
+ * bath, action, force).  Tunable dw_batched (1 [default]: an application is one launch over all slices where the scalar-addressing Wilson kernel applies; read-only
+ * dw_active).  RCCL ranks as the Wilson operator (no in-process PE grid); every other entry point answers LQCD_ERR_UNSUPPORTED. */
 int lqcd_op_create_domainwall(lqcd_ctx_t ctx, lqcd_op_t* op, lqcd_gauge_t g, double M, double mass, int L5, const int bc[4]);
 int lqcd_spinor_create_5d(lqcd_ctx_t ctx, lqcd_spinor_t* s, int L5);      /* Initialize_pseudofermion_fields(U[1], "Domainwall", L5 = L5) (universe.jl:128) */
 int lqcd_spinor_slice(lqcd_spinor_t s5, int i5, lqcd_spinor_t* view);     /* 0-based; the view owns nothing and must not be used after its parent is destroyed */

@@ -303,6 +303,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "pipe_min_chunks")) return &c->tun.pipe_min_chunks;
     if (!strcmp(key, "lazy_links")) return &c->tun.lazy_links;
     if (!strcmp(key, "lazy_merge")) return &c->tun.lazy_merge;
+    if (!strcmp(key, "dw_batched")) return &c->tun.dw_batched;
     if (!strcmp(key, "bicg_fused")) return &c->tun.bicg_fused;
     if (!strcmp(key, "gauge_delta")) return &c->tun.gauge_delta;
     if (!strcmp(key, "dslash_s18")) return &c->tun.dslash_s18;
@@ -322,6 +323,7 @@ extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
 extern "C" int lqcd_ctx_get_param(lqcd_ctx_t c, const char* key, int* value) {
     ARGCHK(c && key && value, "lqcd_ctx_get_param: null");
     // read-only views of the recorded link operations (md.hip): the open triple (0 none, 1 exp, 2 exp + mul, 3 staple, 4 staple + mul), deferred triples
+    if (!strcmp(key, "dw_active")) { *value = c->tun.dw_active; return LQCD_OK; }
     if (!strcmp(key, "lazy_open")) { *value = c->lazy.kind; return LQCD_OK; }
     if (!strcmp(key, "lazy_deferred")) { *value = (int)c->lazy.done.size() + (c->lazy.has_pend ? 4 : 0) + (c->lazy.has_pp ? 4 : 0); return LQCD_OK; }
     int* p = param_ptr(c, key);

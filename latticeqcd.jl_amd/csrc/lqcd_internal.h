@@ -430,6 +430,9 @@ struct Tunables {
     int lazy_links = 1;       // the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,
                               // lqcd_link_staple -> lqcd_link_mul -> lqcd_link_add_ta) are recorded and run as ONE fused launch each, four completed triples of one
                               // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel
+    int dw_batched = 1;       // Domainwall operator: the L5 slices of an application as one launch of the scalar-addressing Wilson kernel with the fifth-direction hops in its
+                              // epilogue (where that kernel applies: fp64, one GPU, z-planes of whole chunks); 0: L5 Wilson launches + one fifth-direction pass
+    int dw_active = 0;        // read-only: the last Domainwall application ran as one five-dimensional launch
     int lazy_merge = 2;       // (with lazy_links) a complete link update U <- exp(a P) U waits; the next one of the same U, P with nothing in between that reads U or
                               // writes P adds its step: exp(b P) exp(a P) = exp((a + b) P), one pass instead of two (the back-to-back half steps of
                               // runMD_QPQ_sw!, standardMD.jl:146-166: 11 link passes per MD step instead of 20); lqcd_gauge_exp_update takes part.  2 (default; one GPU): a complete
@@ -660,6 +663,11 @@ struct StencilCall {
     const double2* dot_z[2] = {nullptr, nullptr};
     double* dot_partial = nullptr;
     int dot_conj = 0;             // 1: <out, z> (the imaginary part changes sign)
+    // Domainwall (domainwall.hip): the L5 slices of a five-dimensional field in ONE launch of the scalar-addressing kernel -- in / xin / out point at slice 0, slice s5 is
+    // dw_slice elements further on -- with the fifth-direction hops -P_A psi(s+1) - P_B psi(s-1) (mass term at the walls) added in the epilogue
+    int dw_ls = 0;
+    size_t dw_slice = 0;
+    double dw_mass = 0.0;
     int clover_on_hop = 0;        // 1 (fp64 direction-split kernel, r = 1): `clover` holds packed blocks that are applied to the HOP SUM, out = a xin + b C (H in) -- the
                                   // inverse clover blocks of the even-odd Wilson-clover solver; the diagonal term stays plain
 };
@@ -711,6 +719,7 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
 bool any_partitioned(lqcd_ctx_s* c);
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec = 0, bool clover = false);
+bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s);      // a StencilCall with dw_ls > 1 can run (stencil.hip)
 bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, bool clover);   // the persistent kernel runs for this call (large lattices only)
 // the operator's full-lattice applications carry the packed clover blocks into the stencil (make_full_call's rule)
 inline bool op_fused_clover(const lqcd_op_s* op) {

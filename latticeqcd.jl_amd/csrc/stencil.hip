@@ -332,6 +332,11 @@ struct PipeArgs {
     const real2* dotz[2];     // dot mode of the scalar-addressing kernel (StencilCall::dot_z, see KArgs)
     double* dot_partial;
     int dot_conj;
+    // DW5 instance (Domainwall operator): L5 slices per launch, block b -> (virtual block, slice) with the XCD of b kept (see wilson_dirsplit_s)
+    int ls;
+    unsigned long long slice_bytes;      // bytes between the same parity block of consecutive slices
+    FastDiv d_ls;
+    real dw_mass;
 };
 
 // next virtual block for this workgroup: from queue q (virtual blocks 8 j + q, j = 0 .. nvirt/8 - 1, handed out in order), moving on to the
@@ -423,6 +428,8 @@ __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
     return s;
 }
 
+template <typename T>
+__device__ inline const real2* boff64(const T* base, unsigned long long bytes) { return reinterpret_cast<const real2*>(reinterpret_cast<const char*>(base) + bytes); }
 template <typename T>
 __device__ inline const real2* boff(const T* base, unsigned bytes) { return reinterpret_cast<const real2*>(reinterpret_cast<const char*>(base) + bytes); }
 
@@ -654,8 +661,25 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
 // load, no branch around a load.  Per launch -20 % VALU and -42 % SALU instructions than variant 1 (profiles/r03_pmc_pipe_static.csv), i.e. a
 // shorter way from dispatch to the first load.  Same operations in the same order per site, same |.|^2 partial per workgroup: bit-identical to
 // variant 1 including the CG iterates.
-template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false>
-__device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim) {
+template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false>
+__device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim) {
+    // DW5: this workgroup's slice s5 of the five-dimensional fields; block ids keep their XCD (b & 7) and the L5 slices of a chunk follow each other on it, so the
+    // links of the chunk are fetched from the fabric once and hit the XCD's L2 for the other slices
+    int vblock = (int)blockIdx.x, s5 = 0;
+    if constexpr (DW5) {
+        const int g8 = (int)(blockIdx.x >> 3), gq = fdiv_nb(g8, a_.d_ls);
+        s5 = g8 - gq * a_.ls;
+        vblock = gq * 8 + (int)(blockIdx.x & 7);
+    }
+    PipeArgs a5;
+    if constexpr (DW5) {
+        a5 = a_;
+        const unsigned long long off = (unsigned long long)s5 * a_.slice_bytes;
+        a5.in[0] = boff64(a_.in[0], off); a5.in[1] = boff64(a_.in[1], off);
+        a5.xin[0] = boff64(a_.xin[0], off); a5.xin[1] = boff64(a_.xin[1], off);
+        a5.dst[0] = const_cast<real2*>(boff64(a_.dst[0], off)); a5.dst[1] = const_cast<real2*>(boff64(a_.dst[1], off));
+    }
+    const PipeArgs& a = DW5 ? a5 : a_;      // (every other instance reads the kernel arguments where they are)
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;
     constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;
@@ -667,7 +691,7 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     constexpr bool LATE_R = DELTA || !R12;            // fp64: the instances that would spill at 3 waves per SIMD with the old r held across the hops
 #endif
     const size_t gpar = (size_t)a.nch * 4 * NL * 64;
-    const PipeSite s = pipe_site<MU, NL>(a, blockIdx.x, lane);
+    const PipeSite s = pipe_site<MU, NL>(a, vblock, lane);
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     const bool z_is_x = DOT && (s.p ? a.dotz[1] == a.xin[1] : a.dotz[0] == a.xin[0]) && a.a != real(0.0);
     if constexpr (DOT) {        // dot mode: z takes the registers the old r has in update mode (requested ahead of the hops, scalar base + lane offset)
@@ -768,6 +792,22 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
     }
+    cd w5[DW5 ? 3 : 1];
+    if constexpr (DW5) {      // fifth-direction hops of this wave's three components: -P_A psi(s+1) - P_B psi(s-1), the mass term at the walls; P_-+ psi = (psi -+ g5 psi)/2
+                              // and (g5 psi)_spin = -psi_(spin xor 2): the partner component is six further on or back.  Issued here: the LDS exchange and the barrier cover them
+        const int su = s5 + 1 < a_.ls ? s5 + 1 : 0, sd = s5 >= 1 ? s5 - 1 : a_.ls - 1;
+        const real cu = real(0.5) * (s5 + 1 < a_.ls ? real(-1.0) : a_.dw_mass), cd_ = real(0.5) * (s5 >= 1 ? real(-1.0) : a_.dw_mass);
+        constexpr real sa = DAG ? real(-1.0) : real(1.0);
+        const real2* pu = boff(boff64(s.p ? a_.xin[1] : a_.xin[0], (unsigned long long)su * a_.slice_bytes), s.own);
+        const real2* pd = boff(boff64(s.p ? a_.xin[1] : a_.xin[0], (unsigned long long)sd * a_.slice_bytes), s.own);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int j = 3 * MU + cc, jp = MU < 2 ? j + 6 : j - 6;
+            const cd u0 = ld(pu + co12(j)), u1 = ld(pu + co12(jp)), d0 = ld(pd + co12(j)), d1 = ld(pd + co12(jp));
+            w5[cc] = mk(cu * (u0.re + sa * u1.re) + cd_ * (d0.re - sa * d1.re), cu * (u0.im + sa * u1.im) + cd_ * (d0.im - sa * d1.im));
+        }
+    }
     if constexpr (LATE_R && !DOT) if (a.upd_scal) {       // the LDS exchange and the barrier cover this load
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
@@ -783,6 +823,7 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
         cd sm = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         cd v = a.b * sm;
         v = mk(fma(a.a, xv[cc].re, v.re), fma(a.a, xv[cc].im, v.im));
+        if constexpr (DW5) v = mk(v.re + w5[cc].re, v.im + w5[cc].im);
         if constexpr (DOT) {        // <z, v> = conj(z) v next to |v|^2 (same expressions as wilson_dirsplit's dot epilogue)
             const cd z = z_is_x ? xv[cc] : rv[cc];
             nrm = fma(v.re, v.re, nrm); nrm = fma(v.im, v.im, nrm);
@@ -801,7 +842,7 @@ __device__ inline void sdir_wave(const PipeArgs& a, real2 (*part)[12][64], int l
     }
 }
 
-template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false>
+template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false>
 __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
     __shared__ double red[DOT ? 12 : 4];
@@ -822,10 +863,10 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     const int lane = threadIdx.x & 63;
     real nrm = 0.0, dre = 0.0, dim = 0.0;
     switch (w) {
-    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
-    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
+    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
     }
     if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue
         double t3[3] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm};
@@ -1433,10 +1474,12 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     a.cps = k.cps; a.cpp = k.cpp; a.cpr = k.cpr; a.per_pass = std::max(1, k.cpr * k.g.L[3]); a.ty = k.ty; a.tz = k.tz; a.ysplit = k.ysplit;
     a.ctr = c->pipe_ctr; a.per_wg = 1;
     a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
+    a.ls = s.dw_ls; a.slice_bytes = (unsigned long long)s.dw_slice * sizeof(real2); a.d_ls = make_fastdiv(std::max(1, s.dw_ls)); a.dw_mass = (real)s.dw_mass;
     return a;
 }
 
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
+    if (s.dw_ls > 1 && !stencil_dw5_applies(c, s)) { set_error("stencil: the five-dimensional launch does not apply to this call (domainwall.hip checks before asking)"); return LQCD_ERR_UNSUPPORTED; }
     if (use_dirsplit(c, s.kind, s.r)) {
         KArgs k = make_kargs(c, s, 64);
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
@@ -1504,6 +1547,13 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             const dim3 pg(c->tun.dslash_pipe == 1 ? wilson_pipe_grid(c, k.nblocks, s.prec) : c->tun.dslash_pipe == 3 ? k.nblocks / a.per_wg : k.nblocks), pb(256);
             const bool ntb = (k.nt & 1) != 0;
 #ifndef LQCD_F32
+            if (s.dw_ls > 1) {      // Domainwall: the L5 slices in one launch, fifth-direction hops in the epilogue (plain loads for the backward link: it is re-used by the next slice)
+                if (c->tun.dslash_pipe != 2 || delta || k.upd_scal || k.norm_partial) { set_error("stencil: the five-dimensional launch needs the scalar-addressing kernel in its plain mode"); return LQCD_ERR_UNSUPPORTED; }
+                const dim3 g5((unsigned)k.nblocks * (unsigned)s.dw_ls);
+                if (!k.gauge12) { set_error("stencil: the five-dimensional launch reads the 12-real links"); return LQCD_ERR_UNSUPPORTED; }      // (its 18-real instance spills 154 VGPRs)
+                if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, false, false, true>), g5, pb, 0, c->stream, a);
+                else hipLaunchKernelGGL((wilson_dirsplit_s<false, true, false, false, false, true>), g5, pb, 0, c->stream, a);
+            } else
             if (delta) {       // rows 0, 1 + fp32 deviation of row 2 (reference-format configurations); plain loads for the backward link as well: the
                                // non-temporal form measured 0.3962 against 0.3915 ms at 32^3x64 (profiles/r04_links_12_plus_delta.log)
                 if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, false, true>), pg, pb, 0, c->stream, a);
@@ -1647,6 +1697,13 @@ int wilson_pipe_grid(lqcd_ctx_s* c, int nvirt, int prec) {
 // The persistent form of variant 1 (tunable dslash_pipe): only where a persistent workgroup has at least pipe_min_chunks chunks to walk (below that the
 // tail imbalance eats the gain) and only the r = 1 Wilson operator; a call that carries the packed clover blocks (fused A x epilogue) keeps
 // the plain variant-1 kernel -- `clover` is that property of the call (StencilCall::clover != nullptr; solvers: op_fused_clover).
+// the L5 slices of a Domainwall application as ONE launch of the scalar-addressing kernel: fp64, one GPU, full-lattice plain mode, 12-real links (fields on the group)
+bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s) {
+    if (kF32Build || s.prec != 0 || s.kind != LQCD_WILSON || s.r != 1.0 || s.parity_mode != 2 || any_partitioned(c)) return false;
+    if (s.upd_scal || s.norm_partial || s.alpha_partials || s.dot_partial || s.clover || s.clover_on_hop || s.gauge12_delta || s.skip_flag) return false;
+    if (c->tun.dslash_pipe != 2 || !s.gauge12) return false;
+    return wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false);
+}
 bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, bool clover) {
     if (c->tun.dslash_variant != 1 || !c->tun.dslash_pipe || clover || kind != LQCD_WILSON || !use_dirsplit(c, kind, r)) return false;
     if (r != 1.0) return false;
