@@ -135,6 +135,23 @@ PY
       rm -rf $out/pmc
     done
     ;;
+  pupmc)      # counters of the one-sweep momentum + link update kernel (separate --pmc passes, kernel trace only)
+    for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
+      n=$(echo $pass | cut -d' ' -f1)
+      (cd /tmp && timeout 200 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_$n -o p -- python $GRAFT_REPO_ROOT/scripts/pu_probe.py 0.005 > /dev/null 2>&1)
+      f=$(find $out/pmc_$n -name "*counter_collection.csv" | head -1)
+      python - "$f" <<'PY' | tee -a $out/pupmc.log
+import csv, sys, collections
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"]
+    if "gauge_force_kernel" in k or "link_exp_update" in k:
+        acc[(k[:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (k, c), v in sorted(acc.items()):
+    print("%-62s %-22s mean %.5e over %d launches" % (k, c, sum(v) / len(v), len(v)))
+PY
+    done
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log
