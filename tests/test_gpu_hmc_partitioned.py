@@ -133,3 +133,65 @@ def test_wilson_clover_md_trajectory_self_partitioned_equals_one_domain(lq, orc,
     a, b = res["single"], res["part"]
     assert np.abs(a[:-1] - b[:-1]).max() < 1e-9 * np.abs(a[:-1]).max()
     assert abs(a[-1] - b[-1]) < 1e-7 and np.isfinite(a[-1])
+
+
+def test_staggered_rhmc_md_trajectory_self_partitioned_equals_one_domain(lq, orc, tmp_path):
+    """BASELINE.json configs[4] in small: a staggered rational (Nf = 2 and Nf = 3) MD trajectory on a partitioned lattice (LQCD_FORCE_PARTITION = y,z,t with
+    world-size-1 RCCL communicators: Dslash halos inside the multi-shift CG, rank-summed inner products, X/Y faces of every pole's force sweep, ghost links and
+    staple faces of the gauge force; the partial fractions are fitted inside the library) against the same trajectory on one domain -- and the mixed-precision
+    action solver on the partitioned lattice against the fp64 one."""
+    import os, subprocess, sys, textwrap
+    L = (8, 4, 6, 8)
+    Uh = orc.unit_gauge(L)
+    Uh = orc.link_update(Uh, 0.3 * orc.gaussian_momenta(L, 921), 1.0, L)
+    xi_h = orc.gaussian_spinor(orc.staggered_shape(L), 922) * np.sqrt(0.5)
+    np.save(tmp_path / "U.npy", Uh)
+    np.save(tmp_path / "xi.npy", xi_h)
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        d, tag, nf, mixed = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+        L, dtau, nsteps = (8, 4, 6, 8), 0.04, 3
+        Uh, xi_h = np.load(d + "/U.npy"), np.load(d + "/xi.npy")
+        lat = lq.Lattice(L)
+        if os.environ.get("LQCD_FORCE_PARTITION"):
+            lat.comm_init(lq.comm_unique_id())
+        lat.set_param("mixed_action_solver", mixed)
+        U = lq.Gaugefields(lat).upload(Uh)
+        D = lq.Dirac_operator(U, None, {"Dirac_operator": "Staggered", "mass": 0.5, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-20})
+        fa = lq.FermiAction(D, {"Nf": nf})
+        assert fa.rational
+        p, G = lq.Gaugefields(lat), lq.Gaugefields(lat)
+        lq.gauss_distribution_(p, 923)
+        xi = lq.Fermionfields(lat, lq.STAGGERED).upload(xi_h)
+        eta = xi.similar()
+        lq.sample_pseudofermions_(eta, U, fa, xi)
+        Sf0 = lq.evaluate_FermiAction(fa, U, eta)
+        assert abs(Sf0 - lq.dot(xi, xi).real) < 1e-6 * Sf0          # the heat bath identity, through the fitted partial fractions
+        H0 = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, 5.7) + Sf0
+        for _ in range(nsteps):
+            lq.U_update_(U, p, 0.5 * dtau)
+            lq.P_update_(U, p, dtau, 5.7)
+            lq.calc_UdSfdU_(G, fa, U, eta)
+            lq.Traceless_antihermitian_add_(p, dtau, G)
+            lq.U_update_(U, p, 0.5 * dtau)
+        H1 = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, 5.7) + lq.evaluate_FermiAction(fa, U, eta)
+        np.save(d + "/out_" + tag + ".npy", np.concatenate([U.download().ravel(), p.download().ravel(), eta.download().ravel(), [H1 - H0]]))
+        print("TRAJ_OK")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for nf in (2, 3):
+        res = {}
+        for tag, mask, mixed in (("single", None, 0), ("part", "14", 0), ("partmixed", "14", 1)):
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.pop("LQCD_FORCE_PARTITION", None)
+            if mask:
+                env["LQCD_FORCE_PARTITION"] = mask
+            r = subprocess.run([sys.executable, "-c", code, str(tmp_path), tag, str(nf), str(mixed)], capture_output=True, text=True, env=env, timeout=400, cwd=root)
+            assert r.returncode == 0 and "TRAJ_OK" in r.stdout, (nf, tag, r.stdout[-2000:], r.stderr[-3000:])
+            res[tag] = np.load(tmp_path / ("out_%s.npy" % tag))
+        a, b, m = res["single"], res["part"], res["partmixed"]
+        assert np.abs(a[:-1] - b[:-1]).max() < 1e-9 * np.abs(a[:-1]).max(), nf
+        assert abs(a[-1] - b[-1]) < 1e-7 and np.isfinite(a[-1]), (nf, a[-1])
+        assert np.abs(m[:-1] - b[:-1]).max() < 1e-7 * np.abs(b[:-1]).max() and abs(m[-1] - b[-1]) < 1e-5, nf
