@@ -226,7 +226,7 @@ def main():
     z5 = x5.similar()
     dt5, (it5, rr5) = timed(lambda: (lq.clear_fermion_(z5), lq.solve_DinvX_(z5, lq.DdagD_operator(D5), x5, return_info=True))[1], reps=2)
     res.append({"config": "16^3x32 x L5 = 8 Domainwall (M = -1.8, m = 0.05): D5 application and CG on D5^+ D5 to 1e-16", "D5_ms": t_d5,
-                "D5_GBps_moved (L5 Wilson launches of 768 B/site + fifth-direction pass of ~1150 B per 5-d site)": L5 * V5 * (768 + 1150) / t_d5 / 1e6,
+                "D5_GBps_on_minimal_bytes (384 + 384/L5 per 5-d site: psi in + out, 12-real links shared by the slices)": L5 * V5 * (384 + 384 / L5) / t_d5 / 1e6,
                 "cg_iters": it5, "cg_ms": 1e3 * dt5, "cg_final_rr": rr5})
     for o in (U, D5, x5, y5, z5):
         o.close()
