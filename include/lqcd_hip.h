@@ -332,7 +332,8 @@ int lqcd_mdom_gauge_force(int n, lqcd_gauge_t* outs, lqcd_gauge_t* Us, double be
  * STOUT_Layer(p.stout_loops, p.stout_ρ, U); src/md/standardMD.jl:192-227: calc_smearedU, calc_UdSfdU! on the smeared links, back_prop;
  * src/updates/standardHMC.jl:67-68).  One STOUT layer with the plaquette loop, Morningstar-Peardon's definition [EXT-RECALL: Gaugefields.jl is not under the
  * reference tree]:  U'_mu(n) = exp(-rho TA(U_mu(n) A_mu(n))) U_mu(n), A = the six staples (those of lqcd_gauge_force).  Several layers = several calls,
- * back-propagated in reverse order with the links each layer started from.  Force fields in the convention of lqcd_fermion_force.  One GPU. */
+ * back-propagated in reverse order with the links each layer started from.  Force fields in the convention of lqcd_fermion_force.  Collective on RCCL
+ * ranks (staple faces; the back-propagation reads a halo-extended block of links and N matrices). */
 /* calculate_Polyakov_loop(U, temp1, temp2) (the Polyakov_loop measurement of every toml under test/; src/system/lqcd.jl:141 -> QCDMeasurements):
  * 1/(NC NX NY NZ) sum_x tr prod_t U_4(x, t), summed over ranks; the time direction must not be partitioned */
 int lqcd_gauge_polyakov(lqcd_gauge_t U, double* re, double* im);

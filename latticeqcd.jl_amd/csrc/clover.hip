@@ -793,6 +793,102 @@ static int clover_ext_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, const double2*
     return LQCD_OK;
 }
 
+// ---- stout back-propagation on a partitioned lattice (md.hip, "stout smearing"): the same 24-loop gather as stout_gather_kernel, reading the links and the N matrices
+// (four per site, carried in planes 0..3 of a Lambda-shaped buffer) from the halo-extended block -- it reaches n + mu - nu, a corner of the neighbouring ranks.
+__global__ __launch_bounds__(256) void stout_gather_ext_kernel(Geom g, ForceSrc src, double2* __restrict__ G, double rho) {
+    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    if (i >= g.Vh) return;
+    int c[4];
+    cb_to_coords(g, p, i, c);
+    cd a[9], Na[9], acc[9];
+    get_link<true>(a, src, g, c, mu);
+    get_lam<true>(Na, src, g, c, mu);
+#pragma unroll
+    for (int e = 0; e < 9; e++) acc[e] = mk(0.0, 0.0);
+    for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        cd b[9], cc[9], d[9], Nb[9], Nc[9], Nd[9], t1[9], t2[9], t3[9], X[9];
+        int cm[4] = {c[0], c[1], c[2], c[3]}, cn[4] = {c[0], c[1], c[2], c[3]};
+        cm[mu] += 1;
+        cn[nu] += 1;
+        // the plaquette (n; mu, nu), this link as a: b = U_nu(n+mu), c = U_mu(n+nu), d = U_nu(n)
+        get_link<true>(b, src, g, cm, nu); get_link<true>(cc, src, g, cn, mu); get_link<true>(d, src, g, c, nu);
+        get_lam<true>(Nb, src, g, cm, nu); get_lam<true>(Nc, src, g, cn, mu); get_lam<true>(Nd, src, g, c, nu);
+        mmx<false, true>(t1, b, cc);           // b c^+
+        mmx<false, true>(X, t1, d);            // X = b c^+ d^+
+        mmx<false, false>(t2, X, Na);
+        mmx<false, false>(t3, Nb, X);
+#pragma unroll
+        for (int e = 0; e < 9; e++) t2[e] = mk(t2[e].re + t3[e].re, t2[e].im + t3[e].im);
+        mmx<false, false>(t3, a, t2);          // a (X Na + Nb X)
+#pragma unroll
+        for (int e = 0; e < 9; e++) acc[e] = mk(acc[e].re + t3[e].re, acc[e].im + t3[e].im);
+        mmx<false, false>(t2, a, X);
+        dag9(t2);                              // (a X)^+ = d c b^+ a^+
+        mmx<false, false>(t3, Nd, t2);
+#pragma unroll
+        for (int e = 0; e < 9; e++) acc[e] = mk(acc[e].re - t3[e].re, acc[e].im - t3[e].im);
+        mmx<false, false>(t2, a, t1);
+        dag9(t2);                              // (a b c^+)^+ = c b^+ a^+
+        mmx<false, false>(t3, Nc, t2);
+        mmx<false, false>(t2, d, t3);
+#pragma unroll
+        for (int e = 0; e < 9; e++) acc[e] = mk(acc[e].re - t2[e].re, acc[e].im - t2[e].im);
+        // the plaquette (n - nu; mu, nu), this link as c: a2 = U_mu(m), b2 = U_nu(m + mu), d2 = U_nu(m), m = n - nu
+        int m[4] = {c[0], c[1], c[2], c[3]};
+        m[nu] -= 1;
+        int mm[4] = {m[0], m[1], m[2], m[3]};
+        mm[mu] += 1;
+        get_link<true>(b, src, g, mm, nu); get_link<true>(cc, src, g, m, mu); get_link<true>(d, src, g, m, nu);       // b2, a2, d2
+        get_lam<true>(Nb, src, g, mm, nu); get_lam<true>(Nc, src, g, m, mu); get_lam<true>(Nd, src, g, m, nu);        // Nb2, Na2, Nd2
+        mmx<false, false>(t1, cc, b);          // a2 b2
+        dag9(t1);                              // R = b2^+ a2^+
+        mmx<false, false>(t2, Nd, d);
+        mmx<false, false>(t3, d, Na);          // Nc of that plaquette is this link's own N
+#pragma unroll
+        for (int e = 0; e < 9; e++) t2[e] = mk(t2[e].re + t3[e].re, t2[e].im + t3[e].im);
+        mmx<false, false>(t3, t1, t2);
+        mmx<false, false>(t2, a, t3);          // c R (Nd2 d2 + d2 Nc)
+#pragma unroll
+        for (int e = 0; e < 9; e++) acc[e] = mk(acc[e].re + t2[e].re, acc[e].im + t2[e].im);
+        mmx<false, false>(t1, Nc, cc);         // Na2 a2
+        mmx<false, false>(t2, cc, Nb);         // a2 Nb2
+#pragma unroll
+        for (int e = 0; e < 9; e++) t1[e] = mk(t1[e].re + t2[e].re, t1[e].im + t2[e].im);
+        mmx<false, false>(t2, t1, b);          // (Na2 a2 + a2 Nb2) b2
+        mmx<false, true>(t1, t2, a);           // ... c^+
+        mmx<true, false>(t2, d, t1);           // d2^+ (...)
+#pragma unroll
+        for (int e = 0; e < 9; e++) acc[e] = mk(acc[e].re - t2[e].re, acc[e].im - t2[e].im);
+    }
+    const int Gs = glink_stride(g);
+    double2* o = G + glink_off(g, p, mu, i);
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+        const cd v = ld(o + (size_t)e * Gs);
+        st(o + (size_t)e * Gs, mk(v.re - rho * acc[e].re, v.im - rho * acc[e].im));
+    }
+}
+
+// G += -rho * (the 24 loop terms) with U and N (planes 0..3 of the Lambda-shaped buffer lamN) taken from the halo-extended block: collective on RCCL ranks
+int stout_gather_ext(lqcd_ctx_s* c, const lqcd_gauge_s* U, const double2* lamN, lqcd_gauge_s* G, double rho) {
+    ARGCHK(c->local_peers.empty(), "stout back-propagation: not available on an in-process PE grid");
+    ForceSrc src;
+    src.U = U->data; src.lam = lamN; src.ext = nullptr;
+    src.eg = ExtGeom();
+    LQCHK(clover_ext_build(c, U, lamN, src.eg));
+    src.ext = c->clover_ext;
+    hipLaunchKernelGGL(stout_gather_ext_kernel, dim3(2 * c->geom.nch), dim3(256), 0, c->stream, c->geom, src, G->data, rho);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+// where the N matrices of a partitioned back-propagation go: direction mu of site (p, i) in plane mu of a Lambda-shaped buffer of the context
+double2* stout_lambda_buffer(lqcd_ctx_s* c) {
+    if (!c->clover_q[0] && hipMalloc((void**)&c->clover_q[0], clover_lambda_elems(c->geom) * sizeof(double2)) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(c->clover_q[0], 0, clover_lambda_elems(c->geom) * sizeof(double2), c->stream);      // planes 4, 5 travel with the faces: keep them finite
+    return c->clover_q[0];
+}
+
 // out = (accumulate ? out : 0) + scale * (clover part of "U dS_f/dU"); lam = scratch of clover_lambda_elems() elements
 int clover_force(lqcd_ctx_s* c, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double2* lam, double kappa,
                  double csw, double scale, int accumulate) {

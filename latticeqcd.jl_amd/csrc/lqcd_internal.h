@@ -747,6 +747,8 @@ int clover_apply(lqcd_ctx_s* c, const double2* clov, lqcd_spinor_s* out, lqcd_sp
 int clover_apply_parity(lqcd_ctx_s* c, const double2* clov, int parity, double2* out, const double2* in, double sa, const double2* z, double sz);
 int clover_invert(lqcd_ctx_s* c, const double2* clov, double2* inv);
 size_t clover_lambda_elems(const Geom& g);
+int stout_gather_ext(lqcd_ctx_s* c, const lqcd_gauge_s* U, const double2* lamN, lqcd_gauge_s* G, double rho);      // partitioned stout back-propagation (clover.hip: halo-extended block)
+double2* stout_lambda_buffer(lqcd_ctx_s* c);
 int clover_force(lqcd_ctx_s* c, const lqcd_gauge_s* U, lqcd_gauge_s* out, lqcd_spinor_s* X, lqcd_spinor_s* Y, double2* lam, double kappa,
                  double csw, double scale, int accumulate);
 

@@ -1352,7 +1352,8 @@ extern "C" int lqcd_momentum_action(lqcd_gauge_t P, double* K) {
 // and the chain rule with the Frechet derivative L(Z, .) of exp in place of the closed-form B matrices (the same linear map, no special cases):
 //     G_i = e^{-Z_i} G'_i e^{Z_i} + force of S~ = -2 rho sum_j Re tr(W_j N_j),   N_j = TA(L(Z_j, e^{-Z_j} G'_j)) held fixed,
 // where G' = "U' dS/dU'" at the smeared links and G = "U dS/dU" at the thin ones, both in the convention of lqcd_fermion_force.  S~ puts N_j at the start of each
-// of the 24 plaquette loops through a link: 6 plaquettes x the 4 links whose staple sums contain them (stout_gather_kernel).  One GPU.
+// of the 24 plaquette loops through a link: 6 plaquettes x the 4 links whose staple sums contain them (stout_gather_kernel; on a partitioned lattice
+// stout_gather_ext_kernel of clover.hip, which reads links and N matrices from the halo-extended block).
 namespace lqcd {
 
 __device__ __forceinline__ void dag3(cd (&o)[9], const cd (&a)[9]) {
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(256) void stout_smear_kernel(Geom g, double2* __res
     store_m3(out + off, Gs, r);
 }
 // per link: Z = -rho TA(W); K = e^{-Z} G'; N = TA(L(Z, K)); G0 = K e^{Z}  (G0 may be written over G')
-__global__ __launch_bounds__(256) void stout_prep_kernel(Geom g, double2* __restrict__ N, double2* G0, const double2* Gp, const double2* __restrict__ W, double rho) {
+__global__ __launch_bounds__(256) void stout_prep_kernel(Geom g, double2* __restrict__ N, double2* G0, const double2* Gp, const double2* __restrict__ W, double rho, int lam_layout) {
     size_t off;
     if (!link_of_thread(g, off)) return;
     const int Gs = glink_stride(g);
@@ -1449,7 +1450,10 @@ __global__ __launch_bounds__(256) void stout_prep_kernel(Geom g, double2* __rest
     mm3(K, em, gp);
     frechet3(l, z, K);
     ta3(n, l, 1.0);
-    store_m3(N + off, Gs, n);
+    if (lam_layout) {      // partitioned lattice: plane mu of the Lambda-shaped buffer the halo-extended block is filled from ([parity][chunk][6][9][64])
+        const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+        store_m3(N + ((((size_t)p * g.nch + (size_t)(i >> 6)) * 6 + mu) * 9) * 64 + (i & 63), 64, n);
+    } else store_m3(N + off, Gs, n);
     dag3(ep, em);                  // Z anti-Hermitian: e^{Z} = (e^{-Z})^+
     mm3(g0, K, ep);
     store_m3(G0 + off, Gs, g0);
@@ -1537,7 +1541,7 @@ extern "C" int lqcd_stout_smear(lqcd_gauge_t out, lqcd_gauge_t U, double rho) {
     ARGCHK(out != U, "lqcd_stout_smear: the smeared links need a field of their own");
     LQCHK(lqcd::links_flush_of(out));
     lqcd_ctx_s* c = U->ctx;
-    ARGCHK(!any_partitioned(c), "lqcd_stout_smear: one GPU only");
+    ARGCHK(c->local_peers.empty(), "lqcd_stout_smear: not available on an in-process PE grid (RCCL ranks only)");
     HIPCHK(hipSetDevice(c->device));
     lqcd_gauge_s* W;
     LQCHK(stout_tmp(c, 0, &W));
@@ -1557,13 +1561,22 @@ extern "C" int lqcd_stout_backprop(lqcd_gauge_t G, lqcd_gauge_t Gs, lqcd_gauge_t
     ARGCHK(G != U && Gs != U, "lqcd_stout_backprop: the force fields must not be the link field");
     LQCHK(lqcd::links_flush_of(G));
     lqcd_ctx_s* c = U->ctx;
-    ARGCHK(!any_partitioned(c), "lqcd_stout_backprop: one GPU only");
+    ARGCHK(c->local_peers.empty(), "lqcd_stout_backprop: not available on an in-process PE grid (RCCL ranks only)");
     HIPCHK(hipSetDevice(c->device));
     lqcd_gauge_s *W, *N;
     LQCHK(stout_tmp(c, 0, &W)); LQCHK(stout_tmp(c, 1, &N));
     LQCHK(staple_force(W, U, -6.0, 0.0, false));
     G->version++;
-    hipLaunchKernelGGL(stout_prep_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, N->data, G->data, Gs->data, W->data, rho);
+    if (any_partitioned(c)) {      // the gather reaches n + mu - nu: links and N matrices from the halo-extended block (clover.hip), collective
+        double2* lamN = stout_lambda_buffer(c);
+        ARGCHK(lamN, "lqcd_stout_backprop: out of device memory");
+        hipLaunchKernelGGL(stout_prep_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, lamN, G->data, Gs->data, W->data, rho, 1);
+        HIPCHK(hipGetLastError());
+        LQCHK(stout_gather_ext(c, U, lamN, G, rho));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return LQCD_OK;
+    }
+    hipLaunchKernelGGL(stout_prep_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, N->data, G->data, Gs->data, W->data, rho, 0);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(stout_gather_kernel, dim3(link_grid(c->geom)), dim3(256), 0, c->stream, c->geom, G->data, U->data, N->data, rho);
     HIPCHK(hipGetLastError());

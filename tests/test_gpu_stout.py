@@ -155,3 +155,37 @@ def test_hmc_with_stout_smeared_fermions_conserves_energy(lq, orc):
         update_stout_(hmc, U)
         dH[dtau] = hmc.dH[0]
     assert abs(dH[0.02]) < 0.5 and abs(dH[0.01]) < 0.3 * abs(dH[0.02]) + 1e-3, dH      # second-order integrator: dH ~ dtau^2
+
+
+def test_rccl_self_partition_stout(lq, orc):
+    """The stout layer and its back-propagation on a partitioned lattice (LQCD_FORCE_PARTITION + world-size-1 RCCL communicators): the smearing through the
+    staple sweep's ghost links and staple faces, the back-propagation's 24-loop gather from the halo-extended block of links and N matrices (it reaches the
+    corner n + mu - nu of the neighbouring ranks) -- both against the numpy restatement."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, ctypes as C, numpy as np
+        sys.path.insert(0, os.getcwd())
+        import latticeqcd_jl_amd as lq
+        from oracle import oracle as orc
+        L, rho = (8, 4, 6, 8), 0.11
+        lat = lq.Lattice(L)
+        lat.comm_init(lq.comm_unique_id())
+        Uh = orc.hot_gauge(L, 111)
+        U = lq.Gaugefields(lat).upload(Uh)
+        nn = lq.CovNeuralnet(U)
+        nn.push_(lq.STOUT_Layer(["plaquette"], [rho], U))
+        Uout, multi, _ = lq.calc_smearedU(U, nn)
+        rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+        assert rel(Uout.download(), orc.stout_smear(Uh, L, rho)) < 1e-13
+        rng = np.random.default_rng(8)
+        Gs = rng.standard_normal(orc.gauge_shape(L)) + 1j * rng.standard_normal(orc.gauge_shape(L))
+        Gd, G = lq.Gaugefields(lat).upload(Gs), lq.Gaugefields(lat)
+        lq.lib.check(lq.lib.lib().lqcd_stout_backprop(G._h, Gd._h, U._h, C.c_double(rho)))
+        assert rel(G.download(), orc.stout_backprop(Gs, Uh, L, rho)) < 1e-12
+        print("RCCL_SELF_STOUT_OK")
+    """)
+    for mask in ("8", "14", "15"):
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "RCCL_SELF_STOUT_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
