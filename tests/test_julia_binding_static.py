@@ -294,3 +294,24 @@ def test_univ_runs_unchanged_after_activate():
     assert "invoke(Gaugefields.Initialize_Gaugefields, Tuple{Any,Any,Vararg{Any}}" in body            # everything else: the package's own method
     assert "Base.delete_method" in text[text.index("function deactivate!()"):text.index("function deactivate!()") + 400]
     assert imported_names(text).get("Initialize_Gaugefields") == "Gaugefields"
+
+
+def test_binding_blocks_are_balanced():
+    """No Julia here to parse the file: at least every block opener (function, if, for, while, struct, let, begin, do, try, module) must meet its `end`.  Comments and
+    strings are stripped; `for` / `if` inside open brackets or parentheses of the same line are comprehensions / generators; `a[end]` and `:end` are not block ends."""
+    src = re.sub(r'"(?:\\.|[^"\\])*"', '""', binding_text())
+    openers = re.compile(r"(?<![\w!.])(function|if|for|while|struct|let|begin|do|try|module|quote|macro)(?![\w!])")
+    stack = []
+    for ln, line in enumerate(src.split("\n"), 1):
+        toks = [(m.start(), m.group(1)) for m in openers.finditer(line)] + [(m.start(), "end") for m in re.finditer(r"(?<![\w!.:\[])end(?![\w!])", line)]
+        for pos, t in sorted(toks):
+            if t == "end":
+                assert stack, "line %d: `end` without an open block" % ln
+                stack.pop()
+            else:
+                head = line[:pos]
+                inside = head.count("[") > head.count("]") or head.count("(") > head.count(")")
+                if t in ("for", "if") and inside:
+                    continue
+                stack.append((ln, t))
+    assert not stack, "unclosed blocks: %s" % stack[:5]
