@@ -315,3 +315,17 @@ def test_binding_blocks_are_balanced():
                     continue
                 stack.append((ln, t))
     assert not stack, "unclosed blocks: %s" % stack[:5]
+
+
+def test_binding_calls_only_names_it_defines_imports_or_base_provides():
+    """A typo in a function name would only show at run time in Julia: every `name(` of the binding must be a method it defines, a name it imports from the two
+    packages / Base / LinearAlgebra, a struct of its own, or one of the Base functions listed here."""
+    src = re.sub(r'"(?:\\.|[^"\\])*"', '""', binding_text())
+    calls = set(re.findall(r"(?<![\w.:@])([A-Za-z_][\w!]*)\(", src))
+    defs = set(re.findall(r"(?m)^\s*(?:function\s+)?(?:[A-Za-z_]\w*\.)*([A-Za-z_][\w!]*)\(", src))
+    defs |= set(re.findall(r"(?m)^(?:mutable\s+)?struct\s+([A-Za-z_]\w*)", src))
+    base = {"ccall", "error", "length", "push!", "Ref", "Cint", "Float64", "Int", "String", "isempty", "get", "haskey", "zeros", "complex", "real", "imag",
+            "finalizer", "println", "lowercase", "rand", "UInt64", "sum", "all", "enumerate", "foreach", "invoke", "which", "getfield", "unsafe_string", "joinpath",
+            "cat", "size", "Tuple", "T", "where", "prod"}
+    unknown = sorted(c for c in calls if c not in defs and c not in imported_names(src) and c not in base)
+    assert not unknown, unknown
