@@ -19,7 +19,12 @@
  * reject a pseudofermion weight of exp(-S_f/2), tests/test_gpu_md.py), so at the level of a
  * single Dslash application or CG solve the status remains **parity unpinned**: no
  * reference data exists there.  The operator conventions are defended by
- * convention-independent identities in tests/test_oracle_identities.py and test_oracle_md.py.
+ * convention-independent identities in tests/test_oracle_identities.py and test_oracle_md.py,
+ * and (round 4) the conventions that are OBSERVABLE are pinned to published physics through the
+ * HIP path this oracle checks: the quenched SU(3) Wilson plaquette at beta 5.7 / 6.0 and the
+ * quenched Wilson pion mass at beta 5.7, kappa 0.1600 / 0.1650 (Butler et al., Nucl. Phys. B 430
+ * (1994) 179) come out within 1 % (tests/test_gpu_quenched_literature.py) -- the normalisation of
+ * beta, of kappa, r = 1 and the hop structure.  That is not parity with the reference's own bits.
  *
  * Memory layouts are the reference's host layouts (Julia column-major):
  *   gauge  U[mu][a,b,ix,iy,iz,it]  (src/updates/givenconfigurations.jl:49)

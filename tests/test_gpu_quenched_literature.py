@@ -47,3 +47,81 @@ def test_quenched_plaquette_lands_on_the_literature_value(lq, beta, lit):
     assert err < 3e-4 and acc > 0.6
     assert abs(mean - lit) < 8e-4 + 3 * err, (mean, err, lit)
     assert abs(expdh - 1.0) < 0.1
+
+
+def _quenched_configs(lq, L, beta, ntherm, nconf, gap, seed):
+    lat = lq.Lattice(L)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="cold", lattice=lat)
+    p, Uold = lq.initialize_TA_Gaugefields(U), lq.Gaugefields(lat)
+    rng = np.random.default_rng(seed)
+    dtau, mdsteps = 0.03, 33
+    for it in range(ntherm + nconf * gap):
+        lq.substitute_U_(Uold, U)
+        lq.gauss_distribution_(p, seed + 7 * it + 1)
+        H0 = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, beta)
+        for _ in range(mdsteps):
+            lq.U_update_(U, p, 0.5 * dtau)
+            lq.P_update_(U, p, dtau, beta)
+            lq.U_update_(U, p, 0.5 * dtau)
+        dH = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, beta) - H0
+        if not np.exp(-dH) >= rng.random():
+            lq.substitute_U_(U, Uold)
+        if it >= ntherm and (it - ntherm) % gap == gap - 1:
+            yield lat, U
+
+
+def _pion_correlator(lq, lat, U, kappa, L):
+    """C(t) = sum_x tr[S(x,t;0) S(x,t;0)^+] from a point source at the origin: gamma5-hermiticity makes the pion correlator the squared modulus of the propagator,
+    whatever the gamma basis (measure_Pion_correlator.jl:376-399 of the reference's retired copies is the same computation)."""
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": kappa, "r": 1.0, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-18,
+                                    "MaxCGstep": 5000, "method_CG": "bicgstab_evenodd"})
+    b, x = lq.Fermionfields(lat, lq.WILSON), lq.Fermionfields(lat, lq.WILSON)
+    C = np.zeros(L[3])
+    for ic in range(3):
+        for isp in range(4):
+            lq.setindex_global_(b, ic, 0, 0, 0, 0, isp)
+            lq.clear_fermion_(x)
+            lq.solve_DinvX_(x, D, b)
+            S = x.download()                                  # [s, t, z, y, x, c]
+            C += (np.abs(S) ** 2).sum(axis=(0, 2, 3, 4, 5))
+    for o in (b, x, D):
+        o.close()
+    return C
+
+
+def _cosh_mass(C, t0, t1):
+    """effective masses from C(t) / C(t+1) = cosh(m (t - T/2)) / cosh(m (t + 1 - T/2)), averaged over t0 <= t < t1"""
+    T = len(C)
+    ms = []
+    for t in range(t0, t1):
+        r = C[t] / C[t + 1]
+        lo, hi = 1e-3, 5.0
+        for _ in range(80):
+            m = 0.5 * (lo + hi)
+            if np.cosh(m * (t - T / 2)) / np.cosh(m * (t + 1 - T / 2)) < r:
+                lo = m
+            else:
+                hi = m
+        ms.append(0.5 * (lo + hi))
+    return float(np.mean(ms))
+
+
+def test_quenched_wilson_pion_mass_lands_on_the_literature_value(lq):
+    """The FERMION operator pinned without the packages: the pion mass of quenched Wilson fermions (r = 1, hopping parameter kappa) at beta = 5.7 is a published number --
+    m_pi a = 0.6905(31) at kappa = 0.1600 and 0.4572(23) at kappa = 0.1650 (F. Butler, H. Chen, J. Sexton, A. Vaccarino, D. Weingarten, Nucl. Phys. B 430 (1994) 179,
+    16^3 x 32 and larger).  m_pi^2 is linear in 1/kappa with slope ~1.4: a 1 % error in the normalisation of kappa would move m_pi at 0.1650 by ~15 %.  12^3 x 24
+    (m_pi L = 8.3 and 5.5), 12 configurations 25 trajectories apart, point source, cosh effective mass at t = 6..10, jackknife error."""
+    L, beta = (12, 12, 12, 24), 5.7
+    lit = {0.1600: 0.6905, 0.1650: 0.4572}
+    cors = {k: [] for k in lit}
+    for lat, U in _quenched_configs(lq, L, beta, 300, 12, 25, seed=57):
+        for kappa in lit:
+            cors[kappa].append(_pion_correlator(lq, lat, U, kappa, L))
+    for kappa, want in lit.items():
+        Cs = np.array(cors[kappa])
+        m = _cosh_mass(Cs.mean(axis=0), 6, 11)
+        jk = np.array([_cosh_mass(np.delete(Cs, i, axis=0).mean(axis=0), 6, 11) for i in range(len(Cs))])
+        err = np.sqrt((len(Cs) - 1) / len(Cs) * ((jk - jk.mean()) ** 2).sum())
+        print("kappa %.4f: m_pi a = %.4f +- %.4f (literature %.4f)" % (kappa, m, err, want))
+        assert err < 0.03 * want
+        assert abs(m - want) < 0.03 * want + 3 * err, (kappa, m, err, want)
