@@ -23,8 +23,11 @@
  * and (round 4) the conventions that are OBSERVABLE are pinned to published physics through the
  * HIP path this oracle checks: the quenched SU(3) Wilson plaquette at beta 5.7 / 6.0 and the
  * quenched Wilson pion mass at beta 5.7, kappa 0.1600 / 0.1650 (Butler et al., Nucl. Phys. B 430
- * (1994) 179) come out within 1 % (tests/test_gpu_quenched_literature.py) -- the normalisation of
- * beta, of kappa, r = 1 and the hop structure.  That is not parity with the reference's own bits.
+ * (1994) 179) come out within 1 %, the quenched staggered Goldstone pion at beta 6.0, m = 0.01 / 0.03
+ * (Gupta et al., Phys. Rev. D 43 (1991) 2003) within 2 % with m_pi^2 proportional to m
+ * (tests/test_gpu_quenched_literature.py) -- the normalisation of beta, of kappa and of the staggered
+ * mass term, r = 1, the hop structure and the staggered phases.  That is not parity with the
+ * reference's own bits.
  *
  * Memory layouts are the reference's host layouts (Julia column-major):
  *   gauge  U[mu][a,b,ix,iy,iz,it]  (src/updates/givenconfigurations.jl:49)
