@@ -27,7 +27,8 @@ def _run(lq, L, beta, dtau, mdsteps, ntherm, nmeas, seed):
             lq.P_update_(U, p, dtau, beta)
             lq.U_update_(U, p, 0.5 * dtau)
         dH = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, beta) - H0
-        ok = np.exp(-dH) >= rng.random()
+        u = rng.random()
+        ok = dH <= 0 or np.exp(-dH) >= u
         if not ok:
             lq.substitute_U_(U, Uold)
         if it >= ntherm:
@@ -64,7 +65,8 @@ def _quenched_configs(lq, L, beta, ntherm, nconf, gap, seed):
             lq.P_update_(U, p, dtau, beta)
             lq.U_update_(U, p, 0.5 * dtau)
         dH = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, beta) - H0
-        if not np.exp(-dH) >= rng.random():
+        u = rng.random()
+        if not (dH <= 0 or np.exp(-dH) >= u):
             lq.substitute_U_(U, Uold)
         if it >= ntherm and (it - ntherm) % gap == gap - 1:
             yield lat, U
