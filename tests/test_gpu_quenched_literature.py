@@ -206,3 +206,18 @@ def test_quenched_clover_critical_kappa(lq):
     print("clover c_sw %.3f: m_pi a = %.4f (kappa %.4f), %.4f (kappa %.4f); kappa_c = %.5f +- %.5f (literature 0.13520; plain Wilson 0.15708)" % (csw, m1, kappas[0], m2, kappas[1], kc, err))
     assert err < 4e-4
     assert abs(kc - 0.13520) < 5e-4 + 3 * err, (kc, err)
+
+
+def test_polyakov_loop_brackets_the_deconfinement_transition(lq):
+    """calculate_Polyakov_loop (the second observable of every trajectory of the reference's runs) against the best-known fact about it: pure SU(3) gauge theory
+    deconfines at beta_c = 5.6925(2) for N_t = 4 (G. Boyd et al., Nucl. Phys. B 469 (1996) 419).  On 12^3 x 4 the modulus of the volume-averaged loop is a
+    finite-size remnant (~ 1 / sqrt(V_3)) at beta = 5.5 and of order 0.1 - 0.2 at beta = 5.9."""
+    L = (12, 12, 12, 4)
+    got = {}
+    for beta in (5.5, 5.9):
+        mods = []
+        for lat, U in _quenched_configs(lq, L, beta, 300, 60, 5, seed=int(10 * beta)):
+            mods.append(abs(lq.calculate_Polyakov_loop(U)))
+        got[beta] = float(np.mean(mods))
+        print("N_t = 4, beta %.1f: <|L|> = %.4f" % (beta, got[beta]))
+    assert got[5.5] < 0.04 and got[5.9] > 0.12, got
