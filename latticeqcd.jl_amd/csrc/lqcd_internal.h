@@ -520,6 +520,7 @@ struct lqcd_ctx_s {
     // fp32 work space of the mixed-precision solver (mixed.hip): links + 4 spinors, allocated on first use
     const void* mix_gauge_of = nullptr;  // gauge handle / version the fp32 link copies in mix_buf[0], mix_buf[5] were made from
     uint64_t mix_gauge_version = 0;
+    bool mix_gauge18_valid = false;      // the 18-real fp32 copy (mix_buf[0]) was made for that version (the site-pair kernel does not read it: skipped there)
     bool mix_gauge12_valid = false;      // the 12-real fp32 copy (mix_buf[5]) was made for that version
     int mix_gauge12_layout = 0;          // ... in which layout: 1 component pairs (stencil.hip fp32 build), 2 site pairs (stencil_pair32.hip)
     void* mix_buf[9] = {};     // 7: fp32 x_j / p_j pool of the mixed-precision multi-shift solver; 8: second search-direction buffer of the fp32 CG
