@@ -46,3 +46,31 @@ def test_backprop_is_the_derivative_through_the_smearing(orc):
         assert abs(fd - an) < 1e-6 * max(1.0, abs(fd)), (fd, an)
     # rho = 0: the smearing is the identity and so is its back-propagation
     assert np.abs(orc.stout_backprop(Gs, U, L, 0.0) - Gs).max() < 1e-14
+
+
+def test_polyakov_loop_restatement(orc):
+    """oracle.polyakov_loop: cold links give 1; the reference's 4^4 Wilson fixture gives a small complex number; a centre transformation of one time slice multiplies
+    the loop by exp(2 pi i / 3) and leaves the plaquette alone; a gauge transformation leaves it alone."""
+    import os
+    from conftest import GOLDEN
+    import latticeqcd_jl_amd as lq
+    Lc = (4, 4, 2, 6)
+    assert abs(orc.polyakov_loop(orc.unit_gauge(Lc), Lc) - 1.0) < 1e-15
+    U = orc.hot_gauge(Lc, 12)
+    p = orc.polyakov_loop(U, Lc)
+    z = np.exp(2j * np.pi / 3)
+    Uz = U.copy()
+    Uz[3, 2] *= z
+    assert abs(orc.polyakov_loop(Uz, Lc) - z * p) < 1e-14 and abs(orc.plaquette(Uz, Lc) - orc.plaquette(U, Lc)) < 1e-14
+    # gauge transformation U_mu(n) -> g(n) U_mu(n) g(n + mu)^+ (host image [b, a] = the transpose)
+    rng = np.random.default_rng(13)
+    g = orc.random_su3(rng, Lc[0] * Lc[1] * Lc[2] * Lc[3]).reshape(Lc[3], Lc[2], Lc[1], Lc[0], 3, 3)
+    Um = orc._mat(U)
+    Ug = np.empty_like(Um)
+    for mu in range(4):
+        Ug[mu] = g @ Um[mu] @ orc._dag(orc._sh(g, Lc, mu, 1))
+    Ugh = np.ascontiguousarray(orc._mat(Ug))
+    assert abs(orc.polyakov_loop(Ugh, Lc) - p) < 1e-13 and abs(orc.plaquette(Ugh, Lc) - orc.plaquette(U, Lc)) < 1e-13
+    L4 = (4, 4, 4, 4)
+    Uf = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L4)
+    assert abs(orc.polyakov_loop(Uf, L4)) < 0.3
