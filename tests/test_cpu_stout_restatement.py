@@ -74,3 +74,20 @@ def test_polyakov_loop_restatement(orc):
     L4 = (4, 4, 4, 4)
     Uf = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L4)
     assert abs(orc.polyakov_loop(Uf, L4)) < 0.3
+
+
+def test_stout_smearing_is_gauge_covariant(orc):
+    """smear(g U g^+) = g smear(U) g^+ : the smeared links transform like links (what makes the smeared fermion action gauge invariant)."""
+    Lc = (4, 4, 2, 4)
+    U = orc.hot_gauge(Lc, 21)
+    rng = np.random.default_rng(22)
+    g = orc.random_su3(rng, Lc[0] * Lc[1] * Lc[2] * Lc[3]).reshape(Lc[3], Lc[2], Lc[1], Lc[0], 3, 3)
+
+    def transform(V):
+        Vm = orc._mat(V)
+        out = np.empty_like(Vm)
+        for mu in range(4):
+            out[mu] = g @ Vm[mu] @ orc._dag(orc._sh(g, Lc, mu, 1))
+        return np.ascontiguousarray(orc._mat(out))
+
+    assert np.abs(orc.stout_smear(transform(U), Lc, 0.13) - transform(orc.stout_smear(U, Lc, 0.13))).max() < 1e-13
