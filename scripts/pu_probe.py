@@ -31,7 +31,7 @@ def tk(fn, reps=20):
 res = {}
 lat.set_param("lazy_merge", 0)
 res["P_update"] = tk(lambda: lq.P_update_(U, p, 1e-9, beta))
-res["U_update"] = tk(lambda: lq.U_update_(U, p, dt * 1e-3) if False else lq.U_update_(U, p, dt))
+res["U_update"] = tk(lambda: lq.U_update_(U, p, dt))
 res["P_then_U_separate"] = tk(lambda: (lq.P_update_(U, p, 1e-9, beta), lq.U_update_(U, p, dt)))
 lat.set_param("lazy_merge", 2)
 res["P_then_U_one_sweep"] = tk(lambda: (lq.P_update_(U, p, 1e-9, beta), lq.U_update_(U, p, dt)))
