@@ -238,5 +238,7 @@ def test_julia_binding_matches_the_c_header():
     # the per-direction entry points and the solvers the reference's callers need are all bound
     for need in ("lqcd_link_exp", "lqcd_link_mul", "lqcd_link_copy", "lqcd_link_add_ta", "lqcd_link_staple", "lqcd_solve_cg_DdagD",
                  "lqcd_solve_bicgstab", "lqcd_solve_bicg", "lqcd_solve_multishift_cg", "lqcd_solve_multishift_mixed_cg", "lqcd_action_create",
-                 "lqcd_action_evaluate", "lqcd_action_force", "lqcd_action_sample_pseudofermions", "lqcd_rational_fit", "lqcd_op_apply"):
+                 "lqcd_action_evaluate", "lqcd_action_force", "lqcd_action_sample_pseudofermions", "lqcd_rational_fit", "lqcd_op_apply",
+                 "lqcd_op_create_domainwall", "lqcd_spinor_create_5d", "lqcd_spinor_slice", "lqcd_stout_smear", "lqcd_stout_backprop", "lqcd_link_mul_adj",
+                 "lqcd_gauge_polyakov"):
         assert need in used, need
