@@ -1,4 +1,9 @@
-"""A pin that does not go through the reference's un-vendored packages at all: the average plaquette of the pure SU(3) Wilson gauge action is one of the best known
+"""Pins that do not go through the reference's un-vendored packages at all: published numbers of quenched lattice QCD, reproduced on the device with the library's own
+HMC and solvers -- the plaquette (gauge legs), the Wilson pion and rho at beta = 5.7 (the Wilson operator), the staggered Goldstone pion at beta = 6.0 (the staggered operator),
+the critical hopping parameter with and without the non-perturbative clover term at beta = 6.0 (the clover term), the Polyakov loop across the N_t = 4 transition.  The literature
+values are quoted from memory of the cited tables (there is no network here); the tolerances are set accordingly.
+
+First the gauge legs: the average plaquette of the pure SU(3) Wilson gauge action is one of the best known
 numbers of lattice QCD.  A quenched HMC with the library's gauge legs (staple force, momentum heat bath and update, exponential link update, actions, Metropolis step as in
 standardHMC.jl:41-91 with quench = true) must land on it -- which fixes the normalisation of beta (S_g = -(beta/3) sum Re tr U_p, the reference's `β/2` on the plaquette
 and its adjoint, universe.jl:92-95), of the force and of the kinetic term together.  d<P>/d beta is about 0.15 here: the tolerance below resolves beta to better than 1 %.
