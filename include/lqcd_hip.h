@@ -192,7 +192,7 @@ int lqcd_op_set_gauge(lqcd_op_t op, lqcd_gauge_t g);   /* the D(U) rebind idiom 
  * dw_active).  RCCL ranks as the Wilson operator (no in-process PE grid); every other entry point answers LQCD_ERR_UNSUPPORTED. */
 int lqcd_op_create_domainwall(lqcd_ctx_t ctx, lqcd_op_t* op, lqcd_gauge_t g, double M, double mass, int L5, const int bc[4]);
 int lqcd_spinor_create_5d(lqcd_ctx_t ctx, lqcd_spinor_t* s, int L5);      /* Initialize_pseudofermion_fields(U[1], "Domainwall", L5 = L5) (universe.jl:128) */
-int lqcd_spinor_slice(lqcd_spinor_t s5, int i5, lqcd_spinor_t* view);     /* 0-based; the view owns nothing and must not be used after its parent is destroyed */
+int lqcd_spinor_slice(lqcd_spinor_t s5, int i5, lqcd_spinor_t* view);     /* 0-based; the view owns nothing; a parent destroyed first keeps its storage until its last view is destroyed */
 /* mul!(y, D, x) / mul!(y, D', x) on FULL spinors */
 int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, int dagger);
 /* mul!(y, DdagD_operator(D), x):  out = D^dagger D in  (tmp is library scratch) */

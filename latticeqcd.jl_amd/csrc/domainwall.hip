@@ -55,6 +55,7 @@ lqcd_spinor_s slice_view(const lqcd_spinor_s* s5, int i5) {
     v.kind = LQCD_WILSON;
     v.ls = 1;
     v.owner = false;
+    v.view_of = nullptr; v.nviews = 0; v.zombie = false;
     v.elems = s5->elems / s5->ls;
     v.data = s5->data + (size_t)i5 * v.elems;
     return v;
@@ -225,11 +226,16 @@ extern "C" int lqcd_spinor_create_5d(lqcd_ctx_t ctx, lqcd_spinor_t* s, int L5) {
 }
 
 // x.w[i5] of the reference's five-dimensional field: a Wilson field that ALIASES slice i5 (0-based) of s5 -- upload / download / fill / BLAS go through it.
-// The view owns nothing: destroy it before (or after) its parent, never use it after the parent is gone.
+// The view owns nothing; a parent destroyed while views exist keeps its storage until the last view is destroyed (finalizers of a garbage collector run in any order).
 extern "C" int lqcd_spinor_slice(lqcd_spinor_t s5, int i5, lqcd_spinor_t* view) {
     ARGCHK(s5 && view && s5->kind == LQCD_DOMAINWALL && i5 >= 0 && i5 < s5->ls, "lqcd_spinor_slice: need a five-dimensional field and 0 <= i5 < L5");
+    ARGCHK(!s5->zombie, "lqcd_spinor_slice: the five-dimensional field has been destroyed");
     lqcd_spinor_s* v = new lqcd_spinor_s;
     *v = slice_view(s5, i5);
+    v->view_of = s5;
+    v->nviews = 0;
+    v->zombie = false;
+    s5->nviews++;
     *view = v;
     return LQCD_OK;
 }

@@ -398,6 +398,13 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
 extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
     if (!s) return LQCD_OK;
     // (no hipSetDevice: see lqcd_gauge_destroy)
+    if (s->view_of) {                      // a slice view: the last one of a destroyed parent takes the parent's storage with it
+        lqcd_spinor_s* parent = s->view_of;
+        delete s;
+        if (--parent->nviews == 0 && parent->zombie) { (void)hipFree(parent->data); delete parent; }
+        return LQCD_OK;
+    }
+    if (s->nviews > 0) { s->zombie = true; return LQCD_OK; }      // views are still out: the storage stays until the last of them is destroyed
     if (s->owner) (void)hipFree(s->data);
     delete s;
     return LQCD_OK;

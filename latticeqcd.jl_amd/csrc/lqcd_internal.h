@@ -567,6 +567,9 @@ struct lqcd_spinor_s {
     bool in_use = false;  // scratch-pool flag
     int ls = 1;           // LQCD_DOMAINWALL: extent of the fifth direction, ls Wilson fields in one allocation (domainwall.hip)
     bool owner = true;    // false: a slice view of a five-dimensional field (lqcd_spinor_slice) -- destroy frees the handle only
+    lqcd_spinor_s* view_of = nullptr;   // a slice view: its five-dimensional field ...
+    int nviews = 0;                     // ... which counts its live views and, destroyed while some exist (finalizers run in any order), keeps its storage until the last is gone
+    bool zombie = false;
 };
 
 struct lqcd_op_s {

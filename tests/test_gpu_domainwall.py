@@ -223,3 +223,27 @@ def test_rccl_self_partition_domainwall(lq, orc):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "RCCL_SELF_DW_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_slice_views_outlive_their_field_safely(lq, orc):
+    """Finalizers of a garbage collector run in any order: a five-dimensional field destroyed while slice views exist keeps its storage until the last view is gone."""
+    L, L5 = (8, 8, 8, 8), 6
+    lat = lq.Lattice(L)
+    x = lq.Fermionfields(lat, lq.DOMAINWALL, L5=L5)
+    ph = _rand5(orc, L, L5, 17)
+    x.upload(ph)
+    import ctypes as C
+
+    def free_bytes():
+        f, t = C.c_int64(0), C.c_int64(0)
+        lq.lib.check(lq.lib.lib().lqcd_device_mem_info(0, C.byref(f), C.byref(t)))
+        return f.value
+    free0 = free_bytes()
+    views = x.w
+    x.close()                                        # the parent goes first
+    assert np.array_equal(views[3].download(), ph[3])      # the storage is still there
+    for v in views[:-1]:
+        v.close()
+    assert np.array_equal(views[-1].download(), ph[-1])
+    views[-1].close()                                # the last view frees it
+    assert free_bytes() >= free0 + ph.nbytes // 2      # the field's storage came back only now
