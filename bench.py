@@ -285,6 +285,43 @@ def main():
       except Exception as e:
         out["after_md_trajectory"] = {"error": str(e)}
 
+    # ---- secondary (outside the timed region): ONE molecular-dynamics step of the 2-flavour Wilson HMC on this lattice, measured end to end with everything resident --
+    # the reference's runMD_QPQ_sw! (standardMD.jl:146-166, Sexton-Weingarten N = 10: 10 momentum updates, 20 link half steps, one P_update_fermion! = calc_UdSfdU! with
+    # eps_CG 1e-16 + Traceless_antihermitian_add!) on a copy of the links, steps of 1e-9 so that the configuration stays where it is; fp64 and with the fp32 inner chain
+    if world == 1 and not force_dist:
+      try:
+        U3, p3, G3 = lq.Gaugefields(lat), lq.Gaugefields(lat), lq.Gaugefields(lat)
+        lq.substitute_U_(U3, U)
+        lq.gauss_distribution_(p3, 4243)
+        D3 = lq.Dirac_operator(U3, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": (1, 1, 1, -1), "eps_CG": 1e-16})
+        fa3 = lq.FermiAction(D3)
+        eta3 = lq.Fermionfields(lat, lq.WILSON)
+        lq.sample_pseudofermions_(eta3, U3, fa3, b)
+
+        def md_step():
+            for half in range(2):
+                for _ in range(5):
+                    lq.U_update_(U3, p3, 0.5e-9)
+                    lq.P_update_(U3, p3, 1e-9, 5.7)
+                    lq.U_update_(U3, p3, 0.5e-9)
+                if half == 0:
+                    lq.calc_UdSfdU_(G3, fa3, U3, eta3)
+                    lq.Traceless_antihermitian_add_(p3, 1e-9, G3)
+        md = {}
+        for mixed in (0, 1):
+            lat.set_param("mixed_action_solver", mixed)
+            md_step(); lq.calculate_Plaquette(U3)
+            t0 = time.perf_counter()
+            md_step(); md_step(); lq.calculate_Plaquette(U3)
+            md["mixed_precision_solver_ms" if mixed else "fp64_ms"] = 1e3 * (time.perf_counter() - t0) / 2
+        lat.set_param("mixed_action_solver", 0)
+        md["lazy_merge"] = lat.get_param("lazy_merge")
+        out["md_step_wilson_hmc"] = md
+        for o in (eta3, fa3, D3, G3, p3, U3):
+            o.close()
+      except Exception as e:
+        out["md_step_wilson_hmc"] = {"error": str(e)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lq, U, b, gL)
         # max |HIP - oracle| / max |oracle| of D b (default and 18-real kernel instances) and D^+ b on the bench lattice itself
