@@ -111,7 +111,7 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * products from the Schur operator's epilogue and, up to 1024 chunks per parity, reductions and scalar steps in the consumers' prologues; 1 the same with separate reduction
  * launches -- bit-identical to 2; 0 the generic chain), action_eo_solver (1 [default]: lqcd_fermi_action / lqcd_calc_UdSfdU / lqcd_action_* solve the Wilson(-clover) normal
  * equations as two even-odd BiCGStab solves under the reference's stopping rule; 0: CG), bicg_mixed (1: lqcd_solve_bicgstab_eo on the plain Wilson operator runs an fp32 inner
- * chain inside an fp64 defect correction, the stopping rule holds for the true fp64 residual; mixed_action_solver = 1 switches it on for the action solves), lazy_links (1 [default]: the per-direction link-call triples are recorded and fused,
+ * chain inside an fp64 defect correction, the stopping rule holds for the true fp64 residual; mixed_action_solver = 1 switches it on for the action solves), lazy_links (1: the per-direction link-call triples are recorded and fused -- the temporaries of a completed triple are then never written, so the C ABI's default is 0 (eager) and the Julia / Python bindings switch it on when they create a context,
  * see lqcd_link_*; read-only lazy_open, lazy_deferred), lazy_merge (1 [default]: a complete link update U <- exp(a P) U waits unlaunched and a second one of the same
  * fields, with nothing in between that reads U or writes P, adds its step -- the back-to-back half steps of runMD_QPQ_sw!, standardMD.jl:146-166). */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);

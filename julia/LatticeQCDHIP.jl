@@ -69,6 +69,9 @@ function HIPLattice(L::NTuple{4,Int}; PEs = (1, 1, 1, 1), rank = 0, device = 0)
     check(ccall((:lqcd_ctx_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cint}, Ptr{Cint}, Cint),
                 h, device, Cint[L...], Cint[PEs...], rank))
     lat = HIPLattice(h[], L, PEs, rank, 2, nothing, Any[])
+    # U_update! / P_update! hand the temporaries of their per-direction call triples back to the pool unread (AbstractMD.jl:95-97,113-117): the binding
+    # switches the library's fusion of those triples on (the plain C ABI is eager by default: a fused triple never writes its temporaries)
+    check(ccall((:lqcd_ctx_set_param, LIB), Cint, (Ptr{Cvoid}, Cstring, Cint), lat.h, "lazy_links", 1))
     finalizer(l -> ccall((:lqcd_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), l.h), lat)
     return lat
 end

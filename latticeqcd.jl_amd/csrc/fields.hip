@@ -596,12 +596,22 @@ static int spinor_fill_mode(lqcd_spinor_t s, uint64_t seed, int mode) {
     lqcd_ctx_s* c = s->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int nt = 2 * c->geom.Vh;
-    // a five-dimensional field: slice i5 is the four-dimensional fill with seed + i5 (one stream per slice, keyed by the global site as ever)
-    const size_t slice = s->elems / s->ls;
-    for (int i5 = 0; i5 < s->ls; i5++) {
-        double2* base = s->data + (size_t)i5 * slice;
-        hipLaunchKernelGGL(spinor_fill, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, base, base + slice / 2, s->ncomp, seed + (uint64_t)i5, mode);
+    if (s->ls == 1) {
+        // a half-lattice field is ONE parity block: the absent parity is a null pointer the kernel skips (spinor_block's rule), so an EVEN / ODD
+        // field receives exactly the numbers the same parity of a FULL fill with this seed would
+        hipLaunchKernelGGL(spinor_fill, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, spinor_block(s, 0), spinor_block(s, 1), s->ncomp, seed, mode);
         HIPCHK(hipGetLastError());
+    } else {
+        // a five-dimensional field (always FULL): slice i5 is the four-dimensional fill with a seed hashed from (seed, i5) -- one stream per slice, keyed by
+        // the global site as ever, and no collision with a field filled with a neighbouring seed
+        ARGCHK(s->subset == LQCD_FULL, "spinor fill: a five-dimensional field is a FULL field");
+        const size_t slice = s->elems / s->ls;
+        for (int i5 = 0; i5 < s->ls; i5++) {
+            double2* base = s->data + (size_t)i5 * slice;
+            const uint64_t seed5 = splitmix64(seed ^ splitmix64(0x5D5D5D5D00000000ull + (uint64_t)i5));
+            hipLaunchKernelGGL(spinor_fill, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->geom, base, base + slice / 2, s->ncomp, seed5, mode);
+            HIPCHK(hipGetLastError());
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return LQCD_OK;

@@ -427,9 +427,12 @@ struct Tunables {
                               // iteration instead of 17, identical iterates); 0 = the generic chain (what the clover / full-lattice solvers run)
     int action_eo_solver = 1; // lqcd_fermi_action / lqcd_calc_UdSfdU, Wilson(-clover): X = (D^+D)^-1 eta through two even-odd BiCGStab solves (Y = D^-+ eta, X = D^-1 Y)
                               // instead of the CG on the normal equations (0: the reference's form); same stopping rule for the same residual (actions.hip)
-    int lazy_links = 1;       // the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,
+    int lazy_links = 0;       // 1: the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,
                               // lqcd_link_staple -> lqcd_link_mul -> lqcd_link_add_ta) are recorded and run as ONE fused launch each, four completed triples of one
-                              // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel
+                              // update as one four-direction launch (md.hip "lazy link triples"); 0: every call launches its own kernel.  The temporaries of a
+                              // completed fused triple are never written, so the plain C ABI is EAGER by default (every field holds what the call says it does);
+                              // the Julia and Python bindings, whose callers hand the temporaries back to their pool unread, switch it on when they create a
+                              // context
     int dw_batched = 1;       // Domainwall operator: the L5 slices of an application as one launch of the scalar-addressing Wilson kernel with the fifth-direction hops in its
                               // epilogue (where that kernel applies: fp64, one GPU, z-planes of whole chunks); 0: L5 Wilson launches + one fifth-direction pass
     int dw_active = 0;        // read-only: the last Domainwall application ran as one five-dimensional launch

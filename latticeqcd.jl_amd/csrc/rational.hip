@@ -355,8 +355,61 @@ extern "C" int lqcd_rational_fit(double alpha, double lam_min, double lam_max, d
 }
 
 // ---------------------------------------------------------------------------------- spectrum of D^+D (Lanczos on the device, scalars on the host)
-extern "C" int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, double* theta_min, double* theta_max) {
-    ARGCHK(op && steps >= 2 && theta_min && theta_max, "lqcd_estimate_spectrum: bad argument");
+// |last component| of the normalised eigenvector of the symmetric tridiagonal (a, b) that belongs to its eigenvalue theta: three steps of inverse iteration,
+// each a tridiagonal solve with partial pivoting (the elimination of LAPACK's dgtsv: the fill-in is one second superdiagonal).
+static double tridiag_last_component(const std::vector<double>& a, const std::vector<double>& b, double theta) {
+    const int n = (int)a.size();
+    if (n == 1) return 1.0;
+    double scale = 0.0;
+    for (int i = 0; i < n; i++) scale = std::max(scale, std::fabs(a[i]) + (i < n - 1 ? std::fabs(b[i]) : 0.0));
+    const double shift = theta + 1e-13 * std::max(scale, 1e-300);      // off the eigenvalue by a few ulps of the matrix norm: (T - shift) is invertible
+    std::vector<double> x(n);
+    for (int i = 0; i < n; i++) x[i] = 1.0 + 0.37 * std::sin(1.7 * i + 0.3);      // a start vector that is not orthogonal to anything in particular
+    for (int sweep = 0; sweep < 3; sweep++) {
+        std::vector<double> d(n), du(n - 1), du2(std::max(0, n - 2), 0.0), dl(n - 1);
+        for (int i = 0; i < n; i++) d[i] = a[i] - shift;
+        for (int i = 0; i < n - 1; i++) { du[i] = b[i]; dl[i] = b[i]; }
+        for (int i = 0; i < n - 1; i++) {
+            if (std::fabs(d[i]) >= std::fabs(dl[i])) {          // no row interchange
+                const double piv = d[i] != 0.0 ? d[i] : 1e-300 * scale;
+                const double m = dl[i] / piv;
+                d[i] = piv;
+                d[i + 1] -= m * du[i];
+                x[i + 1] -= m * x[i];
+                if (i < n - 2) du2[i] = 0.0;
+            } else {                                            // rows i and i + 1 change places
+                const double m = d[i] / dl[i];
+                d[i] = dl[i];
+                const double t = d[i + 1];
+                d[i + 1] = du[i] - m * t;
+                du[i] = t;
+                if (i < n - 2) { du2[i] = du[i + 1]; du[i + 1] = -m * du2[i]; }
+                const double tx = x[i];
+                x[i] = x[i + 1];
+                x[i + 1] = tx - m * x[i + 1];
+            }
+        }
+        if (d[n - 1] == 0.0) d[n - 1] = 1e-300 * scale;
+        x[n - 1] /= d[n - 1];
+        if (n > 1) x[n - 2] = (x[n - 2] - du[n - 2] * x[n - 1]) / d[n - 2];
+        for (int i = n - 3; i >= 0; i--) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
+        double nrm = 0.0;
+        for (int i = 0; i < n; i++) nrm = std::max(nrm, std::fabs(x[i]));
+        for (int i = 0; i < n; i++) x[i] /= nrm;                // (max-norm first: the solve amplifies by 1 / distance to the spectrum)
+        nrm = 0.0;
+        for (int i = 0; i < n; i++) nrm += x[i] * x[i];
+        nrm = std::sqrt(nrm);
+        for (int i = 0; i < n; i++) x[i] /= nrm;
+    }
+    return std::fabs(x[n - 1]);
+}
+
+// Lanczos on D^+D with the residual bound of the extreme Ritz pairs: a Ritz value theta of the k-step tridiagonal with eigenvector s has
+// |D^+D y - theta y| = |beta_k s_k| for its Ritz vector y, so an eigenvalue of D^+D lies within that distance of theta.  The smallest Ritz value
+// converges from above, slowly for an ill-conditioned operator: the run continues past min_steps (checked every 10 steps) until
+// bound_min <= rel_tol theta_min, or gives up at max_steps -- *converged says which.  bound_min / bound_max: the residual bounds of the two ends.
+static int lanczos_certified(lqcd_op_t op, int min_steps, int max_steps, double rel_tol, uint64_t seed, double* theta_min, double* theta_max,
+                             double* bound_min, double* bound_max, int* steps_used, bool* converged) {
     lqcd_ctx_s* c = op->ctx;
     ScratchScope sc(c);
     lqcd_spinor_s *v = sc.get(op->kind, LQCD_FULL), *vp = sc.get(op->kind, LQCD_FULL), *w = sc.get(op->kind, LQCD_FULL);
@@ -368,7 +421,8 @@ extern "C" int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, do
     LQCHK(lqcd_spinor_zero(vp));
     std::vector<double> al, be;
     double beta = 0.0;
-    for (int j = 0; j < steps; j++) {
+    *converged = false;
+    for (int j = 0; j < max_steps; j++) {
         LQCHK(lqcd_op_apply_DdagD(op, w, v));
         double a = 0;
         LQCHK(lqcd_dot(v, w, &a, &im));
@@ -377,17 +431,34 @@ extern "C" int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, do
         al.push_back(a);
         double ww = 0;
         LQCHK(lqcd_norm2(w, &ww));
-        beta = std::sqrt(std::max(ww, 0.0));
-        if (beta < 1e-12 * std::fabs(a) || j == steps - 1) break;
+        beta = std::sqrt(std::max(ww, 0.0));      // beta_{j+1}: the coupling of the (j+1)-step tridiagonal to what it has not seen yet
+        const int k = j + 1;
+        const bool invariant = beta < 1e-12 * std::fabs(a);
+        if (invariant || k == max_steps || (k >= min_steps && (k - min_steps) % 10 == 0)) {
+            std::vector<double> bk(be.begin(), be.begin() + (k - 1));
+            *theta_min = tridiag_eigenvalue(al, bk, 0);
+            *theta_max = tridiag_eigenvalue(al, bk, k - 1);
+            *bound_min = invariant ? 0.0 : beta * tridiag_last_component(al, bk, *theta_min);
+            *bound_max = invariant ? 0.0 : beta * tridiag_last_component(al, bk, *theta_max);
+            *steps_used = k;
+            if (*bound_min <= rel_tol * std::fabs(*theta_min)) { *converged = true; break; }
+            if (invariant || k == max_steps) break;
+        }
         be.push_back(beta);
         LQCHK(lqcd_spinor_copy(vp, v));
         LQCHK(lqcd_spinor_copy(v, w));
         LQCHK(lqcd_scale(1.0 / beta, 0.0, v));
     }
-    be.resize(al.size() - 1);
-    *theta_min = tridiag_eigenvalue(al, be, 0);
-    *theta_max = tridiag_eigenvalue(al, be, (int)al.size() - 1);
     return LQCD_OK;
+}
+
+// the plain k-step estimate (extreme Ritz values, no certificate): what the bindings' estimate_spectrum returns
+extern "C" int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, double* theta_min, double* theta_max) {
+    ARGCHK(op && steps >= 2 && theta_min && theta_max, "lqcd_estimate_spectrum: bad argument");
+    double bmin = 0, bmax = 0;
+    int used = 0;
+    bool conv = false;
+    return lanczos_certified(op, steps, steps, 0.0, seed, theta_min, theta_max, &bmin, &bmax, &used, &conv);
 }
 
 // ---------------------------------------------------------------------------------- FermiAction handle
@@ -397,10 +468,34 @@ struct lqcd_action_s {
     int maxiter = 3000;
     bool rational = false, evensite = false, explicit_interval = false;
     int lanczos_steps = 60, refits = 0;
+    int lanczos_used = 0;              // steps the last certified Lanczos run took, the residual bound |beta_k s_k| of its smallest Ritz value
+    double ritz_bound = 0.0;
     double tol_action = 1e-12, tol_md = 1e-8;
     double lo = 0, hi = 0;
     Fit fit[3];       // 0: x^(-alpha) for the action, 1: the same for the MD force (looser), 2: x^(alpha/2 - 1) for the heat bath
 };
+
+// Spectral interval of D^+D on the current links for the Wilson(-clover) rational action, CERTIFIED: the Lanczos run continues (up to 8 x
+// rhmc_lanczos_steps) until the residual bound of the smallest Ritz value is below 10 % of it; *tmin / *tmax are the Ritz values moved outwards by their
+// bounds.  need_lo: the caller has no lower edge of its own -- an unconverged smallest Ritz value is then an error (a fit made from it could be used
+// outside its interval without anybody noticing), to be resolved with rhmc_lambda_min or more rhmc_lanczos_steps.
+static int action_spectrum(lqcd_action_s* fa, double* tmin, double* tmax, bool need_lo) {
+    double th0 = 0, th1 = 0, b0 = 0, b1 = 0;
+    bool conv = false;
+    const int min_steps = std::max(2, fa->lanczos_steps);
+    LQCHK(lanczos_certified(fa->op, min_steps, 8 * min_steps, 0.1, 4711, &th0, &th1, &b0, &b1, &fa->lanczos_used, &conv));
+    fa->ritz_bound = b0;
+    if (!conv && need_lo) {
+        char buf[400];
+        snprintf(buf, sizeof buf, "FermiAction: the smallest Ritz value of D'D, %.3e, has not converged after %d Lanczos steps (residual bound %.3e): "
+                 "the lower edge of the rational fit cannot be certified -- pass rhmc_lambda_min (and rhmc_lambda_max), or raise rhmc_lanczos_steps", th0, fa->lanczos_used, b0);
+        set_error(buf);
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    *tmin = std::max(th0 - b0, 0.0);
+    *tmax = th1 + b1;
+    return LQCD_OK;
+}
 
 static int action_fit(lqcd_action_s* fa, double lo, double hi) {
     const double al[3] = {fa->alpha, fa->alpha, 1.0 - 0.5 * fa->alpha};
@@ -464,9 +559,9 @@ extern "C" int lqcd_action_create(lqcd_op_t op, double nf, double eps, int maxit
             hi = (op->km * op->km + 16.0) * (1.0 + 1e-9);
         } else {                               // Wilson(-clover): no analytic lower bound -- Lanczos estimate on the current links with a margin
             double tmin = 0, tmax = 0;
-            int st = lqcd_estimate_spectrum(op, fa->lanczos_steps, 4711, &tmin, &tmax);
+            int st = action_spectrum(fa, &tmin, &tmax, !have_lo);
             if (st != LQCD_OK) { delete fa; return st; }
-            lo = have_lo ? plo : 0.5 * tmin;
+            lo = have_lo ? plo : 0.5 * tmin;      // tmin: the certified lower end, smallest Ritz value minus its residual bound
             hi = have_hi ? phi : 1.2 * tmax;
         }
         if (!(lo > 0 && lo < hi)) { delete fa; set_error("FermiAction: need 0 < rhmc_lambda_min < rhmc_lambda_max"); return LQCD_ERR_ARG; }
@@ -499,6 +594,8 @@ extern "C" int lqcd_action_get(lqcd_action_t fa, const char* key, double* value)
     else if (k == "lambda_min") *value = fa->lo;
     else if (k == "lambda_max") *value = fa->hi;
     else if (k == "interval_refits") *value = fa->refits;
+    else if (k == "lanczos_steps_used") *value = fa->lanczos_used;
+    else if (k == "ritz_bound") *value = fa->ritz_bound;
     else if (k == "explicit_interval") *value = fa->explicit_interval;
     else { set_error("lqcd_action_get: unknown key " + k); return LQCD_ERR_ARG; }
     return LQCD_OK;
@@ -537,7 +634,7 @@ extern "C" int lqcd_action_check_interval(lqcd_action_t fa) {
     ARGCHK(fa, "lqcd_action_check_interval: null");
     if (!(fa->rational && fa->op->kind == LQCD_WILSON)) return LQCD_OK;
     double tmin = 0, tmax = 0;
-    LQCHK(lqcd_estimate_spectrum(fa->op, fa->lanczos_steps, 4711, &tmin, &tmax));
+    LQCHK(action_spectrum(fa, &tmin, &tmax, !fa->explicit_interval));      // certified ends: Ritz values moved outwards by their residual bounds
     if (fa->explicit_interval) {
         if (fa->lo <= tmin && tmax <= fa->hi) return LQCD_OK;
         char buf[320];

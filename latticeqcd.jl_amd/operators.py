@@ -45,6 +45,9 @@ class Lattice:
         self.local_L = tuple(lo)
         self.origin = tuple(org)
         self.nranks = int(np.prod(self.pe))
+        # the reference's callers discard the temporaries of their per-direction call triples (unused!, AbstractMD.jl:95-97,113-117): this binding
+        # switches the library's fusion of those triples on (the plain C ABI is eager by default)
+        self.set_param("lazy_links", 1)
 
     # The per-direction call triples of the reference's U_update! / P_update! (AbstractMD.jl:91-93, 108-110) are recorded and fused BELOW the C ABI
     # (csrc/md.hip "lazy link triples", tunable lazy_links); this binding makes one stateless call per generic.  The three attributes below only

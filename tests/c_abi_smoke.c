@@ -156,6 +156,9 @@ int main(void) {
         CHECK(lqcd_momentum_gaussian(P, 9));
         CHECK(lqcd_gauge_copy(Ua, U)); CHECK(lqcd_gauge_copy(Ub, U));
         CHECK(lqcd_gauge_unit(T1)); CHECK(lqcd_gauge_unit(T2));
+        CHECK(lqcd_ctx_get_param(ctx, "lazy_links", &open));
+        if (open != 0) { fprintf(stderr, "the plain C ABI must be eager by default (lazy_links = %d)\n", open); return 1; }
+        CHECK(lqcd_ctx_set_param(ctx, "lazy_links", 1));              /* what the Julia / Python bindings do when they create a context */
         CHECK(lqcd_link_exp(T1, 0, 0.3, P, 1));                       /* recorded */
         CHECK(lqcd_ctx_get_param(ctx, "lazy_open", &open));
         if (open != 1) { fprintf(stderr, "lqcd_link_exp was not recorded (lazy_open = %d)\n", open); return 1; }

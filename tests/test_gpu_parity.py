@@ -64,6 +64,29 @@ def test_upload_download_round_trip_bit_exact(gpu, orc, L):
             assert np.array_equal(got, psi * mask)
 
 
+@pytest.mark.parametrize("L", [(4, 4, 4, 4), (8, 4, 6, 2)])
+def test_half_lattice_random_fill_is_the_matching_half_of_a_full_fill(gpu, L):
+    """gauss_distribution_fermion! / Z4 on an EVEN or ODD field: exactly the numbers that parity of a FULL fill with the same seed receives,
+    nothing written outside the field's one parity block (the fill used to address a second block inside the half field)."""
+    lq = gpu
+    lat = lq.Lattice(L)
+    x, y, z, t = np.meshgrid(*[np.arange(L[mu]) for mu in range(4)], indexing="ij")
+    par = ((x + y + z + t) & 1).transpose(3, 2, 1, 0)
+    for kind in (lq.WILSON, lq.STAGGERED):
+        for fill in (lq.gauss_distribution_fermion_, lq.Z4_distribution_fermi_):
+            full = lq.Fermionfields(lat, kind)
+            fill(full, 77)
+            fh = full.download()
+            for sub, p in ((lq.EVEN, 0), (lq.ODD, 1)):
+                guard = [lq.Fermionfields(lat, kind, sub) for _ in range(3)]      # allocations around the field under test
+                for g in guard:
+                    lq.clear_fermion_(g)
+                fill(guard[1], 77)
+                mask = (par == p)[..., None] if kind == lq.STAGGERED else (par == p)[None, ..., None]
+                assert np.array_equal(guard[1].download(), fh * mask)
+                assert not guard[0].download().any() and not guard[2].download().any()
+
+
 def test_reference_fixture_plaquette_on_gpu(gpu, orc):
     """The reference's thermalised configurations decode and give the golden plaquette on the device."""
     import json

@@ -291,8 +291,16 @@ def test_action_handle_decides_and_fits_below_the_c_abi(lq, orc, name, km, nf, a
     if name == "Staggered":
         assert abs(lo / km ** 2 - 1) < 1e-8 and abs(hi / (km ** 2 + 16) - 1) < 1e-8
     else:
-        tmin, tmax = lq.estimate_spectrum(lq.DdagD_operator(D))
-        assert abs(lo / (0.5 * tmin) - 1) < 1e-12 and abs(hi / (1.2 * tmax) - 1) < 1e-12
+        # the lower edge is CERTIFIED: the Lanczos run continues until the residual bound |beta_k s_k| of the smallest Ritz value is below
+        # 10 % of it, and the fit starts at half of (Ritz value - bound).  Checked against the exact spectrum of the oracle's dense D^+D.
+        w = np.linalg.eigvalsh(orc.dense_DdagD(orc.WILSON, orc.hot_gauge(L, 861), L, km, 1.0, BC))
+        bound, used = fa._get("ritz_bound"), int(fa._get("lanczos_steps_used"))
+        theta = 2.0 * lo + bound                                    # the smallest Ritz value the edge was made from
+        assert used >= 60 and 0.0 <= bound <= 0.1 * theta
+        assert w[0] * (1 - 1e-9) <= theta and np.abs(w - theta).min() <= bound * (1 + 1e-6) + 1e-12      # a Ritz value lies above lambda_min, an eigenvalue within its bound
+        assert lo <= 0.5 * w[0] * (1 + 1e-9) and 1.2 * w[-1] * (1 - 1e-6) <= hi <= 1.2 * w[-1] * 1.1
+        tmin, tmax = lq.estimate_spectrum(lq.DdagD_operator(D))     # the plain 60-step estimate (no certificate) brackets from inside
+        assert tmin >= w[0] * (1 - 1e-9) and tmax <= w[-1] * (1 + 1e-9)
     x = np.exp(np.linspace(np.log(lo), np.log(hi), 9001))
     for which, (power, tol) in enumerate(((alpha, 1e-12), (alpha, 1e-8), (1 - alpha / 2, 1e-12))):
         a0, res, poles = (fa.rhmc_action, fa.rhmc_MD, fa.rhmc_sampling)[which]
