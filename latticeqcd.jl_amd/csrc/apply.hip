@@ -173,12 +173,29 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
     }
+    c->tun.halo_fold_active = 0;
     if (c->tun.halo_stream_mode == 3) {
         // everything in order on the compute stream, no overlap and no cross-queue join: pack -> exchange -> interior -> exterior.  A join costs
         // ~13 us (barrier packets) and the exchange kernel slows the interior it runs beside; at small local volumes with a short exchange that
         // is more than the overlap hides
         if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
         LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 1));
+        // folded (round 5): the ghosts are complete before the stencil launch starts, so that launch takes the boundary hops from them itself (stencil.hip FOLD
+        // instances) -- no exterior launch, no norm corrections, no exterior partials (stencil_num_partials follows halo_fold_applies).  A following
+        // application's faces (pack_next: the D p -> D^+ pair of the fused CG) are packed from the finished output by a pack launch
+        if (halo_fold_applies(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr) && !s.clover_on_hop && !s.dot_partial && !s.alpha_partials && s.dw_ls <= 1) {
+            StencilCall f = s;
+            f.fold = 1;
+            c->tun.halo_fold_active = 1;
+            LQCHK(launch_stencil_interior(c, f));
+            if (s.pack_next >= 0) {
+                StencilCall pk = s;
+                pk.in[0] = s.out[0]; pk.in[1] = s.out[1];
+                pk.dagger = s.pack_next;
+                LQCHK(launch_stencil_pack(c, pk));
+            }
+            return LQCD_OK;
+        }
         LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
     }
@@ -205,6 +222,22 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+}
+
+// The halo schedule of a partitioned context is chosen by timing, at the first plain full-lattice application (halo_stream_mode = -1 above), and the choice decides
+// how many |.|^2 partials an application writes (the folded schedule has no exterior corrections).  A solver that counts partials settles the choice first.
+int halo_schedule_settle(lqcd_op_s* op) {
+    lqcd_ctx_s* c = op->ctx;
+    if (c->tun.halo_stream_mode >= 0 || !any_partitioned(c) || !c->has_comm || !c->local_peers.empty() || op->kind == LQCD_DOMAINWALL) return LQCD_OK;
+    lqcd_spinor_s* a = scratch_get(c, op->kind, LQCD_FULL);
+    lqcd_spinor_s* b = scratch_get(c, op->kind, LQCD_FULL);
+    int st = (a && b) ? LQCD_OK : LQCD_ERR_HIP;
+    if (st == LQCD_OK && hipMemsetAsync(a->data, 0, a->elems * sizeof(double2), c->stream) != hipSuccess) st = LQCD_ERR_HIP;
+    if (st == LQCD_OK) st = op_apply_async(op, b, a, 0, nullptr);
+    if (st == LQCD_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = LQCD_ERR_HIP;
+    if (a) scratch_put(a);
+    if (b) scratch_put(b);
+    return st;
 }
 
 // ---------------------------------------------------------------------------------- operator -> stencil calls

@@ -280,6 +280,8 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "nt_blas")) return &c->tun.nt_blas;
     if (!strcmp(key, "cg_fold_scalars")) return &c->tun.cg_fold_scalars;
     if (!strcmp(key, "halo_fuse")) return &c->tun.halo_fuse;
+    if (!strcmp(key, "halo_fold")) return &c->tun.halo_fold;
+    if (!strcmp(key, "halo_fold_active")) return &c->tun.halo_fold_active;
     if (!strcmp(key, "cg_defer_x")) return &c->tun.cg_defer_x;
     if (!strcmp(key, "staggered_parity_solve")) return &c->tun.staggered_parity_solve;
     if (!strcmp(key, "halo_tuned_us0")) return &c->tun.halo_tuned_us[0];

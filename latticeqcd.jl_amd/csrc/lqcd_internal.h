@@ -385,6 +385,10 @@ struct Tunables {
     int halo_tuned_us[4] = {0, 0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
+    int halo_fold = 1;        // halo schedule 3 (everything in order on one stream), Wilson r = 1, fp64, scalar-addressing kernel, x unpartitioned: the interior launch reads
+                              // the ghost buffers itself (the exchange is complete before it starts) -- no exterior launch, no norm corrections (stencil.hip FOLD instances);
+                              // 0: the separate exterior kernel
+    int halo_fold_active = 0; // read-only: the last partitioned stencil application ran folded (no exterior launch)
     int halo_fuse = 2;        // partitioned fused CG (Wilson, fp64): bit 0 = the exterior's last block does the final reduction (no reduce_final launch),
                               // bit 1 = the exterior of D p packs the faces D^+ needs and the x/p update packs the new p (no pack launches).
                               // One-GPU proxy at the N = 8 local volume (profiles/r03_halo_fuse_proxy.log): bit 1 +1.2 %, bit 0 -7 % (the last
@@ -677,6 +681,8 @@ struct StencilCall {
     double dw_mass = 0.0;
     int clover_on_hop = 0;        // 1 (fp64 direction-split kernel, r = 1): `clover` holds packed blocks that are applied to the HOP SUM, out = a xin + b C (H in) -- the
                                   // inverse clover blocks of the even-odd Wilson-clover solver; the diagonal term stays plain
+    int fold = 0;                 // set by stencil_apply (folded one-stream halo schedule): the exchange is complete when the interior launch starts and that launch takes
+                                  // the boundary hops from the ghost buffers itself -- no exterior launch, the |.|^2 partials of the interior are complete
 };
 // slots of the device scalar block d_scal used by the solvers
 enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18 };
@@ -719,11 +725,13 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);
 int make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, StencilCall& s);
+int halo_schedule_settle(lqcd_op_s* op);   // partitioned context with halo_stream_mode = -1: run the one-off schedule timing now (apply.hip)
 int op_refresh_clover(lqcd_op_s* op);   // rebuilds A when the links moved; clover_version follows only a successful build
 void apply_bc(lqcd_ctx_s* c, const int bc[4]);
 int op_apply_async(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, double* norm_partial, const double* skip_flag = nullptr);
 int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int maxiter, bool fixed, int* iters, double* final_rr);
 bool any_partitioned(lqcd_ctx_s* c);
+bool halo_fold_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover);   // the folded one-stream schedule runs for such a call (stencil.hip)
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec = 0, bool clover = false);
 bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s);      // a StencilCall with dw_ls > 1 can run (stencil.hip)

@@ -338,7 +338,8 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         // tmp = D p for the D^+ that follows and the x/p update packs the new search direction for the next D p (no pack launches).
         // Wilson r = 1 only (a general-r application is two r = 1 passes with different projectors).
         const bool part = any_partitioned(c) && c->has_comm && c->local_peers.empty();
-        const bool fr = part && (c->tun.halo_fuse & 1);
+        const bool folded = part && halo_fold_applies(c, op->kind, op->r, 2, 0, op_fused_clover(op));      // no exterior launch: nothing for bit 0 to ride on
+        const bool fr = part && (c->tun.halo_fuse & 1) && !folded;
         const bool fp = part && defer && (c->tun.halo_fuse & 2) && op->kind == LQCD_WILSON && op->r == 1.0;
         {
             apply_bc(c, op->bc);      // another operator of this context (other boundary signs) may have been applied since the last iteration of an open session
@@ -434,6 +435,7 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
 int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n = x->elems;
+    LQCHK(halo_schedule_settle(op));      // the iteration counts |.|^2 partials: the halo schedule (folded or not) is fixed from here on
     // r = b - D^+ D x ; p = r
     LQCHK(op_apply_async(op, w.tmp, x, 0, nullptr));
     LQCHK(op_apply_async(op, w.q, w.tmp, 1, nullptr));
@@ -1349,6 +1351,7 @@ extern "C" int lqcd_solve_multishift_cg(lqcd_op_t op, lqcd_spinor_t x0, lqcd_spi
         HIPCHK(hipStreamSynchronize(c->stream));
         int it = 0;
         bool converged = rr < eps;
+        LQCHK(halo_schedule_settle(op));
         const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op)), nbu = stream_grid(c, n), check_every = 8;
         while (!converged && it < maxiter) {
             const int burst = std::min(check_every, maxiter - it);

@@ -337,6 +337,13 @@ struct PipeArgs {
     unsigned long long slice_bytes;      // bytes between the same parity block of consecutive slices
     FastDiv d_ls;
     real dw_mass;
+    // FOLD instance (partitioned lattice, one-stream schedule: the exchange is complete when the kernel starts): the hops that leave the rank are taken
+    // from the ghost buffers by the SAME launch -- no exterior kernel, complete |.|^2 partials.  Bit mu of fold: direction mu (1, 2, 3) is partitioned.
+    int fold;
+    const real2* gh_f[4];     // ghost of the forward hop at the upper face: P psi(n + mu) packed by the +mu neighbour ([slot][6][Fh], HArgs::recv_fwd)
+    const real2* gh_b[4];     // ghost of the backward hop at the lower face: U^+ P psi(n - mu) from the -mu neighbour (HArgs::recv_bwd)
+    int Fh[4];                // sites of a face per parity
+    real gsf[4], gsb[4];      // sign of a ghost hop: the boundary condition where this rank sits on the global boundary, else 1
 };
 
 // next virtual block for this workgroup: from queue q (virtual blocks 8 j + q, j = 0 .. nvirt/8 - 1, handed out in order), moving on to the
@@ -379,6 +386,8 @@ struct PipeSite {
     unsigned uf, ub;           // link byte offsets inside the gauge field's parity block
     real sf, sb;
     int p;
+    bool wf, wb;               // the forward / backward hop of this direction wraps the local lattice (MU >= 2: wave-uniform)
+    int fidx;                  // index of the site inside the face of direction MU (coords_to_face), MU >= 1
 };
 template <int MU, int NL>      // NL: 16-byte elements per link (9: 18 reals, 6: 12 reals)
 __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
@@ -403,6 +412,8 @@ __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
         s.ub = (unsigned)cb * LKC + MU * LKM + (unsigned)lane * LKL;
         s.sf = wf ? a.sgn_f[MU] : real(1.0);
         s.sb = wb ? a.sgn_b[MU] : real(1.0);
+        s.wf = wf; s.wb = wb;
+        s.fidx = ((MU == 2 ? t : z) * a.cpp + yc) * 64 + lane;      // z face: (x, y, t); t face: (x, y, z) -- the z-plane index of the site + the plane count
     } else {
         const int cbp = yc * 64 + lane;               // index inside the z-plane
         const int y = fdiv(cbp, a.dXH), xh = cbp - y * a.XH;
@@ -424,6 +435,8 @@ __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
         s.ub = (unsigned)(nb >> 6) * LKC + MU * LKM + (unsigned)(nb & 63) * LKL;
         s.sf = wf ? a.sgn_f[MU] : real(1.0);
         s.sb = wb ? a.sgn_b[MU] : real(1.0);
+        s.wf = wf; s.wb = wb;
+        s.fidx = xh + a.XH * (z + a.L2 * t);          // y face: (x, z, t)
     }
     return s;
 }
@@ -661,7 +674,45 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
 // load, no branch around a load.  Per launch -20 % VALU and -42 % SALU instructions than variant 1 (profiles/r03_pmc_pipe_static.csv), i.e. a
 // shorter way from dispatch to the first load.  Same operations in the same order per site, same |.|^2 partial per workgroup: bit-identical to
 // variant 1 including the CG iterates.
-template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false>
+// FOLD instances: the operands of a hop that leaves the rank.  The ghost of a face site holds the SPIN-PROJECTED half spinor (6 components, stride Fh) the pack
+// kernels wrote: it is loaded into components 0..5 and the other six are zero, so the projection that follows reproduces it (h = ghost + i^k 0; t direction:
+// the factor 2 of the projection is undone by the sign, which takes a factor 1/2 -- exact).  The backward ghost is U^+ P psi already: its link is the unit
+// matrix (rows 0, 1; row 2 rebuilt or set), so su3_mv returns h.  Same instructions for face and bulk lanes, no exterior kernel, complete |.|^2 partials.
+// z / t faces are whole chunks (face is wave-uniform: a scalar branch around the loads); the y face is one row of four inside a chunk (per-lane select).
+template <int MU, int NS, int F0>
+__device__ inline void fold_load_spinor(cd* sp, const real2* __restrict__ reg, const real2* __restrict__ ghost, int Fh, bool face) {
+    if constexpr (MU >= 2) {
+        if (face) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) sp[j] = ld(ghost + (size_t)j * Fh);
+#pragma unroll
+            for (int j = 6; j < NS; j++) sp[j] = mk(0.0, 0.0);
+        } else load_comps12<F0, NS, false>(sp, reg);
+    } else {
+        const real2* __restrict__ src = face ? ghost : reg + co12(F0);
+        const size_t st = face ? (size_t)Fh : co12(1);
+#pragma unroll
+        for (int j = 0; j < 6; j++) sp[j] = ld(src + (size_t)j * st);
+#pragma unroll
+        for (int j = 6; j < NS; j++) {
+            const cd v = ld(reg + co12(F0 + j));
+            sp[j].re = face ? real(0.0) : v.re;      // (component by component: a select between two structs is lowered through scratch memory)
+            sp[j].im = face ? real(0.0) : v.im;
+        }
+    }
+}
+template <int MU, bool R12>
+__device__ inline void fold_unit_link(cd (&u)[9], bool face) {      // (called with the link loaded: MU == 1 selects per lane, MU >= 2 overwrites under the scalar branch)
+    constexpr int N = R12 ? 6 : 9;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const real dg = (j == 0 || j == 4 || j == 8) ? real(1.0) : real(0.0);
+        u[j].re = face ? dg : u[j].re;
+        u[j].im = face ? real(0.0) : u[j].im;
+    }
+}
+
+template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false>
 __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim) {
     // DW5: this workgroup's slice s5 of the five-dimensional fields; block ids keep their XCD (b & 7) and the L5 slices of a chunk follow each other on it, so the
     // links of the chunk are fetched from the fabric once and hit the XCD's L2 for the other slices
@@ -732,9 +783,22 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
         reconstruct<MU, -SF>(acc, chi0, chi1);
     }
 #else
+    // FOLD: this lane's forward / backward hop leaves the rank -- its operand is the ghost (MU >= 2: wave-uniform)
+    bool gF = false, gB = false;
+    real sgF = s.sf, sgB = s.sb;
+    if constexpr (FOLD && MU >= 1) {
+        if ((a.fold >> MU) & 1) {
+            constexpr real half = MU == 3 ? real(0.5) : real(1.0);
+            gF = s.wf; gB = s.wb;
+            sgF = gF ? half * a.gsf[MU] : s.sf;
+            sgB = gB ? half * a.gsb[MU] : s.sb;
+        }
+    }
+    const size_t gslot = FOLD ? (size_t)(a.both ? s.p : 0) * 6 * (size_t)a.Fh[MU] + (size_t)s.fidx : 0;
     {
         cd sF[NS], uF[9], dF[2];
-        load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
+        if constexpr (FOLD && MU >= 1) fold_load_spinor<MU, NS, FF>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf), a.gh_f[MU] + gslot, a.Fh[MU], gF);
+        else load_comps12<FF, NS, false>(sF, boff(s.p ? a.in[0] : a.in[1], s.nf));
         load_link_any<R12, false>(uF, boff(a.gauge + (s.p ? gpar : 0), s.uf), 64);
         if constexpr (DELTA) { dF[0] = ld(boff(a.gauge + (s.p ? gpar : 0), s.uf) + 6 * 64); dF[1] = ld(boff(a.gauge + (s.p ? gpar : 0), s.uf) + 7 * 64); }
 #if LQCD_SDIR_GLDS
@@ -755,7 +819,7 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
         if constexpr (DELTA) add_delta_row2(uF, dF);
 #endif
         project_regs<MU, SF>(h0, h1, sF);
-        pipe_sign(h0, h1, s.sf);
+        pipe_sign(h0, h1, sgF);
         su3_mv<false>(chi0, uF, h0);
         su3_mv<false>(chi1, uF, h1);
         reconstruct<MU, SF>(acc, chi0, chi1);
@@ -769,8 +833,18 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
 #pragma unroll
         for (int j = 0; j < NS; j++) sB[j] = ld(&part[MU][j][lane]);
 #else
-        load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
-        load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        if constexpr (FOLD && MU >= 2) {
+            fold_load_spinor<MU, NS, FB>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb), a.gh_b[MU] + gslot, a.Fh[MU], gB);
+            if (gB) fold_unit_link<MU, R12>(uB, true);      // (scalar branch: the ghost is U^+ P psi already, no link is read)
+            else load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        } else if constexpr (FOLD && MU == 1) {
+            fold_load_spinor<MU, NS, FB>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb), a.gh_b[MU] + gslot, a.Fh[MU], gB);
+            load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+            fold_unit_link<MU, R12>(uB, gB);
+        } else {
+            load_comps12<FB, NS, false>(sB, boff(s.p ? a.in[0] : a.in[1], s.nb));
+            load_link_any<R12, NTB>(uB, boff(a.gauge + (s.p ? 0 : gpar), s.ub), 64);
+        }
 #endif
         if constexpr (DELTA) {
             const real2* db = boff(a.gauge + (s.p ? 0 : gpar), s.ub);
@@ -782,7 +856,7 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
         if constexpr (DELTA) add_delta_row2(uB, dB);
 #endif
         project_regs<MU, -SF>(h0, h1, sB);
-        pipe_sign(h0, h1, s.sb);
+        pipe_sign(h0, h1, sgB);
         su3_mv<true>(chi0, uB, h0);
         su3_mv<true>(chi1, uB, h1);
         reconstruct<MU, -SF>(acc, chi0, chi1);
@@ -842,7 +916,7 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
     }
 }
 
-template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false>
+template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false>
 __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
     __shared__ double red[DOT ? 12 : 4];
@@ -863,10 +937,10 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     const int lane = threadIdx.x & 63;
     real nrm = 0.0, dre = 0.0, dim = 0.0;
     switch (w) {
-    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
-    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
+    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
     }
     if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue
         double t3[3] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm};
@@ -1475,6 +1549,16 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     a.ctr = c->pipe_ctr; a.per_wg = 1;
     a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
     a.ls = s.dw_ls; a.slice_bytes = (unsigned long long)s.dw_slice * sizeof(real2); a.d_ls = make_fastdiv(std::max(1, s.dw_ls)); a.dw_mass = (real)s.dw_mass;
+    a.fold = 0;
+    for (int mu = 0; mu < 4; mu++) {
+        // ghost buffers of this call's message size: [recv_bwd | recv_fwd] back to back (make_hargs' rule)
+        const size_t cnt = (size_t)(s.parity_mode == 2 ? 2 : 1) * 6 * face_half_sites(c->geom, mu);
+        a.gh_b[mu] = (const real2*)c->recv_bwd[mu]; a.gh_f[mu] = (const real2*)c->recv_bwd[mu] + cnt;
+        a.Fh[mu] = face_half_sites(c->geom, mu);
+        a.gsf[mu] = (c->coord[mu] == c->pe[mu] - 1) ? real(c->geom.bc_fwd[mu]) : real(1.0);
+        a.gsb[mu] = (c->coord[mu] == 0) ? real(c->geom.bc_bwd[mu]) : real(1.0);
+        if (s.fold && k.g.part[mu]) a.fold |= 1 << mu;
+    }
     return a;
 }
 
@@ -1484,7 +1568,7 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         KArgs k = make_kargs(c, s, 64);
         const size_t pad = (size_t)c->tun.lds_pad_kb * 1024;
         // "12 + delta" links are read by the scalar-addressing Wilson kernel alone: every other launch takes the 18 stored reals
-        const bool delta = s.gauge12_delta && !kF32Build && s.kind == LQCD_WILSON && k.gauge12 && !k.alpha_partials && !k.dot_partial && !s.clover_on_hop && !k.clover &&
+        const bool delta = s.gauge12_delta && !kF32Build && s.kind == LQCD_WILSON && k.gauge12 && !k.alpha_partials && !k.dot_partial && !s.clover_on_hop && !k.clover && !s.fold &&
                            c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false);
         if (s.gauge12_delta && !delta) { k.gauge12 = nullptr; c->tun.recon_active = 0; }
         if (s.kind == LQCD_STAGGERED) {
@@ -1553,6 +1637,14 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                 if (!k.gauge12) { set_error("stencil: the five-dimensional launch reads the 12-real links"); return LQCD_ERR_UNSUPPORTED; }      // (its 18-real instance spills 154 VGPRs)
                 if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, false, false, true>), g5, pb, 0, c->stream, a);
                 else hipLaunchKernelGGL((wilson_dirsplit_s<false, true, false, false, false, true>), g5, pb, 0, c->stream, a);
+            } else
+            if (s.fold) {      // partitioned lattice, exchange complete (apply.hip, folded one-stream schedule): boundary hops from the ghost buffers in this launch
+                if (persist || delta || s.dw_ls > 1 || k.g.part[0]) { set_error("stencil: the folded launch needs the scalar-addressing kernel and an unpartitioned x direction"); return LQCD_ERR_UNSUPPORTED; }
+#define LQ_FOLD(D, R) do { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<D, R, true, false, false, false, true>), pg, pb, 0, c->stream, a); \
+                           else hipLaunchKernelGGL((wilson_dirsplit_s<D, R, false, false, false, false, true>), pg, pb, 0, c->stream, a); } while (0)
+                if (k.gauge12) { if (s.dagger) LQ_FOLD(true, true); else LQ_FOLD(false, true); }
+                else { if (s.dagger) LQ_FOLD(true, false); else LQ_FOLD(false, false); }
+#undef LQ_FOLD
             } else
             if (delta) {       // rows 0, 1 + fp32 deviation of row 2 (reference-format configurations); plain loads for the backward link as well: the
                                // non-temporal form measured 0.3962 against 0.3915 ms at 32^3x64 (profiles/r04_links_12_plus_delta.log)
@@ -1717,9 +1809,19 @@ bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, boo
     if (c->tun.dslash_pipe == 2 || c->tun.dslash_pipe == 3) return true;      // hardware dispatch order: no minimum size
     return nvirt >= std::max(1, c->tun.pipe_min_chunks) * wilson_pipe_grid(c, nvirt, 0);
 }
-// interior block partials + (partitioned lattice) the exterior kernel's correction partials
+// The folded one-stream halo schedule (apply.hip stencil_apply; tunable halo_fold): pack -> exchange -> ONE stencil launch that reads the ghost buffers itself.
+// Where: the RCCL path with schedule 3 chosen, Wilson r = 1 in fp64 on the scalar-addressing kernel (either link format: dslash_s18), no clover term in the
+// launch, x unpartitioned (the x face cuts through chunks lane by lane; the recommended PE grids keep x whole).
+bool halo_fold_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
+    if (!c->tun.halo_fold || c->tun.halo_stream_mode != 3 || kF32Build) return false;
+    if (!any_partitioned(c) || !c->has_comm || !c->local_peers.empty() || c->geom.part[0]) return false;
+    if (kind != LQCD_WILSON || prec != 0 || clover || c->tun.dslash_pipe != 2 || !c->tun.dslash_s18) return false;
+    (void)r;      // on a partitioned lattice a general-r application is two r = 1 calls (apply.hip split_general_r): the launch geometry is the r = 1 one for every r
+    return wilson_pipe_applies(c, kind, 1.0, parity_mode, false);
+}
+// interior block partials + (partitioned lattice, unless the launch is folded) the exterior kernel's correction partials
 int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
-    const int nt = max_face_threads(c, parity_mode);
+    const int nt = halo_fold_applies(c, kind, r, parity_mode, prec, clover) ? 0 : max_face_threads(c, parity_mode);
     return stencil_num_blocks(c, kind, r, parity_mode, prec, clover) + (nt > 0 ? ((nt + 127) / 128) * 8 : 0);
 }
 #endif

@@ -152,6 +152,27 @@ for (k, c), v in sorted(acc.items()):
 PY
     done
     ;;
+  fold)       # round 5: folded halo schedule (boundary hops inside the stencil launch) -- tests, the N = 8 / 4 / 2 one-die proxy with halo_fold 0 / 1, kernel timelines
+    timeout 900 python -m pytest tests/test_gpu_halo_fuse.py -q -x 2>&1 | tail -6 | tee $out/pytest.log
+    timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "half_lattice or rccl or c_abi or partitioned" 2>&1 | tail -4 | tee -a $out/pytest.log
+    timeout 900 python -m pytest tests/test_gpu_rhmc.py tests/test_gpu_reference_callers.py tests/test_gpu_md_partitioned.py tests/test_gpu_hmc_partitioned.py -q -x 2>&1 | tail -4 | tee -a $out/pytest.log
+    for f in 0 1; do for extra in "" "--set nt_blas=0" "--set nt_blas=0 --set nt_store=0"; do
+      LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 200 --warm 20 --cg 400 --set halo_stream_mode=3 --set halo_fold=$f $extra 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=8 fold=$f /"; echo
+    done; done | tee $out/proxy.log
+    for f in 0 1; do
+      LQCD_FORCE_PARTITION=12 timeout 200 python scripts/dslash_probe.py --lattice 32,32,16,32 --selfcomm 1 --reps 200 --warm 20 --cg 300 --set halo_stream_mode=3 --set halo_fold=$f 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=4 fold=$f /"; echo
+      LQCD_FORCE_PARTITION=8 timeout 200 python scripts/dslash_probe.py --lattice 32,32,32,32 --selfcomm 1 --reps 200 --warm 20 --cg 300 --set halo_stream_mode=3 --set halo_fold=$f 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=2 fold=$f /"; echo
+    done | tee -a $out/proxy.log
+    LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 200 --warm 20 --cg 400 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=8 tuner /" | tee -a $out/proxy.log; echo
+    timeout 200 python scripts/dslash_probe.py --lattice 32,32,32,64 --reps 200 --warm 20 --cg 300 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=1 /" | tee -a $out/proxy.log; echo
+    for f in 0 1; do
+      (cd /tmp && LQCD_FORCE_PARTITION=14 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/trace$f -o t -- python $GRAFT_REPO_ROOT/scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 20 --warm 5 --cg 64 --set halo_stream_mode=3 --set halo_fold=$f 2>&1 | grep "^cg")
+      t=$(find $out/trace$f -name "*kernel_trace.csv" | head -1)
+      echo "== halo_fold $f (halo_stream_mode 3)" | tee -a $out/timeline.log
+      python scripts/timeline.py "$t" cg_update_odd 2>&1 | tee -a $out/timeline.log
+      rm -rf $out/trace$f
+    done
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

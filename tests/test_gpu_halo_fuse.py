@@ -1,4 +1,5 @@
-"""Partitioned fused CG with the fused tails of the exterior / update launches (tunable halo_fuse): bit 0 = the
+"""Partitioned fused CG with the folded halo schedule (round 5, tunable halo_fold: schedule 3 with the boundary hops taken from the ghost buffers inside the
+stencil launch, no exterior kernel) and the fused tails of the exterior / update launches (tunable halo_fuse): bit 0 = the
 exterior kernel's last block sums the |.|^2 partials (no reduce_final launch), bit 1 = the exterior of D p packs the faces D^+ needs and the
 x/p update packs the new search direction (no pack launches).  Run through the real RCCL path on one GPU (self-partition, world-size-1
 communicators).  Pre-packed faces carry the bits a pack launch would have produced, so bit 1 alone must not change a single bit of the
@@ -18,6 +19,7 @@ CODE = textwrap.dedent("""
     import latticeqcd_jl_amd as lq
     from oracle import oracle as orc
     L, K, BC = %s, 0.141139, (1, 1, 1, -1)
+    FOLDS = %d          # the folded halo schedule applies to this lattice / partition mask
     lat = lq.Lattice(L)
     lat.comm_init(lq.comm_unique_id())
     U = orc.hot_gauge(L, 111)
@@ -28,18 +30,36 @@ CODE = textwrap.dedent("""
     xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, K, 1.0, BC, eps=1e-19)
     assert st == 0
     sols = {}
+    folded = 0
+    y = x.similar()
     for mode in (-1, 0, 1, 2, 3):
+      for hfold in ((1, 0) if mode in (-1, 3) else (0,)):          # halo_fold acts on schedule 3 (which the tuner, mode -1, may pick)
+        lat.set_param("halo_fold", hfold)
         for fold in (1, 0):
             for fuse in (0, 1, 2, 3):
                 lat.set_param("halo_stream_mode", mode); lat.set_param("cg_fold_scalars", fold); lat.set_param("halo_fuse", fuse)
                 sol = x.similar()
                 it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(D), x, return_info=True)
+                folded += lat.get_param("halo_fold_active")
                 s = sol.download()
                 err = np.abs(s - xo).max() / np.abs(xo).max()
-                assert abs(it - ito) <= 1 and rr < 1e-19 and err < 1e-9, (mode, fold, fuse, it, ito, rr, err)
-                sols[(mode, fold, fuse)] = s
-            assert np.array_equal(sols[(mode, fold, 0)], sols[(mode, fold, 2)]), ("pre-packed faces changed the solution", mode, fold)
-            assert np.array_equal(sols[(mode, fold, 1)], sols[(mode, fold, 3)]), ("pre-packed faces changed the solution", mode, fold)
+                assert abs(it - ito) <= 1 and rr < 1e-19 and err < 1e-9, (mode, hfold, fold, fuse, it, ito, rr, err)
+                sols[(mode, hfold, fold, fuse)] = s
+            if mode == -1 and hfold:      # the tuner may pick the folded schedule for one solve and another for the next: equal to rounding only
+                continue
+            assert np.array_equal(sols[(mode, hfold, fold, 0)], sols[(mode, hfold, fold, 2)]), ("pre-packed faces changed the solution", mode, hfold, fold)
+            assert np.array_equal(sols[(mode, hfold, fold, 1)], sols[(mode, hfold, fold, 3)]), ("pre-packed faces changed the solution", mode, hfold, fold)
+        # the folded schedule's Dslash (boundary hops from the ghost buffers inside the stencil launch) against the oracle, D and D^+
+        lat.set_param("halo_stream_mode", mode)
+        for dag in (False, True):
+            lq.mul_(y, D.adjoint() if dag else D, x)
+            ref = orc.apply_D(lq.WILSON, U, psi, L, K, 1.0, BC, dag)
+            e = np.abs(y.download() - ref).max() / np.abs(ref).max()
+            assert e < 1e-13, (mode, hfold, dag, e)
+        if mode == 3 and hfold and FOLDS:
+            assert lat.get_param("halo_fold_active") == 1, "the folded schedule did not run where it applies"
+    assert (folded > 0) == bool(FOLDS), (folded, FOLDS)
+    lat.set_param("halo_fold", 1)
     # the staggered operator takes the fused reduction only
     Ds = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Staggered", "mass": 0.5, "boundarycondition": BC, "eps_CG": 1e-19})
     ps = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 113)
@@ -61,10 +81,12 @@ CODE = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("L,mask", [((8, 4, 6, 8), "8"), ((8, 4, 6, 8), "14"), ((8, 4, 6, 8), "15"), ((16, 8, 8, 4), "14")])
-def test_fused_tails_on_the_rccl_path(lq, L, mask):
+# folds: z-planes of whole chunks (XH * LY a multiple of 64), the chunks of a t-slice split over 8 XCDs, x unpartitioned (stencil.hip halo_fold_applies)
+@pytest.mark.parametrize("L,mask,folds", [((8, 4, 6, 8), "8", 0), ((8, 4, 6, 8), "14", 0), ((8, 4, 6, 8), "15", 0), ((16, 8, 8, 4), "14", 1), ((16, 8, 8, 4), "8", 1),
+                                          ((16, 8, 8, 4), "15", 0), ((16, 16, 8, 4), "12", 1), ((32, 4, 8, 6), "6", 1)])
+def test_fused_tails_on_the_rccl_path(lq, L, mask, folds):
     assert lq.lib.device_count() > 0, "no HIP device visible: the product has no CPU fallback"
     env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", CODE % (L,)], capture_output=True, text=True, env=env, timeout=600,
+    r = subprocess.run([sys.executable, "-c", CODE % (L, folds)], capture_output=True, text=True, env=env, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "HALO_FUSE_OK" in r.stdout, (mask, r.stdout[-1500:], r.stderr[-3000:])
