@@ -783,6 +783,8 @@ class CovNeuralnet:
 
 def calc_smearedU(U, nn):
     """calc_smearedU(U, cov_neural_net) (standardMD.jl:91,207; standardHMC.jl:68) -> (Uout, Uout_multi, nothing); Uout_multi[k] = the links after layer k + 1."""
+    if nn is None:      # update! reaches this with cov_neural_net = nothing (standardHMC.jl:67 compares the VALUE nothing with the TYPE Nothing): the links themselves
+        return U, None, None
     cur = U
     for layer, out in zip(nn.layers, nn._out):
         check(_l.lib().lqcd_stout_smear(out._h, cur._h, C.c_double(layer.rho)))
