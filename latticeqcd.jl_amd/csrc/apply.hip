@@ -100,8 +100,15 @@ bool any_partitioned(lqcd_ctx_s* c) {
 }
 
 // full stencil on one rank: pack -> (exchange || interior) -> exterior
+int flush_waiting_pack(lqcd_ctx_s* c) {      // a pack launch left waiting by the folded schedule whose reduction never came: run it on its own
+    if (!c->has_waiting_pack) return LQCD_OK;
+    c->has_waiting_pack = false;
+    return launch_stencil_pack(c, *static_cast<StencilCall*>(c->waiting_pack));
+}
+
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     HIPCHK(hipSetDevice(c->device));
+    LQCHK(flush_waiting_pack(c));
     if (s.prec == 2) return launch_pair32_interior(c, s);      // fp32 site-pair fields (unpartitioned lattices only: checked by the launcher)
     if (!any_partitioned(c)) return s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s);
     if (s.kind == LQCD_WILSON && s.r != 1.0) {
@@ -192,7 +199,11 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
                 StencilCall pk = s;
                 pk.in[0] = s.out[0]; pk.in[1] = s.out[1];
                 pk.dagger = s.pack_next;
-                LQCHK(launch_stencil_pack(c, pk));
+                if (s.defer_pack) {      // the caller's reduction of this application's partials is the next launch: the pack rides in it (reduce_pack_to_slot)
+                    if (!c->waiting_pack) c->waiting_pack = new StencilCall;
+                    *static_cast<StencilCall*>(c->waiting_pack) = pk;
+                    c->has_waiting_pack = true;
+                } else LQCHK(launch_stencil_pack(c, pk));
             }
             return LQCD_OK;
         }

@@ -47,48 +47,6 @@ __global__ __launch_bounds__(RB) void norm2_kernel(const double2* __restrict__ a
 // sums nblocks partials of `nvals` interleaved values into scal[slot..slot+nvals) in a fixed order (1024 threads, each a
 // strided partial sum, then a wave/LDS tree), optionally followed by a CG scalar step on the same thread (single rank):
 //   op 1: alpha = rr / pq      op 2: beta = rr'/rr, rr = rr', iters++, done = rr' < eps     (flags: see ops.hip)
-constexpr int FB = 1024;
-__device__ inline void cg_scalar_step(double* s, int op) {
-    if (op == 1) {
-        if (s[S_DONE] != 0.0) { s[S_XDONE] = 1.0; return; }
-        s[S_ALPHA] = s[S_RR] / s[S_PQ];
-    } else if (op == 2) {
-        if (s[S_DONE] != 0.0) return;
-        const double rrn = s[S_RRNEW];
-        s[S_BETA] = rrn / s[S_RR];
-        s[S_RR] = rrn;
-        s[S_ITERS] += 1.0;
-        if (rrn < s[S_EPS]) s[S_DONE] = 1.0;
-    } else if (op >= 3 && op <= 6) {
-        // BiCGStab (ops.hip bicgstab_core): 3 alpha = rho/<r0,v> ; 4 half-step test on |s|^2 ; 5 omega = <t,s>/|t|^2 ;
-        // 6 iters++, convergence / breakdown, beta = (rho'/rho)(alpha/omega), rho = rho'
-        if (s[B_DONE] != 0.0) return;
-        if (op == 3) {
-            c2 rho = {s[B_RHO], s[B_RHO + 1]}, r0v = {s[B_R0V], s[B_R0V + 1]};
-            const c2 a = bicg_alpha(rho, r0v);
-            s[B_ALPHA] = a.re;
-            s[B_ALPHA + 1] = a.im;
-        } else if (op == 4) {
-            s[B_HALF] = (s[B_SS] < s[B_EPS]) ? 1.0 : 0.0;
-        } else if (op == 5) {
-            c2 ts = {s[B_TS], s[B_TS + 1]};
-            const c2 w = bicg_omega(ts, s[B_TT], s[B_HALF] != 0.0);     // half step: x += alpha p only, r = s
-            s[B_OMEGA] = w.re;
-            s[B_OMEGA + 1] = w.im;
-        } else {
-            s[B_ITERS] += 1.0;
-            const double rr = (s[B_HALF] != 0.0) ? s[B_SS] : s[B_RR];
-            s[B_RES] = rr;
-            if (s[B_HALF] != 0.0 || rr < s[B_EPS]) { s[B_DONE] = 1.0; return; }
-            if (!(fabs(rr) <= 1.79e308)) { s[B_DONE] = 2.0; return; }     // NaN / inf: breakdown
-            c2 rho1 = {s[B_RHO1], s[B_RHO1 + 1]}, rho = {s[B_RHO], s[B_RHO + 1]}, al = {s[B_ALPHA], s[B_ALPHA + 1]}, om = {s[B_OMEGA], s[B_OMEGA + 1]};
-            const c2 b = bicg_beta(rho1, rho, al, om);
-            s[B_BETA] = b.re;
-            s[B_BETA + 1] = b.im;
-            s[B_RHO] = rho1.re; s[B_RHO + 1] = rho1.im;
-        }
-    }
-}
 __global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op) {
     __shared__ double red[FB / 64];
     if (nblocks <= 1024) {      // small reductions: one wave, in the order the folded prologues use (sum_partials_small_nv) -- a latency chain of
@@ -102,19 +60,9 @@ __global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ pa
         return;
     }
     for (int v = 0; v < nvals; v++) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int i = threadIdx.x;
-        for (; i + 3 * FB < nblocks; i += 4 * FB) {
-            s0 += partial[(size_t)i * nvals + v];
-            s1 += partial[(size_t)(i + FB) * nvals + v];
-            s2 += partial[(size_t)(i + 2 * FB) * nvals + v];
-            s3 += partial[(size_t)(i + 3 * FB) * nvals + v];
-        }
-        for (; i < nblocks; i += FB) s0 += partial[(size_t)i * nvals + v];
-        double s = (s0 + s1) + (s2 + s3);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        const double s = sum_partials_class(partial, nblocks, nvals, v, (int)threadIdx.x);      // this thread's class of partials (lqcd_internal.h)
+        const double w = shfl_tree_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0;
@@ -193,6 +141,23 @@ int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allredu
     HIPCHK(hipGetLastError());
     if (multi) {
         NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm_red, c->stream));
+        if (cg_op) {
+            hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return LQCD_OK;
+}
+
+// reduce_to_slot(nvals = 1, with the all-reduce) when the folded halo schedule left a pack launch waiting (StencilCall::defer_pack): both in ONE launch
+// (stencil.hip wilson_pack_reduce: the same summation order as reduce_final, bit for bit)
+int reduce_pack_to_slot(lqcd_ctx_s* c, int nblocks, int slot, int cg_op) {
+    if (!c->has_waiting_pack) return reduce_to_slot(c, nblocks, 1, slot, true, cg_op);
+    c->has_waiting_pack = false;
+    const bool multi = c->has_comm;
+    LQCHK(launch_pack_reduce(c, *static_cast<StencilCall*>(c->waiting_pack), c->d_partial, nblocks, slot, multi ? 0 : cg_op));
+    if (multi) {
+        NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, 1, ncclDouble, ncclSum, c->comm_red, c->stream));
         if (cg_op) {
             hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
             HIPCHK(hipGetLastError());

@@ -274,6 +274,78 @@ __device__ inline c2 bicg_beta(c2 rho1, c2 rho, c2 alpha, c2 omega) {   // beta 
     return b;
 }
 
+// ---------------------------------------------------------------- the summation order of LARGE reductions (more than 1024 block partials)
+// reduce_final (blas.hip, one block of FB = 1024 threads): thread c owns the class of partials c, c + FB, c + 2 FB, ... and sums it with four interleaved
+// accumulators; the 64 class sums of a wave go through a __shfl_down tree, the 16 wave sums are added in sequence by thread 0.  The pieces live here because a
+// second kernel reproduces that order bit for bit with 256 threads (stencil.hip wilson_pack_reduce: thread t owns classes t, t + 256, t + 512, t + 768).
+constexpr int FB = 1024;
+__device__ inline double sum_partials_class(const double* __restrict__ partial, int nblocks, int nvals, int v, int cls) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int i = cls;
+    for (; i + 3 * FB < nblocks; i += 4 * FB) {
+        s0 += partial[(size_t)i * nvals + v];
+        s1 += partial[(size_t)(i + FB) * nvals + v];
+        s2 += partial[(size_t)(i + 2 * FB) * nvals + v];
+        s3 += partial[(size_t)(i + 3 * FB) * nvals + v];
+    }
+    for (; i < nblocks; i += FB) s0 += partial[(size_t)i * nvals + v];
+    return (s0 + s1) + (s2 + s3);
+}
+__device__ inline double shfl_tree_sum(double s) {      // lane 0 holds the sum of the wave's 64 values (the order every reduction of this library uses)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    return s;
+}
+
+// ---------------------------------------------------------------- the CG / BiCGStab scalar steps behind a reduction (one thread)
+// slots of the device scalar block d_scal used by the solvers
+enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18 };
+// BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
+enum { B_RHO = 24, B_R0V = 26, B_VV = 28, B_ALPHA = 29, B_SS = 31, B_TS = 32, B_TT = 34, B_OMEGA = 35, B_RR = 37, B_RHO1 = 38, B_BETA = 40,
+       B_DONE = 42, B_ITERS = 43, B_EPS = 44, B_HALF = 45, B_RES = 46, B_RHOB = 47, B_END = 49 };      // B_R0V..B_VV, B_TS..B_TT and B_RR..B_RHO1 are filled by one
+                                                                                                     // 3-value reduction each; B_RHOB: second rho slot of the fused chain
+__device__ inline void cg_scalar_step(double* s, int op) {
+    if (op == 1) {
+        if (s[S_DONE] != 0.0) { s[S_XDONE] = 1.0; return; }
+        s[S_ALPHA] = s[S_RR] / s[S_PQ];
+    } else if (op == 2) {
+        if (s[S_DONE] != 0.0) return;
+        const double rrn = s[S_RRNEW];
+        s[S_BETA] = rrn / s[S_RR];
+        s[S_RR] = rrn;
+        s[S_ITERS] += 1.0;
+        if (rrn < s[S_EPS]) s[S_DONE] = 1.0;
+    } else if (op >= 3 && op <= 6) {
+        // BiCGStab (ops.hip bicgstab_core): 3 alpha = rho/<r0,v> ; 4 half-step test on |s|^2 ; 5 omega = <t,s>/|t|^2 ;
+        // 6 iters++, convergence / breakdown, beta = (rho'/rho)(alpha/omega), rho = rho'
+        if (s[B_DONE] != 0.0) return;
+        if (op == 3) {
+            c2 rho = {s[B_RHO], s[B_RHO + 1]}, r0v = {s[B_R0V], s[B_R0V + 1]};
+            const c2 a = bicg_alpha(rho, r0v);
+            s[B_ALPHA] = a.re;
+            s[B_ALPHA + 1] = a.im;
+        } else if (op == 4) {
+            s[B_HALF] = (s[B_SS] < s[B_EPS]) ? 1.0 : 0.0;
+        } else if (op == 5) {
+            c2 ts = {s[B_TS], s[B_TS + 1]};
+            const c2 w = bicg_omega(ts, s[B_TT], s[B_HALF] != 0.0);     // half step: x += alpha p only, r = s
+            s[B_OMEGA] = w.re;
+            s[B_OMEGA + 1] = w.im;
+        } else {
+            s[B_ITERS] += 1.0;
+            const double rr = (s[B_HALF] != 0.0) ? s[B_SS] : s[B_RR];
+            s[B_RES] = rr;
+            if (s[B_HALF] != 0.0 || rr < s[B_EPS]) { s[B_DONE] = 1.0; return; }
+            if (!(fabs(rr) <= 1.79e308)) { s[B_DONE] = 2.0; return; }     // NaN / inf: breakdown
+            c2 rho1 = {s[B_RHO1], s[B_RHO1 + 1]}, rho = {s[B_RHO], s[B_RHO + 1]}, al = {s[B_ALPHA], s[B_ALPHA + 1]}, om = {s[B_OMEGA], s[B_OMEGA + 1]};
+            const c2 b = bicg_beta(rho1, rho, al, om);
+            s[B_BETA] = b.re;
+            s[B_BETA + 1] = b.im;
+            s[B_RHO] = rho1.re; s[B_RHO + 1] = rho1.im;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- counter-based RNG (identical bits on every rank / decomposition)
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -542,6 +614,8 @@ struct lqcd_ctx_s {
     void* cg_session = nullptr;   // open timing session of lqcd_cg_session_* (ops.hip), if any
     int num_cu = 256;
     lqcd::LazyLinks lazy;         // recorded single-direction link operations (md.hip)
+    bool has_waiting_pack = false;   // folded halo schedule: the pack launch for the next application waits for the reduction it shares a launch with (apply.hip, blas.hip)
+    void* waiting_pack = nullptr;    // its StencilCall (owned)
 };
 
 struct lqcd_gauge_s {
@@ -681,15 +755,11 @@ struct StencilCall {
     double dw_mass = 0.0;
     int clover_on_hop = 0;        // 1 (fp64 direction-split kernel, r = 1): `clover` holds packed blocks that are applied to the HOP SUM, out = a xin + b C (H in) -- the
                                   // inverse clover blocks of the even-odd Wilson-clover solver; the diagonal term stays plain
+    int defer_pack = 0;           // folded schedule, pack_next >= 0: the caller sums this application's |.|^2 partials next (reduce_pack_to_slot) -- the pack launch for the
+                                  // following application waits in the context and runs as ONE launch with that reduction
     int fold = 0;                 // set by stencil_apply (folded one-stream halo schedule): the exchange is complete when the interior launch starts and that launch takes
                                   // the boundary hops from the ghost buffers itself -- no exterior launch, the |.|^2 partials of the interior are complete
 };
-// slots of the device scalar block d_scal used by the solvers
-enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18 };
-// BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
-enum { B_RHO = 24, B_R0V = 26, B_VV = 28, B_ALPHA = 29, B_SS = 31, B_TS = 32, B_TT = 34, B_OMEGA = 35, B_RR = 37, B_RHO1 = 38, B_BETA = 40,
-       B_DONE = 42, B_ITERS = 43, B_EPS = 44, B_HALF = 45, B_RES = 46, B_RHOB = 47, B_END = 49 };      // B_R0V..B_VV, B_TS..B_TT and B_RR..B_RHO1 are filled by one
-                                                                                                     // 3-value reduction each; B_RHOB: second rho slot of the fused chain
 // stencil.hip, once per precision (p64 is the inline namespace everywhere except in the fp32 build of stencil.hip).
 // With prec = 1 the field pointers of a StencilCall address float2 data (cast), scalars stay double.
 #ifdef LQCD_F32      // reopen each namespace the way it was declared at the top of this header
@@ -725,6 +795,7 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);
 int make_full_call(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger, StencilCall& s);
+int flush_waiting_pack(lqcd_ctx_s* c);       // apply.hip
 int halo_schedule_settle(lqcd_op_s* op);   // partitioned context with halo_stream_mode = -1: run the one-off schedule timing now (apply.hip)
 int op_refresh_clover(lqcd_op_s* op);   // rebuilds A when the links moved; clover_version follows only a successful build
 void apply_bc(lqcd_ctx_s* c, const int bc[4]);
@@ -753,6 +824,8 @@ int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n);
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n);
 int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0, const double* partial = nullptr);   // partial: default the context's d_partial
 int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op);
+int reduce_pack_to_slot(lqcd_ctx_s* c, int nblocks, int slot, int cg_op);      // reduce_to_slot(nvals = 1, all-reduce) + the pack launch the folded schedule left waiting (StencilCall::defer_pack)
+LQCD_REOPEN_P64 { int launch_pack_reduce(lqcd_ctx_s* c, const StencilCall& s, const double* partial, int nblocks, int slot, int op); }
 int stream_grid(lqcd_ctx_s* c, size_t n);
 
 // clover.hip

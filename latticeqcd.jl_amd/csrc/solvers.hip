@@ -348,10 +348,10 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
             s1.norm_partial = c->d_partial;
             s1.skip_flag = c->tun.cg_skip_done ? c->d_scal : nullptr;      // a no-op once the solve has converged inside a burst
             if (fr) s1.red_slot = S_PQ;
-            if (fp) { s1.pack_next = 1; s1.prepacked = (w.p_packed && w.pack_epoch == c->halo_epoch) ? 1 : 0; }
+            if (fp) { s1.pack_next = 1; s1.prepacked = (w.p_packed && w.pack_epoch == c->halo_epoch) ? 1 : 0; s1.defer_pack = folded ? 1 : 0; }
             LQCHK(stencil_apply(c, s1));
         }
-        LQCHK(fr ? reduce_tail(c, 1, S_PQ, fold ? 0 : 1) : reduce_to_slot(c, nbs, 1, S_PQ, true, fold ? 0 : 1));      // + alpha = rr / pq
+        LQCHK(fr ? reduce_tail(c, 1, S_PQ, fold ? 0 : 1) : reduce_pack_to_slot(c, nbs, S_PQ, fold ? 0 : 1));      // + alpha = rr / pq (+ the pack launch the folded schedule left waiting)
         apply_bc(c, op->bc);
         StencilCall s2;
         LQCHK(make_full_call(op, po, w.tmp, 1, s2));          // update mode writes r only: `out` is a placeholder (the buffer that is dead until the p update)

@@ -1171,6 +1171,47 @@ __global__ __launch_bounds__(128) void wilson_pack(HArgs k) {
     }
 }
 
+#ifndef LQCD_F32
+// Pack launch of the folded schedule with the final reduction of the application's |.|^2 partials riding along (fused CG: D p -> [pack D p for D^+ | sum |D p|^2] ->
+// exchange -> D^+): grid (x, 9), row 0 = ONE reduction block (dispatched first), rows 1..8 = the pack blocks of wilson_pack with 256 threads each.  The reduction
+// reproduces reduce_final (blas.hip) bit for bit -- small sums: the one-wave order; large sums: thread t owns the classes t, t + 256, t + 512, t + 768 of the
+// 1024-thread kernel, one __shfl_down tree per class group, the 16 wave sums added in sequence -- so iterates do not depend on which launch did the sum.
+__global__ __launch_bounds__(256) void wilson_pack_reduce(HArgs k, const double* __restrict__ partial, int nblocks, double* scal, int slot, int op) {
+    if (blockIdx.y == 0) {
+        if (blockIdx.x != 0) return;
+        __shared__ double red[FB / 64];
+        if (nblocks <= 1024) {
+            if (threadIdx.x < 64) {
+                const double t = sum_partials_small_nv(partial, nblocks, 1, 0);
+                if (threadIdx.x == 0) { scal[slot] = t; if (op) cg_scalar_step(scal, op); }
+            }
+            return;
+        }
+        const int w = (int)threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double t = shfl_tree_sum(sum_partials_class(partial, nblocks, 1, 0, (int)threadIdx.x + 256 * q));
+            if ((threadIdx.x & 63) == 0) red[w + 4 * q] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0;
+            for (int j = 0; j < FB / 64; j++) t += red[j];
+            scal[slot] = t;
+            if (op) cg_scalar_step(scal, op);
+        }
+        return;
+    }
+    const int y = (int)blockIdx.y - 1, side = y & 1;
+    switch (y >> 1) {
+    case 0: wilson_pack_dir<0>(k, side); break;
+    case 1: wilson_pack_dir<1>(k, side); break;
+    case 2: wilson_pack_dir<2>(k, side); break;
+    default: wilson_pack_dir<3>(k, side); break;
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------ halo: exterior (fused)
 // out(n) += b * (all hop contributions that crossed a rank boundary).  ONE launch: blockIdx.y = 2*mu + side enumerates the
 // faces; a boundary site that lies on several faces (edges, corners) is OWNED by its lowest partitioned direction (and,
@@ -1739,6 +1780,19 @@ int launch_stencil_pack(lqcd_ctx_s* c, const StencilCall& s) {
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
+
+#ifndef LQCD_F32
+// the pack launch of `s` (Wilson) + the sum of nblocks |.|^2 partials into d_scal[slot] (+ a CG scalar step), one launch (wilson_pack_reduce)
+int launch_pack_reduce(lqcd_ctx_s* c, const StencilCall& s, const double* partial, int nblocks, int slot, int op) {
+    const int nt = max_face_threads(c, s.parity_mode);
+    HArgs h = make_hargs(c, s);
+    c->halo_epoch++;
+    dim3 grid(std::max(1, (nt + 255) / 256), 9), block(256);
+    hipLaunchKernelGGL(wilson_pack_reduce, grid, block, 0, c->stream, h, partial, nblocks, c->d_scal, slot, op);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+#endif
 
 int launch_stencil_exterior(lqcd_ctx_s* c, const StencilCall& s) {
     const int nt = max_face_threads(c, s.parity_mode);

@@ -1,7 +1,7 @@
 """Device-resident HMC streams for the statistical parity tests (tests/test_gpu_hmc_statistics.py) and scripts/hmc_stats.py.
 One trajectory = the reference's update!(::StandardHMC) (standardHMC.jl:41-91) with runMD_QPQ! (standardMD.jl:127-144) or
-runMD_QPQ_sw! (:146-166), written with the fused four-direction calls (the per-direction transliteration is
-tests/test_gpu_reference_callers.py)."""
+runMD_QPQ_sw! (:146-166), written with the fused four-direction calls (the callers' own per-direction sequences are replayed from their
+call trace in tests/test_gpu_reference_callers.py)."""
 import os
 
 import numpy as np

@@ -1,6 +1,6 @@
 """Dirac_operator = "Domainwall" (universe.jl:116-128; test/test_domainwallhmc.toml; the fifth HMC fermion test of test/runtests.jl:132-137) against the
 oracle's restatement (oracle/oracle.py domainwall_*: numpy over the C Wilson operator, itself checked by identities in tests/test_oracle_domainwall.py), and
-the reference's test case -- Domainwall_m = 1 = the Pauli-Villars mass -- through the transliterated callers."""
+the reference's test case -- Domainwall_m = 1 = the Pauli-Villars mass -- through the reference's callers replayed from their call trace."""
 import os
 
 import numpy as np
@@ -149,8 +149,8 @@ def test_force_is_the_derivative_of_the_device_action(lq, orc):
 def test_reference_test_case_pauli_villars_mass_is_a_spectator(lq, orc):
     """test/test_domainwallhmc.toml: Domainwall_m = 1.0 = the Pauli-Villars mass, M = -1, L5 = 4, beta 5.7, dtau 0.05, 20 MD steps, started from the
     4x4x2x2 configuration of test/confs_HMC_L04040404_beta5.7_Domainwall.  D = D_PV: S_f = phi^+ phi for every gauge field and the fermion force vanishes, so the
-    trajectory is the quenched one with a spectator field -- through the reference's unchanged callers (transliterated in test_gpu_reference_callers.py)."""
-    import test_gpu_reference_callers as rc
+    trajectory is the quenched one with a spectator field -- through the reference's unchanged callers, replayed from their call trace (tests/ref_trace.py)."""
+    from ref_trace import Replay, standard_hmc, standard_md
     L = (4, 4, 2, 2)
     Uh = lq.gauge_io.load_BridgeText(os.path.join(GOLDEN, "domainwall_4x4x2x2.ildg.txt"), L)
     plaq_file = orc.plaquette(Uh, L)
@@ -168,13 +168,18 @@ def test_reference_test_case_pauli_villars_mass_is_a_spectator(lq, orc):
             D = lq.Dirac_operator(U, x, {"Dirac_operator": "Domainwall", "mass": 1.0, "L5": 4, "M": -1.0, "eps_CG": 1e-19, "verbose_level": 2,
                                          "MaxCGstep": 3000, "boundarycondition": BC})
             fa = lq.FermiAction(D, {})
-        hmc = rc.StandardHMC(lq, U, ga, quench, 0.05, 20, fa, seed=5)
-        acc = [rc.update_(hmc, U) for _ in range(2)]
-        res[quench] = (U.download(), hmc.dH, acc, lq.calculate_Plaquette(U))
+        md = standard_md(lq, U, ga, 0.05, 20, fermi_action=fa)
+        hmc, dHs = standard_hmc(lq, U, md), []
+        # (the momenta take the first seed of a trajectory in both runs: the quenched replay skips the two pseudofermion draws, so seeds are set per trajectory)
+        rp = Replay(lq, hooks={("after", "update!"): lambda env: dHs.append(env["Snew"] - env["Sold"])})
+        acc = []
+        for traj in range(2):
+            rp.seed, rp.rng = 5 + 10 * traj, np.random.default_rng(5 + 10 * traj)
+            acc.append(rp.call("update!", hmc, U))
+        res[quench] = (U.download(), dHs, acc, lq.calculate_Plaquette(U))
         if not quench:
-            md = hmc.md
-            S = lq.evaluate_FermiAction(fa, U, md.eta)
-            assert abs(S - lq.dot(md.eta, md.eta).real) < 1e-9 * S      # S_f = phi^+ phi on the evolved links
+            S = lq.evaluate_FermiAction(fa, U, md["η"])
+            assert abs(S - lq.dot(md["η"], md["η"]).real) < 1e-9 * S      # S_f = phi^+ phi on the evolved links
     assert np.abs(res[False][0] - res[True][0]).max() < 1e-8            # the same links as the quenched trajectory (same momenta seeds) ...
     assert np.abs(np.array(res[False][1]) - np.array(res[True][1])).max() < 1e-7      # ... and the same dH: the spectator's action does not move
     assert all(abs(d) < 0.5 for d in res[False][1])

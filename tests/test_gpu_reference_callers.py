@@ -1,249 +1,139 @@
-"""The reference's UNCHANGED callers, transliterated line by line on top of the per-direction interface they really use
-(U[mu], p[mu], one temporary link field at a time), must reproduce the fused four-direction trajectory of tests/test_gpu_md.py.
-
-Transliterated (Julia `!` -> `_`, `μ = 1:Dim` kept 1-based, everything else verbatim):
-  U_update!, P_update!, P_update_fermion!        /root/reference/src/md/AbstractMD.jl:78-135
-  StandardMD, initialize_MD!, runMD_QPQ_sw!      /root/reference/src/md/standardMD.jl:5-166
-  update!(::StandardHMC)                         /root/reference/src/updates/standardHMC.jl:41-91
-  the construction of gauge_action / fermi_action  /root/reference/src/system/universe.jl:88-138
-The only liberties: the random numbers (the device generators are counter based and take a seed; the accept test draws from
-numpy) -- the reference's own RNG stream is not reproducible outside Julia either."""
+"""The reference's UNCHANGED callers on the device-backed field types.  Their call sequences are DATA here -- tests/golden/ref_call_trace.json, generated
+from /root/reference by tests/golden/make_ref_call_trace.py: for U_update!, P_update!, both P_update_fermion! methods, initialize_MD!, runMD!,
+runMD_QPQ!, runMD_QPQ_sw!, runMD_PQP! and update! the ordered list of generic calls with the role of every argument, loop bounds and conditions -- and
+tests/ref_trace.py replays them against the binding, one binding function per generic (U[mu], p[mu], one temporary link field at a time, exactly the
+interface the callers use).  What comes out is compared with the CPU ORACLE's trajectory from the same momenta and pseudofermion (tests/oracle_md.py on
+oracle/oracle.py's primitives), not with another device path.
+Reference sites: /root/reference/src/md/AbstractMD.jl:78-135, src/md/standardMD.jl:82-227, src/updates/standardHMC.jl:41-91, src/system/universe.jl:88-138."""
 import os
 
 import numpy as np
 import pytest
 
+import oracle_md
 from conftest import GOLDEN, rel_err
-from test_gpu_md import BC, BETA, KAPPA, DeviceHMC
+from ref_trace import Raised, Replay, standard_hmc, standard_md
+from test_gpu_md import BC, BETA, KAPPA
 
 pytestmark = pytest.mark.gpu
 Dim = 4
+L4 = (4, 4, 4, 4)
 
 
-class StandardMD:
-    """struct StandardMD + its constructor (standardMD.jl:5-80)."""
-
-    def __init__(self, lq, U, gauge_action, quench, dtau, MDsteps, fermi_action=None, QPQ=True, SextonWeingargten=False, Nsw=2):
-        self.lq = lq
-        self.p = lq.initialize_TA_Gaugefields(U)      # p = initialize_TA_Gaugefields(U)
-        if quench:
-            self.eta = self.xi = None
-            if SextonWeingargten:
-                raise RuntimeError("The quench update does not need the SextonWeingargten method. Put SextonWeingargten = false")
-        elif fermi_action is None:
-            self.eta = self.xi = None
-        else:
-            self.eta = fermi_action._temporary_fermionfields[0].similar()    # η = similar(fermi_action._temporary_fermionfields[1])
-            self.xi = self.eta.similar()                                      # ξ = similar(η)
-        assert Nsw % 2 == 0, f"Nsw should be even number! now Nsw = {Nsw}"
-        self.gauge_action, self.quench, self.dtau, self.MDsteps = gauge_action, quench, dtau, MDsteps
-        self.QPQ, self.fermi_action, self.SextonWeingargten, self.Nsw = QPQ, fermi_action, SextonWeingargten, Nsw
-        self.seed = 0
+def plaquette_action(lq, U, beta):
+    """The gauge action the reference's runs build (universe.jl:88-96): the plaquette loops and their adjoints with coefficient beta / 2."""
+    ga = lq.GaugeAction(U)
+    ga.push_(beta / 2, lq.make_loops_fromname("plaquette", Dim=Dim) + lq.make_loops_fromname("plaquette", Dim=Dim, adjoint=True))
+    return ga
 
 
-def U_update_(U, p, eps, md):                                   # AbstractMD.jl:78-98
-    lq = md.lq
-    temps = lq.get_temporary_gaugefields(md.gauge_action)
-    temp1, it_temp1 = lq.get_temp(temps)
-    temp2, it_temp2 = lq.get_temp(temps)
-    expU, it_expU = lq.get_temp(temps)
-    W, it_W = lq.get_temp(temps)
-    for mu in range(1, Dim + 1):
-        lq.exptU_(expU, eps * md.dtau, p[mu], [temp1, temp2])
-        lq.mul_(W, expU, U[mu])
-        lq.substitute_U_(U[mu], W)
-    lq.unused_(temps, it_temp1)
-    lq.unused_(temps, it_temp2)
-    lq.unused_(temps, it_expU)
-    lq.unused_(temps, it_W)
-
-
-def P_update_(U, p, eps, md):                                   # AbstractMD.jl:100-118   p -> p + factor*U*dSdUμ
-    lq = md.lq
-    NC = U[1].NC
-    temps = lq.get_temporary_gaugefields(md.gauge_action)
-    dSdUmu, its_dSdUmu = lq.get_temp(temps)
-    factor = -eps * md.dtau / NC
-    temp1, it_temp1 = lq.get_temp(temps)
-    for mu in range(1, Dim + 1):
-        lq.calc_dSdUmu_(dSdUmu, md.gauge_action, mu, U)
-        lq.mul_(temp1, U[mu], dSdUmu)                          # U*dSdUμ
-        lq.Traceless_antihermitian_add_(p[mu], factor, temp1)
-    lq.unused_(temps, its_dSdUmu)
-    lq.unused_(temps, it_temp1)
-
-
-def P_update_fermion_(U, p, eps, md):                           # AbstractMD.jl:120-135
-    lq = md.lq
-    temps = lq.get_temporary_gaugefields(md.gauge_action)
-    UdSfdUmu, its_UdSfdUmu = lq.get_temp(temps, Dim)
-    factor = -eps * md.dtau
-    lq.calc_UdSfdU_(UdSfdUmu, md.fermi_action, U, md.eta)
-    for mu in range(1, Dim + 1):
-        lq.Traceless_antihermitian_add_(p[mu], factor, UdSfdUmu[mu - 1])
-    lq.unused_(temps, its_UdSfdUmu)
-
-
-def initialize_MD_(U, md):                                      # standardMD.jl:82-101
-    lq = md.lq
-    md.seed += 3
-    lq.gauss_distribution_(md.p, md.seed)                       # gauss_distribution!(md.p)  #initial momentum
-    if not md.quench:
-        lq.gauss_sampling_in_action_(md.xi, U, md.fermi_action, md.seed + 1)
-        lq.sample_pseudofermions_(md.eta, U, md.fermi_action, md.xi)
-
-
-def runMD_QPQ_sw_(U, md):                                       # standardMD.jl:146-166
-    p = md.p
-    for itrj in range(md.MDsteps):
-        for isw in range(md.Nsw // 2):
-            U_update_(U, p, 0.5 / md.Nsw, md)
-            P_update_(U, p, 1.0 / md.Nsw, md)
-            U_update_(U, p, 0.5 / md.Nsw, md)
-        if not md.quench:
-            P_update_fermion_(U, p, 1.0, md)
-        for isw in range(md.Nsw // 2):
-            U_update_(U, p, 0.5 / md.Nsw, md)
-            P_update_(U, p, 1.0 / md.Nsw, md)
-            U_update_(U, p, 0.5 / md.Nsw, md)
-
-
-def runMD_QPQ_(U, md):                                          # standardMD.jl:127-144
-    p = md.p
-    for itrj in range(md.MDsteps):
-        U_update_(U, p, 0.5, md)
-        P_update_(U, p, 1.0, md)
-        if not md.quench:
-            P_update_fermion_(U, p, 1.0, md)
-        U_update_(U, p, 0.5, md)
-
-
-def runMD_(U, md):                                              # standardMD.jl:103-125
-    if md.QPQ:
-        if md.SextonWeingargten:
-            runMD_QPQ_sw_(U, md)
-        else:
-            runMD_QPQ_(U, md)
-    else:
-        raise RuntimeError("PQP update is not transliterated")
-
-
-class StandardHMC:                                              # standardHMC.jl:1-38
-    def __init__(self, lq, U, gauge_action, quench, dtau, MDsteps, fermi_action, SextonWeingargten=False, QPQ=True, Nsw=2, seed=0):
-        self.md = StandardMD(lq, U, gauge_action, quench, dtau, MDsteps, fermi_action, QPQ=QPQ, SextonWeingargten=SextonWeingargten, Nsw=Nsw)
-        self.md.seed = seed
-        self.Uold = U.similar()
-        self.rng = np.random.default_rng(seed)
-        self.dH = []
-
-
-def update_(updatemethod, U):                                   # standardHMC.jl:41-91
-    md = updatemethod.md
-    lq = md.lq
-    NC = U[1].NC
-    Uold = updatemethod.Uold
-    lq.substitute_U_(Uold, U)                                   # previous configuration
-    initialize_MD_(U, md)
-    Sp = md.p * md.p / 2
-    Sg = -lq.evaluate_GaugeAction(md.gauge_action, U) / NC
-    Sold = Sp + Sg
-    if not md.quench:
-        Sfold = lq.dot(md.xi, md.xi).real
-        Sold += Sfold
-    runMD_(U, md)
-    Sp = md.p * md.p / 2
-    Sg = -lq.evaluate_GaugeAction(md.gauge_action, U) / NC
-    Snew = Sp + Sg
-    if not md.quench:
-        Sfnew = lq.evaluate_FermiAction(md.fermi_action, U, md.eta)
-        Snew += Sfnew
-    updatemethod.dH.append(Snew - Sold)
-    accept = np.exp(Sold - Snew) >= updatemethod.rng.random()
-    if not accept:
-        lq.substitute_U_(U, Uold)                               # back to previous configuration
-    return accept
-
-
-def _universe(lq, U, kappa, beta):
-    """universe.jl:88-138: gauge_action = GaugeAction(U); push!(gauge_action, beta/2, plaqloop + plaqloop'); D; FermiAction(D, Dict())."""
-    gauge_action = lq.GaugeAction(U)
-    plaqloop = lq.make_loops_fromname("plaquette", Dim=Dim)
-    plaqloop = plaqloop + lq.make_loops_fromname("plaquette", Dim=Dim, adjoint=True)      # append!(plaqloop, plaqloop')
-    gauge_action.push_(beta / 2, plaqloop)
+def wilson_action(lq, U, kappa, eps=1e-19):
+    """Two flavours of Wilson fermions with the parameter dictionary of universe.jl:103-138."""
     x = lq.Initialize_pseudofermion_fields(U[1], "Wilson", nowing=True)
-    params = {"Dirac_operator": "Wilson", "κ": kappa, "r": 1.0, "faster version": True, "eps_CG": 1e-19, "verbose_level": 2,
-              "MaxCGstep": 3000, "boundarycondition": BC}
-    D = lq.Dirac_operator(U, x, params)
-    fermi_action = lq.FermiAction(D, {})
-    return gauge_action, fermi_action
+    D = lq.Dirac_operator(U, x, {"Dirac_operator": "Wilson", "κ": kappa, "r": 1.0, "faster version": True, "eps_CG": eps, "verbose_level": 2,
+                                 "MaxCGstep": 3000, "boundarycondition": BC})
+    return lq.FermiAction(D, {})
 
 
 def _fixture(lq):
-    L = (4, 4, 4, 4)
-    Uh = lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L)
-    return L, Uh
+    return lq.gauge_io.load_ildg(os.path.join(GOLDEN, "wilson_4x4x4x4.ildg"), L4)
 
 
-def test_single_direction_entry_points_match_the_fused_ones(lq, orc):
-    """P_update! / U_update! written with U[mu], p[mu] and temporaries (5 single-direction C entry points) = the fused kernels."""
+def test_replayed_momentum_and_link_updates_match_the_oracle(lq, orc):
+    """P_update! / U_update! replayed from the trace (per direction: calc_dSdUμ! -> mul! -> Traceless_antihermitian_add!, exptU! -> mul! -> substitute_U!)
+    against the oracle's gauge_force / momentum_add_ta / link_update, and against the fused four-direction entry points."""
     L = (8, 4, 6, 4)
     lat = lq.Lattice(L)
     Uh, Ph = orc.hot_gauge(L, 31), orc.gaussian_momenta(L, 32)
     U1, P1 = lq.Gaugefields(lat).upload(Uh), lq.Gaugefields(lat).upload(Ph)
     U2, P2 = lq.Gaugefields(lat).upload(Uh), lq.Gaugefields(lat).upload(Ph)
-    ga = lq.GaugeAction(U1)
-    ga.push_(BETA / 2, lq.make_loops_fromname("plaquette") + lq.make_loops_fromname("plaquette", adjoint=True))
-
-    class MD:
-        pass
-    md = MD()
-    md.lq, md.gauge_action, md.dtau = lq, ga, 0.05
-    P_update_(U1, P1, 0.3, md)
+    ga = plaquette_action(lq, U1, BETA)
+    md = standard_md(lq, U1, ga, 0.05, 20)
+    rp = Replay(lq)
+    rp.call("P_update!", U1, P1, 0.3, md)
+    assert [n for n in rp.log if n.endswith("!")].count("calc_dSdUμ!") == Dim
+    Po = orc.momentum_add_ta(Ph.copy(), 0.3 * 0.05, orc.gauge_force(Uh, L, BETA), L)
+    assert rel_err(P1.download(), Po) < 1e-13
     lq.P_update_(U2, P2, 0.3 * 0.05, BETA)
     assert rel_err(P1.download(), P2.download()) < 1e-14
-    U_update_(U1, P1, 0.7, md)
+    rp.call("U_update!", U1, P1, 0.7, md)
+    Uo = orc.link_update(Uh.copy(), Po, 0.7 * 0.05, L)
+    assert rel_err(U1.download(), Uo) < 1e-13
     lq.U_update_(U2, P2, 0.7 * 0.05)
     assert rel_err(U1.download(), U2.download()) < 1e-14
-    # staple alone against the oracle's force:  G = -(beta/6) U * A  and  dSdUmu = (beta/2) A
-    G = lq.Gaugefields(lat)
-    lq.gauge_force_(G, U2, BETA)
-    Gh, U2h = G.download(), U2.download()
+    # the staple generic on its own:  U[mu] * dSdUmu = -3 G_mu with the oracle's G = -(beta/6) U A
+    Go = orc.gauge_force(Uo, L, BETA)
     temps = lq.get_temporary_gaugefields(ga)
     dS, it = lq.get_temp(temps)
     T, it2 = lq.get_temp(temps)
     for mu in range(1, 5):
-        lq.calc_dSdUmu_(dS, ga, mu, U2)
-        lq.mul_(T, U2[mu], dS)
-        assert rel_err(-T.download() / 3.0, Gh[mu - 1]) < 1e-13
+        lq.calc_dSdUmu_(dS, ga, mu, U1)
+        lq.mul_(T, U1[mu], dS)
+        assert rel_err(-T.download() / 3.0, Go[mu - 1]) < 1e-13
     lq.unused_(temps, [it, it2])
-    assert abs(-lq.evaluate_GaugeAction(ga, U2) / 3 - lq.evaluate_GaugeAction(U2, BETA)) < 1e-9
-    assert abs(P1 * P1 / 2 - lq.momentum_action(P1)) < 1e-9
+    assert abs(-lq.evaluate_GaugeAction(ga, U1) / 3 - orc.gauge_action(Uo, L, BETA)) < 1e-9
+    assert abs(P1 * P1 / 2 - orc.momentum_action(Po, L)) < 1e-9
 
 
-@pytest.mark.parametrize("reunit,lazy", [(1, 1), (0, 1), (0, 0)])
-def test_transliterated_reference_callers_reproduce_the_fused_trajectory(lq, reunit, lazy):
-    """update!(::StandardHMC) exactly as the reference wrote it, on U[mu] / p[mu], against DeviceHMC (fused kernels): same seeds,
-    same momenta and noise, so the trajectories must agree to rounding (1e-12 on the links, 1e-9 on dH).  md_reunitarize = 0 is the reference's
-    LITERAL link update exp(t p) U (no projection anywhere), lazy_links = 0 its literal call sequence (every generic its own kernel): the defaults
-    (projection of on-group links inside the update pass, fused triples) are optimisations of THIS path and must not be the only one covered."""
-    L, Uh = _fixture(lq)
-    dtau, mdsteps, nsw, seed = 0.05, 20, 10, 1234
-    lata, latb = lq.Lattice(L), lq.Lattice(L)
-    for lat in (lata, latb):
-        lat.set_param("md_reunitarize", reunit)
-    latb.set_param("lazy_links", lazy)
-    Ua = lq.Gaugefields(lata).upload(Uh)
-    Ub = lq.Gaugefields(latb).upload(Uh)
-    fused = DeviceHMC(lq, Ua, KAPPA, BETA, dtau, mdsteps, nsw, seed)
-    gauge_action, fermi_action = _universe(lq, Ub, KAPPA, BETA)
-    hmc = StandardHMC(lq, Ub, gauge_action, False, dtau, mdsteps, fermi_action, SextonWeingargten=True, Nsw=nsw, seed=seed)
-    for traj in range(2):
-        acc_a = fused.update()
-        acc_b = update_(hmc, Ub)
-        assert acc_a == acc_b
-        assert abs(fused.dH[-1] - hmc.dH[-1]) < 1e-8, (fused.dH[-1], hmc.dH[-1])
-        assert rel_err(Ub.download(), Ua.download()) < 1e-12
-    assert abs(lq.calculate_Plaquette(Ua) - lq.calculate_Plaquette(Ub)) < 1e-13
+SCHEMES = {"QPQ_sw": dict(QPQ=True, SextonWeingargten=True, Nsw=10), "QPQ": dict(QPQ=True, SextonWeingargten=False), "PQP": dict(QPQ=False, SextonWeingargten=False)}
+
+
+@pytest.mark.parametrize("scheme,quench,reunit,lazy", [("QPQ_sw", False, 1, 1), ("QPQ_sw", False, 0, 1), ("QPQ_sw", False, 0, 0), ("QPQ", False, 1, 1), ("PQP", False, 1, 1),
+                                                       ("QPQ", True, 1, 1), ("PQP", True, 0, 0)])
+def test_replayed_update_reproduces_the_oracle_trajectory(lq, orc, scheme, quench, reunit, lazy):
+    """update!(::StandardHMC) replayed call by call from the reference's trace, started from its thermalised Wilson configuration (test/test_wilson.toml: beta 5.7,
+    kappa 0.141139, dtau 0.05, 20 MD steps, Sexton-Weingarten N = 10), against the oracle's trajectory from the momenta and the pseudofermion the device drew:
+    links to 1e-9, momenta to 1e-8, dH to 1e-6, the same accept decision.  md_reunitarize = 0 is the reference's literal link update exp(t p) U (no projection),
+    lazy_links = 0 its literal call sequence (every generic its own kernel): the defaults are optimisations of THIS path and must not be the only one covered.
+    All three integrators of runMD! (standardMD.jl:103-190), quenched and dynamical."""
+    Uh = _fixture(lq)
+    dtau, mdsteps = 0.05, 20
+    lat = lq.Lattice(L4)
+    lat.set_param("md_reunitarize", reunit)
+    lat.set_param("lazy_links", lazy)
+    U = lq.Gaugefields(lat).upload(Uh)
+    ga = plaquette_action(lq, U, BETA)
+    fa = None if quench else wilson_action(lq, U, KAPPA)
+    md = standard_md(lq, U, ga, dtau, mdsteps, fermi_action=fa, **SCHEMES[scheme])
+    hmc = standard_hmc(lq, U, md)
+    seen = {}
+
+    def drawn(env):      # the random fields the device drew: the oracle starts from the same ones
+        seen["P"] = env["md"]["p"].download()
+        seen["eta"] = None if quench else env["md"]["η"].download()
+        seen["xi2"] = 0.0 if quench else lq.dot(env["md"]["ξ"], env["md"]["ξ"]).real
+
+    def evolved(env):
+        seen["U1"], seen["P1"] = env["U"].download(), env["md"]["p"].download()
+
+    rp = Replay(lq, seed=1234, hooks={("after", "initialize_MD!"): drawn, ("after", "runMD!"): evolved,
+                                      ("after", "update!"): lambda env: seen.update(dH=env["Snew"] - env["Sold"])})
+    for traj in range(1 if scheme != "QPQ_sw" or reunit == 0 else 2):
+        U0 = U.download()
+        accepted = rp.call("update!", hmc, U)
+        ferm = None if quench else (orc.WILSON, KAPPA, BC, seen["eta"], 1e-19)
+        Uo, Po = oracle_md.trajectory(orc, U0, seen["P"], L4, BETA, dtau, mdsteps, scheme, 10, ferm)
+        assert rel_err(seen["U1"], Uo) < 1e-9 and rel_err(seen["P1"], Po) < 1e-8, (scheme, traj)
+        Hold = orc.momentum_action(seen["P"], L4) + orc.gauge_action(U0, L4, BETA) + seen["xi2"]
+        dH = oracle_md.hamiltonian(orc, Uo, Po, L4, BETA, ferm) - Hold
+        assert abs(dH) < 2.0 and abs(seen["dH"] - dH) < 1e-6, (seen["dH"], dH)      # the device's Snew - Sold is the oracle's
+        # the accept decision the replay took is the one this dH and the same uniform deviate give; a rejected trajectory restores the links bit for bit
+        u = np.random.default_rng(1234).random(traj + 1)[-1]
+        assert accepted == bool(np.exp(-dH) >= u) or abs(np.exp(-dH) - u) < 1e-5
+        assert np.array_equal(U.download(), seen["U1"] if accepted else U0)
+    if not quench:
+        assert rp.log.count("calc_UdSfdU!") == mdsteps * (2 if scheme == "PQP" else 1) * (traj + 1)
+
+
+def test_runMD_refuses_what_the_reference_refuses(lq, orc):
+    """runMD! (standardMD.jl:103-124): PQP with Sexton-Weingarten raises in the reference -- and in the replay, before any field is touched."""
+    lat = lq.Lattice(L4)
+    U = lq.Gaugefields(lat).upload(_fixture(lq))
+    md = standard_md(lq, U, plaquette_action(lq, U, BETA), 0.05, 2, QPQ=False, SextonWeingargten=True)
+    before = U.download()
+    with pytest.raises(Raised):
+        Replay(lq).call("runMD!", U, md)
+    assert np.array_equal(U.download(), before)
 
 
 def test_lazy_per_direction_triples_equal_the_eager_calls(lq, orc):
@@ -258,15 +148,13 @@ def test_lazy_per_direction_triples_equal_the_eager_calls(lq, orc):
         lat = lq.Lattice(L)
         lat.lazy_links = lazy
         U = lq.Gaugefields(lat).upload(Uh)
-        ga = lq.GaugeAction(U)
-        pl = lq.make_loops_fromname("plaquette", Dim=Dim)
-        ga.push_(5.7 / 2, pl + lq.make_loops_fromname("plaquette", Dim=Dim, adjoint=True))
-        md = StandardMD(lq, U, ga, True, 0.05, 20)
+        md = standard_md(lq, U, plaquette_action(lq, U, 5.7), 0.05, 20)
         lq.gauss_distribution_(md.p, 33)
+        rp = Replay(lq)
         for _ in range(3):
-            U_update_(U, md.p, 0.5, md)
-            P_update_(U, md.p, 1.0, md)
-            U_update_(U, md.p, 0.5, md)
+            rp.call("U_update!", U, md.p, 0.5, md)
+            rp.call("P_update!", U, md.p, 1.0, md)
+            rp.call("U_update!", U, md.p, 0.5, md)
         assert lat._lazy is None
         res[lazy] = (U.download(), md.p.download(), lq.unitarity_deviation(U))
         assert not lat._done

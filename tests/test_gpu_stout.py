@@ -1,71 +1,19 @@
 """Stout smearing of the links the fermion action sees (universe.jl:147-171; standardMD.jl:82-101, 192-227; standardHMC.jl:67-68): the device layer and its
 back-propagation against the numpy restatement (oracle.stout_*, itself checked by finite differences in tests/test_cpu_stout_restatement.py), the fermion force
-through the smearing against finite differences of the device action, and energy conservation of the reference's unchanged callers -- the CovNeuralnet
-methods transliterated below as test_gpu_reference_callers.py transliterates the others."""
+through the smearing against finite differences of the device action, and energy conservation of the reference's unchanged callers -- their CovNeuralnet
+methods replayed from the call trace (tests/golden/ref_call_trace.json, tests/ref_trace.py: the P_update_fermion! method that dispatches on TC <: CovNeuralnet,
+the smeared branch of initialize_MD!, update! with md.cov_neural_net set), as tests/test_gpu_reference_callers.py replays the others."""
 import numpy as np
 import pytest
 import scipy.linalg as sla
 
-import test_gpu_reference_callers as rc
 from conftest import rel_err
+from ref_trace import Replay, standard_hmc, standard_md
+from test_gpu_reference_callers import plaquette_action, wilson_action
 
 pytestmark = pytest.mark.gpu
 Dim = 4
 BC = (1, 1, 1, -1)
-
-
-def P_update_fermion_stout_(U, p, eps, md):                     # standardMD.jl:192-227 (TC <: CovNeuralnet)
-    lq = md.lq
-    temps = lq.get_temporary_gaugefields(md.gauge_action)
-    UdSfdUmu, its_UdSfdUmu = lq.get_temp(temps, Dim)
-    factor = -eps * md.dtau
-    Uout, Uout_multi, _ = lq.calc_smearedU(U, md.cov_neural_net)
-    for mu in range(1, Dim + 1):
-        lq.calc_UdSfdU_(UdSfdUmu, md.fermi_action, Uout, md.eta)
-        lq.mul_(md.dSdU[mu], Uout[mu].H, UdSfdUmu[mu - 1])
-    lq.unused_(temps, its_UdSfdUmu)
-    dSdUbare = lq.back_prop(md.dSdU, md.cov_neural_net, Uout_multi, U)
-    temp1, it_temp1 = lq.get_temp(temps)
-    for mu in range(1, Dim + 1):
-        lq.mul_(temp1, U[mu], dSdUbare[mu])                      # U*dSdUμ
-        lq.Traceless_antihermitian_add_(p[mu], factor, temp1)
-    lq.unused_(temps, it_temp1)
-
-
-def initialize_MD_stout_(U, md):                                 # standardMD.jl:82-101 (TC != Nothing)
-    lq = md.lq
-    md.seed += 3
-    lq.gauss_distribution_(md.p, md.seed)
-    Uout, Uout_multi, _ = lq.calc_smearedU(U, md.cov_neural_net)
-    lq.gauss_sampling_in_action_(md.xi, Uout, md.fermi_action, md.seed + 1)
-    lq.sample_pseudofermions_(md.eta, Uout, md.fermi_action, md.xi)
-
-
-def runMD_QPQ_stout_(U, md):                                     # standardMD.jl:127-144 with the CovNeuralnet method of P_update_fermion!
-    p = md.p
-    for itrj in range(md.MDsteps):
-        rc.U_update_(U, p, 0.5, md)
-        rc.P_update_(U, p, 1.0, md)
-        P_update_fermion_stout_(U, p, 1.0, md)
-        rc.U_update_(U, p, 0.5, md)
-
-
-def update_stout_(hmc, U):                                       # standardHMC.jl:41-91 with md.cov_neural_net set (:67-68)
-    md = hmc.md
-    lq = md.lq
-    NC = U[1].NC
-    lq.substitute_U_(hmc.Uold, U)
-    initialize_MD_stout_(U, md)
-    Sold = md.p * md.p / 2 - lq.evaluate_GaugeAction(md.gauge_action, U) / NC + lq.dot(md.xi, md.xi).real
-    runMD_QPQ_stout_(U, md)
-    Snew = md.p * md.p / 2 - lq.evaluate_GaugeAction(md.gauge_action, U) / NC
-    Uout, Uout_multi, _ = lq.calc_smearedU(U, md.cov_neural_net)
-    Snew += lq.evaluate_FermiAction(md.fermi_action, Uout, md.eta)
-    hmc.dH.append(Snew - Sold)
-    accept = np.exp(Sold - Snew) >= hmc.rng.random()
-    if not accept:
-        lq.substitute_U_(U, hmc.Uold)
-    return accept
 
 
 @pytest.mark.parametrize("L,rho", [((4, 4, 4, 8), 0.1), ((8, 4, 4, 4), 0.15)])
@@ -91,19 +39,17 @@ def test_smearing_and_backpropagation_match_the_oracle(lq, orc, L, rho):
         lq.STOUT_Layer(["plaquette", "rectangular"], [0.1, 0.05], U)
 
 
-def _universe_stout(lq, U, kappa, rhos):
-    ga, fa = rc._universe(lq, U, kappa, 5.7)
-    nn = lq.CovNeuralnet(U)                                           # universe.jl:150-171
+def stout_net(lq, U, rhos):
+    """The stack of stout layers between the links of the MD and the links the fermion action sees (universe.jl:147-171): one plaquette layer per rho."""
+    nn = lq.CovNeuralnet(U)
     for rho in rhos:
         nn.push_(lq.STOUT_Layer(["plaquette"], [rho], U))
-    return ga, fa, nn
+    return nn
 
 
-def _md(lq, U, ga, fa, nn, dtau, steps, seed=0):
-    hmc = rc.StandardHMC(lq, U, ga, False, dtau, steps, fa, seed=seed)
-    hmc.md.cov_neural_net = nn
-    hmc.md.dSdU = U.similar()                                         # standardMD.jl:58: dSdU = similar(U)
-    return hmc
+def smeared_md(lq, U, kappa, rhos, dtau, steps, eps=1e-19):
+    fa = wilson_action(lq, U, kappa, eps)
+    return standard_md(lq, U, plaquette_action(lq, U, 5.7), dtau, steps, fermi_action=fa, cov_neural_net=stout_net(lq, U, rhos))
 
 
 @pytest.mark.parametrize("rhos", [(0.1,), (0.08, 0.12)])
@@ -112,20 +58,21 @@ def test_fermion_force_through_the_smearing_is_the_derivative_of_the_action(lq, 
     Uh = orc.hot_gauge(L, 9)
     lat = lq.Lattice(L)
     U = lq.Gaugefields(lat).upload(Uh)
-    ga, fa, nn = _universe_stout(lq, U, 0.12, rhos)
-    fa.D.eps_CG = 1e-24
-    hmc = _md(lq, U, ga, fa, nn, 0.05, 1)
-    md = hmc.md
-    initialize_MD_stout_(U, md)
+    md = smeared_md(lq, U, 0.12, rhos, 0.05, 1, eps=1e-24)
+    fa, nn = md.fermi_action, md.cov_neural_net
+    rp = Replay(lq, seed=0)
+    rp.call("initialize_MD!", U, md)                                  # the smeared branch: heat bath on calc_smearedU(U, nn)
+    assert rp.log.count("calc_smearedU") == 1
     p0 = md.p.download()
-    P_update_fermion_stout_(U, md.p, 1.0, md)
-    dp = (md.p.download() - p0) / (-md.dtau)                          # = TA(U dS/dU) in the reference's sign (factor = -eps dtau)
+    rp.call("P_update_fermion!", U, md.p, 1.0, md)                    # dispatches to the TC <: CovNeuralnet method (standardMD.jl:192-227)
+    assert rp.log.count("back_prop") == 1 and rp.log.count("mul!") == 2 * Dim
+    dp = (md.p.download() - p0) / (-md["Δτ"])                         # = TA(U dS/dU) in the reference's sign (factor = -eps dtau)
     rng = np.random.default_rng(10)
 
     def S(V):
         U2 = lq.Gaugefields(lat).upload(V)
         Uout, _, _ = lq.calc_smearedU(U2, nn)
-        return lq.evaluate_FermiAction(fa, Uout, md.eta)
+        return lq.evaluate_FermiAction(fa, Uout, md["η"])
 
     for _ in range(3):
         idx = tuple(int(rng.integers(n)) for n in (4, L[3], L[2], L[1], L[0]))
@@ -150,10 +97,12 @@ def test_hmc_with_stout_smeared_fermions_conserves_energy(lq, orc):
     for dtau, steps in ((0.02, 10), (0.01, 20)):
         lat = lq.Lattice(L)
         U = lq.Gaugefields(lat).upload(Uh)
-        ga, fa, nn = _universe_stout(lq, U, 0.12, (0.1,))
-        hmc = _md(lq, U, ga, fa, nn, dtau, steps, seed=3)
-        update_stout_(hmc, U)
-        dH[dtau] = hmc.dH[0]
+        md = smeared_md(lq, U, 0.12, (0.1,), dtau, steps)
+        out = {}
+        rp = Replay(lq, seed=3, hooks={("after", "update!"): lambda env: out.update(dH=env["Snew"] - env["Sold"])})
+        rp.call("update!", standard_hmc(lq, U, md), U)
+        assert rp.log.count("calc_smearedU") == 2 + steps and rp.log.count("back_prop") == steps      # heat bath, every fermion kick, final action
+        dH[dtau] = out["dH"]
     assert abs(dH[0.02]) < 0.5 and abs(dH[0.01]) < 0.3 * abs(dH[0.02]) + 1e-3, dH      # second-order integrator: dH ~ dtau^2
 
 
