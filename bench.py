@@ -28,6 +28,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 WILSON_FLOP_PER_SITE = 1320
 WILSON_BYTES_PER_SITE = 960    # read psi 192 + 4 links 576 + write 192
 KAPPA = 0.141139
+CG_TRAFFIC = {}               # filled by measure_traffic(): PMC bytes per launch of the kernels of a CG iteration
 KERNEL_NAMES = {0: "wilson_interior", 1: "wilson_dirsplit", 2: "wilson_hopsplit", 3: "wilson_hopsplit_persist", 4: "wilson_lanesplit",
                 5: "wilson_dirsplit4", 6: "wilson_dirsplit_lds", 7: "wilson_pair4", 8: "wilson_dirsplit_both"}
 
@@ -171,6 +172,26 @@ def main():
                      "frac_by_bytes_moved": moved_per_site * Vloc / (ms_dslash * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
 
+    # ---- the CG iteration's own roofline: what the fused iteration MOVES (the SURVEY 8(d) figure of 4224 B/site is the UNFUSED model -- 2 x 960 + 12 spinor
+    # passes -- and would read as ~1.0 x peak against ms_per_step; the fused iteration writes no q = D^+D p, updates r in D^+'s epilogue, x every second iteration,
+    # and reads 12 of the 18 reals of a link)
+    link_b = 384 if recon_active else 576
+    per_kernel_moved = {"D": 192 + link_b + 192, "Ddag_update_mode": 192 + link_b + 192 + 192, "cg_update_even": 3 * 192, "cg_update_odd": 6 * 192}
+    moved_iter = (per_kernel_moved["D"] + per_kernel_moved["Ddag_update_mode"] + 0.5 * (per_kernel_moved["cg_update_even"] + per_kernel_moved["cg_update_odd"])) * Vloc
+    t_iter = dt / args.steps
+    cg_traffic = None
+    if CG_TRAFFIC and all(CG_TRAFFIC.get(k) for k in per_kernel_moved):
+        cg_traffic = CG_TRAFFIC["D"] + CG_TRAFFIC["Ddag_update_mode"] + 0.5 * (CG_TRAFFIC["cg_update_even"] + CG_TRAFFIC["cg_update_odd"])
+    out["cg_roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                          "bytes_moved_per_site_per_kernel": per_kernel_moved, "bytes_moved_per_iteration": moved_iter,
+                          "achieved": moved_iter / t_iter / 1e9, "frac": moved_iter / t_iter / 1e9 / HBM_PEAK_GBS,
+                          "traffic_per_kernel": dict(CG_TRAFFIC) if CG_TRAFFIC else None, "traffic": cg_traffic,
+                          "frac_by_traffic": (cg_traffic / t_iter / 1e9 / HBM_PEAK_GBS) if cg_traffic else None,
+                          "survey_unfused_model_bytes_per_site": 4224,
+                          "note": "frac = bytes the fused iteration must move / ms_per_step / peak; roofline.frac (Dslash) is on SURVEY 8(d)'s 960 algorithmic B/site "
+                                  "while the default kernel moves 768 (roofline.frac_by_bytes_moved)"}
+    out["roofline"]["note"] = "frac is on the 960-B/site algorithmic model of SURVEY 8(d); the default kernel rebuilds row 2 of every link and moves 768 B/site (frac_by_bytes_moved)"
+
     # ---- secondary, N > 1 (outside the timed region): where the time of a partitioned operator application goes on real links
     if (world > 1 or force_dist) and any(p > 1 for p in pe) or (force_dist and os.environ.get("LQCD_FORCE_PARTITION")):
         import ctypes as C
@@ -185,8 +206,14 @@ def main():
         t = torch.tensor(vals, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         v = [None if float(z) != float(z) else float(z) for z in t]   # NaN (a failed diagnostic) -> null, keeps the line valid JSON
+        folded = bool(lat.get_param("halo_stream_mode") == 3 and lat.get_param("halo_fold") and v[4] == 0.0)
         out["halo_phases_ms_max_over_ranks"] = {"pack": v[0], "interior": v[1], "exchange_after_pack": v[2],
-                                                "idle_wait_for_exchange": v[3], "exterior": v[4], "total_synchronised": v[5]}
+                                                "idle_wait_for_exchange": v[3], "exterior": v[4], "total_synchronised": v[5],
+                                                # inside the fused CG the pack launch of a folded application is gone too: the x/p update and the reduction launch write the faces
+                                                "schedule": "folded: pack -> exchange -> one stencil launch reading the ghost buffers (no exterior kernel)" if folded
+                                                else "pack -> exchange || interior -> exterior",
+                                                "pack_launches_per_cg_iteration": 0 if lat.get_param("halo_fuse") & 2 else 2,
+                                                "exterior_launches_per_cg_iteration": 0 if folded else 2}
         out["allreduce_latency_us"] = v[6]
         face = [lat.local_L[0] * lat.local_L[1] * lat.local_L[2] * lat.local_L[3] // lat.local_L[mu] if pe[mu] > 1 else 0 for mu in range(4)]
         out["halo_bytes_per_peer_and_direction"] = [96 * f for f in face]
@@ -368,6 +395,12 @@ def pmc_child(args):
         lat.set_param("gauge_recon", recon)
         for _ in range(6):
             lq.mul_(y, D, b)
+    lat.set_param("gauge_recon", recon0)
+    # ... and a window of the fused CG iteration (cg_roofline.traffic): D, D^+ in update mode, the two deferred-x update kernels
+    x = b.similar()
+    sess = lq.CGSession(D, x, b)
+    sess.iterate(12)
+    sess.close()
     lat.sync()
 
 
@@ -395,7 +428,7 @@ def measure_traffic(args):
             acc = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] == counter and "wilson_" in row["Kernel_Name"]:
+                    if row["Counter_Name"] == counter and ("wilson_" in row["Kernel_Name"] or "cg_update" in row["Kernel_Name"]):
                         a = acc.setdefault(row["Kernel_Name"], [0.0, 0])
                         a[0] += float(row["Counter_Value"]); a[1] += 1
             vals[counter] = {k: v[0] / v[1] for k, v in acc.items()}
@@ -410,9 +443,15 @@ def measure_traffic(args):
             return None
         k = ks[0]
         return (2.0 * vals["FETCH_SIZE"][k] + vals["WRITE_SIZE"][k]) * 1024.0
-    is18 = lambda k: "<false, false" in k.replace("(bool)0", "false").replace("(bool)1", "true")
+    norm = lambda k: k.replace("(bool)0", "false").replace("(bool)1", "true")
+    is18 = lambda k: "wilson_" in k and "<false, false" in norm(k)
+    isdag = lambda k: "wilson_" in k and "<true," in norm(k)
     t18 = per_kernel(is18)
-    tdef = per_kernel(lambda k: not is18(k)) or t18
+    tdef = per_kernel(lambda k: "wilson_" in k and not is18(k) and not isdag(k)) or t18
+    # per launch of the other kernels of a CG iteration (the D^+ average holds one plain launch of the set-up among its 13: -1.5 %)
+    CG_TRAFFIC.clear()
+    CG_TRAFFIC.update({"D": tdef, "Ddag_update_mode": per_kernel(lambda k: isdag(k) and not "<true, false" in norm(k)),
+                       "cg_update_even": per_kernel(lambda k: "cg_update_even" in k), "cg_update_odd": per_kernel(lambda k: "cg_update_odd" in k)})
     src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only) over 6 launches of the kernel; "
            "(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 64 B per 128-B request)")
     return tdef, t18, src
@@ -458,9 +497,12 @@ def cpu_baseline(lq, U, b, gL):
     Uh, bh = U.download(), b.download()
     bc = (1, 1, 1, -1)
     orc.set_threads(1)
-    t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=0); t_setup = time.perf_counter() - t0
-    t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=1); t_one = time.perf_counter() - t0
-    per_iter = max(t_one - t_setup, 1e-9)
+    samples = []
+    for _ in range(3):      # three independent differences; `value` is their median (one difference is one sample)
+        t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=0); t_setup = time.perf_counter() - t0
+        t0 = time.perf_counter(); orc.cg_DdagD_fixed(orc.WILSON, Uh, bh, gL, KAPPA, 1.0, bc, niter=1); t_one = time.perf_counter() - t0
+        samples.append(max(t_one - t_setup, 1e-9))
+    per_iter = sorted(samples)[1]
     t0 = time.perf_counter(); ref_D = orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc); t_d = time.perf_counter() - t0
     # the oracle's D b at the FULL bench lattice is also the parity check of the kernels this line times: the default (12-real when the links are
     # unitary) and the all-18-reals instance, and D^+ (all host cores for that one)
@@ -500,7 +542,8 @@ def cpu_baseline(lq, U, b, gL):
                 "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / ta_d / 1e9,
                 "sample": "the same oracle window with OpenMP over all host cores: (time(2 iterations) - time(0)) / 2"}
     return {"value": 1.0 / per_iter, "unit": "iter/s", "cores": 1, "kind": "port",
-            "sample": "oracle CG on the same %dx%dx%dx%d configuration: time(1 iteration) - time(0 iterations), 1 thread" % gL,
+            "sample": "oracle CG on the same %dx%dx%dx%d configuration: median of 3 x [time(1 iteration) - time(0 iterations)], 1 thread" % gL,
+            "samples_iter_per_s": [1.0 / t for t in samples],
             "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / t_d / 1e9, "all_cores": allc, "julia_probe": probe,
             "fullsize_dslash_rel_err": parity}
 

@@ -73,6 +73,33 @@ extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spin
     apply_bc(c, op->bc);
     StencilCall s;
     LQCHK(make_full_call(op, out, in, dagger ? 1 : 0, s));
+    LQCHK(halo_schedule_settle(op));
+    // the folded one-stream schedule (round 5; what the solvers run when the collective timing picked schedule 3 and halo_fold applies): pack -> exchange ->
+    // ONE stencil launch that takes the boundary hops from the ghost buffers.  ms[1] = that launch, ms[2] = the exchange, ms[3] = ms[4] = 0: nothing waits and
+    // there is no exterior kernel.  (Inside the fused CG the pack launch is gone as well: the x/p update and the reduction launch write the faces.)
+    if (halo_fold_applies(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr)) {
+        StencilCall f = s;
+        f.fold = 1;
+        for (int r = 0; r < reps + 2; r++) {
+            HIPCHK(hipEventRecord(e[0], c->stream));
+            LQCHK(launch_stencil_pack(c, s));
+            HIPCHK(hipEventRecord(e[1], c->stream));
+            LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0, 1));
+            HIPCHK(hipEventRecord(e[2], c->stream));
+            LQCHK(launch_stencil_interior(c, f));
+            HIPCHK(hipEventRecord(e[3], c->stream));
+            HIPCHK(hipEventSynchronize(e[3]));
+            if (r < 2) continue;
+            float t;
+            HIPCHK(hipEventElapsedTime(&t, e[0], e[1])); acc[0] += t;
+            HIPCHK(hipEventElapsedTime(&t, e[1], e[2])); acc[2] += t;
+            HIPCHK(hipEventElapsedTime(&t, e[2], e[3])); acc[1] += t;
+            HIPCHK(hipEventElapsedTime(&t, e[0], e[3])); acc[5] += t;
+        }
+        for (int k = 0; k < 6; k++) ms[k] = acc[k] / reps;
+        for (auto& ev : e) (void)hipEventDestroy(ev);
+        return LQCD_OK;
+    }
     for (int r = 0; r < reps + 2; r++) {          // two untimed warm-up applications
         HIPCHK(hipEventRecord(e[0], c->stream));
         LQCHK(launch_stencil_pack(c, s));

@@ -6,14 +6,21 @@ cd "$(dirname "$0")"
 ARCH=gfx950      # MI355X only: cg_persist.hip's 72 KiB of static LDS, the MFMA-free fp64 kernels and every tuning constant assume CDNA4
 OUT=${LQCD_OUT:-liblqcd_hip.so}
 BDIR=build/${OUT%.so}
-# LQCD_VARIANTS=1: also build the measured-and-slower Wilson kernel variants 2-8 (stencil_alt.hip, dslash_variant >= 2) -- experiments and their
-# tests only; the shipped library carries the default kernels (a dslash_variant >= 2 then runs variant 1)
+# LQCD_VARIANTS=1: also build the measured-and-slower Wilson kernel variants 2-8 (experiments/stencil_alt/stencil_alt.hip, dslash_variant >= 2) -- an experiment
+# build (experiments/stencil_alt/README.md); the product library carries the default kernels only (a dslash_variant >= 2 then runs variant 1)
 ALT=""; ALTO=""
-if [ "${LQCD_VARIANTS:-0}" = "1" ]; then LQCD_EXTRA_FLAGS="$LQCD_EXTRA_FLAGS -DLQCD_VARIANTS"; ALT="stencil_alt"; BDIR=${BDIR}_variants; fi
+if [ "${LQCD_VARIANTS:-0}" = "1" ]; then LQCD_EXTRA_FLAGS="$LQCD_EXTRA_FLAGS -DLQCD_VARIANTS"; ALT="stencil_alt"; BDIR=${BDIR}_variants; OUT=${LQCD_OUT:-liblqcd_hip_variants.so}; fi
 FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Wno-unused-variable $LQCD_EXTRA_FLAGS"
 mkdir -p $BDIR
 pids=()
-for f in stencil $ALT stencil_pair32 cg_persist fields blas apply solvers actions rational bench_api mdom capi force mixed md clover domainwall; do
+if [ -n "$ALT" ]; then
+  mkdir -p $BDIR
+  if [ ! -f $BDIR/stencil_alt.o ] || [ ../../experiments/stencil_alt/stencil_alt.hip -nt $BDIR/stencil_alt.o ] || [ lqcd_internal.h -nt $BDIR/stencil_alt.o ] || [ stencil_common.h -nt $BDIR/stencil_alt.o ]; then
+    ( hipcc $FLAGS -I. -c ../../experiments/stencil_alt/stencil_alt.hip -o $BDIR/stencil_alt.o ) &
+    pids+=($!)
+  fi
+fi
+for f in stencil stencil_pair32 cg_persist fields blas apply solvers actions rational bench_api mdom capi force mixed md clover domainwall; do
   if [ ! -f $BDIR/$f.o ] || [ $f.hip -nt $BDIR/$f.o ] || [ lqcd_internal.h -nt $BDIR/$f.o ] || [ ops_internal.h -nt $BDIR/$f.o ] || [ stencil_common.h -nt $BDIR/$f.o ] || [ ../../include/lqcd_hip.h -nt $BDIR/$f.o ] || [ build.sh -nt $BDIR/$f.o ]; then
     ( hipcc $FLAGS -c $f.hip -o $BDIR/$f.o ) &
     pids+=($!)

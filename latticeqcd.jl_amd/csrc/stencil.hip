@@ -1,5 +1,5 @@
 // stencil.hip -- Wilson and staggered Dslash for gfx950 (CDNA4): the default kernels (both precisions), the halo kernels and the launchers.
-// Shared device helpers: stencil_common.h.  Opt-in Wilson variants 2-8 (measured alternatives, fp64 only): stencil_alt.hip.
+// Shared device helpers: stencil_common.h.  Opt-in Wilson variants 2-8 (measured alternatives, fp64 only): experiments/stencil_alt/stencil_alt.hip (LQCD_VARIANTS builds).
 //
 // Replaces LinearAlgebra.mul!(y, D::Dirac_operator, x) / mul!(y, D', x) of LatticeDiracOperators.jl
 // (operator built at /root/reference/src/system/universe.jl:106-116,137).
@@ -866,9 +866,15 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
     }
+    if constexpr (LATE_R && !DOT) if (a.upd_scal) {       // the LDS exchange and the barrier cover this load
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
     cd w5[DW5 ? 3 : 1];
     if constexpr (DW5) {      // fifth-direction hops of this wave's three components: -P_A psi(s+1) - P_B psi(s-1), the mass term at the walls; P_-+ psi = (psi -+ g5 psi)/2
-                              // and (g5 psi)_spin = -psi_(spin xor 2): the partner component is six further on or back.  Issued here: the LDS exchange and the barrier cover them
+                              // and (g5 psi)_spin = -psi_(spin xor 2): the partner component is six further on or back.  Issued behind the stores of the partial sums (round 5: the twelve accumulators are dead by now -- the instance no longer spills): the barrier and the LDS reads cover them
         const int su = s5 + 1 < a_.ls ? s5 + 1 : 0, sd = s5 >= 1 ? s5 - 1 : a_.ls - 1;
         const real cu = real(0.5) * (s5 + 1 < a_.ls ? real(-1.0) : a_.dw_mass), cd_ = real(0.5) * (s5 >= 1 ? real(-1.0) : a_.dw_mass);
         constexpr real sa = DAG ? real(-1.0) : real(1.0);
@@ -882,12 +888,6 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
             w5[cc] = mk(cu * (u0.re + sa * u1.re) + cd_ * (d0.re - sa * d1.re), cu * (u0.im + sa * u1.im) + cd_ * (d0.im - sa * d1.im));
         }
     }
-    if constexpr (LATE_R && !DOT) if (a.upd_scal) {       // the LDS exchange and the barrier cover this load
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
-    }
-#pragma unroll
-    for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
     __syncthreads();
     real2* dstp = const_cast<real2*>(boff(s.p ? a.dst[1] : a.dst[0], s.own));
 #pragma unroll

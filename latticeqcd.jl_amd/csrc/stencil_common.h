@@ -1,5 +1,5 @@
 // stencil_common.h -- argument structs, addressing, load/store and SU(3) helpers shared by the stencil translation units
-// (stencil.hip: the default kernels, both precisions; stencil_alt.hip: the opt-in Wilson variants 2-8, fp64).  Everything lives in the
+// (stencil.hip: the default kernels, both precisions; experiments/stencil_alt/stencil_alt.hip: the opt-in Wilson variants 2-8, fp64, experiment builds only).  Everything lives in the
 // precision namespace (lqcd::p64 / lqcd::p32) the including file is compiled for.
 #pragma once
 #include "lqcd_internal.h"

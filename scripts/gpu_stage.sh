@@ -173,6 +173,22 @@ PY
       rm -rf $out/trace$f
     done
     ;;
+  call2)      # round 5, call 2: the whole GPU suite on the tree with the trace-replayed callers, fused pack + reduction, DW5 without spills; proxy; bench line
+    timeout 1800 python -m pytest tests -m gpu -q -x --durations=12 2>&1 | tail -30 | tee $out/pytest.log
+    for f in 0 1; do
+      LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 200 --warm 20 --cg 400 --set halo_stream_mode=3 --set halo_fold=$f 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=8 fold=$f /"; echo
+    done | tee $out/proxy.log
+    LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 200 --warm 20 --cg 400 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=8 tuner /" | tee -a $out/proxy.log; echo
+    timeout 200 python scripts/dslash_probe.py --lattice 32,32,32,64 --reps 200 --warm 20 --cg 300 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=1 /" | tee -a $out/proxy.log; echo
+    (cd /tmp && LQCD_FORCE_PARTITION=14 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/trace1 -o t -- python $GRAFT_REPO_ROOT/scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 20 --warm 5 --cg 64 --set halo_stream_mode=3 --set halo_fold=1 2>&1 | grep "^cg")
+    t=$(find $out/trace1 -name "*kernel_trace.csv" | head -1)
+    echo "== halo_fold 1 (halo_stream_mode 3), pack + reduction in one launch" | tee $out/timeline.log
+    python scripts/timeline.py "$t" cg_update_odd 2>&1 | tee -a $out/timeline.log
+    rm -rf $out/trace1
+    timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench_n1.json 2> $out/bench_n1.err; tail -c 3000 $out/bench_n1.json; tail -3 $out/bench_n1.err
+    LQCD_BENCH_FORCE_DIST=1 LQCD_FORCE_PARTITION=14 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --lattice 32,16,16,32 --no-cpu-baseline --no-pmc > $out/bench_proxy_n8local.json 2> $out/bench_proxy.err; python -c "
+import json; d=json.load(open('$out/bench_proxy_n8local.json')); print({k: d.get(k) for k in ('value','ms_per_step','halo_phases_ms_max_over_ranks','halo_stream_mode_rank0','allreduce_latency_us')})"; tail -3 $out/bench_proxy.err
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log
