@@ -152,9 +152,7 @@ extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     CgWork w;
-    w.r = scratch_get(c, x->kind, LQCD_FULL); w.p = scratch_get(c, x->kind, LQCD_FULL);
-    w.q = scratch_get(c, x->kind, LQCD_FULL); w.tmp = scratch_get(c, x->kind, LQCD_FULL);
-    if (!(w.r && w.p && w.q && w.tmp)) return LQCD_ERR_HIP;
+    LQCHK(cg_work_get(c, x->kind, w));
     double rr;
     int st = cg_setup(op, x, b, w, -1.0, &rr);
     for (int i = 0; i < warm && st == LQCD_OK; i++) st = cg_enqueue_iteration(op, x, w);
@@ -170,7 +168,7 @@ extern "C" int lqcd_bench_cg(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_t b, int
     }
     if (st == LQCD_OK) st = cg_flush_x(op, x, w);
     (void)hipStreamSynchronize(c->stream);
-    scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+    cg_work_put(w);
     return st;
 }
 
@@ -185,13 +183,11 @@ extern "C" int lqcd_cg_session_begin(lqcd_op_t op, lqcd_spinor_t x, lqcd_spinor_
     HIPCHK(hipSetDevice(c->device));
     CgSession* ses = new CgSession;
     CgWork& w = ses->w;
-    w.r = scratch_get(c, x->kind, LQCD_FULL); w.p = scratch_get(c, x->kind, LQCD_FULL);
-    w.q = scratch_get(c, x->kind, LQCD_FULL); w.tmp = scratch_get(c, x->kind, LQCD_FULL);
-    int st = (w.r && w.p && w.q && w.tmp) ? LQCD_OK : LQCD_ERR_HIP;
+    int st = cg_work_get(c, x->kind, w);
     double rr;
     if (st == LQCD_OK) st = cg_setup(op, x, b, w, -1.0, &rr);
     if (st != LQCD_OK) {
-        scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+        cg_work_put(w);
         delete ses;
         return st;
     }
@@ -214,7 +210,7 @@ extern "C" int lqcd_cg_session_end(lqcd_op_t op) {
     CgWork& w = ses->w;
     const int st = cg_flush_x(op, ses->x, w);       // a pending deferred x update; its status is the status of the session
     (void)hipStreamSynchronize(op->ctx->stream);
-    scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+    cg_work_put(w);
     delete ses;
     op->ctx->cg_session = nullptr;
     return st;

@@ -299,7 +299,8 @@ __device__ inline double shfl_tree_sum(double s) {      // lane 0 holds the sum 
 
 // ---------------------------------------------------------------- the CG / BiCGStab scalar steps behind a reduction (one thread)
 // slots of the device scalar block d_scal used by the solvers
-enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18 };
+enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S_ITERS = 13, S_EPS = 14, S_RRNEW = 15, S_XDONE = 16, S_RROLD = 17, S_APREV = 18,
+       S_AHIST = 64 };      // S_AHIST .. +7: the step lengths of the search directions whose x update is still pending (cg_defer_x >= 3: ring of p buffers)
 // BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
 enum { B_RHO = 24, B_R0V = 26, B_VV = 28, B_ALPHA = 29, B_SS = 31, B_TS = 32, B_TT = 34, B_OMEGA = 35, B_RR = 37, B_RHO1 = 38, B_BETA = 40,
        B_DONE = 42, B_ITERS = 43, B_EPS = 44, B_HALF = 45, B_RES = 46, B_RHOB = 47, B_END = 49 };      // B_R0V..B_VV, B_TS..B_TT and B_RR..B_RHO1 are filled by one
@@ -472,8 +473,10 @@ struct Tunables {
                               // max |row2 - conj(row0 x row1)| past the 12-real gate (1e-14) within ~280 link updates; 0 = the reference's literal update
     int staple_recon = 1;     // staple sweep on a field whose links are known to be on the group: rows 0, 1 are loaded, row 2 is rebuilt (2/3 of the L2 -> L1 bytes)
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
-    int cg_defer_x = 1;       // fused CG: x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
-                              // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates
+    int cg_defer_x = 4;       // fused CG: 1 / 2 = x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
+                              // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates; K = 3..8 (round 5; 288 GB of HBM make
+                              // the buffers free): a ring of K search-direction buffers, x += sum of K terms every K-th iteration -- (4 K + 1) / K update passes per
+                              // iteration instead of 4.5 (K = 4: 4.25), the same iterates
     int cg_persist = 1;       // staggered CG on an unpartitioned lattice of <= 256 chunks: the whole solve is ONE launch (cg_persist.hip), two grid-wide
                               // synchronisations per iteration instead of three dependent launches; 0: the cg_small launch chain
     int cg_small = 1;         // fused CG on an unpartitioned lattice with <= 1024 stencil workgroups: the two reduction launches of an iteration are folded
@@ -679,7 +682,7 @@ struct lqcd_op_s {
 namespace lqcd {
 
 constexpr int MAX_PARTIAL_BLOCKS = 4096;
-constexpr int SCAL_DOUBLES = 64;
+constexpr int SCAL_DOUBLES = 96;
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);

@@ -25,7 +25,12 @@ struct CgWork {
     bool p_packed = false;   // partitioned lattice, halo_fuse bit 1: the send buffers hold the faces of the current search direction (packed by the last x/p update)
     int form = -1;      // iteration form fixed at cg_setup (0 plain, 1 deferred x, 2 small-lattice): the tunables may change while a session is open
     int k = 0;          // iterations enqueued so far (parity selects the p buffer when the x update is deferred: p_k lives in p for even k, in q for odd k)
+    int ring = 2;       // form 1: search-direction buffers in rotation (2: p, q; K > 2: p, q, more[0..K-3]; p_k lives in buffer k % K), fixed at cg_setup
+    lqcd_spinor_s* more[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    lqcd_spinor_s* buf(int j) const { return j == 0 ? p : j == 1 ? q : more[j - 2]; }
 };
+int cg_work_get(lqcd_ctx_s* c, int kind, CgWork& w);      // the four work vectors of a solve from the context's scratch pool (the ring's extra buffers follow in cg_setup)
+void cg_work_put(CgWork& w);
 int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);
 int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w);    // applies a pending deferred x update (end of a window that stopped on an even iteration)
 int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, double eps, double* rr0);

@@ -217,6 +217,77 @@ __global__ __launch_bounds__(UB) void cg_flush_kernel(const double* __restrict__
         x[i] = xv;
     }
 }
+// Deferred x update over a ring of K search-direction buffers (cg_defer_x = K >= 3): p_k lives in buffer k % K.  Iteration k with m = k % K < K - 1:
+// p_{k+1} = r + beta p_k into the next buffer, alpha_k kept in S_AHIST[m], x untouched -- 3 streams.  m = K - 1 (or the iteration that converges, whatever m):
+// x += alpha_{k-m} p_{k-m} + ... + alpha_k p_k in that order (the operations two single updates would do: identical bits), then p_{k+1} over the oldest buffer,
+// which this thread has just read -- K + 4 streams.  (4 K + 1) / K passes per iteration instead of the 4.5 of the two-buffer form.
+struct CgRing { const double2* b[8]; };      // the buffers that hold pending directions, oldest first (entries >= m unused); indexed by unrolled constants only
+template <bool NT, bool FOLD, bool PACK = false>
+__global__ __launch_bounds__(UB) void cg_update_ring(double* __restrict__ s, double2* __restrict__ x, CgRing ring, int m, int flush, const double2* __restrict__ pk,
+                                                      double2* pnext, const double2* __restrict__ r, size_t n, int nbf, HArgs h, int npx) {
+    if (s[S_XDONE] != 0.0) return;
+    const FoldBeta fb = cg_beta<FOLD>(s);
+    const double al = s[S_ALPHA], be = fb.be;
+    const bool cont = fb.cont;
+    const int npk = PACK ? 8 * npx : 0, fb0 = (int)blockIdx.x - npk;
+    if constexpr (PACK) {
+        if (fb0 < 0) {
+            if (cont) wilson_pack_axpy_block(h, (int)blockIdx.x, npx, be);
+            return;
+        }
+    }
+    if (flush || !cont) {
+        double ah[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) ah[j] = j < m ? s[S_AHIST + j] : 0.0;
+        for (size_t i = (size_t)fb0 * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
+            double2 xv = ldx<NT>(x + i);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (j < m) {
+                    const double2 pj = ldx<NT>(ring.b[j] + i);
+                    xv.x = fma(ah[j], pj.x, xv.x); xv.y = fma(ah[j], pj.y, xv.y);
+                }
+            }
+            const double2 pv = ldx<NT>(pk + i);
+            xv.x = fma(al, pv.x, xv.x); xv.y = fma(al, pv.y, xv.y);
+            stx<NT>(x + i, xv);
+            if (cont) {
+                const double2 rv = ldx<NT>(r + i);
+                double2 o;
+                o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
+                stx<NT>(pnext + i, o);
+            }
+        }
+    } else {
+        for (size_t i = (size_t)fb0 * UB + threadIdx.x; i < n; i += (size_t)nbf * UB) {
+            const double2 pv = ldx<NT>(pk + i), rv = ldx<NT>(r + i);
+            double2 o;
+            o.x = fma(be, pv.x, rv.x); o.y = fma(be, pv.y, rv.y);
+            stx<NT>(pnext + i, o);
+        }
+        if (fb0 == 0 && threadIdx.x == 0) s[S_AHIST + m] = al;
+    }
+    cg_beta_commit<FOLD>(s, fb, fb0 == 0);
+}
+// x += sum of the m pending terms, for a window that ended (unconverged) in the middle of the ring
+__global__ __launch_bounds__(UB) void cg_flush_ring(const double* __restrict__ s, double2* __restrict__ x, CgRing ring, int m, size_t n) {
+    if (s[S_DONE] != 0.0) return;
+    double ah[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ah[j] = j < m ? s[S_AHIST + j] : 0.0;
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        double2 xv = x[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < m) {
+                const double2 pj = ring.b[j][i];
+                xv.x = fma(ah[j], pj.x, xv.x); xv.y = fma(ah[j], pj.y, xv.y);
+            }
+        }
+        x[i] = xv;
+    }
+}
 // p = r + beta p
 __global__ __launch_bounds__(UB) void cg_update_p(const double* __restrict__ s, double2* __restrict__ p, const double2* __restrict__ r, size_t n) {
     if (s[S_DONE] != 0.0) return;
@@ -285,9 +356,37 @@ static bool cg_defers_x(lqcd_op_s* op) {
     if (!(c->tun.cg_fused >= 2 && c->tun.cg_defer_x)) return false;
     return !(c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op))));
 }
+int cg_work_get(lqcd_ctx_s* c, int kind, CgWork& w) {
+    w.r = scratch_get(c, kind, LQCD_FULL); w.p = scratch_get(c, kind, LQCD_FULL);
+    w.q = scratch_get(c, kind, LQCD_FULL); w.tmp = scratch_get(c, kind, LQCD_FULL);
+    if (!(w.r && w.p && w.q && w.tmp)) { cg_work_put(w); return LQCD_ERR_HIP; }
+    return LQCD_OK;
+}
+void cg_work_put(CgWork& w) {
+    for (lqcd_spinor_s** f : {&w.r, &w.p, &w.q, &w.tmp}) { if (*f) scratch_put(*f); *f = nullptr; }
+    for (lqcd_spinor_s*& f : w.more) { if (f) scratch_put(f); f = nullptr; }
+}
+// buffers of the deferred-x form: 2, or the ring of cg_defer_x = K = 3..8 (cg_setup takes the extra ones from the scratch pool; if the pool cannot grow: 2)
+static int cg_ring_wanted(lqcd_op_s* op) {
+    const int k = op->ctx->tun.cg_defer_x;
+    return (k >= 3 && op->kind != LQCD_DOMAINWALL) ? std::min(k, 8) : 2;
+}
+static CgRing cg_ring_pending(const CgWork& w, int m) {      // the buffers of p_{k-m} .. p_{k-1}, oldest first, for k = w.k
+    CgRing ring;
+    for (int j = 0; j < 8; j++) ring.b[j] = j < m ? w.buf((w.k - m + j) % w.ring)->data : nullptr;
+    return ring;
+}
 int cg_flush_x(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
     lqcd_ctx_s* c = op->ctx;
     const bool deferred = w.form >= 0 ? w.form == 1 : cg_defers_x(op);     // the form the iterations were enqueued in (recorded by cg_setup)
+    if (deferred && w.ring > 2) {
+        const int m = w.k % w.ring;       // directions p_{k-m} .. p_{k-1} are still to be added
+        if (m == 0) return LQCD_OK;
+        hipLaunchKernelGGL(cg_flush_ring, dim3(stream_grid(c, x->elems)), dim3(UB), 0, c->stream, c->d_scal, x->data, cg_ring_pending(w, m), m, x->elems);
+        HIPCHK(hipGetLastError());
+        w.k += w.ring - m;      // nothing pending any more (a window is never continued after its flush)
+        return LQCD_OK;
+    }
     if (!deferred || !(w.k & 1)) return LQCD_OK;
     const size_t n = x->elems;
     hipLaunchKernelGGL(cg_flush_kernel, dim3(stream_grid(c, n)), dim3(UB), 0, c->stream, c->d_scal, x->data, w.p->data, n);   // p_k of an even k lives in w.p
@@ -328,8 +427,9 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
         //   beta, convergence ; x += alpha p, p = r + beta p
         const int nbs = stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op));
         const bool defer = form == 1;
-        lqcd_spinor_s* pk = (defer && (w.k & 1)) ? w.q : w.p;        // q = D^+D p is never written in this form: its buffer is the second p
-        lqcd_spinor_s* po = (defer && (w.k & 1)) ? w.p : w.q;
+        const bool ringed = defer && w.ring > 2;
+        lqcd_spinor_s* pk = ringed ? w.buf(w.k % w.ring) : (defer && (w.k & 1)) ? w.q : w.p;        // q = D^+D p is never written in this form: its buffer is the second p
+        lqcd_spinor_s* po = ringed ? w.buf((w.k + 1) % w.ring) : (defer && (w.k & 1)) ? w.p : w.q;
         // several ranks: reduce_final -> all-reduce -> one-thread scalar kernel are three dependent launches per reduction; with `fold` the scalar
         // steps move into the prologues of the kernels that consume them (deferred-x form only)
         const bool fold = c->has_comm && defer && c->tun.cg_fold_scalars;
@@ -388,9 +488,19 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
 #define LQ_UPD(KERN, A, B, C) do { \
             if (c->tun.nt_blas) { if (fold) LQ_UPD3(KERN, true, true, A, B, C); else LQ_UPD3(KERN, true, false, A, B, C); } \
             else { if (fold) LQ_UPD3(KERN, false, true, A, B, C); else LQ_UPD3(KERN, false, false, A, B, C); } } while (0)
+#define LQ_RING3(NT_, FO_) do { \
+            if (fp) hipLaunchKernelGGL((cg_update_ring<NT_, FO_, true>), ug, ub, 0, c->stream, c->d_scal, x->data, ring, rm, rflush, pk->data, po->data, w.r->data, n, nbu, h, npx); \
+            else hipLaunchKernelGGL((cg_update_ring<NT_, FO_, false>), ug, ub, 0, c->stream, c->d_scal, x->data, ring, rm, rflush, pk->data, po->data, w.r->data, n, nbu, h, npx); } while (0)
         if (!defer) hipLaunchKernelGGL(cg_update_xp, ug, ub, 0, c->stream, c->d_scal, x->data, w.p->data, w.r->data, n);
+        else if (ringed) {
+            const int rm = w.k % w.ring, rflush = rm == w.ring - 1 ? 1 : 0;
+            const CgRing ring = cg_ring_pending(w, rm);
+            if (c->tun.nt_blas) { if (fold) LQ_RING3(true, true); else LQ_RING3(true, false); }
+            else { if (fold) LQ_RING3(false, true); else LQ_RING3(false, false); }
+        }
         else if (w.k & 1) LQ_UPD(cg_update_odd, po->data, pk->data, w.r->data);
         else LQ_UPD(cg_update_even, pk->data, po->data, w.r->data);
+#undef LQ_RING3
 #undef LQ_UPD
 #undef LQ_UPD3
         w.p_packed = fp;
@@ -449,6 +559,17 @@ int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, doubl
     w.k = 0; w.p_packed = false;
     w.form = (c->tun.cg_fused >= 2 && c->tun.cg_small && cg_small_ok(op, stencil_num_partials(c, op->kind, op->r, 2, 0, op_fused_clover(op)))) ? 2
              : (cg_defers_x(op) ? 1 : 0);
+    w.ring = 2;
+    if (w.form == 1) {      // the ring of search-direction buffers (cg_defer_x = K): K - 2 more vectors, or the two-buffer form if the pool cannot grow
+        const int want = cg_ring_wanted(op);
+        bool ok = true;
+        for (int j = 0; j < want - 2 && ok; j++) {
+            if (!w.more[j]) w.more[j] = scratch_get(c, x->kind, LQCD_FULL);
+            ok = w.more[j] != nullptr;
+        }
+        if (ok) w.ring = want;
+        else for (lqcd_spinor_s*& f : w.more) { if (f) scratch_put(f); f = nullptr; }
+    }
     return LQCD_OK;
 }
 
@@ -456,15 +577,10 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     lqcd_ctx_s* c = op->ctx;
     HIPCHK(hipSetDevice(c->device));
     CgWork w;
-    w.r = scratch_get(c, x->kind, LQCD_FULL);
-    w.p = scratch_get(c, x->kind, LQCD_FULL);
-    w.q = scratch_get(c, x->kind, LQCD_FULL);
-    w.tmp = scratch_get(c, x->kind, LQCD_FULL);
-    int st = LQCD_OK;
+    int st = cg_work_get(c, x->kind, w);
     double rr = 0;
     int it = 0;
     bool converged = false;
-    if (!(w.r && w.p && w.q && w.tmp)) st = LQCD_ERR_HIP;
     // launch-bound staggered lattices: initial residual and all iterations in one launch (cg_persist.hip); x is complete on return
     bool one_launch = st == LQCD_OK && maxiter > 0 && c->tun.graph == 0 && cg_persist_ok(op);
     if (one_launch) {
@@ -534,7 +650,7 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
         st = cg_flush_x(op, x, w);
         if (st == LQCD_OK) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) st = hip_fail(e, "cg flush", __FILE__, __LINE__); }
     }
-    scratch_put(w.r); scratch_put(w.p); scratch_put(w.q); scratch_put(w.tmp);
+    cg_work_put(w);
     if (iters) *iters = it;
     if (final_rr) *final_rr = rr;
     if (st != LQCD_OK) return st;

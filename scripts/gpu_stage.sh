@@ -189,6 +189,14 @@ PY
     LQCD_BENCH_FORCE_DIST=1 LQCD_FORCE_PARTITION=14 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --lattice 32,16,16,32 --no-cpu-baseline --no-pmc > $out/bench_proxy_n8local.json 2> $out/bench_proxy.err; python -c "
 import json; d=json.load(open('$out/bench_proxy_n8local.json')); print({k: d.get(k) for k in ('value','ms_per_step','halo_phases_ms_max_over_ranks','halo_stream_mode_rank0','allreduce_latency_us')})"; tail -3 $out/bench_proxy.err
     ;;
+  call3)      # round 5, call 3: where did the suite stall (per-test timeout with stack dump), the ring of search-direction buffers (cg_defer_x = K), proxy with it
+    timeout 900 python -m pytest tests/test_gpu_reference_callers.py -q -x --timeout=200 --timeout-method=thread --durations=12 2>&1 | tail -60 | tee $out/pytest_callers.log
+    timeout 600 python -m pytest tests/test_gpu_solver_edges.py tests/test_gpu_stout.py -q -x --timeout=200 --timeout-method=thread --durations=6 2>&1 | tail -25 | tee $out/pytest_edges.log
+    for k in 2 4 8; do
+      timeout 200 python scripts/dslash_probe.py --lattice 32,32,32,64 --reps 100 --warm 20 --cg 300 --set cg_defer_x=$k 2>&1 | grep -E "^cg" | sed "s/^/N=1 cg_defer_x=$k /"
+      LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 50 --warm 20 --cg 400 --set halo_stream_mode=3 --set cg_defer_x=$k 2>&1 | grep -E "^cg" | sed "s/^/N=8 fold=1 cg_defer_x=$k /"
+    done | tee $out/ring.log
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

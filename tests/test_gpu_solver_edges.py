@@ -206,9 +206,9 @@ def test_bicg_matches_oracle(lq, orc, kind_name, dagger):
 
 @pytest.mark.parametrize("kind_name", ["Wilson", "Staggered"])
 def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
-    """cg_defer_x (default): x is updated every second iteration with both search directions, p ping-pongs between two buffers.  Same
-    operations in the same order per element: the solution, the iteration count and windows of odd AND even length (the odd one ends with
-    a pending update that must be flushed) are bit-identical to the plain fused iteration."""
+    """cg_defer_x: 1 = x is updated every second iteration with both search directions, p ping-pongs between two buffers; K = 3..8 (default 4, round 5) = a ring
+    of K search-direction buffers, x += K terms every K-th iteration.  Same operations in the same order per element: the solution, the iteration count and
+    windows of every length modulo the ring (one that ends inside the ring leaves pending updates that must be flushed) are bit-identical to the plain fused iteration."""
     kind = lq.WILSON if kind_name == "Wilson" else lq.STAGGERED
     L = (8, 8, 8, 8)
     lat = lq.Lattice(L)
@@ -219,12 +219,12 @@ def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
     lq.gauss_distribution_fermion_(b, 962)
     A = lq.DdagD_operator(D)
     res = {}
-    for defer in (0, 1):
+    for defer in (0, 1, 3, 4, 8):
         lat.set_param("cg_defer_x", defer)
         x = b.similar()
         info = lq.solve_DinvX_(x, A, b, return_info=True)
         wins = []
-        for niter in (1, 4, 5, 9, 16):
+        for niter in (1, 2, 3, 4, 5, 7, 8, 9, 16, 17):
             xw = b.similar()
             lq.lib.check(lq.lib.lib().lqcd_solve_cg_DdagD_fixed(D._h, xw._h, b._h, niter))
             wins.append(xw.download())
@@ -234,10 +234,11 @@ def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
             lq.solve_DinvX_(xe, A, b)
         A.MaxCGstep = 3000
         res[defer] = (info, x.download(), wins, xe.download())
-    assert res[0][0] == res[1][0] and res[1][0][1] < 1e-18
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][3], res[1][3])
-    for a, c in zip(res[0][2], res[1][2]):
-        assert np.array_equal(a, c)
+    for defer in (1, 3, 4, 8):
+        assert res[0][0] == res[defer][0] and res[defer][0][1] < 1e-18, defer
+        assert np.array_equal(res[0][1], res[defer][1]) and np.array_equal(res[0][3], res[defer][3]), defer
+        for a, c in zip(res[0][2], res[defer][2]):
+            assert np.array_equal(a, c), defer
 
 
 def test_evenodd_bicgstab_fused_chain_is_bit_identical_to_the_unfolded_one(lq, orc):
