@@ -92,9 +92,10 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * md_remap (1 [default]: the staple sweep follows the stencil's XCD-aware workgroup map), md_reunitarize (1 [default]: lqcd_gauge_exp_update projects the updated
  * links back onto SU(3) in the same pass; 0: the reference's literal update), cg_fold_scalars (1 [default]: several ranks, the scalar steps behind the two all-reduces of a
  * CG iteration run in the consumers' prologues), nt_blas (1 [default]: non-temporal loads / stores in the CG update kernels),
- * cg_skip_done, cg_defer_x (1 or 2: the fused CG updates x every second iteration with both search directions, p alternating between
- * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates; K = 3..8 [default 4, round 5]: a ring of K search-direction buffers,
- * x += K terms every K-th iteration, (4 K + 1) / K update passes per iteration; 0: x every iteration),
+ * cg_skip_done, cg_defer_x (2: the fused CG updates x every second iteration with both search directions, p alternating between
+ * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates; K = 3..8 (round 5): a ring of K search-direction buffers,
+ * x += K terms every K-th iteration, (4 K + 1) / K update passes per iteration; 1 [default]: 2 on an unpartitioned lattice, 8 on a partitioned one (what was measured
+ * faster in each case); 0: x every iteration),
  * halo_fold (1 [default], round 5: where the collective timing picks the one-stream halo schedule 3, the Wilson r = 1 stencil launch takes the boundary hops from the ghost
  * buffers itself -- no exterior kernel; fp64 scalar-addressing kernel, x unpartitioned; read-only halo_fold_active), cg_persist (1 [default]: a staggered CG on an unpartitioned lattice of
  * at most 256 chunks of 64 sites runs as ONE launch -- initial residual and all iterations, two grid-wide synchronisations per iteration, every wait bounded: if the workgroups are not all resident (a busy GPU) x is left untouched, the solve is

@@ -473,10 +473,11 @@ struct Tunables {
                               // max |row2 - conj(row0 x row1)| past the 12-real gate (1e-14) within ~280 link updates; 0 = the reference's literal update
     int staple_recon = 1;     // staple sweep on a field whose links are known to be on the group: rows 0, 1 are loaded, row 2 is rebuilt (2/3 of the L2 -> L1 bytes)
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
-    int cg_defer_x = 4;       // fused CG: 1 / 2 = x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
+    int cg_defer_x = 1;       // fused CG: 2 = x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
                               // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates; K = 3..8 (round 5; 288 GB of HBM make
                               // the buffers free): a ring of K search-direction buffers, x += sum of K terms every K-th iteration -- (4 K + 1) / K update passes per
-                              // iteration instead of 4.5 (K = 4: 4.25), the same iterates
+                              // iteration instead of 4.5 (K = 4: 4.25), the same iterates; 1 (default): 2 on an unpartitioned lattice, 8 on a partitioned one (measured:
+                              // solvers.hip cg_ring_wanted); 0: x every iteration
     int cg_persist = 1;       // staggered CG on an unpartitioned lattice of <= 256 chunks: the whole solve is ONE launch (cg_persist.hip), two grid-wide
                               // synchronisations per iteration instead of three dependent launches; 0: the cg_small launch chain
     int cg_small = 1;         // fused CG on an unpartitioned lattice with <= 1024 stencil workgroups: the two reduction launches of an iteration are folded

@@ -367,9 +367,14 @@ void cg_work_put(CgWork& w) {
     for (lqcd_spinor_s*& f : w.more) { if (f) scratch_put(f); f = nullptr; }
 }
 // buffers of the deferred-x form: 2, or the ring of cg_defer_x = K = 3..8 (cg_setup takes the extra ones from the scratch pool; if the pool cannot grow: 2)
+// Measured (profiles/r05_cg_ring.log): at 32^3x64 on one GPU the ring does not pay (K = 2 / 4 / 8: 919.8 / 912.6 / 913.5 iter/s -- the flush kernel's K + 4 streams cost what
+// the saved passes win); at the N = 8 local volume, where the vectors live in the Infinity Cache, it does (5207 / 5254 / 5286 iter/s).  cg_defer_x = 1 (default) therefore
+// means: two buffers on an unpartitioned lattice, a ring of 8 on a partitioned one; 2 and 3..8 force a size.
 static int cg_ring_wanted(lqcd_op_s* op) {
     const int k = op->ctx->tun.cg_defer_x;
-    return (k >= 3 && op->kind != LQCD_DOMAINWALL) ? std::min(k, 8) : 2;
+    if (op->kind == LQCD_DOMAINWALL) return 2;
+    if (k >= 3) return std::min(k, 8);
+    return (k == 1 && any_partitioned(op->ctx)) ? 8 : 2;
 }
 static CgRing cg_ring_pending(const CgWork& w, int m) {      // the buffers of p_{k-m} .. p_{k-1}, oldest first, for k = w.k
     CgRing ring;

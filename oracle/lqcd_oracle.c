@@ -629,7 +629,7 @@ void orc_wilson_force(double* Gd, const double* Ud, const double* Xd, const doub
     long V = vol(L);
     cplx Gm[4][4][4];
     for (int nu = 0; nu < 4; nu++) gamma_mat(nu, Gm[nu]);
-#pragma omp parallel for collapse(2)
+#pragma omp parallel for collapse(2) num_threads(g_threads)
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
             for (int y = 0; y < L[1]; y++)
@@ -674,7 +674,7 @@ void orc_staggered_force(double* Gd, const double* Ud, const double* Xd, const d
     const cplx *U = (const cplx*)Ud, *X = (const cplx*)Xd, *Y = (const cplx*)Yd;
     cplx* G = (cplx*)Gd;
     long V = vol(L);
-#pragma omp parallel for collapse(2)
+#pragma omp parallel for collapse(2) num_threads(g_threads)
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
             for (int y = 0; y < L[1]; y++)
@@ -758,7 +758,7 @@ void orc_gauge_force(double* Gd, const double* Ud, const int L[4], double beta) 
     const cplx* U = (const cplx*)Ud;
     cplx* G = (cplx*)Gd;
     long V = vol(L);
-#pragma omp parallel for collapse(2)       /* same arithmetic per link whatever the thread count */
+#pragma omp parallel for collapse(2) num_threads(g_threads)       /* same arithmetic per link whatever the thread count */
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
             for (int y = 0; y < L[1]; y++)
@@ -782,7 +782,7 @@ void orc_momentum_add_ta(double* Pd, double cf, const double* Gd, const int L[4]
     const cplx* G = (const cplx*)Gd;
     long V = vol(L);
     for (int mu = 0; mu < 4; mu++)
-#pragma omp parallel for
+#pragma omp parallel for num_threads(g_threads)
         for (long s = 0; s < V; s++) {
             cplx M[3][3], tr = 0;
             for (int a = 0; a < 3; a++)
@@ -812,7 +812,7 @@ void orc_link_update(double* Ud, const double* Pd, double dt, const int L[4]) {
     const cplx* P = (const cplx*)Pd;
     long V = vol(L);
     for (int mu = 0; mu < 4; mu++)
-#pragma omp parallel for
+#pragma omp parallel for num_threads(g_threads)
         for (long s = 0; s < V; s++) {
             cplx X[3][3], E[3][3], T[3][3], Um[3][3];
             for (int a = 0; a < 3; a++)

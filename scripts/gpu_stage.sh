@@ -197,6 +197,17 @@ import json; d=json.load(open('$out/bench_proxy_n8local.json')); print({k: d.get
       LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 50 --warm 20 --cg 400 --set halo_stream_mode=3 --set cg_defer_x=$k 2>&1 | grep -E "^cg" | sed "s/^/N=8 fold=1 cg_defer_x=$k /"
     done | tee $out/ring.log
     ;;
+  call4)      # round 5, call 4: RCCL point-to-point channel settings against the halo exchange of the N = 8 proxy; the replayed callers with the oracle on one thread
+    for e in "" "NCCL_NCHANNELS_PER_PEER=4" "NCCL_NCHANNELS_PER_PEER=8" "NCCL_NCHANNELS_PER_PEER=16" "NCCL_NCHANNELS_PER_PEER=32" "NCCL_MIN_P2P_NCHANNELS=8 NCCL_MAX_P2P_NCHANNELS=8" "NCCL_MIN_P2P_NCHANNELS=16 NCCL_MAX_P2P_NCHANNELS=16" "NCCL_MIN_NCHANNELS=32" "NCCL_P2P_NET_CHUNKSIZE=1048576 NCCL_NCHANNELS_PER_PEER=8"; do
+      env $e LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 200 --warm 20 --cg 400 --set halo_stream_mode=3 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/[$e] /"; echo
+    done | tee $out/nccl_env.log
+    (cd /tmp && LQCD_FORCE_PARTITION=14 NCCL_NCHANNELS_PER_PEER=8 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/trace1 -o t -- python $GRAFT_REPO_ROOT/scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 20 --warm 5 --cg 64 --set halo_stream_mode=3 2>&1 | grep "^cg")
+    t=$(find $out/trace1 -name "*kernel_trace.csv" | head -1)
+    echo "== NCCL_NCHANNELS_PER_PEER=8" | tee $out/timeline.log
+    python scripts/timeline.py "$t" cg_update_ring 2>&1 | tee -a $out/timeline.log
+    rm -rf $out/trace1
+    timeout 600 python -m pytest tests/test_gpu_reference_callers.py tests/test_gpu_solver_edges.py -q -x --timeout=200 --timeout-method=thread --durations=5 2>&1 | tail -12 | tee $out/pytest.log
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log
