@@ -190,20 +190,20 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         // folded (round 5): the ghosts are complete before the stencil launch starts, so that launch takes the boundary hops from them itself (stencil.hip FOLD
         // instances) -- no exterior launch, no norm corrections, no exterior partials (stencil_num_partials follows halo_fold_applies).  A following
         // application's faces (pack_next: the D p -> D^+ pair of the fused CG) are packed from the finished output by a pack launch
-        if (halo_fold_applies(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr) && !s.clover_on_hop && !s.dot_partial && !s.alpha_partials && s.dw_ls <= 1) {
+        if (halo_fold_applies(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr) && !s.dot_partial && !s.alpha_partials && s.dw_ls <= 1) {
             StencilCall f = s;
             f.fold = 1;
             c->tun.halo_fold_active = 1;
-            LQCHK(launch_stencil_interior(c, f));
+            LQCHK(s.prec ? p32::launch_stencil_interior(c, f) : launch_stencil_interior(c, f));
             if (s.pack_next >= 0) {
                 StencilCall pk = s;
                 pk.in[0] = s.out[0]; pk.in[1] = s.out[1];
                 pk.dagger = s.pack_next;
-                if (s.defer_pack) {      // the caller's reduction of this application's partials is the next launch: the pack rides in it (reduce_pack_to_slot)
+                if (s.defer_pack && !s.prec && s.kind == LQCD_WILSON) {      // the caller's reduction of this application's partials is the next launch: the pack rides in it (reduce_pack_to_slot)
                     if (!c->waiting_pack) c->waiting_pack = new StencilCall;
                     *static_cast<StencilCall*>(c->waiting_pack) = pk;
                     c->has_waiting_pack = true;
-                } else LQCHK(launch_stencil_pack(c, pk));
+                } else LQCHK(s.prec ? p32::launch_stencil_pack(c, pk) : launch_stencil_pack(c, pk));
             }
             return LQCD_OK;
         }

@@ -183,6 +183,10 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
         for (int mu = 0; mu < 4; mu++)
             if ((mask >> mu) & 1) c->geom.part[mu] = 1;
     }
+    // testing aids of the same kind: the halo schedule (0..3, -1 = the collective one-off timing) and the folded form of schedule 3, so that the self-partition tests
+    // can pin the schedule they mean to cover without touching their drivers
+    if (const char* e = getenv("LQCD_HALO_STREAM_MODE")) c->tun.halo_stream_mode = atoi(e);
+    if (const char* e = getenv("LQCD_HALO_FOLD")) c->tun.halo_fold = atoi(e);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

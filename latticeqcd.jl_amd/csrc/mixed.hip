@@ -333,6 +333,7 @@ struct VariantPin {
 // (handle, version): a sequence of solves on the same links converts once.
 static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
     lqcd_ctx_s* c = op->ctx;
+    LQCHK(halo_schedule_settle(op));      // the inner solvers count |.|^2 partials: the halo schedule (folded or not, also for the fp32 build) is fixed from here on
     const bool clov = op->csw != 0.0 && op->clover != nullptr;
     if (clov && !(op->r == 1.0 && c->tun.dslash_variant == 1)) {
         set_error("mixed-precision solvers: the Wilson-clover operator needs the direction-split kernel (r = 1, dslash_variant = 1) in the fp32 inner solver");

@@ -75,8 +75,17 @@ __global__ __launch_bounds__(TB) void wilson_interior(KArgs k) {
 // through LDS and wave w writes spin row w.  Compared with one-lane-does-all-8-hops this cuts the wave lifetime ~6x and
 // phase-aligns the waves that touch the same lines, so the re-use of psi (9x) and of the links (2x) falls inside the
 // residency time of the XCD's 4 MiB L2 (measured: profiles/).  r = 1 only.
-template <int MU, bool DAG, bool R12>
-__device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i) {
+// (defined with the halo kernels below) out(n) += the hops of direction NU that cross a rank boundary, taken from the ghost buffers
+template <int NU, bool DAG>
+__device__ __forceinline__ void wilson_ext_add(cd (&acc)[12], const HArgs& k, const int (&c)[4], int slot, int pout, int i);
+template <int NU>
+__device__ __forceinline__ void staggered_ext_add(cd (&acc)[3], const HArgs& k, const int (&c)[4], int slot, int pout, int i);
+
+// FOLD (folded one-stream halo schedule, apply.hip): the exchange is complete when the kernel starts, so the hops that leave the rank -- skipped by sign 0 above --
+// are added from the ghost buffers by the direction wave itself (wilson_ext_add: the arithmetic of the exterior kernel).  Any partitioned direction, any instance of
+// this kernel (clover epilogue, inverse clover blocks on the hop sum, fp32 build); the scalar-addressing kernel has its own FOLD instances (sdir_wave).
+template <int MU, bool DAG, bool R12, bool FOLD = false>
+__device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i, const HArgs* h = nullptr) {
     Nbr n;
     int c[4];
     neighbours(k.g, p, i, n, c);
@@ -111,6 +120,7 @@ __device__ inline void dirsplit_hops(cd (&acc)[12], const KArgs& k, int p, int i
 #endif
     if (n.sf[MU] != 0.0) wilson_hop<MU, SF, false, R12>(acc, psi + sp12_off(n.fwd[MU]), Uf, Vh, Us, n.sf[MU], (k.nt & 2) != 0);
     if (n.sb[MU] != 0.0) wilson_hop<MU, -SF, true, R12>(acc, psi + sp12_off(n.bwd[MU]), Ub, Vh, Us, n.sb[MU], (k.nt & 1) != 0, (k.nt & 8) != 0);
+    if constexpr (FOLD) wilson_ext_add<MU, DAG>(acc, *h, c, k.parity_mode == 2 ? p : 0, p, i);
 }
 
 // rows 3*W .. 3*W+2 of A x for the packed clover field (clover.hip: two Hermitian 6x6 blocks in the chiral basis chi_(-+) =
@@ -161,8 +171,8 @@ __device__ inline void clover_rows(cd (&out)[3], const real2* __restrict__ a, co
 // CINV (even-odd Wilson-clover solver): the packed matrix k.clover (the INVERSE clover blocks of the output parity) is applied to the HOP SUM,
 // out = a xin + b C (H in), where CLOV applies it to the diagonal term -- the Schur operator 1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe becomes two launches
 // with no intermediate field (every wave rebuilds the 12 summed components from the four direction partials: 48 LDS reads instead of 12).
-template <bool DAG, bool R12 = false, bool CLOV = false, bool DOT = false, bool CINV = false>
-__global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
+template <bool DAG, bool R12, bool CLOV, bool DOT, bool CINV, bool FOLD>
+__device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs* hf) {
     __shared__ real2 part[4][12][64];  // 48 KiB
     __shared__ double red[DOT ? 12 : 4];
     if (upd_done(k)) return;
@@ -208,10 +218,10 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
     }
     if (valid) {
         switch (w) {
-        case 0: dirsplit_hops<0, DAG, R12>(acc, k, p, i); break;
-        case 1: dirsplit_hops<1, DAG, R12>(acc, k, p, i); break;
-        case 2: dirsplit_hops<2, DAG, R12>(acc, k, p, i); break;
-        default: dirsplit_hops<3, DAG, R12>(acc, k, p, i); break;
+        case 0: dirsplit_hops<0, DAG, R12, FOLD>(acc, k, p, i, hf); break;
+        case 1: dirsplit_hops<1, DAG, R12, FOLD>(acc, k, p, i, hf); break;
+        case 2: dirsplit_hops<2, DAG, R12, FOLD>(acc, k, p, i, hf); break;
+        default: dirsplit_hops<3, DAG, R12, FOLD>(acc, k, p, i, hf); break;
         }
     }
     if (LQCD_UPD_PREFETCH == 2 && valid && k.upd_scal) {
@@ -280,6 +290,17 @@ __global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) {
         if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
+
+template <bool DAG, bool R12 = false, bool CLOV = false, bool DOT = false, bool CINV = false>
+__global__ LQCD_DS_BOUNDS void wilson_dirsplit(KArgs k) { wilson_dirsplit_body<DAG, R12, CLOV, DOT, CINV, false>(k, nullptr); }
+// the same launch with the boundary hops folded in (no exterior kernel): the HArgs carry the ghost buffers and the boundary signs of this rank
+#ifdef LQCD_F32
+#define LQCD_DS_BOUNDS_FOLD LQCD_DS_BOUNDS
+#else
+#define LQCD_DS_BOUNDS_FOLD __launch_bounds__(256, CLOV ? 2 : 3)      // (the ghost path adds ~4 VGPRs: without the cap two 18-real instances land on 169 and lose a wave per SIMD)
+#endif
+template <bool DAG, bool R12 = false, bool CLOV = false, bool CINV = false>
+__global__ LQCD_DS_BOUNDS_FOLD void wilson_dirsplit_fold(KArgs k, HArgs h) { wilson_dirsplit_body<DAG, R12, CLOV, false, CINV, true>(k, &h); }
 
 
 // ------------------------------------------------------------------------------------------ Wilson, direction-split, persistent + software-pipelined
@@ -1027,8 +1048,8 @@ __global__ __launch_bounds__(TB) void staggered_interior(KArgs k) {
 // BOTH (unpartitioned lattices: no hop is ever skipped): no branch in the body, the loads of the forward AND the backward hop are issued
 // back to back -- one memory round trip per wave instead of two -- and the arithmetic follows in stag_hop's order (bit-identical results).
 // The staggered kernel is light on registers, so unlike the Wilson variant 8 this costs little occupancy.
-template <bool R12, bool BOTH = false, bool NTB = false>
-__global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
+template <bool R12, bool BOTH, bool NTB, bool FOLD>
+__device__ __forceinline__ void staggered_dirsplit_body(const KArgs& k, const HArgs* hf) {
     __shared__ real2 part[4][3][64];
     __shared__ double red[4];
     if (upd_done(k)) return;
@@ -1095,6 +1116,15 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         const real2* __restrict__ Ub = R12 ? k.gauge12 + gl12_off(k.g, 1 - p, w, nb) : k.gauge + glink_off(k.g, 1 - p, w, nb);
         if (sf != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nf), Uf, Vh, Us, eta * sf, false, (k.nt & 2) != 0);
         if (sb != 0.0) stag_hop<R12>(acc, psi + sp_off(3, nb), Ub, Vh, Us, -eta * sb, true, (k.nt & 1) != 0);
+        if constexpr (FOLD) {      // folded halo schedule: this direction's hops that leave the rank, from the ghost buffers (the exterior kernel's arithmetic)
+            const int slot = k.parity_mode == 2 ? p : 0;
+            switch (w) {
+            case 0: staggered_ext_add<0>(acc, *hf, c, slot, p, i); break;
+            case 1: staggered_ext_add<1>(acc, *hf, c, slot, p, i); break;
+            case 2: staggered_ext_add<2>(acc, *hf, c, slot, p, i); break;
+            default: staggered_ext_add<3>(acc, *hf, c, slot, p, i); break;
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
@@ -1114,6 +1144,11 @@ __global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) {
         if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
+
+template <bool R12, bool BOTH = false, bool NTB = false>
+__global__ __launch_bounds__(256) void staggered_dirsplit(KArgs k) { staggered_dirsplit_body<R12, BOTH, NTB, false>(k, nullptr); }
+template <bool R12>
+__global__ __launch_bounds__(256) void staggered_dirsplit_fold(KArgs k, HArgs h) { staggered_dirsplit_body<R12, false, false, true>(k, &h); }
 
 // ------------------------------------------------------------------------------------------ halo: pack
 // blockIdx.y = 2*mu + side.  side 0: lower face (x_mu = 0) -> send_bwd[mu] = P psi   (receiver's forward hop)
@@ -1603,6 +1638,32 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     return a;
 }
 
+static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s);
+
+// folded launch of the direction-split kernels (every case the scalar-addressing FOLD instances do not take)
+static int launch_dirsplit_fold(lqcd_ctx_s* c, const StencilCall& s, const KArgs& k) {
+    if (k.dot_partial || k.alpha_partials || s.dw_ls > 1 || (s.kind == LQCD_WILSON && s.r != 1.0)) {
+        set_error("stencil: the folded launch has no dot / small-lattice / five-dimensional / general-r form");
+        return LQCD_ERR_UNSUPPORTED;
+    }
+    HArgs h = make_hargs(c, s);
+    const dim3 grid(k.nblocks), block(256);
+    if (s.kind == LQCD_STAGGERED) {
+        if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit_fold<true>), grid, block, 0, c->stream, k, h);
+        else hipLaunchKernelGGL((staggered_dirsplit_fold<false>), grid, block, 0, c->stream, k, h);
+    } else {
+#define LQ_DF(R, CL, CI) do { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit_fold<true, R, CL, CI>), grid, block, 0, c->stream, k, h); \
+                              else hipLaunchKernelGGL((wilson_dirsplit_fold<false, R, CL, CI>), grid, block, 0, c->stream, k, h); } while (0)
+        if (s.clover_on_hop) { if (!k.clover) { set_error("stencil: clover-on-hop needs the packed blocks"); return LQCD_ERR_UNSUPPORTED; }
+                               if (k.gauge12) LQ_DF(true, false, true); else LQ_DF(false, false, true); }
+        else if (k.clover) { if (k.gauge12) LQ_DF(true, true, false); else LQ_DF(false, true, false); }
+        else { if (k.gauge12) LQ_DF(true, false, false); else LQ_DF(false, false, false); }
+#undef LQ_DF
+    }
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
 int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
     if (s.dw_ls > 1 && !stencil_dw5_applies(c, s)) { set_error("stencil: the five-dimensional launch does not apply to this call (domainwall.hip checks before asking)"); return LQCD_ERR_UNSUPPORTED; }
     if (use_dirsplit(c, s.kind, s.r)) {
@@ -1612,6 +1673,11 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         const bool delta = s.gauge12_delta && !kF32Build && s.kind == LQCD_WILSON && k.gauge12 && !k.alpha_partials && !k.dot_partial && !s.clover_on_hop && !k.clover && !s.fold &&
                            c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false);
         if (s.gauge12_delta && !delta) { k.gauge12 = nullptr; c->tun.recon_active = 0; }
+        if (s.fold) {      // folded halo schedule: the scalar-addressing FOLD instances where they exist, the folded twins of the direction-split kernels otherwise
+            const bool sdir = !kF32Build && s.kind == LQCD_WILSON && s.r == 1.0 && !k.clover && !s.clover_on_hop && !k.dot_partial && !k.alpha_partials && s.dw_ls <= 1 &&
+                              !k.g.part[0] && c->tun.dslash_pipe == 2 && (k.gauge12 || c->tun.dslash_s18) && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false);
+            if (!sdir) return launch_dirsplit_fold(c, s, k);
+        }
         if (s.kind == LQCD_STAGGERED) {
             const bool both = c->tun.stag_both && !(c->geom.part[0] || c->geom.part[1] || c->geom.part[2] || c->geom.part[3]);
             const dim3 sg(k.nblocks), sb_(256);
@@ -1864,14 +1930,18 @@ bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, boo
     return nvirt >= std::max(1, c->tun.pipe_min_chunks) * wilson_pipe_grid(c, nvirt, 0);
 }
 // The folded one-stream halo schedule (apply.hip stencil_apply; tunable halo_fold): pack -> exchange -> ONE stencil launch that reads the ghost buffers itself.
-// Where: the RCCL path with schedule 3 chosen, Wilson r = 1 in fp64 on the scalar-addressing kernel (either link format: dslash_s18), no clover term in the
-// launch, x unpartitioned (the x face cuts through chunks lane by lane; the recommended PE grids keep x whole).
+// Where: the RCCL path with schedule 3 chosen; Wilson (r = 1 calls: plain, clover epilogue, inverse clover blocks on the hop sum) and staggered, fp64 and the fp32
+// build.  The scalar-addressing Wilson kernel has its own FOLD instances (fp64, x unpartitioned, no clover term); everything else takes the folded twins of the
+// direction-split kernels (wilson_dirsplit_fold / staggered_dirsplit_fold: the exterior kernel's arithmetic inside the direction waves).
 bool halo_fold_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
-    if (!c->tun.halo_fold || c->tun.halo_stream_mode != 3 || kF32Build) return false;
-    if (!any_partitioned(c) || !c->has_comm || !c->local_peers.empty() || c->geom.part[0]) return false;
-    if (kind != LQCD_WILSON || prec != 0 || clover || c->tun.dslash_pipe != 2 || !c->tun.dslash_s18) return false;
-    (void)r;      // on a partitioned lattice a general-r application is two r = 1 calls (apply.hip split_general_r): the launch geometry is the r = 1 one for every r
-    return wilson_pipe_applies(c, kind, 1.0, parity_mode, false);
+    if (!c->tun.halo_fold || c->tun.halo_stream_mode != 3) return false;
+    if (!any_partitioned(c) || !c->has_comm || !c->local_peers.empty()) return false;
+    if ((kind != LQCD_WILSON && kind != LQCD_STAGGERED) || (prec != 0 && prec != 1)) return false;
+    // the direction-split kernels with one workgroup per chunk (default and scalar-addressing form): every instance has a folded twin.  Not the persistent forms
+    // (dslash_pipe 1 / 3) and not the experiment variants.
+    if (c->tun.dslash_variant != 1 || (c->tun.dslash_pipe != 0 && c->tun.dslash_pipe != 2)) return false;
+    (void)r; (void)parity_mode; (void)clover;      // on a partitioned lattice a general-r application is two r = 1 calls (apply.hip split_general_r)
+    return true;
 }
 // interior block partials + (partitioned lattice, unless the launch is folded) the exterior kernel's correction partials
 int stencil_num_partials(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {

@@ -28,7 +28,7 @@ for kv in a.set:
     lat.set_param(k, int(v))
 U = lq.Gaugefields(lat)
 lq.lib.check(lq.lib.lib().lqcd_gauge_hot_start(U._h, ctypes.c_uint64(111)))
-D = lq.Dirac_operator(U, None, {"Dirac_operator": a.kind, "κ": 0.141139, "mass": 0.5})
+D = lq.Dirac_operator(U, None, {"Dirac_operator": a.kind, "κ": 0.141139, "mass": 0.5, "Clover_coefficient": 1.0})
 kind = lq.STAGGERED if a.kind == "Staggered" else lq.WILSON
 b = lq.Fermionfields(lat, kind)
 lq.gauss_distribution_fermion_(b, 112)

@@ -208,6 +208,18 @@ import json; d=json.load(open('$out/bench_proxy_n8local.json')); print({k: d.get
     rm -rf $out/trace1
     timeout 600 python -m pytest tests/test_gpu_reference_callers.py tests/test_gpu_solver_edges.py -q -x --timeout=200 --timeout-method=thread --durations=5 2>&1 | tail -12 | tee $out/pytest.log
     ;;
+  call5)      # round 5, call 5: the folded schedule for every operator (clover, staggered, fp32, x-partitioned): every self-partition test, proxies of configs 4 and 5
+    timeout 1500 python -m pytest tests/test_gpu_halo_fuse.py tests/test_gpu_clover.py tests/test_gpu_mixed.py tests/test_gpu_md_partitioned.py tests/test_gpu_hmc_partitioned.py \
+        tests/test_gpu_bench_dist.py tests/test_gpu_stout.py tests/test_gpu_solver_edges.py -q -x --timeout=300 --timeout-method=thread --durations=8 2>&1 | tail -22 | tee $out/pytest_a.log
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_domainwall.py tests/test_gpu_pipe.py -q -x -k "rccl or partition" --timeout=300 --timeout-method=thread 2>&1 | tail -6 | tee $out/pytest_b.log
+    for f in 0 1; do
+      LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --kind Staggered --lattice 48,24,24,48 --selfcomm 1 --reps 100 --warm 20 --cg 200 --set halo_stream_mode=3 --set halo_fold=$f 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/staggered 48^3x96 N=8 local fold=$f /"; echo
+      LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --kind WilsonClover --lattice 32,16,16,32 --selfcomm 1 --reps 100 --warm 20 --cg 200 --set halo_stream_mode=3 --set halo_fold=$f 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/clover 32^3x64 N=8 local fold=$f /"; echo
+      LQCD_FORCE_PARTITION=15 timeout 200 python scripts/dslash_probe.py --lattice 16,16,16,32 --selfcomm 1 --reps 100 --warm 20 --cg 200 --set halo_stream_mode=3 --set halo_fold=$f 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/wilson N=16 local (x too) fold=$f /"; echo
+    done | tee $out/proxy_configs45.log
+    LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 100 --warm 20 --cg 400 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/wilson N=8 tuner /" | tee -a $out/proxy_configs45.log; echo
+    timeout 200 python scripts/dslash_probe.py --lattice 32,32,32,64 --reps 100 --warm 20 --cg 300 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=1 /" | tee -a $out/proxy_configs45.log; echo
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log

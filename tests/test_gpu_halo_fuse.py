@@ -60,16 +60,26 @@ CODE = textwrap.dedent("""
             assert lat.get_param("halo_fold_active") == 1, "the folded schedule did not run where it applies"
     assert (folded > 0) == bool(FOLDS), (folded, FOLDS)
     lat.set_param("halo_fold", 1)
-    # the staggered operator takes the fused reduction only
+    # the staggered operator: the fused reduction only (unfolded schedules), and the folded twin of its direction-split kernel (schedule 3)
     Ds = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Staggered", "mass": 0.5, "boundarycondition": BC, "eps_CG": 1e-19})
     ps = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 113)
     xs = lq.Fermionfields(lat, lq.STAGGERED).upload(ps)
+    ys = xs.similar()
     xo, ito, rro, st = orc.cg_DdagD(orc.STAGGERED, U, ps, L, 0.5, 1.0, BC, eps=1e-19)
-    for fuse in (0, 3):
-        lat.set_param("halo_fuse", fuse)
-        sol = xs.similar()
-        it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(Ds), xs, return_info=True)
-        assert st == 0 and abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (fuse, it, ito)
+    for mode, hfold in ((0, 1), (3, 0), (3, 1)):
+        lat.set_param("halo_stream_mode", mode); lat.set_param("halo_fold", hfold)
+        for dag in (False, True):
+            lq.mul_(ys, Ds.adjoint() if dag else Ds, xs)
+            ref = orc.apply_D(lq.STAGGERED, U, ps, L, 0.5, 1.0, BC, dag)
+            e = np.abs(ys.download() - ref).max() / np.abs(ref).max()
+            assert e < 1e-13, ("staggered", mode, hfold, dag, e)
+        assert lat.get_param("halo_fold_active") == (1 if mode == 3 and hfold else 0)
+        for fuse in (0, 3):
+            lat.set_param("halo_fuse", fuse)
+            sol = xs.similar()
+            it, rr = lq.solve_DinvX_(sol, lq.DdagD_operator(Ds), xs, return_info=True)
+            assert st == 0 and abs(it - ito) <= 1 and np.abs(sol.download() - xo).max() / np.abs(xo).max() < 1e-9, (mode, hfold, fuse, it, ito)
+    lat.set_param("halo_stream_mode", -1)
     # general r (two r = 1 passes per application): no pre-packing, same answer
     Dr = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": 0.12, "r": 0.8, "boundarycondition": BC, "eps_CG": 1e-19})
     xo, ito, rro, st = orc.cg_DdagD(orc.WILSON, U, psi, L, 0.12, 0.8, BC, eps=1e-19)
@@ -81,9 +91,11 @@ CODE = textwrap.dedent("""
 """)
 
 
-# folds: z-planes of whole chunks (XH * LY a multiple of 64), the chunks of a t-slice split over 8 XCDs, x unpartitioned (stencil.hip halo_fold_applies)
-@pytest.mark.parametrize("L,mask,folds", [((8, 4, 6, 8), "8", 0), ((8, 4, 6, 8), "14", 0), ((8, 4, 6, 8), "15", 0), ((16, 8, 8, 4), "14", 1), ((16, 8, 8, 4), "8", 1),
-                                          ((16, 8, 8, 4), "15", 0), ((16, 16, 8, 4), "12", 1), ((32, 4, 8, 6), "6", 1)])
+# Every partitioned lattice folds (stencil.hip halo_fold_applies).  Which kernel: the scalar-addressing FOLD instances where z-planes are whole chunks (XH * LY a
+# multiple of 64), the chunks of a t-slice split over 8 XCDs and x is unpartitioned -- (16,8,8,4) masks 14 / 8, (16,16,8,4), (32,4,8,6); the folded twins of the
+# direction-split kernels everywhere else -- (8,4,6,8) and every mask with the x bit.
+@pytest.mark.parametrize("L,mask,folds", [((8, 4, 6, 8), "8", 1), ((8, 4, 6, 8), "14", 1), ((8, 4, 6, 8), "15", 1), ((16, 8, 8, 4), "14", 1), ((16, 8, 8, 4), "8", 1),
+                                          ((16, 8, 8, 4), "15", 1), ((16, 16, 8, 4), "12", 1), ((32, 4, 8, 6), "6", 1)])
 def test_fused_tails_on_the_rccl_path(lq, L, mask, folds):
     assert lq.lib.device_count() > 0, "no HIP device visible: the product has no CPU fallback"
     env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -126,6 +126,7 @@ def test_wilson_clover_md_trajectory_self_partitioned_equals_one_domain(lq, orc,
         env.pop("LQCD_FORCE_PARTITION", None)
         if mask:
             env["LQCD_FORCE_PARTITION"] = mask
+            env["LQCD_HALO_STREAM_MODE"] = "3"      # the folded one-stream schedule (the unpartitioned run it is compared with has no halos)
         r = subprocess.run([sys.executable, "-c", code, str(tmp_path), tag], capture_output=True, text=True, env=env, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "TRAJ_OK" in r.stdout, (tag, r.stdout[-2000:], r.stderr[-3000:])
@@ -188,6 +189,7 @@ def test_staggered_rhmc_md_trajectory_self_partitioned_equals_one_domain(lq, orc
             env.pop("LQCD_FORCE_PARTITION", None)
             if mask:
                 env["LQCD_FORCE_PARTITION"] = mask
+                env["LQCD_HALO_STREAM_MODE"] = "3"      # the folded one-stream schedule (the unpartitioned run it is compared with has no halos)
             r = subprocess.run([sys.executable, "-c", code, str(tmp_path), tag, str(nf), str(mixed)], capture_output=True, text=True, env=env, timeout=400, cwd=root)
             assert r.returncode == 0 and "TRAJ_OK" in r.stdout, (nf, tag, r.stdout[-2000:], r.stderr[-3000:])
             res[tag] = np.load(tmp_path / ("out_%s.npy" % tag))

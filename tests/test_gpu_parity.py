@@ -549,7 +549,7 @@ def test_rccl_self_partition_general_r_solvers(gpu, orc):
         print("RCCL_SELF_R_OK")
     """)
     for mask in ("8", "14"):
-        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0", LQCD_HALO_STREAM_MODE=("-1" if mask == "8" else "3"))      # t only: the tuner's choice; the others: the folded one-stream schedule
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "RCCL_SELF_R_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
@@ -615,7 +615,7 @@ def test_rccl_self_partition_dslash_and_cg(gpu, orc):
         print("RCCL_SELF_OK")
     """)
     for mask in ("8", "14", "15"):     # t only; y,z,t (the 8-GPU grid shape); all four
-        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, LQCD_FORCE_PARTITION=mask, HSA_ENABLE_IPC_MODE_LEGACY="0", LQCD_HALO_STREAM_MODE=("-1" if mask == "8" else "3"))      # t only: the tuner's choice; the others: the folded one-stream schedule
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "RCCL_SELF_OK" in r.stdout, (mask, r.stdout[-2000:], r.stderr[-3000:])
