@@ -184,7 +184,9 @@ def test_pipe_rccl_self_partition(gpu, orc):
         for dag in (False, True):
             lq.mul_(y, D.adjoint() if dag else D, x)
             ref = orc.wilson_D(Up, psi, L, K, 1.0, BC, dag)
-            assert lat.get_param("recon_active") == 2 and np.abs(y.download() - ref).max() / np.abs(ref).max() < 1e-13, ("delta", dag, lat.get_param("recon_active"))
+            # (the folded halo schedule has no "12 + delta" instance: it reads the 18 stored reals of such a field)
+            want = 0 if lat.get_param("halo_fold_active") else 2
+            assert lat.get_param("recon_active") == want and np.abs(y.download() - ref).max() / np.abs(ref).max() < 1e-13, ("delta", dag, lat.get_param("recon_active"), want)
         print("PIPE_SELF_OK")
     """)
     for mask in ("8", "14", "15"):
