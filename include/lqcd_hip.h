@@ -96,8 +96,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * two buffers -- 9 instead of 10 spinor passes per iteration on average, identical iterates; K = 3..8 (round 5): a ring of K search-direction buffers,
  * x += K terms every K-th iteration, (4 K + 1) / K update passes per iteration; 1 [default]: 2 on an unpartitioned lattice, 8 on a partitioned one (what was measured
  * faster in each case); 0: x every iteration),
- * halo_fold (1 [default], round 5: where the collective timing picks the one-stream halo schedule 3, the Wilson r = 1 stencil launch takes the boundary hops from the ghost
- * buffers itself -- no exterior kernel; fp64 scalar-addressing kernel, x unpartitioned; read-only halo_fold_active), cg_persist (1 [default]: a staggered CG on an unpartitioned lattice of
+ * halo_fold (1 [default], round 5: where the collective timing picks the one-stream halo schedule 3, the stencil launch takes the boundary hops from the ghost
+ * buffers itself -- no exterior kernel, for every operator and both precisions; read-only halo_fold_active), cg_persist (1 [default]: a staggered CG on an unpartitioned lattice of
  * at most 256 chunks of 64 sites runs as ONE launch -- initial residual and all iterations, two grid-wide synchronisations per iteration, every wait bounded: if the workgroups are not all resident (a busy GPU) x is left untouched, the solve is
  * repeated by the launch chain and the key drops to 0; 0: the launch chain; 2: test hook that forces that fall-back), cg_small (1 [default]: on an unpartitioned lattice with <= 1024 stencil workgroups the two reduction launches of a fused CG
  * iteration are folded into the prologues of the kernels that consume them -- 3 dependent launches instead of 5, identical iterates), clover_fused (1 [default]: A x in the epilogue of the split kernel), clover_transport (1: partitioned-lattice

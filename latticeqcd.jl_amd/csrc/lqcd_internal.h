@@ -474,9 +474,9 @@ struct Tunables {
     int halo_tuned_us[4] = {0, 0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
-    int halo_fold = 1;        // halo schedule 3 (everything in order on one stream), Wilson r = 1, fp64, scalar-addressing kernel, x unpartitioned: the interior launch reads
-                              // the ghost buffers itself (the exchange is complete before it starts) -- no exterior launch, no norm corrections (stencil.hip FOLD instances);
-                              // 0: the separate exterior kernel
+    int halo_fold = 1;        // halo schedule 3 (everything in order on one stream): the stencil launch reads the ghost buffers itself (the exchange is complete before it
+                              // starts) -- no exterior launch, no norm corrections; scalar-addressing Wilson kernel: its FOLD instances, everything else: the folded twins of
+                              // the direction-split kernels (stencil.hip halo_fold_applies); 0: the separate exterior kernel
     int halo_fold_active = 0; // read-only: the last partitioned stencil application ran folded (no exterior launch)
     int halo_fuse = 2;        // partitioned fused CG (Wilson, fp64): bit 0 = the exterior's last block does the final reduction (no reduce_final launch),
                               // bit 1 = the exterior of D p packs the faces D^+ needs and the x/p update packs the new p (no pack launches).
