@@ -220,6 +220,31 @@ import json; d=json.load(open('$out/bench_proxy_n8local.json')); print({k: d.get
     LQCD_FORCE_PARTITION=14 timeout 200 python scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 100 --warm 20 --cg 400 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/wilson N=8 tuner /" | tee -a $out/proxy_configs45.log; echo
     timeout 200 python scripts/dslash_probe.py --lattice 32,32,32,64 --reps 100 --warm 20 --cg 300 2>&1 | grep -E "^dslash|^cg" | tr '\n' ' ' | sed "s/^/N=1 /" | tee -a $out/proxy_configs45.log; echo
     ;;
+  proxyprof)  # round 5: rocprofv3 evidence of the partitioned CG at the N = 8 local volume (folded schedule): kernel stats, fabric traffic of its kernels
+    P="python $GRAFT_REPO_ROOT/scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 20 --warm 5 --cg 400 --set halo_stream_mode=3"
+    (cd /tmp && LQCD_FORCE_PARTITION=14 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -o p -- $P 2>&1 | grep "^cg")
+    f=$(find $out/stats -name "*kernel_stats.csv" | head -1); cp "$f" $out/kernel_stats.csv; head -12 $out/kernel_stats.csv | cut -c1-200
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      (cd /tmp && LQCD_FORCE_PARTITION=14 timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_$ctr -o p -- python $GRAFT_REPO_ROOT/scripts/dslash_probe.py --lattice 32,16,16,32 --selfcomm 1 --reps 5 --warm 2 --cg 40 --set halo_stream_mode=3 > /dev/null 2>&1)
+    done
+    python - $out <<'PY' | tee $out/pmc_traffic.log
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(out + "/pmc_" + ctr + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == ctr:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")[:70]][ctr].append(float(r["Counter_Value"]))
+print("# fabric traffic per launch at the N = 8 local volume 32x16x16x32 (262144 sites): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md")
+for k, v in sorted(acc.items()):
+    if v["FETCH_SIZE"] and v["WRITE_SIZE"]:
+        fe, wr = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+        b = (2 * fe + wr) * 1024
+        print("%-72s launches %4d  traffic %8.2f MB = %6.0f B/site" % (k, len(v["FETCH_SIZE"]), b / 1e6, b / 262144))
+PY
+    rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+    ;;
   suite)      # what the driver does at round end
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -3
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 2>&1 | tail -25 | tee $out/pytest.log
