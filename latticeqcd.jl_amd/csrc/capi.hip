@@ -183,6 +183,19 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
         for (int mu = 0; mu < 4; mu++)
             if ((mask >> mu) & 1) c->geom.part[mu] = 1;
     }
+    // Volume-adaptive defaults (round 5, profiles/r05_small_volume_hints.log; every one of them can be set afterwards).  The map and the cache hints were tuned at
+    // 32^3 x 64, where links and spinors stream from HBM.  At the local volumes of a partitioned run the picture changes: (i) a t-slice of fewer than 256 chunks per
+    // parity splits into 8 sub-domains (one per XCD, tiled 2 x in y) instead of 16 -- with 16 every XCD sweeps t twice over sub-domains of 4-8 chunks and loses the
+    // t-neighbour locality; (ii) 12-real links of at most 256 MB stay in the Infinity Cache between applications unless their last use streams them through (nt_gauge
+    // bit 0); (iii) an output spinor of at most 64 MB is read again (by D^+, by the update) before it would leave the cache: plain stores.  N = 8 local volume of
+    // 32^3 x 64: 187.7 -> 181.9 us per CG iteration; N = 4: 325.1 -> 319.5; N = 2 and N = 1: unchanged (the defaults stay).
+    {
+        const Geom& g = c->geom;
+        const long slice = (long)g.XH * g.L[1] * g.L[2];
+        if (slice % 64 == 0 && slice / 64 < 256) { c->tun.xcd_nsub = 8; c->tun.xcd_ysplit = 2; }
+        if (gauge12_elems(g) * sizeof(double2) <= ((size_t)256 << 20)) c->tun.nt_gauge = 0;
+        if ((size_t)24 * g.Vh * sizeof(double2) <= ((size_t)64 << 20)) c->tun.nt_store = 0;
+    }
     // testing aids of the same kind: the halo schedule (0..3, -1 = the collective one-off timing) and the folded form of schedule 3, so that the self-partition tests
     // can pin the schedule they mean to cover without touching their drivers
     if (const char* e = getenv("LQCD_HALO_STREAM_MODE")) c->tun.halo_stream_mode = atoi(e);

@@ -14,9 +14,13 @@ L = (16, 16, 16, 32)
 if "--L" in args:
     L = tuple(int(v) for v in args[args.index("--L") + 1].split(","))
 reps = int(args[args.index("--reps") + 1]) if "--reps" in args else 20
-modes = [int(a) for a in args if a.isdigit() and len(a) == 1] or [2]
 U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
 lat = U.lattice
+while "--set" in args:      # --set key=value: library tunable
+    i = args.index("--set")
+    k, v = args[i + 1].split("=")
+    lat.set_param(k, int(v))
+    del args[i:i + 2]
 csw = float(args[args.index("--csw") + 1]) if "--csw" in args else 0.0
 D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover" if csw else "Wilson", "Clover_coefficient": csw, "κ": 0.141139, "eps_CG": 1e-16, "MaxCGstep": 3000})
 D.method_CG = "bicgstab_evenodd"
@@ -49,6 +53,7 @@ if "--diff" in args:
         print("after %d iterations: max |x(unfolded) - x(folded)| = %.3e (relative %.3e)" % (k, d, d / np.abs(got[1]).max()))
     sys.exit(0)
 import time
+modes = [int(a) for a in args if a.isdigit() and len(a) == 1] or [2]
 for m in modes:
     lat.set_param("bicg_fused", m)
     lq.clear_fermion_(x)
