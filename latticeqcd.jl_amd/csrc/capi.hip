@@ -184,7 +184,7 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
             if ((mask >> mu) & 1) c->geom.part[mu] = 1;
     }
     // Volume-adaptive defaults (round 5, profiles/r05_small_volume_hints.log; every one of them can be set afterwards).  The map and the cache hints were tuned at
-    // 32^3 x 64, where links and spinors stream from HBM.  At the local volumes of a partitioned run the picture changes: (i) a t-slice of fewer than 256 chunks per
+    // 32^3 x 64, where links and spinors stream from HBM.  At the local volumes of a partitioned run the picture changes: (i) a t-slice of at most 128 chunks per
     // parity splits into 8 sub-domains (one per XCD, tiled 2 x in y) instead of 16 -- with 16 every XCD sweeps t twice over sub-domains of 4-8 chunks and loses the
     // t-neighbour locality; (ii) 12-real links of at most 256 MB stay in the Infinity Cache between applications unless their last use streams them through (nt_gauge
     // bit 0); (iii) an output spinor of at most 64 MB is read again (by D^+, by the update) before it would leave the cache: plain stores.  N = 8 local volume of
@@ -192,7 +192,7 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     {
         const Geom& g = c->geom;
         const long slice = (long)g.XH * g.L[1] * g.L[2];
-        if (slice % 64 == 0 && slice / 64 < 256) { c->tun.xcd_nsub = 8; c->tun.xcd_ysplit = 2; }
+        if (slice % 64 == 0 && slice / 64 <= 128) { c->tun.xcd_nsub = 8; c->tun.xcd_ysplit = 2; }
         if (gauge12_elems(g) * sizeof(double2) <= ((size_t)256 << 20)) c->tun.nt_gauge = 0;
         if ((size_t)24 * g.Vh * sizeof(double2) <= ((size_t)64 << 20)) c->tun.nt_store = 0;
     }
