@@ -596,6 +596,12 @@ function estimate_spectrum(A::HIPDdagD; steps = 60, seed = 4711)
     check(ccall((:lqcd_estimate_spectrum, LIB), Cint, (Ptr{Cvoid}, Cint, UInt64, Ref{Float64}, Ref{Float64}), A.D.h, steps, seed, lo, hi))
     return lo[], hi[]
 end
+# Ritz value `index` (1-based, ascending) of a Lanczos tridiagonal and |last eigenvector component|: β_n times it bounds the distance to an eigenvalue
+function tridiag_ritz(diag::Vector{Float64}, offdiag::Vector{Float64}, index::Integer)
+    θ, s = Ref{Float64}(0), Ref{Float64}(0)
+    check(ccall((:lqcd_tridiag_ritz, LIB), Cint, (Cint, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Float64}, Ref{Float64}), length(diag), diag, offdiag, index - 1, θ, s))
+    return θ[], s[]
+end
 rational_apply!(y::HIPFermion, D::HIPDirac, x::HIPFermion, a0, res::Vector{Float64}, poles::Vector{Float64}) =
     check(ccall((:lqcd_rational_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Ptr{Cint}),
                 D.h, y.h, x.h, a0, length(res), res, poles, D.eps_CG, D.MaxCGstep, C_NULL))

@@ -452,6 +452,18 @@ static int lanczos_certified(lqcd_op_t op, int min_steps, int max_steps, double 
     return LQCD_OK;
 }
 
+// the host half of the certificate on its own (no device): the index-th eigenvalue (ascending) of the symmetric tridiagonal and |last component| of its
+// normalised eigenvector, so that the bound can be checked against a dense eigensolver without a GPU (tests/test_rational.py)
+extern "C" int lqcd_tridiag_ritz(int n, const double* diag, const double* offdiag, int index, double* theta, double* last_component) {
+    ARGCHK(n >= 1 && diag && (offdiag || n == 1) && theta && last_component, "lqcd_tridiag_ritz: bad argument");
+    ARGCHK(index >= 0 && index < n, "lqcd_tridiag_ritz: index out of range");
+    std::vector<double> a(diag, diag + n), b;
+    if (n > 1) b.assign(offdiag, offdiag + (n - 1));
+    *theta = tridiag_eigenvalue(a, b, index);
+    *last_component = tridiag_last_component(a, b, *theta);
+    return LQCD_OK;
+}
+
 // the plain k-step estimate (extreme Ritz values, no certificate): what the bindings' estimate_spectrum returns
 extern "C" int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, double* theta_min, double* theta_max) {
     ARGCHK(op && steps >= 2 && theta_min && theta_max, "lqcd_estimate_spectrum: bad argument");

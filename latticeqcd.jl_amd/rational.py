@@ -34,3 +34,16 @@ def inverse_power_partial_fractions(alpha, lam_min, lam_max, tol=1e-10, max_pole
 def evaluate(a0, res, poles, x):
     x = np.asarray(x, dtype=np.float64)
     return (a0 + (np.asarray(res)[None, :] / (x.reshape(-1, 1) + np.asarray(poles)[None, :])).sum(axis=1)).reshape(x.shape)
+
+
+def tridiag_ritz(diag, offdiag, index):
+    """(theta, |last component of its normalised eigenvector|) for the index-th eigenvalue (ascending) of the symmetric tridiagonal -- the host
+    half of the Lanczos certificate of the rational actions (lqcd_tridiag_ritz): beta_n * last_component bounds |theta - eigenvalue of D'D|."""
+    d = np.ascontiguousarray(diag, dtype=np.float64)
+    e = np.ascontiguousarray(offdiag, dtype=np.float64)
+    if len(e) != max(len(d) - 1, 0):
+        raise ValueError("offdiag must hold len(diag) - 1 entries")
+    theta, last = C.c_double(0), C.c_double(0)
+    _l.check(_l.lib().lqcd_tridiag_ritz(int(len(d)), d.ctypes.data_as(C.POINTER(C.c_double)), e.ctypes.data_as(C.POINTER(C.c_double)), int(index),
+                                        C.byref(theta), C.byref(last)))
+    return float(theta.value), float(last.value)

@@ -53,3 +53,46 @@ def test_c_export_argument_errors_and_unreachable_accuracy(lq):
     assert fit(0.5, 1e-8, 16.0, 1e-15) == lq.lib.ERR_NOT_CONVERGED and b"rational fit" in L.lqcd_last_error()
     assert fit(0.5, 0.25, 16.25, 1e-10, cap=3) == lq.lib.ERR_NOT_CONVERGED          # three poles cannot reach 1e-10
     assert fit(0.5, 0.25, 16.25, 1e-10) == 0 and 6 <= n.value <= 14
+
+
+# the host half of the Lanczos certificate behind the Wilson rational action's fit interval (csrc/rational.hip lanczos_certified): Ritz value and
+# |last eigenvector component| of the Lanczos tridiagonal against LAPACK, and the residual bound |beta_k s_k| against the true spectrum of a dense matrix
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 60, 200])
+def test_tridiag_ritz_pair_against_dense_eigensolver(lq, n):
+    rng = np.random.default_rng(n)
+    d, e = rng.uniform(0.5, 3.0, n), rng.uniform(0.1, 1.0, max(n - 1, 0)) * rng.choice([-1.0, 1.0], max(n - 1, 0))
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    w, V = np.linalg.eigh(T)
+    for index in sorted({0, n // 2, n - 1}):
+        theta, last = lq.rational.tridiag_ritz(d, e, index)
+        assert abs(theta - w[index]) <= 1e-12 * np.abs(w).max()
+        gap = min([abs(w[index] - w[j]) for j in range(n) if j != index] or [1.0])
+        assert abs(last - abs(V[-1, index])) <= 1e-9 / min(gap, 1.0) + 1e-13
+    with pytest.raises(lq.LQCDError):
+        lq.rational.tridiag_ritz(d, e, n)
+
+
+@pytest.mark.parametrize("cond", [1e2, 1e5])
+def test_ritz_bound_contains_an_eigenvalue(lq, cond):
+    rng = np.random.default_rng(5)
+    N = 300
+    lam = np.exp(rng.uniform(np.log(1.0 / cond), 0.0, N))          # an ill-conditioned positive spectrum, as D'D near the critical kappa
+    Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    A = (Q * lam) @ Q.T
+    v = rng.standard_normal(N)
+    v /= np.linalg.norm(v)
+    vp, beta, al, be = np.zeros(N), 0.0, [], []
+    for k in range(1, 61):
+        w = A @ v
+        a = v @ w
+        w -= a * v + beta * vp
+        al.append(a)
+        beta = np.linalg.norm(w)
+        if k % 10 == 0:
+            for index in (0, k - 1):
+                theta, last = lq.rational.tridiag_ritz(al, be, index)
+                dist = np.abs(lam - theta).min()
+                assert dist <= beta * last * (1 + 1e-6) + 1e-12, (k, index, dist, beta * last)
+            assert theta <= lam.max() * (1 + 1e-12) and lq.rational.tridiag_ritz(al, be, 0)[0] >= lam.min() * (1 - 1e-12)
+        be.append(beta)
+        vp, v = v, w / beta
