@@ -1,10 +1,13 @@
 """Device-resident HMC streams for the statistical parity tests (tests/test_gpu_hmc_statistics.py) and scripts/hmc_stats.py.
-One trajectory = the reference's update!(::StandardHMC) (standardHMC.jl:41-91) with runMD_QPQ! (standardMD.jl:127-144) or
-runMD_QPQ_sw! (:146-166), written with the fused four-direction calls (the callers' own per-direction sequences are replayed from their
-call trace in tests/test_gpu_reference_callers.py)."""
+One trajectory = momentum + pseudofermion refresh, `mdsteps` MD steps of the integrator's stage table (tests/oracle_md.py `stages`, the table the
+oracle's trajectory runs on: QPQ leapfrog, or its Sexton-Weingarten form for the actions the reference's test files run with SextonWeingargten = true),
+Metropolis test -- on the fused four-direction entry points.  (The reference callers' own per-direction sequences are replayed from their call trace in
+tests/test_gpu_reference_callers.py.)"""
 import os
 
 import numpy as np
+
+from oracle_md import stages
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BETA, MASS, KAPPA = 5.7, 0.5, 0.141139
@@ -47,10 +50,15 @@ def run_stream(lq, action, ntraj, seed, dtau=None, mdsteps=None, params=None):
         h = lq.momentum_action(p) + lq.evaluate_GaugeAction(U, BETA)
         return h + (lq.evaluate_FermiAction(fa, U, phi) if fa is not None else 0.0)
 
-    def gauge_leg(eps):            # U_update!(eps/2) P_update!(eps) U_update!(eps/2)
-        lq.U_update_(U, p, 0.5 * eps * dtau)
-        lq.P_update_(U, p, eps * dtau, BETA)
-        lq.U_update_(U, p, 0.5 * eps * dtau)
+    def md_step():
+        for leg, coeff in stages("QPQ_sw" if nsw else "QPQ", nsw):
+            if leg == "U":
+                lq.U_update_(U, p, coeff * dtau)
+            elif leg == "G":
+                lq.P_update_(U, p, coeff * dtau, BETA)
+            elif fa is not None:
+                lq.calc_UdSfdU_(G, fa, U, phi)
+                lq.Traceless_antihermitian_add_(p, coeff * dtau, G)
 
     plaq, dHs, acc = [], [], []
     for traj in range(ntraj):
@@ -61,20 +69,7 @@ def run_stream(lq, action, ntraj, seed, dtau=None, mdsteps=None, params=None):
             lq.sample_pseudofermions_(phi, U, fa, xi)
         H0 = H()
         for _ in range(mdsteps):
-            if nsw:                # runMD_QPQ_sw!
-                for _ in range(nsw // 2):
-                    gauge_leg(1.0 / nsw)
-                lq.calc_UdSfdU_(G, fa, U, phi)
-                lq.Traceless_antihermitian_add_(p, dtau, G)
-                for _ in range(nsw // 2):
-                    gauge_leg(1.0 / nsw)
-            else:                  # runMD_QPQ!
-                lq.U_update_(U, p, 0.5 * dtau)
-                lq.P_update_(U, p, dtau, BETA)
-                if fa is not None:
-                    lq.calc_UdSfdU_(G, fa, U, phi)
-                    lq.Traceless_antihermitian_add_(p, dtau, G)
-                lq.U_update_(U, p, 0.5 * dtau)
+            md_step()
         dH = H() - H0
         ok = bool(np.exp(-dH) >= rng.random())
         if not ok:
