@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, rel_err
+from oracle_md import stages
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +75,8 @@ def test_momentum_sampling(gpu, orc):
 
 
 class DeviceHMC:
-    """The reference's update!(::StandardHMC) + runMD_QPQ_sw! (standardHMC.jl:41-91, standardMD.jl:146-166), every field resident."""
+    """A Sexton-Weingarten HMC on the fused entry points, every field resident: what the reference's update!(::StandardHMC) with runMD_QPQ_sw!
+    (standardHMC.jl:41-91, standardMD.jl:146-166) amounts to.  (The callers' own call sequences: tests/test_gpu_reference_callers.py.)"""
 
     def __init__(self, lq, U, kappa, beta, dtau, mdsteps, nsw, seed, dirac="Wilson", csw=0.0):
         self.lq, self.U, self.beta, self.dtau, self.mdsteps, self.nsw = lq, U, beta, dtau, mdsteps, nsw
@@ -99,12 +101,10 @@ class DeviceHMC:
         self.lq.Traceless_antihermitian_add_(self.p, eps * self.dtau, self.G)
 
     def run_md(self):
+        legs = {"U": self.U_update, "G": self.P_update, "F": self.P_update_fermion}
         for _ in range(self.mdsteps):
-            for _ in range(self.nsw // 2):
-                self.U_update(0.5 / self.nsw); self.P_update(1.0 / self.nsw); self.U_update(0.5 / self.nsw)
-            self.P_update_fermion(1.0)
-            for _ in range(self.nsw // 2):
-                self.U_update(0.5 / self.nsw); self.P_update(1.0 / self.nsw); self.U_update(0.5 / self.nsw)
+            for leg, coeff in stages("QPQ_sw", self.nsw):      # the integrator table the oracle's trajectory runs on (tests/oracle_md.py)
+                legs[leg](coeff)
 
     def H_new(self):
         return self.lq.momentum_action(self.p) + self.lq.evaluate_GaugeAction(self.U, self.beta) + self.lq.evaluate_FermiAction(self.fa, self.U, self.eta)
