@@ -117,7 +117,11 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * equations as two even-odd BiCGStab solves under the reference's stopping rule; 0: CG), bicg_mixed (1: lqcd_solve_bicgstab_eo on the plain Wilson operator runs an fp32 inner
  * chain inside an fp64 defect correction, the stopping rule holds for the true fp64 residual; mixed_action_solver = 1 switches it on for the action solves), lazy_links (1: the per-direction link-call triples are recorded and fused -- the temporaries of a completed triple are then never written, so the C ABI's default is 0 (eager) and the Julia / Python bindings switch it on when they create a context,
  * see lqcd_link_*; read-only lazy_open, lazy_deferred), lazy_merge (1 [default]: a complete link update U <- exp(a P) U waits unlaunched and a second one of the same
- * fields, with nothing in between that reads U or writes P, adds its step -- the back-to-back half steps of runMD_QPQ_sw!, standardMD.jl:146-166). */
+ * fields, with nothing in between that reads U or writes P, adds its step -- the back-to-back half steps of runMD_QPQ_sw!, standardMD.jl:146-166).
+ * Threads: calls on one context must not overlap (one lock per context in a host that uses several threads).  The exception is lqcd_gauge_destroy / lqcd_spinor_destroy,
+ * which garbage collectors call from finalizer threads: with lazy_links on, a gauge-shaped field destroyed from another thread than the context's own (the creating thread,
+ * or the one that last set adopt_thread = 1) is parked and freed by the context's thread at its next lqcd_gauge_create / lqcd_ctx_sync / lqcd_ctx_destroy (read-only
+ * parked_fields counts them); slice views are counted under a lock. */
 int lqcd_ctx_set_param(lqcd_ctx_t ctx, const char* key, int value);
 int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);
 

@@ -26,6 +26,24 @@ static void ctx_set_live(const lqcd_ctx_s* c, bool live) {
         if (g_live[i] == c) { g_live.erase(g_live.begin() + i); break; }
     if (live) g_live.push_back(c);
 }
+bool ctx_park_gauge(lqcd_gauge_s* g) {
+    std::lock_guard<std::mutex> lk(g_live_mu);      // lqcd_ctx_destroy leaves the live set under the same lock before it drains: nothing is parked on a dying context
+    lqcd_ctx_s* c = g->ctx;
+    bool live = false;
+    for (const lqcd_ctx_s* p : g_live) live = live || p == c;
+    if (!live || !c->tun.lazy_links || std::this_thread::get_id() == c->home_thread) return false;
+    c->parked_gauges.push_back(g);
+    return true;
+}
+int ctx_drain_parked(lqcd_ctx_s* c) {
+    std::vector<lqcd_gauge_s*> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        mine.swap(c->parked_gauges);
+    }
+    for (lqcd_gauge_s* g : mine) (void)gauge_destroy_now(g);
+    return LQCD_OK;
+}
 void set_error(const std::string& msg) { g_err = msg; }
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
@@ -166,6 +184,7 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     const long long V = (long long)L[0] * L[1] * L[2] * L[3];
     ARGCHK(V / 2 < (1ll << 31) / 16, "lqcd_ctx_create: local volume too large for 32-bit site indices");
     lqcd_ctx_s* c = new lqcd_ctx_s;
+    c->home_thread = std::this_thread::get_id();
     c->device = device;
     c->rank = rank;
     c->nranks = pe[0] * pe[1] * pe[2] * pe[3];
@@ -241,6 +260,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     ctx_set_live(c, false);      // recorded link operations are dropped with the context: their fields cannot be used without it
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    (void)ctx_drain_parked(c);      // fields that finalizer threads handed over (the context is no longer live: freed without a flush)
     for (lqcd_spinor_s* s : c->scratch) { (void)hipFree(s->data); delete s; }
     for (int mu = 0; mu < 4; mu++) {
         (void)hipFree(c->send_fwd[mu]); (void)hipFree(c->recv_bwd[mu]);   // send_bwd / recv_fwd are the second halves of these
@@ -264,6 +284,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
 
 extern "C" int lqcd_ctx_sync(lqcd_ctx_t c) {
     ARGCHK(c, "lqcd_ctx_sync: null");
+    LQCHK(ctx_drain_parked(c));
     LQCHK(links_flush_of(c));
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -333,6 +354,13 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
     ARGCHK(c && key, "lqcd_ctx_set_param: null");
+    if (!strcmp(key, "adopt_thread")) {      // the calling thread is the context's own from here on (a host that hands a context to a worker thread for good)
+        {
+            std::lock_guard<std::mutex> lk(g_live_mu);
+            c->home_thread = std::this_thread::get_id();
+        }
+        return ctx_drain_parked(c);
+    }
     int* p = param_ptr(c, key);
     ARGCHK(p, std::string("lqcd_ctx_set_param: unknown key ") + key);
     if (!strcmp(key, "dslash_block")) ARGCHK(value == 64 || value == 128 || value == 256, "dslash_block must be 64, 128 or 256");
@@ -344,6 +372,11 @@ extern "C" int lqcd_ctx_get_param(lqcd_ctx_t c, const char* key, int* value) {
     ARGCHK(c && key && value, "lqcd_ctx_get_param: null");
     // read-only views of the recorded link operations (md.hip): the open triple (0 none, 1 exp, 2 exp + mul, 3 staple, 4 staple + mul), deferred triples
     if (!strcmp(key, "dw_active")) { *value = c->tun.dw_active; return LQCD_OK; }
+    if (!strcmp(key, "parked_fields")) {      // gauge-shaped fields that another thread's destroy call left for this context's thread to free
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        *value = (int)c->parked_gauges.size();
+        return LQCD_OK;
+    }
     if (!strcmp(key, "lazy_open")) { *value = c->lazy.kind; return LQCD_OK; }
     if (!strcmp(key, "lazy_deferred")) { *value = (int)c->lazy.done.size() + (c->lazy.has_pend ? 4 : 0) + (c->lazy.has_pp ? 4 : 0); return LQCD_OK; }
     int* p = param_ptr(c, key);

@@ -229,6 +229,7 @@ extern "C" int lqcd_spinor_create_5d(lqcd_ctx_t ctx, lqcd_spinor_t* s, int L5) {
 // The view owns nothing; a parent destroyed while views exist keeps its storage until the last view is destroyed (finalizers of a garbage collector run in any order).
 extern "C" int lqcd_spinor_slice(lqcd_spinor_t s5, int i5, lqcd_spinor_t* view) {
     ARGCHK(s5 && view && s5->kind == LQCD_DOMAINWALL && i5 >= 0 && i5 < s5->ls, "lqcd_spinor_slice: need a five-dimensional field and 0 <= i5 < L5");
+    std::lock_guard<std::mutex> lk(lqcd::view_mutex());
     ARGCHK(!s5->zombie, "lqcd_spinor_slice: the five-dimensional field has been destroyed");
     lqcd_spinor_s* v = new lqcd_spinor_s;
     *v = slice_view(s5, i5);

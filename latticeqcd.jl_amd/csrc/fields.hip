@@ -246,6 +246,7 @@ using namespace lqcd;
 extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
     ARGCHK(ctx && g, "lqcd_gauge_create: null argument");
     HIPCHK(hipSetDevice(ctx->device));
+    LQCHK(lqcd::ctx_drain_parked(ctx));      // fields whose destroy call came from another thread (a finalizer): their storage goes before new storage is asked for
     lqcd_gauge_s* x = new lqcd_gauge_s;
     x->ctx = ctx;
     // versions are unique across handles (handle epoch in the upper 32 bits, writes counted in the lower): caches keyed on a
@@ -262,15 +263,28 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
     return LQCD_OK;
 }
 
-extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
-    if (!g) return LQCD_OK;
+namespace lqcd {
+std::mutex& view_mutex() {
+    static std::mutex m;
+    return m;
+}
+int gauge_destroy_now(lqcd_gauge_s* g) {
     // (no hipSetDevice: the context may already be gone -- finalizers run in any order -- and hipFree does not need it)
-    if (lqcd::ctx_is_live(g->ctx)) (void)lqcd::links_flush_of(g);      // recorded link operations may name this field: they run before its storage goes
+    if (ctx_is_live(g->ctx)) (void)links_flush_of(g);      // recorded link operations may name this field: they run before its storage goes
     (void)hipFree(g->data);
     (void)hipFree(g->data12);
     (void)hipFree(g->data12d);
     delete g;
     return LQCD_OK;
+}
+}   // namespace lqcd
+
+extern "C" int lqcd_gauge_destroy(lqcd_gauge_t g) {
+    if (!g) return LQCD_OK;
+    // A destroy call from another thread than the context's own (a finalizer thread, while the context's thread may be inside a library call) must not run the
+    // recorded link operations or touch their record: the field is parked and the context's thread frees it (capi.hip ctx_park_gauge; only while lazy_links is on)
+    if (lqcd::ctx_park_gauge(g)) return LQCD_OK;
+    return lqcd::gauge_destroy_now(g);
 }
 
 static int gauge_xfer(lqcd_gauge_t g, double* host, int layout, int to_device, int wing = 0) {
@@ -398,6 +412,7 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
 extern "C" int lqcd_spinor_destroy(lqcd_spinor_t s) {
     if (!s) return LQCD_OK;
     // (no hipSetDevice: see lqcd_gauge_destroy)
+    std::lock_guard<std::mutex> lk(lqcd::view_mutex());      // the view count of a five-dimensional field: destroy calls may come from finalizer threads
     if (s->view_of) {                      // a slice view: the last one of a destroyed parent takes the parent's storage with it
         lqcd_spinor_s* parent = s->view_of;
         delete s;

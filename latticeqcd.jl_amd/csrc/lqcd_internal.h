@@ -13,7 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lqcd_hip.h"
@@ -636,6 +638,11 @@ struct lqcd_ctx_s {
     lqcd::LazyLinks lazy;         // recorded single-direction link operations (md.hip)
     bool has_waiting_pack = false;   // folded halo schedule: the pack launch for the next application waits for the reduction it shares a launch with (apply.hip, blas.hip)
     void* waiting_pack = nullptr;    // its StencilCall (owned)
+    // destroy calls from another thread than the context's own (a garbage collector's finalizer thread): a gauge-shaped field that recorded link
+    // operations may name is not flushed and freed there -- it is parked (under capi.hip's g_live_mu) and the context's thread frees it at its next field
+    // creation / lqcd_ctx_sync / lqcd_ctx_destroy.  home_thread: the creating thread, or the one that last set the parameter "adopt_thread".
+    std::thread::id home_thread;
+    std::vector<lqcd_gauge_s*> parked_gauges;
 };
 
 struct lqcd_gauge_s {
@@ -869,6 +876,10 @@ int gauge_pack_face(lqcd_gauge_s* g, int mu, double2* dst);
 
 // md.hip: run every recorded / deferred single-direction link operation of the context now (no-op when there is none)
 int links_flush(lqcd_ctx_s* c);
+bool ctx_park_gauge(lqcd_gauge_s* g);      // capi.hip: true = called from a foreign thread while the context records link operations: parked, the caller must not touch it
+int ctx_drain_parked(lqcd_ctx_s* c);       // frees what foreign threads parked (called on the context's thread)
+int gauge_destroy_now(lqcd_gauge_s* g);     // fields.hip
+std::mutex& view_mutex();                  // fields.hip: guards nviews / zombie of five-dimensional fields (slice views are created and destroyed under it)
 bool ctx_is_live(const lqcd_ctx_s* c);     // capi.hip: finalizers run in any order -- a field may outlive its context
 inline int links_flush_of(lqcd_ctx_s* c) { return (c && c->lazy.busy()) ? links_flush(c) : LQCD_OK; }
 inline int links_flush_of(lqcd_gauge_s* g) { return g ? links_flush_of(g->ctx) : LQCD_OK; }

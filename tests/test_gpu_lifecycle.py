@@ -67,3 +67,58 @@ def test_destroy_order_and_double_close_are_harmless(lq):
     x.close(); x.close()
     U.close(); U.close()
     lat.close(); lat.close()
+
+
+def test_destroy_from_another_thread_is_parked_for_the_context_thread(lq):
+    """a finalizer thread's lqcd_gauge_destroy must neither run nor read the recorded link operations (the context's thread may be inside a call).
+    The field is parked; the context's thread flushes what names it and frees it at its next sync / gauge creation."""
+    import threading
+    L = (16, 16, 16, 16)
+    plaq = {}
+    for how in ("same_thread", "other_thread", "adopted"):
+        U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=3)
+        lat = U.lattice
+        assert lat.get_param("lazy_links") == 1 and lat.get_param("parked_fields") == 0      # the bindings switch the recorded link operations on
+        p = lq.initialize_TA_Gaugefields(U)
+        lq.gauss_distribution_(p, 5)
+        lq.U_update_(U, p, 0.01)
+        lat.sync()                                           # (work space of the update exists from here on)
+        lq.U_update_(U, p, 0.01)
+        assert lat.get_param("lazy_deferred") == 4          # the link update waits for one to merge with: it names U and p
+        before = _free(lq)
+        if how == "same_thread":
+            p.close()                                        # runs what names p, then frees it
+            assert lat.get_param("parked_fields") == 0 and lat.get_param("lazy_deferred") == 0
+        else:
+            if how == "adopted":                             # a worker that owns the context from now on destroys at once
+                t = threading.Thread(target=lambda: (lat.set_param("adopt_thread", 1), p.close()))
+            else:
+                t = threading.Thread(target=p.close)
+            t.start()
+            t.join()
+            if how == "adopted":
+                assert lat.get_param("parked_fields") == 0 and lat.get_param("lazy_deferred") == 0
+                lat.set_param("adopt_thread", 1)             # back to this thread
+            else:
+                assert lat.get_param("parked_fields") == 1 and lat.get_param("lazy_deferred") == 4      # nothing ran, nothing was read
+                assert _free(lq) - before < 8 << 20                                                        # and nothing was freed
+                lat.sync()                                                                                 # the context's thread: flush, free
+                assert lat.get_param("parked_fields") == 0 and lat.get_param("lazy_deferred") == 0
+        assert _free(lq) - before > 30 << 20                 # the 37.7 MB of the momenta are back
+        plaq[how] = lq.calculate_Plaquette(U)
+        U.close()
+        lat.close()
+    assert plaq["same_thread"] == plaq["other_thread"] == plaq["adopted"]
+
+    # a context destroyed with fields still parked takes them along
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="cold")
+    lat = U.lattice
+    G = lq.Gaugefields(lat)
+    base = _free(lq)
+    t = threading.Thread(target=G.close)
+    t.start()
+    t.join()
+    assert lat.get_param("parked_fields") == 1
+    U.close()
+    lat.close()
+    assert _free(lq) - base > 60 << 20
