@@ -40,7 +40,7 @@ enum {
     LQCD_ERR_ARG = 1,           /* bad argument / shape mismatch */
     LQCD_ERR_HIP = 2,           /* HIP runtime error (no device, OOM, launch failure) */
     LQCD_ERR_NOT_CONVERGED = 3, /* solver hit maxiter: the reference raises error(...) here */
-    LQCD_ERR_COMM = 4,          /* RCCL error */
+    LQCD_ERR_COMM = 4,          /* RCCL error, or a peer-mapped exchange that gave up waiting (dead rank) */
     LQCD_ERR_UNSUPPORTED = 5
 };
 
@@ -130,6 +130,18 @@ int lqcd_ctx_get_param(lqcd_ctx_t ctx, const char* key, int* value);
  * lqcd_ctx_comm_init.  Replaces the MPI.Init / PEs plumbing of src/mpi/mpimodule.jl:4-13. */
 int lqcd_comm_unique_id(unsigned char id[256]);
 int lqcd_ctx_comm_init(lqcd_ctx_t ctx, const unsigned char id[256], int nranks);
+/* The second communication backend: peer-mapped windows (csrc/comm.hip; SURVEY.md 8(e) "or peer-mapped writes").  Every rank allocates one device
+ * "window" (ghost buffers, mailboxes, flag words, reduction slots), lqcd_ctx_peer_export writes its 256-byte description (hipIpcMemHandle, process,
+ * device, layout check), the host gathers the descriptions of all ranks in rank order (MPI.Allgather / torch.distributed.all_gather) and every rank
+ * calls lqcd_ctx_peer_init with the nranks x 256 bytes.  From then on the pack kernels store faces straight into the neighbours' ghost buffers, the
+ * exchange is a one-wave flag kernel and the solver's scalar sums travel through slots -- no RCCL launch anywhere.  One node (<= 8 ranks, same host);
+ * ranks MAY share a device (the world-size-2 tests run two processes on one GPU).  Either this pair or lqcd_ctx_comm_init, not both.  Replaces the same
+ * MPI plumbing of the reference (src/mpirun.jl:17-19, src/mpi/mpimodule.jl:4-13). */
+#define LQCD_PEER_BLOB_BYTES 256
+int lqcd_ctx_peer_export(lqcd_ctx_t ctx, unsigned char blob[LQCD_PEER_BLOB_BYTES]);
+int lqcd_ctx_peer_init(lqcd_ctx_t ctx, const unsigned char* blobs, int nranks);
+enum { LQCD_COMM_NONE = 0, LQCD_COMM_RCCL = 1, LQCD_COMM_PEER = 2 };
+int lqcd_ctx_comm_backend(lqcd_ctx_t ctx, int* backend);
 /* in-process emulation of a PE grid on ONE device (testing the halo path without RCCL): link `n` contexts that
  * were created with ranks 0..n-1 of the same pe_grid; afterwards use the lqcd_mdom_* collectives below. */
 int lqcd_ctx_link_local(lqcd_ctx_t* ctxs, int n);

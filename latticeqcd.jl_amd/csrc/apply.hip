@@ -109,6 +109,7 @@ int flush_waiting_pack(lqcd_ctx_s* c) {      // a pack launch left waiting by th
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     HIPCHK(hipSetDevice(c->device));
     LQCHK(flush_waiting_pack(c));
+    c->tun.halo_fold_active = 0;      // (before any early return: the key describes THIS application)
     if (s.prec == 2) return launch_pair32_interior(c, s);      // fp32 site-pair fields (unpartitioned lattices only: checked by the launcher)
     if (!any_partitioned(c)) return s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s);
     if (s.kind == LQCD_WILSON && s.r != 1.0) {
@@ -144,14 +145,16 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             HIPCHK(hipEventSynchronize(c->ev_tune1));
             HIPCHK(hipEventElapsedTime(&ms[mode], c->ev_tune0, c->ev_tune1));
         }
-        // the choice is collective: every rank adopts the schedule with the smallest time summed over the ranks (one 12-byte all-reduce), so that
+        // the choice is collective: every rank adopts the schedule with the smallest time summed over the ranks (one 32-byte all-reduce), so that
         // no two ranks interleave their sends and receives differently and a slow rank's view counts
         if (c->has_comm) {      // (a one-rank communicator -- self-partition tests -- takes the same path: the all-reduce is then the identity)
-            float* d_ms = (float*)c->d_partial;
-            HIPCHK(hipMemcpyAsync(d_ms, ms, sizeof(ms), hipMemcpyHostToDevice, c->stream));
-            NCCLCHK(ncclAllReduce(d_ms, d_ms, 4, ncclFloat, ncclSum, c->comm_red, c->stream));      // the compute stream's communicator
-            HIPCHK(hipMemcpyAsync(ms, d_ms, sizeof(ms), hipMemcpyDeviceToHost, c->stream));
+            double* d_ms = c->d_scal + SCAL_DOUBLES - 8;      // (the host-value all-reduce's staging doubles)
+            double dms[4] = {ms[0], ms[1], ms[2], ms[3]};
+            HIPCHK(hipMemcpyAsync(d_ms, dms, sizeof(dms), hipMemcpyHostToDevice, c->stream));
+            LQCHK(comm_allreduce(c, d_ms, 4));      // on the compute stream
+            HIPCHK(hipMemcpyAsync(dms, d_ms, sizeof(dms), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+            for (int mode = 0; mode < 4; mode++) ms[mode] = (float)dms[mode];
             for (int mode = 0; mode < 4; mode++) ms[mode] /= (float)c->nranks;
         }
         int best = 0;
@@ -176,17 +179,16 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         }
         HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
         if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
-        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 1));
+        LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
     }
-    c->tun.halo_fold_active = 0;
     if (c->tun.halo_stream_mode == 3) {
         // everything in order on the compute stream, no overlap and no cross-queue join: pack -> exchange -> interior -> exterior.  A join costs
         // ~13 us (barrier packets) and the exchange kernel slows the interior it runs beside; at small local volumes with a short exchange that
         // is more than the overlap hides
         if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
-        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 1));
+        LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
         // folded (round 5): the ghosts are complete before the stencil launch starts, so that launch takes the boundary hops from them itself (stencil.hip FOLD
         // instances) -- no exterior launch, no norm corrections, no exterior partials (stencil_num_partials follows halo_fold_applies).  A following
         // application's faces (pack_next: the D p -> D^+ pair of the fused CG) are packed from the finished output by a pack launch
@@ -224,12 +226,12 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             c->stream = main_stream;
             LQCHK(st);
         }
-        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 2));
+        LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
     }
     if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
-    LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, s.prec, 0));
+    LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 0));
     LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);

@@ -65,7 +65,7 @@ extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spin
     LQCHK(check_full(op, out, in, "lqcd_bench_halo_phases"));
     ARGCHK(reps > 0 && ms, "lqcd_bench_halo_phases: bad arguments");
     lqcd_ctx_s* c = op->ctx;
-    ARGCHK(any_partitioned(c) && c->has_comm && c->local_peers.empty(), "lqcd_bench_halo_phases: needs a partitioned context with RCCL communicators");
+    ARGCHK(any_partitioned(c) && c->has_comm && c->local_peers.empty(), "lqcd_bench_halo_phases: needs a partitioned context with a communicator (RCCL or peer-mapped)");
     HIPCHK(hipSetDevice(c->device));
     hipEvent_t e[6];
     for (auto& ev : e) HIPCHK(hipEventCreate(&ev));
@@ -84,7 +84,7 @@ extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spin
             HIPCHK(hipEventRecord(e[0], c->stream));
             LQCHK(launch_stencil_pack(c, s));
             HIPCHK(hipEventRecord(e[1], c->stream));
-            LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0, 1));
+            LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, 0, 1));
             HIPCHK(hipEventRecord(e[2], c->stream));
             LQCHK(launch_stencil_interior(c, f));
             HIPCHK(hipEventRecord(e[3], c->stream));
@@ -104,7 +104,7 @@ extern "C" int lqcd_bench_halo_phases(lqcd_op_t op, lqcd_spinor_t out, lqcd_spin
         HIPCHK(hipEventRecord(e[0], c->stream));
         LQCHK(launch_stencil_pack(c, s));
         HIPCHK(hipEventRecord(e[1], c->stream));
-        LQCHK(halo_exchange_rccl(c, s.kind, s.parity_mode, 0, 0));
+        LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, 0, 0));
         HIPCHK(hipEventRecord(e[5], c->comm_stream));
         LQCHK(launch_stencil_interior(c, s));
         HIPCHK(hipEventRecord(e[2], c->stream));
@@ -135,9 +135,9 @@ extern "C" int lqcd_bench_allreduce(lqcd_ctx_t c, int reps, double* us) {
     HIPCHK(hipSetDevice(c->device));
     double* d = c->d_scal + S_RED0;
     HIPCHK(hipMemsetAsync(d, 0, sizeof(double), c->stream));   // 0 + 0 + ... stays finite however often it is summed
-    for (int i = 0; i < 5; i++) NCCLCHK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, c->comm_red, c->stream));
+    for (int i = 0; i < 5; i++) LQCHK(comm_allreduce(c, d, 1));
     HIPCHK(hipEventRecord(c->ev_t0, c->stream));
-    for (int i = 0; i < reps; i++) NCCLCHK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, c->comm_red, c->stream));
+    for (int i = 0; i < reps; i++) LQCHK(comm_allreduce(c, d, 1));
     HIPCHK(hipEventRecord(c->ev_t1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev_t1));
     float t = 0;

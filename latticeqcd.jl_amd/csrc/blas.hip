@@ -5,6 +5,8 @@
 // per-block partials that a single-block kernel sums in a fixed order (bit-reproducible run to run).
 #include "lqcd_internal.h"
 
+#include <cstring>
+
 namespace lqcd {
 
 constexpr int RB = 256;  // reduction / streaming block size
@@ -47,13 +49,24 @@ __global__ __launch_bounds__(RB) void norm2_kernel(const double2* __restrict__ a
 // sums nblocks partials of `nvals` interleaved values into scal[slot..slot+nvals) in a fixed order (1024 threads, each a
 // strided partial sum, then a wave/LDS tree), optionally followed by a CG scalar step on the same thread (single rank):
 //   op 1: alpha = rr / pq      op 2: beta = rr'/rr, rr = rr', iters++, done = rr' < eps     (flags: see ops.hip)
-__global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op) {
+__global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op, PeerRedArgs pr) {
     __shared__ double red[FB / 64];
+    __shared__ double tot[PEER_RED_VALS];
+    // pr.nranks > 0 (peer-mapped backend, comm.hip): the sum over the ranks happens HERE, in the wave that holds the local sums -- no all-reduce launch
     if (nblocks <= 1024) {      // small reductions: one wave, in the order the folded prologues use (sum_partials_small_nv) -- a latency chain of
         if (threadIdx.x < 64) { //  16 loads + one DPP tree instead of a 1024-thread tree with two barriers per value
+            double mine = 0.0;
             for (int v = 0; v < nvals; v++) {
                 const double t = sum_partials_small_nv(partial, nblocks, nvals, v);
-                if (threadIdx.x == 0) scal[slot + v] = t;
+                if (pr.nranks) { if (((int)threadIdx.x >> 3) == v) mine = t; }
+                else if (threadIdx.x == 0) scal[slot + v] = t;
+            }
+            if (pr.nranks) {
+                const double s = peer_allreduce_wave(pr, mine, nvals);
+                for (int q = 0; q < nvals; q++) {
+                    const double v = __shfl(s, 8 * q, 64);
+                    if (threadIdx.x == 0) scal[slot + q] = v;
+                }
             }
             if (op && threadIdx.x == 0) cg_scalar_step(scal, op);
         }
@@ -67,13 +80,20 @@ __global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ pa
         if (threadIdx.x == 0) {
             double t = 0;
             for (int w = 0; w < FB / 64; w++) t += red[w];
-            scal[slot + v] = t;
+            if (pr.nranks) tot[v] = t; else scal[slot + v] = t;
         }
         __syncthreads();
     }
+    if (pr.nranks && threadIdx.x < 64) {
+        const int k = (int)threadIdx.x >> 3;
+        const double s = peer_allreduce_wave(pr, k < nvals ? tot[k] : 0.0, nvals);
+        for (int q = 0; q < nvals; q++) {
+            const double v = __shfl(s, 8 * q, 64);
+            if (threadIdx.x == 0) scal[slot + q] = v;
+        }
+    }
     if (op && threadIdx.x == 0) cg_scalar_step(scal, op);
 }
-__global__ void cg_scalar_kernel(double* s, int op) { cg_scalar_step(s, op); }
 
 __global__ __launch_bounds__(RB) void axpy_kernel(double ar, double ai, const double2* __restrict__ x, double2* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n; i += (size_t)gridDim.x * RB) {
@@ -111,41 +131,36 @@ int stream_grid(lqcd_ctx_s* c, size_t n) {
     return (int)nb;
 }
 
-// sum over ranks of n host doubles (RCCL all-reduce through the device scalar block)
+// sum over ranks of n host doubles (all-reduce through the device scalar block)
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n) {
     if (!c->has_comm) return LQCD_OK;
     ARGCHK(n <= 8, "allreduce_host: too many values");
     double* d = c->d_scal + SCAL_DOUBLES - 8;
     HIPCHK(hipMemcpyAsync(d, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(ncclAllReduce(d, d, n, ncclDouble, ncclSum, c->comm_red, c->stream));
+    LQCHK(comm_allreduce(c, d, n));
     HIPCHK(hipMemcpyAsync(vals, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return LQCD_OK;
+    return comm_check(c);
 }
 
 // the part of reduce_to_slot behind the one-block sum, for a slot that the producing launch has already filled (the exterior kernel's last
 // block, halo_fuse bit 0): all-reduce over the ranks and the CG's scalar step
 int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op) {
-    if (c->has_comm) NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm_red, c->stream));
-    if (cg_op) {
-        hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
-        HIPCHK(hipGetLastError());
-    }
+    if (c->has_comm || cg_op) return comm_allreduce(c, c->d_scal + slot, nvals, cg_op);
     return LQCD_OK;
 }
 
-// device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks
+// device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks.  RCCL: reduce_final -> ncclAllReduce -> one-thread
+// scalar step; peer-mapped backend: ONE launch (the reduction block adds the ranks' slots itself and does the scalar step)
 int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op, const double* partial) {
     const bool multi = allreduce && c->has_comm;   // also at world size 1 (self-partition tests exercise the collective)
-    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, partial ? partial : c->d_partial, nblocks, nvals, c->d_scal, slot, multi ? 0 : cg_op);
+    const bool peer = multi && c->peer.on;
+    if (peer) ARGCHK(nvals <= PEER_RED_VALS, "reduce_to_slot: more than 8 values in one reduction over the ranks");
+    PeerRedArgs pr;
+    if (peer) pr = comm_red_args(c); else memset(&pr, 0, sizeof pr);
+    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, partial ? partial : c->d_partial, nblocks, nvals, c->d_scal, slot, (multi && !peer) ? 0 : cg_op, pr);
     HIPCHK(hipGetLastError());
-    if (multi) {
-        NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, nvals, ncclDouble, ncclSum, c->comm_red, c->stream));
-        if (cg_op) {
-            hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
-            HIPCHK(hipGetLastError());
-        }
-    }
+    if (multi && !peer) LQCHK(comm_allreduce(c, c->d_scal + slot, nvals, cg_op));
     return LQCD_OK;
 }
 
@@ -154,15 +169,9 @@ int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allredu
 int reduce_pack_to_slot(lqcd_ctx_s* c, int nblocks, int slot, int cg_op) {
     if (!c->has_waiting_pack) return reduce_to_slot(c, nblocks, 1, slot, true, cg_op);
     c->has_waiting_pack = false;
-    const bool multi = c->has_comm;
-    LQCHK(launch_pack_reduce(c, *static_cast<StencilCall*>(c->waiting_pack), c->d_partial, nblocks, slot, multi ? 0 : cg_op));
-    if (multi) {
-        NCCLCHK(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, 1, ncclDouble, ncclSum, c->comm_red, c->stream));
-        if (cg_op) {
-            hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scal, cg_op);
-            HIPCHK(hipGetLastError());
-        }
-    }
+    const bool multi = c->has_comm, peer = multi && c->peer.on;
+    LQCHK(launch_pack_reduce(c, *static_cast<StencilCall*>(c->waiting_pack), c->d_partial, nblocks, slot, (multi && !peer) ? 0 : cg_op));
+    if (multi && !peer) LQCHK(comm_allreduce(c, c->d_scal + slot, 1, cg_op));
     return LQCD_OK;
 }
 

@@ -20,7 +20,7 @@ if [ -n "$ALT" ]; then
     pids+=($!)
   fi
 fi
-for f in stencil stencil_pair32 cg_persist fields blas apply solvers actions rational bench_api mdom capi force mixed md clover domainwall; do
+for f in stencil stencil_pair32 cg_persist fields blas apply comm solvers actions rational bench_api mdom capi force mixed md clover domainwall; do
   if [ ! -f $BDIR/$f.o ] || [ $f.hip -nt $BDIR/$f.o ] || [ lqcd_internal.h -nt $BDIR/$f.o ] || [ ops_internal.h -nt $BDIR/$f.o ] || [ stencil_common.h -nt $BDIR/$f.o ] || [ ../../include/lqcd_hip.h -nt $BDIR/$f.o ] || [ build.sh -nt $BDIR/$f.o ]; then
     ( hipcc $FLAGS -c $f.hip -o $BDIR/$f.o ) &
     pids+=($!)
@@ -31,5 +31,5 @@ if [ ! -f $BDIR/stencil32.o ] || [ stencil.hip -nt $BDIR/stencil32.o ] || [ sten
   pids+=($!)
 fi
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=$ARCH -shared -fPIC -o $OUT $BDIR/stencil.o $BDIR/stencil32.o ${ALT:+$BDIR/stencil_alt.o} $BDIR/stencil_pair32.o $BDIR/cg_persist.o $BDIR/fields.o $BDIR/blas.o $BDIR/apply.o $BDIR/solvers.o $BDIR/actions.o $BDIR/rational.o $BDIR/bench_api.o $BDIR/mdom.o $BDIR/capi.o $BDIR/force.o $BDIR/mixed.o $BDIR/md.o $BDIR/clover.o $BDIR/domainwall.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=$ARCH -shared -fPIC -o $OUT $BDIR/stencil.o $BDIR/stencil32.o ${ALT:+$BDIR/stencil_alt.o} $BDIR/stencil_pair32.o $BDIR/cg_persist.o $BDIR/fields.o $BDIR/blas.o $BDIR/apply.o $BDIR/comm.o $BDIR/solvers.o $BDIR/actions.o $BDIR/rational.o $BDIR/bench_api.o $BDIR/mdom.o $BDIR/capi.o $BDIR/force.o $BDIR/mixed.o $BDIR/md.o $BDIR/clover.o $BDIR/domainwall.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $(pwd)/$OUT"

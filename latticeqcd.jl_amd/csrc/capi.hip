@@ -272,7 +272,8 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     for (lqcd_gauge_s*& t : c->stout_tmp) if (t) { (void)hipFree(t->data); (void)hipFree(t->data12); (void)hipFree(t->data12d); delete t; t = nullptr; }
     (void)hipFree(c->gauge_spare);
     (void)hipFree(c->clover_ext); (void)hipFree(c->clover_ext_buf[0]); (void)hipFree(c->clover_ext_buf[1]);
-    if (c->has_comm) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
+    if (c->has_comm && !c->peer.on) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
+    comm_teardown(c);      // the peer-mapped backend's windows (comm.hip)
     delete static_cast<lqcd::StencilCall*>(c->waiting_pack);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipFree(c->pipe_ctr); (void)hipFree(c->cgp_ctr); (void)hipHostFree(c->h_scal);
     (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1);
@@ -289,7 +290,7 @@ extern "C" int lqcd_ctx_sync(lqcd_ctx_t c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->comm_stream));
-    return LQCD_OK;
+    return comm_check(c);      // peer-mapped backend: a wait that gave up (dead rank) surfaces here
 }
 
 static int* param_ptr(lqcd_ctx_s* c, const char* key) {
@@ -350,6 +351,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "dslash_s18")) return &c->tun.dslash_s18;
     if (!strcmp(key, "bicg_mixed")) return &c->tun.bicg_mixed;
     if (!strcmp(key, "action_eo_solver")) return &c->tun.action_eo_solver;
+    if (!strcmp(key, "peer_timeout_ms")) return &c->peer.timeout_ms;
     return nullptr;
 }
 extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
@@ -403,6 +405,7 @@ extern "C" int lqcd_ctx_comm_init(lqcd_ctx_t c, const unsigned char id[256], int
     ARGCHK(c && id, "lqcd_ctx_comm_init: null");
     ARGCHK(nranks == c->nranks, "lqcd_ctx_comm_init: nranks does not match the PE grid");
     ARGCHK(!c->has_comm, "lqcd_ctx_comm_init: communicator already initialised");
+    ARGCHK(!c->peer.exported, "lqcd_ctx_comm_init: this context has exported a peer-mapped window (lqcd_ctx_peer_export): one backend per context");
     HIPCHK(hipSetDevice(c->device));
     // The first thing a multi-GPU run does with the fabric.  A failure here must say WHO failed and WHAT RCCL said: the message goes to
     // lqcd_last_error() and, because a job with a dead rank usually never gets to print it, to stderr as well.
@@ -463,15 +466,13 @@ extern "C" int lqcd_gauge_plaquette(lqcd_gauge_t g, double* plaq) {
             st = gauge_pack_face(g, mu, sendb[mu]);
         }
         if (st == LQCD_OK) {
-            ncclGroupStart();
+            CommXfer x[4];
+            int n = 0;
             for (int mu = 0; mu < 4; mu++) {
                 if (!c->geom.part[mu]) continue;
-                const size_t nd = (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu) * 2;
-                ncclSend(sendb[mu], nd, ncclDouble, c->nbr_bwd[mu], c->comm_red, c->stream);
-                ncclRecv(ghost[mu], nd, ncclDouble, c->nbr_fwd[mu], c->comm_red, c->stream);
+                x[n++] = CommXfer{sendb[mu], ghost[mu], (size_t)2 * 4 * 9 * face_half_sites(c->geom, mu) * sizeof(double2), mu, 1};      // lower faces travel backward
             }
-            ncclResult_t r = ncclGroupEnd();
-            if (r != ncclSuccess) st = nccl_fail(r, "plaquette halo", __FILE__, __LINE__);
+            st = comm_sendrecv(c, x, n, c->stream, false);
         }
     }
     double sum = 0;

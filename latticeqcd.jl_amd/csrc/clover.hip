@@ -772,14 +772,11 @@ static int clover_ext_build(lqcd_ctx_s* c, const lqcd_gauge_s* U, const double2*
         double2* src = sendb;
         if (c->geom.part[d]) {
             // my lower boundary layer (side 0) is the -d neighbour's upper halo (side 1), my upper layer its +d neighbour's lower halo
-            ARGCHK(c->has_comm, "clover force: communicator not initialised (call lqcd_ctx_comm_init)");
-            const size_t nd = 90 * F * 2;     // doubles per side
-            NCCLCHK(ncclGroupStart());
-            NCCLCHK(ncclSend(sendb, nd, ncclDouble, c->nbr_bwd[d], c->comm_red, c->stream));
-            NCCLCHK(ncclSend(sendb + 90 * F, nd, ncclDouble, c->nbr_fwd[d], c->comm_red, c->stream));
-            NCCLCHK(ncclRecv(recvb + 90 * F, nd, ncclDouble, c->nbr_fwd[d], c->comm_red, c->stream));   // their lower layer -> my upper halo
-            NCCLCHK(ncclRecv(recvb, nd, ncclDouble, c->nbr_bwd[d], c->comm_red, c->stream));            // their upper layer -> my lower halo
-            NCCLCHK(ncclGroupEnd());
+            ARGCHK(c->has_comm, "clover force: communicator not initialised (call lqcd_ctx_comm_init or lqcd_ctx_peer_init)");
+            const size_t nb = 90 * F * sizeof(double2);     // bytes per side
+            const CommXfer x[2] = {{sendb, recvb + 90 * F, nb, d, 1},            // my lower layer travels backward; their lower layer -> my upper halo
+                                   {sendb + 90 * F, recvb, nb, d, 0}};           // my upper layer travels forward; their upper layer -> my lower halo
+            LQCHK(comm_sendrecv(c, x, 2, c->stream, false));
             src = recvb;
         } else {
             // periodic wrap on this rank: lower halo <- own upper layer, upper halo <- own lower layer

@@ -280,17 +280,16 @@ int launch_force_pack(lqcd_ctx_s* c, int kind, lqcd_spinor_s* X, lqcd_spinor_s* 
 // lower face -> the -mu neighbour (which reads it as the ghost of its upper face)
 int force_halo_exchange_rccl(lqcd_ctx_s* c, int kind) {
     const int nc = kind == LQCD_WILSON ? 12 : 3;
-    ARGCHK(c->has_comm, "fermion force halo exchange: communicator not initialised (call lqcd_ctx_comm_init)");
+    ARGCHK(c->has_comm, "fermion force halo exchange: communicator not initialised (call lqcd_ctx_comm_init or lqcd_ctx_peer_init)");
     HIPCHK(hipEventRecord(c->ev_pack, c->stream));
     HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
-    NCCLCHK(ncclGroupStart());
+    CommXfer x[4];
+    int n = 0;
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
-        const size_t n = force_halo_elems(c, mu, nc) * 2;  // doubles
-        NCCLCHK(ncclSend(c->force_send[mu], n, ncclDouble, c->nbr_bwd[mu], c->comm, c->comm_stream));
-        NCCLCHK(ncclRecv(c->force_recv[mu], n, ncclDouble, c->nbr_fwd[mu], c->comm, c->comm_stream));
+        x[n++] = CommXfer{c->force_send[mu], c->force_recv[mu], force_halo_elems(c, mu, nc) * sizeof(double2), mu, 1};      // travels backward
     }
-    NCCLCHK(ncclGroupEnd());
+    LQCHK(comm_sendrecv(c, x, n, c->comm_stream, true));
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return LQCD_OK;

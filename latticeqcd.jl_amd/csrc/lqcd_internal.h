@@ -584,6 +584,97 @@ constexpr int PIPE_CTR_WORDS = 10 * 32;          // the context's counter block 
 constexpr int PIPE_CTR_RED_WORD = 8 * 32 + 16;   // kernel, 128 B apart; two more words of the exit counter's line: the exterior's reduction ticket (stencil.hip) ...
 constexpr int PIPE_CTR_NOTPROJ_WORD = 8 * 32 + 24;   // ... and the "some link was not projected" flag of the link updates (md.hip)
 
+
+
+
+// ---------------------------------------------------------------- peer-mapped communication backend (comm.hip, round 6)
+// Beside RCCL: every rank owns ONE device allocation (its "window": ghost buffers of the stencil, mailboxes of the rarer face exchanges, flag words, slots of the
+// scalar reductions), exports it with hipIpcGetMemHandle and maps the windows of the other ranks.  Producers store faces STRAIGHT into the neighbour's ghost buffer;
+// ordering is by 64-bit sequence numbers in flag words, raised and awaited by one-wave kernels in stream order (no large kernel ever spins, so several ranks can
+// share one device -- the world-size-2 tests on one GPU -- without deadlock); interprocess HIP events cannot be waited on across processes on this stack
+// (profiles/r06_ipc_probe.log: hipStreamWaitEvent -> invalid argument).  The layout is a pure function of the local geometry, identical on every rank.
+constexpr int PEER_MAX_RANKS = 8;       // one node of MI355X
+constexpr int PEER_RED_RING = 4;        // reductions in flight before a slot is reused (ranks are never more than one reduction apart: 2 would do)
+constexpr int PEER_RED_VALS = 8;        // values per reduction
+constexpr size_t PEER_FLAG_STRIDE = 128;    // bytes between flag words (each on a line of its own)
+struct PeerLayout {
+    size_t halo_flag = 0;   // [4 mu][2 side] u64, side 0: written by my -mu neighbour (its forward face has landed), side 1: by my +mu neighbour
+    size_t aux_flag = 0;    // [4][2] u64: number of the last mailbox message that has landed in box (mu, side)
+    size_t aux_ack = 0;     // [4][2] u64: number of the last message I sent in direction (mu, dirn) that its receiver has copied out of the box
+    size_t red_flag = 0;    // [ring][PEER_MAX_RANKS] u64
+    size_t red_val = 0;     // [ring][PEER_MAX_RANKS][PEER_RED_VALS] double
+    size_t ghost[4] = {};   // partitioned directions: 2 buffers (exchange number & 1) of [from -mu | from +mu]
+    size_t ghost_bytes[4] = {};     // bytes of ONE buffer
+    size_t aux_box[4] = {}; // partitioned directions: [side 0 | side 1], aux_cap bytes each
+    size_t aux_cap[4] = {};
+    size_t total = 0;
+};
+struct PeerComm {
+    bool on = false;                // this context communicates through mapped windows (has_comm is set as well)
+    bool exported = false;
+    int finegrained = 1;            // the window is fine-grained device memory (remote stores bypass the L2: required between devices; 0 only for one-device experiments)
+    char* win[PEER_MAX_RANKS] = {}; // mapped base of every rank's window (own rank: the allocation itself)
+    bool opened[PEER_MAX_RANKS] = {};   // mapped by hipIpcOpenMemHandle (closed at teardown)
+    PeerLayout lay;
+    uint64_t xchg_seq = 0;          // stencil halo exchanges issued so far: producers write buffer xchg_seq & 1, consumers read buffer (xchg_seq - 1) & 1
+    uint64_t red_seq = 0;           // reductions issued so far
+    uint64_t aux_sent[4][2] = {}, aux_rcvd[4][2] = {};
+    unsigned* status = nullptr;     // pinned host words, written by a wait that gave up: [0] what (1 halo, 2 reduction, 3 mailbox data, 4 mailbox ack), [1] index, [2..3] the number awaited
+    int timeout_ms = 60000;
+};
+// argument block of a reduction over the ranks inside a kernel (peer_allreduce_wave below); nranks == 0: not a peer context / nothing to do
+struct PeerRedArgs {
+    double* val[PEER_MAX_RANKS];                // rank r's slot block of this reduction: [source rank][PEER_RED_VALS]
+    unsigned long long* flag[PEER_MAX_RANKS];   // rank r's flag words of this reduction: [source rank]
+    int nranks, rank;
+    unsigned long long seq, limit;              // limit: ticks of the 100 MHz clock a wait may take
+    unsigned* status;
+};
+
+#ifdef __HIPCC__
+// entry j of an 8-pointer table held in kernel arguments, without a dynamic index (which would send the whole argument struct through scratch)
+template <typename T>
+__device__ __forceinline__ T* pick8(T* const (&t)[PEER_MAX_RANKS], int j) {
+    T* p = t[0];
+    p = j == 1 ? t[1] : p; p = j == 2 ? t[2] : p; p = j == 3 ? t[3] : p; p = j == 4 ? t[4] : p;
+    p = j == 5 ? t[5] : p; p = j == 6 ? t[6] : p; p = j == 7 ? t[7] : p;
+    return p;
+}
+__device__ __forceinline__ void peer_give_up(unsigned* status, unsigned what, unsigned idx, unsigned long long awaited) {
+    if (status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        status[1] = idx; status[2] = (unsigned)awaited; status[3] = (unsigned)(awaited >> 32);
+        __hip_atomic_store(status, what, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// Sum over the ranks of n <= PEER_RED_VALS doubles, by ONE full wave (all 64 lanes active, wave-uniform n): lane r + 8 k passes this rank's value k in `mine`
+// (the same in all r) and gets the sum of value k over the ranks back.  Every rank stores its values into slot [its rank] of every rank's window, raises the
+// slot's flag to the reduction's number, waits for the nranks flags of its own window and adds the nranks slots IN RANK ORDER -- every rank forms the same
+// bits, so convergence decisions taken from the sum agree.  A wait that outlives a.limit ticks records itself in a.status (host: comm_check) and returns.
+__device__ inline double peer_allreduce_wave(const PeerRedArgs& a, double mine, int n) {
+    const int l = threadIdx.x & 63, r = l & 7, k = l >> 3;
+    const bool act = r < a.nranks && k < n;
+    if (act) __hip_atomic_store(pick8(a.val, r) + a.rank * PEER_RED_VALS + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (act && k == 0) __hip_atomic_store(pick8(a.flag, r) + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* myflag = pick8(a.flag, a.rank);
+    const double* myval = pick8(a.val, a.rank);
+    bool ok = !(r < a.nranks && k == 0);
+    const unsigned long long t0 = wall_clock64();
+    while (!__all(ok)) {
+        if (!ok) ok = __hip_atomic_load(myflag + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
+        if (!ok) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > a.limit) { peer_give_up(a.status, 2u, (unsigned)r, a.seq); ok = true; }
+        }
+    }
+    __threadfence_system();
+    const double x = act ? __hip_atomic_load(myval + r * PEER_RED_VALS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+    double s = __shfl(x, 8 * k, 64);
+    for (int q = 1; q < a.nranks; q++) s += __shfl(x, 8 * k + q, 64);
+    return s;
+}
+#endif
+
 }  // namespace lqcd
 
 struct lqcd_ctx_s {
@@ -629,6 +720,7 @@ struct lqcd_ctx_s {
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;
+    lqcd::PeerComm peer;            // the peer-mapped backend (comm.hip); peer.on: it, not RCCL, carries this context's exchanges
     std::vector<lqcd_ctx_s*> local_peers;  // in-process emulation of the PE grid
     // scratch spinors owned by the context (Temporalfields analogue)
     std::vector<lqcd_spinor_s*> scratch;
@@ -734,6 +826,26 @@ int nccl_fail(ncclResult_t e, const char* what, const char* file, int line);
             return LQCD_ERR_ARG;              \
         }                                     \
     } while (0)
+
+
+// comm.hip: the two communication backends behind one set of calls.  RCCL (lqcd_ctx_comm_init): grouped ncclSend / ncclRecv, ncclAllReduce.  Peer-mapped windows
+// (lqcd_ctx_peer_export / lqcd_ctx_peer_init): direct stores + flag words, see PeerComm above.
+struct CommXfer {           // one leg of a face exchange: send `bytes` to the neighbour in direction (mu, dirn) and receive as much from the opposite neighbour
+    const void* send;
+    void* recv;
+    size_t bytes;
+    int mu;
+    int dirn;               // 0: the message travels forward (to nbr_fwd[mu], from nbr_bwd[mu]); 1: backward
+};
+int comm_sendrecv(lqcd_ctx_s* c, const CommXfer* x, int n, hipStream_t stream, bool halo_comm);     // halo_comm: RCCL uses the halo communicator (comm stream) instead of comm_red
+int comm_allreduce(lqcd_ctx_s* c, double* d_inout, int n, int cg_op = 0);        // in place on device doubles, on the compute stream; cg_op: the CG scalar step behind it (peer: same launch)
+int comm_halo_exchange(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);     // the stencil's face exchange (where: see apply.hip)
+PeerRedArgs comm_red_args(lqcd_ctx_s* c);       // peer backend: the argument block of the NEXT reduction (counts it); otherwise nranks = 0
+int comm_check(lqcd_ctx_s* c);                  // peer backend: LQCD_ERR_COMM if a wait gave up since the last check (call behind a stream synchronisation)
+void comm_teardown(lqcd_ctx_s* c);              // peer backend: unmap / free the windows (lqcd_ctx_destroy)
+// where this context's producers store the faces of the next exchange / its consumers find the ghosts of the last one (bases of [fwd | bwd], [from bwd | from fwd])
+double2* halo_send_base(lqcd_ctx_s* c, int mu, int toward_bwd);
+const double2* halo_recv_base(lqcd_ctx_s* c, int mu);
 
 // ---- kernel launchers implemented across the .hip files
 // stencil: out = a * xin + b * Hop(in), for the parities selected by `parity_mode` (0, 1, or 2 = both).

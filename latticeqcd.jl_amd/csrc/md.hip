@@ -852,16 +852,14 @@ static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse, bool t
 
 // send `sendb[mu]` to one neighbour and receive into `recvb[mu]` from the opposite one, all partitioned directions in one group
 int gf_exchange_rccl(lqcd_ctx_s* c, double2* const sendb[4], double2* const recvb[4], bool to_backward) {
-    ARGCHK(c->has_comm, "staple force: communicator not initialised (call lqcd_ctx_comm_init)");
-    NCCLCHK(ncclGroupStart());
+    ARGCHK(c->has_comm, "staple force: communicator not initialised (call lqcd_ctx_comm_init or lqcd_ctx_peer_init)");
+    CommXfer x[4];
+    int n = 0;
     for (int mu = 0; mu < 4; mu++) {
         if (!c->geom.part[mu]) continue;
-        const size_t nd = gf_face_elems(c, mu) * 2;
-        NCCLCHK(ncclSend(sendb[mu], nd, ncclDouble, to_backward ? c->nbr_bwd[mu] : c->nbr_fwd[mu], c->comm_red, c->stream));
-        NCCLCHK(ncclRecv(recvb[mu], nd, ncclDouble, to_backward ? c->nbr_fwd[mu] : c->nbr_bwd[mu], c->comm_red, c->stream));
+        x[n++] = CommXfer{sendb[mu], recvb[mu], gf_face_elems(c, mu) * sizeof(double2), mu, to_backward ? 1 : 0};
     }
-    NCCLCHK(ncclGroupEnd());
-    return LQCD_OK;
+    return comm_sendrecv(c, x, n, c->stream, false);
 }
 
 static int staple_force(lqcd_gauge_s* out, lqcd_gauge_s* U, double beta, double factor, bool fuse, int mu_only = -1, int mu_out = 0,

@@ -483,7 +483,7 @@ int cg_enqueue_iteration(lqcd_op_s* op, lqcd_spinor_s* x, CgWork& w) {
             for (int q = 0; q < 2; q++) { h.in[q] = spinor_block(pk, q); h.upd[q] = spinor_block(w.r, q); }
             for (int mu = 0; mu < 4; mu++) {
                 const size_t cnt = (size_t)2 * 6 * face_half_sites(c->geom, mu);      // [send_fwd | send_bwd] back to back (stencil.hip make_hargs)
-                h.send_fwd[mu] = c->send_fwd[mu]; h.send_bwd[mu] = c->send_fwd[mu] + cnt;
+                h.send_fwd[mu] = halo_send_base(c, mu, 0); h.send_bwd[mu] = halo_send_base(c, mu, 1) + cnt;
             }
         }
         const dim3 ug(nbu + npack), ub(UB);
@@ -566,7 +566,10 @@ int cg_setup(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, CgWork& w, doubl
              : (cg_defers_x(op) ? 1 : 0);
     w.ring = 2;
     if (w.form == 1) {      // the ring of search-direction buffers (cg_defer_x = K): K - 2 more vectors, or the two-buffer form if the pool cannot grow
-        const int want = cg_ring_wanted(op);
+        int want = cg_ring_wanted(op);
+        // a captured burst (tunable graph) replays the launches of iterations k = 0..7 with their buffer roles baked in: the ring must return to its starting state after
+        // 8 iterations, i.e. divide the burst (K = 3, 5, 6, 7 silently broke the replay) -- otherwise the two-buffer form
+        if (c->tun.graph != 0 && !any_partitioned(c) && (8 % want) != 0) want = 2;
         bool ok = true;
         for (int j = 0; j < want - 2 && ok; j++) {
             if (!w.more[j]) w.more[j] = scratch_get(c, x->kind, LQCD_FULL);
@@ -606,7 +609,7 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     double rr_prev = rr;
     // tunable "graph": a burst of check_every iterations is captured once into a hipGraph and replayed -- one launch per
     // burst instead of 5 per iteration.  Pays on launch-bound (small) lattices; single-stream (unpartitioned) contexts only.
-    const bool use_graph = c->tun.graph != 0 && !any_partitioned(c);
+    const bool use_graph = c->tun.graph != 0 && !any_partitioned(c) && !(c->has_comm && c->peer.on);      // (the peer-mapped reductions carry a sequence number per launch)
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     while (st == LQCD_OK && !one_launch && !converged && it < maxiter) {

@@ -17,6 +17,8 @@
 // Multi-GPU: hops that leave the rank are skipped by the interior kernel and added by the exterior
 // kernels from spin-projected halos packed by pack kernels (see halo layout in lqcd_internal.h).
 #include "stencil_common.h"
+
+#include <cstring>
 namespace lqcd {
 inline namespace LQCD_PNS {
 
@@ -1211,13 +1213,16 @@ __global__ __launch_bounds__(128) void wilson_pack(HArgs k) {
 // exchange -> D^+): grid (x, 9), row 0 = ONE reduction block (dispatched first), rows 1..8 = the pack blocks of wilson_pack with 256 threads each.  The reduction
 // reproduces reduce_final (blas.hip) bit for bit -- small sums: the one-wave order; large sums: thread t owns the classes t, t + 256, t + 512, t + 768 of the
 // 1024-thread kernel, one __shfl_down tree per class group, the 16 wave sums added in sequence -- so iterates do not depend on which launch did the sum.
-__global__ __launch_bounds__(256) void wilson_pack_reduce(HArgs k, const double* __restrict__ partial, int nblocks, double* scal, int slot, int op) {
+__global__ __launch_bounds__(256) void wilson_pack_reduce(HArgs k, const double* __restrict__ partial, int nblocks, double* scal, int slot, int op, PeerRedArgs pr) {
     if (blockIdx.y == 0) {
         if (blockIdx.x != 0) return;
         __shared__ double red[FB / 64];
+        __shared__ double tot;
+        // pr.nranks > 0 (peer-mapped backend): wave 0 adds the ranks' sums right here (comm.hip peer_allreduce_wave), beside the pack blocks
         if (nblocks <= 1024) {
             if (threadIdx.x < 64) {
-                const double t = sum_partials_small_nv(partial, nblocks, 1, 0);
+                double t = sum_partials_small_nv(partial, nblocks, 1, 0);
+                if (pr.nranks) t = __shfl(peer_allreduce_wave(pr, t, 1), 0, 64);
                 if (threadIdx.x == 0) { scal[slot] = t; if (op) cg_scalar_step(scal, op); }
             }
             return;
@@ -1232,8 +1237,13 @@ __global__ __launch_bounds__(256) void wilson_pack_reduce(HArgs k, const double*
         if (threadIdx.x == 0) {
             double t = 0;
             for (int j = 0; j < FB / 64; j++) t += red[j];
-            scal[slot] = t;
-            if (op) cg_scalar_step(scal, op);
+            tot = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double t = tot;
+            if (pr.nranks) t = __shfl(peer_allreduce_wave(pr, t, 1), 0, 64);
+            if (threadIdx.x == 0) { scal[slot] = t; if (op) cg_scalar_step(scal, op); }
         }
         return;
     }
@@ -1629,7 +1639,7 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     for (int mu = 0; mu < 4; mu++) {
         // ghost buffers of this call's message size: [recv_bwd | recv_fwd] back to back (make_hargs' rule)
         const size_t cnt = (size_t)(s.parity_mode == 2 ? 2 : 1) * 6 * face_half_sites(c->geom, mu);
-        a.gh_b[mu] = (const real2*)c->recv_bwd[mu]; a.gh_f[mu] = (const real2*)c->recv_bwd[mu] + cnt;
+        a.gh_b[mu] = (const real2*)halo_recv_base(c, mu); a.gh_f[mu] = (const real2*)halo_recv_base(c, mu) + cnt;
         a.Fh[mu] = face_half_sites(c->geom, mu);
         a.gsf[mu] = (c->coord[mu] == c->pe[mu] - 1) ? real(c->geom.bc_fwd[mu]) : real(1.0);
         a.gsb[mu] = (c->coord[mu] == 0) ? real(c->geom.bc_bwd[mu]) : real(1.0);
@@ -1812,8 +1822,9 @@ static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s) {
         // [send_fwd | send_bwd] and [recv_bwd | recv_fwd] are packed back to back for THIS call's message size (elements of this
         // build's precision), so that a pair of faces bound for the same rank is one contiguous message (ops.hip)
         const size_t cnt = (size_t)(s.parity_mode == 2 ? 2 : 1) * (s.kind == LQCD_WILSON ? 6 : 3) * face_half_sites(c->geom, mu);
-        h.send_fwd[mu] = (real2*)c->send_fwd[mu]; h.send_bwd[mu] = (real2*)c->send_fwd[mu] + cnt;
-        h.recv_bwd[mu] = (const real2*)c->recv_bwd[mu]; h.recv_fwd[mu] = (const real2*)c->recv_bwd[mu] + cnt;
+        // (peer-mapped backend: the "send buffers" are the neighbours' ghost buffers of the next exchange, comm.hip halo_send_base)
+        h.send_fwd[mu] = (real2*)halo_send_base(c, mu, 0); h.send_bwd[mu] = (real2*)halo_send_base(c, mu, 1) + cnt;
+        h.recv_bwd[mu] = (const real2*)halo_recv_base(c, mu); h.recv_fwd[mu] = (const real2*)halo_recv_base(c, mu) + cnt;
         h.sign_fwd[mu] = (c->coord[mu] == c->pe[mu] - 1) ? c->geom.bc_fwd[mu] : 1.0;
         h.sign_bwd[mu] = (c->coord[mu] == 0) ? c->geom.bc_bwd[mu] : 1.0;
     }
@@ -1854,7 +1865,9 @@ int launch_pack_reduce(lqcd_ctx_s* c, const StencilCall& s, const double* partia
     HArgs h = make_hargs(c, s);
     c->halo_epoch++;
     dim3 grid(std::max(1, (nt + 255) / 256), 9), block(256);
-    hipLaunchKernelGGL(wilson_pack_reduce, grid, block, 0, c->stream, h, partial, nblocks, c->d_scal, slot, op);
+    PeerRedArgs pr;
+    if (c->has_comm && c->peer.on) pr = comm_red_args(c); else memset(&pr, 0, sizeof pr);
+    hipLaunchKernelGGL(wilson_pack_reduce, grid, block, 0, c->stream, h, partial, nblocks, c->d_scal, slot, op, pr);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }

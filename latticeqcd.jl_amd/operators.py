@@ -17,6 +17,7 @@ Host arrays are numpy complex128, C order, with the memory image of the Julia ar
   gauge U[mu,t,z,y,x,b,a], Wilson psi[s,t,z,y,x,c], staggered psi[t,z,y,x,c]   (local sub-lattice of this rank).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -97,8 +98,36 @@ class Lattice:
 
     def comm_init(self, unique_id):
         assert len(unique_id) == 256
+        # test aid: LQCD_SELFCOMM_BACKEND=peer sends a ONE-rank communicator (the self-partitioned tests: LQCD_FORCE_PARTITION) through the peer-mapped
+        # backend instead of RCCL, so that the same test bodies cover both (tests/test_gpu_peer_selfmapped.py)
+        if self.nranks == 1 and os.environ.get("LQCD_SELFCOMM_BACKEND", "") == "peer":
+            return self.comm_init_peer()
         buf = (C.c_ubyte * 256)(*bytes(unique_id))
         check(_l.lib().lqcd_ctx_comm_init(self._h, buf, self.nranks))
+
+    # the peer-mapped backend (csrc/comm.hip): export -> the host gathers the blobs of all ranks in rank order -> init
+    def peer_export(self):
+        buf = (C.c_ubyte * 256)()
+        check(_l.lib().lqcd_ctx_peer_export(self._h, buf))
+        return bytes(buf)
+
+    def peer_init(self, blobs):
+        """blobs: the 256-byte descriptions of ranks 0..nranks-1 (a list, or their concatenation)."""
+        raw = b"".join(bytes(b) for b in blobs) if not isinstance(blobs, (bytes, bytearray)) else bytes(blobs)
+        assert len(raw) == 256 * self.nranks, (len(raw), self.nranks)
+        buf = (C.c_ubyte * len(raw))(*raw)
+        check(_l.lib().lqcd_ctx_peer_init(self._h, buf, self.nranks))
+
+    def comm_init_peer(self, all_gather=None):
+        """One call for both steps; all_gather(blob) -> list of every rank's blob in rank order (default: this rank alone, the self-partitioned proxy)."""
+        mine = self.peer_export()
+        self.peer_init(all_gather(mine) if all_gather else [mine])
+
+    @property
+    def comm_backend(self):
+        v = C.c_int(0)
+        check(_l.lib().lqcd_ctx_comm_backend(self._h, C.byref(v)))
+        return {0: "none", 1: "rccl", 2: "peer"}[v.value]
 
     def close(self):
         if self._h:

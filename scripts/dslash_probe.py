@@ -17,11 +17,13 @@ ap.add_argument("--cg", type=int, default=0)
 ap.add_argument("--kind", default="Wilson")
 ap.add_argument("--dagger", type=int, default=0)
 ap.add_argument("--set", action="append", default=[])
-ap.add_argument("--selfcomm", type=int, default=0, help="init world-size-1 RCCL communicators (use with LQCD_FORCE_PARTITION)")
+ap.add_argument("--selfcomm", type=int, default=0, help="1: init world-size-1 RCCL communicators, 2: the peer-mapped backend mapped onto itself (use with LQCD_FORCE_PARTITION)")
 a = ap.parse_args()
 L = tuple(int(v) for v in a.lattice.split(","))
 lat = lq.Lattice(L)
-if a.selfcomm:
+if a.selfcomm == 2:
+    lat.comm_init_peer()
+elif a.selfcomm:
     lat.comm_init(lq.comm_unique_id())
 for kv in a.set:
     k, v = kv.split("=")
