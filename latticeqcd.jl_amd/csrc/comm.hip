@@ -78,38 +78,8 @@ static_assert(sizeof(PeerBlob) <= 256, "PeerBlob must fit LQCD_PEER_BLOB_BYTES")
 constexpr uint32_t PEER_MAGIC = 0x5051434cu;   // "LCQP"
 
 // ---------------------------------------------------------------------------------- kernels
-struct PeerSyncArgs {
-    unsigned long long* sig[PEER_MAX_RANKS];     // flag words in the neighbours' windows that this rank raises
-    unsigned long long* wt[PEER_MAX_RANKS];      // flag words in this rank's window it waits for
-    int nsig, nwt;
-    unsigned long long sig_seq[PEER_MAX_RANKS], wt_seq[PEER_MAX_RANKS];
-    unsigned long long limit;
-    unsigned* status;
-    unsigned what;
-};
-__device__ __forceinline__ unsigned long long pick8v(const unsigned long long (&t)[PEER_MAX_RANKS], int j) {
-    unsigned long long p = t[0];
-    p = j == 1 ? t[1] : p; p = j == 2 ? t[2] : p; p = j == 3 ? t[3] : p; p = j == 4 ? t[4] : p;
-    p = j == 5 ? t[5] : p; p = j == 6 ? t[6] : p; p = j == 7 ? t[7] : p;
-    return p;
-}
-// One wave.  Lane j < nsig: everything this stream has produced so far is visible before flag sig[j] rises to sig_seq[j]; lane j < nwt: wait until flag
-// wt[j] has reached wt_seq[j].  The kernels behind this one in the stream find the faces the neighbours stored before THEY raised the flags.
-__global__ __launch_bounds__(64) void peer_sync_kernel(PeerSyncArgs a) {
-    const int j = threadIdx.x;
-    __threadfence_system();
-    if (j < a.nsig) __hip_atomic_store(pick8(a.sig, j), pick8v(a.sig_seq, j), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (j < a.nwt) {
-        const unsigned long long* w = pick8(a.wt, j);
-        const unsigned long long want = pick8v(a.wt_seq, j);
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > a.limit) { peer_give_up(a.status, a.what, (unsigned)j, want); break; }
-        }
-    }
-    __threadfence_system();
-}
+// One wave: the exchange step as a launch of its own (lqcd_internal.h peer_signal_wait_wave)
+__global__ __launch_bounds__(64) void peer_sync_kernel(PeerSyncArgs a) { peer_signal_wait_wave(a); }
 
 // sum over the ranks of n device doubles in place + the CG scalar step behind it: the stand-alone form of peer_allreduce_wave (the reduction launches of
 // blas.hip / stencil.hip carry it in their own tails)
@@ -143,6 +113,7 @@ PeerRedArgs comm_red_args(lqcd_ctx_s* c) {
     a.nranks = c->nranks; a.rank = c->rank;
     a.seq = seq; a.limit = peer_limit(c);
     a.status = c->peer.status;
+    a.fence = 0;      // values and flags are system-scope atomics (they bypass the caches); completion of the value stores orders them before the flags
     return a;
 }
 
@@ -167,14 +138,8 @@ const double2* halo_recv_base(lqcd_ctx_s* c, int mu) {
     return (const double2*)(c->peer.win[c->rank] + c->peer.lay.ghost[mu] + (size_t)((c->peer.xchg_seq + 1) & 1) * c->peer.lay.ghost_bytes[mu]);
 }
 
-// the exchange step of a stencil application: the faces are in the neighbours' ghost buffers already (halo_send_base), what is left is the ordering
-static int halo_exchange_peer(lqcd_ctx_s* c, int where) {
-    const bool in_order = where == 1;
-    hipStream_t xs = in_order ? c->stream : c->comm_stream;
-    if (where == 0) {
-        HIPCHK(hipEventRecord(c->ev_pack, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
-    }
+// flag words of the next stencil exchange (counts it)
+static PeerSyncArgs halo_sync_args(lqcd_ctx_s* c) {
     PeerSyncArgs a;
     memset(&a, 0, sizeof a);
     const uint64_t seq = ++c->peer.xchg_seq;
@@ -191,7 +156,18 @@ static int halo_exchange_peer(lqcd_ctx_s* c, int where) {
     }
     a.nsig = a.nwt = n;
     a.limit = peer_limit(c); a.status = c->peer.status; a.what = 1u;
-    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, xs, a);
+    a.fence = 1;
+    return a;
+}
+// the exchange step of a stencil application: the faces are in the neighbours' ghost buffers already (halo_send_base), what is left is the ordering
+static int halo_exchange_peer(lqcd_ctx_s* c, int where) {
+    const bool in_order = where == 1;
+    hipStream_t xs = in_order ? c->stream : c->comm_stream;
+    if (where == 0) {
+        HIPCHK(hipEventRecord(c->ev_pack, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+    }
+    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, xs, halo_sync_args(c));
     HIPCHK(hipGetLastError());
     if (!in_order) HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     return LQCD_OK;
@@ -232,6 +208,7 @@ static int sendrecv_peer(lqcd_ctx_s* c, const CommXfer* x, int n, hipStream_t s)
         w3.sig[i] = flag_at(P.win[src], P.lay.aux_ack, box); w3.sig_seq[i] = P.aux_rcvd[mu][d] + 1;
     }
     w1.nwt = n; w1.limit = peer_limit(c); w1.status = P.status; w1.what = 4u;
+    w1.fence = 0; w2.fence = 1; w3.fence = 0;      // the data ride on step 2; steps 1 and 3 order no data (kernel boundaries do: the copies are launches of their own)
     w2.nsig = w2.nwt = n; w2.limit = w1.limit; w2.status = P.status; w2.what = 3u;
     w3.nsig = n; w3.limit = w1.limit; w3.status = P.status; w3.what = 4u;
     hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, w1);

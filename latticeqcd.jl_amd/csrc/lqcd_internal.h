@@ -622,6 +622,18 @@ struct PeerComm {
     unsigned* status = nullptr;     // pinned host words, written by a wait that gave up: [0] what (1 halo, 2 reduction, 3 mailbox data, 4 mailbox ack), [1] index, [2..3] the number awaited
     int timeout_ms = 60000;
 };
+// argument block of an exchange step: flag words to raise / to wait for (peer_signal_wait_wave below); nsig == nwt == 0: nothing to do
+struct PeerSyncArgs {
+    unsigned long long* sig[PEER_MAX_RANKS];     // flag words in the neighbours' windows that this rank raises
+    unsigned long long* wt[PEER_MAX_RANKS];      // flag words in this rank's window it waits for
+    int nsig, nwt;
+    unsigned long long sig_seq[PEER_MAX_RANKS], wt_seq[PEER_MAX_RANKS];
+    unsigned long long limit;
+    unsigned* status;
+    unsigned what;
+    int fence;      // 1: system-scope release / acquire fences around the flag operations (the stand-alone exchange step: the L2 is clean behind the producer's kernel end,
+                    // so the write-back costs nothing there); 0: only completion of the wave's own stores (the mailbox acknowledgements, which order no data)
+};
 // argument block of a reduction over the ranks inside a kernel (peer_allreduce_wave below); nranks == 0: not a peer context / nothing to do
 struct PeerRedArgs {
     double* val[PEER_MAX_RANKS];                // rank r's slot block of this reduction: [source rank][PEER_RED_VALS]
@@ -629,6 +641,7 @@ struct PeerRedArgs {
     int nranks, rank;
     unsigned long long seq, limit;              // limit: ticks of the 100 MHz clock a wait may take
     unsigned* status;
+    int fence;                                  // as in PeerSyncArgs
 };
 
 #ifdef __HIPCC__
@@ -646,6 +659,40 @@ __device__ __forceinline__ void peer_give_up(unsigned* status, unsigned what, un
         __hip_atomic_store(status, what, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+__device__ __forceinline__ unsigned long long pick8v(const unsigned long long (&t)[PEER_MAX_RANKS], int j) {
+    unsigned long long p = t[0];
+    p = j == 1 ? t[1] : p; p = j == 2 ? t[2] : p; p = j == 3 ? t[3] : p; p = j == 4 ? t[4] : p;
+    p = j == 5 ? t[5] : p; p = j == 6 ? t[6] : p; p = j == 7 ? t[7] : p;
+    return p;
+}
+// Ordering of earlier stores before a flag store that follows.  fence = 1: a system-scope release fence -- the stand-alone exchange step runs behind the kernel end of
+// the producer, where the L2 holds nothing dirty, so the write-back it implies is cheap.  INSIDE a producer launch it is not: an in-kernel exchange step (a ticket among
+// the pack blocks, then fence + flag) measured 60 us per launch (the whole L2 is written back), and without the fence the faces stored through an IPC mapping were still
+// in the writer's L2 when the other process read them (profiles/r06_peer_insync_ab.log) -- the step stays a launch of its own.  fence = 0: completion of this wave's own
+// stores (vmcnt counts stores on gfx9-family parts), enough where every word involved is written by system-scope atomics, which bypass the caches.
+__device__ __forceinline__ void peer_release(int fence) {
+    if (fence) __threadfence_system();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// The exchange step, by one full wave.  Lane j < nsig: everything this stream has stored so far is visible before flag
+// sig[j] rises to sig_seq[j]; lane j < nwt: wait until flag wt[j] has reached wt_seq[j] -- the launches behind this one find the faces the neighbours stored
+// before THEY raised the flags (their kernel-start acquire; fence = 1 adds an acquire fence here).  A wait that outlives a.limit records itself in a.status and
+// returns (comm_check turns it into LQCD_ERR_COMM).  Flag words are only ever touched by system-scope atomics, which bypass the caches.
+__device__ inline void peer_signal_wait_wave(const PeerSyncArgs& a) {
+    const int j = threadIdx.x & 63;
+    peer_release(a.fence);
+    if (j < a.nsig) __hip_atomic_store(pick8(a.sig, j), pick8v(a.sig_seq, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (j < a.nwt) {
+        const unsigned long long* w = pick8(a.wt, j);
+        const unsigned long long want = pick8v(a.wt_seq, j);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > a.limit) { peer_give_up(a.status, a.what, (unsigned)j, want); break; }
+        }
+    }
+    if (a.fence) __threadfence_system();
+}
 // Sum over the ranks of n <= PEER_RED_VALS doubles, by ONE full wave (all 64 lanes active, wave-uniform n): lane r + 8 k passes this rank's value k in `mine`
 // (the same in all r) and gets the sum of value k over the ranks back.  Every rank stores its values into slot [its rank] of every rank's window, raises the
 // slot's flag to the reduction's number, waits for the nranks flags of its own window and adds the nranks slots IN RANK ORDER -- every rank forms the same
@@ -654,20 +701,21 @@ __device__ inline double peer_allreduce_wave(const PeerRedArgs& a, double mine, 
     const int l = threadIdx.x & 63, r = l & 7, k = l >> 3;
     const bool act = r < a.nranks && k < n;
     if (act) __hip_atomic_store(pick8(a.val, r) + a.rank * PEER_RED_VALS + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    if (act && k == 0) __hip_atomic_store(pick8(a.flag, r) + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    peer_release(a.fence);       // the values (of every lane of this wave) before the flags
+    if (act && k == 0) __hip_atomic_store(pick8(a.flag, r) + a.rank, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* myflag = pick8(a.flag, a.rank);
     const double* myval = pick8(a.val, a.rank);
     bool ok = !(r < a.nranks && k == 0);
     const unsigned long long t0 = wall_clock64();
     while (!__all(ok)) {
-        if (!ok) ok = __hip_atomic_load(myflag + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
+        if (!ok) ok = __hip_atomic_load(myflag + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
         if (!ok) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > a.limit) { peer_give_up(a.status, 2u, (unsigned)r, a.seq); ok = true; }
         }
     }
-    __threadfence_system();
+    if (a.fence) __threadfence_system();
+    else asm volatile("" ::: "memory");      // (the value loads below are issued after the flag loads have returned: the loop inspected them)
     const double x = act ? __hip_atomic_load(myval + r * PEER_RED_VALS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
     double s = __shfl(x, 8 * k, 64);
     for (int q = 1; q < a.nranks; q++) s += __shfl(x, 8 * k + q, 64);

@@ -7,6 +7,7 @@
 #include "stencil_common.h"      // HArgs, wilson_pack_axpy_block: pack blocks appended to the x/p update launch (partitioned lattices)
 
 #include <algorithm>
+#include <cstring>
 #include <cmath>
 #include <complex>
 #include <functional>

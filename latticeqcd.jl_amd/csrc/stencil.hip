@@ -1219,29 +1219,23 @@ __global__ __launch_bounds__(256) void wilson_pack_reduce(HArgs k, const double*
         __shared__ double red[FB / 64];
         __shared__ double tot;
         // pr.nranks > 0 (peer-mapped backend): wave 0 adds the ranks' sums right here (comm.hip peer_allreduce_wave), beside the pack blocks
-        if (nblocks <= 1024) {
-            if (threadIdx.x < 64) {
-                double t = sum_partials_small_nv(partial, nblocks, 1, 0);
-                if (pr.nranks) t = __shfl(peer_allreduce_wave(pr, t, 1), 0, 64);
-                if (threadIdx.x == 0) { scal[slot] = t; if (op) cg_scalar_step(scal, op); }
-            }
-            return;
-        }
-        const int w = (int)threadIdx.x >> 6;
+        if (nblocks > 1024) {
+            const int w = (int)threadIdx.x >> 6;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const double t = shfl_tree_sum(sum_partials_class(partial, nblocks, 1, 0, (int)threadIdx.x + 256 * q));
-            if ((threadIdx.x & 63) == 0) red[w + 4 * q] = t;
+            for (int q = 0; q < 4; q++) {
+                const double t = shfl_tree_sum(sum_partials_class(partial, nblocks, 1, 0, (int)threadIdx.x + 256 * q));
+                if ((threadIdx.x & 63) == 0) red[w + 4 * q] = t;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0;
+                for (int j = 0; j < FB / 64; j++) t += red[j];
+                tot = t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0;
-            for (int j = 0; j < FB / 64; j++) t += red[j];
-            tot = t;
-        }
-        __syncthreads();
         if (threadIdx.x < 64) {
-            double t = tot;
+            double t = nblocks > 1024 ? tot : sum_partials_small_nv(partial, nblocks, 1, 0);
             if (pr.nranks) t = __shfl(peer_allreduce_wave(pr, t, 1), 0, 64);
             if (threadIdx.x == 0) { scal[slot] = t; if (op) cg_scalar_step(scal, op); }
         }
