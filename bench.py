@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--dslash-reps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pe-grid", type=str, default="")
+    ap.add_argument("--comm", choices=("auto", "peer", "rccl"), default="auto",
+                    help="N > 1: communication backend -- peer = hipIpc-mapped windows (csrc/comm.hip), rccl = RCCL send/recv + all-reduce, "
+                         "auto = peer, falling back to rccl (on every rank) if any rank cannot map its neighbours; reported in config.comm_backend")
     ap.add_argument("--set", action="append", default=[], help="library tunable key=value")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -78,10 +81,32 @@ def main():
     for kv in args.set:
         k, v = kv.split("=")
         lat.set_param(k, int(v))
+    comm_note = None
     if world > 1 or force_dist:
-        box = [lq.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        lat.comm_init(box[0])
+        import torch
+        if args.comm in ("auto", "peer"):
+            ok, err = 1, ""
+            try:
+                blobs = [None] * world
+                dist.all_gather_object(blobs, lat.peer_export())      # the 256-byte window descriptions, in rank order
+                lat.peer_init(blobs)
+            except Exception as e:                                    # noqa: BLE001  (whatever it is, every rank must learn of it)
+                ok, err = 0, str(e)
+            t = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                if args.comm == "peer":
+                    raise RuntimeError("--comm peer: a rank could not set up its peer-mapped windows" + (": " + err if err else ""))
+                comm_note = "peer-mapped windows unavailable on some rank" + (" (rank %d: %s)" % (rank, err) if err else "") + ": fell back to RCCL"
+                lat.close()                                           # a context that exported a window keeps to that backend: start over
+                lat = lq.Lattice(gL, pe, rank, device=local_rank)
+                for kv in args.set:
+                    k, v = kv.split("=")
+                    lat.set_param(k, int(v))
+        if lat.comm_backend == "none":
+            box = [lq.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            lat.comm_init(box[0])
         _flush_c_stdio()
 
     def device_sync():
@@ -159,7 +184,8 @@ def main():
                    "pe_grid": list(pe), "local_lattice": list(lat.local_L), "dslash_variant": lat.get_param("dslash_variant"),
                    "xcd_remap": lat.get_param("xcd_remap"), "xcd_nsub": lat.get_param("xcd_nsub"),
                    "xcd_ysplit": lat.get_param("xcd_ysplit"), "cg_fused": lat.get_param("cg_fused"),
-                   "gauge_recon": lat.get_param("gauge_recon"), "gauge_recon_active": recon_active},
+                   "gauge_recon": lat.get_param("gauge_recon"), "gauge_recon_active": recon_active,
+                   "comm_backend": lat.comm_backend, "comm_requested": args.comm, "comm_note": comm_note},
         "dslash_gflops": dslash_gflops,
         "dslash_ms": ms_dslash,
         "dslash_ms_median_per_launch_events": ms_median,

@@ -83,6 +83,20 @@ function comm_unique_id()
 end
 comm_init!(lat::HIPLattice, id::Vector{UInt8}) =
     check(ccall((:lqcd_ctx_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), lat.h, id, prod(lat.PEs)))
+# The second backend (csrc/comm.hip): peer-mapped windows.  Every rank exports the 256-byte description of its window, the host gathers them in rank order
+# (peer_init!(lat, MPI.Allgather(peer_export(lat), comm)): nranks * 256 bytes) and every rank maps the others'.  One node, <= 8 ranks.
+function peer_export(lat::HIPLattice)
+    blob = zeros(UInt8, 256)
+    check(ccall((:lqcd_ctx_peer_export, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}), lat.h, blob))
+    return blob
+end
+peer_init!(lat::HIPLattice, blobs::Vector{UInt8}) =
+    check(ccall((:lqcd_ctx_peer_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), lat.h, blobs, prod(lat.PEs)))
+function comm_backend(lat::HIPLattice)
+    b = Ref{Cint}(0)
+    check(ccall((:lqcd_ctx_comm_backend, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), lat.h, b))
+    return (:none, :rccl, :peer)[b[] + 1]
+end
 set_param!(lat::HIPLattice, key::String, value::Integer) =
     check(ccall((:lqcd_ctx_set_param, LIB), Cint, (Ptr{Cvoid}, Cstring, Cint), lat.h, key, value))
 

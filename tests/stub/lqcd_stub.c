@@ -51,9 +51,11 @@ int lqcd_ctx_get_param(void* cc, const char* k, int* v) {
     return OK;
 }
 int lqcd_comm_unique_id(unsigned char* id) { for (int i = 0; i < 256; i++) id[i] = (unsigned char)(37 * i + 11); return OK; }
+static int g_backend[64];
 int lqcd_ctx_comm_init(void* cc, const unsigned char* id, int nranks) {
     ctx_t* c = (ctx_t*)cc;
     if (nranks != c->nranks) return 1;
+    g_backend[c->rank & 63] = 1;
     const char* d = getenv("LQCD_STUB_DIR");
     if (d) {
         char path[1024];
@@ -63,6 +65,29 @@ int lqcd_ctx_comm_init(void* cc, const unsigned char* id, int nranks) {
     }
     return OK;
 }
+/* the peer-mapped backend's bootstrap: the blob carries the rank, peer_init checks that the gathered blobs are in rank order and records them like comm_init does */
+int lqcd_ctx_peer_export(void* cc, unsigned char* blob) {
+    ctx_t* c = (ctx_t*)cc;
+    if (getenv("LQCD_STUB_PEER_FAILS")) return 4;
+    memset(blob, 0, 256);
+    blob[0] = 'S'; blob[1] = (unsigned char)c->rank; blob[2] = (unsigned char)c->nranks;
+    return OK;
+}
+int lqcd_ctx_peer_init(void* cc, const unsigned char* blobs, int nranks) {
+    ctx_t* c = (ctx_t*)cc;
+    if (nranks != c->nranks) return 1;
+    for (int r = 0; r < nranks; r++) if (blobs[256 * r] != 'S' || blobs[256 * r + 1] != (unsigned char)r) return 4;
+    const char* d = getenv("LQCD_STUB_DIR");
+    if (d) {
+        char path[1024];
+        snprintf(path, sizeof path, "%s/rank%d.peer", d, c->rank);
+        FILE* f = fopen(path, "wb");
+        if (f) { fprintf(f, "pe=%d,%d,%d,%d nranks=%d device=%d\n", c->pe[0], c->pe[1], c->pe[2], c->pe[3], nranks, c->device); fclose(f); }
+    }
+    g_backend[c->rank & 63] = 2;
+    return OK;
+}
+int lqcd_ctx_comm_backend(void* cc, int* b) { ctx_t* c = (ctx_t*)cc; *b = g_backend[c->rank & 63]; return OK; }
 static int handle(void** h) { *h = malloc(8); return OK; }
 int lqcd_gauge_create(void* c, void** h) { (void)c; return handle(h); }
 int lqcd_gauge_destroy(void* h) { free(h); return OK; }

@@ -132,26 +132,38 @@ def test_bench_control_path_two_processes(lq, tmp_path):
     stub_dir = os.path.join(ROOT, "tests", "stub")
     r = subprocess.run(["make", "-s", "-C", stub_dir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    env = dict(os.environ, LQCD_HIP_LIB=os.path.join(stub_dir, "liblqcd_stub.so"), LQCD_STUB_REAL_LIB=lq.lib.SO_PATH,
-               LQCD_STUB_DIR=str(tmp_path))
-    env.pop("LQCD_BENCH_FORCE_DIST", None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"],
-                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    out = json.loads(lines[-1])                                     # the JSON line is the LAST line of the job's stdout
-    assert sum(1 for ln in lines if ln.startswith("{")) == 1        # and only rank 0 prints one
-    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "strong"
-    assert out["config"]["pe_grid"] == [1, 1, 1, 2] and out["config"]["local_lattice"] == [32, 32, 32, 32]
-    assert abs(out["dslash_ms"] - 0.1) < 1e-12                      # max over ranks: rank 1 reported 2 x 0.05 ms
-    assert abs(out["allreduce_latency_us"] - 20.0) < 1e-12 and abs(out["halo_phases_ms_max_over_ranks"]["pack"] - 0.02) < 1e-12
-    assert out["halo_bytes_per_peer_and_direction"] == [0, 0, 0, 96 * 32 * 32 * 32]
-    assert out["roofline"]["traffic"] is None and "cpu_baseline" not in out      # N = 1 extras stay out of the N > 1 line
-    ids = [open(os.path.join(str(tmp_path), "rank%d.id" % k), "rb").read() for k in (0, 1)]
     pattern = bytes((37 * i + 11) % 256 for i in range(256))
-    assert ids[0][:256] == pattern and ids[1][:256] == pattern     # both ranks initialised their communicators with rank 0's id
-    assert b"pe=1,1,1,2 nranks=2 device=0" in ids[0] and b"device=1" in ids[1]   # one device per local rank
+    # three bootstraps: the default (peer-mapped windows: the 256-byte descriptions gathered in rank order), --comm rccl (rank 0's id broadcast),
+    # and the default on a machine where a rank cannot map its peers (every rank falls back to RCCL together, and the line says so)
+    for k, (flags, extra, want) in enumerate(((["--comm", "rccl"], {}, "rccl"), ([], {}, "peer"), ([], {"LQCD_STUB_PEER_FAILS": "1"}, "rccl"))):
+        d = tmp_path / ("run%d" % k)
+        d.mkdir()
+        env = dict(os.environ, LQCD_HIP_LIB=os.path.join(stub_dir, "liblqcd_stub.so"), LQCD_STUB_REAL_LIB=lq.lib.SO_PATH, LQCD_STUB_DIR=str(d), **extra)
+        env.pop("LQCD_BENCH_FORCE_DIST", None)
+        port = str(29617 + k)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"] + flags,
+                           capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        out = json.loads(lines[-1])                                     # the JSON line is the LAST line of the job's stdout
+        assert sum(1 for ln in lines if ln.startswith("{")) == 1        # and only rank 0 prints one
+        assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "strong"
+        assert out["config"]["pe_grid"] == [1, 1, 1, 2] and out["config"]["local_lattice"] == [32, 32, 32, 32]
+        assert out["config"]["comm_backend"] == want and out["config"]["comm_requested"] == (flags[1] if flags else "auto")
+        assert (out["config"]["comm_note"] is not None) == bool(extra)  # the fallback is reported, nothing else is
+        assert abs(out["dslash_ms"] - 0.1) < 1e-12                      # max over ranks: rank 1 reported 2 x 0.05 ms
+        assert abs(out["allreduce_latency_us"] - 20.0) < 1e-12 and abs(out["halo_phases_ms_max_over_ranks"]["pack"] - 0.02) < 1e-12
+        assert out["halo_bytes_per_peer_and_direction"] == [0, 0, 0, 96 * 32 * 32 * 32]
+        assert out["roofline"]["traffic"] is None and "cpu_baseline" not in out      # N = 1 extras stay out of the N > 1 line
+        if want == "rccl":
+            ids = [open(os.path.join(str(d), "rank%d.id" % q), "rb").read() for q in (0, 1)]
+            assert ids[0][:256] == pattern and ids[1][:256] == pattern     # both ranks initialised their communicators with rank 0's id
+            assert b"pe=1,1,1,2 nranks=2 device=0" in ids[0] and b"device=1" in ids[1]   # one device per local rank
+        else:
+            pr = [open(os.path.join(str(d), "rank%d.peer" % q), "rb").read() for q in (0, 1)]      # written once the gathered blobs were in rank order
+            assert b"pe=1,1,1,2 nranks=2 device=0" in pr[0] and b"device=1" in pr[1]
+            assert not os.path.exists(os.path.join(str(d), "rank0.id"))
 
 
 # ------------------------------------------------------------------ the Julia binding against the header (no Julia in the image)
