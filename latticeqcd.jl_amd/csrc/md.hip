@@ -20,6 +20,30 @@ typedef cd m3[9];
 #ifndef LQCD_STAPLE_TWOROW
 #define LQCD_STAPLE_TWOROW 1    // ... and two-row products inside it (r04)
 #endif
+#ifndef LQCD_STAPLE_NT
+#define LQCD_STAPLE_NT 1        // round 6: the one-sweep form streams the momenta (read + written once) and the new links (written once) past the caches: the block
+                                // U_update! P_update! U_update! 1.416 -> 1.359 ms at 32^3x64 (profiles/r06_staple_ab.log) -- the sweep is bound by the memory path, not by issue
+#endif
+typedef double v2d_md __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cd ld_stream(const double2* p) {
+#if LQCD_STAPLE_NT
+    const v2d_md v = __builtin_nontemporal_load(reinterpret_cast<const v2d_md*>(p));
+    return mk(v.x, v.y);
+#else
+    return ld(p);
+#endif
+}
+__device__ __forceinline__ void st_stream(double2* p, cd v) {
+#if LQCD_STAPLE_NT
+    const v2d_md t = {v.re, v.im};
+    __builtin_nontemporal_store(t, reinterpret_cast<v2d_md*>(p));
+#else
+    st(p, v);
+#endif
+}
+#ifndef LQCD_STAPLE_ROWS3
+#define LQCD_STAPLE_ROWS3 0
+#endif
 #ifndef LQCD_STAPLE_BURST
 #define LQCD_STAPLE_BURST 1     // two-row staple sweep: the five neighbour links of a plane in one load burst
 #endif
@@ -290,24 +314,34 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
         cd a1[9], a2[9], l1[9], l2[9], l3[9], u3[9], t1[9], t2[9];
         int m[4] = {c[0], c[1], c[2], c[3]};
         shift(m, g, NU, -1);
+#if LQCD_STAPLE_ROWS3      // experiment (round 6, measured SLOWER: 1.416 -> 1.494 ms per block, profiles/r06_staple_ab.log): the links that enter a product as its right operand
+                           // come with all three rows -- three finish_u less per plane (-13 % VALU), 39 instead of 30 loads: the bytes cost more than the instructions save
+        load_u_raw(a1, link_at_shifted(g, k.U, c, MU, 1, NU), Gs);      // U_nu(n+mu)
+        load_m3(a2, link_at_shifted(g, k.U, c, NU, 1, MU), Gs);         // U_mu(n+nu)
+        load_m3(l1, link_at_shifted(g, k.U, m, MU, 1, NU), Gs);         // U_nu(m+mu)
+        load_u_raw(l2, link_at(g, k.U, m, MU), Gs);                     // U_mu(m)
+        load_m3(l3, link_at(g, k.U, m, NU), Gs);                        // U_nu(m)
+#else
         load_u_raw(a1, link_at_shifted(g, k.U, c, MU, 1, NU), Gs);      // U_nu(n+mu)
         load_u_raw(a2, link_at_shifted(g, k.U, c, NU, 1, MU), Gs);      // U_mu(n+nu)
         load_u_raw(l1, link_at_shifted(g, k.U, m, MU, 1, NU), Gs);      // U_nu(m+mu)
         load_u_raw(l2, link_at(g, k.U, m, MU), Gs);                     // U_mu(m)
         load_u_raw(l3, link_at(g, k.U, m, NU), Gs);                     // U_nu(m)
+#endif
 #pragma unroll
         for (int e = 0; e < 9; e++) { const double2 t = own[NU][e][lane]; u3[e] = mk(t.x, t.y); }
 #if LQCD_STAPLE_TWOROW
         // every staple is a product of SU(3) matrices: rows 0, 1 of each product (two thirds of the multiplications), row 2 rebuilt like a link's
-        finish_u(a2);
+        if (!LQCD_STAPLE_ROWS3) finish_u(a2);
         mm2_nd(t1, a1, a2);         // rows 0, 1 of a1 a2^+ need rows 0, 1 of a1 only
         mm2_nd(t2, t1, u3);
         finish_u(t2);
 #pragma unroll
         for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
-        finish_u(l1);
+        if (!LQCD_STAPLE_ROWS3) finish_u(l1);
         mm2(t1, l2, l1);            // Q = l2 l1, rows 0, 1
-        finish_u(t1); finish_u(l3);
+        finish_u(t1);
+        if (!LQCD_STAPLE_ROWS3) finish_u(l3);
         mm2_dn(t2, t1, l3);         // rows 0, 1 of Q^+ l3 = l1^+ l2^+ l3
         finish_u(t2);
 #pragma unroll
@@ -403,9 +437,9 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
         a[0].im -= tr; a[4].im -= tr; a[8].im -= tr;
 #pragma unroll
         for (int e = 0; e < 9; e++) {
-            const cd pv = ld(o + (size_t)e * Gs);
+            const cd pv = EXPU ? ld_stream(o + (size_t)e * Gs) : ld(o + (size_t)e * Gs);
             a[e] = mk(pv.re + a[e].re, pv.im + a[e].im);
-            st(o + (size_t)e * Gs, a[e]);
+            if constexpr (EXPU) st_stream(o + (size_t)e * Gs, a[e]); else st(o + (size_t)e * Gs, a[e]);
         }
         if constexpr (EXPU) {      // the link update that follows this momentum update: exp(dt P_new) U_mu(n) into the second link buffer
             cd ex[9], t[9];
@@ -414,7 +448,7 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
             if (k.reunit) project_if_on_group(t, k.notproj);
             double2* uo = k.uout + glink_off(g, p, MU, i);
 #pragma unroll
-            for (int e = 0; e < 9; e++) st(uo + (size_t)e * Gs, t[e]);
+            for (int e = 0; e < 9; e++) st_stream(uo + (size_t)e * Gs, t[e]);
         }
     }
 }

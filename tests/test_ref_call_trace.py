@@ -45,8 +45,6 @@ def test_golden_files_hold_runs_not_programs():
     assert not os.path.exists(os.path.join(GOLDEN, "ref_call_trace.json"))
     ignore = open(os.path.join(ROOT, ".gpurunignore")).read().split()
     assert "tests/refgen/" in ignore or "tests/refgen" in ignore
-    # and where it has travelled anyway it cannot run: it needs the reference tree
-    assert os.path.isdir(REF) or not os.path.isdir(REFGEN) or True
 
 
 def test_traces_cover_the_callers_of_survey_8a():
