@@ -54,6 +54,7 @@ int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int w
         NCCLCHK(ncclRecv(rb + cnt * esize, n, dt, c->nbr_fwd[mu], c->comm, xs));
     }
     NCCLCHK(ncclGroupEnd());
+    LQCHK(comm_inject_delay(c, xs));
     if (!in_order) HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     return LQCD_OK;
 }
@@ -124,7 +125,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
     ARGCHK(c->local_peers.empty(), "this context belongs to an in-process PE grid: use the lqcd_mdom_* collectives");
     // norm partials: the interior writes |.|^2 of what it produced, the exterior appends the corrections of the sites it updates
     if (c->tun.halo_stream_mode < 0) {
-        // auto: time both schedules once on the first plain full-lattice application (idempotent: it only rewrites `out`).  Every rank
+        // auto: time the five schedules once on the first plain full-lattice application (idempotent: it only rewrites `out`).  Every rank
         // issues the same exchanges whichever schedule it ends up with, so the choice is local.
         if (s.parity_mode != 2 || s.upd_scal || s.upd[0] || s.upd[1]) {
             c->tun.halo_stream_mode = 0;
@@ -132,11 +133,12 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             c->tun.halo_stream_mode = -1;
             return st;
         }
-        float ms[4] = {0.f, 0.f, 0.f, 0.f};
+        constexpr int NM = 5;
+        float ms[NM] = {0.f, 0.f, 0.f, 0.f, 0.f};
         StencilCall t = s;          // the timed applications pack for themselves and leave the fused tails alone
         t.prepacked = 0; t.pack_next = -1; t.red_slot = -1;
         const bool tails = s.pack_next >= 0 || s.red_slot >= 0;
-        for (int mode = 0; mode < 4; mode++) {
+        for (int mode = 0; mode < NM; mode++) {
             c->tun.halo_stream_mode = mode;
             LQCHK(stencil_apply(c, t));
             HIPCHK(hipEventRecord(c->ev_tune0, c->stream));
@@ -145,96 +147,134 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             HIPCHK(hipEventSynchronize(c->ev_tune1));
             HIPCHK(hipEventElapsedTime(&ms[mode], c->ev_tune0, c->ev_tune1));
         }
-        // the choice is collective: every rank adopts the schedule with the smallest time summed over the ranks (one 32-byte all-reduce), so that
+        // the choice is collective: every rank adopts the schedule with the smallest time summed over the ranks (one 40-byte all-reduce), so that
         // no two ranks interleave their sends and receives differently and a slow rank's view counts
         if (c->has_comm) {      // (a one-rank communicator -- self-partition tests -- takes the same path: the all-reduce is then the identity)
             double* d_ms = c->d_scal + SCAL_DOUBLES - 8;      // (the host-value all-reduce's staging doubles)
-            double dms[4] = {ms[0], ms[1], ms[2], ms[3]};
+            double dms[NM];
+            for (int mode = 0; mode < NM; mode++) dms[mode] = ms[mode];
             HIPCHK(hipMemcpyAsync(d_ms, dms, sizeof(dms), hipMemcpyHostToDevice, c->stream));
-            LQCHK(comm_allreduce(c, d_ms, 4));      // on the compute stream
+            LQCHK(comm_allreduce(c, d_ms, NM));      // on the compute stream
             HIPCHK(hipMemcpyAsync(dms, d_ms, sizeof(dms), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            for (int mode = 0; mode < 4; mode++) ms[mode] = (float)dms[mode];
-            for (int mode = 0; mode < 4; mode++) ms[mode] /= (float)c->nranks;
+            for (int mode = 0; mode < NM; mode++) ms[mode] = (float)dms[mode] / (float)c->nranks;
         }
         int best = 0;
-        for (int mode = 1; mode < 4; mode++)
+        for (int mode = 1; mode < NM; mode++)
             if (ms[mode] < ms[best]) best = mode;
         c->tun.halo_stream_mode = best;
-        for (int mode = 0; mode < 4; mode++) c->tun.halo_tuned_us[mode] = (int)(250.f * ms[mode]);
+        for (int mode = 0; mode < NM; mode++) c->tun.halo_tuned_us[mode] = (int)(250.f * ms[mode]);
         if (tails) { t = s; t.prepacked = 0; return stencil_apply(c, t); }      // once more with the caller's tails (the send buffers hold this input's faces)
         return LQCD_OK;      // `out` holds the result of the last tuning application
     }
-    if (c->tun.halo_stream_mode == 1) {
+    const int mode = c->tun.halo_stream_mode;
+    ARGCHK(mode >= 0 && mode <= 4, "halo_stream_mode must be -1 (timed once) or 0..4");
+    auto launch_interior = [&](const StencilCall& q) { return q.prec ? p32::launch_stencil_interior(c, q) : launch_stencil_interior(c, q); };
+    auto launch_pack = [&](const StencilCall& q) { return q.prec ? p32::launch_stencil_pack(c, q) : launch_stencil_pack(c, q); };
+    auto launch_exterior = [&](const StencilCall& q) { return q.prec ? p32::launch_stencil_exterior(c, q) : launch_stencil_exterior(c, q); };
+    auto on_comm_stream = [&](const std::function<int()>& f) {      // the launchers enqueue on c->stream
+        hipStream_t main_stream = c->stream;
+        c->stream = c->comm_stream;
+        const int st = f();
+        c->stream = main_stream;
+        return st;
+    };
+    // ---- folded schedules (halo_fold): the stencil kernel takes the boundary hops from the ghost buffers itself -- no exterior kernel, no norm corrections, complete
+    // |.|^2 partials (stencil_num_partials follows halo_fold_applies).  Schedule 3 (round 5): everything in order on one stream, ONE launch behind the exchange.
+    // Round 6: the same kernel runs on two disjoint sets of chunks -- "bulk" (no site on a partitioned face; needs no ghost) beside the exchange, "boundary" after
+    // arrival -- which gives the overlapping schedules 0-2 the fold (they used to fall back to interior + exterior) and a new schedule 4: pack -> bulk -> exchange step ->
+    // boundary in order on ONE stream.  With the peer-mapped backend the faces travel while the bulk runs (the pack stored them into the neighbour's window; the
+    // exchange step is only the wait), and there is no cross-queue join (~13 us) to pay for the overlap.
+    if (halo_fold_applies(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr) && !s.dot_partial && !s.alpha_partials && s.dw_ls <= 1) {
+        StencilCall all = s, bulk = s, bnd = s;
+        all.fold = 1; bulk.fold = 2; bnd.fold = 3;
+        c->tun.halo_fold_active = 1;
+        if (mode == 3) {
+            if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
+            LQCHK(launch_interior(all));
+        } else if (mode == 4) {
+            if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(launch_interior(bulk));
+            LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
+            LQCHK(launch_interior(bnd));
+        } else if (mode == 0) {          // exchange on the communication stream behind the pack, bulk on the compute stream
+            if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 0));
+            LQCHK(launch_interior(bulk));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+            LQCHK(launch_interior(bnd));
+        } else if (mode == 2) {          // bulk enqueued first; pack -> exchange on the communication stream behind an event
+            HIPCHK(hipEventRecord(c->ev_pack, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+            LQCHK(launch_interior(bulk));
+            if (!s.prepacked) LQCHK(on_comm_stream([&] { return launch_pack(s); }));
+            LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 2));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+            LQCHK(launch_interior(bnd));
+        } else {                         // 1: pack -> exchange -> boundary in order on the compute stream, the bulk beside them on the second stream
+            HIPCHK(hipEventRecord(c->ev_pack, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+            LQCHK(on_comm_stream([&] { return launch_interior(bulk); }));
+            HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
+            if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+            LQCHK(launch_interior(bnd));
+        }
+        // a following application's faces (pack_next: the D p -> D^+ pair of the fused CG) are packed from the finished output by a pack launch
+        if (s.pack_next >= 0) {
+            StencilCall pk = s;
+            pk.in[0] = s.out[0]; pk.in[1] = s.out[1];
+            pk.dagger = s.pack_next;
+            if (s.defer_pack && !s.prec && s.kind == LQCD_WILSON) {      // the caller's reduction of this application's partials is the next launch: the pack rides in it (reduce_pack_to_slot)
+                if (!c->waiting_pack) c->waiting_pack = new StencilCall;
+                *static_cast<StencilCall*>(c->waiting_pack) = pk;
+                c->has_waiting_pack = true;
+            } else LQCHK(launch_pack(pk));
+        }
+        return LQCD_OK;
+    }
+    // ---- interior + exterior schedules (halo_fold = 0, or a call / kernel form without a folded instance)
+    if (mode == 1) {
         // pack -> exchange -> exterior stay in order on the compute stream (no queue hop on the path that carries the messages);
         // the interior runs beside them on the second stream, forked and joined by events
         HIPCHK(hipEventRecord(c->ev_pack, c->stream));                 // the inputs of this call are complete
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
-        {
-            hipStream_t main_stream = c->stream;
-            c->stream = c->comm_stream;                                // the launchers enqueue on c->stream
-            const int st = s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s);
-            c->stream = main_stream;
-            LQCHK(st);
-        }
+        LQCHK(on_comm_stream([&] { return launch_interior(s); }));
         HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
-        if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+        if (!s.prepacked) LQCHK(launch_pack(s));
         LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
-        return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+        return launch_exterior(s);
     }
-    if (c->tun.halo_stream_mode == 3) {
+    if (mode == 3 || mode == 4) {
         // everything in order on the compute stream, no overlap and no cross-queue join: pack -> exchange -> interior -> exterior.  A join costs
         // ~13 us (barrier packets) and the exchange kernel slows the interior it runs beside; at small local volumes with a short exchange that
-        // is more than the overlap hides
-        if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+        // is more than the overlap hides.  (4 without a folded instance: the interior in front of the exchange step.)
+        if (!s.prepacked) LQCHK(launch_pack(s));
+        if (mode == 4) LQCHK(launch_interior(s));
         LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
-        // folded (round 5): the ghosts are complete before the stencil launch starts, so that launch takes the boundary hops from them itself (stencil.hip FOLD
-        // instances) -- no exterior launch, no norm corrections, no exterior partials (stencil_num_partials follows halo_fold_applies).  A following
-        // application's faces (pack_next: the D p -> D^+ pair of the fused CG) are packed from the finished output by a pack launch
-        if (halo_fold_applies(c, s.kind, s.r, s.parity_mode, s.prec, s.clover != nullptr) && !s.dot_partial && !s.alpha_partials && s.dw_ls <= 1) {
-            StencilCall f = s;
-            f.fold = 1;
-            c->tun.halo_fold_active = 1;
-            LQCHK(s.prec ? p32::launch_stencil_interior(c, f) : launch_stencil_interior(c, f));
-            if (s.pack_next >= 0) {
-                StencilCall pk = s;
-                pk.in[0] = s.out[0]; pk.in[1] = s.out[1];
-                pk.dagger = s.pack_next;
-                if (s.defer_pack && !s.prec && s.kind == LQCD_WILSON) {      // the caller's reduction of this application's partials is the next launch: the pack rides in it (reduce_pack_to_slot)
-                    if (!c->waiting_pack) c->waiting_pack = new StencilCall;
-                    *static_cast<StencilCall*>(c->waiting_pack) = pk;
-                    c->has_waiting_pack = true;
-                } else LQCHK(s.prec ? p32::launch_stencil_pack(c, pk) : launch_stencil_pack(c, pk));
-            }
-            return LQCD_OK;
-        }
-        LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
-        return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+        if (mode == 3) LQCHK(launch_interior(s));
+        return launch_exterior(s);
     }
-    if (c->tun.halo_stream_mode == 2) {
+    if (mode == 2) {
         // the interior is enqueued FIRST on the compute stream (the GPU starts it while the host is still busy issuing the RCCL group)
         // and stays in order with the exterior; pack -> exchange run on the second stream behind an event -- the schedule for an
         // exchange that is shorter than the interior: the fork / join latencies hide behind the interior kernel
         HIPCHK(hipEventRecord(c->ev_pack, c->stream));                 // the inputs of this call are complete
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
-        LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
-        {
-            hipStream_t main_stream = c->stream;
-            c->stream = c->comm_stream;
-            const int st = s.prepacked ? LQCD_OK : (s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
-            c->stream = main_stream;
-            LQCHK(st);
-        }
+        LQCHK(launch_interior(s));
+        if (!s.prepacked) LQCHK(on_comm_stream([&] { return launch_pack(s); }));
         LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
-        return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+        return launch_exterior(s);
     }
-    if (!s.prepacked) LQCHK(s.prec ? p32::launch_stencil_pack(c, s) : launch_stencil_pack(c, s));
+    if (!s.prepacked) LQCHK(launch_pack(s));
     LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 0));
-    LQCHK(s.prec ? p32::launch_stencil_interior(c, s) : launch_stencil_interior(c, s));
+    LQCHK(launch_interior(s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
-    return s.prec ? p32::launch_stencil_exterior(c, s) : launch_stencil_exterior(c, s);
+    return launch_exterior(s);
 }
 
 // The halo schedule of a partitioned context is chosen by timing, at the first plain full-lattice application (halo_stream_mode = -1 above), and the choice decides

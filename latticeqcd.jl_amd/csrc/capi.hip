@@ -217,8 +217,16 @@ extern "C" int lqcd_ctx_create(lqcd_ctx_t* out, int device, const int gL[4], con
     }
     // testing aids of the same kind: the halo schedule (0..3, -1 = the collective one-off timing) and the folded form of schedule 3, so that the self-partition tests
     // can pin the schedule they mean to cover without touching their drivers
-    if (const char* e = getenv("LQCD_HALO_STREAM_MODE")) c->tun.halo_stream_mode = atoi(e);
-    if (const char* e = getenv("LQCD_HALO_FOLD")) c->tun.halo_fold = atoi(e);
+    if (const char* e = getenv("LQCD_HALO_STREAM_MODE")) {
+        const int v = atoi(e);
+        if (v < -1 || v > 4) { set_error(std::string("LQCD_HALO_STREAM_MODE=") + e + ": the halo schedule is -1 (timed once) or 0..4"); delete c; return LQCD_ERR_ARG; }
+        c->tun.halo_stream_mode = v;
+    }
+    if (const char* e = getenv("LQCD_HALO_FOLD")) {
+        const int v = atoi(e);
+        if (v != 0 && v != 1) { set_error(std::string("LQCD_HALO_FOLD=") + e + ": 0 or 1"); delete c; return LQCD_ERR_ARG; }
+        c->tun.halo_fold = v;
+    }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -328,6 +336,8 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "halo_tuned_us1")) return &c->tun.halo_tuned_us[1];
     if (!strcmp(key, "halo_tuned_us2")) return &c->tun.halo_tuned_us[2];
     if (!strcmp(key, "halo_tuned_us3")) return &c->tun.halo_tuned_us[3];
+    if (!strcmp(key, "halo_tuned_us4")) return &c->tun.halo_tuned_us[4];
+    if (!strcmp(key, "halo_inject_us")) return &c->tun.halo_inject_us;
     if (!strcmp(key, "halo_merge")) return &c->tun.halo_merge;
     if (!strcmp(key, "recon_active")) return &c->tun.recon_active;
     if (!strcmp(key, "variants_built")) return &c->tun.variants_built;
@@ -366,6 +376,8 @@ extern "C" int lqcd_ctx_set_param(lqcd_ctx_t c, const char* key, int value) {
     int* p = param_ptr(c, key);
     ARGCHK(p, std::string("lqcd_ctx_set_param: unknown key ") + key);
     if (!strcmp(key, "dslash_block")) ARGCHK(value == 64 || value == 128 || value == 256, "dslash_block must be 64, 128 or 256");
+    if (!strcmp(key, "halo_stream_mode")) ARGCHK(value >= -1 && value <= 4, "halo_stream_mode must be -1 (timed once) or 0..4");
+    if (!strcmp(key, "halo_inject_us")) ARGCHK(value >= 0 && value <= 100000, "halo_inject_us: 0..100000");
     if ((!strcmp(key, "lazy_links") || !strcmp(key, "lazy_merge")) && !value) LQCHK(links_flush_of(c));      // switching to eager calls: what is recorded runs now
     *p = value;
     return LQCD_OK;

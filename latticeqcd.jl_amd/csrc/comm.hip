@@ -95,6 +95,19 @@ __global__ __launch_bounds__(64) void peer_allreduce_kernel(PeerRedArgs a, doubl
 }
 __global__ void peer_scalar_step_kernel(double* s, int op) { cg_scalar_step(s, op); }
 
+// TEST AID (tunable halo_inject_us): one wave that spins for `ticks` of the 100 MHz clock -- launched behind a face exchange on its stream, it makes the exchange
+// complete that much later, the way a transfer over a real link would
+__global__ __launch_bounds__(64) void comm_delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int comm_inject_delay(lqcd_ctx_s* c, hipStream_t s) {
+    if (c->tun.halo_inject_us <= 0) return LQCD_OK;
+    hipLaunchKernelGGL(comm_delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)c->tun.halo_inject_us * 100ull);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
 __global__ __launch_bounds__(256) void peer_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -169,6 +182,7 @@ static int halo_exchange_peer(lqcd_ctx_s* c, int where) {
     }
     hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, xs, halo_sync_args(c));
     HIPCHK(hipGetLastError());
+    LQCHK(comm_inject_delay(c, xs));
     if (!in_order) HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     return LQCD_OK;
 }

@@ -472,13 +472,17 @@ struct Tunables {
                                // (no queue hop on the message path; pays when the exchange is the longer leg);
                                // 2 = interior enqueued first on the compute stream and in order with the exterior, pack -> exchange on the
                                // second stream (pays when the interior is the longer leg); 3 = everything in order on the compute stream (no overlap, no
-                               // ~13 us cross-queue join: pays when the exchange is short); -1 = time all four once, collectively
-    int halo_tuned_us[4] = {0, 0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
+                               // ~13 us cross-queue join: pays when the exchange is short); 4 (round 6) = one stream, the bulk of the folded stencil launch
+                               // in FRONT of the exchange step and its boundary chunks behind it (peer-mapped backend: the faces fly while the bulk runs);
+                               // -1 = time all five once, collectively
+    int halo_tuned_us[5] = {0, 0, 0, 0, 0};   // per-application times the auto choice was made from (0: not tuned yet)
+    int halo_inject_us = 0;    // TEST AID: every face exchange completes this many microseconds late (a timed one-wave spin behind the exchange on its stream) -- stands in for
+                               // the flight time of real links on the one-GPU proxy, so that the schedules' crossover can be measured (profiles/r06_schedule_latency_table.log)
     int staggered_parity_solve = 1;  // lqcd_fermi_action / lqcd_calc_UdSfdU: a staggered pseudofermion with a zero odd half is solved with
                                      // the half-lattice CG of lqcd_solve_cg_DdagD_parity (0: always the full-lattice CG)
-    int halo_fold = 1;        // halo schedule 3 (everything in order on one stream): the stencil launch reads the ghost buffers itself (the exchange is complete before it
-                              // starts) -- no exterior launch, no norm corrections; scalar-addressing Wilson kernel: its FOLD instances, everything else: the folded twins of
-                              // the direction-split kernels (stencil.hip halo_fold_applies); 0: the separate exterior kernel
+    int halo_fold = 1;        // the stencil launch reads the ghost buffers itself -- no exterior launch, no norm corrections; scalar-addressing Wilson kernel: its FOLD
+                              // instances, everything else: the folded twins of the direction-split kernels (stencil.hip halo_fold_applies).  Schedule 3: one launch behind
+                              // the exchange; schedules 0-2, 4 (round 6): a bulk launch beside / in front of the exchange + a boundary launch behind it.  0: interior + exterior kernels
     int halo_fold_active = 0; // read-only: the last partitioned stencil application ran folded (no exterior launch)
     int halo_fuse = 2;        // partitioned fused CG (Wilson, fp64): bit 0 = the exterior's last block does the final reduction (no reduce_final launch),
                               // bit 1 = the exterior of D p packs the faces D^+ needs and the x/p update packs the new p (no pack launches).
@@ -889,6 +893,7 @@ int comm_sendrecv(lqcd_ctx_s* c, const CommXfer* x, int n, hipStream_t stream, b
 int comm_allreduce(lqcd_ctx_s* c, double* d_inout, int n, int cg_op = 0);        // in place on device doubles, on the compute stream; cg_op: the CG scalar step behind it (peer: same launch)
 int comm_halo_exchange(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);     // the stencil's face exchange (where: see apply.hip)
 PeerRedArgs comm_red_args(lqcd_ctx_s* c);       // peer backend: the argument block of the NEXT reduction (counts it); otherwise nranks = 0
+int comm_inject_delay(lqcd_ctx_s* c, hipStream_t s);      // test aid: tunable halo_inject_us
 int comm_check(lqcd_ctx_s* c);                  // peer backend: LQCD_ERR_COMM if a wait gave up since the last check (call behind a stream synchronisation)
 void comm_teardown(lqcd_ctx_s* c);              // peer backend: unmap / free the windows (lqcd_ctx_destroy)
 // where this context's producers store the faces of the next exchange / its consumers find the ghosts of the last one (bases of [fwd | bwd], [from bwd | from fwd])
@@ -944,8 +949,9 @@ struct StencilCall {
                                   // inverse clover blocks of the even-odd Wilson-clover solver; the diagonal term stays plain
     int defer_pack = 0;           // folded schedule, pack_next >= 0: the caller sums this application's |.|^2 partials next (reduce_pack_to_slot) -- the pack launch for the
                                   // following application waits in the context and runs as ONE launch with that reduction
-    int fold = 0;                 // set by stencil_apply (folded one-stream halo schedule): the exchange is complete when the interior launch starts and that launch takes
-                                  // the boundary hops from the ghost buffers itself -- no exterior launch, the |.|^2 partials of the interior are complete
+    int fold = 0;                 // set by stencil_apply (folded halo schedules): 1 = the exchange is complete when the launch starts and it takes the boundary hops from the
+                                  // ghost buffers itself -- no exterior launch, complete |.|^2 partials; 2 / 3 (round 6, overlapping schedules) = the same kernel on the
+                                  // chunks WITHOUT / WITH a site on a partitioned face: "bulk" runs beside the exchange, "boundary" after arrival
 };
 // stencil.hip, once per precision (p64 is the inline namespace everywhere except in the fp32 build of stencil.hip).
 // With prec = 1 the field pointers of a StencilCall address float2 data (cast), scalars stay double.

@@ -173,6 +173,22 @@ __device__ inline void clover_rows(cd (&out)[3], const real2* __restrict__ a, co
 // CINV (even-odd Wilson-clover solver): the packed matrix k.clover (the INVERSE clover blocks of the output parity) is applied to the HOP SUM,
 // out = a xin + b C (H in), where CLOV applies it to the diagonal term -- the Schur operator 1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe becomes two launches
 // with no intermediate field (every wave rebuilds the 12 summed components from the four direction partials: 48 LDS reads instead of 12).
+// folded twins, bulk / boundary launches (KArgs::fsel): does this workgroup's chunk sit out this launch?  Every wave of the workgroup holds the same 64 sites, so
+// the ballot is the same in all of them (no LDS, no barrier).  A chunk with a site on a partitioned face is a boundary chunk.
+__device__ __forceinline__ bool fold_chunk_skipped(const KArgs& k, int chunk, int p) {
+    if (!k.fsel) return false;
+    const int i = chunk * 64 + (int)(threadIdx.x & 63);
+    bool b = false;
+    if (i < k.g.Vh) {
+        int c[4];
+        cb_to_coords(k.g, p, i, c);
+#pragma unroll
+        for (int mu = 0; mu < 4; mu++) b = b || (k.g.part[mu] && (c[mu] == 0 || c[mu] == k.g.L[mu] - 1));
+    }
+    const bool bnd = __any(b);
+    return (k.fsel == 1) == bnd;
+}
+
 template <bool DAG, bool R12, bool CLOV, bool DOT, bool CINV, bool FOLD>
 __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs* hf) {
     __shared__ real2 part[4][12][64];  // 48 KiB
@@ -181,6 +197,7 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
     const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
+    if constexpr (FOLD) { if (fold_chunk_skipped(k, chunk, p)) return; }
     const int Vh = sp_stride(k.g);  // spinor component stride in elements
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -363,6 +380,7 @@ struct PipeArgs {
     // FOLD instance (partitioned lattice, one-stream schedule: the exchange is complete when the kernel starts): the hops that leave the rank are taken
     // from the ghost buffers by the SAME launch -- no exterior kernel, complete |.|^2 partials.  Bit mu of fold: direction mu (1, 2, 3) is partitioned.
     int fold;
+    int fsel;                 // 0: every chunk; 1: bulk chunks only (no site on a partitioned face), 2: boundary chunks only (KArgs::fsel)
     const real2* gh_f[4];     // ghost of the forward hop at the upper face: P psi(n + mu) packed by the +mu neighbour ([slot][6][Fh], HArgs::recv_fwd)
     const real2* gh_b[4];     // ghost of the backward hop at the lower face: U^+ P psi(n - mu) from the -mu neighbour (HArgs::recv_bwd)
     int Fh[4];                // sites of a face per parity
@@ -956,6 +974,16 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
             al_upd = (real)al;
         } else al_upd = (real)a.upd_scal[S_ALPHA];
     }
+    if constexpr (FOLD) {
+        if (a.fsel) {      // bulk / boundary launch of an overlapping schedule: t, z and the y rows of a chunk are workgroup-uniform
+            int p_, t, z, yc;
+            pipe_map(a, (int)blockIdx.x, p_, t, z, yc);
+            const int y0 = fdiv(yc * 64, a.dXH), y1 = fdiv(yc * 64 + 63, a.dXH);
+            const bool bnd = (((a.fold >> 3) & 1) && (t == 0 || t == a.LT - 1)) || (((a.fold >> 2) & 1) && (z == 0 || z == a.L2 - 1)) ||
+                             (((a.fold >> 1) & 1) && (y0 == 0 || y1 == a.L1 - 1));
+            if ((a.fsel == 1) == bnd) return;
+        }
+    }
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     real nrm = 0.0, dre = 0.0, dim = 0.0;
@@ -1058,6 +1086,7 @@ __device__ __forceinline__ void staggered_dirsplit_body(const KArgs& k, const HA
     const real al_upd = update_alpha(k);
     int chunk, p;
     map_block(k, chunk, p);
+    if constexpr (FOLD) { if (fold_chunk_skipped(k, chunk, p)) return; }
     const int Vh = sp_stride(k.g);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1578,6 +1607,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.skip = s.skip_flag;
     k.alpha_partials = s.alpha_partials; k.alpha_n = s.alpha_n; k.scal_w = s.scal_w;
     k.dotz[0] = (const real2*)s.dot_z[0]; k.dotz[1] = (const real2*)s.dot_z[1]; k.dot_partial = s.dot_partial; k.dot_conj = s.dot_conj;
+    k.fsel = s.fold >= 2 ? s.fold - 1 : 0;
     return k;
 }
 
@@ -1630,6 +1660,7 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     a.d_perpass = k.d_perpass; a.d_cpr = k.d_cpr; a.d_ysplit = k.d_ysplit; a.d_ty = k.d_ty; a.d_cpp = make_fastdiv(std::max(1, k.cpp));
     a.ls = s.dw_ls; a.slice_bytes = (unsigned long long)s.dw_slice * sizeof(real2); a.d_ls = make_fastdiv(std::max(1, s.dw_ls)); a.dw_mass = (real)s.dw_mass;
     a.fold = 0;
+    a.fsel = s.fold >= 2 ? s.fold - 1 : 0;
     for (int mu = 0; mu < 4; mu++) {
         // ghost buffers of this call's message size: [recv_bwd | recv_fwd] back to back (make_hargs' rule)
         const size_t cnt = (size_t)(s.parity_mode == 2 ? 2 : 1) * 6 * face_half_sites(c->geom, mu);
@@ -1941,7 +1972,7 @@ bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, boo
 // build.  The scalar-addressing Wilson kernel has its own FOLD instances (fp64, x unpartitioned, no clover term); everything else takes the folded twins of the
 // direction-split kernels (wilson_dirsplit_fold / staggered_dirsplit_fold: the exterior kernel's arithmetic inside the direction waves).
 bool halo_fold_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover) {
-    if (!c->tun.halo_fold || c->tun.halo_stream_mode != 3) return false;
+    if (!c->tun.halo_fold) return false;      // (every schedule has a folded form since round 6)
     if (!any_partitioned(c) || !c->has_comm || !c->local_peers.empty()) return false;
     if ((kind != LQCD_WILSON && kind != LQCD_STAGGERED) || (prec != 0 && prec != 1)) return false;
     // the direction-split kernels with one workgroup per chunk (default and scalar-addressing form): every instance has a folded twin.  Not the persistent forms

@@ -41,6 +41,8 @@ struct KArgs {
     const real2* dotz[2];     // dot mode (StencilCall::dot_z): Re / Im <z, out> and |out|^2 per workgroup -> dot_partial[3 b ..]; dot_conj: <out, z> instead
     double* dot_partial;
     int dot_conj;
+    int fsel;                 // folded launches (round 6, overlapping schedules): 0 every chunk, 1 only the chunks with no site on a partitioned face ("bulk": runs
+                              // beside the exchange), 2 only the others ("boundary": after arrival) -- the two launches write disjoint sites and disjoint |.|^2 partials
 };
 
 typedef real v2d __attribute__((ext_vector_type(2)));

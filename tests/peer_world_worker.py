@@ -35,7 +35,7 @@ def main():
     gL = tuple(int(v) for v in os.environ["PEER_TEST_LATTICE"].split(","))
     pe = tuple(int(v) for v in os.environ["PEER_TEST_PE"].split(","))
     kinds = os.environ.get("PEER_TEST_KINDS", "Wilson,Staggered,WilsonClover").split(",")
-    sched = os.environ.get("PEER_TEST_SCHEDULES", "3,0,1,2,-1").split(",")
+    sched = os.environ.get("PEER_TEST_SCHEDULES", "3,4,0,1,2,-1").split(",")
     assert int(np.prod(pe)) == world
     lat = lq.Lattice(gL, pe, rank, device=0)            # every rank on the ONE device
     lat.set_param("peer_timeout_ms", 20000)

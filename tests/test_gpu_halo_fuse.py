@@ -1,5 +1,6 @@
-"""Partitioned fused CG with the folded halo schedule (round 5, tunable halo_fold: schedule 3 with the boundary hops taken from the ghost buffers inside the
-stencil launch, no exterior kernel) and the fused tails of the exterior / update launches (tunable halo_fuse): bit 0 = the
+"""Partitioned fused CG with the folded halo schedules (tunable halo_fold: the boundary hops are taken from the ghost buffers inside the stencil launch, no
+exterior kernel -- round 5: schedule 3, one launch behind the exchange; round 6: every schedule, as a bulk launch beside / in front of the exchange and a boundary
+launch behind it, incl. the new one-stream schedule 4 and an exchange that completes late, halo_inject_us) and the fused tails of the exterior / update launches (tunable halo_fuse): bit 0 = the
 exterior kernel's last block sums the |.|^2 partials (no reduce_final launch), bit 1 = the exterior of D p packs the faces D^+ needs and the
 x/p update packs the new search direction (no pack launches).  Run through the real RCCL path on one GPU (self-partition, world-size-1
 communicators).  Pre-packed faces carry the bits a pack launch would have produced, so bit 1 alone must not change a single bit of the
@@ -32,9 +33,10 @@ CODE = textwrap.dedent("""
     sols = {}
     folded = 0
     y = x.similar()
-    for mode in (-1, 0, 1, 2, 3):
-      for hfold in ((1, 0) if mode in (-1, 3) else (0,)):          # halo_fold acts on schedule 3 (which the tuner, mode -1, may pick)
+    for mode in (-1, 0, 1, 2, 3, 4):
+      for hfold in (1, 0):
         lat.set_param("halo_fold", hfold)
+        lat.set_param("halo_inject_us", 30 if (mode in (0, 4) and hfold) else 0)      # an exchange that completes late (the stand-in for real links) changes nothing but the time
         for fold in (1, 0):
             for fuse in (0, 1, 2, 3):
                 lat.set_param("halo_stream_mode", mode); lat.set_param("cg_fold_scalars", fold); lat.set_param("halo_fuse", fuse)
@@ -45,7 +47,7 @@ CODE = textwrap.dedent("""
                 err = np.abs(s - xo).max() / np.abs(xo).max()
                 assert abs(it - ito) <= 1 and rr < 1e-19 and err < 1e-9, (mode, hfold, fold, fuse, it, ito, rr, err)
                 sols[(mode, hfold, fold, fuse)] = s
-            if mode == -1 and hfold:      # the tuner may pick the folded schedule for one solve and another for the next: equal to rounding only
+            if mode == -1:      # the tuner may pick one schedule for one solve and another for the next: equal to rounding only
                 continue
             assert np.array_equal(sols[(mode, hfold, fold, 0)], sols[(mode, hfold, fold, 2)]), ("pre-packed faces changed the solution", mode, hfold, fold)
             assert np.array_equal(sols[(mode, hfold, fold, 1)], sols[(mode, hfold, fold, 3)]), ("pre-packed faces changed the solution", mode, hfold, fold)
@@ -56,24 +58,23 @@ CODE = textwrap.dedent("""
             ref = orc.apply_D(lq.WILSON, U, psi, L, K, 1.0, BC, dag)
             e = np.abs(y.download() - ref).max() / np.abs(ref).max()
             assert e < 1e-13, (mode, hfold, dag, e)
-        if mode == 3 and hfold and FOLDS:
-            assert lat.get_param("halo_fold_active") == 1, "the folded schedule did not run where it applies"
+        assert lat.get_param("halo_fold_active") == (1 if hfold and FOLDS else 0), ("the folded launches did not run where they apply", mode, hfold)
     assert (folded > 0) == bool(FOLDS), (folded, FOLDS)
-    lat.set_param("halo_fold", 1)
-    # the staggered operator: the fused reduction only (unfolded schedules), and the folded twin of its direction-split kernel (schedule 3)
+    lat.set_param("halo_fold", 1); lat.set_param("halo_inject_us", 0)
+    # the staggered operator: the fused reduction only (unfolded schedules), and the folded twin of its direction-split kernel (every schedule)
     Ds = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Staggered", "mass": 0.5, "boundarycondition": BC, "eps_CG": 1e-19})
     ps = orc.gaussian_spinor(lat.fermion_shape(lq.STAGGERED), 113)
     xs = lq.Fermionfields(lat, lq.STAGGERED).upload(ps)
     ys = xs.similar()
     xo, ito, rro, st = orc.cg_DdagD(orc.STAGGERED, U, ps, L, 0.5, 1.0, BC, eps=1e-19)
-    for mode, hfold in ((0, 1), (3, 0), (3, 1)):
+    for mode, hfold in ((0, 1), (3, 0), (3, 1), (4, 1), (1, 1), (2, 1), (2, 0)):
         lat.set_param("halo_stream_mode", mode); lat.set_param("halo_fold", hfold)
         for dag in (False, True):
             lq.mul_(ys, Ds.adjoint() if dag else Ds, xs)
             ref = orc.apply_D(lq.STAGGERED, U, ps, L, 0.5, 1.0, BC, dag)
             e = np.abs(ys.download() - ref).max() / np.abs(ref).max()
             assert e < 1e-13, ("staggered", mode, hfold, dag, e)
-        assert lat.get_param("halo_fold_active") == (1 if mode == 3 and hfold else 0)
+        assert lat.get_param("halo_fold_active") == (1 if hfold else 0)
         for fuse in (0, 3):
             lat.set_param("halo_fuse", fuse)
             sol = xs.similar()

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _port = [29640]
 
 
-def run_world(n, lattice, pe, kinds="Wilson,Staggered,WilsonClover", schedules="3,0,1,2,-1", timeout=420, extra_env=None):
+def run_world(n, lattice, pe, kinds="Wilson,Staggered,WilsonClover", schedules="3,4,0,1,2,-1", timeout=420, extra_env=None):
     _port[0] += 1
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port[0]), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
                PEER_TEST_LATTICE=",".join(map(str, lattice)), PEER_TEST_PE=",".join(map(str, pe)), PEER_TEST_KINDS=kinds, PEER_TEST_SCHEDULES=schedules)
@@ -43,12 +43,12 @@ def test_two_processes_one_gpu_equal_the_oracle(gpu, orc, pe):
 
 def test_two_processes_x_partitioned(gpu, orc):
     """x (the contiguous axis) partitioned: the per-lane ghost selects of the folded twins."""
-    run_world(2, (16, 4, 4, 8), (2, 1, 1, 1), kinds="Wilson,Staggered", schedules="3,0")
+    run_world(2, (16, 4, 4, 8), (2, 1, 1, 1), kinds="Wilson,Staggered", schedules="3,4,0")
 
 
 def test_four_processes_one_gpu(gpu, orc):
     """(1,1,2,2): two partitioned directions, four ranks, every rank has two distinct neighbours."""
-    run_world(4, (8, 8, 8, 16), (1, 1, 2, 2), kinds="Wilson,Staggered", schedules="3,-1", timeout=600)
+    run_world(4, (8, 8, 8, 16), (1, 1, 2, 2), kinds="Wilson,Staggered", schedules="3,4,-1", timeout=600)
 
 
 def test_two_processes_coarse_grained_window(gpu, orc):
