@@ -191,15 +191,18 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         c->tun.halo_fold_active = 1;
         if (mode == 3) {
             if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(comm_inject_stamp(c, c->stream));
             LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
             LQCHK(launch_interior(all));
         } else if (mode == 4) {
             if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(comm_inject_stamp(c, c->stream));
             LQCHK(launch_interior(bulk));
             LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
             LQCHK(launch_interior(bnd));
         } else if (mode == 0) {          // exchange on the communication stream behind the pack, bulk on the compute stream
             if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(comm_inject_stamp(c, c->stream));
             LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 0));
             LQCHK(launch_interior(bulk));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
@@ -209,6 +212,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
             LQCHK(launch_interior(bulk));
             if (!s.prepacked) LQCHK(on_comm_stream([&] { return launch_pack(s); }));
+            LQCHK(comm_inject_stamp(c, c->comm_stream));
             LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 2));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
             LQCHK(launch_interior(bnd));
@@ -218,6 +222,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
             LQCHK(on_comm_stream([&] { return launch_interior(bulk); }));
             HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
             if (!s.prepacked) LQCHK(launch_pack(s));
+            LQCHK(comm_inject_stamp(c, c->stream));
             LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
             LQCHK(launch_interior(bnd));
@@ -244,6 +249,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         LQCHK(on_comm_stream([&] { return launch_interior(s); }));
         HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
         if (!s.prepacked) LQCHK(launch_pack(s));
+        LQCHK(comm_inject_stamp(c, c->stream));
         LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return launch_exterior(s);
@@ -253,6 +259,7 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         // ~13 us (barrier packets) and the exchange kernel slows the interior it runs beside; at small local volumes with a short exchange that
         // is more than the overlap hides.  (4 without a folded instance: the interior in front of the exchange step.)
         if (!s.prepacked) LQCHK(launch_pack(s));
+        LQCHK(comm_inject_stamp(c, c->stream));
         if (mode == 4) LQCHK(launch_interior(s));
         LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 1));
         if (mode == 3) LQCHK(launch_interior(s));
@@ -266,11 +273,13 @@ int stencil_apply(lqcd_ctx_s* c, const StencilCall& s) {
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
         LQCHK(launch_interior(s));
         if (!s.prepacked) LQCHK(on_comm_stream([&] { return launch_pack(s); }));
+        LQCHK(comm_inject_stamp(c, c->comm_stream));
         LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         return launch_exterior(s);
     }
     if (!s.prepacked) LQCHK(launch_pack(s));
+    LQCHK(comm_inject_stamp(c, c->stream));
     LQCHK(comm_halo_exchange(c, s.kind, s.parity_mode, s.prec, 0));
     LQCHK(launch_interior(s));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));

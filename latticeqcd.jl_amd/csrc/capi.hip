@@ -282,6 +282,7 @@ extern "C" int lqcd_ctx_destroy(lqcd_ctx_t c) {
     (void)hipFree(c->clover_ext); (void)hipFree(c->clover_ext_buf[0]); (void)hipFree(c->clover_ext_buf[1]);
     if (c->has_comm && !c->peer.on) { ncclCommDestroy(c->comm); ncclCommDestroy(c->comm_red); }
     comm_teardown(c);      // the peer-mapped backend's windows (comm.hip)
+    for (lqcd::FoldLists& f : c->fold_lists) { (void)hipFree(f.d_list[0]); (void)hipFree(f.d_list[1]); }
     delete static_cast<lqcd::StencilCall*>(c->waiting_pack);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_scal); (void)hipFree(c->pipe_ctr); (void)hipFree(c->cgp_ctr); (void)hipHostFree(c->h_scal);
     (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1);

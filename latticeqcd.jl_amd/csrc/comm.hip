@@ -95,15 +95,24 @@ __global__ __launch_bounds__(64) void peer_allreduce_kernel(PeerRedArgs a, doubl
 }
 __global__ void peer_scalar_step_kernel(double* s, int op) { cg_scalar_step(s, op); }
 
-// TEST AID (tunable halo_inject_us): one wave that spins for `ticks` of the 100 MHz clock -- launched behind a face exchange on its stream, it makes the exchange
-// complete that much later, the way a transfer over a real link would
-__global__ __launch_bounds__(64) void comm_delay_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+// TEST AID (tunable halo_inject_us): the faces of an exchange "arrive" that many microseconds after they were sent -- the way a transfer over a real link would,
+// on the one-GPU proxy.  comm_inject_stamp (behind the producer of the faces, in stream order) records the time of the send; comm_inject_delay (behind the exchange
+// step, on its stream) is one wave that spins until stamp + delay.  A schedule that puts work between the two hides the flight time; one that does not, pays it.
+__global__ void comm_stamp_kernel(unsigned long long* stamp) { *stamp = wall_clock64(); }
+__global__ __launch_bounds__(64) void comm_delay_kernel(const unsigned long long* stamp, unsigned long long ticks) {
+    const unsigned long long t0 = *stamp;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
+static unsigned long long* inject_word(lqcd_ctx_s* c) { return (unsigned long long*)(c->pipe_ctr + 9 * 32); }      // a line of its own in the context's counter block
+int comm_inject_stamp(lqcd_ctx_s* c, hipStream_t s) {
+    if (c->tun.halo_inject_us <= 0) return LQCD_OK;
+    hipLaunchKernelGGL(comm_stamp_kernel, dim3(1), dim3(1), 0, s, inject_word(c));
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
 }
 int comm_inject_delay(lqcd_ctx_s* c, hipStream_t s) {
     if (c->tun.halo_inject_us <= 0) return LQCD_OK;
-    hipLaunchKernelGGL(comm_delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)c->tun.halo_inject_us * 100ull);
+    hipLaunchKernelGGL(comm_delay_kernel, dim3(1), dim3(64), 0, s, inject_word(c), (unsigned long long)c->tun.halo_inject_us * 100ull);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }

@@ -626,6 +626,12 @@ struct PeerComm {
     unsigned* status = nullptr;     // pinned host words, written by a wait that gave up: [0] what (1 halo, 2 reduction, 3 mailbox data, 4 mailbox ack), [1] index, [2..3] the number awaited
     int timeout_ms = 60000;
 };
+// bulk / boundary lists of the folded stencil launches (stencil.hip fold_lists_get): virtual blocks in the order of the workgroup map, kept per context
+struct FoldLists {
+    int family, parity_mode, nvirt, mask, remap, nsub, ysplit;      // what the lists were made for (family 0: scalar-addressing kernel, 1: the folded twins)
+    int* d_list[2];                                                 // 0: bulk (no site on a partitioned face), 1: boundary
+    int n[2];
+};
 // argument block of an exchange step: flag words to raise / to wait for (peer_signal_wait_wave below); nsig == nwt == 0: nothing to do
 struct PeerSyncArgs {
     unsigned long long* sig[PEER_MAX_RANKS];     // flag words in the neighbours' windows that this rank raises
@@ -773,6 +779,7 @@ struct lqcd_ctx_s {
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
     bool has_comm = false;
     lqcd::PeerComm peer;            // the peer-mapped backend (comm.hip); peer.on: it, not RCCL, carries this context's exchanges
+    std::vector<lqcd::FoldLists> fold_lists;      // bulk / boundary block lists of the folded launches (stencil.hip)
     std::vector<lqcd_ctx_s*> local_peers;  // in-process emulation of the PE grid
     // scratch spinors owned by the context (Temporalfields analogue)
     std::vector<lqcd_spinor_s*> scratch;
@@ -893,7 +900,8 @@ int comm_sendrecv(lqcd_ctx_s* c, const CommXfer* x, int n, hipStream_t stream, b
 int comm_allreduce(lqcd_ctx_s* c, double* d_inout, int n, int cg_op = 0);        // in place on device doubles, on the compute stream; cg_op: the CG scalar step behind it (peer: same launch)
 int comm_halo_exchange(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);     // the stencil's face exchange (where: see apply.hip)
 PeerRedArgs comm_red_args(lqcd_ctx_s* c);       // peer backend: the argument block of the NEXT reduction (counts it); otherwise nranks = 0
-int comm_inject_delay(lqcd_ctx_s* c, hipStream_t s);      // test aid: tunable halo_inject_us
+int comm_inject_stamp(lqcd_ctx_s* c, hipStream_t s);      // test aid (tunable halo_inject_us): the faces are sent HERE in stream order ...
+int comm_inject_delay(lqcd_ctx_s* c, hipStream_t s);      // ... and arrive halo_inject_us later
 int comm_check(lqcd_ctx_s* c);                  // peer backend: LQCD_ERR_COMM if a wait gave up since the last check (call behind a stream synchronisation)
 void comm_teardown(lqcd_ctx_s* c);              // peer backend: unmap / free the windows (lqcd_ctx_destroy)
 // where this context's producers store the faces of the next exchange / its consumers find the ghosts of the last one (bases of [fwd | bwd], [from bwd | from fwd])

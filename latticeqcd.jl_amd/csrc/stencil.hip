@@ -306,7 +306,7 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
         if (lane == 0) red[w] = nrm;
         __syncthreads();
-        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) k.norm_partial[vblock_of(k)] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -381,6 +381,7 @@ struct PipeArgs {
     // from the ghost buffers by the SAME launch -- no exterior kernel, complete |.|^2 partials.  Bit mu of fold: direction mu (1, 2, 3) is partitioned.
     int fold;
     int fsel;                 // 0: every chunk; 1: bulk chunks only (no site on a partitioned face), 2: boundary chunks only (KArgs::fsel)
+    const int* vlist;         // fsel launches: virtual block of workgroup b (KArgs::vlist); null: b itself
     const real2* gh_f[4];     // ghost of the forward hop at the upper face: P psi(n + mu) packed by the +mu neighbour ([slot][6][Fh], HArgs::recv_fwd)
     const real2* gh_b[4];     // ghost of the backward hop at the lower face: U^+ P psi(n - mu) from the -mu neighbour (HArgs::recv_bwd)
     int Fh[4];                // sites of a face per parity
@@ -754,10 +755,10 @@ __device__ inline void fold_unit_link(cd (&u)[9], bool face) {      // (called w
 }
 
 template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false>
-__device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim) {
+__device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim, int vb) {
     // DW5: this workgroup's slice s5 of the five-dimensional fields; block ids keep their XCD (b & 7) and the L5 slices of a chunk follow each other on it, so the
     // links of the chunk are fetched from the fabric once and hit the XCD's L2 for the other slices
-    int vblock = (int)blockIdx.x, s5 = 0;
+    int vblock = vb, s5 = 0;      // (vb: blockIdx.x, or the entry of the bulk / boundary list of a folded launch)
     if constexpr (DW5) {
         const int g8 = (int)(blockIdx.x >> 3), gq = fdiv_nb(g8, a_.d_ls);
         s5 = g8 - gq * a_.ls;
@@ -974,10 +975,13 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
             al_upd = (real)al;
         } else al_upd = (real)a.upd_scal[S_ALPHA];
     }
+    int vb = (int)blockIdx.x;
     if constexpr (FOLD) {
-        if (a.fsel) {      // bulk / boundary launch of an overlapping schedule: t, z and the y rows of a chunk are workgroup-uniform
+        if (a.vlist) vb = a.vlist[blockIdx.x];
+        if (a.fsel) {      // bulk / boundary launch of an overlapping schedule: t, z and the y rows of a chunk are workgroup-uniform.  (The launch covers the chunks of its
+                           // kind only -- vlist, built by fold_classify_s with this very arithmetic; the test stays as the authority)
             int p_, t, z, yc;
-            pipe_map(a, (int)blockIdx.x, p_, t, z, yc);
+            pipe_map(a, vb, p_, t, z, yc);
             const int y0 = fdiv(yc * 64, a.dXH), y1 = fdiv(yc * 64 + 63, a.dXH);
             const bool bnd = (((a.fold >> 3) & 1) && (t == 0 || t == a.LT - 1)) || (((a.fold >> 2) & 1) && (z == 0 || z == a.L2 - 1)) ||
                              (((a.fold >> 1) & 1) && (y0 == 0 || y1 == a.L1 - 1));
@@ -988,10 +992,10 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     const int lane = threadIdx.x & 63;
     real nrm = 0.0, dre = 0.0, dim = 0.0;
     switch (w) {
-    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
-    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
+    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
+    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
+    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
     }
     if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue
         double t3[3] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm};
@@ -1010,7 +1014,7 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
         if (lane == 0) red[w] = nrm;
         __syncthreads();
-        if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) a.norm_partial[vb] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -1172,7 +1176,7 @@ __device__ __forceinline__ void staggered_dirsplit_body(const KArgs& k, const HA
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
         if (lane == 0) red[w] = nrm;
         __syncthreads();
-        if (threadIdx.x == 0) k.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) k.norm_partial[vblock_of(k)] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -1608,6 +1612,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.alpha_partials = s.alpha_partials; k.alpha_n = s.alpha_n; k.scal_w = s.scal_w;
     k.dotz[0] = (const real2*)s.dot_z[0]; k.dotz[1] = (const real2*)s.dot_z[1]; k.dot_partial = s.dot_partial; k.dot_conj = s.dot_conj;
     k.fsel = s.fold >= 2 ? s.fold - 1 : 0;
+    k.vlist = nullptr;
     return k;
 }
 
@@ -1661,6 +1666,7 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     a.ls = s.dw_ls; a.slice_bytes = (unsigned long long)s.dw_slice * sizeof(real2); a.d_ls = make_fastdiv(std::max(1, s.dw_ls)); a.dw_mass = (real)s.dw_mass;
     a.fold = 0;
     a.fsel = s.fold >= 2 ? s.fold - 1 : 0;
+    a.vlist = nullptr;
     for (int mu = 0; mu < 4; mu++) {
         // ghost buffers of this call's message size: [recv_bwd | recv_fwd] back to back (make_hargs' rule)
         const size_t cnt = (size_t)(s.parity_mode == 2 ? 2 : 1) * 6 * face_half_sites(c->geom, mu);
@@ -1675,14 +1681,77 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
 
 static HArgs make_hargs(lqcd_ctx_s* c, const StencilCall& s);
 
+// ---- bulk / boundary lists of the folded launches.  Which chunks have a site on a partitioned face is decided ON THE DEVICE, by the arithmetic the kernels use
+// themselves (pipe_map of the scalar-addressing kernel; map_block_v + the ballot of fold_chunk_skipped for the twins), once per (kernel family, parity mode, map);
+// the host only compacts the flags in the order of the map and keeps the two lists in the context.
+__global__ void fold_classify_s(PipeArgs a, int n, unsigned char* bnd) {
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= n) return;
+    int p_, t, z, yc;
+    pipe_map(a, b, p_, t, z, yc);
+    const int y0 = fdiv(yc * 64, a.dXH), y1 = fdiv(yc * 64 + 63, a.dXH);
+    bnd[b] = ((((a.fold >> 3) & 1) && (t == 0 || t == a.LT - 1)) || (((a.fold >> 2) & 1) && (z == 0 || z == a.L2 - 1)) ||
+              (((a.fold >> 1) & 1) && (y0 == 0 || y1 == a.L1 - 1))) ? 1 : 0;
+}
+__global__ __launch_bounds__(64) void fold_classify_k(KArgs k, unsigned char* bnd) {
+    int chunk, p;
+    map_block_v(k, (int)blockIdx.x, chunk, p);
+    KArgs q = k;
+    q.fsel = 1;      // "skipped by the bulk launch" = boundary
+    const bool b = fold_chunk_skipped(q, chunk, p);
+    if (threadIdx.x == 0) bnd[blockIdx.x] = b ? 1 : 0;
+}
+static int fold_lists_get(lqcd_ctx_s* c, int family, const StencilCall& s, const KArgs& k, const PipeArgs* a, const int** list, int* n) {
+    const int which = s.fold == 2 ? 0 : 1;
+    int mask = 0;
+    for (int mu = 0; mu < 4; mu++) mask |= (c->geom.part[mu] ? 1 : 0) << mu;
+    for (const FoldLists& f : c->fold_lists)
+        if (f.family == family && f.parity_mode == s.parity_mode && f.nvirt == k.nblocks && f.mask == mask && f.remap == k.remap && f.nsub == k.nsub && f.ysplit == k.ysplit) {
+            *list = f.d_list[which]; *n = f.n[which];
+            return LQCD_OK;
+        }
+    const int nv = k.nblocks;
+    unsigned char* d_flag = nullptr;
+    HIPCHK(hipMalloc((void**)&d_flag, (size_t)nv));
+    if (family == 0) hipLaunchKernelGGL(fold_classify_s, dim3((nv + 255) / 256), dim3(256), 0, c->stream, *a, nv, d_flag);
+    else { KArgs q = k; q.vlist = nullptr; hipLaunchKernelGGL(fold_classify_k, dim3(nv), dim3(64), 0, c->stream, q, d_flag); }
+    std::vector<unsigned char> flag((size_t)nv);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(flag.data(), d_flag, (size_t)nv, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_flag);
+    if (e != hipSuccess) return hip_fail(e, "fold_lists_get", __FILE__, __LINE__);
+    FoldLists f;
+    f.family = family; f.parity_mode = s.parity_mode; f.nvirt = nv; f.mask = mask; f.remap = k.remap; f.nsub = k.nsub; f.ysplit = k.ysplit;
+    std::vector<int> l[2];
+    for (int b = 0; b < nv; b++) l[flag[(size_t)b] ? 1 : 0].push_back(b);
+    for (int w = 0; w < 2; w++) {
+        f.n[w] = (int)l[w].size();
+        f.d_list[w] = nullptr;
+        if (f.n[w]) {
+            HIPCHK(hipMalloc((void**)&f.d_list[w], l[w].size() * sizeof(int)));
+            HIPCHK(hipMemcpy(f.d_list[w], l[w].data(), l[w].size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    c->fold_lists.push_back(f);
+    *list = f.d_list[which]; *n = f.n[which];
+    return LQCD_OK;
+}
+
 // folded launch of the direction-split kernels (every case the scalar-addressing FOLD instances do not take)
-static int launch_dirsplit_fold(lqcd_ctx_s* c, const StencilCall& s, const KArgs& k) {
-    if (k.dot_partial || k.alpha_partials || s.dw_ls > 1 || (s.kind == LQCD_WILSON && s.r != 1.0)) {
+static int launch_dirsplit_fold(lqcd_ctx_s* c, const StencilCall& s, const KArgs& k_all) {
+    if (k_all.dot_partial || k_all.alpha_partials || s.dw_ls > 1 || (s.kind == LQCD_WILSON && s.r != 1.0)) {
         set_error("stencil: the folded launch has no dot / small-lattice / five-dimensional / general-r form");
         return LQCD_ERR_UNSUPPORTED;
     }
     HArgs h = make_hargs(c, s);
-    const dim3 grid(k.nblocks), block(256);
+    KArgs k = k_all;
+    int nb = k.nblocks;
+    if (s.fold >= 2) {      // bulk / boundary launch: only the chunks of its kind
+        LQCHK(fold_lists_get(c, 1, s, k_all, nullptr, &k.vlist, &nb));
+        if (nb == 0) return LQCD_OK;
+    }
+    const dim3 grid(nb), block(256);
     if (s.kind == LQCD_STAGGERED) {
         if (k.gauge12) hipLaunchKernelGGL((staggered_dirsplit_fold<true>), grid, block, 0, c->stream, k, h);
         else hipLaunchKernelGGL((staggered_dirsplit_fold<false>), grid, block, 0, c->stream, k, h);
@@ -1782,8 +1851,15 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             } else
             if (s.fold) {      // partitioned lattice, exchange complete (apply.hip, folded one-stream schedule): boundary hops from the ghost buffers in this launch
                 if (persist || delta || s.dw_ls > 1 || k.g.part[0]) { set_error("stencil: the folded launch needs the scalar-addressing kernel and an unpartitioned x direction"); return LQCD_ERR_UNSUPPORTED; }
-#define LQ_FOLD(D, R) do { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<D, R, true, false, false, false, true>), pg, pb, 0, c->stream, a); \
-                           else hipLaunchKernelGGL((wilson_dirsplit_s<D, R, false, false, false, false, true>), pg, pb, 0, c->stream, a); } while (0)
+                dim3 fg = pg;
+                if (s.fold >= 2) {      // bulk / boundary launch: only the chunks of its kind, in the order of the map
+                    int nb = 0;
+                    LQCHK(fold_lists_get(c, 0, s, k, &a, &a.vlist, &nb));
+                    if (nb == 0) return LQCD_OK;
+                    fg = dim3(nb);
+                }
+#define LQ_FOLD(D, R) do { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<D, R, true, false, false, false, true>), fg, pb, 0, c->stream, a); \
+                           else hipLaunchKernelGGL((wilson_dirsplit_s<D, R, false, false, false, false, true>), fg, pb, 0, c->stream, a); } while (0)
                 if (k.gauge12) { if (s.dagger) LQ_FOLD(true, true); else LQ_FOLD(false, true); }
                 else { if (s.dagger) LQ_FOLD(true, false); else LQ_FOLD(false, false); }
 #undef LQ_FOLD

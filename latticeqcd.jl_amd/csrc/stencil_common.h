@@ -41,6 +41,7 @@ struct KArgs {
     const real2* dotz[2];     // dot mode (StencilCall::dot_z): Re / Im <z, out> and |out|^2 per workgroup -> dot_partial[3 b ..]; dot_conj: <out, z> instead
     double* dot_partial;
     int dot_conj;
+    const int* vlist;         // folded bulk / boundary launches: virtual block of workgroup b (the launch covers only the chunks of its kind, in the order of the map); null: b itself
     int fsel;                 // folded launches (round 6, overlapping schedules): 0 every chunk, 1 only the chunks with no site on a partitioned face ("bulk": runs
                               // beside the exchange), 2 only the others ("boundary": after arrival) -- the two launches write disjoint sites and disjoint |.|^2 partials
 };
@@ -209,7 +210,8 @@ __device__ inline void map_block_v(const KArgs& k, int b, int& chunk, int& p) {
     if (both) { chunk = lb >> 1; p = lb & 1; } else { chunk = lb; p = k.parity_mode; }
 }
 
-__device__ inline void map_block(const KArgs& k, int& chunk, int& p) { map_block_v(k, blockIdx.x, chunk, p); }
+__device__ inline int vblock_of(const KArgs& k) { return k.vlist ? k.vlist[blockIdx.x] : (int)blockIdx.x; }      // (workgroup-uniform: a scalar load)
+__device__ inline void map_block(const KArgs& k, int& chunk, int& p) { map_block_v(k, vblock_of(k), chunk, p); }
 
 // gamma_mu (mu = 0,1,2) has one entry per row: row a -> column PERM[mu][a], value i^GK[mu][a]
 // (SURVEY.md Appendix A).  gamma_4 = diag(1,1,-1,-1).

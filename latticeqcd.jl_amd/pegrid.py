@@ -2,7 +2,7 @@
 
 The reference's only parallelism concept is a 4-D process grid PEs = (px,py,pz,pt) (src/mpirun.jl:17-19,
 src/mpi/mpimodule.jl:9-13).  These helpers choose a grid for N GPUs (keep x, the contiguous axis,
-unpartitioned; spread faces over as many distinct xGMI peers as possible) and slice global host arrays.
+unpartitioned; at least three distinct xGMI peers at 8 GPUs; whole-chunk faces first -- see choose_pe_grid) and slice global host arrays.
 The same decomposition rule is implemented in C (lqcd_decompose); tests check they agree.
 """
 import numpy as np
@@ -39,24 +39,30 @@ def decompose(global_L, pe, rank):
     return local, origin, tuple(fwd), tuple(bwd)
 
 
-def choose_pe_grid(global_L, ngpu):
-    """Partition t first, then z, then y; never x; prefer grids touching >= 3 distinct peers at 8 GPUs: (1,2,2,2)."""
+def choose_pe_grid(global_L, ngpu, min_local=8):
+    """Partition t and z in turn while their local extents stay >= min_local, then y; never x (the contiguous axis).  8 GPUs on 32^3 x 64: (1,1,2,4) -- three
+    distinct xGMI peers (one in z, two in t; at most 3.1 MB per peer and application, as for (1,2,2,2)), 65 536 halo sites instead of 81 920, and -- what decided it,
+    round 6 -- z and t faces are whole 64-site chunks of the stencil kernels while a y face cuts through every second chunk: with y unpartitioned 23 % of the chunks
+    touch a face instead of 59 %, so the bulk launch of the overlapping schedules has something to hide the exchange behind.  Measured on the one-GPU proxy
+    (profiles/r06_schedule_latency_table.log): CG iterations / s at the 8-GPU local volume, (1,1,2,4) vs (1,2,2,2): 6674 vs 6454 with no flight time, 5449 vs 4620
+    with 40 us per exchange."""
     pe = [1, 1, 1, 1]
     n = ngpu
-    order = [3, 2, 1]
-    i = 0
-    guard = 0
+
+    def can_split(mu, floor):
+        return global_L[mu] % (pe[mu] * 2) == 0 and (global_L[mu] // (pe[mu] * 2)) % 2 == 0 and global_L[mu] // (pe[mu] * 2) >= floor
+
     while n > 1:
-        mu = order[i % 3]
-        if n % 2 == 0 and global_L[mu] % (pe[mu] * 2) == 0 and (global_L[mu] // (pe[mu] * 2)) % 2 == 0:
-            pe[mu] *= 2
-            n //= 2
-            guard = 0
+        if n % 2:
+            raise ValueError(f"cannot build a PE grid for {ngpu} GPUs on lattice {global_L}")
+        for mu, floor in ((3, min_local), (2, min_local), (1, min_local), (3, 2), (2, 2), (1, 2)):
+            # t before z at equal split counts (t is the long axis of the lattices of BASELINE.json); a direction is taken again only after the other had its turn
+            if can_split(mu, floor) and not (mu == 3 and pe[3] > pe[2] and can_split(2, floor)):
+                pe[mu] *= 2
+                n //= 2
+                break
         else:
-            guard += 1
-            if guard > 3:
-                raise ValueError(f"cannot build a PE grid for {ngpu} GPUs on lattice {global_L}")
-        i += 1
+            raise ValueError(f"cannot build a PE grid for {ngpu} GPUs on lattice {global_L}")
     return tuple(pe)
 
 
