@@ -89,7 +89,7 @@ def test_choose_pe_grid(lq):
     assert lq.pegrid.choose_pe_grid((32, 32, 32, 64), 4) == (1, 1, 2, 2)
     assert lq.pegrid.choose_pe_grid((32, 32, 32, 64), 8) == (1, 1, 2, 4)   # 3 distinct peers (z, t-1, t+1), x unpartitioned; y too (round 6: whole-chunk faces)
     assert lq.pegrid.choose_pe_grid((48, 48, 48, 96), 8) == (1, 1, 2, 4)
-    assert lq.pegrid.choose_pe_grid((32, 32, 32, 64), 16) == (1, 1, 4, 4) and lq.pegrid.choose_pe_grid((32, 32, 32, 64), 64) == (1, 4, 4, 4)   # y only once z, t are down to 8
+    assert lq.pegrid.choose_pe_grid((32, 32, 32, 64), 16) == (1, 1, 4, 4) and lq.pegrid.choose_pe_grid((32, 32, 32, 64), 64) == (1, 2, 4, 8)   # y only once z, t are down to 8
     with pytest.raises(ValueError):
         lq.pegrid.choose_pe_grid((4, 4, 4, 4), 16)
 
