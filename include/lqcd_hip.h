@@ -307,7 +307,7 @@ int lqcd_rational_fit(double alpha, double lam_min, double lam_max, double tol, 
 /* extreme Ritz values of D^+D from `steps` Lanczos iterations on the device: theta_max converges to the largest eigenvalue from below, theta_min to
  * the smallest from above -- use them with a margin.  The Wilson rational action takes its fit interval from here when none is given. */
 int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, double* theta_min, double* theta_max);
-/* The host half of the certificate behind the rational actions' fit interval (lanczos_steps_used / ritz_bound of lqcd_action_get): the index-th
+/* The host half of the residual bound behind the rational actions' fit interval (lanczos_steps_used / ritz_bound of lqcd_action_get): the index-th
  * eigenvalue (ascending, 0-based) of the symmetric n x n tridiagonal (diag[n], offdiag[n-1]) and |last component| of its normalised eigenvector.
  * With the Lanczos coefficients of D^+D, beta_n * last_component bounds the distance from theta to an eigenvalue of D^+D.  Host-only, no GPU. */
 int lqcd_tridiag_ritz(int n, const double* diag, const double* offdiag, int index, double* theta, double* last_component);

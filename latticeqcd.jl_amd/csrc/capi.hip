@@ -56,6 +56,8 @@ int nccl_fail(ncclResult_t e, const char* what, const char* file, int line) {
 }
 
 lqcd_spinor_s* scratch_get(lqcd_ctx_s* c, int kind, int subset) {
+    if (std::this_thread::get_id() == c->home_thread && !c->parked_gauges.empty()) (void)ctx_drain_parked(c);      // what finalizer threads handed over (a long
+                                                                                                                    // run may never create a gauge field or sync again)
     const int want_sub = subset == LQCD_FULL ? LQCD_FULL : LQCD_EVEN;  // half fields are interchangeable
     for (lqcd_spinor_s* s : c->scratch)
         if (!s->in_use && s->kind == kind && (s->subset == LQCD_FULL) == (want_sub == LQCD_FULL)) {
@@ -387,6 +389,11 @@ extern "C" int lqcd_ctx_get_param(lqcd_ctx_t c, const char* key, int* value) {
     ARGCHK(c && key && value, "lqcd_ctx_get_param: null");
     // read-only views of the recorded link operations (md.hip): the open triple (0 none, 1 exp, 2 exp + mul, 3 staple, 4 staple + mul), deferred triples
     if (!strcmp(key, "dw_active")) { *value = c->tun.dw_active; return LQCD_OK; }
+    if (!strcmp(key, "adopt_thread")) {      // 1: the calling thread is the context's own (the creating one, or the last to set adopt_thread)
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        *value = std::this_thread::get_id() == c->home_thread ? 1 : 0;
+        return LQCD_OK;
+    }
     if (!strcmp(key, "parked_fields")) {      // gauge-shaped fields that another thread's destroy call left for this context's thread to free
         std::lock_guard<std::mutex> lk(g_live_mu);
         *value = (int)c->parked_gauges.size();

@@ -408,7 +408,7 @@ static double tridiag_last_component(const std::vector<double>& a, const std::ve
 // |D^+D y - theta y| = |beta_k s_k| for its Ritz vector y, so an eigenvalue of D^+D lies within that distance of theta.  The smallest Ritz value
 // converges from above, slowly for an ill-conditioned operator: the run continues past min_steps (checked every 10 steps) until
 // bound_min <= rel_tol theta_min, or gives up at max_steps -- *converged says which.  bound_min / bound_max: the residual bounds of the two ends.
-static int lanczos_certified(lqcd_op_t op, int min_steps, int max_steps, double rel_tol, uint64_t seed, double* theta_min, double* theta_max,
+static int lanczos_bounded(lqcd_op_t op, int min_steps, int max_steps, double rel_tol, uint64_t seed, double* theta_min, double* theta_max,
                              double* bound_min, double* bound_max, int* steps_used, bool* converged) {
     lqcd_ctx_s* c = op->ctx;
     ScratchScope sc(c);
@@ -452,7 +452,7 @@ static int lanczos_certified(lqcd_op_t op, int min_steps, int max_steps, double 
     return LQCD_OK;
 }
 
-// the host half of the certificate on its own (no device): the index-th eigenvalue (ascending) of the symmetric tridiagonal and |last component| of its
+// the host half of the residual bound on its own (no device): the index-th eigenvalue (ascending) of the symmetric tridiagonal and |last component| of its
 // normalised eigenvector, so that the bound can be checked against a dense eigensolver without a GPU (tests/test_rational.py)
 extern "C" int lqcd_tridiag_ritz(int n, const double* diag, const double* offdiag, int index, double* theta, double* last_component) {
     ARGCHK(n >= 1 && diag && (offdiag || n == 1) && theta && last_component, "lqcd_tridiag_ritz: bad argument");
@@ -464,13 +464,13 @@ extern "C" int lqcd_tridiag_ritz(int n, const double* diag, const double* offdia
     return LQCD_OK;
 }
 
-// the plain k-step estimate (extreme Ritz values, no certificate): what the bindings' estimate_spectrum returns
+// the plain k-step estimate (extreme Ritz values, no residual bound): what the bindings' estimate_spectrum returns
 extern "C" int lqcd_estimate_spectrum(lqcd_op_t op, int steps, uint64_t seed, double* theta_min, double* theta_max) {
     ARGCHK(op && steps >= 2 && theta_min && theta_max, "lqcd_estimate_spectrum: bad argument");
     double bmin = 0, bmax = 0;
     int used = 0;
     bool conv = false;
-    return lanczos_certified(op, steps, steps, 0.0, seed, theta_min, theta_max, &bmin, &bmax, &used, &conv);
+    return lanczos_bounded(op, steps, steps, 0.0, seed, theta_min, theta_max, &bmin, &bmax, &used, &conv);
 }
 
 // ---------------------------------------------------------------------------------- FermiAction handle
@@ -480,7 +480,7 @@ struct lqcd_action_s {
     int maxiter = 3000;
     bool rational = false, evensite = false, explicit_interval = false;
     int lanczos_steps = 60, refits = 0;
-    int lanczos_used = 0;              // steps the last certified Lanczos run took, the residual bound |beta_k s_k| of its smallest Ritz value
+    int lanczos_used = 0;              // steps the last Lanczos run took, the residual bound |beta_k s_k| of its smallest Ritz value
     double ritz_bound = 0.0;
     double tol_action = 1e-12, tol_md = 1e-8;
     double lo = 0, hi = 0;
@@ -495,12 +495,12 @@ static int action_spectrum(lqcd_action_s* fa, double* tmin, double* tmax, bool n
     double th0 = 0, th1 = 0, b0 = 0, b1 = 0;
     bool conv = false;
     const int min_steps = std::max(2, fa->lanczos_steps);
-    LQCHK(lanczos_certified(fa->op, min_steps, 8 * min_steps, 0.1, 4711, &th0, &th1, &b0, &b1, &fa->lanczos_used, &conv));
+    LQCHK(lanczos_bounded(fa->op, min_steps, 8 * min_steps, 0.1, 4711, &th0, &th1, &b0, &b1, &fa->lanczos_used, &conv));
     fa->ritz_bound = b0;
     if (!conv && need_lo) {
         char buf[400];
         snprintf(buf, sizeof buf, "FermiAction: the smallest Ritz value of D'D, %.3e, has not converged after %d Lanczos steps (residual bound %.3e): "
-                 "the lower edge of the rational fit cannot be certified -- pass rhmc_lambda_min (and rhmc_lambda_max), or raise rhmc_lanczos_steps", th0, fa->lanczos_used, b0);
+                 "the residual bound of the smallest Ritz value did not converge: no lower edge for the rational fit -- pass rhmc_lambda_min (and rhmc_lambda_max), or raise rhmc_lanczos_steps", th0, fa->lanczos_used, b0);
         set_error(buf);
         return LQCD_ERR_NOT_CONVERGED;
     }
@@ -573,7 +573,8 @@ extern "C" int lqcd_action_create(lqcd_op_t op, double nf, double eps, int maxit
             double tmin = 0, tmax = 0;
             int st = action_spectrum(fa, &tmin, &tmax, !have_lo);
             if (st != LQCD_OK) { delete fa; return st; }
-            lo = have_lo ? plo : 0.5 * tmin;      // tmin: the certified lower end, smallest Ritz value minus its residual bound
+            lo = have_lo ? plo : 0.5 * tmin;      // tmin: smallest Ritz value minus its residual bound |beta_k s_k| -- SOME eigenvalue lies that close to it; that none lies below is not proven (no
+                                                  // reorthogonalisation: ghosts), which is why every use of the interval is guarded by lqcd_action_check_interval
             hi = have_hi ? phi : 1.2 * tmax;
         }
         if (!(lo > 0 && lo < hi)) { delete fa; set_error("FermiAction: need 0 < rhmc_lambda_min < rhmc_lambda_max"); return LQCD_ERR_ARG; }
@@ -646,7 +647,7 @@ extern "C" int lqcd_action_check_interval(lqcd_action_t fa) {
     ARGCHK(fa, "lqcd_action_check_interval: null");
     if (!(fa->rational && fa->op->kind == LQCD_WILSON)) return LQCD_OK;
     double tmin = 0, tmax = 0;
-    LQCHK(action_spectrum(fa, &tmin, &tmax, !fa->explicit_interval));      // certified ends: Ritz values moved outwards by their residual bounds
+    LQCHK(action_spectrum(fa, &tmin, &tmax, !fa->explicit_interval));      // ends: Ritz values moved outwards by their residual bounds (estimates, not certificates)
     if (fa->explicit_interval) {
         if (fa->lo <= tmin && tmax <= fa->hi) return LQCD_OK;
         char buf[320];

@@ -662,7 +662,8 @@ int cg_run(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double eps, int ma
     cg_work_put(w);
     if (iters) *iters = it;
     if (final_rr) *final_rr = rr;
-    if (st != LQCD_OK) return st;
+    if (st != LQCD_OK) { c->has_waiting_pack = false; return st; }      // (a pack left waiting by the failed iteration names work vectors that went back to the pool)
+    if (comm_check(c) != LQCD_OK) return LQCD_ERR_COMM;                 // peer-mapped backend: a wait gave up (dead rank)
     if (!fixed && !converged) {
         set_error("The CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
         return LQCD_ERR_NOT_CONVERGED;

@@ -182,7 +182,7 @@ static void wilson_D_plain(cplx* out, const cplx* U, const cplx* in, const int L
     cplx G[4][4][4];
     for (int nu = 0; nu < 4; nu++) gamma_mat(nu, G[nu]);
 #ifdef _OPENMP
-#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(static)
+#pragma omp parallel for collapse(3) num_threads(g_threads) schedule(static)      /* rows of x: the partition par_range() reproduces for the vectors */
 #endif
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
@@ -264,7 +264,7 @@ void orc_staggered_D(double* outd, const double* Ud, const double* ind, const in
     const cplx* in = (const cplx*)ind;
     double hs = dagger ? -0.5 : 0.5; /* D_hop^dagger = -D_hop */
 #ifdef _OPENMP
-#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(static)
+#pragma omp parallel for collapse(3) num_threads(g_threads) schedule(static)
 #endif
     for (int t = 0; t < L[3]; t++)
         for (int z = 0; z < L[2]; z++)
@@ -321,6 +321,105 @@ static cplx cdot(const cplx* a, const cplx* b, long n) {
     return s;
 }
 
+/* ---- the same loops on several threads (the "all host cores" leg of bench.py's cpu_baseline; one thread = the plain loops above, bit for bit).
+ * A vector is nblk blocks (the spin components of the reference layout) of m = n / nblk numbers; thread k owns the SAME index range of every block -- the
+ * sites the stencil's static (t,z,y) partition gives it, so that the pages a thread touches first (NUMA) are the pages it works on in every loop.
+ * Sums: one partial per thread over its ranges, added in thread order -- deterministic for a given thread count. */
+static void par_range(long m, int nth, int k, long* j0, long* j1) { *j0 = m * k / nth; *j1 = m * (k + 1) / nth; }
+static int vec_blocks(long n, const int L[4]) { return (n == 12 * vol(L)) ? 4 : 1; }
+static double par_norm2(const cplx* a, long n, int nblk) {
+    if (g_threads <= 1) return norm2(a, n);
+    double part[1024];
+    const int nth = g_threads > 1024 ? 1024 : g_threads;
+    const long m = n / nblk;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nth)
+#endif
+    {
+#ifdef _OPENMP
+        const int k = omp_get_thread_num();
+#else
+        const int k = 0;
+#endif
+        long j0, j1;
+        par_range(m, nth, k, &j0, &j1);
+        double sum = 0;
+        for (int bk = 0; bk < nblk; bk++)
+            for (long j = j0; j < j1; j++) { const cplx v = a[bk * m + j]; sum += creal(v) * creal(v) + cimag(v) * cimag(v); }
+        part[k] = sum;
+    }
+    double tot = 0;
+    for (int k = 0; k < nth; k++) tot += part[k];
+    return tot;
+}
+static cplx par_cdot(const cplx* a, const cplx* b, long n, int nblk) {
+    if (g_threads <= 1) return cdot(a, b, n);
+    cplx part[1024];
+    const int nth = g_threads > 1024 ? 1024 : g_threads;
+    const long m = n / nblk;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nth)
+#endif
+    {
+#ifdef _OPENMP
+        const int k = omp_get_thread_num();
+#else
+        const int k = 0;
+#endif
+        long j0, j1;
+        par_range(m, nth, k, &j0, &j1);
+        cplx sum = 0;
+        for (int bk = 0; bk < nblk; bk++)
+            for (long j = j0; j < j1; j++) sum += conj(a[bk * m + j]) * b[bk * m + j];
+        part[k] = sum;
+    }
+    cplx tot = 0;
+    for (int k = 0; k < nth; k++) tot += part[k];
+    return tot;
+}
+/* scale_y 0: y += xa x;  1: y = ya y + xa x;  2: y = xa x (y is not read: first touch of a fresh vector) */
+static void par_axpby(cplx xa, const cplx* x, double ya, int scale_y, cplx* y, long n, int nblk) {
+    const int nth = g_threads > 1024 ? 1024 : (g_threads < 1 ? 1 : g_threads);
+    const long m = n / nblk;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nth)
+#endif
+    {
+#ifdef _OPENMP
+        const int k = omp_get_thread_num();
+#else
+        const int k = 0;
+#endif
+        long j0, j1;
+        par_range(m, nth, k, &j0, &j1);
+        for (int bk = 0; bk < nblk; bk++)
+            for (long j = j0; j < j1; j++) {
+                const long i = bk * m + j;
+                if (scale_y == 2) y[i] = xa * x[i]; else if (scale_y) y[i] = ya * y[i] + xa * x[i]; else y[i] += xa * x[i];
+            }
+    }
+}
+/* first touch by the owning thread: dst <- src (nblk blocks of n / nblk numbers), for the arrays the caller hands to the all-cores leg */
+void orc_numa_copy(double* dstd, const double* srcd, long n, int nblk) {
+    cplx* dst = (cplx*)dstd;
+    const cplx* src = (const cplx*)srcd;
+    const int nth = g_threads > 1024 ? 1024 : (g_threads < 1 ? 1 : g_threads);
+    const long m = n / nblk;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nth)
+#endif
+    {
+#ifdef _OPENMP
+        const int k = omp_get_thread_num();
+#else
+        const int k = 0;
+#endif
+        long j0, j1;
+        par_range(m, nth, k, &j0, &j1);
+        for (int bk = 0; bk < nblk; bk++) memcpy(dst + bk * m + j0, src + bk * m + j0, sizeof(cplx) * (size_t)(j1 - j0));
+    }
+}
+
 /* ------------------------------------------------------------------ operator dispatch */
 typedef struct {
     int kind;
@@ -352,23 +451,25 @@ static int cg_core(const op_t* o, cplx* x, const cplx* b, double eps, int maxite
     cplx* q = (cplx*)malloc(sizeof(cplx) * n);
     cplx* tmp = (cplx*)malloc(sizeof(cplx) * n);
     int status = 1, it = 0;
+    const int nblk = vec_blocks(n, o->L), par = g_threads > 1;      /* several threads: the same loops, each thread on its own sites (par_* above) */
     op_D(o, tmp, x, 0);
     op_D(o, q, tmp, 1);
-    for (long i = 0; i < n; i++) res[i] = b[i] - q[i];
-    memcpy(p, res, sizeof(cplx) * n);
-    double rnorm = norm2(res, n);
+    if (par) { par_axpby(1.0, b, 0.0, 2, res, n, nblk); par_axpby(-1.0, q, 1.0, 0, res, n, nblk); par_axpby(1.0, res, 0.0, 2, p, n, nblk); }
+    else { for (long i = 0; i < n; i++) res[i] = b[i] - q[i]; memcpy(p, res, sizeof(cplx) * n); }
+    double rnorm = par ? par_norm2(res, n, nblk) : norm2(res, n);
     if (!fixed && rnorm < eps) { status = 0; goto done; }
     for (it = 1; it <= maxiter; it++) {
         op_D(o, tmp, p, 0);
         op_D(o, q, tmp, 1);
-        cplx c1 = cdot(p, q, n);
+        cplx c1 = par ? par_cdot(p, q, n, nblk) : cdot(p, q, n);
         cplx alpha = rnorm / c1;
-        for (long i = 0; i < n; i++) x[i] += alpha * p[i];
-        for (long i = 0; i < n; i++) res[i] -= alpha * q[i];
-        double c3 = norm2(res, n);
+        if (par) { par_axpby(alpha, p, 1.0, 0, x, n, nblk); par_axpby(-alpha, q, 1.0, 0, res, n, nblk); }
+        else { for (long i = 0; i < n; i++) x[i] += alpha * p[i]; for (long i = 0; i < n; i++) res[i] -= alpha * q[i]; }
+        double c3 = par ? par_norm2(res, n, nblk) : norm2(res, n);
         if (!fixed && c3 < eps) { rnorm = c3; status = 0; break; }
         double beta = c3 / rnorm;
-        for (long i = 0; i < n; i++) p[i] = beta * p[i] + res[i];
+        if (par) par_axpby(1.0, res, beta, 1, p, n, nblk);
+        else for (long i = 0; i < n; i++) p[i] = beta * p[i] + res[i];
         rnorm = c3;
     }
     if (it > maxiter) it = maxiter;

@@ -48,6 +48,8 @@ enum { ORC_WILSON = 0, ORC_STAGGERED = 1 };
 
 /* number of threads used by the site loops (1 = the reference's serial loop) */
 void orc_set_threads(int n);
+/* dst <- src, every thread copying (= first touching) the index ranges it owns in the threaded loops: nblk blocks of n / nblk complex numbers (bench.py, all-cores leg) */
+void orc_numa_copy(double* dst, const double* src, long n, int nblk);
 int orc_get_threads(void);
 
 /* plaquette, normalisation 1/(6*V*NC): src/measurements/unusedfiles/measure_plaquette.jl:41 */

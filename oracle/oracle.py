@@ -54,6 +54,15 @@ def set_threads(n):
     lib().orc_set_threads(int(n))
 
 
+def numa_copy(a, nblk):
+    """A copy of `a` whose pages are first touched by the threads that own them in the oracle's threaded loops (set_threads first): nblk blocks --
+    the four directions of a gauge field, the four spin components of a Wilson spinor (reference layout: they are the slowest index)."""
+    a = np.ascontiguousarray(a)
+    out = np.empty_like(a)
+    lib().orc_numa_copy(_p(out), _p(a), C.c_long(a.size), int(nblk))
+    return out
+
+
 def gauge_shape(L):
     return (4, L[3], L[2], L[1], L[0], 3, 3)
 
