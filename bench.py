@@ -55,6 +55,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LQCD_BENCH_SHARE_DEVICE"):      # testing aid: every rank on device 0 -- the N > 1 path with REAL processes on a one-GPU box (peer-mapped backend only:
+        local_rank = 0                                 # RCCL refuses two ranks on one device); the figures of such a run are not performance numbers
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -185,7 +187,8 @@ def main():
                    "xcd_remap": lat.get_param("xcd_remap"), "xcd_nsub": lat.get_param("xcd_nsub"),
                    "xcd_ysplit": lat.get_param("xcd_ysplit"), "cg_fused": lat.get_param("cg_fused"),
                    "gauge_recon": lat.get_param("gauge_recon"), "gauge_recon_active": recon_active,
-                   "comm_backend": lat.comm_backend, "comm_requested": args.comm, "comm_note": comm_note},
+                   "comm_backend": lat.comm_backend, "comm_requested": args.comm, "comm_note": comm_note,
+                   "ranks_share_device_0": bool(os.environ.get("LQCD_BENCH_SHARE_DEVICE"))},
         "dslash_gflops": dslash_gflops,
         "dslash_ms": ms_dslash,
         "dslash_ms_median_per_launch_events": ms_median,
