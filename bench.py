@@ -246,10 +246,9 @@ def main():
         out["allreduce_latency_us"] = v[6]
         face = [lat.local_L[0] * lat.local_L[1] * lat.local_L[2] * lat.local_L[3] // lat.local_L[mu] if pe[mu] > 1 else 0 for mu in range(4)]
         out["halo_bytes_per_peer_and_direction"] = [96 * f for f in face]
-        try:        # which schedule the library's one-off timing picked on rank 0 (0: exchange on the 2nd stream, 1: interior on it, 2: pack + exchange on it with the interior enqueued first, 3: one stream, no overlap, no join)
+        try:        # which schedule the library's one-off timing picked on rank 0 (0: exchange on the 2nd stream, 1: interior on it, 2: pack + exchange on it with the interior enqueued first, 3: one stream, no overlap, no join, 4: one stream, bulk in front of the exchange step and boundary behind it)
             out["halo_stream_mode_rank0"] = {"chosen": lat.get_param("halo_stream_mode"),
-                                             "us_per_application": [lat.get_param("halo_tuned_us0"), lat.get_param("halo_tuned_us1"),
-                                                                    lat.get_param("halo_tuned_us2"), lat.get_param("halo_tuned_us3")]}
+                                             "us_per_application": [lat.get_param("halo_tuned_us%d" % m) for m in range(5)]}
         except Exception:
             pass
 
