@@ -563,7 +563,7 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
 static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n4 = (size_t)6 * c->geom.Vh, b32 = nh * sizeof(float2);      // the sites only: the padding chunk of a parity block is not part of a pair field
-    const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : stencil_num_blocks(c, LQCD_WILSON, 1.0, 0, 1);
+    const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : (c->geom.Vh + 63) / 64;      // (dot instances: one workgroup per 64-site chunk, whatever dslash_pipe says)
     const int nbk = (int)std::min<size_t>(1024, (n4 + UB - 1) / UB);
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
     double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)3 * nbs;

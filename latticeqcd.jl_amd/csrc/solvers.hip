@@ -956,6 +956,30 @@ __global__ __launch_bounds__(UB) void bicgf_p(BicgF a, double2* __restrict__ p, 
     for (size_t i = i0 + KE * stride; i < n; i += stride) one(i, v[i], r[i], p[i]);
 }
 
+// start of a solve in two launches and no host round trip (round 6; it used to be three copies, an axpy, a norm, a reduction, a read-back and an upload of the scalar
+// block: 135 us in front of the first iteration of a 12-iteration solve at 16^3x32): r = rhs - v (v = M x0), r0 = r, p = r, |r|^2 partials ...
+__global__ __launch_bounds__(UB) void bicgf_init(double2* __restrict__ r, double2* __restrict__ r0, double2* __restrict__ p, const double2* __restrict__ rhs,
+                                                  const double2* __restrict__ v, size_t n, double* partial) {
+    double acc[1] = {0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
+        const double2 b = rhs[i], q = v[i];
+        double2 o;
+        o.x = b.x - q.x; o.y = b.y - q.y;
+        r[i] = o; r0[i] = o; p[i] = o;
+        acc[0] = fma(o.x, o.x, acc[0]); acc[0] = fma(o.y, o.y, acc[0]);
+    }
+    block_reduce_nv<1>(acc, partial);
+}
+// ... and the scalar block of the chain from their sum (<= 1024 partials, one wave): rho = rho' = |r|^2, eps, the residual, done if it is below eps already
+__global__ __launch_bounds__(64) void bicgf_init_scal(const double* __restrict__ partial, int nb, double* sc, double eps) {
+    const double rr = sum_partials_small_nv(partial, nb, 1, 0);
+    if (threadIdx.x == 0) {
+        for (int j = B_RHO; j < B_END; j++) sc[j] = 0.0;
+        sc[B_RHO] = rr; sc[B_RHOB] = rr; sc[B_EPS] = eps; sc[B_RES] = rr;
+        if (rr < eps) sc[B_DONE] = 1.0;
+    }
+}
+
 // xe = M^-1 rhs on the even sites, M = 1 - k^2 H_eo H_oe (dagger: H -> H^+).  w[0..5] = r, r0, p, v, s, t; to: an odd-parity work vector.
 // Same recurrences, stopping rule (|s|^2 < eps half-step exit, |r|^2 < eps) and iteration count as bicgstab_core.
 // Ai != nullptr: Wilson-clover, M = 1 - k^2 A_ee^-1 H_eo A_oo^-1 H_oe with the packed inverse blocks applied to the hop sums inside the two hops
@@ -975,15 +999,17 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
     const double k = op->km;
     const size_t n = xe.elems, bytes = n * sizeof(double2);
     lqcd_spinor_s *r = w[0], *r0 = w[1], *p = w[2], *v = w[3], *s = w[4], *t = w[5];
-    const int nbs = stencil_num_blocks(c, LQCD_WILSON, 1.0, 0);                 // workgroups (= partials) of one hop on one parity
+    const int nbs = (c->geom.Vh + 63) / 64;                                     // workgroups (= partials) of one DOT hop on one parity: always one per 64-site chunk (the dot
+                                                                                // instances have no multi-chunk / persistent form; stencil_num_blocks would say otherwise under dslash_pipe = 1 / 3)
     const int nbk = (int)std::min<size_t>(1024, (n + UB - 1) / UB);             // streaming kernels: at most 1024 partials (one prologue sums them)
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
     double* P0 = c->d_partial;                  // <r0, v> (+ |v|^2)      [nbs x 3]
     double* P1 = P0 + (size_t)3 * nbs;          // |s|^2                  [nbk]
     double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]
     double* P3 = P2 + (size_t)3 * nbs;          // |r|^2, <r0, r>         [nbk x 3]
-    const double* skip = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
-    auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj) -> int {
+    const double* skip_ = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
+    auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj, bool skippable = true) -> int {
+        const double* skip = skippable ? skip_ : nullptr;
         StencilCall s1 = make_hop_call(op, to, in, nullptr, 0.0, 1.0, dg);      // t_o = [A_oo^-1] H_oe in
         s1.skip_flag = skip;
         if (Ai) { s1.clover = Ai; s1.clover_on_hop = 1; }
@@ -994,28 +1020,19 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
         if (z) { s2.dot_z[0] = z->data; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
         return stencil_apply(c, s2);
     };
-    HIPCHK(hipMemsetAsync(c->d_scal + B_DONE, 0, sizeof(double), c->stream));      // the hops test this flag: the one the LAST solve left must not skip M x below
-    LQCHK(schur(v, &xe, nullptr, nullptr, 0));
-    HIPCHK(hipMemcpyAsync(r->data, rhs->data, bytes, hipMemcpyDeviceToDevice, c->stream));
-    LQCHK(blas_axpy(c, -1.0, 0.0, v->data, r->data, n));
-    HIPCHK(hipMemcpyAsync(r0->data, r->data, bytes, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(p->data, r->data, bytes, hipMemcpyDeviceToDevice, c->stream));
-    double rr;
-    LQCHK(blas_norm2(c, r->data, n, &rr, true));
-    double init[B_END - B_RHO] = {0};
-    init[B_RHO - B_RHO] = rr;
-    init[B_RHOB - B_RHO] = rr;
-    init[B_EPS - B_RHO] = eps;
-    init[B_RES - B_RHO] = rr;
-    HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // v = M x0 with hops that do not look at the done flag (the LAST solve left it raised), then r = rhs - v, r0 = p = r and the scalar block, all on the device
+    LQCHK(schur(v, &xe, nullptr, nullptr, 0, false));
+    hipLaunchKernelGGL(bicgf_init, dim3(nbk), dim3(UB), 0, c->stream, r->data, r0->data, p->data, rhs->data, v->data, n, P1);
+    hipLaunchKernelGGL(bicgf_init_scal, dim3(1), dim3(64), 0, c->stream, P1, nbk, c->d_scal, eps);
+    HIPCHK(hipGetLastError());
+    (void)bytes;
+    double rr = 0.0;
     int it = 0, st = LQCD_ERR_NOT_CONVERGED, enq = 0;
     bool breakdown = false;
-    if (rr < eps) st = LQCD_OK;
     // Polling the done flag is a host round trip that idles the GPU for ~40 us: the first burst runs up to one iteration short of what the last
     // solve with this operator took (successive solves of an MD trajectory take the same count within one or two; iterations enqueued behind the
     // converging one are no-ops), later bursts are short.
-    int check_every = std::max(4, std::min(op->bicg_hint - 1, 64));
+    int check_every = std::max(4, std::min(op->bicg_hint, 64));      // (round 6: the last count itself -- a solve that takes it again is polled ONCE; one short made every solve pay two polls)
     while (st != LQCD_OK && !breakdown && it < maxiter) {
         const int burst = std::min(check_every, maxiter - it);
         check_every = 2;
