@@ -523,7 +523,9 @@ struct Tunables {
 #else
     int variants_built = 0;   // read-only: dslash_variant >= 2 runs variant 1 (built without -DLQCD_VARIANTS)
 #endif
-    int bicg_fused = 2;       // even-odd BiCGStab, plain Wilson r = 1 on an unpartitioned lattice: 1 = the inner products come from the epilogues of the Schur
+    int bicg_fused = 2;       // even-odd BiCGStab, plain Wilson r = 1 on an unpartitioned lattice: 3 [opt-in, round 6] = 2 + the x / r update and the p update as ONE launch
+                              // with a grid-wide barrier between them (6 launches per iteration; all <= 1024 workgroups resident) -- bit-identical and NO faster (111.5 vs
+                              // 111.3 us per iteration at 16^3x32, profiles/r06_bicgstab_eo_chain.log: the barrier costs what the launch boundary did); 1 = the inner products come from the epilogues of the Schur
                               // operator's second hop (no dot-product passes), reductions and scalar steps as separate one-block launches; 2 [default] = on lattices of
                               // <= 1024 chunks per parity the reductions and scalar steps also move into the prologues of the consumers (7 dependent launches per
                               // iteration instead of 17, identical iterates); 0 = the generic chain (what the clover / full-lattice solvers run)

@@ -956,6 +956,160 @@ __global__ __launch_bounds__(UB) void bicgf_p(BicgF a, double2* __restrict__ p, 
     for (size_t i = i0 + KE * stride; i < n; i += stride) one(i, v[i], r[i], p[i]);
 }
 
+// ---- bicg_fused = 3 (round 6, opt-in: measured no faster than two launches -- the grid barrier costs what the launch boundary did): the x / r update and the p update
+// as ONE launch with a grid-wide barrier between them.  The p update needs rho' = <r0, r> of the WHOLE new
+// residual, i.e. a global dependency -- but not a new launch: all <= 1024 workgroups of the streaming launch are resident at once (checked with the occupancy query), so
+// they can meet at a barrier (arrivals spread over eight counters 128 B apart, the scheme of cg_persist.hip), sum the block partials themselves and go on with the
+// elements they still hold in registers: the new r and the old p are not read again, one launch boundary and its prologue are gone.  Same operations on the same values
+// in the same order as bicgf_xr + bicgf_p: the same bits (tests/test_gpu_solver_edges.py).  The partials cross workgroups (and XCDs, each with its own L2) inside a
+// running kernel: they are stored and loaded with agent-scope atomics.
+__device__ inline double ldc_a(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double sum_partials_small_nv_c(const double* partial, int n, int nvals, int v) {      // sum_partials_small_nv (lqcd_internal.h) on agent-scope loads: the same order
+    const int lane = threadIdx.x & 63;
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int i = lane + 64 * k;
+        t[k] = i < n ? ldc_a(partial + (size_t)i * nvals + v) : 0.0;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += t[k];
+    return wave_sum(s);
+}
+constexpr unsigned long long kBarrierLimit = 20000000ull;      // ticks of 10 ns: 0.2 s
+// all workgroups of the launch; false: gave up (somebody else holds the device: the workgroups were not all resident)
+__device__ inline bool grid_barrier_sharded(unsigned* ctr, unsigned epoch, int nwg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's published stores are acknowledged
+    __syncthreads();                                        // ... and those of the other waves of the workgroup
+    __shared__ int okw;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_fetch_add(ctr + 32 * (blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned mine = lane < 8 ? (unsigned)((nwg - lane + 7) / 8) * epoch : 0u;      // arrivals this lane's counter must show
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        for (;;) {
+            const unsigned v = lane < 8 ? __hip_atomic_load(ctr + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__all((int)(v - mine) >= 0)) break;      // wrap-safe comparison
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > kBarrierLimit) { ok = 0; break; }
+        }
+        if (lane == 0) okw = ok;
+    }
+    __syncthreads();
+    return okw != 0;
+}
+__global__ __launch_bounds__(UB) void bicgf_xrp(BicgF a, double2* __restrict__ x, double2* __restrict__ r, double2* __restrict__ p, const double2* __restrict__ s,
+                                                 const double2* __restrict__ t, const double2* __restrict__ r0, const double2* __restrict__ v, size_t n,
+                                                 unsigned* ctr, unsigned epoch) {
+    const bool done0 = a.sc[B_DONE] != 0.0;      // (every workgroup still meets the barrier: the host counts one per launch)
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    double2 pp[KE], ps[KE], pt[KE], pz[KE], px[KE], pv_[KE], rn[KE];
+    double wr = 0.0, wi = 0.0, ss = 0.0;
+    bool half = false;
+    if (!done0) {
+#pragma unroll
+        for (int e = 0; e < KE; e++) {
+            const size_t i = i0 + e * stride;
+            if (i < n) { pp[e] = p[i]; ps[e] = s[i]; pt[e] = t[i]; pz[e] = r0[i]; px[e] = x[i]; pv_[e] = v[i]; }
+        }
+        // ---- the body of bicgf_xr
+        const double ar = a.sc[B_ALPHA], ai = a.sc[B_ALPHA + 1];
+        double tt;
+        c2 ts;
+        {
+            double t1[1], t3[3];
+            block_sum_partials<1>(a.pin2, a.pin2_n, t1);
+            block_sum_partials<3>(a.pin, a.pin_n, t3);
+            ss = t1[0]; ts.re = t3[0]; ts.im = t3[1]; tt = t3[2];
+        }
+        half = ss < a.sc[B_EPS];
+        const c2 om = bicg_omega(ts, tt, half);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.sc[B_SS] = ss; a.sc[B_HALF] = half ? 1.0 : 0.0; a.sc[B_TS] = ts.re; a.sc[B_TS + 1] = ts.im; a.sc[B_TT] = tt;
+            a.sc[B_OMEGA] = om.re; a.sc[B_OMEGA + 1] = om.im;
+        }
+        wr = om.re; wi = om.im;
+        double acc[3] = {0, 0, 0};
+        auto one = [&](size_t i, const double2 pv, const double2 sv, const double2 tv, const double2 zv, double2 xv) -> double2 {
+            double2 rv = sv;
+            xv.x = fma(ar, pv.x, xv.x); xv.x = fma(-ai, pv.y, xv.x);
+            xv.y = fma(ar, pv.y, xv.y); xv.y = fma(ai, pv.x, xv.y);
+            xv.x = fma(wr, sv.x, xv.x); xv.x = fma(-wi, sv.y, xv.x);
+            xv.y = fma(wr, sv.y, xv.y); xv.y = fma(wi, sv.x, xv.y);
+            rv.x = fma(-wr, tv.x, rv.x); rv.x = fma(wi, tv.y, rv.x);
+            rv.y = fma(-wr, tv.y, rv.y); rv.y = fma(-wi, tv.x, rv.y);
+            x[i] = xv; r[i] = rv;
+            acc[0] = fma(rv.x, rv.x, acc[0]); acc[0] = fma(rv.y, rv.y, acc[0]);
+            acc[1] = fma(zv.x, rv.x, acc[1]); acc[1] = fma(zv.y, rv.y, acc[1]);
+            acc[2] = fma(zv.x, rv.y, acc[2]); acc[2] = fma(-zv.y, rv.x, acc[2]);
+            return rv;
+        };
+#pragma unroll
+        for (int e = 0; e < KE; e++) {
+            const size_t i = i0 + e * stride;
+            if (i < n) rn[e] = one(i, pp[e], ps[e], pt[e], pz[e], px[e]);
+        }
+        for (size_t i = i0 + KE * stride; i < n; i += stride) (void)one(i, p[i], s[i], t[i], r0[i], x[i]);
+        // block partials in block_reduce_nv's order, published with agent-scope stores
+        __shared__ double red[3][UB / 64];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
+            if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = acc[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double tsum = 0;
+#pragma unroll
+            for (int w = 0; w < UB / 64; w++) tsum += red[threadIdx.x][w];
+            __hip_atomic_store(a.pout + (size_t)blockIdx.x * 3 + threadIdx.x, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const bool met = grid_barrier_sharded(ctr, epoch, (int)gridDim.x);
+    if (done0) return;
+    if (!met) { if (threadIdx.x == 0) a.sc[B_DONE] = 3.0; return; }      // the host reports it (and switches the fusion off for this context)
+    // ---- the body of bicgf_p, on the registers of the elements this thread has just updated
+    double rrn;
+    c2 rho1, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]}, al = {a.sc[B_ALPHA], a.sc[B_ALPHA + 1]}, om = {wr, wi};
+    {
+        __shared__ double sh3[3];
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const double tq = sum_partials_small_nv_c(a.pout, (int)gridDim.x, 3, q);
+                if (threadIdx.x == 0) sh3[q] = tq;
+            }
+        }
+        __syncthreads();
+        rrn = sh3[0]; rho1.re = sh3[1]; rho1.im = sh3[2];
+    }
+    const double rr = half ? ss : rrn;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead) { a.sc[B_ITERS] += 1.0; a.sc[B_RES] = rr; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im; }
+    if (half || rr < a.sc[B_EPS]) { if (lead) a.sc[B_DONE] = 1.0; return; }
+    if (!(fabs(rr) <= 1.79e308)) { if (lead) a.sc[B_DONE] = 2.0; return; }      // NaN / inf: breakdown
+    const c2 be = bicg_beta(rho1, rho, al, om);
+    if (lead) { a.sc[B_BETA] = be.re; a.sc[B_BETA + 1] = be.im; a.sc[a.rho_out] = rho1.re; a.sc[a.rho_out + 1] = rho1.im; }
+    const double br = be.re, bi = be.im;
+    auto onep = [&](size_t i, const double2 vv, const double2 rv, double2 pv) {
+        pv.x = fma(-wr, vv.x, pv.x); pv.x = fma(wi, vv.y, pv.x);
+        pv.y = fma(-wr, vv.y, pv.y); pv.y = fma(-wi, vv.x, pv.y);
+        double2 o;
+        o.x = fma(br, pv.x, rv.x); o.x = fma(-bi, pv.y, o.x);
+        o.y = fma(br, pv.y, rv.y); o.y = fma(bi, pv.x, o.y);
+        p[i] = o;
+    };
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) onep(i, pv_[e], rn[e], pp[e]);
+    }
+    for (size_t i = i0 + KE * stride; i < n; i += stride) onep(i, v[i], r[i], p[i]);
+}
+
 // start of a solve in two launches and no host round trip (round 6; it used to be three copies, an axpy, a norm, a reduction, a read-back and an upload of the scalar
 // block: 135 us in front of the first iteration of a 12-iteration solve at 16^3x32): r = rhs - v (v = M x0), r0 = r, p = r, |r|^2 partials ...
 __global__ __launch_bounds__(UB) void bicgf_init(double2* __restrict__ r, double2* __restrict__ r0, double2* __restrict__ p, const double2* __restrict__ rhs,
@@ -1003,6 +1157,18 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
                                                                                 // instances have no multi-chunk / persistent form; stencil_num_blocks would say otherwise under dslash_pipe = 1 / 3)
     const int nbk = (int)std::min<size_t>(1024, (n + UB - 1) / UB);             // streaming kernels: at most 1024 partials (one prologue sums them)
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
+    // bicg_fused = 3: x / r and p update as one launch with a grid barrier -- only while every workgroup of it is resident at once (and nobody shares the device: a
+    // barrier that is not met within 0.2 s ends the solve with an error and switches the fusion off)
+    bool xrp = fold && c->tun.bicg_fused >= 3;
+    if (xrp) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bicgf_xrp, UB, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        if ((long)per_cu * c->num_cu < nbk) xrp = false;
+    }
+    if (xrp && (c->cgp_nwg != nbk || c->cgp_epoch > 100000000u)) {      // the barrier counters (shared with the one-launch CG): never reset between launches of one grid size
+        HIPCHK(hipMemsetAsync(c->cgp_ctr, 0, 9 * 32 * sizeof(unsigned), c->stream));
+        c->cgp_epoch = 0; c->cgp_nwg = nbk;
+    }
     double* P0 = c->d_partial;                  // <r0, v> (+ |v|^2)      [nbs x 3]
     double* P1 = P0 + (size_t)3 * nbs;          // |s|^2                  [nbk]
     double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]
@@ -1051,6 +1217,11 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
             LQCHK(schur(t, s, s, P2, 1));                                                                    // t = M s, <t, s>, |t|^2
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
             a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
+            if (xrp) {
+                hipLaunchKernelGGL(bicgf_xrp, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, r0->data, v->data, n, c->cgp_ctr, ++c->cgp_epoch);
+                HIPCHK(hipGetLastError());
+                continue;
+            }
             hipLaunchKernelGGL(bicgf_xr, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, r0->data, n);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 3, B_RR, true, 0, P3));
             a.pin = P3; a.pin_n = nbk; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
@@ -1063,6 +1234,11 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
         rr = c->h_scal[B_RES - B_RHO];
         const double done = c->h_scal[B_DONE - B_RHO];
         if (done == 1.0) st = LQCD_OK;
+        else if (done == 3.0) {      // the grid barrier of the fused x / r / p launch was not met: the device is shared with somebody who keeps its workgroups from all being resident
+            c->tun.bicg_fused = 2; c->cgp_nwg = -1;
+            set_error("even-odd BiCGStab: the grid barrier of the fused update launch (bicg_fused = 3) timed out -- is the device shared?  bicg_fused is 2 for this context from here on; solve again");
+            return LQCD_ERR_HIP;
+        }
         else if (done != 0.0) breakdown = true;
     }
     if (iters) *iters = it;

@@ -29,7 +29,7 @@ lq.gauss_distribution_fermion_(b, 112)
 x = b.similar()
 if "--repeat" in args:      # run-to-run determinism of each form at the test's tolerance
     D.eps_CG = 1e-19
-    for m in (2, 1, 2, 1, 0, 0):
+    for m in (3, 2, 1, 3, 2, 1, 0, 0):
         lat.set_param("bicg_fused", m)
         for rep in range(3):
             lq.clear_fermion_(x)
