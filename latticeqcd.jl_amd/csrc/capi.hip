@@ -327,6 +327,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "cg_persist")) return &c->tun.cg_persist;
     if (!strcmp(key, "md_remap")) return &c->tun.md_remap;
     if (!strcmp(key, "staple_recon")) return &c->tun.staple_recon;
+    if (!strcmp(key, "staple_tile")) return &c->tun.staple_tile;
     if (!strcmp(key, "md_reunitarize")) return &c->tun.md_reunitarize;
     if (!strcmp(key, "nt_blas")) return &c->tun.nt_blas;
     if (!strcmp(key, "cg_fold_scalars")) return &c->tun.cg_fold_scalars;

@@ -494,6 +494,8 @@ struct Tunables {
                               // (a field that was never on the group to that precision, e.g. a text-file configuration, is not touched): rounding alone carries
                               // max |row2 - conj(row0 x row1)| past the 12-real gate (1e-14) within ~280 link updates; 0 = the reference's literal update
     int staple_recon = 1;     // staple sweep on a field whose links are known to be on the group: rows 0, 1 are loaded, row 2 is rebuilt (2/3 of the L2 -> L1 bytes)
+    int staple_tile = 1;      // staple sweep (single GPU, links on the group, chunks of whole x-rows): the links of both parities of a chunk sit in LDS and every neighbour link
+                              // inside that (x, y) tile is read from there (md.hip gauge_force_kernel_tile); 0: every neighbour link through the L1 / L2 path
     int md_remap = 1;         // staple sweep: workgroups follow the Dslash kernels' XCD-aware tile sweep (0: plain chunk order)
     int cg_defer_x = 1;       // fused CG: 2 = x is updated every SECOND iteration with both search directions (x += a_k p_k + a_{k+1} p_{k+1}, p ping-pongs
                               // between two buffers): 9 instead of 10 spinor passes per iteration on average, identical iterates; K = 3..8 (round 5; 288 GB of HBM make

@@ -41,6 +41,20 @@ __device__ __forceinline__ void st_stream(double2* p, cd v) {
     st(p, v);
 #endif
 }
+#ifndef LQCD_STAPLE_TILE_ROWS
+#define LQCD_STAPLE_TILE_ROWS 6     // rows of a link in the tile's LDS copy times three: 6 = rows 0, 1 (48 KiB: THREE workgroups per CU at 146..151 VGPRs -- the default, -5 %),
+                                    // 9 = all three rows (72 KiB, two workgroups per CU, no row-2 rebuild for the operands from LDS: -1.7 %; profiles/r06_staple_ab.log)
+#endif
+#ifndef LQCD_STAPLE_TILE_OCC
+#define LQCD_STAPLE_TILE_OCC 3
+#endif
+#ifndef LQCD_STAPLE_TILE_Y
+#define LQCD_STAPLE_TILE_Y 0        // 1: the y rows of the tile too, through generic pointers (flat loads): 256 VGPRs + 19..51 spilled, 1.483 ms per block against 1.329 -- off
+#endif
+#ifndef LQCD_STAPLE_TILE_BURST
+#define LQCD_STAPLE_TILE_BURST 0    // tile form: 1 = all five neighbour links of a plane in one burst (214 VGPRs, two workgroups per CU: no gain); 0 = the lower staple's loads
+                                    // behind the upper staple's sum -- one staple in registers at a time is what lets three workgroups share a CU
+#endif
 #ifndef LQCD_STAPLE_ROWS3
 #define LQCD_STAPLE_ROWS3 0
 #endif
@@ -394,8 +408,83 @@ __device__ __forceinline__ void staple_plane(cd (&A)[9], const GFArgs& k, int (&
     }
 }
 
-template <int MODE, int MU, bool PART, bool R2, bool EXPU = false>
-__device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int lane, const double2 (*own)[9][64]) {
+// ---- TILE form of the staple plane (round 6): the workgroup keeps rows 0, 1 of the links of BOTH parities of its chunk in LDS -- a chunk of 64 checkerboard sites is
+// 64 / XH whole x-rows, so with the other parity it is a closed (x, y) tile of 128 sites -- and the neighbour links at n + x / n - x (12 of the 60 loads per site) are
+// read from there; the loads of a plane come in two groups (upper staple, then lower staple), which holds the kernel at 146..151 VGPRs: THREE workgroups per CU
+// instead of two.  One Sexton-Weingarten block at 32^3x64: 1.339 -> 1.272 ms (profiles/r06_staple_ab.log).  The y rows of the tile (another 10.5 loads) would need a
+// per-lane choice between LDS and global memory: generic pointers / flat loads, 256 registers and spills -- measured 12 % SLOWER (LQCD_STAPLE_TILE_Y).
+// lane of n + x / n - x inside the chunk of the other parity (x = 2 xh + q wraps inside its row), of n +- y (same xh, next / previous row: the caller checks the row)
+__device__ __forceinline__ int tile_lane_px(int lane, int xh, int q, int XH) { return q ? (xh + 1 == XH ? lane - (XH - 1) : lane + 1) : lane; }
+__device__ __forceinline__ int tile_lane_mx(int lane, int xh, int q, int XH) { return q ? lane : (xh == 0 ? lane + XH - 1 : lane - 1); }
+template <int MODE, int MU, int NU>
+__device__ __forceinline__ void staple_plane_tile(cd (&A)[9], const GFArgs& k, int (&c)[4], int lane, const double2 (*own2)[4][LQCD_STAPLE_TILE_ROWS][64]) {
+    if constexpr (MU != NU) {
+        const Geom& g = k.g;
+        const int Gs = glink_stride(g), XH = g.XH, rows = 64 / XH;      // (the LDS copy has the component stride of the field: 64 elements)
+        const int yr = lane / XH, xh = lane - yr * XH, q = c[0] & 1;
+        // where the five neighbour links of the plane live: in the tile (LDS, lane index there) or outside (global memory).  x: always inside (compile time);
+        // y: the row decides per lane -- ONE load sequence through a generic pointer that is an LDS address in some lanes and a global one in others
+        const bool up_mu = MU == 0 || (MU == 1 && yr + 1 < rows), up_nu = NU == 0 || (NU == 1 && yr + 1 < rows), dn_nu = NU == 0 || (NU == 1 && yr >= 1);
+        const int l_pmu = MU == 0 ? tile_lane_px(lane, xh, q, XH) : lane + XH;        // n + mu (other parity)
+        const int l_pnu = NU == 0 ? tile_lane_px(lane, xh, q, XH) : lane + XH;        // n + nu
+        const int l_m = NU == 0 ? tile_lane_mx(lane, xh, q, XH) : lane - XH;          // m = n - nu
+        const bool in_l1 = (MU == 0 && NU == 1) ? yr >= 1 : (MU == 1 && NU == 0) ? yr + 1 < rows : false;      // m + mu (this parity): only the (x, y) planes stay inside
+        int l_l1 = 0;
+        if constexpr (MU == 0 && NU == 1) l_l1 = tile_lane_px(lane - XH, xh, q, XH);                 // a y hop keeps x: same xh, same q
+        if constexpr (MU == 1 && NU == 0) l_l1 = tile_lane_mx(lane, xh, q, XH) + XH;
+        int m[4] = {c[0], c[1], c[2], c[3]};
+        shift(m, g, NU, -1);
+#if LQCD_STAPLE_TILE_Y       // the y rows too: one generic pointer per operand, an LDS address in some lanes and a global one in others (flat loads)
+        constexpr int YMAX = 1;
+#else                        // x hops only: every select is made at compile time (ds_read or global_load, never a flat load)
+        constexpr int YMAX = 0;
+#endif
+        const double2* pa1 = (MU <= YMAX && up_mu) ? &own2[1][NU][0][l_pmu & 63] : link_at_shifted(g, k.U, c, MU, 1, NU);      // U_nu(n+mu)
+        const double2* pa2 = (NU <= YMAX && up_nu) ? &own2[1][MU][0][l_pnu & 63] : link_at_shifted(g, k.U, c, NU, 1, MU);      // U_mu(n+nu)
+        const double2* pl1 = (YMAX && in_l1) ? &own2[0][NU][0][l_l1 & 63] : link_at_shifted(g, k.U, m, MU, 1, NU);             // U_nu(m+mu)
+        const double2* pl2 = (NU <= YMAX && dn_nu) ? &own2[1][MU][0][l_m & 63] : link_at(g, k.U, m, MU);                       // U_mu(m)
+        const double2* pl3 = (NU <= YMAX && dn_nu) ? &own2[1][NU][0][l_m & 63] : link_at(g, k.U, m, NU);                       // U_nu(m)
+        cd a1[9], a2[9], l1[9], l2[9], l3[9], u3[9], t1[9], t2[9];
+        // one burst for everything that may come from global memory; what is in LDS for every lane (the x cases) is read where it is used (short latency, no
+        // registers held across the burst)
+        if constexpr (MU != 0) load_u_raw(a1, pa1, Gs);
+        if constexpr (NU != 0) load_u_raw(a2, pa2, Gs);
+#if LQCD_STAPLE_TILE_BURST
+        load_u_raw(l1, pl1, Gs);
+        if constexpr (NU != 0) { load_u_raw(l2, pl2, Gs); load_u_raw(l3, pl3, Gs); }
+#endif
+        if constexpr (MU == 0) load_u_raw(a1, pa1, Gs);
+        if constexpr (NU == 0) { if constexpr (LQCD_STAPLE_TILE_ROWS == 9) load_m3(a2, pa2, Gs); else { load_u_raw(a2, pa2, Gs); finish_u(a2); } }      // x: from the LDS copy
+        else finish_u(a2);
+        mm2_nd(t1, a1, a2);         // rows 0, 1 of a1 a2^+ need rows 0, 1 of a1 only
+#pragma unroll
+        for (int e = 0; e < LQCD_STAPLE_TILE_ROWS; e++) { const double2 t = own2[0][NU][e][lane]; u3[e] = mk(t.x, t.y); }
+        if constexpr (LQCD_STAPLE_TILE_ROWS == 6) finish_u(u3);
+        mm2_nd(t2, t1, u3);
+        finish_u(t2);
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+#if !LQCD_STAPLE_TILE_BURST
+        asm volatile("" : "+v"(A[0].re), "+v"(A[4].im), "+v"(A[8].re));      // the lower staple's loads behind the upper staple's sum: 256 registers hold one staple at a time
+        load_u_raw(l1, pl1, Gs);
+        if constexpr (NU != 0) { load_u_raw(l2, pl2, Gs); load_u_raw(l3, pl3, Gs); }
+#endif
+        finish_u(l1);
+        if constexpr (NU == 0) load_u_raw(l2, pl2, Gs);
+        mm2(t1, l2, l1);            // Q = l2 l1, rows 0, 1
+        finish_u(t1);
+        if constexpr (NU == 0) { if constexpr (LQCD_STAPLE_TILE_ROWS == 9) load_m3(l3, pl3, Gs); else { load_u_raw(l3, pl3, Gs); finish_u(l3); } }
+        else finish_u(l3);
+        mm2_dn(t2, t1, l3);         // rows 0, 1 of Q^+ l3 = l1^+ l2^+ l3
+        finish_u(t2);
+#pragma unroll
+        for (int e = 0; e < 9; e++) A[e] = A[e] + t2[e];
+        asm volatile("" : "+v"(c[0]), "+v"(A[0].re), "+v"(A[0].im), "+v"(A[4].re), "+v"(A[4].im), "+v"(A[8].re), "+v"(A[8].im));
+    }
+}
+
+template <int MODE, int MU, bool PART, bool R2, bool EXPU = false, bool TILE = false>
+__device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int lane, const double2 (*own)[9][64], const double2 (*own2)[4][LQCD_STAPLE_TILE_ROWS][64] = nullptr) {
     constexpr bool FUSE_TA = MODE == 1 || MODE == 3;
     const Geom& g = k.g;
     const int Gs = glink_stride(g);
@@ -404,10 +493,17 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
     cd A[9];
 #pragma unroll
     for (int e = 0; e < 9; e++) A[e] = mk(0.0, 0.0);
-    staple_plane<MODE, MU, 0, PART, R2>(A, k, c, p, lane, own);
-    staple_plane<MODE, MU, 1, PART, R2>(A, k, c, p, lane, own);
-    staple_plane<MODE, MU, 2, PART, R2>(A, k, c, p, lane, own);
-    staple_plane<MODE, MU, 3, PART, R2>(A, k, c, p, lane, own);
+    if constexpr (TILE) {
+        staple_plane_tile<MODE, MU, 0>(A, k, c, lane, own2);
+        staple_plane_tile<MODE, MU, 1>(A, k, c, lane, own2);
+        staple_plane_tile<MODE, MU, 2>(A, k, c, lane, own2);
+        staple_plane_tile<MODE, MU, 3>(A, k, c, lane, own2);
+    } else {
+        staple_plane<MODE, MU, 0, PART, R2>(A, k, c, p, lane, own);
+        staple_plane<MODE, MU, 1, PART, R2>(A, k, c, p, lane, own);
+        staple_plane<MODE, MU, 2, PART, R2>(A, k, c, p, lane, own);
+        staple_plane<MODE, MU, 3, PART, R2>(A, k, c, p, lane, own);
+    }
     const double coef = k.coef;
     if constexpr (MODE == 2) {
         double2* o2 = k.out + glink_off(g, p, k.mu_out, i);
@@ -417,7 +513,11 @@ __device__ __forceinline__ void staple_links(const GFArgs& k, int p, int i, int 
     }
     cd um[9], r[9];
     if constexpr (MODE == 3) load_m3(um, k.U + glink_off(g, p, MU, i), Gs);      // one direction per launch: the link comes from memory
-    else {
+    else if constexpr (TILE) {
+#pragma unroll
+        for (int e = 0; e < LQCD_STAPLE_TILE_ROWS; e++) { const double2 t = own2[0][MU][e][lane]; um[e] = mk(t.x, t.y); }
+        if constexpr (LQCD_STAPLE_TILE_ROWS == 6) finish_u(um);
+    } else {
 #pragma unroll
         for (int e = 0; e < 9; e++) { const double2 t = own[MU][e][lane]; um[e] = mk(t.x, t.y); }      // U_mu(n) from LDS
     }
@@ -490,6 +590,38 @@ __global__ __launch_bounds__(256, LQCD_STAPLE_OCC) void gauge_force_kernel(GFArg
     case 2: staple_links<MODE, 2, PART, R2, EXPU>(k, p, i, lane, own); break;
     default: staple_links<MODE, 3, PART, R2, EXPU>(k, p, i, lane, own); break;
     }
+}
+
+// the TILE form (single GPU, links on the group, chunks of whole x-rows): MODE 0 / 1, optionally with the link update behind it.  LDS: the links of both parities of
+// the chunk, all three rows: 72 KiB per workgroup, two workgroups per CU.
+template <int MODE, bool EXPU>
+__global__ __launch_bounds__(256, LQCD_STAPLE_TILE_OCC) void gauge_force_kernel_tile(GFArgs k) {
+    const Geom& g = k.g;
+    int chunk, p;
+    block_map(k.bm, blockIdx.x, chunk, p);
+    const int lane = threadIdx.x & 63;
+    const int i = chunk * 64 + lane;
+    const int mu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ double2 own2[2][4][LQCD_STAPLE_TILE_ROWS][64];      // [0]: this workgroup's parity, [1]: the other one
+    {
+        cd um[9], uo[9];
+        load_u<true>(um, k.U + glink_off(g, p, mu, i), glink_stride(g));
+        load_u<true>(uo, k.U + glink_off(g, 1 - p, mu, i), glink_stride(g));
+#pragma unroll
+        for (int e = 0; e < LQCD_STAPLE_TILE_ROWS; e++) { own2[0][mu][e][lane] = mk2(um[e].re, um[e].im); own2[1][mu][e][lane] = mk2(uo[e].re, uo[e].im); }
+    }
+    __syncthreads();
+    switch (mu) {
+    case 0: staple_links<MODE, 0, false, true, EXPU, true>(k, p, i, lane, nullptr, own2); break;
+    case 1: staple_links<MODE, 1, false, true, EXPU, true>(k, p, i, lane, nullptr, own2); break;
+    case 2: staple_links<MODE, 2, false, true, EXPU, true>(k, p, i, lane, nullptr, own2); break;
+    default: staple_links<MODE, 3, false, true, EXPU, true>(k, p, i, lane, nullptr, own2); break;
+    }
+}
+// the tile form applies: a chunk is 64 / XH whole x-rows of one (z, t) plane (XH a divisor of 64, the rows of a plane divide into chunks, every chunk full)
+static bool staple_tile_ok(lqcd_ctx_s* c) {
+    const Geom& g = c->geom;
+    return c->tun.staple_tile && g.XH >= 1 && g.XH <= 64 && 64 % g.XH == 0 && g.L[1] % (64 / g.XH) == 0 && g.Vh % 64 == 0 && !any_partitioned(c);
 }
 
 // upper nu-face of a partitioned direction nu = blockIdx.y: W_{mu nu}(m) for the three mu != nu, packed for the +nu neighbour
@@ -875,9 +1007,11 @@ static int launch_staple_sweep(lqcd_ctx_s* c, const GFArgs& k, bool fuse, bool t
         if (k.mu_only >= 0 && fuse) { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<3, false, true>), grid, dim3(64), 0, c->stream, k);
                                       else hipLaunchKernelGGL((gauge_force_kernel<3, false>), grid, dim3(64), 0, c->stream, k); }
         else if (k.mu_only >= 0) hipLaunchKernelGGL((gauge_force_kernel<2, false>), grid, dim3(64), 0, c->stream, k);
-        else if (fuse) { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<1, false, true>), grid, dim3(256), 0, c->stream, k);
+        else if (fuse) { if (two_rows && staple_tile_ok(c)) hipLaunchKernelGGL((gauge_force_kernel_tile<1, false>), grid, dim3(256), 0, c->stream, k);
+                         else if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<1, false, true>), grid, dim3(256), 0, c->stream, k);
                          else hipLaunchKernelGGL((gauge_force_kernel<1, false>), grid, dim3(256), 0, c->stream, k); }
-        else { if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<0, false, true>), grid, dim3(256), 0, c->stream, k);
+        else { if (two_rows && staple_tile_ok(c)) hipLaunchKernelGGL((gauge_force_kernel_tile<0, false>), grid, dim3(256), 0, c->stream, k);
+               else if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<0, false, true>), grid, dim3(256), 0, c->stream, k);
                else hipLaunchKernelGGL((gauge_force_kernel<0, false>), grid, dim3(256), 0, c->stream, k); }
     }
     HIPCHK(hipGetLastError());
@@ -939,7 +1073,8 @@ static int staple_force_expu(lqcd_gauge_s* P, lqcd_gauge_s* U, double beta, doub
     P->version++;
     if (k.reunit) HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
     const dim3 grid(2 * c->geom.nch);
-    if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<1, false, true, true>), grid, dim3(256), 0, c->stream, k);
+    if (two_rows && staple_tile_ok(c)) hipLaunchKernelGGL((gauge_force_kernel_tile<1, true>), grid, dim3(256), 0, c->stream, k);
+    else if (two_rows) hipLaunchKernelGGL((gauge_force_kernel<1, false, true, true>), grid, dim3(256), 0, c->stream, k);
     else hipLaunchKernelGGL((gauge_force_kernel<1, false, false, true>), grid, dim3(256), 0, c->stream, k);
     HIPCHK(hipGetLastError());
     if (k.reunit) HIPCHK(hipMemcpyAsync(&notproj, flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
