@@ -498,6 +498,28 @@ def kernel_name(lat, recon_active):
     return "wilson_dirsplit<false,true,false>" if recon_active else "wilson_dirsplit<false,false,false>"
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (the GPU boxes show 256 CPUs and grant 16:
+    /sys/fs/cgroup/cpu.max = "1600000 100000" -- 256 OpenMP threads on a 16-core quota ran the all-cores leg at 2 x one core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse is None:
+                q = float(txt)
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+                quota = None if q <= 0 else q / per
+            else:
+                quota = parse(txt)
+            if quota:
+                n = max(1, min(n, int(quota + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(lq, U, b, gL):
     """The CPU path timed on this box's host cores on a bounded sample of the same workload.  Preferred:
     the reference itself, if `julia` and its packages happen to be installed here (probed at run time, there is no network) --
@@ -546,7 +568,7 @@ def cpu_baseline(lq, U, b, gL):
             lq.mul_(y, D, b)
             parity["recon%d_active%d" % (recon, lat.get_param("recon_active"))] = float(abs(y.download() - ref_D).max() / scale)
         lat.set_param("gauge_recon", recon0)
-        orc.set_threads(os.cpu_count() or 1)
+        orc.set_threads(usable_cores())
         ref_Dd = orc.wilson_D(Uh, bh, gL, KAPPA, 1.0, bc, dagger=True)
         orc.set_threads(1)
         lq.mul_(y, D.adjoint(), b)
@@ -558,7 +580,7 @@ def cpu_baseline(lq, U, b, gL):
     del ref_D
     # the same window with the oracle's OpenMP loops on every host core, reported beside the single-thread figure (the reference's loop is
     # serial: `value` stays the 1-thread number, this one says what the box's cores could do with the same arithmetic)
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     allc = None
     if ncores > 1:
         orc.set_threads(ncores)
@@ -571,7 +593,7 @@ def cpu_baseline(lq, U, b, gL):
         t0 = time.perf_counter(); orc.wilson_D(Un, bn, gL, KAPPA, 1.0, bc); ta_d = time.perf_counter() - t0
         orc.set_threads(1)
         del Un, bn
-        allc = {"cores": ncores, "value": 4.0 / max(ta2 - ta0, 1e-9), "unit": "iter/s",
+        allc = {"cores": ncores, "cpus_visible": os.cpu_count(), "value": 4.0 / max(ta2 - ta0, 1e-9), "unit": "iter/s",
                 "dslash_gflops": WILSON_FLOP_PER_SITE * gL[0] * gL[1] * gL[2] * gL[3] / ta_d / 1e9,
                 "sample": "the same oracle window with every loop (stencil over (t,z,y) rows, BLAS-1, inner products) on all host cores, inputs and work vectors first "
                           "touched by the owning threads: (time(4 iterations) - time(0)) / 4; a restatement of the reference's serial algorithm, not the reference"}

@@ -487,7 +487,7 @@ extern "C" int lqcd_op_apply(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in, 
     LQCHK(check_full(op, out, in, "lqcd_op_apply"));
     LQCHK(op_apply_async(op, out, in, dagger ? 1 : 0, nullptr));
     HIPCHK(hipStreamSynchronize(op->ctx->stream));
-    return LQCD_OK;
+    return comm_check(op->ctx);      // peer-mapped backend: a face that never came (dead rank) is an error, not a result
 }
 
 extern "C" int lqcd_op_apply_DdagD(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_t in) {
@@ -500,6 +500,7 @@ extern "C" int lqcd_op_apply_DdagD(lqcd_op_t op, lqcd_spinor_t out, lqcd_spinor_
     hipError_t e = hipStreamSynchronize(op->ctx->stream);
     scratch_put(tmp);
     if (st == LQCD_OK && e != hipSuccess) st = hip_fail(e, "sync DdagD", __FILE__, __LINE__);
+    if (st == LQCD_OK) st = comm_check(op->ctx);
     return st;
 }
 

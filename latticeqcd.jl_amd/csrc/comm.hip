@@ -146,8 +146,7 @@ int comm_check(lqcd_ctx_s* c) {
     const unsigned long long seq = (unsigned long long)c->peer.status[2] | ((unsigned long long)c->peer.status[3] << 32);
     set_error(std::string("peer-mapped communication: rank ") + std::to_string(c->rank) + " gave up waiting for " + what[w < 5 ? w : 0] + " (index " + std::to_string(idx) +
               ", number " + std::to_string(seq) + ") after " + std::to_string(c->peer.timeout_ms) + " ms -- a peer rank has died, or the ranks do not issue the same sequence of exchanges");
-    c->peer.status[0] = 0u;
-    return LQCD_ERR_COMM;
+    return LQCD_ERR_COMM;      // (sticky: the window protocol has lost a sequence number; the context cannot communicate any more)
 }
 
 double2* halo_send_base(lqcd_ctx_s* c, int mu, int toward_bwd) {
@@ -263,14 +262,19 @@ void comm_teardown(lqcd_ctx_s* c) {
 }
 
 // ---------------------------------------------------------------------------------- the backend-neutral calls
+// a wait that gave up (a rank died) fails every later exchange at once instead of letting each of them time out in turn
+#define PEER_FAIL_FAST(c) do { if ((c)->peer.on && (c)->peer.status && (c)->peer.status[0] != 0u) return comm_check(c); } while (0)
+
 int comm_halo_exchange(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where) {
     ARGCHK(c->has_comm, "halo exchange: communicator not initialised (call lqcd_ctx_comm_init or lqcd_ctx_peer_init)");
+    PEER_FAIL_FAST(c);
     if (c->peer.on) return halo_exchange_peer(c, where);
     return halo_exchange_rccl(c, kind, parity_mode, prec, where);
 }
 
 int comm_sendrecv(lqcd_ctx_s* c, const CommXfer* x, int n, hipStream_t stream, bool halo_comm) {
     ARGCHK(c->has_comm, "face exchange: communicator not initialised (call lqcd_ctx_comm_init or lqcd_ctx_peer_init)");
+    PEER_FAIL_FAST(c);
     if (c->peer.on) return sendrecv_peer(c, x, n, stream);
     ncclComm_t comm = halo_comm ? c->comm : c->comm_red;
     NCCLCHK(ncclGroupStart());
@@ -284,6 +288,7 @@ int comm_sendrecv(lqcd_ctx_s* c, const CommXfer* x, int n, hipStream_t stream, b
 }
 
 int comm_allreduce(lqcd_ctx_s* c, double* d, int n, int cg_op) {
+    PEER_FAIL_FAST(c);
     if (c->has_comm && c->peer.on) {
         ARGCHK(n >= 1 && n <= PEER_RED_VALS, "comm_allreduce: 1..8 values");
         hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(64), 0, c->stream, comm_red_args(c), d, n, c->d_scal, cg_op);

@@ -43,6 +43,27 @@ def main():
     assert lat.comm_backend == "peer"
     U = orc.hot_gauge(gL, 111)
     Ud = lq.Gaugefields(lat).upload(lq.pegrid.local_view(U, lat.local_L, lat.origin, lead=1))
+    if os.environ.get("PEER_TEST_DEAD_RANK"):      # a rank that dies: its neighbours' waits time out, the call reports LQCD_ERR_COMM -- and so does every later one, at once
+        import time
+        lat.set_param("peer_timeout_ms", 1500)
+        dist.barrier()
+        if rank == int(os.environ["PEER_TEST_DEAD_RANK"]):
+            os._exit(0)
+        D = lq.Dirac_operator(Ud, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "boundarycondition": BC})
+        x = lq.Fermionfields(lat, lq.WILSON)
+        lq.gauss_distribution_fermion_(x, 5)
+        y = x.similar()
+        t0 = time.perf_counter()
+        for attempt in range(2):
+            try:
+                lq.mul_(y, D, x)
+                raise AssertionError("an exchange with a dead rank returned a result")
+            except lq.LQCDError as e:
+                assert e.code == lq.lib.ERR_COMM and "gave up waiting" in str(e), str(e)
+        dt = time.perf_counter() - t0
+        assert 1.0 < dt < 10.0, dt      # one timeout, then fail-fast
+        print(f"PEER_DEAD_OK rank {rank} after {dt:.1f} s", flush=True)
+        os._exit(0)
     # the mailbox path: link faces for the plaquette
     assert abs(lq.calculate_Plaquette(Ud) - orc.plaquette(U, gL)) < 1e-13
     for name in kinds:

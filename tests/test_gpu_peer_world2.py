@@ -54,3 +54,16 @@ def test_four_processes_one_gpu(gpu, orc):
 def test_two_processes_coarse_grained_window(gpu, orc):
     """The window as plain (coarse-grained) device memory: a one-device experiment setting, same results."""
     run_world(2, (8, 8, 8, 16), (1, 1, 1, 2), kinds="Wilson", schedules="3,0", extra_env={"LQCD_PEER_FINEGRAINED": "0"})
+
+
+def test_a_dead_rank_is_reported_not_waited_for(gpu, orc):
+    """Rank 1 exits after the bootstrap.  Rank 0's next exchange waits for a flag that never rises: the one-wave wait gives up after peer_timeout_ms, the call returns
+    LQCD_ERR_COMM (no hang, no result) and every later call fails at once."""
+    _port[0] += 1
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port[0]), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               PEER_TEST_LATTICE="8,8,8,16", PEER_TEST_PE="1,1,1,2", PEER_TEST_DEAD_RANK="1")
+    env.pop("LQCD_FORCE_PARTITION", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_port[0]), os.path.join(ROOT, "tests", "peer_world_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=180, cwd=ROOT)
+    assert "PEER_DEAD_OK rank 0" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
