@@ -123,6 +123,31 @@ def main():
     V = gL[0] * gL[1] * gL[2] * gL[3]
     Vloc = V // world
 
+    # ---- N > 1: before anything is timed, the halo path must reproduce the one-GPU value of |D b|^2 (same global problem).  Under --comm auto a peer-mapped backend
+    # that fails it is replaced by RCCL on every rank -- the first run on real links must not report the speed of a wrong answer.
+    selfcheck = None
+    if world > 1 or force_dist:
+        selfcheck = halo_selfcheck(lq, D, b, y, gL)
+        if selfcheck is not None and not selfcheck["ok"] and lat.comm_backend == "peer" and args.comm == "auto":
+            comm_note = "peer-mapped windows gave |D b|^2 = %.17e, expected %.17e: fell back to RCCL" % (selfcheck["norm2_Db"], selfcheck["expected"])
+            for o in (x, y, b, D, U):
+                o.close()
+            lat.close()
+            lat = lq.Lattice(gL, pe, rank, device=local_rank)
+            for kv in args.set:
+                k, v = kv.split("=")
+                lat.set_param(k, int(v))
+            box = [lq.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            lat.comm_init(box[0])
+            U = lq.Gaugefields(lat)
+            lq.lib.check(lq.lib.lib().lqcd_gauge_hot_start(U._h, __import__("ctypes").c_uint64(111)))
+            D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "r": 1.0, "boundarycondition": (1, 1, 1, -1)})
+            b = lq.Fermionfields(lat, lq.WILSON)
+            lq.gauss_distribution_fermion_(b, 112)
+            x, y = b.similar(), b.similar()
+            selfcheck = halo_selfcheck(lq, D, b, y, gL)
+
     # ---- Dslash kernel timing (HIP events on the stream the kernel is launched on)
     def settle(op=None, n=600):
         # untimed: ~0.2-0.3 s of the kernel itself, so that a timing which follows an idle stretch (start-up, the --pmc child processes)
@@ -244,6 +269,7 @@ def main():
                                                 "pack_launches_per_cg_iteration": 0 if lat.get_param("halo_fuse") & 2 else 2,
                                                 "exterior_launches_per_cg_iteration": 0 if folded else 2}
         out["allreduce_latency_us"] = v[6]
+        out["halo_selfcheck"] = selfcheck      # |D b|^2 of the partitioned operator against the one-GPU value of the same global problem
         face = [lat.local_L[0] * lat.local_L[1] * lat.local_L[2] * lat.local_L[3] // lat.local_L[mu] if pe[mu] > 1 else 0 for mu in range(4)]
         out["halo_bytes_per_peer_and_direction"] = [96 * f for f in face]
         try:        # which schedule the library's one-off timing picked on rank 0 (0: exchange on the 2nd stream, 1: interior on it, 2: pack + exchange on it with the interior enqueued first, 3: one stream, no overlap, no join, 4: one stream, bulk in front of the exchange step and boundary behind it)
@@ -496,6 +522,22 @@ def kernel_name(lat, recon_active):
     if pipe == 2 and recon_active:
         return "wilson_dirsplit_s<false,true,true>"
     return "wilson_dirsplit<false,true,false>" if recon_active else "wilson_dirsplit<false,false,false>"
+
+
+# |D b|^2 of the bench's synthetic problem (hot-start links seed 111, Gaussian source seed 112, kappa 0.141139, BC (1,1,1,-1)) measured on ONE GPU: the generators are
+# keyed by GLOBAL site, so any decomposition of the lattice must reproduce the number -- a partitioned run that does not has a broken halo path (scripts/norm_probe.py)
+DB_NORM2_ONE_GPU = {(32, 32, 32, 64): 6.63734359571458697e+07, (16, 16, 16, 32): 4.15102466603872832e+06}
+
+
+def halo_selfcheck(lq, D, b, y, gL):
+    """{"norm2_Db", "expected", "rel_diff", "ok"}: the partitioned operator against the one-GPU value of the same synthetic problem (None if the lattice has no entry)."""
+    exp = DB_NORM2_ONE_GPU.get(tuple(gL))
+    if exp is None:
+        return None
+    lq.mul_(y, D, b)
+    got = lq.dot(y, y).real
+    rel = abs(got - exp) / exp
+    return {"norm2_Db": got, "expected": exp, "rel_diff": rel, "ok": bool(rel < 1e-11)}
 
 
 def usable_cores():

@@ -23,6 +23,7 @@ static void* real_lib(void) {
     return h;
 }
 #define OK 0
+static int rank_of_env_early(void) { const char* r = getenv("RANK"); return r ? atoi(r) : 0; }
 const char* lqcd_last_error(void) { return "lqcd_stub: no error text"; }
 int lqcd_version(void) { int (*f)(void) = real_lib() ? (int (*)(void))dlsym(real_lib(), "lqcd_version") : NULL; return f ? f() : 0; }
 int lqcd_device_count(void) { return 8; }
@@ -88,6 +89,15 @@ int lqcd_ctx_peer_init(void* cc, const unsigned char* blobs, int nranks) {
     return OK;
 }
 int lqcd_ctx_comm_backend(void* cc, int* b) { ctx_t* c = (ctx_t*)cc; *b = g_backend[c->rank & 63]; return OK; }
+/* the halo self-check of the N > 1 line: |D b|^2 of the synthetic 32^3x64 problem; LQCD_STUB_BAD_NORM makes the peer "backend" return a wrong one (bench.py must then
+ * fall back to RCCL on every rank) */
+int lqcd_op_apply(void* op, void* out, void* in, int dagger) { (void)op; (void)out; (void)in; (void)dagger; return OK; }
+int lqcd_dot(void* a, void* b, double* re, double* im) {
+    (void)a; (void)b;
+    const int bad = getenv("LQCD_STUB_BAD_NORM") && g_backend[rank_of_env_early() & 63] == 2;
+    *re = bad ? 1.0 : 6.63734359571458697e+07; *im = 0.0;
+    return OK;
+}
 static int handle(void** h) { *h = malloc(8); return OK; }
 int lqcd_gauge_create(void* c, void** h) { (void)c; return handle(h); }
 int lqcd_gauge_destroy(void* h) { free(h); return OK; }

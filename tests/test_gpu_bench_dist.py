@@ -26,6 +26,7 @@ def test_bench_distributed_control_path_on_a_self_partitioned_lattice(mask):
     ph = d["halo_phases_ms_max_over_ranks"]
     assert all(ph[k] is not None and ph[k] >= 0 for k in ("pack", "interior", "exterior", "total_synchronised")), ph
     assert d["allreduce_latency_us"] > 0 and d["halo_stream_mode_rank0"]["chosen"] in (0, 1, 2, 3, 4)
+    assert d["halo_selfcheck"]["ok"] is True
 
 
 @pytest.mark.parametrize("nproc,lattice,comm", [(2, "16,16,16,32", "peer"), (4, "16,16,16,32", "auto")])
@@ -47,6 +48,7 @@ def test_bench_with_real_processes_on_one_gpu(nproc, lattice, comm):
     d = json.loads(lines[0])
     assert d["n_gpus"] == nproc and d["steps"] == 40 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["comm_backend"] == "peer" and d["config"]["ranks_share_device_0"] is True and d["config"]["comm_note"] is None
+    assert d["halo_selfcheck"]["ok"] is True and d["halo_selfcheck"]["rel_diff"] < 1e-12      # the processes' halo path reproduces the one-GPU |D b|^2 of the same global problem
     pe = d["config"]["pe_grid"]
     assert pe[0] * pe[1] * pe[2] * pe[3] == nproc and pe[0] == 1
     ph = d["halo_phases_ms_max_over_ranks"]

@@ -137,7 +137,8 @@ def test_bench_control_path_two_processes(lq, tmp_path):
     pattern = bytes((37 * i + 11) % 256 for i in range(256))
     # three bootstraps: the default (peer-mapped windows: the 256-byte descriptions gathered in rank order), --comm rccl (rank 0's id broadcast),
     # and the default on a machine where a rank cannot map its peers (every rank falls back to RCCL together, and the line says so)
-    for k, (flags, extra, want) in enumerate(((["--comm", "rccl"], {}, "rccl"), ([], {}, "peer"), ([], {"LQCD_STUB_PEER_FAILS": "1"}, "rccl"))):
+    for k, (flags, extra, want) in enumerate(((["--comm", "rccl"], {}, "rccl"), ([], {}, "peer"), ([], {"LQCD_STUB_PEER_FAILS": "1"}, "rccl"),
+                                              ([], {"LQCD_STUB_BAD_NORM": "1"}, "rccl"))):      # ... and where the peer path gives a wrong |D b|^2: fallback after the self-check
         d = tmp_path / ("run%d" % k)
         d.mkdir()
         env = dict(os.environ, LQCD_HIP_LIB=os.path.join(stub_dir, "liblqcd_stub.so"), LQCD_STUB_REAL_LIB=lq.lib.SO_PATH, LQCD_STUB_DIR=str(d), **extra)
@@ -158,6 +159,7 @@ def test_bench_control_path_two_processes(lq, tmp_path):
         assert abs(out["allreduce_latency_us"] - 20.0) < 1e-12 and abs(out["halo_phases_ms_max_over_ranks"]["pack"] - 0.02) < 1e-12
         assert out["halo_bytes_per_peer_and_direction"] == [0, 0, 0, 96 * 32 * 32 * 32]
         assert out["roofline"]["traffic"] is None and "cpu_baseline" not in out      # N = 1 extras stay out of the N > 1 line
+        assert out["halo_selfcheck"]["ok"] is True and out["halo_selfcheck"]["rel_diff"] == 0.0
         if want == "rccl":
             ids = [open(os.path.join(str(d), "rank%d.id" % q), "rb").read() for q in (0, 1)]
             assert ids[0][:256] == pattern and ids[1][:256] == pattern     # both ranks initialised their communicators with rank 0's id
