@@ -48,6 +48,9 @@ __device__ __forceinline__ void st_stream(double2* p, cd v) {
 #ifndef LQCD_STAPLE_TILE_OCC
 #define LQCD_STAPLE_TILE_OCC 3
 #endif
+#ifndef LQCD_STAPLE_TILE_NBR
+#define LQCD_STAPLE_TILE_NBR 1      // 1: the other parity's links are in LDS too and the x neighbours come from there; 0 (experiment): own parity only (24 KiB)
+#endif
 #ifndef LQCD_STAPLE_TILE_Y
 #define LQCD_STAPLE_TILE_Y 0        // 1: the y rows of the tile too, through generic pointers (flat loads): 256 VGPRs + 19..51 spilled, 1.483 ms per block against 1.329 -- off
 #endif
@@ -436,14 +439,16 @@ __device__ __forceinline__ void staple_plane_tile(cd (&A)[9], const GFArgs& k, i
         shift(m, g, NU, -1);
 #if LQCD_STAPLE_TILE_Y       // the y rows too: one generic pointer per operand, an LDS address in some lanes and a global one in others (flat loads)
         constexpr int YMAX = 1;
-#else                        // x hops only: every select is made at compile time (ds_read or global_load, never a flat load)
+#elif LQCD_STAPLE_TILE_NBR   // x hops only: every select is made at compile time (ds_read or global_load, never a flat load)
         constexpr int YMAX = 0;
+#else
+        constexpr int YMAX = -1;
 #endif
-        const double2* pa1 = (MU <= YMAX && up_mu) ? &own2[1][NU][0][l_pmu & 63] : link_at_shifted(g, k.U, c, MU, 1, NU);      // U_nu(n+mu)
-        const double2* pa2 = (NU <= YMAX && up_nu) ? &own2[1][MU][0][l_pnu & 63] : link_at_shifted(g, k.U, c, NU, 1, MU);      // U_mu(n+nu)
+        const double2* pa1 = (MU <= YMAX && up_mu) ? &own2[LQCD_STAPLE_TILE_NBR][NU][0][l_pmu & 63] : link_at_shifted(g, k.U, c, MU, 1, NU);      // U_nu(n+mu)
+        const double2* pa2 = (NU <= YMAX && up_nu) ? &own2[LQCD_STAPLE_TILE_NBR][MU][0][l_pnu & 63] : link_at_shifted(g, k.U, c, NU, 1, MU);      // U_mu(n+nu)
         const double2* pl1 = (YMAX && in_l1) ? &own2[0][NU][0][l_l1 & 63] : link_at_shifted(g, k.U, m, MU, 1, NU);             // U_nu(m+mu)
-        const double2* pl2 = (NU <= YMAX && dn_nu) ? &own2[1][MU][0][l_m & 63] : link_at(g, k.U, m, MU);                       // U_mu(m)
-        const double2* pl3 = (NU <= YMAX && dn_nu) ? &own2[1][NU][0][l_m & 63] : link_at(g, k.U, m, NU);                       // U_nu(m)
+        const double2* pl2 = (NU <= YMAX && dn_nu) ? &own2[LQCD_STAPLE_TILE_NBR][MU][0][l_m & 63] : link_at(g, k.U, m, MU);                       // U_mu(m)
+        const double2* pl3 = (NU <= YMAX && dn_nu) ? &own2[LQCD_STAPLE_TILE_NBR][NU][0][l_m & 63] : link_at(g, k.U, m, NU);                       // U_nu(m)
         cd a1[9], a2[9], l1[9], l2[9], l3[9], u3[9], t1[9], t2[9];
         // one burst for everything that may come from global memory; what is in LDS for every lane (the x cases) is read where it is used (short latency, no
         // registers held across the burst)
@@ -602,13 +607,13 @@ __global__ __launch_bounds__(256, LQCD_STAPLE_TILE_OCC) void gauge_force_kernel_
     const int lane = threadIdx.x & 63;
     const int i = chunk * 64 + lane;
     const int mu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    __shared__ double2 own2[2][4][LQCD_STAPLE_TILE_ROWS][64];      // [0]: this workgroup's parity, [1]: the other one
+    __shared__ double2 own2[1 + LQCD_STAPLE_TILE_NBR][4][LQCD_STAPLE_TILE_ROWS][64];      // [0]: this workgroup's parity, [1]: the other one
     {
         cd um[9], uo[9];
         load_u<true>(um, k.U + glink_off(g, p, mu, i), glink_stride(g));
-        load_u<true>(uo, k.U + glink_off(g, 1 - p, mu, i), glink_stride(g));
+        if (LQCD_STAPLE_TILE_NBR) load_u<true>(uo, k.U + glink_off(g, 1 - p, mu, i), glink_stride(g));
 #pragma unroll
-        for (int e = 0; e < LQCD_STAPLE_TILE_ROWS; e++) { own2[0][mu][e][lane] = mk2(um[e].re, um[e].im); own2[1][mu][e][lane] = mk2(uo[e].re, uo[e].im); }
+        for (int e = 0; e < LQCD_STAPLE_TILE_ROWS; e++) { own2[0][mu][e][lane] = mk2(um[e].re, um[e].im); if (LQCD_STAPLE_TILE_NBR) own2[LQCD_STAPLE_TILE_NBR][mu][e][lane] = mk2(uo[e].re, uo[e].im); }
     }
     __syncthreads();
     switch (mu) {
