@@ -365,6 +365,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "dslash_s18")) return &c->tun.dslash_s18;
     if (!strcmp(key, "bicg_mixed")) return &c->tun.bicg_mixed;
     if (!strcmp(key, "action_eo_solver")) return &c->tun.action_eo_solver;
+    if (!strcmp(key, "bicg_xrp_active")) return &c->tun.bicg_xrp_active;
     if (!strcmp(key, "peer_timeout_ms")) return &c->peer.timeout_ms;
     return nullptr;
 }

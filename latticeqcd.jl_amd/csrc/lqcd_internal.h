@@ -526,11 +526,12 @@ struct Tunables {
     int variants_built = 0;   // read-only: dslash_variant >= 2 runs variant 1 (built without -DLQCD_VARIANTS)
 #endif
     int bicg_fused = 2;       // even-odd BiCGStab, plain Wilson r = 1 on an unpartitioned lattice: 3 [opt-in, round 6] = 2 + the x / r update and the p update as ONE launch
-                              // with a grid-wide barrier between them (6 launches per iteration; all <= 1024 workgroups resident) -- bit-identical and NO faster (111.5 vs
-                              // 111.3 us per iteration at 16^3x32, profiles/r06_bicgstab_eo_chain.log: the barrier costs what the launch boundary did); 1 = the inner products come from the epilogues of the Schur
+                              // with a grid-wide barrier between them (6 launches per iteration; all <= 1024 workgroups resident) -- bit-identical and SLOWER (128.6 vs
+                              // 112.4 us per iteration at 16^3x32, profiles/r06_bicgstab_eo_chain.log: a barrier of 1024 workgroups costs more than the launch boundary it replaces); 1 = the inner products come from the epilogues of the Schur
                               // operator's second hop (no dot-product passes), reductions and scalar steps as separate one-block launches; 2 [default] = on lattices of
                               // <= 1024 chunks per parity the reductions and scalar steps also move into the prologues of the consumers (7 dependent launches per
                               // iteration instead of 17, identical iterates); 0 = the generic chain (what the clover / full-lattice solvers run)
+    int bicg_xrp_active = 0;  // read-only: the last even-odd BiCGStab solve ran the fused x / r / p launch (bicg_fused = 3 and every workgroup of it resident)
     int action_eo_solver = 1; // lqcd_fermi_action / lqcd_calc_UdSfdU, Wilson(-clover): X = (D^+D)^-1 eta through two even-odd BiCGStab solves (Y = D^-+ eta, X = D^-1 Y)
                               // instead of the CG on the normal equations (0: the reference's form); same stopping rule for the same residual (actions.hip)
     int lazy_links = 0;       // 1: the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,

@@ -956,7 +956,7 @@ __global__ __launch_bounds__(UB) void bicgf_p(BicgF a, double2* __restrict__ p, 
     for (size_t i = i0 + KE * stride; i < n; i += stride) one(i, v[i], r[i], p[i]);
 }
 
-// ---- bicg_fused = 3 (round 6, opt-in: measured no faster than two launches -- the grid barrier costs what the launch boundary did): the x / r update and the p update
+// ---- bicg_fused = 3 (round 6, opt-in: measured SLOWER than two launches, 128.6 vs 112.4 us per iteration at 16^3x32 -- a barrier of 1024 workgroups costs more than the launch boundary): the x / r update and the p update
 // as ONE launch with a grid-wide barrier between them.  The p update needs rho' = <r0, r> of the WHOLE new
 // residual, i.e. a global dependency -- but not a new launch: all <= 1024 workgroups of the streaming launch are resident at once (checked with the occupancy query), so
 // they can meet at a barrier (arrivals spread over eight counters 128 B apart, the scheme of cg_persist.hip), sum the block partials themselves and go on with the
@@ -1000,7 +1000,7 @@ __device__ inline bool grid_barrier_sharded(unsigned* ctr, unsigned epoch, int n
     __syncthreads();
     return okw != 0;
 }
-__global__ __launch_bounds__(UB) void bicgf_xrp(BicgF a, double2* __restrict__ x, double2* __restrict__ r, double2* __restrict__ p, const double2* __restrict__ s,
+__global__ __launch_bounds__(UB, 4) void bicgf_xrp(BicgF a, double2* __restrict__ x, double2* __restrict__ r, double2* __restrict__ p, const double2* __restrict__ s,
                                                  const double2* __restrict__ t, const double2* __restrict__ r0, const double2* __restrict__ v, size_t n,
                                                  unsigned* ctr, unsigned epoch) {
     const bool done0 = a.sc[B_DONE] != 0.0;      // (every workgroup still meets the barrier: the host counts one per launch)
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(UB) void bicgf_xrp(BicgF a, double2* __restrict__ x
 #pragma unroll
         for (int e = 0; e < KE; e++) {
             const size_t i = i0 + e * stride;
-            if (i < n) { pp[e] = p[i]; ps[e] = s[i]; pt[e] = t[i]; pz[e] = r0[i]; px[e] = x[i]; pv_[e] = v[i]; }
+            if (i < n) { pp[e] = p[i]; ps[e] = s[i]; pt[e] = t[i]; pz[e] = r0[i]; px[e] = x[i]; }
         }
         // ---- the body of bicgf_xr
         const double ar = a.sc[B_ALPHA], ai = a.sc[B_ALPHA + 1];
@@ -1052,6 +1052,12 @@ __global__ __launch_bounds__(UB) void bicgf_xrp(BicgF a, double2* __restrict__ x
             if (i < n) rn[e] = one(i, pp[e], ps[e], pt[e], pz[e], px[e]);
         }
         for (size_t i = i0 + KE * stride; i < n; i += stride) (void)one(i, p[i], s[i], t[i], r0[i], x[i]);
+        // v for the p update: requested now (the registers of s, t, r0, x are free), it lands while the workgroups meet at the barrier
+#pragma unroll
+        for (int e = 0; e < KE; e++) {
+            const size_t i = i0 + e * stride;
+            if (i < n) pv_[e] = v[i];
+        }
         // block partials in block_reduce_nv's order, published with agent-scope stores
         __shared__ double red[3][UB / 64];
 #pragma unroll
@@ -1165,6 +1171,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bicgf_xrp, UB, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
         if ((long)per_cu * c->num_cu < nbk) xrp = false;
     }
+    c->tun.bicg_xrp_active = xrp ? 1 : 0;
     if (xrp && (c->cgp_nwg != nbk || c->cgp_epoch > 100000000u)) {      // the barrier counters (shared with the one-launch CG): never reset between launches of one grid size
         HIPCHK(hipMemsetAsync(c->cgp_ctr, 0, 9 * 32 * sizeof(unsigned), c->stream));
         c->cgp_epoch = 0; c->cgp_nwg = nbk;

@@ -244,7 +244,7 @@ def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
 def test_evenodd_bicgstab_fused_chain_is_bit_identical_to_the_unfolded_one(lq, orc):
     """Tunable bicg_fused.  1: the inner products of an iteration come from the epilogue of the Schur operator's second hop, reductions and scalar steps
     are separate one-block launches; 2 (default): on lattices of <= 1024 chunks per parity they run in the consumers' prologues -- 7 dependent launches
-    per iteration instead of 17; 3 (opt-in, round 6): the x / r and the p update as one launch with a grid barrier -- 6 (measured no faster).  Same partials, same summation order, same scalar
+    per iteration instead of 17; 3 (opt-in, round 6): the x / r and the p update as one launch with a grid barrier -- 6 (measured slower).  Same partials, same summation order, same scalar
     expressions: the same BITS in x, the same iteration count.  0 is
     the generic chain (separate dot-product kernels, other partial sums): equal to rounding.  All against the oracle's solution."""
     for L, dagger, csw in (((8, 8, 8, 16), False, 0.0), ((16, 16, 16, 32), True, 0.0), ((4, 4, 4, 8), False, 0.0), ((8, 8, 8, 16), True, 1.3), ((16, 16, 16, 32), False, 1.0)):
@@ -263,6 +263,7 @@ def test_evenodd_bicgstab_fused_chain_is_bit_identical_to_the_unfolded_one(lq, o
             it, rr = lq.solve_DinvX_(x, Dd, b, return_info=True)
             out[mode] = (x.download(), it, rr)
             assert rr < 1e-19
+            assert lat.get_param("bicg_xrp_active") == (1 if mode == 3 else 0), mode      # the fused launch did run (every workgroup of it resident) / did not
         lat.set_param("bicg_fused", 2)
         assert out[2][1] == out[1][1] and out[2][2] == out[1][2] and np.array_equal(out[2][0], out[1][0]), L      # folded == unfolded, bit for bit
         assert out[3][1] == out[2][1] and out[3][2] == out[2][2] and np.array_equal(out[3][0], out[2][0]), L      # ... == the x / r / p update as one launch with a grid barrier (round 6)
