@@ -46,9 +46,11 @@ def test_two_processes_x_partitioned(gpu, orc):
     run_world(2, (16, 4, 4, 8), (2, 1, 1, 1), kinds="Wilson,Staggered", schedules="3,4,0")
 
 
-def test_four_processes_one_gpu(gpu, orc):
-    """(1,1,2,2): two partitioned directions, four ranks, every rank has two distinct neighbours."""
-    run_world(4, (8, 8, 8, 16), (1, 1, 2, 2), kinds="Wilson,Staggered", schedules="3,4,-1", timeout=600)
+@pytest.mark.parametrize("pe", [(1, 1, 2, 2), (1, 1, 1, 4)])
+def test_four_processes_one_gpu(gpu, orc, pe):
+    """(1,1,2,2): two partitioned directions, four ranks.  (1,1,1,4): a ring of four in t -- the forward and the backward neighbour of a rank are DIFFERENT ranks
+    (two windows per direction), the one-directional mailbox exchanges go round a ring (their acknowledgements matter), only ranks 0 and 3 own the global boundary."""
+    run_world(4, (8, 8, 8, 16), pe, kinds="Wilson,Staggered,WilsonClover", schedules="3,4,0,-1", timeout=600)
 
 
 def test_two_processes_coarse_grained_window(gpu, orc):
