@@ -256,6 +256,11 @@ extern "C" int lqcd_gauge_create(lqcd_ctx_t ctx, lqcd_gauge_t* g) {
     x->elems = gauge_elems(ctx->geom);
     x->data = nullptr;
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
+    if (e != hipSuccess && std::this_thread::get_id() == ctx->home_thread) {      // fields that finalizer threads parked still hold device memory: free them and try once more
+        (void)hipGetLastError();
+        (void)lqcd::ctx_drain_parked(ctx);
+        e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
+    }
     if (e != hipSuccess) { delete x; return hip_fail(e, "hipMalloc(gauge)", __FILE__, __LINE__); }
     e = hipMemsetAsync(x->data, 0, x->elems * sizeof(double2), ctx->stream);  // stride padding stays zero
     if (e != hipSuccess) { (void)hipFree(x->data); delete x; return hip_fail(e, "memset(gauge)", __FILE__, __LINE__); }
@@ -402,6 +407,11 @@ extern "C" int lqcd_spinor_create(lqcd_ctx_t ctx, lqcd_spinor_t* s, int kind, in
     x->elems = (size_t)x->ncomp * ctx->geom.Vs * (subset == LQCD_FULL ? 2 : 1);
     x->data = nullptr;
     hipError_t e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
+    if (e != hipSuccess && std::this_thread::get_id() == ctx->home_thread) {      // (as for gauge fields: parked storage is released and the allocation repeated once)
+        (void)hipGetLastError();
+        (void)lqcd::ctx_drain_parked(ctx);
+        e = hipMalloc((void**)&x->data, x->elems * sizeof(double2));
+    }
     if (e != hipSuccess) { delete x; return hip_fail(e, "hipMalloc(spinor)", __FILE__, __LINE__); }
     e = hipMemsetAsync(x->data, 0, x->elems * sizeof(double2), ctx->stream);
     if (e != hipSuccess) { (void)hipFree(x->data); delete x; return hip_fail(e, "memset(spinor)", __FILE__, __LINE__); }
