@@ -293,8 +293,7 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
         double t3[3] = {(double)dre, (double)(k.dot_conj ? -dim : dim), (double)nrm};
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t3[q] += __shfl_down(t3[q], off, 64);
+            t3[q] = wave_sum(t3[q]);
             if (lane == 0) red[4 * q + w] = t3[q];
         }
         __syncthreads();
@@ -302,8 +301,7 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
         return;
     }
     if (k.norm_partial) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        nrm = wave_sum(nrm);
         if (lane == 0) red[w] = nrm;
         __syncthreads();
         if (threadIdx.x == 0) k.norm_partial[vblock_of(k)] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -697,8 +695,7 @@ __global__ __launch_bounds__(256, LQCD_PIPE_OCC) void wilson_dirsplit_pipe(PipeA
         }
     }
     if (a.norm_partial) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        nrm = wave_sum(nrm);
         if (lane == 0) red[w] = nrm;
         __syncthreads();
         if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1001,8 +998,7 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
         double t3[3] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm};
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t3[q] += __shfl_down(t3[q], off, 64);
+            t3[q] = wave_sum(t3[q]);
             if (lane == 0) red[4 * q + w] = t3[q];
         }
         __syncthreads();
@@ -1010,8 +1006,7 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
         return;
     }
     if (a.norm_partial) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        nrm = wave_sum(nrm);
         if (lane == 0) red[w] = nrm;
         __syncthreads();
         if (threadIdx.x == 0) a.norm_partial[vb] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1172,8 +1167,7 @@ __device__ __forceinline__ void staggered_dirsplit_body(const KArgs& k, const HA
         emit_pre(k, p, (size_t)w * Vh + sp_off(3, i), v, nrm, al_upd, rv);
     }
     if (k.norm_partial) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+        nrm = wave_sum(nrm);
         if (lane == 0) red[w] = nrm;
         __syncthreads();
         if (threadIdx.x == 0) k.norm_partial[vblock_of(k)] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1392,8 +1386,7 @@ __device__ inline void ext_partial(const HArgs& k, real corr) {
     if (!k.norm_partial) return;
     __shared__ double red[2];
     __shared__ unsigned last;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) corr += __shfl_down(corr, off, 64);
+    corr = wave_sum(corr);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = corr;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1420,8 +1413,7 @@ __device__ inline void ext_partial(const HArgs& k, real corr) {
     for (; j < k.partial_offset; j += 128) s0 += k.norm_partial[j];
     for (j = k.partial_offset + threadIdx.x; j < k.red_n; j += 128) s1 += __hip_atomic_load(k.norm_partial + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double s = (s0 + s1) + (s2 + s3);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    s = wave_sum(s);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

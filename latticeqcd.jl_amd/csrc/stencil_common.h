@@ -456,8 +456,7 @@ __device__ inline void neighbours(const Geom& g, int p, int i, Nbr& n, int c[4])
 template <int TB>
 __device__ inline void block_norm_partial(double v, double* partial) {
     __shared__ double red[TB / 64];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {

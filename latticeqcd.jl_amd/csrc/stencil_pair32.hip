@@ -373,8 +373,7 @@ __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
         double t3[3] = {(double)dre.x + (double)dre.y, a.dot_conj ? -di : di, (double)nrm.x + (double)nrm.y};
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t3[q] += __shfl_down(t3[q], off, 64);
+            t3[q] = wave_sum(t3[q]);
             if (lane == 0) red[4 * q + w] = t3[q];
         }
         __syncthreads();
@@ -383,8 +382,7 @@ __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
     }
     if (a.norm_partial) {
         double s = (double)nrm.x + (double)nrm.y;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        s = wave_sum(s);
         if (lane == 0) red[w] = s;
         __syncthreads();
         if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
