@@ -548,6 +548,15 @@ struct Tunables {
                               // runMD_QPQ_sw!, standardMD.jl:146-166: 11 link passes per MD step instead of 20); lqcd_gauge_exp_update takes part.  2 (default; one GPU): a complete
                               // momentum update P_update! waits as well, and runs with the link update that follows it as ONE sweep (staple_force_expu: the new
                               // links go to a second buffer that changes places with the field's).  0: every complete update is launched at once
+    int bicg_reliable = 0;        // mixed-precision even-odd BiCGStab, 1: behind a correction step the fp32 chain goes on with its search direction, r0 and scalars (the true
+                                  // residual replaces the recursive one: a reliable update) instead of starting again from p = r.  Measured at 32^3 x 64 on a hot configuration
+                                  // (profiles/r06_links16_reliable.log): no fewer iterations -- kappa 0.141: 14 / 13-14, 0.19: 28 / 28, 0.22: 57 / 62 -- restarted BiCGStab loses
+                                  // nothing on these systems, so the default stays 0
+    int mixed_links16 = 1;        // site-pair inner operator of the mixed-precision solvers: links as int16 fixed point, value = n / 32767 (8 bytes per pair element instead of 16;
+                                  // stencil_pair32.hip ldx16).  The inner operator then differs from the outer one by 1.2e-5 (measured, relative to the result), so a correction
+                                  // step gains four digits instead of six.  1: in the even-odd BiCGStab (the action / force solves), where the step count stays three at
+                                  // eps = 1e-16 and a solve takes 11.4 instead of 13.0 ms at 32^3 x 64; 2: in every mixed-precision solver (the CG on D^+D loses: 49.5 vs
+                                  // 46.5 ms, a fourth restart); 0: fp32 links
     int pair32_active = 0;    // read-only: the last mixed-precision solve / lqcd_op_apply_f32 ran the fp32 site-pair kernel
     int recon_active = 0;     // read-only: 1 if the last operator application used the 12-real links, 2: rows 0, 1 + the fp32 deviation of row 2 ("12 + delta")
     int bicg_mixed = 0;       // 1: the even-odd BiCGStab of the plain Wilson operator (lqcd_solve_bicgstab_eo, and through it the action / force solves) runs the fp32 chain
@@ -778,7 +787,9 @@ struct lqcd_ctx_s {
     bool mix_gauge18_valid = false;      // the 18-real fp32 copy (mix_buf[0]) was made for that version (the site-pair kernel does not read it: skipped there)
     bool mix_gauge12_valid = false;      // the 12-real fp32 copy (mix_buf[5]) was made for that version
     int mix_gauge12_layout = 0;          // ... in which layout: 1 component pairs (stencil.hip fp32 build), 2 site pairs (stencil_pair32.hip)
-    void* mix_buf[9] = {};     // 7: fp32 x_j / p_j pool of the mixed-precision multi-shift solver; 8: second search-direction buffer of the fp32 CG
+    void* mix_buf[10] = {};    // 9: int16 link copy (mixed_links16)
+    bool mix_gauge16_valid = false;
+        // 7: fp32 x_j / p_j pool of the mixed-precision multi-shift solver; 8: second search-direction buffer of the fp32 CG
     size_t mix_bytes[9] = {};
     ncclComm_t comm = nullptr;      // halo send/recv (communication stream)
     ncclComm_t comm_red = nullptr;  // reductions and other collectives issued on the compute stream
@@ -851,6 +862,7 @@ struct lqcd_op_s {
     double2* clover_inv = nullptr;      // A^-1 in the same packed format (even-odd solver), built on first use
     uint64_t clover_inv_version = 0;
     double2* clover_lambda = nullptr;   // six Hermitian 3x3 matrices per site: scratch of the clover force
+    int bicg32_hint[4] = {0, 0, 0, 0};  // mixed-precision chain: iterations the last solve's correction steps took, per step (mixed.hip)
     int bicg_hint = 0;                  // iterations the last even-odd BiCGStab solve with this operator took (polling schedule of the next one)
     // LQCD_DOMAINWALL (domainwall.hip): km = the fermion mass m; the 4-D Wilson operator of the slices (hop coefficient 1/2), five-dimensional work fields
     int L5 = 0;
@@ -938,6 +950,7 @@ struct StencilCall {
     int alpha_n = 0;
     double* scal_w = nullptr;     // the device scalar block, writable: block 0 records pq, alpha and the rr this iteration started from
     const double2* gauge12 = nullptr;  // compressed links (fp64 build, Wilson r = 1 split kernel) or nullptr
+    const void* gauge16 = nullptr;     // prec == 2 only: the int16 fixed-point pair copy of the 12-real links (stencil_pair32.hip ldx16); the kernel then reads it instead of gauge12
     int gauge12_delta = 0;        // 1: gauge12 is the 8-word "12 + delta" copy (lqcd_gauge_s::data12d); only the scalar-addressing Wilson kernel reads it, every
                                   // other launch of the call falls back to the 18 stored reals
     const double2* clover = nullptr;    // packed clover blocks: the Wilson split kernel (variant 1) applies A to xin in its epilogue
@@ -997,6 +1010,7 @@ int pair32_num_blocks(lqcd_ctx_s* c);
 int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar = 2);      // npar = 1: one parity block
 int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a, int npar = 2);
 int pair32_cvt_gauge12(lqcd_ctx_s* c, float2* dst, const double2* src12);
+int pair32_cvt_gauge16(lqcd_ctx_s* c, void* dst, const double2* src12);
 int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build
 int halo_exchange_rccl(lqcd_ctx_s* c, int kind, int parity_mode, int prec, int where);

@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 namespace lqcd {
 
@@ -234,6 +236,7 @@ static int mix_alloc(lqcd_ctx_s* c, int slot, size_t bytes) {
 }
 
 struct Mix32 {
+    void* gauge16 = nullptr;    // int16 links of the site-pair kernel (mixed_links16), or nullptr
     float2 *gauge, *gauge12, *clover, *x, *r, *p, *t, *p2;      // p2: second search-direction buffer (deferred x update), or nullptr
     size_t blk;   // elements per parity block
     int layout = 0;   // fp32 spinor layout: 0 plain (staggered), 1 Wilson component pairs (stencil.hip, LQCD_F32), 2 Wilson site pairs (stencil_pair32.hip)
@@ -245,6 +248,7 @@ static StencilCall call32(lqcd_op_s* op, const Mix32& m, float2* out, float2* in
     s.kind = op->kind;
     s.gauge = (const double2*)m.gauge;
     s.gauge12 = (const double2*)m.gauge12;
+    s.gauge16 = m.gauge16;
     s.clover = (const double2*)m.clover;
     for (int p = 0; p < 2; p++) {
         s.out[p] = (double2*)(out + p * m.blk);
@@ -331,7 +335,7 @@ struct VariantPin {
 // fp32 copies of the operator's links (18 reals, and 12 reals under the fp64 path's rule) and clover blocks, and the four fp32 work
 // vectors, shared by the mixed-precision CG and the mixed-precision multi-shift CG.  The link copies follow the field
 // (handle, version): a sequence of solves on the same links converts once.
-static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
+static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m, bool eo_chain = false) {
     lqcd_ctx_s* c = op->ctx;
     LQCHK(halo_schedule_settle(op));      // the inner solvers count |.|^2 partials: the halo schedule (folded or not, also for the fp32 build) is fixed from here on
     const bool clov = op->csw != 0.0 && op->clover != nullptr;
@@ -366,7 +370,7 @@ static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
     c->tun.pair32_active = pair ? 1 : 0;
     const int glayout = pair ? 2 : 1;
     const bool same_links = c->mix_gauge_of == (const void*)op->gauge && c->mix_gauge_version == op->gauge->version;
-    if (!same_links) { c->mix_gauge18_valid = false; c->mix_gauge12_valid = false; }
+    if (!same_links) { c->mix_gauge18_valid = false; c->mix_gauge12_valid = false; c->mix_gauge16_valid = false; }
     const bool need18 = !pair;      // the site-pair kernel reads the 12-real pair copy alone: no 18-real fp32 copy per link update (0.35 ms at 32^3x64)
     if (need18 && !c->mix_gauge18_valid) {
         hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, ng)), dim3(MB), 0, c->stream, m.gauge, op->gauge->data, ng, 1.0);
@@ -385,6 +389,13 @@ static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m) {
         else hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
         c->mix_gauge12_valid = true;
         c->mix_gauge12_layout = glayout;
+    }
+    m.gauge16 = nullptr;
+    if (pair && (c->tun.mixed_links16 >= 2 || (c->tun.mixed_links16 == 1 && eo_chain))) {
+        LQCHK(mix_alloc(c, 9, gauge12_elems(c->geom) * sizeof(float2) / 2));
+        if (!c->mix_gauge16_valid) LQCHK(pair32_cvt_gauge16(c, c->mix_buf[9], op->gauge->data12));
+        c->mix_gauge16_valid = true;
+        m.gauge16 = c->mix_buf[9];
     }
     c->mix_gauge_of = (const void*)op->gauge;
     c->mix_gauge_version = op->gauge->version;
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(UB) void bicgf32_xr(BicgF a, float4* __restrict__ x
 // p = r + beta (p - omega v)
 template <bool PAIR>
 __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p, const float4* __restrict__ r, const float4* __restrict__ v, size_t n4) {
-    if (a.sc[B_DONE] != 0.0) return;
+    if (!a.cont && a.sc[B_DONE] != 0.0) return;
     const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
     float4 pv_[2], pr[2], pp[2];
 #pragma unroll
@@ -518,9 +529,13 @@ __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p,
     else { rrn = a.sc[B_RR]; rho1.re = a.sc[B_RHO1]; rho1.im = a.sc[B_RHO1 + 1]; }
     const double rr = half ? a.sc[B_SS] : rrn;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-    if (lead) { a.sc[B_ITERS] += 1.0; a.sc[B_RES] = rr; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im; }
-    if (half || rr < a.sc[B_EPS]) { if (lead) a.sc[B_DONE] = 1.0; return; }
-    if (!(fabs(rr) <= 1.79e308)) { if (lead) a.sc[B_DONE] = 2.0; return; }
+    if (a.cont) {      // r is the true residual of a reliable update, rho1 = <r0, r> with it: no test, the chain is armed for the next stretch
+        if (lead) { a.sc[B_RES] = rrn; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im; a.sc[B_EPS] = a.cont_eps; a.sc[B_DONE] = 0.0; }
+    } else {
+        if (lead) { a.sc[B_ITERS] += 1.0; a.sc[B_RES] = rr; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im; }
+        if (half || rr < a.sc[B_EPS]) { if (lead) a.sc[B_DONE] = 1.0; return; }
+        if (!(fabs(rr) <= 1.79e308)) { if (lead) a.sc[B_DONE] = 2.0; return; }
+    }
     const c2 be = bicg_beta(rho1, rho, al, om);
     if (lead) { a.sc[B_BETA] = be.re; a.sc[B_BETA + 1] = be.im; a.sc[a.rho_out] = rho1.re; a.sc[a.rho_out + 1] = rho1.im; }
     const float br = (float)be.re, bi = (float)be.im, wr = -(float)wrd, wi = -(float)wid;
@@ -534,10 +549,22 @@ __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p,
     for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pv_[e], pr[e], pp[e]); }
     for (size_t i = i0 + 2 * stride; i < n4; i += stride) one(i, v[i], r[i], p[i]);
 }
+// partials |r|^2, <r0, r> (the three values bicgf32_xr leaves for bicgf32_p) of a residual that was replaced by the true one
+template <bool PAIR>
+__global__ __launch_bounds__(UB) void bicgf32_r0r(BicgF a, const float4* __restrict__ r0, const float4* __restrict__ r, size_t n4) {
+    double acc[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n4; i += (size_t)gridDim.x * UB) {
+        const float4 rv = r[i];
+        acc[0] += norm4(rv);
+        cdot4<PAIR>(acc[1], acc[2], r0[i], rv);
+    }
+    block_reduce_nv<3>(acc, a.pout);
+}
 // r = rhs - q (fp64) with |r|^2 partials is residual_kernel above (sigma = 0)
 
 struct Eo32 {
     float2 *gauge, *gauge12;
+    const void* gauge16 = nullptr;
     const float2* ainv = nullptr;                  // Wilson-clover: fp32 copy of the packed inverse clover blocks (applied to the hop sums inside the hops)
     float2 *x, *r, *r0, *p, *v, *s, *t, *to;      // half-lattice vectors
     int layout;                                    // 1: component pairs (fp32 build of stencil.hip), 2: site pairs (stencil_pair32.hip: half the launches' latencies per site)
@@ -546,13 +573,13 @@ struct Eo32 {
 static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const float2* z, double* dotp, int conj, int dg, const double* skip) {
     lqcd_ctx_s* c = op->ctx;
     StencilCall s1;
-    s1.kind = LQCD_WILSON; s1.gauge = (const double2*)m.gauge; s1.gauge12 = (const double2*)m.gauge12;
+    s1.kind = LQCD_WILSON; s1.gauge = (const double2*)m.gauge; s1.gauge12 = (const double2*)m.gauge12; s1.gauge16 = m.gauge16;
     s1.out[0] = nullptr; s1.out[1] = (double2*)m.to; s1.in[0] = (const double2*)in; s1.in[1] = nullptr; s1.xin[0] = s1.xin[1] = nullptr;
     s1.a = 0.0; s1.b = 1.0; s1.r = 1.0; s1.dagger = dg; s1.parity_mode = 1; s1.prec = m.layout == 2 ? 2 : 1; s1.skip_flag = skip;
     if (m.ainv) { s1.clover = (const double2*)m.ainv; s1.clover_on_hop = 1; }
     LQCHK(stencil_apply(c, s1));
     StencilCall s2;
-    s2.kind = LQCD_WILSON; s2.gauge = (const double2*)m.gauge; s2.gauge12 = (const double2*)m.gauge12;
+    s2.kind = LQCD_WILSON; s2.gauge = (const double2*)m.gauge; s2.gauge12 = (const double2*)m.gauge12; s2.gauge16 = m.gauge16;
     s2.out[0] = (double2*)out; s2.out[1] = nullptr; s2.in[0] = nullptr; s2.in[1] = (const double2*)m.to; s2.xin[0] = (const double2*)in; s2.xin[1] = nullptr;
     s2.a = 1.0; s2.b = -op->km * op->km; s2.r = 1.0; s2.dagger = dg; s2.parity_mode = 0; s2.prec = m.layout == 2 ? 2 : 1; s2.skip_flag = skip;
     if (m.ainv) { s2.clover = (const double2*)m.ainv; s2.clover_on_hop = 1; }
@@ -560,7 +587,9 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
     return stencil_apply(c, s2);
 }
 // e ~ M^-1 rhs32 (|rhs32|^2 = 1, zero guess) until the recursive residual is below eps2; m.r holds rhs32 on entry
-static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters) {
+// cont (reliable update, tunable bicg_reliable): m.r holds the true residual in the units of the chain's first right-hand side; the chain keeps p, v, r0 and its scalars,
+// x starts again at 0, <r0, r> is formed with the new r and p = r + beta (p - omega v) as the iteration that stopped would have done; *iters counts from the restart
+static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters, bool cont = false, int first_burst = 0, int* full_stop = nullptr) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n4 = (size_t)6 * c->geom.Vh, b32 = nh * sizeof(float2);      // the sites only: the padding chunk of a parity block is not part of a pair field
     const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : (c->geom.Vh + 63) / 64;      // (dot instances: one workgroup per 64-site chunk, whatever dslash_pipe says)
@@ -569,12 +598,29 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
     double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)3 * nbs;
     const double* skip = c->d_scal + (B_DONE - S_DONE);
     HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));
-    HIPCHK(hipMemcpyAsync(m.r0, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(m.p, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
-    double init[B_END - B_RHO] = {0};
-    init[B_RHO - B_RHO] = 1.0; init[B_RHOB - B_RHO] = 1.0; init[B_EPS - B_RHO] = eps2; init[B_RES - B_RHO] = 1.0;
-    HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    int it = 0, enq = 0, check_every = std::max(4, std::min(op->bicg_hint - 1, 64));
+    int it = 0, enq = 0;
+    if (!cont) {
+        HIPCHK(hipMemcpyAsync(m.r0, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(m.p, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
+        double init[B_END - B_RHO] = {0};
+        init[B_RHO - B_RHO] = 1.0; init[B_RHOB - B_RHO] = 1.0; init[B_EPS - B_RHO] = eps2; init[B_RES - B_RHO] = 1.0;
+        HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    } else {
+        it = enq = *iters;      // iterations of the chain so far: iteration e reads rho from slot e & 1 and leaves the next one in the other
+        BicgF a;
+        a.sc = c->d_scal; a.fold = fold ? 1 : 0;
+        a.rho_in = ((enq - 1) & 1) ? B_RHOB : B_RHO; a.rho_out = ((enq - 1) & 1) ? B_RHO : B_RHOB;
+        a.pin = P3; a.pin_n = nbk; a.pin2 = nullptr; a.pin2_n = 0; a.pout = P3;
+        a.cont = 1; a.cont_eps = eps2;
+        if (m.layout == 2) hipLaunchKernelGGL(bicgf32_r0r<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (const float4*)m.r0, (const float4*)m.r, n4);
+        else hipLaunchKernelGGL(bicgf32_r0r<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (const float4*)m.r0, (const float4*)m.r, n4);
+        if (!fold) LQCHK(reduce_to_slot(c, nbk, 3, B_RR, true, 0, P3));
+        a.pout = nullptr;
+        if (m.layout == 2) hipLaunchKernelGGL(bicgf32_p<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
+        else hipLaunchKernelGGL(bicgf32_p<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
+        HIPCHK(hipGetLastError());
+    }
+    int check_every = first_burst > 0 ? std::min(first_burst, 64) : std::max(4, std::min(op->bicg_hint - 1, 64));
     double done = 0.0;
     while (done == 0.0 && it < maxiter) {
         const int burst = std::min(check_every, maxiter - it);
@@ -609,8 +655,9 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
         done = c->h_scal[B_DONE - B_RHO];
     }
     *iters = it;
+    if (full_stop) *full_stop = (done == 1.0 && c->h_scal[B_HALF - B_RHO] == 0.0) ? 1 : 0;      // stopped behind a whole iteration: the chain can go on after a reliable update
     if (done == 2.0) { set_error("mixed-precision even-odd BiCGStab: the fp32 chain broke down"); return LQCD_ERR_NOT_CONVERGED; }
-    if (done == 1.0) op->bicg_hint = it;
+    if (done == 1.0 && !cont && first_burst == 0) op->bicg_hint = it;
     return LQCD_OK;      // an inner solve that ran out of iterations still improves x: the outer loop decides
 }
 
@@ -620,10 +667,10 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
     const size_t nh = xe.elems, nfull = 2 * nh;
     // fp32 links and work space: the buffers of the mixed-precision CG (four full-lattice vectors = eight halves), component-pair layout
     Mix32 mm;
-    LQCHK(mix_prepare(op, nfull, mm));             // layout 2 (site pairs) where stencil_pair32.hip applies, else the component pairs of the fp32 build
+    LQCHK(mix_prepare(op, nfull, mm, true));       // layout 2 (site pairs) where stencil_pair32.hip applies, else the component pairs of the fp32 build
     Eo32 m;
     m.layout = mm.layout;
-    m.gauge = mm.gauge; m.gauge12 = mm.gauge12;
+    m.gauge = mm.gauge; m.gauge12 = mm.gauge12; m.gauge16 = mm.gauge16;
     if (Ai) {      // Wilson-clover (layout 1: the site-pair kernel carries no clover term): the inverse blocks in fp32, rebuilt with the inverse
         const size_t nc = clover_elems(c->geom);
         LQCHK(mix_alloc(c, 6, nc * sizeof(float2)));      // the slot of the fp32 clover blocks of the mixed-precision CG (converted per solve there as well)
@@ -650,22 +697,36 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         HIPCHK(hipMemcpyAsync(r->data, rhs->data, nh * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
         LQCHK(blas_norm2(c, rhs->data, nh, &rr, true));
     } else LQCHK(true_residual(&rr));
-    int total = 0, outer = 0;
+    int total = 0, outer = 0, chain_it = 0, live = 0;
+    double scale0 = 1.0;
+    // digits one correction step can gain: six with fp32 links; the int16 links of mixed_links16 differ from the true ones by 1.5e-5 per real, which the
+    // inverse amplifies -- four and a half
+    const double digits = (m.layout == 2 && m.gauge16) ? 4.5 : 6.0;
     while (rr >= eps && outer < 12 && total < maxiter) {
-        // as few correction steps as an fp32 recurrence supports: one per 1e-6 of the residual norm still to go, the reduction split evenly
+        // as few correction steps as the inner recurrence supports, the reduction split evenly
         const double togo = std::sqrt(eps / rr) * 0.5;
-        const int nsteps = std::max(1, (int)std::ceil(std::log10(1.0 / std::min(togo, 0.1)) / 6.0));
+        const int nsteps = std::max(1, (int)std::ceil(std::log10(1.0 / std::min(togo, 0.1)) / digits));
         const double tol = std::max(std::pow(togo, 1.0 / nsteps), 2e-7);
-        if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, r->data, 1.0 / std::sqrt(rr), 1));
-        else LQCHK(to_f32(c, 1, m.r, r->data, nh, 1.0 / std::sqrt(rr)));
-        int it = 0;
-        LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol, maxiter - total, &it));
-        total += it;
-        if (m.layout == 2) LQCHK(pair32_axpy_to_f64(c, xe.data, m.x, std::sqrt(rr), 1));
-        else LQCHK(add_from_f32(c, 1, xe.data, m.x, std::sqrt(rr), nh));
+        // reliable update (bicg_reliable): the chain that stopped behind a whole iteration goes on -- same r0, p, v and scalars, same units (scale0) -- with the true residual
+        // in place of the recursive one; otherwise a new chain on the normalised residual
+        const bool cont = live && c->tun.bicg_reliable;
+        if (!cont) { scale0 = 1.0 / std::sqrt(rr); chain_it = 0; }
+        if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, r->data, scale0, 1));
+        else LQCHK(to_f32(c, 1, m.r, r->data, nh, scale0));
+        int it = chain_it;
+        const int hint = op->bicg32_hint[std::min(outer, 3)];
+        LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol * rr * scale0 * scale0, chain_it + (maxiter - total), &it, cont, hint, &live));
+        const int step_its = it - chain_it;
+        total += step_its;
+        chain_it = it;
+        op->bicg32_hint[std::min(outer, 3)] = step_its;
+        if (m.layout == 2) LQCHK(pair32_axpy_to_f64(c, xe.data, m.x, 1.0 / scale0, 1));
+        else LQCHK(add_from_f32(c, 1, xe.data, m.x, 1.0 / scale0, nh));
         double rrn = 0;
         LQCHK(true_residual(&rrn));
         outer++;
+        static const bool trace = getenv("LQCD_MIXED_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[lqcd] mixed e-o BiCGStab: step %d (%s), inner tolerance %.2e, %d iterations, |r|^2 %.3e -> %.3e (asked %.3e)\n", outer, cont ? "goes on" : "new chain", tol, step_its, rr, rrn, eps);
         const bool stalled = !(rrn < 0.0625 * rr);
         rr = rrn;
         if (stalled) break;

@@ -86,6 +86,8 @@ struct BicgF {
     const double* pin2;     // bicgf_xr: the |s|^2 partials of bicgf_s
     int pin2_n;
     double* pout;           // this kernel's partials
+    int cont = 0;           // bicgf32_p after a reliable update (mixed.hip): no stopping test, the chain is re-armed (B_DONE = 0, B_EPS = cont_eps)
+    double cont_eps = 0.0;
 };
 #endif
 int schur_wilson(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, lqcd_spinor_s* to, int dg, const double2* Ai = nullptr);      // out = (1 - k^2 [A^-1] H_eo [A^-1] H_oe) in on the even sites (fp64)

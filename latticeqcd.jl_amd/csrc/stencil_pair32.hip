@@ -22,6 +22,7 @@
 #include "lqcd_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace lqcd {
 namespace pair32 {
@@ -36,6 +37,23 @@ __device__ __forceinline__ cx ldx_nt(const float4* p) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
     cx r; r.re = v2f{v.x, v.y}; r.im = v2f{v.z, v.w}; return r;
+}
+// 16-bit links (tunable mixed_links16): a link element of a pair is one 8-byte word of four fixed-point int16, (re_A, re_B) in .x and (im_A, im_B) in .y, value = n / 32767
+// (|u| <= 1 for a unitary matrix: an absolute rounding error of 1.5e-5 per real, where fp16 would leave 2.4e-4 next to 1).  Two converts per word half and one packed multiply per two reals.
+constexpr float L16_SCALE = 1.f / 32767.f;
+template <bool NT>
+__device__ __forceinline__ cx ldx16(const uint2* p) {
+    uint2 v;
+    if constexpr (NT) {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u t = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));
+        v.x = t.x; v.y = t.y;
+    } else v = *p;
+    const v2f sc = {L16_SCALE, L16_SCALE};
+    cx r;
+    r.re = v2f{(float)(short)(v.x & 0xffffu), (float)((int)v.x >> 16)} * sc;
+    r.im = v2f{(float)(short)(v.y & 0xffffu), (float)((int)v.y >> 16)} * sc;
+    return r;
 }
 __device__ __forceinline__ void stx(float4* p, cx v) { *p = make_float4(v.re.x, v.re.y, v.im.x, v.im.y); }
 __device__ __forceinline__ void stx_nt(float4* p, cx v) {
@@ -126,6 +144,7 @@ __device__ __forceinline__ void reconstruct(cx (&acc)[12], const cx (&chi0)[3], 
 
 struct PairArgs {
     const float4* gauge;      // rows 0, 1 of every link, pair layout
+    const uint2* gauge16;     // H16 instances: the same elements as four int16 (ldx16)
     float4* dst[2];           // out, or r in update mode (read and written)
     const float4* in[2];
     const float4* xin[2];
@@ -238,7 +257,7 @@ __device__ __forceinline__ void apply_sign(cx (&h0)[3], cx (&h1)[3], v2f sign) {
     }
 }
 
-template <int MU, bool DAG, bool NTB, bool DOT = false>
+template <int MU, bool DAG, bool NTB, bool DOT = false, bool H16 = false>
 __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][64], int lane, float al_upd, v2f& nrm, v2f& dre, v2f& dim) {
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;
@@ -270,10 +289,11 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
         cx sp[NS], u[9];
         const float4* ps = boff(s.p ? a.in[0] : a.in[1], s.nf);
         const float4* pu = boff(a.gauge + (s.p ? gpar : 0), s.uf);
+        const uint2* pu16 = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.gauge16 + (s.p ? gpar : 0)) + (s.uf >> 1));
 #pragma unroll
         for (int j = 0; j < NS; j++) sp[j] = ldx(ps + (FF + j) * 64);
 #pragma unroll
-        for (int j = 0; j < 6; j++) u[j] = ldx(pu + j * 64);
+        for (int j = 0; j < 6; j++) u[j] = H16 ? ldx16<false>(pu16 + j * 64) : ldx(pu + j * 64);
         if (MU == 3 && s.swf) {
 #pragma unroll
             for (int j = 0; j < NS; j++) sp[j] = swap_slots(sp[j]);
@@ -290,10 +310,11 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
         cx sp[NS], u[9];
         const float4* ps = boff(s.p ? a.in[0] : a.in[1], s.nb);
         const float4* pu = boff(a.gauge + (s.p ? 0 : gpar), s.ub);
+        const uint2* pu16 = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.gauge16 + (s.p ? 0 : gpar)) + (s.ub >> 1));
 #pragma unroll
         for (int j = 0; j < NS; j++) sp[j] = ldx(ps + (FB + j) * 64);
 #pragma unroll
-        for (int j = 0; j < 6; j++) u[j] = NTB ? ldx_nt(pu + j * 64) : ldx(pu + j * 64);
+        for (int j = 0; j < 6; j++) u[j] = H16 ? ldx16<NTB>(pu16 + j * 64) : (NTB ? ldx_nt(pu + j * 64) : ldx(pu + j * 64));
         if (MU == 3 && s.swb) {
 #pragma unroll
             for (int j = 0; j < NS; j++) sp[j] = swap_slots(sp[j]);
@@ -353,7 +374,7 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
     }
 }
 
-template <bool DAG, bool NTB, bool DOT = false>
+template <bool DAG, bool NTB, bool DOT = false, bool H16 = false>
 __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
     __shared__ float4 part[4][12][64];  // 48 KiB
     __shared__ double red[DOT ? 12 : 4];
@@ -363,10 +384,10 @@ __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
     const int lane = threadIdx.x & 63;
     v2f nrm = splat(0.f), dre = splat(0.f), dim = splat(0.f);
     switch (w) {
-    case 0: pair_wave<0, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 1: pair_wave<1, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 2: pair_wave<2, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
-    default: pair_wave<3, DAG, NTB, DOT>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 0: pair_wave<0, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 1: pair_wave<1, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 2: pair_wave<2, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
+    default: pair_wave<3, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
     }
     if constexpr (DOT) {                // three sums per workgroup (both slots of a lane), the order of the fp64 kernels' dot epilogue
         const double di = (double)dim.x + (double)dim.y;
@@ -428,6 +449,19 @@ __global__ __launch_bounds__(256) void cvt_gauge12_pair32(float4* __restrict__ d
     }
 }
 
+// links as int16: the same element order, 8 bytes per element
+__global__ __launch_bounds__(256) void cvt_gauge12_pair16(uint2* __restrict__ dst, const double2* __restrict__ src12, int Vh, int nch, int nchp) {
+    const size_t n = (size_t)2 * nchp * 4 * 6 * 64;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const int lane = (int)(t & 63), e = (int)((t >> 6) % 6), mu = (int)((t / 384) % 4), chp = (int)((t / 1536) % nchp), p = (int)(t / ((size_t)1536 * nchp));
+        const int iA = chp * 64 + lane, iB = iA + Vh / 2;
+        const double2 a = src12[((((size_t)p * nch + (iA >> 6)) * 4 + mu) * 6 + e) * 64 + (iA & 63)];
+        const double2 b = src12[((((size_t)p * nch + (iB >> 6)) * 4 + mu) * 6 + e) * 64 + (iB & 63)];
+        auto q = [](double v) { return (unsigned)(__double2int_rn(fmin(fmax(v, -1.0), 1.0) * 32767.0) & 0xffff); };
+        dst[t] = make_uint2(q(a.x) | (q(b.x) << 16), q(a.y) | (q(b.y) << 16));
+    }
+}
+
 }  // namespace pair32
 
 // ------------------------------------------------------------------------------------------ host side
@@ -462,6 +496,13 @@ int pair32_cvt_gauge12(lqcd_ctx_s* c, float2* dst, const double2* src12) {
     return LQCD_OK;
 }
 
+int pair32_cvt_gauge16(lqcd_ctx_s* c, void* dst, const double2* src12) {
+    const Geom& g = c->geom;
+    hipLaunchKernelGGL(pair32::cvt_gauge12_pair16, dim3(stream_grid(c, (size_t)g.nch * 1536)), dim3(256), 0, c->stream, (uint2*)dst, src12, g.Vh, g.nch, g.nch / 2);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
 // the launcher behind stencil_apply for StencilCall::prec == 2 (fields in pair layout; full-lattice applications only)
 int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     using namespace pair32;
@@ -471,6 +512,7 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     const Geom& g = c->geom;
     PairArgs a;
     a.gauge = (const float4*)s.gauge12;
+    a.gauge16 = (const uint2*)s.gauge16;
     const bool upd = s.upd_scal != nullptr;
     for (int p = 0; p < 2; p++) { a.dst[p] = (float4*)(upd ? s.upd[p] : s.out[p]); a.in[p] = (const float4*)s.in[p]; a.xin[p] = (const float4*)s.xin[p]; }
     for (int p = 0; p < 2; p++) { a.xacc[p] = upd ? (float4*)s.xacc[p] : nullptr; a.pacc[p] = upd ? (const float4*)s.pacc[p] : nullptr; }
@@ -497,15 +539,13 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     a.d_ty = make_fastdiv(std::max(1, a.ty)); a.d_cpp = make_fastdiv(std::max(1, a.cpp));
     const dim3 grid(s.parity_mode == 2 ? pair32_num_blocks(c) : pair32_num_blocks(c) / 2), block(256);
     const bool ntb = (c->tun.nt_gauge & 1) != 0;
-    if (s.dot_partial) {
-        if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<true, true, true>), grid, block, 0, c->stream, a);
-                        else hipLaunchKernelGGL((wilson_dirsplit_pair32<true, false, true>), grid, block, 0, c->stream, a); }
-        else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<false, true, true>), grid, block, 0, c->stream, a);
-               else hipLaunchKernelGGL((wilson_dirsplit_pair32<false, false, true>), grid, block, 0, c->stream, a); }
-    } else if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<true, true>), grid, block, 0, c->stream, a);
-                    else hipLaunchKernelGGL((wilson_dirsplit_pair32<true, false>), grid, block, 0, c->stream, a); }
-    else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_pair32<false, true>), grid, block, 0, c->stream, a);
-           else hipLaunchKernelGGL((wilson_dirsplit_pair32<false, false>), grid, block, 0, c->stream, a); }
+    auto go = [&](auto dag, auto nt, auto dot, auto h16) {
+        hipLaunchKernelGGL((wilson_dirsplit_pair32<decltype(dag)::value, decltype(nt)::value, decltype(dot)::value, decltype(h16)::value>), grid, block, 0, c->stream, a);
+    };
+    auto pick = [&](auto dag, auto nt, auto dot) { if (a.gauge16) go(dag, nt, dot, std::true_type()); else go(dag, nt, dot, std::false_type()); };
+    auto pick2 = [&](auto dag, auto nt) { if (s.dot_partial) pick(dag, nt, std::true_type()); else pick(dag, nt, std::false_type()); };
+    auto pick3 = [&](auto dag) { if (ntb) pick2(dag, std::true_type()); else pick2(dag, std::false_type()); };
+    if (s.dagger) pick3(std::true_type()); else pick3(std::false_type());
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Even-odd BiCGStab probe (config 3 lattice by default): where an iteration's time goes in each form of the chain (tunable bicg_fused), and the first
-iteration at which two forms differ.  usage: bicg_probe.py [mode ...] [--L x,y,z,t] [--diff] [--reps n]"""
+iteration at which two forms differ.  usage: bicg_probe.py [mode ...] [--L x,y,z,t] [--diff] [--reps n] [--kappa k] [--csw c] [--set key=value ...]"""
 import os
 import sys
 
@@ -22,7 +22,12 @@ while "--set" in args:      # --set key=value: library tunable
     lat.set_param(k, int(v))
     del args[i:i + 2]
 csw = float(args[args.index("--csw") + 1]) if "--csw" in args else 0.0
-D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover" if csw else "Wilson", "Clover_coefficient": csw, "κ": 0.141139, "eps_CG": 1e-16, "MaxCGstep": 3000})
+kappa = float(args[args.index("--kappa") + 1]) if "--kappa" in args else 0.141139
+for opt in ("--L", "--reps", "--csw", "--kappa"):      # (what is left are the one-digit modes)
+    if opt in args:
+        i = args.index(opt)
+        del args[i:i + 2]
+D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover" if csw else "Wilson", "Clover_coefficient": csw, "κ": kappa, "eps_CG": 1e-16, "MaxCGstep": 3000})
 D.method_CG = "bicgstab_evenodd"
 b = lq.Fermionfields(lat, lq.WILSON)
 lq.gauss_distribution_fermion_(b, 112)

@@ -321,11 +321,14 @@ def test_mixed_precision_evenodd_bicgstab_wilson_clover(gpu, orc):
     assert abs(S1 - S0) < 1e-10 * abs(S0) and rel_err(G1.download(), G0.download()) < 1e-8
 
 
+@pytest.mark.parametrize("links16,reliable", [(1, 1), (0, 0), (1, 0), (0, 1)])
 @pytest.mark.parametrize("L,dagger", [((8, 8, 8, 16), False), ((16, 16, 16, 32), True)])
-def test_mixed_precision_evenodd_bicgstab_keeps_the_stopping_rule(gpu, orc, L, dagger):
+def test_mixed_precision_evenodd_bicgstab_keeps_the_stopping_rule(gpu, orc, L, dagger, links16, reliable):
     """Tunable bicg_mixed: the even-odd BiCGStab of the plain Wilson operator with an fp32 inner chain (same fused structure as the fp64 one) inside an
     fp64 defect correction.  Contract of lqcd_solve_bicgstab_eo unchanged: r.r < eps for the TRUE fp64 residual -- recomputed here by the oracle --
-    and the fp64 solver's solution to solver accuracy; at least two correction steps at eps = 1e-19 (an fp32 recurrence gives ~1e-6 per step)."""
+    and the fp64 solver's solution to solver accuracy; at least two correction steps at eps = 1e-19 (an fp32 recurrence gives ~1e-6 per step).
+    links16: the site-pair inner operator (16^3 x 32 here; 8^3 x 16 has no whole-chunk planes and keeps the one-site kernel) reads int16 links; reliable: the
+    fp32 chain goes on behind a correction step instead of starting again."""
     import os
     lq = gpu
     KAPPA = 0.141139
@@ -340,8 +343,12 @@ def test_mixed_precision_evenodd_bicgstab_keeps_the_stopping_rule(gpu, orc, L, d
     x64, x32 = b.similar(), b.similar()
     it64, rr64 = lq.solve_DinvX_(x64, Dd, b, return_info=True)
     lat.set_param("bicg_mixed", 1)
+    lat.set_param("mixed_links16", links16)
+    lat.set_param("bicg_reliable", reliable)
     it32, rr32 = lq.solve_DinvX_(x32, Dd, b, return_info=True)
     lat.set_param("bicg_mixed", 0)
+    lat.set_param("bicg_reliable", 0)
+    assert lat.get_param("pair32_active") == (1 if L[0] == 16 else 0)
     assert rr32 < 1e-19 and it32 >= it64           # the fp32 iterations of all correction steps together
     assert rel_err(x32.download(), x64.download()) < 1e-9
     orc.set_threads(os.cpu_count() or 1)
@@ -362,3 +369,29 @@ def test_mixed_precision_evenodd_bicgstab_keeps_the_stopping_rule(gpu, orc, L, d
     lq.calc_UdSfdU_(G1, fa, U, eta)
     lat.set_param("mixed_action_solver", 0)
     assert abs(S1 - S0) < 1e-10 * abs(S0) and rel_err(G1.download(), G0.download()) < 1e-8
+
+
+def test_int16_links_of_the_site_pair_operator(gpu, orc):
+    """mixed_links16 = 2: the fp32 site-pair kernel reads its links as int16 fixed point (n / 32767).  One application against the ORACLE's fp64 result: the error is
+    that of the 1.5e-5 link rounding (well above fp32's, well below a part in 1e4), D and D^+; with fp32 links the same call is fp32-accurate."""
+    lq = gpu
+    L, KAPPA = (16, 16, 16, 32), 0.141139
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    Uh = U.download()
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA})
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    bh = b.download()
+    out = b.similar()
+    for dagger in (False, True):
+        ref = orc.wilson_D(Uh, bh, L, KAPPA, 1.0, (1, 1, 1, -1), dagger)
+        Dd = D.adjoint() if dagger else D
+        err = {}
+        for l16 in (0, 2):
+            lat.set_param("mixed_links16", l16)
+            lq.mul_f32_(out, Dd, b)
+            assert lat.get_param("pair32_active") == 1
+            err[l16] = np.abs(out.download() - ref).max() / np.abs(ref).max()
+        lat.set_param("mixed_links16", 1)
+        assert err[0] < 1e-6 and 1e-6 < err[2] < 1e-4, err
