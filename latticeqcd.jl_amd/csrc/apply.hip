@@ -454,6 +454,7 @@ extern "C" int lqcd_op_destroy(lqcd_op_t op) {
     if (op->clover_tmp) lqcd_spinor_destroy(op->clover_tmp);
     if (op->dw_wilson) lqcd_op_destroy(op->dw_wilson);
     for (lqcd_spinor_s* w : op->dw_work) if (w) lqcd_spinor_destroy(w);
+    (void)hipFree(op->dw_partial);
     delete op;
     return LQCD_OK;
 }

@@ -362,6 +362,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "lazy_links")) return &c->tun.lazy_links;
     if (!strcmp(key, "lazy_merge")) return &c->tun.lazy_merge;
     if (!strcmp(key, "dw_batched")) return &c->tun.dw_batched;
+    if (!strcmp(key, "dw_fused_cg")) return &c->tun.dw_fused_cg;
     if (!strcmp(key, "bicg_fused")) return &c->tun.bicg_fused;
     if (!strcmp(key, "gauge_delta")) return &c->tun.gauge_delta;
     if (!strcmp(key, "dslash_s18")) return &c->tun.dslash_s18;

@@ -111,16 +111,100 @@ int dw_work(lqcd_op_s* op, int i, lqcd_spinor_s** out) {
     return LQCD_OK;
 }
 
-// x = (D5(mass)^+ D5(mass))^-1 b from a zero guess
-int dw_solve(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double mass, double eps, int maxiter, int* iters, double* rr) {
+// the batched call of dw_apply_raw (all slices in one launch), or false where it does not apply
+bool dw_batched_call(lqcd_op_s* op, double2* out, const double2* in, int dagger, double mass, StencilCall& sc) {
+    lqcd_ctx_s* c = op->ctx;
+    if (!c->tun.dw_batched) return false;
+    lqcd_op_s* w = op->dw_wilson;
+    w->gauge = op->gauge;
+    const size_t slice = (size_t)12 * c->geom.Vs * 2;
+    lqcd_spinor_s vi, vo;
+    vi.ctx = vo.ctx = c; vi.kind = vo.kind = LQCD_WILSON; vi.subset = vo.subset = LQCD_FULL; vi.ncomp = vo.ncomp = 12;
+    vi.elems = vo.elems = slice; vi.owner = vo.owner = false;
+    vi.data = const_cast<double2*>(in);
+    vo.data = out;
+    if (make_full_call(w, &vo, &vi, dagger, sc) != LQCD_OK) return false;
+    sc.a = 5.0 + op->dw_M;
+    sc.b = -0.5;
+    sc.dw_ls = op->L5; sc.dw_slice = slice; sc.dw_mass = mass;
+    return stencil_dw5_applies(c, sc);
+}
+
+// x = (D5(mass)^+ D5(mass))^-1 b from a zero guess.
+// Where the five-dimensional launch applies (tunable dw_fused_cg): the fused iteration of the four-dimensional CG (solvers.hip cg_enqueue_iteration, its plain form) --
+//     t = D p with |t|^2 partials in the epilogue (one per workgroup = chunk x slice) ;  alpha = rr / |t|^2 in the reduction launch ;
+//     D^+ t in update mode: r -= alpha (D^+ t), |r|^2 partials, q = D^+D p never written ;  beta and the stopping test in the reduction launch ;
+//     x += alpha p, p = r + beta p in one pass
+// = 5 launches and 5 vector passes beside the operator per iteration where cg_generic has 11 and 11.  Same recurrences and stopping rule (r.r < eps).
+int dw_solve(lqcd_op_s* op, lqcd_spinor_s* x, lqcd_spinor_s* b, double mass, double eps, int maxiter, int* iters, double* rr_out) {
     lqcd_ctx_s* c = op->ctx;
     lqcd_spinor_s *r, *p, *q, *t;
     LQCHK(dw_work(op, 0, &r)); LQCHK(dw_work(op, 1, &p)); LQCHK(dw_work(op, 2, &q)); LQCHK(dw_work(op, 3, &t));
-    ApplyFn A = [&](double2* out, const double2* in) -> int {
-        LQCHK(dw_apply_raw(op, t->data, in, 0, mass));
-        return dw_apply_raw(op, out, t->data, 1, mass);
-    };
-    return cg_generic(c, A, x->elems, x->data, b->data, r->data, p->data, q->data, eps, maxiter, iters, rr);
+    StencilCall probe;
+    const bool fused = c->tun.dw_fused_cg && c->tun.cg_fused >= 2 && !c->has_comm && dw_batched_call(op, t->data, p->data, 0, mass, probe);
+    if (!fused) {
+        ApplyFn A = [&](double2* out, const double2* in) -> int {
+            LQCHK(dw_apply_raw(op, t->data, in, 0, mass));
+            return dw_apply_raw(op, out, t->data, 1, mass);
+        };
+        return cg_generic(c, A, x->elems, x->data, b->data, r->data, p->data, q->data, eps, maxiter, iters, rr_out);
+    }
+    const size_t n = x->elems, slice = (size_t)12 * c->geom.Vs * 2;
+    const int nparts = stencil_num_blocks(c, LQCD_WILSON, 1.0, 2, 0, false) * op->L5;
+    if (op->dw_partial_n < (size_t)nparts) {
+        if (op->dw_partial) HIPCHK(hipFree(op->dw_partial));
+        op->dw_partial = nullptr; op->dw_partial_n = 0;
+        HIPCHK(hipMalloc((void**)&op->dw_partial, (size_t)nparts * sizeof(double)));
+        op->dw_partial_n = (size_t)nparts;
+    }
+    // r = b - D^+D x ; p = r
+    LQCHK(dw_apply_raw(op, t->data, x->data, 0, mass));
+    LQCHK(dw_apply_raw(op, q->data, t->data, 1, mass));
+    HIPCHK(hipMemcpyAsync(r->data, b->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    LQCHK(blas_axpy(c, -1.0, 0.0, q->data, r->data, n));
+    HIPCHK(hipMemcpyAsync(p->data, r->data, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    double rr = 0;
+    LQCHK(blas_norm2(c, r->data, n, &rr, true));
+    double init[9] = {rr, 0, 0, 0, 0, 0, eps, 0, 0};   // S_RR .. S_XDONE
+    HIPCHK(hipMemcpyAsync(c->d_scal + S_RR, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int it = 0;
+    bool converged = rr < eps;
+    const int check_every = 8;
+    auto upd_ptr = [&](lqcd_spinor_s* f, int par) { return f->data + (size_t)par * (slice / 2); };
+    while (!converged && it < maxiter) {
+        const int burst = std::min(check_every, maxiter - it);
+        for (int k = 0; k < burst; k++) {
+            apply_bc(c, op->bc);
+            StencilCall s1;
+            if (!dw_batched_call(op, t->data, p->data, 0, mass, s1)) { set_error("Domainwall CG: the five-dimensional launch stopped applying inside a solve"); return LQCD_ERR_UNSUPPORTED; }
+            s1.norm_partial = op->dw_partial;
+            s1.skip_flag = c->d_scal;
+            LQCHK(stencil_apply(c, s1));
+            LQCHK(reduce_to_slot(c, nparts, 1, S_PQ, true, 1, op->dw_partial));          // + alpha = rr / pq
+            StencilCall s2;
+            if (!dw_batched_call(op, q->data, t->data, 1, mass, s2)) { set_error("Domainwall CG: the five-dimensional launch stopped applying inside a solve"); return LQCD_ERR_UNSUPPORTED; }
+            s2.norm_partial = op->dw_partial;
+            s2.upd_scal = c->d_scal;
+            s2.upd[0] = upd_ptr(r, 0); s2.upd[1] = upd_ptr(r, 1);                         // slice 0 of r; the launch adds the slice offsets
+            LQCHK(stencil_apply(c, s2));
+            LQCHK(reduce_to_slot(c, nparts, 1, S_RRNEW, true, 2, op->dw_partial));       // + beta, stopping test, iteration count
+            LQCHK(cg_launch_update_xp(c, x->data, p->data, r->data, n));
+        }
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RR, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rr = c->h_scal[0];
+        it = (int)c->h_scal[S_ITERS - S_RR];
+        if (c->h_scal[S_DONE - S_RR] != 0.0) converged = true;
+        if (!std::isfinite(rr)) { set_error("CG: residual is not finite"); return LQCD_ERR_NOT_CONVERGED; }
+    }
+    if (iters) *iters = it;
+    if (rr_out) *rr_out = rr;
+    if (!converged) {
+        set_error("The CG is not converged! maxsteps = " + std::to_string(maxiter) + ", residual = " + std::to_string(rr));
+        return LQCD_ERR_NOT_CONVERGED;
+    }
+    return LQCD_OK;
 }
 
 }  // namespace

@@ -542,6 +542,8 @@ struct Tunables {
                               // context
     int dw_batched = 1;       // Domainwall operator: the L5 slices of an application as one launch of the scalar-addressing Wilson kernel with the fifth-direction hops in its
                               // epilogue (where that kernel applies: fp64, one GPU, z-planes of whole chunks); 0: L5 Wilson launches + one fifth-direction pass
+    int dw_fused_cg = 1;      // Domainwall solves: 1 = the fused CG iteration of the four-dimensional operators on the five-dimensional launch (|D p|^2 partials in D's epilogue,
+                              // r -= alpha D^+ t in D^+'s, x / p update in one pass: 5 vector passes and 5 launches per iteration instead of 11 and 11); 0: cg_generic
     int dw_active = 0;        // read-only: the last Domainwall application ran as one five-dimensional launch
     int lazy_merge = 2;       // (with lazy_links) a complete link update U <- exp(a P) U waits; the next one of the same U, P with nothing in between that reads U or
                               // writes P adds its step: exp(b P) exp(a P) = exp((a + b) P), one pass instead of two (the back-to-back half steps of
@@ -869,6 +871,8 @@ struct lqcd_op_s {
     double dw_M = 0.0;
     lqcd_op_s* dw_wilson = nullptr;
     lqcd_spinor_s* dw_work[8] = {};
+    double* dw_partial = nullptr;       // |.|^2 partials of the five-dimensional launch: one per workgroup = chunk x slice (domainwall.hip dw_solve)
+    size_t dw_partial_n = 0;
 };
 
 namespace lqcd {

@@ -100,6 +100,8 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
 // CG for a Hermitian positive operator given as an enqueue function (solvers.hip); x holds the initial guess, r, p, q: work of n elements
 int cg_generic(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* r, double2* p, double2* q, double eps,
                int maxiter, int* iters, double* final_rr);
+// solvers.hip: the fused tail of a CG iteration, x += alpha p ; p = r + beta p (device scalars; a no-op behind the converging iteration), on raw buffers
+int cg_launch_update_xp(lqcd_ctx_s* c, double2* x, double2* p, const double2* r, size_t n);
 // domainwall.hip: the five-dimensional operator behind the entry points of the four-dimensional ones
 int dw_op_apply(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in, int dagger);
 int dw_op_apply_DdagD(lqcd_op_s* op, lqcd_spinor_s* out, lqcd_spinor_s* in);

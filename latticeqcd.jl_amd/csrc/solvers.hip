@@ -1279,6 +1279,12 @@ extern "C" int lqcd_solve_cg_DdagD_fixed(lqcd_op_t op, lqcd_spinor_t x, lqcd_spi
 // CG with device-resident scalars for a Hermitian positive operator given as an enqueue function (reference form:
 // alpha = rr / <p, A p>); x holds the initial guess, work = three fields of n elements.  Used where the fused full-lattice
 // iteration of cg_run does not apply (parity blocks).
+int lqcd::cg_launch_update_xp(lqcd_ctx_s* c, double2* x, double2* p, const double2* r, size_t n) {
+    hipLaunchKernelGGL(cg_update_xp, dim3(stream_grid(c, n)), dim3(UB), 0, c->stream, c->d_scal, x, p, r, n);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+
 int lqcd::cg_generic(lqcd_ctx_s* c, const ApplyFn& A, size_t n, double2* x, const double2* b, double2* r, double2* p, double2* q, double eps,
                      int maxiter, int* iters, double* final_rr) {
     LQCHK(A(q, x));

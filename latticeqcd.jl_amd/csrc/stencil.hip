@@ -1835,7 +1835,7 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             const bool ntb = (k.nt & 1) != 0;
 #ifndef LQCD_F32
             if (s.dw_ls > 1) {      // Domainwall: the L5 slices in one launch, fifth-direction hops in the epilogue (plain loads for the backward link: it is re-used by the next slice)
-                if (c->tun.dslash_pipe != 2 || delta || k.upd_scal || k.norm_partial) { set_error("stencil: the five-dimensional launch needs the scalar-addressing kernel in its plain mode"); return LQCD_ERR_UNSUPPORTED; }
+                if (c->tun.dslash_pipe != 2 || delta) { set_error("stencil: the five-dimensional launch needs the scalar-addressing kernel in its plain mode"); return LQCD_ERR_UNSUPPORTED; }
                 const dim3 g5((unsigned)k.nblocks * (unsigned)s.dw_ls);
                 if (!k.gauge12) { set_error("stencil: the five-dimensional launch reads the 12-real links"); return LQCD_ERR_UNSUPPORTED; }      // (its 18-real instance spills 154 VGPRs)
                 if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, false, false, true>), g5, pb, 0, c->stream, a);
@@ -2018,7 +2018,7 @@ int wilson_pipe_grid(lqcd_ctx_s* c, int nvirt, int prec) {
 // the L5 slices of a Domainwall application as ONE launch of the scalar-addressing kernel: fp64, one GPU, full-lattice plain mode, 12-real links (fields on the group)
 bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s) {
     if (kF32Build || s.prec != 0 || s.kind != LQCD_WILSON || s.r != 1.0 || s.parity_mode != 2 || any_partitioned(c)) return false;
-    if (s.upd_scal || s.norm_partial || s.alpha_partials || s.dot_partial || s.clover || s.clover_on_hop || s.gauge12_delta || s.skip_flag) return false;
+    if (s.alpha_partials || s.dot_partial || s.clover || s.clover_on_hop || s.gauge12_delta) return false;      // (|.|^2 partials -- one per workgroup = chunk x slice -- and the update mode ride along: dw_solve)
     if (c->tun.dslash_pipe != 2 || !s.gauge12) return false;
     return wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false);
 }

@@ -30,5 +30,18 @@ for L, L5 in cases:
     # bytes a five-dimensional site needs at least: psi in + out 384, links 384 / L5 (12-real, shared by the slices)
     print("sets", sets, "L", L, "L5", L5, "D5 ms one launch %.4f / slice by slice %.4f; one launch: %.0f GB/s on (384 + 384/L5) B per 5-d site" %
           (out[1], out[0], V5 * (384 + 384 / L5) / out[1] / 1e6))
+    lat.set_param("dw_batched", 1)
+    if L[0] == 16:      # the CG on D^+D: fused iteration on the five-dimensional launch vs the generic loop (fixed number of iterations: eps unreachable)
+        D2 = lq.Dirac_operator(U, x, {"Dirac_operator": "Domainwall", "mass": 0.05, "L5": L5, "M": -1.8, "eps_CG": 1e-60, "MaxCGstep": 40})
+        for fused in (1, 0, 1, 0):
+            lat.set_param("dw_fused_cg", fused)
+            lq.clear_fermion_(y)
+            t0 = time.perf_counter()
+            try:
+                lq.solve_DinvX_(y, lq.DdagD_operator(D2), x)
+            except lq.NotConverged:
+                pass
+            print("   CG on D^+D, dw_fused_cg %d: %.3f ms per iteration (40 iterations, setup included)" % (fused, 1e3 * (time.perf_counter() - t0) / 40))
+        D2.close()
     for o in (y, x, D, U):
         o.close()

@@ -91,6 +91,32 @@ def test_cg_solution_matches_the_oracle(lq, orc):
     assert np.vdot(res, res).real < 4e-19                              # the true residual of the device solution, by the oracle's operator
 
 
+def test_fused_cg_on_the_five_dimensional_launch(lq, orc):
+    """dw_fused_cg: where all slices go through one launch the CG runs the fused iteration of the four-dimensional solver (|D p|^2 and the update r -= alpha D^+ t in the
+    operator's epilogues, one partial per chunk and slice).  Against the oracle's CG and against the generic 11-pass loop: same solution, same count, true residual < eps."""
+    L, L5, M, mass = (16, 8, 8, 8), 4, -1.0, 0.1
+    Uh, lat, U, b, D = _setup(lq, orc, L, L5, M, mass)
+    bh = _rand5(orc, L, L5, 4)
+    b.upload(bh)
+    got = {}
+    for fused in (1, 0):
+        lat.set_param("dw_fused_cg", fused)
+        x = b.similar()
+        it, rr = lq.solve_DinvX_(x, lq.DdagD_operator(D), b, return_info=True)
+        assert lat.get_param("dw_active") == 1 and rr < 1e-19
+        got[fused] = (it, x.download())
+    lat.set_param("dw_fused_cg", 1)
+    assert abs(got[1][0] - got[0][0]) <= 1 and rel_err(got[1][1], got[0][1]) < 1e-10
+    orc.set_threads(os.cpu_count() or 1)
+    try:
+        xo, ito, rro = orc.domainwall_cg(Uh, bh, L, M, mass, BC, eps=1e-19)
+        res = bh - orc.domainwall_D(Uh, orc.domainwall_D(Uh, got[1][1], L, M, mass, BC), L, M, mass, BC, dagger=True)
+    finally:
+        orc.set_threads(1)
+    assert abs(got[1][0] - ito) <= 2 and rel_err(got[1][1], xo) < 1e-9
+    assert np.vdot(res, res).real < 4e-19
+
+
 def test_action_heat_bath_and_force(lq, orc):
     L, L5, M, mass = (4, 4, 4, 4), 4, -1.0, 0.2
     Uh, lat, U, phi, D = _setup(lq, orc, L, L5, M, mass, eps_CG=1e-22)
