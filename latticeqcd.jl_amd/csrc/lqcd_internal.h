@@ -864,7 +864,7 @@ struct lqcd_op_s {
     double2* clover_inv = nullptr;      // A^-1 in the same packed format (even-odd solver), built on first use
     uint64_t clover_inv_version = 0;
     double2* clover_lambda = nullptr;   // six Hermitian 3x3 matrices per site: scratch of the clover force
-    int bicg32_hint[4] = {0, 0, 0, 0};  // mixed-precision chain: iterations the last solve's correction steps took, per step (mixed.hip)
+    int bicg32_hint[2][4] = {};         // mixed-precision chain: iterations the last solve's correction steps took, per step, for D and D^+ apart (the action solves alternate) (mixed.hip)
     int bicg_hint = 0;                  // iterations the last even-odd BiCGStab solve with this operator took (polling schedule of the next one)
     // LQCD_DOMAINWALL (domainwall.hip): km = the fermion mass m; the 4-D Wilson operator of the slices (hop coefficient 1/2), five-dimensional work fields
     int L5 = 0;
@@ -1011,7 +1011,7 @@ int launch_fermion_force(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_ga
 // stencil_pair32.hip: fp32 Wilson Dslash on site pairs (StencilCall::prec == 2) and the conversions of its field layout
 bool pair32_geometry_ok(lqcd_ctx_s* c);
 int pair32_num_blocks(lqcd_ctx_s* c);
-int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar = 2);      // npar = 1: one parity block
+int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar = 2, float2* dst2 = nullptr, float2* dst3 = nullptr, float2* xzero = nullptr);      // npar = 1: one parity block
 int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a, int npar = 2);
 int pair32_cvt_gauge12(lqcd_ctx_s* c, float2* dst, const double2* src12);
 int pair32_cvt_gauge16(lqcd_ctx_s* c, void* dst, const double2* src12);

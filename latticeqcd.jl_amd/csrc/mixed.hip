@@ -76,6 +76,25 @@ __global__ __launch_bounds__(MB) void axpy_from_f32(double2* __restrict__ y, con
         y[i] = yv;
     }
 }
+// |a|^2 and |b|^2 block partials, two per block
+__global__ __launch_bounds__(MB) void norm2_two_kernel(const double2* __restrict__ a, const double2* __restrict__ b, size_t n, double* partial) {
+    __shared__ double red[2][MB / 64];
+    double sa = 0, sb = 0;
+    for (size_t i = (size_t)blockIdx.x * MB + threadIdx.x; i < n; i += (size_t)gridDim.x * MB) {
+        const double2 u = a[i], v = b[i];
+        sa = fma(u.x, u.x, sa); sa = fma(u.y, u.y, sa);
+        sb = fma(v.x, v.x, sb); sb = fma(v.y, v.y, sb);
+    }
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < MB / 64; w++) t += red[threadIdx.x][w];
+        partial[2 * blockIdx.x + threadIdx.x] = t;
+    }
+}
 // r = b - q - sigma x  (fp64) with |r|^2 block partials  (sigma = 0: x is not read)
 __global__ __launch_bounds__(MB) void residual_kernel(double2* __restrict__ r, const double2* __restrict__ b, const double2* __restrict__ q,
                                                        const double2* __restrict__ x, double sigma, size_t n, double* partial) {
@@ -589,7 +608,7 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
 // e ~ M^-1 rhs32 (|rhs32|^2 = 1, zero guess) until the recursive residual is below eps2; m.r holds rhs32 on entry
 // cont (reliable update, tunable bicg_reliable): m.r holds the true residual in the units of the chain's first right-hand side; the chain keeps p, v, r0 and its scalars,
 // x starts again at 0, <r0, r> is formed with the new r and p = r + beta (p - omega v) as the iteration that stopped would have done; *iters counts from the restart
-static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters, bool cont = false, int first_burst = 0, int* full_stop = nullptr) {
+static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters, bool cont = false, int first_burst = 0, int* full_stop = nullptr, bool pre_init = false) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n4 = (size_t)6 * c->geom.Vh, b32 = nh * sizeof(float2);      // the sites only: the padding chunk of a parity block is not part of a pair field
     const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : (c->geom.Vh + 63) / 64;      // (dot instances: one workgroup per 64-site chunk, whatever dslash_pipe says)
@@ -597,11 +616,13 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
     double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)3 * nbs;
     const double* skip = c->d_scal + (B_DONE - S_DONE);
-    HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));
+    if (!pre_init) HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));      // (pre_init: the conversion that made m.r also set x = 0, r0 = p = r)
     int it = 0, enq = 0;
     if (!cont) {
-        HIPCHK(hipMemcpyAsync(m.r0, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(m.p, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
+        if (!pre_init) {
+            HIPCHK(hipMemcpyAsync(m.r0, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(m.p, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
+        }
         double init[B_END - B_RHO] = {0};
         init[B_RHO - B_RHO] = 1.0; init[B_RHOB - B_RHO] = 1.0; init[B_EPS - B_RHO] = eps2; init[B_RES - B_RHO] = 1.0;
         HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
@@ -692,11 +713,17 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         return LQCD_OK;
     };
     double rr = 0, xx = 0;
-    LQCHK(blas_norm2(c, xe.data, nh, &xx, true));
-    if (xx == 0.0) {      // zero guess (what the action solves pass): r = rhs, no Schur application needed
-        HIPCHK(hipMemcpyAsync(r->data, rhs->data, nh * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-        LQCHK(blas_norm2(c, rhs->data, nh, &rr, true));
-    } else LQCHK(true_residual(&rr));
+    {      // |x|^2 and |rhs|^2 in one launch and one read-back
+        hipLaunchKernelGGL(norm2_two_kernel, dim3(nb), dim3(MB), 0, c->stream, (const double2*)xe.data, (const double2*)rhs->data, nh, c->d_partial);
+        HIPCHK(hipGetLastError());
+        LQCHK(reduce_to_slot(c, nb, 2, S_RED0, true, 0));
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        xx = c->h_scal[0]; rr = c->h_scal[1];
+    }
+    const double2* rsrc = r->data;      // the fp64 residual the next correction step converts
+    if (xx == 0.0) rsrc = rhs->data;    // zero guess (what the action solves pass): r = rhs, no Schur application, no copy
+    else LQCHK(true_residual(&rr));
     int total = 0, outer = 0, chain_it = 0, live = 0;
     double scale0 = 1.0;
     // digits one correction step can gain: six with fp32 links; the int16 links of mixed_links16 differ from the true ones by 1.5e-5 per real, which the
@@ -711,15 +738,17 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         // in place of the recursive one; otherwise a new chain on the normalised residual
         const bool cont = live && c->tun.bicg_reliable;
         if (!cont) { scale0 = 1.0 / std::sqrt(rr); chain_it = 0; }
-        if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, r->data, scale0, 1));
-        else LQCHK(to_f32(c, 1, m.r, r->data, nh, scale0));
+        const bool pre_init = m.layout == 2 && !cont;      // a new chain on site pairs: r, r0 = r, p = r and x = 0 in the one pass of the conversion
+        if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, rsrc, scale0, 1, pre_init ? m.r0 : nullptr, pre_init ? m.p : nullptr, pre_init ? m.x : nullptr));
+        else LQCHK(to_f32(c, 1, m.r, rsrc, nh, scale0));
+        rsrc = r->data;
         int it = chain_it;
-        const int hint = op->bicg32_hint[std::min(outer, 3)];
-        LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol * rr * scale0 * scale0, chain_it + (maxiter - total), &it, cont, hint, &live));
+        const int hint = op->bicg32_hint[dg ? 1 : 0][std::min(outer, 3)];
+        LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol * rr * scale0 * scale0, chain_it + (maxiter - total), &it, cont, hint, &live, pre_init));
         const int step_its = it - chain_it;
         total += step_its;
         chain_it = it;
-        op->bicg32_hint[std::min(outer, 3)] = step_its;
+        op->bicg32_hint[dg ? 1 : 0][std::min(outer, 3)] = step_its;
         if (m.layout == 2) LQCHK(pair32_axpy_to_f64(c, xe.data, m.x, 1.0 / scale0, 1));
         else LQCHK(add_from_f32(c, 1, xe.data, m.x, 1.0 / scale0, nh));
         double rrn = 0;

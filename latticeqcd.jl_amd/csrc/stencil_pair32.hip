@@ -413,13 +413,21 @@ __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
 // ------------------------------------------------------------------------------------------ layout conversions
 // pair (p, i) of the half lattice <-> sites (p, i) and (p, i + Vh/2) of the full lattice; blk64 = fp64 elements of one parity block
 // (a parity block of either field is blk64 elements of its own type apart: the padding chunk of the fp64 layout stays unused in the pair field)
-__global__ __launch_bounds__(256) void cvt_wilson_to_pair32(float4* __restrict__ dst, const double2* __restrict__ src, int Vh, int nchp, size_t blk64, double scale, int npar) {
+// dst2 / dst3 (may be null): two more copies of the converted field, xzero (may be null): a field of the same shape set to zero -- the start of an fp32 BiCGStab chain
+// (r, r0 = r, p = r, x = 0) in one pass over the fp64 residual
+__global__ __launch_bounds__(256) void cvt_wilson_to_pair32(float4* __restrict__ dst, const double2* __restrict__ src, int Vh, int nchp, size_t blk64, double scale, int npar,
+                                                            float4* __restrict__ dst2 = nullptr, float4* __restrict__ dst3 = nullptr, float4* __restrict__ xzero = nullptr) {
     const size_t n = (size_t)npar * nchp * 768;       // npar = 1: ONE parity block (the even-odd solver's half-lattice vectors; dst / src point at it)
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
         const int lane = (int)(t & 63), j = (int)((t >> 6) % 12), chp = (int)((t / 768) % nchp), p = (int)(t / ((size_t)768 * nchp));
         const int iA = chp * 64 + lane, iB = iA + Vh / 2;
         const double2 a = src[p * blk64 + (size_t)(iA >> 6) * 768 + j * 64 + (iA & 63)], b = src[p * blk64 + (size_t)(iB >> 6) * 768 + j * 64 + (iB & 63)];
-        dst[p * (blk64 / 2) + ((size_t)chp * 12 + j) * 64 + lane] = make_float4((float)(a.x * scale), (float)(b.x * scale), (float)(a.y * scale), (float)(b.y * scale));
+        const size_t o = p * (blk64 / 2) + ((size_t)chp * 12 + j) * 64 + lane;
+        const float4 v = make_float4((float)(a.x * scale), (float)(b.x * scale), (float)(a.y * scale), (float)(b.y * scale));
+        dst[o] = v;
+        if (dst2) dst2[o] = v;
+        if (dst3) dst3[o] = v;
+        if (xzero) xzero[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 // y (fp64, full lattice) += a * x (pairs)
@@ -475,10 +483,10 @@ bool pair32_geometry_ok(lqcd_ctx_s* c) {
 }
 int pair32_num_blocks(lqcd_ctx_s* c) { return c->geom.nch; }      // 2 parities x nch / 2 chunks of pairs
 
-int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar) {
+int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar, float2* dst2, float2* dst3, float2* xzero) {
     const Geom& g = c->geom;
     hipLaunchKernelGGL(pair32::cvt_wilson_to_pair32, dim3(stream_grid(c, (size_t)g.nch * 768)), dim3(256), 0, c->stream, (float4*)dst, src, g.Vh, g.nch / 2,
-                       (size_t)12 * g.Vs, scale, npar);
+                       (size_t)12 * g.Vs, scale, npar, (float4*)dst2, (float4*)dst3, (float4*)xzero);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
