@@ -1014,6 +1014,7 @@ int pair32_num_blocks(lqcd_ctx_s* c);
 int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double scale, int npar = 2, float2* dst2 = nullptr, float2* dst3 = nullptr, float2* xzero = nullptr);      // npar = 1: one parity block
 int pair32_axpy_to_f64(lqcd_ctx_s* c, double2* y, const float2* x, double a, int npar = 2);
 int pair32_cvt_gauge12(lqcd_ctx_s* c, float2* dst, const double2* src12);
+int pair32_residual(lqcd_ctx_s* c, float2* dst, const double2* rhs, const double2* q, double scale, float2* dst2, float2* dst3, float2* xzero, int* nb);
 int pair32_cvt_gauge16(lqcd_ctx_s* c, void* dst, const double2* src12);
 int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s);
 int stencil_apply(lqcd_ctx_s* c, const StencilCall& s);  // full sequence incl. halo exchange (RCCL path); s.prec selects the build

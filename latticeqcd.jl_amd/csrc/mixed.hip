@@ -605,10 +605,10 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
     if (z) { s2.dot_z[0] = (const double2*)z; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
     return stencil_apply(c, s2);
 }
-// e ~ M^-1 rhs32 (|rhs32|^2 = 1, zero guess) until the recursive residual is below eps2; m.r holds rhs32 on entry
+// e ~ M^-1 rhs32 (|rhs32|^2 = rho0, zero guess) until the recursive residual is below eps2; m.r holds rhs32 on entry
 // cont (reliable update, tunable bicg_reliable): m.r holds the true residual in the units of the chain's first right-hand side; the chain keeps p, v, r0 and its scalars,
 // x starts again at 0, <r0, r> is formed with the new r and p = r + beta (p - omega v) as the iteration that stopped would have done; *iters counts from the restart
-static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters, bool cont = false, int first_burst = 0, int* full_stop = nullptr, bool pre_init = false) {
+static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, double eps2, int maxiter, int* iters, bool cont = false, int first_burst = 0, int* full_stop = nullptr, bool pre_init = false, double rho0 = 1.0) {
     lqcd_ctx_s* c = op->ctx;
     const size_t n4 = (size_t)6 * c->geom.Vh, b32 = nh * sizeof(float2);      // the sites only: the padding chunk of a parity block is not part of a pair field
     const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : (c->geom.Vh + 63) / 64;      // (dot instances: one workgroup per 64-site chunk, whatever dslash_pipe says)
@@ -624,7 +624,7 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
             HIPCHK(hipMemcpyAsync(m.p, m.r, b32, hipMemcpyDeviceToDevice, c->stream));
         }
         double init[B_END - B_RHO] = {0};
-        init[B_RHO - B_RHO] = 1.0; init[B_RHOB - B_RHO] = 1.0; init[B_EPS - B_RHO] = eps2; init[B_RES - B_RHO] = 1.0;
+        init[B_RHO - B_RHO] = rho0; init[B_RHOB - B_RHO] = rho0; init[B_EPS - B_RHO] = eps2; init[B_RES - B_RHO] = rho0;      // rho_0 = <r0, r> = |r|^2 (1 for a normalised right-hand side)
         HIPCHK(hipMemcpyAsync(c->d_scal + B_RHO, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     } else {
         it = enq = *iters;      // iterations of the chain so far: iteration e reads rho from slot e & 1 and leaves the next one in the other
@@ -726,6 +726,10 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
     else LQCHK(true_residual(&rr));
     int total = 0, outer = 0, chain_it = 0, live = 0;
     double scale0 = 1.0;
+    // site pairs: the true residual behind a correction step is written straight into the fp32 fields of the next one (pair32_residual), scaled by an ESTIMATE of 1 / |r| --
+    // the chain's stopping threshold carries the exact norm, the recurrences do not care about the scale
+    bool have32 = false;
+    double scale_have = 1.0;
     // digits one correction step can gain: six with fp32 links; the int16 links of mixed_links16 differ from the true ones by 1.5e-5 per real, which the
     // inverse amplifies -- four and a half
     const double digits = (m.layout == 2 && m.gauge16) ? 4.5 : 6.0;
@@ -737,14 +741,16 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         // reliable update (bicg_reliable): the chain that stopped behind a whole iteration goes on -- same r0, p, v and scalars, same units (scale0) -- with the true residual
         // in place of the recursive one; otherwise a new chain on the normalised residual
         const bool cont = live && c->tun.bicg_reliable;
-        if (!cont) { scale0 = 1.0 / std::sqrt(rr); chain_it = 0; }
+        if (!cont) { scale0 = have32 ? scale_have : 1.0 / std::sqrt(rr); chain_it = 0; }
         const bool pre_init = m.layout == 2 && !cont;      // a new chain on site pairs: r, r0 = r, p = r and x = 0 in the one pass of the conversion
-        if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, rsrc, scale0, 1, pre_init ? m.r0 : nullptr, pre_init ? m.p : nullptr, pre_init ? m.x : nullptr));
+        if (have32) {}      // (done behind the last step)
+        else if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, rsrc, scale0, 1, pre_init ? m.r0 : nullptr, pre_init ? m.p : nullptr, pre_init ? m.x : nullptr));
         else LQCHK(to_f32(c, 1, m.r, rsrc, nh, scale0));
+        have32 = false;
         rsrc = r->data;
         int it = chain_it;
         const int hint = op->bicg32_hint[dg ? 1 : 0][std::min(outer, 3)];
-        LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol * rr * scale0 * scale0, chain_it + (maxiter - total), &it, cont, hint, &live, pre_init));
+        LQCHK(inner_bicgstab_eo32(op, m, nh, dg, tol * tol * rr * scale0 * scale0, chain_it + (maxiter - total), &it, cont, hint, &live, pre_init, rr * scale0 * scale0));
         const int step_its = it - chain_it;
         total += step_its;
         chain_it = it;
@@ -752,7 +758,18 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         if (m.layout == 2) LQCHK(pair32_axpy_to_f64(c, xe.data, m.x, 1.0 / scale0, 1));
         else LQCHK(add_from_f32(c, 1, xe.data, m.x, 1.0 / scale0, nh));
         double rrn = 0;
-        LQCHK(true_residual(&rrn));
+        if (m.layout == 2) {
+            const bool goes_on = live && c->tun.bicg_reliable;
+            scale_have = goes_on ? scale0 : scale0 / tol;
+            int nbp = 0;
+            LQCHK(schur_wilson(op, q, &xe, to, dg, Ai));
+            LQCHK(pair32_residual(c, m.r, rhs->data, q->data, scale_have, goes_on ? nullptr : m.r0, goes_on ? nullptr : m.p, goes_on ? nullptr : m.x, &nbp));
+            LQCHK(reduce_to_slot(c, nbp, 1, S_RED0, true, 0));
+            HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            rrn = c->h_scal[0];
+            have32 = true;
+        } else LQCHK(true_residual(&rrn));
         outer++;
         static const bool trace = getenv("LQCD_MIXED_TRACE") != nullptr;
         if (trace) fprintf(stderr, "[lqcd] mixed e-o BiCGStab: step %d (%s), inner tolerance %.2e, %d iterations, |r|^2 %.3e -> %.3e (asked %.3e)\n", outer, cont ? "goes on" : "new chain", tol, step_its, rr, rrn, eps);

@@ -430,6 +430,31 @@ __global__ __launch_bounds__(256) void cvt_wilson_to_pair32(float4* __restrict__
         if (xzero) xzero[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+// the fp64 residual rhs - q of ONE parity block, scaled, straight into the pair layout (+ the copies / zero field of cvt_wilson_to_pair32) with |rhs - q|^2 block partials:
+// the true residual behind a correction step of the mixed-precision even-odd BiCGStab and the start of the next fp32 chain in one pass (mixed.hip)
+__global__ __launch_bounds__(256) void residual_to_pair32(float4* __restrict__ dst, const double2* __restrict__ rhs, const double2* __restrict__ q, int Vh, int nchp, double scale,
+                                                          float4* __restrict__ dst2, float4* __restrict__ dst3, float4* __restrict__ xzero, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const size_t n = (size_t)nchp * 768;
+    double acc = 0.0;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const int lane = (int)(t & 63), j = (int)((t >> 6) % 12), chp = (int)(t / 768);
+        const int iA = chp * 64 + lane, iB = iA + Vh / 2;
+        const size_t oA = (size_t)(iA >> 6) * 768 + j * 64 + (iA & 63), oB = (size_t)(iB >> 6) * 768 + j * 64 + (iB & 63);
+        const double2 ra = rhs[oA], qa = q[oA], rb = rhs[oB], qb = q[oB];
+        const double ax = ra.x - qa.x, ay = ra.y - qa.y, bx = rb.x - qb.x, by = rb.y - qb.y;
+        acc = fma(ax, ax, acc); acc = fma(ay, ay, acc); acc = fma(bx, bx, acc); acc = fma(by, by, acc);
+        const float4 v = make_float4((float)(ax * scale), (float)(bx * scale), (float)(ay * scale), (float)(by * scale));
+        dst[t] = v;
+        if (dst2) dst2[t] = v;
+        if (dst3) dst3[t] = v;
+        if (xzero) xzero[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 // y (fp64, full lattice) += a * x (pairs)
 __global__ __launch_bounds__(256) void axpy_from_pair32(double2* __restrict__ y, const float4* __restrict__ x, int Vh, int nchp, size_t blk64, double a, int npar) {
     const size_t n = (size_t)npar * nchp * 768;
@@ -487,6 +512,15 @@ int pair32_cvt_spinor(lqcd_ctx_s* c, float2* dst, const double2* src, double sca
     const Geom& g = c->geom;
     hipLaunchKernelGGL(pair32::cvt_wilson_to_pair32, dim3(stream_grid(c, (size_t)g.nch * 768)), dim3(256), 0, c->stream, (float4*)dst, src, g.Vh, g.nch / 2,
                        (size_t)12 * g.Vs, scale, npar, (float4*)dst2, (float4*)dst3, (float4*)xzero);
+    HIPCHK(hipGetLastError());
+    return LQCD_OK;
+}
+// one parity block; returns the number of block partials in *nb (c->d_partial)
+int pair32_residual(lqcd_ctx_s* c, float2* dst, const double2* rhs, const double2* q, double scale, float2* dst2, float2* dst3, float2* xzero, int* nb) {
+    const Geom& g = c->geom;
+    *nb = stream_grid(c, (size_t)g.nch / 2 * 768);
+    hipLaunchKernelGGL(pair32::residual_to_pair32, dim3(*nb), dim3(256), 0, c->stream, (float4*)dst, rhs, q, g.Vh, g.nch / 2, scale, (float4*)dst2, (float4*)dst3, (float4*)xzero,
+                       c->d_partial);
     HIPCHK(hipGetLastError());
     return LQCD_OK;
 }
