@@ -321,7 +321,7 @@ enum { S_RED0 = 0, S_RR = 8, S_PQ = 9, S_ALPHA = 10, S_BETA = 11, S_DONE = 12, S
        S_AHIST = 64 };      // S_AHIST .. +7: the step lengths of the search directions whose x update is still pending (cg_defer_x >= 3: ring of p buffers)
 // BiCGStab block (complex scalars are two consecutive doubles; B_TS..B_TT and B_RR..B_RHO1 are filled by one 3-value reduction)
 enum { B_RHO = 24, B_R0V = 26, B_VV = 28, B_ALPHA = 29, B_SS = 31, B_TS = 32, B_TT = 34, B_OMEGA = 35, B_RR = 37, B_RHO1 = 38, B_BETA = 40,
-       B_DONE = 42, B_ITERS = 43, B_EPS = 44, B_HALF = 45, B_RES = 46, B_RHOB = 47, B_END = 49 };      // B_R0V..B_VV, B_TS..B_TT and B_RR..B_RHO1 are filled by one
+       B_DONE = 42, B_ITERS = 43, B_EPS = 44, B_HALF = 45, B_RES = 46, B_RHOB = 47, B_TS5 = 49, B_UNSURE = 54, B_END = 55 };   // B_TS5: <t, s>, |t|^2, <r0, t> of the merged chain (bicg_fused = 4), one 5-value reduction;      // B_R0V..B_VV, B_TS..B_TT and B_RR..B_RHO1 are filled by one
                                                                                                      // 3-value reduction each; B_RHOB: second rho slot of the fused chain
 __device__ inline void cg_scalar_step(double* s, int op) {
     if (op == 1) {
@@ -525,13 +525,17 @@ struct Tunables {
 #else
     int variants_built = 0;   // read-only: dslash_variant >= 2 runs variant 1 (built without -DLQCD_VARIANTS)
 #endif
-    int bicg_fused = 2;       // even-odd BiCGStab, plain Wilson r = 1 on an unpartitioned lattice: 3 [opt-in, round 6] = 2 + the x / r update and the p update as ONE launch
+    int bicg_fused = 4;       // even-odd BiCGStab, plain Wilson r = 1 on an unpartitioned lattice: 4 [default, round 6] = 2 + the x / r update and the p update as ONE launch WITHOUT a
+                              // barrier: rho' and |r'|^2 from inner products that exist before r' does (solvers.hip bicgf_xrp_rec; <r0, t> from a second inner product in the dot
+                              // epilogue of the scalar-addressing kernel) -- 6 launches, 12 vector passes instead of 14: 112.4 -> 106.0 us per iteration at 16^3x32, 20.9 -> 19.9 ms per
+                              // solve at 32^3x64; equal to form 2 up to the rounding of the two recurrences (no drift: rho - alpha <r0, v> = <r0, s> = 0 in every iteration); where that
+                              // kernel does not apply (clover, 18-real links, small planes) it IS form 2.  3 [opt-in, round 6] = 2 + the x / r update and the p update as ONE launch
                               // with a grid-wide barrier between them (6 launches per iteration; all <= 1024 workgroups resident) -- bit-identical and SLOWER (128.6 vs
                               // 112.4 us per iteration at 16^3x32, profiles/r06_bicgstab_eo_chain.log: a barrier of 1024 workgroups costs more than the launch boundary it replaces); 1 = the inner products come from the epilogues of the Schur
-                              // operator's second hop (no dot-product passes), reductions and scalar steps as separate one-block launches; 2 [default] = on lattices of
+                              // operator's second hop (no dot-product passes), reductions and scalar steps as separate one-block launches; 2 = on lattices of
                               // <= 1024 chunks per parity the reductions and scalar steps also move into the prologues of the consumers (7 dependent launches per
                               // iteration instead of 17, identical iterates); 0 = the generic chain (what the clover / full-lattice solvers run)
-    int bicg_xrp_active = 0;  // read-only: the last even-odd BiCGStab solve ran the fused x / r / p launch (bicg_fused = 3 and every workgroup of it resident)
+    int bicg_xrp_active = 0;  // read-only: the last even-odd BiCGStab solve ran the fused x / r / p launch -- 1: bicg_fused = 3 (grid barrier, every workgroup resident), 2: bicg_fused = 4 (recurrences)
     int action_eo_solver = 1; // lqcd_fermi_action / lqcd_calc_UdSfdU, Wilson(-clover): X = (D^+D)^-1 eta through two even-odd BiCGStab solves (Y = D^-+ eta, X = D^-1 Y)
                               // instead of the CG on the normal equations (0: the reference's form); same stopping rule for the same residual (actions.hip)
     int lazy_links = 0;       // 1: the per-direction call triples of the reference's U_update! / P_update! (lqcd_link_exp -> lqcd_link_mul -> lqcd_link_copy,
@@ -550,6 +554,8 @@ struct Tunables {
                               // runMD_QPQ_sw!, standardMD.jl:146-166: 11 link passes per MD step instead of 20); lqcd_gauge_exp_update takes part.  2 (default; one GPU): a complete
                               // momentum update P_update! waits as well, and runs with the link update that follows it as ONE sweep (staple_force_expu: the new
                               // links go to a second buffer that changes places with the field's).  0: every complete update is launched at once
+    int bicg_rec_guard = 6;       // bicg_fused = 4: digits of cancellation the recurrence |r'|^2 = |s|^2 - |<t,s>|^2 / |t|^2 may show before the stopping test waits for the summed |r'|^2
+                                  // (one kernel later); 0 makes every test wait (tests)
     int bicg_reliable = 0;        // mixed-precision even-odd BiCGStab, 1: behind a correction step the fp32 chain goes on with its search direction, r0 and scalars (the true
                                   // residual replaces the recursive one: a reliable update) instead of starting again from p = r.  Measured at 32^3 x 64 on a hot configuration
                                   // (profiles/r06_links16_reliable.log): no fewer iterations -- kappa 0.141: 14 / 13-14, 0.19: 28 / 28, 0.22: 57 / 62 -- restarted BiCGStab loses
@@ -970,6 +976,8 @@ struct StencilCall {
     const double2* dot_z[2] = {nullptr, nullptr};
     double* dot_partial = nullptr;
     int dot_conj = 0;             // 1: <out, z> (the imaginary part changes sign)
+    const double2* dot_z2[2] = {nullptr, nullptr};      // scalar-addressing kernel, z = xin only: a second inner product <z2, out> (never conjugated) -> FIVE values per workgroup,
+                                                          // dot_partial[5 b + (0..4)] = Re / Im <z, out>, |out|^2, Re / Im <z2, out>  (merged BiCGStab chain: <r0, t> beside <t, s>)
     // Domainwall (domainwall.hip): the L5 slices of a five-dimensional field in ONE launch of the scalar-addressing kernel -- in / xin / out point at slice 0, slice s5 is
     // dw_slice elements further on -- with the fifth-direction hops -P_A psi(s+1) - P_B psi(s-1) (mass term at the walls) added in the epilogue
     int dw_ls = 0;
@@ -1030,6 +1038,7 @@ bool any_partitioned(lqcd_ctx_s* c);
 bool halo_fold_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover);   // the folded one-stream schedule runs for such a call (stencil.hip)
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec = 0, bool clover = false);
+bool stencil_dot2_applies(lqcd_ctx_s* c, int parity_mode, bool have12);
 bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s);      // a StencilCall with dw_ls > 1 can run (stencil.hip)
 bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, bool clover);   // the persistent kernel runs for this call (large lattices only)
 // the operator's full-lattice applications carry the packed clover blocks into the stencil (make_full_call's rule)

@@ -86,6 +86,9 @@ struct BicgF {
     const double* pin2;     // bicgf_xr: the |s|^2 partials of bicgf_s
     int pin2_n;
     double* pout;           // this kernel's partials
+    const double* pin3 = nullptr;   // bicg_fused = 4, bicgf_s: the |r'|^2 partials the merged update launch left when its recurrence was not to be trusted (B_UNSURE)
+    int pin3_n = 0;
+    double guard = 1e-6;    // bicgf_xrp_rec: trust the recurrence for |r'|^2 while it exceeds guard * |s|^2
     int cont = 0;           // bicgf32_p after a reliable update (mixed.hip): no stopping test, the chain is re-armed (B_DONE = 0, B_EPS = cont_eps)
     double cont_eps = 0.0;
 };

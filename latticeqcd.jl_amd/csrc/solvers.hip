@@ -847,6 +847,12 @@ __global__ __launch_bounds__(UB) void bicgf_s(BicgF a, double2* __restrict__ s, 
         r0v.re = t3[0]; r0v.im = t3[1];
     } else { r0v.re = a.sc[B_R0V]; r0v.im = a.sc[B_R0V + 1]; }
     const c2 al = bicg_alpha(rho, r0v);
+    if (a.pin3 && a.sc[B_UNSURE] != 0.0) {      // bicg_fused = 4: the last update launch left the stopping test to the |r'|^2 it summed (every workgroup reaches the same verdict)
+        double t1[1];
+        block_sum_partials<1>(a.pin3, a.pin3_n, t1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc[B_RES] = t1[0]; a.sc[B_RR] = t1[0]; }
+        if (t1[0] < a.sc[B_EPS]) { if (blockIdx.x == 0 && threadIdx.x == 0) a.sc[B_DONE] = 1.0; return; }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc[B_R0V] = r0v.re; a.sc[B_R0V + 1] = r0v.im; a.sc[B_ALPHA] = al.re; a.sc[B_ALPHA + 1] = al.im; }
     const double ar = al.re, ai = al.im;
     double acc[1] = {0};
@@ -1116,6 +1122,90 @@ __global__ __launch_bounds__(UB, 4) void bicgf_xrp(BicgF a, double2* __restrict_
     for (size_t i = i0 + KE * stride; i < n; i += stride) onep(i, v[i], r[i], p[i]);
 }
 
+
+// bicg_fused = 4: x / r update and p update as ONE launch WITHOUT a barrier.  What the p update needs from the new residual -- rho' = <r0, r'> and the stopping test --
+// follows from inner products that exist before r' does:  r' = s - omega t and s = r - alpha v give
+//     rho' = rho - alpha <r0, v> - omega <r0, t> ,        |r'|^2 = |s|^2 - |<t, s>|^2 / |t|^2
+// with <r0, t> formed next to <t, s>, |t|^2 in the epilogue of the Schur operator's second hop (StencilCall::dot_z2: five values per workgroup).  One launch, one
+// reduction and two vector passes less per iteration than bicg_fused = 2 (x, p, s, t, v read, x, r, p written; r0 is read by the hop instead of here).  The iterates
+// equal those of the other forms up to the rounding of the two recurrences (fp64: ~1e-16 of |r0| |r| per iteration, tests/test_gpu_solver_edges.py); the
+// stopping test trusts the recurrence for |r'|^2 only while it is free of cancellation (|r'|^2 > 1e-6 |s|^2), otherwise this launch also sums the |r'|^2 it
+// writes and the NEXT iteration's first streaming kernel decides (bicgf_s, a.pin3; the two hops in between are wasted once).
+__global__ __launch_bounds__(UB) void bicgf_xrp_rec(BicgF a, double2* __restrict__ x, double2* __restrict__ r, double2* __restrict__ p, const double2* __restrict__ s,
+                                                     const double2* __restrict__ t, const double2* __restrict__ v, size_t n) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    double2 pp[KE], ps[KE], pt[KE], px[KE], pv_[KE];
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) { pp[e] = p[i]; ps[e] = s[i]; pt[e] = t[i]; px[e] = x[i]; pv_[e] = v[i]; }
+    }
+    const c2 al = {a.sc[B_ALPHA], a.sc[B_ALPHA + 1]}, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]}, r0v = {a.sc[B_R0V], a.sc[B_R0V + 1]};
+    double ss, tt;
+    c2 ts, r0t;
+    if (a.fold) {
+        double t1[1], t5[5];
+        block_sum_partials<1>(a.pin2, a.pin2_n, t1);
+        block_sum_partials<5>(a.pin, a.pin_n, t5);
+        ss = t1[0]; ts.re = t5[0]; ts.im = t5[1]; tt = t5[2]; r0t.re = t5[3]; r0t.im = t5[4];
+    } else { ss = a.sc[B_SS]; ts.re = a.sc[B_TS5]; ts.im = a.sc[B_TS5 + 1]; tt = a.sc[B_TS5 + 2]; r0t.re = a.sc[B_TS5 + 3]; r0t.im = a.sc[B_TS5 + 4]; }
+    const bool half = ss < a.sc[B_EPS];
+    const c2 om = bicg_omega(ts, tt, half);
+    // rho' = rho - alpha <r0, v> - omega <r0, t>
+    c2 rho1;
+    rho1.re = rho.re - (al.re * r0v.re - al.im * r0v.im) - (om.re * r0t.re - om.im * r0t.im);
+    rho1.im = rho.im - (al.re * r0v.im + al.im * r0v.re) - (om.re * r0t.im + om.im * r0t.re);
+    const double rrn = half ? ss : ss - (ts.re * ts.re + ts.im * ts.im) / tt;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const bool finite = fabs(rrn) <= 1.79e308 && fabs(ss) <= 1.79e308;
+    const bool done = half || (finite && rrn < a.sc[B_EPS] && rrn > a.guard * ss);
+    const bool unsure = !half && finite && !(rrn > a.guard * ss);      // the recurrence for |r'|^2 has cancelled six digits: the sum below decides, one kernel later
+    if (lead) {
+        a.sc[B_SS] = ss; a.sc[B_HALF] = half ? 1.0 : 0.0; a.sc[B_TS] = ts.re; a.sc[B_TS + 1] = ts.im; a.sc[B_TT] = tt;
+        a.sc[B_OMEGA] = om.re; a.sc[B_OMEGA + 1] = om.im;
+        a.sc[B_ITERS] += 1.0; a.sc[B_RES] = rrn; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im;
+        if (done) a.sc[B_DONE] = 1.0;
+        else if (!finite) a.sc[B_DONE] = 2.0;
+    }
+    const double ar = al.re, ai = al.im, wr = om.re, wi = om.im;
+    c2 be = {0.0, 0.0};
+    const bool go_on = !done && finite;
+    if (go_on) {
+        be = bicg_beta(rho1, rho, al, om);
+        if (lead) { a.sc[B_BETA] = be.re; a.sc[B_BETA + 1] = be.im; a.sc[a.rho_out] = rho1.re; a.sc[a.rho_out + 1] = rho1.im; }
+    }
+    const double br = be.re, bi = be.im;
+    double acc[1] = {0};
+    auto one = [&](size_t i, double2 pv, const double2 sv, const double2 tv, double2 xv, const double2 vv) {
+        double2 rv = sv;
+        xv.x = fma(ar, pv.x, xv.x); xv.x = fma(-ai, pv.y, xv.x);
+        xv.y = fma(ar, pv.y, xv.y); xv.y = fma(ai, pv.x, xv.y);
+        xv.x = fma(wr, sv.x, xv.x); xv.x = fma(-wi, sv.y, xv.x);
+        xv.y = fma(wr, sv.y, xv.y); xv.y = fma(wi, sv.x, xv.y);
+        rv.x = fma(-wr, tv.x, rv.x); rv.x = fma(wi, tv.y, rv.x);
+        rv.y = fma(-wr, tv.y, rv.y); rv.y = fma(-wi, tv.x, rv.y);
+        x[i] = xv; r[i] = rv;
+        acc[0] = fma(rv.x, rv.x, acc[0]); acc[0] = fma(rv.y, rv.y, acc[0]);
+        if (go_on) {
+            pv.x = fma(-wr, vv.x, pv.x); pv.x = fma(wi, vv.y, pv.x);
+            pv.y = fma(-wr, vv.y, pv.y); pv.y = fma(-wi, vv.x, pv.y);
+            double2 o;
+            o.x = fma(br, pv.x, rv.x); o.x = fma(-bi, pv.y, o.x);
+            o.y = fma(br, pv.y, rv.y); o.y = fma(bi, pv.x, o.y);
+            p[i] = o;
+        }
+    };
+#pragma unroll
+    for (int e = 0; e < KE; e++) {
+        const size_t i = i0 + e * stride;
+        if (i < n) one(i, pp[e], ps[e], pt[e], px[e], pv_[e]);
+    }
+    for (size_t i = i0 + KE * stride; i < n; i += stride) one(i, p[i], s[i], t[i], x[i], v[i]);
+    if (unsure) block_reduce_nv<1>(acc, a.pout);      // (uniform over the grid: every workgroup computed the same scalars)
+    if (lead) a.sc[B_UNSURE] = unsure ? 1.0 : 0.0;    // "the sum of |r'|^2 in a.pout is waiting for a verdict"
+}
+
 // start of a solve in two launches and no host round trip (round 6; it used to be three copies, an axpy, a norm, a reduction, a read-back and an upload of the scalar
 // block: 135 us in front of the first iteration of a 12-iteration solve at 16^3x32): r = rhs - v (v = M x0), r0 = r, p = r, |r|^2 partials ...
 __global__ __launch_bounds__(UB) void bicgf_init(double2* __restrict__ r, double2* __restrict__ r0, double2* __restrict__ p, const double2* __restrict__ rhs,
@@ -1163,25 +1253,32 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
                                                                                 // instances have no multi-chunk / persistent form; stencil_num_blocks would say otherwise under dslash_pipe = 1 / 3)
     const int nbk = (int)std::min<size_t>(1024, (n + UB - 1) / UB);             // streaming kernels: at most 1024 partials (one prologue sums them)
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
-    // bicg_fused = 3: x / r and p update as one launch with a grid barrier -- only while every workgroup of it is resident at once (and nobody shares the device: a
+    // bicg_fused = 3 (4 is not a superset of it): x / r and p update as one launch with a grid barrier -- only while every workgroup of it is resident at once (and nobody shares the device: a
     // barrier that is not met within 0.2 s ends the solve with an error and switches the fusion off)
-    bool xrp = fold && c->tun.bicg_fused >= 3;
+    bool xrp = fold && c->tun.bicg_fused == 3;
     if (xrp) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bicgf_xrp, UB, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
         if ((long)per_cu * c->num_cu < nbk) xrp = false;
     }
-    c->tun.bicg_xrp_active = xrp ? 1 : 0;
+    // bicg_fused = 4: the merged update launch on the two recurrences (bicgf_xrp_rec); needs the second inner product of the dot epilogue (scalar-addressing kernel, plain Wilson)
+    bool rec = false;
+    if (c->tun.bicg_fused == 4 && !Ai) {
+        const StencilCall probe = make_hop_call(op, v, to, p, 1.0, -k * k, dg);
+        rec = stencil_dot2_applies(c, 0, probe.gauge12 != nullptr && !probe.gauge12_delta);
+    }
+    if (rec) xrp = false;
+    c->tun.bicg_xrp_active = xrp ? 1 : (rec ? 2 : 0);
     if (xrp && (c->cgp_nwg != nbk || c->cgp_epoch > 100000000u)) {      // the barrier counters (shared with the one-launch CG): never reset between launches of one grid size
         HIPCHK(hipMemsetAsync(c->cgp_ctr, 0, 9 * 32 * sizeof(unsigned), c->stream));
         c->cgp_epoch = 0; c->cgp_nwg = nbk;
     }
     double* P0 = c->d_partial;                  // <r0, v> (+ |v|^2)      [nbs x 3]
     double* P1 = P0 + (size_t)3 * nbs;          // |s|^2                  [nbk]
-    double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]
-    double* P3 = P2 + (size_t)3 * nbs;          // |r|^2, <r0, r>         [nbk x 3]
+    double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]   (bicg_fused = 4: + <r0, t>, nbs x 5)
+    double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;   // |r|^2, <r0, r>    [nbk x 3]
     const double* skip_ = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
-    auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj, bool skippable = true) -> int {
+    auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj, bool skippable = true, const lqcd_spinor_s* z2 = nullptr) -> int {
         const double* skip = skippable ? skip_ : nullptr;
         StencilCall s1 = make_hop_call(op, to, in, nullptr, 0.0, 1.0, dg);      // t_o = [A_oo^-1] H_oe in
         s1.skip_flag = skip;
@@ -1191,6 +1288,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
         s2.skip_flag = skip;
         if (Ai) { s2.clover = Ai; s2.clover_on_hop = 1; }
         if (z) { s2.dot_z[0] = z->data; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
+        if (z2) { s2.dot_z2[0] = z2->data; s2.dot_z2[1] = nullptr; }
         return stencil_apply(c, s2);
     };
     // v = M x0 with hops that do not look at the done flag (the LAST solve left it raised), then r = rhs - v, r0 = p = r and the scalar block, all on the device
@@ -1219,8 +1317,18 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
             LQCHK(schur(v, p, r0, P0, 0));                                                                   // v = M p, <r0, v>
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0));
             a.pin = P0; a.pin_n = nbs; a.pout = P1;
+            if (rec) { a.pin3 = P3; a.pin3_n = nbk; }
             hipLaunchKernelGGL(bicgf_s, dim3(nbk), dim3(UB), 0, c->stream, a, s->data, r->data, v->data, n);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
+            if (rec) {
+                LQCHK(schur(t, s, s, P2, 1, true, r0));                                                      // t = M s, <t, s>, |t|^2, <r0, t>
+                if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2));
+                a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
+                a.guard = std::pow(10.0, -(double)c->tun.bicg_rec_guard);
+                hipLaunchKernelGGL(bicgf_xrp_rec, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, v->data, n);
+                HIPCHK(hipGetLastError());
+                continue;
+            }
             LQCHK(schur(t, s, s, P2, 1));                                                                    // t = M s, <t, s>, |t|^2
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
             a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;

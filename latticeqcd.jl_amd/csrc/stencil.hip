@@ -368,6 +368,7 @@ struct PipeArgs {
                               // nullptr: no queue -- workgroup b walks the per_wg consecutive virtual blocks b * per_wg .. (dslash_pipe = 3)
     int per_wg;
     const real2* dotz[2];     // dot mode of the scalar-addressing kernel (StencilCall::dot_z, see KArgs)
+    const real2* dotz2[2];    // StencilCall::dot_z2: second inner product of the dot epilogue (five values per workgroup)
     double* dot_partial;
     int dot_conj;
     // DW5 instance (Domainwall operator): L5 slices per launch, block b -> (virtual block, slice) with the XCD of b kept (see wilson_dirsplit_s)
@@ -752,7 +753,7 @@ __device__ inline void fold_unit_link(cd (&u)[9], bool face) {      // (called w
 }
 
 template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false>
-__device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim, int vb) {
+__device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim, int vb, real& dre2, real& dim2) {
     // DW5: this workgroup's slice s5 of the five-dimensional fields; block ids keep their XCD (b & 7) and the L5 slices of a chunk follow each other on it, so the
     // links of the chunk are fetched from the fabric once and hit the XCD's L2 for the other slices
     int vblock = vb, s5 = 0;      // (vb: blockIdx.x, or the entry of the bulk / boundary list of a folded launch)
@@ -784,10 +785,14 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
     const PipeSite s = pipe_site<MU, NL>(a, vblock, lane);
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     const bool z_is_x = DOT && (s.p ? a.dotz[1] == a.xin[1] : a.dotz[0] == a.xin[0]) && a.a != real(0.0);
+    const bool two = DOT && z_is_x && (s.p ? a.dotz2[1] : a.dotz2[0]) != nullptr;      // second inner product: z = xin leaves the registers of z to z2
     if constexpr (DOT) {        // dot mode: z takes the registers the old r has in update mode (requested ahead of the hops, scalar base + lane offset)
         if (!z_is_x) {
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dotz[1] : a.dotz[0], s.own) + co12(3 * MU + cc));
+        } else if (two) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dotz2[1] : a.dotz2[0], s.own) + co12(3 * MU + cc));
         }
     } else if (!LATE_R && a.upd_scal) {    // (18-real and 12 + delta links: their extra words take these registers during the hops; the old r is requested behind them)
 #pragma unroll
@@ -943,6 +948,11 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
             if (a.nt_store) st_nt(dstp + co12(j), v); else st(dstp + co12(j), v);
             dre = fma(z.re, v.re, dre); dre = fma(z.im, v.im, dre);
             dim = fma(z.re, v.im, dim); dim = fma(-z.im, v.re, dim);
+            if (two) {
+                const cd z2 = rv[cc];
+                dre2 = fma(z2.re, v.re, dre2); dre2 = fma(z2.im, v.im, dre2);
+                dim2 = fma(z2.re, v.im, dim2); dim2 = fma(-z2.im, v.re, dim2);
+            }
         } else if (a.upd_scal) {
             cd r = rv[cc];
             r.re = fma(-al_upd, v.re, r.re); r.im = fma(-al_upd, v.im, r.im);
@@ -958,7 +968,7 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
 template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false>
 __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
-    __shared__ double red[DOT ? 12 : 4];
+    __shared__ double red[DOT ? 20 : 4];
     if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) {
         if (a.scal_w && blockIdx.x == 0 && threadIdx.x == 0) a.scal_w[S_XDONE] = 1.0;
         return;
@@ -987,22 +997,26 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     }
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    real nrm = 0.0, dre = 0.0, dim = 0.0;
+    real nrm = 0.0, dre = 0.0, dim = 0.0, dre2 = 0.0, dim2 = 0.0;
     switch (w) {
-    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
-    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
-    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
-    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb); break;
+    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
+    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
+    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
+    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
     }
-    if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue
-        double t3[3] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm};
+    if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue; five with a second inner product (dot_z2)
+        const bool five = a.dotz2[0] != nullptr || a.dotz2[1] != nullptr;
+        double t3[5] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm, (double)dre2, (double)dim2};
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            t3[q] = wave_sum(t3[q]);
-            if (lane == 0) red[4 * q + w] = t3[q];
+        for (int q = 0; q < 5; q++) {
+            if (q < 3 || five) {
+                t3[q] = wave_sum(t3[q]);
+                if (lane == 0) red[4 * q + w] = t3[q];
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 3) a.dot_partial[3 * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        const int nv = five ? 5 : 3;
+        if ((int)threadIdx.x < nv) a.dot_partial[nv * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
         return;
     }
     if (a.norm_partial) {
@@ -1603,6 +1617,7 @@ static KArgs make_kargs(lqcd_ctx_s* c, const StencilCall& s, int TB) {
     k.skip = s.skip_flag;
     k.alpha_partials = s.alpha_partials; k.alpha_n = s.alpha_n; k.scal_w = s.scal_w;
     k.dotz[0] = (const real2*)s.dot_z[0]; k.dotz[1] = (const real2*)s.dot_z[1]; k.dot_partial = s.dot_partial; k.dot_conj = s.dot_conj;
+    k.dotz2[0] = (const real2*)s.dot_z2[0]; k.dotz2[1] = (const real2*)s.dot_z2[1];
     k.fsel = s.fold >= 2 ? s.fold - 1 : 0;
     k.vlist = nullptr;
     return k;
@@ -1641,7 +1656,7 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     PipeArgs a;
     a.gauge = k.gauge12 ? k.gauge12 : k.gauge;
     const bool upd = k.upd_scal != nullptr;
-    for (int p = 0; p < 2; p++) { a.dst[p] = upd ? k.upd[p] : k.out[p]; a.in[p] = k.in[p]; a.xin[p] = k.xin[p]; a.dotz[p] = k.dotz[p]; }
+    for (int p = 0; p < 2; p++) { a.dst[p] = upd ? k.upd[p] : k.out[p]; a.in[p] = k.in[p]; a.xin[p] = k.xin[p]; a.dotz[p] = k.dotz[p]; a.dotz2[p] = k.dotz2[p]; }
     a.dot_partial = k.dot_partial; a.dot_conj = k.dot_conj;
     a.norm_partial = k.norm_partial; a.upd_scal = k.upd_scal; a.skip = k.skip; a.scal_w = k.scal_w;
     a.a = k.a; a.b = k.b;
@@ -1808,6 +1823,9 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                 launched = true;
             }
 #endif
+            if (s.dot_z2[0] || s.dot_z2[1]) {
+                if (!launched || s.clover_on_hop) { set_error("stencil: the second inner product of the dot epilogue exists in the scalar-addressing kernel only (stencil_dot2_applies)"); return LQCD_ERR_UNSUPPORTED; }
+            }
             if (!launched) {            // the plain direction-split kernel (fp32 build: the inner chain of the mixed-precision even-odd solver)
                 if (k.gauge12) {
                     if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true>), grid, block, pad, c->stream, k);
@@ -2016,6 +2034,10 @@ int wilson_pipe_grid(lqcd_ctx_s* c, int nvirt, int prec) {
 // tail imbalance eats the gain) and only the r = 1 Wilson operator; a call that carries the packed clover blocks (fused A x epilogue) keeps
 // the plain variant-1 kernel -- `clover` is that property of the call (StencilCall::clover != nullptr; solvers: op_fused_clover).
 // the L5 slices of a Domainwall application as ONE launch of the scalar-addressing kernel: fp64, one GPU, full-lattice plain mode, 12-real links (fields on the group)
+// dot mode with a second inner product (StencilCall::dot_z2): the fp64 scalar-addressing kernel on 12-real links
+bool stencil_dot2_applies(lqcd_ctx_s* c, int parity_mode, bool have12) {
+    return !kF32Build && have12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, LQCD_WILSON, 1.0, parity_mode, false);
+}
 bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s) {
     if (kF32Build || s.prec != 0 || s.kind != LQCD_WILSON || s.r != 1.0 || s.parity_mode != 2 || any_partitioned(c)) return false;
     if (s.alpha_partials || s.dot_partial || s.clover || s.clover_on_hop || s.gauge12_delta) return false;      // (|.|^2 partials -- one per workgroup = chunk x slice -- and the update mode ride along: dw_solve)

@@ -38,6 +38,7 @@ struct KArgs {
     const double* alpha_partials;   // cg_small (see StencilCall): block partials of |D p|^2 to be summed in the prologue, or nullptr
     int alpha_n;
     double* scal_w;
+    const real2* dotz2[2];    // StencilCall::dot_z2 (scalar-addressing kernel only)
     const real2* dotz[2];     // dot mode (StencilCall::dot_z): Re / Im <z, out> and |out|^2 per workgroup -> dot_partial[3 b ..]; dot_conj: <out, z> instead
     double* dot_partial;
     int dot_conj;

@@ -241,6 +241,40 @@ def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
             assert np.array_equal(a, c), defer
 
 
+@pytest.mark.parametrize("L,dagger", [((16, 8, 8, 8), False), ((16, 16, 16, 32), True)])
+def test_evenodd_bicgstab_merged_update_on_the_recurrences(lq, orc, L, dagger):
+    """bicg_fused = 4 (opt-in): x / r and p update as ONE launch without a barrier -- rho' = rho - alpha <r0, v> - omega <r0, t> and |r'|^2 = |s|^2 - |<t,s>|^2 / |t|^2
+    from inner products that exist before r' does (<r0, t> from a second inner product in the dot epilogue of the scalar-addressing kernel).  Equal to the default
+    chain up to the rounding of the two recurrences: same iteration count, solution to 1e-10, stopping rule on the recursive residual, true residual recomputed here.
+    bicg_rec_guard = 0 distrusts the recurrence for |r'|^2 always: the stopping test then waits for the summed |r'|^2 (the next iteration's first streaming kernel)."""
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
+    Dd = D.adjoint() if dagger else D
+    Dd.method_CG = "bicgstab_evenodd"
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    out = {}
+    for mode, guard in ((2, 6), (4, 6), (4, 0)):
+        lat.set_param("bicg_fused", mode)
+        lat.set_param("bicg_rec_guard", guard)
+        x = b.similar()
+        it, rr = lq.solve_DinvX_(x, Dd, b, return_info=True)
+        assert rr < 1e-19 and lat.get_param("bicg_xrp_active") == (2 if mode == 4 else 0), (mode, guard)
+        r = b.similar()
+        lq.mul_(r, Dd, x)
+        lq.add_fermion_(r, -1.0, b)
+        assert lq.dot(r, r).real < 1e-18, (mode, guard)           # the true residual of the full system (the even-odd solve stops on the Schur system's recursive one)
+        out[(mode, guard)] = (x.download(), it)
+    lat.set_param("bicg_fused", 2)
+    lat.set_param("bicg_rec_guard", 6)
+    for key in ((4, 6), (4, 0)):
+        assert abs(out[key][1] - out[(2, 6)][1]) <= 1 and rel_err(out[key][0], out[(2, 6)][0]) < 1e-10, key
+    if L[3] == 8:
+        xo, ito, rro, st = orc.wilson_bicgstab_eo(U.download(), b.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger, eps=1e-19)
+        assert st == 0 and abs(ito - out[(4, 6)][1]) <= 1 and rel_err(out[(4, 6)][0], xo) < 1e-9
+
+
 def test_evenodd_bicgstab_fused_chain_is_bit_identical_to_the_unfolded_one(lq, orc):
     """Tunable bicg_fused.  1: the inner products of an iteration come from the epilogue of the Schur operator's second hop, reductions and scalar steps
     are separate one-block launches; 2 (default): on lattices of <= 1024 chunks per parity they run in the consumers' prologues -- 7 dependent launches
