@@ -479,6 +479,12 @@ __global__ __launch_bounds__(UB) void bicgf32_s(BicgF a, float4* __restrict__ s,
     if (a.fold) { double t3[3]; block_sum_partials<3>(a.pin, a.pin_n, t3); r0v.re = t3[0]; r0v.im = t3[1]; }
     else { r0v.re = a.sc[B_R0V]; r0v.im = a.sc[B_R0V + 1]; }
     const c2 al = bicg_alpha(rho, r0v);
+    if (a.pin3 && a.sc[B_UNSURE] != 0.0) {      // merged chain: the last update launch left the stopping test to the |r'|^2 it summed (solvers.hip bicgf_s)
+        double t1[1];
+        block_sum_partials<1>(a.pin3, a.pin3_n, t1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc[B_RES] = t1[0]; a.sc[B_RR] = t1[0]; }
+        if (t1[0] < a.sc[B_EPS]) { if (blockIdx.x == 0 && threadIdx.x == 0) a.sc[B_DONE] = 1.0; return; }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc[B_R0V] = r0v.re; a.sc[B_R0V + 1] = r0v.im; a.sc[B_ALPHA] = al.re; a.sc[B_ALPHA + 1] = al.im; }
     const float ar = -(float)al.re, ai = -(float)al.im;
     double acc[1] = {0};
@@ -568,6 +574,70 @@ __global__ __launch_bounds__(UB) void bicgf32_p(BicgF a, float4* __restrict__ p,
     for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pv_[e], pr[e], pp[e]); }
     for (size_t i = i0 + 2 * stride; i < n4; i += stride) one(i, v[i], r[i], p[i]);
 }
+// the merged update launch of solvers.hip bicgf_xrp_rec on fp32 vectors: x += alpha p + omega s ; r = s - omega t ; p = r + beta (p - omega v) with
+// rho' = rho - alpha <r0, v> - omega <r0, t> and |r'|^2 = |s|^2 - |<t, s>|^2 / |t|^2 (double scalars from double sums of fp32 products)
+template <bool PAIR>
+__global__ __launch_bounds__(UB) void bicgf32_xrp_rec(BicgF a, float4* __restrict__ x, float4* __restrict__ r, float4* __restrict__ p, const float4* __restrict__ s,
+                                                       const float4* __restrict__ t, const float4* __restrict__ v, size_t n4) {
+    if (a.sc[B_DONE] != 0.0) return;
+    const size_t i0 = (size_t)blockIdx.x * UB + threadIdx.x, stride = (size_t)gridDim.x * UB;
+    float4 pp[2], ps[2], pt[2], px[2], pv_[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) { pp[e] = p[i]; ps[e] = s[i]; pt[e] = t[i]; px[e] = x[i]; pv_[e] = v[i]; } }
+    const c2 al = {a.sc[B_ALPHA], a.sc[B_ALPHA + 1]}, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]}, r0v = {a.sc[B_R0V], a.sc[B_R0V + 1]};
+    double ss, tt;
+    c2 ts, r0t;
+    if (a.fold) {
+        double t1[1], t5[5];
+        block_sum_partials<1>(a.pin2, a.pin2_n, t1);
+        block_sum_partials<5>(a.pin, a.pin_n, t5);
+        ss = t1[0]; ts.re = t5[0]; ts.im = t5[1]; tt = t5[2]; r0t.re = t5[3]; r0t.im = t5[4];
+    } else { ss = a.sc[B_SS]; ts.re = a.sc[B_TS5]; ts.im = a.sc[B_TS5 + 1]; tt = a.sc[B_TS5 + 2]; r0t.re = a.sc[B_TS5 + 3]; r0t.im = a.sc[B_TS5 + 4]; }
+    const bool half = ss < a.sc[B_EPS];
+    const c2 om = bicg_omega(ts, tt, half);
+    c2 rho1;
+    rho1.re = rho.re - (al.re * r0v.re - al.im * r0v.im) - (om.re * r0t.re - om.im * r0t.im);
+    rho1.im = rho.im - (al.re * r0v.im + al.im * r0v.re) - (om.re * r0t.im + om.im * r0t.re);
+    const double rrn = half ? ss : ss - (ts.re * ts.re + ts.im * ts.im) / tt;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const bool finite = fabs(rrn) <= 1.79e308 && fabs(ss) <= 1.79e308;
+    const bool done = half || (finite && rrn < a.sc[B_EPS] && rrn > a.guard * ss);
+    const bool unsure = !half && finite && !(rrn > a.guard * ss);
+    if (lead) {
+        a.sc[B_SS] = ss; a.sc[B_HALF] = half ? 1.0 : 0.0; a.sc[B_TS] = ts.re; a.sc[B_TS + 1] = ts.im; a.sc[B_TT] = tt;
+        a.sc[B_OMEGA] = om.re; a.sc[B_OMEGA + 1] = om.im;
+        a.sc[B_ITERS] += 1.0; a.sc[B_RES] = rrn; a.sc[B_RR] = rrn; a.sc[B_RHO1] = rho1.re; a.sc[B_RHO1 + 1] = rho1.im;
+        if (done) a.sc[B_DONE] = 1.0;
+        else if (!finite) a.sc[B_DONE] = 2.0;
+    }
+    const bool go_on = !done && finite;
+    c2 be = {0.0, 0.0};
+    if (go_on) {
+        be = bicg_beta(rho1, rho, al, om);
+        if (lead) { a.sc[B_BETA] = be.re; a.sc[B_BETA + 1] = be.im; a.sc[a.rho_out] = rho1.re; a.sc[a.rho_out + 1] = rho1.im; }
+    }
+    const float ar = (float)al.re, ai = (float)al.im, wr = (float)om.re, wi = (float)om.im, br = (float)be.re, bi = (float)be.im;
+    double acc[1] = {0};
+    auto one = [&](size_t i, float4 pv, const float4 sv, const float4 tv, float4 xv, const float4 vv) {
+        float4 rv = sv;
+        cfma4<PAIR>(xv, ar, ai, pv);
+        cfma4<PAIR>(xv, wr, wi, sv);
+        cfma4<PAIR>(rv, -wr, -wi, tv);
+        x[i] = xv; r[i] = rv;
+        acc[0] += norm4(rv);
+        if (go_on) {
+            cfma4<PAIR>(pv, -wr, -wi, vv);      // p - omega v
+            float4 o = rv;
+            cfma4<PAIR>(o, br, bi, pv);
+            p[i] = o;
+        }
+    };
+#pragma unroll
+    for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) one(i, pp[e], ps[e], pt[e], px[e], pv_[e]); }
+    for (size_t i = i0 + 2 * stride; i < n4; i += stride) one(i, p[i], s[i], t[i], x[i], v[i]);
+    if (unsure) block_reduce_nv<1>(acc, a.pout);
+    if (lead) a.sc[B_UNSURE] = unsure ? 1.0 : 0.0;
+}
 // partials |r|^2, <r0, r> (the three values bicgf32_xr leaves for bicgf32_p) of a residual that was replaced by the true one
 template <bool PAIR>
 __global__ __launch_bounds__(UB) void bicgf32_r0r(BicgF a, const float4* __restrict__ r0, const float4* __restrict__ r, size_t n4) {
@@ -589,7 +659,7 @@ struct Eo32 {
     int layout;                                    // 1: component pairs (fp32 build of stencil.hip), 2: site pairs (stencil_pair32.hip: half the launches' latencies per site)
 };
 // one Schur application on the fp32 fields: to = H_oe in, out = in - k^2 H_eo to [+ inner-product epilogue]
-static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const float2* z, double* dotp, int conj, int dg, const double* skip) {
+static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const float2* z, double* dotp, int conj, int dg, const double* skip, const float2* z2 = nullptr) {
     lqcd_ctx_s* c = op->ctx;
     StencilCall s1;
     s1.kind = LQCD_WILSON; s1.gauge = (const double2*)m.gauge; s1.gauge12 = (const double2*)m.gauge12; s1.gauge16 = m.gauge16;
@@ -603,6 +673,7 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
     s2.a = 1.0; s2.b = -op->km * op->km; s2.r = 1.0; s2.dagger = dg; s2.parity_mode = 0; s2.prec = m.layout == 2 ? 2 : 1; s2.skip_flag = skip;
     if (m.ainv) { s2.clover = (const double2*)m.ainv; s2.clover_on_hop = 1; }
     if (z) { s2.dot_z[0] = (const double2*)z; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
+    if (z2) { s2.dot_z2[0] = (const double2*)z2; s2.dot_z2[1] = nullptr; }
     return stencil_apply(c, s2);
 }
 // e ~ M^-1 rhs32 (|rhs32|^2 = rho0, zero guess) until the recursive residual is below eps2; m.r holds rhs32 on entry
@@ -614,7 +685,9 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
     const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : (c->geom.Vh + 63) / 64;      // (dot instances: one workgroup per 64-site chunk, whatever dslash_pipe says)
     const int nbk = (int)std::min<size_t>(1024, (n4 + UB - 1) / UB);
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
-    double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)3 * nbs;
+    // the merged update launch on the two recurrences (bicg_fused = 4, solvers.hip): site pairs only (the second inner product lives in stencil_pair32.hip's dot epilogue)
+    const bool rec = c->tun.bicg_fused == 4 && m.layout == 2 && !m.ainv;
+    double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;
     const double* skip = c->d_scal + (B_DONE - S_DONE);
     if (!pre_init) HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));      // (pre_init: the conversion that made m.r also set x = 0, r0 = p = r)
     int it = 0, enq = 0;
@@ -654,9 +727,20 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
             LQCHK(schur32(op, m, m.v, m.p, m.r0, P0, 0, dg, skip));
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0));
             a.pin = P0; a.pin_n = nbs; a.pout = P1;
+            if (rec) { a.pin3 = P3; a.pin3_n = nbk; }
             if (m.layout == 2) hipLaunchKernelGGL(bicgf32_s<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
             else hipLaunchKernelGGL(bicgf32_s<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
+            if (rec) {
+                LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip, m.r0));
+                if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2));
+                a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
+                a.guard = std::pow(10.0, -(double)c->tun.bicg_rec_guard);
+                hipLaunchKernelGGL(bicgf32_xrp_rec<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (float4*)m.p, (const float4*)m.s, (const float4*)m.t,
+                                   (const float4*)m.v, n4);
+                HIPCHK(hipGetLastError());
+                continue;
+            }
             LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip));
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
             a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;

@@ -154,6 +154,7 @@ struct PairArgs {
     const double* upd_scal;
     const double* skip;
     const float4* dotz[2];    // dot mode (StencilCall::dot_z): Re / Im <z, out> and |out|^2 per workgroup -> dot_partial[3 b ..]
+    const float4* dotz2[2];   // StencilCall::dot_z2 (z = xin only): a second inner product <z2, out> -> five values per workgroup
     double* dot_partial;
     int dot_conj;
     float a, b;
@@ -258,7 +259,7 @@ __device__ __forceinline__ void apply_sign(cx (&h0)[3], cx (&h1)[3], v2f sign) {
 }
 
 template <int MU, bool DAG, bool NTB, bool DOT = false, bool H16 = false>
-__device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][64], int lane, float al_upd, v2f& nrm, v2f& dre, v2f& dim) {
+__device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][64], int lane, float al_upd, v2f& nrm, v2f& dre, v2f& dim, v2f& dre2, v2f& dim2) {
     constexpr int SF = DAG ? -1 : 1;
     constexpr int NS = MU == 3 ? 6 : 12;
     constexpr int FF = MU == 3 ? (SF > 0 ? 6 : 0) : 0;
@@ -269,10 +270,14 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) { xv[cc] = mkx(splat(0.f), splat(0.f)); rv[cc] = xv[cc]; }
     const bool z_is_x = DOT && (s.p ? a.dotz[1] == a.xin[1] : a.dotz[0] == a.xin[0]) && a.a != 0.f;
+    const bool two = DOT && z_is_x && (s.p ? a.dotz2[1] : a.dotz2[0]) != nullptr;      // second inner product: z = xin leaves the registers of z to z2
     if constexpr (DOT) {        // dot mode: z takes the registers the old r has in update mode
         if (!z_is_x) {
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) rv[cc] = ldx(boff(s.p ? a.dotz[1] : a.dotz[0], s.own) + (3 * MU + cc) * 64);
+        } else if (two) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) rv[cc] = ldx(boff(s.p ? a.dotz2[1] : a.dotz2[0], s.own) + (3 * MU + cc) * 64);
         }
     } else if (a.upd_scal) {
 #pragma unroll
@@ -357,6 +362,11 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
             if (a.nt_store) stx_nt(dstp + j * 64, v); else stx(dstp + j * 64, v);
             dre = vfma(z.re, v.re, dre); dre = vfma(z.im, v.im, dre);
             dim = vfma(z.re, v.im, dim); dim = vfma(-z.im, v.re, dim);
+            if (two) {
+                const cx z2 = rv[cc];
+                dre2 = vfma(z2.re, v.re, dre2); dre2 = vfma(z2.im, v.im, dre2);
+                dim2 = vfma(z2.re, v.im, dim2); dim2 = vfma(-z2.im, v.re, dim2);
+            }
         } else if (a.upd_scal) {
             cx r = rv[cc];
             r.re = vfma(mal, v.re, r.re); r.im = vfma(mal, v.im, r.im);
@@ -377,28 +387,32 @@ __device__ __forceinline__ void pair_wave(const PairArgs& a, float4 (*part)[12][
 template <bool DAG, bool NTB, bool DOT = false, bool H16 = false>
 __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
     __shared__ float4 part[4][12][64];  // 48 KiB
-    __shared__ double red[DOT ? 12 : 4];
+    __shared__ double red[DOT ? 20 : 4];
     if ((a.upd_scal && a.upd_scal[S_DONE] != 0.0) || (a.skip && a.skip[S_DONE] != 0.0)) return;
     const float al_upd = a.upd_scal ? (float)a.upd_scal[S_ALPHA] : 0.f;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    v2f nrm = splat(0.f), dre = splat(0.f), dim = splat(0.f);
+    v2f nrm = splat(0.f), dre = splat(0.f), dim = splat(0.f), dre2 = splat(0.f), dim2 = splat(0.f);
     switch (w) {
-    case 0: pair_wave<0, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 1: pair_wave<1, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
-    case 2: pair_wave<2, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
-    default: pair_wave<3, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim); break;
+    case 0: pair_wave<0, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim, dre2, dim2); break;
+    case 1: pair_wave<1, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim, dre2, dim2); break;
+    case 2: pair_wave<2, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim, dre2, dim2); break;
+    default: pair_wave<3, DAG, NTB, DOT, H16>(a, part, lane, al_upd, nrm, dre, dim, dre2, dim2); break;
     }
     if constexpr (DOT) {                // three sums per workgroup (both slots of a lane), the order of the fp64 kernels' dot epilogue
         const double di = (double)dim.x + (double)dim.y;
-        double t3[3] = {(double)dre.x + (double)dre.y, a.dot_conj ? -di : di, (double)nrm.x + (double)nrm.y};
+        const bool five = a.dotz2[0] != nullptr || a.dotz2[1] != nullptr;
+        double t3[5] = {(double)dre.x + (double)dre.y, a.dot_conj ? -di : di, (double)nrm.x + (double)nrm.y, (double)dre2.x + (double)dre2.y, (double)dim2.x + (double)dim2.y};
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            t3[q] = wave_sum(t3[q]);
-            if (lane == 0) red[4 * q + w] = t3[q];
+        for (int q = 0; q < 5; q++) {
+            if (q < 3 || five) {
+                t3[q] = wave_sum(t3[q]);
+                if (lane == 0) red[4 * q + w] = t3[q];
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 3) a.dot_partial[3 * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        const int nv = five ? 5 : 3;
+        if ((int)threadIdx.x < nv) a.dot_partial[nv * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
         return;
     }
     if (a.norm_partial) {
@@ -559,7 +573,7 @@ int launch_pair32_interior(lqcd_ctx_s* c, const StencilCall& s) {
     for (int p = 0; p < 2; p++) { a.dst[p] = (float4*)(upd ? s.upd[p] : s.out[p]); a.in[p] = (const float4*)s.in[p]; a.xin[p] = (const float4*)s.xin[p]; }
     for (int p = 0; p < 2; p++) { a.xacc[p] = upd ? (float4*)s.xacc[p] : nullptr; a.pacc[p] = upd ? (const float4*)s.pacc[p] : nullptr; }
     a.norm_partial = s.norm_partial; a.upd_scal = s.upd_scal; a.skip = s.skip_flag;
-    for (int p = 0; p < 2; p++) a.dotz[p] = (const float4*)s.dot_z[p];
+    for (int p = 0; p < 2; p++) { a.dotz[p] = (const float4*)s.dot_z[p]; a.dotz2[p] = (const float4*)s.dot_z2[p]; }
     a.dot_partial = s.dot_partial; a.dot_conj = s.dot_conj;
     a.a = (float)s.a; a.b = (float)s.b;
     a.nt_store = c->tun.nt_store != 0;

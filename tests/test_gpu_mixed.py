@@ -395,3 +395,32 @@ def test_int16_links_of_the_site_pair_operator(gpu, orc):
             err[l16] = np.abs(out.download() - ref).max() / np.abs(ref).max()
         lat.set_param("mixed_links16", 1)
         assert err[0] < 1e-6 and 1e-6 < err[2] < 1e-4, err
+
+
+def test_mixed_evenodd_chain_merged_update_and_its_guard(gpu, orc):
+    """The fp32 chain of the mixed-precision even-odd BiCGStab under bicg_fused = 4 (x / r / p update as one launch on the recurrences for rho' and |r'|^2, default)
+    against bicg_fused = 2, and with bicg_rec_guard = 0 (the stopping test never trusts the recurrence: the summed |r'|^2 decides one kernel later): the true fp64
+    residual meets the rule every time, the solutions agree to solver accuracy."""
+    lq = gpu
+    L = (16, 16, 16, 32)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.141139, "eps_CG": 1e-19, "MaxCGstep": 3000})
+    D.method_CG = "bicgstab_evenodd"
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    lat.set_param("bicg_mixed", 1)
+    got = {}
+    for fused, guard in ((2, 6), (4, 6), (4, 0)):
+        lat.set_param("bicg_fused", fused)
+        lat.set_param("bicg_rec_guard", guard)
+        x = b.similar()
+        it, rr = lq.solve_DinvX_(x, D, b, return_info=True)
+        assert rr < 1e-19 and lat.get_param("pair32_active") == 1, (fused, guard)
+        r = b.similar()
+        lq.mul_(r, D, x)
+        lq.add_fermion_(r, -1.0, b)
+        assert lq.dot(r, r).real < 1e-18, (fused, guard)
+        got[(fused, guard)] = x.download()
+    lat.set_param("bicg_mixed", 0); lat.set_param("bicg_fused", 4); lat.set_param("bicg_rec_guard", 6)
+    assert rel_err(got[(4, 6)], got[(2, 6)]) < 1e-9 and rel_err(got[(4, 0)], got[(2, 6)]) < 1e-9
