@@ -93,7 +93,7 @@ def test_cg_solution_matches_the_oracle(lq, orc):
 
 def test_fused_cg_on_the_five_dimensional_launch(lq, orc):
     """dw_fused_cg: where all slices go through one launch the CG runs the fused iteration of the four-dimensional solver (|D p|^2 and the update r -= alpha D^+ t in the
-    operator's epilogues, one partial per chunk and slice).  Against the oracle's CG and against the generic 11-pass loop: same solution, same count, true residual < eps."""
+    operator's epilogues, one partial per chunk and slice).  Against the generic 11-pass loop (same solution, same count) and the oracle's operator (true residual < eps)."""
     L, L5, M, mass = (16, 8, 8, 8), 4, -1.0, 0.1
     Uh, lat, U, b, D = _setup(lq, orc, L, L5, M, mass)
     bh = _rand5(orc, L, L5, 4)
@@ -107,13 +107,11 @@ def test_fused_cg_on_the_five_dimensional_launch(lq, orc):
         got[fused] = (it, x.download())
     lat.set_param("dw_fused_cg", 1)
     assert abs(got[1][0] - got[0][0]) <= 1 and rel_err(got[1][1], got[0][1]) < 1e-10
-    orc.set_threads(os.cpu_count() or 1)
-    try:
-        xo, ito, rro = orc.domainwall_cg(Uh, bh, L, M, mass, BC, eps=1e-19)
+    orc.set_threads(os.cpu_count() or 1)      # (the oracle's own CG at this size takes two minutes: its operator certifies the solution instead; the generic loop is
+    try:                                      #  compared with the oracle's CG in test_cg_solution_matches_the_oracle)
         res = bh - orc.domainwall_D(Uh, orc.domainwall_D(Uh, got[1][1], L, M, mass, BC), L, M, mass, BC, dagger=True)
     finally:
         orc.set_threads(1)
-    assert abs(got[1][0] - ito) <= 2 and rel_err(got[1][1], xo) < 1e-9
     assert np.vdot(res, res).real < 4e-19
 
 
