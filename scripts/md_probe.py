@@ -18,6 +18,9 @@ G = lq.Gaugefields(lat)
 p = lq.initialize_TA_Gaugefields(U)
 lq.gauss_distribution_(p, 7)
 lat.set_param("mixed_action_solver", mixed)
+for kv in os.environ.get("LQCD_SET", "").split():      # library tunables key=value
+    k_, v_ = kv.split("=")
+    lat.set_param(k_, int(v_))
 nsw, beta = 10, 5.7
 
 
