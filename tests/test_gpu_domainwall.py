@@ -91,10 +91,11 @@ def test_cg_solution_matches_the_oracle(lq, orc):
     assert np.vdot(res, res).real < 4e-19                              # the true residual of the device solution, by the oracle's operator
 
 
-def test_fused_cg_on_the_five_dimensional_launch(lq, orc):
+@pytest.mark.parametrize("L,L5", [((16, 8, 8, 8), 4), ((16, 16, 16, 16), 4)])      # 512 and 8192 partials per reduction (the one-wave and the 1024-thread form of reduce_final)
+def test_fused_cg_on_the_five_dimensional_launch(lq, orc, L, L5):
     """dw_fused_cg: where all slices go through one launch the CG runs the fused iteration of the four-dimensional solver (|D p|^2 and the update r -= alpha D^+ t in the
     operator's epilogues, one partial per chunk and slice).  Against the generic 11-pass loop (same solution, same count) and the oracle's operator (true residual < eps)."""
-    L, L5, M, mass = (16, 8, 8, 8), 4, -1.0, 0.1
+    M, mass = -1.0, 0.1
     Uh, lat, U, b, D = _setup(lq, orc, L, L5, M, mass)
     bh = _rand5(orc, L, L5, 4)
     b.upload(bh)
