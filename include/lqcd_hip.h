@@ -369,7 +369,7 @@ int lqcd_link_mul_adj(lqcd_gauge_t C, int mu_c, lqcd_gauge_t A, int mu_a, lqcd_g
 int lqcd_stout_smear(lqcd_gauge_t out, lqcd_gauge_t U, double rho);                     /* out != U */
 int lqcd_stout_backprop(lqcd_gauge_t G, lqcd_gauge_t Gs, lqcd_gauge_t U, double rho);   /* G at the thin links U from Gs at the smeared links; G = Gs allowed */
 int lqcd_momentum_add_ta(lqcd_gauge_t P, double factor, lqcd_gauge_t G); /* Traceless_antihermitian_add!(p, factor, G) (AbstractMD.jl:110,131) */
-int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta); /* P_update! (AbstractMD.jl:99-118) fused: P += factor TA(gauge force), the force field is never stored */
+int lqcd_momentum_add_gauge_force(lqcd_gauge_t P, double factor, lqcd_gauge_t U, double beta); /* P_update! (AbstractMD.jl:99-118) fused: P += factor TA(gauge force), the force field is never stored.  P must hold traceless anti-Hermitian matrices (the reference's p[mu] is a TA field by type; every writer of the library -- lqcd_momentum_gaussian, the *_add_ta entries -- stores them exactly so): the sweep reads the upper triangle of P only */
 int lqcd_gauge_exp_update(lqcd_gauge_t U, double dt, lqcd_gauge_t P);    /* U_update! (AbstractMD.jl:78-97): U <- exp(dt P) U (tunable md_reunitarize: projected back onto SU(3) in the same pass) */
 int lqcd_gauge_reunitarize(lqcd_gauge_t U);                              /* no reference counterpart: every link back onto SU(3) (Gram-Schmidt rows 0,1; row 2 = conj(row0 x row1)); once per trajectory keeps the 12-real Dslash alive under per-direction callers */
 int lqcd_momentum_gaussian(lqcd_gauge_t P, uint64_t seed);               /* gauss_distribution!(p) (src/md/standardMD.jl:86); keyed by GLOBAL site */
