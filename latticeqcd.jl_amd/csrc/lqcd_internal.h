@@ -554,6 +554,7 @@ struct Tunables {
                               // runMD_QPQ_sw!, standardMD.jl:146-166: 11 link passes per MD step instead of 20); lqcd_gauge_exp_update takes part.  2 (default; one GPU): a complete
                               // momentum update P_update! waits as well, and runs with the link update that follows it as ONE sweep (staple_force_expu: the new
                               // links go to a second buffer that changes places with the field's).  0: every complete update is launched at once
+    int mixed_lean_residual = 0;  // test aid: the fused true residual of the mixed even-odd BiCGStab never writes r0 / p / x (what it does behind a step that was expected to be the last)
     int bicg_rec_guard = 6;       // bicg_fused = 4: digits of cancellation the recurrence |r'|^2 = |s|^2 - |<t,s>|^2 / |t|^2 may show before the stopping test waits for the summed |r'|^2
                                   // (one kernel later); 0 makes every test wait (tests)
     int bicg_reliable = 0;        // mixed-precision even-odd BiCGStab, 1: behind a correction step the fp32 chain goes on with its search direction, r0 and scalars (the true

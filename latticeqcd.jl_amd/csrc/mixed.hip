@@ -812,7 +812,7 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
     double scale0 = 1.0;
     // site pairs: the true residual behind a correction step is written straight into the fp32 fields of the next one (pair32_residual), scaled by an ESTIMATE of 1 / |r| --
     // the chain's stopping threshold carries the exact norm, the recurrences do not care about the scale
-    bool have32 = false;
+    bool have32 = false, have_full = false;      // have_full: r0 = p = r and x = 0 were written as well
     double scale_have = 1.0;
     // digits one correction step can gain: six with fp32 links; the int16 links of mixed_links16 differ from the true ones by 1.5e-5 per real, which the
     // inverse amplifies -- four and a half
@@ -826,7 +826,7 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         // in place of the recursive one; otherwise a new chain on the normalised residual
         const bool cont = live && c->tun.bicg_reliable;
         if (!cont) { scale0 = have32 ? scale_have : 1.0 / std::sqrt(rr); chain_it = 0; }
-        const bool pre_init = m.layout == 2 && !cont;      // a new chain on site pairs: r, r0 = r, p = r and x = 0 in the one pass of the conversion
+        const bool pre_init = m.layout == 2 && !cont && (!have32 || have_full);      // a new chain on site pairs: r, r0 = r, p = r and x = 0 in the one pass of the conversion
         if (have32) {}      // (done behind the last step)
         else if (m.layout == 2) LQCHK(pair32_cvt_spinor(c, m.r, rsrc, scale0, 1, pre_init ? m.r0 : nullptr, pre_init ? m.p : nullptr, pre_init ? m.x : nullptr));
         else LQCHK(to_f32(c, 1, m.r, rsrc, nh, scale0));
@@ -845,9 +845,10 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         if (m.layout == 2) {
             const bool goes_on = live && c->tun.bicg_reliable;
             scale_have = goes_on ? scale0 : scale0 / tol;
+            have_full = !goes_on && nsteps > 1 && !c->tun.mixed_lean_residual;      // (the step that was to reach eps: the three extra fields are written only if it did not -- by the copies of a new chain)
             int nbp = 0;
             LQCHK(schur_wilson(op, q, &xe, to, dg, Ai));
-            LQCHK(pair32_residual(c, m.r, rhs->data, q->data, scale_have, goes_on ? nullptr : m.r0, goes_on ? nullptr : m.p, goes_on ? nullptr : m.x, &nbp));
+            LQCHK(pair32_residual(c, m.r, rhs->data, q->data, scale_have, have_full ? m.r0 : nullptr, have_full ? m.p : nullptr, have_full ? m.x : nullptr, &nbp));
             LQCHK(reduce_to_slot(c, nbp, 1, S_RED0, true, 0));
             HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));

@@ -411,9 +411,10 @@ def test_mixed_evenodd_chain_merged_update_and_its_guard(gpu, orc):
     lq.gauss_distribution_fermion_(b, 112)
     lat.set_param("bicg_mixed", 1)
     got = {}
-    for fused, guard in ((2, 6), (4, 6), (4, 0)):
+    for fused, guard in ((2, 6), (4, 6), (4, 0), (4, -1)):
         lat.set_param("bicg_fused", fused)
-        lat.set_param("bicg_rec_guard", guard)
+        lat.set_param("bicg_rec_guard", max(guard, 0) if guard != -1 else 6)
+        lat.set_param("mixed_lean_residual", 1 if guard == -1 else 0)      # (-1: every correction step starts from the residual alone, as behind a step that was to be the last)
         x = b.similar()
         it, rr = lq.solve_DinvX_(x, D, b, return_info=True)
         assert rr < 1e-19 and lat.get_param("pair32_active") == 1, (fused, guard)
@@ -422,5 +423,5 @@ def test_mixed_evenodd_chain_merged_update_and_its_guard(gpu, orc):
         lq.add_fermion_(r, -1.0, b)
         assert lq.dot(r, r).real < 1e-18, (fused, guard)
         got[(fused, guard)] = x.download()
-    lat.set_param("bicg_mixed", 0); lat.set_param("bicg_fused", 4); lat.set_param("bicg_rec_guard", 6)
-    assert rel_err(got[(4, 6)], got[(2, 6)]) < 1e-9 and rel_err(got[(4, 0)], got[(2, 6)]) < 1e-9
+    lat.set_param("bicg_mixed", 0); lat.set_param("bicg_fused", 4); lat.set_param("bicg_rec_guard", 6); lat.set_param("mixed_lean_residual", 0)
+    assert rel_err(got[(4, 6)], got[(2, 6)]) < 1e-9 and rel_err(got[(4, 0)], got[(2, 6)]) < 1e-9 and rel_err(got[(4, -1)], got[(2, 6)]) < 1e-9
