@@ -60,8 +60,10 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
             // Wilson-clover: the even-odd solver iterates on the A_ee^-1-preconditioned Schur system, whose residual is A_ee^-1 times the residual of the
             // system the rule is stated for -- the true residual can exceed the solver's by |A| <= 1 + 6 kappa c_sw: both targets tighten by |A|^2
             const double nA = op->csw != 0.0 ? 1.0 + 6.0 * std::fabs(op->km * op->csw) : 1.0;
+            c->zero_guess_hint = true;      // Yw and X were cleared above: the solver need neither test that nor apply M to zero
             st = lqcd_solve_bicgstab_eo(op, Yw, eta, 1, 0.25 * eps / (nA * nA), maxiter, &it1, nullptr);
             if (st == LQCD_OK) st = lqcd_solve_bicgstab_eo(op, X, Yw, 0, 0.25 * eps / (nD * nD * nA * nA), maxiter, &it2, nullptr);
+            c->zero_guess_hint = false;
             c->tun.bicg_mixed = mixed0;
             if (st != LQCD_OK && st != LQCD_ERR_NOT_CONVERGED) { if (Yw != Y) scratch_put(Yw); return st; }
         }

@@ -767,6 +767,7 @@ struct lqcd_ctx_s {
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     hipEvent_t ev_tune0 = nullptr, ev_tune1 = nullptr;   // the halo-schedule tuner's own timing events (ev_t0 / ev_t1 belong to the bench entry points)
     // reductions
+    bool zero_guess_hint = false; // set by a caller that has just cleared the solution field (actions.hip): the even-odd BiCGStab skips M x0 and the |x0|^2 test
     double* d_partial = nullptr;  // [MAX_PARTIAL_BLOCKS * 4]
     double* d_scal = nullptr;     // small device scalar block (solver state)
     double* h_scal = nullptr;     // pinned mirror

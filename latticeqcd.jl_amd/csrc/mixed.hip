@@ -797,13 +797,13 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
         return LQCD_OK;
     };
     double rr = 0, xx = 0;
-    {      // |x|^2 and |rhs|^2 in one launch and one read-back
-        hipLaunchKernelGGL(norm2_two_kernel, dim3(nb), dim3(MB), 0, c->stream, (const double2*)xe.data, (const double2*)rhs->data, nh, c->d_partial);
+    {      // |x|^2 and |rhs|^2 in one launch and one read-back (a caller that has just cleared x says so: |rhs|^2 twice, x is not read)
+        hipLaunchKernelGGL(norm2_two_kernel, dim3(nb), dim3(MB), 0, c->stream, (const double2*)(c->zero_guess_hint ? rhs->data : xe.data), (const double2*)rhs->data, nh, c->d_partial);
         HIPCHK(hipGetLastError());
         LQCHK(reduce_to_slot(c, nb, 2, S_RED0, true, 0));
         HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal + S_RED0, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        xx = c->h_scal[0]; rr = c->h_scal[1];
+        xx = c->zero_guess_hint ? 0.0 : c->h_scal[0]; rr = c->h_scal[1];
     }
     const double2* rsrc = r->data;      // the fp64 residual the next correction step converts
     if (xx == 0.0) rsrc = rhs->data;    // zero guess (what the action solves pass): r = rhs, no Schur application, no copy
@@ -867,7 +867,10 @@ int bicgstab_eo_wilson_mixed(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rh
     if (rr < eps) return LQCD_OK;
     // fp32 accuracy exhausted (or a breakdown of the fp32 recurrence): the fp64 chain finishes from the current iterate
     int it64 = 0;
+    const bool hint = c->zero_guess_hint;
+    c->zero_guess_hint = false;      // (x is the current iterate now, whatever the caller said about its guess)
     const int st = bicgstab_eo_wilson(op, xe, rhs, w, to, dg, eps, std::max(1, maxiter - total), &it64, final_rr, Ai);
+    c->zero_guess_hint = hint;
     if (iters) *iters = total + it64;
     return st;
 }

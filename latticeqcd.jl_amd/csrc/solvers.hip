@@ -1209,10 +1209,10 @@ __global__ __launch_bounds__(UB) void bicgf_xrp_rec(BicgF a, double2* __restrict
 // start of a solve in two launches and no host round trip (round 6; it used to be three copies, an axpy, a norm, a reduction, a read-back and an upload of the scalar
 // block: 135 us in front of the first iteration of a 12-iteration solve at 16^3x32): r = rhs - v (v = M x0), r0 = r, p = r, |r|^2 partials ...
 __global__ __launch_bounds__(UB) void bicgf_init(double2* __restrict__ r, double2* __restrict__ r0, double2* __restrict__ p, const double2* __restrict__ rhs,
-                                                  const double2* __restrict__ v, size_t n, double* partial) {
+                                                  const double2* __restrict__ v, size_t n, double* partial) {      // v == nullptr: zero guess, r = rhs
     double acc[1] = {0};
     for (size_t i = (size_t)blockIdx.x * UB + threadIdx.x; i < n; i += (size_t)gridDim.x * UB) {
-        const double2 b = rhs[i], q = v[i];
+        const double2 b = rhs[i], q = v ? v[i] : make_double2(0.0, 0.0);
         double2 o;
         o.x = b.x - q.x; o.y = b.y - q.y;
         r[i] = o; r0[i] = o; p[i] = o;
@@ -1292,8 +1292,9 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
         return stencil_apply(c, s2);
     };
     // v = M x0 with hops that do not look at the done flag (the LAST solve left it raised), then r = rhs - v, r0 = p = r and the scalar block, all on the device
-    LQCHK(schur(v, &xe, nullptr, nullptr, 0, false));
-    hipLaunchKernelGGL(bicgf_init, dim3(nbk), dim3(UB), 0, c->stream, r->data, r0->data, p->data, rhs->data, v->data, n, P1);
+    const bool zero_guess = c->zero_guess_hint;      // the caller has just cleared x (the action / force solves): M x0 = 0 is not computed
+    if (!zero_guess) LQCHK(schur(v, &xe, nullptr, nullptr, 0, false));
+    hipLaunchKernelGGL(bicgf_init, dim3(nbk), dim3(UB), 0, c->stream, r->data, r0->data, p->data, rhs->data, zero_guess ? (const double2*)nullptr : (const double2*)v->data, n, P1);
     hipLaunchKernelGGL(bicgf_init_scal, dim3(1), dim3(64), 0, c->stream, P1, nbk, c->d_scal, eps);
     HIPCHK(hipGetLastError());
     (void)bytes;
