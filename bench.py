@@ -127,9 +127,24 @@ def main():
     # that fails it is replaced by RCCL on every rank -- the first run on real links must not report the speed of a wrong answer.
     selfcheck = None
     if world > 1 or force_dist:
-        selfcheck = halo_selfcheck(lq, D, b, y, gL)
+        try:
+            selfcheck = halo_selfcheck(lq, D, b, y, gL)
+        except Exception as e:      # a wait of the peer-mapped backend that gave up (dead link, no peer access across devices): treated as a failed check, not as a crash
+            selfcheck = {"norm2_Db": float("nan"), "expected": DB_NORM2_ONE_GPU.get(tuple(gL), float("nan")), "rel_diff": float("nan"), "ok": False, "error": str(e)[:300]}
+        if selfcheck is not None and dist is not None and world > 1:      # one verdict for every rank: a fall-back must be taken by all of them or by none
+            import torch
+            flag = torch.tensor([1 if selfcheck["ok"] else 0], dtype=torch.int32)
+            if dist.get_backend() == "nccl":
+                flag = flag.cuda()
+            try:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    selfcheck["ok"] = False
+            except Exception as e:
+                selfcheck["agreement_error"] = str(e)[:200]
         if selfcheck is not None and not selfcheck["ok"] and lat.comm_backend == "peer" and args.comm == "auto":
-            comm_note = "peer-mapped windows gave |D b|^2 = %.17e, expected %.17e: fell back to RCCL" % (selfcheck["norm2_Db"], selfcheck["expected"])
+            comm_note = "peer-mapped windows gave |D b|^2 = %.17e, expected %.17e%s: fell back to RCCL" % (
+                selfcheck["norm2_Db"], selfcheck["expected"], (" (" + selfcheck["error"] + ")") if "error" in selfcheck else "")
             for o in (x, y, b, D, U):
                 o.close()
             lat.close()
