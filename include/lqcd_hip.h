@@ -115,8 +115,7 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * scalar-addressing Wilson kernel as rows 0, 1 in fp64 + the fp32 deviation of row 2, 128 B per link; results equal the 18-real kernel's to fp64 rounding; recon_active reads 2),
  * dslash_s18 (1 [default]: the scalar-addressing kernel also on the 18 stored reals), bicg_fused (even-odd BiCGStab of the Wilson / Wilson-clover operator: 2 inner
  * products from the Schur operator's epilogue and, up to 1024 chunks per parity, reductions and scalar steps in the consumers' prologues; 1 the same with separate reduction
- * launches -- bit-identical to 2; 4 [default] = 2 with the x / r and p updates merged into one launch on recurrences for rho' and |r'|^2 (plain Wilson where the
- * scalar-addressing / site-pair kernels apply, otherwise form 2; equal to 2 up to rounding; bicg_rec_guard: digits of cancellation the |r'|^2 recurrence may show before the
+ * launches -- bit-identical to 2; 4 [default] = 2 with the x / r and p updates merged into one launch on recurrences for rho' and |r'|^2 (equal to 2 up to rounding; bicg_rec_guard: digits of cancellation the |r'|^2 recurrence may show before the
  * stopping test waits for the summed value); 3 = 2 with a grid barrier between the two updates (slower); 0 the generic chain; read-only bicg_xrp_active: 0 | 1 (form 3) | 2 (form 4)), action_eo_solver (1 [default]: lqcd_fermi_action / lqcd_calc_UdSfdU / lqcd_action_* solve the Wilson(-clover) normal
  * equations as two even-odd BiCGStab solves under the reference's stopping rule; 0: CG), bicg_mixed (1: lqcd_solve_bicgstab_eo on the plain Wilson operator runs an fp32 inner
  * chain inside an fp64 defect correction, the stopping rule holds for the true fp64 residual; mixed_action_solver = 1 switches it on for the action solves), lazy_links (1: the per-direction link-call triples are recorded and fused -- the temporaries of a completed triple are then never written, so the C ABI's default is 0 (eager) and the Julia / Python bindings switch it on when they create a context,

@@ -527,9 +527,8 @@ struct Tunables {
 #endif
     int bicg_fused = 4;       // even-odd BiCGStab, plain Wilson r = 1 on an unpartitioned lattice: 4 [default, round 6] = 2 + the x / r update and the p update as ONE launch WITHOUT a
                               // barrier: rho' and |r'|^2 from inner products that exist before r' does (solvers.hip bicgf_xrp_rec; <r0, t> from a second inner product in the dot
-                              // epilogue of the scalar-addressing kernel) -- 6 launches, 12 vector passes instead of 14: 112.4 -> 106.0 us per iteration at 16^3x32, 20.9 -> 19.9 ms per
-                              // solve at 32^3x64; equal to form 2 up to the rounding of the two recurrences (no drift: rho - alpha <r0, v> = <r0, s> = 0 in every iteration); where that
-                              // kernel does not apply (clover, 18-real links, small planes) it IS form 2.  3 [opt-in, round 6] = 2 + the x / r update and the p update as ONE launch
+                              // epilogue of every dot-mode kernel, Wilson-clover included) -- 6 launches, 12 vector passes instead of 14: 112.4 -> 106.0 us per iteration at 16^3x32, 20.9 -> 19.9 ms per
+                              // solve at 32^3x64; equal to form 2 up to the rounding of the two recurrences (no drift: rho - alpha <r0, v> = <r0, s> = 0 in every iteration); Wilson-clover 16^3x32: 186 -> 174 us per iteration.  3 [opt-in, round 6] = 2 + the x / r update and the p update as ONE launch
                               // with a grid-wide barrier between them (6 launches per iteration; all <= 1024 workgroups resident) -- bit-identical and SLOWER (128.6 vs
                               // 112.4 us per iteration at 16^3x32, profiles/r06_bicgstab_eo_chain.log: a barrier of 1024 workgroups costs more than the launch boundary it replaces); 1 = the inner products come from the epilogues of the Schur
                               // operator's second hop (no dot-product passes), reductions and scalar steps as separate one-block launches; 2 = on lattices of
@@ -978,7 +977,7 @@ struct StencilCall {
     const double2* dot_z[2] = {nullptr, nullptr};
     double* dot_partial = nullptr;
     int dot_conj = 0;             // 1: <out, z> (the imaginary part changes sign)
-    const double2* dot_z2[2] = {nullptr, nullptr};      // scalar-addressing kernel, z = xin only: a second inner product <z2, out> (never conjugated) -> FIVE values per workgroup,
+    const double2* dot_z2[2] = {nullptr, nullptr};      // every dot-mode kernel, z = xin only: a second inner product <z2, out> (never conjugated) -> FIVE values per workgroup,
                                                           // dot_partial[5 b + (0..4)] = Re / Im <z, out>, |out|^2, Re / Im <z2, out>  (merged BiCGStab chain: <r0, t> beside <t, s>)
     // Domainwall (domainwall.hip): the L5 slices of a five-dimensional field in ONE launch of the scalar-addressing kernel -- in / xin / out point at slice 0, slice s5 is
     // dw_slice elements further on -- with the fifth-direction hops -P_A psi(s+1) - P_B psi(s-1) (mass term at the walls) added in the epilogue
@@ -1040,7 +1039,6 @@ bool any_partitioned(lqcd_ctx_s* c);
 bool halo_fold_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec, bool clover);   // the folded one-stream schedule runs for such a call (stencil.hip)
 int halo_exchange_local_all(lqcd_ctx_s** ctxs, int n, int kind, int parity_mode);
 int stencil_num_blocks(lqcd_ctx_s* c, int kind, double r, int parity_mode, int prec = 0, bool clover = false);
-bool stencil_dot2_applies(lqcd_ctx_s* c, int parity_mode, bool have12);
 bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s);      // a StencilCall with dw_ls > 1 can run (stencil.hip)
 bool wilson_pipe_applies(lqcd_ctx_s* c, int kind, double r, int parity_mode, bool clover);   // the persistent kernel runs for this call (large lattices only)
 // the operator's full-lattice applications carry the packed clover blocks into the stencil (make_full_call's rule)

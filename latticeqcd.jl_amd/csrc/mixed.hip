@@ -685,8 +685,8 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
     const int nbs = m.layout == 2 ? pair32_num_blocks(c) / 2 : (c->geom.Vh + 63) / 64;      // (dot instances: one workgroup per 64-site chunk, whatever dslash_pipe says)
     const int nbk = (int)std::min<size_t>(1024, (n4 + UB - 1) / UB);
     const bool fold = c->tun.bicg_fused >= 2 && nbs <= 1024;
-    // the merged update launch on the two recurrences (bicg_fused = 4, solvers.hip): site pairs only (the second inner product lives in stencil_pair32.hip's dot epilogue)
-    const bool rec = c->tun.bicg_fused == 4 && m.layout == 2 && !m.ainv;
+    // the merged update launch on the two recurrences (bicg_fused = 4, solvers.hip)
+    const bool rec = c->tun.bicg_fused == 4;
     double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;
     const double* skip = c->d_scal + (B_DONE - S_DONE);
     if (!pre_init) HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));      // (pre_init: the conversion that made m.r also set x = 0, r0 = p = r)
@@ -736,8 +736,10 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
                 if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2));
                 a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
                 a.guard = std::pow(10.0, -(double)c->tun.bicg_rec_guard);
-                hipLaunchKernelGGL(bicgf32_xrp_rec<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (float4*)m.p, (const float4*)m.s, (const float4*)m.t,
-                                   (const float4*)m.v, n4);
+                if (m.layout == 2) hipLaunchKernelGGL(bicgf32_xrp_rec<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (float4*)m.p, (const float4*)m.s,
+                                                      (const float4*)m.t, (const float4*)m.v, n4);
+                else hipLaunchKernelGGL(bicgf32_xrp_rec<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (float4*)m.p, (const float4*)m.s,
+                                        (const float4*)m.t, (const float4*)m.v, n4);
                 HIPCHK(hipGetLastError());
                 continue;
             }

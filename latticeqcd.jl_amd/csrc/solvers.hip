@@ -1261,12 +1261,8 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bicgf_xrp, UB, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
         if ((long)per_cu * c->num_cu < nbk) xrp = false;
     }
-    // bicg_fused = 4: the merged update launch on the two recurrences (bicgf_xrp_rec); needs the second inner product of the dot epilogue (scalar-addressing kernel, plain Wilson)
-    bool rec = false;
-    if (c->tun.bicg_fused == 4 && !Ai) {
-        const StencilCall probe = make_hop_call(op, v, to, p, 1.0, -k * k, dg);
-        rec = stencil_dot2_applies(c, 0, probe.gauge12 != nullptr && !probe.gauge12_delta);
-    }
+    // bicg_fused = 4: the merged update launch on the two recurrences (bicgf_xrp_rec), <r0, t> from the second inner product of the dot epilogue
+    const bool rec = c->tun.bicg_fused == 4;      // (every dot-mode kernel forms the second inner product: plain, clover-on-hop, scalar-addressing)
     if (rec) xrp = false;
     c->tun.bicg_xrp_active = xrp ? 1 : (rec ? 2 : 0);
     if (xrp && (c->cgp_nwg != nbk || c->cgp_epoch > 100000000u)) {      // the barrier counters (shared with the one-launch CG): never reset between launches of one grid size

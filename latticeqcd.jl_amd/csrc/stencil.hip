@@ -192,7 +192,7 @@ __device__ __forceinline__ bool fold_chunk_skipped(const KArgs& k, int chunk, in
 template <bool DAG, bool R12, bool CLOV, bool DOT, bool CINV, bool FOLD>
 __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs* hf) {
     __shared__ real2 part[4][12][64];  // 48 KiB
-    __shared__ double red[DOT ? 12 : 4];
+    __shared__ double red[DOT ? 20 : 4];
     if (upd_done(k)) return;
     const real al_upd = update_alpha(k);
     int chunk, p;
@@ -252,6 +252,13 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
 #pragma unroll                      // 3 waves/SIMD); the LDS exchange and the barrier cover the load
         for (int cc = 0; cc < 3; cc++) zv[cc] = !valid ? mk(0, 0) : (k.dotz[p] == k.xin[p] && k.a != 0.0) ? xv[cc] : ld(k.dotz[p] + sp12_off(i) + co12(3 * w + cc));
     }                               // (z = the diagonal term's field -- <t, s> with t = M s -- is in registers already)
+    // second inner product (StencilCall::dot_z2, only beside z = xin): <z2, out> -> five values per workgroup (merged BiCGStab chain: <r0, t> beside <t, s>, |t|^2)
+    const bool two = DOT && k.dotz2[p] != nullptr && k.dotz[p] == k.xin[p] && k.a != 0.0;
+    cd z2[DOT ? 3 : 1];
+    if constexpr (DOT) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) z2[cc] = (valid && two) ? ld(k.dotz2[p] + sp12_off(i) + co12(3 * w + cc)) : mk(0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < 12; j++) part[w][j][lane] = mk2(acc[j].re, acc[j].im);
     if constexpr (CLOV) if (valid && k.a != 0.0) {   // this wave's rows of A xin (its partial sums are already on their way to LDS)
@@ -260,7 +267,7 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
         else clover_rows<0>(xv, ca, cpsi, w >= 2);
     }
     __syncthreads();
-    real nrm = 0.0, dre = 0.0, dim = 0.0;
+    real nrm = 0.0, dre = 0.0, dim = 0.0, dre2 = 0.0, dim2 = 0.0;
     cd hs[CINV ? 3 : 1];
     if constexpr (CINV) if (valid) {        // this wave's rows of C (H in): all 12 summed components, then the packed 6x6 blocks
         cd v12[12];
@@ -286,18 +293,24 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
             if constexpr (DOT) {        // <z, v> = conj(z) v
                 dre = fma(zv[cc].re, v.re, dre); dre = fma(zv[cc].im, v.im, dre);
                 dim = fma(zv[cc].re, v.im, dim); dim = fma(-zv[cc].im, v.re, dim);
+                dre2 = fma(z2[cc].re, v.re, dre2); dre2 = fma(z2[cc].im, v.im, dre2);
+                dim2 = fma(z2[cc].re, v.im, dim2); dim2 = fma(-z2[cc].im, v.re, dim2);
             }
         }
     }
-    if constexpr (DOT) {                // three sums per workgroup: a wave tree each, then the four waves in a fixed order
-        double t3[3] = {(double)dre, (double)(k.dot_conj ? -dim : dim), (double)nrm};
+    if constexpr (DOT) {                // three sums per workgroup: a wave tree each, then the four waves in a fixed order; five with a second inner product
+        const bool five = k.dotz2[0] != nullptr || k.dotz2[1] != nullptr;
+        double t3[5] = {(double)dre, (double)(k.dot_conj ? -dim : dim), (double)nrm, (double)dre2, (double)dim2};
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            t3[q] = wave_sum(t3[q]);
-            if (lane == 0) red[4 * q + w] = t3[q];
+        for (int q = 0; q < 5; q++) {
+            if (q < 3 || five) {
+                t3[q] = wave_sum(t3[q]);
+                if (lane == 0) red[4 * q + w] = t3[q];
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 3) k.dot_partial[3 * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        const int nv = five ? 5 : 3;
+        if ((int)threadIdx.x < nv) k.dot_partial[nv * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
         return;
     }
     if (k.norm_partial) {
@@ -1823,9 +1836,6 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
                 launched = true;
             }
 #endif
-            if (s.dot_z2[0] || s.dot_z2[1]) {
-                if (!launched || s.clover_on_hop) { set_error("stencil: the second inner product of the dot epilogue exists in the scalar-addressing kernel only (stencil_dot2_applies)"); return LQCD_ERR_UNSUPPORTED; }
-            }
             if (!launched) {            // the plain direction-split kernel (fp32 build: the inner chain of the mixed-precision even-odd solver)
                 if (k.gauge12) {
                     if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true>), grid, block, pad, c->stream, k);
@@ -2034,10 +2044,6 @@ int wilson_pipe_grid(lqcd_ctx_s* c, int nvirt, int prec) {
 // tail imbalance eats the gain) and only the r = 1 Wilson operator; a call that carries the packed clover blocks (fused A x epilogue) keeps
 // the plain variant-1 kernel -- `clover` is that property of the call (StencilCall::clover != nullptr; solvers: op_fused_clover).
 // the L5 slices of a Domainwall application as ONE launch of the scalar-addressing kernel: fp64, one GPU, full-lattice plain mode, 12-real links (fields on the group)
-// dot mode with a second inner product (StencilCall::dot_z2): the fp64 scalar-addressing kernel on 12-real links
-bool stencil_dot2_applies(lqcd_ctx_s* c, int parity_mode, bool have12) {
-    return !kF32Build && have12 && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, LQCD_WILSON, 1.0, parity_mode, false);
-}
 bool stencil_dw5_applies(lqcd_ctx_s* c, const StencilCall& s) {
     if (kF32Build || s.prec != 0 || s.kind != LQCD_WILSON || s.r != 1.0 || s.parity_mode != 2 || any_partitioned(c)) return false;
     if (s.alpha_partials || s.dot_partial || s.clover || s.clover_on_hop || s.gauge12_delta) return false;      // (|.|^2 partials -- one per workgroup = chunk x slice -- and the update mode ride along: dw_solve)

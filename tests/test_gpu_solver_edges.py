@@ -241,15 +241,16 @@ def test_deferred_x_update_gives_identical_iterates(lq, orc, kind_name):
             assert np.array_equal(a, c), defer
 
 
-@pytest.mark.parametrize("L,dagger", [((16, 8, 8, 8), False), ((16, 16, 16, 32), True)])
-def test_evenodd_bicgstab_merged_update_on_the_recurrences(lq, orc, L, dagger):
+@pytest.mark.parametrize("L,dagger,csw", [((16, 8, 8, 8), False, 0.0), ((16, 16, 16, 32), True, 0.0), ((8, 8, 8, 16), True, 0.0), ((8, 8, 8, 16), False, 1.3), ((16, 16, 16, 32), True, 1.0)])
+def test_evenodd_bicgstab_merged_update_on_the_recurrences(lq, orc, L, dagger, csw):
     """bicg_fused = 4 (opt-in): x / r and p update as ONE launch without a barrier -- rho' = rho - alpha <r0, v> - omega <r0, t> and |r'|^2 = |s|^2 - |<t,s>|^2 / |t|^2
-    from inner products that exist before r' does (<r0, t> from a second inner product in the dot epilogue of the scalar-addressing kernel).  Equal to the default
+    from inner products that exist before r' does (<r0, t> from a second inner product in the dot epilogue: scalar-addressing kernel, plain direction-split kernel on small
+    planes, clover-on-hop kernel of the Wilson-clover Schur operator).  Equal to the two-launch
     chain up to the rounding of the two recurrences: same iteration count, solution to 1e-10, stopping rule on the recursive residual, true residual recomputed here.
     bicg_rec_guard = 0 distrusts the recurrence for |r'|^2 always: the stopping test then waits for the summed |r'|^2 (the next iteration's first streaming kernel)."""
     U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
     lat = U.lattice
-    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover" if csw else "Wilson", "Clover_coefficient": csw, "κ": KAPPA, "eps_CG": 1e-19, "MaxCGstep": 3000})
     Dd = D.adjoint() if dagger else D
     Dd.method_CG = "bicgstab_evenodd"
     b = lq.Fermionfields(lat, lq.WILSON)
@@ -264,13 +265,13 @@ def test_evenodd_bicgstab_merged_update_on_the_recurrences(lq, orc, L, dagger):
         r = b.similar()
         lq.mul_(r, Dd, x)
         lq.add_fermion_(r, -1.0, b)
-        assert lq.dot(r, r).real < 1e-18, (mode, guard)           # the true residual of the full system (the even-odd solve stops on the Schur system's recursive one)
+        assert lq.dot(r, r).real < (1e-17 if csw else 1e-18), (mode, guard)           # the true residual of the full system (the even-odd solve stops on the [A^-1-preconditioned] Schur system's recursive one)
         out[(mode, guard)] = (x.download(), it)
     lat.set_param("bicg_fused", 2)
     lat.set_param("bicg_rec_guard", 6)
     for key in ((4, 6), (4, 0)):
         assert abs(out[key][1] - out[(2, 6)][1]) <= 1 and rel_err(out[key][0], out[(2, 6)][0]) < 1e-10, key
-    if L[3] == 8:
+    if L[3] == 8 and not csw:
         xo, ito, rro, st = orc.wilson_bicgstab_eo(U.download(), b.download(), L, KAPPA, 1.0, (1, 1, 1, -1), dagger, eps=1e-19)
         assert st == 0 and abs(ito - out[(4, 6)][1]) <= 1 and rel_err(out[(4, 6)][0], xo) < 1e-9
 
