@@ -87,7 +87,8 @@ int lqcd_ctx_sync(lqcd_ctx_t ctx);
  * workgroup, pipelined; 0: plain variant 1.  Forms 1 and 3 measured slower, LABNOTES.md section 2 "Round 3"), mixed_pair32 (1 [default]: the mixed-precision Wilson
  * solvers use the fp32 site-pair kernel on unpartitioned lattices with T % 4 == 0; read-only pair32_active), mixed_links16 (that kernel reads its links as int16 fixed point;
  * 1 [default]: in the even-odd BiCGStab of the action / force solves, 2: in every mixed-precision solver, 0: fp32 links), bicg_reliable (1: the fp32 chain of that BiCGStab goes on
- * behind a correction step instead of starting again; default 0), dw_fused_cg (1 [default]: Domainwall solves run the fused CG iteration on the five-dimensional launch), stag_both (1: the staggered split kernel issues the loads of both hops back to back);
+ * behind a correction step instead of starting again; default 0), dw_fused_cg (1 [default]: Domainwall solves run the fused CG iteration on the five-dimensional launch), clover_hop_s (1 [default]: the hops of the even-odd Wilson-clover
+ * solver run the scalar-addressing kernel with the inverse clover blocks in its epilogue), stag_both (1: the staggered split kernel issues the loads of both hops back to back);
  * solvers / actions: mixed_action_solver (1: lqcd_fermi_action / lqcd_calc_UdSfdU / the staggered rational entries solve with the
  * mixed-precision CG; 2: the same, and every rational entry solves all its poles with lqcd_solve_multishift_mixed_cg -- measured slower than the fp64
  * multi-shift CG at 48^3x96 with 18 poles, default 0), staggered_parity_solve (1 [default]: half-lattice CG for a staggered eta whose odd half is zero),

@@ -534,6 +534,8 @@ struct Tunables {
                               // operator's second hop (no dot-product passes), reductions and scalar steps as separate one-block launches; 2 = on lattices of
                               // <= 1024 chunks per parity the reductions and scalar steps also move into the prologues of the consumers (7 dependent launches per
                               // iteration instead of 17, identical iterates); 0 = the generic chain (what the clover / full-lattice solvers run)
+    int clover_hop_s = 1;     // even-odd Wilson-clover solver: the hops with the inverse clover blocks on the hop sum run the scalar-addressing kernel (CINV instance of
+                              // wilson_dirsplit_s) where it applies; 0: the plain direction-split kernel
     int bicg_xrp_active = 0;  // read-only: the last even-odd BiCGStab solve ran the fused x / r / p launch -- 1: bicg_fused = 3 (grid barrier, every workgroup resident), 2: bicg_fused = 4 (recurrences)
     int action_eo_solver = 1; // lqcd_fermi_action / lqcd_calc_UdSfdU, Wilson(-clover): X = (D^+D)^-1 eta through two even-odd BiCGStab solves (Y = D^-+ eta, X = D^-1 Y)
                               // instead of the CG on the normal equations (0: the reference's form); same stopping rule for the same residual (actions.hip)

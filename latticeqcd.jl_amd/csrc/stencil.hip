@@ -362,6 +362,7 @@ __global__ LQCD_DS_BOUNDS_FOLD void wilson_dirsplit_fold(KArgs k, HArgs h) { wil
 #endif
 struct PipeArgs {
     const real2* gauge;       // the 18-real field, or the 12-real copy (template R12)
+    const real2* clover;      // CINV instances (StencilCall::clover_on_hop): packed 6x6 blocks applied to the hop sum
     real2* dst[2];            // out, or r in update mode (read and written)
     const real2* in[2];
     const real2* xin[2];
@@ -442,6 +443,7 @@ struct PipeSite {
     int p;
     bool wf, wb;               // the forward / backward hop of this direction wraps the local lattice (MU >= 2: wave-uniform)
     int fidx;                  // index of the site inside the face of direction MU (coords_to_face), MU >= 1
+    int chunk;                 // 64-site chunk inside the parity block (wave-uniform)
 };
 template <int MU, int NL>      // NL: 16-byte elements per link (9: 18 reals, 6: 12 reals)
 __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
@@ -455,6 +457,7 @@ __device__ inline PipeSite pipe_site(const PipeArgs& a, int b, int lane) {
     pipe_map(a, b, s.p, t, z, yc);
     const int chunk = t * a.cps + z * a.cpp + yc;
     s.own = (unsigned)chunk * SPC + (unsigned)lane * 16u;
+    s.chunk = chunk;
     s.uf = (unsigned)chunk * LKC + MU * LKM + (unsigned)lane * LKL;
     if constexpr (MU >= 2) {      // the neighbour of a chunk is a chunk: everything but the lane term is wave-uniform
         const int c = MU == 2 ? z : t, Lc = MU == 2 ? a.L2 : a.LT, st = MU == 2 ? a.cpp : a.cps;
@@ -765,7 +768,7 @@ __device__ inline void fold_unit_link(cd (&u)[9], bool face) {      // (called w
     }
 }
 
-template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false>
+template <int MU, bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false, bool CINV = false>
 __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int lane, real al_upd, real& nrm, real& dre, real& dim, int vb, real& dre2, real& dim2) {
     // DW5: this workgroup's slice s5 of the five-dimensional fields; block ids keep their XCD (b & 7) and the L5 slices of a chunk follow each other on it, so the
     // links of the chunk are fetched from the fabric once and hit the XCD's L2 for the other slices
@@ -799,7 +802,7 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
     cd xv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)}, rv[3] = {mk(0, 0), mk(0, 0), mk(0, 0)};
     const bool z_is_x = DOT && (s.p ? a.dotz[1] == a.xin[1] : a.dotz[0] == a.xin[0]) && a.a != real(0.0);
     const bool two = DOT && z_is_x && (s.p ? a.dotz2[1] : a.dotz2[0]) != nullptr;      // second inner product: z = xin leaves the registers of z to z2
-    if constexpr (DOT) {        // dot mode: z takes the registers the old r has in update mode (requested ahead of the hops, scalar base + lane offset)
+    auto load_z = [&]() {
         if (!z_is_x) {
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dotz[1] : a.dotz[0], s.own) + co12(3 * MU + cc));
@@ -807,11 +810,14 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dotz2[1] : a.dotz2[0], s.own) + co12(3 * MU + cc));
         }
+    };
+    if constexpr (DOT) {        // dot mode: z takes the registers the old r has in update mode (requested ahead of the hops, scalar base + lane offset; CINV instances: behind them)
+        if constexpr (!CINV) load_z();
     } else if (!LATE_R && a.upd_scal) {    // (18-real and 12 + delta links: their extra words take these registers during the hops; the old r is requested behind them)
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) rv[cc] = ld(boff(s.p ? a.dst[1] : a.dst[0], s.own) + co12(3 * MU + cc));
     }
-    constexpr bool LATE_X = LATE_R && !R12 && !DOT;      // all 18 reals: the diagonal term's load moves behind the hops as well
+    constexpr bool LATE_X = (LATE_R && !R12 && !DOT) || (CINV && DOT);      // all 18 reals, and the dot instances with the clover blocks in the epilogue: the diagonal term's load moves behind the hops as well
     if (!LATE_X && a.a != real(0.0)) {
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) xv[cc] = ld(boff(s.p ? a.xin[1] : a.xin[0], s.own) + co12(3 * MU + cc));
@@ -929,6 +935,7 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
     }
 #pragma unroll
     for (int j = 0; j < 12; j++) part[MU][j][lane] = mk2(acc[j].re, acc[j].im);
+    if constexpr (DOT && CINV) load_z();      // (the barrier and the block products cover the load)
     cd w5[DW5 ? 3 : 1];
     if constexpr (DW5) {      // fifth-direction hops of this wave's three components: -P_A psi(s+1) - P_B psi(s-1), the mass term at the walls; P_-+ psi = (psi -+ g5 psi)/2
                               // and (g5 psi)_spin = -psi_(spin xor 2): the partner component is six further on or back.  Issued behind the stores of the partial sums (round 5: the twelve accumulators are dead by now -- the instance no longer spills): the barrier and the LDS reads cover them
@@ -947,11 +954,54 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
     }
     __syncthreads();
     real2* dstp = const_cast<real2*>(boff(s.p ? a.dst[1] : a.dst[0], s.own));
+    cd hs[CINV ? 3 : 1];
+    if constexpr (CINV) {       // this wave's rows of C (H in): all 12 summed components, then the packed 6x6 blocks (the epilogue of wilson_dirsplit's CINV instances)
+        // one chiral block at a time, its six chi components summed from LDS when the block needs them (12 summed components held at once would spill a few registers
+        // at three workgroups per CU); the same additions in the same order as clover_rows on a full v12
+        auto vsum = [&](int j) {
+            const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
+            return mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        };
+        const real2* __restrict__ ca = a.clover + (((size_t)s.p * a.nch + (size_t)s.chunk) * 36) * 64 + lane;
+        constexpr int S1 = MU & 1;
+        constexpr bool lower = MU >= 2;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) hs[cc] = mk(0.0, 0.0);
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const real sg = b == 0 ? real(-1.0) : real(1.0);
+            cd chi[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const cd u = vsum(q), l = vsum(6 + q);
+                chi[q] = mk(u.re + sg * l.re, u.im + sg * l.im);
+                if (q & 1) __builtin_amdgcn_sched_barrier(0);      // (16 LDS reads in flight at a time: the scheduler otherwise batches all 48 of a block -- and the next block's -- and spills)
+            }
+            const real2* __restrict__ ab = ca + (size_t)(18 * b) * 64;
+            const real wgt = real(0.5) * ((b == 0 && lower) ? real(-1.0) : real(1.0));
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                const int r = 3 * S1 + cc;
+                const cd dd = ld(ab + (size_t)(r >> 1) * 64);
+                const real d = (r & 1) ? dd.im : dd.re;
+                cd y = mk(d * chi[r].re, d * chi[r].im);
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    if (q == r) continue;
+                    const int lo = q < r ? q : r, hi = q < r ? r : q;
+                    const cd m = ld(ab + (size_t)(3 + 5 * lo - (lo * (lo - 1)) / 2 + (hi - lo - 1)) * 64);
+                    if (q > r) cfma(y, m, chi[q]); else cfma_conj(y, m, chi[q]);
+                }
+                hs[cc] = mk(hs[cc].re + wgt * y.re, hs[cc].im + wgt * y.im);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) {
         const int j = 3 * MU + cc;
         const real2 s0 = part[0][j][lane], s1 = part[1][j][lane], s2 = part[2][j][lane], s3 = part[3][j][lane];
-        cd sm = mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        cd sm = CINV ? hs[cc] : mk((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         cd v = a.b * sm;
         v = mk(fma(a.a, xv[cc].re, v.re), fma(a.a, xv[cc].im, v.im));
         if constexpr (DW5) v = mk(v.re + w5[cc].re, v.im + w5[cc].im);
@@ -978,7 +1028,7 @@ __device__ inline void sdir_wave(const PipeArgs& a_, real2 (*part)[12][64], int 
     }
 }
 
-template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false>
+template <bool DAG, bool R12, bool NTB, bool DOT = false, bool DELTA = false, bool DW5 = false, bool FOLD = false, bool CINV = false>
 __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     __shared__ real2 part[4][12][64];  // 48 KiB (fp32: 24)
     __shared__ double red[DOT ? 20 : 4];
@@ -1012,10 +1062,10 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     const int lane = threadIdx.x & 63;
     real nrm = 0.0, dre = 0.0, dim = 0.0, dre2 = 0.0, dim2 = 0.0;
     switch (w) {
-    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
-    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
-    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
-    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5, FOLD>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
+    case 0: sdir_wave<0, DAG, R12, NTB, DOT, DELTA, DW5, FOLD, CINV>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
+    case 1: sdir_wave<1, DAG, R12, NTB, DOT, DELTA, DW5, FOLD, CINV>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
+    case 2: sdir_wave<2, DAG, R12, NTB, DOT, DELTA, DW5, FOLD, CINV>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
+    default: sdir_wave<3, DAG, R12, NTB, DOT, DELTA, DW5, FOLD, CINV>(a, part, lane, al_upd, nrm, dre, dim, vb, dre2, dim2); break;
     }
     if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue; five with a second inner product (dot_z2)
         const bool five = a.dotz2[0] != nullptr || a.dotz2[1] != nullptr;
@@ -1671,6 +1721,7 @@ static PipeArgs make_pipe_args(lqcd_ctx_s* c, const KArgs& k, const StencilCall&
     const bool upd = k.upd_scal != nullptr;
     for (int p = 0; p < 2; p++) { a.dst[p] = upd ? k.upd[p] : k.out[p]; a.in[p] = k.in[p]; a.xin[p] = k.xin[p]; a.dotz[p] = k.dotz[p]; a.dotz2[p] = k.dotz2[p]; }
     a.dot_partial = k.dot_partial; a.dot_conj = k.dot_conj;
+    a.clover = k.clover;
     a.norm_partial = k.norm_partial; a.upd_scal = k.upd_scal; a.skip = k.skip; a.scal_w = k.scal_w;
     a.a = k.a; a.b = k.b;
     a.nt_store = (k.nt & 4) != 0;
@@ -1818,6 +1869,18 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
             if ((k.clover && !s.clover_on_hop) || s.r != 1.0) { set_error("stencil: dot mode needs the Wilson r = 1 kernel without a diagonal clover term"); return LQCD_ERR_UNSUPPORTED; }
             dim3 grid(k.nblocks), block(256);
             bool launched = false;
+#ifndef LQCD_F32
+            if (s.clover_on_hop && k.gauge12 && c->tun.clover_hop_s && c->tun.dslash_pipe == 2 && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {
+                // round 6: the scalar-addressing kernel with the inverse blocks in its epilogue (CINV instance)
+                PipeArgs a = make_pipe_args(c, k, s);
+                const bool ntb = (k.nt & 1) != 0;
+                if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, true, true, false, false, false, true>), grid, block, 0, c->stream, a);
+                                else hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, true, false, false, false, true>), grid, block, 0, c->stream, a); }
+                else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<false, true, true, true, false, false, false, true>), grid, block, 0, c->stream, a);
+                       else hipLaunchKernelGGL((wilson_dirsplit_s<false, true, false, true, false, false, false, true>), grid, block, 0, c->stream, a); }
+                launched = true;
+            } else
+#endif
             if (s.clover_on_hop) {      // even-odd clover solver: inverse blocks on the hop sum + the inner-product epilogue (both builds)
                 if (k.gauge12) { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, true, true>), grid, block, pad, c->stream, k);
                                  else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, true, true>), grid, block, pad, c->stream, k); }
@@ -1848,6 +1911,16 @@ int launch_stencil_interior(lqcd_ctx_s* c, const StencilCall& s) {
         } else if (s.kind == LQCD_WILSON && s.clover_on_hop) {      // even-odd clover solver: out = a xin + b C (H in), C = the inverse clover blocks of the output parity
             if (!k.clover || s.r != 1.0) { set_error("stencil: clover-on-hop needs the packed blocks and r = 1"); return LQCD_ERR_UNSUPPORTED; }
             dim3 grid(k.nblocks), block(256);
+#ifndef LQCD_F32
+            if (k.gauge12 && c->tun.clover_hop_s && c->tun.dslash_pipe == 2 && !k.alpha_partials && !s.fold && wilson_pipe_applies(c, s.kind, s.r, s.parity_mode, false)) {
+                PipeArgs a = make_pipe_args(c, k, s);      // round 6: the scalar-addressing kernel, inverse blocks in its epilogue
+                const bool ntb = (k.nt & 1) != 0;
+                if (s.dagger) { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<true, true, true, false, false, false, false, true>), grid, block, 0, c->stream, a);
+                                else hipLaunchKernelGGL((wilson_dirsplit_s<true, true, false, false, false, false, false, true>), grid, block, 0, c->stream, a); }
+                else { if (ntb) hipLaunchKernelGGL((wilson_dirsplit_s<false, true, true, false, false, false, false, true>), grid, block, 0, c->stream, a);
+                       else hipLaunchKernelGGL((wilson_dirsplit_s<false, true, false, false, false, false, false, true>), grid, block, 0, c->stream, a); }
+            } else
+#endif
             if (k.gauge12) { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, true, false, false, true>), grid, block, pad, c->stream, k);
                              else hipLaunchKernelGGL((wilson_dirsplit<false, true, false, false, true>), grid, block, pad, c->stream, k); }
             else { if (s.dagger) hipLaunchKernelGGL((wilson_dirsplit<true, false, false, false, true>), grid, block, pad, c->stream, k);

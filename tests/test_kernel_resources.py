@@ -12,6 +12,8 @@ ALLOWED = {
     "gauge_hot": "one-off initialisation of a hot start (Gram-Schmidt on a private 3x3 array)",
     "wilson_dirsplit_pipe": "the persistent forms of the stencil (dslash_pipe = 1 / 3): opt-in experiments, never the default",
     "p3217wilson_dirsplit_s": "fp32 instances of the scalar-addressing kernel: compiled with the shared source, never launched (stencil.hip launch_stencil_interior: !kF32Build)",
+    "ELb1ELb0ELb0ELb0ELb1EEEvNS0_8PipeArgsE": "dot instances of the scalar-addressing kernel with the inverse clover blocks in the epilogue (round 6): 6 dwords -- thread id, lane and one double, "
+                                              "stored once at the top and reloaded in the epilogue; every placement of the z load that was tried moved or grew the spill (stencil.hip sdir_wave CINV)",
     "clover_lambda_kernel": "clover force, once per MD step: six Hermitian 3x3 accumulators per site (dynamic plane index)",
     "stout_gather_ext_kernel": "stout back-propagation on a partitioned lattice, once per MD step: 13 live 3x3 matrices (ROUND_NOTES r4)",
 }
