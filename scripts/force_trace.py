@@ -1,4 +1,4 @@
-"""calc_UdSfdU! (AbstractMD.jl:129) with the mixed-precision solver at 32^3x64, a few calls -- for rocprofv3 --kernel-trace (gpurun helper)."""
+"""calc_UdSfdU! (AbstractMD.jl:129) at 32^3x64, a few calls -- for rocprofv3 --kernel-trace (gpurun helper).  env: MIXED=0|1 (solver), CSW=c (Wilson-clover), LQCD_SET="key=value ..." """
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import latticeqcd_jl_amd as lq
@@ -7,7 +7,8 @@ lat = U.lattice
 for kv in os.environ.get("LQCD_SET", "").split():
     k, v = kv.split("=")
     lat.set_param(k, int(v))
-D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": 0.141139, "eps_CG": 1e-16, "MaxCGstep": 3000})
+csw = float(os.environ.get("CSW", "0"))
+D = lq.Dirac_operator(U, None, {"Dirac_operator": "WilsonClover" if csw else "Wilson", "Clover_coefficient": csw, "κ": 0.141139, "eps_CG": 1e-16, "MaxCGstep": 3000})
 fa = lq.FermiAction(D)
 eta = lq.Fermionfields(lat, lq.WILSON); X = eta.similar()
 lq.gauss_distribution_fermion_(X, 5)
