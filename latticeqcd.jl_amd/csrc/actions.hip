@@ -75,9 +75,11 @@ extern "C" int lqcd_fermi_action(lqcd_op_t op, lqcd_spinor_t eta, lqcd_spinor_t 
         }
     }
     if (Y && !have_Y) LQCHK(op_apply_async(op, Y, X, 0, nullptr));
-    double re = 0, im = 0;
-    LQCHK(blas_dot(c, eta->data, X->data, eta->elems, &re, &im, true));
-    if (Sf) *Sf = re;
+    if (Sf) {      // (the force evaluation asks for X and Y only: no inner product, no read-back)
+        double re = 0, im = 0;
+        LQCHK(blas_dot(c, eta->data, X->data, eta->elems, &re, &im, true));
+        *Sf = re;
+    }
     return LQCD_OK;
 }
 

@@ -681,11 +681,18 @@ __global__ __launch_bounds__(256) void momentum_add_ta_kernel(Geom g, double2* _
         for (int q = 0; q < 3; q++) a[r * 3 + q] = mk(0.5 * (m[r * 3 + q].re - m[q * 3 + r].re), 0.5 * (m[r * 3 + q].im + m[q * 3 + r].im));
     const double tr = (a[0].im + a[4].im + a[8].im) / 3.0;    // the anti-Hermitian part has an imaginary trace
     a[0].im -= tr; a[4].im -= tr; a[8].im -= tr;
+    // (the momenta are anti-Hermitian and so is the increment: the upper triangle is read, the lower one follows -- the same bits, see staple_links)
+    cd o[9];
+    auto addp = [&](auto E) {
+        constexpr int e = decltype(E)::value;
+        const cd pv = ld(P + off + (size_t)e * Gs);
+        o[e] = mk(fma(cf, a[e].re, pv.re), fma(cf, a[e].im, pv.im));
+    };
+    addp(std::integral_constant<int, 0>()); addp(std::integral_constant<int, 1>()); addp(std::integral_constant<int, 2>());
+    addp(std::integral_constant<int, 4>()); addp(std::integral_constant<int, 5>()); addp(std::integral_constant<int, 8>());
+    o[3] = mk(-o[1].re, o[1].im); o[6] = mk(-o[2].re, o[2].im); o[7] = mk(-o[5].re, o[5].im);
 #pragma unroll
-    for (int e = 0; e < 9; e++) {
-        cd pv = ld(P + off + (size_t)e * Gs);
-        st(P + off + (size_t)e * Gs, mk(fma(cf, a[e].re, pv.re), fma(cf, a[e].im, pv.im)));
-    }
+    for (int e = 0; e < 9; e++) st(P + off + (size_t)e * Gs, o[e]);
 }
 
 // exp(dt P).  Below max-abs-row-sum norm 2 of X = dt P (an MD step has a few 1e-2) the Taylor series is summed through the Cayley-Hamilton identity
