@@ -403,7 +403,8 @@ static int mix_prepare(lqcd_op_s* op, size_t n, Mix32& m, bool eo_chain = false)
         const size_t nc = clover_elems(c->geom);
         hipLaunchKernelGGL(cvt_to_f32, dim3(stream_grid(c, nc)), dim3(MB), 0, c->stream, m.clover, op->clover, nc, 1.0);
     }
-    if (use12 && !(c->mix_gauge12_valid && c->mix_gauge12_layout == glayout)) {
+    const bool only16 = pair && (c->tun.mixed_links16 >= 2 || (c->tun.mixed_links16 == 1 && eo_chain));      // the site-pair kernel will read the int16 copy alone: no fp32 pair copy for this solve
+    if (use12 && !only16 && !(c->mix_gauge12_valid && c->mix_gauge12_layout == glayout)) {
         if (pair) LQCHK(pair32_cvt_gauge12(c, m.gauge12, op->gauge->data12));
         else hipLaunchKernelGGL(cvt_gauge12_f32, dim3((2 * c->geom.Vh * 4 + MB - 1) / MB), dim3(MB), 0, c->stream, c->geom, op->gauge->data, m.gauge12);
         c->mix_gauge12_valid = true;
