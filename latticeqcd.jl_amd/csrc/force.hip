@@ -36,6 +36,7 @@ struct FArgs {
     int nc;                    // components per spinor: 12 | 3
     double scale;              // out = (acc ? out : 0) + scale * G   (sums over the poles of a rational action)
     int acc;
+    BlockMap bm;               // workgroup -> (chunk, parity): the XCD tile sweep of the Dslash kernels (tunable md_remap), or plain order
 };
 
 // (g_MU psi)[S][c] for a full 4-spinor held in registers
@@ -165,7 +166,9 @@ __device__ __forceinline__ void wilson_force_site(const FArgs& k, int p, int i, 
 template <bool ACC>
 __global__ __launch_bounds__(256) void wilson_force_kernel(FArgs k) {
     const Geom& g = k.g;
-    const int p = blockIdx.x & 1, i = (blockIdx.x >> 1) * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
+    int chunk, p;
+    block_map(k.bm, blockIdx.x, chunk, p);
+    const int i = chunk * 64 + (threadIdx.x & 63), mu = threadIdx.x >> 6;
     if (i >= g.Vh) return;
     int c[4];
     cb_to_coords(g, p, i, c);
@@ -262,6 +265,7 @@ static FArgs make_fargs(lqcd_ctx_s* c, int kind, const lqcd_gauge_s* U, lqcd_gau
     k.nc = kind == LQCD_WILSON ? 12 : 3;
     k.scale = 1.0;
     k.acc = 0;
+    k.bm = make_block_map(c->geom, c->tun.md_remap ? c->tun.xcd_remap : 0, c->tun.xcd_nsub, c->tun.xcd_ysplit);
     return k;
 }
 
