@@ -49,7 +49,7 @@ __global__ __launch_bounds__(RB) void norm2_kernel(const double2* __restrict__ a
 // sums nblocks partials of `nvals` interleaved values into scal[slot..slot+nvals) in a fixed order (1024 threads, each a
 // strided partial sum, then a wave/LDS tree), optionally followed by a CG scalar step on the same thread (single rank):
 //   op 1: alpha = rr / pq      op 2: beta = rr'/rr, rr = rr', iters++, done = rr' < eps     (flags: see ops.hip)
-__global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op, PeerRedArgs pr) {
+__global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op, PeerRedArgs pr, int soa) {      // soa: [value][block] partials (large form only)
     __shared__ double tot[PEER_RED_VALS];
     // pr.nranks > 0 (peer-mapped backend, comm.hip): the sum over the ranks happens HERE, in the wave that holds the local sums -- no all-reduce launch
     if (nblocks <= 1024) {      // small reductions: one wave, in the order the folded prologues use (sum_partials_small_nv) -- a latency chain of
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ pa
     double cls[PEER_RED_VALS];
 #pragma unroll
     for (int v = 0; v < PEER_RED_VALS; v++)
-        if (v < nvals) cls[v] = sum_partials_class(partial, nblocks, nvals, v, (int)threadIdx.x);
+        if (v < nvals) cls[v] = sum_partials_class(partial, nblocks, nvals, v, (int)threadIdx.x, soa != 0);
 #pragma unroll
     for (int v = 0; v < PEER_RED_VALS; v++)
         if (v < nvals) {
@@ -159,14 +159,15 @@ int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op) {
 
 // device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks.  RCCL: reduce_final -> ncclAllReduce -> one-thread
 // scalar step; peer-mapped backend: ONE launch (the reduction block adds the ranks' slots itself and does the scalar step)
-int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op, const double* partial) {
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op, const double* partial, bool soa) {
+    ARGCHK(!soa || nblocks > 1024, "reduce_to_slot: the [value][block] layout exists for reductions of more than 1024 partials only");
     const bool multi = allreduce && c->has_comm;   // also at world size 1 (self-partition tests exercise the collective)
     const bool peer = multi && c->peer.on;
     ARGCHK(nvals >= 1 && nvals <= PEER_RED_VALS, "reduce_to_slot: one to eight values per reduction");
     if (peer) ARGCHK(nvals <= PEER_RED_VALS, "reduce_to_slot: more than 8 values in one reduction over the ranks");
     PeerRedArgs pr;
     if (peer) pr = comm_red_args(c); else memset(&pr, 0, sizeof pr);
-    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, partial ? partial : c->d_partial, nblocks, nvals, c->d_scal, slot, (multi && !peer) ? 0 : cg_op, pr);
+    hipLaunchKernelGGL(reduce_final, dim3(1), dim3(FB), 0, c->stream, partial ? partial : c->d_partial, nblocks, nvals, c->d_scal, slot, (multi && !peer) ? 0 : cg_op, pr, soa ? 1 : 0);
     HIPCHK(hipGetLastError());
     if (multi && !peer) LQCHK(comm_allreduce(c, c->d_scal + slot, nvals, cg_op));
     return LQCD_OK;

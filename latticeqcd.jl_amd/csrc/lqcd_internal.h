@@ -281,7 +281,10 @@ __device__ inline c2 bicg_beta(c2 rho1, c2 rho, c2 alpha, c2 omega) {   // beta 
 // accumulators; the 64 class sums of a wave go through a __shfl_down tree, the 16 wave sums are added in sequence by thread 0.  The pieces live here because a
 // second kernel reproduces that order bit for bit with 256 threads (stencil.hip wilson_pack_reduce: thread t owns classes t, t + 256, t + 512, t + 768).
 constexpr int FB = 1024;
-__device__ inline double sum_partials_class(const double* __restrict__ partial, int nblocks, int nvals, int v, int cls) {
+__device__ inline double sum_partials_class(const double* __restrict__ partial, int nblocks, int nvals, int v, int cls, bool soa = false) {
+    // element (block i, value v): partial[i * nvals + v], or partial[v * nblocks + i] in the [value][workgroup] layout (same additions, coalesced reads)
+    const size_t si = soa ? 1 : (size_t)nvals;
+    partial += soa ? (size_t)v * nblocks : (size_t)v;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int i = cls;
     // sixteen, then eight loads in flight per thread before the first addition (one memory round trip for 16 K / 8 K partials instead of four / two); the additions
@@ -289,24 +292,24 @@ __device__ inline double sum_partials_class(const double* __restrict__ partial, 
     for (; i + 15 * FB < nblocks; i += 16 * FB) {
         double t[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) t[k] = partial[(size_t)(i + k * FB) * nvals + v];
+        for (int k = 0; k < 16; k++) t[k] = partial[(size_t)(i + k * FB) * si];
 #pragma unroll
         for (int q = 0; q < 4; q++) { s0 += t[4 * q]; s1 += t[4 * q + 1]; s2 += t[4 * q + 2]; s3 += t[4 * q + 3]; }
     }
     for (; i + 7 * FB < nblocks; i += 8 * FB) {
         double t[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[k] = partial[(size_t)(i + k * FB) * nvals + v];
+        for (int k = 0; k < 8; k++) t[k] = partial[(size_t)(i + k * FB) * si];
 #pragma unroll
         for (int q = 0; q < 2; q++) { s0 += t[4 * q]; s1 += t[4 * q + 1]; s2 += t[4 * q + 2]; s3 += t[4 * q + 3]; }
     }
     for (; i + 3 * FB < nblocks; i += 4 * FB) {
-        s0 += partial[(size_t)i * nvals + v];
-        s1 += partial[(size_t)(i + FB) * nvals + v];
-        s2 += partial[(size_t)(i + 2 * FB) * nvals + v];
-        s3 += partial[(size_t)(i + 3 * FB) * nvals + v];
+        s0 += partial[(size_t)i * si];
+        s1 += partial[(size_t)(i + FB) * si];
+        s2 += partial[(size_t)(i + 2 * FB) * si];
+        s3 += partial[(size_t)(i + 3 * FB) * si];
     }
-    for (; i < nblocks; i += FB) s0 += partial[(size_t)i * nvals + v];
+    for (; i < nblocks; i += FB) s0 += partial[(size_t)i * si];
     return (s0 + s1) + (s2 + s3);
 }
 __device__ inline double shfl_tree_sum(double s) {      // lane 0 holds the sum of the wave's 64 values (the order every reduction of this library uses)
@@ -978,7 +981,8 @@ struct StencilCall {
     // dot_partial[3 b + (0,1,2)] = Re <z, out>, Im <z, out>, |out|^2 (<a, b> = sum conj(a) b) with z = dot_z (parity blocks like out)
     const double2* dot_z[2] = {nullptr, nullptr};
     double* dot_partial = nullptr;
-    int dot_conj = 0;             // 1: <out, z> (the imaginary part changes sign)
+    int dot_conj = 0;             // bit 0: <out, z> (the imaginary part changes sign); bit 1: the partials go out as [value][workgroup] instead of [workgroup][value] -- what the
+                                  // one-block reduction of MORE than 1024 workgroups reads coalesced (reduce_to_slot, soa = true); the folded prologues read [workgroup][value]
     const double2* dot_z2[2] = {nullptr, nullptr};      // every dot-mode kernel, z = xin only: a second inner product <z2, out> (never conjugated) -> FIVE values per workgroup,
                                                           // dot_partial[5 b + (0..4)] = Re / Im <z, out>, |out|^2, Re / Im <z2, out>  (merged BiCGStab chain: <r0, t> beside <t, s>)
     // Domainwall (domainwall.hip): the L5 slices of a five-dimensional field in ONE launch of the scalar-addressing kernel -- in / xin / out point at slice 0, slice s5 is
@@ -1058,7 +1062,7 @@ int blas_axpy(lqcd_ctx_s* c, double ar, double ai, const double2* x, double2* y,
 int blas_axpby(lqcd_ctx_s* c, double ar, double ai, const double2* x, double br, double bi, double2* y, size_t n);
 int blas_scale(lqcd_ctx_s* c, double ar, double ai, double2* x, size_t n);
 int allreduce_host(lqcd_ctx_s* c, double* vals, int n);
-int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0, const double* partial = nullptr);   // partial: default the context's d_partial
+int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op = 0, const double* partial = nullptr, bool soa = false);   // partial: default the context's d_partial
 int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op);
 int reduce_pack_to_slot(lqcd_ctx_s* c, int nblocks, int slot, int cg_op);      // reduce_to_slot(nvals = 1, all-reduce) + the pack launch the folded schedule left waiting (StencilCall::defer_pack)
 LQCD_REOPEN_P64 { int launch_pack_reduce(lqcd_ctx_s* c, const StencilCall& s, const double* partial, int nblocks, int slot, int op); }

@@ -660,7 +660,7 @@ struct Eo32 {
     int layout;                                    // 1: component pairs (fp32 build of stencil.hip), 2: site pairs (stencil_pair32.hip: half the launches' latencies per site)
 };
 // one Schur application on the fp32 fields: to = H_oe in, out = in - k^2 H_eo to [+ inner-product epilogue]
-static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const float2* z, double* dotp, int conj, int dg, const double* skip, const float2* z2 = nullptr) {
+static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const float2* z, double* dotp, int conj, int dg, const double* skip, const float2* z2 = nullptr, bool soa = false) {
     lqcd_ctx_s* c = op->ctx;
     StencilCall s1;
     s1.kind = LQCD_WILSON; s1.gauge = (const double2*)m.gauge; s1.gauge12 = (const double2*)m.gauge12; s1.gauge16 = m.gauge16;
@@ -673,7 +673,7 @@ static int schur32(lqcd_op_s* op, const Eo32& m, float2* out, float2* in, const 
     s2.out[0] = (double2*)out; s2.out[1] = nullptr; s2.in[0] = nullptr; s2.in[1] = (const double2*)m.to; s2.xin[0] = (const double2*)in; s2.xin[1] = nullptr;
     s2.a = 1.0; s2.b = -op->km * op->km; s2.r = 1.0; s2.dagger = dg; s2.parity_mode = 0; s2.prec = m.layout == 2 ? 2 : 1; s2.skip_flag = skip;
     if (m.ainv) { s2.clover = (const double2*)m.ainv; s2.clover_on_hop = 1; }
-    if (z) { s2.dot_z[0] = (const double2*)z; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
+    if (z) { s2.dot_z[0] = (const double2*)z; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj | (soa ? 2 : 0); }
     if (z2) { s2.dot_z2[0] = (const double2*)z2; s2.dot_z2[1] = nullptr; }
     return stencil_apply(c, s2);
 }
@@ -690,6 +690,7 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
     const bool rec = c->tun.bicg_fused == 4;
     double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;
     const double* skip = c->d_scal + (B_DONE - S_DONE);
+    const bool soa = !fold && nbs > 1024;      // (solvers.hip: [value][workgroup] dot partials for the one-block reductions of large lattices)
     if (!pre_init) HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));      // (pre_init: the conversion that made m.r also set x = 0, r0 = p = r)
     int it = 0, enq = 0;
     if (!cont) {
@@ -725,16 +726,16 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
             a.sc = c->d_scal; a.fold = fold ? 1 : 0;
             a.rho_in = (enq & 1) ? B_RHOB : B_RHO; a.rho_out = (enq & 1) ? B_RHO : B_RHOB;
             a.pin2 = nullptr; a.pin2_n = 0;
-            LQCHK(schur32(op, m, m.v, m.p, m.r0, P0, 0, dg, skip));
-            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0));
+            LQCHK(schur32(op, m, m.v, m.p, m.r0, P0, 0, dg, skip, nullptr, soa));
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0, soa));
             a.pin = P0; a.pin_n = nbs; a.pout = P1;
             if (rec) { a.pin3 = P3; a.pin3_n = nbk; }
             if (m.layout == 2) hipLaunchKernelGGL(bicgf32_s<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
             else hipLaunchKernelGGL(bicgf32_s<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
             if (rec) {
-                LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip, m.r0));
-                if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2));
+                LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip, m.r0, soa));
+                if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2, soa));
                 a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
                 a.guard = std::pow(10.0, -(double)c->tun.bicg_rec_guard);
                 if (m.layout == 2) hipLaunchKernelGGL(bicgf32_xrp_rec<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (float4*)m.p, (const float4*)m.s,
@@ -744,8 +745,8 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
                 HIPCHK(hipGetLastError());
                 continue;
             }
-            LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip));
-            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
+            LQCHK(schur32(op, m, m.t, m.s, m.s, P2, 1, dg, skip, nullptr, soa));
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2, soa));
             a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
             if (m.layout == 2) hipLaunchKernelGGL(bicgf32_xr<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (const float4*)m.p, (const float4*)m.s,
                                                   (const float4*)m.t, (const float4*)m.r0, n4);

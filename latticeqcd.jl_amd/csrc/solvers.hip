@@ -1273,6 +1273,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
     double* P1 = P0 + (size_t)3 * nbs;          // |s|^2                  [nbk]
     double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]   (bicg_fused = 4: + <r0, t>, nbs x 5)
     double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;   // |r|^2, <r0, r>    [nbk x 3]
+    const bool soa = !fold && nbs > 1024;      // unfolded reductions of more than 1024 workgroups: the dot partials go out [value][workgroup], which the one-block reduction reads coalesced
     const double* skip_ = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
     auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj, bool skippable = true, const lqcd_spinor_s* z2 = nullptr) -> int {
         const double* skip = skippable ? skip_ : nullptr;
@@ -1283,7 +1284,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
         StencilCall s2 = make_hop_call(op, out, to, in, 1.0, -k * k, dg);       // out = in - k^2 [A_ee^-1] H_eo t_o
         s2.skip_flag = skip;
         if (Ai) { s2.clover = Ai; s2.clover_on_hop = 1; }
-        if (z) { s2.dot_z[0] = z->data; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj; }
+        if (z) { s2.dot_z[0] = z->data; s2.dot_z[1] = nullptr; s2.dot_partial = dotp; s2.dot_conj = conj | (soa ? 2 : 0); }
         if (z2) { s2.dot_z2[0] = z2->data; s2.dot_z2[1] = nullptr; }
         return stencil_apply(c, s2);
     };
@@ -1312,14 +1313,14 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
             a.rho_out = (enq & 1) ? B_RHO : B_RHOB;      // the other workgroups still read this one
             a.pin2 = nullptr; a.pin2_n = 0;
             LQCHK(schur(v, p, r0, P0, 0));                                                                   // v = M p, <r0, v>
-            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0));
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0, soa));
             a.pin = P0; a.pin_n = nbs; a.pout = P1;
             if (rec) { a.pin3 = P3; a.pin3_n = nbk; }
             hipLaunchKernelGGL(bicgf_s, dim3(nbk), dim3(UB), 0, c->stream, a, s->data, r->data, v->data, n);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
             if (rec) {
                 LQCHK(schur(t, s, s, P2, 1, true, r0));                                                      // t = M s, <t, s>, |t|^2, <r0, t>
-                if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2));
+                if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2, soa));
                 a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
                 a.guard = std::pow(10.0, -(double)c->tun.bicg_rec_guard);
                 hipLaunchKernelGGL(bicgf_xrp_rec, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, v->data, n);
@@ -1327,7 +1328,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
                 continue;
             }
             LQCHK(schur(t, s, s, P2, 1));                                                                    // t = M s, <t, s>, |t|^2
-            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2));
+            if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_TS, true, 0, P2, soa));
             a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
             if (xrp) {
                 hipLaunchKernelGGL(bicgf_xrp, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, r0->data, v->data, n, c->cgp_ctr, ++c->cgp_epoch);

@@ -300,7 +300,7 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
     }
     if constexpr (DOT) {                // three sums per workgroup: a wave tree each, then the four waves in a fixed order; five with a second inner product
         const bool five = k.dotz2[0] != nullptr || k.dotz2[1] != nullptr;
-        double t3[5] = {(double)dre, (double)(k.dot_conj ? -dim : dim), (double)nrm, (double)dre2, (double)dim2};
+        double t3[5] = {(double)dre, (double)((k.dot_conj & 1) ? -dim : dim), (double)nrm, (double)dre2, (double)dim2};
 #pragma unroll
         for (int q = 0; q < 5; q++) {
             if (q < 3 || five) {
@@ -310,7 +310,8 @@ __device__ __forceinline__ void wilson_dirsplit_body(const KArgs& k, const HArgs
         }
         __syncthreads();
         const int nv = five ? 5 : 3;
-        if ((int)threadIdx.x < nv) k.dot_partial[nv * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        if ((int)threadIdx.x < nv) k.dot_partial[(k.dot_conj & 2) ? (size_t)threadIdx.x * gridDim.x + blockIdx.x : nv * (size_t)blockIdx.x + threadIdx.x] =
+            (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);      // (bit 1 of dot_conj: [value][workgroup] layout)
         return;
     }
     if (k.norm_partial) {
@@ -1069,7 +1070,7 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
     }
     if constexpr (DOT) {                // three sums per workgroup, the order of wilson_dirsplit's dot epilogue; five with a second inner product (dot_z2)
         const bool five = a.dotz2[0] != nullptr || a.dotz2[1] != nullptr;
-        double t3[5] = {(double)dre, (double)(a.dot_conj ? -dim : dim), (double)nrm, (double)dre2, (double)dim2};
+        double t3[5] = {(double)dre, (double)((a.dot_conj & 1) ? -dim : dim), (double)nrm, (double)dre2, (double)dim2};
 #pragma unroll
         for (int q = 0; q < 5; q++) {
             if (q < 3 || five) {
@@ -1079,7 +1080,8 @@ __global__ LQCD_DS_BOUNDS_S void wilson_dirsplit_s(PipeArgs a) {
         }
         __syncthreads();
         const int nv = five ? 5 : 3;
-        if ((int)threadIdx.x < nv) a.dot_partial[nv * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        if ((int)threadIdx.x < nv) a.dot_partial[(a.dot_conj & 2) ? (size_t)threadIdx.x * gridDim.x + blockIdx.x : nv * (size_t)blockIdx.x + threadIdx.x] =
+            (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
         return;
     }
     if (a.norm_partial) {

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
     if constexpr (DOT) {                // three sums per workgroup (both slots of a lane), the order of the fp64 kernels' dot epilogue
         const double di = (double)dim.x + (double)dim.y;
         const bool five = a.dotz2[0] != nullptr || a.dotz2[1] != nullptr;
-        double t3[5] = {(double)dre.x + (double)dre.y, a.dot_conj ? -di : di, (double)nrm.x + (double)nrm.y, (double)dre2.x + (double)dre2.y, (double)dim2.x + (double)dim2.y};
+        double t3[5] = {(double)dre.x + (double)dre.y, (a.dot_conj & 1) ? -di : di, (double)nrm.x + (double)nrm.y, (double)dre2.x + (double)dre2.y, (double)dim2.x + (double)dim2.y};
 #pragma unroll
         for (int q = 0; q < 5; q++) {
             if (q < 3 || five) {
@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256, 3) void wilson_dirsplit_pair32(PairArgs a) {
         }
         __syncthreads();
         const int nv = five ? 5 : 3;
-        if ((int)threadIdx.x < nv) a.dot_partial[nv * (size_t)blockIdx.x + threadIdx.x] = (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
+        if ((int)threadIdx.x < nv) a.dot_partial[(a.dot_conj & 2) ? (size_t)threadIdx.x * gridDim.x + blockIdx.x : nv * (size_t)blockIdx.x + threadIdx.x] =
+            (red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + (red[4 * threadIdx.x + 2] + red[4 * threadIdx.x + 3]);
         return;
     }
     if (a.norm_partial) {
