@@ -1144,12 +1144,16 @@ __global__ __launch_bounds__(UB) void bicgf_xrp_rec(BicgF a, double2* __restrict
     const c2 al = {a.sc[B_ALPHA], a.sc[B_ALPHA + 1]}, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]}, r0v = {a.sc[B_R0V], a.sc[B_R0V + 1]};
     double ss, tt;
     c2 ts, r0t;
-    if (a.fold) {
+    if (a.fold == 1) {
         double t1[1], t5[5];
         block_sum_partials<1>(a.pin2, a.pin2_n, t1);
         block_sum_partials<5>(a.pin, a.pin_n, t5);
         ss = t1[0]; ts.re = t5[0]; ts.im = t5[1]; tt = t5[2]; r0t.re = t5[3]; r0t.im = t5[4];
-    } else { ss = a.sc[B_SS]; ts.re = a.sc[B_TS5]; ts.im = a.sc[B_TS5 + 1]; tt = a.sc[B_TS5 + 2]; r0t.re = a.sc[B_TS5 + 3]; r0t.im = a.sc[B_TS5 + 4]; }
+    } else {
+        if (a.fold == 2) { double t1[1]; block_sum_partials<1>(a.pin2, a.pin2_n, t1); ss = t1[0]; }      // large lattices: the <= 1024 partials of |s|^2 are still summed here (one launch less)
+        else ss = a.sc[B_SS];
+        ts.re = a.sc[B_TS5]; ts.im = a.sc[B_TS5 + 1]; tt = a.sc[B_TS5 + 2]; r0t.re = a.sc[B_TS5 + 3]; r0t.im = a.sc[B_TS5 + 4];
+    }
     const bool half = ss < a.sc[B_EPS];
     const c2 om = bicg_omega(ts, tt, half);
     // rho' = rho - alpha <r0, v> - omega <r0, t>
@@ -1317,11 +1321,12 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
             a.pin = P0; a.pin_n = nbs; a.pout = P1;
             if (rec) { a.pin3 = P3; a.pin3_n = nbk; }
             hipLaunchKernelGGL(bicgf_s, dim3(nbk), dim3(UB), 0, c->stream, a, s->data, r->data, v->data, n);
-            if (!fold) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));
+            if (!fold && !rec) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));      // (merged chain: the update launch sums the <= 1024 partials of |s|^2 itself)
             if (rec) {
                 LQCHK(schur(t, s, s, P2, 1, true, r0));                                                      // t = M s, <t, s>, |t|^2, <r0, t>
                 if (!fold) LQCHK(reduce_to_slot(c, nbs, 5, B_TS5, true, 0, P2, soa));
                 a.pin = P2; a.pin_n = nbs; a.pin2 = P1; a.pin2_n = nbk; a.pout = P3;
+                if (!fold) a.fold = 2;
                 a.guard = std::pow(10.0, -(double)c->tun.bicg_rec_guard);
                 hipLaunchKernelGGL(bicgf_xrp_rec, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, v->data, n);
                 HIPCHK(hipGetLastError());
