@@ -49,14 +49,14 @@ __global__ __launch_bounds__(RB) void norm2_kernel(const double2* __restrict__ a
 // sums nblocks partials of `nvals` interleaved values into scal[slot..slot+nvals) in a fixed order (1024 threads, each a
 // strided partial sum, then a wave/LDS tree), optionally followed by a CG scalar step on the same thread (single rank):
 //   op 1: alpha = rr / pq      op 2: beta = rr'/rr, rr = rr', iters++, done = rr' < eps     (flags: see ops.hip)
-__global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op, PeerRedArgs pr, int soa) {      // soa: [value][block] partials (large form only)
+__global__ __launch_bounds__(FB) void reduce_final(const double* __restrict__ partial, int nblocks, int nvals, double* scal, int slot, int op, PeerRedArgs pr, int soa) {      // soa: [value][block] partials
     __shared__ double tot[PEER_RED_VALS];
     // pr.nranks > 0 (peer-mapped backend, comm.hip): the sum over the ranks happens HERE, in the wave that holds the local sums -- no all-reduce launch
     if (nblocks <= 1024) {      // small reductions: one wave, in the order the folded prologues use (sum_partials_small_nv) -- a latency chain of
         if (threadIdx.x < 64) { //  16 loads + one DPP tree instead of a 1024-thread tree with two barriers per value
             double mine = 0.0;
             for (int v = 0; v < nvals; v++) {
-                const double t = sum_partials_small_nv(partial, nblocks, nvals, v);
+                const double t = sum_partials_small_nv(partial, nblocks, nvals, v, soa != 0);
                 if (pr.nranks) { if (((int)threadIdx.x >> 3) == v) mine = t; }
                 else if (threadIdx.x == 0) scal[slot + v] = t;
             }
@@ -160,7 +160,6 @@ int reduce_tail(lqcd_ctx_s* c, int nvals, int slot, int cg_op) {
 // device-side reduction of partials into d_scal[slot..], followed by an all-reduce when running on several ranks.  RCCL: reduce_final -> ncclAllReduce -> one-thread
 // scalar step; peer-mapped backend: ONE launch (the reduction block adds the ranks' slots itself and does the scalar step)
 int reduce_to_slot(lqcd_ctx_s* c, int nblocks, int nvals, int slot, bool allreduce, int cg_op, const double* partial, bool soa) {
-    ARGCHK(!soa || nblocks > 1024, "reduce_to_slot: the [value][block] layout exists for reductions of more than 1024 partials only");
     const bool multi = allreduce && c->has_comm;   // also at world size 1 (self-partition tests exercise the collective)
     const bool peer = multi && c->peer.on;
     ARGCHK(nvals >= 1 && nvals <= PEER_RED_VALS, "reduce_to_slot: one to eight values per reduction");

@@ -318,6 +318,7 @@ static int* param_ptr(lqcd_ctx_s* c, const char* key) {
     if (!strcmp(key, "mixed_links16")) return &c->tun.mixed_links16;
     if (!strcmp(key, "bicg_reliable")) return &c->tun.bicg_reliable;
     if (!strcmp(key, "bicg_rec_guard")) return &c->tun.bicg_rec_guard;
+    if (!strcmp(key, "bicg_dot_soa")) return &c->tun.bicg_dot_soa;
     if (!strcmp(key, "clover_hop_s")) return &c->tun.clover_hop_s;
     if (!strcmp(key, "mixed_lean_residual")) return &c->tun.mixed_lean_residual;
     if (!strcmp(key, "mixed_xfuse")) return &c->tun.mixed_xfuse;

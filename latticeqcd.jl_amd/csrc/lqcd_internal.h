@@ -234,13 +234,13 @@ __device__ inline double wave_sum(double v) {
 // Lane l adds partials l, l + 64, l + 128, ... in sequence (at most 16 independent loads in flight), one DPP wave sum at the end.  reduce_final
 // (blas.hip) uses this function for n <= 1024, the consumers that fold a reduction into their prologue (cg_small, the fused BiCGStab chain) call it
 // in every wave: the same bits everywhere.  All 64 lanes of the calling wave must be active.
-__device__ inline double sum_partials_small_nv(const double* __restrict__ partial, int n, int nvals, int v) {
+__device__ inline double sum_partials_small_nv(const double* __restrict__ partial, int n, int nvals, int v, bool soa = false) {      // soa: [value][block] partials (coalesced)
     const int lane = threadIdx.x & 63;
     double t[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {      // all loads first (one memory round trip, not sixteen), then the additions in sequence; a missing partial is +0.0
         const int i = lane + 64 * k;
-        t[k] = i < n ? partial[(size_t)i * nvals + v] : 0.0;
+        t[k] = i < n ? partial[soa ? (size_t)v * n + i : (size_t)i * nvals + v] : 0.0;
     }
     double s = 0.0;
 #pragma unroll
@@ -559,6 +559,8 @@ struct Tunables {
                               // momentum update P_update! waits as well, and runs with the link update that follows it as ONE sweep (staple_force_expu: the new
                               // links go to a second buffer that changes places with the field's).  0: every complete update is launched at once
     int mixed_lean_residual = 0;  // test aid: the fused true residual of the mixed even-odd BiCGStab never writes r0 / p / x (what it does behind a step that was expected to be the last)
+    int bicg_dot_soa = 1;         // dot partials of the even-odd chains as [value][workgroup]: 1 = where the reductions are separate launches (more than 1024 workgroups: reduce_final
+                                  // reads them coalesced, 14.9 -> 8.4 us), 2 = also where the consumers' prologues sum them, 0 = never
     int bicg_rec_guard = 6;       // bicg_fused = 4: digits of cancellation the recurrence |r'|^2 = |s|^2 - |<t,s>|^2 / |t|^2 may show before the stopping test waits for the summed |r'|^2
                                   // (one kernel later); 0 makes every test wait (tests)
     int bicg_reliable = 0;        // mixed-precision even-odd BiCGStab, 1: behind a correction step the fp32 chain goes on with its search direction, r0 and scalars (the true

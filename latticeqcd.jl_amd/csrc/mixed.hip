@@ -477,7 +477,7 @@ __global__ __launch_bounds__(UB) void bicgf32_s(BicgF a, float4* __restrict__ s,
 #pragma unroll
     for (int e = 0; e < 2; e++) { const size_t i = i0 + e * stride; if (i < n4) { pr[e] = r[i]; pv[e] = v[i]; } }
     c2 r0v, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]};
-    if (a.fold) { double t3[3]; block_sum_partials<3>(a.pin, a.pin_n, t3); r0v.re = t3[0]; r0v.im = t3[1]; }
+    if (a.fold) { double t3[3]; block_sum_partials<3>(a.pin, a.pin_n, t3, a.pin_soa != 0); r0v.re = t3[0]; r0v.im = t3[1]; }
     else { r0v.re = a.sc[B_R0V]; r0v.im = a.sc[B_R0V + 1]; }
     const c2 al = bicg_alpha(rho, r0v);
     if (a.pin3 && a.sc[B_UNSURE] != 0.0) {      // merged chain: the last update launch left the stopping test to the |r'|^2 it summed (solvers.hip bicgf_s)
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(UB) void bicgf32_xr(BicgF a, float4* __restrict__ x
     if (a.fold) {
         double t1[1], t3[3];
         block_sum_partials<1>(a.pin2, a.pin2_n, t1);
-        block_sum_partials<3>(a.pin, a.pin_n, t3);
+        block_sum_partials<3>(a.pin, a.pin_n, t3, a.pin_soa != 0);
         ss = t1[0]; ts.re = t3[0]; ts.im = t3[1]; tt = t3[2];
     } else { ss = a.sc[B_SS]; ts.re = a.sc[B_TS]; ts.im = a.sc[B_TS + 1]; tt = a.sc[B_TT]; }
     const bool half = ss < a.sc[B_EPS];
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(UB) void bicgf32_xrp_rec(BicgF a, float4* __restric
     if (a.fold == 1) {
         double t1[1], t5[5];
         block_sum_partials<1>(a.pin2, a.pin2_n, t1);
-        block_sum_partials<5>(a.pin, a.pin_n, t5);
+        block_sum_partials<5>(a.pin, a.pin_n, t5, a.pin_soa != 0);
         ss = t1[0]; ts.re = t5[0]; ts.im = t5[1]; tt = t5[2]; r0t.re = t5[3]; r0t.im = t5[4];
     } else {
         if (a.fold == 2) { double t1[1]; block_sum_partials<1>(a.pin2, a.pin2_n, t1); ss = t1[0]; }      // large lattices: the <= 1024 partials of |s|^2 are still summed here (one launch less)
@@ -694,7 +694,7 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
     const bool rec = c->tun.bicg_fused == 4;
     double* P0 = c->d_partial; double* P1 = P0 + (size_t)3 * nbs; double* P2 = P1 + nbk; double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;
     const double* skip = c->d_scal + (B_DONE - S_DONE);
-    const bool soa = !fold && nbs > 1024;      // (solvers.hip: [value][workgroup] dot partials for the one-block reductions of large lattices)
+    const bool soa = c->tun.bicg_dot_soa >= 2 || (c->tun.bicg_dot_soa == 1 && !fold && nbs > 1024);      // (solvers.hip: [value][workgroup] dot partials)
     if (!pre_init) HIPCHK(hipMemsetAsync(m.x, 0, b32, c->stream));      // (pre_init: the conversion that made m.r also set x = 0, r0 = p = r)
     int it = 0, enq = 0;
     if (!cont) {
@@ -732,7 +732,7 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
             a.pin2 = nullptr; a.pin2_n = 0;
             LQCHK(schur32(op, m, m.v, m.p, m.r0, P0, 0, dg, skip, nullptr, soa));
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0, soa));
-            a.pin = P0; a.pin_n = nbs; a.pout = P1;
+            a.pin = P0; a.pin_n = nbs; a.pin_soa = soa ? 1 : 0; a.pout = P1;
             if (rec) { a.pin3 = P3; a.pin3_n = nbk; }
             if (m.layout == 2) hipLaunchKernelGGL(bicgf32_s<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
             else hipLaunchKernelGGL(bicgf32_s<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.s, (const float4*)m.r, (const float4*)m.v, n4);
@@ -758,7 +758,7 @@ static int inner_bicgstab_eo32(lqcd_op_s* op, const Eo32& m, size_t nh, int dg, 
             else hipLaunchKernelGGL(bicgf32_xr<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.x, (float4*)m.r, (const float4*)m.p, (const float4*)m.s,
                                     (const float4*)m.t, (const float4*)m.r0, n4);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 3, B_RR, true, 0, P3));
-            a.pin = P3; a.pin_n = nbk; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
+            a.pin = P3; a.pin_n = nbk; a.pin_soa = 0; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
             if (m.layout == 2) hipLaunchKernelGGL(bicgf32_p<true>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
             else hipLaunchKernelGGL(bicgf32_p<false>, dim3(nbk), dim3(UB), 0, c->stream, a, (float4*)m.p, (const float4*)m.r, (const float4*)m.v, n4);
             HIPCHK(hipGetLastError());

@@ -64,12 +64,12 @@ __device__ inline void block_reduce_nv(double (&a)[NV], double* partial) {
 // the NV sums of a producer's partials, the same bits in every thread of the workgroup: ONE wave loads and adds them (every wave doing so made the
 // prologue 5-9 us of texture-path time for 1024 workgroups), the others take the result from LDS
 template <int NV>
-__device__ inline void block_sum_partials(const double* __restrict__ partial, int n, double (&out)[NV]) {
+__device__ inline void block_sum_partials(const double* __restrict__ partial, int n, double (&out)[NV], bool soa = false) {
     __shared__ double sh[NV];
     if (threadIdx.x < 64) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            const double t = sum_partials_small_nv(partial, n, NV, v);
+            const double t = sum_partials_small_nv(partial, n, NV, v, soa);
             if (threadIdx.x == 0) sh[v] = t;
         }
     }
@@ -83,6 +83,7 @@ struct BicgF {
     int fold;
     const double* pin;      // fold: the producer's partials ...
     int pin_n;              // ... of that many workgroups
+    int pin_soa = 0;        // ... in the [value][workgroup] layout (the dot partials of the hops; the streaming kernels' own partials stay [workgroup][value])
     const double* pin2;     // bicgf_xr: the |s|^2 partials of bicgf_s
     int pin2_n;
     double* pout;           // this kernel's partials

@@ -843,7 +843,7 @@ __global__ __launch_bounds__(UB) void bicgf_s(BicgF a, double2* __restrict__ s, 
     c2 r0v, rho = {a.sc[a.rho_in], a.sc[a.rho_in + 1]};
     if (a.fold) {
         double t3[3];
-        block_sum_partials<3>(a.pin, a.pin_n, t3);
+        block_sum_partials<3>(a.pin, a.pin_n, t3, a.pin_soa != 0);
         r0v.re = t3[0]; r0v.im = t3[1];
     } else { r0v.re = a.sc[B_R0V]; r0v.im = a.sc[B_R0V + 1]; }
     const c2 al = bicg_alpha(rho, r0v);
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(UB) void bicgf_xr(BicgF a, double2* __restrict__ x,
     if (a.fold) {
         double t1[1], t3[3];
         block_sum_partials<1>(a.pin2, a.pin2_n, t1);
-        block_sum_partials<3>(a.pin, a.pin_n, t3);
+        block_sum_partials<3>(a.pin, a.pin_n, t3, a.pin_soa != 0);
         ss = t1[0]; ts.re = t3[0]; ts.im = t3[1]; tt = t3[2];
     } else { ss = a.sc[B_SS]; ts.re = a.sc[B_TS]; ts.im = a.sc[B_TS + 1]; tt = a.sc[B_TT]; }
     const bool half = ss < a.sc[B_EPS];
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(UB, 4) void bicgf_xrp(BicgF a, double2* __restrict_
         {
             double t1[1], t3[3];
             block_sum_partials<1>(a.pin2, a.pin2_n, t1);
-            block_sum_partials<3>(a.pin, a.pin_n, t3);
+            block_sum_partials<3>(a.pin, a.pin_n, t3, a.pin_soa != 0);
             ss = t1[0]; ts.re = t3[0]; ts.im = t3[1]; tt = t3[2];
         }
         half = ss < a.sc[B_EPS];
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(UB) void bicgf_xrp_rec(BicgF a, double2* __restrict
     if (a.fold == 1) {
         double t1[1], t5[5];
         block_sum_partials<1>(a.pin2, a.pin2_n, t1);
-        block_sum_partials<5>(a.pin, a.pin_n, t5);
+        block_sum_partials<5>(a.pin, a.pin_n, t5, a.pin_soa != 0);
         ss = t1[0]; ts.re = t5[0]; ts.im = t5[1]; tt = t5[2]; r0t.re = t5[3]; r0t.im = t5[4];
     } else {
         if (a.fold == 2) { double t1[1]; block_sum_partials<1>(a.pin2, a.pin2_n, t1); ss = t1[0]; }      // large lattices: the <= 1024 partials of |s|^2 are still summed here (one launch less)
@@ -1277,7 +1277,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
     double* P1 = P0 + (size_t)3 * nbs;          // |s|^2                  [nbk]
     double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]   (bicg_fused = 4: + <r0, t>, nbs x 5)
     double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;   // |r|^2, <r0, r>    [nbk x 3]
-    const bool soa = !fold && nbs > 1024;      // unfolded reductions of more than 1024 workgroups: the dot partials go out [value][workgroup], which the one-block reduction reads coalesced
+    const bool soa = c->tun.bicg_dot_soa >= 2 || (c->tun.bicg_dot_soa == 1 && !fold && nbs > 1024);      // the dot partials of the hops as [value][workgroup] (tunable bicg_dot_soa)
     const double* skip_ = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
     auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj, bool skippable = true, const lqcd_spinor_s* z2 = nullptr) -> int {
         const double* skip = skippable ? skip_ : nullptr;
@@ -1318,7 +1318,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
             a.pin2 = nullptr; a.pin2_n = 0;
             LQCHK(schur(v, p, r0, P0, 0));                                                                   // v = M p, <r0, v>
             if (!fold) LQCHK(reduce_to_slot(c, nbs, 3, B_R0V, true, 0, P0, soa));
-            a.pin = P0; a.pin_n = nbs; a.pout = P1;
+            a.pin = P0; a.pin_n = nbs; a.pin_soa = soa ? 1 : 0; a.pout = P1;
             if (rec) { a.pin3 = P3; a.pin3_n = nbk; }
             hipLaunchKernelGGL(bicgf_s, dim3(nbk), dim3(UB), 0, c->stream, a, s->data, r->data, v->data, n);
             if (!fold && !rec) LQCHK(reduce_to_slot(c, nbk, 1, B_SS, true, 0, P1));      // (merged chain: the update launch sums the <= 1024 partials of |s|^2 itself)
@@ -1342,7 +1342,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
             }
             hipLaunchKernelGGL(bicgf_xr, dim3(nbk), dim3(UB), 0, c->stream, a, xe.data, r->data, p->data, s->data, t->data, r0->data, n);
             if (!fold) LQCHK(reduce_to_slot(c, nbk, 3, B_RR, true, 0, P3));
-            a.pin = P3; a.pin_n = nbk; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
+            a.pin = P3; a.pin_n = nbk; a.pin_soa = 0; a.pin2 = nullptr; a.pin2_n = 0; a.pout = nullptr;
             hipLaunchKernelGGL(bicgf_p, dim3(nbk), dim3(UB), 0, c->stream, a, p->data, r->data, v->data, n);
             HIPCHK(hipGetLastError());
         }
