@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(UB, 4) void bicgf_xrp(BicgF a, double2* __restrict_
         {
             double t1[1], t3[3];
             block_sum_partials<1>(a.pin2, a.pin2_n, t1);
-            block_sum_partials<3>(a.pin, a.pin_n, t3, a.pin_soa != 0);
+            block_sum_partials<3>(a.pin, a.pin_n, t3);      // (this form keeps the [workgroup][value] partials: the host never asks for the other layout with it -- the kernel sits at its register cap)
             ss = t1[0]; ts.re = t3[0]; ts.im = t3[1]; tt = t3[2];
         }
         half = ss < a.sc[B_EPS];
@@ -1277,7 +1277,7 @@ int bicgstab_eo_wilson(lqcd_op_s* op, lqcd_spinor_s& xe, lqcd_spinor_s* rhs, lqc
     double* P1 = P0 + (size_t)3 * nbs;          // |s|^2                  [nbk]
     double* P2 = P1 + nbk;                      // <t, s>, |t|^2          [nbs x 3]   (bicg_fused = 4: + <r0, t>, nbs x 5)
     double* P3 = P2 + (size_t)(rec ? 5 : 3) * nbs;   // |r|^2, <r0, r>    [nbk x 3]
-    const bool soa = c->tun.bicg_dot_soa >= 2 || (c->tun.bicg_dot_soa == 1 && !fold && nbs > 1024);      // the dot partials of the hops as [value][workgroup] (tunable bicg_dot_soa)
+    const bool soa = !xrp && (c->tun.bicg_dot_soa >= 2 || (c->tun.bicg_dot_soa == 1 && !fold && nbs > 1024));      // the dot partials of the hops as [value][workgroup] (tunable bicg_dot_soa)
     const double* skip_ = c->d_scal + (B_DONE - S_DONE);      // the kernels test skip[S_DONE]: the hops become no-ops once the solve is done
     auto schur = [&](lqcd_spinor_s* out, lqcd_spinor_s* in, const lqcd_spinor_s* z, double* dotp, int conj, bool skippable = true, const lqcd_spinor_s* z2 = nullptr) -> int {
         const double* skip = skippable ? skip_ : nullptr;
