@@ -267,6 +267,15 @@ def test_evenodd_bicgstab_merged_update_on_the_recurrences(lq, orc, L, dagger, c
         lq.add_fermion_(r, -1.0, b)
         assert lq.dot(r, r).real < (1e-17 if csw else 1e-18), (mode, guard)           # the true residual of the full system (the even-odd solve stops on the [A^-1-preconditioned] Schur system's recursive one)
         out[(mode, guard)] = (x.download(), it)
+    # the layout of the hops' dot partials ([workgroup][value] or [value][workgroup], tunable bicg_dot_soa) changes addresses, not additions: the same bits
+    lat.set_param("bicg_fused", 4)
+    lat.set_param("bicg_rec_guard", 6)
+    for soa in (0, 2):
+        lat.set_param("bicg_dot_soa", soa)
+        x = b.similar()
+        it, rr = lq.solve_DinvX_(x, Dd, b, return_info=True)
+        assert it == out[(4, 6)][1] and np.array_equal(x.download(), out[(4, 6)][0]), soa
+    lat.set_param("bicg_dot_soa", 1)
     lat.set_param("bicg_fused", 2)
     lat.set_param("bicg_rec_guard", 6)
     for key in ((4, 6), (4, 0)):
