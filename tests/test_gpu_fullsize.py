@@ -351,3 +351,33 @@ def test_fermion_force_sweeps_match_oracle_at_baseline_sizes(lq, orc_all_threads
         assert rel_err(G.download(), ref) < 1e-13, name
         for o in (G, X, Y, D, U):
             o.close()
+
+
+def test_evenodd_bicgstab_32x32x32x64_dot_partial_layouts_and_forms(lq):
+    """32^3 x 64, where the reductions of the even-odd chain are separate launches (8192 workgroups per hop): the [value][workgroup] layout of the hops' dot partials
+    (bicg_dot_soa, default) against the [workgroup][value] one -- same additions, same bits -- for the fp64 chain and its fp32 twin inside the mixed-precision solver, and
+    the merged update launch (bicg_fused = 4) against the two-launch form: same iteration count, solution to 1e-10, true residual of the full system below the target."""
+    L = (32, 32, 32, 64)
+    U = lq.Initialize_Gaugefields(3, 0, *L, condition="hot", randomseed=111)
+    lat = U.lattice
+    D = lq.Dirac_operator(U, None, {"Dirac_operator": "Wilson", "κ": KAPPA, "eps_CG": 1e-16, "MaxCGstep": 3000})
+    D.method_CG = "bicgstab_evenodd"
+    b = lq.Fermionfields(lat, lq.WILSON)
+    lq.gauss_distribution_fermion_(b, 112)
+    got = {}
+    for mixed in (0, 1):
+        lat.set_param("bicg_mixed", mixed)
+        for fused, soa in ((4, 1), (4, 0), (2, 1)):
+            lat.set_param("bicg_fused", fused)
+            lat.set_param("bicg_dot_soa", soa)
+            x = b.similar()
+            it, rr = lq.solve_DinvX_(x, D, b, return_info=True)
+            r = b.similar()
+            lq.mul_(r, D, x)
+            lq.add_fermion_(r, -1.0, b)
+            assert rr < 1e-16 and lq.dot(r, r).real < 1e-15, (mixed, fused, soa)
+            got[(mixed, fused, soa)] = (it, x.download())
+            x.close(); r.close()
+        assert got[(mixed, 4, 1)][0] == got[(mixed, 4, 0)][0] and np.array_equal(got[(mixed, 4, 1)][1], got[(mixed, 4, 0)][1]), mixed
+        assert abs(got[(mixed, 4, 1)][0] - got[(mixed, 2, 1)][0]) <= 1 and rel_err(got[(mixed, 4, 1)][1], got[(mixed, 2, 1)][1]) < (1e-9 if mixed else 1e-10), mixed
+    lat.set_param("bicg_mixed", 0); lat.set_param("bicg_fused", 4); lat.set_param("bicg_dot_soa", 1)
